@@ -1,0 +1,359 @@
+"""CPU restatement of the per-frame neural-point render/optimise hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  torch-CPU fp32, written from
+the numerical specification in SURVEY.md Appendix A; every function cites the
+reference lines (relative to /root/reference) whose behaviour it restates and is
+pinned against golden vectors captured from the imported reference
+(tests/golden/*.npz, tests/test_oracle_golden.py).
+
+Conventions
+-----------
+R rays, S samples per ray, P = R*S query points (ray-major: point r*S+s),
+k = 8 neighbours, C = 32 feature channels, N cloud points.
+Weights are a flat dict keyed by the reference's state_dict names
+('geo_decoder.pts_linears.0.weight', ...) plus 'color_decoder.embedder._B'
+(a fixed random [3,20] matrix that the reference keeps outside its state_dict,
+src/conv_onet/models/decoder.py:32).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+TWO_PI = 2.0 * math.pi
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+# --------------------------------------------------------------------------- pose / rays
+def quat_to_c2w(cam):
+    """cam = (qw,qx,qy,qz, tx,ty,tz), quaternion NOT normalised -> [3,4].
+
+    Restates get_camera_from_tensor / quad2rotation (src/common.py:301-343).
+    """
+    qr, qi, qj, qk = cam[0], cam[1], cam[2], cam[3]
+    two_s = 2.0 / (cam[:4] * cam[:4]).sum()
+    rows = [
+        torch.stack([1 - two_s * (qj ** 2 + qk ** 2), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr)]),
+        torch.stack([two_s * (qi * qj + qk * qr), 1 - two_s * (qi ** 2 + qk ** 2), two_s * (qj * qk - qi * qr)]),
+        torch.stack([two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi ** 2 + qj ** 2)]),
+    ]
+    rot = torch.stack(rows)
+    return torch.cat([rot, cam[4:7].reshape(3, 1)], dim=1)
+
+
+def c2w_to_cam(c2w):
+    """4x4 / 3x4 -> (qw,qx,qy,qz,T) float32.  get_tensor_from_camera (src/common.py:354-379)."""
+    from scipy.spatial.transform import Rotation
+    m = np.asarray(c2w, dtype=np.float64)
+    q = Rotation.from_matrix(m[:3, :3]).as_quat()          # x,y,z,w
+    q = np.roll(q, 1)                                       # w,x,y,z
+    return torch.from_numpy(np.concatenate([q, m[:3, 3]])).float()
+
+
+def rays_from_uv(i, j, c2w, fx, fy, cx, cy):
+    """Pixel (i=column, j=row) -> (rays_o, rays_d), un-normalised directions.
+
+    get_rays_from_uv (src/common.py:104-120).
+    """
+    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs.reshape(-1, 1, 3) * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def image_rays(H, W, fx, fy, cx, cy, c2w, crop_edge=0):
+    """All rays of an image, row-major.  get_rays (src/common.py:425-442)."""
+    jj, ii = torch.meshgrid(
+        torch.linspace(crop_edge, H - 1 - crop_edge, H - 2 * crop_edge),
+        torch.linspace(crop_edge, W - 1 - crop_edge, W - 2 * crop_edge), indexing='ij')
+    ro, rd = rays_from_uv(ii.reshape(-1), jj.reshape(-1), c2w, fx, fy, cx, cy)
+    return ro, rd
+
+
+def inside_threshold(depth):
+    """min(10*median, 1.2*max) over the (positive) depths of a batch.
+
+    Tracker.py:153-155, Mapper.py:674-676.  torch.median = lower median.
+    """
+    return torch.minimum(10 * depth.median(), 1.2 * depth.max())
+
+
+# --------------------------------------------------------------------------- depth-guided samples
+def sample_z(gt_depth, near_surface, far_surface, near_end, S):
+    """Per-ray sample depths z[R,S] (Renderer.py:98-165, sample_near_pcl=False)."""
+    gt = gt_depth.reshape(-1).float()
+    far_bb = torch.minimum(5 * gt.mean(), torch.max(gt * 1.2))
+    if torch.max(gt) > 0:
+        far = torch.clamp(far_bb, 0, torch.max(gt * 1.2))
+    else:
+        far = far_bb
+    t = torch.linspace(0.0, 1.0, steps=S)
+    g = gt.reshape(-1, 1).repeat(1, S)
+    z_nonzero = near_surface * g * (1. - t) + far_surface * g * t
+    z_zero = torch.linspace(near_end, float(far), steps=S).reshape(1, S).expand(gt.shape[0], S)
+    z = torch.where((gt > 0).reshape(-1, 1), z_nonzero, z_zero)
+    return z, far
+
+
+def sample_points(rays_o, rays_d, z):
+    """p[r,s] = o + d*z (rounded multiply then rounded add; Renderer.py:167-169)."""
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+    return pts.reshape(-1, 3)
+
+
+# --------------------------------------------------------------------------- neighbour search
+def knn_exact(points, queries, k, r2, chunk=2048):
+    """Exact radius-limited top-k neighbour search — THE contract of lk_knn_query.
+
+    d2 = (dx*dx + dy*dy) + dz*dz in fp32 (round after every op, no fma; the same
+    formula the reference's tracker path uses, decoder.py:194-195).  Candidates
+    are points with d2 <= r2; the k smallest by (d2, index) are returned in
+    ascending order; empty slots hold idx = -1, d2 = FLT_MAX.  count = number of
+    returned entries with d2 < r2 (strict), i.e. neural_point.py:1701-1706 applied
+    to the returned list.  r2 is a scalar or a per-query [P] array (fp32).
+
+    The reference uses approximate FAISS IVF (neural_point.py:1659-1708); parity
+    with it is unpinned (oracle/__init__.py).
+    """
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(-1, 3))
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(-1, 3))
+    P, N = q.shape[0], pts.shape[0]
+    r2 = np.broadcast_to(np.asarray(r2, dtype=np.float32).reshape(-1), (P,)) if np.ndim(r2) else \
+        np.full((P,), np.float32(r2), dtype=np.float32)
+    out_d = np.full((P, k), np.float32(FLT_MAX), dtype=np.float32)
+    out_i = np.full((P, k), -1, dtype=np.int32)
+    cnt = np.zeros((P,), dtype=np.int32)
+    if N == 0 or P == 0:
+        return out_d, out_i, cnt
+    for s in range(0, P, chunk):
+        qq = q[s:s + chunk]
+        dx = qq[:, None, 0] - pts[None, :, 0]
+        dy = qq[:, None, 1] - pts[None, :, 1]
+        dz = qq[:, None, 2] - pts[None, :, 2]
+        d2 = (dx * dx + dy * dy) + dz * dz                       # fp32, rounded per op
+        rr = r2[s:s + chunk, None]
+        d2m = np.where(d2 <= rr, d2, np.float32(np.inf))
+        kk = min(k, N)
+        # stable argsort on d2 keeps index order among equal distances => (d2, idx) order
+        order = np.argsort(d2m, axis=1, kind='stable')[:, :kk]
+        dsel = np.take_along_axis(d2m, order, axis=1)
+        ok = np.isfinite(dsel)
+        out_d[s:s + chunk, :kk] = np.where(ok, dsel, np.float32(FLT_MAX))
+        out_i[s:s + chunk, :kk] = np.where(ok, order, -1).astype(np.int32)
+        cnt[s:s + chunk] = (ok & (dsel < rr)).sum(1).astype(np.int32)
+    return out_d, out_i, cnt
+
+
+# --------------------------------------------------------------------------- interpolation
+def softplus100(x):
+    return F.softplus(x, beta=100)          # torch threshold: linear when 100*x > 20
+
+
+def fourier(x, B, concat):
+    """GaussianFourierFeatureTransform.forward (decoder.py:34-43).
+
+    (2*pi*x) @ B with K=3: torch-CPU evaluates this as a0*b0 then two fused
+    multiply-adds in k order (pinned by tests/test_oracle_golden.py::test_embed_fma_order);
+    the HIP kernels use exactly that sequence so sin/cos see bit-identical arguments.
+    """
+    y = (TWO_PI * x) @ B
+    return torch.cat((torch.sin(y), torch.cos(y)), dim=-1) if concat else torch.sin(y)
+
+
+def interp_weights(p, pos, idx, d2, r2, tracker):
+    """Normalised inverse-squared-distance weights [P,k] (decoder.py:189-220, 440-472).
+
+    tracker=True recomputes D differentiably from the positions and overwrites
+    out-of-radius entries with 1e4 (decoder.py:191-198).
+    """
+    valid = idx >= 0
+    I = idx.clamp(min=0).long()
+    r2c = r2.reshape(-1, 1) if torch.is_tensor(r2) and r2.dim() > 0 else r2
+    if tracker:
+        D = torch.sum(torch.square(pos[I] - p.reshape(-1, 1, 3)), dim=-1)
+        D = torch.where(valid, D, torch.full_like(D, FLT_MAX))
+        D = torch.where(D > r2c, torch.full_like(D, 1e4), D)
+    else:
+        D = d2
+    w = 1.0 / (D + 1e-10)
+    w = torch.where((D > r2c) | (~valid), torch.zeros_like(w), w)
+    w = w / torch.clamp(w.abs().sum(dim=1, keepdim=True), min=1e-12)
+    return w, I
+
+
+def interpolate(p, pos, feats, idx, d2, r2, count, min_nn, noise, tracker,
+                relpos=None):
+    """Feature at query points: c[P,C], has[P] (decoder.py:180-231 / 431-492).
+
+    relpos = (B_r[3,10], W1[128,52], b1, W2[32,128], b2) enables the colour
+    decoder's per-neighbour relative-position MLP (decoder.py:477-485).
+    Rows with count < min_nn get the shared `noise` vector (decoder.py:228-229).
+    """
+    w, I = interp_weights(p, pos, idx, d2, r2, tracker)
+    nf = feats[I]                                             # [P,k,C]
+    if relpos is not None:
+        B_r, W1, b1, W2, b2 = relpos
+        rel = pos[I] - p.reshape(-1, 1, 3)
+        emb = fourier(rel.reshape(-1, 3), B_r, concat=True).reshape(rel.shape[0], rel.shape[1], -1)
+        x = torch.cat([emb, nf], dim=-1)
+        nf = F.linear(softplus100(F.linear(x, W1, b1)), W2, b2)
+    c = (w.unsqueeze(-1) * nf).sum(dim=1)
+    has = count >= min_nn
+    c = torch.where(has.reshape(-1, 1), c, noise.reshape(1, -1).expand_as(c))
+    return c, has
+
+
+# --------------------------------------------------------------------------- decoders
+def _mlp5(e, c, W, prefix, act):
+    """5-block trunk shared by both decoders (decoder.py:274-288, 523-533)."""
+    h = e
+    for i in range(5):
+        h = F.linear(h, W[f'{prefix}.pts_linears.{i}.weight'], W[f'{prefix}.pts_linears.{i}.bias'])
+        h = act(h)
+        h = h + F.linear(c, W[f'{prefix}.fc_c.{i}.weight'], W[f'{prefix}.fc_c.{i}.bias'])
+        if i == 2:
+            h = torch.cat([e, h], -1)
+    return F.linear(h, W[f'{prefix}.output_linear.weight'], W[f'{prefix}.output_linear.bias'])
+
+
+def geo_mlp(p, c, W):
+    """Occupancy logit per point (MLP_geometry.forward, decoder.py:263-288). relu trunk."""
+    e = fourier(p, W['geo_decoder.embedder._B'], concat=False)
+    return _mlp5(e, c, W, 'geo_decoder', F.relu).squeeze(-1)
+
+
+def exposure_affine(W, exposure_feat):
+    """MLP_exposure (decoder.py:326-342): 8 -> 128 softplus100 -> 12."""
+    h = softplus100(F.linear(exposure_feat, W['color_decoder.mlp_exposure.linear1.weight'],
+                             W['color_decoder.mlp_exposure.linear1.bias']))
+    return F.linear(h, W['color_decoder.mlp_exposure.linear2.weight'],
+                    W['color_decoder.mlp_exposure.linear2.bias'])
+
+
+def color_mlp(p, c, W, affine=None, sigmoid=True):
+    """RGB per point (MLP_color.forward, decoder.py:513-546). softplus(beta=100) trunk.
+
+    affine (12,) = exposure transform applied before the sigmoid (decoder.py:534-540);
+    sigmoid=False returns raw logits (decoder.py:541-542, mapper exposure path).
+    """
+    e = fourier(p, W['color_decoder.embedder._B'], concat=True)
+    out = _mlp5(e, c, W, 'color_decoder', softplus100)
+    if affine is not None:
+        out = out @ affine[:9].reshape(3, 3) + affine[-3:]
+    return torch.sigmoid(out) if sigmoid else out
+
+
+# --------------------------------------------------------------------------- composite
+def composite(occ, rgb, z, coef):
+    """Alpha-composite S samples per ray (raw2outputs_nerf_color, common.py:382-422).
+
+    occ [R,S], rgb [R,S,3], z [R,S] -> depth[R], var[R], color[R,3], w[R,S].
+    """
+    alpha = torch.sigmoid(coef * occ)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1. - alpha + 1e-10], -1), -1)[:, :-1]
+    w = alpha * T
+    wsum = w.sum(-1, keepdim=True) + 1e-10
+    color = (w[..., None] * rgb).sum(-2) / wsum
+    depth = (w * z).sum(-1) / wsum.squeeze(-1)
+    tmp = z - depth.unsqueeze(-1)
+    var = (w * tmp * tmp).sum(1)
+    return depth, var, color, w
+
+
+# --------------------------------------------------------------------------- full render
+class RenderCfg:
+    """Scalar knobs of the path (configs/point_slam.yaml + dataset yaml, resolved)."""
+
+    def __init__(self, S=5, near_surface=0.98, far_surface=1.02, near_end=0.3, coef=0.1,
+                 k=8, min_nn=2, radius_query=0.08, rel_pos=True, exposure=False):
+        self.S, self.near_surface, self.far_surface, self.near_end = S, near_surface, far_surface, near_end
+        self.coef, self.k, self.min_nn, self.radius_query = coef, k, min_nn, radius_query
+        self.rel_pos, self.exposure = rel_pos, exposure
+
+
+def relpos_params(W):
+    return (W['color_decoder.embedder_rel_pos._B'],
+            W['color_decoder.mlp_col_neighbor.linear1.weight'], W['color_decoder.mlp_col_neighbor.linear1.bias'],
+            W['color_decoder.mlp_col_neighbor.linear2.weight'], W['color_decoder.mlp_col_neighbor.linear2.bias'])
+
+
+def render_batch(cfg, rays_o, rays_d, gt_depth, pos, geo_feats, col_feats, W, stage,
+                 tracker=False, r2_ray=None, noise_geo=None, noise_col=None, affine=None,
+                 color_sigmoid=True, knn=None):
+    """Renderer.render_batch_ray (Renderer.py:71-201) + NICER.forward (decoder.py:573-610).
+
+    Returns dict(depth, var, color, valid_ray, has, z, idx, d2, count, w).
+    r2_ray: per-ray squared query radius [R] (dynamic radius) or None (static).
+    """
+    R, S, C = rays_o.shape[0], cfg.S, geo_feats.shape[1]
+    z, _ = sample_z(gt_depth, cfg.near_surface, cfg.far_surface, cfg.near_end, S)
+    p = sample_points(rays_o, rays_d, z)
+    if r2_ray is None:
+        r2 = torch.tensor(np.float32(cfg.radius_query ** 2))
+        r2_np = np.float32(cfg.radius_query ** 2)
+    else:
+        r2 = r2_ray.float().reshape(-1, 1).repeat(1, S).reshape(-1)
+        r2_np = r2.numpy()
+    if knn is None:
+        d2, idx, count = knn_exact(pos.detach().numpy(), p.detach().numpy(), cfg.k, r2_np)
+    else:
+        d2, idx, count = knn
+    d2, idx, count = torch.from_numpy(np.asarray(d2)), torch.from_numpy(np.asarray(idx)), \
+        torch.from_numpy(np.asarray(count))
+    if noise_geo is None:
+        noise_geo = torch.zeros(C)
+    if noise_col is None:
+        noise_col = torch.zeros(C)
+    c_geo, has = interpolate(p, pos, geo_feats, idx, d2, r2, count, cfg.min_nn, noise_geo, tracker)
+    occ = geo_mlp(p, c_geo, W)
+    valid_ray = has.reshape(R, S).sum(1) >= int(S / 2 + 1)                 # decoder.py:259-260
+    if stage == 'color':
+        c_col, _ = interpolate(p, pos, col_feats, idx, d2, r2, count, cfg.min_nn, noise_col, tracker,
+                               relpos=relpos_params(W) if cfg.rel_pos else None)
+        rgb = color_mlp(p, c_col, W, affine=affine, sigmoid=color_sigmoid)
+    else:
+        rgb = torch.zeros(R * S, 3)
+    # Renderer.py:184-186: occupancy of no-neighbour samples is overwritten with -100 by an
+    # un-recorded in-place write; autograd still routes the gradient to the original logit.
+    occ_eff = torch.where(has, occ, occ + (-100.0 - occ).detach())
+    depth, var, color, w = composite(occ_eff.reshape(R, S), rgb.reshape(R, S, 3), z, cfg.coef)
+    depth = torch.where(gt_depth.reshape(-1) > 0, depth, torch.zeros_like(depth))   # Renderer.py:197-198
+    return dict(depth=depth, var=var, color=color, valid_ray=valid_ray, has=has, z=z, p=p,
+                idx=idx, d2=d2, count=count, w=w, occ=occ, rgb=rgb)
+
+
+# --------------------------------------------------------------------------- losses
+def mapper_loss(depth, color, valid_ray, gt_depth, gt_color, stage, w_color):
+    """Mapper.py:691-720 (no exposure): L1 depth (+ w_color * L1 colour in stage 'color')."""
+    m = (gt_depth > 0) & valid_ray & (~torch.isnan(depth))
+    geo = torch.abs(gt_depth[m] - depth[m]).sum()
+    col = torch.abs(gt_color[m] - color[m]).sum() if stage == 'color' else torch.zeros(())
+    return geo + w_color * col, geo, col, m
+
+
+def tracker_loss(depth, var, color, gt_depth, gt_color, w_color, use_color=True):
+    """Tracker.py:169-191 (handle_dynamic=True): uncertainty-normalised L1 + colour L1."""
+    unc = var.detach()
+    nan_mask = (~torch.isnan(depth)) & (~torch.isnan(unc))
+    tmp = torch.abs(gt_depth - depth) / torch.sqrt(unc + 1e-10)
+    m = (tmp < 10 * tmp.mean()) & (gt_depth > 0) & nan_mask
+    geo = torch.clamp(tmp, min=0.0, max=1e3)[m].sum()
+    col = torch.abs(gt_color - color)[m].sum()
+    loss = geo + w_color * col if use_color else geo
+    return loss, geo, col, m
+
+
+# --------------------------------------------------------------------------- Adam
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam single-tensor update (amsgrad=False, weight_decay=0), in place.
+
+    Mapper.py:570,723; Tracker.py:352,194.  `step` is the 1-based step count.
+    """
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+    return p

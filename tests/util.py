@@ -1,0 +1,35 @@
+"""Shared helpers for tests (golden loading, weight dicts, tolerances)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CFG_NAMES = ('replica', 'tum', 'scannet')
+
+
+def load(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def tens(d, *keys):
+    return [torch.from_numpy(np.asarray(d[k])) for k in keys]
+
+
+def weights(name):
+    return {k: torch.from_numpy(v) for k, v in load('weights_' + name).items()}
+
+
+# resolved hot-path knobs per dataset config
+CFG = {
+    'replica': dict(near_surface=0.98, far_surface=1.02, rel_pos=True, exposure=False, dynamic=False),
+    'tum': dict(near_surface=0.98, far_surface=1.02, rel_pos=False, exposure=False, dynamic=True),
+    'scannet': dict(near_surface=0.96, far_surface=1.04, rel_pos=False, exposure=True, dynamic=True),
+}
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
