@@ -1,0 +1,191 @@
+/* loopy_hip.h — C ABI of libloopyhip.so: the MI355X (gfx950) implementation of
+ * Loopy-SLAM's per-frame neural-point render / optimise hot path.
+ *
+ * The reference (eriksandstroem/Loopy-SLAM) has no FFI; its seam for this path is the
+ * Python API (Renderer.render_batch_ray, NICER.forward, NeuralPointCloud.find_neighbors_faiss,
+ * torch.optim.Adam ...).  Each entry point below names the reference code it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless named host_*; the caller (PyTorch) owns all
+ *    buffers; the library allocates only what an lk_knn_t handle owns;
+ *  - every call returns 0 on success, <0 on error (lk_last_error() gives the message,
+ *    thread-local); nothing throws across the ABI;
+ *  - kernels are enqueued on `stream` (a hipStream_t; torch.cuda.current_stream().cuda_stream)
+ *    and never synchronise the device;
+ *  - fp32 everywhere; indices int32; R rays, S samples/ray (<= 8), P = R*S points in
+ *    ray-major order (point r*S+s), k = 8 neighbours, C = 32 channels, N cloud points.
+ */
+#ifndef LOOPY_HIP_H
+#define LOOPY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LK_ABI_VERSION 1
+#define LK_K 8          /* pointcloud.nn_num   (configs/point_slam.yaml:136) */
+#define LK_C 32         /* model.c_dim         (configs/point_slam.yaml:11)  */
+#define LK_S_MAX 8      /* rendering.N_surface is 5 in every config          */
+
+#define LK_OK 0
+#define LK_ERR_ARG (-1)
+#define LK_ERR_HIP (-2)
+#define LK_ERR_STATE (-3)
+
+typedef struct lk_knn_s* lk_knn_t;
+
+int lk_version(void);
+const char* lk_last_error(void);
+
+/* ---------------------------------------------------------------- neighbour index
+ * Replaces the FAISS-GPU IVF index of NeuralPointCloud (src/neural_point.py:67-72 create,
+ * :1623-1627 train+add, :1659-1708 find_neighbors_faiss) by an exact uniform-grid search.
+ * Contract (oracle/hotpath.py::knn_exact): d2 = (dx*dx+dy*dy)+dz*dz in fp32, candidates
+ * d2 <= r2, the k=8 smallest by (d2, index) ascending, empty slots idx=-1 / d2=FLT_MAX,
+ * count = #returned with d2 < r2.
+ */
+int lk_knn_create(float cell_size, int64_t capacity_points, int64_t max_cells, lk_knn_t* out);
+int lk_knn_destroy(lk_knn_t h);
+/* (Re)build the grid over pos[0..N).  Appending points = rebuilding with the larger N
+ * (counting sort, O(N), device only, no host sync).  pos must stay alive and unchanged
+ * until the next build (the grid keeps its own sorted copy; pos itself is not read by queries). */
+int lk_knn_build(lk_knn_t h, const float* pos, int64_t N, void* stream);
+int64_t lk_knn_size(lk_knn_t h);
+/* r2_per_query may be NULL (then r2_scalar is used for every query). */
+int lk_knn_query(lk_knn_t h, const float* q, int64_t P, float r2_scalar, const float* r2_per_query,
+                 float* out_d2 /*[P,8]*/, int32_t* out_idx /*[P,8]*/, int32_t* out_count /*[P]*/,
+                 void* stream);
+
+/* ---------------------------------------------------------------- decoder weights
+ * NICER = MLP_geometry (hidden 32, relu) + MLP_color (hidden 128, softplus beta=100)
+ * (src/conv_onet/models/decoder.py:106-288, 345-546).  The kernels read ONE packed fp32
+ * blob; lk_weight_layout() describes it so the host can pack/unpack a state_dict.
+ * Every matrix is stored [out][in_padded] (torch layout, input dim zero-padded to a
+ * multiple of 8; the geometry skip layer's input is [e(93) pad 3 | h(32)]).
+ */
+typedef struct {
+    char name[64];      /* reference state_dict key, e.g. "color_decoder.pts_linears.3.weight" */
+    int64_t offset;     /* in floats, multiple of 64 */
+    int32_t rows, cols; /* logical shape (cols = 1 for vectors) */
+    int32_t ld;         /* padded row length in the blob */
+    int32_t col_split;  /* if >0: logical cols [col_split..) start at padded col `col_shift` */
+    int32_t col_shift;
+} lk_weight_entry;
+int lk_weight_layout(lk_weight_entry* out, int max_entries); /* returns #entries */
+int64_t lk_weight_blob_floats(void);
+
+/* ---------------------------------------------------------------- render forward / backward */
+#define LK_FLAG_STAGE_COLOR   (1u << 0)  /* NICER stage 'color' (else 'geometry': rgb = 0)          */
+#define LK_FLAG_TRACKER       (1u << 1)  /* is_tracker: gradient flows to the sample positions      */
+#define LK_FLAG_REL_POS       (1u << 2)  /* model.encode_rel_pos_in_col                             */
+#define LK_FLAG_COLOR_LOGITS  (1u << 3)  /* colour decoder returns pre-sigmoid logits (decoder.py:541-542) */
+#define LK_FLAG_SAVE_ACT      (1u << 4)  /* forward keeps the activations lk_render_bwd needs        */
+#define LK_FLAG_GRAD_FEATS    (1u << 5)  /* backward: d/d geo_feats, d/d col_feats                   */
+#define LK_FLAG_GRAD_WEIGHTS  (1u << 6)  /* backward: d/d decoder blob                               */
+#define LK_FLAG_GRAD_RAYS     (1u << 7)  /* backward: d/d rays_o, d/d rays_d (tracker / BA)          */
+#define LK_FLAG_ALL_DEPTH_POS (1u << 8)  /* caller guarantees gt_depth > 0 for every ray            */
+
+typedef struct {
+    /* ---- sizes */
+    int32_t R, S;
+    int32_t stats_chunk;        /* rays per far_bb group: R for a training batch, ray_batch_size (3000)
+                                   for render_img (Renderer.py:102-121 is evaluated per batch) */
+    uint32_t flags;
+    /* ---- inputs */
+    const float* rays_o;        /* [R,3] */
+    const float* rays_d;        /* [R,3] */
+    const float* gt_depth;      /* [R]   */
+    const float* r2_ray;        /* [R] squared query radius per ray, or NULL -> r2_static */
+    lk_knn_t knn;
+    const float* pos;           /* [N,3] cloud positions in original order (rel-pos MLP, tracker gradients) */
+    const float* geo_feats;     /* [N,32] */
+    const float* col_feats;     /* [N,32] */
+    const float* weights;       /* packed blob */
+    const float* affine;        /* [12] exposure transform applied before the sigmoid, or NULL */
+    const float* noise_geo;     /* [32] feature of samples without neighbours, or NULL (zeros) */
+    const float* noise_col;     /* [32] */
+    float near_surface, far_surface, near_end, coef, r2_static;
+    int32_t min_nn;
+    /* ---- outputs (Renderer.render_batch_ray: src/utils/Renderer.py:71-201) */
+    float* depth;               /* [R]   */
+    float* var;                 /* [R]   */
+    float* color;               /* [R,3] */
+    uint8_t* valid_ray;         /* [R]   */
+    /* ---- state shared by forward and backward (caller allocated) */
+    float* z;                   /* [R,S]   */
+    int32_t* nbr_idx;           /* [P,8]   */
+    float* nbr_w;               /* [P,8] normalised interpolation weights */
+    int32_t* nbr_count;         /* [P]     */
+    float* c_geo;               /* [P,32]  */
+    float* c_col;               /* [P,32]  */
+    float* raw;                 /* [P,4] rgb(or logits), occ */
+    float* far_stats;           /* [ceil(R/stats_chunk)] */
+    float* act;                 /* SAVE_ACT: lk_render_act_floats(R,S,flags) floats, else NULL */
+    /* ---- backward inputs */
+    const float* d_depth;       /* [R]   */
+    const float* d_var;         /* [R] or NULL */
+    const float* d_color;       /* [R,3] */
+    /* ---- backward outputs (ACCUMULATED into: caller zeroes) */
+    float* g_geo_feats;         /* [N,32] */
+    float* g_col_feats;         /* [N,32] */
+    float* g_weights;           /* blob-shaped */
+    float* g_rays_o;            /* [R,3] (overwritten) */
+    float* g_rays_d;            /* [R,3] (overwritten) */
+    float* g_affine;            /* [12] accumulated, or NULL */
+    /* ---- backward scratch */
+    float* bwd_scratch;         /* lk_render_bwd_scratch_floats(R,S,flags) floats */
+} lk_render_desc;
+
+int64_t lk_render_act_floats(int32_t R, int32_t S, uint32_t flags);
+int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t flags);
+/* Renderer.render_batch_ray + NICER.forward + raw2outputs_nerf_color
+ * (Renderer.py:71-201, decoder.py:573-610, common.py:382-422). */
+int lk_render_fwd(const lk_render_desc* d, void* stream);
+/* autograd backward of the same graph (Mapper.py:722, Tracker.py:193). */
+int lk_render_bwd(const lk_render_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- losses (fused with d/d outputs)
+ * Mapper (src/Mapper.py:691-720, non-exposure branch): mask = gt>0 & valid_ray & !nan(depth);
+ *   loss = sum|gt-depth| + w_color*sum|gt_color-color| (colour term only if use_color).
+ * Tracker (src/Tracker.py:169-191): u = |gt-depth|/sqrt(var+1e-10); mask = u < 10*mean(u) & gt>0 & !nan;
+ *   loss = sum clamp(u,0,1e3) + w_color*sum|gt_color-color|.
+ * out_loss[0..3] = {loss, geo_loss, color_loss, #masked rays}; d_depth/d_color are overwritten. */
+int lk_loss_mapper(int32_t R, const float* depth, const float* color, const uint8_t* valid_ray,
+                   const float* gt_depth, const float* gt_color, float w_color, int32_t use_color,
+                   float* d_depth, float* d_color, float* out_loss, void* stream);
+int lk_loss_tracker(int32_t R, const float* depth, const float* var, const float* color,
+                    const float* gt_depth, const float* gt_color, float w_color, int32_t use_color,
+                    float* d_depth, float* d_color, float* out_loss, float* scratch /*[R+8]*/, void* stream);
+
+/* ---------------------------------------------------------------- Adam
+ * torch.optim.Adam (amsgrad=False, weight_decay=0) on up to LK_ADAM_MAX_SEG tensors in one launch
+ * (Mapper.py:570,723; Tracker.py:352,194).  `step` is the 1-based step count of that tensor. */
+#define LK_ADAM_MAX_SEG 16
+typedef struct {
+    float* p; const float* g; float* m; float* v;
+    int64_t n;
+    float lr; int32_t step;
+} lk_adam_seg;
+int lk_adam_step(const lk_adam_seg* host_segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream);
+
+/* ---------------------------------------------------------------- rays / pose / compaction
+ * get_camera_from_tensor + get_rays_from_uv (src/common.py:301-343,104-120): cam = (qw,qx,qy,qz,tx,ty,tz). */
+int lk_rays_from_pose(const float* cam7, const float* pix_i, const float* pix_j, int32_t R,
+                      float fx, float fy, float cx, float cy, float* rays_o, float* rays_d, void* stream);
+/* d loss / d cam7 from d rays (overwrites g_cam7[7]). */
+int lk_pose_bwd(const float* cam7, const float* pix_i, const float* pix_j, int32_t R,
+                float fx, float fy, float cx, float cy, const float* g_rays_o, const float* g_rays_d,
+                float* g_cam7, void* stream);
+/* Stable stream compaction (wave ballot + prefix sum): out_index[0..count) = i with mask[i]!=0. */
+int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, void* stream);
+/* thr = min(10*median(depth), 1.2*max(depth)) over depth>0 (Tracker.py:153-155, Mapper.py:674-676);
+ * mask[i] = depth[i] > 0 && depth[i] <= thr.  scratch: n uint32. */
+int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* out_thr, uint32_t* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOOPY_HIP_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of libloopyhip.so (C ABI: include/loopy_hip.h).
+
+The product path loads exactly one library: the in-tree gfx950 build
+``loopy_slam_amd/libloopyhip.so`` (built by ``loopy_slam_amd/csrc/build.py`` /
+``__graft_entry__.build()``).  There is no CPU fallback: if the library is missing
+or no HIP device is visible, ``get_lib()`` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libloopyhip.so')
+
+LK_K = 8
+LK_C = 32
+LK_S_MAX = 8
+
+FLAG_STAGE_COLOR = 1 << 0
+FLAG_TRACKER = 1 << 1
+FLAG_REL_POS = 1 << 2
+FLAG_COLOR_LOGITS = 1 << 3
+FLAG_SAVE_ACT = 1 << 4
+FLAG_GRAD_FEATS = 1 << 5
+FLAG_GRAD_WEIGHTS = 1 << 6
+FLAG_GRAD_RAYS = 1 << 7
+FLAG_ALL_DEPTH_POS = 1 << 8
+
+ADAM_MAX_SEG = 16
+
+_fp = C.c_void_p     # every device pointer crosses the ABI as an integer address
+
+
+class WeightEntry(C.Structure):
+    _fields_ = [('name', C.c_char * 64), ('offset', C.c_int64), ('rows', C.c_int32), ('cols', C.c_int32),
+                ('ld', C.c_int32), ('col_split', C.c_int32), ('col_shift', C.c_int32)]
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [
+        ('R', C.c_int32), ('S', C.c_int32), ('stats_chunk', C.c_int32), ('flags', C.c_uint32),
+        ('rays_o', _fp), ('rays_d', _fp), ('gt_depth', _fp), ('r2_ray', _fp),
+        ('knn', _fp), ('pos', _fp), ('geo_feats', _fp), ('col_feats', _fp), ('weights', _fp),
+        ('affine', _fp), ('noise_geo', _fp), ('noise_col', _fp),
+        ('near_surface', C.c_float), ('far_surface', C.c_float), ('near_end', C.c_float), ('coef', C.c_float),
+        ('r2_static', C.c_float), ('min_nn', C.c_int32),
+        ('depth', _fp), ('var', _fp), ('color', _fp), ('valid_ray', _fp),
+        ('z', _fp), ('nbr_idx', _fp), ('nbr_w', _fp), ('nbr_count', _fp), ('c_geo', _fp), ('c_col', _fp),
+        ('raw', _fp), ('far_stats', _fp), ('act', _fp),
+        ('d_depth', _fp), ('d_var', _fp), ('d_color', _fp),
+        ('g_geo_feats', _fp), ('g_col_feats', _fp), ('g_weights', _fp), ('g_rays_o', _fp), ('g_rays_d', _fp),
+        ('g_affine', _fp), ('bwd_scratch', _fp),
+    ]
+
+
+class AdamSeg(C.Structure):
+    _fields_ = [('p', _fp), ('g', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int64), ('lr', C.c_float),
+                ('step', C.c_int32)]
+
+
+class LoopyError(RuntimeError):
+    pass
+
+
+class LoopyLib:
+    """Typed handle on one loaded libloopyhip build."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise LoopyError(f'{path} not found: build it with `python loopy_slam_amd/csrc/build.py` '
+                             f'(or __graft_entry__.build()); there is no CPU fallback')
+        self.path = path
+        self.dll = C.CDLL(path)
+        d = self.dll
+        d.lk_version.restype = C.c_int
+        d.lk_last_error.restype = C.c_char_p
+        d.lk_knn_create.argtypes = [C.c_float, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]
+        d.lk_knn_destroy.argtypes = [C.c_void_p]
+        d.lk_knn_build.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_void_p]
+        d.lk_knn_size.argtypes = [C.c_void_p]
+        d.lk_knn_size.restype = C.c_int64
+        d.lk_knn_query.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_float, _fp, _fp, _fp, _fp, C.c_void_p]
+        d.lk_weight_layout.argtypes = [C.POINTER(WeightEntry), C.c_int]
+        d.lk_weight_blob_floats.restype = C.c_int64
+        d.lk_render_act_floats.argtypes = [C.c_int32, C.c_int32, C.c_uint32]
+        d.lk_render_act_floats.restype = C.c_int64
+        d.lk_render_fwd.argtypes = [C.POINTER(RenderDesc), C.c_void_p]
+        for name, argtypes, restype in (
+            ('lk_render_bwd_scratch_floats', [C.c_int32, C.c_int32, C.c_uint32], C.c_int64),
+            ('lk_render_bwd', [C.POINTER(RenderDesc), C.c_void_p], C.c_int),
+            ('lk_loss_mapper', [C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_int32, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_loss_tracker', [C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_adam_step', [C.POINTER(AdamSeg), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p], C.c_int),
+            ('lk_rays_from_pose', [_fp, _fp, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_pose_bwd', [_fp, _fp, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_compact', [_fp, C.c_int32, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_inside_mask', [_fp, C.c_int32, _fp, _fp, _fp, C.c_void_p], C.c_int),
+        ):
+            if hasattr(d, name):
+                fn = getattr(d, name)
+                fn.argtypes = argtypes
+                fn.restype = restype
+        if d.lk_version() != 1:
+            raise LoopyError(f'{path}: ABI version {d.lk_version()} != 1')
+
+    def check(self, rc, what=''):
+        if rc != 0:
+            raise LoopyError(f'{what} failed (rc={rc}): {self.dll.lk_last_error().decode()}')
+
+    def weight_layout(self):
+        n = self.dll.lk_weight_layout(None, 0)
+        arr = (WeightEntry * n)()
+        self.dll.lk_weight_layout(arr, n)
+        return [dict(name=e.name.decode(), offset=e.offset, rows=e.rows, cols=e.cols, ld=e.ld,
+                     col_split=e.col_split, col_shift=e.col_shift) for e in arr]
+
+    def blob_floats(self):
+        return int(self.dll.lk_weight_blob_floats())
+
+
+_LIB = None
+
+
+def get_lib():
+    """The product library.  Raises if it is not built or no GPU is visible (no CPU path)."""
+    global _LIB
+    if _LIB is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise LoopyError('loopy_slam_amd needs a HIP device (MI355X); none is visible and there is no CPU fallback')
+        _LIB = LoopyLib(LIB_PATH)
+    return _LIB
+
+
+def ptr(t):
+    """Device address of a tensor (or 0 for None)."""
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Build libloopyhip.so (gfx950 code object + host stubs) in-tree with hipcc.
+
+    python loopy_slam_amd/csrc/build.py [--force] [--verbose]
+
+hipcc cross-compiles for gfx950 without a GPU; the .so is git-ignored but travels to
+the GPU box with the gpurun snapshot.  Sources: every *.hip in this directory.
+"""
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, 'libloopyhip.so')
+OBJ = os.path.join(HERE, '_obj')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-ffp-contract=fast']
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=False):
+    srcs = sorted(glob.glob(os.path.join(HERE, '*.hip')))
+    hdrs = sorted(glob.glob(os.path.join(HERE, '*.h'))) + [os.path.join(PKG, '..', 'include', 'loopy_hip.h')]
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + '.o')
+        if force or _newer([s] + hdrs, o):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = [HIPCC] + FLAGS + ['-c', s, '-o', o]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return s, r.returncode, r.stdout + r.stderr
+
+    failed = False
+    with cf.ThreadPoolExecutor(max_workers=max(1, min(8, len(jobs)))) as ex:
+        for s, rc, log in ex.map(cc, jobs):
+            if rc != 0 or (verbose and log.strip()):
+                print(f'--- {os.path.basename(s)} (rc={rc})\n{log}', file=sys.stderr)
+            failed |= rc != 0
+    if failed:
+        raise RuntimeError('hipcc failed')
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + '.o') for s in srcs]
+    if force or jobs or _newer(objs, OUT):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stdout + r.stderr, file=sys.stderr)
+            raise RuntimeError('link failed')
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv))

@@ -1,0 +1,158 @@
+// Shared host/device helpers for libloopyhip (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#include "../../include/loopy_hip.h"
+#include "lk_weights.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LK_TWO_PI 6.283185307179586f
+#define LK_FLT_MAX 3.402823466e+38f
+
+// ------------------------------------------------------------------ host side: errors
+void lk_set_error(const char* fmt, ...);
+#define LK_HIP_TRY(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            lk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return LK_ERR_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+#define LK_LAUNCH_CHECK()                                                                  \
+    do {                                                                                   \
+        hipError_t _e = hipGetLastError();                                                 \
+        if (_e != hipSuccess) {                                                            \
+            lk_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return LK_ERR_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+#define LK_REQUIRE(cond, msg)                                                              \
+    do {                                                                                   \
+        if (!(cond)) { lk_set_error("%s (%s:%d)", msg, __FILE__, __LINE__); return LK_ERR_ARG; } \
+    } while (0)
+
+static inline int lk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ neighbour grid (device resident)
+struct LkGrid {
+    float ox, oy, oz;      // origin = min corner of the point AABB
+    float cell, inv_cell;  // cell edge (>= requested; grown until dx*dy*dz <= max_cells)
+    int dx, dy, dz;
+    int ncells;
+    int n;                 // points in the grid
+    int min_enc[3], max_enc[3];   // order-preserving int encodings of the AABB (reduction scratch)
+};
+
+struct lk_knn_s {
+    float cell_size;
+    int64_t capacity;      // points
+    int64_t max_cells;
+    int64_t n;             // points of the last build (host copy)
+    LkGrid* grid;          // device
+    float4* sorted;        // [capacity] (x,y,z,bitcast original index), cell order
+    int32_t* cell_start;   // [max_cells + 1] exclusive prefix of per-cell counts
+    int32_t* cell_of;      // [capacity]
+    int32_t* rank_of;      // [capacity]
+    int32_t* block_sums;   // scan scratch
+    int32_t n_scan_blocks;
+};
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ int lk_lane() { return (int)(threadIdx.x & 63u); }
+
+// squared distance exactly as the contract states: (dx*dx + dy*dy) + dz*dz, one rounding per op
+__device__ __forceinline__ float lk_dist2(float qx, float qy, float qz, float px, float py, float pz) {
+    const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// sample position p = o + d*z with a rounded multiply then a rounded add (Renderer.py:167-168)
+__device__ __forceinline__ float lk_madd_rn(float o, float d, float z) { return __fadd_rn(o, __fmul_rn(d, z)); }
+
+// Fourier argument (2*pi*x) @ B[:,u] evaluated as torch-CPU does for K=3: a0*b0, then fma, fma
+// (pinned by tests/test_oracle_golden.py::test_embed_fma_order).  a_i = fl(2*pi*x_i).
+__device__ __forceinline__ float lk_fourier_arg(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return fmaf(a2, b2, fmaf(a1, b1, __fmul_rn(a0, b0)));
+}
+
+__device__ __forceinline__ float lk_softplus100(float x) {
+    const float t = 100.0f * x;
+    return t > 20.0f ? x : log1pf(expf(t)) / 100.0f;     // torch softplus(beta=100, threshold=20)
+}
+// d softplus100 / dx expressed through the OUTPUT a = softplus100(x): sigmoid(100x) = 1 - exp(-100a)
+__device__ __forceinline__ float lk_softplus100_grad_from_out(float a) { return -expm1f(-100.0f * a); }
+__device__ __forceinline__ float lk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// C/D-fragment bookkeeping of v_mfma_f32_32x32x2_f32: lane l, register r holds
+// row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+__device__ __forceinline__ int lk_frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 lk_mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 lk_zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
+}
+
+// ------------------------------------------------------------------ register-chained transposed GEMM
+// Activations live as "CT tiles": a [32 units x 32 samples] block held in the MFMA C/D layout
+// (lane = sample column, registers = unit rows).  One layer is Y^T = W * X^T with
+//   A operand = W[out = nb*32 + (lane&31)][k],  B operand = X^T[k][sample = lane&31].
+// The reduction index k is walked in the order the C/D layout stores rows: at step (g,t) the
+// low half-wave carries k = 8g+t and the high half k = 8g+4+t — exactly register 4g+t of the
+// CT tile of the previous layer, so a layer's output feeds the next layer's B operand straight
+// from registers (no LDS, no barrier).  W is [out][ld] row-major (torch layout), ld % 4 == 0;
+// a lane fetches its four t-consecutive weights with one 16-byte load.
+template <int NB, int NG>
+__device__ __forceinline__ void lk_gemm_kblock(f32x16 (&acc)[NB], const float* __restrict__ W, int ld,
+                                               int kcol0, const f32x16& x, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float4 a = *reinterpret_cast<const float4*>(W + (size_t)(nb * 32 + i) * ld + kcol0 + 8 * g + 4 * h);
+            acc[nb] = lk_mfma(a.x, x[4 * g + 0], acc[nb]);
+            acc[nb] = lk_mfma(a.y, x[4 * g + 1], acc[nb]);
+            acc[nb] = lk_mfma(a.z, x[4 * g + 2], acc[nb]);
+            acc[nb] = lk_mfma(a.w, x[4 * g + 3], acc[nb]);
+        }
+    }
+}
+
+// Transposed variant for the backward data pass: dX^T = W^T * dY^T,
+//   A operand = W[out = k][in = kb_out*32 + (lane&31)]  (k walks the rows of the dY CT tile).
+// out_col0 = first input column of the 32-wide output block; nrow0 = first row (out unit) of the dY tile.
+template <int NG>
+__device__ __forceinline__ void lk_gemm_kblock_T(f32x16& acc, const float* __restrict__ W, int ld,
+                                                 int out_col0, int nrow0, const f32x16& dy, int lane, int col_limit) {
+    const int i = lane & 31, h = lane >> 5;
+    const bool ok = (out_col0 + i) < col_limit;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = nrow0 + 8 * g + 4 * h + t;
+            const float a = ok ? W[(size_t)n * ld + out_col0 + i] : 0.0f;
+            acc = lk_mfma(a, dy[4 * g + t], acc);
+        }
+    }
+}
+
+// per-row vector (bias) of a CT tile: v[unit(r,h)] for r = 0..15, unit0 = first unit of the tile
+__device__ __forceinline__ void lk_add_rowvec(f32x16& acc, const float* __restrict__ v, int unit0, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(v + unit0 + 8 * g + 4 * h);
+        acc[4 * g + 0] += b.x; acc[4 * g + 1] += b.y; acc[4 * g + 2] += b.z; acc[4 * g + 3] += b.w;
+    }
+}

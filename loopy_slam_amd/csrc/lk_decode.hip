@@ -1,0 +1,343 @@
+// Fused decoder forward on the matrix cores (compute-bound half of the render forward).
+//   reference: GaussianFourierFeatureTransform (src/conv_onet/models/decoder.py:12-43),
+//              MLP_geometry.forward (decoder.py:263-288), MLP_color.forward (decoder.py:513-546),
+//              MLP_col_neighbor / rel-pos branch of MLP_color.get_feature_at_pos (decoder.py:477-490),
+//              NICER.forward stage dispatch (decoder.py:573-610).
+//
+// Design (CDNA4): one wave64 owns 32 sample points.  Activations are kept TRANSPOSED in the MFMA
+// C/D layout ("CT tile": 32 units x 32 samples, lane = sample column) so that each layer
+// Y^T = W X^T uses v_mfma_f32_32x32x2_f32 with A = weights (16-byte loads straight from the
+// L2-resident blob) and B = the previous layer's accumulator registers.  No LDS, no barriers,
+// exact fp32 (fma-chain) arithmetic at the fp32 matrix rate.  See lk_common.h::lk_gemm_kblock.
+#include "lk_common.h"
+#include "lk_kernels.h"
+
+using namespace lkw;
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 ct_load_rows32(const float* __restrict__ row /* 32 floats of this sample */,
+                                                 bool live, int lane) {
+    const int h = lane >> 5;
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) v = *reinterpret_cast<const float4*>(row + 8 * g + 4 * h);
+        t[4 * g + 0] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
+    }
+    return t;
+}
+
+__device__ __forceinline__ void ct_store_rows32(float* __restrict__ row, const f32x16& t, bool live, int lane) {
+    const int h = lane >> 5;
+    if (!live) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(row + 8 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+}
+
+// geometry embedding tile b (units 32b..32b+31 of sin((2*pi*p) @ B_g), B_g padded [3][96])
+__device__ __forceinline__ f32x16 geo_embed_tile(const float* __restrict__ B, int b, float a0, float a1, float a2, int lane) {
+    const int h = lane >> 5;
+    f32x16 e;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int u0 = 32 * b + 8 * g + 4 * h;
+        const float4 b0 = *reinterpret_cast<const float4*>(B + u0);
+        const float4 b1 = *reinterpret_cast<const float4*>(B + EGP + u0);
+        const float4 b2 = *reinterpret_cast<const float4*>(B + 2 * EGP + u0);
+        e[4 * g + 0] = (u0 + 0 < EG) ? sinf(lk_fourier_arg(a0, a1, a2, b0.x, b1.x, b2.x)) : 0.0f;
+        e[4 * g + 1] = (u0 + 1 < EG) ? sinf(lk_fourier_arg(a0, a1, a2, b0.y, b1.y, b2.y)) : 0.0f;
+        e[4 * g + 2] = (u0 + 2 < EG) ? sinf(lk_fourier_arg(a0, a1, a2, b0.z, b1.z, b2.z)) : 0.0f;
+        e[4 * g + 3] = (u0 + 3 < EG) ? sinf(lk_fourier_arg(a0, a1, a2, b0.w, b1.w, b2.w)) : 0.0f;
+    }
+    return e;
+}
+
+// [sin(x_0..n-1), cos(x_0..n-1)] embedding unit u of a [3][n] matrix (colour: n = 20, rel-pos: n = 10)
+__device__ __forceinline__ float sincos_embed_unit(const float* __restrict__ B, int n, int u, float a0, float a1, float a2) {
+    if (u >= 2 * n) return 0.0f;
+    const int xi = (u < n) ? u : u - n;
+    const float x = lk_fourier_arg(a0, a1, a2, B[xi], B[n + xi], B[2 * n + xi]);
+    return (u < n) ? sinf(x) : cosf(x);
+}
+
+template <int NG>
+__device__ __forceinline__ f32x16 sincos_embed_tile(const float* __restrict__ B, int n, int b, float a0, float a1, float a2, int lane) {
+    const int h = lane >> 5;
+    f32x16 e = lk_zero16();
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            e[4 * g + t] = sincos_embed_unit(B, n, 32 * b + 8 * g + 4 * h + t, a0, a1, a2);
+    return e;
+}
+
+// bias + activation (+ optional save) + fc_c(c): h = act(acc + b) + (U c + u)
+template <int NB, bool SOFTPLUS>
+__device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB], const float* __restrict__ bias,
+                                             const float* __restrict__ U, const float* __restrict__ ubias,
+                                             const f32x16& c, float* __restrict__ save_a, bool live, int lane) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        lk_add_rowvec(acc[nb], bias, nb * 32, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = SOFTPLUS ? lk_softplus100(acc[nb][r]) : fmaxf(acc[nb][r], 0.0f);
+        if (save_a) ct_store_rows32(save_a + nb * 32, acc[nb], live, lane);
+        lk_add_rowvec(acc[nb], ubias, nb * 32, lane);
+    }
+    lk_gemm_kblock<NB, 4>(acc, U, CF, 0, c, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
+    const int lane = lk_lane();
+    const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int sample0 = wave * 32;
+    if (sample0 >= a.P) return;                                  // whole wave leaves together
+    const int sample = sample0 + (lane & 31);
+    const bool live = sample < a.P;
+    const int h = lane >> 5;
+    const int sp = live ? sample : a.P - 1;                      // clamp: dead lanes compute, never store
+    const int r = sp / a.S;
+    const float z = a.z[sp];
+    const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
+    const float py = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
+    const float pz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
+    const float a0 = __fmul_rn(LK_TWO_PI, px), a1 = __fmul_rn(LK_TWO_PI, py), a2 = __fmul_rn(LK_TWO_PI, pz);
+    const float* __restrict__ W = a.W;
+    const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
+    float* act_geo = save ? a.act + (size_t)sp * LK_ACT_GEO_A : nullptr;
+    float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A : nullptr;
+    float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H : nullptr;
+
+    // ================= geometry decoder (hidden 32, relu) =================
+    float occ;
+    {
+        const f32x16 e0 = geo_embed_tile(W + G_EB, 0, a0, a1, a2, lane);
+        const f32x16 e1 = geo_embed_tile(W + G_EB, 1, a0, a1, a2, lane);
+        const f32x16 e2 = geo_embed_tile(W + G_EB, 2, a0, a1, a2, lane);
+        const f32x16 cg = ct_load_rows32(a.c_geo + (size_t)sp * LK_C, true, lane);
+        f32x16 acc[1], hh;
+        // layer 0: 93 -> 32
+        acc[0] = lk_zero16();
+        lk_gemm_kblock<1, 4>(acc, W + G_W0, EGP, 0, e0, lane);
+        lk_gemm_kblock<1, 4>(acc, W + G_W0, EGP, 32, e1, lane);
+        lk_gemm_kblock<1, 4>(acc, W + G_W0, EGP, 64, e2, lane);
+        layer_finish<1, false>(acc, W + G_B0, W + G_U0, W + G_U0 + a64(HG * CF), cg, act_geo, live, lane);
+        hh = acc[0];
+        // layers 1, 2: 32 -> 32
+        acc[0] = lk_zero16();
+        lk_gemm_kblock<1, 4>(acc, W + G_W1, HG, 0, hh, lane);
+        layer_finish<1, false>(acc, W + G_B1, W + G_U0 + G_USTRIDE, W + G_U0 + G_USTRIDE + a64(HG * CF), cg,
+                               act_geo ? act_geo + 32 : nullptr, live, lane);
+        hh = acc[0];
+        acc[0] = lk_zero16();
+        lk_gemm_kblock<1, 4>(acc, W + G_W2, HG, 0, hh, lane);
+        layer_finish<1, false>(acc, W + G_B2, W + G_U0 + 2 * G_USTRIDE, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cg,
+                               act_geo ? act_geo + 64 : nullptr, live, lane);
+        hh = acc[0];
+        // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
+        acc[0] = lk_zero16();
+        lk_gemm_kblock<1, 4>(acc, W + G_W3, EGP + HG, 0, e0, lane);
+        lk_gemm_kblock<1, 4>(acc, W + G_W3, EGP + HG, 32, e1, lane);
+        lk_gemm_kblock<1, 4>(acc, W + G_W3, EGP + HG, 64, e2, lane);
+        lk_gemm_kblock<1, 4>(acc, W + G_W3, EGP + HG, 96, hh, lane);
+        layer_finish<1, false>(acc, W + G_B3, W + G_U0 + 3 * G_USTRIDE, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cg,
+                               act_geo ? act_geo + 96 : nullptr, live, lane);
+        hh = acc[0];
+        // layer 4
+        acc[0] = lk_zero16();
+        lk_gemm_kblock<1, 4>(acc, W + G_W4, HG, 0, hh, lane);
+        layer_finish<1, false>(acc, W + G_B4, W + G_U0 + 4 * G_USTRIDE, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cg,
+                               act_geo ? act_geo + 128 : nullptr, live, lane);
+        // output 32 -> 1 on the VALU: each half-wave holds 16 of the 32 units of its sample
+        float part = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 wo = *reinterpret_cast<const float4*>(W + G_WO + 8 * g + 4 * h);
+            part = fmaf(wo.x, acc[0][4 * g], part); part = fmaf(wo.y, acc[0][4 * g + 1], part);
+            part = fmaf(wo.z, acc[0][4 * g + 2], part); part = fmaf(wo.w, acc[0][4 * g + 3], part);
+        }
+        part += __shfl_xor(part, 32);
+        occ = part + W[G_BO];
+    }
+
+    // ================= colour decoder (hidden 128, softplus beta=100) =================
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    if (a.flags & LK_FLAG_STAGE_COLOR) {
+        const f32x16 e0 = sincos_embed_tile<4>(W + C_EB, 20, 0, a0, a1, a2, lane);
+        const f32x16 e1 = sincos_embed_tile<1>(W + C_EB, 20, 1, a0, a1, a2, lane);
+        const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
+        f32x16 acc[4], hh[4];
+        // layer 0: 40 -> 128
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
+        lk_gemm_kblock<4, 4>(acc, W + C_W0, EC, 0, e0, lane);
+        lk_gemm_kblock<4, 1>(acc, W + C_W0, EC, 32, e1, lane);
+        layer_finish<4, true>(acc, W + C_B0, W + C_U0, W + C_U0 + a64(HC * CF), cc, act_col_a, live, lane);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + nb * 32, hh[nb], live, lane); }
+        // layers 1, 2: 128 -> 128
+#pragma unroll
+        for (int L = 1; L <= 2; ++L) {
+            const float* Wl = W + (L == 1 ? C_W1 : C_W2);
+            const float* Bl = W + (L == 1 ? C_B1 : C_B2);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) lk_gemm_kblock<4, 4>(acc, Wl, HC, 32 * kb, hh[kb], lane);
+            layer_finish<4, true>(acc, Bl, W + C_U0 + L * C_USTRIDE, W + C_U0 + L * C_USTRIDE + a64(HC * CF), cc,
+                                  act_col_a ? act_col_a + L * 128 : nullptr, live, lane);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + L * 128 + nb * 32, hh[nb], live, lane); }
+        }
+        // layer 3 (skip): [e(40) | h(128)] -> 128
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
+        lk_gemm_kblock<4, 4>(acc, W + C_W3, EC + HC, 0, e0, lane);
+        lk_gemm_kblock<4, 1>(acc, W + C_W3, EC + HC, 32, e1, lane);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) lk_gemm_kblock<4, 4>(acc, W + C_W3, EC + HC, EC + 32 * kb, hh[kb], lane);
+        layer_finish<4, true>(acc, W + C_B3, W + C_U0 + 3 * C_USTRIDE, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), cc,
+                              act_col_a ? act_col_a + 3 * 128 : nullptr, live, lane);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + 3 * 128 + nb * 32, hh[nb], live, lane); }
+        // layer 4
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) lk_gemm_kblock<4, 4>(acc, W + C_W4, HC, 32 * kb, hh[kb], lane);
+        layer_finish<4, true>(acc, W + C_B4, W + C_U0 + 4 * C_USTRIDE, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), cc,
+                              act_col_a ? act_col_a + 4 * 128 : nullptr, live, lane);
+        if (save) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) ct_store_rows32(act_col_h + 4 * 128 + nb * 32, acc[nb], live, lane);
+        }
+        // output 128 -> 3 on the VALU
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u = 32 * nb + 8 * g + 4 * h;
+                const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + u);
+                const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
+                const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
+                const float v0 = acc[nb][4 * g], v1 = acc[nb][4 * g + 1], v2 = acc[nb][4 * g + 2], v3 = acc[nb][4 * g + 3];
+                o0 = fmaf(w0.x, v0, o0); o0 = fmaf(w0.y, v1, o0); o0 = fmaf(w0.z, v2, o0); o0 = fmaf(w0.w, v3, o0);
+                o1 = fmaf(w1.x, v0, o1); o1 = fmaf(w1.y, v1, o1); o1 = fmaf(w1.z, v2, o1); o1 = fmaf(w1.w, v3, o1);
+                o2 = fmaf(w2.x, v0, o2); o2 = fmaf(w2.y, v1, o2); o2 = fmaf(w2.z, v2, o2); o2 = fmaf(w2.w, v3, o2);
+            }
+        }
+        o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
+        o0 += W[C_BO]; o1 += W[C_BO + 1]; o2 += W[C_BO + 2];
+        if (a.affine) {                      // out @ A + t, A = affine[:9].reshape(3,3) (decoder.py:536-539)
+            const float* A = a.affine;
+            const float t0 = o0 * A[0] + o1 * A[3] + o2 * A[6] + A[9];
+            const float t1 = o0 * A[1] + o1 * A[4] + o2 * A[7] + A[10];
+            const float t2 = o0 * A[2] + o1 * A[5] + o2 * A[8] + A[11];
+            o0 = t0; o1 = t1; o2 = t2;
+        }
+        if (!(a.flags & LK_FLAG_COLOR_LOGITS)) { o0 = lk_sigmoid(o0); o1 = lk_sigmoid(o1); o2 = lk_sigmoid(o2); }
+    }
+    if (live && h == 0) *reinterpret_cast<float4*>(a.raw + (size_t)sample * 4) = make_float4(o0, o1, o2, occ);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Relative-position neighbour MLP: one wave = 32 neighbour rows = 4 samples x 8 neighbours.
+//   x_j = [sin(2 pi D_j B_r), cos(2 pi D_j B_r), F[I_j]] (52) -> 128 softplus100 -> 32;  c = sum_j w_j f_j
+__global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
+    const int lane = lk_lane();
+    const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int sample0 = wave * 4;
+    if (sample0 >= a.P) return;
+    const int h = lane >> 5;
+    const int j = lane & 31;                    // row of the tile: sample j>>3, neighbour j&7
+    const int sample = sample0 + (j >> 3);
+    const bool live = sample < a.P;
+    const int sp = live ? sample : a.P - 1;
+    const int nb_i = j & 7;
+    const int r = sp / a.S;
+    const float z = a.z[sp];
+    const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
+    const float py = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
+    const float pz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
+    int idx = a.nbr_idx[(size_t)sp * LK_K + nb_i];
+    const float wgt = (idx >= 0) ? a.nbr_w[(size_t)sp * LK_K + nb_i] : 0.0f;
+    if (idx < 0) idx = 0;                       // padded slot: finite dummy row, weight 0
+    // D = x_I - p (decoder.py:478-479); arguments a_i = fl(2 pi D_i)
+    const float a0 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx], px));
+    const float a1 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 1], py));
+    const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
+    const float* __restrict__ W = a.W;
+    const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
+    // X^T tiles: units 0..19 embedding, 20..51 feature channels 0..31, 52..55 zero
+    f32x16 x0, x1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int u0 = 8 * g + 4 * h;
+        if (u0 < ER) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x0[4 * g + t] = sincos_embed_unit(W + R_EB, 10, u0 + t, a0, a1, a2);
+        } else {
+            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            x0[4 * g] = v.x; x0[4 * g + 1] = v.y; x0[4 * g + 2] = v.z; x0[4 * g + 3] = v.w;
+        }
+    }
+    x1 = lk_zero16();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int u0 = 32 + 8 * g + 4 * h;
+        if (u0 < KR) {
+            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            x1[4 * g] = v.x; x1[4 * g + 1] = v.y; x1[4 * g + 2] = v.z; x1[4 * g + 3] = v.w;
+        }
+    }
+    f32x16 hid[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_zero16();
+    lk_gemm_kblock<4, 4>(hid, W + R_W1, KRP, 0, x0, lane);
+    lk_gemm_kblock<4, 3>(hid, W + R_W1, KRP, 32, x1, lane);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        lk_add_rowvec(hid[nb], W + R_B1, nb * 32, lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hid[nb][q] = lk_softplus100(hid[nb][q]);
+    }
+    f32x16 out[1];
+    out[0] = lk_zero16();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) lk_gemm_kblock<1, 4>(out, W + R_W2, HC, 32 * kb, hid[kb], lane);
+    lk_add_rowvec(out[0], W + R_B2, 0, lane);
+    // c[ch] = sum over the 8 neighbour rows of a sample (8 consecutive lanes) of w * f[ch]
+    const bool has = a.nbr_count[sp] >= a.min_nn;
+    float* __restrict__ crow = a.c_col + (size_t)sp * LK_C;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float s = wgt * out[0][4 * g + t];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            v[t] = s;
+        }
+        if (live && nb_i == 0) {
+            const int ch = 8 * g + 4 * h;
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (!has) o = a.noise_col ? *reinterpret_cast<const float4*>(a.noise_col + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(crow + ch) = o;
+        }
+    }
+}
+
+int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
+    const int waves = lk_cdiv(a.P, 32);
+    hipLaunchKernelGGL(k_decode_fwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    return LK_OK;
+}
+int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {
+    const int waves = lk_cdiv(a.P, 4);
+    hipLaunchKernelGGL(k_relpos_fwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    return LK_OK;
+}

@@ -1,0 +1,170 @@
+// Depth-guided sampling + radius-kNN + inverse-distance feature interpolation (HBM-bound half of
+// the render forward), and the per-ray alpha composite.
+//   reference: Renderer.render_batch_ray z-sampling (src/utils/Renderer.py:98-176),
+//              NeuralPointCloud.find_neighbors_faiss (src/neural_point.py:1659-1708),
+//              MLP_*.get_feature_at_pos (src/conv_onet/models/decoder.py:180-231, 431-492),
+//              raw2outputs_nerf_color (src/common.py:382-422), Renderer.py:184-200.
+#include "lk_common.h"
+#include "lk_knn_dev.h"
+#include "lk_kernels.h"
+
+// torch.linspace(start, end, steps)[i] (symmetric evaluation, aten RangeFactories)
+__device__ __forceinline__ float lk_linspace(float start, float end, int steps, int i) {
+    if (steps <= 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+// far_bb per group of `chunk` rays (Renderer.py:102-121): far = clamp(min(5*mean, 1.2*max), 0, 1.2*max)
+__global__ __launch_bounds__(256) void k_depth_stats(const float* __restrict__ gt, int R, int chunk,
+                                                     float* __restrict__ far_out) {
+    __shared__ float ssum[4], smax[4];
+    const int b = blockIdx.x;
+    const int lo = b * chunk, hi = min(R, lo + chunk);
+    float sum = 0.0f, mx = -LK_FLT_MAX;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) { const float v = gt[i]; sum += v; mx = fmaxf(mx, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if (lk_lane() == 0) { ssum[threadIdx.x >> 6] = sum; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sum = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+        mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        const float mean = sum / (float)(hi - lo);
+        const float mx12 = mx * 1.2f;
+        const float far_bb = fminf(5.0f * mean, mx12);
+        far_out[b] = (mx > 0.0f) ? fminf(fmaxf(far_bb, 0.0f), mx12) : far_bb;
+    }
+}
+
+// One thread per sample point: z, p, exact top-8 within radius, normalised weights; then the wave
+// gathers the 8 feature rows of each of its 64 samples cooperatively (8 lanes x 16 B = one 128-B
+// row per load) and writes the interpolated features.
+__global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
+    const int pidx = blockIdx.x * 256 + (int)threadIdx.x;
+    const bool live = pidx < a.P;
+    const int lane = lk_lane();
+    float d[LK_K], w[LK_K];
+    int id[LK_K];
+    int count = 0;
+#pragma unroll
+    for (int j = 0; j < LK_K; ++j) { d[j] = LK_FLT_MAX; id[j] = -1; w[j] = 0.0f; }
+    if (live) {
+        const int r = pidx / a.S, s = pidx - r * a.S;
+        const float gt = a.gt_depth[r];
+        float z;
+        if (gt > 0.0f) {
+            const float t = lk_linspace(0.0f, 1.0f, a.S, s);
+            z = __fadd_rn(__fmul_rn(__fmul_rn(a.near_surface, gt), __fsub_rn(1.0f, t)),
+                          __fmul_rn(__fmul_rn(a.far_surface, gt), t));
+        } else {
+            const float far = a.far_stats ? a.far_stats[r / a.stats_chunk] : 0.0f;
+            z = lk_linspace(a.near_end, far, a.S, s);
+        }
+        a.z[pidx] = z;
+        const float qx = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
+        const float qy = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
+        const float qz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
+        const float r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
+        lk_knn_scan(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, d, id);
+        // w = 1/(D+1e-10), zero outside the radius, L1-normalised (decoder.py:210-220)
+        float wsum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < LK_K; ++j) {
+            const bool in = id[j] >= 0 && d[j] <= r2;
+            w[j] = in ? 1.0f / (d[j] + 1e-10f) : 0.0f;
+            wsum += w[j];
+            count += (id[j] >= 0 && d[j] < r2) ? 1 : 0;
+        }
+        const float inv = 1.0f / fmaxf(wsum, 1e-12f);
+#pragma unroll
+        for (int j = 0; j < LK_K; ++j) w[j] = w[j] * inv;
+        int4* oi = reinterpret_cast<int4*>(a.nbr_idx + (size_t)pidx * LK_K);
+        oi[0] = make_int4(id[0], id[1], id[2], id[3]);
+        oi[1] = make_int4(id[4], id[5], id[6], id[7]);
+        float4* ow = reinterpret_cast<float4*>(a.nbr_w + (size_t)pidx * LK_K);
+        ow[0] = make_float4(w[0], w[1], w[2], w[3]);
+        ow[1] = make_float4(w[4], w[5], w[6], w[7]);
+        a.nbr_count[pidx] = count;
+    }
+    // ---- cooperative gather: round t serves samples t*8 .. t*8+7 of this wave
+    const int sub = lane & 7;                         // which float4 of the 32-channel row
+    const int wave_base = blockIdx.x * 256 + ((int)threadIdx.x & ~63);
+    const bool do_col = (a.flags & LK_FLAG_STAGE_COLOR) && !(a.flags & LK_FLAG_REL_POS);
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+        const int src = t * 8 + (lane >> 3);
+        float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ac = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < LK_K; ++j) {
+            const int ij = __shfl(id[j], src);
+            const float wj = __shfl(w[j], src);
+            if (wj != 0.0f) {
+                const float4 g = *reinterpret_cast<const float4*>(a.geo_feats + (size_t)ij * LK_C + sub * 4);
+                ag.x = fmaf(wj, g.x, ag.x); ag.y = fmaf(wj, g.y, ag.y); ag.z = fmaf(wj, g.z, ag.z); ag.w = fmaf(wj, g.w, ag.w);
+                if (do_col) {
+                    const float4 c = *reinterpret_cast<const float4*>(a.col_feats + (size_t)ij * LK_C + sub * 4);
+                    ac.x = fmaf(wj, c.x, ac.x); ac.y = fmaf(wj, c.y, ac.y); ac.z = fmaf(wj, c.z, ac.z); ac.w = fmaf(wj, c.w, ac.w);
+                }
+            }
+        }
+        const int cnt = __shfl(count, src);
+        const int sp = wave_base + src;
+        if (sp < a.P) {
+            if (cnt < a.min_nn) {      // no usable neighbourhood: the shared noise vector (decoder.py:228-229)
+                ag = a.noise_geo ? *reinterpret_cast<const float4*>(a.noise_geo + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ac = a.noise_col ? *reinterpret_cast<const float4*>(a.noise_col + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *reinterpret_cast<float4*>(a.c_geo + (size_t)sp * LK_C + sub * 4) = ag;
+            if (do_col) *reinterpret_cast<float4*>(a.c_col + (size_t)sp * LK_C + sub * 4) = ac;
+        }
+    }
+}
+
+// One thread per ray: occupancy of unsupported samples := -100, alpha composite, validity.
+__global__ __launch_bounds__(256) void k_composite(LkCompositeArgs a) {
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    if (r >= a.R) return;
+    float T = 1.0f, wsum = 0.0f, dsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    float wv[LK_S_MAX], zv[LK_S_MAX];
+    int nhas = 0;
+#pragma unroll
+    for (int s = 0; s < LK_S_MAX; ++s) {
+        if (s < a.S) {
+            const int p = r * a.S + s;
+            const float4 raw = *reinterpret_cast<const float4*>(a.raw + (size_t)p * 4);
+            const bool has = a.nbr_count[p] >= a.min_nn;
+            nhas += has ? 1 : 0;
+            const float occ = has ? raw.w : -100.0f;
+            const float alpha = lk_sigmoid(a.coef * occ);
+            const float w = alpha * T;
+            T *= (1.0f - alpha + 1e-10f);
+            const float z = a.z[p];
+            wv[s] = w; zv[s] = z;
+            wsum += w; dsum += w * z;
+            c0 += w * raw.x; c1 += w * raw.y; c2 += w * raw.z;
+        } else { wv[s] = 0.0f; zv[s] = 0.0f; }
+    }
+    const float ws = wsum + 1e-10f;
+    const float depth = dsum / ws;
+    float var = 0.0f;
+#pragma unroll
+    for (int s = 0; s < LK_S_MAX; ++s) { const float t = zv[s] - depth; var += wv[s] * t * t; }
+    a.depth[r] = (a.gt_depth[r] > 0.0f) ? depth : 0.0f;        // Renderer.py:197-198
+    a.var[r] = var;
+    a.color[3 * r] = c0 / ws; a.color[3 * r + 1] = c1 / ws; a.color[3 * r + 2] = c2 / ws;
+    a.valid_ray[r] = (nhas >= a.S / 2 + 1) ? 1 : 0;            // decoder.py:259-260
+}
+
+int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_depth_stats, dim3(lk_cdiv(R, chunk)), dim3(256), 0, st, gt, R, chunk, far_out);
+    return LK_OK;
+}
+int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_sample_interp, dim3(lk_cdiv(a.P, 256)), dim3(256), 0, st, a);
+    return LK_OK;
+}
+int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_composite, dim3(lk_cdiv(a.R, 256)), dim3(256), 0, st, a);
+    return LK_OK;
+}

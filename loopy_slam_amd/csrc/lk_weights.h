@@ -1,0 +1,63 @@
+// Packed decoder-weight blob layout (see include/loopy_hip.h, lk_weight_layout).
+// Offsets are compile-time constants shared by the kernels and the host table.
+// Reference shapes: SURVEY.md Appendix C / src/conv_onet/models/decoder.py:125-170,364-420.
+#pragma once
+#include <stdint.h>
+
+namespace lkw {
+
+constexpr int a64(int x) { return (x + 63) / 64 * 64; }
+
+constexpr int CF = 32;     // feature channels (c_dim)
+constexpr int HG = 32;     // geometry hidden width
+constexpr int EG = 93;     // geometry Fourier features (sin only)
+constexpr int EGP = 96;    // padded
+constexpr int HC = 128;    // colour hidden width
+constexpr int EC = 40;     // colour Fourier features ([sin 20, cos 20])
+constexpr int ER = 20;     // rel-pos Fourier features ([sin 10, cos 10])
+constexpr int KR = 52;     // rel-pos MLP input (20 + 32)
+constexpr int KRP = 56;    // padded
+
+// ---- geometry decoder
+constexpr int G_EB = 0;                              // [3][96]   embedder._B (cols 93..95 = 0)
+constexpr int G_W0 = G_EB + a64(3 * EGP);            // [32][96]
+constexpr int G_B0 = G_W0 + a64(HG * EGP);
+constexpr int G_W1 = G_B0 + a64(HG);                 // [32][32]
+constexpr int G_B1 = G_W1 + a64(HG * HG);
+constexpr int G_W2 = G_B1 + a64(HG);
+constexpr int G_B2 = G_W2 + a64(HG * HG);
+constexpr int G_W3 = G_B2 + a64(HG);                 // [32][128] = [e(93) 0 0 0 | h(32)]
+constexpr int G_B3 = G_W3 + a64(HG * (EGP + HG));
+constexpr int G_W4 = G_B3 + a64(HG);
+constexpr int G_B4 = G_W4 + a64(HG * HG);
+constexpr int G_U0 = G_B4 + a64(HG);                 // fc_c.i [32][32], bias [32], i = 0..4, stride G_USTRIDE
+constexpr int G_USTRIDE = a64(HG * CF) + a64(HG);
+constexpr int G_WO = G_U0 + 5 * G_USTRIDE;           // [32]
+constexpr int G_BO = G_WO + a64(HG);                 // [1]
+constexpr int G_END = G_BO + 64;
+
+// ---- colour decoder
+constexpr int C_EB = G_END;                          // [3][20]   embedder._B (fixed, not a Parameter)
+constexpr int C_W0 = C_EB + a64(3 * 20);             // [128][40]
+constexpr int C_B0 = C_W0 + a64(HC * EC);
+constexpr int C_W1 = C_B0 + a64(HC);                 // [128][128]
+constexpr int C_B1 = C_W1 + a64(HC * HC);
+constexpr int C_W2 = C_B1 + a64(HC);
+constexpr int C_B2 = C_W2 + a64(HC * HC);
+constexpr int C_W3 = C_B2 + a64(HC);                 // [128][168] = [e(40) | h(128)]
+constexpr int C_B3 = C_W3 + a64(HC * (EC + HC));
+constexpr int C_W4 = C_B3 + a64(HC);
+constexpr int C_B4 = C_W4 + a64(HC * HC);
+constexpr int C_U0 = C_B4 + a64(HC);                 // fc_c.i [128][32], bias [128], stride C_USTRIDE
+constexpr int C_USTRIDE = a64(HC * CF) + a64(HC);
+constexpr int C_WO = C_U0 + 5 * C_USTRIDE;           // [3][128]
+constexpr int C_BO = C_WO + a64(3 * HC);             // [3]
+// ---- colour decoder: relative-position neighbour MLP
+constexpr int R_EB = C_BO + 64;                      // [3][10]  embedder_rel_pos._B
+constexpr int R_W1 = R_EB + a64(3 * 10);             // [128][56] (cols 52..55 = 0)
+constexpr int R_B1 = R_W1 + a64(HC * KRP);
+constexpr int R_W2 = R_B1 + a64(HC);                 // [32][128]
+constexpr int R_B2 = R_W2 + a64(32 * HC);
+constexpr int BLOB_FLOATS = R_B2 + 64;
+
+}  // namespace lkw

@@ -1,0 +1,187 @@
+// TEST-ONLY host emulation of the slice of HIP that loopy_slam_amd/csrc uses.
+//
+// Purpose: this container has no GPU and GPU minutes are scarce, so the kernel
+// *logic* (indexing, MFMA fragment bookkeeping, barriers, atomics) is exercised on
+// the CPU by compiling the unmodified .hip sources against this header
+// (`-I tests/hipemu`, which shadows <hip/hip_runtime.h>) into
+// tests/hipemu/_build/libloopyhip_emu.so.  Only tests load that library.  The
+// product package loads libloopyhip.so (gfx950 code object) and nothing else; there
+// is no CPU fallback in the product path.
+//
+// Model: blocks run one after another on the calling OS thread; the threads of a
+// block are fibers (hand-rolled x86-64 context switch) scheduled round-robin and
+// switched only at __syncthreads() and at wave collectives (shuffles, ballots,
+// MFMA).  A wave is 64 consecutive threads.  MFMA follows the gfx950 lane layout
+// documented in /opt/skills/guides/cdna_hip_programming.md §3:
+//   32x32x2 f32:  A: lane l holds A[i=l&31][k=l>>5];  B: lane l holds B[k=l>>5][j=l&31];
+//                 C/D: lane l, reg r holds D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31];
+//                 D = fma(a_k1, b_k1, fma(a_k0, b_k0, C))  (k-ordered fp32 fma chain).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <tuple>
+
+#define HIPEMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+struct uint3 { unsigned x, y, z; };
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+namespace hipemu {
+struct Lane;
+struct LaneView { uint3 tid; uint3 bid; dim3 bdim; dim3 gdim; };
+extern LaneView* cur_view;
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void syncthreads();
+// wave collectives (all ALIVE lanes of the wave must call them convergently)
+uint32_t wave_exchange_u32(uint32_t v, int src_lane);          // returns v of src_lane (garbage if exited)
+uint64_t wave_ballot(bool p);
+void wave_mfma32x32x2(float a, float b, const float* c, float* d);
+void wave_mfma16x16x4(float a, float b, const float* c, float* d);
+int lane_id();
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur_view->tid)
+#define blockIdx (hipemu::cur_view->bid)
+#define blockDim (hipemu::cur_view->bdim)
+#define gridDim (hipemu::cur_view->gdim)
+#define warpSize 64
+
+namespace hipemu {
+template <typename K, typename... A>
+static inline void launch_k(dim3 grid, dim3 block, K kernel, A... args) {
+    // arguments are evaluated at the launch site and passed by value, as on the device
+    std::function<void()> body = [=]() { kernel(args...); };
+    launch(grid, block, body);
+}
+}  // namespace hipemu
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch_k(dim3(grid), dim3(block), kernel, __VA_ARGS__)
+
+static inline void __syncthreads() { hipemu::syncthreads(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+// ---- wave intrinsics
+static inline int __lane_id() { return hipemu::lane_id(); }
+template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+    static_assert(sizeof(T) == 4, "emu shuffles are 32-bit");
+    uint32_t u; std::memcpy(&u, &v, 4);
+    int lane = hipemu::lane_id();
+    int s = (lane & ~(width - 1)) | (src & (width - 1));
+    u = hipemu::wave_exchange_u32(u, s);
+    T r; std::memcpy(&r, &u, 4); return r;
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    return __shfl(v, (hipemu::lane_id() ^ mask) & (width - 1), width);
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int lane = hipemu::lane_id(); int l = lane & (width - 1);
+    return __shfl(v, (l + (int)d < width) ? l + (int)d : l, width);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int lane = hipemu::lane_id(); int l = lane & (width - 1);
+    return __shfl(v, (l - (int)d >= 0) ? l - (int)d : l, width);
+}
+static inline unsigned long long __ballot(int p) { return hipemu::wave_ballot(p != 0); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
+static inline int __any(int p) { return __ballot(p) != 0ull; }
+
+// ---- MFMA
+typedef float f32x16_emu __attribute__((ext_vector_type(16)));
+typedef float f32x4_emu __attribute__((ext_vector_type(4)));
+static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_emu c, int, int, int) {
+    float ci[16], di[16];
+    for (int r = 0; r < 16; ++r) ci[r] = c[r];
+    hipemu::wave_mfma32x32x2(a, b, ci, di);
+    f32x16_emu d;
+    for (int r = 0; r < 16; ++r) d[r] = di[r];
+    return d;
+}
+static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_emu c, int, int, int) {
+    float ci[4], di[4];
+    for (int r = 0; r < 4; ++r) ci[r] = c[r];
+    hipemu::wave_mfma16x16x4(a, b, ci, di);
+    f32x4_emu d;
+    for (int r = 0; r < 4; ++r) d[r] = di[r];
+    return d;
+}
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+
+// ---- math (round-to-nearest, never contracted)
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fmaf_rn(float a, float b, float c) { return std::fmaf(a, b, c); }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline float __uint_as_float(unsigned i) { float f; std::memcpy(&f, &i, 4); return f; }
+// floorf/sqrtf/fabsf/fminf/fmaxf/expf/logf/log1pf/expm1f/sinf/cosf/fmaf come from <cmath> (global namespace)
+template <typename T> static inline T min(T a, T b) { return a < b ? a : b; }
+template <typename T> static inline T max(T a, T b) { return a > b ? a : b; }
+
+// ---- atomics (single OS thread => plain read-modify-write)
+template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+static inline float unsafeAtomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+
+// ---- host API
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : 2; }
+template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }

@@ -1,0 +1,182 @@
+"""Parity of the HIP forward path against the CPU oracle and the golden vectors.
+
+Each test runs on two back-ends:
+  emu  (CPU, `-m "not gpu"`): the unmodified .hip sources compiled for the host against
+       tests/hipemu — checks the kernels' logic without a GPU;
+  hip  (`-m gpu`): the real gfx950 library through the C ABI.
+Tolerances: kNN indices / distances / counts bit-exact; rendered depth, colour, variance within
+1e-4 relative (fp32), as BASELINE.json's north_star states.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hotpath as H
+from loopy_slam_amd import core
+from util import load, tens, weights, CFG, CFG_NAMES, make_engine, backends
+
+torch.set_num_threads(1)
+
+
+def rcfg(name):
+    c = CFG[name]
+    return core.RenderCfg(S=5, near_surface=c['near_surface'], far_surface=c['far_surface'], near_end=0.3,
+                          coef=0.1, min_nn=2, radius_query=0.08, rel_pos=c['rel_pos'], exposure=c['exposure'])
+
+
+def ocfg(name):
+    c = CFG[name]
+    return H.RenderCfg(S=5, near_surface=c['near_surface'], far_surface=c['far_surface'], near_end=0.3, coef=0.1,
+                       k=8, min_nn=2, radius_query=0.08, rel_pos=c['rel_pos'], exposure=c['exposure'])
+
+
+# ------------------------------------------------------------------ kNN: bit-exact
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('name', CFG_NAMES)
+def test_knn_matches_oracle_bit_exact(backend, name):
+    eng = make_engine(backend)
+    g = load(f'g4_interp_{name}')
+    p, pos = tens(g, 'p', 'pos')
+    if CFG[name]['dynamic']:
+        r2 = (torch.from_numpy(g['r_pts']).reshape(-1) ** 2).float()
+        r2_o = r2.numpy()
+        r2_k = eng.f32(r2)
+    else:
+        r2_o = np.float32(0.08 ** 2)
+        r2_k = float(r2_o)
+    od, oi, oc = H.knn_exact(pos.numpy(), p.numpy(), 8, r2_o)
+    knn = core.KnnIndex(eng, capacity=pos.shape[0] + 16)
+    knn.build(eng.f32(pos))
+    d2, idx, cnt = knn.query(eng.f32(p), r2_k)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(d2.cpu().numpy(), od)
+    assert np.array_equal(cnt.cpu().numpy(), oc)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_knn_edge_cases(backend):
+    """empty cloud, single point, duplicate points (index tie-break), queries far outside the grid,
+    more than 8 points inside the radius, rebuild with more points (append)."""
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(5)
+    knn = core.KnnIndex(eng, capacity=5000, cell_size=0.08)
+    q = torch.rand(300, 3, generator=gen) * 2 - 1
+    # empty
+    knn.build(eng.zeros(0, 3))
+    d2, idx, cnt = knn.query(eng.f32(q), 0.01)
+    assert (idx.cpu() == -1).all() and (cnt.cpu() == 0).all()
+    # duplicates + cluster + outliers
+    base = torch.rand(40, 3, generator=gen) * 2 - 1
+    pts = torch.cat([base, base[:10], base[:10] + 1e-4, torch.tensor([[50.0, -30.0, 7.0]]),
+                     base[:1] + 0.002 * torch.randn(30, 3, generator=gen)])
+    qq = torch.cat([q, base, torch.tensor([[1e3, 1e3, 1e3], [-40.0, 2.0, 3.0], [50.0, -30.0, 7.01]])])
+    for r2 in (0.0064, 0.0256, 1.0):
+        od, oi, oc = H.knn_exact(pts.numpy(), qq.numpy(), 8, np.float32(r2))
+        knn.build(eng.f32(pts))
+        d2, idx, cnt = knn.query(eng.f32(qq), float(np.float32(r2)))
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.array_equal(d2.cpu().numpy(), od)
+        assert np.array_equal(cnt.cpu().numpy(), oc)
+    # append = rebuild with the longer array
+    more = torch.cat([pts, torch.rand(700, 3, generator=gen) * 2 - 1])
+    knn.build(eng.f32(more))
+    assert knn.n == more.shape[0]
+    od, oi, oc = H.knn_exact(more.numpy(), qq.numpy(), 8, np.float32(0.0256))
+    d2, idx, cnt = knn.query(eng.f32(qq), float(np.float32(0.0256)))
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(cnt.cpu().numpy(), oc)
+
+
+# ------------------------------------------------------------------ weights blob round trip
+@pytest.mark.parametrize('backend', backends())
+def test_weight_blob_roundtrip(backend):
+    eng = make_engine(backend)
+    W = weights('replica')
+    blob = core.DecoderBlob(eng).pack(W)
+    back = blob.unpack()
+    n = 0
+    for k, v in back.items():
+        assert torch.equal(v.reshape(W[k].shape), W[k]), k
+        n += 1
+    assert n >= 50
+    # padding stays zero
+    assert float(blob.blob.abs().sum().cpu()) == pytest.approx(sum(float(W[k].abs().sum()) for k in back), rel=1e-5)
+
+
+# ------------------------------------------------------------------ end-to-end forward vs golden + oracle
+def run_forward(eng, name, g, stage, tracker=False, affine=None, color_logits=False, stats_chunk=None):
+    cfg = rcfg(name)
+    W = weights(name)
+    blob = core.DecoderBlob(eng).pack(W)
+    ro, rd, gd, pos, geo, col = [eng.f32(x) for x in tens(g, 'rays_o', 'rays_d', 'gt_depth', 'pos', 'geo', 'col')]
+    knn = core.KnnIndex(eng, capacity=pos.shape[0])
+    knn.build(pos)
+    st = core.RenderState(eng, ro.shape[0], cfg.S)
+    r2 = eng.f32((torch.from_numpy(g['r_query']) ** 2).float()) if CFG[name]['dynamic'] else None
+    ng = eng.f32(g['noise_geo'])
+    nc = eng.f32(g['noise_col']) if 'noise_col' in g else None
+    aff = eng.f32(affine) if affine is not None else None
+    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob.blob, stage, tracker=tracker, r2_ray=r2,
+                        noise_geo=ng, noise_col=nc, affine=aff, color_logits=color_logits, stats_chunk=stats_chunk)
+    return st
+
+
+def check_outputs(st, g, has_color=True):
+    assert np.array_equal(st.valid_ray.cpu().numpy().astype(bool), g['valid_ray'])
+    np.testing.assert_allclose(st.depth.cpu().numpy(), g['depth'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st.var.cpu().numpy(), g['var'], rtol=1e-3, atol=1e-8)
+    if has_color:
+        np.testing.assert_allclose(st.color.cpu().numpy(), g['color'], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('stage', ('geometry', 'color'))
+@pytest.mark.parametrize('name', CFG_NAMES)
+def test_forward_mapper_golden(backend, name, stage):
+    eng = make_engine(backend)
+    g = load(f'g6_render_{name}_map_{stage}')
+    st = run_forward(eng, name, g, stage, color_logits=CFG[name]['exposure'])
+    check_outputs(st, g)
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('name', CFG_NAMES)
+def test_forward_tracker_golden(backend, name):
+    eng = make_engine(backend)
+    g = load(f'g6_render_{name}_track')
+    aff = None
+    if CFG[name]['exposure']:
+        aff = H.exposure_affine(weights(name), torch.from_numpy(g['exposure_feat']))
+    st = run_forward(eng, name, g, 'color', tracker=True, affine=aff)
+    check_outputs(st, g)
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('name', CFG_NAMES)
+def test_forward_img_zero_depth_golden(backend, name):
+    eng = make_engine(backend)
+    g = load(f'g6_render_{name}_img')
+    aff = None
+    if CFG[name]['exposure']:
+        aff = H.exposure_affine(weights(name), torch.from_numpy(g['exposure_feat']))
+    st = run_forward(eng, name, g, 'color', affine=aff)
+    check_outputs(st, g)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_forward_intermediates_vs_oracle(backend):
+    """z, neighbour lists, weights, interpolated features and raw decoder outputs against the oracle."""
+    eng = make_engine(backend)
+    name = 'replica'
+    g = load(f'g6_render_{name}_map_color')
+    st = run_forward(eng, name, g, 'color')
+    W = weights(name)
+    ro, rd, gd, pos, geo, col = tens(g, 'rays_o', 'rays_d', 'gt_depth', 'pos', 'geo', 'col')
+    with torch.no_grad():
+        o = H.render_batch(ocfg(name), ro, rd, gd, pos, geo, col, W, 'color',
+                           noise_geo=torch.from_numpy(g['noise_geo']), noise_col=torch.from_numpy(g['noise_col']))
+    assert np.array_equal(st.z.cpu().numpy(), o['z'].numpy())                       # bit-exact sample depths
+    assert np.array_equal(st.nbr_idx.cpu().numpy(), o['idx'].numpy())               # bit-exact neighbours
+    assert np.array_equal(st.nbr_count.cpu().numpy(), o['count'].numpy())
+    raw = st.raw.cpu().numpy()
+    np.testing.assert_allclose(raw[:, 3], o['occ'].numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(raw[:, :3], o['rgb'].numpy(), rtol=1e-4, atol=2e-5)

@@ -33,3 +33,28 @@ def relerr(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ---------------------------------------------------------------------------- kernel back-ends
+_EMU = {}
+
+
+def make_engine(backend):
+    """backend 'hip': the product library on cuda:0 (GPU tests).
+    backend 'emu': TEST-ONLY host build of the same .hip sources against tests/hipemu (CPU tests of
+    the kernels' logic); the product package itself never loads it."""
+    import sys
+    import torch
+    from loopy_slam_amd import _ffi, core
+    if backend == 'hip':
+        return core.Engine()
+    if 'lib' not in _EMU:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipemu'))
+        import build_emu
+        _EMU['lib'] = _ffi.LoopyLib(build_emu.build())
+    return core.Engine(lib=_EMU['lib'], device='cpu')
+
+
+def backends():
+    import pytest
+    return [pytest.param('emu', id='emu'), pytest.param('hip', marks=pytest.mark.gpu, id='hip')]
