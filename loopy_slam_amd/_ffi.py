@@ -69,6 +69,9 @@ class LoopyLib:
             raise LoopyError(f'{path} not found: build it with `python loopy_slam_amd/csrc/build.py` '
                              f'(or __graft_entry__.build()); there is no CPU fallback')
         self.path = path
+        # torch must initialise ITS HIP runtime first: loading libloopyhip.so before torch would pull
+        # in /opt/rocm's libamdhip64 as a second runtime instance in the process (no device visible to it).
+        import torch  # noqa: F401
         self.dll = C.CDLL(path)
         d = self.dll
         d.lk_version.restype = C.c_int

@@ -18,7 +18,7 @@ OUT = os.path.join(PKG, 'libloopyhip.so')
 OBJ = os.path.join(HERE, '_obj')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-ffp-contract=fast']
+         '-ffp-contract=off']
 
 
 def _newer(src_list, target):
@@ -32,6 +32,10 @@ def build(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(HERE, '*.hip')))
     hdrs = sorted(glob.glob(os.path.join(HERE, '*.h'))) + [os.path.join(PKG, '..', 'include', 'loopy_hip.h')]
     os.makedirs(OBJ, exist_ok=True)
+    stamp = os.path.join(OBJ, 'flags.txt')
+    cur = ' '.join([HIPCC] + FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != cur:
+        force = True
     jobs = []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + '.o')
@@ -54,6 +58,7 @@ def build(force=False, verbose=False):
             failed |= rc != 0
     if failed:
         raise RuntimeError('hipcc failed')
+    open(stamp, 'w').write(cur)
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + '.o') for s in srcs]
     if force or jobs or _newer(objs, OUT):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs

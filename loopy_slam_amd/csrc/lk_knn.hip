@@ -167,26 +167,32 @@ __global__ __launch_bounds__(256) void k_scatter(const float* __restrict__ pos, 
     sorted[dst] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], __int_as_float(i));
 }
 
+template <int T>
 __global__ __launch_bounds__(256) void k_knn_query(const LkGrid* __restrict__ g, const float4* __restrict__ sorted,
                                                    const int32_t* __restrict__ cell_start,
                                                    const float* __restrict__ q, int P, float r2_scalar,
                                                    const float* __restrict__ r2_per_query,
                                                    float* __restrict__ out_d2, int32_t* __restrict__ out_idx,
                                                    int32_t* __restrict__ out_count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const int qi_raw = blockIdx.x * (256 / T) + (int)threadIdx.x / T;
+    const int sub = (int)threadIdx.x % T;
+    const bool live = qi_raw < P;
+    const int i = live ? qi_raw : P - 1;             // dead groups shadow the last query (shuffles stay convergent)
     const float r2 = r2_per_query ? r2_per_query[i] : r2_scalar;
     float d[LK_K];
     int id[LK_K];
-    lk_knn_scan(g, sorted, cell_start, q[3 * i], q[3 * i + 1], q[3 * i + 2], r2, d, id);
+    lk_knn_scan_coop<T>(g, sorted, cell_start, q[3 * i], q[3 * i + 1], q[3 * i + 2], r2, sub, d, id);
+    if (!live) return;
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < LK_K; ++j) {
-        out_d2[(size_t)i * LK_K + j] = d[j];
-        out_idx[(size_t)i * LK_K + j] = id[j];
         cnt += (id[j] >= 0 && d[j] < r2) ? 1 : 0;
+        if (sub == (j % T)) {
+            out_d2[(size_t)i * LK_K + j] = d[j];
+            out_idx[(size_t)i * LK_K + j] = id[j];
+        }
     }
-    out_count[i] = cnt;
+    if (sub == 0) out_count[i] = cnt;
 }
 
 // ------------------------------------------------------------------ host API
@@ -266,8 +272,12 @@ extern "C" int lk_knn_query(lk_knn_t h, const float* q, int64_t P, float r2_scal
     LK_REQUIRE(P >= 0 && P < (1ll << 31), "lk_knn_query: P out of range");
     if (P == 0) return LK_OK;
     LK_REQUIRE(q && out_d2 && out_idx && out_count, "lk_knn_query: NULL buffer");
-    hipLaunchKernelGGL(k_knn_query, dim3(lk_cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream_, h->grid, h->sorted,
-                       h->cell_start, q, (int)P, r2_scalar, r2_per_query, out_d2, out_idx, out_count);
+    if (P < (1 << 16))      // small batches: more lanes per query to shorten each lane's serial chain
+        hipLaunchKernelGGL((k_knn_query<16>), dim3(lk_cdiv(P, 16)), dim3(256), 0, (hipStream_t)stream_, h->grid, h->sorted,
+                           h->cell_start, q, (int)P, r2_scalar, r2_per_query, out_d2, out_idx, out_count);
+    else
+        hipLaunchKernelGGL((k_knn_query<8>), dim3(lk_cdiv(P, 32)), dim3(256), 0, (hipStream_t)stream_, h->grid, h->sorted,
+                           h->cell_start, q, (int)P, r2_scalar, r2_per_query, out_d2, out_idx, out_count);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

@@ -37,88 +37,77 @@ __global__ __launch_bounds__(256) void k_depth_stats(const float* __restrict__ g
     }
 }
 
-// One thread per sample point: z, p, exact top-8 within radius, normalised weights; then the wave
-// gathers the 8 feature rows of each of its 64 samples cooperatively (8 lanes x 16 B = one 128-B
-// row per load) and writes the interpolated features.
+// Eight lanes per sample point (32 points per 256-thread block): z and p (every lane, redundantly),
+// cooperative exact top-8 within the radius, normalised weights, then lane `sub` gathers its float4
+// of each of the 8 neighbour rows (8 lanes x 16 B = one 128-B feature row per load instruction).
 __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
-    const int pidx = blockIdx.x * 256 + (int)threadIdx.x;
-    const bool live = pidx < a.P;
-    const int lane = lk_lane();
+    const int sub = (int)threadIdx.x & 7;
+    const int p_raw = blockIdx.x * 32 + ((int)threadIdx.x >> 3);
+    const bool live = p_raw < a.P;
+    const int pidx = live ? p_raw : a.P - 1;           // dead groups shadow the last point, never store
+    const int r = pidx / a.S, s = pidx - r * a.S;
+    const float gt = a.gt_depth[r];
+    float z;
+    if (gt > 0.0f) {
+        const float t = lk_linspace(0.0f, 1.0f, a.S, s);
+        z = __fadd_rn(__fmul_rn(__fmul_rn(a.near_surface, gt), __fsub_rn(1.0f, t)),
+                      __fmul_rn(__fmul_rn(a.far_surface, gt), t));
+    } else {
+        const float far = a.far_stats ? a.far_stats[r / a.stats_chunk] : 0.0f;
+        z = lk_linspace(a.near_end, far, a.S, s);
+    }
+    const float qx = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
+    const float qy = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
+    const float qz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
+    const float r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
     float d[LK_K], w[LK_K];
     int id[LK_K];
+    lk_knn_scan_coop<8>(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, sub, d, id);
+    // w = 1/(D+1e-10), zero outside the radius, L1-normalised (decoder.py:210-220)
+    float wsum = 0.0f;
     int count = 0;
 #pragma unroll
-    for (int j = 0; j < LK_K; ++j) { d[j] = LK_FLT_MAX; id[j] = -1; w[j] = 0.0f; }
-    if (live) {
-        const int r = pidx / a.S, s = pidx - r * a.S;
-        const float gt = a.gt_depth[r];
-        float z;
-        if (gt > 0.0f) {
-            const float t = lk_linspace(0.0f, 1.0f, a.S, s);
-            z = __fadd_rn(__fmul_rn(__fmul_rn(a.near_surface, gt), __fsub_rn(1.0f, t)),
-                          __fmul_rn(__fmul_rn(a.far_surface, gt), t));
-        } else {
-            const float far = a.far_stats ? a.far_stats[r / a.stats_chunk] : 0.0f;
-            z = lk_linspace(a.near_end, far, a.S, s);
-        }
-        a.z[pidx] = z;
-        const float qx = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
-        const float qy = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
-        const float qz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
-        const float r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
-        lk_knn_scan(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, d, id);
-        // w = 1/(D+1e-10), zero outside the radius, L1-normalised (decoder.py:210-220)
-        float wsum = 0.0f;
-#pragma unroll
-        for (int j = 0; j < LK_K; ++j) {
-            const bool in = id[j] >= 0 && d[j] <= r2;
-            w[j] = in ? 1.0f / (d[j] + 1e-10f) : 0.0f;
-            wsum += w[j];
-            count += (id[j] >= 0 && d[j] < r2) ? 1 : 0;
-        }
-        const float inv = 1.0f / fmaxf(wsum, 1e-12f);
-#pragma unroll
-        for (int j = 0; j < LK_K; ++j) w[j] = w[j] * inv;
-        int4* oi = reinterpret_cast<int4*>(a.nbr_idx + (size_t)pidx * LK_K);
-        oi[0] = make_int4(id[0], id[1], id[2], id[3]);
-        oi[1] = make_int4(id[4], id[5], id[6], id[7]);
-        float4* ow = reinterpret_cast<float4*>(a.nbr_w + (size_t)pidx * LK_K);
-        ow[0] = make_float4(w[0], w[1], w[2], w[3]);
-        ow[1] = make_float4(w[4], w[5], w[6], w[7]);
-        a.nbr_count[pidx] = count;
+    for (int j = 0; j < LK_K; ++j) {
+        const bool in = id[j] >= 0 && d[j] <= r2;
+        w[j] = in ? 1.0f / (d[j] + 1e-10f) : 0.0f;
+        wsum += w[j];
+        count += (id[j] >= 0 && d[j] < r2) ? 1 : 0;
     }
-    // ---- cooperative gather: round t serves samples t*8 .. t*8+7 of this wave
-    const int sub = lane & 7;                         // which float4 of the 32-channel row
-    const int wave_base = blockIdx.x * 256 + ((int)threadIdx.x & ~63);
+    const float inv = 1.0f / fmaxf(wsum, 1e-12f);
+#pragma unroll
+    for (int j = 0; j < LK_K; ++j) w[j] = w[j] * inv;
+    if (!live) return;
+    // lane `sub` publishes neighbour slot `sub`
+    {
+        float wj = w[0];
+        int ij = id[0];
+#pragma unroll
+        for (int j = 1; j < LK_K; ++j) { wj = (sub == j) ? w[j] : wj; ij = (sub == j) ? id[j] : ij; }
+        a.nbr_idx[(size_t)pidx * LK_K + sub] = ij;
+        a.nbr_w[(size_t)pidx * LK_K + sub] = wj;
+        if (sub == 0) { a.nbr_count[pidx] = count; a.z[pidx] = z; }
+    }
     const bool do_col = (a.flags & LK_FLAG_STAGE_COLOR) && !(a.flags & LK_FLAG_REL_POS);
-#pragma unroll 1
-    for (int t = 0; t < 8; ++t) {
-        const int src = t * 8 + (lane >> 3);
-        float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ac = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ac = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (count >= a.min_nn) {
 #pragma unroll
         for (int j = 0; j < LK_K; ++j) {
-            const int ij = __shfl(id[j], src);
-            const float wj = __shfl(w[j], src);
-            if (wj != 0.0f) {
-                const float4 g = *reinterpret_cast<const float4*>(a.geo_feats + (size_t)ij * LK_C + sub * 4);
+            if (w[j] != 0.0f) {
+                const float wj = w[j];
+                const float4 g = *reinterpret_cast<const float4*>(a.geo_feats + (size_t)id[j] * LK_C + sub * 4);
                 ag.x = fmaf(wj, g.x, ag.x); ag.y = fmaf(wj, g.y, ag.y); ag.z = fmaf(wj, g.z, ag.z); ag.w = fmaf(wj, g.w, ag.w);
                 if (do_col) {
-                    const float4 c = *reinterpret_cast<const float4*>(a.col_feats + (size_t)ij * LK_C + sub * 4);
+                    const float4 c = *reinterpret_cast<const float4*>(a.col_feats + (size_t)id[j] * LK_C + sub * 4);
                     ac.x = fmaf(wj, c.x, ac.x); ac.y = fmaf(wj, c.y, ac.y); ac.z = fmaf(wj, c.z, ac.z); ac.w = fmaf(wj, c.w, ac.w);
                 }
             }
         }
-        const int cnt = __shfl(count, src);
-        const int sp = wave_base + src;
-        if (sp < a.P) {
-            if (cnt < a.min_nn) {      // no usable neighbourhood: the shared noise vector (decoder.py:228-229)
-                ag = a.noise_geo ? *reinterpret_cast<const float4*>(a.noise_geo + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                ac = a.noise_col ? *reinterpret_cast<const float4*>(a.noise_col + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            *reinterpret_cast<float4*>(a.c_geo + (size_t)sp * LK_C + sub * 4) = ag;
-            if (do_col) *reinterpret_cast<float4*>(a.c_col + (size_t)sp * LK_C + sub * 4) = ac;
-        }
+    } else {            // no usable neighbourhood: the shared noise vector (decoder.py:228-229)
+        if (a.noise_geo) ag = *reinterpret_cast<const float4*>(a.noise_geo + sub * 4);
+        if (a.noise_col) ac = *reinterpret_cast<const float4*>(a.noise_col + sub * 4);
     }
+    *reinterpret_cast<float4*>(a.c_geo + (size_t)pidx * LK_C + sub * 4) = ag;
+    if (do_col) *reinterpret_cast<float4*>(a.c_col + (size_t)pidx * LK_C + sub * 4) = ac;
 }
 
 // One thread per ray: occupancy of unsupported samples := -100, alpha composite, validity.
@@ -161,7 +150,7 @@ int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hip
     return LK_OK;
 }
 int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_sample_interp, dim3(lk_cdiv(a.P, 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_sample_interp, dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st) {

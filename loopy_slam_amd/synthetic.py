@@ -1,0 +1,129 @@
+"""Synthetic RGB-D room for benchmarks and parity tests at full size.
+
+Scene: axis-aligned box room 6 x 4 x 3 m (walls get a sinusoidal relief), camera inside on a
+closed loop, intrinsics of the TUM config (fx 517.3, fy 516.5, cx 318.6, cy 255.3, 640x480).
+Depth = exact ray/box hit (metres, 2 % zero holes on request), RGB = procedural texture in [0,1].
+The neural point cloud is laid down the way NeuralPointCloud.add_neural_points does
+(src/neural_point.py:1557-1631): three points per chosen pixel at (0.98, 1.0, 1.02) * depth,
+features ~ N(0, 0.1).  Everything is plain torch on whatever device is asked for; no dataset,
+no network.
+"""
+import math
+
+import torch
+
+ROOM = (6.0, 4.0, 3.0)
+TUM_INTR = dict(H=480, W=640, fx=517.3, fy=516.5, cx=318.6, cy=255.3)
+
+
+def loop_pose(k, n=200, device='cpu'):
+    """c2w [4,4] of pose k of n on a closed loop inside the room (camera looks down -z)."""
+    a = 2 * math.pi * k / n
+    eye = torch.tensor([0.9 * math.cos(a), 0.6 * math.sin(a), 0.1 * math.sin(2 * a)])
+    yaw = a + math.pi / 2
+    fwd = torch.tensor([math.cos(yaw), math.sin(yaw), -0.1])
+    fwd = fwd / fwd.norm()
+    up = torch.tensor([0.0, 0.0, 1.0])
+    right = torch.linalg.cross(fwd, up)
+    right = right / right.norm()
+    up2 = torch.linalg.cross(right, fwd)
+    c2w = torch.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, up2, -fwd, eye
+    return c2w.to(device)
+
+
+def pixel_rays(c2w, i, j, intr=TUM_INTR):
+    """get_rays_from_uv convention (src/common.py:104-120): i = column, j = row, un-normalised d."""
+    dirs = torch.stack([(i - intr['cx']) / intr['fx'], -(j - intr['cy']) / intr['fy'], -torch.ones_like(i)], -1)
+    rays_d = (dirs[:, None, :] * c2w[:3, :3]).sum(-1)
+    rays_o = c2w[:3, 3].expand_as(rays_d)
+    return rays_o.contiguous(), rays_d.contiguous()
+
+
+def room_depth(rays_o, rays_d):
+    """Distance parameter t (in units of |d|, i.e. the reference's z-depth) to the box walls + relief."""
+    half = torch.tensor(ROOM, device=rays_o.device) / 2
+    inv = 1.0 / torch.where(rays_d.abs() < 1e-9, torch.full_like(rays_d, 1e-9), rays_d)
+    t1 = (half - rays_o) * inv
+    t2 = (-half - rays_o) * inv
+    t = torch.maximum(t1, t2).min(dim=-1).values
+    hit = rays_o + rays_d * t[:, None]
+    relief = 0.03 * torch.sin(3.0 * hit[:, 0]) * torch.sin(2.5 * hit[:, 1] + 1.0) * torch.cos(2.0 * hit[:, 2])
+    return (t * (1.0 + relief / t.clamp(min=0.5))).float()
+
+
+def room_color(points):
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    r = 0.5 + 0.5 * torch.sin(2.1 * x + 0.5) * torch.cos(1.7 * y)
+    g = 0.5 + 0.5 * torch.sin(1.3 * y + 2.0 * z)
+    b = 0.5 + 0.5 * torch.cos(2.9 * z + 0.7 * x)
+    return torch.stack([r, g, b], -1).clamp(0, 1).float()
+
+
+def render_frame(k, intr=TUM_INTR, holes=0.02, device='cpu', seed=1219, n_poses=200):
+    """Synthetic RGB-D frame k: (depth [H,W], color [H,W,3], c2w [4,4])."""
+    H, W = intr['H'], intr['W']
+    c2w = loop_pose(k, n_poses, device)
+    jj, ii = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W, device=device, dtype=torch.float32), indexing='ij')
+    ro, rd = pixel_rays(c2w, ii.reshape(-1), jj.reshape(-1), intr)
+    d = room_depth(ro, rd)
+    col = room_color(ro + rd * d[:, None])
+    if holes > 0:
+        g = torch.Generator(device='cpu').manual_seed(seed + k)
+        m = (torch.rand(H * W, generator=g) < holes).to(device)
+        d = torch.where(m, torch.zeros_like(d), d)
+    return d.reshape(H, W), col.reshape(H, W, 3), c2w
+
+
+def build_cloud(n_points, device='cpu', seed=1219, intr=TUM_INTR, n_views=24, c_dim=32):
+    """Point cloud of about n_points (multiple of 3): pixels of n_views loop poses, 3 points per
+    pixel along the ray at (0.98, 1.0, 1.02) * depth; geo/col features ~ N(0, 0.1)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    per_view = (n_points // 3 + n_views - 1) // n_views
+    pts = []
+    for v in range(n_views):
+        c2w = loop_pose(v * (200 // n_views), 200, 'cpu')
+        i = torch.rand(per_view, generator=g) * (intr['W'] - 1)
+        j = torch.rand(per_view, generator=g) * (intr['H'] - 1)
+        ro, rd = pixel_rays(c2w, i, j, intr)
+        d = room_depth(ro, rd)
+        for t in (0.98, 1.0, 1.02):
+            pts.append(ro + rd * (d * t)[:, None])
+    pos = torch.cat(pts, 0)[:n_points].float().contiguous()
+    geo = (0.1 * torch.randn(pos.shape[0], c_dim, generator=g)).float()
+    col = (0.1 * torch.randn(pos.shape[0], c_dim, generator=g)).float()
+    return pos.to(device), geo.to(device), col.to(device)
+
+
+def default_weights(seed=1219, rel_pos=True, exposure=False):
+    """Random-init decoder weights with the reference's shapes and init scheme
+    (xavier_uniform(relu gain) trunk, default nn.Linear fc_c, B ~ N(0, scale^2); decoder.py:84-93,145-170,386-420)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def xavier(out_f, in_f, gain):
+        a = gain * math.sqrt(6.0 / (in_f + out_f))
+        return (torch.rand(out_f, in_f, generator=g) * 2 - 1) * a
+
+    def linear(out_f, in_f):
+        a = 1.0 / math.sqrt(in_f)
+        return (torch.rand(out_f, in_f, generator=g) * 2 - 1) * a, (torch.rand(out_f, generator=g) * 2 - 1) * a
+
+    W = {}
+    for pre, Hd, E in (('geo_decoder', 32, 93), ('color_decoder', 128, 40)):
+        dims = [E, Hd, Hd, Hd + E, Hd]
+        for i in range(5):
+            W[f'{pre}.pts_linears.{i}.weight'] = xavier(Hd, dims[i], math.sqrt(2.0))
+            W[f'{pre}.pts_linears.{i}.bias'] = torch.zeros(Hd)
+            W[f'{pre}.fc_c.{i}.weight'], W[f'{pre}.fc_c.{i}.bias'] = linear(Hd, 32)
+        n_out = 1 if pre == 'geo_decoder' else 3
+        W[f'{pre}.output_linear.weight'] = xavier(n_out, Hd, math.sqrt(2.0) if n_out == 1 else 1.0)
+        W[f'{pre}.output_linear.bias'] = torch.zeros(n_out)
+    W['geo_decoder.embedder._B'] = torch.randn(3, 93, generator=g) * 25
+    W['color_decoder.embedder._B'] = torch.randn(3, 20, generator=g) * 32
+    W['color_decoder.embedder_rel_pos._B'] = torch.randn(3, 10, generator=g) * 32
+    W['color_decoder.mlp_col_neighbor.linear1.weight'] = xavier(128, 52, 1.0)
+    W['color_decoder.mlp_col_neighbor.linear1.bias'] = linear(128, 52)[1]
+    W['color_decoder.mlp_col_neighbor.linear2.weight'] = xavier(32, 128, 1.0)
+    W['color_decoder.mlp_col_neighbor.linear2.bias'] = linear(32, 128)[1]
+    return W
