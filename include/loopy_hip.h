@@ -76,6 +76,10 @@ typedef struct {
 } lk_weight_entry;
 int lk_weight_layout(lk_weight_entry* out, int max_entries); /* returns #entries */
 int64_t lk_weight_blob_floats(void);
+/* The GEMM operands are streamed from a derived "fragment" copy of the blob (MFMA operand order,
+ * forward + transposed); refresh it after every change of the master blob (optimiser step, load). */
+int64_t lk_weight_frag_floats(void);
+int lk_weights_repack(const float* blob, float* frag, void* stream);
 
 /* ---------------------------------------------------------------- render forward / backward */
 #define LK_FLAG_STAGE_COLOR   (1u << 0)  /* NICER stage 'color' (else 'geometry': rgb = 0)          */
@@ -103,7 +107,8 @@ typedef struct {
     const float* pos;           /* [N,3] cloud positions in original order (rel-pos MLP, tracker gradients) */
     const float* geo_feats;     /* [N,32] */
     const float* col_feats;     /* [N,32] */
-    const float* weights;       /* packed blob */
+    const float* weights;       /* packed blob (master, plain [out][in_padded] matrices) */
+    const float* weights_frag;  /* lk_weights_repack(weights) */
     const float* affine;        /* [12] exposure transform applied before the sigmoid, or NULL */
     const float* noise_geo;     /* [32] feature of samples without neighbours, or NULL (zeros) */
     const float* noise_col;     /* [32] */

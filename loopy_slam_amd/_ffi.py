@@ -39,7 +39,7 @@ class RenderDesc(C.Structure):
     _fields_ = [
         ('R', C.c_int32), ('S', C.c_int32), ('stats_chunk', C.c_int32), ('flags', C.c_uint32),
         ('rays_o', _fp), ('rays_d', _fp), ('gt_depth', _fp), ('r2_ray', _fp),
-        ('knn', _fp), ('pos', _fp), ('geo_feats', _fp), ('col_feats', _fp), ('weights', _fp),
+        ('knn', _fp), ('pos', _fp), ('geo_feats', _fp), ('col_feats', _fp), ('weights', _fp), ('weights_frag', _fp),
         ('affine', _fp), ('noise_geo', _fp), ('noise_col', _fp),
         ('near_surface', C.c_float), ('far_surface', C.c_float), ('near_end', C.c_float), ('coef', C.c_float),
         ('r2_static', C.c_float), ('min_nn', C.c_int32),
@@ -84,6 +84,8 @@ class LoopyLib:
         d.lk_knn_query.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_float, _fp, _fp, _fp, _fp, C.c_void_p]
         d.lk_weight_layout.argtypes = [C.POINTER(WeightEntry), C.c_int]
         d.lk_weight_blob_floats.restype = C.c_int64
+        d.lk_weight_frag_floats.restype = C.c_int64
+        d.lk_weights_repack.argtypes = [_fp, _fp, C.c_void_p]
         d.lk_render_act_floats.argtypes = [C.c_int32, C.c_int32, C.c_uint32]
         d.lk_render_act_floats.restype = C.c_int64
         d.lk_render_fwd.argtypes = [C.POINTER(RenderDesc), C.c_void_p]

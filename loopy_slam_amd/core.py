@@ -118,6 +118,7 @@ class DecoderBlob:
         self.layout = {e['name']: e for e in eng.lib.weight_layout()}
         self.n = eng.lib.blob_floats()
         self.blob = eng.zeros(self.n)
+        self.frag = eng.zeros(int(eng.lib.dll.lk_weight_frag_floats()))
 
     def _view(self, e, flat):
         if e['cols'] == 1 and e['ld'] == 1:
@@ -142,6 +143,12 @@ class DecoderBlob:
                 else:
                     v[:, :e['cols']] = t
         self.blob.copy_(host.to(self.eng.device))
+        return self.repack()
+
+    def repack(self):
+        """Refresh the fragment copy the kernels read (call after every change of `blob`)."""
+        self.eng.lib.check(self.eng.lib.dll.lk_weights_repack(ptr(self.blob), ptr(self.frag), self.eng.stream),
+                           'lk_weights_repack')
         return self
 
     def unpack(self, flat=None):
@@ -204,7 +211,7 @@ class RenderState:
         self.keep = None
 
 
-def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, blob, stage,
+def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, dec, stage,
               tracker=False, r2_ray=None, noise_geo=None, noise_col=None, affine=None,
               color_logits=False, save_act=False, stats_chunk=None, extra_flags=0):
     d = RenderDesc()
@@ -224,7 +231,8 @@ def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_f
     d.stats_chunk = int(stats_chunk) if stats_chunk else max(1, R)
     d.rays_o, d.rays_d, d.gt_depth, d.r2_ray = ptr(rays_o), ptr(rays_d), ptr(gt_depth), ptr(r2_ray)
     d.knn = knn.h
-    d.pos, d.geo_feats, d.col_feats, d.weights = ptr(pos), ptr(geo_feats), ptr(col_feats), ptr(blob)
+    d.pos, d.geo_feats, d.col_feats = ptr(pos), ptr(geo_feats), ptr(col_feats)
+    d.weights, d.weights_frag = ptr(dec.blob), ptr(dec.frag)
     d.affine, d.noise_geo, d.noise_col = ptr(affine), ptr(noise_geo), ptr(noise_col)
     d.near_surface, d.far_surface, d.near_end, d.coef = cfg.near_surface, cfg.far_surface, cfg.near_end, cfg.coef
     d.r2_static, d.min_nn = cfg.r2_static, cfg.min_nn
@@ -233,12 +241,12 @@ def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_f
     d.c_geo, d.c_col, d.raw, d.far_stats, d.act = ptr(st.c_geo), ptr(st.c_col), ptr(st.raw), ptr(st.far_stats), ptr(st.act)
     st.desc = d
     # keep every tensor referenced by raw pointers alive until the next call
-    st.keep = (rays_o, rays_d, gt_depth, r2_ray, pos, geo_feats, col_feats, blob, affine, noise_geo, noise_col)
+    st.keep = (rays_o, rays_d, gt_depth, r2_ray, pos, geo_feats, col_feats, dec, affine, noise_geo, noise_col)
     return d
 
 
-def render_forward(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, blob, stage, **kw):
+def render_forward(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, dec, stage, **kw):
     """Fill `st` (depth, var, color, valid_ray + saved state).  All tensors fp32 contiguous on eng.device."""
-    d = fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, blob, stage, **kw)
+    d = fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, dec, stage, **kw)
     eng.lib.check(eng.lib.dll.lk_render_fwd(C.byref(d), eng.stream), 'lk_render_fwd')
     return st

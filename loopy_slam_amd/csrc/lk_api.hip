@@ -99,7 +99,7 @@ static int check_desc(const lk_render_desc* d, const char* who) {
     if (d->R < 0 || d->S < 1 || d->S > LK_S_MAX) { lk_set_error("%s: bad R/S (%d, %d)", who, d->R, d->S); return LK_ERR_ARG; }
     if ((int64_t)d->R * d->S >= (1ll << 31)) { lk_set_error("%s: R*S too large", who); return LK_ERR_ARG; }
     if (!d->knn) { lk_set_error("%s: NULL knn handle", who); return LK_ERR_ARG; }
-    if (d->R > 0 && (!d->rays_o || !d->rays_d || !d->gt_depth || !d->geo_feats || !d->weights || !d->z || !d->nbr_idx ||
+    if (d->R > 0 && (!d->rays_o || !d->rays_d || !d->gt_depth || !d->geo_feats || !d->weights || !d->weights_frag || !d->z || !d->nbr_idx ||
                      !d->nbr_w || !d->nbr_count || !d->c_geo || !d->raw)) {
         lk_set_error("%s: NULL buffer in descriptor", who); return LK_ERR_ARG;
     }
@@ -143,13 +143,13 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
         ra.rays_o = d->rays_o; ra.rays_d = d->rays_d; ra.z = d->z; ra.sorted_unused = nullptr;
         ra.pos = d->pos; ra.col_feats = d->col_feats;
         ra.nbr_idx = d->nbr_idx; ra.nbr_w = d->nbr_w; ra.nbr_count = d->nbr_count;
-        ra.W = d->weights; ra.noise_col = d->noise_col; ra.c_col = d->c_col;
+        ra.W = d->weights; ra.Wfrag = d->weights_frag; ra.noise_col = d->noise_col; ra.c_col = d->c_col;
         lk_launch_relpos_fwd(ra, st);
     }
     LkDecodeArgs da;
     da.R = d->R; da.S = d->S; da.P = P; da.flags = d->flags;
     da.rays_o = d->rays_o; da.rays_d = d->rays_d; da.z = d->z;
-    da.c_geo = d->c_geo; da.c_col = d->c_col; da.W = d->weights; da.affine = d->affine;
+    da.c_geo = d->c_geo; da.c_col = d->c_col; da.W = d->weights; da.Wfrag = d->weights_frag; da.affine = d->affine;
     da.raw = d->raw; da.act = d->act;
     lk_launch_decode_fwd(da, st);
 

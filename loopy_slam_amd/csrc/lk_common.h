@@ -109,40 +109,27 @@ __device__ __forceinline__ f32x16 lk_zero16() {
 // The reduction index k is walked in the order the C/D layout stores rows: at step (g,t) the
 // low half-wave carries k = 8g+t and the high half k = 8g+4+t — exactly register 4g+t of the
 // CT tile of the previous layer, so a layer's output feeds the next layer's B operand straight
-// from registers (no LDS, no barrier).  W is [out][ld] row-major (torch layout), ld % 4 == 0;
-// a lane fetches its four t-consecutive weights with one 16-byte load.
+// from registers (no LDS, no barrier).
+//
+// The A operands come from the FRAGMENT blob (lk_weights.h): block (g, nb) is 64 lanes x 16 B =
+// one contiguous 1-KiB piece holding, for lane l, the four t-consecutive weights it needs, so a
+// wave-wide load touches 8 fully used 128-B lines (a row-major [out][in] matrix would touch 32
+// lines and use a quarter of each).  `frag` = first block of the matrix, NBT = blocks per k-group
+// (= out/32 for the forward form, = virtual_in/32 for the transposed form), g0 = first k-group,
+// nb0 = first output block.  The same routine serves dX^T = W^T dY^T on the transposed fragments.
 template <int NB, int NG>
-__device__ __forceinline__ void lk_gemm_kblock(f32x16 (&acc)[NB], const float* __restrict__ W, int ld,
-                                               int kcol0, const f32x16& x, int lane) {
-    const int i = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void lk_gemm_frag(f32x16 (&acc)[NB], const float* __restrict__ frag, int NBT,
+                                             int g0, int nb0, const f32x16& x, int lane) {
+    const float* __restrict__ base = frag + ((size_t)g0 * NBT + nb0) * 256 + lane * 4;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const float4 a = *reinterpret_cast<const float4*>(W + (size_t)(nb * 32 + i) * ld + kcol0 + 8 * g + 4 * h);
+            const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)g * NBT + nb) * 256);
             acc[nb] = lk_mfma(a.x, x[4 * g + 0], acc[nb]);
             acc[nb] = lk_mfma(a.y, x[4 * g + 1], acc[nb]);
             acc[nb] = lk_mfma(a.z, x[4 * g + 2], acc[nb]);
             acc[nb] = lk_mfma(a.w, x[4 * g + 3], acc[nb]);
-        }
-    }
-}
-
-// Transposed variant for the backward data pass: dX^T = W^T * dY^T,
-//   A operand = W[out = k][in = kb_out*32 + (lane&31)]  (k walks the rows of the dY CT tile).
-// out_col0 = first input column of the 32-wide output block; nrow0 = first row (out unit) of the dY tile.
-template <int NG>
-__device__ __forceinline__ void lk_gemm_kblock_T(f32x16& acc, const float* __restrict__ W, int ld,
-                                                 int out_col0, int nrow0, const f32x16& dy, int lane, int col_limit) {
-    const int i = lane & 31, h = lane >> 5;
-    const bool ok = (out_col0 + i) < col_limit;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = nrow0 + 8 * g + 4 * h + t;
-            const float a = ok ? W[(size_t)n * ld + out_col0 + i] : 0.0f;
-            acc = lk_mfma(a, dy[4 * g + t], acc);
         }
     }
 }

@@ -8,7 +8,7 @@
 // C/D layout ("CT tile": 32 units x 32 samples, lane = sample column) so that each layer
 // Y^T = W X^T uses v_mfma_f32_32x32x2_f32 with A = weights (16-byte loads straight from the
 // L2-resident blob) and B = the previous layer's accumulator registers.  No LDS, no barriers,
-// exact fp32 (fma-chain) arithmetic at the fp32 matrix rate.  See lk_common.h::lk_gemm_kblock.
+// exact fp32 (fma-chain) arithmetic at the fp32 matrix rate.  See lk_common.h::lk_gemm_frag.
 #include "lk_common.h"
 #include "lk_kernels.h"
 
@@ -77,7 +77,7 @@ __device__ __forceinline__ f32x16 sincos_embed_tile(const float* __restrict__ B,
 // bias + activation (+ optional save) + fc_c(c): h = act(acc + b) + (U c + u)
 template <int NB, bool SOFTPLUS>
 __device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB], const float* __restrict__ bias,
-                                             const float* __restrict__ U, const float* __restrict__ ubias,
+                                             const float* __restrict__ Ufrag, const float* __restrict__ ubias,
                                              const f32x16& c, float* __restrict__ save_a, bool live, int lane) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB], const float* __r
         if (save_a) ct_store_rows32(save_a + nb * 32, acc[nb], live, lane);
         lk_add_rowvec(acc[nb], ubias, nb * 32, lane);
     }
-    lk_gemm_kblock<NB, 4>(acc, U, CF, 0, c, lane);
+    lk_gemm_frag<NB, 4>(acc, Ufrag, NB, 0, 0, c, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
     const float pz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
     const float a0 = __fmul_rn(LK_TWO_PI, px), a1 = __fmul_rn(LK_TWO_PI, py), a2 = __fmul_rn(LK_TWO_PI, pz);
     const float* __restrict__ W = a.W;
+    const float* __restrict__ F = a.Wfrag;
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_geo = save ? a.act + (size_t)sp * LK_ACT_GEO_A : nullptr;
     float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A : nullptr;
@@ -122,35 +123,35 @@ __global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
         f32x16 acc[1], hh;
         // layer 0: 93 -> 32
         acc[0] = lk_zero16();
-        lk_gemm_kblock<1, 4>(acc, W + G_W0, EGP, 0, e0, lane);
-        lk_gemm_kblock<1, 4>(acc, W + G_W0, EGP, 32, e1, lane);
-        lk_gemm_kblock<1, 4>(acc, W + G_W0, EGP, 64, e2, lane);
-        layer_finish<1, false>(acc, W + G_B0, W + G_U0, W + G_U0 + a64(HG * CF), cg, act_geo, live, lane);
+        lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 0, 0, e0, lane);
+        lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 4, 0, e1, lane);
+        lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 8, 0, e2, lane);
+        layer_finish<1, false>(acc, W + G_B0, F + FM5_FWD, W + G_U0 + a64(HG * CF), cg, act_geo, live, lane);
         hh = acc[0];
         // layers 1, 2: 32 -> 32
         acc[0] = lk_zero16();
-        lk_gemm_kblock<1, 4>(acc, W + G_W1, HG, 0, hh, lane);
-        layer_finish<1, false>(acc, W + G_B1, W + G_U0 + G_USTRIDE, W + G_U0 + G_USTRIDE + a64(HG * CF), cg,
+        lk_gemm_frag<1, 4>(acc, F + FM1_FWD, 1, 0, 0, hh, lane);
+        layer_finish<1, false>(acc, W + G_B1, F + FM6_FWD, W + G_U0 + G_USTRIDE + a64(HG * CF), cg,
                                act_geo ? act_geo + 32 : nullptr, live, lane);
         hh = acc[0];
         acc[0] = lk_zero16();
-        lk_gemm_kblock<1, 4>(acc, W + G_W2, HG, 0, hh, lane);
-        layer_finish<1, false>(acc, W + G_B2, W + G_U0 + 2 * G_USTRIDE, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cg,
+        lk_gemm_frag<1, 4>(acc, F + FM2_FWD, 1, 0, 0, hh, lane);
+        layer_finish<1, false>(acc, W + G_B2, F + FM7_FWD, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cg,
                                act_geo ? act_geo + 64 : nullptr, live, lane);
         hh = acc[0];
         // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
         acc[0] = lk_zero16();
-        lk_gemm_kblock<1, 4>(acc, W + G_W3, EGP + HG, 0, e0, lane);
-        lk_gemm_kblock<1, 4>(acc, W + G_W3, EGP + HG, 32, e1, lane);
-        lk_gemm_kblock<1, 4>(acc, W + G_W3, EGP + HG, 64, e2, lane);
-        lk_gemm_kblock<1, 4>(acc, W + G_W3, EGP + HG, 96, hh, lane);
-        layer_finish<1, false>(acc, W + G_B3, W + G_U0 + 3 * G_USTRIDE, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cg,
+        lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 0, 0, e0, lane);
+        lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 4, 0, e1, lane);
+        lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 8, 0, e2, lane);
+        lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 12, 0, hh, lane);
+        layer_finish<1, false>(acc, W + G_B3, F + FM8_FWD, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cg,
                                act_geo ? act_geo + 96 : nullptr, live, lane);
         hh = acc[0];
         // layer 4
         acc[0] = lk_zero16();
-        lk_gemm_kblock<1, 4>(acc, W + G_W4, HG, 0, hh, lane);
-        layer_finish<1, false>(acc, W + G_B4, W + G_U0 + 4 * G_USTRIDE, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cg,
+        lk_gemm_frag<1, 4>(acc, F + FM4_FWD, 1, 0, 0, hh, lane);
+        layer_finish<1, false>(acc, W + G_B4, F + FM9_FWD, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cg,
                                act_geo ? act_geo + 128 : nullptr, live, lane);
         // output 32 -> 1 on the VALU: each half-wave holds 16 of the 32 units of its sample
         float part = 0.0f;
@@ -174,21 +175,21 @@ __global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
         // layer 0: 40 -> 128
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
-        lk_gemm_kblock<4, 4>(acc, W + C_W0, EC, 0, e0, lane);
-        lk_gemm_kblock<4, 1>(acc, W + C_W0, EC, 32, e1, lane);
-        layer_finish<4, true>(acc, W + C_B0, W + C_U0, W + C_U0 + a64(HC * CF), cc, act_col_a, live, lane);
+        lk_gemm_frag<4, 4>(acc, F + FM10_FWD, 4, 0, 0, e0, lane);
+        lk_gemm_frag<4, 1>(acc, F + FM10_FWD, 4, 4, 0, e1, lane);
+        layer_finish<4, true>(acc, W + C_B0, F + FM15_FWD, W + C_U0 + a64(HC * CF), cc, act_col_a, live, lane);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + nb * 32, hh[nb], live, lane); }
         // layers 1, 2: 128 -> 128
 #pragma unroll
         for (int L = 1; L <= 2; ++L) {
-            const float* Wl = W + (L == 1 ? C_W1 : C_W2);
+            const float* Wl = F + (L == 1 ? FM11_FWD : FM12_FWD);
             const float* Bl = W + (L == 1 ? C_B1 : C_B2);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) lk_gemm_kblock<4, 4>(acc, Wl, HC, 32 * kb, hh[kb], lane);
-            layer_finish<4, true>(acc, Bl, W + C_U0 + L * C_USTRIDE, W + C_U0 + L * C_USTRIDE + a64(HC * CF), cc,
+            for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<4, 4>(acc, Wl, 4, 4 * kb, 0, hh[kb], lane);
+            layer_finish<4, true>(acc, Bl, F + (L == 1 ? FM16_FWD : FM17_FWD), W + C_U0 + L * C_USTRIDE + a64(HC * CF), cc,
                                   act_col_a ? act_col_a + L * 128 : nullptr, live, lane);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + L * 128 + nb * 32, hh[nb], live, lane); }
@@ -196,11 +197,11 @@ __global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
         // layer 3 (skip): [e(40) | h(128)] -> 128
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
-        lk_gemm_kblock<4, 4>(acc, W + C_W3, EC + HC, 0, e0, lane);
-        lk_gemm_kblock<4, 1>(acc, W + C_W3, EC + HC, 32, e1, lane);
+        lk_gemm_frag<4, 4>(acc, F + FM13_FWD, 4, 0, 0, e0, lane);
+        lk_gemm_frag<4, 1>(acc, F + FM13_FWD, 4, 4, 0, e1, lane);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) lk_gemm_kblock<4, 4>(acc, W + C_W3, EC + HC, EC + 32 * kb, hh[kb], lane);
-        layer_finish<4, true>(acc, W + C_B3, W + C_U0 + 3 * C_USTRIDE, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), cc,
+        for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<4, 4>(acc, F + FM13_FWD, 4, 5 + 4 * kb, 0, hh[kb], lane);
+        layer_finish<4, true>(acc, W + C_B3, F + FM18_FWD, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), cc,
                               act_col_a ? act_col_a + 3 * 128 : nullptr, live, lane);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + 3 * 128 + nb * 32, hh[nb], live, lane); }
@@ -208,8 +209,8 @@ __global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) lk_gemm_kblock<4, 4>(acc, W + C_W4, HC, 32 * kb, hh[kb], lane);
-        layer_finish<4, true>(acc, W + C_B4, W + C_U0 + 4 * C_USTRIDE, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), cc,
+        for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<4, 4>(acc, F + FM14_FWD, 4, 4 * kb, 0, hh[kb], lane);
+        layer_finish<4, true>(acc, W + C_B4, F + FM19_FWD, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), cc,
                               act_col_a ? act_col_a + 4 * 128 : nullptr, live, lane);
         if (save) {
 #pragma unroll
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     const float a1 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 1], py));
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
+    const float* __restrict__ F = a.Wfrag;
     const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
     // X^T tiles: units 0..19 embedding, 20..51 feature channels 0..31, 52..55 zero
     f32x16 x0, x1;
@@ -297,8 +299,8 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     f32x16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_zero16();
-    lk_gemm_kblock<4, 4>(hid, W + R_W1, KRP, 0, x0, lane);
-    lk_gemm_kblock<4, 3>(hid, W + R_W1, KRP, 32, x1, lane);
+    lk_gemm_frag<4, 4>(hid, F + FM20_FWD, 4, 0, 0, x0, lane);
+    lk_gemm_frag<4, 3>(hid, F + FM20_FWD, 4, 4, 0, x1, lane);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         lk_add_rowvec(hid[nb], W + R_B1, nb * 32, lane);
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     f32x16 out[1];
     out[0] = lk_zero16();
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) lk_gemm_kblock<1, 4>(out, W + R_W2, HC, 32 * kb, hid[kb], lane);
+    for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<1, 4>(out, F + FM21_FWD, 1, 4 * kb, 0, hid[kb], lane);
     lk_add_rowvec(out[0], W + R_B2, 0, lane);
     // c[ch] = sum over the 8 neighbour rows of a sample (8 consecutive lanes) of w * f[ch]
     const bool has = a.nbr_count[sp] >= a.min_nn;

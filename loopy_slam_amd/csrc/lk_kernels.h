@@ -26,7 +26,8 @@ struct LkDecodeArgs {
     unsigned flags;
     const float* rays_o; const float* rays_d; const float* z;
     const float* c_geo; const float* c_col;       // [P,32]
-    const float* W;                               // packed blob
+    const float* W;                               // packed blob (plain master)
+    const float* Wfrag;                           // fragment blob (lk_weights_repack)
     const float* affine;                          // [12] or NULL
     float* raw;                                   // [P,4]
     float* act;                                   // SAVE_ACT scratch or NULL
@@ -40,7 +41,7 @@ struct LkRelposArgs {
     const float* pos;                             // [N,3] cloud positions (original order)
     const float* col_feats;                       // [N,32]
     const int32_t* nbr_idx; const float* nbr_w; const int32_t* nbr_count;
-    const float* W; const float* noise_col;
+    const float* W; const float* Wfrag; const float* noise_col;
     float* c_col;                                 // [P,32]
 };
 

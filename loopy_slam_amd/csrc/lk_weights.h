@@ -60,4 +60,72 @@ constexpr int R_W2 = R_B1 + a64(HC);                 // [32][128]
 constexpr int R_B2 = R_W2 + a64(32 * HC);
 constexpr int BLOB_FLOATS = R_B2 + 64;
 
+
+// ---------------------------------------------------------------------------------------------
+// Derived "fragment" blob (lk_weights_repack): every GEMM matrix re-laid so that one wave-wide
+// 16-byte load is ONE contiguous, fully used 1-KiB block.
+//   forward   block (kg, nb): lane l, t  ->  W[nb*32 + (l&31)][8*kg + 4*(l>>5) + t]          (kg-major)
+//   transposed block (ng, kb): lane l, t ->  W[8*ng + 4*(l>>5) + t][vcol = kb*32 + (l&31)]   (ng-major)
+// "vcol" is a virtual input column: the embedding part of a skip/first layer is padded to a
+// multiple of 32 (colour: 40 -> 64) so that every 32-wide block of dX^T is either embedding or hidden.
+struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwd, tr; };
+
+
+// fwd size = rows*ld ; tr size = kv*rows
+#define LKW_FM(idx, plain_, rows_, ld_, ereal_, evirt_, kv_, prev_end_) \
+    constexpr int FM##idx##_FWD = prev_end_;                             \
+    constexpr int FM##idx##_TR = FM##idx##_FWD + (rows_) * (ld_);        \
+    constexpr int FM##idx##_END = FM##idx##_TR + (kv_) * (rows_);
+
+// index:            plain   rows ld            e_real e_virt kv
+LKW_FM(0,  G_W0, HG, EGP,        EGP, EGP, 96,  0)
+LKW_FM(1,  G_W1, HG, HG,         HG,  HG,  32,  FM0_END)
+LKW_FM(2,  G_W2, HG, HG,         HG,  HG,  32,  FM1_END)
+LKW_FM(3,  G_W3, HG, EGP + HG,   128, 128, 128, FM2_END)
+LKW_FM(4,  G_W4, HG, HG,         HG,  HG,  32,  FM3_END)
+LKW_FM(5,  G_U0 + 0 * G_USTRIDE, HG, CF, CF, CF, 32, FM4_END)
+LKW_FM(6,  G_U0 + 1 * G_USTRIDE, HG, CF, CF, CF, 32, FM5_END)
+LKW_FM(7,  G_U0 + 2 * G_USTRIDE, HG, CF, CF, CF, 32, FM6_END)
+LKW_FM(8,  G_U0 + 3 * G_USTRIDE, HG, CF, CF, CF, 32, FM7_END)
+LKW_FM(9,  G_U0 + 4 * G_USTRIDE, HG, CF, CF, CF, 32, FM8_END)
+LKW_FM(10, C_W0, HC, EC,         EC,  64,  64,  FM9_END)
+LKW_FM(11, C_W1, HC, HC,         HC,  HC,  128, FM10_END)
+LKW_FM(12, C_W2, HC, HC,         HC,  HC,  128, FM11_END)
+LKW_FM(13, C_W3, HC, EC + HC,    EC,  64,  192, FM12_END)
+LKW_FM(14, C_W4, HC, HC,         HC,  HC,  128, FM13_END)
+LKW_FM(15, C_U0 + 0 * C_USTRIDE, HC, CF, CF, CF, 32, FM14_END)
+LKW_FM(16, C_U0 + 1 * C_USTRIDE, HC, CF, CF, CF, 32, FM15_END)
+LKW_FM(17, C_U0 + 2 * C_USTRIDE, HC, CF, CF, CF, 32, FM16_END)
+LKW_FM(18, C_U0 + 3 * C_USTRIDE, HC, CF, CF, CF, 32, FM17_END)
+LKW_FM(19, C_U0 + 4 * C_USTRIDE, HC, CF, CF, CF, 32, FM18_END)
+LKW_FM(20, R_W1, HC, KRP,        KRP, 64,  64,  FM19_END)
+LKW_FM(21, R_W2, CF, HC,         HC,  HC,  128, FM20_END)
+constexpr int FRAG_FLOATS = FM21_END;
+constexpr int N_FRAG_MATS = 22;
+
+#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWD, FM##idx##_TR}
+#define LKW_FRAG_TABLE                                                                 \
+    LKW_FM_ROW(0,  G_W0, HG, EGP,        EGP, EGP, 96),                                \
+    LKW_FM_ROW(1,  G_W1, HG, HG,         HG,  HG,  32),                                \
+    LKW_FM_ROW(2,  G_W2, HG, HG,         HG,  HG,  32),                                \
+    LKW_FM_ROW(3,  G_W3, HG, EGP + HG,   128, 128, 128),                               \
+    LKW_FM_ROW(4,  G_W4, HG, HG,         HG,  HG,  32),                                \
+    LKW_FM_ROW(5,  G_U0 + 0 * G_USTRIDE, HG, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(6,  G_U0 + 1 * G_USTRIDE, HG, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(7,  G_U0 + 2 * G_USTRIDE, HG, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(8,  G_U0 + 3 * G_USTRIDE, HG, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(9,  G_U0 + 4 * G_USTRIDE, HG, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(10, C_W0, HC, EC,         EC,  64,  64),                                \
+    LKW_FM_ROW(11, C_W1, HC, HC,         HC,  HC,  128),                               \
+    LKW_FM_ROW(12, C_W2, HC, HC,         HC,  HC,  128),                               \
+    LKW_FM_ROW(13, C_W3, HC, EC + HC,    EC,  64,  192),                               \
+    LKW_FM_ROW(14, C_W4, HC, HC,         HC,  HC,  128),                               \
+    LKW_FM_ROW(15, C_U0 + 0 * C_USTRIDE, HC, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(16, C_U0 + 1 * C_USTRIDE, HC, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(17, C_U0 + 2 * C_USTRIDE, HC, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(18, C_U0 + 3 * C_USTRIDE, HC, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(19, C_U0 + 4 * C_USTRIDE, HC, CF, CF, CF, 32),                          \
+    LKW_FM_ROW(20, R_W1, HC, KRP,        KRP, 64,  64),                                \
+    LKW_FM_ROW(21, R_W2, CF, HC,         HC,  HC,  128)
+
 }  // namespace lkw

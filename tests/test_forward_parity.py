@@ -115,7 +115,7 @@ def run_forward(eng, name, g, stage, tracker=False, affine=None, color_logits=Fa
     ng = eng.f32(g['noise_geo'])
     nc = eng.f32(g['noise_col']) if 'noise_col' in g else None
     aff = eng.f32(affine) if affine is not None else None
-    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob.blob, stage, tracker=tracker, r2_ray=r2,
+    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage, tracker=tracker, r2_ray=r2,
                         noise_geo=ng, noise_col=nc, affine=aff, color_logits=color_logits, stats_chunk=stats_chunk)
     return st
 

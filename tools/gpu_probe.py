@@ -37,13 +37,13 @@ for N in NS:
         st = core.RenderState(eng, R, cfg.S)
         for stage in ('geometry', 'color'):
             for _ in range(3):
-                core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob.blob, stage)
+                core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n = 10
             e0.record()
             for _ in range(n):
-                core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob.blob, stage)
+                core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
             print(f'  R={R:7d} rel_pos={int(rel)} {stage:8s}: {ms:8.3f} ms  {R/ms/1e3:9.1f} Mrays/s  valid={int(st.valid_ray.sum())} meanhas={float((st.nbr_count>=2).float().mean()):.2f}')
