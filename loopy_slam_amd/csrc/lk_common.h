@@ -79,13 +79,51 @@ __device__ __forceinline__ float lk_fourier_arg(float a0, float a1, float a2, fl
     return fmaf(a2, b2, fmaf(a1, b1, __fmul_rn(a0, b0)));
 }
 
+// ---- compact transcendental helpers.  The decoders evaluate ~500 activations and ~140 Fourier
+// features per sample; OCML's fully accurate expf/log1pf/sinf (with the inlined Payne-Hanek path
+// for large arguments) made the fused kernel ~400 KB of code, i.e. instruction-cache bound.  These
+// versions are branch-free, a dozen instructions each, and accurate to ~1e-7 ABSOLUTE, which is
+// what matters for O(1) activations (validated against the oracle in tests/).
 __device__ __forceinline__ float lk_softplus100(float x) {
+    // torch softplus(beta=100, threshold=20): log1p(exp(100x))/100, linear above the threshold.
+    // v_exp_f32 / v_log_f32 (1 ulp relative): |error| <= ~2e-9 absolute on the result.
     const float t = 100.0f * x;
-    return t > 20.0f ? x : log1pf(expf(t)) / 100.0f;     // torch softplus(beta=100, threshold=20)
+    const float soft = __logf(1.0f + __expf(t)) * 0.01f;
+    return t > 20.0f ? x : soft;
 }
 // d softplus100 / dx expressed through the OUTPUT a = softplus100(x): sigmoid(100x) = 1 - exp(-100a)
-__device__ __forceinline__ float lk_softplus100_grad_from_out(float a) { return -expm1f(-100.0f * a); }
-__device__ __forceinline__ float lk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float lk_softplus100_grad_from_out(float a) { return 1.0f - __expf(-100.0f * a); }
+__device__ __forceinline__ float lk_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// sin / cos for |x| < ~1e5: n = rint(x * 2/pi); r = x - n*pi/2 by a 3-term Cody-Waite reduction with
+// fma (pi/2 = P1 + P2 + P3, P1 has 8 significant bits so n*P1 is exact), then the fdlibm minimax
+// kernels on [-pi/4, pi/4] and a quadrant select.  ~1-2 ulp.
+__device__ __forceinline__ void lk_sincos_core(float x, float& s, float& c, int& q) {
+    const float n = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-n, 1.5703125f, x);
+    r = fmaf(-n, 4.837512969970703125e-4f, r);
+    r = fmaf(-n, 7.54978995489188e-8f, r);
+    const float r2 = r * r;
+    const float ps = fmaf(r2, fmaf(r2, fmaf(r2, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f),
+                                   8.3333293858894631756e-3f), -1.66666666416265235595e-1f);
+    s = fmaf(r * r2, ps, r);
+    const float pc = fmaf(r2, fmaf(r2, fmaf(r2, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f),
+                                   4.16666233237390631894e-2f), -4.99999997251031003120e-1f);
+    c = fmaf(r2, pc, 1.0f);
+    q = (int)n;
+}
+__device__ __forceinline__ float lk_sinf(float x) {
+    float s, c; int q;
+    lk_sincos_core(x, s, c, q);
+    const float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+__device__ __forceinline__ float lk_cosf(float x) {
+    float s, c; int q;
+    lk_sincos_core(x, s, c, q);
+    const float v = (q & 1) ? s : c;
+    return ((q + 1) & 2) ? -v : v;
+}
 
 // C/D-fragment bookkeeping of v_mfma_f32_32x32x2_f32: lane l, register r holds
 // row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.

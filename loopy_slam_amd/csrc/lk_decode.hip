@@ -46,10 +46,10 @@ __device__ __forceinline__ f32x16 geo_embed_tile(const float* __restrict__ B, in
         const float4 b0 = *reinterpret_cast<const float4*>(B + u0);
         const float4 b1 = *reinterpret_cast<const float4*>(B + EGP + u0);
         const float4 b2 = *reinterpret_cast<const float4*>(B + 2 * EGP + u0);
-        e[4 * g + 0] = (u0 + 0 < EG) ? sinf(lk_fourier_arg(a0, a1, a2, b0.x, b1.x, b2.x)) : 0.0f;
-        e[4 * g + 1] = (u0 + 1 < EG) ? sinf(lk_fourier_arg(a0, a1, a2, b0.y, b1.y, b2.y)) : 0.0f;
-        e[4 * g + 2] = (u0 + 2 < EG) ? sinf(lk_fourier_arg(a0, a1, a2, b0.z, b1.z, b2.z)) : 0.0f;
-        e[4 * g + 3] = (u0 + 3 < EG) ? sinf(lk_fourier_arg(a0, a1, a2, b0.w, b1.w, b2.w)) : 0.0f;
+        e[4 * g + 0] = (u0 + 0 < EG) ? lk_sinf(lk_fourier_arg(a0, a1, a2, b0.x, b1.x, b2.x)) : 0.0f;
+        e[4 * g + 1] = (u0 + 1 < EG) ? lk_sinf(lk_fourier_arg(a0, a1, a2, b0.y, b1.y, b2.y)) : 0.0f;
+        e[4 * g + 2] = (u0 + 2 < EG) ? lk_sinf(lk_fourier_arg(a0, a1, a2, b0.z, b1.z, b2.z)) : 0.0f;
+        e[4 * g + 3] = (u0 + 3 < EG) ? lk_sinf(lk_fourier_arg(a0, a1, a2, b0.w, b1.w, b2.w)) : 0.0f;
     }
     return e;
 }
@@ -59,7 +59,7 @@ __device__ __forceinline__ float sincos_embed_unit(const float* __restrict__ B, 
     if (u >= 2 * n) return 0.0f;
     const int xi = (u < n) ? u : u - n;
     const float x = lk_fourier_arg(a0, a1, a2, B[xi], B[n + xi], B[2 * n + xi]);
-    return (u < n) ? sinf(x) : cosf(x);
+    return (u < n) ? lk_sinf(x) : lk_cosf(x);
 }
 
 template <int NG>

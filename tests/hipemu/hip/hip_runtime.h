@@ -153,6 +153,8 @@ static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); retur
 static inline unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline float __uint_as_float(unsigned i) { float f; std::memcpy(&f, &i, 4); return f; }
+#define __expf(x) (::expf(x))
+#define __logf(x) (::logf(x))
 // floorf/sqrtf/fabsf/fminf/fmaxf/expf/logf/log1pf/expm1f/sinf/cosf/fmaf come from <cmath> (global namespace)
 template <typename T> static inline T min(T a, T b) { return a < b ? a : b; }
 template <typename T> static inline T max(T a, T b) { return a > b ? a : b; }
