@@ -250,3 +250,46 @@ def render_forward(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, 
     d = fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, dec, stage, **kw)
     eng.lib.check(eng.lib.dll.lk_render_fwd(C.byref(d), eng.stream), 'lk_render_fwd')
     return st
+
+
+class GradState:
+    """Gradient buffers of one render call (accumulated into by lk_render_bwd: zero them per step)."""
+
+    def __init__(self, eng, N, R, blob_floats, feats=True, weights=True, rays=False, affine=False):
+        self.g_geo = eng.zeros(N, 32) if feats else None
+        self.g_col = eng.zeros(N, 32) if feats else None
+        self.g_weights = eng.zeros(blob_floats) if weights else None
+        self.g_rays_o = eng.zeros(R, 3) if rays else None
+        self.g_rays_d = eng.zeros(R, 3) if rays else None
+        self.g_affine = eng.zeros(12) if affine else None
+        self.scratch = None
+
+    def zero_(self):
+        for t in (self.g_geo, self.g_col, self.g_weights, self.g_affine):
+            if t is not None:
+                t.zero_()
+
+
+def render_backward(eng, st, gs, d_depth, d_color=None, d_var=None):
+    """lk_render_bwd on the state of the preceding render_forward(save_act=True).
+    Which gradients are produced is decided by the buffers present in `gs`."""
+    d = st.desc
+    assert d is not None and (d.flags & _ffi.FLAG_SAVE_ACT), 'run render_forward(..., save_act=True) first'
+    flags = d.flags & ~(_ffi.FLAG_GRAD_FEATS | _ffi.FLAG_GRAD_WEIGHTS | _ffi.FLAG_GRAD_RAYS)
+    if gs.g_geo is not None:
+        flags |= _ffi.FLAG_GRAD_FEATS
+    if gs.g_weights is not None:
+        flags |= _ffi.FLAG_GRAD_WEIGHTS
+    if gs.g_rays_o is not None:
+        flags |= _ffi.FLAG_GRAD_RAYS
+    d.flags = flags
+    need = int(eng.lib.dll.lk_render_bwd_scratch_floats(d.R, d.S, flags))
+    if gs.scratch is None or gs.scratch.numel() < need:
+        gs.scratch = eng.empty(max(1, need))
+    d.d_depth, d.d_var, d.d_color = ptr(d_depth), ptr(d_var), ptr(d_color)
+    d.g_geo_feats, d.g_col_feats, d.g_weights = ptr(gs.g_geo), ptr(gs.g_col), ptr(gs.g_weights)
+    d.g_rays_o, d.g_rays_d, d.g_affine = ptr(gs.g_rays_o), ptr(gs.g_rays_d), ptr(gs.g_affine)
+    d.bwd_scratch = ptr(gs.scratch)
+    st.keep_bwd = (d_depth, d_color, d_var)
+    eng.lib.check(eng.lib.dll.lk_render_bwd(C.byref(d), eng.stream), 'lk_render_bwd')
+    return gs

@@ -161,3 +161,146 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
     LK_LAUNCH_CHECK();
     return LK_OK;
 }
+
+// ------------------------------------------------------------------ render backward
+namespace {
+struct BwdLayout { int64_t d_raw, dc_geo, dc_col, dp_embed, dp_rel, dp_total, dw_rel, w_eff, dlogit, dh_col, rows, total; };
+BwdLayout bwd_layout(int64_t P, uint32_t flags) {
+    BwdLayout L;
+    int64_t o = 0;
+    L.d_raw = o; o += 4 * P;
+    L.dc_geo = o; o += 32 * P;
+    L.dc_col = o; o += 32 * P;
+    L.dp_embed = o; o += 4 * P;
+    L.dp_rel = o; o += 4 * P;
+    L.dp_total = o; o += 4 * P;
+    L.dw_rel = o; o += 8 * P;
+    L.w_eff = o; o += 8 * P;
+    L.dlogit = o; o += 4 * P;
+    const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    L.dh_col = o; if (color && gw) o += 640 * P;
+    L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 320 * P;
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+extern "C" int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t flags) {
+    return bwd_layout((int64_t)R * S, flags).total;
+}
+
+extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
+    int rc = check_desc(d, "lk_render_bwd");
+    if (rc != LK_OK) return rc;
+    if (d->R == 0) return LK_OK;
+    LK_REQUIRE(d->act != nullptr && (d->flags & LK_FLAG_SAVE_ACT), "lk_render_bwd: the forward must run with SAVE_ACT and act");
+    LK_REQUIRE(d->bwd_scratch != nullptr && d->d_depth != nullptr, "lk_render_bwd: bwd_scratch / d_depth missing");
+    const uint32_t flags = d->flags;
+    const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, relpos = color && (flags & LK_FLAG_REL_POS);
+    const bool gf = (flags & LK_FLAG_GRAD_FEATS) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0, gr = (flags & LK_FLAG_GRAD_RAYS) != 0;
+    LK_REQUIRE(!gf || (d->g_geo_feats && (!color || d->g_col_feats)), "lk_render_bwd: GRAD_FEATS needs g_geo_feats/g_col_feats");
+    LK_REQUIRE(!gw || d->g_weights, "lk_render_bwd: GRAD_WEIGHTS needs g_weights");
+    LK_REQUIRE(!gr || (d->g_rays_o && d->g_rays_d && d->pos), "lk_render_bwd: GRAD_RAYS needs g_rays_o/g_rays_d/pos");
+    LK_REQUIRE(!color || d->d_color, "lk_render_bwd: colour stage needs d_color");
+    hipStream_t st = (hipStream_t)stream_;
+    const int P = d->R * d->S;
+    const BwdLayout L = bwd_layout(P, flags);
+    float* S0 = d->bwd_scratch;
+
+    LkCompositeBwdArgs cb;
+    cb.R = d->R; cb.S = d->S; cb.min_nn = d->min_nn; cb.coef = d->coef;
+    cb.raw = d->raw; cb.z = d->z; cb.nbr_count = d->nbr_count; cb.gt_depth = d->gt_depth;
+    cb.d_depth = d->d_depth; cb.d_var = d->d_var; cb.d_color = color ? d->d_color : nullptr;
+    cb.d_raw = S0 + L.d_raw;
+    lk_launch_composite_bwd(cb, st);
+
+    LkDecodeBwdArgs db;
+    db.R = d->R; db.S = d->S; db.P = P; db.flags = flags;
+    db.rays_o = d->rays_o; db.rays_d = d->rays_d; db.z = d->z;
+    db.W = d->weights; db.Wfrag = d->weights_frag; db.affine = d->affine;
+    db.act = d->act; db.raw = d->raw; db.d_raw = S0 + L.d_raw;
+    db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dh_col = S0 + L.dh_col; db.dlogit = S0 + L.dlogit;
+    db.dp_embed = S0 + L.dp_embed; db.g_weights = d->g_weights; db.g_affine = d->g_affine;
+    lk_launch_decode_bwd(db, st);
+
+    if (relpos) {
+        LkRelposBwdArgs rb;
+        rb.R = d->R; rb.S = d->S; rb.P = P; rb.min_nn = d->min_nn; rb.flags = flags;
+        rb.rays_o = d->rays_o; rb.rays_d = d->rays_d; rb.z = d->z; rb.pos = d->pos; rb.col_feats = d->col_feats;
+        rb.nbr_idx = d->nbr_idx; rb.nbr_w = d->nbr_w; rb.nbr_count = d->nbr_count;
+        rb.W = d->weights; rb.Wfrag = d->weights_frag; rb.dc_col = S0 + L.dc_col;
+        rb.g_col_feats = d->g_col_feats; rb.g_weights = d->g_weights;
+        rb.dw_rel = S0 + L.dw_rel; rb.dp_rel = S0 + L.dp_rel; rb.rows = S0 + L.rows; rb.w_eff = S0 + L.w_eff;
+        lk_launch_relpos_bwd(rb, st);
+    }
+
+    if (gf || gr) {
+        LkInterpBwdArgs ib;
+        ib.R = d->R; ib.S = d->S; ib.P = P; ib.min_nn = d->min_nn; ib.flags = flags;
+        ib.rays_o = d->rays_o; ib.rays_d = d->rays_d; ib.z = d->z; ib.r2_ray = d->r2_ray; ib.r2_static = d->r2_static;
+        ib.pos = d->pos; ib.geo_feats = d->geo_feats; ib.col_feats = d->col_feats;
+        ib.nbr_idx = d->nbr_idx; ib.nbr_w = d->nbr_w; ib.nbr_count = d->nbr_count;
+        ib.dc_geo = S0 + L.dc_geo; ib.dc_col = S0 + L.dc_col;
+        ib.dw_rel = relpos ? S0 + L.dw_rel : nullptr;
+        ib.dp_embed = S0 + L.dp_embed; ib.dp_rel = relpos ? S0 + L.dp_rel : nullptr;
+        ib.g_geo_feats = d->g_geo_feats; ib.g_col_feats = d->g_col_feats; ib.dp_total = S0 + L.dp_total;
+        lk_launch_interp_bwd(ib, st);
+    }
+    if (gr) {
+        LkRaysBwdArgs rr;
+        rr.R = d->R; rr.S = d->S; rr.z = d->z; rr.dp_total = S0 + L.dp_total; rr.g_rays_o = d->g_rays_o; rr.g_rays_d = d->g_rays_d;
+        lk_launch_rays_bwd(rr, st);
+    }
+    if (gw && color) {
+        // colour decoder weight gradients as streamed reductions over the saved rows (geometry decoder weights
+        // other than embedder._B are frozen in every reference config: mapping.fix_geo_decoder = True)
+        const float* act_a = d->act + (size_t)P * LK_ACT_GEO_A;
+        const float* act_h = d->act + (size_t)P * (LK_ACT_GEO_A + LK_ACT_COL_A);
+        const float* act_e = d->act + (size_t)P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H);
+        const float* dh = S0 + L.dh_col;
+        float* G = d->g_weights;
+        LkWgradArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        int nj = 0;
+        const int w_off[5] = {C_W0, C_W1, C_W2, C_W3, C_W4}, b_off[5] = {C_B0, C_B1, C_B2, C_B3, C_B4};
+        const int w_ld[5] = {EC, HC, HC, EC + HC, HC};
+        for (int i = 0; i < 5; ++i) {
+            LkWgradJob& J = wa.job[nj++];
+            J.A = dh + i * 128; J.lda = 640; J.a_mode = 1; J.A2 = act_a + i * 128; J.lda2 = LK_ACT_COL_A;
+            if (i == 0) { J.B = act_e; J.ldb = LK_ACT_COL_E; }
+            else if (i == 3) { J.B = act_e; J.ldb = LK_ACT_COL_E; J.B2 = act_h + 2 * 128; J.ldb2 = LK_ACT_COL_H; J.k_split = EC; }
+            else { J.B = act_h + (i - 1) * 128; J.ldb = LK_ACT_COL_H; }
+            J.N = HC; J.K = w_ld[i]; J.rows = P; J.dW = G + w_off[i]; J.ldw = w_ld[i]; J.db = G + b_off[i];
+        }
+        for (int i = 0; i < 5; ++i) {
+            LkWgradJob& J = wa.job[nj++];
+            J.A = dh + i * 128; J.lda = 640; J.a_mode = 0;
+            J.B = d->c_col; J.ldb = LK_C;
+            J.N = HC; J.K = CF; J.rows = P; J.dW = G + C_U0 + i * C_USTRIDE; J.ldw = CF; J.db = G + C_U0 + i * C_USTRIDE + a64(HC * CF);
+        }
+        {
+            LkWgradJob& J = wa.job[nj++];
+            J.A = S0 + L.dlogit; J.lda = 4; J.a_mode = 0;
+            J.B = act_h + 4 * 128; J.ldb = LK_ACT_COL_H;
+            J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
+        }
+        wa.n_jobs = nj; wa.chunk = 1024;
+        lk_launch_wgrad(wa, P, st);
+        if (relpos) {
+            LkWgradArgs wr;
+            memset(&wr, 0, sizeof(wr));
+            const float* rows = S0 + L.rows;
+            LkWgradJob& J1 = wr.job[0];       // linear1: [128][52]
+            J1.A = rows + 128; J1.lda = 320; J1.a_mode = 0; J1.B = rows + 256; J1.ldb = 320;
+            J1.N = HC; J1.K = KR; J1.rows = 8 * P; J1.dW = G + R_W1; J1.ldw = KRP; J1.db = G + R_B1;
+            LkWgradJob& J2 = wr.job[1];       // linear2: [32][128], A = w_eff[row] * dc[row>>3]
+            J2.A = S0 + L.dc_col; J2.lda = LK_C; J2.a_mode = 2; J2.A2 = S0 + L.w_eff; J2.lda2 = 1;
+            J2.B = rows; J2.ldb = 320;
+            J2.N = CF; J2.K = HC; J2.rows = 8 * P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
+            wr.n_jobs = 2; wr.chunk = 4096;
+            lk_launch_wgrad(wr, 8 * P, st);
+        }
+    }
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}

@@ -1,0 +1,313 @@
+// Backward of the render graph (autograd of Renderer.render_batch_ray: Mapper.py:722, Tracker.py:193).
+//   k_composite_bwd   d(depth,var,color) -> d raw[P,4]                        (common.py:408-421)
+//   k_decode_bwd      d raw -> d c_geo, d c_col, d h_i (for wgrad), d p, d B_g  (decoder.py:263-288, 513-546)
+// Same register-chained MFMA scheme as the forward (lk_common.h::lk_gemm_frag) on the TRANSPOSED
+// weight fragments: dX^T = W^T dY^T, the dY CT tile being the B operand.
+#include "lk_common.h"
+#include "lk_kernels.h"
+
+using namespace lkw;
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_composite_bwd(LkCompositeBwdArgs a) {
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    if (r >= a.R) return;
+    float al[LK_S_MAX], be[LK_S_MAX], Tt[LK_S_MAX], wv[LK_S_MAX], zv[LK_S_MAX], cr[LK_S_MAX], cg[LK_S_MAX], cb[LK_S_MAX];
+    float T = 1.0f, wsum = 0.0f, dsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int s = 0; s < LK_S_MAX; ++s) {
+        al[s] = be[s] = Tt[s] = wv[s] = zv[s] = cr[s] = cg[s] = cb[s] = 0.0f;
+        if (s < a.S) {
+            const int p = r * a.S + s;
+            const float4 raw = *reinterpret_cast<const float4*>(a.raw + (size_t)p * 4);
+            const bool has = a.nbr_count[p] >= a.min_nn;
+            const float occ = has ? raw.w : -100.0f;
+            const float alpha = lk_sigmoid(a.coef * occ);
+            al[s] = alpha; Tt[s] = T; be[s] = 1.0f - alpha + 1e-10f;
+            const float w = alpha * T;
+            T *= be[s];
+            wv[s] = w; zv[s] = a.z[p];
+            cr[s] = raw.x; cg[s] = raw.y; cb[s] = raw.z;
+            wsum += w; dsum += w * zv[s];
+            c0 += w * raw.x; c1 += w * raw.y; c2 += w * raw.z;
+        }
+    }
+    const float W = wsum + 1e-10f;
+    const float depth = dsum / W;
+    const float col0 = c0 / W, col1 = c1 / W, col2 = c2 / W;
+    const float gvar = a.d_var ? a.d_var[r] : 0.0f;
+    float gdep = (a.gt_depth[r] > 0.0f) ? a.d_depth[r] : 0.0f;          // depth of zero-depth rays is overwritten
+    float dvar_ddepth = 0.0f;
+#pragma unroll
+    for (int s = 0; s < LK_S_MAX; ++s) dvar_ddepth += -2.0f * wv[s] * (zv[s] - depth);
+    gdep += gvar * dvar_ddepth;
+    const float g0 = a.d_color ? a.d_color[3 * r] : 0.0f, g1 = a.d_color ? a.d_color[3 * r + 1] : 0.0f,
+                g2 = a.d_color ? a.d_color[3 * r + 2] : 0.0f;
+    float gw[LK_S_MAX];
+#pragma unroll
+    for (int s = 0; s < LK_S_MAX; ++s) {
+        const float dz = zv[s] - depth;
+        gw[s] = (gdep * dz + g0 * (cr[s] - col0) + g1 * (cg[s] - col1) + g2 * (cb[s] - col2)) / W + gvar * dz * dz;
+    }
+    float suffix = 0.0f;                                                // sum_{u>s} gw_u w_u
+#pragma unroll
+    for (int s = LK_S_MAX - 1; s >= 0; --s) {
+        if (s < a.S) {
+            const float galpha = gw[s] * Tt[s] - suffix / be[s];
+            const float gocc = galpha * al[s] * (1.0f - al[s]) * a.coef;
+            suffix += gw[s] * wv[s];
+            const float k = wv[s] / W;
+            *reinterpret_cast<float4*>(a.d_raw + (size_t)(r * a.S + s) * 4) = make_float4(g0 * k, g1 * k, g2 * k, gocc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 ct_load32(const float* __restrict__ row, int lane) {
+    const int h = lane >> 5;
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 8 * g + 4 * h);
+        t[4 * g + 0] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
+    }
+    return t;
+}
+__device__ __forceinline__ void ct_store32(float* __restrict__ row, const f32x16& t, bool live, int lane) {
+    const int h = lane >> 5;
+    if (!live) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(row + 8 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+}
+
+__global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a) {
+    const int lane = lk_lane();
+    const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int sample0 = wave * 32;
+    if (sample0 >= a.P) return;
+    const int sample = sample0 + (lane & 31);
+    const bool live = sample < a.P;
+    const int h = lane >> 5;
+    const int sp = live ? sample : a.P - 1;
+    const int r = sp / a.S;
+    const float z = a.z[sp];
+    const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
+    const float py = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
+    const float pz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
+    const float a0 = __fmul_rn(LK_TWO_PI, px), a1 = __fmul_rn(LK_TWO_PI, py), a2 = __fmul_rn(LK_TWO_PI, pz);
+    const float* __restrict__ W = a.W;
+    const float* __restrict__ F = a.Wfrag;
+    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
+    const float* act_geo = a.act + (size_t)sp * LK_ACT_GEO_A;
+    const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A;
+    const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H;
+    float4 draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
+    if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
+    float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;                     // this lane's share of dL/dp (embedding paths)
+
+    // ================= colour decoder =================
+    if (a.flags & LK_FLAG_STAGE_COLOR) {
+        float g0 = draw.x, g1 = draw.y, g2 = draw.z;
+        const float4 yo = *reinterpret_cast<const float4*>(a.raw + (size_t)sp * 4);
+        if (!(a.flags & LK_FLAG_COLOR_LOGITS)) {                 // through the sigmoid
+            g0 *= yo.x * (1.0f - yo.x); g1 *= yo.y * (1.0f - yo.y); g2 *= yo.z * (1.0f - yo.z);
+        }
+        f32x16 h4[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) h4[nb] = ct_load32(act_col_h + 4 * 128 + nb * 32, lane);
+        if (a.affine) {                                          // out' = out @ A + t  (decoder.py:536-539)
+            // recompute the pre-affine output o = Wo h4 + bo
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int u = 32 * nb + 8 * g + 4 * h;
+                    const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + u);
+                    const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
+                    const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
+                    const float v0 = h4[nb][4 * g], v1 = h4[nb][4 * g + 1], v2 = h4[nb][4 * g + 2], v3 = h4[nb][4 * g + 3];
+                    o0 = fmaf(w0.x, v0, o0); o0 = fmaf(w0.y, v1, o0); o0 = fmaf(w0.z, v2, o0); o0 = fmaf(w0.w, v3, o0);
+                    o1 = fmaf(w1.x, v0, o1); o1 = fmaf(w1.y, v1, o1); o1 = fmaf(w1.z, v2, o1); o1 = fmaf(w1.w, v3, o1);
+                    o2 = fmaf(w2.x, v0, o2); o2 = fmaf(w2.y, v1, o2); o2 = fmaf(w2.z, v2, o2); o2 = fmaf(w2.w, v3, o2);
+                }
+            o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
+            o0 += W[C_BO]; o1 += W[C_BO + 1]; o2 += W[C_BO + 2];
+            const float* A = a.affine;
+            if (a.g_affine) {                                    // d affine: sum over samples
+                const float gm[3] = {g0, g1, g2};
+                const float oo[3] = {o0, o1, o2};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const float v = lk_half_wave_sum(oo[c] * gm[m]);
+                        if (lane == 0) atomicAdd(a.g_affine + c * 3 + m, v);
+                    }
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const float v = lk_half_wave_sum(gm[m]);
+                    if (lane == 0) atomicAdd(a.g_affine + 9 + m, v);
+                }
+            }
+            const float t0 = g0 * A[0] + g1 * A[1] + g2 * A[2];
+            const float t1 = g0 * A[3] + g1 * A[4] + g2 * A[5];
+            const float t2 = g0 * A[6] + g1 * A[7] + g2 * A[8];
+            g0 = t0; g1 = t1; g2 = t2;
+        }
+        if (want_w && live && h == 0) *reinterpret_cast<float4*>(a.dlogit + (size_t)sp * 4) = make_float4(g0, g1, g2, 0.0f);
+        // dh4 = Wo^T d out
+        f32x16 dh[4], dy[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u = 32 * nb + 8 * g + 4 * h;
+                const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + u);
+                const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
+                const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
+                dh[nb][4 * g + 0] = w0.x * g0 + w1.x * g1 + w2.x * g2;
+                dh[nb][4 * g + 1] = w0.y * g0 + w1.y * g1 + w2.y * g2;
+                dh[nb][4 * g + 2] = w0.z * g0 + w1.z * g1 + w2.z * g2;
+                dh[nb][4 * g + 3] = w0.w * g0 + w1.w * g1 + w2.w * g2;
+            }
+        f32x16 dc[1], de[2];
+        dc[0] = lk_zero16(); de[0] = lk_zero16(); de[1] = lk_zero16();
+#pragma unroll
+        for (int i = 4; i >= 0; --i) {
+            if (want_w) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + nb * 32, dh[nb], live, lane);
+            }
+            const float* Utr = F + (i == 0 ? FM15_TR : i == 1 ? FM16_TR : i == 2 ? FM17_TR : i == 3 ? FM18_TR : FM19_TR);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<1, 4>(dc, Utr, 1, 4 * nb, 0, dh[nb], lane);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const f32x16 av = ct_load32(act_col_a + i * 128 + nb * 32, lane);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dy[nb][q] = dh[nb][q] * lk_softplus100_grad_from_out(av[q]);
+            }
+            if (i == 4 || i == 2 || i == 1) {
+                const float* Wtr = F + (i == 4 ? FM14_TR : i == 2 ? FM12_TR : FM11_TR);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dh[kb] = lk_zero16();
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<4, 4>(dh, Wtr, 4, 4 * nb, 0, dy[nb], lane);
+            } else if (i == 3) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dh[kb] = lk_zero16();
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<4, 4>(dh, F + FM13_TR, 6, 4 * nb, 2, dy[nb], lane);
+                if (want_p) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<2, 4>(de, F + FM13_TR, 6, 4 * nb, 0, dy[nb], lane);
+                }
+            } else {   // i == 0: only the embedding receives gradient
+                if (want_p) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<2, 4>(de, F + FM10_TR, 2, 4 * nb, 0, dy[nb], lane);
+                }
+            }
+        }
+        ct_store32(a.dc_col + (size_t)sp * LK_C, dc[0], live, lane);
+        if (want_p) {    // e_u = sin(x_u) (u<20) | cos(x_{u-20});  dp_i += de_u * f'(x) * 2 pi * B[i][xi]
+            const float* B = W + C_EB;
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int u = 32 * tile + lk_frag_row(q, h);
+                    if (u < EC) {
+                        const int xi = (u < 20) ? u : u - 20;
+                        const float b0 = B[xi], b1 = B[20 + xi], b2 = B[40 + xi];
+                        const float x = lk_fourier_arg(a0, a1, a2, b0, b1, b2);
+                        const float f = (u < 20) ? lk_cosf(x) : -lk_sinf(x);
+                        const float gx = de[tile][q] * f * LK_TWO_PI;
+                        dpx = fmaf(gx, b0, dpx); dpy = fmaf(gx, b1, dpy); dpz = fmaf(gx, b2, dpz);
+                    }
+                }
+        }
+    }
+
+    // ================= geometry decoder =================
+    {
+        const float docc = draw.w;
+        f32x16 dh, dy, dcg[1], de[3], acc1[1], acc4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 wo = *reinterpret_cast<const float4*>(W + G_WO + 8 * g + 4 * h);
+            dh[4 * g] = wo.x * docc; dh[4 * g + 1] = wo.y * docc; dh[4 * g + 2] = wo.z * docc; dh[4 * g + 3] = wo.w * docc;
+        }
+        dcg[0] = lk_zero16(); de[0] = lk_zero16(); de[1] = lk_zero16(); de[2] = lk_zero16();
+#pragma unroll
+        for (int i = 4; i >= 0; --i) {
+            const float* Utr = F + (i == 0 ? FM5_TR : i == 1 ? FM6_TR : i == 2 ? FM7_TR : i == 3 ? FM8_TR : FM9_TR);
+            lk_gemm_frag<1, 4>(dcg, Utr, 1, 0, 0, dh, lane);
+            const f32x16 av = ct_load32(act_geo + i * 32, lane);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dy[q] = (av[q] > 0.0f) ? dh[q] : 0.0f;
+            if (i == 4 || i == 2 || i == 1) {
+                acc1[0] = lk_zero16();
+                lk_gemm_frag<1, 4>(acc1, F + (i == 4 ? FM4_TR : i == 2 ? FM2_TR : FM1_TR), 1, 0, 0, dy, lane);
+                dh = acc1[0];
+            } else if (i == 3) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc4[kb] = lk_zero16();
+                lk_gemm_frag<4, 4>(acc4, F + FM3_TR, 4, 0, 0, dy, lane);
+                de[0] = acc4[0]; de[1] = acc4[1]; de[2] = acc4[2];
+                dh = acc4[3];
+            } else {
+                lk_gemm_frag<3, 4>(de, F + FM0_TR, 3, 0, 0, dy, lane);
+            }
+        }
+        ct_store32(a.dc_geo + (size_t)sp * LK_C, dcg[0], live, lane);
+        // e_u = sin(x_u): ge_u = de_u cos(x_u);  dB[i][u] += sum_s ge_u a_i(s);  dp_i += ge_u 2 pi B[i][u]
+        const float* B = W + G_EB;
+#pragma unroll
+        for (int tile = 0; tile < 3; ++tile)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u0 = 32 * tile + 8 * g + 4 * h;
+                const float4 b0 = *reinterpret_cast<const float4*>(B + u0);
+                const float4 b1 = *reinterpret_cast<const float4*>(B + EGP + u0);
+                const float4 b2 = *reinterpret_cast<const float4*>(B + 2 * EGP + u0);
+                const float bb0[4] = {b0.x, b0.y, b0.z, b0.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w}, bb2[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int u = u0 + t;
+                    float ge = 0.0f;
+                    if (u < EG) ge = de[tile][4 * g + t] * lk_cosf(lk_fourier_arg(a0, a1, a2, bb0[t], bb1[t], bb2[t]));
+                    if (want_p) {
+                        const float gx = ge * LK_TWO_PI;
+                        dpx = fmaf(gx, bb0[t], dpx); dpy = fmaf(gx, bb1[t], dpy); dpz = fmaf(gx, bb2[t], dpz);
+                    }
+                    if (want_w) {
+                        const float s0 = lk_half_wave_sum(ge * a0), s1 = lk_half_wave_sum(ge * a1), s2 = lk_half_wave_sum(ge * a2);
+                        if ((lane & 31) == 0 && u < EG) {
+                            atomicAdd(a.g_weights + G_EB + u, s0);
+                            atomicAdd(a.g_weights + G_EB + EGP + u, s1);
+                            atomicAdd(a.g_weights + G_EB + 2 * EGP + u, s2);
+                        }
+                    }
+                }
+            }
+    }
+    if (want_p) {
+        dpx += __shfl_xor(dpx, 32); dpy += __shfl_xor(dpy, 32); dpz += __shfl_xor(dpz, 32);
+        if (live && h == 0) *reinterpret_cast<float4*>(a.dp_embed + (size_t)sp * 4) = make_float4(dpx, dpy, dpz, 0.0f);
+    }
+}
+
+int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_composite_bwd, dim3(lk_cdiv(a.R, 256)), dim3(256), 0, st, a);
+    return LK_OK;
+}
+int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
+    const int waves = lk_cdiv(a.P, 32);
+    hipLaunchKernelGGL(k_decode_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    return LK_OK;
+}

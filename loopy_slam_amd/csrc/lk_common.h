@@ -172,6 +172,12 @@ __device__ __forceinline__ void lk_gemm_frag(f32x16 (&acc)[NB], const float* __r
     }
 }
 
+// sum over the 32 sample columns held by the lanes of one half-wave (lanes with equal lane>>5)
+__device__ __forceinline__ float lk_half_wave_sum(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+    return v;
+}
+
 // per-row vector (bias) of a CT tile: v[unit(r,h)] for r = 0..15, unit0 = first unit of the tile
 __device__ __forceinline__ void lk_add_rowvec(f32x16& acc, const float* __restrict__ v, int unit0, int lane) {
     const int h = lane >> 5;

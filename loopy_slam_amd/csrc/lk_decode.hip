@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
         const f32x16 e0 = sincos_embed_tile<4>(W + C_EB, 20, 0, a0, a1, a2, lane);
         const f32x16 e1 = sincos_embed_tile<1>(W + C_EB, 20, 1, a0, a1, a2, lane);
         const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
+        if (save && live) {          // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
+            float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
+            ct_store_rows32(erow, e0, true, lane);
+            *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1[0], e1[1], e1[2], e1[3]);
+        }
         f32x16 acc[4], hh[4];
         // layer 0: 40 -> 128
 #pragma unroll

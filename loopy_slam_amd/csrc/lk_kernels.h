@@ -45,6 +45,80 @@ struct LkRelposArgs {
     float* c_col;                                 // [P,32]
 };
 
+struct LkCompositeBwdArgs {
+    int R, S, min_nn;
+    float coef;
+    const float* raw; const float* z; const int32_t* nbr_count; const float* gt_depth;
+    const float* d_depth; const float* d_var; const float* d_color;
+    float* d_raw;                                  // [P,4]
+};
+
+struct LkDecodeBwdArgs {
+    int R, S, P;
+    unsigned flags;
+    const float* rays_o; const float* rays_d; const float* z;
+    const float* W; const float* Wfrag; const float* affine;
+    const float* act; const float* raw; const float* d_raw;
+    float* dc_geo; float* dc_col;                  // [P,32]
+    float* dh_col;                                 // [P,640] (GRAD_WEIGHTS)
+    float* dlogit;                                 // [P,4]   (GRAD_WEIGHTS)
+    float* dp_embed;                               // [P,4]   (GRAD_RAYS)
+    float* g_weights; float* g_affine;
+};
+
+// interpolation backward: feature-row scatter (+ tracker: weights -> distances -> positions)
+struct LkInterpBwdArgs {
+    int R, S, P, min_nn;
+    unsigned flags;
+    const float* rays_o; const float* rays_d; const float* z; const float* r2_ray; float r2_static;
+    const float* pos; const float* geo_feats; const float* col_feats;
+    const int32_t* nbr_idx; const float* nbr_w; const int32_t* nbr_count;
+    const float* dc_geo; const float* dc_col;
+    const float* dw_rel;                           // [P,8] d loss / d normalised weight from the rel-pos branch, or NULL
+    const float* dp_embed; const float* dp_rel;    // [P,4] or NULL
+    float* g_geo_feats; float* g_col_feats;        // [N,32] accumulated
+    float* dp_total;                               // [P,4] (GRAD_RAYS)
+};
+
+struct LkRaysBwdArgs { int R, S; const float* z; const float* dp_total; float* g_rays_o; float* g_rays_d; };
+
+// rel-pos neighbour MLP backward
+struct LkRelposBwdArgs {
+    int R, S, P, min_nn;
+    unsigned flags;
+    const float* rays_o; const float* rays_d; const float* z;
+    const float* pos; const float* col_feats;
+    const int32_t* nbr_idx; const float* nbr_w; const int32_t* nbr_count;
+    const float* W; const float* Wfrag;
+    const float* dc_col;                           // [P,32]
+    float* g_col_feats; float* g_weights;
+    float* dw_rel;                                 // [P,8]  (GRAD_RAYS)
+    float* dp_rel;                                 // [P,4]  (GRAD_RAYS)
+    float* rows;                                   // [8P][320]: hid(128) | dhid(128) | x(64)  (GRAD_WEIGHTS)
+    float* w_eff;                                  // [8P] weight actually applied to each neighbour row
+};
+
+// weight gradients: dW[n][k] += sum_rows A[row][n] * B[row][k]  (one wave per (job, n-block, row chunk))
+struct LkWgradJob {
+    const float* A; int lda; int a_mode;           // 0 plain, 1 A*softplus'(A2), 2 nbr_w[row]*dc[row>>3][n]
+    const float* A2; int lda2;
+    const float* B; int ldb;
+    const float* B2; int ldb2; int k_split;        // optional second source for columns k >= k_split
+    int N, K;                                      // logical sizes (N <= 128, K <= 168)
+    int rows;
+    float* dW; int ldw;                            // plain blob matrix [N][ldw]
+    float* db;                                     // bias gradient [N] or NULL
+};
+#define LK_WGRAD_MAX_JOBS 16
+struct LkWgradArgs { LkWgradJob job[LK_WGRAD_MAX_JOBS]; int n_jobs; int chunk; };
+
+int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st);
+int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st);
+int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st);
+int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st);
+int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st);
+int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st);
+
 int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st);
 int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st);
 int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st);
@@ -52,9 +126,10 @@ int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st);
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st);
 
 // activation scratch layout (floats per sample), SAVE_ACT
-//   [P][160] geometry a_i | [P][640] colour a_i | [P][640] colour h_i   (i = 0..4, row-major per sample)
+//   [P][160] geometry a_i | [P][640] colour a_i | [P][640] colour h_i | [P][40] colour embedding  (i = 0..4)
 //   a_i = act(W_i x_i + b_i), h_i = a_i + fc_c_i(c)
 #define LK_ACT_GEO_A (5 * 32)
 #define LK_ACT_COL_A (5 * 128)
 #define LK_ACT_COL_H (5 * 128)
-#define LK_ACT_FLOATS_PER_SAMPLE (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H)
+#define LK_ACT_COL_E 40       // colour Fourier embedding (input of layers 0 and 3)
+#define LK_ACT_FLOATS_PER_SAMPLE (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H + LK_ACT_COL_E)

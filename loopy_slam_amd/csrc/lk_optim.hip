@@ -1,0 +1,369 @@
+// Everything around the render call inside one optimisation iteration:
+//   losses fused with their output gradients (Mapper.py:691-720, Tracker.py:169-191),
+//   multi-tensor Adam (torch.optim.Adam semantics; Mapper.py:570,723, Tracker.py:352,194),
+//   pose -> rays and its backward (common.py:301-343, 104-120),
+//   inside-mask threshold (median / max) and stable ballot + prefix-sum compaction
+//   (Tracker.py:153-160, Mapper.py:674-681, common.py:249-255).
+#include "lk_common.h"
+
+#include <math.h>
+#include <string.h>
+
+// ------------------------------------------------------------------ block reduction helper
+__device__ __forceinline__ float block_sum_256(float v, float* sh /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lk_lane() == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+// ------------------------------------------------------------------ mapper loss
+__global__ __launch_bounds__(256) void k_loss_mapper(int R, const float* __restrict__ depth, const float* __restrict__ color,
+                                                     const uint8_t* __restrict__ valid, const float* __restrict__ gt_depth,
+                                                     const float* __restrict__ gt_color, float w_color, int use_color,
+                                                     float* __restrict__ d_depth, float* __restrict__ d_color,
+                                                     float* __restrict__ out) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    float geo = 0.0f, col = 0.0f, cnt = 0.0f;
+    if (r < R) {
+        const float d = depth[r], g = gt_depth[r];
+        const bool m = (g > 0.0f) && valid[r] && !(d != d);
+        float dd = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
+        if (m) {
+            geo = fabsf(g - d);
+            dd = sgn(d - g);
+            cnt = 1.0f;
+            if (use_color) {
+                const float e0 = color[3 * r] - gt_color[3 * r], e1 = color[3 * r + 1] - gt_color[3 * r + 1],
+                            e2 = color[3 * r + 2] - gt_color[3 * r + 2];
+                col = fabsf(e0) + fabsf(e1) + fabsf(e2);
+                dc0 = w_color * sgn(e0); dc1 = w_color * sgn(e1); dc2 = w_color * sgn(e2);
+            }
+        }
+        d_depth[r] = dd;
+        d_color[3 * r] = dc0; d_color[3 * r + 1] = dc1; d_color[3 * r + 2] = dc2;
+    }
+    geo = block_sum_256(geo, sh);
+    col = block_sum_256(col, sh);
+    cnt = block_sum_256(cnt, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(out + 0, geo + (use_color ? w_color * col : 0.0f));
+        atomicAdd(out + 1, geo);
+        atomicAdd(out + 2, col);
+        atomicAdd(out + 3, cnt);
+    }
+}
+
+// ------------------------------------------------------------------ tracker loss (two passes: mean of the normalised residual)
+__global__ __launch_bounds__(256) void k_loss_tracker_pass1(int R, const float* __restrict__ depth, const float* __restrict__ var,
+                                                            const float* __restrict__ gt_depth, float* __restrict__ scratch) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    float t = 0.0f;
+    if (r < R) {
+        t = fabsf(gt_depth[r] - depth[r]) / sqrtf(var[r] + 1e-10f);
+        scratch[r] = t;
+    }
+    t = block_sum_256(t, sh);
+    if (threadIdx.x == 0) atomicAdd(scratch + R, t);
+}
+
+__global__ __launch_bounds__(256) void k_loss_tracker_pass2(int R, const float* __restrict__ depth, const float* __restrict__ var,
+                                                            const float* __restrict__ color, const float* __restrict__ gt_depth,
+                                                            const float* __restrict__ gt_color, float w_color, int use_color,
+                                                            const float* __restrict__ scratch, float* __restrict__ d_depth,
+                                                            float* __restrict__ d_color, float* __restrict__ out) {
+    __shared__ float sh[4];
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    const float thr = 10.0f * (scratch[R] / (float)R);
+    float geo = 0.0f, col = 0.0f, cnt = 0.0f;
+    if (r < R) {
+        const float d = depth[r], v = var[r], g = gt_depth[r], t = scratch[r];
+        const bool m = (t < thr) && (g > 0.0f) && !(d != d) && !(v != v);
+        float dd = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
+        if (m) {
+            geo = fminf(fmaxf(t, 0.0f), 1e3f);
+            if (t <= 1e3f) dd = sgn(d - g) / sqrtf(v + 1e-10f);
+            cnt = 1.0f;
+            const float e0 = color[3 * r] - gt_color[3 * r], e1 = color[3 * r + 1] - gt_color[3 * r + 1],
+                        e2 = color[3 * r + 2] - gt_color[3 * r + 2];
+            col = fabsf(e0) + fabsf(e1) + fabsf(e2);
+            if (use_color) { dc0 = w_color * sgn(e0); dc1 = w_color * sgn(e1); dc2 = w_color * sgn(e2); }
+        }
+        d_depth[r] = dd;
+        d_color[3 * r] = dc0; d_color[3 * r + 1] = dc1; d_color[3 * r + 2] = dc2;
+    }
+    geo = block_sum_256(geo, sh);
+    col = block_sum_256(col, sh);
+    cnt = block_sum_256(cnt, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(out + 0, geo + (use_color ? w_color * col : 0.0f));
+        atomicAdd(out + 1, geo);
+        atomicAdd(out + 2, col);
+        atomicAdd(out + 3, cnt);
+    }
+}
+
+// ------------------------------------------------------------------ Adam
+struct AdamSegDev { float* p; const float* g; float* m; float* v; long long n; float step_size, bc2_sqrt; };
+struct AdamArgs { AdamSegDev s[LK_ADAM_MAX_SEG]; int n_seg; float beta1, beta2, eps; };
+
+__global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+    const AdamSegDev S = a.s[blockIdx.y];
+    const float b1 = a.beta1, b2 = a.beta2, om1 = 1.0f - a.beta1, om2 = 1.0f - a.beta2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < S.n; i += (long long)gridDim.x * 256) {
+        const float g = S.g[i];
+        const float m = S.m[i] * b1 + om1 * g;              // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
+        const float v = S.v[i] * b2 + om2 * (g * g);        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+        const float denom = sqrtf(v) / S.bc2_sqrt + a.eps;  // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+        S.m[i] = m;
+        S.v[i] = v;
+        S.p[i] = S.p[i] - S.step_size * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-lr/bias_correction1)
+    }
+}
+
+// ------------------------------------------------------------------ pose -> rays
+__device__ __forceinline__ void quat_rot(const float* __restrict__ cam, float (&Rm)[9]) {
+    const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
+    const float s = 2.0f / (qr * qr + qi * qi + qj * qj + qk * qk);
+    Rm[0] = 1.0f - s * (qj * qj + qk * qk); Rm[1] = s * (qi * qj - qk * qr); Rm[2] = s * (qi * qk + qj * qr);
+    Rm[3] = s * (qi * qj + qk * qr); Rm[4] = 1.0f - s * (qi * qi + qk * qk); Rm[5] = s * (qj * qk - qi * qr);
+    Rm[6] = s * (qi * qk - qj * qr); Rm[7] = s * (qj * qk + qi * qr); Rm[8] = 1.0f - s * (qi * qi + qj * qj);
+}
+
+__global__ __launch_bounds__(256) void k_rays_from_pose(const float* __restrict__ cam, const float* __restrict__ pi,
+                                                        const float* __restrict__ pj, int R, float fx, float fy, float cx,
+                                                        float cy, float* __restrict__ ro, float* __restrict__ rd) {
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    if (r >= R) return;
+    float Rm[9];
+    quat_rot(cam, Rm);
+    const float d0 = (pi[r] - cx) / fx, d1 = -(pj[r] - cy) / fy, d2 = -1.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        rd[3 * r + a] = (d0 * Rm[3 * a] + d1 * Rm[3 * a + 1]) + d2 * Rm[3 * a + 2];
+        ro[3 * r + a] = cam[4 + a];
+    }
+}
+
+// d loss / d cam7 from d rays: single block (R is a ray batch, <= ~1e4 in the tracker)
+__global__ __launch_bounds__(256) void k_pose_bwd(const float* __restrict__ cam, const float* __restrict__ pi,
+                                                  const float* __restrict__ pj, int R, float fx, float fy, float cx, float cy,
+                                                  const float* __restrict__ g_ro, const float* __restrict__ g_rd,
+                                                  float* __restrict__ g_cam) {
+    __shared__ float sh[4];
+    __shared__ float acc[12];
+    float G[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gT[3] = {0.f, 0.f, 0.f};
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float dir[3] = {(pi[r] - cx) / fx, -(pj[r] - cy) / fy, -1.0f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float g = g_rd[3 * r + a];
+            G[3 * a] = fmaf(g, dir[0], G[3 * a]); G[3 * a + 1] = fmaf(g, dir[1], G[3 * a + 1]); G[3 * a + 2] = fmaf(g, dir[2], G[3 * a + 2]);
+            gT[a] += g_ro[3 * r + a];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { const float s = block_sum_256(G[q], sh); if (threadIdx.x == 0) acc[q] = s; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const float s = block_sum_256(gT[q], sh); if (threadIdx.x == 0) acc[9 + q] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
+        const float N = qr * qr + qi * qi + qj * qj + qk * qk, s = 2.0f / N;
+        const float P[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
+                            qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr,
+                            qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)};
+        float gp = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) gp += acc[q] * P[q];
+        const float* g = acc;
+        const float dPr = g[1] * (-qk) + g[2] * qj + g[3] * qk + g[5] * (-qi) + g[6] * (-qj) + g[7] * qi;
+        const float dPi = g[1] * qj + g[2] * qk + g[3] * qj + g[4] * (-2.0f * qi) + g[5] * (-qr) + g[6] * qk + g[7] * qr + g[8] * (-2.0f * qi);
+        const float dPj = g[0] * (-2.0f * qj) + g[1] * qi + g[2] * qr + g[3] * qi + g[5] * qk + g[6] * (-qr) + g[7] * qk + g[8] * (-2.0f * qj);
+        const float dPk = g[0] * (-2.0f * qk) + g[1] * (-qr) + g[2] * qi + g[3] * qr + g[4] * (-2.0f * qk) + g[5] * qj + g[6] * qi + g[7] * qj;
+        const float ds = -s * s;            // d s / d q_x = -s^2 q_x
+        g_cam[0] = ds * qr * gp + s * dPr;
+        g_cam[1] = ds * qi * gp + s * dPi;
+        g_cam[2] = ds * qj * gp + s * dPj;
+        g_cam[3] = ds * qk * gp + s * dPk;
+        g_cam[4] = acc[9]; g_cam[5] = acc[10]; g_cam[6] = acc[11];
+    }
+}
+
+// ------------------------------------------------------------------ stable compaction (single block, 1024 threads)
+__global__ __launch_bounds__(1024) void k_compact(const uint8_t* __restrict__ mask, int n, int32_t* __restrict__ out_index,
+                                                  int32_t* __restrict__ out_count) {
+    __shared__ int wcount[16];
+    __shared__ int base;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + t;
+        const bool keep = (i < n) && mask[i] != 0;
+        const unsigned long long b = __ballot(keep);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[w] = __popcll(b);
+        __syncthreads();
+        int woff = base;
+        for (int q = 0; q < w; ++q) woff += wcount[q];
+        if (keep) out_index[woff + before] = i;
+        __syncthreads();
+        if (t == 1023) base = woff + __popcll(b);
+        __syncthreads();
+    }
+    if (t == 0) *out_count = base;
+}
+
+// ------------------------------------------------------------------ inside mask: thr = min(10*median(d>0), 1.2*max)
+__global__ __launch_bounds__(1024) void k_inside_mask(const float* __restrict__ depth, int n, uint8_t* __restrict__ mask,
+                                                      float* __restrict__ out_thr, uint32_t* __restrict__ scratch) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_rank, s_cnt, s_maxbits;
+    const int t = threadIdx.x;
+    if (t == 0) { s_cnt = 0; s_maxbits = 0; }
+    __syncthreads();
+    unsigned mycnt = 0, mymax = 0;
+    for (int i = t; i < n; i += 1024) {
+        const float d = depth[i];
+        const unsigned u = (d > 0.0f) ? __float_as_uint(d) : 0u;     // positive floats order like their bit patterns
+        scratch[i] = u;
+        if (u) { ++mycnt; mymax = max(mymax, u); }
+    }
+    atomicAdd(&s_cnt, mycnt);
+    atomicMax(&s_maxbits, mymax);
+    __syncthreads();
+    const unsigned m = s_cnt;
+    if (m == 0) {
+        for (int i = t; i < n; i += 1024) mask[i] = 0;
+        if (t == 0) *out_thr = 0.0f;
+        return;
+    }
+    if (t == 0) { s_prefix = 0; s_rank = (m - 1) / 2; }              // torch.median: lower of the two middle values
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
+        for (int i = t; i < n; i += 1024) {
+            const unsigned u = scratch[i];
+            if (u && (u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned rank = s_rank, b = 0;
+            for (; b < 256; ++b) { if (rank < hist[b]) break; rank -= hist[b]; }
+            s_rank = rank;
+            s_prefix = prefix | (b << shift);
+        }
+        __syncthreads();
+    }
+    const float med = __uint_as_float(s_prefix);
+    const float mx = __uint_as_float(s_maxbits);
+    const float thr = fminf(10.0f * med, 1.2f * mx);
+    for (int i = t; i < n; i += 1024) { const float d = depth[i]; mask[i] = (d > 0.0f && d <= thr) ? 1 : 0; }
+    if (t == 0) *out_thr = thr;
+}
+
+// ------------------------------------------------------------------ host API
+extern "C" int lk_loss_mapper(int32_t R, const float* depth, const float* color, const uint8_t* valid_ray,
+                              const float* gt_depth, const float* gt_color, float w_color, int32_t use_color,
+                              float* d_depth, float* d_color, float* out_loss, void* stream_) {
+    LK_REQUIRE(R >= 0 && out_loss, "lk_loss_mapper: bad arguments");
+    hipStream_t st = (hipStream_t)stream_;
+    LK_HIP_TRY(hipMemsetAsync(out_loss, 0, 4 * sizeof(float), st));
+    if (R == 0) return LK_OK;
+    LK_REQUIRE(depth && color && valid_ray && gt_depth && gt_color && d_depth && d_color, "lk_loss_mapper: NULL buffer");
+    hipLaunchKernelGGL(k_loss_mapper, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, color, valid_ray, gt_depth,
+                       gt_color, w_color, (int)use_color, d_depth, d_color, out_loss);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+extern "C" int lk_loss_tracker(int32_t R, const float* depth, const float* var, const float* color,
+                               const float* gt_depth, const float* gt_color, float w_color, int32_t use_color,
+                               float* d_depth, float* d_color, float* out_loss, float* scratch, void* stream_) {
+    LK_REQUIRE(R >= 0 && out_loss && scratch, "lk_loss_tracker: bad arguments");
+    hipStream_t st = (hipStream_t)stream_;
+    LK_HIP_TRY(hipMemsetAsync(out_loss, 0, 4 * sizeof(float), st));
+    if (R == 0) return LK_OK;
+    LK_REQUIRE(depth && var && color && gt_depth && gt_color && d_depth && d_color, "lk_loss_tracker: NULL buffer");
+    LK_HIP_TRY(hipMemsetAsync(scratch + R, 0, sizeof(float), st));
+    hipLaunchKernelGGL(k_loss_tracker_pass1, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, gt_depth, scratch);
+    hipLaunchKernelGGL(k_loss_tracker_pass2, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, color, gt_depth,
+                       gt_color, w_color, (int)use_color, (const float*)scratch, d_depth, d_color, out_loss);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+extern "C" int lk_adam_step(const lk_adam_seg* segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream_) {
+    LK_REQUIRE(n_seg >= 0 && n_seg <= LK_ADAM_MAX_SEG, "lk_adam_step: too many segments");
+    if (n_seg == 0) return LK_OK;
+    LK_REQUIRE(segs != nullptr, "lk_adam_step: NULL segments");
+    AdamArgs a;
+    memset(&a, 0, sizeof(a));
+    long long nmax = 0;
+    for (int i = 0; i < n_seg; ++i) {
+        LK_REQUIRE(segs[i].n >= 0 && segs[i].step >= 1, "lk_adam_step: bad segment");
+        LK_REQUIRE(segs[i].n == 0 || (segs[i].p && segs[i].g && segs[i].m && segs[i].v), "lk_adam_step: NULL tensor");
+        const double bc1 = 1.0 - pow((double)beta1, (double)segs[i].step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)segs[i].step);
+        a.s[i].p = segs[i].p; a.s[i].g = segs[i].g; a.s[i].m = segs[i].m; a.s[i].v = segs[i].v; a.s[i].n = segs[i].n;
+        a.s[i].step_size = (float)((double)segs[i].lr / bc1);
+        a.s[i].bc2_sqrt = (float)sqrt(bc2);
+        if (segs[i].n > nmax) nmax = segs[i].n;
+    }
+    a.n_seg = n_seg; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    if (nmax == 0) return LK_OK;
+    int gx = lk_cdiv(nmax, 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_adam, dim3(gx, n_seg), dim3(256), 0, (hipStream_t)stream_, a);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+extern "C" int lk_rays_from_pose(const float* cam7, const float* pix_i, const float* pix_j, int32_t R,
+                                 float fx, float fy, float cx, float cy, float* rays_o, float* rays_d, void* stream_) {
+    LK_REQUIRE(R >= 0, "lk_rays_from_pose: R < 0");
+    if (R == 0) return LK_OK;
+    LK_REQUIRE(cam7 && pix_i && pix_j && rays_o && rays_d, "lk_rays_from_pose: NULL buffer");
+    hipLaunchKernelGGL(k_rays_from_pose, dim3(lk_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream_, cam7, pix_i, pix_j, (int)R,
+                       fx, fy, cx, cy, rays_o, rays_d);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+extern "C" int lk_pose_bwd(const float* cam7, const float* pix_i, const float* pix_j, int32_t R,
+                           float fx, float fy, float cx, float cy, const float* g_rays_o, const float* g_rays_d,
+                           float* g_cam7, void* stream_) {
+    LK_REQUIRE(R >= 0 && cam7 && g_cam7, "lk_pose_bwd: bad arguments");
+    LK_REQUIRE(R == 0 || (pix_i && pix_j && g_rays_o && g_rays_d), "lk_pose_bwd: NULL buffer");
+    hipLaunchKernelGGL(k_pose_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream_, cam7, pix_i, pix_j, (int)R, fx, fy, cx, cy,
+                       g_rays_o, g_rays_d, g_cam7);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+extern "C" int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, void* stream_) {
+    LK_REQUIRE(n >= 0 && out_count, "lk_compact: bad arguments");
+    LK_REQUIRE(n == 0 || (mask && out_index), "lk_compact: NULL buffer");
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, (hipStream_t)stream_, mask, (int)n, out_index, out_count);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+extern "C" int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* out_thr, uint32_t* scratch, void* stream_) {
+    LK_REQUIRE(n >= 0 && out_thr, "lk_inside_mask: bad arguments");
+    if (n == 0) return LK_OK;
+    LK_REQUIRE(depth && mask && scratch, "lk_inside_mask: NULL buffer");
+    hipLaunchKernelGGL(k_inside_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream_, depth, (int)n, mask, out_thr, scratch);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}

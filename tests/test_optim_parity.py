@@ -1,0 +1,132 @@
+"""Fused loss kernels, multi-tensor Adam, pose<->rays, inside-mask and compaction against the
+oracle / golden vectors (both back-ends, see test_forward_parity.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hotpath as H
+from loopy_slam_amd import core, optim
+from util import load, tens, make_engine, backends, relerr
+
+torch.set_num_threads(1)
+
+
+class _St:
+    pass
+
+
+def _fake_state(eng, depth, var, color, valid):
+    st = _St()
+    st.depth, st.var, st.color = eng.f32(depth), eng.f32(var), eng.f32(color)
+    st.valid_ray = valid.to(torch.uint8).to(eng.device).contiguous()
+    return st
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('stage', ('geometry', 'color'))
+def test_loss_mapper(backend, stage):
+    eng = make_engine(backend)
+    g = load(f'g6_render_replica_map_{stage}')
+    depth, var, color, gd, gc = tens(g, 'depth', 'var', 'color', 'gt_depth', 'gt_color')
+    depth = depth.clone()
+    depth[3] = float('nan')                       # NaN depth is masked (Mapper.py:692)
+    valid = torch.from_numpy(g['valid_ray'])
+    st = _fake_state(eng, depth, var, color, valid)
+    R = depth.shape[0]
+    dd, dc, out = eng.empty(R), eng.empty(R, 3), eng.empty(4)
+    optim.loss_mapper(eng, st, eng.f32(gd), eng.f32(gc), float(g['w_color']), stage == 'color', dd, dc, out)
+    dl = depth.clone().requires_grad_(True)
+    cl = color.clone().requires_grad_(True)
+    loss, geo, col, m = H.mapper_loss(dl, cl, valid, gd, gc, stage, float(g['w_color']))
+    loss.backward()
+    o = out.cpu().numpy()
+    assert abs(o[0] - loss.item()) <= 1e-5 * abs(loss.item()) and abs(o[1] - geo.item()) <= 1e-5 * abs(geo.item())
+    assert o[3] == int(m.sum())
+    np.testing.assert_allclose(dd.cpu().numpy(), torch.nan_to_num(dl.grad).numpy(), atol=0)
+    if stage == 'color':
+        np.testing.assert_allclose(dc.cpu().numpy(), cl.grad.numpy(), atol=1e-7)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_loss_tracker(backend):
+    eng = make_engine(backend)
+    g = load('g6_render_tum_track')
+    depth, var, color, gd, gc = tens(g, 'depth', 'var', 'color', 'gt_depth', 'gt_color')
+    st = _fake_state(eng, depth, var, color, torch.ones(depth.shape[0], dtype=torch.bool))
+    R = depth.shape[0]
+    dd, dc, out, scr = eng.empty(R), eng.empty(R, 3), eng.empty(4), eng.empty(R + 8)
+    optim.loss_tracker(eng, st, eng.f32(gd), eng.f32(gc), float(g['w_color']), True, dd, dc, out, scr)
+    dl = depth.clone().requires_grad_(True)
+    cl = color.clone().requires_grad_(True)
+    loss, geo, col, m = H.tracker_loss(dl, var, cl, gd, gc, float(g['w_color']))
+    loss.backward()
+    o = out.cpu().numpy()
+    assert abs(o[0] - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    assert o[3] == int(m.sum())
+    np.testing.assert_allclose(dd.cpu().numpy(), dl.grad.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dc.cpu().numpy(), cl.grad.numpy(), atol=1e-7)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_adam_matches_torch_trajectory(backend):
+    """G8: 20 steps, 3 tensors, lr switch geometry->colour, a tensor without gradient in stage 1."""
+    eng = make_engine(backend)
+    g = load('g8_adam')
+    P = [eng.f32(g[k]).clone() for k in ('dec0', 'geo0', 'col0')]
+    opt = optim.Adam(eng)
+    n_geo = int(g['n_geo_stage'])
+    for it in range(20):
+        stage_geo = it < n_geo
+        lrs = (0.001, 0.03, 0.0) if stage_geo else (0.005, 0.005, 0.005)
+        segs = []
+        for t, gk in enumerate(('gd', 'gg', 'gc')):
+            if t == 2 and stage_geo:
+                continue
+            segs.append((t, P[t].view(-1), eng.f32(g[gk][it]).view(-1), lrs[t]))
+        opt.step(segs)
+        for t, k in enumerate(('dec', 'geo', 'col')):
+            np.testing.assert_allclose(P[t].cpu().numpy(), g[k][it], rtol=3e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_pose_rays_fwd_bwd(backend):
+    eng = make_engine(backend)
+    g = load('g6_render_replica_track')
+    cam, i, j = tens(g, 'cam', 'i', 'j')
+    intr = [float(x) for x in g['intr']]
+    R = i.shape[0]
+    ro, rd = eng.empty(R, 3), eng.empty(R, 3)
+    optim.rays_from_pose(eng, eng.f32(cam), eng.f32(i), eng.f32(j), intr, ro, rd)
+    np.testing.assert_allclose(rd.cpu().numpy(), g['rays_d'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ro.cpu().numpy(), g['rays_o'], rtol=0, atol=0)
+    gc = eng.empty(7)
+    optim.pose_bwd(eng, eng.f32(cam), eng.f32(i), eng.f32(j), intr, eng.f32(g['grad_rays_o']), eng.f32(g['grad_rays_d']), gc)
+    assert relerr(gc.cpu(), g['grad_cam']) < 1e-4
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_inside_mask_and_compact(backend):
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(3)
+    for n in (1, 2, 7, 1024, 5000, 12345):
+        d = torch.rand(n, generator=gen) * 4
+        d[torch.rand(n, generator=gen) < 0.1] = 0.0
+        if n > 100:
+            d[5] = 1000.0                          # an outlier far beyond 10*median
+        pos = d[d > 0]
+        mask = eng.empty(n, dtype=torch.uint8)
+        thr = eng.empty(1)
+        optim.inside_mask(eng, eng.f32(d), mask, thr, eng.empty(n, dtype=torch.int32))
+        if pos.numel():
+            ref_thr = H.inside_threshold(pos)
+            assert float(thr.cpu()) == float(ref_thr)
+            ref_mask = (d > 0) & (d <= ref_thr)
+        else:
+            ref_mask = torch.zeros(n, dtype=torch.bool)
+        assert np.array_equal(mask.cpu().numpy().astype(bool), ref_mask.numpy())
+        idx = eng.empty(n, dtype=torch.int32)
+        cnt = eng.empty(1, dtype=torch.int32)
+        optim.compact(eng, mask, idx, cnt)
+        k = int(cnt.cpu())
+        assert k == int(ref_mask.sum())
+        assert np.array_equal(idx.cpu().numpy()[:k], torch.nonzero(ref_mask).reshape(-1).numpy())
