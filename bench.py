@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: frames/s (track+map) and rays/s on the Replica room0 work budget,
+synthetic 640x480 RGB-D, N GPUs of one node (one process per GPU, RCCL gradient all-reduce).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one frame-equivalent of the reference's budget (loopy_slam_amd/workload.py):
+40 tracking iterations x 1500 rays + 60 mapping iterations x 5000 rays (24 geometry + 36 colour),
+each iteration = ray gather, inside-mask, render forward, loss, render backward, Adam.
+Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for how roofline / cpu_baseline are obtained.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--points', type=int, default=100_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from loopy_slam_amd import core, workload, parallel, profile
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dctx = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        dctx = parallel.DistContext(rank, world)
+    eng = core.Engine()
+    budget = workload.Budget(n_points=args.points)
+    wl = workload.FrameWorkload(eng, budget, dist=dctx)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    # HIP events on the launch stream around the dominant kernel only (all kernels with BENCH_PROFILE_ALL=1)
+    prof = profile.KernelTimer(eng, '*' if os.environ.get('BENCH_PROFILE_ALL') else 'k_decode_bwd')
+    prof.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kstat = prof.stop()
+    if world > 1:
+        t = torch.tensor([dt], device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rays_per_step = budget.rays_per_frame
+    total_rays = rays_per_step * args.steps * world
+    out = {
+        'metric': 'rays/s (track+map, Replica room0 per-frame budget, 640x480 synthetic RGB-D)',
+        'value': total_rays / dt, 'unit': 'rays/s',
+        'frames_per_s': args.steps * world / dt,
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'Replica room0 budget: 40 track it x 1500 rays + 60 map it x 5000 rays per frame '
+                               '(24 geometry + 36 colour), S=5, k=8, C=32, rel-pos colour MLP, '
+                               f'N={budget.n_points} points, 640x480 synthetic room',
+                   'rays_per_step': rays_per_step, 'parallelism': f'dp{world} (ray-sharded, grad all-reduce)'},
+    }
+    if rank == 0:
+        out['roofline'] = profile.roofline_decode_bwd(kstat, budget)
+        if os.environ.get('BENCH_PROFILE_ALL'):
+            out['kernel_ms_per_step'] = {k: round(v['total_ms'] / args.steps, 3) for k, v in kstat.items()}
+        if not args.no_cpu_baseline:
+            import bench_cpu_baseline
+            out['cpu_baseline'] = bench_cpu_baseline.run(budget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

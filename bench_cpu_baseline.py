@@ -1,0 +1,77 @@
+"""cpu_baseline leg of bench.py: the CPU oracle (oracle/hotpath.py — the torch-CPU restatement of the
+reference path, kind "port") timed on the GPU box's host cores on a BOUNDED sample of the benchmark workload:
+one tracking iteration (1500 rays), one 'geometry' and one 'color' mapping iteration (5000 rays each), each
+= render forward + loss + autograd backward + torch.optim.Adam step, after one untimed warm-up of each.
+The per-frame time is extrapolated with the budget's iteration counts (40 / 24 / 36).
+This is a reported baseline, never a target, and the only place outside tests/ and smoke() that touches oracle/."""
+import os
+import time
+
+import torch
+
+
+def run(budget, seed=1219):
+    from oracle import hotpath as H
+    from loopy_slam_amd import synthetic as syn
+    from loopy_slam_amd.common import get_tensor_from_camera
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(seed)
+    W = {k: v.clone() for k, v in syn.default_weights(seed, rel_pos=budget.rel_pos).items()}
+    pos, geo, col = syn.build_cloud(budget.n_points, device='cpu', seed=seed)
+    depth, color, c2w = syn.render_frame(0, device='cpu', holes=0.02, seed=seed)
+    Hh, Ww = depth.shape
+    intr = (syn.TUM_INTR['fx'], syn.TUM_INTR['fy'], syn.TUM_INTR['cx'], syn.TUM_INTR['cy'])
+    cfg = H.RenderCfg(rel_pos=budget.rel_pos)
+    r2 = float(cfg.radius_query ** 2)
+
+    def batch(R, c2w_):
+        idx = torch.randint(0, Hh * Ww, (R,), generator=g)
+        i, j = (idx % Ww).float(), (idx // Ww).float()
+        ro, rd = H.rays_from_uv(i, j, c2w_, *intr)
+        gd, gc = depth.reshape(-1)[idx], color.reshape(-1, 3)[idx]
+        keep = gd > 0
+        keep = keep & (gd <= H.inside_threshold(gd[keep]))
+        return ro[keep], rd[keep], gd[keep], gc[keep]
+
+    def knn_for(ro, rd, gd):
+        z, _ = H.sample_z(gd, cfg.near_surface, cfg.far_surface, cfg.near_end, cfg.S)
+        p = H.sample_points(ro.detach(), rd.detach(), z)
+        return H.knn_tree(pos.numpy(), p.numpy(), 8, r2)
+
+    def map_iter(stage):
+        Wt = {k: (v.clone().requires_grad_(True) if k.startswith('color_decoder') or k == 'geo_decoder.embedder._B' else v)
+              for k, v in W.items()}
+        gp, cp = geo.clone().requires_grad_(True), col.clone().requires_grad_(True)
+        opt = torch.optim.Adam([{'params': [v for v in Wt.values() if v.requires_grad], 'lr': 0.005},
+                                {'params': [gp], 'lr': 0.005}, {'params': [cp], 'lr': 0.005}])
+        t0 = time.perf_counter()
+        ro, rd, gd, gc = batch(budget.map_rays, c2w)
+        out = H.render_batch(cfg, ro, rd, gd, pos, gp, cp, Wt, stage, knn=knn_for(ro, rd, gd))
+        loss, _, _, _ = H.mapper_loss(out['depth'], out['color'], out['valid_ray'], gd, gc, stage, 0.1)
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    def track_iter():
+        cam = get_tensor_from_camera(c2w).clone().requires_grad_(True)
+        opt = torch.optim.Adam([cam], lr=budget.cam_lr)
+        t0 = time.perf_counter()
+        ro, rd, gd, gc = batch(budget.track_rays, H.quat_to_c2w(cam))
+        out = H.render_batch(cfg, ro, rd, gd, pos, geo, col, W, 'color', tracker=True, knn=knn_for(ro, rd, gd))
+        loss, _, _, _ = H.tracker_loss(out['depth'], out['var'], out['color'], gd, gc, 0.5)
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    track_iter(); t_track = track_iter()
+    map_iter('geometry'); t_geo = map_iter('geometry')
+    map_iter('color'); t_col = map_iter('color')
+    n_col = budget.map_iters - budget.map_geo_iters
+    t_frame = budget.track_iters * t_track + budget.map_geo_iters * t_geo + n_col * t_col
+    return {'value': budget.rays_per_frame / t_frame, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 tracking iteration ({budget.track_rays} rays, {t_track:.2f} s) + 1 geometry ({t_geo:.2f} s) + 1 colour '
+                      f'({t_col:.2f} s) mapping iteration ({budget.map_rays} rays each), N={budget.n_points} points, '
+                      f'extrapolated to the {budget.track_iters}/{budget.map_geo_iters}/{n_col} per-frame budget '
+                      f'({t_frame:.1f} s/frame); torch {torch.__version__} CPU, {cores} threads',
+            'frames_per_s': 1.0 / t_frame}

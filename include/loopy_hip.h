@@ -170,9 +170,13 @@ int lk_loss_tracker(int32_t R, const float* depth, const float* var, const float
  * (Mapper.py:570,723; Tracker.py:352,194).  `step` is the 1-based step count of that tensor. */
 #define LK_ADAM_MAX_SEG 16
 typedef struct {
-    float* p; const float* g; float* m; float* v;
-    int64_t n;
+    float* p; float* g; float* m; float* v;   /* m, v: compact optimiser state of n floats */
+    int64_t n;                                /* elements updated by this segment */
     float lr; int32_t step;
+    const int32_t* row_index;                 /* optional: element i lives at p[row_index[i/row_len]*row_len + i%row_len]
+                                                 (frustum-selected feature rows updated in place in the full table) */
+    int32_t row_len;
+    int32_t zero_grad;                        /* clear the consumed gradient entries */
 } lk_adam_seg;
 int lk_adam_step(const lk_adam_seg* host_segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream);
 
@@ -180,6 +184,16 @@ int lk_adam_step(const lk_adam_seg* host_segs, int32_t n_seg, float beta1, float
  * get_camera_from_tensor + get_rays_from_uv (src/common.py:301-343,104-120): cam = (qw,qx,qy,qz,tx,ty,tz). */
 int lk_rays_from_pose(const float* cam7, const float* pix_i, const float* pix_j, int32_t R,
                       float fx, float fy, float cx, float cy, float* rays_o, float* rays_d, void* stream);
+/* One launch for a multi-keyframe ray batch: get_samples/get_sample_uv/select_uv/get_rays_from_uv
+ * (src/common.py:104-172,237-259; Mapper.py:625-665, Tracker.py:142-146).  Ray r reads frame frame_id[r]
+ * (NULL: frame 0) of the stacked images at window pixel rnd[r] in [0, h*w) (row-major over the window
+ * [H0,H0+h) x [W0,W0+w)); c2w_stack holds row-major [3|4][4] matrices, c2w_stride floats apart.
+ * pix_i/pix_j/r2_ray/r2_map_stack/frame_id may be NULL. */
+int lk_gather_rays(const float* depth_stack, const float* color_stack, const float* c2w_stack, int32_t c2w_stride,
+                   const float* r2_map_stack, const int32_t* frame_id, const int32_t* rnd, int32_t R,
+                   int32_t H, int32_t W, int32_t H0, int32_t W0, int32_t w, float fx, float fy, float cx, float cy,
+                   float* rays_o, float* rays_d, float* gt_depth, float* gt_color, float* pix_i, float* pix_j,
+                   float* r2_ray, void* stream);
 /* d loss / d cam7 from d rays (overwrites g_cam7[7]). */
 int lk_pose_bwd(const float* cam7, const float* pix_i, const float* pix_j, int32_t R,
                 float fx, float fy, float cx, float cy, const float* g_rays_o, const float* g_rays_d,
@@ -187,8 +201,18 @@ int lk_pose_bwd(const float* cam7, const float* pix_i, const float* pix_j, int32
 /* Stable stream compaction (wave ballot + prefix sum): out_index[0..count) = i with mask[i]!=0. */
 int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, void* stream);
 /* thr = min(10*median(depth), 1.2*max(depth)) over depth>0 (Tracker.py:153-155, Mapper.py:674-676);
- * mask[i] = depth[i] > 0 && depth[i] <= thr.  scratch: n uint32. */
-int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* out_thr, uint32_t* scratch, void* stream);
+ * mask[i] = depth[i] > 0 && depth[i] <= thr (mask may be NULL); depth_filtered[i] = mask ? depth : 0 (may be
+ * NULL or alias depth): a ray with gt_depth 0 is "absent" for the losses, which keeps the batch shape static
+ * (no host sync) while matching the reference's boolean-index filtering.  scratch: n uint32. */
+int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* depth_filtered, float* out_thr,
+                   uint32_t* scratch, void* stream);
+
+/* ---------------------------------------------------------------- measurement
+ * Per-kernel GPU time with HIP events recorded on the launch stream around the selected kernels
+ * (names: comma-separated, e.g. "k_decode_bwd", or "*").  lk_profile_end synchronises those events and writes
+ * "name calls total_ms" lines into buf.  Used by bench.py for the roofline figure. */
+int lk_profile_begin(const char* names);
+int lk_profile_end(char* buf, int cap);
 
 #ifdef __cplusplus
 }

@@ -54,7 +54,7 @@ class RenderDesc(C.Structure):
 
 class AdamSeg(C.Structure):
     _fields_ = [('p', _fp), ('g', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int64), ('lr', C.c_float),
-                ('step', C.c_int32)]
+                ('step', C.c_int32), ('row_index', _fp), ('row_len', C.c_int32), ('zero_grad', C.c_int32)]
 
 
 class LoopyError(RuntimeError):
@@ -97,8 +97,13 @@ class LoopyLib:
             ('lk_adam_step', [C.POINTER(AdamSeg), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p], C.c_int),
             ('lk_rays_from_pose', [_fp, _fp, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_pose_bwd', [_fp, _fp, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_gather_rays', [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                C.c_void_p], C.c_int),
+            ('lk_profile_begin', [C.c_char_p], C.c_int),
+            ('lk_profile_end', [C.c_char_p, C.c_int], C.c_int),
             ('lk_compact', [_fp, C.c_int32, _fp, _fp, C.c_void_p], C.c_int),
-            ('lk_inside_mask', [_fp, C.c_int32, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_inside_mask', [_fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
         ):
             if hasattr(d, name):
                 fn = getattr(d, name)

@@ -304,3 +304,72 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     LK_LAUNCH_CHECK();
     return LK_OK;
 }
+
+// ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
+#include <vector>
+#include <string>
+namespace {
+const char* kKernelNames[LKK_COUNT] = {"k_depth_stats", "k_sample_interp", "k_relpos_fwd", "k_decode_fwd", "k_composite",
+                                       "k_composite_bwd", "k_decode_bwd", "k_relpos_bwd", "k_interp_bwd", "k_rays_bwd", "k_wgrad"};
+struct ProfState {
+    bool on = false;
+    bool enabled[LKK_COUNT] = {};
+    std::vector<hipEvent_t> ev0[LKK_COUNT], ev1[LKK_COUNT];
+};
+ProfState g_prof;
+}  // namespace
+
+void lk_prof_before(int kid, hipStream_t st) {
+    if (!g_prof.on || !g_prof.enabled[kid]) return;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+    g_prof.ev0[kid].push_back(e0);
+    g_prof.ev1[kid].push_back(e1);
+    (void)hipEventRecord(e0, st);
+}
+void lk_prof_after(int kid, hipStream_t st) {
+    if (!g_prof.on || !g_prof.enabled[kid] || g_prof.ev1[kid].empty()) return;
+    (void)hipEventRecord(g_prof.ev1[kid].back(), st);
+}
+
+/* names: comma-separated kernel names, or "*" for all */
+extern "C" int lk_profile_begin(const char* names) {
+    LK_REQUIRE(names != nullptr, "lk_profile_begin: NULL names");
+    const std::string s(names);
+    for (int k = 0; k < LKK_COUNT; ++k) {
+        g_prof.enabled[k] = (s == "*") || (("," + s + ",").find(std::string(",") + kKernelNames[k] + ",") != std::string::npos);
+        g_prof.ev0[k].clear();
+        g_prof.ev1[k].clear();
+    }
+    g_prof.on = true;
+    return LK_OK;
+}
+
+/* Synchronises the recorded events; writes "name calls total_ms\n" lines into buf. */
+extern "C" int lk_profile_end(char* buf, int cap) {
+    g_prof.on = false;
+    std::string out;
+    for (int k = 0; k < LKK_COUNT; ++k) {
+        double total = 0.0;
+        const size_t n = g_prof.ev0[k].size();
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.0f;
+            (void)hipEventSynchronize(g_prof.ev1[k][i]);
+            if (hipEventElapsedTime(&ms, g_prof.ev0[k][i], g_prof.ev1[k][i]) == hipSuccess) total += ms;
+            (void)hipEventDestroy(g_prof.ev0[k][i]);
+            (void)hipEventDestroy(g_prof.ev1[k][i]);
+        }
+        g_prof.ev0[k].clear();
+        g_prof.ev1[k].clear();
+        if (n) {
+            char line[160];
+            snprintf(line, sizeof(line), "%s %zu %.6f\n", kKernelNames[k], n, total);
+            out += line;
+        }
+    }
+    if (buf && cap > 0) {
+        strncpy(buf, out.c_str(), (size_t)cap - 1);
+        buf[cap - 1] = 0;
+    }
+    return LK_OK;
+}

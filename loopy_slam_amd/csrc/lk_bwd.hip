@@ -303,10 +303,12 @@ __global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a) {
 }
 
 int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_COMPOSITE_BWD, st);
     hipLaunchKernelGGL(k_composite_bwd, dim3(lk_cdiv(a.R, 256)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_DECODE_BWD, st);
     const int waves = lk_cdiv(a.P, 32);
     hipLaunchKernelGGL(k_decode_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;

@@ -360,19 +360,23 @@ __global__ __launch_bounds__(64) void k_wgrad(LkWgradArgs a) {
 }
 
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_INTERP_BWD, st);
     hipLaunchKernelGGL(k_interp_bwd, dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_RAYS_BWD, st);
     hipLaunchKernelGGL(k_rays_bwd, dim3(lk_cdiv(a.R, 256)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_RELPOS_BWD, st);
     const int waves = lk_cdiv(a.P, 4);
     hipLaunchKernelGGL(k_relpos_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st) {
+    LkProfScope prof_(LKK_WGRAD, st);
     int items = 0;
     for (int j = 0; j < a.n_jobs; ++j) items += (a.job[j].N + 31) / 32;
     if (items == 0 || max_rows <= 0) return LK_OK;

@@ -339,11 +339,13 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
 }
 
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_DECODE_FWD, st);
     const int waves = lk_cdiv(a.P, 32);
     hipLaunchKernelGGL(k_decode_fwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_RELPOS_FWD, st);
     const int waves = lk_cdiv(a.P, 4);
     hipLaunchKernelGGL(k_relpos_fwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;

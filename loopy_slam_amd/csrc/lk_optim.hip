@@ -64,13 +64,18 @@ __global__ __launch_bounds__(256) void k_loss_tracker_pass1(int R, const float* 
                                                             const float* __restrict__ gt_depth, float* __restrict__ scratch) {
     __shared__ float sh[4];
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
-    float t = 0.0f;
+    // Rays with gt_depth <= 0 are "absent": the reference filters them out BEFORE rendering
+    // (get_samples depth_filter + inside mask, Tracker.py:142-160), so they take no part in the mean.
+    float t = 0.0f, c = 0.0f;
     if (r < R) {
-        t = fabsf(gt_depth[r] - depth[r]) / sqrtf(var[r] + 1e-10f);
+        const bool present = gt_depth[r] > 0.0f;
+        t = present ? fabsf(gt_depth[r] - depth[r]) / sqrtf(var[r] + 1e-10f) : 0.0f;
+        c = present ? 1.0f : 0.0f;
         scratch[r] = t;
     }
     t = block_sum_256(t, sh);
-    if (threadIdx.x == 0) atomicAdd(scratch + R, t);
+    c = block_sum_256(c, sh);
+    if (threadIdx.x == 0) { atomicAdd(scratch + R, t); atomicAdd(scratch + R + 1, c); }
 }
 
 __global__ __launch_bounds__(256) void k_loss_tracker_pass2(int R, const float* __restrict__ depth, const float* __restrict__ var,
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void k_loss_tracker_pass2(int R, const float* 
                                                             float* __restrict__ d_color, float* __restrict__ out) {
     __shared__ float sh[4];
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
-    const float thr = 10.0f * (scratch[R] / (float)R);
+    const float thr = 10.0f * (scratch[R] / fmaxf(scratch[R + 1], 1.0f));
     float geo = 0.0f, col = 0.0f, cnt = 0.0f;
     if (r < R) {
         const float d = depth[r], v = var[r], g = gt_depth[r], t = scratch[r];
@@ -110,20 +115,32 @@ __global__ __launch_bounds__(256) void k_loss_tracker_pass2(int R, const float* 
 }
 
 // ------------------------------------------------------------------ Adam
-struct AdamSegDev { float* p; const float* g; float* m; float* v; long long n; float step_size, bc2_sqrt; };
+struct AdamSegDev {
+    float* p; float* g; float* m; float* v; long long n; float step_size, bc2_sqrt;
+    const int32_t* row_index; int row_len; int zero_grad;
+};
 struct AdamArgs { AdamSegDev s[LK_ADAM_MAX_SEG]; int n_seg; float beta1, beta2, eps; };
 
+// Element i of a segment is p[i] — or, with a row index (frustum-selected feature rows optimised in place in
+// the full table, Mapper.py:498-512,578-586), p[row_index[i / row_len] * row_len + i % row_len]; m and v are
+// always compact.  zero_grad clears the consumed gradient so the next iteration's scatter-add starts from 0.
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const AdamSegDev S = a.s[blockIdx.y];
     const float b1 = a.beta1, b2 = a.beta2, om1 = 1.0f - a.beta1, om2 = 1.0f - a.beta2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < S.n; i += (long long)gridDim.x * 256) {
-        const float g = S.g[i];
+        long long e = i;
+        if (S.row_index) {
+            const long long row = i / S.row_len;
+            e = (long long)S.row_index[row] * S.row_len + (i - row * S.row_len);
+        }
+        const float g = S.g[e];
         const float m = S.m[i] * b1 + om1 * g;              // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
         const float v = S.v[i] * b2 + om2 * (g * g);        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
         const float denom = sqrtf(v) / S.bc2_sqrt + a.eps;  // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
         S.m[i] = m;
         S.v[i] = v;
-        S.p[i] = S.p[i] - S.step_size * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-lr/bias_correction1)
+        S.p[e] = S.p[e] - S.step_size * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-lr/bias_correction1)
+        if (S.zero_grad) S.g[e] = 0.0f;
     }
 }
 
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(1024) void k_compact(const uint8_t* __restrict__ ma
 }
 
 // ------------------------------------------------------------------ inside mask: thr = min(10*median(d>0), 1.2*max)
-__global__ __launch_bounds__(1024) void k_inside_mask(const float* __restrict__ depth, int n, uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n, uint8_t* __restrict__ mask, float* depth_filtered,
                                                       float* __restrict__ out_thr, uint32_t* __restrict__ scratch) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_rank, s_cnt, s_maxbits;
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* __restrict__ 
     __syncthreads();
     const unsigned m = s_cnt;
     if (m == 0) {
-        for (int i = t; i < n; i += 1024) mask[i] = 0;
+        for (int i = t; i < n; i += 1024) { if (mask) mask[i] = 0; if (depth_filtered) depth_filtered[i] = 0.0f; }
         if (t == 0) *out_thr = 0.0f;
         return;
     }
@@ -268,7 +285,12 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* __restrict__ 
     const float med = __uint_as_float(s_prefix);
     const float mx = __uint_as_float(s_maxbits);
     const float thr = fminf(10.0f * med, 1.2f * mx);
-    for (int i = t; i < n; i += 1024) { const float d = depth[i]; mask[i] = (d > 0.0f && d <= thr) ? 1 : 0; }
+    for (int i = t; i < n; i += 1024) {
+        const float d = depth[i];
+        const bool in = d > 0.0f && d <= thr;
+        if (mask) mask[i] = in ? 1 : 0;
+        if (depth_filtered) depth_filtered[i] = in ? d : 0.0f;      // rejected rays become "absent" (gt_depth = 0)
+    }
     if (t == 0) *out_thr = thr;
 }
 
@@ -295,7 +317,7 @@ extern "C" int lk_loss_tracker(int32_t R, const float* depth, const float* var, 
     LK_HIP_TRY(hipMemsetAsync(out_loss, 0, 4 * sizeof(float), st));
     if (R == 0) return LK_OK;
     LK_REQUIRE(depth && var && color && gt_depth && gt_color && d_depth && d_color, "lk_loss_tracker: NULL buffer");
-    LK_HIP_TRY(hipMemsetAsync(scratch + R, 0, sizeof(float), st));
+    LK_HIP_TRY(hipMemsetAsync(scratch + R, 0, 2 * sizeof(float), st));
     hipLaunchKernelGGL(k_loss_tracker_pass1, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, gt_depth, scratch);
     hipLaunchKernelGGL(k_loss_tracker_pass2, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, color, gt_depth,
                        gt_color, w_color, (int)use_color, (const float*)scratch, d_depth, d_color, out_loss);
@@ -316,6 +338,8 @@ extern "C" int lk_adam_step(const lk_adam_seg* segs, int32_t n_seg, float beta1,
         const double bc1 = 1.0 - pow((double)beta1, (double)segs[i].step);
         const double bc2 = 1.0 - pow((double)beta2, (double)segs[i].step);
         a.s[i].p = segs[i].p; a.s[i].g = segs[i].g; a.s[i].m = segs[i].m; a.s[i].v = segs[i].v; a.s[i].n = segs[i].n;
+        a.s[i].row_index = segs[i].row_index; a.s[i].row_len = segs[i].row_len > 0 ? segs[i].row_len : 1;
+        a.s[i].zero_grad = segs[i].zero_grad;
         a.s[i].step_size = (float)((double)segs[i].lr / bc1);
         a.s[i].bc2_sqrt = (float)sqrt(bc2);
         if (segs[i].n > nmax) nmax = segs[i].n;
@@ -359,11 +383,62 @@ extern "C" int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, in
     return LK_OK;
 }
 
-extern "C" int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* out_thr, uint32_t* scratch, void* stream_) {
+extern "C" int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* depth_filtered, float* out_thr,
+                              uint32_t* scratch, void* stream_) {
     LK_REQUIRE(n >= 0 && out_thr, "lk_inside_mask: bad arguments");
     if (n == 0) return LK_OK;
-    LK_REQUIRE(depth && mask && scratch, "lk_inside_mask: NULL buffer");
-    hipLaunchKernelGGL(k_inside_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream_, depth, (int)n, mask, out_thr, scratch);
+    LK_REQUIRE(depth && scratch && (mask || depth_filtered), "lk_inside_mask: NULL buffer");
+    hipLaunchKernelGGL(k_inside_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream_, depth, (int)n, mask, depth_filtered, out_thr, scratch);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------ ray batch from stacked keyframes
+// get_samples / get_sample_uv / select_uv / get_rays_from_uv (common.py:104-172, 237-259) for a whole
+// multi-keyframe batch in one launch: ray r looks at frame frame_id[r], window pixel rnd[r] (row-major over
+// [H0,H0+h) x [W0,W0+w)), and gets its depth, colour, (optional) squared query radius and world ray.
+struct GatherArgs {
+    const float* depth; const float* color; const float* c2w; const float* r2_map;
+    const int32_t* frame_id; const int32_t* rnd;
+    int R, H, W, H0, W0, w, c2w_stride;
+    float fx, fy, cx, cy;
+    float* rays_o; float* rays_d; float* gt_depth; float* gt_color; float* pix_i; float* pix_j; float* r2_ray;
+};
+
+__global__ __launch_bounds__(256) void k_gather_rays(GatherArgs a) {
+    const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    if (r >= a.R) return;
+    const int f = a.frame_id ? a.frame_id[r] : 0;
+    const int q = a.rnd[r];
+    const int i = a.W0 + q % a.w, j = a.H0 + q / a.w;
+    const size_t pix = ((size_t)f * a.H + j) * a.W + i;
+    a.gt_depth[r] = a.depth[pix];
+    a.gt_color[3 * r] = a.color[3 * pix]; a.gt_color[3 * r + 1] = a.color[3 * pix + 1]; a.gt_color[3 * r + 2] = a.color[3 * pix + 2];
+    if (a.r2_ray) a.r2_ray[r] = a.r2_map ? a.r2_map[pix] : 0.0f;
+    if (a.pix_i) { a.pix_i[r] = (float)i; a.pix_j[r] = (float)j; }
+    const float* M = a.c2w + (size_t)f * a.c2w_stride;             // row-major [3 or 4][4]
+    const float d0 = ((float)i - a.cx) / a.fx, d1 = -((float)j - a.cy) / a.fy, d2 = -1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.rays_d[3 * r + c] = (d0 * M[4 * c] + d1 * M[4 * c + 1]) + d2 * M[4 * c + 2];
+        a.rays_o[3 * r + c] = M[4 * c + 3];
+    }
+}
+
+extern "C" int lk_gather_rays(const float* depth_stack, const float* color_stack, const float* c2w_stack, int32_t c2w_stride,
+                              const float* r2_map_stack, const int32_t* frame_id, const int32_t* rnd, int32_t R,
+                              int32_t H, int32_t W, int32_t H0, int32_t W0, int32_t w, float fx, float fy, float cx, float cy,
+                              float* rays_o, float* rays_d, float* gt_depth, float* gt_color, float* pix_i, float* pix_j,
+                              float* r2_ray, void* stream_) {
+    LK_REQUIRE(R >= 0 && w > 0, "lk_gather_rays: bad sizes");
+    if (R == 0) return LK_OK;
+    LK_REQUIRE(depth_stack && color_stack && c2w_stack && rnd && rays_o && rays_d && gt_depth && gt_color, "lk_gather_rays: NULL buffer");
+    GatherArgs a;
+    a.depth = depth_stack; a.color = color_stack; a.c2w = c2w_stack; a.r2_map = r2_map_stack; a.frame_id = frame_id; a.rnd = rnd;
+    a.R = R; a.H = H; a.W = W; a.H0 = H0; a.W0 = W0; a.w = w; a.c2w_stride = c2w_stride;
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.gt_depth = gt_depth; a.gt_color = gt_color; a.pix_i = pix_i; a.pix_j = pix_j; a.r2_ray = r2_ray;
+    hipLaunchKernelGGL(k_gather_rays, dim3(lk_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream_, a);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

@@ -146,14 +146,17 @@ __global__ __launch_bounds__(256) void k_composite(LkCompositeArgs a) {
 }
 
 int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st) {
+    LkProfScope prof_(LKK_DEPTH_STATS, st);
     hipLaunchKernelGGL(k_depth_stats, dim3(lk_cdiv(R, chunk)), dim3(256), 0, st, gt, R, chunk, far_out);
     return LK_OK;
 }
 int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_SAMPLE_INTERP, st);
     hipLaunchKernelGGL(k_sample_interp, dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_COMPOSITE, st);
     hipLaunchKernelGGL(k_composite, dim3(lk_cdiv(a.R, 256)), dim3(256), 0, st, a);
     return LK_OK;
 }

@@ -34,19 +34,28 @@ class Adam:
         self.eng, self.beta1, self.beta2, self.eps = eng, beta1, beta2, eps
         self.state = {}
 
-    def step(self, segs):
-        """segs: list of (key, param, grad, lr).  param/grad: contiguous fp32 tensors of equal numel."""
+    def step(self, segs, zero_grad=False):
+        """segs: list of (key, param, grad, lr) or (key, table, grad_table, lr, row_index).
+        Without row_index param/grad are contiguous fp32 tensors of equal numel; with row_index
+        (int32 [n_rows]) the rows table[row_index] of a [N, row_len] table are updated in place."""
         assert len(segs) <= _ffi.ADAM_MAX_SEG
         arr = (AdamSeg * max(1, len(segs)))()
         keep = []
-        for k, (key, p, g, lr) in enumerate(segs):
+        for k, seg in enumerate(segs):
+            key, p, g, lr = seg[:4]
+            rows = seg[4] if len(seg) > 4 else None
+            n = p.numel() if rows is None else rows.numel() * p.shape[1]
             st = self.state.get(key)
             if st is None:
-                st = self.state[key] = dict(m=torch.zeros_like(p), v=torch.zeros_like(p), step=0)
+                st = self.state[key] = dict(m=torch.zeros(n, dtype=torch.float32, device=p.device),
+                                            v=torch.zeros(n, dtype=torch.float32, device=p.device), step=0)
+            assert st['m'].numel() == n
             st['step'] += 1
             arr[k].p, arr[k].g, arr[k].m, arr[k].v = ptr(p), ptr(g), ptr(st['m']), ptr(st['v'])
-            arr[k].n, arr[k].lr, arr[k].step = p.numel(), lr, st['step']
-            keep.append((p, g))
+            arr[k].n, arr[k].lr, arr[k].step = n, lr, st['step']
+            arr[k].row_index, arr[k].row_len = ptr(rows), (p.shape[1] if rows is not None else 1)
+            arr[k].zero_grad = int(bool(zero_grad))
+            keep.append((p, g, rows))
         self.eng.lib.check(self.eng.lib.dll.lk_adam_step(arr, len(segs), C.c_float(self.beta1), C.c_float(self.beta2),
                                                          C.c_float(self.eps), self.eng.stream), 'lk_adam_step')
 
@@ -65,10 +74,24 @@ def pose_bwd(eng, cam7, pix_i, pix_j, intr, g_rays_o, g_rays_d, g_cam7):
                                           eng.stream), 'lk_pose_bwd')
 
 
-def inside_mask(eng, depth, mask, thr, scratch):
-    eng.lib.check(eng.lib.dll.lk_inside_mask(ptr(depth), depth.shape[0], ptr(mask), ptr(thr), ptr(scratch), eng.stream),
-                  'lk_inside_mask')
+def inside_mask(eng, depth, mask, thr, scratch, depth_filtered=None):
+    eng.lib.check(eng.lib.dll.lk_inside_mask(ptr(depth), depth.shape[0], ptr(mask), ptr(depth_filtered), ptr(thr), ptr(scratch),
+                                             eng.stream), 'lk_inside_mask')
 
 
 def compact(eng, mask, out_index, out_count):
     eng.lib.check(eng.lib.dll.lk_compact(ptr(mask), mask.shape[0], ptr(out_index), ptr(out_count), eng.stream), 'lk_compact')
+
+
+def gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, window, intr, out, r2_map_stack=None):
+    """out: dict(rays_o, rays_d, gt_depth, gt_color[, pix_i, pix_j, r2_ray]); window = (H0, H1, W0, W1)."""
+    H0, H1, W0, W1 = window
+    fx, fy, cx, cy = intr
+    R = rnd.shape[0]
+    stride = c2w_stack.shape[-2] * 4
+    eng.lib.check(eng.lib.dll.lk_gather_rays(ptr(depth_stack), ptr(color_stack), ptr(c2w_stack), stride, ptr(r2_map_stack),
+                                             ptr(frame_id), ptr(rnd), R, H, W, H0, W0, W1 - W0,
+                                             C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                             ptr(out['rays_o']), ptr(out['rays_d']), ptr(out['gt_depth']), ptr(out['gt_color']),
+                                             ptr(out.get('pix_i')), ptr(out.get('pix_j')), ptr(out.get('r2_ray')), eng.stream),
+                  'lk_gather_rays')

@@ -1,0 +1,94 @@
+"""The benchmark workload: one "frame-equivalent" of the reference's per-frame work budget on a
+synthetic 640x480 RGB-D room.
+
+Replica room0 budget (configs/Replica/replica.yaml:21-22,25,33,36-37; configs/point_slam.yaml:92):
+  tracking  40 iterations x 1500 rays   every frame
+  mapping   300 iterations x 5000 rays  every 5th frame  -> 60 iterations per frame,
+            geo_iter_ratio 0.4 -> 24 'geometry' + 36 'color' iterations
+  => 360 000 rays per frame, S = 5 samples per ray, rel-pos colour MLP on, static radius 0.08.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import core, steps, synthetic as syn
+from .common import get_tensor_from_camera
+
+
+@dataclass
+class Budget:
+    name: str = 'replica_room0'
+    track_iters: int = 40
+    track_rays: int = 1500
+    map_iters: int = 60
+    map_geo_iters: int = 24
+    map_rays: int = 5000
+    n_points: int = 100_000
+    window: int = 12                      # mapping_window_size keyframes sampled per iteration
+    ignore_edge: int = 100                # tracking.ignore_edge_W/H on Replica (scaled image: see below)
+    cam_lr: float = 0.002
+    rel_pos: bool = True
+
+    @property
+    def rays_per_frame(self):
+        return self.track_iters * self.track_rays + self.map_iters * self.map_rays
+
+
+MAP_LRS = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}     # mapping.stage.* (replica.yaml)
+
+
+class FrameWorkload:
+    """Device-resident scene + the two optimisers; step() = track one frame + its share of mapping."""
+
+    def __init__(self, eng, budget=None, seed=1219, dist=None):
+        self.eng, self.b = eng, budget or Budget()
+        b = self.b
+        dev = eng.device
+        self.intr = (syn.TUM_INTR['fx'], syn.TUM_INTR['fy'], syn.TUM_INTR['cx'], syn.TUM_INTR['cy'])
+        self.H, self.W = syn.TUM_INTR['H'], syn.TUM_INTR['W']
+        self.cfg = core.RenderCfg(rel_pos=b.rel_pos)
+        self.dec = core.DecoderBlob(eng).pack(syn.default_weights(seed, rel_pos=b.rel_pos))
+        pos, geo, col = syn.build_cloud(b.n_points, device='cpu', seed=seed)
+        self.pos, self.geo, self.col = pos.to(dev), geo.to(dev), col.to(dev)
+        self.knn = core.KnnIndex(eng, capacity=b.n_points)
+        self.knn.build(self.pos)
+        # keyframe window: stacked depth / colour / pose
+        ds, cs, ps = [], [], []
+        for k in range(b.window):
+            d, c, p = syn.render_frame(3 * k, device=dev, holes=0.02, seed=seed)
+            ds.append(d); cs.append(c); ps.append(p)
+        self.depth_stack = torch.stack(ds).contiguous()
+        self.color_stack = torch.stack(cs).contiguous()
+        self.c2w_stack = torch.stack(ps).contiguous()
+        self.frames = (self.depth_stack, self.color_stack, self.c2w_stack, None)
+        # frustum row selection stand-in: all rows (the frustum test itself is a §8f 'next' row)
+        self.rows = torch.arange(b.n_points, dtype=torch.int32, device=dev)
+        self.mapper = steps.MapOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col, self.rows,
+                                         b.map_rays, MAP_LRS, w_color=0.1, dist=dist)
+        self.tracker = steps.TrackOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col,
+                                            b.track_rays, b.cam_lr, separate_lr=True, w_color=0.5)
+        self.gen = torch.Generator(device='cpu').manual_seed(seed + (dist.rank if dist is not None else 0))
+        self.cam0 = get_tensor_from_camera(self.c2w_stack[0]).to(dev)
+        self.map_log = eng.zeros(b.map_iters, 4)
+        self.frame_no = 0
+
+    def _draws(self, iters, R, n):
+        return torch.randint(0, n, (iters, R), generator=self.gen, dtype=torch.int32).to(self.eng.device)
+
+    def step(self):
+        """One frame-equivalent: 40 tracking iterations + 60 mapping iterations (24 geometry + 36 colour)."""
+        b, eng = self.b, self.eng
+        H, W = self.H, self.W
+        e = min(b.ignore_edge, H // 4)
+        win = (e, H - e, e, W - e)
+        rnd_t = self._draws(b.track_iters, b.track_rays, (win[1] - win[0]) * (win[3] - win[2]))
+        k = self.frame_no % b.window
+        best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win, self.intr, rnd_t)
+        rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
+        fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(eng.device)      # pixels // window frames each
+        self.mapper.begin_frame()
+        for it in range(b.map_iters):
+            stage = 'geometry' if it < b.map_geo_iters else 'color'
+            self.mapper.iterate(stage, self.frames, rnd_m[it], fid, (0, H, 0, W), self.intr, H, W, log_row=self.map_log[it])
+        self.frame_no += 1
+        return best, tlog, self.map_log

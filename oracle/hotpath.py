@@ -357,3 +357,29 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
     p.addcdiv_(m, denom, value=-(lr / bc1))
     return p
+
+
+def knn_tree(points, queries, k, r2):
+    """Same contract as knn_exact for large clouds (CPU baseline timing): a KD-tree proposes the k nearest
+    within the radius, distances are then recomputed in fp32 with the contract's formula and re-ordered by
+    (d2, index).  (Only differs from knn_exact if fp64 and fp32 orderings disagree at the k-th neighbour.)"""
+    from scipy.spatial import cKDTree
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(-1, 3))
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(-1, 3))
+    P = q.shape[0]
+    r2a = np.broadcast_to(np.asarray(r2, dtype=np.float32).reshape(-1), (P,)) if np.ndim(r2) else np.full((P,), np.float32(r2), np.float32)
+    tree = cKDTree(pts.astype(np.float64))
+    rmax = float(np.sqrt(r2a.max())) * 1.001
+    _, ii = tree.query(q.astype(np.float64), k=k, distance_upper_bound=rmax, workers=-1)
+    ok = ii < pts.shape[0]
+    I = np.where(ok, ii, 0)
+    d = pts[I] - q[:, None, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    ok &= d2 <= r2a[:, None]
+    d2 = np.where(ok, d2, np.float32(np.inf)).astype(np.float32)
+    key = np.lexsort((np.where(ok, ii, np.iinfo(np.int64).max), d2), axis=1)
+    d2 = np.take_along_axis(d2, key, 1)
+    idx = np.take_along_axis(np.where(ok, ii, -1), key, 1).astype(np.int32)
+    okk = np.isfinite(d2)
+    cnt = (okk & (d2 < r2a[:, None])).sum(1).astype(np.int32)
+    return np.where(okk, d2, np.float32(FLT_MAX)).astype(np.float32), idx, cnt

@@ -1,0 +1,170 @@
+"""End-to-end parity of the per-frame optimisation loops (loopy_slam_amd.steps) against an oracle loop
+written with torch autograd + torch.optim.Adam over the oracle's render (oracle/hotpath.py), i.e. the
+reference's Mapper.optimize_map / Tracker.optimize_cam_in_batch inner loops on a miniature scene."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hotpath as H
+from loopy_slam_amd import core, steps, synthetic as syn
+from util import make_engine, backends, relerr
+
+torch.set_num_threads(1)
+HH, WW = 24, 32
+INTR = (40.0, 40.0, 15.5, 11.5)
+
+
+def mini_scene(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    c2w = torch.eye(4)
+    c2w[:3, 3] = torch.tensor([0.1, -0.05, 0.2])
+    jj, ii = torch.meshgrid(torch.arange(HH, dtype=torch.float32), torch.arange(WW, dtype=torch.float32), indexing='ij')
+    ro, rd = H.rays_from_uv(ii.reshape(-1), jj.reshape(-1), c2w, *INTR)
+    depth = (1.0 + 0.15 * torch.sin(ii / 5.0) * torch.cos(jj / 4.0)).reshape(-1)
+    depth[::17] = 0.0                                   # holes
+    depth[5] = 40.0                                     # outlier beyond the inside mask
+    color = torch.rand(HH * WW, 3, generator=g)
+    pts = []
+    ok = (depth > 0) & (depth < 10)
+    for t in (0.98, 1.0, 1.02):
+        pts.append((ro + rd * (depth * t)[:, None])[ok] + 0.004 * torch.randn(int(ok.sum()), 3, generator=g))
+    pos = torch.cat(pts).float().contiguous()
+    geo = (0.1 * torch.randn(pos.shape[0], 32, generator=g)).float()
+    col = (0.1 * torch.randn(pos.shape[0], 32, generator=g)).float()
+    return c2w, depth.reshape(HH, WW), color.reshape(HH, WW, 3), pos, geo, col
+
+
+def oracle_rays(c2w, depth_img, color_img, rnd):
+    i = (rnd % WW).float()
+    j = (rnd // WW).float()
+    ro, rd = H.rays_from_uv(i, j, c2w, *INTR)
+    gd = depth_img.reshape(-1)[rnd.long()]
+    gc = color_img.reshape(-1, 3)[rnd.long()]
+    return ro, rd, gd, gc, i, j
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('rel_pos', (True, False))
+def test_map_iterations_match_oracle(backend, rel_pos):
+    eng = make_engine(backend)
+    c2w, depth_img, color_img, pos, geo, col = mini_scene()
+    W = syn.default_weights(seed=7)
+    R, iters = 96, 3
+    g = torch.Generator().manual_seed(11)
+    rnd_all = torch.randint(0, HH * WW, (iters, R), generator=g, dtype=torch.int32)
+    rows = torch.arange(0, pos.shape[0], 2, dtype=torch.int32)               # "frustum" = every other point
+    lrs = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
+    stages = ['geometry', 'color', 'color']
+    # ---------------- oracle loop (reference semantics: params = clones of the selected rows)
+    ocfg = H.RenderCfg(rel_pos=rel_pos)
+    Wt = {k: v.clone() for k, v in W.items()}
+    dec_names = list(steps.GEO_DECODER_PARAMS) + [n for n in steps.COLOR_DECODER_PARAMS]
+    for n in dec_names:
+        Wt[n].requires_grad_(True)
+    geo_o, col_o = geo.clone(), col.clone()
+    geo_p = geo_o[rows.long()].clone().requires_grad_(True)
+    col_p = col_o[rows.long()].clone().requires_grad_(True)
+    opt = torch.optim.Adam([{'params': [Wt[n] for n in dec_names], 'lr': 0}, {'params': [geo_p], 'lr': 0}, {'params': [col_p], 'lr': 0}])
+    o_losses = []
+    for it in range(iters):
+        stage = stages[it]
+        for gi in range(3):
+            opt.param_groups[gi]['lr'] = lrs[stage][gi]
+        opt.zero_grad()
+        geo_t = geo_o.clone(); geo_t[rows.long()] = geo_p
+        col_t = col_o.clone(); col_t[rows.long()] = col_p
+        ro, rd, gd, gc, _, _ = oracle_rays(c2w, depth_img, color_img, rnd_all[it])
+        keep = gd > 0
+        thr = H.inside_threshold(gd[keep])
+        keep = keep & (gd <= thr)
+        out = H.render_batch(ocfg, ro[keep], rd[keep], gd[keep], pos, geo_t, col_t, Wt, stage)
+        loss, _, _, _ = H.mapper_loss(out['depth'], out['color'], out['valid_ray'], gd[keep], gc[keep], stage, 0.1)
+        loss.backward()
+        opt.step()
+        o_losses.append(loss.item())
+    # ---------------- kernels
+    cfg = core.RenderCfg(rel_pos=rel_pos)
+    dec = core.DecoderBlob(eng).pack(W)
+    pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
+    knn = core.KnnIndex(eng, capacity=pos.shape[0])
+    knn.build(pos_d)
+    mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, rows.to(eng.device), R, lrs, w_color=0.1)
+    mo.begin_frame()
+    frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
+    fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
+    k_losses = []
+    for it in range(iters):
+        out4 = mo.iterate(stages[it], frames, rnd_all[it].to(eng.device), fid, (0, HH, 0, WW), INTR, HH, WW)
+        k_losses.append(float(out4[0].cpu()))
+    np.testing.assert_allclose(k_losses, o_losses, rtol=2e-4)
+    r = rows.long()
+    # selected rows moved by Adam, the others untouched
+    assert float((geo_d.cpu()[r] - geo[r]).abs().max()) > 1e-3
+    other = torch.ones(pos.shape[0], dtype=torch.bool); other[r] = False
+    assert torch.equal(geo_d.cpu()[other], geo[other]) and torch.equal(col_d.cpu()[other], col[other])
+    # Adam's first steps are sign-like (lr * g / (|g| + 1e-8)): entries whose gradient is of the order of eps
+    # amplify fp32 summation-order noise, so bound the bulk tightly and the tail by a fraction of one lr step
+    for mine, ref, lr in ((geo_d.cpu()[r], geo_p.detach(), 0.03), (col_d.cpu()[r], col_p.detach(), 0.005)):
+        err = (mine - ref).abs().reshape(-1)
+        assert float(torch.quantile(err, 0.999)) < 2e-5, float(torch.quantile(err, 0.999))
+        assert float(err.max()) < 0.5 * lr, float(err.max())
+    Wk = dec.unpack()
+    for n in dec_names:
+        if n not in Wk:
+            continue
+        if not rel_pos and ('mlp_col_neighbor' in n or 'embedder_rel_pos' in n):
+            continue
+        d = float((Wk[n].reshape(Wt[n].shape) - Wt[n].detach()).abs().max())
+        moved = float((Wt[n].detach() - W[n]).abs().max())
+        assert d <= 2e-4 * max(1.0, float(W[n].abs().max())) + 0.05 * moved, (n, d, moved)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_track_iterations_match_oracle(backend):
+    eng = make_engine(backend)
+    c2w, depth_img, color_img, pos, geo, col = mini_scene(1)
+    W = syn.default_weights(seed=8)
+    R, iters, lr = 80, 4, 0.002
+    g = torch.Generator().manual_seed(12)
+    win = (2, HH - 2, 2, WW - 2)
+    w_w = win[3] - win[2]
+    n_win = (win[1] - win[0]) * w_w
+    rnd_all = torch.randint(0, n_win, (iters, R), generator=g, dtype=torch.int32)
+    cam0 = H.c2w_to_cam(c2w) + torch.tensor([0.0, 0.002, -0.001, 0.0015, 0.004, -0.003, 0.002])
+    # ---------------- oracle loop (Tracker.py:313-401, separate_LR)
+    ocfg = H.RenderCfg(rel_pos=True)
+    q = cam0[:4].clone().requires_grad_(True)
+    T = cam0[4:].clone().requires_grad_(True)
+    opt = torch.optim.Adam([{'params': [T], 'lr': lr}, {'params': [q], 'lr': 0.2 * lr}])
+    o_losses, o_cams = [], []
+    for it in range(iters):
+        cam = torch.cat([q, T])
+        o_cams.append(cam.detach().clone())
+        opt.zero_grad()
+        rr = rnd_all[it]
+        i = (win[2] + rr % w_w).float()
+        j = (win[0] + rr // w_w).float()
+        ro, rd = H.rays_from_uv(i, j, H.quat_to_c2w(cam), *INTR)
+        flat = (j.long() * WW + i.long())
+        gd = depth_img.reshape(-1)[flat]
+        gc = color_img.reshape(-1, 3)[flat]
+        keep = gd > 0
+        keep = keep & (gd <= H.inside_threshold(gd[keep]))
+        out = H.render_batch(ocfg, ro[keep], rd[keep], gd[keep], pos, geo, col, W, 'color', tracker=True)
+        loss, _, _, _ = H.tracker_loss(out['depth'], out['var'], out['color'], gd[keep], gc[keep], 0.5)
+        loss.backward()
+        opt.step()
+        o_losses.append(loss.item())
+    # ---------------- kernels
+    cfg = core.RenderCfg(rel_pos=True)
+    dec = core.DecoderBlob(eng).pack(W)
+    pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo), eng.f32(col)
+    knn = core.KnnIndex(eng, capacity=pos.shape[0])
+    knn.build(pos_d)
+    to = steps.TrackOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, R, lr, separate_lr=True, w_color=0.5)
+    best, log = to.track(eng.f32(cam0), eng.f32(depth_img), eng.f32(color_img), iters, win, INTR, rnd_all.to(eng.device))
+    np.testing.assert_allclose(log[:, 0].cpu().numpy(), o_losses, rtol=5e-4)
+    k = int(np.argmin(o_losses))
+    np.testing.assert_allclose(best.cpu().numpy(), o_cams[k].numpy(), rtol=0, atol=2e-5)
