@@ -14,7 +14,9 @@ def run(budget, seed=1219):
     from oracle import hotpath as H
     from loopy_slam_amd import synthetic as syn
     from loopy_slam_amd.common import get_tensor_from_camera
-    cores = os.cpu_count() or 1
+    # small-matrix torch-CPU ops stop scaling (and collapse from oversubscription) beyond a few tens of threads:
+    # 256 threads measured 170x slower than 8 on this path, so the baseline uses at most 16 host threads
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(seed)
     W = {k: v.clone() for k, v in syn.default_weights(seed, rel_pos=budget.rel_pos).items()}

@@ -164,7 +164,7 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
 
 // ------------------------------------------------------------------ render backward
 namespace {
-struct BwdLayout { int64_t d_raw, dc_geo, dc_col, dp_embed, dp_rel, dp_total, dw_rel, w_eff, dlogit, dh_col, rows, total; };
+struct BwdLayout { int64_t d_raw, dc_geo, dc_col, dp_embed, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, dh_col, rows, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -177,6 +177,8 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.dw_rel = o; o += 8 * P;
     L.w_eff = o; o += 8 * P;
     L.dlogit = o; o += 4 * P;
+    L.part_bg = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 32), 4) * 288;
+    L.part_br = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 4), 4) * 32;
     const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     L.dh_col = o; if (color && gw) o += 640 * P;
     L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 320 * P;
@@ -220,8 +222,9 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     db.W = d->weights; db.Wfrag = d->weights_frag; db.affine = d->affine;
     db.act = d->act; db.raw = d->raw; db.d_raw = S0 + L.d_raw;
     db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dh_col = S0 + L.dh_col; db.dlogit = S0 + L.dlogit;
-    db.dp_embed = S0 + L.dp_embed; db.g_weights = d->g_weights; db.g_affine = d->g_affine;
+    db.dp_embed = S0 + L.dp_embed; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.part_bg = S0 + L.part_bg;
     lk_launch_decode_bwd(db, st);
+    if (gw) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
     if (relpos) {
         LkRelposBwdArgs rb;
@@ -231,7 +234,9 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
         rb.W = d->weights; rb.Wfrag = d->weights_frag; rb.dc_col = S0 + L.dc_col;
         rb.g_col_feats = d->g_col_feats; rb.g_weights = d->g_weights;
         rb.dw_rel = S0 + L.dw_rel; rb.dp_rel = S0 + L.dp_rel; rb.rows = S0 + L.rows; rb.w_eff = S0 + L.w_eff;
+        rb.part_br = S0 + L.part_br;
         lk_launch_relpos_bwd(rb, st);
+        if (gw) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
     }
 
     if (gf || gr) {
@@ -284,7 +289,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J.B = act_h + 4 * 128; J.ldb = LK_ACT_COL_H;
             J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
         }
-        wa.n_jobs = nj; wa.chunk = 1024;
+        wa.n_jobs = nj; wa.chunk = 512;
         lk_launch_wgrad(wa, P, st);
         if (relpos) {
             LkWgradArgs wr;
@@ -297,7 +302,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J2.A = S0 + L.dc_col; J2.lda = LK_C; J2.a_mode = 2; J2.A2 = S0 + L.w_eff; J2.lda2 = 1;
             J2.B = rows; J2.ldb = 320;
             J2.N = CF; J2.K = HC; J2.rows = 8 * P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
-            wr.n_jobs = 2; wr.chunk = 4096;
+            wr.n_jobs = 2; wr.chunk = 2048;
             lk_launch_wgrad(wr, 8 * P, st);
         }
     }

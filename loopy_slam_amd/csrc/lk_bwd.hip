@@ -81,11 +81,9 @@ __device__ __forceinline__ void ct_store32(float* __restrict__ row, const f32x16
         *reinterpret_cast<float4*>(row + 8 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
 }
 
-__global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a) {
+// one wave = 32 sample points; part = this wave's [3][96] slice of the workgroup's d B_g partial sums (LDS)
+__device__ __forceinline__ void decode_bwd_wave(const LkDecodeBwdArgs& a, int sample0, float* __restrict__ part) {
     const int lane = lk_lane();
-    const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    const int sample0 = wave * 32;
-    if (sample0 >= a.P) return;
     const int sample = sample0 + (lane & 31);
     const bool live = sample < a.P;
     const int h = lane >> 5;
@@ -287,11 +285,7 @@ __global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a) {
                     }
                     if (want_w) {
                         const float s0 = lk_half_wave_sum(ge * a0), s1 = lk_half_wave_sum(ge * a1), s2 = lk_half_wave_sum(ge * a2);
-                        if ((lane & 31) == 0 && u < EG) {
-                            atomicAdd(a.g_weights + G_EB + u, s0);
-                            atomicAdd(a.g_weights + G_EB + EGP + u, s1);
-                            atomicAdd(a.g_weights + G_EB + 2 * EGP + u, s2);
-                        }
+                        if ((lane & 31) == 0) { part[u] = s0; part[EGP + u] = s1; part[2 * EGP + u] = s2; }
                     }
                 }
             }
@@ -300,6 +294,43 @@ __global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a) {
         dpx += __shfl_xor(dpx, 32); dpy += __shfl_xor(dpy, 32); dpz += __shfl_xor(dpz, 32);
         if (live && h == 0) *reinterpret_cast<float4*>(a.dp_embed + (size_t)sp * 4) = make_float4(dpx, dpy, dpz, 0.0f);
     }
+}
+
+// Hot-address atomics are the slowest thing this chip does (a few hundred distinct addresses hit by every
+// wave serialise in the memory-side atomic unit): the embedding-matrix gradient is therefore reduced
+// wave -> LDS -> one partial row per workgroup, and summed by k_reduce_partials.
+__global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a) {
+    __shared__ float s_part[4][3 * EGP];
+    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    const int w = (int)threadIdx.x >> 6;
+    if (want_w) {
+        for (int e = threadIdx.x; e < 4 * 3 * EGP; e += 256) (&s_part[0][0])[e] = 0.0f;
+        __syncthreads();
+    }
+    const int sample0 = (blockIdx.x * 4 + w) * 32;
+    if (sample0 < a.P) decode_bwd_wave(a, sample0, s_part[w]);
+    if (want_w) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 3 * EGP; e += 256)
+            a.part_bg[(size_t)blockIdx.x * (3 * EGP) + e] = s_part[0][e] + s_part[1][e] + s_part[2][e] + s_part[3][e];
+    }
+}
+
+// out[j] += sum_p part[p][j]   (one thread column per j; 4 row-lanes per column, combined through LDS)
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int col = blockIdx.x * 64 + ((int)threadIdx.x & 63), q = (int)threadIdx.x >> 6;
+    float s = 0.0f;
+    if (col < width)
+        for (int p = q; p < n_parts; p += 4) s += part[(size_t)p * width + col];
+    sh[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && col < width) out[col] += sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(lk_cdiv(width, 64)), dim3(256), 0, st, part, n_parts, width, out);
+    return LK_OK;
 }
 
 int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st) {

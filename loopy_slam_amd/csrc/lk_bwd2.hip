@@ -126,11 +126,8 @@ __device__ __forceinline__ float rp_embed_unit(const float* __restrict__ B, int 
     return (u < 10) ? lk_sinf(x) : lk_cosf(x);
 }
 
-__global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
+__device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sample0, float* __restrict__ part) {
     const int lane = lk_lane();
-    const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    const int sample0 = wave * 4;
-    if (sample0 >= a.P) return;
     const int h = lane >> 5;
     const int j = lane & 31;
     const int sample = sample0 + (j >> 3);
@@ -262,10 +259,10 @@ __global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
                     }
                     if (want_w) {
                         const float s0 = lk_half_wave_sum(gx * a0), s1 = lk_half_wave_sum(gx * a1), s2 = lk_half_wave_sum(gx * a2);
-                        if ((lane & 31) == 0) {
-                            atomicAdd(a.g_weights + R_EB + xi, s0);
-                            atomicAdd(a.g_weights + R_EB + 10 + xi, s1);
-                            atomicAdd(a.g_weights + R_EB + 20 + xi, s2);
+                        if ((lane & 31) == 0) {      // two units (sin, cos) and both half-waves meet in one slot: LDS atomics
+                            atomicAdd(part + xi, s0);
+                            atomicAdd(part + 10 + xi, s1);
+                            atomicAdd(part + 20 + xi, s2);
                         }
                     }
                 }
@@ -287,76 +284,136 @@ __global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// dW[n][k] += sum_rows A[row][n] * B[row][k].  One wave per (job, 32-row block of dW, chunk of rows):
-// A and B are read straight from the row-major activation scratch (a half-wave reads one 128-B line),
-// two rows per v_mfma_f32_32x32x2_f32, accumulators live in registers for the whole chunk and are
-// flushed once with coalesced atomics.  Bias gradients ride along as a running sum of the A operand.
-__device__ __forceinline__ float wg_load_a(const LkWgradJob& J, size_t row, int n) {
-    if (n >= J.N) return 0.0f;
-    if (J.a_mode == 0) return J.A[row * J.lda + n];
-    if (J.a_mode == 1) return J.A[row * J.lda + n] * lk_softplus100_grad_from_out(J.A2[row * J.lda2 + n]);
-    return J.A2[row] * J.A[(row >> 3) * J.lda + n];           // rel-pos: w[row] * dc[sample][n]
-}
-__device__ __forceinline__ float wg_load_b(const LkWgradJob& J, size_t row, int k) {
-    if (k >= J.K) return 0.0f;
-    if (J.B2 && k >= J.k_split) return J.B2[row * J.ldb2 + (k - J.k_split)];
-    return J.B[row * J.ldb + k];
+__global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
+    __shared__ float s_part[4][32];
+    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    const int w = (int)threadIdx.x >> 6;
+    if (want_w) {
+        if (threadIdx.x < 128) (&s_part[0][0])[threadIdx.x] = 0.0f;
+        __syncthreads();
+    }
+    const int sample0 = (blockIdx.x * 4 + w) * 4;
+    if (sample0 < a.P) relpos_bwd_wave(a, sample0, s_part[w]);
+    if (want_w) {
+        __syncthreads();
+        if (threadIdx.x < 32)
+            a.part_br[(size_t)blockIdx.x * 32 + threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] +
+                                                                 s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+    }
 }
 
-__global__ __launch_bounds__(64) void k_wgrad(LkWgradArgs a) {
-    const int lane = lk_lane();
-    // decode the work item: blockIdx.y enumerates (job, n-block)
-    int item = blockIdx.y, ji = 0;
-    for (; ji < a.n_jobs; ++ji) {
-        const int nbj = (a.job[ji].N + 31) >> 5;
-        if (item < nbj) break;
-        item -= nbj;
+// ---------------------------------------------------------------------------------------------
+// dW[n][k] += sum_rows A[row][n] * B[row][k]  for every decoder matrix (one "job" each).
+// One 4-wave workgroup per (job, chunk of rows).  Rows are streamed 32 at a time: all 256 threads fetch the
+// A and B row tiles with coalesced 16-byte loads (register prefetch of the next tile overlaps the MFMAs of the
+// current one), the element-wise factor of A (softplus', or the rel-pos row weight) is applied on the fly, the
+// tiles go through LDS once, and each wave owns a subset of the 32x32 output blocks: 16 k-steps of
+// v_mfma_f32_32x32x2_f32 per tile and block, operands read conflict-free from LDS.  Accumulators stay in
+// registers for the whole chunk and are flushed once with line-coalesced atomics; bias gradients are the
+// column sums of the A tiles.
+#define WG_RT 32
+#define WG_LDA 132
+#define WG_LDB 196
+
+__device__ __forceinline__ float4 wg_fetch_a(const LkWgradJob& J, long long row, long long c1, int c4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < c1) {
+        if (J.a_mode == 2) {
+            const float w = J.A2[row];
+            const float4 d = *reinterpret_cast<const float4*>(J.A + (size_t)(row >> 3) * J.lda + 4 * c4);
+            v = make_float4(w * d.x, w * d.y, w * d.z, w * d.w);
+        } else {
+            v = *reinterpret_cast<const float4*>(J.A + (size_t)row * J.lda + 4 * c4);
+            if (J.a_mode == 1) {
+                const float4 g = *reinterpret_cast<const float4*>(J.A2 + (size_t)row * J.lda2 + 4 * c4);
+                v.x *= lk_softplus100_grad_from_out(g.x); v.y *= lk_softplus100_grad_from_out(g.y);
+                v.z *= lk_softplus100_grad_from_out(g.z); v.w *= lk_softplus100_grad_from_out(g.w);
+            }
+        }
     }
-    if (ji >= a.n_jobs) return;
-    const LkWgradJob& J = a.job[ji];
-    const int nb = item;
+    return v;
+}
+__device__ __forceinline__ float4 wg_fetch_b(const LkWgradJob& J, long long row, long long c1, int c4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < c1) {
+        const int k = 4 * c4;
+        if (J.B2 && k >= J.k_split) v = *reinterpret_cast<const float4*>(J.B2 + (size_t)row * J.ldb2 + (k - J.k_split));
+        else v = *reinterpret_cast<const float4*>(J.B + (size_t)row * J.ldb + k);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[WG_RT * WG_LDA];
+    __shared__ __attribute__((aligned(16))) float sB[WG_RT * WG_LDB];
+    const LkWgradJob& J = a.job[blockIdx.y];
     const long long c0 = (long long)blockIdx.x * a.chunk;
-    if (c0 >= J.rows) return;
+    if (c0 >= J.rows) return;                                          // uniform per block
     const long long c1 = (c0 + a.chunk < J.rows) ? c0 + a.chunk : J.rows;
-    const int KB = (J.K + 31) >> 5;
-    const int n = nb * 32 + (lane & 31);
-    const int kl = lane & 31;
-    const int hh = lane >> 5;
+    const int t = (int)threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int N4 = (J.N + 3) >> 2, K4 = (J.K + 3) >> 2;                // float4 columns of the A / B tiles
+    const int NB = (J.N + 31) >> 5, KB = (J.K + 31) >> 5, U = NB * KB; // 32x32 output blocks, U <= 24
+    const int nA = WG_RT * N4, nB = WG_RT * K4;                        // float4 elements per tile
     f32x16 acc[6];
 #pragma unroll
-    for (int kb = 0; kb < 6; ++kb) acc[kb] = lk_zero16();
+    for (int q = 0; q < 6; ++q) acc[q] = lk_zero16();
     float bsum = 0.0f;
-    for (long long row = c0 + hh; row < c1 + hh; row += 2) {     // both halves iterate the same count
-        const bool ok = row < c1;
-        const float av = ok ? wg_load_a(J, (size_t)row, n) : 0.0f;
-        bsum += av;
+    float4 ra[4], rb[6];
+    // zero the padding columns once (tiles narrower than a multiple of 32 leave stale LDS otherwise)
+    for (int e = t; e < WG_RT * WG_LDA; e += 256) sA[e] = 0.0f;
+    for (int e = t; e < WG_RT * WG_LDB; e += 256) sB[e] = 0.0f;
 #pragma unroll
-        for (int kb = 0; kb < 6; ++kb) {
-            if (kb < KB) {
-                const float bv = ok ? wg_load_b(J, (size_t)row, kb * 32 + kl) : 0.0f;
-                acc[kb] = lk_mfma(av, bv, acc[kb]);
+    for (int q = 0; q < 4; ++q) { const int e = t + 256 * q; ra[q] = (e < nA) ? wg_fetch_a(J, c0 + e / N4, c1, e % N4) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { const int e = t + 256 * q; rb[q] = (e < nB) ? wg_fetch_b(J, c0 + e / K4, c1, e % K4) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (long long tile = c0; tile < c1; tile += WG_RT) {
+        __syncthreads();                                               // previous tile fully consumed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = t + 256 * q; if (e < nA) *reinterpret_cast<float4*>(sA + (e / N4) * WG_LDA + 4 * (e % N4)) = ra[q]; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const int e = t + 256 * q; if (e < nB) *reinterpret_cast<float4*>(sB + (e / K4) * WG_LDB + 4 * (e % K4)) = rb[q]; }
+        __syncthreads();
+        const long long nxt = tile + WG_RT;
+        if (nxt < c1) {                                                // prefetch the next tile into registers
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int e = t + 256 * q; if (e < nA) ra[q] = wg_fetch_a(J, nxt + e / N4, c1, e % N4); }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { const int e = t + 256 * q; if (e < nB) rb[q] = wg_fetch_b(J, nxt + e / K4, c1, e % K4); }
+        }
+        if (J.db && t < J.N) {
+#pragma unroll 8
+            for (int r = 0; r < WG_RT; ++r) bsum += sA[r * WG_LDA + t];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int u = w + 4 * q;
+            if (u < U) {                                               // wave-uniform
+                const int nb = u / KB, kb = u - nb * KB;
+                const float* pa = sA + hh * WG_LDA + nb * 32 + l31;
+                const float* pb = sB + hh * WG_LDB + kb * 32 + l31;
+#pragma unroll
+                for (int s2 = 0; s2 < WG_RT / 2; ++s2)
+                    acc[q] = lk_mfma(pa[2 * s2 * WG_LDA], pb[2 * s2 * WG_LDB], acc[q]);
             }
         }
     }
     // flush: lane holds column k = kb*32 + (lane&31), rows n = nb*32 + frag_row(r, half)
 #pragma unroll
-    for (int kb = 0; kb < 6; ++kb) {
-        if (kb < KB) {
-            const int k = kb * 32 + kl;
+    for (int q = 0; q < 6; ++q) {
+        const int u = w + 4 * q;
+        if (u < U) {
+            const int nb = u / KB, kb = u - nb * KB;
+            const int k = kb * 32 + l31;
             if (k < J.K) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nn = nb * 32 + lk_frag_row(r, hh);
-                    if (nn < J.N) atomicAdd(J.dW + (size_t)nn * J.ldw + k, acc[kb][r]);
+                    if (nn < J.N) atomicAdd(J.dW + (size_t)nn * J.ldw + k, acc[q][r]);
                 }
             }
         }
     }
-    if (J.db) {
-        bsum += __shfl_xor(bsum, 32);
-        if (hh == 0 && n < J.N) atomicAdd(J.db + n, bsum);
-    }
+    if (J.db && t < J.N) atomicAdd(J.db + t, bsum);
 }
 
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
@@ -377,9 +434,7 @@ int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
 }
 int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st) {
     LkProfScope prof_(LKK_WGRAD, st);
-    int items = 0;
-    for (int j = 0; j < a.n_jobs; ++j) items += (a.job[j].N + 31) / 32;
-    if (items == 0 || max_rows <= 0) return LK_OK;
-    hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(max_rows, a.chunk), items), dim3(64), 0, st, a);
+    if (a.n_jobs == 0 || max_rows <= 0) return LK_OK;
+    hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(max_rows, a.chunk), a.n_jobs), dim3(256), 0, st, a);
     return LK_OK;
 }

@@ -75,6 +75,7 @@ struct LkDecodeBwdArgs {
     float* dlogit;                                 // [P,4]   (GRAD_WEIGHTS)
     float* dp_embed;                               // [P,4]   (GRAD_RAYS)
     float* g_weights; float* g_affine;
+    float* part_bg;                                // [n_blocks][288] per-workgroup partial sums of d embedder._B (GRAD_WEIGHTS)
 };
 
 // interpolation backward: feature-row scatter (+ tracker: weights -> distances -> positions)
@@ -107,6 +108,7 @@ struct LkRelposBwdArgs {
     float* dp_rel;                                 // [P,4]  (GRAD_RAYS)
     float* rows;                                   // [8P][320]: hid(128) | dhid(128) | x(64)  (GRAD_WEIGHTS)
     float* w_eff;                                  // [8P] weight actually applied to each neighbour row
+    float* part_br;                                // [n_blocks][32] per-workgroup partial sums of d embedder_rel_pos._B
 };
 
 // weight gradients: dW[n][k] += sum_rows A[row][n] * B[row][k]  (one wave per (job, n-block, row chunk))
@@ -129,6 +131,7 @@ int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st);
 int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st);
 int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st);
 int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st);
+int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st);
 
 int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st);
 int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st);
