@@ -53,9 +53,18 @@ def main():
 
     for _ in range(args.warmup):
         wl.step()
+    # one extra untimed step with HIP events around EVERY kernel picks the dominant kernel of this workload ...
     barrier()
-    # HIP events on the launch stream around the dominant kernel only (all kernels with BENCH_PROFILE_ALL=1)
-    prof = profile.KernelTimer(eng, '*' if os.environ.get('BENCH_PROFILE_ALL') else 'k_decode_bwd')
+    prof_all = profile.KernelTimer(eng, '*')
+    prof_all.start()
+    wl.step()
+    barrier()
+    kall = prof_all.stop()
+    dominant = os.environ.get('BENCH_ROOFLINE_KERNEL') or profile.dominant_kernel(
+        {k: v for k, v in kall.items() if k in profile.work_per_step(budget)})
+    # ... and the timed region records events on the launch stream around that kernel only
+    prof = profile.KernelTimer(eng, dominant)
+    barrier()
     prof.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -82,9 +91,8 @@ def main():
                    'rays_per_step': rays_per_step, 'parallelism': f'dp{world} (ray-sharded, grad all-reduce)'},
     }
     if rank == 0:
-        out['roofline'] = profile.roofline_decode_bwd(kstat, budget)
-        if os.environ.get('BENCH_PROFILE_ALL'):
-            out['kernel_ms_per_step'] = {k: round(v['total_ms'] / args.steps, 3) for k, v in kstat.items()}
+        out['roofline'] = profile.roofline(kstat, budget, dominant)
+        out['kernel_ms_per_step'] = {k: round(v['total_ms'], 3) for k, v in sorted(kall.items(), key=lambda kv: -kv[1]['total_ms'])}
         if not args.no_cpu_baseline:
             import bench_cpu_baseline
             out['cpu_baseline'] = bench_cpu_baseline.run(budget)

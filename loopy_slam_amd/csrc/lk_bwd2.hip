@@ -245,28 +245,33 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int u0 = 32 * tile + 8 * g + 4 * h;
-            if (u0 < ER) {
+            const bool is_emb = u0 < ER;                 // uniform per half-wave (group 2 of tile 0 is mixed)
+            if (tile == 0 && g < 3) {                    // groups that hold embedding units in at least one half
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int u = u0 + t;
-                    const int xi = (u < 10) ? u : u - 10;
+                    const int xi = is_emb ? ((u < 10) ? u : u - 10) : 0;
                     const float b0 = B[xi], b1 = B[10 + xi], b2 = B[20 + xi];
-                    const float x = lk_fourier_arg(a0, a1, a2, b0, b1, b2);
-                    const float f = (u < 10) ? lk_cosf(x) : -lk_sinf(x);
-                    const float gx = dx[tile][4 * g + t] * f;
+                    float gx = 0.0f;
+                    if (is_emb) {
+                        const float x = lk_fourier_arg(a0, a1, a2, b0, b1, b2);
+                        const float f = (u < 10) ? lk_cosf(x) : -lk_sinf(x);
+                        gx = dx[tile][4 * g + t] * f;
+                    }
                     if (want_p) {
                         dax = fmaf(gx * LK_TWO_PI, b0, dax); day = fmaf(gx * LK_TWO_PI, b1, day); daz = fmaf(gx * LK_TWO_PI, b2, daz);
                     }
-                    if (want_w) {
+                    if (want_w) {                        // every lane takes part in the reductions (convergent shuffles)
                         const float s0 = lk_half_wave_sum(gx * a0), s1 = lk_half_wave_sum(gx * a1), s2 = lk_half_wave_sum(gx * a2);
-                        if ((lane & 31) == 0) {      // two units (sin, cos) and both half-waves meet in one slot: LDS atomics
+                        if ((lane & 31) == 0 && is_emb) {   // two units (sin, cos) and both half-waves meet in one slot: LDS atomics
                             atomicAdd(part + xi, s0);
                             atomicAdd(part + 10 + xi, s1);
                             atomicAdd(part + 20 + xi, s2);
                         }
                     }
                 }
-            } else if (u0 < KR) {
+            }
+            if (!is_emb && u0 < KR) {
                 if ((a.flags & LK_FLAG_GRAD_FEATS) && wgt != 0.0f) {
                     float* gc = a.g_col_feats + (size_t)idx * LK_C + (u0 - ER);
                     atomicAdd(gc + 0, dx[tile][4 * g]); atomicAdd(gc + 1, dx[tile][4 * g + 1]);

@@ -1,18 +1,32 @@
 """Per-kernel timing (lk_profile_*: HIP events on the launch stream) and the roofline bookkeeping
 bench.py reports.  Peaks from /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32)
-157.3 TFLOP/s, HBM3E 8 TB/s."""
+157.3 TFLOP/s dense, HBM3E 8 TB/s.
+
+Algorithmic work per unit (DESIGN.md §Kernels states the same figures):
+  multiply-adds per SAMPLE POINT
+    decode fwd   geometry 15 479 - 279 (embedding on the VALU) = 15 200 ; colour 96 640
+    decode bwd   (backward-data) geometry 15 392 ; colour 86 400 (+ 10 240 embedding columns in tracker mode)
+    rel-pos fwd  8 neighbours x (128x52 + 32x128) = 86 016 ;  bwd 8 x (128x52 fwd + 32x128 + 128x52 bwd) = 139 264
+                 (+ 8 x 32x128 for the recomputed output in tracker mode)
+    wgrad        colour matrices 96 640 ; rel-pos matrices 86 016
+  bytes per SAMPLE POINT
+    sample/interpolate  8 x 128 B feature rows per decoder gathered + 128 B written per decoder + 80 B
+                        neighbour list/weights/count/z  (the grid candidate scan is extra, not counted)
+    interp bwd          8 x 128 B read-modify-write per decoder (feature-gradient scatter) + 256 B read
+"""
 import ctypes as C
 
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+S = 5
 
-# algorithmic multiply-adds per SAMPLE POINT of k_decode_bwd (backward-data of both decoders):
-#   colour: W4^T,W2^T,W1^T (3 x 128x128) + W3^T hidden part (128x128) + 5 x U^T (128x32) + Wo^T (3x128)
-#   geometry: W4^T,W2^T,W1^T (3 x 32x32) + W3^T (32x128) + W0^T (32x96) + 5 x U^T (32x32) + wo (32)
-MAC_DECODE_BWD_COLOR = 3 * 128 * 128 + 128 * 128 + 5 * 128 * 32 + 3 * 128
-MAC_DECODE_BWD_GEO = 3 * 32 * 32 + 32 * 128 + 32 * 96 + 5 * 32 * 32 + 32
-# tracker mode adds the embedding columns of the colour skip / first layer: W3^T (128x40) + W0^T (128x40)
-MAC_DECODE_BWD_TRACK_EXTRA = 2 * 128 * 40
+MAC = dict(
+    dec_fwd_geo=15200, dec_fwd_col=96640,
+    dec_bwd_geo=3 * 32 * 32 + 32 * 128 + 32 * 96 + 5 * 32 * 32 + 32,
+    dec_bwd_col=3 * 128 * 128 + 128 * 128 + 5 * 128 * 32 + 3 * 128, dec_bwd_track_extra=2 * 128 * 40,
+    rel_fwd=8 * (128 * 52 + 32 * 128), rel_bwd=8 * (2 * 128 * 52 + 32 * 128), rel_bwd_track_extra=8 * 32 * 128,
+    wgrad_col=96640, wgrad_rel=8 * (128 * 52 + 32 * 128),
+)
 
 
 class KernelTimer:
@@ -32,20 +46,50 @@ class KernelTimer:
         return out
 
 
-def roofline_decode_bwd(kstat, budget, steps=1):
-    """achieved = algorithmic FLOPs of all k_decode_bwd launches of the timed region / their summed duration."""
-    k = kstat.get('k_decode_bwd')
-    if not k or k['total_ms'] <= 0:
+def work_per_step(b):
+    """kernel -> (bound, algorithmic units per benchmark step, unit, launches per step) for budget b."""
+    Pm, Pt = b.map_rays * S, b.track_rays * S
+    n_geo, n_col, n_trk = b.map_geo_iters, b.map_iters - b.map_geo_iters, b.track_iters
+    rel = 1 if b.rel_pos else 0
+    fl = lambda macs: 2.0 * macs
+    feat_rows = 8 * 128
+    w = {
+        'k_decode_fwd': ('mfma', fl(n_geo * Pm * MAC['dec_fwd_geo'] + (n_col * Pm + n_trk * Pt) * (MAC['dec_fwd_geo'] + MAC['dec_fwd_col'])),
+                         'flop', b.map_iters + n_trk),
+        'k_decode_bwd': ('mfma', fl(n_geo * Pm * MAC['dec_bwd_geo'] + n_col * Pm * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col']) +
+                                    n_trk * Pt * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col'] + MAC['dec_bwd_track_extra'])),
+                         'flop', b.map_iters + n_trk),
+        'k_wgrad': ('mfma', fl(n_col * Pm * (MAC['wgrad_col'] + rel * MAC['wgrad_rel'])), 'flop', n_col * (1 + rel)),
+        'k_sample_interp': ('hbm', float(n_geo * Pm * (feat_rows + 128 + 80) + n_col * Pm * ((2 - rel) * (feat_rows + 128) + 80) +
+                                         n_trk * Pt * ((2 - rel) * (feat_rows + 128) + 80)), 'byte', b.map_iters + n_trk),
+        'k_interp_bwd': ('hbm', float(n_geo * Pm * (2 * feat_rows + 256) + n_col * Pm * ((2 - rel) * 2 * feat_rows + 256) +
+                                      n_trk * Pt * (2 * feat_rows + 256)), 'byte', b.map_iters + n_trk),
+    }
+    if rel:
+        w['k_relpos_fwd'] = ('mfma', fl((n_col * Pm + n_trk * Pt) * MAC['rel_fwd']), 'flop', n_col + n_trk)
+        w['k_relpos_bwd'] = ('mfma', fl(n_col * Pm * MAC['rel_bwd'] + n_trk * Pt * (MAC['rel_bwd'] + MAC['rel_bwd_track_extra'])),
+                             'flop', n_col + n_trk)
+    return w
+
+
+def dominant_kernel(kstat):
+    return max(kstat.items(), key=lambda kv: kv[1]['total_ms'])[0] if kstat else None
+
+
+def roofline(kstat, budget, kernel):
+    """achieved = algorithmic work of all launches of `kernel` in the timed region / their summed duration."""
+    k = kstat.get(kernel)
+    model = work_per_step(budget).get(kernel)
+    if not k or k['total_ms'] <= 0 or model is None:
         return None
-    S = 5
-    macs_per_step = (budget.map_geo_iters * budget.map_rays * S * MAC_DECODE_BWD_GEO +
-                     (budget.map_iters - budget.map_geo_iters) * budget.map_rays * S * (MAC_DECODE_BWD_GEO + MAC_DECODE_BWD_COLOR) +
-                     budget.track_iters * budget.track_rays * S * (MAC_DECODE_BWD_GEO + MAC_DECODE_BWD_COLOR + MAC_DECODE_BWD_TRACK_EXTRA))
-    launches_per_step = budget.map_iters + budget.track_iters
-    n_steps = k['calls'] / launches_per_step
-    flops = 2.0 * macs_per_step * n_steps
-    achieved = flops / (k['total_ms'] * 1e-3) / 1e12
-    return {'kernel': 'k_decode_bwd', 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
-            'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'],
-            'flops_per_launch_avg': flops / k['calls']}
+    bound, units, unit, launches = model
+    n_steps = k['calls'] / launches
+    total = units * n_steps
+    secs = k['total_ms'] * 1e-3
+    if bound == 'mfma':
+        achieved, peak, u = total / secs / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
+    else:
+        achieved, peak, u = total / secs / 1e9, PEAK_HBM_GBS, 'GB/s'
+    return {'kernel': kernel, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': u, 'frac': achieved / peak,
+            'traffic': None, 'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'],
+            'algorithmic_' + unit + 's_per_launch_avg': total / k['calls']}

@@ -1,0 +1,642 @@
+"""Drop-in host classes with the reference's names and call signatures for the render/optimise path:
+
+  NICER             src/conv_onet/models/decoder.py:549-626   (weights container + state_dict, forward)
+  NeuralPointCloud  src/neural_point.py:29-124, 1252-1708     (query/store half; one segment, no loop closure)
+  Renderer          src/utils/Renderer.py:6-276               (render_batch_ray, render_img)
+  Mapper            src/Mapper.py:35-1049                     (optimize_map; map_frame = one pass of run()'s body)
+  Tracker           src/Tracker.py:29-427                     (optimize_cam_in_batch; track_frame = run()'s body)
+  Point_SLAM        src/Point_SLAM.py:37-252                  (single-process orchestration)
+
+All arithmetic of the hot path runs in libloopyhip (loopy_slam_amd.core / .steps / .optim); what remains here is
+per-frame bookkeeping in torch.  Out of scope: loop closure / fragments, datasets, meshing,
+visualisation, checkpoints, the mapper-side exposure affine.  Every class takes an optional `eng` (core.Engine);
+the default is the gfx950 library on the current CUDA device.
+"""
+import math
+import types
+
+import numpy as np
+import torch
+
+from . import _ffi, core, optim, steps, synthetic
+from .common import get_camera_from_tensor, get_tensor_from_camera, get_rays, get_samples, get_rays_from_uv
+
+
+def render_cfg_from(cfg, coef):
+    r, p = cfg['rendering'], cfg['pointcloud']
+    return core.RenderCfg(S=r['N_surface'], near_surface=r['near_end_surface'], far_surface=r['far_end_surface'],
+                          near_end=r['near_end'], coef=coef, min_nn=p['min_nn_num'], radius_query=p['radius_query'],
+                          rel_pos=cfg['model']['encode_rel_pos_in_col'], exposure=cfg['model']['encode_exposure'])
+
+
+# ============================================================================================ NICER
+class _SubDecoder:
+    """View of one decoder's entries ('geo_decoder.' / 'color_decoder.') for load_state_dict / state_dict."""
+
+    def __init__(self, owner, prefix):
+        self.owner, self.prefix = owner, prefix
+
+    def state_dict(self):
+        return {k[len(self.prefix):]: v for k, v in self.owner.state_dict().items() if k.startswith(self.prefix)}
+
+    def load_state_dict(self, sd, strict=True):
+        return self.owner.load_state_dict({self.prefix + k: v for k, v in sd.items()}, strict=strict, _only_prefix=self.prefix)
+
+    def parameters(self):
+        return [v for k, v in self.owner.state_dict().items() if k.startswith(self.prefix)]
+
+
+class NICER:
+    """MLP_geometry (hidden 32) + MLP_color (hidden 128) as one packed weight blob on the device."""
+
+    # reference parameters that exist but never influence an output (kept only for state_dict round trips)
+    _UNUSED = {'geo_decoder.embedder_rel_pos._B': (3, 10), 'geo_decoder.mlp_col_neighbor.linear1.weight': (32, 52),
+               'geo_decoder.mlp_col_neighbor.linear1.bias': (32,), 'geo_decoder.mlp_col_neighbor.linear2.weight': (32, 32),
+               'geo_decoder.mlp_col_neighbor.linear2.bias': (32,)}
+
+    def __init__(self, cfg, eng=None, dim=3, c_dim=32, hidden_size=128, pos_embedding_method='fourier',
+                 use_view_direction=False):
+        assert c_dim == 32 and hidden_size == 128 and dim == 3, 'kernels are built for c_dim 32 / hidden 128'
+        self.cfg = cfg
+        self.eng = eng if eng is not None else core.Engine()
+        self.dec = core.DecoderBlob(self.eng)
+        seed = cfg.get('setup_seed', 1219)
+        W = synthetic.default_weights(seed, rel_pos=cfg['model']['encode_rel_pos_in_col'])
+        self.dec.pack(W)
+        g = torch.Generator().manual_seed(seed + 1)
+        self.extra = {k: torch.randn(*s, generator=g) * 0.01 for k, s in self._UNUSED.items()}
+        self.encode_exposure = cfg['model']['encode_exposure']
+        if self.encode_exposure:      # MLP_exposure (decoder.py:326-342): 8 -> 128 softplus(100) -> 12, N(0, 0.01) weights
+            self.mlp_exposure = torch.nn.Sequential(torch.nn.Linear(cfg['model']['exposure_dim'], 128), torch.nn.Softplus(beta=100),
+                                                    torch.nn.Linear(128, 12)).to(self.eng.device)
+            with torch.no_grad():
+                self.mlp_exposure[0].weight.normal_(0, 0.01, generator=None)
+                self.mlp_exposure[2].weight.normal_(0, 0.01, generator=None)
+        self.geo_decoder = _SubDecoder(self, 'geo_decoder.')
+        self.color_decoder = _SubDecoder(self, 'color_decoder.')
+
+    # ---- state_dict with the reference's key names
+    def state_dict(self):
+        sd = {k: v for k, v in self.dec.unpack().items() if k != 'color_decoder.embedder._B'}
+        sd.update({k: v.clone() for k, v in self.extra.items()})
+        if self.encode_exposure:
+            sd['color_decoder.mlp_exposure.linear1.weight'] = self.mlp_exposure[0].weight.detach().cpu()
+            sd['color_decoder.mlp_exposure.linear1.bias'] = self.mlp_exposure[0].bias.detach().cpu()
+            sd['color_decoder.mlp_exposure.linear2.weight'] = self.mlp_exposure[2].weight.detach().cpu()
+            sd['color_decoder.mlp_exposure.linear2.bias'] = self.mlp_exposure[2].bias.detach().cpu()
+        return sd
+
+    def load_state_dict(self, sd, strict=True, _only_prefix=None):
+        cur = self.dec.unpack()
+        known = set(cur) | set(self.extra)
+        unexpected = [k for k in sd if k not in known and 'mlp_exposure' not in k]
+        missing = [k for k in known if k not in sd and k != 'color_decoder.embedder._B'
+                   and (_only_prefix is None or k.startswith(_only_prefix))]
+        if strict and (unexpected or missing):
+            raise RuntimeError(f'load_state_dict: missing {missing}, unexpected {unexpected}')
+        for k, v in sd.items():
+            if k in cur:
+                cur[k] = torch.as_tensor(v).float()
+            elif k in self.extra:
+                self.extra[k] = torch.as_tensor(v).float().clone()
+            elif 'mlp_exposure' in k and self.encode_exposure:
+                mod = self.mlp_exposure[0] if 'linear1' in k else self.mlp_exposure[2]
+                getattr(mod, 'weight' if k.endswith('weight') else 'bias').data.copy_(torch.as_tensor(v))
+        self.dec.pack(cur)
+        return types.SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def set_color_embedder_B(self, B):
+        """The colour decoder's fixed random Fourier matrix is not in the reference's state_dict (decoder.py:32)."""
+        cur = self.dec.unpack()
+        cur['color_decoder.embedder._B'] = torch.as_tensor(B).float()
+        self.dec.pack(cur)
+
+    def to(self, device):
+        return self
+
+    def share_memory(self):
+        return self
+
+    def exposure_affine(self, exposure_feat):
+        return self.mlp_exposure(exposure_feat) if (self.encode_exposure and exposure_feat is not None) else None
+
+    def forward(self, p, npc, stage, npc_geo_feats, npc_col_feats, pts_num=16, is_tracker=False, cloud_pos=None,
+                pts_views_d=None, dynamic_r_query=None, exposure_feat=None):
+        """raw [P,4] (rgb, occupancy), ray_mask [P/pts_num], point_mask [P] for arbitrary query points
+        (decoder.py:573-610).  Forward only; the differentiable path is Renderer.render_batch_ray."""
+        eng = self.eng
+        p = p.reshape(-1, 3).float().contiguous()
+        P = p.shape[0]
+        cfg = render_cfg_from(self.cfg, 0.1)
+        cfg.S = 1                                   # one "sample" per zero-length ray: p = o + 0 * z
+        st = core.RenderState(eng, P, 1)
+        zeros, ones = torch.zeros_like(p), torch.ones(P, device=p.device)
+        r2 = (dynamic_r_query.reshape(-1).double() ** 2).float().contiguous() if dynamic_r_query is not None else None
+        aff = self.exposure_affine(exposure_feat)
+        logits = self.encode_exposure and exposure_feat is None
+        core.render_forward(eng, cfg, st, p, zeros, ones, npc.knn, npc.cloud_pos(), npc_geo_feats, npc_col_feats, self.dec,
+                            'color' if stage in ('color', 'mesh', 'color_only') else 'geometry', tracker=is_tracker, r2_ray=r2,
+                            affine=aff.detach().contiguous() if aff is not None else None, color_logits=logits)
+        point_mask = st.nbr_count >= cfg.min_nn
+        S = self.cfg['rendering']['N_surface']
+        ray_mask = point_mask.view(-1, pts_num).sum(1) >= int(S / 2 + 1) if P % pts_num == 0 else None
+        return st.raw.clone(), ray_mask, point_mask
+
+    __call__ = forward
+
+
+# ============================================================================================ NeuralPointCloud
+class NeuralPointCloud:
+    """Tensor-resident neural point cloud: positions, geometry / colour feature tables, exact grid index."""
+
+    def __init__(self, cfg, slam=None, args=None, eng=None, capacity=1 << 18):
+        self.cfg = cfg
+        self.eng = eng if eng is not None else core.Engine()
+        pc = cfg['pointcloud']
+        self.c_dim = cfg['model']['c_dim']
+        self.nn_num, self.N_add = pc['nn_num'], pc['N_add']
+        assert self.nn_num == 8 and self.c_dim == 32
+        self.radius_add, self.radius_min, self.radius_query = pc['radius_add'], pc['radius_min'], pc['radius_query']
+        self.radius_mesh = pc.get('radius_mesh', pc['radius_query'])
+        self.near_end_surface, self.far_end_surface = pc['near_end_surface'], pc['far_end_surface']
+        self.use_dynamic_radius = cfg['use_dynamic_radius']
+        self._cell = max(pc['radius_query'], 1e-3)
+        self._gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219))
+        self._alloc(capacity)
+        self.n = 0
+        self._input_pos, self._input_rgb = [], []
+
+    def _alloc(self, cap):
+        e = self.eng
+        self.capacity = int(cap)
+        self._pos, self._geo, self._col = e.zeros(cap, 3), e.zeros(cap, 32), e.zeros(cap, 32)
+        self.knn = core.KnnIndex(e, self.capacity, cell_size=self._cell)
+
+    def _grow(self, need):
+        if need <= self.capacity:
+            return
+        old = (self._pos, self._geo, self._col)
+        self._alloc(max(need, 2 * self.capacity))
+        for new, o in zip((self._pos, self._geo, self._col), old):
+            new[:self.n] = o[:self.n]
+        if self.n:
+            self.knn.build(self._pos[:self.n])
+
+    # ---- accessors with the reference's names (neural_point.py:1328-1546)
+    def device(self):
+        return self.eng.device
+
+    def cloud_pos(self):
+        return self._pos[:self.n]
+
+    def get_cloud_pos(self, end=False):
+        return self._pos[:self.n]
+
+    def get_geo_feats(self, end=False):
+        return self._geo[:self.n]
+
+    def get_col_feats(self, end=False):
+        return self._col[:self.n]
+
+    def update_geo_feats(self, feats, indices=None, end=False):
+        if indices is not None:
+            self._geo[:self.n][torch.as_tensor(indices, device=self.eng.device).long()] = feats.detach()
+        elif feats.data_ptr() != self._geo.data_ptr():
+            self._geo[:self.n] = feats.detach()
+
+    def update_col_feats(self, feats, indices=None, end=False):
+        if indices is not None:
+            self._col[:self.n][torch.as_tensor(indices, device=self.eng.device).long()] = feats.detach()
+        elif feats.data_ptr() != self._col.data_ptr():
+            self._col[:self.n] = feats.detach()
+
+    def pts_num(self):
+        return self.n
+
+    def index_ntotal(self):
+        return self.n
+
+    def get_radius_query(self):
+        return self.radius_query
+
+    def input_pos(self):
+        return torch.cat(self._input_pos) if self._input_pos else self.eng.zeros(0, 3)
+
+    def input_rgb(self):
+        return torch.cat(self._input_rgb) if self._input_rgb else self.eng.zeros(0, 3)
+
+    # ---- search (neural_point.py:1659-1708)
+    def find_neighbors_faiss(self, pos, step='add', retrain=False, is_pts_grad=False, dynamic_radius=None):
+        assert step in ('add', 'query', 'mesh')
+        radius = self.radius_query if step == 'query' else (self.radius_mesh if step == 'mesh' else
+                                                            (self.radius_min if is_pts_grad else self.radius_add))
+        pos = pos.reshape(-1, 3).float().contiguous()
+        if dynamic_radius is not None and dynamic_radius.numel() == pos.shape[0]:
+            r2 = (dynamic_radius.reshape(-1).double() ** 2).float().contiguous()
+        else:
+            r2 = float(np.float32(radius ** 2))
+        D, I, cnt = self.knn.query(pos, r2)
+        return D, I.long(), cnt
+
+    # ---- insertion (neural_point.py:1557-1631): radius de-dup against the existing cloud, N_add points per ray
+    def add_neural_points(self, batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color, train=False, is_pts_grad=False,
+                          dynamic_radius=None, idx=None, gt_color=None, gt_depth=None, cur_c2w=None, gt_camera=None):
+        if batch_rays_o.shape[0] == 0:
+            return 0
+        m = batch_gt_depth > 0
+        ro, rd, gd, gc = batch_rays_o[m], batch_rays_d[m], batch_gt_depth[m], batch_gt_color[m] * 255
+        dyn = dynamic_radius[m] if dynamic_radius is not None else None
+        pts_gt = ro + rd * gd[:, None]
+        keep = torch.ones(pts_gt.shape[0], dtype=torch.bool, device=pts_gt.device)
+        if self.n > 0:
+            _, _, cnt = self.find_neighbors_faiss(pts_gt, step='add', is_pts_grad=is_pts_grad, dynamic_radius=dyn)
+            keep = cnt == 0
+        self._input_pos.append(pts_gt[keep])
+        self._input_rgb.append(gc[keep])
+        t = torch.linspace(0.0, 1.0, steps=self.N_add, device=gd.device)
+        g3 = gd[:, None].repeat(1, self.N_add)
+        z = self.near_end_surface * g3 * (1. - t) + self.far_end_surface * g3 * t
+        pts = (ro[:, None, :] + rd[:, None, :] * z[:, :, None])[keep].reshape(-1, 3)
+        k = pts.shape[0]
+        if k:
+            self._grow(self.n + k)
+            self._pos[self.n:self.n + k] = pts
+            self._geo[self.n:self.n + k] = (torch.randn(k, 32, generator=self._gen) * 0.1).to(self.eng.device)
+            self._col[self.n:self.n + k] = (torch.randn(k, 32, generator=self._gen) * 0.1).to(self.eng.device)
+            self.n += k
+            self.knn.build(self._pos[:self.n])             # counting-sort rebuild on the device (no IVF re-training)
+        return int(keep.sum())
+
+
+# ============================================================================================ Renderer
+class _RenderFn(torch.autograd.Function):
+    """autograd bridge: forward = lk_render_fwd, backward = lk_render_bwd."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, geo_feats, col_feats, blob, affine, pack):
+        eng, cfg, knn, pos, dec, gt_depth, stage, tracker, r2, logits, chunk = pack
+        R = rays_o.shape[0]
+        st = core.RenderState(eng, R, cfg.S, need_act=True)
+        core.render_forward(eng, cfg, st, rays_o.detach().contiguous(), rays_d.detach().contiguous(), gt_depth, knn, pos,
+                            geo_feats.detach(), col_feats.detach(), dec, stage, tracker=tracker, r2_ray=r2,
+                            affine=affine.detach().contiguous() if affine is not None else None, color_logits=logits,
+                            save_act=True, stats_chunk=chunk)
+        ctx.pack, ctx.st = pack, st
+        ctx.needs = (rays_o.requires_grad or rays_d.requires_grad, geo_feats.requires_grad or col_feats.requires_grad,
+                     blob.requires_grad, affine is not None and affine.requires_grad)
+        ctx.N = geo_feats.shape[0]
+        ctx.mark_non_differentiable(st.valid_ray)
+        return st.depth, st.var, st.color, st.valid_ray
+
+    @staticmethod
+    def backward(ctx, g_depth, g_var, g_color, _):
+        eng, cfg, knn, pos, dec = ctx.pack[:5]
+        rays, feats, weights, aff = ctx.needs
+        R = ctx.st.R
+        gs = core.GradState(eng, ctx.N, R, dec.n, feats=feats, weights=weights, rays=rays, affine=aff)
+        z = lambda t, *s: eng.zeros(*s) if t is None else t.contiguous()
+        core.render_backward(eng, ctx.st, gs, z(g_depth, R), z(g_color, R, 3), z(g_var, R))
+        return (gs.g_rays_o, gs.g_rays_d, gs.g_geo, gs.g_col, gs.g_weights, gs.g_affine, None)
+
+
+class Renderer:
+    def __init__(self, cfg, args=None, slam=None, points_batch_size=500000, ray_batch_size=3000):
+        self.cfg = cfg
+        self.ray_batch_size, self.points_batch_size = ray_batch_size, points_batch_size
+        self.N_surface = cfg['rendering']['N_surface']
+        self.use_dynamic_radius = cfg['use_dynamic_radius']
+        self.sigmoid_coefficient = cfg['rendering']['sigmoid_coef_mapper']     # set externally like the reference
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
+
+    def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None, npc_geo_feats=None,
+                         npc_col_feats=None, is_tracker=False, cloud_pos=None, dynamic_r_query=None, exposure_feat=None,
+                         _stats_chunk=None):
+        """(depth [R], uncertainty [R], color [R,3], valid_ray_mask [R] bool) — Renderer.py:71-201."""
+        eng = decoders.eng
+        cfg = render_cfg_from(self.cfg, self.sigmoid_coefficient)
+        R = rays_o.shape[0]
+        if gt_depth is None:
+            gt_depth = eng.zeros(R)
+        gt_depth = gt_depth.reshape(-1).float().contiguous()
+        geo = npc_geo_feats if npc_geo_feats is not None else npc.get_geo_feats()
+        col = npc_col_feats if npc_col_feats is not None else npc.get_col_feats()
+        pos = cloud_pos if cloud_pos is not None else npc.cloud_pos()
+        r2 = (dynamic_r_query.reshape(-1).double() ** 2).float().contiguous() if (self.use_dynamic_radius and dynamic_r_query is not None) else None
+        aff = decoders.exposure_affine(exposure_feat)
+        logits = decoders.encode_exposure and exposure_feat is None
+        blob = decoders.dec.blob
+        pack = (eng, cfg, npc.knn, pos.contiguous(), decoders.dec, gt_depth, stage, is_tracker, r2, logits, _stats_chunk)
+        depth, var, color, valid = _RenderFn.apply(rays_o.float(), rays_d.float(), geo, col, blob, aff, pack)
+        return depth, var, color, valid.bool()
+
+    def render_img(self, npc, decoders, c2w, device, stage, gt_depth=None, npc_geo_feats=None, npc_col_feats=None,
+                   dynamic_r_query=None, cloud_pos=None, exposure_feat=None):
+        """Whole image in ONE fused pass over all H*W rays (the reference loops over 3000-ray batches,
+        Renderer.py:241-266); far_bb is still evaluated per ray_batch_size group."""
+        with torch.no_grad():
+            ro, rd = get_rays(self.H, self.W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            gd = gt_depth.reshape(-1) if gt_depth is not None else None
+            d, u, c, _ = self.render_batch_ray(npc, decoders, rd.reshape(-1, 3).contiguous(), ro.reshape(-1, 3).contiguous(), device,
+                                               stage, gt_depth=gd, npc_geo_feats=npc_geo_feats, npc_col_feats=npc_col_feats,
+                                               cloud_pos=cloud_pos, dynamic_r_query=dynamic_r_query, exposure_feat=exposure_feat,
+                                               _stats_chunk=self.ray_batch_size)
+            return d.double().reshape(self.H, self.W), u.double().reshape(self.H, self.W), c.reshape(self.H, self.W, 3)
+
+
+# ============================================================================================ Mapper
+class Mapper:
+    def __init__(self, cfg, args, slam):
+        self.cfg, self.slam = cfg, slam
+        self.eng = slam.eng
+        m = cfg['mapping']
+        self.npc, self.decoders, self.renderer = slam.npc, slam.shared_decoders, slam.renderer_map
+        self.renderer.sigmoid_coefficient = cfg['rendering']['sigmoid_coef_mapper']
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
+        self.every_frame, self.keyframe_every = m['every_frame'], m['keyframe_every']
+        self.mapping_pixels, self.pixels_adding = m['pixels'], m['pixels_adding']
+        self.num_joint_iters, self.iters_first = m['iters'], m['iters_first']
+        self.geo_iter_ratio, self.geo_iter_first, self.min_iter_ratio = m['geo_iter_ratio'], m['geo_iter_first'], m['min_iter_ratio']
+        self.mapping_window_size, self.w_color_loss = m['mapping_window_size'], m['w_color_loss']
+        self.frustum_feature_selection, self.frustum_edge = m['frustum_feature_selection'], m['frustum_edge']
+        self.filter_before_add_points = m['filter_before_add_points']
+        self.use_dynamic_radius = cfg['use_dynamic_radius']
+        self.keyframe_list, self.keyframe_dict = [], []
+        self.gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219) + 7)
+        self.prev_c2w = None
+        self.last_log = None
+
+    def set_pipe(self, pipe):
+        self.pipe = pipe
+
+    # -- frustum feature selection (Mapper.py:165-217): project every point, bilinear depth lookup, z test
+    def get_mask_from_c2w(self, c2w, depth):
+        pts = self.npc.cloud_pos()
+        w2c = torch.linalg.inv(c2w.double()).float().to(pts.device)
+        cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
+        x, y, zc = -cam[:, 0], cam[:, 1], cam[:, 2]                 # cam_cord[:, 0] *= -1
+        z = zc + 1e-5
+        u = (self.fx * x + self.cx * zc) / z
+        v = (self.fy * y + self.cy * zc) / z
+        d = _bilinear_zero_border(depth, u, v)
+        d = torch.where(d == 0, d.max(), d)
+        e = self.frustum_edge
+        mask = (u < self.W - e) & (u > e) & (v < self.H - e) & (v > e) & (0 <= -z) & (-z <= d + 0.5)
+        return torch.nonzero(mask).reshape(-1).to(torch.int32)
+
+    def filter_point_before_add(self, rays_o, rays_d, gt_depth, prev_c2w):
+        pts = rays_o + rays_d * gt_depth[:, None]
+        w2c = torch.linalg.inv(prev_c2w.double()).float().to(pts.device)
+        cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
+        zc = cam[:, 2]
+        z = zc + 1e-5
+        u = (self.fx * -cam[:, 0] + self.cx * zc) / z
+        v = (self.fy * cam[:, 1] + self.cy * zc) / z
+        inside = (u < self.W) & (u > 0) & (v < self.H) & (v > 0)
+        return ~inside
+
+    def keyframe_selection_overlap(self, gt_color, gt_depth, c2w, keyframe_dict, k, N_samples=8, pixels=200):
+        """Keyframes that see the current frame's points, random k of them (Mapper.py:219-282)."""
+        dev = self.eng.device
+        ro, rd, gd, _ = get_samples(0, self.H, 0, self.W, pixels, self.H, self.W, self.fx, self.fy, self.cx, self.cy, c2w,
+                                    gt_depth, gt_color, dev, depth_filter=True)
+        t = torch.linspace(0., 1., N_samples, device=dev)
+        z = gd[:, None] * 0.8 * (1 - t) + (gd[:, None] + 0.5) * t
+        pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(-1, 3)
+        scored = []
+        for kid, kf in enumerate(keyframe_dict):
+            w2c = torch.linalg.inv(kf['est_c2w'].double()).float().to(dev)
+            cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
+            zc = cam[:, 2] + 1e-5
+            u = (self.fx * -cam[:, 0] + self.cx * cam[:, 2]) / zc
+            v = (self.fy * cam[:, 1] + self.cy * cam[:, 2]) / zc
+            m = (u < self.W - 20) & (u > 20) & (v < self.H - 20) & (v > 20) & (cam[:, 2] < 0)
+            scored.append((float(m.float().mean()), kid))
+        scored = [kid for p, kid in sorted(scored, reverse=True) if p > 0.0]
+        perm = torch.randperm(len(scored), generator=self.gen).tolist()
+        return [scored[i] for i in perm[:k]]
+
+    # -- one optimize_map call (Mapper.py:347-807)
+    def optimize_map(self, num_joint_iters, idx, cur_gt_color, cur_gt_depth, gt_cur_c2w, keyframe_dict, keyframe_list,
+                     cur_c2w, color_refine=False, new_fragment=False):
+        cfg, eng, npc = self.cfg, self.eng, self.npc
+        H, W = self.H, self.W
+        intr = (self.fx, self.fy, self.cx, self.cy)
+        init = idx == 0
+        # 1. keyframes of the window (overlap selection + the most recent keyframe + the current frame)
+        sel = []
+        if len(keyframe_dict) > 0:
+            sel = self.keyframe_selection_overlap(cur_gt_color, cur_gt_depth, cur_c2w, keyframe_dict[:-1], self.mapping_window_size - 2)
+            if len(keyframe_list) > 0:
+                sel = sel + [len(keyframe_dict) - 1]
+        frames_d = [keyframe_dict[k]['depth'] for k in sel] + [cur_gt_depth]
+        frames_c = [keyframe_dict[k]['color'] for k in sel] + [cur_gt_color]
+        frames_p = [keyframe_dict[k]['est_c2w'] for k in sel] + [cur_c2w]
+        # 2. add neural points seen by the current frame (Mapper.py:429-482)
+        ro, rd, gd, gc, i, j = get_samples(0, H, 0, W, self.pixels_adding, H, W, *intr, cur_c2w, cur_gt_depth, cur_gt_color,
+                                           eng.device, depth_filter=True, return_index=True, generator=None)
+        if not init and self.filter_before_add_points and self.prev_c2w is not None:
+            keep = self.filter_point_before_add(ro, rd, gd, self.prev_c2w)
+            ro, rd, gd, gc = ro[keep], rd[keep], gd[keep], gc[keep]
+        frame_pts_add = npc.add_neural_points(ro, rd, gd, gc)
+        # 3. rows to optimise
+        rows = self.get_mask_from_c2w(cur_c2w, cur_gt_depth) if (self.frustum_feature_selection and not color_refine) else None
+        # 4. iteration count (Mapper.py:572-574)
+        if idx > 0 and not color_refine:
+            num_joint_iters = int(np.clip(int(num_joint_iters * frame_pts_add / 300), int(self.min_iter_ratio * num_joint_iters),
+                                          2 * num_joint_iters))
+        stage_cfg = cfg['mapping']['init' if init else 'stage']
+        lrs = {s: (stage_cfg[s]['decoders_lr'], stage_cfg[s]['geometry_lr'], stage_cfg[s]['color_lr']) for s in ('geometry', 'color')}
+        F = len(frames_d)
+        pix = self.mapping_pixels // F
+        R = pix * F
+        rcfg = render_cfg_from(cfg, cfg['rendering']['sigmoid_coef_mapper'])
+        mo = steps.MapOptimizer(eng, rcfg, self.decoders.dec, npc.knn, npc.cloud_pos(), npc.get_geo_feats(), npc.get_col_feats(),
+                                rows, R, lrs, w_color=self.w_color_loss, dist=getattr(self.slam, 'dist', None))
+        mo.begin_frame()
+        stack = (torch.stack(frames_d).contiguous(), torch.stack(frames_c).contiguous(),
+                 torch.stack([p.float() for p in frames_p]).contiguous(), None)
+        fid = torch.arange(F, dtype=torch.int32).repeat_interleave(pix).to(eng.device)
+        rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen, dtype=torch.int32).to(eng.device)
+        log = eng.zeros(num_joint_iters, 4)
+        geo_iters = self.geo_iter_first if init else int(num_joint_iters * self.geo_iter_ratio)
+        for it in range(num_joint_iters):
+            stage = 'geometry' if it <= geo_iters else 'color'
+            mo.iterate(stage, stack, rnd[it], fid, (0, H, 0, W), intr, H, W, log_row=log[it])
+        self.last_log = log
+        self.prev_c2w = cur_c2w.clone()
+        return None
+
+    def map_frame(self, idx, gt_color, gt_depth, gt_c2w, cur_c2w=None):
+        """One mapped frame: the body of Mapper.run's loop (Mapper.py:835-1037) minus I/O and visualisation."""
+        cur_c2w = cur_c2w if cur_c2w is not None else self.slam.estimate_c2w_list[idx].to(self.eng.device)
+        iters = self.iters_first if idx == 0 else self.num_joint_iters
+        self.optimize_map(iters, idx, gt_color, gt_depth, gt_c2w, self.keyframe_dict, self.keyframe_list, cur_c2w)
+        if idx % self.keyframe_every == 0 or idx == self.slam.n_img - 2:
+            self.keyframe_list.append(idx)
+            self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': gt_color, 'depth': gt_depth, 'est_c2w': cur_c2w.clone()})
+        self.slam.mapping_idx[0] = idx
+        return self.last_log
+
+    def run(self, time_string=None):
+        raise NotImplementedError('Point_SLAM.run drives map_frame / track_frame in one process')
+
+
+def _bilinear_zero_border(img, u, v):
+    """cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) at float pixel coordinates (u = column, v = row)."""
+    H, W = img.shape
+    u0, v0 = torch.floor(u), torch.floor(v)
+    fu, fv = u - u0, v - v0
+    out = torch.zeros_like(u)
+    for du, dv, wgt in ((0, 0, (1 - fu) * (1 - fv)), (1, 0, fu * (1 - fv)), (0, 1, (1 - fu) * fv), (1, 1, fu * fv)):
+        uu, vv = (u0 + du).long(), (v0 + dv).long()
+        ok = (uu >= 0) & (uu < W) & (vv >= 0) & (vv < H)
+        val = img[vv.clamp(0, H - 1), uu.clamp(0, W - 1)]
+        out = out + torch.where(ok, val * wgt, torch.zeros_like(val))
+    return out
+
+
+# ============================================================================================ Tracker
+class Tracker:
+    def __init__(self, cfg, args, slam):
+        self.cfg, self.slam = cfg, slam
+        self.eng = slam.eng
+        t = cfg['tracking']
+        self.npc, self.decoders, self.renderer = slam.npc, slam.shared_decoders, slam.renderer
+        self.renderer.sigmoid_coefficient = cfg['rendering']['sigmoid_coef_tracker']
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
+        self.cam_lr, self.num_cam_iters, self.tracking_pixels = t['lr'], t['iters'], t['pixels']
+        self.separate_LR, self.w_color_loss = t['separate_LR'], t['w_color_loss']
+        self.ignore_edge_W, self.ignore_edge_H = t['ignore_edge_W'], t['ignore_edge_H']
+        self.use_color_in_tracking, self.const_speed_assumption = t['use_color_in_tracking'], t['const_speed_assumption']
+        self.gt_camera = t.get('gt_camera', False)
+        self.gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219) + 3)
+        self.last_log = None
+
+    def set_pipe(self, pipe):
+        self.pipe = pipe
+
+    def update_para_from_mapping(self):
+        pass            # one process, one copy of the map: nothing to clone (Tracker.py:199-212)
+
+    def optimize_cam_in_batch(self, camera_tensor, gt_color, gt_depth, batch_size, optimizer=None, selected_index=None):
+        """One pose iteration through the autograd bridge with a caller-supplied torch optimiser
+        (reference signature, Tracker.py:102-197).  track_frame uses the fused loop instead."""
+        dev = self.eng.device
+        H, W = self.H, self.W
+        c2w = get_camera_from_tensor(camera_tensor)
+        ro, rd, gd, gc, i, j = get_samples(self.ignore_edge_H, H - self.ignore_edge_H, self.ignore_edge_W, W - self.ignore_edge_W,
+                                           batch_size, H, W, self.fx, self.fy, self.cx, self.cy, c2w, gt_depth, gt_color, dev,
+                                           depth_filter=True, return_index=True)
+        with torch.no_grad():
+            inside = gd <= torch.minimum(10 * gd.median(), 1.2 * gd.max())
+        ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+        depth, unc, color, _ = self.renderer.render_batch_ray(self.npc, self.decoders, rd, ro, dev, 'color', gt_depth=gd, is_tracker=True)
+        unc = unc.detach()
+        tmp = torch.abs(gd - depth) / torch.sqrt(unc + 1e-10)
+        mask = (tmp < 10 * tmp.mean()) & (gd > 0) & (~torch.isnan(depth)) & (~torch.isnan(unc))
+        geo_loss = torch.clamp(tmp, min=0.0, max=1e3)[mask].sum()
+        color_loss = torch.abs(gc - color)[mask].sum()
+        loss = geo_loss + (self.w_color_loss * color_loss if self.use_color_in_tracking else 0.0)
+        if optimizer is not None:
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        return loss.item(), (color_loss / mask.shape[0]).item(), (geo_loss / mask.shape[0]).item()
+
+    def track_frame(self, idx, gt_color, gt_depth, gt_c2w):
+        """Pose of frame idx (Tracker.py:281-409)."""
+        slam, eng = self.slam, self.eng
+        if idx == 0 or self.gt_camera:
+            c2w = gt_c2w.clone()
+        else:
+            pre = slam.estimate_c2w_list[idx - 1].to(eng.device).float()
+            if self.const_speed_assumption and idx - 2 >= 0:
+                delta = pre @ torch.linalg.inv(slam.estimate_c2w_list[idx - 2].to(eng.device).float())
+                init = delta @ pre
+            else:
+                init = pre
+            cam = get_tensor_from_camera(init).to(eng.device)
+            gt_cam = get_tensor_from_camera(gt_c2w).to(eng.device)
+            if torch.dot(cam[:4], gt_cam[:4]).item() < 0:
+                cam[:4] *= -1
+            rcfg = render_cfg_from(self.cfg, self.cfg['rendering']['sigmoid_coef_tracker'])
+            to = steps.TrackOptimizer(eng, rcfg, self.decoders.dec, self.npc.knn, self.npc.cloud_pos(), self.npc.get_geo_feats(),
+                                      self.npc.get_col_feats(), self.tracking_pixels, self.cam_lr, separate_lr=self.separate_LR,
+                                      w_color=self.w_color_loss, use_color=self.use_color_in_tracking)
+            win = (self.ignore_edge_H, self.H - self.ignore_edge_H, self.ignore_edge_W, self.W - self.ignore_edge_W)
+            n = (win[1] - win[0]) * (win[3] - win[2])
+            rnd = torch.randint(0, n, (self.num_cam_iters, self.tracking_pixels), generator=self.gen, dtype=torch.int32).to(eng.device)
+            best, log = to.track(cam, gt_depth, gt_color, self.num_cam_iters, win, (self.fx, self.fy, self.cx, self.cy), rnd)
+            self.last_log = log
+            c2w = torch.eye(4, device=eng.device)
+            c2w[:3] = get_camera_from_tensor(best)
+        slam.estimate_c2w_list[idx] = c2w.detach().cpu()
+        slam.gt_c2w_list[idx] = gt_c2w.detach().cpu()
+        slam.idx[0] = idx
+        return c2w
+
+    def run(self, time_string=None):
+        raise NotImplementedError('Point_SLAM.run drives map_frame / track_frame in one process')
+
+
+# ============================================================================================ Point_SLAM
+class SyntheticRoomDataset:
+    """(idx, color [H,W,3], depth [H,W], c2w [4,4]) from loopy_slam_amd.synthetic."""
+
+    def __init__(self, cfg, device, n_frames=None):
+        self.cfg, self.device = cfg, device
+        self.n_img = n_frames or cfg['data'].get('n_frames', 50)
+        c = cfg['cam']
+        self.intr = dict(H=c['H'], W=c['W'], fx=c['fx'], fy=c['fy'], cx=c['cx'], cy=c['cy'])
+
+    def __len__(self):
+        return self.n_img
+
+    def __getitem__(self, idx):
+        d, c, p = synthetic.render_frame(idx, intr=self.intr, device=self.device, holes=0.01, n_poses=2000)   # ~3 mm, 0.2 deg per frame
+        return idx, c, d, p
+
+
+class Point_SLAM:
+    def __init__(self, cfg, args=None, share_npc=True, share_decoders=True, time_string=None, eng=None, dataset=None, dist=None):
+        self.cfg, self.args = cfg, args
+        self.eng = eng if eng is not None else core.Engine()
+        self.dist = dist
+        c = cfg['cam']
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = c['H'], c['W'], c['fx'], c['fy'], c['cx'], c['cy']
+        self.update_cam()
+        self.shared_decoders = NICER(cfg, eng=self.eng)
+        self.frame_reader = dataset if dataset is not None else SyntheticRoomDataset(cfg, self.eng.device)
+        self.n_img = len(self.frame_reader)
+        self.estimate_c2w_list = torch.zeros((self.n_img, 4, 4))
+        self.gt_c2w_list = torch.zeros((self.n_img, 4, 4))
+        self.idx = torch.zeros(1, dtype=torch.int32)
+        self.mapping_idx = torch.zeros(1, dtype=torch.int32)
+        self.npc = NeuralPointCloud(cfg, self, args, eng=self.eng)
+        self.renderer = Renderer(cfg, args, self)
+        self.renderer_map = Renderer(cfg, args, self)
+        self.mapper = Mapper(cfg, args, self)
+        self.tracker = Tracker(cfg, args, self)
+
+    def update_cam(self):
+        """crop_edge shifts the principal point and shrinks the image (Point_SLAM.py:155-175)."""
+        e = self.cfg['cam'].get('crop_edge', 0) or 0
+        if e > 0:
+            self.H -= 2 * e
+            self.W -= 2 * e
+            self.cx -= e
+            self.cy -= e
+
+    def run(self, n_frames=None, callback=None):
+        """Alternate tracking (every frame) and mapping (frame 0 and every `every_frame`-th), as the reference's
+        two processes do through their pipe (Tracker.py:272-273,417-418; Mapper.py:836-842)."""
+        n = n_frames or self.n_img
+        every = self.cfg['mapping']['every_frame']
+        for i in range(n):
+            idx, color, depth, c2w = self.frame_reader[i]
+            est = self.tracker.track_frame(idx, color, depth, c2w)
+            if idx == 0 or idx % every == 0 or idx == n - 1:
+                self.mapper.map_frame(idx, color, depth, c2w, cur_c2w=est)
+            if callback:
+                callback(idx, est, c2w)
+        return self.estimate_c2w_list[:n], self.gt_c2w_list[:n]

@@ -1,0 +1,105 @@
+"""Multi-GPU path on CPU: world_size 2, gloo.  Ray-sharded data parallel — every rank renders/back-propagates its
+shard, ONE all-reduce sums {decoder-blob, selected feature-row} gradients, the same Adam step runs everywhere
+(loopy_slam_amd/parallel.py).  Checked against a single process that sees both shards in one batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+HH, WW = 24, 32
+INTR = (40.0, 40.0, 15.5, 11.5)
+R, ITERS = 64, 2
+LRS = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
+STAGES = ['geometry', 'color']
+
+
+def build(eng, R_batch, dctx):
+    from loopy_slam_amd import core, steps, synthetic as syn
+    from test_steps_parity import mini_scene
+    c2w, depth_img, color_img, pos, geo, col = mini_scene(3)
+    depth_img = depth_img.clone()
+    depth_img.reshape(-1)[5] = 1.0                       # no outlier: the inside mask keeps every positive depth
+    dec = core.DecoderBlob(eng).pack(syn.default_weights(seed=9))
+    pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
+    knn = core.KnnIndex(eng, capacity=pos.shape[0])
+    knn.build(pos_d)
+    rows = torch.arange(0, pos.shape[0], 3, dtype=torch.int32)
+    mo = steps.MapOptimizer(eng, core.RenderCfg(rel_pos=True), dec, knn, pos_d, geo_d, col_d, rows.to(eng.device), R_batch, LRS,
+                            w_color=0.1, dist=dctx)
+    mo.begin_frame()
+    frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
+    return mo, frames, dec, geo_d, col_d
+
+
+def draws():
+    g = torch.Generator().manual_seed(21)
+    return torch.randint(0, HH * WW, (ITERS, 2, R), generator=g, dtype=torch.int32)
+
+
+def worker(rank, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    from loopy_slam_amd import parallel
+    from util import make_engine
+    eng = make_engine('emu')
+    mo, frames, dec, geo_d, col_d = build(eng, R, parallel.DistContext(rank, 2))
+    rnd = draws()
+    fid = torch.zeros(R, dtype=torch.int32)
+    losses = []
+    for it in range(ITERS):
+        out4 = mo.iterate(STAGES[it], frames, rnd[it, rank].contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
+        t = out4.clone()
+        dist.all_reduce(t)
+        losses.append(float(t[0]))
+    if rank == 0:
+        q.put((losses, dec.blob.clone(), geo_d.clone(), col_d.clone()))
+    else:
+        q.put((losses, dec.blob.clone(), None, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_grad_allreduce_matches_single_process():
+    from util import make_engine
+    torch.set_num_threads(1)
+    eng = make_engine('emu')
+    mo, frames, dec, geo_d, col_d = build(eng, 2 * R, None)
+    rnd = draws()
+    fid = torch.zeros(2 * R, dtype=torch.int32)
+    ref_losses = []
+    for it in range(ITERS):
+        out4 = mo.iterate(STAGES[it], frames, rnd[it].reshape(-1).contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
+        ref_losses.append(float(out4[0]))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = [r for r in res if r[2] is not None][0]
+    other = [r for r in res if r[2] is None][0]
+    np.testing.assert_allclose(full[0], ref_losses, rtol=1e-5)
+    assert torch.equal(full[1], other[1])                                   # identical parameters on both ranks
+    np.testing.assert_allclose(full[1].numpy(), dec.blob.numpy(), rtol=0, atol=2e-5)
+    err = (full[2] - geo_d).abs()
+    assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.015
+    err = (full[3] - col_d).abs()
+    assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.0025
