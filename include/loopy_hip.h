@@ -207,6 +207,15 @@ int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_
 int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* depth_filtered, float* out_thr,
                    uint32_t* scratch, void* stream);
 
+/* ---------------------------------------------------------------- weight-gradient building block
+ * dW[n][k] += sum_rows A'[row][n] * B[row][k], db[n] += sum_rows A'[row][n] (db may be NULL); row-major operands.
+ * a_mode 0: A' = A;  1: A' = A * softplus100'(A2) with A2 the activation OUTPUT;  2: A' = A2[row] * A[row>>3]
+ * (rel-pos: per-neighbour weight times the per-sample gradient).  This is what lk_render_bwd runs for every
+ * decoder matrix (torch: grad of nn.Linear weights, decoder.py:265-288,480-546). */
+int lk_wgrad_single(const float* A, int32_t lda, int32_t a_mode, const float* A2, int32_t lda2,
+                    const float* B, int32_t ldb, int32_t N, int32_t K, int64_t rows,
+                    float* dW, int32_t ldw, float* db, int32_t chunk, void* stream);
+
 /* ---------------------------------------------------------------- measurement
  * Per-kernel GPU time with HIP events recorded on the launch stream around the selected kernels
  * (names: comma-separated, e.g. "k_decode_bwd", or "*").  lk_profile_end synchronises those events and writes

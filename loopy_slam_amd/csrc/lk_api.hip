@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 using namespace lkw;
 
@@ -164,7 +165,7 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
 
 // ------------------------------------------------------------------ render backward
 namespace {
-struct BwdLayout { int64_t d_raw, dc_geo, dc_col, dp_embed, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, dh_col, rows, total; };
+struct BwdLayout { int64_t d_raw, dc_geo, dc_col, dp_embed, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -180,10 +181,28 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.part_bg = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 32), 4) * 288;
     L.part_br = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 4), 4) * 32;
     const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    L.hbar = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 128 * P;
+    L.w_sum = o; o += P;
     L.dh_col = o; if (color && gw) o += 640 * P;
-    L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 320 * P;
+    L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 192 * P;
     L.total = o;
     return L;
+}
+}  // namespace
+
+// side stream for the part of the backward that is independent of the rest (colour weight gradients): the
+// kernels of one training batch are latency bound (fewer waves than SIMDs), so running two of them side by side
+// is close to free.  Fork/join with events; created once per process.
+namespace {
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+SideStream& side_stream() {
+    static SideStream s;
+    if (!s.st) {
+        s.ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return s;
 }
 }  // namespace
 
@@ -226,37 +245,18 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     lk_launch_decode_bwd(db, st);
     if (gw) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
-    if (relpos) {
-        LkRelposBwdArgs rb;
-        rb.R = d->R; rb.S = d->S; rb.P = P; rb.min_nn = d->min_nn; rb.flags = flags;
-        rb.rays_o = d->rays_o; rb.rays_d = d->rays_d; rb.z = d->z; rb.pos = d->pos; rb.col_feats = d->col_feats;
-        rb.nbr_idx = d->nbr_idx; rb.nbr_w = d->nbr_w; rb.nbr_count = d->nbr_count;
-        rb.W = d->weights; rb.Wfrag = d->weights_frag; rb.dc_col = S0 + L.dc_col;
-        rb.g_col_feats = d->g_col_feats; rb.g_weights = d->g_weights;
-        rb.dw_rel = S0 + L.dw_rel; rb.dp_rel = S0 + L.dp_rel; rb.rows = S0 + L.rows; rb.w_eff = S0 + L.w_eff;
-        rb.part_br = S0 + L.part_br;
-        lk_launch_relpos_bwd(rb, st);
-        if (gw) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
-    }
-
-    if (gf || gr) {
-        LkInterpBwdArgs ib;
-        ib.R = d->R; ib.S = d->S; ib.P = P; ib.min_nn = d->min_nn; ib.flags = flags;
-        ib.rays_o = d->rays_o; ib.rays_d = d->rays_d; ib.z = d->z; ib.r2_ray = d->r2_ray; ib.r2_static = d->r2_static;
-        ib.pos = d->pos; ib.geo_feats = d->geo_feats; ib.col_feats = d->col_feats;
-        ib.nbr_idx = d->nbr_idx; ib.nbr_w = d->nbr_w; ib.nbr_count = d->nbr_count;
-        ib.dc_geo = S0 + L.dc_geo; ib.dc_col = S0 + L.dc_col;
-        ib.dw_rel = relpos ? S0 + L.dw_rel : nullptr;
-        ib.dp_embed = S0 + L.dp_embed; ib.dp_rel = relpos ? S0 + L.dp_rel : nullptr;
-        ib.g_geo_feats = d->g_geo_feats; ib.g_col_feats = d->g_col_feats; ib.dp_total = S0 + L.dp_total;
-        lk_launch_interp_bwd(ib, st);
-    }
-    if (gr) {
-        LkRaysBwdArgs rr;
-        rr.R = d->R; rr.S = d->S; rr.z = d->z; rr.dp_total = S0 + L.dp_total; rr.g_rays_o = d->g_rays_o; rr.g_rays_d = d->g_rays_d;
-        lk_launch_rays_bwd(rr, st);
-    }
+    SideStream& ss = side_stream();
+    // Measured on MI355X: forking the colour weight gradients next to the rel-pos backward gained only 5 % (both
+    // are memory-pipeline bound, not latency bound) and blurs per-kernel timing, so it stays off.
+    const bool kForkColorWgrad = false;
+    const bool forked = kForkColorWgrad && gw && color && ss.ok;
     if (gw && color) {
+        hipStream_t wst = st;
+        if (forked) {
+            (void)hipEventRecord(ss.fork, st);
+            (void)hipStreamWaitEvent(ss.st, ss.fork, 0);
+            wst = ss.st;
+        }
         // colour decoder weight gradients as streamed reductions over the saved rows (geometry decoder weights
         // other than embedder._B are frozen in every reference config: mapping.fix_geo_decoder = True)
         const float* act_a = d->act + (size_t)P * LK_ACT_GEO_A;
@@ -289,23 +289,77 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J.B = act_h + 4 * 128; J.ldb = LK_ACT_COL_H;
             J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
         }
-        wa.n_jobs = nj; wa.chunk = 512;
-        lk_launch_wgrad(wa, P, st);
-        if (relpos) {
+        wa.n_jobs = nj; wa.chunk = getenv("LK_EXP_CHUNK") ? atoi(getenv("LK_EXP_CHUNK")) : 256;
+        lk_launch_wgrad(wa, P, wst);
+        if (forked) (void)hipEventRecord(ss.join, ss.st);
+    }
+
+    if (relpos) {
+        LkRelposBwdArgs rb;
+        rb.R = d->R; rb.S = d->S; rb.P = P; rb.min_nn = d->min_nn; rb.flags = flags;
+        rb.rays_o = d->rays_o; rb.rays_d = d->rays_d; rb.z = d->z; rb.pos = d->pos; rb.col_feats = d->col_feats;
+        rb.nbr_idx = d->nbr_idx; rb.nbr_w = d->nbr_w; rb.nbr_count = d->nbr_count;
+        rb.W = d->weights; rb.Wfrag = d->weights_frag; rb.dc_col = S0 + L.dc_col;
+        rb.g_col_feats = d->g_col_feats; rb.g_weights = d->g_weights;
+        rb.dw_rel = S0 + L.dw_rel; rb.dp_rel = S0 + L.dp_rel; rb.rows = S0 + L.rows; rb.w_eff = S0 + L.w_eff;
+        rb.part_br = S0 + L.part_br; rb.hbar = S0 + L.hbar; rb.w_sum = S0 + L.w_sum;
+        lk_launch_relpos_bwd(rb, st);
+        if (gw) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
+    }
+
+    if (gf || gr) {
+        LkInterpBwdArgs ib;
+        ib.R = d->R; ib.S = d->S; ib.P = P; ib.min_nn = d->min_nn; ib.flags = flags;
+        ib.rays_o = d->rays_o; ib.rays_d = d->rays_d; ib.z = d->z; ib.r2_ray = d->r2_ray; ib.r2_static = d->r2_static;
+        ib.pos = d->pos; ib.geo_feats = d->geo_feats; ib.col_feats = d->col_feats;
+        ib.nbr_idx = d->nbr_idx; ib.nbr_w = d->nbr_w; ib.nbr_count = d->nbr_count;
+        ib.dc_geo = S0 + L.dc_geo; ib.dc_col = S0 + L.dc_col;
+        ib.dw_rel = relpos ? S0 + L.dw_rel : nullptr;
+        ib.dp_embed = S0 + L.dp_embed; ib.dp_rel = relpos ? S0 + L.dp_rel : nullptr;
+        ib.g_geo_feats = d->g_geo_feats; ib.g_col_feats = d->g_col_feats; ib.dp_total = S0 + L.dp_total;
+        lk_launch_interp_bwd(ib, st);
+    }
+    if (gr) {
+        LkRaysBwdArgs rr;
+        rr.R = d->R; rr.S = d->S; rr.z = d->z; rr.dp_total = S0 + L.dp_total; rr.g_rays_o = d->g_rays_o; rr.g_rays_d = d->g_rays_d;
+        lk_launch_rays_bwd(rr, st);
+    }
+    if (gw && relpos) {
+        float* G = d->g_weights;
+        {
             LkWgradArgs wr;
             memset(&wr, 0, sizeof(wr));
             const float* rows = S0 + L.rows;
-            LkWgradJob& J1 = wr.job[0];       // linear1: [128][52]
-            J1.A = rows + 128; J1.lda = 320; J1.a_mode = 0; J1.B = rows + 256; J1.ldb = 320;
+            LkWgradJob& J1 = wr.job[0];       // linear1 [128][52]: rows = neighbour rows, A = d hid, B = x
+            J1.A = rows; J1.lda = 192; J1.a_mode = 0; J1.B = rows + 128; J1.ldb = 192;
             J1.N = HC; J1.K = KR; J1.rows = 8 * P; J1.dW = G + R_W1; J1.ldw = KRP; J1.db = G + R_B1;
-            LkWgradJob& J2 = wr.job[1];       // linear2: [32][128], A = w_eff[row] * dc[row>>3]
-            J2.A = S0 + L.dc_col; J2.lda = LK_C; J2.a_mode = 2; J2.A2 = S0 + L.w_eff; J2.lda2 = 1;
-            J2.B = rows; J2.ldb = 320;
-            J2.N = CF; J2.K = HC; J2.rows = 8 * P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
-            wr.n_jobs = 2; wr.chunk = 2048;
+            LkWgradJob& J2 = wr.job[1];       // linear2 [32][128]: rows = SAMPLES, A = (sum_j w_j) * d c, B = sum_j w_j hid_j
+            J2.A = S0 + L.dc_col; J2.lda = LK_C; J2.a_mode = 2; J2.A2 = S0 + L.w_sum; J2.lda2 = 1;
+            J2.B = S0 + L.hbar; J2.ldb = 128;
+            J2.N = CF; J2.K = HC; J2.rows = P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
+            wr.n_jobs = 2; wr.chunk = getenv("LK_EXP_CHUNK2") ? atoi(getenv("LK_EXP_CHUNK2")) : 512;
             lk_launch_wgrad(wr, 8 * P, st);
         }
     }
+    if (forked) (void)hipStreamWaitEvent(st, ss.join, 0);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+// ------------------------------------------------------------------ building block: one weight-gradient reduction
+extern "C" int lk_wgrad_single(const float* A, int32_t lda, int32_t a_mode, const float* A2, int32_t lda2,
+                               const float* B, int32_t ldb, int32_t N, int32_t K, int64_t rows,
+                               float* dW, int32_t ldw, float* db, int32_t chunk, void* stream_) {
+    LK_REQUIRE(A && B && dW && N > 0 && N <= 128 && K > 0 && K <= 192 && rows >= 0 && chunk >= 32, "lk_wgrad_single: bad arguments");
+    LK_REQUIRE((N % 4 == 0 || lda >= ((N + 3) / 4) * 4) && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "lk_wgrad_single: rows must be float4-addressable");
+    if (rows == 0) return LK_OK;
+    LkWgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    LkWgradJob& J = wa.job[0];
+    J.A = A; J.lda = lda; J.a_mode = a_mode; J.A2 = A2; J.lda2 = lda2; J.B = B; J.ldb = ldb;
+    J.N = N; J.K = K; J.rows = (int)rows; J.dW = dW; J.ldw = ldw; J.db = db;
+    wa.n_jobs = 1; wa.chunk = chunk;
+    lk_launch_wgrad(wa, (int)rows, (hipStream_t)stream_);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

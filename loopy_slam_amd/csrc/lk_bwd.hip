@@ -316,20 +316,23 @@ __global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a) {
     }
 }
 
-// out[j] += sum_p part[p][j]   (one thread column per j; 4 row-lanes per column, combined through LDS)
+// out[j] += sum_p part[p][j].  grid = (width/64, ceil(n_parts/256)): 64 columns x 4 row-lanes per block, 64 partial rows
+// per lane, combined through LDS, then ONE atomic per (block, column) — a few tens of adds per address in total.
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out) {
     __shared__ float sh[4][64];
     const int col = blockIdx.x * 64 + ((int)threadIdx.x & 63), q = (int)threadIdx.x >> 6;
+    const int p0 = blockIdx.y * 256;
+    const int p1 = (p0 + 256 < n_parts) ? p0 + 256 : n_parts;
     float s = 0.0f;
     if (col < width)
-        for (int p = q; p < n_parts; p += 4) s += part[(size_t)p * width + col];
+        for (int p = p0 + q; p < p1; p += 4) s += part[(size_t)p * width + col];
     sh[q][threadIdx.x & 63] = s;
     __syncthreads();
-    if (q == 0 && col < width) out[col] += sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (q == 0 && col < width) atomicAdd(out + col, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(lk_cdiv(width, 64)), dim3(256), 0, st, part, n_parts, width, out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(lk_cdiv(width, 64), lk_cdiv(n_parts, 256)), dim3(256), 0, st, part, n_parts, width, out);
     return LK_OK;
 }
 

@@ -215,23 +215,43 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) dhid[nb][q] *= lk_softplus100_grad_from_out(hid[nb][q]);
-    if (want_w && live) {     // rows for the streamed weight-gradient reductions: hid | dhid | x
-        if (h == 0) a.w_eff[(size_t)sp * 8 + nb_i] = wgt;
-        float* row = a.rows + ((size_t)sp * 8 + nb_i) * 320;
+    if (want_w) {
+        // operands of the streamed weight-gradient reductions.
+        //   linear1: rows [8P][192] = d hid (128) | x (64)
+        //   linear2: dW2 = sum_rows (w d c) hid^T = sum_samples d c (sum_j w_j hid_j)^T  -> only the per-SAMPLE weighted
+        //            hidden vector Hbar [P][128] and the per-sample weight sum are needed (8x fewer rows, no hid rows)
+        if (live) {
+            if (h == 0) a.w_eff[(size_t)sp * 8 + nb_i] = wgt;
+            float* row = a.rows + ((size_t)sp * 8 + nb_i) * 192;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(row + nb * 32 + 8 * g + 4 * h) =
+                        make_float4(dhid[nb][4 * g], dhid[nb][4 * g + 1], dhid[nb][4 * g + 2], dhid[nb][4 * g + 3]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(row + 128 + 8 * g + 4 * h) = make_float4(x0[4 * g], x0[4 * g + 1], x0[4 * g + 2], x0[4 * g + 3]);
+                *reinterpret_cast<float4*>(row + 160 + 8 * g + 4 * h) = make_float4(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3]);
+            }
+        }
+        float wsum = wgt;
+        wsum += __shfl_xor(wsum, 1); wsum += __shfl_xor(wsum, 2); wsum += __shfl_xor(wsum, 4);
+        if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<float4*>(row + nb * 32 + 8 * g + 4 * h) =
-                    make_float4(hid[nb][4 * g], hid[nb][4 * g + 1], hid[nb][4 * g + 2], hid[nb][4 * g + 3]);
-                *reinterpret_cast<float4*>(row + 128 + nb * 32 + 8 * g + 4 * h) =
-                    make_float4(dhid[nb][4 * g], dhid[nb][4 * g + 1], dhid[nb][4 * g + 2], dhid[nb][4 * g + 3]);
-            }
+                float v[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<float4*>(row + 256 + 8 * g + 4 * h) = make_float4(x0[4 * g], x0[4 * g + 1], x0[4 * g + 2], x0[4 * g + 3]);
-            *reinterpret_cast<float4*>(row + 288 + 8 * g + 4 * h) = make_float4(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3]);
-        }
+                for (int t = 0; t < 4; ++t) {
+                    float sred = wgt * hid[nb][4 * g + t];
+                    sred += __shfl_xor(sred, 1); sred += __shfl_xor(sred, 2); sred += __shfl_xor(sred, 4);
+                    v[t] = sred;
+                }
+                if (live && nb_i == 0)
+                    *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+            }
     }
     // ---- d x = W1^T d hid   (virtual 64 input units: 0..19 embedding, 20..51 feature channels)
     f32x16 dx[2];
@@ -320,32 +340,34 @@ __global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
 #define WG_LDA 132
 #define WG_LDB 196
 
-__device__ __forceinline__ float4 wg_fetch_a(const LkWgradJob& J, long long row, long long c1, int c4) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < c1) {
-        if (J.a_mode == 2) {
-            const float w = J.A2[row];
-            const float4 d = *reinterpret_cast<const float4*>(J.A + (size_t)(row >> 3) * J.lda + 4 * c4);
-            v = make_float4(w * d.x, w * d.y, w * d.z, w * d.w);
-        } else {
-            v = *reinterpret_cast<const float4*>(J.A + (size_t)row * J.lda + 4 * c4);
-            if (J.a_mode == 1) {
-                const float4 g = *reinterpret_cast<const float4*>(J.A2 + (size_t)row * J.lda2 + 4 * c4);
-                v.x *= lk_softplus100_grad_from_out(g.x); v.y *= lk_softplus100_grad_from_out(g.y);
-                v.z *= lk_softplus100_grad_from_out(g.z); v.w *= lk_softplus100_grad_from_out(g.w);
-            }
-        }
+// Raw operand fetches.  Nothing may CONSUME a prefetched register before the MFMA phase of the current tile has
+// been issued (a select or multiply right after the load makes the compiler wait for the data first, which
+// serialised load latency and MFMAs: 5.3 us per tile instead of 2): addresses are clamped instead of
+// predicated, and masking / the softplus' factor / the rel-pos row weight are applied when the tile is written to LDS.
+__device__ __forceinline__ void wg_fetch_a(const LkWgradJob& J, long long row, int c4, float4& v, float4& v2) {
+    if (J.a_mode == 2) {
+        v = *reinterpret_cast<const float4*>(J.A + (size_t)row * J.lda + 4 * c4);
+        const float w = J.A2[row];
+        v2 = make_float4(w, w, w, w);
+    } else {
+        v = *reinterpret_cast<const float4*>(J.A + (size_t)row * J.lda + 4 * c4);
+        if (J.a_mode == 1) v2 = *reinterpret_cast<const float4*>(J.A2 + (size_t)row * J.lda2 + 4 * c4);
+    }
+}
+__device__ __forceinline__ float4 wg_finish_a(const LkWgradJob& J, float4 v, float4 v2, bool ok) {
+    if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (J.a_mode == 1) {
+        v.x *= lk_softplus100_grad_from_out(v2.x); v.y *= lk_softplus100_grad_from_out(v2.y);
+        v.z *= lk_softplus100_grad_from_out(v2.z); v.w *= lk_softplus100_grad_from_out(v2.w);
+    } else if (J.a_mode == 2) {
+        v.x *= v2.x; v.y *= v2.x; v.z *= v2.x; v.w *= v2.x;
     }
     return v;
 }
-__device__ __forceinline__ float4 wg_fetch_b(const LkWgradJob& J, long long row, long long c1, int c4) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < c1) {
-        const int k = 4 * c4;
-        if (J.B2 && k >= J.k_split) v = *reinterpret_cast<const float4*>(J.B2 + (size_t)row * J.ldb2 + (k - J.k_split));
-        else v = *reinterpret_cast<const float4*>(J.B + (size_t)row * J.ldb + k);
-    }
-    return v;
+__device__ __forceinline__ float4 wg_fetch_b(const LkWgradJob& J, long long row, int c4) {
+    const int k = 4 * c4;
+    if (J.B2 && k >= J.k_split) return *reinterpret_cast<const float4*>(J.B2 + (size_t)row * J.ldb2 + (k - J.k_split));
+    return *reinterpret_cast<const float4*>(J.B + (size_t)row * J.ldb + k);
 }
 
 __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
@@ -363,27 +385,36 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) acc[q] = lk_zero16();
     float bsum = 0.0f;
-    float4 ra[4], rb[6];
+    float4 ra[4], ra2[4], rb[6];
     // zero the padding columns once (tiles narrower than a multiple of 32 leave stale LDS otherwise)
     for (int e = t; e < WG_RT * WG_LDA; e += 256) sA[e] = 0.0f;
     for (int e = t; e < WG_RT * WG_LDB; e += 256) sB[e] = 0.0f;
+    // element -> (row-in-tile, float4 column), clamped so that every thread always has a legal address
+    int ar[4], ac[4], br[6], bc[6];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int e = t + 256 * q; ra[q] = (e < nA) ? wg_fetch_a(J, c0 + e / N4, c1, e % N4) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int q = 0; q < 4; ++q) { const int e = min(t + 256 * q, nA - 1); ar[q] = e / N4; ac[q] = e - ar[q] * N4; ra2[q] = make_float4(1.f, 1.f, 1.f, 1.f); }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { const int e = t + 256 * q; rb[q] = (e < nB) ? wg_fetch_b(J, c0 + e / K4, c1, e % K4) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int q = 0; q < 6; ++q) { const int e = min(t + 256 * q, nB - 1); br[q] = e / K4; bc[q] = e - br[q] * K4; }
+    const long long last = c1 - 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wg_fetch_a(J, min(c0 + ar[q], last), ac[q], ra[q], ra2[q]);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rb[q] = wg_fetch_b(J, min(c0 + br[q], last), bc[q]);
     for (long long tile = c0; tile < c1; tile += WG_RT) {
         __syncthreads();                                               // previous tile fully consumed
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int e = t + 256 * q; if (e < nA) *reinterpret_cast<float4*>(sA + (e / N4) * WG_LDA + 4 * (e % N4)) = ra[q]; }
+        for (int q = 0; q < 4; ++q)
+            if (t + 256 * q < nA) *reinterpret_cast<float4*>(sA + ar[q] * WG_LDA + 4 * ac[q]) = wg_finish_a(J, ra[q], ra2[q], tile + ar[q] < c1);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { const int e = t + 256 * q; if (e < nB) *reinterpret_cast<float4*>(sB + (e / K4) * WG_LDB + 4 * (e % K4)) = rb[q]; }
+        for (int q = 0; q < 6; ++q)
+            if (t + 256 * q < nB) *reinterpret_cast<float4*>(sB + br[q] * WG_LDB + 4 * bc[q]) = (tile + br[q] < c1) ? rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         const long long nxt = tile + WG_RT;
-        if (nxt < c1) {                                                // prefetch the next tile into registers
+        if (nxt < c1) {                                                // prefetch the next tile: raw loads only
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int e = t + 256 * q; if (e < nA) ra[q] = wg_fetch_a(J, nxt + e / N4, c1, e % N4); }
+            for (int q = 0; q < 4; ++q) wg_fetch_a(J, min(nxt + ar[q], last), ac[q], ra[q], ra2[q]);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) { const int e = t + 256 * q; if (e < nB) rb[q] = wg_fetch_b(J, nxt + e / K4, c1, e % K4); }
+            for (int q = 0; q < 6; ++q) rb[q] = wg_fetch_b(J, min(nxt + br[q], last), bc[q]);
         }
         if (J.db && t < J.N) {
 #pragma unroll 8
@@ -396,9 +427,13 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
                 const int nb = u / KB, kb = u - nb * KB;
                 const float* pa = sA + hh * WG_LDA + nb * 32 + l31;
                 const float* pb = sB + hh * WG_LDB + kb * 32 + l31;
+                // all 32 operand reads of this block are issued before its 16 MFMAs: with one wave per SIMD nothing
+                // else hides the LDS latency (an interleaved read->MFMA chain measured 2.7x the MFMA time)
+                float av[WG_RT / 2], bv[WG_RT / 2];
 #pragma unroll
-                for (int s2 = 0; s2 < WG_RT / 2; ++s2)
-                    acc[q] = lk_mfma(pa[2 * s2 * WG_LDA], pb[2 * s2 * WG_LDB], acc[q]);
+                for (int s2 = 0; s2 < WG_RT / 2; ++s2) { av[s2] = pa[2 * s2 * WG_LDA]; bv[s2] = pb[2 * s2 * WG_LDB]; }
+#pragma unroll
+                for (int s2 = 0; s2 < WG_RT / 2; ++s2) acc[q] = lk_mfma(av[s2], bv[s2], acc[q]);
             }
         }
     }

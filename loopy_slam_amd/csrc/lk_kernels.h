@@ -106,14 +106,16 @@ struct LkRelposBwdArgs {
     float* g_col_feats; float* g_weights;
     float* dw_rel;                                 // [P,8]  (GRAD_RAYS)
     float* dp_rel;                                 // [P,4]  (GRAD_RAYS)
-    float* rows;                                   // [8P][320]: hid(128) | dhid(128) | x(64)  (GRAD_WEIGHTS)
+    float* rows;                                   // [8P][192]: dhid(128) | x(64)  (GRAD_WEIGHTS)
+    float* hbar;                                   // [P][128] sum_j w_j hid_j
+    float* w_sum;                                  // [P] sum_j w_j
     float* w_eff;                                  // [8P] weight actually applied to each neighbour row
     float* part_br;                                // [n_blocks][32] per-workgroup partial sums of d embedder_rel_pos._B
 };
 
 // weight gradients: dW[n][k] += sum_rows A[row][n] * B[row][k]  (one wave per (job, n-block, row chunk))
 struct LkWgradJob {
-    const float* A; int lda; int a_mode;           // 0 plain, 1 A*softplus'(A2), 2 nbr_w[row]*dc[row>>3][n]
+    const float* A; int lda; int a_mode;           // 0 plain, 1 A*softplus'(A2), 2 A2[row]*A[row][n]
     const float* A2; int lda2;
     const float* B; int ldb;
     const float* B2; int ldb2; int k_split;        // optional second source for columns k >= k_split

@@ -274,11 +274,24 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
             if (u && (u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (t == 0) {
-            unsigned rank = s_rank, b = 0;
-            for (; b < 256; ++b) { if (rank < hist[b]) break; rank -= hist[b]; }
-            s_rank = rank;
-            s_prefix = prefix | (b << shift);
+        // locate the bin that holds the wanted rank: wave 0 scans the 256-bin histogram (4 bins per lane)
+        if (t < 64) {
+            const unsigned rank = s_rank;                   // every lane reads before the (later) single write
+            const unsigned h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+            const unsigned tot = h0 + h1 + h2 + h3;
+            unsigned incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned nbv = __shfl_up(incl, o);
+                if (t >= o) incl += nbv;
+            }
+            const unsigned excl = incl - tot;
+            if (rank >= excl && rank < incl) {              // exactly one lane
+                unsigned r = rank - excl, b = 4 * t;
+                if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
+                s_rank = r;
+                s_prefix = prefix | (b << shift);
+            }
         }
         __syncthreads();
     }

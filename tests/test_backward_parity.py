@@ -107,3 +107,40 @@ def test_backward_tracker_golden(backend, name):
     if CFG[name]['exposure']:
         aff_t.backward(gs.g_affine.cpu())
         assert relerr(ef.grad, g['grad_exposure_feat']) < TOL
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('N,K,rows,mode', [(128, 128, 333, 0), (128, 168, 100, 1), (32, 128, 640, 2), (3, 128, 77, 0), (128, 40, 64, 1)])
+def test_wgrad_single_vs_matmul(backend, N, K, rows, mode):
+    """The weight-gradient reduction kernel against a plain matmul (ragged row counts, narrow/wide matrices,
+    the three A-operand modes, bias sums)."""
+    import ctypes as C
+    from loopy_slam_amd._ffi import ptr
+    eng = make_engine(backend)
+    g = torch.Generator().manual_seed(N * 1000 + K + rows)
+    lda = 4 if N == 3 else N + 4
+    ldb = K + 8
+    B = torch.randn(rows, ldb, generator=g)
+    if mode == 2:
+        A = torch.randn(rows, lda, generator=g)
+        A2 = torch.rand(rows, generator=g)
+        Aeff = A2[:, None] * A[:, :N]
+        lda2 = 1
+    else:
+        A = torch.randn(rows, lda, generator=g)
+        if N == 3:
+            A[:, 3] = 0
+        A2 = torch.rand(rows, lda, generator=g) * 0.05
+        lda2 = lda
+        Aeff = A[:, :N] * (1 - torch.exp(-100 * A2[:, :N])) if mode == 1 else A[:, :N]
+    ref = Aeff.double().T @ B[:, :K].double()
+    refb = Aeff.double().sum(0)
+    ldw = K + 4
+    dW, db = eng.zeros(N, ldw), eng.zeros(N)
+    Ad, A2d, Bd = eng.f32(A), eng.f32(A2), eng.f32(B)          # keep the device buffers alive across the launch
+    rc = eng.lib.dll.lk_wgrad_single(ptr(Ad), lda, mode, ptr(A2d), lda2, ptr(Bd), ldb, N, K, rows,
+                                     ptr(dW), ldw, ptr(db), 64, eng.stream)
+    eng.lib.check(rc, 'lk_wgrad_single')
+    np.testing.assert_allclose(dW.cpu().numpy()[:, :K], ref.numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    assert float(dW.cpu()[:, K:].abs().max()) == 0.0
+    np.testing.assert_allclose(db.cpu().numpy(), refb.numpy(), rtol=1e-4, atol=1e-4 * float(refb.abs().max()))
