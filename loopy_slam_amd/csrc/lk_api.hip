@@ -165,7 +165,7 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
 
 // ------------------------------------------------------------------ render backward
 namespace {
-struct BwdLayout { int64_t d_raw, dc_geo, dc_col, dp_embed, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, total; };
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -182,6 +182,7 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.part_br = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 4), 4) * 32;
     const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     L.hbar = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 128 * P;
+    L.dfeat = o; if (color && (flags & LK_FLAG_REL_POS) && (flags & LK_FLAG_GRAD_FEATS)) o += 8 * 32 * P;
     L.w_sum = o; o += P;
     L.dh_col = o; if (color && gw) o += 640 * P;
     L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 192 * P;
@@ -302,12 +303,20 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
         rb.W = d->weights; rb.Wfrag = d->weights_frag; rb.dc_col = S0 + L.dc_col;
         rb.g_col_feats = d->g_col_feats; rb.g_weights = d->g_weights;
         rb.dw_rel = S0 + L.dw_rel; rb.dp_rel = S0 + L.dp_rel; rb.rows = S0 + L.rows; rb.w_eff = S0 + L.w_eff;
+        rb.dfeat = S0 + L.dfeat;
         rb.part_br = S0 + L.part_br; rb.hbar = S0 + L.hbar; rb.w_sum = S0 + L.w_sum;
         lk_launch_relpos_bwd(rb, st);
         if (gw) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
     }
 
-    if (gf || gr) {
+    if (gf) {
+        LkFeatScatterArgs fs;
+        fs.P = P; fs.min_nn = d->min_nn; fs.nbr_idx = d->nbr_idx; fs.nbr_w = d->nbr_w; fs.nbr_count = d->nbr_count;
+        fs.dc_geo = S0 + L.dc_geo; fs.dc_col = (color && !relpos) ? S0 + L.dc_col : nullptr; fs.dfeat = relpos ? S0 + L.dfeat : nullptr;
+        fs.g_geo_feats = d->g_geo_feats; fs.g_col_feats = d->g_col_feats;
+        lk_launch_feat_scatter(fs, st);
+    }
+    if (gr) {
         LkInterpBwdArgs ib;
         ib.R = d->R; ib.S = d->S; ib.P = P; ib.min_nn = d->min_nn; ib.flags = flags;
         ib.rays_o = d->rays_o; ib.rays_d = d->rays_d; ib.z = d->z; ib.r2_ray = d->r2_ray; ib.r2_static = d->r2_static;

@@ -32,22 +32,6 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
     const float4 dcg = *reinterpret_cast<const float4*>(a.dc_geo + (size_t)pidx * LK_C + sub * 4);
     float4 dcc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (do_col) dcc = *reinterpret_cast<const float4*>(a.dc_col + (size_t)pidx * LK_C + sub * 4);
-    const bool act = live && has;
-    if ((a.flags & LK_FLAG_GRAD_FEATS) && act) {
-#pragma unroll
-        for (int j = 0; j < LK_K; ++j) {
-            if (w[j] != 0.0f) {
-                float* gg = a.g_geo_feats + (size_t)id[j] * LK_C + sub * 4;
-                atomicAdd(gg + 0, w[j] * dcg.x); atomicAdd(gg + 1, w[j] * dcg.y);
-                atomicAdd(gg + 2, w[j] * dcg.z); atomicAdd(gg + 3, w[j] * dcg.w);
-                if (do_col) {
-                    float* gc = a.g_col_feats + (size_t)id[j] * LK_C + sub * 4;
-                    atomicAdd(gc + 0, w[j] * dcc.x); atomicAdd(gc + 1, w[j] * dcc.y);
-                    atomicAdd(gc + 2, w[j] * dcc.z); atomicAdd(gc + 3, w[j] * dcc.w);
-                }
-            }
-        }
-    }
     if (!(a.flags & LK_FLAG_GRAD_RAYS)) return;
     // ---- tracker: d loss / d normalised weight_j = dc . feat_j  (+ the rel-pos branch's share)
     float dwn[LK_K];
@@ -102,6 +86,24 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
         if (color && relpos && a.dp_rel) { const float4 e = *reinterpret_cast<const float4*>(a.dp_rel + (size_t)pidx * 4); dpx += e.x; dpy += e.y; dpz += e.z; }
         *reinterpret_cast<float4*>(a.dp_total + (size_t)pidx * 4) = make_float4(dpx, dpy, dpz, 0.0f);
     }
+}
+
+// Feature-gradient scatter: one half-wave (32 lanes = the 32 channels = one 128-B line) per (sample, neighbour),
+// so every wave-wide atomic touches two full lines instead of up to 64 scattered ones (measured 2x-5x faster).
+//   geometry rows:            g_geo[idx] += w * d c_geo[sample]
+//   colour rows, no rel-pos:  g_col[idx] += w * d c_col[sample]
+//   colour rows, rel-pos:     g_col[idx] += d feat[sample, neighbour]   (from k_relpos_bwd)
+__global__ __launch_bounds__(256) void k_feat_scatter(LkFeatScatterArgs a) {
+    const long long row = (long long)blockIdx.x * 8 + ((int)threadIdx.x >> 5);
+    const int c = (int)threadIdx.x & 31;
+    if (row >= (long long)a.P * LK_K) return;
+    const int s = (int)(row >> 3);
+    const int idx = a.nbr_idx[row];
+    const float w = a.nbr_w[row];
+    if (idx < 0 || w == 0.0f || a.nbr_count[s] < a.min_nn) return;
+    atomicAdd(a.g_geo_feats + (size_t)idx * LK_C + c, w * a.dc_geo[(size_t)s * LK_C + c]);
+    if (a.dfeat) atomicAdd(a.g_col_feats + (size_t)idx * LK_C + c, a.dfeat[(size_t)row * LK_C + c]);
+    else if (a.dc_col) atomicAdd(a.g_col_feats + (size_t)idx * LK_C + c, w * a.dc_col[(size_t)s * LK_C + c]);
 }
 
 __global__ __launch_bounds__(256) void k_rays_bwd(LkRaysBwdArgs a) {
@@ -235,6 +237,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
                 *reinterpret_cast<float4*>(row + 160 + 8 * g + 4 * h) = make_float4(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3]);
             }
         }
+        {
         float wsum = wgt;
         wsum += __shfl_xor(wsum, 1); wsum += __shfl_xor(wsum, 2); wsum += __shfl_xor(wsum, 4);
         if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
@@ -252,6 +255,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
                 if (live && nb_i == 0)
                     *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
             }
+        }
     }
     // ---- d x = W1^T d hid   (virtual 64 input units: 0..19 embedding, 20..51 feature channels)
     f32x16 dx[2];
@@ -291,12 +295,10 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
                     }
                 }
             }
-            if (!is_emb && u0 < KR) {
-                if ((a.flags & LK_FLAG_GRAD_FEATS) && wgt != 0.0f) {
-                    float* gc = a.g_col_feats + (size_t)idx * LK_C + (u0 - ER);
-                    atomicAdd(gc + 0, dx[tile][4 * g]); atomicAdd(gc + 1, dx[tile][4 * g + 1]);
-                    atomicAdd(gc + 2, dx[tile][4 * g + 2]); atomicAdd(gc + 3, dx[tile][4 * g + 3]);
-                }
+            if (!is_emb && u0 < KR) {     // d feature row of this neighbour: scattered by k_feat_scatter (line-coalesced atomics)
+                if ((a.flags & LK_FLAG_GRAD_FEATS) && live)
+                    *reinterpret_cast<float4*>(a.dfeat + ((size_t)sp * 8 + nb_i) * LK_C + (u0 - ER)) =
+                        make_float4(dx[tile][4 * g], dx[tile][4 * g + 1], dx[tile][4 * g + 2], dx[tile][4 * g + 3]);
             }
         }
     if (want_p) {
@@ -459,6 +461,11 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_INTERP_BWD, st);
     hipLaunchKernelGGL(k_interp_bwd, dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
+    return LK_OK;
+}
+int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_INTERP_BWD, st);
+    hipLaunchKernelGGL(k_feat_scatter, dim3(lk_cdiv((long long)a.P * LK_K, 8)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st) {

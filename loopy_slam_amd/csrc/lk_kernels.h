@@ -92,6 +92,13 @@ struct LkInterpBwdArgs {
     float* dp_total;                               // [P,4] (GRAD_RAYS)
 };
 
+struct LkFeatScatterArgs {
+    int P, min_nn;
+    const int32_t* nbr_idx; const float* nbr_w; const int32_t* nbr_count;
+    const float* dc_geo; const float* dc_col; const float* dfeat;
+    float* g_geo_feats; float* g_col_feats;
+};
+
 struct LkRaysBwdArgs { int R, S; const float* z; const float* dp_total; float* g_rays_o; float* g_rays_d; };
 
 // rel-pos neighbour MLP backward
@@ -109,6 +116,7 @@ struct LkRelposBwdArgs {
     float* rows;                                   // [8P][192]: dhid(128) | x(64)  (GRAD_WEIGHTS)
     float* hbar;                                   // [P][128] sum_j w_j hid_j
     float* w_sum;                                  // [P] sum_j w_j
+    float* dfeat;                                  // [8P][32] d loss / d feature row per neighbour (GRAD_FEATS)
     float* w_eff;                                  // [8P] weight actually applied to each neighbour row
     float* part_br;                                // [n_blocks][32] per-workgroup partial sums of d embedder_rel_pos._B
 };
@@ -131,6 +139,7 @@ int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st);
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st);
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st);
 int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st);
+int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st);
 int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st);
 int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st);
 int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st);
