@@ -15,22 +15,22 @@ __device__ __forceinline__ int lk_cell_coord(float x, float o, float inv, int d)
     return (int)f;
 }
 
-// keep the 8 smallest (d2, idx) pairs, ascending; fully unrolled so both arrays stay in VGPRs
-__device__ __forceinline__ void lk_top8_insert(float (&d)[LK_K], int (&id)[LK_K], float nd, int ni) {
-    if (nd < d[LK_K - 1] || (nd == d[LK_K - 1] && ni < id[LK_K - 1])) {
-        d[LK_K - 1] = nd;
-        id[LK_K - 1] = ni;
+// A candidate is ONE 64-bit key: (bits of d2) << 32 | index.  d2 >= +0, so the unsigned order of the float bits is the
+// float order and the key order is the strict total order (d2, index) in a single v_cmp_lt_u64.
+// The empty slot is (FLT_MAX, -1) = the largest key any list ever holds.
+#define LK_KEY_EMPTY 0x7f7fffffffffffffull
+__device__ __forceinline__ uint64_t lk_key(float d2, int idx) {
+    return ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)idx;
+}
+
+// insert into the ascending 8-list, dropping the largest: k[s] <- max(k[s-1], min(key, k[s])); branch-free
+__device__ __forceinline__ void lk_top8_insert(uint64_t (&k)[LK_K], uint64_t key) {
 #pragma unroll
-        for (int s = LK_K - 1; s > 0; --s) {
-            const bool sw = (d[s] < d[s - 1]) || (d[s] == d[s - 1] && id[s] < id[s - 1]);
-            const float td = sw ? d[s - 1] : d[s];
-            const int ti = sw ? id[s - 1] : id[s];
-            d[s - 1] = sw ? d[s] : d[s - 1];
-            id[s - 1] = sw ? id[s] : id[s - 1];
-            d[s] = td;
-            id[s] = ti;
-        }
+    for (int s = LK_K - 1; s > 0; --s) {
+        const uint64_t lo = key < k[s] ? key : k[s];
+        k[s] = key < k[s - 1] ? k[s - 1] : lo;
     }
+    k[0] = key < k[0] ? key : k[0];
 }
 
 // All T lanes of a group must call this convergently with the same query (qx,qy,qz,r2).
@@ -41,8 +41,9 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
                                                  const int32_t* __restrict__ cell_start,
                                                  float qx, float qy, float qz, float r2, int sub,
                                                  float (&d)[LK_K], int (&id)[LK_K]) {
+    uint64_t k[LK_K];
 #pragma unroll
-    for (int j = 0; j < LK_K; ++j) { d[j] = LK_FLT_MAX; id[j] = -1; }
+    for (int j = 0; j < LK_K; ++j) k[j] = LK_KEY_EMPTY;
     const float ox = G->ox, oy = G->oy, oz = G->oz, inv = G->inv_cell;
     const int dx = G->dx, dy = G->dy, dz = G->dz;
     const float r = sqrtf(r2) * 1.0001f + 1e-6f;       // box slightly inflated: never misses a cell
@@ -51,32 +52,97 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
     any = any && !((qx + r - ox) * inv < 0.0f || (qx - r - ox) * inv >= (float)dx);
     any = any && !((qy + r - oy) * inv < 0.0f || (qy - r - oy) * inv >= (float)dy);
     any = any && !((qz + r - oz) * inv < 0.0f || (qz - r - oz) * inv >= (float)dz);
+    // Row table: the query box covers ny x nz rows of cells.  The usual case (cell size >= radius) is at most 3 x 3
+    // rows: lane `sub` fetches the [start,end) of rows sub, sub+T (independent loads, one latency), the group
+    // exchanges them by shuffle, and the first T candidates of EVERY row are fetched before any of them is examined
+    // (nine independent 16-B loads in flight instead of nine dependent cell_start -> point round trips).
+    int ix0 = 0, ix1 = 0, iy0 = 0, iy1 = -1, iz0 = 0, iz1 = -1;
     if (any) {
-        const int ix0 = lk_cell_coord(qx - r, ox, inv, dx), ix1 = lk_cell_coord(qx + r, ox, inv, dx);
-        const int iy0 = lk_cell_coord(qy - r, oy, inv, dy), iy1 = lk_cell_coord(qy + r, oy, inv, dy);
-        const int iz0 = lk_cell_coord(qz - r, oz, inv, dz), iz1 = lk_cell_coord(qz + r, oz, inv, dz);
+        ix0 = lk_cell_coord(qx - r, ox, inv, dx); ix1 = lk_cell_coord(qx + r, ox, inv, dx);
+        iy0 = lk_cell_coord(qy - r, oy, inv, dy); iy1 = lk_cell_coord(qy + r, oy, inv, dy);
+        iz0 = lk_cell_coord(qz - r, oz, inv, dz); iz1 = lk_cell_coord(qz + r, oz, inv, dz);
+    }
+    const int ny = iy1 - iy0 + 1, nz = iz1 - iz0 + 1;
+    const int nrows = any ? ny * nz : 0;
+    constexpr int LK_ROWS = 9, NH = (LK_ROWS + T - 1) / T;
+    const int nfast = nrows <= LK_ROWS ? nrows : 0;
+    int my_s[NH], my_e[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int rr = sub + h * T;
+        my_s[h] = 0; my_e[h] = 0;
+        if (rr < nfast) {
+            const int zz = rr / ny, yy = rr - zz * ny;
+            const int row = ((iz0 + zz) * dy + iy0 + yy) * dx;
+            my_s[h] = cell_start[row + ix0];
+            my_e[h] = cell_start[row + ix1 + 1];
+        }
+    }
+    int rs[LK_ROWS], re[LK_ROWS];
+    float4 c[LK_ROWS];
+#pragma unroll
+    for (int i = 0; i < LK_ROWS; ++i) {
+        rs[i] = __shfl(my_s[i / T], i & (T - 1), T) + sub;
+        re[i] = __shfl(my_e[i / T], i & (T - 1), T);
+        if (rs[i] < re[i]) c[i] = sorted[rs[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < LK_ROWS; ++i) {
+        if (rs[i] < re[i]) {
+            const float d2 = lk_dist2(qx, qy, qz, c[i].x, c[i].y, c[i].z);
+            if (d2 <= r2) lk_top8_insert(k, lk_key(d2, __float_as_int(c[i].w)));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LK_ROWS; ++i) {
+#pragma unroll 1
+        for (int t = rs[i] + T; t < re[i]; t += T) {
+            const float4 p = sorted[t];
+            const float d2 = lk_dist2(qx, qy, qz, p.x, p.y, p.z);
+            if (d2 <= r2) lk_top8_insert(k, lk_key(d2, __float_as_int(p.w)));
+        }
+    }
+    if (nrows > LK_ROWS) {          // cells smaller than the radius: plain row walk
+#pragma unroll 1
         for (int iz = iz0; iz <= iz1; ++iz) {
+#pragma unroll 1
             for (int iy = iy0; iy <= iy1; ++iy) {
                 const int row = (iz * dy + iy) * dx;
                 const int s = cell_start[row + ix0];
                 const int e = cell_start[row + ix1 + 1];
+#pragma unroll 1
                 for (int t = s + sub; t < e; t += T) {
                     const float4 p = sorted[t];
                     const float d2 = lk_dist2(qx, qy, qz, p.x, p.y, p.z);
-                    if (d2 <= r2) lk_top8_insert(d, id, d2, __float_as_int(p.w));
+                    if (d2 <= r2) lk_top8_insert(k, lk_key(d2, __float_as_int(p.w)));
                 }
             }
         }
     }
-    // butterfly merge: after round m every lane holds the top-8 of its 2m-lane subgroup
+    // butterfly merge: after round m every lane holds the top-8 of its 2m-lane subgroup.  Two ascending 8-lists
+    // A (mine) and B (partner's): L[i] = min(A[i], B[7-i]) is the 8 smallest of the union as a bitonic sequence,
+    // which three compare-exchange stages sort.  Straight-line code (the order is total, so both partners end
+    // with the identical list).
 #pragma unroll
     for (int m = 1; m < T; m <<= 1) {
-        float od[LK_K];
-        int oi[LK_K];
 #pragma unroll
-        for (int j = 0; j < LK_K; ++j) { od[j] = __shfl_xor(d[j], m); oi[j] = __shfl_xor(id[j], m); }
+        for (int j = 0; j < LK_K / 2; ++j) {           // partner's list reversed against mine, in place
+            const uint64_t hi = __shfl_xor(k[LK_K - 1 - j], m), lo = __shfl_xor(k[j], m);
+            k[j] = hi < k[j] ? hi : k[j];
+            k[LK_K - 1 - j] = lo < k[LK_K - 1 - j] ? lo : k[LK_K - 1 - j];
+        }
 #pragma unroll
-        for (int j = 0; j < LK_K; ++j)
-            if (oi[j] >= 0) lk_top8_insert(d, id, od[j], oi[j]);
+        for (int st = LK_K / 2; st > 0; st >>= 1) {
+#pragma unroll
+            for (int j = 0; j < LK_K; ++j) {
+                if ((j & st) == 0) {
+                    const uint64_t x = k[j], y = k[j + st];
+                    k[j] = y < x ? y : x;
+                    k[j + st] = y < x ? x : y;
+                }
+            }
+        }
     }
+#pragma unroll
+    for (int j = 0; j < LK_K; ++j) { d[j] = __uint_as_float((uint32_t)(k[j] >> 32)); id[j] = (int)(uint32_t)k[j]; }
 }

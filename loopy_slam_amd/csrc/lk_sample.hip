@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void k_depth_stats(const float* __restrict__ g
 // Eight lanes per sample point (32 points per 256-thread block): z and p (every lane, redundantly),
 // cooperative exact top-8 within the radius, normalised weights, then lane `sub` gathers its float4
 // of each of the 8 neighbour rows (8 lanes x 16 B = one 128-B feature row per load instruction).
+// T = lanes per sample point (8: large batches; 16: training batches, halves each lane's serial candidate chain)
+template <int T>
 __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
-    const int sub = (int)threadIdx.x & 7;
-    const int p_raw = blockIdx.x * 32 + ((int)threadIdx.x >> 3);
+    const int sub = (int)threadIdx.x & (T - 1);
+    const int p_raw = blockIdx.x * (256 / T) + (int)threadIdx.x / T;
     const bool live = p_raw < a.P;
     const int pidx = live ? p_raw : a.P - 1;           // dead groups shadow the last point, never store
     const int r = pidx / a.S, s = pidx - r * a.S;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     const float r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
     float d[LK_K], w[LK_K];
     int id[LK_K];
-    lk_knn_scan_coop<8>(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, sub, d, id);
+    lk_knn_scan_coop<T>(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, sub, d, id);
     // w = 1/(D+1e-10), zero outside the radius, L1-normalised (decoder.py:210-220)
     float wsum = 0.0f;
     int count = 0;
@@ -83,31 +85,40 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
         int ij = id[0];
 #pragma unroll
         for (int j = 1; j < LK_K; ++j) { wj = (sub == j) ? w[j] : wj; ij = (sub == j) ? id[j] : ij; }
-        a.nbr_idx[(size_t)pidx * LK_K + sub] = ij;
-        a.nbr_w[(size_t)pidx * LK_K + sub] = wj;
+        if (sub < LK_K) {
+            a.nbr_idx[(size_t)pidx * LK_K + sub] = ij;
+            a.nbr_w[(size_t)pidx * LK_K + sub] = wj;
+        }
         if (sub == 0) { a.nbr_count[pidx] = count; a.z[pidx] = z; }
     }
     const bool do_col = (a.flags & LK_FLAG_STAGE_COLOR) && !(a.flags & LK_FLAG_REL_POS);
+    // gather: with 8 lanes per point every lane serves one float4 of BOTH tables; with 16 lanes the low 8 lanes
+    // serve the geometry row, the high 8 the colour row
+    const int f4 = sub & 7;
+    const bool lane_geo = (T == 8) || sub < 8;
+    const bool lane_col = do_col && ((T == 8) || sub >= 8);
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ac = make_float4(0.f, 0.f, 0.f, 0.f);
     if (count >= a.min_nn) {
 #pragma unroll
         for (int j = 0; j < LK_K; ++j) {
             if (w[j] != 0.0f) {
                 const float wj = w[j];
-                const float4 g = *reinterpret_cast<const float4*>(a.geo_feats + (size_t)id[j] * LK_C + sub * 4);
-                ag.x = fmaf(wj, g.x, ag.x); ag.y = fmaf(wj, g.y, ag.y); ag.z = fmaf(wj, g.z, ag.z); ag.w = fmaf(wj, g.w, ag.w);
-                if (do_col) {
-                    const float4 c = *reinterpret_cast<const float4*>(a.col_feats + (size_t)id[j] * LK_C + sub * 4);
+                if (lane_geo) {
+                    const float4 g = *reinterpret_cast<const float4*>(a.geo_feats + (size_t)id[j] * LK_C + f4 * 4);
+                    ag.x = fmaf(wj, g.x, ag.x); ag.y = fmaf(wj, g.y, ag.y); ag.z = fmaf(wj, g.z, ag.z); ag.w = fmaf(wj, g.w, ag.w);
+                }
+                if (lane_col) {
+                    const float4 c = *reinterpret_cast<const float4*>(a.col_feats + (size_t)id[j] * LK_C + f4 * 4);
                     ac.x = fmaf(wj, c.x, ac.x); ac.y = fmaf(wj, c.y, ac.y); ac.z = fmaf(wj, c.z, ac.z); ac.w = fmaf(wj, c.w, ac.w);
                 }
             }
         }
     } else {            // no usable neighbourhood: the shared noise vector (decoder.py:228-229)
-        if (a.noise_geo) ag = *reinterpret_cast<const float4*>(a.noise_geo + sub * 4);
-        if (a.noise_col) ac = *reinterpret_cast<const float4*>(a.noise_col + sub * 4);
+        if (a.noise_geo) ag = *reinterpret_cast<const float4*>(a.noise_geo + f4 * 4);
+        if (a.noise_col) ac = *reinterpret_cast<const float4*>(a.noise_col + f4 * 4);
     }
-    *reinterpret_cast<float4*>(a.c_geo + (size_t)pidx * LK_C + sub * 4) = ag;
-    if (do_col) *reinterpret_cast<float4*>(a.c_col + (size_t)pidx * LK_C + sub * 4) = ac;
+    if (lane_geo) *reinterpret_cast<float4*>(a.c_geo + (size_t)pidx * LK_C + f4 * 4) = ag;
+    if (lane_col) *reinterpret_cast<float4*>(a.c_col + (size_t)pidx * LK_C + f4 * 4) = ac;
 }
 
 // One thread per ray: occupancy of unsupported samples := -100, alpha composite, validity.
@@ -152,7 +163,8 @@ int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hip
 }
 int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_SAMPLE_INTERP, st);
-    hipLaunchKernelGGL(k_sample_interp, dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
+    if (a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_sample_interp<8>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st) {

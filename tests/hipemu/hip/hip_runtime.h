@@ -94,12 +94,13 @@ static inline void __threadfence_block() {}
 // ---- wave intrinsics
 static inline int __lane_id() { return hipemu::lane_id(); }
 template <typename T> static inline T __shfl(T v, int src, int width = 64) {
-    static_assert(sizeof(T) == 4, "emu shuffles are 32-bit");
-    uint32_t u; std::memcpy(&u, &v, 4);
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "emu shuffles are 32- or 64-bit (two 32-bit exchanges)");
+    uint32_t u[2] = {0, 0}; std::memcpy(u, &v, sizeof(T));
     int lane = hipemu::lane_id();
     int s = (lane & ~(width - 1)) | (src & (width - 1));
-    u = hipemu::wave_exchange_u32(u, s);
-    T r; std::memcpy(&r, &u, 4); return r;
+    u[0] = hipemu::wave_exchange_u32(u[0], s);
+    if (sizeof(T) == 8) u[1] = hipemu::wave_exchange_u32(u[1], s);
+    T r; std::memcpy(&r, u, sizeof(T)); return r;
 }
 template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
     return __shfl(v, (hipemu::lane_id() ^ mask) & (width - 1), width);
