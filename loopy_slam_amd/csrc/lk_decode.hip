@@ -91,152 +91,200 @@ __device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB], const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
-    const int lane = lk_lane();
-    const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    const int sample0 = wave * 32;
-    if (sample0 >= a.P) return;                                  // whole wave leaves together
-    const int sample = sample0 + (lane & 31);
-    const bool live = sample < a.P;
-    const int h = lane >> 5;
-    const int sp = live ? sample : a.P - 1;                      // clamp: dead lanes compute, never store
-    const int r = sp / a.S;
-    const float z = a.z[sp];
+// Sample coordinates shared by both decoder roles: lane -> sample of the tile, p = o + d z, a = fl(2 pi p)
+struct DecSample {
+    int sample, sp, h;
+    bool live;
+    float a0, a1, a2;
+};
+__device__ __forceinline__ DecSample dec_sample(const LkDecodeArgs& a, int tile, int lane) {
+    DecSample d;
+    d.sample = tile * 32 + (lane & 31);
+    d.live = d.sample < a.P;
+    d.h = lane >> 5;
+    d.sp = d.live ? d.sample : a.P - 1;                          // clamp: dead lanes compute, never store
+    const int r = d.sp / a.S;
+    const float z = a.z[d.sp];
     const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
     const float py = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
     const float pz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
-    const float a0 = __fmul_rn(LK_TWO_PI, px), a1 = __fmul_rn(LK_TWO_PI, py), a2 = __fmul_rn(LK_TWO_PI, pz);
+    d.a0 = __fmul_rn(LK_TWO_PI, px); d.a1 = __fmul_rn(LK_TWO_PI, py); d.a2 = __fmul_rn(LK_TWO_PI, pz);
+    return d;
+}
+
+// ================= geometry decoder (hidden 32, relu): one wave = one 32-sample tile, registers only =================
+__device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile, int lane) {
+    const DecSample d = dec_sample(a, tile, lane);
+    const int h = d.h, sp = d.sp;
+    const bool live = d.live;
+    const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
     const float* __restrict__ F = a.Wfrag;
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_geo = save ? a.act + (size_t)sp * LK_ACT_GEO_A : nullptr;
+    const f32x16 e0 = geo_embed_tile(W + G_EB, 0, a0, a1, a2, lane);
+    const f32x16 e1 = geo_embed_tile(W + G_EB, 1, a0, a1, a2, lane);
+    const f32x16 e2 = geo_embed_tile(W + G_EB, 2, a0, a1, a2, lane);
+    const f32x16 cg = ct_load_rows32(a.c_geo + (size_t)sp * LK_C, true, lane);
+    f32x16 acc[1], hh;
+    // layer 0: 93 -> 32
+    acc[0] = lk_zero16();
+    lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 0, 0, e0, lane);
+    lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 4, 0, e1, lane);
+    lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 8, 0, e2, lane);
+    layer_finish<1, false>(acc, W + G_B0, F + FM5_FWD, W + G_U0 + a64(HG * CF), cg, act_geo, live, lane);
+    hh = acc[0];
+    // layers 1, 2: 32 -> 32
+    acc[0] = lk_zero16();
+    lk_gemm_frag<1, 4>(acc, F + FM1_FWD, 1, 0, 0, hh, lane);
+    layer_finish<1, false>(acc, W + G_B1, F + FM6_FWD, W + G_U0 + G_USTRIDE + a64(HG * CF), cg,
+                           act_geo ? act_geo + 32 : nullptr, live, lane);
+    hh = acc[0];
+    acc[0] = lk_zero16();
+    lk_gemm_frag<1, 4>(acc, F + FM2_FWD, 1, 0, 0, hh, lane);
+    layer_finish<1, false>(acc, W + G_B2, F + FM7_FWD, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cg,
+                           act_geo ? act_geo + 64 : nullptr, live, lane);
+    hh = acc[0];
+    // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
+    acc[0] = lk_zero16();
+    lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 0, 0, e0, lane);
+    lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 4, 0, e1, lane);
+    lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 8, 0, e2, lane);
+    lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 12, 0, hh, lane);
+    layer_finish<1, false>(acc, W + G_B3, F + FM8_FWD, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cg,
+                           act_geo ? act_geo + 96 : nullptr, live, lane);
+    hh = acc[0];
+    // layer 4
+    acc[0] = lk_zero16();
+    lk_gemm_frag<1, 4>(acc, F + FM4_FWD, 1, 0, 0, hh, lane);
+    layer_finish<1, false>(acc, W + G_B4, F + FM9_FWD, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cg,
+                           act_geo ? act_geo + 128 : nullptr, live, lane);
+    // output 32 -> 1 on the VALU: each half-wave holds 16 of the 32 units of its sample
+    float part = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 wo = *reinterpret_cast<const float4*>(W + G_WO + 8 * g + 4 * h);
+        part = fmaf(wo.x, acc[0][4 * g], part); part = fmaf(wo.y, acc[0][4 * g + 1], part);
+        part = fmaf(wo.z, acc[0][4 * g + 2], part); part = fmaf(wo.w, acc[0][4 * g + 3], part);
+    }
+    part += __shfl_xor(part, 32);
+    if (live && h == 0) a.raw[(size_t)d.sample * 4 + 3] = part + W[G_BO];
+}
+
+// ================= colour decoder (hidden 128, softplus beta=100): FOUR waves = one 32-sample tile =================
+// Wave w owns output units [32w, 32w+32) of every layer (one accumulator, 64 MFMAs per 128-wide layer), so a tile's
+// serial MFMA chain is a quarter of the one-wave form and a training batch (a few hundred tiles) spreads over four
+// times as many SIMDs.  The next layer needs all 128 units as its B operand: each wave parks its activated CT tile in
+// LDS as the four float4 register chunks of every lane, [wave][chunk][lane] — the reader of chunk (w', j) is the
+// SAME lane id in every wave (the C/D-row walk of lk_gemm_frag), so writes and reads are both lane-contiguous
+// (conflict-free ds_write/read_b128).  Double-buffered: one barrier per layer.
+template <int NG>
+__device__ __forceinline__ void gemm_frag_lds(f32x16& acc, const float* __restrict__ frag, int NBT, int g0, int nb,
+                                              const float4* __restrict__ xs /* [NG][64] chunks */, int lane) {
+    const float* __restrict__ base = frag + ((size_t)g0 * NBT + nb) * 256 + lane * 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const float4 w = *reinterpret_cast<const float4*>(base + (size_t)g * NBT * 256);
+        const float4 x = xs[g * 64 + lane];
+        acc = lk_mfma(w.x, x.x, acc);
+        acc = lk_mfma(w.y, x.y, acc);
+        acc = lk_mfma(w.z, x.z, acc);
+        acc = lk_mfma(w.w, x.w, acc);
+    }
+}
+
+// bias + softplus (+ save) + fc_c(c) for the wave's own 32-unit block `w`
+__device__ __forceinline__ void col_layer_finish(f32x16& acc, int w, const float* __restrict__ bias,
+                                                 const float* __restrict__ Ufrag, const float* __restrict__ ubias,
+                                                 const f32x16& c, float* __restrict__ save_a, bool live, int lane) {
+    lk_add_rowvec(acc, bias, w * 32, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);
+    if (save_a) ct_store_rows32(save_a + w * 32, acc, live, lane);
+    lk_add_rowvec(acc, ubias, w * 32, lane);
+    f32x16 t[1] = {acc};
+    lk_gemm_frag<1, 4>(t, Ufrag, 4, 0, w, c, lane);
+    acc = t[0];
+}
+
+__device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
+                                              float4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */) {
+    const DecSample d = dec_sample(a, tile, lane);
+    const int h = d.h, sp = d.sp;
+    const bool live = d.live;
+    const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
+    const float* __restrict__ W = a.W;
+    const float* __restrict__ F = a.Wfrag;
+    const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A : nullptr;
     float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H : nullptr;
-
-    // ================= geometry decoder (hidden 32, relu) =================
-    float occ;
-    {
-        const f32x16 e0 = geo_embed_tile(W + G_EB, 0, a0, a1, a2, lane);
-        const f32x16 e1 = geo_embed_tile(W + G_EB, 1, a0, a1, a2, lane);
-        const f32x16 e2 = geo_embed_tile(W + G_EB, 2, a0, a1, a2, lane);
-        const f32x16 cg = ct_load_rows32(a.c_geo + (size_t)sp * LK_C, true, lane);
-        f32x16 acc[1], hh;
-        // layer 0: 93 -> 32
-        acc[0] = lk_zero16();
-        lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 0, 0, e0, lane);
-        lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 4, 0, e1, lane);
-        lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 8, 0, e2, lane);
-        layer_finish<1, false>(acc, W + G_B0, F + FM5_FWD, W + G_U0 + a64(HG * CF), cg, act_geo, live, lane);
-        hh = acc[0];
-        // layers 1, 2: 32 -> 32
-        acc[0] = lk_zero16();
-        lk_gemm_frag<1, 4>(acc, F + FM1_FWD, 1, 0, 0, hh, lane);
-        layer_finish<1, false>(acc, W + G_B1, F + FM6_FWD, W + G_U0 + G_USTRIDE + a64(HG * CF), cg,
-                               act_geo ? act_geo + 32 : nullptr, live, lane);
-        hh = acc[0];
-        acc[0] = lk_zero16();
-        lk_gemm_frag<1, 4>(acc, F + FM2_FWD, 1, 0, 0, hh, lane);
-        layer_finish<1, false>(acc, W + G_B2, F + FM7_FWD, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cg,
-                               act_geo ? act_geo + 64 : nullptr, live, lane);
-        hh = acc[0];
-        // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
-        acc[0] = lk_zero16();
-        lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 0, 0, e0, lane);
-        lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 4, 0, e1, lane);
-        lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 8, 0, e2, lane);
-        lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 12, 0, hh, lane);
-        layer_finish<1, false>(acc, W + G_B3, F + FM8_FWD, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cg,
-                               act_geo ? act_geo + 96 : nullptr, live, lane);
-        hh = acc[0];
-        // layer 4
-        acc[0] = lk_zero16();
-        lk_gemm_frag<1, 4>(acc, F + FM4_FWD, 1, 0, 0, hh, lane);
-        layer_finish<1, false>(acc, W + G_B4, F + FM9_FWD, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cg,
-                               act_geo ? act_geo + 128 : nullptr, live, lane);
-        // output 32 -> 1 on the VALU: each half-wave holds 16 of the 32 units of its sample
-        float part = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 wo = *reinterpret_cast<const float4*>(W + G_WO + 8 * g + 4 * h);
-            part = fmaf(wo.x, acc[0][4 * g], part); part = fmaf(wo.y, acc[0][4 * g + 1], part);
-            part = fmaf(wo.z, acc[0][4 * g + 2], part); part = fmaf(wo.w, acc[0][4 * g + 3], part);
-        }
-        part += __shfl_xor(part, 32);
-        occ = part + W[G_BO];
+    const f32x16 e0 = sincos_embed_tile<4>(W + C_EB, 20, 0, a0, a1, a2, lane);
+    const f32x16 e1 = sincos_embed_tile<1>(W + C_EB, 20, 1, a0, a1, a2, lane);
+    const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
+    if (save && live && w == 0) {    // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
+        float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
+        ct_store_rows32(erow, e0, true, lane);
+        *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1[0], e1[1], e1[2], e1[3]);
     }
-
-    // ================= colour decoder (hidden 128, softplus beta=100) =================
+    auto park = [&](const f32x16& t, int buf, int L) {     // own block -> LDS chunks (and the saved h rows)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            s_x[buf][(w * 4 + j) * 64 + lane] = make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
+        if (save) ct_store_rows32(act_col_h + L * 128 + w * 32, t, live, lane);
+    };
+    f32x16 acc[1];
+    // layer 0: 40 -> 128
+    acc[0] = lk_zero16();
+    lk_gemm_frag<1, 4>(acc, F + FM10_FWD, 4, 0, w, e0, lane);
+    lk_gemm_frag<1, 1>(acc, F + FM10_FWD, 4, 4, w, e1, lane);
+    col_layer_finish(acc[0], w, W + C_B0, F + FM15_FWD, W + C_U0 + a64(HC * CF), cc, act_col_a, live, lane);
+    park(acc[0], 0, 0);
+    __syncthreads();
+    // layers 1, 2: 128 -> 128
+#pragma unroll
+    for (int L = 1; L <= 2; ++L) {
+        acc[0] = lk_zero16();
+        gemm_frag_lds<16>(acc[0], F + (L == 1 ? FM11_FWD : FM12_FWD), 4, 0, w, s_x[(L - 1) & 1], lane);
+        col_layer_finish(acc[0], w, W + (L == 1 ? C_B1 : C_B2), F + (L == 1 ? FM16_FWD : FM17_FWD),
+                         W + C_U0 + L * C_USTRIDE + a64(HC * CF), cc, act_col_a ? act_col_a + L * 128 : nullptr, live, lane);
+        park(acc[0], L & 1, L);
+        __syncthreads();
+    }
+    // layer 3 (skip): [e(40) | h(128)] -> 128
+    acc[0] = lk_zero16();
+    lk_gemm_frag<1, 4>(acc, F + FM13_FWD, 4, 0, w, e0, lane);
+    lk_gemm_frag<1, 1>(acc, F + FM13_FWD, 4, 4, w, e1, lane);
+    gemm_frag_lds<16>(acc[0], F + FM13_FWD, 4, 5, w, s_x[0], lane);
+    col_layer_finish(acc[0], w, W + C_B3, F + FM18_FWD, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), cc,
+                     act_col_a ? act_col_a + 3 * 128 : nullptr, live, lane);
+    park(acc[0], 1, 3);
+    __syncthreads();
+    // layer 4
+    acc[0] = lk_zero16();
+    gemm_frag_lds<16>(acc[0], F + FM14_FWD, 4, 0, w, s_x[1], lane);
+    col_layer_finish(acc[0], w, W + C_B4, F + FM19_FWD, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), cc,
+                     act_col_a ? act_col_a + 4 * 128 : nullptr, live, lane);
+    if (save) ct_store_rows32(act_col_h + 4 * 128 + w * 32, acc[0], live, lane);
+    // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
-    if (a.flags & LK_FLAG_STAGE_COLOR) {
-        const f32x16 e0 = sincos_embed_tile<4>(W + C_EB, 20, 0, a0, a1, a2, lane);
-        const f32x16 e1 = sincos_embed_tile<1>(W + C_EB, 20, 1, a0, a1, a2, lane);
-        const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
-        if (save && live) {          // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
-            float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
-            ct_store_rows32(erow, e0, true, lane);
-            *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1[0], e1[1], e1[2], e1[3]);
-        }
-        f32x16 acc[4], hh[4];
-        // layer 0: 40 -> 128
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
-        lk_gemm_frag<4, 4>(acc, F + FM10_FWD, 4, 0, 0, e0, lane);
-        lk_gemm_frag<4, 1>(acc, F + FM10_FWD, 4, 4, 0, e1, lane);
-        layer_finish<4, true>(acc, W + C_B0, F + FM15_FWD, W + C_U0 + a64(HC * CF), cc, act_col_a, live, lane);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + nb * 32, hh[nb], live, lane); }
-        // layers 1, 2: 128 -> 128
-#pragma unroll
-        for (int L = 1; L <= 2; ++L) {
-            const float* Wl = F + (L == 1 ? FM11_FWD : FM12_FWD);
-            const float* Bl = W + (L == 1 ? C_B1 : C_B2);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<4, 4>(acc, Wl, 4, 4 * kb, 0, hh[kb], lane);
-            layer_finish<4, true>(acc, Bl, F + (L == 1 ? FM16_FWD : FM17_FWD), W + C_U0 + L * C_USTRIDE + a64(HC * CF), cc,
-                                  act_col_a ? act_col_a + L * 128 : nullptr, live, lane);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + L * 128 + nb * 32, hh[nb], live, lane); }
-        }
-        // layer 3 (skip): [e(40) | h(128)] -> 128
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
-        lk_gemm_frag<4, 4>(acc, F + FM13_FWD, 4, 0, 0, e0, lane);
-        lk_gemm_frag<4, 1>(acc, F + FM13_FWD, 4, 4, 0, e1, lane);
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<4, 4>(acc, F + FM13_FWD, 4, 5 + 4 * kb, 0, hh[kb], lane);
-        layer_finish<4, true>(acc, W + C_B3, F + FM18_FWD, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), cc,
-                              act_col_a ? act_col_a + 3 * 128 : nullptr, live, lane);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) { hh[nb] = acc[nb]; if (save) ct_store_rows32(act_col_h + 3 * 128 + nb * 32, hh[nb], live, lane); }
-        // layer 4
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[nb] = lk_zero16();
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<4, 4>(acc, F + FM14_FWD, 4, 4 * kb, 0, hh[kb], lane);
-        layer_finish<4, true>(acc, W + C_B4, F + FM19_FWD, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), cc,
-                              act_col_a ? act_col_a + 4 * 128 : nullptr, live, lane);
-        if (save) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) ct_store_rows32(act_col_h + 4 * 128 + nb * 32, acc[nb], live, lane);
-        }
-        // output 128 -> 3 on the VALU
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int u = 32 * nb + 8 * g + 4 * h;
-                const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + u);
-                const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
-                const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
-                const float v0 = acc[nb][4 * g], v1 = acc[nb][4 * g + 1], v2 = acc[nb][4 * g + 2], v3 = acc[nb][4 * g + 3];
-                o0 = fmaf(w0.x, v0, o0); o0 = fmaf(w0.y, v1, o0); o0 = fmaf(w0.z, v2, o0); o0 = fmaf(w0.w, v3, o0);
-                o1 = fmaf(w1.x, v0, o1); o1 = fmaf(w1.y, v1, o1); o1 = fmaf(w1.z, v2, o1); o1 = fmaf(w1.w, v3, o1);
-                o2 = fmaf(w2.x, v0, o2); o2 = fmaf(w2.y, v1, o2); o2 = fmaf(w2.z, v2, o2); o2 = fmaf(w2.w, v3, o2);
-            }
-        }
-        o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
+    for (int g = 0; g < 4; ++g) {
+        const int u = 32 * w + 8 * g + 4 * h;
+        const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + u);
+        const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
+        const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
+        const float v0 = acc[0][4 * g], v1 = acc[0][4 * g + 1], v2 = acc[0][4 * g + 2], v3 = acc[0][4 * g + 3];
+        o0 = fmaf(w0.x, v0, o0); o0 = fmaf(w0.y, v1, o0); o0 = fmaf(w0.z, v2, o0); o0 = fmaf(w0.w, v3, o0);
+        o1 = fmaf(w1.x, v0, o1); o1 = fmaf(w1.y, v1, o1); o1 = fmaf(w1.z, v2, o1); o1 = fmaf(w1.w, v3, o1);
+        o2 = fmaf(w2.x, v0, o2); o2 = fmaf(w2.y, v1, o2); o2 = fmaf(w2.z, v2, o2); o2 = fmaf(w2.w, v3, o2);
+    }
+    o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
+    if (h == 0) { s_o[w][lane] = o0; s_o[w][32 + lane] = o1; s_o[w][64 + lane] = o2; }
+    __syncthreads();
+    if (w == 0 && h == 0) {
+        o0 = ((s_o[0][lane] + s_o[1][lane]) + s_o[2][lane]) + s_o[3][lane];
+        o1 = ((s_o[0][32 + lane] + s_o[1][32 + lane]) + s_o[2][32 + lane]) + s_o[3][32 + lane];
+        o2 = ((s_o[0][64 + lane] + s_o[1][64 + lane]) + s_o[2][64 + lane]) + s_o[3][64 + lane];
         o0 += W[C_BO]; o1 += W[C_BO + 1]; o2 += W[C_BO + 2];
         if (a.affine) {                      // out @ A + t, A = affine[:9].reshape(3,3) (decoder.py:536-539)
             const float* A = a.affine;
@@ -246,8 +294,32 @@ __global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a) {
             o0 = t0; o1 = t1; o2 = t2;
         }
         if (!(a.flags & LK_FLAG_COLOR_LOGITS)) { o0 = lk_sigmoid(o0); o1 = lk_sigmoid(o1); o2 = lk_sigmoid(o2); }
+        if (live) {
+            float* out = a.raw + (size_t)d.sample * 4;
+            out[0] = o0; out[1] = o1; out[2] = o2;
+        }
     }
-    if (live && h == 0) *reinterpret_cast<float4*>(a.raw + (size_t)sample * 4) = make_float4(o0, o1, o2, occ);
+}
+
+// Block roles: the first `n_col_blocks` workgroups are colour tiles (4 waves per tile), the rest run the geometry
+// decoder (4 independent tiles per workgroup).  raw[:, 0:3] and raw[:, 3] are written by the two roles separately;
+// in the geometry stage there are no colour blocks and raw[:, 0:3] is zero-filled by the geometry wave.
+__global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a, int n_col_blocks) {
+    __shared__ float4 s_x[2][16 * 64];
+    __shared__ float s_o[4][3 * 32];
+    const int lane = lk_lane();
+    const int w = (int)threadIdx.x >> 6;
+    if ((int)blockIdx.x < n_col_blocks) {
+        decode_col_wg(a, blockIdx.x, w, lane, s_x, s_o);
+        return;
+    }
+    const int tile = ((int)blockIdx.x - n_col_blocks) * 4 + w;
+    if (tile * 32 >= a.P) return;
+    decode_geo_wave(a, tile, lane);
+    if (n_col_blocks == 0) {
+        const int sample = tile * 32 + (lane & 31);
+        if (sample < a.P && lane < 32) { float* out = a.raw + (size_t)sample * 4; out[0] = 0.0f; out[1] = 0.0f; out[2] = 0.0f; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,8 +412,9 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
 
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
-    const int waves = lk_cdiv(a.P, 32);
-    hipLaunchKernelGGL(k_decode_fwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    const int tiles = lk_cdiv(a.P, 32);
+    const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
+    hipLaunchKernelGGL(k_decode_fwd, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     return LK_OK;
 }
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {
