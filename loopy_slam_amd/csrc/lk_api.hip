@@ -165,7 +165,7 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
 
 // ------------------------------------------------------------------ render backward
 namespace {
-struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, total; };
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -173,6 +173,7 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.dc_geo = o; o += 32 * P;
     L.dc_col = o; o += 32 * P;
     L.dp_embed = o; o += 4 * P;
+    L.dp_embed_col = o; o += 4 * P;
     L.dp_rel = o; o += 4 * P;
     L.dp_total = o; o += 4 * P;
     L.dw_rel = o; o += 8 * P;
@@ -242,7 +243,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     db.W = d->weights; db.Wfrag = d->weights_frag; db.affine = d->affine;
     db.act = d->act; db.raw = d->raw; db.d_raw = S0 + L.d_raw;
     db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dh_col = S0 + L.dh_col; db.dlogit = S0 + L.dlogit;
-    db.dp_embed = S0 + L.dp_embed; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.part_bg = S0 + L.part_bg;
+    db.dp_embed = S0 + L.dp_embed; db.dp_embed_col = S0 + L.dp_embed_col; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.part_bg = S0 + L.part_bg;
     lk_launch_decode_bwd(db, st);
     if (gw) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
@@ -324,7 +325,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
         ib.nbr_idx = d->nbr_idx; ib.nbr_w = d->nbr_w; ib.nbr_count = d->nbr_count;
         ib.dc_geo = S0 + L.dc_geo; ib.dc_col = S0 + L.dc_col;
         ib.dw_rel = relpos ? S0 + L.dw_rel : nullptr;
-        ib.dp_embed = S0 + L.dp_embed; ib.dp_rel = relpos ? S0 + L.dp_rel : nullptr;
+        ib.dp_embed = S0 + L.dp_embed; ib.dp_embed_col = color ? S0 + L.dp_embed_col : nullptr; ib.dp_rel = relpos ? S0 + L.dp_rel : nullptr;
         ib.g_geo_feats = d->g_geo_feats; ib.g_col_feats = d->g_col_feats; ib.dp_total = S0 + L.dp_total;
         lk_launch_interp_bwd(ib, st);
     }

@@ -81,68 +81,89 @@ __device__ __forceinline__ void ct_store32(float* __restrict__ row, const f32x16
         *reinterpret_cast<float4*>(row + 8 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
 }
 
-// one wave = 32 sample points; part = this wave's [3][96] slice of the workgroup's d B_g partial sums (LDS)
-__device__ __forceinline__ void decode_bwd_wave(const LkDecodeBwdArgs& a, int sample0, float* __restrict__ part) {
-    const int lane = lk_lane();
-    const int sample = sample0 + (lane & 31);
-    const bool live = sample < a.P;
-    const int h = lane >> 5;
-    const int sp = live ? sample : a.P - 1;
-    const int r = sp / a.S;
-    const float z = a.z[sp];
+// Sample coordinates shared by both roles
+struct BwdSample {
+    int sample, sp, h;
+    bool live;
+    float a0, a1, a2;
+};
+__device__ __forceinline__ BwdSample bwd_sample(const LkDecodeBwdArgs& a, int tile, int lane) {
+    BwdSample d;
+    d.sample = tile * 32 + (lane & 31);
+    d.live = d.sample < a.P;
+    d.h = lane >> 5;
+    d.sp = d.live ? d.sample : a.P - 1;
+    const int r = d.sp / a.S;
+    const float z = a.z[d.sp];
     const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
     const float py = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
     const float pz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
-    const float a0 = __fmul_rn(LK_TWO_PI, px), a1 = __fmul_rn(LK_TWO_PI, py), a2 = __fmul_rn(LK_TWO_PI, pz);
+    d.a0 = __fmul_rn(LK_TWO_PI, px); d.a1 = __fmul_rn(LK_TWO_PI, py); d.a2 = __fmul_rn(LK_TWO_PI, pz);
+    return d;
+}
+
+// ================= colour decoder backward-data: FOUR waves = one 32-sample tile =================
+// Mirror of decode_col_wg: wave w owns units [32w, 32w+32) of every layer's gradient.  Per layer i = 4..0:
+//   d c  += U_i^T[:, own units] d h_i[own]                (partial over the wave's units; summed over waves at the end)
+//   d y_i = d h_i * softplus'(a_i)                        (own units)  -> parked in LDS (same lane-chunk scheme)
+//   d h_{i-1}[own] = W_i^T[own, :] d y_i                  (B operand = all four parked blocks)
+// The embedding gradient tiles (tracker mode) are spread evenly: layer 3's two tiles on waves 0,1, layer 0's on
+// waves 2,3; every wave turns its tile into a d p partial and wave 0 adds the four.
+__device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int tile, int w, int lane,
+                                                  float4* __restrict__ s_x /* [2][16*64] */, float (*s_o)[3 * 32]) {
+    const BwdSample d = bwd_sample(a, tile, lane);
+    const int h = d.h, sp = d.sp;
+    const bool live = d.live;
+    const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
     const float* __restrict__ F = a.Wfrag;
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
-    const float* act_geo = a.act + (size_t)sp * LK_ACT_GEO_A;
     const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A;
     const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H;
     float4 draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
     if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
-    float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;                     // this lane's share of dL/dp (embedding paths)
-
-    // ================= colour decoder =================
-    if (a.flags & LK_FLAG_STAGE_COLOR) {
-        float g0 = draw.x, g1 = draw.y, g2 = draw.z;
-        const float4 yo = *reinterpret_cast<const float4*>(a.raw + (size_t)sp * 4);
-        if (!(a.flags & LK_FLAG_COLOR_LOGITS)) {                 // through the sigmoid
-            g0 *= yo.x * (1.0f - yo.x); g1 *= yo.y * (1.0f - yo.y); g2 *= yo.z * (1.0f - yo.z);
-        }
-        f32x16 h4[4];
+    float g0 = draw.x, g1 = draw.y, g2 = draw.z;
+    const float4 yo = *reinterpret_cast<const float4*>(a.raw + (size_t)sp * 4);
+    if (!(a.flags & LK_FLAG_COLOR_LOGITS)) {                     // through the sigmoid
+        g0 *= yo.x * (1.0f - yo.x); g1 *= yo.y * (1.0f - yo.y); g2 *= yo.z * (1.0f - yo.z);
+    }
+    // output-layer weights of the wave's own units
+    float4 wo0[4], wo1[4], wo2[4];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) h4[nb] = ct_load32(act_col_h + 4 * 128 + nb * 32, lane);
-        if (a.affine) {                                          // out' = out @ A + t  (decoder.py:536-539)
-            // recompute the pre-affine output o = Wo h4 + bo
+    for (int g = 0; g < 4; ++g) {
+        const int u = 32 * w + 8 * g + 4 * h;
+        wo0[g] = *reinterpret_cast<const float4*>(W + C_WO + u);
+        wo1[g] = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
+        wo2[g] = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
+    }
+    if (a.affine) {                                              // out' = out @ A + t  (decoder.py:536-539)
+        if (a.g_affine) {
+            // recompute the pre-affine output o = Wo h4 + bo: per-wave partial over its units, summed by wave 0
+            const f32x16 h4 = ct_load32(act_col_h + 4 * 128 + w * 32, lane);
             float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int u = 32 * nb + 8 * g + 4 * h;
-                    const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + u);
-                    const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
-                    const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
-                    const float v0 = h4[nb][4 * g], v1 = h4[nb][4 * g + 1], v2 = h4[nb][4 * g + 2], v3 = h4[nb][4 * g + 3];
-                    o0 = fmaf(w0.x, v0, o0); o0 = fmaf(w0.y, v1, o0); o0 = fmaf(w0.z, v2, o0); o0 = fmaf(w0.w, v3, o0);
-                    o1 = fmaf(w1.x, v0, o1); o1 = fmaf(w1.y, v1, o1); o1 = fmaf(w1.z, v2, o1); o1 = fmaf(w1.w, v3, o1);
-                    o2 = fmaf(w2.x, v0, o2); o2 = fmaf(w2.y, v1, o2); o2 = fmaf(w2.z, v2, o2); o2 = fmaf(w2.w, v3, o2);
-                }
+            for (int g = 0; g < 4; ++g) {
+                const float v0 = h4[4 * g], v1 = h4[4 * g + 1], v2 = h4[4 * g + 2], v3 = h4[4 * g + 3];
+                o0 = fmaf(wo0[g].x, v0, o0); o0 = fmaf(wo0[g].y, v1, o0); o0 = fmaf(wo0[g].z, v2, o0); o0 = fmaf(wo0[g].w, v3, o0);
+                o1 = fmaf(wo1[g].x, v0, o1); o1 = fmaf(wo1[g].y, v1, o1); o1 = fmaf(wo1[g].z, v2, o1); o1 = fmaf(wo1[g].w, v3, o1);
+                o2 = fmaf(wo2[g].x, v0, o2); o2 = fmaf(wo2[g].y, v1, o2); o2 = fmaf(wo2[g].z, v2, o2); o2 = fmaf(wo2[g].w, v3, o2);
+            }
             o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
-            o0 += W[C_BO]; o1 += W[C_BO + 1]; o2 += W[C_BO + 2];
-            const float* A = a.affine;
-            if (a.g_affine) {                                    // d affine: sum over samples
+            if (h == 0) { s_o[w][lane] = o0; s_o[w][32 + lane] = o1; s_o[w][64 + lane] = o2; }
+            __syncthreads();
+            if (w == 0) {
+                const int c = lane & 31;
+                const float oo[3] = {((s_o[0][c] + s_o[1][c]) + s_o[2][c]) + s_o[3][c] + W[C_BO],
+                                     ((s_o[0][32 + c] + s_o[1][32 + c]) + s_o[2][32 + c]) + s_o[3][32 + c] + W[C_BO + 1],
+                                     ((s_o[0][64 + c] + s_o[1][64 + c]) + s_o[2][64 + c]) + s_o[3][64 + c] + W[C_BO + 2]};
                 const float gm[3] = {g0, g1, g2};
-                const float oo[3] = {o0, o1, o2};
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int c3 = 0; c3 < 3; ++c3)
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
-                        const float v = lk_half_wave_sum(oo[c] * gm[m]);
-                        if (lane == 0) atomicAdd(a.g_affine + c * 3 + m, v);
+                        const float v = lk_half_wave_sum(oo[c3] * gm[m]);
+                        if (lane == 0) atomicAdd(a.g_affine + c3 * 3 + m, v);
                     }
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
@@ -150,87 +171,107 @@ __device__ __forceinline__ void decode_bwd_wave(const LkDecodeBwdArgs& a, int sa
                     if (lane == 0) atomicAdd(a.g_affine + 9 + m, v);
                 }
             }
-            const float t0 = g0 * A[0] + g1 * A[1] + g2 * A[2];
-            const float t1 = g0 * A[3] + g1 * A[4] + g2 * A[5];
-            const float t2 = g0 * A[6] + g1 * A[7] + g2 * A[8];
-            g0 = t0; g1 = t1; g2 = t2;
+            __syncthreads();                                     // s_o is reused for the d p partials
         }
-        if (want_w && live && h == 0) *reinterpret_cast<float4*>(a.dlogit + (size_t)sp * 4) = make_float4(g0, g1, g2, 0.0f);
-        // dh4 = Wo^T d out
-        f32x16 dh[4], dy[4];
+        const float* A = a.affine;
+        const float t0 = g0 * A[0] + g1 * A[1] + g2 * A[2];
+        const float t1 = g0 * A[3] + g1 * A[4] + g2 * A[5];
+        const float t2 = g0 * A[6] + g1 * A[7] + g2 * A[8];
+        g0 = t0; g1 = t1; g2 = t2;
+    }
+    if (want_w && live && h == 0 && w == 0) *reinterpret_cast<float4*>(a.dlogit + (size_t)sp * 4) = make_float4(g0, g1, g2, 0.0f);
+    // dh4[own] = Wo^T d out
+    f32x16 dh, dy;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+    for (int g = 0; g < 4; ++g) {
+        dh[4 * g + 0] = wo0[g].x * g0 + wo1[g].x * g1 + wo2[g].x * g2;
+        dh[4 * g + 1] = wo0[g].y * g0 + wo1[g].y * g1 + wo2[g].y * g2;
+        dh[4 * g + 2] = wo0[g].z * g0 + wo1[g].z * g1 + wo2[g].z * g2;
+        dh[4 * g + 3] = wo0[g].w * g0 + wo1[g].w * g1 + wo2[g].w * g2;
+    }
+    f32x16 dc[1], de;
+    dc[0] = lk_zero16(); de = lk_zero16();
+    int buf = 0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int u = 32 * nb + 8 * g + 4 * h;
-                const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + u);
-                const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
-                const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
-                dh[nb][4 * g + 0] = w0.x * g0 + w1.x * g1 + w2.x * g2;
-                dh[nb][4 * g + 1] = w0.y * g0 + w1.y * g1 + w2.y * g2;
-                dh[nb][4 * g + 2] = w0.z * g0 + w1.z * g1 + w2.z * g2;
-                dh[nb][4 * g + 3] = w0.w * g0 + w1.w * g1 + w2.w * g2;
-            }
-        f32x16 dc[1], de[2];
-        dc[0] = lk_zero16(); de[0] = lk_zero16(); de[1] = lk_zero16();
+    for (int i = 4; i >= 0; --i) {
+        if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dh, live, lane);
+        const float* Utr = F + (i == 0 ? FM15_TR : i == 1 ? FM16_TR : i == 2 ? FM17_TR : i == 3 ? FM18_TR : FM19_TR);
+        lk_gemm_frag<1, 4>(dc, Utr, 1, 4 * w, 0, dh, lane);
+        const f32x16 av = ct_load32(act_col_a + i * 128 + w * 32, lane);
 #pragma unroll
-        for (int i = 4; i >= 0; --i) {
-            if (want_w) {
+        for (int q = 0; q < 16; ++q) dy[q] = dh[q] * lk_softplus100_grad_from_out(av[q]);
+        if (i == 0 && !want_p) break;
+        float4* xs = s_x + buf * (16 * 64);
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + nb * 32, dh[nb], live, lane);
-            }
-            const float* Utr = F + (i == 0 ? FM15_TR : i == 1 ? FM16_TR : i == 2 ? FM17_TR : i == 3 ? FM18_TR : FM19_TR);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<1, 4>(dc, Utr, 1, 4 * nb, 0, dh[nb], lane);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const f32x16 av = ct_load32(act_col_a + i * 128 + nb * 32, lane);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) dy[nb][q] = dh[nb][q] * lk_softplus100_grad_from_out(av[q]);
-            }
-            if (i == 4 || i == 2 || i == 1) {
-                const float* Wtr = F + (i == 4 ? FM14_TR : i == 2 ? FM12_TR : FM11_TR);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dh[kb] = lk_zero16();
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<4, 4>(dh, Wtr, 4, 4 * nb, 0, dy[nb], lane);
-            } else if (i == 3) {
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dh[kb] = lk_zero16();
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<4, 4>(dh, F + FM13_TR, 6, 4 * nb, 2, dy[nb], lane);
-                if (want_p) {
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<2, 4>(de, F + FM13_TR, 6, 4 * nb, 0, dy[nb], lane);
-                }
-            } else {   // i == 0: only the embedding receives gradient
-                if (want_p) {
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<2, 4>(de, F + FM10_TR, 2, 4 * nb, 0, dy[nb], lane);
-                }
-            }
-        }
-        ct_store32(a.dc_col + (size_t)sp * LK_C, dc[0], live, lane);
-        if (want_p) {    // e_u = sin(x_u) (u<20) | cos(x_{u-20});  dp_i += de_u * f'(x) * 2 pi * B[i][xi]
-            const float* B = W + C_EB;
-#pragma unroll
-            for (int tile = 0; tile < 2; ++tile)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int u = 32 * tile + lk_frag_row(q, h);
-                    if (u < EC) {
-                        const int xi = (u < 20) ? u : u - 20;
-                        const float b0 = B[xi], b1 = B[20 + xi], b2 = B[40 + xi];
-                        const float x = lk_fourier_arg(a0, a1, a2, b0, b1, b2);
-                        const float f = (u < 20) ? lk_cosf(x) : -lk_sinf(x);
-                        const float gx = de[tile][q] * f * LK_TWO_PI;
-                        dpx = fmaf(gx, b0, dpx); dpy = fmaf(gx, b1, dpy); dpz = fmaf(gx, b2, dpz);
-                    }
-                }
+        for (int j = 0; j < 4; ++j) xs[(w * 4 + j) * 64 + lane] = make_float4(dy[4 * j], dy[4 * j + 1], dy[4 * j + 2], dy[4 * j + 3]);
+        __syncthreads();
+        buf ^= 1;
+        if (i == 4 || i == 2 || i == 1) {
+            dh = lk_zero16();
+            lk_gemm_frag_lds<16>(dh, F + (i == 4 ? FM14_TR : i == 2 ? FM12_TR : FM11_TR), 4, 0, w, xs, lane);
+        } else if (i == 3) {
+            dh = lk_zero16();
+            lk_gemm_frag_lds<16>(dh, F + FM13_TR, 6, 0, 2 + w, xs, lane);
+            if (want_p && w < 2) lk_gemm_frag_lds<16>(de, F + FM13_TR, 6, 0, w, xs, lane);
+        } else {       // i == 0: only the embedding receives gradient
+            if (w >= 2) lk_gemm_frag_lds<16>(de, F + FM10_TR, 2, 0, w - 2, xs, lane);
         }
     }
+    // d c: park the per-wave partials, wave w sums register chunk w of all four -> one float4 per lane
+    {
+        float4* xs = s_x + buf * (16 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[(w * 4 + j) * 64 + lane] = make_float4(dc[0][4 * j], dc[0][4 * j + 1], dc[0][4 * j + 2], dc[0][4 * j + 3]);
+        float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;
+        if (want_p) {    // e_u = sin(x_u) (u<20) | cos(x_{u-20});  dp_i += de_u * f'(x) * 2 pi * B[i][xi]
+            const float* B = W + C_EB;
+            const int et = w & 1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int u = 32 * et + lk_frag_row(q, h);
+                if (u < EC) {
+                    const int xi = (u < 20) ? u : u - 20;
+                    const float b0 = B[xi], b1 = B[20 + xi], b2 = B[40 + xi];
+                    const float x = lk_fourier_arg(a0, a1, a2, b0, b1, b2);
+                    const float f = (u < 20) ? lk_cosf(x) : -lk_sinf(x);
+                    const float gx = de[q] * f * LK_TWO_PI;
+                    dpx = fmaf(gx, b0, dpx); dpy = fmaf(gx, b1, dpy); dpz = fmaf(gx, b2, dpz);
+                }
+            }
+            dpx += __shfl_xor(dpx, 32); dpy += __shfl_xor(dpy, 32); dpz += __shfl_xor(dpz, 32);
+            if (h == 0) { s_o[w][lane] = dpx; s_o[w][32 + lane] = dpy; s_o[w][64 + lane] = dpz; }
+        }
+        __syncthreads();
+        float4 c0 = xs[(0 * 4 + w) * 64 + lane];
+        const float4 c1 = xs[(1 * 4 + w) * 64 + lane], c2 = xs[(2 * 4 + w) * 64 + lane], c3 = xs[(3 * 4 + w) * 64 + lane];
+        c0.x = ((c0.x + c1.x) + c2.x) + c3.x; c0.y = ((c0.y + c1.y) + c2.y) + c3.y;
+        c0.z = ((c0.z + c1.z) + c2.z) + c3.z; c0.w = ((c0.w + c1.w) + c2.w) + c3.w;
+        if (live) *reinterpret_cast<float4*>(a.dc_col + (size_t)sp * LK_C + 8 * w + 4 * h) = c0;
+        if (want_p && w == 0 && h == 0 && live) {
+            const float x = ((s_o[0][lane] + s_o[1][lane]) + s_o[2][lane]) + s_o[3][lane];
+            const float y = ((s_o[0][32 + lane] + s_o[1][32 + lane]) + s_o[2][32 + lane]) + s_o[3][32 + lane];
+            const float z = ((s_o[0][64 + lane] + s_o[1][64 + lane]) + s_o[2][64 + lane]) + s_o[3][64 + lane];
+            *reinterpret_cast<float4*>(a.dp_embed_col + (size_t)sp * 4) = make_float4(x, y, z, 0.0f);
+        }
+    }
+}
 
+// ================= geometry decoder backward: one wave = one 32-sample tile =================
+// part = this wave's [3][96] slice of the workgroup's d B_g partial sums (LDS)
+__device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, int tile, float* __restrict__ part) {
+    const int lane = lk_lane();
+    const BwdSample d = bwd_sample(a, tile, lane);
+    const int h = d.h, sp = d.sp;
+    const bool live = d.live;
+    const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
+    const float* __restrict__ W = a.W;
+    const float* __restrict__ F = a.Wfrag;
+    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
+    const float* act_geo = a.act + (size_t)sp * LK_ACT_GEO_A;
+    float4 draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
+    if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
+    float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;                     // this lane's share of dL/dp (embedding path)
     // ================= geometry decoder =================
     {
         const float docc = draw.w;
@@ -299,20 +340,28 @@ __device__ __forceinline__ void decode_bwd_wave(const LkDecodeBwdArgs& a, int sa
 // Hot-address atomics are the slowest thing this chip does (a few hundred distinct addresses hit by every
 // wave serialise in the memory-side atomic unit): the embedding-matrix gradient is therefore reduced
 // wave -> LDS -> one partial row per workgroup, and summed by k_reduce_partials.
-__global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a) {
-    __shared__ float s_part[4][3 * EGP];
-    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+// Block roles as in k_decode_fwd: the first n_col_blocks workgroups are colour tiles, the rest geometry (4 tiles each).
+__global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
+    __shared__ float4 s_x[2 * 16 * 64];
+    __shared__ float s_o[4][3 * 32];
     const int w = (int)threadIdx.x >> 6;
+    if ((int)blockIdx.x < n_col_blocks) {
+        decode_bwd_col_wg(a, blockIdx.x, w, lk_lane(), s_x, s_o);
+        return;
+    }
+    float (*s_part)[3 * EGP] = reinterpret_cast<float (*)[3 * EGP]>(s_x);
+    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    const int gb = (int)blockIdx.x - n_col_blocks;
     if (want_w) {
         for (int e = threadIdx.x; e < 4 * 3 * EGP; e += 256) (&s_part[0][0])[e] = 0.0f;
         __syncthreads();
     }
-    const int sample0 = (blockIdx.x * 4 + w) * 32;
-    if (sample0 < a.P) decode_bwd_wave(a, sample0, s_part[w]);
+    const int tile = gb * 4 + w;
+    if (tile * 32 < a.P) decode_bwd_geo_wave(a, tile, s_part[w]);
     if (want_w) {
         __syncthreads();
         for (int e = threadIdx.x; e < 3 * EGP; e += 256)
-            a.part_bg[(size_t)blockIdx.x * (3 * EGP) + e] = s_part[0][e] + s_part[1][e] + s_part[2][e] + s_part[3][e];
+            a.part_bg[(size_t)gb * (3 * EGP) + e] = s_part[0][e] + s_part[1][e] + s_part[2][e] + s_part[3][e];
     }
 }
 
@@ -343,7 +392,8 @@ int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st) {
 }
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_BWD, st);
-    const int waves = lk_cdiv(a.P, 32);
-    hipLaunchKernelGGL(k_decode_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    const int tiles = lk_cdiv(a.P, 32);
+    const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
+    hipLaunchKernelGGL(k_decode_bwd, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     return LK_OK;
 }

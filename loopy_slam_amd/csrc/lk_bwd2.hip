@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
     }
     if (live && sub == 0) {
         if (a.dp_embed) { const float4 e = *reinterpret_cast<const float4*>(a.dp_embed + (size_t)pidx * 4); dpx += e.x; dpy += e.y; dpz += e.z; }
+        if (color && a.dp_embed_col) { const float4 e = *reinterpret_cast<const float4*>(a.dp_embed_col + (size_t)pidx * 4); dpx += e.x; dpy += e.y; dpz += e.z; }
         if (color && relpos && a.dp_rel) { const float4 e = *reinterpret_cast<const float4*>(a.dp_rel + (size_t)pidx * 4); dpx += e.x; dpy += e.y; dpz += e.z; }
         *reinterpret_cast<float4*>(a.dp_total + (size_t)pidx * 4) = make_float4(dpx, dpy, dpz, 0.0f);
     }

@@ -172,6 +172,23 @@ __device__ __forceinline__ void lk_gemm_frag(f32x16 (&acc)[NB], const float* __r
     }
 }
 
+// Same walk with the B operand parked in LDS as per-lane float4 register chunks: xs[g * 64 + lane] = registers
+// 4g'..4g'+3 of CT tile (g / 4) as written by the lane with the same id in the wave owning that tile.
+template <int NG>
+__device__ __forceinline__ void lk_gemm_frag_lds(f32x16& acc, const float* __restrict__ frag, int NBT, int g0, int nb,
+                                              const float4* __restrict__ xs /* [NG][64] chunks */, int lane) {
+    const float* __restrict__ base = frag + ((size_t)g0 * NBT + nb) * 256 + lane * 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const float4 w = *reinterpret_cast<const float4*>(base + (size_t)g * NBT * 256);
+        const float4 x = xs[g * 64 + lane];
+        acc = lk_mfma(w.x, x.x, acc);
+        acc = lk_mfma(w.y, x.y, acc);
+        acc = lk_mfma(w.z, x.z, acc);
+        acc = lk_mfma(w.w, x.w, acc);
+    }
+}
+
 // sum over the 32 sample columns held by the lanes of one half-wave (lanes with equal lane>>5)
 __device__ __forceinline__ float lk_half_wave_sum(float v) {
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);

@@ -178,21 +178,6 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
 // LDS as the four float4 register chunks of every lane, [wave][chunk][lane] — the reader of chunk (w', j) is the
 // SAME lane id in every wave (the C/D-row walk of lk_gemm_frag), so writes and reads are both lane-contiguous
 // (conflict-free ds_write/read_b128).  Double-buffered: one barrier per layer.
-template <int NG>
-__device__ __forceinline__ void gemm_frag_lds(f32x16& acc, const float* __restrict__ frag, int NBT, int g0, int nb,
-                                              const float4* __restrict__ xs /* [NG][64] chunks */, int lane) {
-    const float* __restrict__ base = frag + ((size_t)g0 * NBT + nb) * 256 + lane * 4;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const float4 w = *reinterpret_cast<const float4*>(base + (size_t)g * NBT * 256);
-        const float4 x = xs[g * 64 + lane];
-        acc = lk_mfma(w.x, x.x, acc);
-        acc = lk_mfma(w.y, x.y, acc);
-        acc = lk_mfma(w.z, x.z, acc);
-        acc = lk_mfma(w.w, x.w, acc);
-    }
-}
-
 // bias + softplus (+ save) + fc_c(c) for the wave's own 32-unit block `w`
 __device__ __forceinline__ void col_layer_finish(f32x16& acc, int w, const float* __restrict__ bias,
                                                  const float* __restrict__ Ufrag, const float* __restrict__ ubias,
@@ -244,7 +229,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
 #pragma unroll
     for (int L = 1; L <= 2; ++L) {
         acc[0] = lk_zero16();
-        gemm_frag_lds<16>(acc[0], F + (L == 1 ? FM11_FWD : FM12_FWD), 4, 0, w, s_x[(L - 1) & 1], lane);
+        lk_gemm_frag_lds<16>(acc[0], F + (L == 1 ? FM11_FWD : FM12_FWD), 4, 0, w, s_x[(L - 1) & 1], lane);
         col_layer_finish(acc[0], w, W + (L == 1 ? C_B1 : C_B2), F + (L == 1 ? FM16_FWD : FM17_FWD),
                          W + C_U0 + L * C_USTRIDE + a64(HC * CF), cc, act_col_a ? act_col_a + L * 128 : nullptr, live, lane);
         park(acc[0], L & 1, L);
@@ -254,14 +239,14 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     acc[0] = lk_zero16();
     lk_gemm_frag<1, 4>(acc, F + FM13_FWD, 4, 0, w, e0, lane);
     lk_gemm_frag<1, 1>(acc, F + FM13_FWD, 4, 4, w, e1, lane);
-    gemm_frag_lds<16>(acc[0], F + FM13_FWD, 4, 5, w, s_x[0], lane);
+    lk_gemm_frag_lds<16>(acc[0], F + FM13_FWD, 4, 5, w, s_x[0], lane);
     col_layer_finish(acc[0], w, W + C_B3, F + FM18_FWD, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), cc,
                      act_col_a ? act_col_a + 3 * 128 : nullptr, live, lane);
     park(acc[0], 1, 3);
     __syncthreads();
     // layer 4
     acc[0] = lk_zero16();
-    gemm_frag_lds<16>(acc[0], F + FM14_FWD, 4, 0, w, s_x[1], lane);
+    lk_gemm_frag_lds<16>(acc[0], F + FM14_FWD, 4, 0, w, s_x[1], lane);
     col_layer_finish(acc[0], w, W + C_B4, F + FM19_FWD, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), cc,
                      act_col_a ? act_col_a + 4 * 128 : nullptr, live, lane);
     if (save) ct_store_rows32(act_col_h + 4 * 128 + w * 32, acc[0], live, lane);

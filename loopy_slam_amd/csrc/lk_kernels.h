@@ -73,7 +73,8 @@ struct LkDecodeBwdArgs {
     float* dc_geo; float* dc_col;                  // [P,32]
     float* dh_col;                                 // [P,640] (GRAD_WEIGHTS)
     float* dlogit;                                 // [P,4]   (GRAD_WEIGHTS)
-    float* dp_embed;                               // [P,4]   (GRAD_RAYS)
+    float* dp_embed;                               // [P,4]   (GRAD_RAYS) geometry-decoder embedding path
+    float* dp_embed_col;                           // [P,4]   (GRAD_RAYS, colour stage) colour-decoder embedding path
     float* g_weights; float* g_affine;
     float* part_bg;                                // [n_blocks][288] per-workgroup partial sums of d embedder._B (GRAD_WEIGHTS)
 };
@@ -87,7 +88,7 @@ struct LkInterpBwdArgs {
     const int32_t* nbr_idx; const float* nbr_w; const int32_t* nbr_count;
     const float* dc_geo; const float* dc_col;
     const float* dw_rel;                           // [P,8] d loss / d normalised weight from the rel-pos branch, or NULL
-    const float* dp_embed; const float* dp_rel;    // [P,4] or NULL
+    const float* dp_embed; const float* dp_embed_col; const float* dp_rel;    // [P,4] or NULL
     float* g_geo_feats; float* g_col_feats;        // [N,32] accumulated
     float* dp_total;                               // [P,4] (GRAD_RAYS)
 };
