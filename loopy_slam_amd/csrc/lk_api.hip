@@ -291,7 +291,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J.B = act_h + 4 * 128; J.ldb = LK_ACT_COL_H;
             J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
         }
-        wa.n_jobs = nj; wa.chunk = getenv("LK_EXP_CHUNK") ? atoi(getenv("LK_EXP_CHUNK")) : 256;
+        wa.n_jobs = nj; wa.chunk = getenv("LK_EXP_CHUNK") ? atoi(getenv("LK_EXP_CHUNK")) : 0;
         lk_launch_wgrad(wa, P, wst);
         if (forked) (void)hipEventRecord(ss.join, ss.st);
     }
@@ -347,7 +347,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J2.A = S0 + L.dc_col; J2.lda = LK_C; J2.a_mode = 2; J2.A2 = S0 + L.w_sum; J2.lda2 = 1;
             J2.B = S0 + L.hbar; J2.ldb = 128;
             J2.N = CF; J2.K = HC; J2.rows = P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
-            wr.n_jobs = 2; wr.chunk = getenv("LK_EXP_CHUNK2") ? atoi(getenv("LK_EXP_CHUNK2")) : 512;
+            wr.n_jobs = 2; wr.chunk = getenv("LK_EXP_CHUNK2") ? atoi(getenv("LK_EXP_CHUNK2")) : 0;
             lk_launch_wgrad(wr, 8 * P, st);
         }
     }

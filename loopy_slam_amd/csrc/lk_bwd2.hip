@@ -331,132 +331,140 @@ __global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// dW[n][k] += sum_rows A[row][n] * B[row][k]  for every decoder matrix (one "job" each).
-// One 4-wave workgroup per (job, chunk of rows).  Rows are streamed 32 at a time: all 256 threads fetch the
-// A and B row tiles with coalesced 16-byte loads (register prefetch of the next tile overlaps the MFMAs of the
-// current one), the element-wise factor of A (softplus', or the rel-pos row weight) is applied on the fly, the
-// tiles go through LDS once, and each wave owns a subset of the 32x32 output blocks: 16 k-steps of
-// v_mfma_f32_32x32x2_f32 per tile and block, operands read conflict-free from LDS.  Accumulators stay in
-// registers for the whole chunk and are flushed once with line-coalesced atomics; bias gradients are the
-// column sums of the A tiles.
-#define WG_RT 32
-#define WG_LDA 132
-#define WG_LDB 196
+// dW[n][k] += sum_rows A'[row][n] * B[row][k]  for every decoder matrix (one "job" each): a reduction GEMM with a
+// small output (<= 128 x 168) and a very long reduction (the rows = samples or neighbour rows).
+//
+// One WAVE per (unit, chunk of rows), no LDS, no barriers.  A unit is an (N piece) x (K piece) of a job, a piece being
+// 32*V consecutive columns (V = 1 or 2) handled as V interleaved 32x32 MFMA blocks: lane i of a half-wave owns
+// columns piece0 + V*i .. +V-1, so ONE V-float load per lane is, for a pair of rows (half-wave = row), at the same
+// time a fully coalesced 128*V-byte row segment and the A (resp. B) operand of v_mfma_f32_32x32x2_f32 for V blocks
+// (block b = the columns congruent to b mod V — any column permutation is as good as another for an outer product).
+// Per pair of rows a (2,2) unit issues 3 loads (A, the element-wise factor source A2, B) and 4 MFMAs; loads are
+// batched WG_STEPS pairs ahead in registers.  The bias gradient is the running column sum of the A' operand.
+// Accumulators are flushed once per chunk with atomics.
+#define WG_STEPS 8
 
-// Raw operand fetches.  Nothing may CONSUME a prefetched register before the MFMA phase of the current tile has
-// been issued (a select or multiply right after the load makes the compiler wait for the data first, which
-// serialised load latency and MFMAs: 5.3 us per tile instead of 2): addresses are clamped instead of
-// predicated, and masking / the softplus' factor / the rel-pos row weight are applied when the tile is written to LDS.
-__device__ __forceinline__ void wg_fetch_a(const LkWgradJob& J, long long row, int c4, float4& v, float4& v2) {
-    if (J.a_mode == 2) {
-        v = *reinterpret_cast<const float4*>(J.A + (size_t)row * J.lda + 4 * c4);
-        const float w = J.A2[row];
-        v2 = make_float4(w, w, w, w);
-    } else {
-        v = *reinterpret_cast<const float4*>(J.A + (size_t)row * J.lda + 4 * c4);
-        if (J.a_mode == 1) v2 = *reinterpret_cast<const float4*>(J.A2 + (size_t)row * J.lda2 + 4 * c4);
+template <int V> struct WgVec;
+template <> struct WgVec<1> { float v[1]; };
+template <> struct WgVec<2> { float v[2]; };
+template <int V>
+__device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
+    WgVec<V> r;
+    if (V == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[V - 1] = t.y; }
+    else r.v[0] = *p;
+    return r;
+}
+
+template <int NV, int KV, int MODE>
+__device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int c1, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
+    const int ncol = n0 + NV * i, kcol = k0 + KV * i;
+    bool nok[NV], kok[KV];
+#pragma unroll
+    for (int b = 0; b < NV; ++b) nok[b] = ncol + b < J.N;
+#pragma unroll
+    for (int b = 0; b < KV; ++b) kok[b] = kcol + b < J.K;
+    const int ncl = nok[0] ? ncol : 0;
+    const float* __restrict__ pA = J.A + ncl;
+    const float* __restrict__ pA2 = (MODE == 1) ? J.A2 + ncl : J.A2;
+    const float* __restrict__ pB;
+    int ldb;
+    if (J.B2 && kcol >= J.k_split) { pB = J.B2 + (kcol - J.k_split); ldb = J.ldb2; }
+    else { pB = J.B + (kok[0] ? kcol : 0); ldb = J.ldb; }
+    const int lda = J.lda, lda2 = J.lda2;
+    constexpr int mode = MODE;
+    f32x16 acc[NV][KV];
+#pragma unroll
+    for (int bn = 0; bn < NV; ++bn)
+#pragma unroll
+        for (int bk = 0; bk < KV; ++bk) acc[bn][bk] = lk_zero16();
+    float bsum[NV];
+#pragma unroll
+    for (int b = 0; b < NV; ++b) bsum[b] = 0.0f;
+    const int last = c1 - 1;
+    WgVec<NV> ra[WG_STEPS], ra2[WG_STEPS];
+    WgVec<KV> rb[WG_STEPS];
+    float rw[WG_STEPS];
+    auto fetch = [&](int row0) {
+#pragma unroll
+        for (int s = 0; s < WG_STEPS; ++s) {
+            int row = row0 + 2 * s + h;
+            row = row < last ? row : last;
+            ra[s] = wg_load<NV>(pA + (size_t)row * lda);
+            if (mode == 1) ra2[s] = wg_load<NV>(pA2 + (size_t)row * lda2);
+            if (mode == 2) rw[s] = pA2[row];
+            rb[s] = wg_load<KV>(pB + (size_t)row * ldb);
+        }
+    };
+    fetch(c0);
+    for (int row0 = c0; row0 < c1; row0 += 2 * WG_STEPS) {
+        // current batch -> private copies, next batch in flight while the MFMAs of this one run
+        WgVec<NV> ca[WG_STEPS], ca2[WG_STEPS];
+        WgVec<KV> cb[WG_STEPS];
+        float cw[WG_STEPS];
+#pragma unroll
+        for (int s = 0; s < WG_STEPS; ++s) { ca[s] = ra[s]; ca2[s] = ra2[s]; cb[s] = rb[s]; cw[s] = rw[s]; }
+        if (row0 + 2 * WG_STEPS < c1) fetch(row0 + 2 * WG_STEPS);
+#pragma unroll
+        for (int s = 0; s < WG_STEPS; ++s) {
+            const bool ok = row0 + 2 * s + h < c1;
+            float av[NV];
+#pragma unroll
+            for (int b = 0; b < NV; ++b) {
+                float f = 1.0f;
+                if (mode == 1) f = lk_softplus100_grad_from_out(ca2[s].v[b]);
+                if (mode == 2) f = cw[s];
+                av[b] = (ok && nok[b]) ? ca[s].v[b] * f : 0.0f;
+                bsum[b] += av[b];
+            }
+#pragma unroll
+            for (int bn = 0; bn < NV; ++bn)
+#pragma unroll
+                for (int bk = 0; bk < KV; ++bk) acc[bn][bk] = lk_mfma(av[bn], cb[s].v[bk], acc[bn][bk]);
+        }
+    }
+    // flush: block (bn, bk), register r of lane (j = lane&31, h): n = n0 + NV*frag_row(r,h) + bn, k = k0 + KV*j + bk
+#pragma unroll
+    for (int bn = 0; bn < NV; ++bn)
+#pragma unroll
+        for (int bk = 0; bk < KV; ++bk) {
+            if (!kok[bk]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + NV * lk_frag_row(r, h) + bn;
+                if (nn < J.N) atomicAdd(J.dW + (size_t)nn * J.ldw + kcol + bk, acc[bn][bk][r]);
+            }
+        }
+    if (J.db && k0 == 0) {
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+            const float v = bsum[b] + __shfl_xor(bsum[b], 32);
+            if (h == 0 && nok[b]) atomicAdd(J.db + ncol + b, v);
+        }
     }
 }
-__device__ __forceinline__ float4 wg_finish_a(const LkWgradJob& J, float4 v, float4 v2, bool ok) {
-    if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
-    if (J.a_mode == 1) {
-        v.x *= lk_softplus100_grad_from_out(v2.x); v.y *= lk_softplus100_grad_from_out(v2.y);
-        v.z *= lk_softplus100_grad_from_out(v2.z); v.w *= lk_softplus100_grad_from_out(v2.w);
-    } else if (J.a_mode == 2) {
-        v.x *= v2.x; v.y *= v2.x; v.z *= v2.x; v.w *= v2.x;
-    }
-    return v;
-}
-__device__ __forceinline__ float4 wg_fetch_b(const LkWgradJob& J, long long row, int c4) {
-    const int k = 4 * c4;
-    if (J.B2 && k >= J.k_split) return *reinterpret_cast<const float4*>(J.B2 + (size_t)row * J.ldb2 + (k - J.k_split));
-    return *reinterpret_cast<const float4*>(J.B + (size_t)row * J.ldb + k);
+
+template <int NV, int KV>
+__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int c1, int lane) {
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0>(J, n0, k0, c0, c1, lane);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1>(J, n0, k0, c0, c1, lane);
+    else wgrad_unit<NV, KV, 2>(J, n0, k0, c0, c1, lane);
 }
 
 __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float sA[WG_RT * WG_LDA];
-    __shared__ __attribute__((aligned(16))) float sB[WG_RT * WG_LDB];
-    const LkWgradJob& J = a.job[blockIdx.y];
-    const long long c0 = (long long)blockIdx.x * a.chunk;
-    if (c0 >= J.rows) return;                                          // uniform per block
-    const long long c1 = (c0 + a.chunk < J.rows) ? c0 + a.chunk : J.rows;
-    const int t = (int)threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int N4 = (J.N + 3) >> 2, K4 = (J.K + 3) >> 2;                // float4 columns of the A / B tiles
-    const int NB = (J.N + 31) >> 5, KB = (J.K + 31) >> 5, U = NB * KB; // 32x32 output blocks, U <= 24
-    const int nA = WG_RT * N4, nB = WG_RT * K4;                        // float4 elements per tile
-    f32x16 acc[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) acc[q] = lk_zero16();
-    float bsum = 0.0f;
-    float4 ra[4], ra2[4], rb[6];
-    // zero the padding columns once (tiles narrower than a multiple of 32 leave stale LDS otherwise)
-    for (int e = t; e < WG_RT * WG_LDA; e += 256) sA[e] = 0.0f;
-    for (int e = t; e < WG_RT * WG_LDB; e += 256) sB[e] = 0.0f;
-    // element -> (row-in-tile, float4 column), clamped so that every thread always has a legal address
-    int ar[4], ac[4], br[6], bc[6];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const int e = min(t + 256 * q, nA - 1); ar[q] = e / N4; ac[q] = e - ar[q] * N4; ra2[q] = make_float4(1.f, 1.f, 1.f, 1.f); }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { const int e = min(t + 256 * q, nB - 1); br[q] = e / K4; bc[q] = e - br[q] * K4; }
-    const long long last = c1 - 1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wg_fetch_a(J, min(c0 + ar[q], last), ac[q], ra[q], ra2[q]);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) rb[q] = wg_fetch_b(J, min(c0 + br[q], last), bc[q]);
-    for (long long tile = c0; tile < c1; tile += WG_RT) {
-        __syncthreads();                                               // previous tile fully consumed
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (t + 256 * q < nA) *reinterpret_cast<float4*>(sA + ar[q] * WG_LDA + 4 * ac[q]) = wg_finish_a(J, ra[q], ra2[q], tile + ar[q] < c1);
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-            if (t + 256 * q < nB) *reinterpret_cast<float4*>(sB + br[q] * WG_LDB + 4 * bc[q]) = (tile + br[q] < c1) ? rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        const long long nxt = tile + WG_RT;
-        if (nxt < c1) {                                                // prefetch the next tile: raw loads only
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wg_fetch_a(J, min(nxt + ar[q], last), ac[q], ra[q], ra2[q]);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) rb[q] = wg_fetch_b(J, min(nxt + br[q], last), bc[q]);
-        }
-        if (J.db && t < J.N) {
-#pragma unroll 8
-            for (int r = 0; r < WG_RT; ++r) bsum += sA[r * WG_LDA + t];
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int u = w + 4 * q;
-            if (u < U) {                                               // wave-uniform
-                const int nb = u / KB, kb = u - nb * KB;
-                const float* pa = sA + hh * WG_LDA + nb * 32 + l31;
-                const float* pb = sB + hh * WG_LDB + kb * 32 + l31;
-                // all 32 operand reads of this block are issued before its 16 MFMAs: with one wave per SIMD nothing
-                // else hides the LDS latency (an interleaved read->MFMA chain measured 2.7x the MFMA time)
-                float av[WG_RT / 2], bv[WG_RT / 2];
-#pragma unroll
-                for (int s2 = 0; s2 < WG_RT / 2; ++s2) { av[s2] = pa[2 * s2 * WG_LDA]; bv[s2] = pb[2 * s2 * WG_LDB]; }
-#pragma unroll
-                for (int s2 = 0; s2 < WG_RT / 2; ++s2) acc[q] = lk_mfma(av[s2], bv[s2], acc[q]);
-            }
-        }
-    }
-    // flush: lane holds column k = kb*32 + (lane&31), rows n = nb*32 + frag_row(r, half)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int u = w + 4 * q;
-        if (u < U) {
-            const int nb = u / KB, kb = u - nb * KB;
-            const int k = kb * 32 + l31;
-            if (k < J.K) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int nn = nb * 32 + lk_frag_row(r, hh);
-                    if (nn < J.N) atomicAdd(J.dW + (size_t)nn * J.ldw + k, acc[q][r]);
-                }
-            }
-        }
-    }
-    if (J.db && t < J.N) atomicAdd(J.db + t, bsum);
+    const int lane = lk_lane();
+    const int u = lk_uniform((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));     // unit of this wave: scalar
+    if (u >= a.n_units) return;
+    const LkWgradUnit& U = a.unit[u];
+    const LkWgradJob& J = a.job[U.job];
+    const int c0 = (int)blockIdx.y * a.chunk;                          // rows [c0, c1) of the job
+    if (c0 >= J.rows) return;                                          // wave-uniform
+    const int c1 = (c0 + a.chunk < J.rows) ? c0 + a.chunk : J.rows;
+    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2>(J, U.n0, U.k0, c0, c1, lane);
+    else if (U.nv == 2) wgrad_unit_mode<2, 1>(J, U.n0, U.k0, c0, c1, lane);
+    else if (U.kv == 2) wgrad_unit_mode<1, 2>(J, U.n0, U.k0, c0, c1, lane);
+    else wgrad_unit_mode<1, 1>(J, U.n0, U.k0, c0, c1, lane);
 }
 
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
@@ -480,9 +488,31 @@ int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_relpos_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;
 }
-int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st) {
+int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
     LkProfScope prof_(LKK_WGRAD, st);
-    if (a.n_jobs == 0 || max_rows <= 0) return LK_OK;
-    hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(max_rows, a.chunk), a.n_jobs), dim3(256), 0, st, a);
+    if (a_in.n_jobs == 0 || max_rows <= 0) return LK_OK;
+    LkWgradArgs a = a_in;
+    // cut every job into (N piece) x (K piece) units of 32 or 64 columns
+    a.n_units = 0;
+    for (int j = 0; j < a.n_jobs; ++j) {
+        const LkWgradJob& J = a.job[j];
+        for (int n0 = 0; n0 < J.N; n0 += 64) {
+            const int nv = (J.N - n0 > 32) ? 2 : 1;
+            for (int k0 = 0; k0 < J.K; k0 += 64) {
+                const int kv = (J.K - k0 > 32) ? 2 : 1;
+                if (a.n_units >= LK_WGRAD_MAX_UNITS) return LK_ERR_ARG;
+                LkWgradUnit& U = a.unit[a.n_units++];
+                U.job = j; U.n0 = n0; U.k0 = k0; U.nv = nv; U.kv = kv;
+            }
+        }
+    }
+    // rows per wave: enough waves to fill the chip about four deep, never below 64 rows (flush cost)
+    if (a.chunk <= 0) {
+        const long long target = 4096 / a.n_units > 0 ? 4096 / a.n_units : 1;
+        long long chunk = (max_rows + target - 1) / target;
+        chunk = ((chunk + 15) / 16) * 16;
+        a.chunk = (int)(chunk < 64 ? 64 : chunk);
+    }
+    hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_units, 4), lk_cdiv(max_rows, a.chunk)), dim3(256), 0, st, a);
     return LK_OK;
 }

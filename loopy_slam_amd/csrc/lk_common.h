@@ -63,6 +63,9 @@ struct lk_knn_s {
 
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ int lk_lane() { return (int)(threadIdx.x & 63u); }
+// value known to be the same in every lane of the wave -> scalar register (lets the compiler use scalar loads and
+// real branches for everything derived from it)
+__device__ __forceinline__ int lk_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // squared distance exactly as the contract states: (dx*dx + dy*dy) + dz*dz, one rounding per op
 __device__ __forceinline__ float lk_dist2(float qx, float qy, float qz, float px, float py, float pz) {

@@ -122,7 +122,7 @@ struct LkRelposBwdArgs {
     float* part_br;                                // [n_blocks][32] per-workgroup partial sums of d embedder_rel_pos._B
 };
 
-// weight gradients: dW[n][k] += sum_rows A[row][n] * B[row][k]  (one wave per (job, n-block, row chunk))
+// weight gradients: dW[n][k] += sum_rows A[row][n] * B[row][k]  (one wave per (job, column unit, row chunk))
 struct LkWgradJob {
     const float* A; int lda; int a_mode;           // 0 plain, 1 A*softplus'(A2), 2 A2[row]*A[row][n]
     const float* A2; int lda2;
@@ -134,7 +134,13 @@ struct LkWgradJob {
     float* db;                                     // bias gradient [N] or NULL
 };
 #define LK_WGRAD_MAX_JOBS 16
-struct LkWgradArgs { LkWgradJob job[LK_WGRAD_MAX_JOBS]; int n_jobs; int chunk; };
+#define LK_WGRAD_MAX_UNITS 48
+struct LkWgradUnit { int job, n0, k0; short nv, kv; };   // columns [n0, n0 + 32 nv) x [k0, k0 + 32 kv) of job
+struct LkWgradArgs {
+    LkWgradJob job[LK_WGRAD_MAX_JOBS]; int n_jobs;
+    int chunk;                                     // rows per wave; <= 0: chosen by the launcher
+    LkWgradUnit unit[LK_WGRAD_MAX_UNITS]; int n_units;   // filled by the launcher
+};
 
 int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st);
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st);
