@@ -165,7 +165,7 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
 
 // ------------------------------------------------------------------ render backward
 namespace {
-struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, total; };
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, wg_part, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -187,26 +187,12 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.w_sum = o; o += P;
     L.dh_col = o; if (color && gw) o += 640 * P;
     L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 192 * P;
+    L.wg_part = o; if (color && gw) o += lk_wgrad_part_floats(P, (flags & LK_FLAG_REL_POS) != 0);
     L.total = o;
     return L;
 }
 }  // namespace
 
-// side stream for the part of the backward that is independent of the rest (colour weight gradients): the
-// kernels of one training batch are latency bound (fewer waves than SIMDs), so running two of them side by side
-// is close to free.  Fork/join with events; created once per process.
-namespace {
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
-SideStream& side_stream() {
-    static SideStream s;
-    if (!s.st) {
-        s.ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
-    }
-    return s;
-}
-}  // namespace
 
 extern "C" int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t flags) {
     return bwd_layout((int64_t)R * S, flags).total;
@@ -247,18 +233,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     lk_launch_decode_bwd(db, st);
     if (gw) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
-    SideStream& ss = side_stream();
-    // Measured on MI355X: forking the colour weight gradients next to the rel-pos backward gained only 5 % (both
-    // are memory-pipeline bound, not latency bound) and blurs per-kernel timing, so it stays off.
-    const bool kForkColorWgrad = false;
-    const bool forked = kForkColorWgrad && gw && color && ss.ok;
     if (gw && color) {
-        hipStream_t wst = st;
-        if (forked) {
-            (void)hipEventRecord(ss.fork, st);
-            (void)hipStreamWaitEvent(ss.st, ss.fork, 0);
-            wst = ss.st;
-        }
         // colour decoder weight gradients as streamed reductions over the saved rows (geometry decoder weights
         // other than embedder._B are frozen in every reference config: mapping.fix_geo_decoder = True)
         const float* act_a = d->act + (size_t)P * LK_ACT_GEO_A;
@@ -291,9 +266,8 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J.B = act_h + 4 * 128; J.ldb = LK_ACT_COL_H;
             J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
         }
-        wa.n_jobs = nj; wa.chunk = getenv("LK_EXP_CHUNK") ? atoi(getenv("LK_EXP_CHUNK")) : 0;
-        lk_launch_wgrad(wa, P, wst);
-        if (forked) (void)hipEventRecord(ss.join, ss.st);
+        wa.n_jobs = nj; wa.chunk = 0; wa.part = S0 + L.wg_part;
+        lk_launch_wgrad(wa, P, st);
     }
 
     if (relpos) {
@@ -347,11 +321,10 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J2.A = S0 + L.dc_col; J2.lda = LK_C; J2.a_mode = 2; J2.A2 = S0 + L.w_sum; J2.lda2 = 1;
             J2.B = S0 + L.hbar; J2.ldb = 128;
             J2.N = CF; J2.K = HC; J2.rows = P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
-            wr.n_jobs = 2; wr.chunk = getenv("LK_EXP_CHUNK2") ? atoi(getenv("LK_EXP_CHUNK2")) : 0;
+            wr.n_jobs = 2; wr.chunk = 0; wr.part = S0 + L.wg_part;
             lk_launch_wgrad(wr, 8 * P, st);
         }
     }
-    if (forked) (void)hipStreamWaitEvent(st, ss.join, 0);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

@@ -339,10 +339,14 @@ __global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
 // columns piece0 + V*i .. +V-1, so ONE V-float load per lane is, for a pair of rows (half-wave = row), at the same
 // time a fully coalesced 128*V-byte row segment and the A (resp. B) operand of v_mfma_f32_32x32x2_f32 for V blocks
 // (block b = the columns congruent to b mod V — any column permutation is as good as another for an outer product).
-// Per pair of rows a (2,2) unit issues 3 loads (A, the element-wise factor source A2, B) and 4 MFMAs; loads are
-// batched WG_STEPS pairs ahead in registers.  The bias gradient is the running column sum of the A' operand.
-// Accumulators are flushed once per chunk with atomics.
-#define WG_STEPS 8
+// Per pair of rows a (2,2) unit issues 3 loads (A, the element-wise factor source A2, B) and 4 MFMAs; loads run
+// WG_STEPS - 1 row pairs ahead of the MFMAs in a register ring.  The bias gradient is the running column sum of the A' operand.
+// Global float atomics are the scarce resource here (they execute memory-side: ~85 G lane-adds/s measured - flushing
+// a 64x64 unit costs as much as 100 row pairs of MFMAs), so inside lk_render_bwd every wave writes its accumulator
+// tile to a partial buffer with plain coalesced stores and k_wgrad_reduce sums the tiles (no atomics, reproducible).
+// The four waves of a workgroup are four consecutive UNITS of the same row chunk, and the grid walks units fastest:
+// the pieces of A / A2 / B that several units need are fetched from HBM once and re-read from L1/L2.
+#define WG_STEPS 16
 
 template <int V> struct WgVec;
 template <> struct WgVec<1> { float v[1]; };
@@ -356,7 +360,8 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
 }
 
 template <int NV, int KV, int MODE>
-__device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int c1, int lane) {
+__device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int c1, int lane,
+                                           float* __restrict__ tile) {
     const int i = lane & 31, h = lane >> 5;
     // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
     const int ncol = n0 + NV * i, kcol = k0 + KV * i;
@@ -386,45 +391,62 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
     WgVec<NV> ra[WG_STEPS], ra2[WG_STEPS];
     WgVec<KV> rb[WG_STEPS];
     float rw[WG_STEPS];
+    auto fetch1 = [&](int s, int row0) {
+        int row = row0 + 2 * s + h;
+        row = row < last ? row : last;
+        ra[s] = wg_load<NV>(pA + (size_t)row * lda);
+        if (mode == 1) ra2[s] = wg_load<NV>(pA2 + (size_t)row * lda2);
+        if (mode == 2) rw[s] = pA2[row];
+        rb[s] = wg_load<KV>(pB + (size_t)row * ldb);
+    };
     auto fetch = [&](int row0) {
 #pragma unroll
-        for (int s = 0; s < WG_STEPS; ++s) {
-            int row = row0 + 2 * s + h;
-            row = row < last ? row : last;
-            ra[s] = wg_load<NV>(pA + (size_t)row * lda);
-            if (mode == 1) ra2[s] = wg_load<NV>(pA2 + (size_t)row * lda2);
-            if (mode == 2) rw[s] = pA2[row];
-            rb[s] = wg_load<KV>(pB + (size_t)row * ldb);
-        }
+        for (int s = 0; s < WG_STEPS; ++s) { fetch1(s, row0); __builtin_amdgcn_sched_barrier(0); }    // issue in slot order
     };
+    // Register ring of WG_STEPS row pairs: slot s is consumed (its 3 loads are the oldest outstanding ones) and
+    // immediately refilled with the pair WG_STEPS further on, so WG_STEPS - 1 pairs are always in flight behind the
+    // MFMAs.  Refills past the end re-read the last row (clamped address) and are masked when consumed.
     fetch(c0);
     for (int row0 = c0; row0 < c1; row0 += 2 * WG_STEPS) {
-        // current batch -> private copies, next batch in flight while the MFMAs of this one run
-        WgVec<NV> ca[WG_STEPS], ca2[WG_STEPS];
-        WgVec<KV> cb[WG_STEPS];
-        float cw[WG_STEPS];
-#pragma unroll
-        for (int s = 0; s < WG_STEPS; ++s) { ca[s] = ra[s]; ca2[s] = ra2[s]; cb[s] = rb[s]; cw[s] = rw[s]; }
-        if (row0 + 2 * WG_STEPS < c1) fetch(row0 + 2 * WG_STEPS);
 #pragma unroll
         for (int s = 0; s < WG_STEPS; ++s) {
             const bool ok = row0 + 2 * s + h < c1;
-            float av[NV];
+            float av[NV], bv[KV];
 #pragma unroll
             for (int b = 0; b < NV; ++b) {
                 float f = 1.0f;
-                if (mode == 1) f = lk_softplus100_grad_from_out(ca2[s].v[b]);
-                if (mode == 2) f = cw[s];
-                av[b] = (ok && nok[b]) ? ca[s].v[b] * f : 0.0f;
+                if (mode == 1) f = lk_softplus100_grad_from_out(ra2[s].v[b]);
+                if (mode == 2) f = rw[s];
+                av[b] = (ok && nok[b]) ? ra[s].v[b] * f : 0.0f;
                 bsum[b] += av[b];
             }
 #pragma unroll
+            for (int b = 0; b < KV; ++b) bv[b] = rb[s].v[b];
+#pragma unroll
             for (int bn = 0; bn < NV; ++bn)
 #pragma unroll
-                for (int bk = 0; bk < KV; ++bk) acc[bn][bk] = lk_mfma(av[bn], cb[s].v[bk], acc[bn][bk]);
+                for (int bk = 0; bk < KV; ++bk) acc[bn][bk] = lk_mfma(av[bn], bv[bk], acc[bn][bk]);
+            fetch1(s, row0 + 2 * WG_STEPS);
+            __builtin_amdgcn_sched_barrier(0);          // keep consume(s) -> refill(s) order: the ring IS the schedule
         }
     }
-    // flush: block (bn, bk), register r of lane (j = lane&31, h): n = n0 + NV*frag_row(r,h) + bn, k = k0 + KV*j + bk
+    if (tile) {        // partial tile [block (bn,bk)][register r][lane] + bias sums: 256-byte coalesced stores
+#pragma unroll
+        for (int bn = 0; bn < NV; ++bn)
+#pragma unroll
+            for (int bk = 0; bk < KV; ++bk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tile[((bn * KV + bk) * 16 + r) * 64 + lane] = acc[bn][bk][r];
+        if (k0 == 0) {
+#pragma unroll
+            for (int b = 0; b < NV; ++b) {
+                const float v = bsum[b] + __shfl_xor(bsum[b], 32);
+                if (h == 0) tile[4 * 16 * 64 + NV * i + b] = v;
+            }
+        }
+        return;
+    }
+    // atomic flush: block (bn, bk), register r of lane (j = lane&31, h): n = n0 + NV*frag_row(r,h) + bn, k = k0 + KV*j + bk
 #pragma unroll
     for (int bn = 0; bn < NV; ++bn)
 #pragma unroll
@@ -446,10 +468,10 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 }
 
 template <int NV, int KV>
-__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int c1, int lane) {
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0>(J, n0, k0, c0, c1, lane);
-    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1>(J, n0, k0, c0, c1, lane);
-    else wgrad_unit<NV, KV, 2>(J, n0, k0, c0, c1, lane);
+__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int c1, int lane, float* tile) {
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0>(J, n0, k0, c0, c1, lane, tile);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1>(J, n0, k0, c0, c1, lane, tile);
+    else wgrad_unit<NV, KV, 2>(J, n0, k0, c0, c1, lane, tile);
 }
 
 __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
@@ -461,10 +483,46 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     const int c0 = (int)blockIdx.y * a.chunk;                          // rows [c0, c1) of the job
     if (c0 >= J.rows) return;                                          // wave-uniform
     const int c1 = (c0 + a.chunk < J.rows) ? c0 + a.chunk : J.rows;
-    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2>(J, U.n0, U.k0, c0, c1, lane);
-    else if (U.nv == 2) wgrad_unit_mode<2, 1>(J, U.n0, U.k0, c0, c1, lane);
-    else if (U.kv == 2) wgrad_unit_mode<1, 2>(J, U.n0, U.k0, c0, c1, lane);
-    else wgrad_unit_mode<1, 1>(J, U.n0, U.k0, c0, c1, lane);
+    float* tile = a.part ? a.part + ((size_t)blockIdx.y * a.n_units + u) * LK_WG_TILE : nullptr;
+    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2>(J, U.n0, U.k0, c0, c1, lane, tile);
+    else if (U.nv == 2) wgrad_unit_mode<2, 1>(J, U.n0, U.k0, c0, c1, lane, tile);
+    else if (U.kv == 2) wgrad_unit_mode<1, 2>(J, U.n0, U.k0, c0, c1, lane, tile);
+    else wgrad_unit_mode<1, 1>(J, U.n0, U.k0, c0, c1, lane, tile);
+}
+
+// dW += sum over row chunks of the partial tiles (tile order: contiguous reads; every output element is owned by
+// exactly one thread, so the read-modify-write of dW needs no atomics and the result is run-to-run reproducible).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
+    __shared__ float sh[8][32];
+    const LkWgradUnit& U = a.unit[blockIdx.x];
+    const LkWgradJob& J = a.job[U.job];
+    const int nv = U.nv, kv = U.kv;
+    // 32 consecutive tile elements x 8 row-block lanes per workgroup
+    const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
+    const int idx = (int)blockIdx.y * 32 + e;
+    const bool in_acc = idx < nv * kv * 1024, in_bias = idx >= 4 * 16 * 64 && idx < 4 * 16 * 64 + 32 * nv;
+    if (!in_acc && !in_bias && (int)blockIdx.y * 32 + 31 >= nv * kv * 1024 && (int)blockIdx.y * 32 < 4 * 16 * 64) return;   // unused blocks of a narrow unit
+    const int nblk = (J.rows + a.chunk - 1) / a.chunk;
+    const size_t stride = (size_t)a.n_units * LK_WG_TILE;
+    const float* __restrict__ src = a.part + (size_t)blockIdx.x * LK_WG_TILE + idx;
+    float s = 0.0f;
+    if (in_acc || in_bias) {
+#pragma unroll 4
+        for (int y = q; y < nblk; y += 8) s += src[(size_t)y * stride];
+    }
+    sh[q][e] = s;
+    __syncthreads();
+    if (q != 0) return;
+    s = ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) + ((sh[4][e] + sh[5][e]) + (sh[6][e] + sh[7][e]));
+    if (in_acc) {
+        const int blk = idx >> 10, r = (idx >> 6) & 15, lane = idx & 63, h = lane >> 5, j = lane & 31;
+        const int bn = blk / kv, bk = blk - bn * kv;
+        const int nn = U.n0 + nv * lk_frag_row(r, h) + bn, k = U.k0 + kv * j + bk;
+        if (nn < J.N && k < J.K) J.dW[(size_t)nn * J.ldw + k] += s;
+    } else if (in_bias) {
+        const int tcol = idx - 4 * 16 * 64;
+        if (J.db && U.k0 == 0 && U.n0 + tcol < J.N) J.db[U.n0 + tcol] += s;
+    }
 }
 
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
@@ -506,10 +564,17 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
             }
         }
     }
-    // rows per wave: enough waves to fill the chip about four deep, never below 64 rows (flush cost)
+    if (a.part) {
+        a.chunk = LK_WG_CHUNK;
+        hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_units, 4), lk_cdiv(max_rows, a.chunk)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(a.n_units, lk_cdiv(LK_WG_TILE, 32)), dim3(256), 0, st, a);
+        return LK_OK;
+    }
+    // atomic flush (no partial buffer): rows per wave for about 4000 waves, never below 64 rows per wave
     if (a.chunk <= 0) {
-        const long long target = 4096 / a.n_units > 0 ? 4096 / a.n_units : 1;
-        long long chunk = (max_rows + target - 1) / target;
+        long long chunks = 4096 / a.n_units;
+        if (chunks < 1) chunks = 1;
+        long long chunk = (max_rows + chunks - 1) / chunks;
         chunk = ((chunk + 15) / 16) * 16;
         a.chunk = (int)(chunk < 64 ? 64 : chunk);
     }

@@ -15,7 +15,7 @@ for (N, K, mode) in ((128, 128, 0), (128, 128, 1), (128, 168, 1), (128, 32, 0), 
     A2 = torch.rand(r, 640 if mode != 2 else 1, device='cuda') * 0.05
     B = torch.randn(r, 640 if K != 52 else 320, device='cuda')
     dW = torch.zeros(N, K + 4, device='cuda'); db = torch.zeros(N, device='cuda')
-    for chunk in (128, 256, 512, 1024):
+    for chunk in [int(c) for c in os.environ.get('CHUNKS', '128,256,512,1024').split(',')]:
         for _ in range(2):
             eng.lib.dll.lk_wgrad_single(ptr(A), lda, mode, ptr(A2), A2.shape[1], ptr(B), B.shape[1], N, K, r, ptr(dW), K + 4, ptr(db), chunk, eng.stream)
         torch.cuda.synchronize()
