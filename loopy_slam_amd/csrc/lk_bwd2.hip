@@ -531,7 +531,7 @@ int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
     return LK_OK;
 }
 int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
-    LkProfScope prof_(LKK_INTERP_BWD, st);
+    LkProfScope prof_(LKK_FEAT_SCATTER, st);
     hipLaunchKernelGGL(k_feat_scatter, dim3(lk_cdiv((long long)a.P * LK_K, 8)), dim3(256), 0, st, a);
     return LK_OK;
 }
@@ -547,7 +547,6 @@ int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
     return LK_OK;
 }
 int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
-    LkProfScope prof_(LKK_WGRAD, st);
     if (a_in.n_jobs == 0 || max_rows <= 0) return LK_OK;
     LkWgradArgs a = a_in;
     // cut every job into (N piece) x (K piece) units of 32 or 64 columns
@@ -566,7 +565,10 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
     }
     if (a.part) {
         a.chunk = LK_WG_CHUNK;
-        hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_units, 4), lk_cdiv(max_rows, a.chunk)), dim3(256), 0, st, a);
+        {
+            LkProfScope prof_(LKK_WGRAD, st);                          // timing scope = k_wgrad alone (as rocprof reports it)
+            hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_units, 4), lk_cdiv(max_rows, a.chunk)), dim3(256), 0, st, a);
+        }
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(a.n_units, lk_cdiv(LK_WG_TILE, 32)), dim3(256), 0, st, a);
         return LK_OK;
     }
@@ -578,6 +580,7 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
         chunk = ((chunk + 15) / 16) * 16;
         a.chunk = (int)(chunk < 64 ? 64 : chunk);
     }
+    LkProfScope prof_(LKK_WGRAD, st);
     hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_units, 4), lk_cdiv(max_rows, a.chunk)), dim3(256), 0, st, a);
     return LK_OK;
 }

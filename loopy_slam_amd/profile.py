@@ -12,7 +12,8 @@ Algorithmic work per unit (DESIGN.md §Kernels states the same figures):
   bytes per SAMPLE POINT
     sample/interpolate  8 x 128 B feature rows per decoder gathered + 128 B written per decoder + 80 B
                         neighbour list/weights/count/z  (the grid candidate scan is extra, not counted)
-    interp bwd          8 x 128 B read-modify-write per decoder (feature-gradient scatter) + 256 B read
+    feature scatter     8 x 128 B read-modify-write per decoder + the gradient rows read (k_feat_scatter)
+    weight gradients    7 984 B of saved rows per sample (colour launch), 6 788 B (rel-pos launch)
 """
 import ctypes as C
 
@@ -47,28 +48,36 @@ class KernelTimer:
 
 
 def work_per_step(b):
-    """kernel -> (bound, algorithmic units per benchmark step, unit, launches per step) for budget b."""
+    """kernel -> dict(flops=, bytes=, launches=) : algorithmic work per benchmark step for budget b (either may be 0:
+    a kernel is priced against the roof that takes longer, flops / MFMA peak or bytes / HBM peak)."""
     Pm, Pt = b.map_rays * S, b.track_rays * S
     n_geo, n_col, n_trk = b.map_geo_iters, b.map_iters - b.map_geo_iters, b.track_iters
     rel = 1 if b.rel_pos else 0
     fl = lambda macs: 2.0 * macs
     feat_rows = 8 * 128
+    # bytes per sample read by the weight-gradient reductions: d h (640) + a (640) + layer inputs h0..h3 (512) + e (40)
+    # + c (32) + h4 (128) + d logit (4) floats; rel-pos launch: 8 neighbour rows x 192 floats + Hbar (128) + d c (32) + 1
+    wg_bytes_col, wg_bytes_rel = 4.0 * (640 + 640 + 512 + 40 + 32 + 128 + 4), 4.0 * (8 * 192 + 128 + 32 + 1)
     w = {
-        'k_decode_fwd': ('mfma', fl(n_geo * Pm * MAC['dec_fwd_geo'] + (n_col * Pm + n_trk * Pt) * (MAC['dec_fwd_geo'] + MAC['dec_fwd_col'])),
-                         'flop', b.map_iters + n_trk),
-        'k_decode_bwd': ('mfma', fl(n_geo * Pm * MAC['dec_bwd_geo'] + n_col * Pm * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col']) +
-                                    n_trk * Pt * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col'] + MAC['dec_bwd_track_extra'])),
-                         'flop', b.map_iters + n_trk),
-        'k_wgrad': ('mfma', fl(n_col * Pm * (MAC['wgrad_col'] + rel * MAC['wgrad_rel'])), 'flop', n_col * (1 + rel)),
-        'k_sample_interp': ('hbm', float(n_geo * Pm * (feat_rows + 128 + 80) + n_col * Pm * ((2 - rel) * (feat_rows + 128) + 80) +
-                                         n_trk * Pt * ((2 - rel) * (feat_rows + 128) + 80)), 'byte', b.map_iters + n_trk),
-        'k_interp_bwd': ('hbm', float(n_geo * Pm * (2 * feat_rows + 256) + n_col * Pm * ((2 - rel) * 2 * feat_rows + 256) +
-                                      n_trk * Pt * (2 * feat_rows + 256)), 'byte', b.map_iters + n_trk),
+        'k_decode_fwd': dict(flops=fl(n_geo * Pm * MAC['dec_fwd_geo'] + (n_col * Pm + n_trk * Pt) * (MAC['dec_fwd_geo'] + MAC['dec_fwd_col'])),
+                             bytes=0.0, launches=b.map_iters + n_trk),
+        'k_decode_bwd': dict(flops=fl(n_geo * Pm * MAC['dec_bwd_geo'] + n_col * Pm * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col']) +
+                                      n_trk * Pt * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col'] + MAC['dec_bwd_track_extra'])),
+                             bytes=0.0, launches=b.map_iters + n_trk),
+        'k_wgrad': dict(flops=fl(n_col * Pm * (MAC['wgrad_col'] + rel * MAC['wgrad_rel'])),
+                        bytes=n_col * Pm * (wg_bytes_col + rel * wg_bytes_rel), launches=n_col * (1 + rel)),
+        'k_sample_interp': dict(flops=0.0, bytes=float(n_geo * Pm * (feat_rows + 128 + 80) + n_col * Pm * ((2 - rel) * (feat_rows + 128) + 80) +
+                                                       n_trk * Pt * ((2 - rel) * (feat_rows + 128) + 80)), launches=b.map_iters + n_trk),
+        # feature-gradient scatter (mapper only): per table 8 x 128 B read-modify-write (+ 8 x 128 B of per-neighbour
+        # gradients read in rel-pos mode, else the 128-B d c row) + 64 B of neighbour ids / weights
+        'k_feat_scatter': dict(flops=0.0, bytes=float(b.map_iters * Pm * (2 * feat_rows + 128 + 64) +
+                                                      n_col * Pm * (2 * feat_rows + (feat_rows if rel else 128))), launches=b.map_iters),
     }
     if rel:
-        w['k_relpos_fwd'] = ('mfma', fl((n_col * Pm + n_trk * Pt) * MAC['rel_fwd']), 'flop', n_col + n_trk)
-        w['k_relpos_bwd'] = ('mfma', fl(n_col * Pm * MAC['rel_bwd'] + n_trk * Pt * (MAC['rel_bwd'] + MAC['rel_bwd_track_extra'])),
-                             'flop', n_col + n_trk)
+        w['k_relpos_fwd'] = dict(flops=fl((n_col * Pm + n_trk * Pt) * MAC['rel_fwd']), bytes=0.0, launches=n_col + n_trk)
+        w['k_relpos_bwd'] = dict(flops=fl(n_col * Pm * MAC['rel_bwd'] + n_trk * Pt * (MAC['rel_bwd'] + MAC['rel_bwd_track_extra'])),
+                                 # mapper: rows [8][192] + d feat [8][32] + Hbar [128] floats written per sample
+                                 bytes=n_col * Pm * 4.0 * (8 * 192 + 8 * 32 + 128), launches=n_col + n_trk)
     return w
 
 
@@ -77,19 +86,22 @@ def dominant_kernel(kstat):
 
 
 def roofline(kstat, budget, kernel):
-    """achieved = algorithmic work of all launches of `kernel` in the timed region / their summed duration."""
+    """achieved = algorithmic work of all launches of `kernel` in the timed region / their summed duration, against the
+    roof (fp32 MFMA or HBM) that bounds this kernel more tightly."""
     k = kstat.get(kernel)
     model = work_per_step(budget).get(kernel)
     if not k or k['total_ms'] <= 0 or model is None:
         return None
-    bound, units, unit, launches = model
-    n_steps = k['calls'] / launches
-    total = units * n_steps
+    n_steps = k['calls'] / model['launches']
     secs = k['total_ms'] * 1e-3
-    if bound == 'mfma':
-        achieved, peak, u = total / secs / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
+    flops, nbytes = model['flops'] * n_steps, model['bytes'] * n_steps
+    t_mfma, t_hbm = flops / (PEAK_F32_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+    out = {'kernel': kernel, 'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'], 'traffic': None}
+    if t_mfma >= t_hbm:
+        out.update(bound='mfma', achieved=flops / secs / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s')
     else:
-        achieved, peak, u = total / secs / 1e9, PEAK_HBM_GBS, 'GB/s'
-    return {'kernel': kernel, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': u, 'frac': achieved / peak,
-            'traffic': None, 'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'],
-            'algorithmic_' + unit + 's_per_launch_avg': total / k['calls']}
+        out.update(bound='hbm', achieved=nbytes / secs / 1e9, peak=PEAK_HBM_GBS, unit='GB/s')
+    out['frac'] = out['achieved'] / out['peak']
+    out['algorithmic_flops_per_launch_avg'] = flops / k['calls']
+    out['algorithmic_bytes_per_launch_avg'] = nbytes / k['calls']
+    return out

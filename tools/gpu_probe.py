@@ -3,7 +3,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from loopy_slam_amd import core, synthetic as syn
+from loopy_slam_amd import core, profile, synthetic as syn
 
 eng = core.Engine()
 print(torch.cuda.get_device_name(0))
@@ -46,4 +46,10 @@ for N in NS:
                 core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
+            if os.environ.get('PROBE_KERNELS'):
+                kt = profile.KernelTimer(eng, '*'); kt.start()
+                for _ in range(n):
+                    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage)
+                torch.cuda.synchronize()
+                print('      ' + '  '.join(f"{k[2:]}={v['total_ms'] / v['calls'] * 1e3:.1f}us" for k, v in kt.stop().items()))
             print(f'  R={R:7d} rel_pos={int(rel)} {stage:8s}: {ms:8.3f} ms  {R/ms/1e3:9.1f} Mrays/s  valid={int(st.valid_ray.sum())} meanhas={float((st.nbr_count>=2).float().mean()):.2f}')
