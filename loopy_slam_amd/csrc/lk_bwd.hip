@@ -189,14 +189,18 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         dh[4 * g + 2] = wo0[g].z * g0 + wo1[g].z * g1 + wo2[g].z * g2;
         dh[4 * g + 3] = wo0[g].w * g0 + wo1[g].w * g1 + wo2[g].w * g2;
     }
-    f32x16 dc[1], de;
-    dc[0] = lk_zero16(); de = lk_zero16();
+    f32x16 dc = lk_zero16(), de = lk_zero16();
     int buf = 0;
+    // weight fragments are fetched one product ahead (lk_frag_prefetch): uv = U_i^T groups of the own units,
+    // wb = the 16 groups of W_i^T for the own output block
+    float4 uv[4], wb[16];
+    lk_frag_prefetch<4>(uv, F + FM19_TR, 1, 4 * w, 0, lane);
+    lk_frag_prefetch<16>(wb, F + FM14_TR, 4, 0, w, lane);
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
         if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dh, live, lane);
-        const float* Utr = F + (i == 0 ? FM15_TR : i == 1 ? FM16_TR : i == 2 ? FM17_TR : i == 3 ? FM18_TR : FM19_TR);
-        lk_gemm_frag<1, 4>(dc, Utr, 1, 4 * w, 0, dh, lane);
+        lk_gemm_regs<4>(dc, uv, dh);
+        if (i > 0) lk_frag_prefetch<4>(uv, F + (i == 1 ? FM15_TR : i == 2 ? FM16_TR : i == 3 ? FM17_TR : FM18_TR), 1, 4 * w, 0, lane);
         const f32x16 av = ct_load32(act_col_a + i * 128 + w * 32, lane);
 #pragma unroll
         for (int q = 0; q < 16; ++q) dy[q] = dh[q] * lk_softplus100_grad_from_out(av[q]);
@@ -206,13 +210,13 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         for (int j = 0; j < 4; ++j) xs[(w * 4 + j) * 64 + lane] = make_float4(dy[4 * j], dy[4 * j + 1], dy[4 * j + 2], dy[4 * j + 3]);
         __syncthreads();
         buf ^= 1;
-        if (i == 4 || i == 2 || i == 1) {
+        if (i >= 1) {
             dh = lk_zero16();
-            lk_gemm_frag_lds<16>(dh, F + (i == 4 ? FM14_TR : i == 2 ? FM12_TR : FM11_TR), 4, 0, w, xs, lane);
-        } else if (i == 3) {
-            dh = lk_zero16();
-            lk_gemm_frag_lds<16>(dh, F + FM13_TR, 6, 0, 2 + w, xs, lane);
-            if (want_p && w < 2) lk_gemm_frag_lds<16>(de, F + FM13_TR, 6, 0, w, xs, lane);
+            lk_gemm_regs_lds<16, 0, 16>(dh, wb, xs, lane);
+            if (i == 3 && want_p && w < 2) lk_gemm_frag_lds<16>(de, F + FM13_TR, 6, 0, w, xs, lane);
+            if (i == 4) lk_frag_prefetch<16>(wb, F + FM13_TR, 6, 0, 2 + w, lane);
+            else if (i == 3) lk_frag_prefetch<16>(wb, F + FM12_TR, 4, 0, w, lane);
+            else if (i == 2) lk_frag_prefetch<16>(wb, F + FM11_TR, 4, 0, w, lane);
         } else {       // i == 0: only the embedding receives gradient
             if (w >= 2) lk_gemm_frag_lds<16>(de, F + FM10_TR, 2, 0, w - 2, xs, lane);
         }
@@ -221,7 +225,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     {
         float4* xs = s_x + buf * (16 * 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xs[(w * 4 + j) * 64 + lane] = make_float4(dc[0][4 * j], dc[0][4 * j + 1], dc[0][4 * j + 2], dc[0][4 * j + 3]);
+        for (int j = 0; j < 4; ++j) xs[(w * 4 + j) * 64 + lane] = make_float4(dc[4 * j], dc[4 * j + 1], dc[4 * j + 2], dc[4 * j + 3]);
         float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;
         if (want_p) {    // e_u = sin(x_u) (u<20) | cos(x_{u-20});  dp_i += de_u * f'(x) * 2 pi * B[i][xi]
             const float* B = W + C_EB;

@@ -192,6 +192,41 @@ __device__ __forceinline__ void lk_gemm_frag_lds(f32x16& acc, const float* __res
     }
 }
 
+// Explicit weight-fragment prefetch.  The compiler schedules an A-operand load right before the MFMAs that use it
+// (minimal registers): with two or three waves per SIMD that exposes an L2 round trip per k-group.  The layer
+// structure offers free slots instead - the weights of the NEXT product do not depend on activations - so they are
+// fetched into registers early (NG x 16 B per lane) and the position is pinned with a scheduling barrier.
+template <int NG>
+__device__ __forceinline__ void lk_frag_prefetch(float4 (&wv)[NG], const float* __restrict__ frag, int NBT, int g0, int nb, int lane) {
+    const float* __restrict__ base = frag + ((size_t)g0 * NBT + nb) * 256 + lane * 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wv[g] = *reinterpret_cast<const float4*>(base + (size_t)g * NBT * 256);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// acc += W[g0..g0+NG) X with the weights already in registers; x = CT tile in registers (NG <= 4 groups of it)
+template <int NG>
+__device__ __forceinline__ void lk_gemm_regs(f32x16& acc, const float4 (&wv)[NG], const f32x16& x) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        acc = lk_mfma(wv[g].x, x[4 * g + 0], acc);
+        acc = lk_mfma(wv[g].y, x[4 * g + 1], acc);
+        acc = lk_mfma(wv[g].z, x[4 * g + 2], acc);
+        acc = lk_mfma(wv[g].w, x[4 * g + 3], acc);
+    }
+}
+// same with the B operand parked in LDS (see lk_gemm_frag_lds); WOFF = first register of wv to use
+template <int NG, int WOFF, int NW>
+__device__ __forceinline__ void lk_gemm_regs_lds(f32x16& acc, const float4 (&wv)[NW], const float4* __restrict__ xs, int lane) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const float4 x = xs[g * 64 + lane];
+        acc = lk_mfma(wv[WOFF + g].x, x.x, acc);
+        acc = lk_mfma(wv[WOFF + g].y, x.y, acc);
+        acc = lk_mfma(wv[WOFF + g].z, x.z, acc);
+        acc = lk_mfma(wv[WOFF + g].w, x.w, acc);
+    }
+}
+
 // sum over the 32 sample columns held by the lanes of one half-wave (lanes with equal lane>>5)
 __device__ __forceinline__ float lk_half_wave_sum(float v) {
     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);

@@ -178,20 +178,6 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
 // LDS as the four float4 register chunks of every lane, [wave][chunk][lane] — the reader of chunk (w', j) is the
 // SAME lane id in every wave (the C/D-row walk of lk_gemm_frag), so writes and reads are both lane-contiguous
 // (conflict-free ds_write/read_b128).  Double-buffered: one barrier per layer.
-// bias + softplus (+ save) + fc_c(c) for the wave's own 32-unit block `w`
-__device__ __forceinline__ void col_layer_finish(f32x16& acc, int w, const float* __restrict__ bias,
-                                                 const float* __restrict__ Ufrag, const float* __restrict__ ubias,
-                                                 const f32x16& c, float* __restrict__ save_a, bool live, int lane) {
-    lk_add_rowvec(acc, bias, w * 32, lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);
-    if (save_a) ct_store_rows32(save_a + w * 32, acc, live, lane);
-    lk_add_rowvec(acc, ubias, w * 32, lane);
-    f32x16 t[1] = {acc};
-    lk_gemm_frag<1, 4>(t, Ufrag, 4, 0, w, c, lane);
-    acc = t[0];
-}
-
 __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
                                               float4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */) {
     const DecSample d = dec_sample(a, tile, lane);
@@ -217,39 +203,63 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
             s_x[buf][(w * 4 + j) * 64 + lane] = make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
         if (save) ct_store_rows32(act_col_h + L * 128 + w * 32, t, live, lane);
     };
-    f32x16 acc[1];
+    // bias + softplus (+ save) + fc_c(c) with prefetched U fragments, for the wave's own 32-unit block
+    auto finish = [&](f32x16& acc, const float* bias, const float4 (&uv)[4], const float* ubias, float* save_a) {
+        lk_add_rowvec(acc, bias, w * 32, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);
+        if (save_a) ct_store_rows32(save_a + w * 32, acc, live, lane);
+        lk_add_rowvec(acc, ubias, w * 32, lane);
+        lk_gemm_regs<4>(acc, uv, cc);
+    };
+    f32x16 acc;
+    float4 wa[5], wb[16], uv[4];      // wa: embedding groups of layers 0 / 3, wb: the 16 hidden groups, uv: fc_c
     // layer 0: 40 -> 128
-    acc[0] = lk_zero16();
-    lk_gemm_frag<1, 4>(acc, F + FM10_FWD, 4, 0, w, e0, lane);
-    lk_gemm_frag<1, 1>(acc, F + FM10_FWD, 4, 4, w, e1, lane);
-    col_layer_finish(acc[0], w, W + C_B0, F + FM15_FWD, W + C_U0 + a64(HC * CF), cc, act_col_a, live, lane);
-    park(acc[0], 0, 0);
+    lk_frag_prefetch<5>(wa, F + FM10_FWD, 4, 0, w, lane);
+    lk_frag_prefetch<4>(uv, F + FM15_FWD, 4, 0, w, lane);
+    acc = lk_zero16();
+    {
+        const float4 (&wa4)[4] = reinterpret_cast<const float4 (&)[4]>(wa);
+        lk_gemm_regs<4>(acc, wa4, e0);
+        const float4 (&wa1)[1] = reinterpret_cast<const float4 (&)[1]>(wa[4]);
+        lk_gemm_regs<1>(acc, wa1, e1);
+    }
+    lk_frag_prefetch<16>(wb, F + FM11_FWD, 4, 0, w, lane);                 // layer 1 weights: in flight during the epilogue
+    finish(acc, W + C_B0, uv, W + C_U0 + a64(HC * CF), act_col_a);
+    park(acc, 0, 0);
+    lk_frag_prefetch<4>(uv, F + FM16_FWD, 4, 0, w, lane);
     __syncthreads();
     // layers 1, 2: 128 -> 128
 #pragma unroll
     for (int L = 1; L <= 2; ++L) {
-        acc[0] = lk_zero16();
-        lk_gemm_frag_lds<16>(acc[0], F + (L == 1 ? FM11_FWD : FM12_FWD), 4, 0, w, s_x[(L - 1) & 1], lane);
-        col_layer_finish(acc[0], w, W + (L == 1 ? C_B1 : C_B2), F + (L == 1 ? FM16_FWD : FM17_FWD),
-                         W + C_U0 + L * C_USTRIDE + a64(HC * CF), cc, act_col_a ? act_col_a + L * 128 : nullptr, live, lane);
-        park(acc[0], L & 1, L);
+        acc = lk_zero16();
+        lk_gemm_regs_lds<16, 0, 16>(acc, wb, s_x[(L - 1) & 1], lane);
+        if (L == 1) lk_frag_prefetch<16>(wb, F + FM12_FWD, 4, 0, w, lane);
+        else { lk_frag_prefetch<5>(wa, F + FM13_FWD, 4, 0, w, lane); lk_frag_prefetch<16>(wb, F + FM13_FWD, 4, 5, w, lane); }
+        finish(acc, W + (L == 1 ? C_B1 : C_B2), uv, W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + L * 128 : nullptr);
+        park(acc, L & 1, L);
+        lk_frag_prefetch<4>(uv, F + (L == 1 ? FM17_FWD : FM18_FWD), 4, 0, w, lane);
         __syncthreads();
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
-    acc[0] = lk_zero16();
-    lk_gemm_frag<1, 4>(acc, F + FM13_FWD, 4, 0, w, e0, lane);
-    lk_gemm_frag<1, 1>(acc, F + FM13_FWD, 4, 4, w, e1, lane);
-    lk_gemm_frag_lds<16>(acc[0], F + FM13_FWD, 4, 5, w, s_x[0], lane);
-    col_layer_finish(acc[0], w, W + C_B3, F + FM18_FWD, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), cc,
-                     act_col_a ? act_col_a + 3 * 128 : nullptr, live, lane);
-    park(acc[0], 1, 3);
+    acc = lk_zero16();
+    {
+        const float4 (&wa4)[4] = reinterpret_cast<const float4 (&)[4]>(wa);
+        lk_gemm_regs<4>(acc, wa4, e0);
+        const float4 (&wa1)[1] = reinterpret_cast<const float4 (&)[1]>(wa[4]);
+        lk_gemm_regs<1>(acc, wa1, e1);
+    }
+    lk_gemm_regs_lds<16, 0, 16>(acc, wb, s_x[0], lane);
+    lk_frag_prefetch<16>(wb, F + FM14_FWD, 4, 0, w, lane);
+    finish(acc, W + C_B3, uv, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 3 * 128 : nullptr);
+    park(acc, 1, 3);
+    lk_frag_prefetch<4>(uv, F + FM19_FWD, 4, 0, w, lane);
     __syncthreads();
     // layer 4
-    acc[0] = lk_zero16();
-    lk_gemm_frag_lds<16>(acc[0], F + FM14_FWD, 4, 0, w, s_x[1], lane);
-    col_layer_finish(acc[0], w, W + C_B4, F + FM19_FWD, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), cc,
-                     act_col_a ? act_col_a + 4 * 128 : nullptr, live, lane);
-    if (save) ct_store_rows32(act_col_h + 4 * 128 + w * 32, acc[0], live, lane);
+    acc = lk_zero16();
+    lk_gemm_regs_lds<16, 0, 16>(acc, wb, s_x[1], lane);
+    finish(acc, W + C_B4, uv, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 4 * 128 : nullptr);
+    if (save) ct_store_rows32(act_col_h + 4 * 128 + w * 32, acc, live, lane);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
@@ -258,7 +268,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + u);
         const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + u);
         const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + u);
-        const float v0 = acc[0][4 * g], v1 = acc[0][4 * g + 1], v2 = acc[0][4 * g + 2], v3 = acc[0][4 * g + 3];
+        const float v0 = acc[4 * g], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
         o0 = fmaf(w0.x, v0, o0); o0 = fmaf(w0.y, v1, o0); o0 = fmaf(w0.z, v2, o0); o0 = fmaf(w0.w, v3, o0);
         o1 = fmaf(w1.x, v0, o1); o1 = fmaf(w1.y, v1, o1); o1 = fmaf(w1.z, v2, o1); o1 = fmaf(w1.w, v3, o1);
         o2 = fmaf(w2.x, v0, o2); o2 = fmaf(w2.y, v1, o2); o2 = fmaf(w2.z, v2, o2); o2 = fmaf(w2.w, v3, o2);
