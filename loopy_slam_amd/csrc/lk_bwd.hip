@@ -345,7 +345,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
 // wave serialise in the memory-side atomic unit): the embedding-matrix gradient is therefore reduced
 // wave -> LDS -> one partial row per workgroup, and summed by k_reduce_partials.
 // Block roles as in k_decode_fwd: the first n_col_blocks workgroups are colour tiles, the rest geometry (4 tiles each).
-__global__ __launch_bounds__(256) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
+__global__ __launch_bounds__(256, 2) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
     __shared__ float4 s_x[2 * 16 * 64];
     __shared__ float s_o[4][3 * 32];
     const int w = (int)threadIdx.x >> 6;
