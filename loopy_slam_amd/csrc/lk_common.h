@@ -87,15 +87,21 @@ __device__ __forceinline__ float lk_fourier_arg(float a0, float a1, float a2, fl
 // for large arguments) made the fused kernel ~400 KB of code, i.e. instruction-cache bound.  These
 // versions are branch-free, a dozen instructions each, and accurate to ~1e-7 ABSOLUTE, which is
 // what matters for O(1) activations (validated against the oracle in tests/).
+// Raw v_exp_f32 / v_log_f32 (base 2, 1 ulp): the libm wrappers add a denormal-range rescue (compare, select, ldexp)
+// around each of them, which doubles the VALU cost of an activation; here the argument of log2 is >= 1 and an
+// underflowing 2^y may flush to 0 (absolute error < 1e-38 on an O(1) activation).
+__device__ __forceinline__ float lk_exp2_raw(float y) { return __builtin_amdgcn_exp2f(y); }
+__device__ __forceinline__ float lk_log2_raw(float y) { return __builtin_amdgcn_logf(y); }
 __device__ __forceinline__ float lk_softplus100(float x) {
     // torch softplus(beta=100, threshold=20): log1p(exp(100x))/100, linear above the threshold.
-    // v_exp_f32 / v_log_f32 (1 ulp relative): |error| <= ~2e-9 absolute on the result.
+    // |error| <= ~2e-9 absolute on the result.
+    // same roundings as exp(t) = 2^(t log2 e) and log(y) = log2(y) ln 2 (the fast-math forms), t = fl(100 x) as in torch
     const float t = 100.0f * x;
-    const float soft = __logf(1.0f + __expf(t)) * 0.01f;
+    const float soft = (lk_log2_raw(1.0f + lk_exp2_raw(t * 1.4426950408889634f)) * 0.6931471805599453f) * 0.01f;
     return t > 20.0f ? x : soft;
 }
 // d softplus100 / dx expressed through the OUTPUT a = softplus100(x): sigmoid(100x) = 1 - exp(-100a)
-__device__ __forceinline__ float lk_softplus100_grad_from_out(float a) { return 1.0f - __expf(-100.0f * a); }
+__device__ __forceinline__ float lk_softplus100_grad_from_out(float a) { return 1.0f - lk_exp2_raw((-100.0f * a) * 1.4426950408889634f); }
 __device__ __forceinline__ float lk_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // sin / cos for |x| < ~1e5: n = rint(x * 2/pi); r = x - n*pi/2 by a 3-term Cody-Waite reduction with

@@ -139,6 +139,8 @@ static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f
     for (int r = 0; r < 4; ++r) d[r] = di[r];
     return d;
 }
+static inline float __builtin_amdgcn_exp2f(float v) { return ::exp2f(v); }
+static inline float __builtin_amdgcn_logf(float v) { return ::log2f(v); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
