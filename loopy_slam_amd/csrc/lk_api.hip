@@ -198,6 +198,24 @@ extern "C" int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t f
     return bwd_layout((int64_t)R * S, flags).total;
 }
 
+// Second stream for the weight-gradient reductions: they only consume what decode_bwd / relpos_bwd saved, so they run
+// beside the rel-pos backward and the feature scatter (fork / join with events; created once per process).
+namespace {
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; bool ok = false; };
+SideStream& side_stream() {
+    static SideStream s;
+    static const bool serial = getenv("LK_SERIAL") != nullptr;     // debugging switch: one stream, clean per-kernel timing
+    if (serial) return s;
+    if (!s.st) {
+        s.ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.mid, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return s;
+}
+}  // namespace
+
 extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     int rc = check_desc(d, "lk_render_bwd");
     if (rc != LK_OK) return rc;
@@ -233,6 +251,14 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     lk_launch_decode_bwd(db, st);
     if (gw) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
+    SideStream& ss = side_stream();
+    const bool forked = gw && color && ss.ok;
+    hipStream_t wst = st;                      // stream of the weight-gradient launches
+    if (forked) {
+        (void)hipEventRecord(ss.fork, st);
+        (void)hipStreamWaitEvent(ss.st, ss.fork, 0);
+        wst = ss.st;
+    }
     if (gw && color) {
         // colour decoder weight gradients as streamed reductions over the saved rows (geometry decoder weights
         // other than embedder._B are frozen in every reference config: mapping.fix_geo_decoder = True)
@@ -267,7 +293,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
         }
         wa.n_jobs = nj; wa.chunk = 0; wa.part = S0 + L.wg_part;
-        lk_launch_wgrad(wa, P, st);
+        lk_launch_wgrad(wa, P, wst);
     }
 
     if (relpos) {
@@ -281,6 +307,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
         rb.dfeat = S0 + L.dfeat;
         rb.part_br = S0 + L.part_br; rb.hbar = S0 + L.hbar; rb.w_sum = S0 + L.w_sum;
         lk_launch_relpos_bwd(rb, st);
+        if (forked) { (void)hipEventRecord(ss.mid, st); (void)hipStreamWaitEvent(wst, ss.mid, 0); }
         if (gw) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
     }
 
@@ -322,9 +349,10 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
             J2.B = S0 + L.hbar; J2.ldb = 128;
             J2.N = CF; J2.K = HC; J2.rows = P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
             wr.n_jobs = 2; wr.chunk = 0; wr.part = S0 + L.wg_part;
-            lk_launch_wgrad(wr, 8 * P, st);
+            lk_launch_wgrad(wr, 8 * P, wst);
         }
     }
+    if (forked) { (void)hipEventRecord(ss.join, wst); (void)hipStreamWaitEvent(st, ss.join, 0); }
     LK_LAUNCH_CHECK();
     return LK_OK;
 }
