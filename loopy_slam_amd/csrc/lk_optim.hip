@@ -114,6 +114,109 @@ __global__ __launch_bounds__(256) void k_loss_tracker_pass2(int R, const float* 
     }
 }
 
+// ------------------------------------------------------------------ one-workgroup forms for training batches
+// R <= LK_LOSS_1WG_MAX rays: a single 1024-thread workgroup owns the whole batch, so the sums need neither atomics
+// nor a zero-fill launch, the tracker's two passes become one kernel, and the result is order-deterministic.
+#define LK_LOSS_1WG_MAX 16384
+__device__ __forceinline__ float block_sum_1024(float v, float* sh /*[16]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lk_lane() == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += sh[i];
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void k_loss_mapper_1wg(int R, const float* __restrict__ depth, const float* __restrict__ color,
+                                                          const uint8_t* __restrict__ valid, const float* __restrict__ gt_depth,
+                                                          const float* __restrict__ gt_color, float w_color, int use_color,
+                                                          float* __restrict__ d_depth, float* __restrict__ d_color,
+                                                          float* __restrict__ out) {
+    __shared__ float sh[16];
+    float geo = 0.0f, col = 0.0f, cnt = 0.0f;
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        const float d = depth[r], g = gt_depth[r];
+        const bool m = (g > 0.0f) && valid[r] && !(d != d);
+        float dd = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
+        if (m) {
+            geo += fabsf(g - d);
+            dd = sgn(d - g);
+            cnt += 1.0f;
+            if (use_color) {
+                const float e0 = color[3 * r] - gt_color[3 * r], e1 = color[3 * r + 1] - gt_color[3 * r + 1],
+                            e2 = color[3 * r + 2] - gt_color[3 * r + 2];
+                col += fabsf(e0) + fabsf(e1) + fabsf(e2);
+                dc0 = w_color * sgn(e0); dc1 = w_color * sgn(e1); dc2 = w_color * sgn(e2);
+            }
+        }
+        d_depth[r] = dd;
+        d_color[3 * r] = dc0; d_color[3 * r + 1] = dc1; d_color[3 * r + 2] = dc2;
+    }
+    geo = block_sum_1024(geo, sh);
+    col = block_sum_1024(col, sh);
+    cnt = block_sum_1024(cnt, sh);
+    if (threadIdx.x == 0) {
+        out[0] = geo + (use_color ? w_color * col : 0.0f);
+        out[1] = geo; out[2] = col; out[3] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_loss_tracker_1wg(int R, const float* __restrict__ depth, const float* __restrict__ var,
+                                                           const float* __restrict__ color, const float* __restrict__ gt_depth,
+                                                           const float* __restrict__ gt_color, float w_color, int use_color,
+                                                           float* __restrict__ d_depth, float* __restrict__ d_color,
+                                                           float* __restrict__ out) {
+    __shared__ float sh[16];
+    constexpr int VPT = LK_LOSS_1WG_MAX / 1024;
+    float tv[VPT];
+    float tsum = 0.0f, csum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+        const int r = (int)threadIdx.x + 1024 * q;
+        tv[q] = 0.0f;
+        if (r < R) {
+            const bool present = gt_depth[r] > 0.0f;     // absent rays take no part in the mean (see pass1 above)
+            tv[q] = present ? fabsf(gt_depth[r] - depth[r]) / sqrtf(var[r] + 1e-10f) : 0.0f;
+            tsum += tv[q];
+            csum += present ? 1.0f : 0.0f;
+        }
+    }
+    tsum = block_sum_1024(tsum, sh);
+    csum = block_sum_1024(csum, sh);
+    const float thr = 10.0f * (tsum / fmaxf(csum, 1.0f));
+    float geo = 0.0f, col = 0.0f, cnt = 0.0f;
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+        const int r = (int)threadIdx.x + 1024 * q;
+        if (r < R) {
+            const float d = depth[r], v = var[r], g = gt_depth[r], t = tv[q];
+            const bool m = (t < thr) && (g > 0.0f) && !(d != d) && !(v != v);
+            float dd = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
+            if (m) {
+                geo += fminf(fmaxf(t, 0.0f), 1e3f);
+                if (t <= 1e3f) dd = sgn(d - g) / sqrtf(v + 1e-10f);
+                cnt += 1.0f;
+                const float e0 = color[3 * r] - gt_color[3 * r], e1 = color[3 * r + 1] - gt_color[3 * r + 1],
+                            e2 = color[3 * r + 2] - gt_color[3 * r + 2];
+                col += fabsf(e0) + fabsf(e1) + fabsf(e2);
+                if (use_color) { dc0 = w_color * sgn(e0); dc1 = w_color * sgn(e1); dc2 = w_color * sgn(e2); }
+            }
+            d_depth[r] = dd;
+            d_color[3 * r] = dc0; d_color[3 * r + 1] = dc1; d_color[3 * r + 2] = dc2;
+        }
+    }
+    geo = block_sum_1024(geo, sh);
+    col = block_sum_1024(col, sh);
+    cnt = block_sum_1024(cnt, sh);
+    if (threadIdx.x == 0) {
+        out[0] = geo + (use_color ? w_color * col : 0.0f);
+        out[1] = geo; out[2] = col; out[3] = cnt;
+    }
+}
+
 // ------------------------------------------------------------------ Adam
 struct AdamSegDev {
     float* p; float* g; float* m; float* v; long long n; float step_size, bc2_sqrt;
@@ -239,19 +342,37 @@ __global__ __launch_bounds__(1024) void k_compact(const uint8_t* __restrict__ ma
 }
 
 // ------------------------------------------------------------------ inside mask: thr = min(10*median(d>0), 1.2*max)
+// Median = 4-pass radix select over the bit patterns of the positive depths (single 1024-thread workgroup).
+// REG = true (n <= LK_MASK_REG_MAX): the values stay in registers between the passes; otherwise they are re-read from
+// `scratch`.  The top byte of a depth takes a handful of values, so in the first pass the histogram is built with
+// one LDS add per (wave, distinct byte) instead of one same-address add per ray.
+#define LK_MASK_REG_MAX 8192
+template <bool REG>
 __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n, uint8_t* __restrict__ mask, float* depth_filtered,
                                                       float* __restrict__ out_thr, uint32_t* __restrict__ scratch) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_rank, s_cnt, s_maxbits;
-    const int t = threadIdx.x;
+    constexpr int VPT = LK_MASK_REG_MAX / 1024;
+    const int t = threadIdx.x, lane = t & 63;
     if (t == 0) { s_cnt = 0; s_maxbits = 0; }
     __syncthreads();
+    unsigned u[VPT];
     unsigned mycnt = 0, mymax = 0;
-    for (int i = t; i < n; i += 1024) {
-        const float d = depth[i];
-        const unsigned u = (d > 0.0f) ? __float_as_uint(d) : 0u;     // positive floats order like their bit patterns
-        scratch[i] = u;
-        if (u) { ++mycnt; mymax = max(mymax, u); }
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int i = t + 1024 * q;
+            const float d = (i < n) ? depth[i] : 0.0f;
+            u[q] = (d > 0.0f) ? __float_as_uint(d) : 0u;            // positive floats order like their bit patterns
+            if (u[q]) { ++mycnt; mymax = max(mymax, u[q]); }
+        }
+    } else {
+        for (int i = t; i < n; i += 1024) {
+            const float d = depth[i];
+            const unsigned v = (d > 0.0f) ? __float_as_uint(d) : 0u;
+            scratch[i] = v;
+            if (v) { ++mycnt; mymax = max(mymax, v); }
+        }
     }
     atomicAdd(&s_cnt, mycnt);
     atomicMax(&s_maxbits, mymax);
@@ -269,9 +390,29 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
         __syncthreads();
         const unsigned prefix = s_prefix;
         const unsigned himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
-        for (int i = t; i < n; i += 1024) {
-            const unsigned u = scratch[i];
-            if (u && (u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        if (REG) {
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) {
+                const bool on = u[q] && (u[q] & himask) == prefix;
+                const unsigned digit = (u[q] >> shift) & 255u;
+                if (shift == 24) {      // all lanes walk the loop together (wave-uniform trip count)
+                    unsigned long long pending = __ballot(on);
+                    while (pending) {
+                        const int leader = __ffsll((long long)pending) - 1;
+                        const unsigned dl = __shfl(digit, leader);
+                        const unsigned long long same = __ballot(on && digit == dl);
+                        if (lane == leader) atomicAdd(&hist[dl], (unsigned)__popcll(same));
+                        pending &= ~same;
+                    }
+                } else if (on) {
+                    atomicAdd(&hist[digit], 1u);
+                }
+            }
+        } else {
+            for (int i = t; i < n; i += 1024) {
+                const unsigned v = scratch[i];
+                if (v && (v & himask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
         // locate the bin that holds the wanted rank: wave 0 scans the 256-bin histogram (4 bins per lane)
@@ -298,11 +439,24 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
     const float med = __uint_as_float(s_prefix);
     const float mx = __uint_as_float(s_maxbits);
     const float thr = fminf(10.0f * med, 1.2f * mx);
-    for (int i = t; i < n; i += 1024) {
-        const float d = depth[i];
-        const bool in = d > 0.0f && d <= thr;
-        if (mask) mask[i] = in ? 1 : 0;
-        if (depth_filtered) depth_filtered[i] = in ? d : 0.0f;      // rejected rays become "absent" (gt_depth = 0)
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            const int i = t + 1024 * q;
+            if (i < n) {
+                const float d = __uint_as_float(u[q]);                  // 0 for non-positive depths
+                const bool in = u[q] && d <= thr;
+                if (mask) mask[i] = in ? 1 : 0;
+                if (depth_filtered) depth_filtered[i] = in ? d : 0.0f;  // rejected rays become "absent" (gt_depth = 0)
+            }
+        }
+    } else {
+        for (int i = t; i < n; i += 1024) {
+            const float d = depth[i];
+            const bool in = d > 0.0f && d <= thr;
+            if (mask) mask[i] = in ? 1 : 0;
+            if (depth_filtered) depth_filtered[i] = in ? d : 0.0f;
+        }
     }
     if (t == 0) *out_thr = thr;
 }
@@ -313,9 +467,15 @@ extern "C" int lk_loss_mapper(int32_t R, const float* depth, const float* color,
                               float* d_depth, float* d_color, float* out_loss, void* stream_) {
     LK_REQUIRE(R >= 0 && out_loss, "lk_loss_mapper: bad arguments");
     hipStream_t st = (hipStream_t)stream_;
+    LK_REQUIRE(R == 0 || (depth && color && valid_ray && gt_depth && gt_color && d_depth && d_color), "lk_loss_mapper: NULL buffer");
+    if (R > 0 && R <= LK_LOSS_1WG_MAX) {
+        hipLaunchKernelGGL(k_loss_mapper_1wg, dim3(1), dim3(1024), 0, st, (int)R, depth, color, valid_ray, gt_depth, gt_color,
+                           w_color, (int)use_color, d_depth, d_color, out_loss);
+        LK_LAUNCH_CHECK();
+        return LK_OK;
+    }
     LK_HIP_TRY(hipMemsetAsync(out_loss, 0, 4 * sizeof(float), st));
     if (R == 0) return LK_OK;
-    LK_REQUIRE(depth && color && valid_ray && gt_depth && gt_color && d_depth && d_color, "lk_loss_mapper: NULL buffer");
     hipLaunchKernelGGL(k_loss_mapper, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, color, valid_ray, gt_depth,
                        gt_color, w_color, (int)use_color, d_depth, d_color, out_loss);
     LK_LAUNCH_CHECK();
@@ -327,9 +487,15 @@ extern "C" int lk_loss_tracker(int32_t R, const float* depth, const float* var, 
                                float* d_depth, float* d_color, float* out_loss, float* scratch, void* stream_) {
     LK_REQUIRE(R >= 0 && out_loss && scratch, "lk_loss_tracker: bad arguments");
     hipStream_t st = (hipStream_t)stream_;
+    LK_REQUIRE(R == 0 || (depth && var && color && gt_depth && gt_color && d_depth && d_color), "lk_loss_tracker: NULL buffer");
+    if (R > 0 && R <= LK_LOSS_1WG_MAX) {
+        hipLaunchKernelGGL(k_loss_tracker_1wg, dim3(1), dim3(1024), 0, st, (int)R, depth, var, color, gt_depth, gt_color,
+                           w_color, (int)use_color, d_depth, d_color, out_loss);
+        LK_LAUNCH_CHECK();
+        return LK_OK;
+    }
     LK_HIP_TRY(hipMemsetAsync(out_loss, 0, 4 * sizeof(float), st));
     if (R == 0) return LK_OK;
-    LK_REQUIRE(depth && var && color && gt_depth && gt_color && d_depth && d_color, "lk_loss_tracker: NULL buffer");
     LK_HIP_TRY(hipMemsetAsync(scratch + R, 0, 2 * sizeof(float), st));
     hipLaunchKernelGGL(k_loss_tracker_pass1, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, gt_depth, scratch);
     hipLaunchKernelGGL(k_loss_tracker_pass2, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, color, gt_depth,
@@ -401,7 +567,10 @@ extern "C" int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, floa
     LK_REQUIRE(n >= 0 && out_thr, "lk_inside_mask: bad arguments");
     if (n == 0) return LK_OK;
     LK_REQUIRE(depth && scratch && (mask || depth_filtered), "lk_inside_mask: NULL buffer");
-    hipLaunchKernelGGL(k_inside_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream_, depth, (int)n, mask, depth_filtered, out_thr, scratch);
+    if (n <= LK_MASK_REG_MAX)
+        hipLaunchKernelGGL((k_inside_mask<true>), dim3(1), dim3(1024), 0, (hipStream_t)stream_, depth, (int)n, mask, depth_filtered, out_thr, scratch);
+    else
+        hipLaunchKernelGGL((k_inside_mask<false>), dim3(1), dim3(1024), 0, (hipStream_t)stream_, depth, (int)n, mask, depth_filtered, out_thr, scratch);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

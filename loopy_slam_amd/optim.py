@@ -95,3 +95,4 @@ def gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, w
                                              ptr(out['rays_o']), ptr(out['rays_d']), ptr(out['gt_depth']), ptr(out['gt_color']),
                                              ptr(out.get('pix_i')), ptr(out.get('pix_j')), ptr(out.get('r2_ray')), eng.stream),
                   'lk_gather_rays')
+

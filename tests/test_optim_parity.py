@@ -68,6 +68,44 @@ def test_loss_tracker(backend):
 
 
 @pytest.mark.parametrize('backend', backends())
+def test_losses_large_batch(backend):
+    """Above 16 384 rays the losses take the multi-workgroup (atomic) kernels: synthetic 20 000-ray batch, absent rays
+    (gt_depth 0), invalid rays and a NaN depth, against the oracle."""
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(11)
+    R = 20000
+    gd = torch.rand(R, generator=gen) * 3 + 0.5
+    gd[torch.rand(R, generator=gen) < 0.05] = 0.0
+    depth = gd + 0.05 * torch.randn(R, generator=gen)
+    depth[7] = float('nan')
+    var = torch.rand(R, generator=gen) * 0.01 + 1e-4
+    color, gc = torch.rand(R, 3, generator=gen), torch.rand(R, 3, generator=gen)
+    valid = torch.rand(R, generator=gen) < 0.9
+    st = _fake_state(eng, depth, var, color, valid)
+    dd, dc, out, scr = eng.empty(R), eng.empty(R, 3), eng.empty(4), eng.empty(R + 8)
+    optim.loss_mapper(eng, st, eng.f32(gd), eng.f32(gc), 0.1, True, dd, dc, out)
+    dl, cl = depth.clone().requires_grad_(True), color.clone().requires_grad_(True)
+    loss, geo, col, m = H.mapper_loss(dl, cl, valid, gd, gc, 'color', 0.1)
+    loss.backward()
+    o = out.cpu().numpy()
+    assert abs(o[0] - loss.item()) <= 2e-5 * abs(loss.item()) and o[3] == int(m.sum())
+    np.testing.assert_allclose(dd.cpu().numpy(), torch.nan_to_num(dl.grad).numpy(), atol=0)
+    np.testing.assert_allclose(dc.cpu().numpy(), cl.grad.numpy(), atol=1e-7)
+    # tracker: the reference never sees absent rays (filtered before rendering) -> compare on the present ones
+    keep = gd > 0
+    depth2 = torch.nan_to_num(depth, nan=1.0)
+    st2 = _fake_state(eng, depth2, var, color, torch.ones(R, dtype=torch.bool))
+    optim.loss_tracker(eng, st2, eng.f32(gd), eng.f32(gc), 0.5, True, dd, dc, out, scr)
+    dl, cl = depth2[keep].clone().requires_grad_(True), color[keep].clone().requires_grad_(True)
+    loss, geo, col, m = H.tracker_loss(dl, var[keep], cl, gd[keep], gc[keep], 0.5)
+    loss.backward()
+    o = out.cpu().numpy()
+    assert abs(o[0] - loss.item()) <= 2e-5 * abs(loss.item()) and o[3] == int(m.sum())
+    np.testing.assert_allclose(dd.cpu().numpy()[keep.numpy()], dl.grad.numpy(), rtol=1e-6, atol=1e-7)
+    assert float(dd.cpu()[~keep].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('backend', backends())
 def test_adam_matches_torch_trajectory(backend):
     """G8: 20 steps, 3 tensors, lr switch geometry->colour, a tensor without gradient in stage 1."""
     eng = make_engine(backend)
@@ -130,3 +168,4 @@ def test_inside_mask_and_compact(backend):
         k = int(cnt.cpu())
         assert k == int(ref_mask.sum())
         assert np.array_equal(idx.cpu().numpy()[:k], torch.nonzero(ref_mask).reshape(-1).numpy())
+
