@@ -200,6 +200,25 @@ int lk_pose_bwd(const float* cam7, const float* pix_i, const float* pix_j, int32
                 float* g_cam7, void* stream);
 /* Stable stream compaction (wave ballot + prefix sum): out_index[0..count) = i with mask[i]!=0. */
 int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, void* stream);
+/* ---------------------------------------------------------------- map maintenance around the hot loop
+ * Frustum row selection, Mapper.get_mask_from_c2w (src/Mapper.py:165-217): out_index[0..*out_count) = ascending indices
+ * of the points of pos[N,3] that project inside the image of the pose (cropped by `edge` pixels, negative = enlarged)
+ * and lie no more than 0.5 m behind the observed depth (bilinear lookup as cv2.remap INTER_LINEAR / constant 0 border;
+ * zero lookups are replaced by the largest lookup).  w2c12_host = rows 0..2 of inv(c2w) (HOST pointer, 12 floats;
+ * the projection itself runs in float64 like the reference's numpy code).  Scratch: float[N], uint8[N], uint32[1]. */
+int lk_frustum_rows(const float* pos, int32_t N, const float* w2c12_host, const float* depth, int32_t H, int32_t W,
+                    float fx, float fy, float cx, float cy, int32_t edge, float* scratch_depth, uint8_t* scratch_mask,
+                    uint32_t* scratch_max, int32_t* out_index, int32_t* out_count, void* stream);
+/* Point insertion, geometry part of NeuralPointCloud.add_neural_points (src/neural_point.py:1557-1631): a ray with
+ * gt_depth > 0 is accepted iff NO point of the index `knn` (NULL or empty: accept all) lies at squared distance
+ * < r2 (r2_per_ray[i] if given, else r2_static) from o + d*gt_depth; accepted ray j (ascending ray order) emits n_add
+ * points o + d*z, z = linspace(near_surface*depth, far_surface*depth, n_add), at out_points[(j*n_add + q)*3].
+ * out_ray_index[0..*out_count) = accepted rays; out_points must hold 3*n_add*n floats.  Rays of one call are not
+ * de-duplicated against each other (as in the reference).  Feature rows of the new points are the caller's
+ * (N(0, 0.1), neural_point.py:1614-1617), followed by lk_knn_build on the grown cloud. */
+int lk_add_points(lk_knn_t knn, const float* rays_o, const float* rays_d, const float* gt_depth, int32_t n,
+                  float r2_static, const float* r2_per_ray, float near_surface, float far_surface, int32_t n_add,
+                  uint8_t* scratch_mask, int32_t* out_ray_index, int32_t* out_count, float* out_points, void* stream);
 /* thr = min(10*median(depth), 1.2*max(depth)) over depth>0 (Tracker.py:153-155, Mapper.py:674-676);
  * mask[i] = depth[i] > 0 && depth[i] <= thr (mask may be NULL); depth_filtered[i] = mask ? depth : 0 (may be
  * NULL or alias depth): a ray with gt_depth 0 is "absent" for the losses, which keeps the batch shape static

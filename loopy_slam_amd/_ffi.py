@@ -100,6 +100,10 @@ class LoopyLib:
             ('lk_gather_rays', [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                 C.c_void_p], C.c_int),
+            ('lk_frustum_rows', [_fp, C.c_int32, C.POINTER(C.c_float), _fp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_add_points', [C.c_void_p, _fp, _fp, _fp, C.c_int32, C.c_float, _fp, C.c_float, C.c_float, C.c_int32,
+                               _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_wgrad_single', [_fp, C.c_int32, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                  _fp, C.c_int32, _fp, C.c_int32, C.c_void_p], C.c_int),
             ('lk_profile_begin', [C.c_char_p], C.c_int),

@@ -554,6 +554,66 @@ extern "C" int lk_pose_bwd(const float* cam7, const float* pix_i, const float* p
     return LK_OK;
 }
 
+// ------------------------------------------------------------------ stable compaction, many blocks (n up to millions)
+// counts per 256-element block -> exclusive scan of the block counts (one workgroup) -> every block re-derives its
+// local ranks with ballots and writes its indices behind its offset.  block_scratch: ceil(n / 256) ints.
+__global__ __launch_bounds__(256) void k_compact_count(const uint8_t* __restrict__ mask, int n, int32_t* __restrict__ block_count) {
+    __shared__ int wc[4];
+    const int i = blockIdx.x * 256 + (int)threadIdx.x;
+    const unsigned long long b = __ballot(i < n && mask[i] != 0);
+    if (lk_lane() == 0) wc[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+__global__ __launch_bounds__(1024) void k_compact_scan(int32_t* __restrict__ block_count, int nb, int32_t* __restrict__ out_count) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nb; c0 += 1024) {
+        const int i = c0 + t;
+        const int v = (i < nb) ? block_count[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int nv = __shfl_up(incl, o); if (lane >= o) incl += nv; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int base = carry;
+        for (int q = 0; q < w; ++q) base += wsum[q];
+        if (i < nb) block_count[i] = base + incl - v;           // exclusive offset of block i
+        __syncthreads();
+        if (t == 1023) carry = base + incl;
+        __syncthreads();
+    }
+    if (t == 0) *out_count = carry;
+}
+__global__ __launch_bounds__(256) void k_compact_scatter(const uint8_t* __restrict__ mask, int n, const int32_t* __restrict__ block_off,
+                                                         int32_t* __restrict__ out_index) {
+    __shared__ int wc[4];
+    const int i = blockIdx.x * 256 + (int)threadIdx.x, lane = lk_lane(), w = (int)threadIdx.x >> 6;
+    const bool keep = i < n && mask[i] != 0;
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) wc[w] = __popcll(b);
+    __syncthreads();
+    int off = block_off[blockIdx.x];
+    for (int q = 0; q < w; ++q) off += wc[q];
+    if (keep) out_index[off + __popcll(b & ((1ull << lane) - 1ull))] = i;
+}
+
+int lk_launch_compact_mb(const uint8_t* mask, int n, int32_t* out_index, int32_t* out_count, int32_t* block_scratch, hipStream_t st) {
+    const int nb = lk_cdiv(n, 256);
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, st, mask, n, block_scratch);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, block_scratch, nb, out_count);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(256), 0, st, mask, n, (const int32_t*)block_scratch, out_index);
+    return LK_OK;
+}
+
+int lk_launch_compact(const uint8_t* mask, int n, int32_t* out_index, int32_t* out_count, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, mask, n, out_index, out_count);
+    return LK_OK;
+}
+
 extern "C" int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, void* stream_) {
     LK_REQUIRE(n >= 0 && out_count, "lk_compact: bad arguments");
     LK_REQUIRE(n == 0 || (mask && out_index), "lk_compact: NULL buffer");

@@ -96,3 +96,39 @@ def gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, w
                                              ptr(out.get('pix_i')), ptr(out.get('pix_j')), ptr(out.get('r2_ray')), eng.stream),
                   'lk_gather_rays')
 
+
+def frustum_rows(eng, pos, c2w, depth, intr, H, W, edge):
+    """Mapper.get_mask_from_c2w on the device (lk_frustum_rows): int32 tensor of the selected row indices, ascending.
+    One host sync (the count) - once per mapped frame."""
+    import numpy as np
+    fx, fy, cx, cy = intr
+    N = pos.shape[0]
+    w2c = np.linalg.inv(c2w.detach().cpu().numpy().astype(np.float32)).astype(np.float32)     # float32 like the reference
+    w12 = (C.c_float * 12)(*[float(x) for x in w2c[:3, :4].reshape(-1)])
+    out = eng.empty(max(N, 1), dtype=torch.int32)
+    cnt = eng.empty(1, dtype=torch.int32)
+    sd = eng.empty(max(N, 1))
+    sm = eng.empty(max(N, 1), dtype=torch.uint8)
+    smax = eng.empty(1, dtype=torch.int32)
+    eng.lib.check(eng.lib.dll.lk_frustum_rows(ptr(pos), N, w12, ptr(depth), H, W, C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                              C.c_float(cy), int(edge), ptr(sd), ptr(sm), ptr(smax), ptr(out), ptr(cnt),
+                                              eng.stream), 'lk_frustum_rows')
+    return out[:int(cnt.item())]
+
+
+def add_points(eng, knn, rays_o, rays_d, gt_depth, r2, near_surface, far_surface, n_add=3):
+    """Geometry part of NeuralPointCloud.add_neural_points (lk_add_points): (accepted ray indices int32 [k], new points
+    [k*n_add, 3]).  knn may be None / empty (first frame).  One host sync (the count)."""
+    n = gt_depth.shape[0]
+    per = r2.contiguous() if torch.is_tensor(r2) else None
+    mask = eng.empty(max(n, 1), dtype=torch.uint8)
+    idx = eng.empty(max(n, 1), dtype=torch.int32)
+    cnt = eng.empty(1, dtype=torch.int32)
+    pts = eng.empty(max(n, 1) * n_add, 3)
+    h = knn.h if knn is not None else None
+    eng.lib.check(eng.lib.dll.lk_add_points(h, ptr(rays_o.contiguous()), ptr(rays_d.contiguous()), ptr(gt_depth.contiguous()), n,
+                                            C.c_float(0.0 if per is not None else float(r2)), ptr(per), C.c_float(near_surface),
+                                            C.c_float(far_surface), n_add, ptr(mask), ptr(idx), ptr(cnt), ptr(pts), eng.stream),
+                  'lk_add_points')
+    k = int(cnt.item())
+    return idx[:k], pts[:k * n_add]

@@ -243,20 +243,19 @@ class NeuralPointCloud:
                           dynamic_radius=None, idx=None, gt_color=None, gt_depth=None, cur_c2w=None, gt_camera=None):
         if batch_rays_o.shape[0] == 0:
             return 0
-        m = batch_gt_depth > 0
-        ro, rd, gd, gc = batch_rays_o[m], batch_rays_d[m], batch_gt_depth[m], batch_gt_color[m] * 255
-        dyn = dynamic_radius[m] if dynamic_radius is not None else None
-        pts_gt = ro + rd * gd[:, None]
-        keep = torch.ones(pts_gt.shape[0], dtype=torch.bool, device=pts_gt.device)
-        if self.n > 0:
-            _, _, cnt = self.find_neighbors_faiss(pts_gt, step='add', is_pts_grad=is_pts_grad, dynamic_radius=dyn)
-            keep = cnt == 0
-        self._input_pos.append(pts_gt[keep])
-        self._input_rgb.append(gc[keep])
-        t = torch.linspace(0.0, 1.0, steps=self.N_add, device=gd.device)
-        g3 = gd[:, None].repeat(1, self.N_add)
-        z = self.near_end_surface * g3 * (1. - t) + self.far_end_surface * g3 * t
-        pts = (ro[:, None, :] + rd[:, None, :] * z[:, :, None])[keep].reshape(-1, 3)
+        ro, rd, gd = batch_rays_o.float().contiguous(), batch_rays_d.float().contiguous(), batch_gt_depth.float().contiguous()
+        radius = self.radius_min if is_pts_grad else self.radius_add
+        if dynamic_radius is not None and dynamic_radius.numel() == gd.shape[0]:
+            r2 = (dynamic_radius.reshape(-1).double() ** 2).float().contiguous()
+        else:
+            r2 = float(np.float32(radius ** 2))
+        # radius test against the existing cloud, compaction and the N_add points per accepted ray: lk_add_points
+        acc, pts = optim.add_points(self.eng, self.knn if self.n > 0 else None, ro, rd, gd, r2, self.near_end_surface,
+                                    self.far_end_surface, self.N_add)
+        accl = acc.long()
+        self._input_pos.append(ro[accl] + rd[accl] * gd[accl, None])
+        self._input_rgb.append(batch_gt_color[accl] * 255)
+        n_acc = acc.shape[0]
         k = pts.shape[0]
         if k:
             self._grow(self.n + k)
@@ -265,7 +264,7 @@ class NeuralPointCloud:
             self._col[self.n:self.n + k] = (torch.randn(k, 32, generator=self._gen) * 0.1).to(self.eng.device)
             self.n += k
             self.knn.build(self._pos[:self.n])             # counting-sort rebuild on the device (no IVF re-training)
-        return int(keep.sum())
+        return n_acc
 
 
 # ============================================================================================ Renderer
@@ -370,18 +369,9 @@ class Mapper:
 
     # -- frustum feature selection (Mapper.py:165-217): project every point, bilinear depth lookup, z test
     def get_mask_from_c2w(self, c2w, depth):
-        pts = self.npc.cloud_pos()
-        w2c = torch.linalg.inv(c2w.double()).float().to(pts.device)
-        cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
-        x, y, zc = -cam[:, 0], cam[:, 1], cam[:, 2]                 # cam_cord[:, 0] *= -1
-        z = zc + 1e-5
-        u = (self.fx * x + self.cx * zc) / z
-        v = (self.fy * y + self.cy * zc) / z
-        d = _bilinear_zero_border(depth, u, v)
-        d = torch.where(d == 0, d.max(), d)
-        e = self.frustum_edge
-        mask = (u < self.W - e) & (u > e) & (v < self.H - e) & (v > e) & (0 <= -z) & (-z <= d + 0.5)
-        return torch.nonzero(mask).reshape(-1).to(torch.int32)
+        """Frustum feature selection (Mapper.py:165-217) on the device: lk_frustum_rows."""
+        return optim.frustum_rows(self.eng, self.npc.cloud_pos(), c2w, depth.float().contiguous(), (self.fx, self.fy, self.cx, self.cy),
+                                  self.H, self.W, self.frustum_edge)
 
     def filter_point_before_add(self, rays_o, rays_d, gt_depth, prev_c2w):
         pts = rays_o + rays_d * gt_depth[:, None]
@@ -479,20 +469,6 @@ class Mapper:
 
     def run(self, time_string=None):
         raise NotImplementedError('Point_SLAM.run drives map_frame / track_frame in one process')
-
-
-def _bilinear_zero_border(img, u, v):
-    """cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) at float pixel coordinates (u = column, v = row)."""
-    H, W = img.shape
-    u0, v0 = torch.floor(u), torch.floor(v)
-    fu, fv = u - u0, v - v0
-    out = torch.zeros_like(u)
-    for du, dv, wgt in ((0, 0, (1 - fu) * (1 - fv)), (1, 0, fu * (1 - fv)), (0, 1, (1 - fu) * fv), (1, 1, fu * fv)):
-        uu, vv = (u0 + du).long(), (v0 + dv).long()
-        ok = (uu >= 0) & (uu < W) & (vv >= 0) & (vv < H)
-        val = img[vv.clamp(0, H - 1), uu.clamp(0, W - 1)]
-        out = out + torch.where(ok, val * wgt, torch.zeros_like(val))
-    return out
 
 
 # ============================================================================================ Tracker

@@ -115,6 +115,13 @@ class MapOptimizer:
             self.loss_log = self.eng.zeros(4)
         return self.loss_log
 
+    def new_frame(self, row_index):
+        """Start of an optimize_map call: the frustum rows of the new frame (Mapper.py:498-512), a fresh Adam
+        (Mapper.py:570) and clean gradient tables."""
+        self.rows = row_index
+        self.adam = optim.Adam(self.eng)
+        self.gs.zero_()
+
     def begin_frame(self):
         """Gradient tables start from zero; rows outside `row_index` may collect (never consumed) scatter
         contributions during the frame, so clear the full tables once per optimize_map call."""

@@ -11,7 +11,7 @@ from dataclasses import dataclass
 
 import torch
 
-from . import core, steps, synthetic as syn
+from . import core, optim, steps, synthetic as syn
 from .common import get_tensor_from_camera
 
 
@@ -28,6 +28,7 @@ class Budget:
     ignore_edge: int = 100                # tracking.ignore_edge_W/H on Replica (scaled image: see below)
     cam_lr: float = 0.002
     rel_pos: bool = True
+    frustum_edge: int = -4                # mapping.frustum_edge (configs/point_slam.yaml:67)
 
     @property
     def rays_per_frame(self):
@@ -61,8 +62,9 @@ class FrameWorkload:
         self.color_stack = torch.stack(cs).contiguous()
         self.c2w_stack = torch.stack(ps).contiguous()
         self.frames = (self.depth_stack, self.color_stack, self.c2w_stack, None)
-        # frustum row selection stand-in: all rows (the frustum test itself is a §8f 'next' row)
-        self.rows = torch.arange(b.n_points, dtype=torch.int32, device=dev)
+        # rows optimised by the mapper = frustum selection of the frame being mapped (Mapper.py:165-217, 498-512),
+        # recomputed at every step like the reference does at every optimize_map call
+        self.rows = optim.frustum_rows(eng, self.pos, self.c2w_stack[0], self.depth_stack[0], self.intr, self.H, self.W, b.frustum_edge)
         self.mapper = steps.MapOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col, self.rows,
                                          b.map_rays, MAP_LRS, w_color=0.1, dist=dist)
         self.tracker = steps.TrackOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col,
@@ -86,7 +88,8 @@ class FrameWorkload:
         best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win, self.intr, rnd_t)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
         fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(eng.device)      # pixels // window frames each
-        self.mapper.begin_frame()
+        self.rows = optim.frustum_rows(eng, self.pos, self.c2w_stack[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge)
+        self.mapper.new_frame(self.rows)
         for it in range(b.map_iters):
             stage = 'geometry' if it < b.map_geo_iters else 'color'
             self.mapper.iterate(stage, self.frames, rnd_m[it], fid, (0, H, 0, W), self.intr, H, W, log_row=self.map_log[it])

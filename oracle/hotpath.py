@@ -383,3 +383,77 @@ def knn_tree(points, queries, k, r2):
     okk = np.isfinite(d2)
     cnt = (okk & (d2 < r2a[:, None])).sum(1).astype(np.int32)
     return np.where(okk, d2, np.float32(FLT_MAX)).astype(np.float32), idx, cnt
+
+
+# ------------------------------------------------------------------ map maintenance around the hot loop
+def remap_linear_zero(img, u, v):
+    """cv2.remap(img, u, v, INTER_LINEAR) with the default BORDER_CONSTANT(0), float32 image and maps, restated from
+    OpenCV's documented algorithm (imgproc remap: the sub-pixel position is quantised to 1/32 - INTER_TAB_SIZE = 32,
+    cvRound = round-half-even - and the four taps are combined with the float32 table weights
+    [(1-ay)(1-ax), (1-ay)ax, ay(1-ax), ay ax] in that order; taps outside the image read 0).
+    PARITY UNPINNED: cv2 is not installed in the build image, the reference's tests never touch this call."""
+    img = np.asarray(img, np.float32)
+    H, W = img.shape
+    u = np.asarray(u, np.float32)
+    v = np.asarray(v, np.float32)
+    big = (np.abs(u) > 1e7) | (np.abs(v) > 1e7) | ~np.isfinite(u) | ~np.isfinite(v)
+    us, vs = np.where(big, np.float32(-1e6), u), np.where(big, np.float32(-1e6), v)
+    sx = np.rint(us.astype(np.float64) * 32.0).astype(np.int64)
+    sy = np.rint(vs.astype(np.float64) * 32.0).astype(np.int64)
+    ix, iy, ax, ay = sx >> 5, sy >> 5, (sx & 31).astype(np.float32) / np.float32(32), (sy & 31).astype(np.float32) / np.float32(32)
+    one = np.float32(1)
+
+    def tap(y, x):
+        ok = (x >= 0) & (x < W) & (y >= 0) & (y < H)
+        return np.where(ok, img[np.clip(y, 0, H - 1), np.clip(x, 0, W - 1)], np.float32(0))
+    w00, w01, w10, w11 = (one - ay) * (one - ax), (one - ay) * ax, ay * (one - ax), ay * ax
+    out = tap(iy, ix) * w00
+    out = out + tap(iy, ix + 1) * w01
+    out = out + tap(iy + 1, ix) * w10
+    out = out + tap(iy + 1, ix + 1) * w11
+    return out.astype(np.float32)
+
+
+def frustum_rows(pos, c2w, depth, fx, fy, cx, cy, H, W, edge):
+    """Mapper.get_mask_from_c2w (src/Mapper.py:165-217): indices of the cloud points inside the (edge-cropped) image
+    of pose c2w and not behind the observed surface by more than 0.5 m.  Arithmetic as the reference: w2c =
+    inv(c2w) in float32, projection in float64 (points are python floats there), uv cast to float32, bilinear depth
+    lookup, zero depths replaced by the max of the sampled depths.  Sums are written out in a fixed order
+    ((a+b)+c)+d so the HIP kernel can match bit for bit."""
+    pos = np.asarray(pos, np.float32).astype(np.float64)
+    w2c = np.linalg.inv(np.asarray(c2w, np.float32)).astype(np.float32).astype(np.float64)
+    x, y, z = pos[:, 0], pos[:, 1], pos[:, 2]
+    cam = [((w2c[r, 0] * x + w2c[r, 1] * y) + w2c[r, 2] * z) + w2c[r, 3] for r in range(3)]
+    cx_, cy_, cz_ = -cam[0], cam[1], cam[2]                       # cam_cord[:, 0] *= -1
+    zz = cz_ + 1e-5
+    u = ((fx * cx_ + cx * cz_) / zz).astype(np.float32)
+    v = ((fy * cy_ + cy * cz_) / zz).astype(np.float32)
+    d = remap_linear_zero(depth, u, v)
+    if d.size:
+        d = np.where(d == 0, d.max(), d)
+    m = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge)
+    m = m & (0 <= -zz) & (-zz <= (d + np.float32(0.5)).astype(np.float64))
+    return np.nonzero(m)[0].astype(np.int32)
+
+
+def add_points(rays_o, rays_d, gt_depth, cloud_pos, r2_add, near_surface, far_surface, n_add=3):
+    """NeuralPointCloud.add_neural_points, geometry only (src/neural_point.py:1557-1631): rays with depth > 0 whose
+    surface point o + d*depth has NO cloud point with squared distance < r2_add (scalar or per-ray) each contribute
+    n_add points at z = linspace(near*depth, far*depth).  Rays of the same call are not de-duplicated against each
+    other.  Returns (accepted ray indices, new points [3*k, 3]).  d2 as in knn_exact: (dx*dx + dy*dy) + dz*dz in f32."""
+    ro, rd, gd = (torch.as_tensor(t, dtype=torch.float32) for t in (rays_o, rays_d, gt_depth))
+    keep = torch.nonzero(gd > 0).reshape(-1)
+    p = (ro[keep] + rd[keep] * gd[keep, None]).numpy()
+    r2 = np.broadcast_to(np.asarray(r2_add, np.float32), gd.shape)[keep.numpy()] if np.ndim(r2_add) else np.float32(r2_add)
+    cloud = np.asarray(cloud_pos, np.float32).reshape(-1, 3)
+    if cloud.shape[0]:
+        d2, idx, cnt = knn_exact(cloud, p, 8, r2)
+        ok = cnt == 0
+    else:
+        ok = np.ones(p.shape[0], bool)
+    acc = keep[torch.from_numpy(ok)]
+    t = torch.linspace(0., 1., n_add)
+    dsurf = gd[acc, None].repeat(1, n_add)
+    z = near_surface * dsurf * (1. - t) + far_surface * dsurf * t
+    pts = ro[acc, None, :] + rd[acc, None, :] * z[..., None]
+    return acc.to(torch.int32), pts.reshape(-1, 3)

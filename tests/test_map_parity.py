@@ -1,0 +1,80 @@
+"""Map maintenance kernels around the hot loop against the oracle: frustum row selection
+(Mapper.get_mask_from_c2w) and point insertion (NeuralPointCloud.add_neural_points) - index work, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from loopy_slam_amd import core, optim, synthetic as syn
+from oracle import hotpath as H
+from util import backends, make_engine
+
+I = syn.TUM_INTR
+INTR = (I['fx'], I['fy'], I['cx'], I['cy'])
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('edge', (-4, 20))
+def test_frustum_rows(backend, edge):
+    """points in front / behind the camera, outside the image, behind the surface by more than 0.5 m, depth holes
+    (replaced by the max lookup), enlarged (negative) and shrunk image window; an empty cloud."""
+    eng = make_engine(backend)
+    pos, _, _ = syn.build_cloud(20000, seed=5)
+    gen = torch.Generator().manual_seed(9)
+    pos = torch.cat([pos, torch.rand(3000, 3, generator=gen) * 8 - 4])          # clutter everywhere, also behind walls
+    for view in (3, 60):
+        depth, _, c2w = syn.render_frame(view, device='cpu', holes=0.05, seed=2)
+        ref = H.frustum_rows(pos.numpy(), c2w.numpy(), depth.numpy(), *INTR, I['H'], I['W'], edge)
+        rows = optim.frustum_rows(eng, eng.f32(pos), c2w, eng.f32(depth), INTR, I['H'], I['W'], edge)
+        assert rows.dtype == torch.int32
+        assert np.array_equal(rows.cpu().numpy(), ref), (view, len(ref), rows.shape)
+        assert 500 < len(ref) < pos.shape[0]
+        small = pos[::5].contiguous()                                             # below 16 384 points: single-workgroup compaction
+        ref = H.frustum_rows(small.numpy(), c2w.numpy(), depth.numpy(), *INTR, I['H'], I['W'], edge)
+        rows = optim.frustum_rows(eng, eng.f32(small), c2w, eng.f32(depth), INTR, I['H'], I['W'], edge)
+        assert np.array_equal(rows.cpu().numpy(), ref)
+    rows = optim.frustum_rows(eng, eng.zeros(0, 3), c2w, eng.f32(depth), INTR, I['H'], I['W'], edge)
+    assert rows.numel() == 0
+
+
+def test_remap_semantics():
+    """the bilinear lookup itself (quantised 1/32 positions, zero border) through a cloud placed on known pixels."""
+    img = np.arange(12, dtype=np.float32).reshape(3, 4) + 1
+    u = np.array([0.0, 0.5, 2.999, 3.0, 3.4, -0.3, 1.25, 1.0 / 64, 3.0 / 64], np.float32)
+    v = np.array([0.0, 0.5, 1.0, 2.0, 2.6, 0.2, -0.75, 0.0, 1.0], np.float32)
+    out = H.remap_linear_zero(img, u, v)
+    assert out[0] == 1.0 and out[1] == (1 + 2 + 5 + 6) / 4 and out[3] == 12.0
+    assert out[4] == np.float32(12.0 * (1 - 0.59375) * (1 - 0.40625))                   # 13/32 and 19/32 after quantisation
+    assert out[7] == 1.0 and out[8] == np.float32(5 * (1 - 2 / 32) + 6 * (2 / 32))      # 1/64 rounds to 0 (half-even), 3/64 to 2/32
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('dynamic', (False, True))
+def test_add_points(backend, dynamic):
+    """first frame (empty index: every positive-depth ray accepted), then a second view against the grown cloud
+    (static r_add = 0.04 or a per-ray radius), zero-depth rays, duplicate rays inside one call (both accepted)."""
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(4)
+    knn = core.KnnIndex(eng, capacity=60000)
+    cloud = torch.zeros(0, 3)
+    near, far = 0.98, 1.02
+    for view, n in ((0, 3000), (4, 4000), (9, 2500)):
+        c2w = syn.loop_pose(view, 200, 'cpu')
+        i = torch.rand(n, generator=gen) * (I['W'] - 1)
+        j = torch.rand(n, generator=gen) * (I['H'] - 1)
+        ro, rd = syn.pixel_rays(c2w, i, j)
+        gd = syn.room_depth(ro, rd)
+        gd[torch.rand(n, generator=gen) < 0.05] = 0.0
+        ro, rd, gd = torch.cat([ro, ro[:5]]), torch.cat([rd, rd[:5]]), torch.cat([gd, gd[:5]])      # duplicates
+        r2 = (torch.rand(gd.shape[0], generator=gen) * 0.06 + 0.02) ** 2 if dynamic else 0.04 ** 2
+        acc_ref, pts_ref = H.add_points(ro, rd, gd, cloud.numpy(), r2.numpy() if dynamic else r2, near, far)
+        if cloud.shape[0]:
+            knn.build(eng.f32(cloud))
+        acc, pts = optim.add_points(eng, knn if cloud.shape[0] else None, eng.f32(ro), eng.f32(rd), eng.f32(gd),
+                                    eng.f32(r2) if dynamic else r2, near, far)
+        assert np.array_equal(acc.cpu().numpy(), acc_ref.numpy()), (view, acc.shape, acc_ref.shape)
+        assert torch.equal(pts.cpu(), pts_ref)
+        if view == 0:
+            assert acc.shape[0] == int((gd > 0).sum())
+        else:
+            assert 0 < acc.shape[0] < int((gd > 0).sum())
+        cloud = torch.cat([cloud, pts_ref])
