@@ -36,11 +36,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # testing hooks for a 1-GPU box: all ranks on device 0 over gloo (RCCL refuses two ranks on one device)
+    one_dev = os.environ.get('LOOPY_DIST_ONE_DEVICE') == '1'
+    backend = os.environ.get('LOOPY_DIST_BACKEND', 'nccl')
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dctx = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
         dctx = parallel.DistContext(rank, world)
     eng = core.Engine()
     budget = workload.Budget(n_points=args.points)
@@ -86,7 +94,7 @@ def main():
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'Replica room0 budget: 40 track it x 1500 rays + 60 map it x 5000 rays per frame '
-                               '(24 geometry + 36 colour), S=5, k=8, C=32, rel-pos colour MLP, '
+                               '(24 geometry + 36 colour) on the frustum rows of the mapped frame, S=5, k=8, C=32, rel-pos colour MLP, '
                                f'N={budget.n_points} points, 640x480 synthetic room',
                    'rays_per_step': rays_per_step, 'parallelism': f'dp{world} (ray-sharded, grad all-reduce)'},
     }

@@ -132,7 +132,7 @@ class TrackOptimizer:
     """Pose optimisation of one frame: Adam over the 7-vector (quaternion wxyz, translation)."""
 
     def __init__(self, eng, cfg, dec, knn, pos, geo_feats, col_feats, R, cam_lr, separate_lr=True, w_color=0.5,
-                 use_color=True, dynamic_radius=False):
+                 use_color=True, dynamic_radius=False, dist=None):
         self.eng, self.cfg, self.dec, self.knn = eng, cfg, dec, knn
         self.pos, self.geo, self.col = pos, geo_feats, col_feats
         self.R, self.cam_lr, self.separate_lr = R, cam_lr, separate_lr
@@ -142,6 +142,7 @@ class TrackOptimizer:
         self.gs = core.GradState(eng, geo_feats.shape[0], R, dec.n, feats=False, weights=False, rays=True)
         self.g_cam = eng.zeros(7)
         self.eye = None
+        self.dist = dist                        # ray-sharded tracking: the 7 pose gradients are summed over ranks
 
     def track(self, cam7_init, depth_img, color_img, iters, window, intr, rnd_all, r2_map=None):
         """Tracker.run loop body for one frame (Tracker.py:313-401).  cam7_init: [7] device tensor.
@@ -168,6 +169,8 @@ class TrackOptimizer:
                                log[it], b.loss_scratch)
             core.render_backward(eng, st, gs, b.d_depth, b.d_color)
             optim.pose_bwd(eng, cam, b.pix_i, b.pix_j, intr, gs.g_rays_o, gs.g_rays_d, self.g_cam)
+            if self.dist is not None:
+                self.dist.all_reduce_vec(self.g_cam)
             if self.separate_lr:                # T: lr, quaternion: 0.2*lr (Tracker.py:317-333)
                 segs = [('T', cam[4:7], self.g_cam[4:7], self.cam_lr), ('q', cam[0:4], self.g_cam[0:4], 0.2 * self.cam_lr)]
             else:

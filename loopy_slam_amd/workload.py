@@ -68,7 +68,7 @@ class FrameWorkload:
         self.mapper = steps.MapOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col, self.rows,
                                          b.map_rays, MAP_LRS, w_color=0.1, dist=dist)
         self.tracker = steps.TrackOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col,
-                                            b.track_rays, b.cam_lr, separate_lr=True, w_color=0.5)
+                                            b.track_rays, b.cam_lr, separate_lr=True, w_color=0.5, dist=dist)
         self.gen = torch.Generator(device='cpu').manual_seed(seed + (dist.rank if dist is not None else 0))
         self.cam0 = get_tensor_from_camera(self.c2w_stack[0]).to(dev)
         self.map_log = eng.zeros(b.map_iters, 4)
