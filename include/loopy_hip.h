@@ -219,6 +219,17 @@ int lk_frustum_rows(const float* pos, int32_t N, const float* w2c12_host, const 
 int lk_add_points(lk_knn_t knn, const float* rays_o, const float* rays_d, const float* gt_depth, int32_t n,
                   float r2_static, const float* r2_per_ray, float near_surface, float far_surface, int32_t n_add,
                   uint8_t* scratch_mask, int32_t* out_ray_index, int32_t* out_count, float* out_points, void* stream);
+/* Per-frame image pre-passes (Tracker.py:243-268, Mapper.py:854-872, common.py:175-234).
+ * lk_radius_maps: grad_mag[H,W] = |Sobel(rgb2gray(color))| (reflected borders), and the dynamic radii as SQUARED
+ * float32 maps: r_add = lerp over [0, 0.01, thr] -> [max, max, min] of the clipped magnitude, r_query = ratio * r_add
+ * (r2_add / r2_query may be NULL).
+ * lk_top_grad_pixels: the K pixels of largest grad_mag over the whole image (ties at the cut in ascending flat index),
+ * kept only inside the window [H0,H1) x [W0,W1) and where depth > 0 (depth may be NULL; depth_limit: also <= 5):
+ * out_index[0..*out_count) ascending flat indices (out_index must hold K ints). */
+int lk_radius_maps(const float* color, int32_t H, int32_t W, double color_grad_threshold, double radius_add_max,
+                   double radius_add_min, double radius_query_ratio, float* grad_mag, float* r2_add, float* r2_query, void* stream);
+int lk_top_grad_pixels(const float* grad_mag, int32_t H, int32_t W, int32_t K, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                       const float* depth, int32_t depth_limit, int32_t* out_index, int32_t* out_count, void* stream);
 /* thr = min(10*median(depth), 1.2*max(depth)) over depth>0 (Tracker.py:153-155, Mapper.py:674-676);
  * mask[i] = depth[i] > 0 && depth[i] <= thr (mask may be NULL); depth_filtered[i] = mask ? depth : 0 (may be
  * NULL or alias depth): a ray with gt_depth 0 is "absent" for the losses, which keeps the batch shape static

@@ -104,6 +104,9 @@ class LoopyLib:
                                  C.c_float, C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_add_points', [C.c_void_p, _fp, _fp, _fp, C.c_int32, C.c_float, _fp, C.c_float, C.c_float, C.c_int32,
                                _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_radius_maps', [_fp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_top_grad_pixels', [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int32,
+                                    _fp, _fp, C.c_void_p], C.c_int),
             ('lk_wgrad_single', [_fp, C.c_int32, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                  _fp, C.c_int32, _fp, C.c_int32, C.c_void_p], C.c_int),
             ('lk_profile_begin', [C.c_char_p], C.c_int),

@@ -193,3 +193,171 @@ extern "C" int lk_add_points(lk_knn_t knn, const float* rays_o, const float* ray
     LK_LAUNCH_CHECK();
     return LK_OK;
 }
+
+// ------------------------------------------------------------------ per-frame image pre-passes
+// Colour-gradient magnitude and the dynamic radius maps (Tracker.py:243-258, Mapper.py:854-872), in float64 like the
+// reference (its images are float64): grey = rgb2gray, Sobel with reflected borders, magnitude, radius = piecewise-
+// linear map of the clipped magnitude; the magnitude and the SQUARED radii are stored as float32 (the ABI's r^2
+// convention).
+struct LkRadiusArgs {
+    const float* color; int H, W;
+    double thr, add_max, slope_add, query_max, slope_query;
+    float* grad_mag; float* r2_add; float* r2_query;
+};
+
+__device__ __forceinline__ double rm_grey(const float* __restrict__ c, int H, int W, int y, int x) {
+    y = y < 0 ? 0 : (y >= H ? H - 1 : y);                       // 'reflect' with a radius-1 kernel = repeat the border pixel
+    x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    const float* p = c + ((size_t)y * W + x) * 3;
+    return ((double)p[0] * 0.2125 + (double)p[1] * 0.7154) + (double)p[2] * 0.0721;
+}
+
+__global__ __launch_bounds__(256) void k_radius_maps(LkRadiusArgs a) {
+    const int i = blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= a.H * a.W) return;
+    const int y = i / a.W, x = i - y * a.W;
+    double g[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) g[dy][dx] = rm_grey(a.color, a.H, a.W, y + dy - 1, x + dx - 1);
+    const double gy = 0.25 * (g[2][0] - g[0][0]) + 0.5 * (g[2][1] - g[0][1]) + 0.25 * (g[2][2] - g[0][2]);
+    const double gx = 0.25 * (g[0][2] - g[0][0]) + 0.5 * (g[1][2] - g[1][0]) + 0.25 * (g[2][2] - g[2][0]);
+    const double mag = sqrt(gx * gx + gy * gy);
+    a.grad_mag[i] = (float)mag;
+    const double xc = fmin(fmax(mag, 0.0), a.thr);
+    const double ra = (xc <= 0.01) ? a.add_max : a.slope_add * (xc - 0.01) + a.add_max;
+    const double rq = (xc <= 0.01) ? a.query_max : a.slope_query * (xc - 0.01) + a.query_max;
+    if (a.r2_add) a.r2_add[i] = (float)(ra * ra);
+    if (a.r2_query) a.r2_query[i] = (float)(rq * rq);
+}
+
+extern "C" int lk_radius_maps(const float* color, int32_t H, int32_t W, double color_grad_threshold, double radius_add_max,
+                              double radius_add_min, double radius_query_ratio, float* grad_mag, float* r2_add, float* r2_query,
+                              void* stream_) {
+    LK_REQUIRE(H > 0 && W > 0 && color && grad_mag, "lk_radius_maps: bad arguments");
+    LK_REQUIRE(color_grad_threshold > 0.01, "lk_radius_maps: color_grad_threshold must exceed 0.01");
+    LkRadiusArgs a;
+    a.color = color; a.H = H; a.W = W;
+    a.thr = color_grad_threshold;                       // config scalars are python floats (float64) in the reference
+    a.add_max = radius_add_max;
+    a.slope_add = (radius_add_min - radius_add_max) / (a.thr - 0.01);
+    a.query_max = radius_query_ratio * radius_add_max;
+    a.slope_query = (radius_query_ratio * radius_add_min - a.query_max) / (a.thr - 0.01);
+    a.grad_mag = grad_mag; a.r2_add = r2_add; a.r2_query = r2_query;
+    hipLaunchKernelGGL(k_radius_maps, dim3(lk_cdiv((int64_t)H * W, 256)), dim3(256), 0, (hipStream_t)stream_, a);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+// Pixel pool with the largest colour gradients (get_selected_index_with_grad, common.py:198-234): the K largest
+// magnitudes of the whole image (K-th value by a 4-pass radix select on the bit patterns; ties at the cut in ascending
+// pixel order), then only pixels inside the window with a valid depth are kept.  One 1024-thread workgroup (the
+// image is 1.2 MB and stays in L2; this runs once per frame).
+__global__ __launch_bounds__(1024) void k_top_grad(const float* __restrict__ grad, int n, int K, int W, int H0, int H1, int W0, int W1,
+                                                   const float* __restrict__ depth, int depth_limit,
+                                                   int32_t* __restrict__ out_index, int32_t* __restrict__ out_count) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_rank, s_above;
+    __shared__ int wa[16], wb[16];
+    __shared__ int s_ties_seen, s_out;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) { s_prefix = 0; s_rank = (unsigned)(n - K); s_above = 0; s_ties_seen = 0; s_out = 0; }   // ascending rank of the K-th largest
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
+        for (int c0 = 0; c0 < n; c0 += 1024) {
+            const int i = c0 + t;
+            const unsigned u = (i < n) ? __float_as_uint(grad[i]) : 0u;
+            const bool on = (i < n) && (u & himask) == prefix;
+            const unsigned digit = (u >> shift) & 255u;
+            if (shift >= 16) {          // few distinct high bytes: one LDS add per (wave, byte)
+                unsigned long long pending = __ballot(on);
+                while (pending) {
+                    const int leader = __ffsll((long long)pending) - 1;
+                    const unsigned dl = __shfl(digit, leader);
+                    const unsigned long long same = __ballot(on && digit == dl);
+                    if (lane == leader) atomicAdd(&hist[dl], (unsigned)__popcll(same));
+                    pending &= ~same;
+                }
+            } else if (on) {
+                atomicAdd(&hist[digit], 1u);
+            }
+        }
+        __syncthreads();
+        if (t < 64) {
+            const unsigned rank = s_rank;
+            const unsigned h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+            const unsigned tot = h0 + h1 + h2 + h3;
+            unsigned incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned nbv = __shfl_up(incl, o);
+                if (t >= o) incl += nbv;
+            }
+            const unsigned excl = incl - tot;
+            if (rank >= excl && rank < incl) {
+                unsigned r = rank - excl, b = 4 * t;
+                if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
+                s_rank = r;
+                s_prefix = prefix | (b << shift);
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned kth = s_prefix;                                  // bit pattern of the K-th largest magnitude
+    // how many are strictly above it -> how many ties at the cut belong to the pool
+    {
+        unsigned cnt = 0;
+        for (int i = t; i < n; i += 1024) cnt += (__float_as_uint(grad[i]) > kth) ? 1u : 0u;
+        atomicAdd(&s_above, cnt);
+    }
+    __syncthreads();
+    const int ties_needed = K - (int)s_above;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + t;
+        const unsigned u = (i < n) ? __float_as_uint(grad[i]) : 0u;
+        const bool tie = (i < n) && u == kth;
+        const unsigned long long bt = __ballot(tie);
+        if (lane == 0) wa[w] = __popcll(bt);
+        __syncthreads();
+        int tie_rank = s_ties_seen + __popcll(bt & ((1ull << lane) - 1ull));
+        for (int q = 0; q < w; ++q) tie_rank += wa[q];
+        bool member = (i < n) && (u > kth || (tie && tie_rank < ties_needed));
+        if (member) {
+            const int y = i / W, x = i - y * W;
+            member = y >= H0 && y < H1 && x >= W0 && x < W1;
+            if (member && depth) { const float d = depth[i]; member = d > 0.0f && (!depth_limit || d <= 5.0f); }
+        }
+        const unsigned long long bm = __ballot(member);
+        if (lane == 0) wb[w] = __popcll(bm);
+        __syncthreads();
+        int off = s_out + __popcll(bm & ((1ull << lane) - 1ull));
+        for (int q = 0; q < w; ++q) off += wb[q];
+        if (member) out_index[off] = i;
+        __syncthreads();
+        if (t == 0) {
+            int ta = 0, tb = 0;
+            for (int q = 0; q < 16; ++q) { ta += wa[q]; tb += wb[q]; }
+            s_ties_seen += ta; s_out += tb;
+        }
+        __syncthreads();
+    }
+    if (t == 0) *out_count = s_out;
+}
+
+extern "C" int lk_top_grad_pixels(const float* grad_mag, int32_t H, int32_t W, int32_t K, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                                  const float* depth, int32_t depth_limit, int32_t* out_index, int32_t* out_count, void* stream_) {
+    LK_REQUIRE(H > 0 && W > 0 && grad_mag && out_index && out_count && K >= 0, "lk_top_grad_pixels: bad arguments");
+    const int n = H * W;
+    if (K > n) K = n;
+    hipStream_t st = (hipStream_t)stream_;
+    if (K == 0) { LK_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int32_t), st)); return LK_OK; }
+    hipLaunchKernelGGL(k_top_grad, dim3(1), dim3(1024), 0, st, grad_mag, n, (int)K, (int)W, (int)H0, (int)H1, (int)W0, (int)W1,
+                       depth, (int)depth_limit, out_index, out_count);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}

@@ -132,3 +132,26 @@ def add_points(eng, knn, rays_o, rays_d, gt_depth, r2, near_surface, far_surface
                   'lk_add_points')
     k = int(cnt.item())
     return idx[:k], pts[:k * n_add]
+
+
+def radius_maps(eng, color, thr, radius_add_max, radius_add_min, ratio):
+    """Colour-gradient magnitude and the dynamic radius maps of one frame (lk_radius_maps):
+    (grad_mag [H,W], r2_add [H,W], r2_query [H,W]) float32, radii SQUARED."""
+    H, W = color.shape[:2]
+    g, ra, rq = eng.empty(H, W), eng.empty(H, W), eng.empty(H, W)
+    eng.lib.check(eng.lib.dll.lk_radius_maps(ptr(color.contiguous()), H, W, C.c_double(thr), C.c_double(radius_add_max),
+                                             C.c_double(radius_add_min), C.c_double(ratio), ptr(g), ptr(ra), ptr(rq), eng.stream),
+                  'lk_radius_maps')
+    return g, ra, rq
+
+
+def top_grad_pixels(eng, grad_mag, k, window, depth=None, depth_limit=False):
+    """Pool of high-gradient pixels (lk_top_grad_pixels): ascending flat indices int32.  One host sync (the count)."""
+    H, W = grad_mag.shape
+    H0, H1, W0, W1 = window
+    k = min(int(k), H * W)
+    out = eng.empty(max(k, 1), dtype=torch.int32)
+    cnt = eng.empty(1, dtype=torch.int32)
+    eng.lib.check(eng.lib.dll.lk_top_grad_pixels(ptr(grad_mag), H, W, k, H0, H1, W0, W1, ptr(depth), int(bool(depth_limit)),
+                                                 ptr(out), ptr(cnt), eng.stream), 'lk_top_grad_pixels')
+    return out[:int(cnt.item())]

@@ -421,13 +421,20 @@ class Mapper:
         frames_d = [keyframe_dict[k]['depth'] for k in sel] + [cur_gt_depth]
         frames_c = [keyframe_dict[k]['color'] for k in sel] + [cur_gt_color]
         frames_p = [keyframe_dict[k]['est_c2w'] for k in sel] + [cur_c2w]
+        r2_add_map = r2_query_map = None
+        if self.use_dynamic_radius:                 # per-pixel radii of the current frame (Mapper.py:854-872)
+            _, r2_add_map, r2_query_map = frame_radius_maps(eng, cfg, cur_gt_color)
+            self.cur_r2_query = r2_query_map
+        frames_r = ([keyframe_dict[k]['r2_query'] for k in sel] + [r2_query_map]) if self.use_dynamic_radius else None
         # 2. add neural points seen by the current frame (Mapper.py:429-482)
         ro, rd, gd, gc, i, j = get_samples(0, H, 0, W, self.pixels_adding, H, W, *intr, cur_c2w, cur_gt_depth, cur_gt_color,
                                            eng.device, depth_filter=True, return_index=True, generator=None)
+        dyn = torch.sqrt(r2_add_map[j.long(), i.long()]) if r2_add_map is not None else None
         if not init and self.filter_before_add_points and self.prev_c2w is not None:
             keep = self.filter_point_before_add(ro, rd, gd, self.prev_c2w)
             ro, rd, gd, gc = ro[keep], rd[keep], gd[keep], gc[keep]
-        frame_pts_add = npc.add_neural_points(ro, rd, gd, gc)
+            dyn = dyn[keep] if dyn is not None else None
+        frame_pts_add = npc.add_neural_points(ro, rd, gd, gc, dynamic_radius=dyn)
         # 3. rows to optimise
         rows = self.get_mask_from_c2w(cur_c2w, cur_gt_depth) if (self.frustum_feature_selection and not color_refine) else None
         # 4. iteration count (Mapper.py:572-574)
@@ -441,10 +448,12 @@ class Mapper:
         R = pix * F
         rcfg = render_cfg_from(cfg, cfg['rendering']['sigmoid_coef_mapper'])
         mo = steps.MapOptimizer(eng, rcfg, self.decoders.dec, npc.knn, npc.cloud_pos(), npc.get_geo_feats(), npc.get_col_feats(),
-                                rows, R, lrs, w_color=self.w_color_loss, dist=getattr(self.slam, 'dist', None))
+                                rows, R, lrs, w_color=self.w_color_loss, dynamic_radius=self.use_dynamic_radius,
+                                dist=getattr(self.slam, 'dist', None))
         mo.begin_frame()
         stack = (torch.stack(frames_d).contiguous(), torch.stack(frames_c).contiguous(),
-                 torch.stack([p.float() for p in frames_p]).contiguous(), None)
+                 torch.stack([p.float() for p in frames_p]).contiguous(),
+                 torch.stack(frames_r).contiguous() if frames_r is not None else None)
         fid = torch.arange(F, dtype=torch.int32).repeat_interleave(pix).to(eng.device)
         rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen, dtype=torch.int32).to(eng.device)
         log = eng.zeros(num_joint_iters, 4)
@@ -463,12 +472,20 @@ class Mapper:
         self.optimize_map(iters, idx, gt_color, gt_depth, gt_c2w, self.keyframe_dict, self.keyframe_list, cur_c2w)
         if idx % self.keyframe_every == 0 or idx == self.slam.n_img - 2:
             self.keyframe_list.append(idx)
-            self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': gt_color, 'depth': gt_depth, 'est_c2w': cur_c2w.clone()})
+            self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': gt_color, 'depth': gt_depth, 'est_c2w': cur_c2w.clone(),
+                                       'r2_query': getattr(self, 'cur_r2_query', None)})
         self.slam.mapping_idx[0] = idx
         return self.last_log
 
     def run(self, time_string=None):
         raise NotImplementedError('Point_SLAM.run drives map_frame / track_frame in one process')
+
+
+def frame_radius_maps(eng, cfg, color):
+    """(grad_mag, r2_add, r2_query) of one frame from the pointcloud config (Tracker.py:243-258, Mapper.py:854-872)."""
+    pc = cfg['pointcloud']
+    return optim.radius_maps(eng, color.float().contiguous(), pc['color_grad_threshold'], pc['radius_add_max'], pc['radius_add_min'],
+                             pc['radius_query_ratio'])
 
 
 # ============================================================================================ Tracker
@@ -485,6 +502,8 @@ class Tracker:
         self.ignore_edge_W, self.ignore_edge_H = t['ignore_edge_W'], t['ignore_edge_H']
         self.use_color_in_tracking, self.const_speed_assumption = t['use_color_in_tracking'], t['const_speed_assumption']
         self.gt_camera = t.get('gt_camera', False)
+        self.use_dynamic_radius = cfg['use_dynamic_radius']
+        self.sample_with_color_grad, self.depth_limit = t.get('sample_with_color_grad', False), t.get('depth_limit', False)
         self.gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219) + 3)
         self.last_log = None
 
@@ -536,13 +555,30 @@ class Tracker:
             if torch.dot(cam[:4], gt_cam[:4]).item() < 0:
                 cam[:4] *= -1
             rcfg = render_cfg_from(self.cfg, self.cfg['rendering']['sigmoid_coef_tracker'])
-            to = steps.TrackOptimizer(eng, rcfg, self.decoders.dec, self.npc.knn, self.npc.cloud_pos(), self.npc.get_geo_feats(),
-                                      self.npc.get_col_feats(), self.tracking_pixels, self.cam_lr, separate_lr=self.separate_LR,
-                                      w_color=self.w_color_loss, use_color=self.use_color_in_tracking)
             win = (self.ignore_edge_H, self.H - self.ignore_edge_H, self.ignore_edge_W, self.W - self.ignore_edge_W)
-            n = (win[1] - win[0]) * (win[3] - win[2])
-            rnd = torch.randint(0, n, (self.num_cam_iters, self.tracking_pixels), generator=self.gen, dtype=torch.int32).to(eng.device)
-            best, log = to.track(cam, gt_depth, gt_color, self.num_cam_iters, win, (self.fx, self.fy, self.cx, self.cy), rnd)
+            n_px = self.tracking_pixels
+            grad = r2_query = None
+            if self.use_dynamic_radius or self.sample_with_color_grad:      # per-frame image pre-pass (Tracker.py:243-268)
+                grad, _, r2q = frame_radius_maps(eng, self.cfg, gt_color)
+                r2_query = r2q if self.use_dynamic_radius else None
+            if self.sample_with_color_grad:
+                # pool of the 15*n highest-gradient pixels inside the window with a valid depth; every iteration draws n
+                # of them without replacement (common.py:198-234, Tracker.py:126-139) -> flat full-image pixel indices
+                pool = optim.top_grad_pixels(eng, grad, 15 * n_px, win, gt_depth.float().contiguous(), self.depth_limit)
+                n_px = min(n_px, int(pool.numel()))
+                order = torch.rand(self.num_cam_iters, pool.numel(), generator=self.gen).argsort(dim=1)[:, :n_px].to(eng.device)
+                rnd = pool[order].contiguous()
+                win_it = (0, self.H, 0, self.W)
+            else:
+                n = (win[1] - win[0]) * (win[3] - win[2])
+                rnd = torch.randint(0, n, (self.num_cam_iters, n_px), generator=self.gen, dtype=torch.int32).to(eng.device)
+                win_it = win
+            to = steps.TrackOptimizer(eng, rcfg, self.decoders.dec, self.npc.knn, self.npc.cloud_pos(), self.npc.get_geo_feats(),
+                                      self.npc.get_col_feats(), n_px, self.cam_lr, separate_lr=self.separate_LR,
+                                      w_color=self.w_color_loss, use_color=self.use_color_in_tracking,
+                                      dynamic_radius=r2_query is not None)
+            best, log = to.track(cam, gt_depth, gt_color, self.num_cam_iters, win_it, (self.fx, self.fy, self.cx, self.cy), rnd,
+                                 r2_map=r2_query)
             self.last_log = log
             c2w = torch.eye(4, device=eng.device)
             c2w[:3] = get_camera_from_tensor(best)

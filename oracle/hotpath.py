@@ -457,3 +457,57 @@ def add_points(rays_o, rays_d, gt_depth, cloud_pos, r2_add, near_surface, far_su
     z = near_surface * dsurf * (1. - t) + far_surface * dsurf * t
     pts = ro[acc, None, :] + rd[acc, None, :] * z[..., None]
     return acc.to(torch.int32), pts.reshape(-1, 3)
+
+
+def color_grad_mag(color):
+    """|Sobel| of the grey image as the reference computes it (Tracker.py:244-248, common.py:182-185, 209-212) with
+    scikit-image 0.19.3 (env.yaml:134; not installed here - restated from its source, the convolution itself is
+    scipy.ndimage.convolve which IS installed).  The reference's colour images are float64 (uint8 / 255. in numpy,
+    datasets.py), so the whole pre-pass runs in float64: rgb2gray = rgb @ [0.2125, 0.7154, 0.0721],
+    sobel_h / sobel_v = convolve(grey, [1,0,-1] x [1,2,1]/4, mode='reflect'), magnitude sqrt(gx^2 + gy^2).
+    Here the image arrives as float32 and is promoted."""
+    import scipy.ndimage as ndi
+    rgb = np.asarray(color, np.float32).astype(np.float64)
+    grey = (rgb[..., 0] * 0.2125 + rgb[..., 1] * 0.7154) + rgb[..., 2] * 0.0721
+    edge, smooth = np.array([1.0, 0.0, -1.0]), np.array([1.0, 2.0, 1.0]) / 4.0
+    gy = ndi.convolve(grey, edge.reshape(3, 1) * smooth.reshape(1, 3), mode='reflect')      # sobel_h: edges along axis 0
+    gx = ndi.convolve(grey, smooth.reshape(3, 1) * edge.reshape(1, 3), mode='reflect')      # sobel_v
+    return np.sqrt(gx ** 2 + gy ** 2)
+
+
+def radius_maps(color, radius_add_max, radius_add_min, ratio, thr):
+    """Per-pixel dynamic radii (Tracker.py:243-258; Mapper.py:854-872 does the same): gradient magnitude clipped to
+    [0, thr], piecewise-linear map [0, 0.01, thr] -> [r_max, r_max, r_min] (scipy interp1d arithmetic
+    slope * (x - x_lo) + y_lo), all float64; r_query = ratio * r_add.  Returns (grad_mag, r_add, r_query) float64."""
+    g = color_grad_mag(color)
+    x = np.clip(g, 0.0, thr)
+
+    def interp(y_max, y_min):
+        slope = (y_min - y_max) / (thr - 0.01)
+        return np.where(x <= 0.01, y_max, slope * (x - 0.01) + y_max)
+    return g, interp(radius_add_max, radius_add_min), interp(ratio * radius_add_max, ratio * radius_add_min)
+
+
+def top_grad_pixels(grad_mag, k, window, depth=None, depth_limit=False):
+    """Pixel pool of get_selected_index_with_grad (common.py:198-234): the k = ratio*n pixels with the largest gradient
+    magnitude of the WHOLE image, then restricted to the window [H0,H1) x [W0,W1) and to depth > 0 (<= 5 with
+    depth_limit).  np.argpartition leaves the choice among equal magnitudes at the cut unspecified; the contract here
+    is: every pixel strictly above the k-th largest value, then ties in ascending flat index.  Returns sorted flat
+    indices (int32)."""
+    g = np.asarray(grad_mag, np.float32)
+    H, W = g.shape
+    flat = g.reshape(-1)
+    k = min(int(k), flat.size)
+    if k <= 0:
+        return np.zeros(0, np.int32)
+    kth = np.sort(flat)[flat.size - k]
+    above = np.nonzero(flat > kth)[0]
+    ties = np.nonzero(flat == kth)[0][:k - above.size]
+    sel = np.sort(np.concatenate([above, ties]))
+    ih, iw = sel // W, sel % W
+    H0, H1, W0, W1 = window
+    m = (ih >= H0) & (ih < H1) & (iw >= W0) & (iw < W1)
+    if depth is not None:
+        d = np.asarray(depth, np.float32).reshape(-1)[sel]
+        m &= (d > 0) & ((d <= 5.0) if depth_limit else True)
+    return sel[m].astype(np.int32)

@@ -78,3 +78,51 @@ def test_add_points(backend, dynamic):
         else:
             assert 0 < acc.shape[0] < int((gd > 0).sum())
         cloud = torch.cat([cloud, pts_ref])
+
+
+def _textured_frame(seed, H=96, W=128):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(H // 8, W // 8, 3, generator=g)
+    color = torch.nn.functional.interpolate(base.permute(2, 0, 1)[None], size=(H, W), mode='bilinear', align_corners=False)[0].permute(1, 2, 0)
+    color = (color + 0.05 * torch.rand(H, W, 3, generator=g)).clamp(0, 1).contiguous()
+    color[10:20, 30:60] = 0.5                                  # a flat patch: zero gradient, many ties
+    depth = torch.rand(H, W, generator=g) * 6 + 0.3
+    depth[torch.rand(H, W, generator=g) < 0.1] = 0.0
+    return color, depth
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_radius_maps(backend):
+    """gradient magnitude and squared radii (float32 of the float64 maps; the kernel sums the Sobel taps in its own
+    order, so allow a float32 rounding); both branches of the map (below 0.01, between, clipped at the threshold)."""
+    eng = make_engine(backend)
+    color, _ = _textured_frame(1)
+    g_ref, ra_ref, rq_ref = H.radius_maps(color.numpy(), 0.08, 0.02, 2, 0.15)
+    assert (g_ref < 0.01).any() and ((g_ref > 0.01) & (g_ref < 0.15)).any() and (g_ref > 0.15).any()
+    g, ra, rq = optim.radius_maps(eng, eng.f32(color), 0.15, 0.08, 0.02, 2)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=2e-7, atol=1e-9)
+    np.testing.assert_allclose(ra.cpu().numpy(), ra_ref ** 2, rtol=2e-7)
+    np.testing.assert_allclose(rq.cpu().numpy(), rq_ref ** 2, rtol=2e-7)
+    assert float(ra.min()) == np.float32(0.02 ** 2) and float(ra.max()) == np.float32(0.08 ** 2)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_top_grad_pixels(backend):
+    """pool = top-K magnitudes of the whole image, then window + depth filters; K larger than the number of non-zero
+    gradients (cut inside the zero ties), K = all pixels, K = 0, the depth_limit variant, no depth."""
+    eng = make_engine(backend)
+    color, depth = _textured_frame(2)
+    Hh, Ww = depth.shape
+    g_ref = H.color_grad_mag(color.numpy()).astype(np.float32)
+    g = eng.f32(torch.from_numpy(g_ref))
+    win = (8, Hh - 8, 12, Ww - 12)
+    for K, dl, use_depth in ((1500, False, True), (1500, True, True), (Hh * Ww - 100, False, True), (Hh * Ww, False, False),
+                             (0, False, True), (37, False, False)):
+        ref = H.top_grad_pixels(g_ref, K, win, depth.numpy() if use_depth else None, dl)
+        got = optim.top_grad_pixels(eng, g, K, win, eng.f32(depth) if use_depth else None, dl)
+        assert np.array_equal(got.cpu().numpy(), ref), (K, dl, use_depth, got.shape, ref.shape)
+    # heavy ties: a quantised magnitude image
+    q = torch.from_numpy(np.round(g_ref * 40) / 40).float()
+    ref = H.top_grad_pixels(q.numpy(), 2000, win, depth.numpy())
+    got = optim.top_grad_pixels(eng, eng.f32(q), 2000, win, eng.f32(depth))
+    assert np.array_equal(got.cpu().numpy(), ref)

@@ -106,3 +106,23 @@ def test_npc_add_dedup_and_nicer_state_dict(backend):
     assert float(dec.state_dict()['geo_decoder.output_linear.bias']) == 3.0
     raw, ray_mask, point_mask = dec.forward(npc.cloud_pos()[:20], npc, 'color', npc.get_geo_feats(), npc.get_col_feats(), pts_num=5)
     assert raw.shape == (20, 4) and point_mask.shape == (20,) and ray_mask.shape == (4,)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_point_slam_dynamic_radius_and_gradient_sampling(backend):
+    """TUM / ScanNet style configuration: per-pixel radii from the colour gradient (insertion + every render of the
+    mapping window + tracking) and tracking rays drawn from the high-gradient pixel pool."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['use_dynamic_radius'] = True
+    cfg['tracking']['sample_with_color_grad'] = True
+    cfg['pointcloud'].update(radius_add_max=0.08, radius_add_min=0.02, radius_query_ratio=2, color_grad_threshold=0.15)
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    est, gt = ps.run()
+    assert ps.npc.pts_num() > 300 and torch.isfinite(est).all()
+    assert float((est[:, :3, 3] - gt[:, :3, 3]).norm(dim=1).max()) < 0.1
+    kf = ps.mapper.keyframe_dict[0]
+    r2 = kf['r2_query']
+    assert r2 is not None and tuple(r2.shape) == tuple(kf['depth'].shape)
+    assert float(r2.max()) <= np.float32(0.16 ** 2) and float(r2.min()) >= np.float32(0.04 ** 2)
+    assert torch.isfinite(ps.mapper.last_log.cpu()).all() and torch.isfinite(ps.tracker.last_log.cpu()).all()
