@@ -13,6 +13,7 @@ visualisation, checkpoints, the mapper-side exposure affine.  Every class takes 
 the default is the gfx950 library on the current CUDA device.
 """
 import math
+import os
 import types
 
 import numpy as np
@@ -110,6 +111,9 @@ class NICER:
         cur = self.dec.unpack()
         cur['color_decoder.embedder._B'] = torch.as_tensor(B).float()
         self.dec.pack(cur)
+
+    def color_embedder_B(self):
+        return self.dec.unpack()['color_decoder.embedder._B'].clone()
 
     def to(self, device):
         return self
@@ -652,3 +656,69 @@ class Point_SLAM:
             if callback:
                 callback(idx, est, c2w)
         return self.estimate_c2w_list[:n], self.gt_c2w_list[:n]
+
+
+# ============================================================================================ checkpoints
+class Logger:
+    """Checkpoints in the reference's format (src/utils/Logger.py:20-65): one `{idx:05d}.tar` with the same keys, so the
+    reference's offline tools (eval_ate.py, get_mesh_tsdf_fusion.py, eval_recon.py) read our runs and `load` resumes
+    theirs.  The map is tensor-resident here; tensors are saved on the CPU (the reference saves python lists for the
+    positions - both load with `torch.tensor(...)`)."""
+
+    def __init__(self, cfg, args, mapper, ckptsdir=None):
+        self.mapper, self.slam = mapper, mapper.slam
+        self.ckptsdir = ckptsdir or os.path.join(cfg['data'].get('output', 'output'), 'ckpts')
+        self.decoders = mapper.decoders
+
+    def log(self, idx, keyframe_dict, keyframe_list, selected_keyframes=None, npc=None, exposure_feat=None, last_log=False):
+        npc = npc if npc is not None else self.mapper.npc
+        os.makedirs(self.ckptsdir, exist_ok=True)
+        path = os.path.join(self.ckptsdir, '{:05d}.tar'.format(idx))
+        cpu = lambda t: t.detach().cpu() if torch.is_tensor(t) else t
+        ck = {
+            'cloud_pos': npc.get_cloud_pos(end=True).detach().cpu().tolist(),
+            'pts_num': npc.pts_num(),
+            'input_pos': npc.input_pos().detach().cpu().tolist(),
+            'input_rgb': npc.input_rgb().detach().cpu().tolist(),
+            'input_normal': [], 'input_normal_cartesian': [],
+            'decoder_state_dict': {k: cpu(v) for k, v in self.decoders.state_dict().items()},
+            'gt_c2w_list': self.slam.gt_c2w_list, 'estimate_c2w_list': self.slam.estimate_c2w_list,
+            'keyframe_list': list(keyframe_list),
+            'keyframe_dict': [{k: cpu(v) for k, v in kf.items()} for kf in keyframe_dict],
+            'selected_keyframes': selected_keyframes if selected_keyframes is not None else {},
+            'idx': idx,
+            'fragments': [],
+            'exposure_feat_all': torch.stack([cpu(e) for e in exposure_feat], dim=0) if exposure_feat is not None else None,
+        }
+        if last_log:
+            ck['geo_feats'] = cpu(npc.get_geo_feats(end=True))
+            ck['col_feats'] = cpu(npc.get_col_feats(end=True))
+        # the colour embedding matrix is not part of the reference's state_dict (decoder.py:32); keep it beside it
+        ck['color_embedder_B'] = cpu(self.decoders.color_embedder_B()) if hasattr(self.decoders, 'color_embedder_B') else None
+        torch.save(ck, path, _use_new_zipfile_serialization=False)
+        return path
+
+    @staticmethod
+    def load(path, slam_obj):
+        """Restore map, decoders, poses and keyframes of `slam_obj` from a checkpoint written by `log(last_log=True)`."""
+        ck = torch.load(path, map_location='cpu', weights_only=False)
+        eng, npc = slam_obj.eng, slam_obj.npc
+        pos = torch.tensor(ck['cloud_pos'], dtype=torch.float32).reshape(-1, 3)
+        n = pos.shape[0]
+        npc._grow(n)
+        npc._pos[:n] = pos.to(eng.device)
+        if 'geo_feats' in ck:
+            npc._geo[:n] = ck['geo_feats'].to(eng.device)
+            npc._col[:n] = ck['col_feats'].to(eng.device)
+        npc.n = n
+        if n:
+            npc.knn.build(npc._pos[:n])
+        if ck.get('color_embedder_B') is not None and hasattr(slam_obj.shared_decoders, 'set_color_embedder_B'):
+            slam_obj.shared_decoders.set_color_embedder_B(ck['color_embedder_B'])
+        slam_obj.shared_decoders.load_state_dict(ck['decoder_state_dict'])
+        slam_obj.gt_c2w_list[:] = ck['gt_c2w_list']
+        slam_obj.estimate_c2w_list[:] = ck['estimate_c2w_list']
+        slam_obj.mapper.keyframe_list = list(ck['keyframe_list'])
+        slam_obj.mapper.keyframe_dict = [{k: (v.to(eng.device) if torch.is_tensor(v) else v) for k, v in kf.items()}
+                                         for kf in ck['keyframe_dict']]
+        return ck['idx']

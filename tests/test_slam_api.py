@@ -126,3 +126,31 @@ def test_point_slam_dynamic_radius_and_gradient_sampling(backend):
     assert r2 is not None and tuple(r2.shape) == tuple(kf['depth'].shape)
     assert float(r2.max()) <= np.float32(0.16 ** 2) and float(r2.min()) >= np.float32(0.04 ** 2)
     assert torch.isfinite(ps.mapper.last_log.cpu()).all() and torch.isfinite(ps.tracker.last_log.cpu()).all()
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_checkpoint_roundtrip_reference_format(backend, tmp_path):
+    """Logger writes the reference's `.tar` layout (src/utils/Logger.py:20-65: same keys, positions as lists, decoder
+    state_dict with the reference's names) and a second system resumes from it: same map, same renders."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    ps.run(n_frames=3)
+    lg = slam.Logger(cfg, None, ps.mapper, ckptsdir=str(tmp_path))
+    path = lg.log(2, ps.mapper.keyframe_dict, ps.mapper.keyframe_list, npc=ps.npc, last_log=True)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    for k in ('geo_feats', 'col_feats', 'cloud_pos', 'pts_num', 'input_pos', 'input_rgb', 'input_normal', 'input_normal_cartesian',
+              'decoder_state_dict', 'gt_c2w_list', 'estimate_c2w_list', 'keyframe_list', 'keyframe_dict', 'selected_keyframes', 'idx',
+              'fragments', 'exposure_feat_all'):
+        assert k in ck, k
+    assert isinstance(ck['cloud_pos'], list) and len(ck['cloud_pos']) == ck['pts_num'] == ps.npc.pts_num()
+    assert 'geo_decoder.pts_linears.0.weight' in ck['decoder_state_dict'] and ck['idx'] == 2
+    ps2 = slam.Point_SLAM(cfg, None, eng=eng)
+    assert slam.Logger.load(path, ps2) == 2
+    assert torch.equal(ps2.npc.cloud_pos().cpu(), ps.npc.cloud_pos().cpu())
+    assert torch.equal(ps2.npc.get_geo_feats().cpu(), ps.npc.get_geo_feats().cpu())
+    assert len(ps2.mapper.keyframe_dict) == len(ps.mapper.keyframe_dict)
+    idx, color, depth, c2w = ps.frame_reader[1]
+    d1, u1, c1 = ps.renderer.render_img(ps.npc, ps.shared_decoders, c2w, eng.device, 'color', gt_depth=depth)
+    d2, u2, c2 = ps2.renderer.render_img(ps2.npc, ps2.shared_decoders, c2w, eng.device, 'color', gt_depth=depth)
+    assert torch.equal(d1.cpu(), d2.cpu()) and torch.equal(c1.cpu(), c2.cpu())
