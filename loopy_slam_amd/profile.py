@@ -102,6 +102,9 @@ def roofline(kstat, budget, kernel):
     else:
         out.update(bound='hbm', achieved=nbytes / secs / 1e9, peak=PEAK_HBM_GBS, unit='GB/s')
     out['frac'] = out['achieved'] / out['peak']
+    if kernel in ('k_wgrad', 'k_relpos_bwd', 'k_feat_scatter'):
+        out['overlap'] = ('k_wgrad runs on a second stream beside k_relpos_bwd / k_feat_scatter: durations are measured while '
+                          'they share the chip (LK_SERIAL=1 times every kernel alone)')
     out['algorithmic_flops_per_launch_avg'] = flops / k['calls']
     out['algorithmic_bytes_per_launch_avg'] = nbytes / k['calls']
     return out
