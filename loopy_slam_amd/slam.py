@@ -242,6 +242,25 @@ class NeuralPointCloud:
         D, I, cnt = self.knn.query(pos, r2)
         return D, I.long(), cnt
 
+    def sample_near_pcl(self, rays_o, rays_d, near, far, num):
+        """For rays without a depth reading: sample between the first two probe depths (of 25 between near and far) that
+        have a cloud point within radius_query (neural_point.py:1734-1786).  Returns (z [n, num] f32, invalid [n] bool).
+        The probes go through the device kNN; disabled in every reference config (sample_near_pcl: False)."""
+        ro, rd = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+        n, intervals = rd.shape[0], 25
+        far = float(far)
+        zp = torch.linspace(near, far, steps=intervals, device=ro.device)
+        pts = (ro[:, None, :] + rd[:, None, :] * zp[None, :, None]).reshape(-1, 3).contiguous()
+        _, _, cnt = self.find_neighbors_faiss(pts, step='query')
+        sup = (cnt.reshape(n, intervals) > 0).cpu().numpy()
+        invalid = sup.sum(-1) < 2
+        sect = np.linspace(near, far, intervals)
+        z = np.tile(np.linspace(near, far, num), (n, 1))
+        for r in np.nonzero(~invalid)[0]:
+            c = np.nonzero(sup[r])[0]
+            z[r] = np.linspace(sect[c[0]], sect[c[1]], num=num)
+        return torch.from_numpy(z).float().to(ro.device), torch.from_numpy(invalid).to(ro.device)
+
     # ---- insertion (neural_point.py:1557-1631): radius de-dup against the existing cloud, N_add points per ray
     def add_neural_points(self, batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color, train=False, is_pts_grad=False,
                           dynamic_radius=None, idx=None, gt_color=None, gt_depth=None, cur_c2w=None, gt_camera=None):
@@ -309,6 +328,10 @@ class Renderer:
         self.N_surface = cfg['rendering']['N_surface']
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self.sigmoid_coefficient = cfg['rendering']['sigmoid_coef_mapper']     # set externally like the reference
+        if cfg['rendering'].get('sample_near_pcl', False):
+            # off in every reference config (replica/tum/scannet.yaml); NeuralPointCloud.sample_near_pcl exists, but the fused
+            # sampler takes its z for depth-less rays from far_bb only
+            raise NotImplementedError('rendering.sample_near_pcl: True is not wired into the fused render (lk_render_fwd)')
         self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
 
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None, npc_geo_feats=None,

@@ -511,3 +511,25 @@ def top_grad_pixels(grad_mag, k, window, depth=None, depth_limit=False):
         d = np.asarray(depth, np.float32).reshape(-1)[sel]
         m &= (d > 0) & ((d <= 5.0) if depth_limit else True)
     return sel[m].astype(np.int32)
+
+
+def sample_near_pcl(rays_o, rays_d, near, far, num, cloud_pos, radius_query, intervals=25):
+    """NeuralPointCloud.sample_near_pcl (src/neural_point.py:1734-1786): probe `intervals` depths between near and far on
+    each ray, keep the span between the first and the last probe that has a cloud point within radius_query
+    (count > 0), and place `num` samples evenly in it (numpy float64 linspace, cast to float32).  Rays with fewer than two
+    supported probes are 'invalid' and keep linspace(near, far, num).  Returns (z [n, num] f32, invalid [n] bool)."""
+    ro = torch.as_tensor(rays_o, dtype=torch.float32).reshape(-1, 3)
+    rd = torch.as_tensor(rays_d, dtype=torch.float32).reshape(-1, 3)
+    n = rd.shape[0]
+    far = float(far)
+    zp = torch.linspace(near, far, steps=intervals)
+    pts = (ro[:, None, :] + rd[:, None, :] * zp[None, :, None]).reshape(-1, 3)
+    _, _, cnt = knn_exact(np.asarray(cloud_pos, np.float32), pts.numpy(), 8, np.float32(radius_query ** 2))
+    sup = cnt.reshape(n, intervals) > 0
+    invalid = sup.sum(-1) < 2
+    sect = np.linspace(near, far, intervals)
+    z = np.tile(np.linspace(near, far, num), (n, 1))
+    for r in np.nonzero(~invalid)[0]:
+        c = np.nonzero(sup[r])[0]
+        z[r] = np.linspace(sect[c[0]], sect[c[1]], num=num)          # item[0], item[1]: the first TWO supported probes
+    return z.astype(np.float32), invalid

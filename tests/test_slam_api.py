@@ -154,3 +154,23 @@ def test_checkpoint_roundtrip_reference_format(backend, tmp_path):
     d1, u1, c1 = ps.renderer.render_img(ps.npc, ps.shared_decoders, c2w, eng.device, 'color', gt_depth=depth)
     d2, u2, c2 = ps2.renderer.render_img(ps2.npc, ps2.shared_decoders, c2w, eng.device, 'color', gt_depth=depth)
     assert torch.equal(d1.cpu(), d2.cpu()) and torch.equal(c1.cpu(), c2.cpu())
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_sample_near_pcl(backend):
+    """NeuralPointCloud.sample_near_pcl against the oracle restatement (probes through the device kNN)."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    npc = slam.NeuralPointCloud(cfg, eng=eng, capacity=4096)
+    g = torch.Generator().manual_seed(3)
+    wall = torch.cat([torch.rand(1500, 2, generator=g) * 4 - 2, torch.full((1500, 1), 2.0)], 1)       # a wall at z = 2
+    wall2 = torch.cat([torch.rand(600, 2, generator=g) * 4 - 2, torch.full((600, 1), 3.1)], 1)       # a second one behind it
+    npc._grow(2100); npc._pos[:2100] = eng.f32(torch.cat([wall, wall2])); npc.n = 2100
+    npc.knn.build(npc._pos[:2100])
+    ro = torch.zeros(40, 3)
+    rd = torch.cat([torch.rand(40, 2, generator=g) * 0.8 - 0.4, torch.ones(40, 1)], 1)
+    rd[:5, 2] = -1.0                                                                                   # looking away: invalid
+    z, inv = npc.sample_near_pcl(eng.f32(ro), eng.f32(rd), 0.3, 4.0, 5)
+    zr, invr = H.sample_near_pcl(ro, rd, 0.3, 4.0, 5, npc.cloud_pos().cpu().numpy(), npc.radius_query)
+    assert np.array_equal(inv.cpu().numpy(), invr) and invr[:5].all() and not invr.all()
+    assert np.array_equal(z.cpu().numpy(), zr)
