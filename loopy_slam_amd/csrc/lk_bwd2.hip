@@ -1,9 +1,9 @@
 // Backward, part 2:
-//   k_interp_bwd  d c_geo / d c_col -> scatter-add into the feature-row gradients; tracker mode: gradient
-//                 through the interpolation weights to the sample position (decoder.py:191-229)
-//   k_rays_bwd    d p -> d rays_o, d rays_d
-//   k_relpos_bwd  backward of the relative-position neighbour MLP (decoder.py:477-488)
-//   k_wgrad       all decoder weight gradients as streamed MFMA reductions over the sample rows
+//   k_interp_bwd    tracker mode: gradient through the interpolation weights to the sample position (decoder.py:191-229)
+//   k_feat_scatter  d c_geo / d c_col / per-neighbour rows -> scatter-add into the feature-row gradients
+//   k_rays_bwd      d p -> d rays_o, d rays_d
+//   k_relpos_bwd    backward of the relative-position neighbour MLP (decoder.py:477-488)
+//   k_wgrad(+_reduce)  all decoder weight gradients as streamed MFMA reductions over the sample rows
 #include "lk_common.h"
 #include "lk_kernels.h"
 

@@ -4,11 +4,13 @@
 //              MLP_col_neighbor / rel-pos branch of MLP_color.get_feature_at_pos (decoder.py:477-490),
 //              NICER.forward stage dispatch (decoder.py:573-610).
 //
-// Design (CDNA4): one wave64 owns 32 sample points.  Activations are kept TRANSPOSED in the MFMA
-// C/D layout ("CT tile": 32 units x 32 samples, lane = sample column) so that each layer
-// Y^T = W X^T uses v_mfma_f32_32x32x2_f32 with A = weights (16-byte loads straight from the
-// L2-resident blob) and B = the previous layer's accumulator registers.  No LDS, no barriers,
-// exact fp32 (fma-chain) arithmetic at the fp32 matrix rate.  See lk_common.h::lk_gemm_frag.
+// Design (CDNA4): a tile is 32 sample points.  Activations are kept TRANSPOSED in the MFMA C/D layout ("CT tile":
+// 32 units x 32 samples, lane = sample column) so that each layer Y^T = W X^T uses v_mfma_f32_32x32x2_f32 with
+// A = weights (16-byte loads of the fragment blob) and B = the previous layer's accumulator registers (see
+// lk_common.h::lk_gemm_frag).  Geometry decoder and rel-pos MLP: one wave per tile, whole network through registers,
+// no LDS, no barrier.  Colour trunk (128 wide): the four waves of a workgroup own 32 output units each and exchange
+// their tiles through LDS as lane-contiguous register chunks (decode_col_wg).  Exact fp32 (fma-chain) arithmetic at
+// the fp32 matrix rate.
 #include "lk_common.h"
 #include "lk_kernels.h"
 
