@@ -1,0 +1,132 @@
+"""Full-size checks on the real GPU (BASELINE.json sizes: 640x480 frames, 1e5..1e6 points) through properties that
+do not need the (slow) oracle at that size: self-consistency of the kNN answers, batch-independence of the render,
+linearity of the backward, sortedness / counts of the index kernels.  The small-size parity tests pin the values."""
+import numpy as np
+import pytest
+import torch
+
+from loopy_slam_amd import core, optim, synthetic as syn
+from util import make_engine
+
+pytestmark = pytest.mark.gpu
+I = syn.TUM_INTR
+INTR = (I['fx'], I['fy'], I['cx'], I['cy'])
+
+
+def _scene(eng, N):
+    pos, geo, col = syn.build_cloud(N, device='cpu')
+    pos, geo, col = eng.f32(pos), eng.f32(geo), eng.f32(col)
+    knn = core.KnnIndex(eng, capacity=N)
+    knn.build(pos)
+    return pos, geo, col, knn
+
+
+def test_knn_million_points_self_consistent():
+    eng = make_engine('hip')
+    pos, _, _, knn = _scene(eng, 1_000_000)
+    g = torch.Generator().manual_seed(0)
+    q = pos[torch.randint(0, pos.shape[0], (100_000,), generator=g).to(eng.device)] + 0.01 * torch.randn(100_000, 3, generator=g).to(eng.device)
+    r2 = 0.08 ** 2
+    d2, idx, cnt = knn.query(q.contiguous(), r2)
+    ok = idx >= 0
+    # ascending (d2, index) order, distances recomputed from the returned indices, everything inside the radius
+    dd = d2.clone(); dd[~ok] = float('inf')
+    assert bool((dd[:, 1:] >= dd[:, :-1]).all())
+    p = pos[idx.clamp(min=0).long()]
+    diff = q[:, None, :] - p
+    rec = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    assert torch.equal(rec[ok], d2[ok]) and bool((d2[ok] <= r2).all())
+    assert torch.equal(cnt, (ok & (d2 < r2)).sum(1).to(torch.int32))
+    # brute force on a slice: the k-th returned distance is the k-th smallest of ALL points in the radius
+    for i in range(0, 100_000, 12_500):
+        all_d = ((q[i] - pos) ** 2).sum(1)
+        inside = int((all_d <= r2).sum())
+        assert int(ok[i].sum()) == min(8, inside)
+        if inside:
+            kth = torch.topk(all_d, min(8, inside), largest=False).values
+            assert torch.allclose(kth, d2[i, :min(8, inside)], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('rel_pos', (True, False))
+def test_full_frame_render_is_batch_independent(rel_pos):
+    """307 200 rays in one launch == the same rays rendered in four launches (every ray is independent given the map)."""
+    eng = make_engine('hip')
+    pos, geo, col, knn = _scene(eng, 100_000)
+    blob = core.DecoderBlob(eng).pack(syn.default_weights(rel_pos=rel_pos))
+    cfg = core.RenderCfg(rel_pos=rel_pos)
+    depth, _, c2w = syn.render_frame(5, device='cuda', holes=0.0)
+    H, W = depth.shape
+    jj, ii = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    ro, rd = syn.pixel_rays(c2w, ii.reshape(-1).cuda(), jj.reshape(-1).cuda())
+    gd = depth.reshape(-1).contiguous()
+    R = H * W
+    st = core.RenderState(eng, R, cfg.S)
+    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, 'color')
+    full_d, full_c, full_v = st.depth.clone(), st.color.clone(), st.var.clone()
+    assert torch.isfinite(full_d).all() and float(st.valid_ray.float().mean()) > 0.9
+    q = R // 4
+    stq = core.RenderState(eng, q, cfg.S)
+    for k in range(4):
+        sl = slice(k * q, (k + 1) * q)
+        core.render_forward(eng, cfg, stq, ro[sl].contiguous(), rd[sl].contiguous(), gd[sl].contiguous(), knn, pos, geo, col, blob, 'color')
+        assert torch.equal(stq.depth, full_d[sl]) and torch.equal(stq.color, full_c[sl]) and torch.equal(stq.var, full_v[sl])
+
+
+def test_backward_is_linear_in_the_output_gradient():
+    """10 000-ray mapping batch: gradients for (2 d_depth, 2 d_color) are twice those for (d_depth, d_color), and the
+    sum of two gradient fields is the gradient of the sum (fp32 accumulation noise only)."""
+    eng = make_engine('hip')
+    pos, geo, col, knn = _scene(eng, 100_000)
+    blob = core.DecoderBlob(eng).pack(syn.default_weights())
+    cfg = core.RenderCfg()
+    depth, _, c2w = syn.render_frame(7, device='cuda', holes=0.02)
+    g = torch.Generator().manual_seed(1)
+    R = 10_000
+    i = torch.randint(0, I['W'], (R,), generator=g).float().cuda()
+    j = torch.randint(0, I['H'], (R,), generator=g).float().cuda()
+    ro, rd = syn.pixel_rays(c2w, i, j)
+    gd = depth[j.long(), i.long()].contiguous()
+    st = core.RenderState(eng, R, cfg.S, need_act=True)
+    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, 'color', save_act=True)
+
+    def grads(dd, dc):
+        gs = core.GradState(eng, pos.shape[0], R, blob.n, feats=True, weights=True)
+        core.render_backward(eng, st, gs, dd, dc)
+        torch.cuda.synchronize()
+        return gs.g_geo.clone(), gs.g_col.clone(), gs.g_weights.clone()
+    d1, c1 = torch.randn(R, generator=g).cuda(), torch.randn(R, 3, generator=g).cuda()
+    d2, c2 = torch.randn(R, generator=g).cuda(), torch.randn(R, 3, generator=g).cuda()
+    a, b, s2, ab = grads(d1, c1), grads(d2, c2), grads(2 * d1, 2 * c1), grads(d1 + d2, c1 + c2)
+    for x, y2, y, z in zip(a, s2, b, ab):
+        scale = float(x.abs().max()) + 1e-12
+        assert float((y2 - 2 * x).abs().max()) <= 2e-5 * scale
+        assert float((z - (x + y)).abs().max()) <= 2e-4 * (scale + float(y.abs().max()))
+
+
+def test_frustum_rows_and_insertion_at_five_million_points():
+    eng = make_engine('hip')
+    N = 5_000_000
+    pos, _, _ = syn.build_cloud(N, device='cpu')
+    pos = eng.f32(pos)
+    depth, _, c2w = syn.render_frame(3, device='cuda', holes=0.02)
+    rows = optim.frustum_rows(eng, pos, c2w, depth, INTR, I['H'], I['W'], -4)
+    assert rows.dtype == torch.int32 and 0 < rows.numel() < N
+    assert bool((rows[1:] > rows[:-1]).all())                                   # ascending, no duplicates
+    # every selected point projects into the (enlarged) image in front of the camera; a sample of rejected ones does not
+    w2c = torch.linalg.inv(c2w.double())
+    cam = pos[rows.long()].double() @ w2c[:3, :3].T + w2c[:3, 3]
+    z = cam[:, 2] + 1e-5
+    u = (I['fx'] * -cam[:, 0] + I['cx'] * cam[:, 2]) / z
+    v = (I['fy'] * cam[:, 1] + I['cy'] * cam[:, 2]) / z
+    assert bool(((u > -4.001) & (u < I['W'] + 4.001) & (v > -4.001) & (v < I['H'] + 4.001) & (z <= 0)).all())
+    knn = core.KnnIndex(eng, capacity=N)
+    knn.build(pos)
+    # re-inserting surface points of the cloud's own views adds nothing; far-away rays are all accepted
+    g = torch.Generator().manual_seed(2)
+    c2 = syn.loop_pose(0, 200, 'cpu')
+    ro, rd = syn.pixel_rays(c2, torch.rand(50_000, generator=g) * (I['W'] - 1), torch.rand(50_000, generator=g) * (I['H'] - 1))
+    gd = syn.room_depth(ro, rd)
+    acc, pts = optim.add_points(eng, knn, eng.f32(ro), eng.f32(rd), eng.f32(gd), 0.04 ** 2, 0.98, 1.02)
+    assert acc.numel() == 0 and pts.numel() == 0
+    acc, pts = optim.add_points(eng, knn, eng.f32(ro + 100.0), eng.f32(rd), eng.f32(gd), 0.04 ** 2, 0.98, 1.02)
+    assert acc.numel() == 50_000 and pts.shape == (150_000, 3) and torch.equal(acc.cpu(), torch.arange(50_000, dtype=torch.int32))
