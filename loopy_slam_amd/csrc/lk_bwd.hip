@@ -369,23 +369,27 @@ __global__ __launch_bounds__(256, 2) void k_decode_bwd(LkDecodeBwdArgs a, int n_
     }
 }
 
-// out[j] += sum_p part[p][j].  grid = (width/64, ceil(n_parts/256)): 64 columns x 4 row-lanes per block, 64 partial rows
-// per lane, combined through LDS, then ONE atomic per (block, column) — a few tens of adds per address in total.
+// out[j] += sum_p part[p][j].  One workgroup per (32-column group, 16 partial rows): 8 row lanes x 32 columns, two
+// rows per lane read coalesced, combined through LDS, then ONE atomic per (workgroup, column) - a few tens to a
+// hundred adds per address in total (~13 ns each when they collide), and no serial loop over the rows.
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out) {
-    __shared__ float sh[4][64];
-    const int col = blockIdx.x * 64 + ((int)threadIdx.x & 63), q = (int)threadIdx.x >> 6;
-    const int p0 = blockIdx.y * 256;
-    const int p1 = (p0 + 256 < n_parts) ? p0 + 256 : n_parts;
+    __shared__ float sh[8][32];
+    const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + e;
+    const int p0 = blockIdx.y * 16 + q;
     float s = 0.0f;
-    if (col < width)
-        for (int p = p0 + q; p < p1; p += 4) s += part[(size_t)p * width + col];
-    sh[q][threadIdx.x & 63] = s;
+    if (col < width) {
+        if (p0 < n_parts) s = part[(size_t)p0 * width + col];
+        if (p0 + 8 < n_parts) s += part[(size_t)(p0 + 8) * width + col];
+    }
+    sh[q][e] = s;
     __syncthreads();
-    if (q == 0 && col < width) atomicAdd(out + col, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (q == 0 && col < width)
+        atomicAdd(out + col, ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) + ((sh[4][e] + sh[5][e]) + (sh[6][e] + sh[7][e])));
 }
 
 int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(lk_cdiv(width, 64), lk_cdiv(n_parts, 256)), dim3(256), 0, st, part, n_parts, width, out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(lk_cdiv(width, 32), lk_cdiv(n_parts, 16)), dim3(256), 0, st, part, n_parts, width, out);
     return LK_OK;
 }
 

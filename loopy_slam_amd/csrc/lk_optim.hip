@@ -383,9 +383,28 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
         if (t == 0) *out_thr = 0.0f;
         return;
     }
+    // Shortcut: thr = min(10*median, 1.2*max) is 1.2*max unless the median itself satisfies fl(10 v) < fl(1.2 max); that
+    // predicate is monotone in v, so the (lower) median at rank (m-1)/2 satisfies it iff MORE than (m-1)/2 values do -
+    // one counting pass instead of the 4-pass radix select (depth images: median ~ max/2, the select almost never runs).
+    const float mx12 = __fmul_rn(1.2f, __uint_as_float(s_maxbits));
+    {
+        unsigned below = 0;
+        if (REG) {
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) below += (u[q] && __fmul_rn(10.0f, __uint_as_float(u[q])) < mx12) ? 1u : 0u;
+        } else {
+            for (int i = t; i < n; i += 1024) { const unsigned v = scratch[i]; below += (v && __fmul_rn(10.0f, __uint_as_float(v)) < mx12) ? 1u : 0u; }
+        }
+        if (t == 0) s_rank = 0;
+        __syncthreads();
+        atomicAdd(&s_rank, below);
+        __syncthreads();
+    }
+    const bool need_median = s_rank > (m - 1) / 2;                    // block-uniform
+    __syncthreads();
     if (t == 0) { s_prefix = 0; s_rank = (m - 1) / 2; }              // torch.median: lower of the two middle values
     __syncthreads();
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int shift = 24; need_median && shift >= 0; shift -= 8) {
         if (t < 256) hist[t] = 0;
         __syncthreads();
         const unsigned prefix = s_prefix;
@@ -437,8 +456,7 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
         __syncthreads();
     }
     const float med = __uint_as_float(s_prefix);
-    const float mx = __uint_as_float(s_maxbits);
-    const float thr = fminf(10.0f * med, 1.2f * mx);
+    const float thr = need_median ? fminf(__fmul_rn(10.0f, med), mx12) : mx12;
     if (REG) {
 #pragma unroll
         for (int q = 0; q < VPT; ++q) {
