@@ -91,6 +91,9 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
 #define LK_FLAG_GRAD_WEIGHTS  (1u << 6)  /* backward: d/d decoder blob                               */
 #define LK_FLAG_GRAD_RAYS     (1u << 7)  /* backward: d/d rays_o, d/d rays_d (tracker / BA)          */
 #define LK_FLAG_ALL_DEPTH_POS (1u << 8)  /* caller guarantees gt_depth > 0 for every ray            */
+#define LK_FLAG_ZERO_ABSENT   (1u << 9)  /* rays with gt_depth <= 0 are ABSENT (filtered rays of a training batch kept for a
+                                           * static shape: the losses ignore them): no far_bb statistics, their samples sit
+                                           * between near_end and 0 */
 
 typedef struct {
     /* ---- sizes */

@@ -24,6 +24,7 @@ FLAG_GRAD_FEATS = 1 << 5
 FLAG_GRAD_WEIGHTS = 1 << 6
 FLAG_GRAD_RAYS = 1 << 7
 FLAG_ALL_DEPTH_POS = 1 << 8
+FLAG_ZERO_ABSENT = 1 << 9
 
 ADAM_MAX_SEG = 16
 

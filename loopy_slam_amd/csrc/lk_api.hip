@@ -121,9 +121,9 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
     LK_REQUIRE(d->depth && d->var && d->color && d->valid_ray, "lk_render_fwd: NULL output buffer");
     hipStream_t st = (hipStream_t)stream_;
     const int P = d->R * d->S;
-    const bool all_pos = (d->flags & LK_FLAG_ALL_DEPTH_POS) != 0;
+    const bool all_pos = (d->flags & (LK_FLAG_ALL_DEPTH_POS | LK_FLAG_ZERO_ABSENT)) != 0;
     if (!all_pos) {
-        LK_REQUIRE(d->far_stats != nullptr, "lk_render_fwd: far_stats required unless ALL_DEPTH_POS");
+        LK_REQUIRE(d->far_stats != nullptr, "lk_render_fwd: far_stats required unless ALL_DEPTH_POS / ZERO_ABSENT");
         lk_launch_depth_stats(d->gt_depth, d->R, d->stats_chunk, d->far_stats, st);
     }
     LkSampleArgs sa;

@@ -87,7 +87,7 @@ class MapOptimizer:
         optim.gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, window, intr, b.as_out(), r2_stack)
         optim.inside_mask(eng, b.gt_depth, None, b.thr, b.scratch_u32, depth_filtered=b.gt_depth)
         core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
-                            self.dec, stage, r2_ray=b.r2_ray, save_act=True)
+                            self.dec, stage, r2_ray=b.r2_ray, save_act=True, extra_flags=_ffi.FLAG_ZERO_ABSENT)
         out4 = log_row if log_row is not None else self._out4()
         optim.loss_mapper(eng, st, b.gt_depth, b.gt_color, self.w_color, stage == 'color', b.d_depth, b.d_color, out4)
         core.render_backward(eng, st, gs, b.d_depth, b.d_color)
@@ -164,7 +164,8 @@ class TrackOptimizer:
             optim.rays_from_pose(eng, cam, b.pix_i, b.pix_j, intr, b.rays_o, b.rays_d)
             optim.inside_mask(eng, b.gt_depth, None, b.thr, b.scratch_u32, depth_filtered=b.gt_depth)
             core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
-                                self.dec, 'color', tracker=True, r2_ray=b.r2_ray, save_act=True)
+                                self.dec, 'color', tracker=True, r2_ray=b.r2_ray, save_act=True,
+                                extra_flags=_ffi.FLAG_ZERO_ABSENT)
             optim.loss_tracker(eng, st, b.gt_depth, b.gt_color, self.w_color, self.use_color, b.d_depth, b.d_color,
                                log[it], b.loss_scratch)
             core.render_backward(eng, st, gs, b.d_depth, b.d_color)
