@@ -163,12 +163,12 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         const float v = lk_half_wave_sum(oo[c3] * gm[m]);
-                        if (lane == 0) atomicAdd(a.g_affine + c3 * 3 + m, v);
+                        if (lane == LK_HWS_LANE) atomicAdd(a.g_affine + c3 * 3 + m, v);
                     }
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     const float v = lk_half_wave_sum(gm[m]);
-                    if (lane == 0) atomicAdd(a.g_affine + 9 + m, v);
+                    if (lane == LK_HWS_LANE) atomicAdd(a.g_affine + 9 + m, v);
                 }
             }
             __syncthreads();                                     // s_o is reused for the d p partials
@@ -330,7 +330,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
                     }
                     if (want_w) {
                         const float s0 = lk_half_wave_sum(ge * a0), s1 = lk_half_wave_sum(ge * a1), s2 = lk_half_wave_sum(ge * a2);
-                        if ((lane & 31) == 0) { part[u] = s0; part[EGP + u] = s1; part[2 * EGP + u] = s2; }
+                        if ((lane & 31) == LK_HWS_LANE) { part[u] = s0; part[EGP + u] = s1; part[2 * EGP + u] = s2; }
                     }
                 }
             }

@@ -288,7 +288,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
                     }
                     if (want_w) {                        // every lane takes part in the reductions (convergent shuffles)
                         const float s0 = lk_half_wave_sum(gx * a0), s1 = lk_half_wave_sum(gx * a1), s2 = lk_half_wave_sum(gx * a2);
-                        if ((lane & 31) == 0 && is_emb) {   // two units (sin, cos) and both half-waves meet in one slot: LDS atomics
+                        if ((lane & 31) == LK_HWS_LANE && is_emb) {   // two units (sin, cos) and both half-waves meet in one slot: LDS atomics
                             atomicAdd(part + xi, s0);
                             atomicAdd(part + 10 + xi, s1);
                             atomicAdd(part + 20 + xi, s2);

@@ -233,9 +233,21 @@ __device__ __forceinline__ void lk_gemm_regs_lds(f32x16& acc, const float4 (&wv)
     }
 }
 
-// sum over the 32 sample columns held by the lanes of one half-wave (lanes with equal lane>>5)
+// Sum over the 32 lanes of each half-wave with DPP adds (plain VALU, no LDS traffic: the ds_bpermute form of the same
+// reduction cost 0.8 ms per benchmark step in the embedding-gradient sections).  quad swaps, then the two mirrors give
+// every lane its 16-lane row total; row_bcast15 adds row 0 (2) into row 1 (3).
+// THE TOTAL IS VALID IN LANES 16..31 AND 48..63 ONLY (lanes with bit 4 set); LK_HWS_LANE is the lane of a half to read.
+#define LK_HWS_LANE 16
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float lk_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float lk_half_wave_sum(float v) {
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+    v += lk_dpp<0xB1, 0xF>(v);          // quad_perm [1,0,3,2]
+    v += lk_dpp<0x4E, 0xF>(v);          // quad_perm [2,3,0,1]
+    v += lk_dpp<0x141, 0xF>(v);         // row_half_mirror: the other quad of the 8-group
+    v += lk_dpp<0x140, 0xF>(v);         // row_mirror: the other 8-group of the row
+    v += lk_dpp<0x142, 0xA>(v);         // row_bcast15 into rows 1 and 3
     return v;
 }
 

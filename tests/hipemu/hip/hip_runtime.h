@@ -139,6 +139,26 @@ static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f
     for (int r = 0; r < 4; ++r) d[r] = di[r];
     return d;
 }
+// DPP data movement (v_mov_b32 dpp): quad_perm, row_shl/shr/ror, row_mirror, row_half_mirror, row_bcast15/31.
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const int lane = hipemu::lane_id(), row = lane >> 4, l16 = lane & 15;
+    int from = lane;
+    bool valid = true;
+    if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl & 15; valid = l16 + n < 16; from = lane + n; }
+    else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl & 15; valid = l16 >= n; from = lane - n; }
+    else if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl & 15; from = (row << 4) | ((l16 - n + 16) & 15); }
+    else if (ctrl == 0x140) from = (row << 4) | (15 - l16);
+    else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
+    else if (ctrl == 0x142) { valid = row >= 1; from = ((row - 1) << 4) | 15; }
+    else if (ctrl == 0x143) { valid = row >= 2; from = 31; }
+    else valid = false;
+    const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> (l16 >> 2)) & 1);
+    const int got = (int)hipemu::wave_exchange_u32((uint32_t)src, valid ? from : lane);     // every lane takes part
+    if (!enabled) return old;
+    if (!valid) return bound_ctrl ? 0 : old;
+    return got;
+}
 static inline float __builtin_amdgcn_exp2f(float v) { return ::exp2f(v); }
 static inline float __builtin_amdgcn_logf(float v) { return ::log2f(v); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
