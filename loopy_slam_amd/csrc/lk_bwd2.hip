@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
                 part += dcc.x * c.x + dcc.y * c.y + dcc.z * c.z + dcc.w * c.w;
             }
         }
-        part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
+        part = lk_sum8(part);
         if (color && relpos && a.dw_rel && has) part += a.dw_rel[(size_t)pidx * LK_K + j];
         dwn[j] = part;
     }
@@ -240,7 +240,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
         }
         {
         float wsum = wgt;
-        wsum += __shfl_xor(wsum, 1); wsum += __shfl_xor(wsum, 2); wsum += __shfl_xor(wsum, 4);
+        wsum = lk_sum8(wsum);
         if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
@@ -250,7 +250,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     float sred = wgt * hid[nb][4 * g + t];
-                    sred += __shfl_xor(sred, 1); sred += __shfl_xor(sred, 2); sred += __shfl_xor(sred, 4);
+                    sred = lk_sum8(sred);
                     v[t] = sred;
                 }
                 if (live && nb_i == 0)
@@ -305,9 +305,9 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     if (want_p) {
         // both halves of a row, then the 8 neighbour rows of the sample; d p = - d (x_I - p)
         dax += __shfl_xor(dax, 32); day += __shfl_xor(day, 32); daz += __shfl_xor(daz, 32);
-        dax += __shfl_xor(dax, 1); dax += __shfl_xor(dax, 2); dax += __shfl_xor(dax, 4);
-        day += __shfl_xor(day, 1); day += __shfl_xor(day, 2); day += __shfl_xor(day, 4);
-        daz += __shfl_xor(daz, 1); daz += __shfl_xor(daz, 2); daz += __shfl_xor(daz, 4);
+        dax = lk_sum8(dax);
+        day = lk_sum8(day);
+        daz = lk_sum8(daz);
         if (live && h == 0 && nb_i == 0) *reinterpret_cast<float4*>(a.dp_rel + (size_t)sp * 4) = make_float4(-dax, -day, -daz, 0.0f);
     }
 }

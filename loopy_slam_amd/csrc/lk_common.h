@@ -251,6 +251,22 @@ __device__ __forceinline__ float lk_half_wave_sum(float v) {
     return v;
 }
 
+// sum over the 8 lanes of an aligned 8-group (the 8 neighbour rows of a sample): every lane gets the total
+__device__ __forceinline__ float lk_sum8(float v) {
+    v += lk_dpp<0xB1, 0xF>(v);
+    v += lk_dpp<0x4E, 0xF>(v);
+    v += lk_dpp<0x141, 0xF>(v);
+    return v;
+}
+// 64-bit value of the partner lane in DPP pairing `CTRL` (quad swaps and the row mirrors are perfect matchings between
+// the two halves of every 2-, 4-, 8- and 16-lane group)
+template <int CTRL>
+__device__ __forceinline__ uint64_t lk_dpp_u64(uint64_t v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
 // per-row vector (bias) of a CT tile: v[unit(r,h)] for r = 0..15, unit0 = first unit of the tile
 __device__ __forceinline__ void lk_add_rowvec(f32x16& acc, const float* __restrict__ v, int unit0, int lane) {
     const int h = lane >> 5;

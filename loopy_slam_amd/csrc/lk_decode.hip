@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float s = wgt * out[0][4 * g + t];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            s = lk_sum8(s);
             v[t] = s;
         }
         if (live && nb_i == 0) {

@@ -33,6 +33,28 @@ __device__ __forceinline__ void lk_top8_insert(uint64_t (&k)[LK_K], uint64_t key
     k[0] = key < k[0] ? key : k[0];
 }
 
+// one butterfly round: my ascending 8-list against the partner's, keep the 8 smallest, re-sort (see the merge note below)
+template <int CTRL>
+__device__ __forceinline__ void lk_knn_merge_round(uint64_t (&k)[LK_K]) {
+#pragma unroll
+    for (int j = 0; j < LK_K / 2; ++j) {           // partner's list reversed against mine, in place
+        const uint64_t hi = lk_dpp_u64<CTRL>(k[LK_K - 1 - j]), lo = lk_dpp_u64<CTRL>(k[j]);
+        k[j] = hi < k[j] ? hi : k[j];
+        k[LK_K - 1 - j] = lo < k[LK_K - 1 - j] ? lo : k[LK_K - 1 - j];
+    }
+#pragma unroll
+    for (int st = LK_K / 2; st > 0; st >>= 1) {
+#pragma unroll
+        for (int j = 0; j < LK_K; ++j) {
+            if ((j & st) == 0) {
+                const uint64_t x = k[j], y = k[j + st];
+                k[j] = y < x ? y : x;
+                k[j + st] = y < x ? x : y;
+            }
+        }
+    }
+}
+
 // All T lanes of a group must call this convergently with the same query (qx,qy,qz,r2).
 // x is the fastest-varying cell coordinate, so the cells [ix0..ix1] of one (iy,iz) row are ONE
 // contiguous range of the cell-sorted point array.
@@ -123,26 +145,12 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
     // A (mine) and B (partner's): L[i] = min(A[i], B[7-i]) is the 8 smallest of the union as a bitonic sequence,
     // which three compare-exchange stages sort.  Straight-line code (the order is total, so both partners end
     // with the identical list).
-#pragma unroll
-    for (int m = 1; m < T; m <<= 1) {
-#pragma unroll
-        for (int j = 0; j < LK_K / 2; ++j) {           // partner's list reversed against mine, in place
-            const uint64_t hi = __shfl_xor(k[LK_K - 1 - j], m), lo = __shfl_xor(k[j], m);
-            k[j] = hi < k[j] ? hi : k[j];
-            k[LK_K - 1 - j] = lo < k[LK_K - 1 - j] ? lo : k[LK_K - 1 - j];
-        }
-#pragma unroll
-        for (int st = LK_K / 2; st > 0; st >>= 1) {
-#pragma unroll
-            for (int j = 0; j < LK_K; ++j) {
-                if ((j & st) == 0) {
-                    const uint64_t x = k[j], y = k[j + st];
-                    k[j] = y < x ? y : x;
-                    k[j + st] = y < x ? x : y;
-                }
-            }
-        }
-    }
+    // round r pairs every lane with one lane of the OTHER half of its 2^(r+1)-lane group: quad swaps for r = 0, 1, then
+    // the mirrors of the 8- and 16-lane groups (DPP moves, no LDS traffic)
+    lk_knn_merge_round<0xB1>(k);
+    lk_knn_merge_round<0x4E>(k);
+    lk_knn_merge_round<0x141>(k);
+    if (T == 16) lk_knn_merge_round<0x140>(k);
 #pragma unroll
     for (int j = 0; j < LK_K; ++j) { d[j] = __uint_as_float((uint32_t)(k[j] >> 32)); id[j] = (int)(uint32_t)k[j]; }
 }
