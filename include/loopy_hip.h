@@ -143,6 +143,8 @@ typedef struct {
     float* g_rays_o;            /* [R,3] (overwritten) */
     float* g_rays_d;            /* [R,3] (overwritten) */
     float* g_affine;            /* [12] accumulated, or NULL */
+    const uint8_t* grad_row_mask; /* [N] or NULL: feature-row gradients are produced only for rows with a non-zero byte
+                                  * (the frustum rows being optimised, Mapper.py:498-512) - the others are never read */
     /* ---- backward scratch */
     float* bwd_scratch;         /* lk_render_bwd_scratch_floats(R,S,flags) floats */
 } lk_render_desc;

@@ -262,6 +262,7 @@ class GradState:
         self.g_rays_o = eng.zeros(R, 3) if rays else None
         self.g_rays_d = eng.zeros(R, 3) if rays else None
         self.g_affine = eng.zeros(12) if affine else None
+        self.row_mask = None            # uint8 [N]: restrict the feature-row gradients to these rows (frustum selection)
         self.scratch = None
 
     def zero_(self):
@@ -289,6 +290,7 @@ def render_backward(eng, st, gs, d_depth, d_color=None, d_var=None):
     d.d_depth, d.d_var, d.d_color = ptr(d_depth), ptr(d_var), ptr(d_color)
     d.g_geo_feats, d.g_col_feats, d.g_weights = ptr(gs.g_geo), ptr(gs.g_col), ptr(gs.g_weights)
     d.g_rays_o, d.g_rays_d, d.g_affine = ptr(gs.g_rays_o), ptr(gs.g_rays_d), ptr(gs.g_affine)
+    d.grad_row_mask = ptr(gs.row_mask)
     d.bwd_scratch = ptr(gs.scratch)
     st.keep_bwd = (d_depth, d_color, d_var)
     eng.lib.check(eng.lib.dll.lk_render_bwd(C.byref(d), eng.stream), 'lk_render_bwd')

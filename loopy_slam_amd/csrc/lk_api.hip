@@ -315,7 +315,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
         LkFeatScatterArgs fs;
         fs.P = P; fs.min_nn = d->min_nn; fs.nbr_idx = d->nbr_idx; fs.nbr_w = d->nbr_w; fs.nbr_count = d->nbr_count;
         fs.dc_geo = S0 + L.dc_geo; fs.dc_col = (color && !relpos) ? S0 + L.dc_col : nullptr; fs.dfeat = relpos ? S0 + L.dfeat : nullptr;
-        fs.g_geo_feats = d->g_geo_feats; fs.g_col_feats = d->g_col_feats;
+        fs.g_geo_feats = d->g_geo_feats; fs.g_col_feats = d->g_col_feats; fs.row_mask = d->grad_row_mask;
         lk_launch_feat_scatter(fs, st);
     }
     if (gr) {

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void k_feat_scatter(LkFeatScatterArgs a) {
     const int idx = a.nbr_idx[row];
     const float w = a.nbr_w[row];
     if (idx < 0 || w == 0.0f || a.nbr_count[s] < a.min_nn) return;
+    if (a.row_mask && !a.row_mask[idx]) return;         // row not being optimised: its gradient is never consumed
     atomicAdd(a.g_geo_feats + (size_t)idx * LK_C + c, w * a.dc_geo[(size_t)s * LK_C + c]);
     if (a.dfeat) atomicAdd(a.g_col_feats + (size_t)idx * LK_C + c, a.dfeat[(size_t)row * LK_C + c]);
     else if (a.dc_col) atomicAdd(a.g_col_feats + (size_t)idx * LK_C + c, w * a.dc_col[(size_t)s * LK_C + c]);

@@ -98,6 +98,7 @@ struct LkFeatScatterArgs {
     const int32_t* nbr_idx; const float* nbr_w; const int32_t* nbr_count;
     const float* dc_geo; const float* dc_col; const float* dfeat;
     float* g_geo_feats; float* g_col_feats;
+    const uint8_t* row_mask;                       // [N] or NULL: scatter only into rows flagged non-zero
 };
 
 struct LkRaysBwdArgs { int R, S; const float* z; const float* dp_total; float* g_rays_o; float* g_rays_d; };

@@ -97,9 +97,9 @@ def gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, w
                   'lk_gather_rays')
 
 
-def frustum_rows(eng, pos, c2w, depth, intr, H, W, edge):
-    """Mapper.get_mask_from_c2w on the device (lk_frustum_rows): int32 tensor of the selected row indices, ascending.
-    One host sync (the count) - once per mapped frame."""
+def frustum_rows(eng, pos, c2w, depth, intr, H, W, edge, return_mask=False):
+    """Mapper.get_mask_from_c2w on the device (lk_frustum_rows): int32 tensor of the selected row indices, ascending
+    (and, with return_mask, the uint8 [N] membership flags).  One host sync (the count) - once per mapped frame."""
     import numpy as np
     fx, fy, cx, cy = intr
     N = pos.shape[0]
@@ -113,7 +113,8 @@ def frustum_rows(eng, pos, c2w, depth, intr, H, W, edge):
     eng.lib.check(eng.lib.dll.lk_frustum_rows(ptr(pos), N, w12, ptr(depth), H, W, C.c_float(fx), C.c_float(fy), C.c_float(cx),
                                               C.c_float(cy), int(edge), ptr(sd), ptr(sm), ptr(smax), ptr(out), ptr(cnt),
                                               eng.stream), 'lk_frustum_rows')
-    return out[:int(cnt.item())]
+    rows = out[:int(cnt.item())]
+    return (rows, sm[:N]) if return_mask else rows
 
 
 def add_points(eng, knn, rays_o, rays_d, gt_depth, r2, near_surface, far_surface, n_add=3):

@@ -115,10 +115,12 @@ class MapOptimizer:
             self.loss_log = self.eng.zeros(4)
         return self.loss_log
 
-    def new_frame(self, row_index):
+    def new_frame(self, row_index, row_mask=None):
         """Start of an optimize_map call: the frustum rows of the new frame (Mapper.py:498-512), a fresh Adam
-        (Mapper.py:570) and clean gradient tables."""
+        (Mapper.py:570) and clean gradient tables.  row_mask (uint8 [N], 1 on the rows of row_index) lets the backward
+        skip the scatter into rows nobody optimises."""
         self.rows = row_index
+        self.gs.row_mask = row_mask
         self.adam = optim.Adam(self.eng)
         self.gs.zero_()
 

@@ -88,8 +88,9 @@ class FrameWorkload:
         best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win, self.intr, rnd_t)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
         fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(eng.device)      # pixels // window frames each
-        self.rows = optim.frustum_rows(eng, self.pos, self.c2w_stack[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge)
-        self.mapper.new_frame(self.rows)
+        self.rows, row_mask = optim.frustum_rows(eng, self.pos, self.c2w_stack[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
+                                                 return_mask=True)
+        self.mapper.new_frame(self.rows, row_mask)
         for it in range(b.map_iters):
             stage = 'geometry' if it < b.map_geo_iters else 'color'
             self.mapper.iterate(stage, self.frames, rnd_m[it], fid, (0, H, 0, W), self.intr, H, W, log_row=self.map_log[it])

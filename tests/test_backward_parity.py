@@ -144,3 +144,27 @@ def test_wgrad_single_vs_matmul(backend, N, K, rows, mode):
     np.testing.assert_allclose(dW.cpu().numpy()[:, :K], ref.numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
     assert float(dW.cpu()[:, K:].abs().max()) == 0.0
     np.testing.assert_allclose(db.cpu().numpy(), refb.numpy(), rtol=1e-4, atol=1e-4 * float(refb.abs().max()))
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('name', ('replica', 'tum'))
+def test_backward_row_mask(backend, name):
+    """grad_row_mask (frustum rows): flagged rows get exactly the unmasked gradient, the others stay untouched;
+    decoder gradients are unaffected."""
+    eng = make_engine(backend)
+    g = load(f'g6_render_{name}_map_color')
+    cfg, dec, st, N, R = setup(eng, name, g, 'color')
+    gen = torch.Generator().manual_seed(3)
+    dd, dc = eng.f32(torch.randn(R, generator=gen)), eng.f32(torch.randn(R, 3, generator=gen))
+    full = core.GradState(eng, N, R, dec.n, feats=True, weights=True)
+    core.render_backward(eng, st, full, dd, dc)
+    mask = (torch.rand(N, generator=gen) < 0.4).to(torch.uint8)
+    part = core.GradState(eng, N, R, dec.n, feats=True, weights=True)
+    part.row_mask = mask.to(eng.device)
+    core.render_backward(eng, st, part, dd, dc)
+    m = mask.bool()
+    for a, b in ((full.g_geo.cpu(), part.g_geo.cpu()), (full.g_col.cpu(), part.g_col.cpu())):
+        scale = float(a.abs().max())
+        assert float((a[m] - b[m]).abs().max()) <= 1e-6 * scale            # same terms, atomics may reorder them
+        assert float(b[~m].abs().max()) == 0.0 and float(a[~m].abs().max()) > 0.0
+    assert relerr(part.g_weights.cpu(), full.g_weights.cpu()) < 1e-6
