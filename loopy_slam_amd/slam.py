@@ -395,10 +395,10 @@ class Mapper:
         self.pipe = pipe
 
     # -- frustum feature selection (Mapper.py:165-217): project every point, bilinear depth lookup, z test
-    def get_mask_from_c2w(self, c2w, depth):
+    def get_mask_from_c2w(self, c2w, depth, return_mask=False):
         """Frustum feature selection (Mapper.py:165-217) on the device: lk_frustum_rows."""
         return optim.frustum_rows(self.eng, self.npc.cloud_pos(), c2w, depth.float().contiguous(), (self.fx, self.fy, self.cx, self.cy),
-                                  self.H, self.W, self.frustum_edge)
+                                  self.H, self.W, self.frustum_edge, return_mask=return_mask)
 
     def filter_point_before_add(self, rays_o, rays_d, gt_depth, prev_c2w):
         pts = rays_o + rays_d * gt_depth[:, None]
@@ -463,7 +463,9 @@ class Mapper:
             dyn = dyn[keep] if dyn is not None else None
         frame_pts_add = npc.add_neural_points(ro, rd, gd, gc, dynamic_radius=dyn)
         # 3. rows to optimise
-        rows = self.get_mask_from_c2w(cur_c2w, cur_gt_depth) if (self.frustum_feature_selection and not color_refine) else None
+        rows = row_mask = None
+        if self.frustum_feature_selection and not color_refine:
+            rows, row_mask = self.get_mask_from_c2w(cur_c2w, cur_gt_depth, return_mask=True)
         # 4. iteration count (Mapper.py:572-574)
         if idx > 0 and not color_refine:
             num_joint_iters = int(np.clip(int(num_joint_iters * frame_pts_add / 300), int(self.min_iter_ratio * num_joint_iters),
@@ -478,6 +480,7 @@ class Mapper:
                                 rows, R, lrs, w_color=self.w_color_loss, dynamic_radius=self.use_dynamic_radius,
                                 dist=getattr(self.slam, 'dist', None))
         mo.begin_frame()
+        mo.gs.row_mask = row_mask               # the backward only scatters into the rows being optimised
         stack = (torch.stack(frames_d).contiguous(), torch.stack(frames_c).contiguous(),
                  torch.stack([p.float() for p in frames_p]).contiguous(),
                  torch.stack(frames_r).contiguous() if frames_r is not None else None)
