@@ -106,7 +106,10 @@ class MapOptimizer:
             if stage == 'color':
                 segs.append(('col', self.col.view(-1), gs.g_col.view(-1), clr))
         self.adam.step(segs, zero_grad=True)
-        self.dec.repack()
+        if stage == 'color':
+            # the geometry stage only moves the embedding matrices (read from the plain blob); the MFMA fragments are
+            # copies of the colour-decoder matrices, which only change in the colour stage
+            self.dec.repack()
         self.it += 1
         return out4
 
