@@ -9,35 +9,48 @@ import torch
 import torch.distributed as dist
 
 
+def _merge(ranges, gap=4096):
+    """(offset, n) ranges -> few contiguous spans (alignment padding between neighbouring tensors rides along: one copy
+    kernel per span instead of one per tensor)."""
+    out = []
+    for off, n in sorted(ranges):
+        if out and off - (out[-1][0] + out[-1][1]) <= gap:
+            out[-1] = (out[-1][0], off + n - out[-1][0])
+        else:
+            out.append((off, n))
+    return out
+
+
 class DistContext:
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
         self._bucket = None
 
-    def all_reduce_grads(self, mo):
-        """mo: steps.MapOptimizer after render_backward.  Sum g_weights, g_geo[rows], g_col[rows] over ranks."""
+    def all_reduce_grads(self, mo, stage='color'):
+        """mo: steps.MapOptimizer after render_backward.  Sum over ranks exactly what this stage's Adam step consumes:
+        the decoder-gradient ranges being stepped (geometry: embedder._B only; colour: + every colour-decoder tensor),
+        g_geo[rows], and in the colour stage g_col[rows] - one bucket, one all-reduce."""
         gs = mo.gs
         rows = mo.rows.long() if mo.rows is not None else None
-        parts = [gs.g_weights]
-        if rows is not None:
-            parts += [gs.g_geo.index_select(0, rows).reshape(-1), gs.g_col.index_select(0, rows).reshape(-1)]
-        else:
-            parts += [gs.g_geo.reshape(-1), gs.g_col.reshape(-1)]
+        ranges = _merge(list(mo.geo_dec_ranges) + (list(mo.col_dec_ranges) if stage == 'color' else []))
+        tables = [gs.g_geo] + ([gs.g_col] if stage == 'color' else [])
+        parts = [gs.g_weights[o:o + n] for o, n in ranges]
+        parts += [(t.index_select(0, rows) if rows is not None else t).reshape(-1) for t in tables]
         n = sum(p.numel() for p in parts)
         if self._bucket is None or self._bucket.numel() != n:
             self._bucket = torch.empty(n, dtype=torch.float32, device=parts[0].device)
         torch.cat(parts, out=self._bucket)
         dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
         o = 0
-        gs.g_weights.copy_(self._bucket[o:o + gs.g_weights.numel()]); o += gs.g_weights.numel()
-        if rows is not None:
-            k = rows.numel() * 32
-            gs.g_geo.index_copy_(0, rows, self._bucket[o:o + k].view(-1, 32)); o += k
-            gs.g_col.index_copy_(0, rows, self._bucket[o:o + k].view(-1, 32)); o += k
-        else:
-            k = gs.g_geo.numel()
-            gs.g_geo.view(-1).copy_(self._bucket[o:o + k]); o += k
-            gs.g_col.view(-1).copy_(self._bucket[o:o + k]); o += k
+        for off, cnt in ranges:
+            gs.g_weights[off:off + cnt].copy_(self._bucket[o:o + cnt]); o += cnt
+        for t in tables:
+            if rows is not None:
+                k = rows.numel() * t.shape[1]
+                t.index_copy_(0, rows, self._bucket[o:o + k].view(-1, t.shape[1])); o += k
+            else:
+                k = t.numel()
+                t.view(-1).copy_(self._bucket[o:o + k]); o += k
 
     def all_reduce_vec(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

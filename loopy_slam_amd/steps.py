@@ -92,7 +92,7 @@ class MapOptimizer:
         optim.loss_mapper(eng, st, b.gt_depth, b.gt_color, self.w_color, stage == 'color', b.d_depth, b.d_color, out4)
         core.render_backward(eng, st, gs, b.d_depth, b.d_color)
         if self.dist is not None:
-            self.dist.all_reduce_grads(self)
+            self.dist.all_reduce_grads(self, stage)
         dlr, glr, clr = self.lrs[stage]
         segs = [(('gdec', k), self.dec.blob[o:o + n], gs.g_weights[o:o + n], dlr) for k, (o, n) in enumerate(self.geo_dec_ranges)]
         if stage == 'color':
