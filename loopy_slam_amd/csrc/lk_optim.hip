@@ -374,8 +374,10 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
             if (v) { ++mycnt; mymax = max(mymax, v); }
         }
     }
-    atomicAdd(&s_cnt, mycnt);
-    atomicMax(&s_maxbits, mymax);
+    // one LDS atomic per WAVE (1024 same-address atomics cost microseconds)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mycnt += __shfl_xor(mycnt, o); mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, o)); }
+    if (lane == 0) { atomicAdd(&s_cnt, mycnt); atomicMax(&s_maxbits, mymax); }
     __syncthreads();
     const unsigned m = s_cnt;
     if (m == 0) {
@@ -397,7 +399,9 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
         }
         if (t == 0) s_rank = 0;
         __syncthreads();
-        atomicAdd(&s_rank, below);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+        if (lane == 0) atomicAdd(&s_rank, below);
         __syncthreads();
     }
     const bool need_median = s_rank > (m - 1) / 2;                    // block-uniform
