@@ -26,6 +26,8 @@ def run(budget, seed=1219):
     intr = (syn.TUM_INTR['fx'], syn.TUM_INTR['fy'], syn.TUM_INTR['cx'], syn.TUM_INTR['cy'])
     cfg = H.RenderCfg(rel_pos=budget.rel_pos)
     r2 = float(cfg.radius_query ** 2)
+    # rows optimised by the mapper = frustum selection of the mapped frame, as in the GPU workload (untimed here)
+    rows = torch.from_numpy(H.frustum_rows(pos.numpy(), c2w.numpy(), depth.numpy(), *intr, Hh, Ww, budget.frustum_edge)).long()
 
     def batch(R, c2w_):
         idx = torch.randint(0, Hh * Ww, (R,), generator=g)
@@ -44,12 +46,14 @@ def run(budget, seed=1219):
     def map_iter(stage):
         Wt = {k: (v.clone().requires_grad_(True) if k.startswith('color_decoder') or k == 'geo_decoder.embedder._B' else v)
               for k, v in W.items()}
-        gp, cp = geo.clone().requires_grad_(True), col.clone().requires_grad_(True)
+        gp, cp = geo[rows].clone().requires_grad_(True), col[rows].clone().requires_grad_(True)     # Mapper.py:578-586
         opt = torch.optim.Adam([{'params': [v for v in Wt.values() if v.requires_grad], 'lr': 0.005},
                                 {'params': [gp], 'lr': 0.005}, {'params': [cp], 'lr': 0.005}])
         t0 = time.perf_counter()
         ro, rd, gd, gc = batch(budget.map_rays, c2w)
-        out = H.render_batch(cfg, ro, rd, gd, pos, gp, cp, Wt, stage, knn=knn_for(ro, rd, gd))
+        geo_t, col_t = geo.clone(), col.clone()
+        geo_t[rows], col_t[rows] = gp, cp
+        out = H.render_batch(cfg, ro, rd, gd, pos, geo_t, col_t, Wt, stage, knn=knn_for(ro, rd, gd))
         loss, _, _, _ = H.mapper_loss(out['depth'], out['color'], out['valid_ray'], gd, gc, stage, 0.1)
         loss.backward()
         opt.step()
