@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
 // The four waves of a workgroup are four consecutive UNITS of the same row chunk, and the grid walks units fastest:
 // the pieces of A / A2 / B that several units need are fetched from HBM once and re-read from L1/L2.
 #define WG_STEPS 16
+#define WG_CHUNK (2 * WG_STEPS)                     // rows per chunk = one ring of row pairs
 
 template <int V> struct WgVec;
 template <> struct WgVec<1> { float v[1]; };
@@ -361,7 +362,7 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
 }
 
 template <int NV, int KV, int MODE>
-__device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int c1, int lane,
+__device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int j, int n_waves, int lane,
                                            float* __restrict__ tile) {
     const int i = lane & 31, h = lane >> 5;
     // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
@@ -388,30 +389,31 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
     float bsum[NV];
 #pragma unroll
     for (int b = 0; b < NV; ++b) bsum[b] = 0.0f;
-    const int last = c1 - 1;
+    // this wave's rows: chunks j, j + n_waves, j + 2 n_waves, ... of WG_CHUNK = 2 * WG_STEPS rows each
+    const int rows = J.rows, last = rows - 1;
+    const int n_chunks = (rows + WG_CHUNK - 1) / WG_CHUNK;
+    const int my_chunks = (j < n_chunks) ? (n_chunks - j + n_waves - 1) / n_waves : 0;
     WgVec<NV> ra[WG_STEPS], ra2[WG_STEPS];
     WgVec<KV> rb[WG_STEPS];
     float rw[WG_STEPS];
-    auto fetch1 = [&](int s, int row0) {
-        int row = row0 + 2 * s + h;
-        row = row < last ? row : last;
+    auto fetch1 = [&](int s, int n) {              // slot s <- row pair s of this wave's n-th chunk (clamped past the end)
+        int row = (j + n * n_waves) * WG_CHUNK + 2 * s + h;
+        row = (row < last && n < my_chunks) ? row : last;
         ra[s] = wg_load<NV>(pA + (size_t)row * lda);
         if (mode == 1) ra2[s] = wg_load<NV>(pA2 + (size_t)row * lda2);
         if (mode == 2) rw[s] = pA2[row];
         rb[s] = wg_load<KV>(pB + (size_t)row * ldb);
     };
-    auto fetch = [&](int row0) {
+    // Register ring of WG_STEPS row pairs = one chunk: slot s is consumed (its 3 loads are the oldest outstanding ones)
+    // and immediately refilled with the same pair of the wave's NEXT chunk, so WG_STEPS - 1 pairs are always in
+    // flight behind the MFMAs.  Refills past the end re-read the last row (clamped address) and are masked when consumed.
 #pragma unroll
-        for (int s = 0; s < WG_STEPS; ++s) { fetch1(s, row0); __builtin_amdgcn_sched_barrier(0); }    // issue in slot order
-    };
-    // Register ring of WG_STEPS row pairs: slot s is consumed (its 3 loads are the oldest outstanding ones) and
-    // immediately refilled with the pair WG_STEPS further on, so WG_STEPS - 1 pairs are always in flight behind the
-    // MFMAs.  Refills past the end re-read the last row (clamped address) and are masked when consumed.
-    fetch(c0);
-    for (int row0 = c0; row0 < c1; row0 += 2 * WG_STEPS) {
+    for (int s = 0; s < WG_STEPS; ++s) { fetch1(s, 0); __builtin_amdgcn_sched_barrier(0); }    // issue in slot order
+    for (int n = 0; n < my_chunks; ++n) {
+        const int row0 = (j + n * n_waves) * WG_CHUNK;
 #pragma unroll
         for (int s = 0; s < WG_STEPS; ++s) {
-            const bool ok = row0 + 2 * s + h < c1;
+            const bool ok = row0 + 2 * s + h < rows;
             float av[NV], bv[KV];
 #pragma unroll
             for (int b = 0; b < NV; ++b) {
@@ -427,7 +429,7 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
             for (int bn = 0; bn < NV; ++bn)
 #pragma unroll
                 for (int bk = 0; bk < KV; ++bk) acc[bn][bk] = lk_mfma(av[bn], bv[bk], acc[bn][bk]);
-            fetch1(s, row0 + 2 * WG_STEPS);
+            fetch1(s, n + 1);
             __builtin_amdgcn_sched_barrier(0);          // keep consume(s) -> refill(s) order: the ring IS the schedule
         }
     }
@@ -469,29 +471,35 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 }
 
 template <int NV, int KV>
-__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int c1, int lane, float* tile) {
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0>(J, n0, k0, c0, c1, lane, tile);
-    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1>(J, n0, k0, c0, c1, lane, tile);
-    else wgrad_unit<NV, KV, 2>(J, n0, k0, c0, c1, lane, tile);
+__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int j, int n_waves, int lane, float* tile) {
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0>(J, n0, k0, j, n_waves, lane, tile);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1>(J, n0, k0, j, n_waves, lane, tile);
+    else wgrad_unit<NV, KV, 2>(J, n0, k0, j, n_waves, lane, tile);
 }
 
+// Wave g of the launch belongs to the unit whose [wave0, wave0 + n_waves) range holds g.  Every unit gets a number of
+// waves proportional to its work (rows x MFMAs per row pair), all of a launch's waves are co-resident (two per SIMD),
+// and wave j of a unit takes the chunks j, j + n_waves, ... of 32 rows: the units sweep the rows at the same speed (the
+// operands several units share are still fetched from HBM once) and every wave finishes at about the same time.
 __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     const int lane = lk_lane();
-    const int u = lk_uniform((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));     // unit of this wave: scalar
-    if (u >= a.n_units) return;
+    const int g = lk_uniform((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));
+    if (g >= a.n_waves) return;
+    int u = 0;
+    while (u + 1 < a.n_units && g >= a.unit[u + 1].wave0) ++u;        // scalar scan, <= 48 entries
     const LkWgradUnit& U = a.unit[u];
     const LkWgradJob& J = a.job[U.job];
-    const int c0 = (int)blockIdx.y * a.chunk;                          // rows [c0, c1) of the job
-    if (c0 >= J.rows) return;                                          // wave-uniform
-    const int c1 = (c0 + a.chunk < J.rows) ? c0 + a.chunk : J.rows;
-    float* tile = a.part ? a.part + ((size_t)blockIdx.y * a.n_units + u) * LK_WG_TILE : nullptr;
-    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2>(J, U.n0, U.k0, c0, c1, lane, tile);
-    else if (U.nv == 2) wgrad_unit_mode<2, 1>(J, U.n0, U.k0, c0, c1, lane, tile);
-    else if (U.kv == 2) wgrad_unit_mode<1, 2>(J, U.n0, U.k0, c0, c1, lane, tile);
-    else wgrad_unit_mode<1, 1>(J, U.n0, U.k0, c0, c1, lane, tile);
+    const int j = g - U.wave0;
+    const int n_chunks = (J.rows + WG_CHUNK - 1) / WG_CHUNK;
+    if (j >= n_chunks) return;                                         // more waves than chunks (tiny problems)
+    float* tile = a.part ? a.part + (size_t)g * LK_WG_TILE : nullptr;
+    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2>(J, U.n0, U.k0, j, U.n_waves, lane, tile);
+    else if (U.nv == 2) wgrad_unit_mode<2, 1>(J, U.n0, U.k0, j, U.n_waves, lane, tile);
+    else if (U.kv == 2) wgrad_unit_mode<1, 2>(J, U.n0, U.k0, j, U.n_waves, lane, tile);
+    else wgrad_unit_mode<1, 1>(J, U.n0, U.k0, j, U.n_waves, lane, tile);
 }
 
-// dW += sum over row chunks of the partial tiles (tile order: contiguous reads; every output element is owned by
+// dW += sum over the unit's waves of the partial tiles (tile order: contiguous reads; every output element is owned by
 // exactly one thread, so the read-modify-write of dW needs no atomics and the result is run-to-run reproducible).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
     __shared__ float sh[8][32];
@@ -503,9 +511,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
     const int idx = (int)blockIdx.y * 32 + e;
     const bool in_acc = idx < nv * kv * 1024, in_bias = idx >= 4 * 16 * 64 && idx < 4 * 16 * 64 + 32 * nv;
     if (!in_acc && !in_bias && (int)blockIdx.y * 32 + 31 >= nv * kv * 1024 && (int)blockIdx.y * 32 < 4 * 16 * 64) return;   // unused blocks of a narrow unit
-    const int nblk = (J.rows + a.chunk - 1) / a.chunk;
-    const size_t stride = (size_t)a.n_units * LK_WG_TILE;
-    const float* __restrict__ src = a.part + (size_t)blockIdx.x * LK_WG_TILE + idx;
+    const int n_chunks = (J.rows + WG_CHUNK - 1) / WG_CHUNK;
+    const int nblk = U.n_waves < n_chunks ? U.n_waves : n_chunks;      // waves of the unit that stored a tile
+    const size_t stride = LK_WG_TILE;
+    const float* __restrict__ src = a.part + (size_t)U.wave0 * LK_WG_TILE + idx;
     float s = 0.0f;
     if (in_acc || in_bias) {
 #pragma unroll 4
@@ -552,6 +561,7 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
     LkWgradArgs a = a_in;
     // cut every job into (N piece) x (K piece) units of 32 or 64 columns
     a.n_units = 0;
+    double work[LK_WGRAD_MAX_UNITS], total = 0.0;
     for (int j = 0; j < a.n_jobs; ++j) {
         const LkWgradJob& J = a.job[j];
         for (int n0 = 0; n0 < J.N; n0 += 64) {
@@ -559,29 +569,30 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
             for (int k0 = 0; k0 < J.K; k0 += 64) {
                 const int kv = (J.K - k0 > 32) ? 2 : 1;
                 if (a.n_units >= LK_WGRAD_MAX_UNITS) return LK_ERR_ARG;
-                LkWgradUnit& U = a.unit[a.n_units++];
+                LkWgradUnit& U = a.unit[a.n_units];
                 U.job = j; U.n0 = n0; U.k0 = k0; U.nv = nv; U.kv = kv;
+                // cost of a row pair: the MFMAs plus about one MFMA's worth of loads / element-wise work
+                work[a.n_units] = (double)J.rows * (nv * kv + (J.a_mode == 1 ? 1.0 : 0.5));
+                total += work[a.n_units++];
             }
         }
     }
-    if (a.part) {
-        a.chunk = LK_WG_CHUNK;
-        {
-            LkProfScope prof_(LKK_WGRAD, st);                          // timing scope = k_wgrad alone (as rocprof reports it)
-            hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_units, 4), lk_cdiv(max_rows, a.chunk)), dim3(256), 0, st, a);
-        }
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(a.n_units, lk_cdiv(LK_WG_TILE, 32)), dim3(256), 0, st, a);
-        return LK_OK;
+    // waves per unit in proportion to its work, LK_WG_MAX_WAVES in total (two per SIMD, all co-resident), at most one
+    // wave per 32-row chunk
+    int next = 0;
+    for (int u = 0; u < a.n_units; ++u) {
+        LkWgradUnit& U = a.unit[u];
+        const int n_chunks = lk_cdiv(a.job[U.job].rows, WG_CHUNK);
+        int w = (int)((LK_WG_MAX_WAVES - a.n_units) * (work[u] / total)) + 1;
+        if (w > n_chunks) w = n_chunks > 0 ? n_chunks : 1;
+        U.wave0 = next; U.n_waves = w;
+        next += w;
     }
-    // atomic flush (no partial buffer): rows per wave for about 4000 waves, never below 64 rows per wave
-    if (a.chunk <= 0) {
-        long long chunks = 4096 / a.n_units;
-        if (chunks < 1) chunks = 1;
-        long long chunk = (max_rows + chunks - 1) / chunks;
-        chunk = ((chunk + 15) / 16) * 16;
-        a.chunk = (int)(chunk < 64 ? 64 : chunk);
+    a.n_waves = next;
+    {
+        LkProfScope prof_(LKK_WGRAD, st);                              // timing scope = k_wgrad alone (as rocprof reports it)
+        hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_waves, 4)), dim3(256), 0, st, a);
     }
-    LkProfScope prof_(LKK_WGRAD, st);
-    hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_units, 4), lk_cdiv(max_rows, a.chunk)), dim3(256), 0, st, a);
+    if (a.part) hipLaunchKernelGGL(k_wgrad_reduce, dim3(a.n_units, lk_cdiv(LK_WG_TILE, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }

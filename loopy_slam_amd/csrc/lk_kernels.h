@@ -136,22 +136,17 @@ struct LkWgradJob {
 };
 #define LK_WGRAD_MAX_JOBS 16
 #define LK_WGRAD_MAX_UNITS 48
-struct LkWgradUnit { int job, n0, k0; short nv, kv; };   // columns [n0, n0 + 32 nv) x [k0, k0 + 32 kv) of job
+struct LkWgradUnit { int job, n0, k0; short nv, kv; int wave0, n_waves; };   // columns [n0, n0 + 32 nv) x [k0, k0 + 32 kv) of job; its waves
 struct LkWgradArgs {
     LkWgradJob job[LK_WGRAD_MAX_JOBS]; int n_jobs;
-    int chunk;                                     // rows per wave; <= 0: chosen by the launcher
-    LkWgradUnit unit[LK_WGRAD_MAX_UNITS]; int n_units;   // filled by the launcher
-    float* part;                                   // [row chunks][n_units][LK_WG_TILE] partial tiles, or NULL (atomic flush)
+    int chunk;                                     // unused (kept for lk_wgrad_single's signature)
+    LkWgradUnit unit[LK_WGRAD_MAX_UNITS]; int n_units, n_waves;   // filled by the launcher
+    float* part;                                   // [n_waves][LK_WG_TILE] partial tiles (one per wave), or NULL (atomic flush)
 };
-#define LK_WG_CHUNK 512                            // rows per wave when partial tiles are used
-#define LK_WG_TILE (4 * 16 * 64 + 64)              // floats per unit tile: accumulators [block][reg][lane] + bias sums
-// floats of LkWgradArgs::part needed by lk_render_bwd for P sample points (colour launch <= 32 units over P rows,
-// rel-pos launch <= 4 units over 8 P rows)
-inline int64_t lk_wgrad_part_floats(int64_t P, bool relpos) {
-    const int64_t col = ((P + LK_WG_CHUNK - 1) / LK_WG_CHUNK) * 32 * LK_WG_TILE;
-    const int64_t rel = relpos ? ((8 * P + LK_WG_CHUNK - 1) / LK_WG_CHUNK) * 4 * LK_WG_TILE : 0;
-    return col > rel ? col : rel;
-}
+#define LK_WG_MAX_WAVES 2048                       // waves of one weight-gradient launch: two per SIMD, all co-resident
+#define LK_WG_TILE (4 * 16 * 64 + 64)              // floats per tile: accumulators [block][reg][lane] + bias sums
+// floats of LkWgradArgs::part (one tile per wave, whatever the problem size)
+inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_WAVES * LK_WG_TILE; }
 
 int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st);
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st);
