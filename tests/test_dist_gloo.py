@@ -46,6 +46,15 @@ def draws():
 
 
 def worker(rank, port, q):
+    try:
+        _worker(rank, port, q)
+    except Exception:                                   # surface the reason in the parent instead of a bare exit code
+        import traceback
+        q.put(('error', rank, traceback.format_exc()))
+        raise
+
+
+def _worker(rank, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.set_num_threads(1)
@@ -81,19 +90,30 @@ def test_two_rank_grad_allreduce_matches_single_process():
     for it in range(ITERS):
         out4 = mo.iterate(STAGES[it], frames, rnd[it].reshape(-1).contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
         ref_losses.append(float(out4[0]))
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = None
+    for attempt in range(2):                             # one retry: the free-port probe / gloo rendezvous can lose a race
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=worker, args=(r, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            res = [q.get(timeout=600) for _ in range(2)]
+        except Exception as e:
+            res = [('error', -1, repr(e))]
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+        errs = [r for r in res if r[0] == 'error']
+        if not errs and all(p.exitcode == 0 for p in procs):
+            break
+        if attempt == 1:
+            raise AssertionError(f'workers failed: {errs} exit codes {[p.exitcode for p in procs]}')
     full = [r for r in res if r[2] is not None][0]
     other = [r for r in res if r[2] is None][0]
     np.testing.assert_allclose(full[0], ref_losses, rtol=1e-5)
