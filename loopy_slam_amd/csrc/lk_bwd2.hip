@@ -210,36 +210,10 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) dout[0][q] *= wgt;
-    // ---- d hid = (W2^T d out) * softplus'(hid)
-    f32x16 dhid[4];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) dhid[kb] = lk_zero16();
-    lk_gemm_frag<4, 4>(dhid, F + FM21_TR, 4, 0, 0, dout[0], lane);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dhid[nb][q] *= lk_softplus100_grad_from_out(hid[nb][q]);
+    // ---- operands of the streamed weight-gradient reductions that need hid itself
+    //   linear2: dW2 = sum_rows (w d c) hid^T = sum_samples d c (sum_j w_j hid_j)^T  -> only the per-SAMPLE weighted
+    //            hidden vector Hbar [P][128] and the per-sample weight sum are needed (8x fewer rows, no hid rows)
     if (want_w) {
-        // operands of the streamed weight-gradient reductions.
-        //   linear1: rows [8P][192] = d hid (128) | x (64)
-        //   linear2: dW2 = sum_rows (w d c) hid^T = sum_samples d c (sum_j w_j hid_j)^T  -> only the per-SAMPLE weighted
-        //            hidden vector Hbar [P][128] and the per-sample weight sum are needed (8x fewer rows, no hid rows)
-        if (live) {
-            if (h == 0) a.w_eff[(size_t)sp * 8 + nb_i] = wgt;
-            float* row = a.rows + ((size_t)sp * 8 + nb_i) * 192;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(row + nb * 32 + 8 * g + 4 * h) =
-                        make_float4(dhid[nb][4 * g], dhid[nb][4 * g + 1], dhid[nb][4 * g + 2], dhid[nb][4 * g + 3]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<float4*>(row + 128 + 8 * g + 4 * h) = make_float4(x0[4 * g], x0[4 * g + 1], x0[4 * g + 2], x0[4 * g + 3]);
-                *reinterpret_cast<float4*>(row + 160 + 8 * g + 4 * h) = make_float4(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3]);
-            }
-        }
-        {
         float wsum = wgt;
         wsum = lk_sum8(wsum);
         if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
@@ -256,6 +230,33 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
                 }
                 if (live && nb_i == 0)
                     *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
+    // ---- d hid = (W2^T d out) * softplus'(hid), block by block IN PLACE of hid (64 fewer live registers)
+    f32x16 (&dhid)[4] = hid;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        f32x16 t[1];
+        t[0] = lk_zero16();
+        lk_gemm_frag<1, 4>(t, F + FM21_TR, 4, 0, nb, dout[0], lane);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dhid[nb][q] = t[0][q] * lk_softplus100_grad_from_out(hid[nb][q]);
+    }
+    if (want_w) {
+        //   linear1: rows [8P][192] = d hid (128) | x (64)
+        if (live) {
+            if (h == 0) a.w_eff[(size_t)sp * 8 + nb_i] = wgt;
+            float* row = a.rows + ((size_t)sp * 8 + nb_i) * 192;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(row + nb * 32 + 8 * g + 4 * h) =
+                        make_float4(dhid[nb][4 * g], dhid[nb][4 * g + 1], dhid[nb][4 * g + 2], dhid[nb][4 * g + 3]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(row + 128 + 8 * g + 4 * h) = make_float4(x0[4 * g], x0[4 * g + 1], x0[4 * g + 2], x0[4 * g + 3]);
+                *reinterpret_cast<float4*>(row + 160 + 8 * g + 4 * h) = make_float4(x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3]);
             }
         }
     }
