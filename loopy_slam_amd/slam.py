@@ -9,7 +9,7 @@
 
 All arithmetic of the hot path runs in libloopyhip (loopy_slam_amd.core / .steps / .optim); what remains here is
 per-frame bookkeeping in torch.  Out of scope: loop closure / fragments, datasets, meshing,
-visualisation, checkpoints, the mapper-side exposure affine.  Every class takes an optional `eng` (core.Engine);
+visualisation.  Every class takes an optional `eng` (core.Engine);
 the default is the gfx950 library on the current CUDA device.
 """
 import math
@@ -453,6 +453,10 @@ class Mapper:
             _, r2_add_map, r2_query_map = frame_radius_maps(eng, cfg, cur_gt_color)
             self.cur_r2_query = r2_query_map
         frames_r = ([keyframe_dict[k]['r2_query'] for k in sel] + [r2_query_map]) if self.use_dynamic_radius else None
+        exposure = None
+        if self.slam.encode_exposure:               # per-keyframe exposure features + the current frame's (Mapper.py:588-607)
+            self.cur_exposure_feat = self.slam.exposure_feat.detach().clone().requires_grad_(True)
+            exposure = (self.decoders.mlp_exposure, [keyframe_dict[k]['exposure_feat'] for k in sel] + [self.cur_exposure_feat])
         # 2. add neural points seen by the current frame (Mapper.py:429-482)
         ro, rd, gd, gc, i, j = get_samples(0, H, 0, W, self.pixels_adding, H, W, *intr, cur_c2w, cur_gt_depth, cur_gt_color,
                                            eng.device, depth_filter=True, return_index=True, generator=None)
@@ -478,7 +482,7 @@ class Mapper:
         rcfg = render_cfg_from(cfg, cfg['rendering']['sigmoid_coef_mapper'])
         mo = steps.MapOptimizer(eng, rcfg, self.decoders.dec, npc.knn, npc.cloud_pos(), npc.get_geo_feats(), npc.get_col_feats(),
                                 rows, R, lrs, w_color=self.w_color_loss, dynamic_radius=self.use_dynamic_radius,
-                                dist=getattr(self.slam, 'dist', None))
+                                dist=getattr(self.slam, 'dist', None), exposure=exposure)
         mo.begin_frame()
         mo.gs.row_mask = row_mask               # the backward only scatters into the rows being optimised
         stack = (torch.stack(frames_d).contiguous(), torch.stack(frames_c).contiguous(),
@@ -503,7 +507,8 @@ class Mapper:
         if idx % self.keyframe_every == 0 or idx == self.slam.n_img - 2:
             self.keyframe_list.append(idx)
             self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': gt_color, 'depth': gt_depth, 'est_c2w': cur_c2w.clone(),
-                                       'r2_query': getattr(self, 'cur_r2_query', None)})
+                                       'r2_query': getattr(self, 'cur_r2_query', None),
+                                       'exposure_feat': getattr(self, 'cur_exposure_feat', None)})
         self.slam.mapping_idx[0] = idx
         return self.last_log
 
@@ -607,8 +612,14 @@ class Tracker:
                                       self.npc.get_col_feats(), n_px, self.cam_lr, separate_lr=self.separate_LR,
                                       w_color=self.w_color_loss, use_color=self.use_color_in_tracking,
                                       dynamic_radius=r2_query is not None)
+            exposure = None
+            if slam.encode_exposure:                # this frame's exposure feature starts from the shared one (Tracker.py:280-283)
+                self.exposure_feat = slam.exposure_feat.detach().clone().requires_grad_(True)
+                exposure = (self.decoders.mlp_exposure, self.exposure_feat)
             best, log = to.track(cam, gt_depth, gt_color, self.num_cam_iters, win_it, (self.fx, self.fy, self.cx, self.cy), rnd,
-                                 r2_map=r2_query)
+                                 r2_map=r2_query, exposure=exposure)
+            if slam.encode_exposure:
+                slam.exposure_feat = self.exposure_feat.detach().clone()           # Tracker.py:412-414
             self.last_log = log
             c2w = torch.eye(4, device=eng.device)
             c2w[:3] = get_camera_from_tensor(best)
@@ -654,6 +665,10 @@ class Point_SLAM:
         self.gt_c2w_list = torch.zeros((self.n_img, 4, 4))
         self.idx = torch.zeros(1, dtype=torch.int32)
         self.mapping_idx = torch.zeros(1, dtype=torch.int32)
+        # one shared exposure feature, cloned by the tracker for every frame and kept per keyframe by the mapper
+        # (Point_SLAM.py:90-96; model.encode_exposure, ScanNet)
+        self.encode_exposure = cfg['model']['encode_exposure']
+        self.exposure_feat = torch.zeros(cfg['model']['exposure_dim'], device=self.eng.device) if self.encode_exposure else None
         self.npc = NeuralPointCloud(cfg, self, args, eng=self.eng)
         self.renderer = Renderer(cfg, args, self)
         self.renderer_map = Renderer(cfg, args, self)

@@ -53,7 +53,7 @@ class MapOptimizer:
     """One optimize_map call: Adam over {decoder params, selected geo rows, selected colour rows}."""
 
     def __init__(self, eng, cfg, dec, knn, pos, geo_feats, col_feats, row_index, R, lrs, w_color=0.1,
-                 dynamic_radius=False, fix_color_decoder=False, dist=None):
+                 dynamic_radius=False, fix_color_decoder=False, dist=None, exposure=None):
         """row_index: int32 [n_f] rows being optimised (frustum selection, Mapper.py:498-512) or None = all rows.
         lrs: dict stage -> (decoders_lr, geometry_lr, color_lr)  (configs mapping.stage.*)."""
         self.eng, self.cfg, self.dec, self.knn = eng, cfg, dec, knn
@@ -77,6 +77,10 @@ class MapOptimizer:
         self.loss_log = None
         self.dist = dist
         self.it = 0
+        # exposure = (mlp_exposure torch module, [exposure_feat tensor per frame of the window]) for model.encode_exposure
+        # (ScanNet): per-keyframe colour affine applied to the RENDERED colour logits (Mapper.py:697-715)
+        self.exposure = exposure
+        self.exp_opt = None
 
     def iterate(self, stage, frames, rnd, frame_id, window, intr, H, W, log_row=None):
         """One joint iteration (Mapper.py:576-735).
@@ -87,9 +91,13 @@ class MapOptimizer:
         optim.gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, window, intr, b.as_out(), r2_stack)
         optim.inside_mask(eng, b.gt_depth, None, b.thr, b.scratch_u32, depth_filtered=b.gt_depth)
         core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
-                            self.dec, stage, r2_ray=b.r2_ray, save_act=True, extra_flags=_ffi.FLAG_ZERO_ABSENT)
+                            self.dec, stage, r2_ray=b.r2_ray, save_act=True, extra_flags=_ffi.FLAG_ZERO_ABSENT,
+                            color_logits=self.exposure is not None)
         out4 = log_row if log_row is not None else self._out4()
-        optim.loss_mapper(eng, st, b.gt_depth, b.gt_color, self.w_color, stage == 'color', b.d_depth, b.d_color, out4)
+        if self.exposure is not None and stage == 'color':
+            self._exposure_loss(st, b, frame_id, out4)
+        else:
+            optim.loss_mapper(eng, st, b.gt_depth, b.gt_color, self.w_color, stage == 'color', b.d_depth, b.d_color, out4)
         core.render_backward(eng, st, gs, b.d_depth, b.d_color)
         if self.dist is not None:
             self.dist.all_reduce_grads(self, stage)
@@ -112,6 +120,31 @@ class MapOptimizer:
             self.dec.repack()
         self.it += 1
         return out4
+
+    def _exposure_loss(self, st, b, frame_id, out4):
+        """Colour stage with exposure encoding (Mapper.py:691-720): the renderer returned colour LOGITS; the rays of
+        keyframe f get sigmoid(logits @ rot_f + trans_f), (rot_f | trans_f) = mlp_exposure(exposure_feat_f).  This per-ray
+        epilogue and the tiny exposure MLP run in torch autograd on [R,3] tensors; what leaves it are d depth / d colour
+        logits for lk_render_bwd and an Adam step (lr 1e-3, Mapper.py:600-607) on the exposure features and the MLP."""
+        mlp, feats = self.exposure
+        if self.exp_opt is None:
+            self.exp_opt = torch.optim.Adam([{'params': feats, 'lr': 0.001}, {'params': list(mlp.parameters()), 'lr': 0.001}])
+        depth = st.depth.detach()
+        color = st.color.detach().clone().requires_grad_(True)
+        aff = torch.stack([mlp(f) for f in feats])                               # [F,12]
+        fid = frame_id.long() if frame_id is not None else torch.zeros(color.shape[0], dtype=torch.long, device=color.device)
+        rot, trans = aff[:, :9].reshape(-1, 3, 3)[fid], aff[:, 9:][fid]
+        col = torch.sigmoid(torch.einsum('rc,rcd->rd', color, rot) + trans)
+        m = (b.gt_depth > 0) & st.valid_ray.bool() & (~torch.isnan(depth))
+        geo = torch.abs(b.gt_depth - depth)[m].sum()
+        closs = torch.abs(b.gt_color - col)[m].sum()
+        loss = geo + self.w_color * closs
+        self.exp_opt.zero_grad()
+        (self.w_color * closs).backward()
+        self.exp_opt.step()
+        b.d_color.copy_(color.grad)
+        b.d_depth.copy_(torch.where(m, torch.sign(depth - b.gt_depth), torch.zeros_like(depth)))
+        out4.copy_(torch.stack([loss.detach(), geo.detach(), closs.detach(), m.sum().float()]))
 
     def _out4(self):
         if self.loss_log is None:
@@ -149,13 +182,20 @@ class TrackOptimizer:
         self.eye = None
         self.dist = dist                        # ray-sharded tracking: the 7 pose gradients are summed over ranks
 
-    def track(self, cam7_init, depth_img, color_img, iters, window, intr, rnd_all, r2_map=None):
+    def track(self, cam7_init, depth_img, color_img, iters, window, intr, rnd_all, r2_map=None, exposure=None):
         """Tracker.run loop body for one frame (Tracker.py:313-401).  cam7_init: [7] device tensor.
         rnd_all int32 [iters, R].  Returns (best cam7, loss log [iters,4]) — one host sync at the end."""
         eng, b, st, gs = self.eng, self.batch, self.st, self.gs
         H, W = depth_img.shape
         cam = cam7_init.clone().contiguous()
         adam = optim.Adam(eng)                  # fresh optimiser per frame (Tracker.py:352)
+        # exposure = (mlp_exposure, exposure_feat of this frame): the colour decoder applies sigmoid(rgb @ rot + trans) per
+        # sample (decoder.py:534-540); feature and MLP get their own Adam groups at lr 1e-3 (Tracker.py:329-344)
+        exp_opt = None
+        if exposure is not None:
+            exp_opt = torch.optim.Adam([{'params': [exposure[1]], 'lr': 0.001}, {'params': list(exposure[0].parameters()), 'lr': 0.001}])
+            if gs.g_affine is None:
+                gs.g_affine = eng.zeros(12)
         log = eng.zeros(iters, 4)
         hist = eng.empty(iters, 7)
         if self.eye is None:
@@ -168,13 +208,22 @@ class TrackOptimizer:
             optim.gather_rays(eng, dstack, cstack, self.eye, None, rnd_all[it], H, W, window, intr, b.as_out(), r2s)
             optim.rays_from_pose(eng, cam, b.pix_i, b.pix_j, intr, b.rays_o, b.rays_d)
             optim.inside_mask(eng, b.gt_depth, None, b.thr, b.scratch_u32, depth_filtered=b.gt_depth)
+            aff = None
+            if exposure is not None:
+                aff_t = exposure[0](exposure[1])                                 # [12], torch autograd through the tiny MLP
+                aff = aff_t.detach().float().contiguous()
+                gs.g_affine.zero_()
             core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
-                                self.dec, 'color', tracker=True, r2_ray=b.r2_ray, save_act=True,
+                                self.dec, 'color', tracker=True, r2_ray=b.r2_ray, save_act=True, affine=aff,
                                 extra_flags=_ffi.FLAG_ZERO_ABSENT)
             optim.loss_tracker(eng, st, b.gt_depth, b.gt_color, self.w_color, self.use_color, b.d_depth, b.d_color,
                                log[it], b.loss_scratch)
             core.render_backward(eng, st, gs, b.d_depth, b.d_color)
             optim.pose_bwd(eng, cam, b.pix_i, b.pix_j, intr, gs.g_rays_o, gs.g_rays_d, self.g_cam)
+            if exp_opt is not None:
+                exp_opt.zero_grad()
+                aff_t.backward(gs.g_affine.to(aff_t.dtype))
+                exp_opt.step()
             if self.dist is not None:
                 self.dist.all_reduce_vec(self.g_cam)
             if self.separate_lr:                # T: lr, quaternion: 0.2*lr (Tracker.py:317-333)

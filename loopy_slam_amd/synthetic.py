@@ -126,4 +126,9 @@ def default_weights(seed=1219, rel_pos=True, exposure=False):
     W['color_decoder.mlp_col_neighbor.linear1.bias'] = linear(128, 52)[1]
     W['color_decoder.mlp_col_neighbor.linear2.weight'] = xavier(32, 128, 1.0)
     W['color_decoder.mlp_col_neighbor.linear2.bias'] = linear(32, 128)[1]
+    if exposure:        # MLP_exposure (decoder.py:326-342): 8 -> 128 -> 12, N(0, 0.01) weights, default nn.Linear biases
+        W['color_decoder.mlp_exposure.linear1.weight'] = torch.randn(128, 8, generator=g) * 0.01
+        W['color_decoder.mlp_exposure.linear1.bias'] = linear(128, 8)[1]
+        W['color_decoder.mlp_exposure.linear2.weight'] = torch.randn(12, 128, generator=g) * 0.01
+        W['color_decoder.mlp_exposure.linear2.bias'] = linear(12, 128)[1]
     return W

@@ -174,3 +174,22 @@ def test_sample_near_pcl(backend):
     zr, invr = H.sample_near_pcl(ro, rd, 0.3, 4.0, 5, npc.cloud_pos().cpu().numpy(), npc.radius_query)
     assert np.array_equal(inv.cpu().numpy(), invr) and invr[:5].all() and not invr.all()
     assert np.array_equal(z.cpu().numpy(), zr)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_point_slam_exposure_config(backend):
+    """ScanNet style model (encode_exposure, no rel-pos): the tracker optimises the frame's exposure feature, keyframes keep
+    theirs and the mapper optimises them together with mlp_exposure."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['model']['encode_exposure'] = True
+    cfg['model']['encode_rel_pos_in_col'] = False
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    w0 = ps.shared_decoders.mlp_exposure[2].bias.detach().clone()
+    est, gt = ps.run()
+    assert torch.isfinite(est).all() and float((est[:, :3, 3] - gt[:, :3, 3]).norm(dim=1).max()) < 0.1
+    kfs = ps.mapper.keyframe_dict
+    assert len(kfs) >= 2 and all(kf['exposure_feat'] is not None and kf['exposure_feat'].shape == (8,) for kf in kfs)
+    assert float(ps.exposure_feat.abs().max()) > 0 and float(kfs[0]['exposure_feat'].detach().abs().max()) > 0       # both moved off zero
+    assert float((ps.shared_decoders.mlp_exposure[2].bias.detach() - w0).abs().max()) > 0
+    assert torch.isfinite(ps.mapper.last_log.cpu()).all() and torch.isfinite(ps.tracker.last_log.cpu()).all()

@@ -171,3 +171,114 @@ def test_track_iterations_match_oracle(backend):
     np.testing.assert_allclose(log[:, 0].cpu().numpy(), o_losses, rtol=5e-4)
     k = int(np.argmin(o_losses))
     np.testing.assert_allclose(best.cpu().numpy(), o_cams[k].numpy(), rtol=0, atol=2e-5)
+
+
+def _exposure_module(W):
+    """torch MLP_exposure (8 -> 128 softplus100 -> 12) holding the oracle weights."""
+    m = torch.nn.Sequential(torch.nn.Linear(8, 128), torch.nn.Softplus(beta=100), torch.nn.Linear(128, 12))
+    with torch.no_grad():
+        m[0].weight.copy_(W['color_decoder.mlp_exposure.linear1.weight']); m[0].bias.copy_(W['color_decoder.mlp_exposure.linear1.bias'])
+        m[2].weight.copy_(W['color_decoder.mlp_exposure.linear2.weight']); m[2].bias.copy_(W['color_decoder.mlp_exposure.linear2.bias'])
+    return m
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_exposure_iterations_match_oracle(backend):
+    """model.encode_exposure (ScanNet): tracker iterations with the decoder-side per-sample affine of the frame's
+    exposure feature (Tracker.py:329-344), then mapper colour iterations with the per-keyframe affine on the rendered
+    logits (Mapper.py:697-715) - exposure features and MLP optimised at lr 1e-3, against oracle loops."""
+    eng = make_engine(backend)
+    c2w, depth_img, color_img, pos, geo, col = mini_scene(2)
+    W = syn.default_weights(seed=4, rel_pos=False, exposure=True)
+    gen = torch.Generator().manual_seed(31)
+    # ------------------------------------------------------------------ tracker
+    R, iters, lr = 72, 3, 0.002
+    win = (2, HH - 2, 2, WW - 2)
+    w_w = win[3] - win[2]
+    rnd_all = torch.randint(0, (win[1] - win[0]) * w_w, (iters, R), generator=gen, dtype=torch.int32)
+    cam0 = H.c2w_to_cam(c2w) + torch.tensor([0.0, 0.002, -0.001, 0.0015, 0.004, -0.003, 0.002])
+    feat0 = 0.3 * torch.randn(8, generator=gen)
+    ocfg = H.RenderCfg(rel_pos=False, exposure=True)
+    Wo = {k: (v.clone().requires_grad_(True) if 'mlp_exposure' in k else v) for k, v in W.items()}
+    cam = cam0.clone().requires_grad_(True)
+    feat = feat0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{'params': [cam], 'lr': lr}, {'params': [feat], 'lr': 0.001},
+                            {'params': [v for k, v in Wo.items() if 'mlp_exposure' in k], 'lr': 0.001}])
+    o_losses = []
+    for it in range(iters):
+        opt.zero_grad()
+        rr = rnd_all[it]
+        i, j = (win[2] + rr % w_w).float(), (win[0] + rr // w_w).float()
+        ro, rd = H.rays_from_uv(i, j, H.quat_to_c2w(cam), *INTR)
+        flat = j.long() * WW + i.long()
+        gd, gc = depth_img.reshape(-1)[flat], color_img.reshape(-1, 3)[flat]
+        keep = gd > 0
+        keep = keep & (gd <= H.inside_threshold(gd[keep]))
+        out = H.render_batch(ocfg, ro[keep], rd[keep], gd[keep], pos, geo, col, Wo, 'color', tracker=True,
+                             affine=H.exposure_affine(Wo, feat))
+        loss, _, _, _ = H.tracker_loss(out['depth'], out['var'], out['color'], gd[keep], gc[keep], 0.5)
+        loss.backward()
+        opt.step()
+        o_losses.append(loss.item())
+    cfg = core.RenderCfg(rel_pos=False, exposure=True)
+    dec = core.DecoderBlob(eng).pack(W)
+    pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo), eng.f32(col)
+    knn = core.KnnIndex(eng, capacity=pos.shape[0]); knn.build(pos_d)
+    mlp = _exposure_module(W).to(eng.device)
+    feat_k = eng.f32(feat0).clone().requires_grad_(True)
+    to = steps.TrackOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, R, lr, separate_lr=False, w_color=0.5)
+    best, log = to.track(eng.f32(cam0), eng.f32(depth_img), eng.f32(color_img), iters, win, INTR, rnd_all.to(eng.device),
+                         exposure=(mlp, feat_k))
+    np.testing.assert_allclose(log[:, 0].cpu().numpy(), o_losses, rtol=5e-4)
+    np.testing.assert_allclose(feat_k.detach().cpu().numpy(), feat.detach().numpy(), atol=2e-4)
+    assert float((feat_k.detach().cpu() - feat0).abs().max()) > 5e-4                       # the feature did move
+    np.testing.assert_allclose(mlp[2].bias.detach().cpu().numpy(), Wo['color_decoder.mlp_exposure.linear2.bias'].detach().numpy(), atol=2e-4)
+    # ------------------------------------------------------------------ mapper, colour stage, two keyframes
+    Rm, iters_m = 96, 2
+    rows = torch.arange(0, pos.shape[0], 2, dtype=torch.int32)
+    lrs = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
+    rnd_m = torch.randint(0, HH * WW, (iters_m, Rm), generator=gen, dtype=torch.int32)
+    fid = (torch.arange(Rm) // (Rm // 2)).to(torch.int32)                                   # first half frame 0, second half frame 1
+    feats0 = [0.3 * torch.randn(8, generator=gen) for _ in range(2)]
+    Wm = {k: v.clone() for k, v in W.items()}
+    train = list(steps.GEO_DECODER_PARAMS) + [n for n in steps.COLOR_DECODER_PARAMS if n in Wm]
+    for n in train + [k for k in Wm if 'mlp_exposure' in k]:
+        Wm[n].requires_grad_(True)
+    geo_p, col_p = geo[rows.long()].clone().requires_grad_(True), col[rows.long()].clone().requires_grad_(True)
+    fo = [f.clone().requires_grad_(True) for f in feats0]
+    opt = torch.optim.Adam([{'params': [Wm[n] for n in train], 'lr': 0.005}, {'params': [geo_p], 'lr': 0.005}, {'params': [col_p], 'lr': 0.005},
+                            {'params': fo, 'lr': 0.001}, {'params': [v for k, v in Wm.items() if 'mlp_exposure' in k], 'lr': 0.001}])
+    om_losses = []
+    mcfg = H.RenderCfg(rel_pos=False, exposure=True)
+    for it in range(iters_m):
+        opt.zero_grad()
+        geo_t, col_t = geo.clone(), col.clone()
+        geo_t[rows.long()], col_t[rows.long()] = geo_p, col_p
+        ro, rd, gd, gc, _, _ = oracle_rays(c2w, depth_img, color_img, rnd_m[it])
+        keep = gd > 0
+        keep = keep & (gd <= H.inside_threshold(gd[keep]))
+        out = H.render_batch(mcfg, ro[keep], rd[keep], gd[keep], pos, geo_t, col_t, Wm, 'color', color_sigmoid=False)
+        color = out['color'].clone()
+        f_keep = fid[keep].long()
+        aff = torch.stack([H.exposure_affine(Wm, f) for f in fo])
+        color = torch.sigmoid(torch.einsum('rc,rcd->rd', color, aff[:, :9].reshape(-1, 3, 3)[f_keep]) + aff[:, 9:][f_keep])
+        m = (gd[keep] > 0) & out['valid_ray'] & (~torch.isnan(out['depth']))
+        loss = torch.abs(gd[keep] - out['depth'])[m].sum() + 0.1 * torch.abs(gc[keep] - color)[m].sum()
+        loss.backward()
+        opt.step()
+        om_losses.append(loss.item())
+    dec2 = core.DecoderBlob(eng).pack(W)
+    geo_d2, col_d2 = eng.f32(geo).clone(), eng.f32(col).clone()
+    mlp2 = _exposure_module(W).to(eng.device)
+    fk = [eng.f32(f).clone().requires_grad_(True) for f in feats0]
+    mo = steps.MapOptimizer(eng, cfg, dec2, knn, pos_d, geo_d2, col_d2, rows.to(eng.device), Rm, lrs, w_color=0.1, exposure=(mlp2, fk))
+    mo.begin_frame()
+    frames = (eng.f32(depth_img).reshape(1, HH, WW).repeat(2, 1, 1), eng.f32(color_img).reshape(1, HH, WW, 3).repeat(2, 1, 1, 1),
+              eng.f32(c2w).reshape(1, 4, 4).repeat(2, 1, 1), None)
+    km = []
+    for it in range(iters_m):
+        out4 = mo.iterate('color', frames, rnd_m[it].to(eng.device), fid.to(eng.device), (0, HH, 0, WW), INTR, HH, WW)
+        km.append(float(out4[0].cpu()))
+    np.testing.assert_allclose(km, om_losses, rtol=5e-4)
+    for a, b in zip(fk, fo):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), atol=2e-4)
