@@ -23,6 +23,12 @@ from . import _ffi, core, optim, steps, synthetic
 from .common import get_camera_from_tensor, get_tensor_from_camera, get_rays, get_samples, get_rays_from_uv
 
 
+def _inv_pose(c2w, device):
+    """world->camera of a 4x4 pose: inverted on the host in float64 (a device solver call costs a library start-up and a
+    launch chain for 16 numbers), returned as float32 on `device`."""
+    return torch.linalg.inv(c2w.detach().double().cpu()).float().to(device)
+
+
 def render_cfg_from(cfg, coef):
     r, p = cfg['rendering'], cfg['pointcloud']
     return core.RenderCfg(S=r['N_surface'], near_surface=r['near_end_surface'], far_surface=r['far_end_surface'],
@@ -402,7 +408,7 @@ class Mapper:
 
     def filter_point_before_add(self, rays_o, rays_d, gt_depth, prev_c2w):
         pts = rays_o + rays_d * gt_depth[:, None]
-        w2c = torch.linalg.inv(prev_c2w.double()).float().to(pts.device)
+        w2c = _inv_pose(prev_c2w, pts.device)
         cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
         zc = cam[:, 2]
         z = zc + 1e-5
@@ -421,7 +427,7 @@ class Mapper:
         pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(-1, 3)
         scored = []
         for kid, kf in enumerate(keyframe_dict):
-            w2c = torch.linalg.inv(kf['est_c2w'].double()).float().to(dev)
+            w2c = _inv_pose(kf['est_c2w'], dev)
             cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
             zc = cam[:, 2] + 1e-5
             u = (self.fx * -cam[:, 0] + self.cx * cam[:, 2]) / zc
@@ -579,16 +585,17 @@ class Tracker:
         if idx == 0 or self.gt_camera:
             c2w = gt_c2w.clone()
         else:
-            pre = slam.estimate_c2w_list[idx - 1].to(eng.device).float()
+            pre = slam.estimate_c2w_list[idx - 1].float()           # pose bookkeeping lives on the host (4x4 algebra)
             if self.const_speed_assumption and idx - 2 >= 0:
-                delta = pre @ torch.linalg.inv(slam.estimate_c2w_list[idx - 2].to(eng.device).float())
+                delta = pre @ torch.linalg.inv(slam.estimate_c2w_list[idx - 2].float())
                 init = delta @ pre
             else:
                 init = pre
-            cam = get_tensor_from_camera(init).to(eng.device)
-            gt_cam = get_tensor_from_camera(gt_c2w).to(eng.device)
-            if torch.dot(cam[:4], gt_cam[:4]).item() < 0:
+            cam = get_tensor_from_camera(init)
+            gt_cam = get_tensor_from_camera(gt_c2w.detach().cpu())
+            if float(torch.dot(cam[:4], gt_cam[:4])) < 0:           # same quaternion hemisphere as the ground truth (Tracker.py:330-331)
                 cam[:4] *= -1
+            cam = cam.to(eng.device)
             rcfg = render_cfg_from(self.cfg, self.cfg['rendering']['sigmoid_coef_tracker'])
             win = (self.ignore_edge_H, self.H - self.ignore_edge_H, self.ignore_edge_W, self.W - self.ignore_edge_W)
             n_px = self.tracking_pixels

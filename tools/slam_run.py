@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""End-to-end run of the drop-in API (Point_SLAM.run: track every frame, map every `every_frame`-th) on the synthetic
+room, the SURVEY 8(d) quality metrics beside the wall-clock rate:
+
+  * frames/s through `Tracker.track_frame` / `Mapper.map_frame` (host code included; frames pre-rendered, the initial 1500-iteration
+    mapping of frame 0 and the one-off start-up costs of the next `every_frame` frames reported separately),
+  * ATE RMSE after a rigid (rotation + translation, no scale) least-squares alignment of the estimated to the true
+    camera centres - the metric of the reference's src/tools/eval_ate.py:195-234,
+  * rendered-depth L1 (cm) of `Renderer.render_img` at the estimated poses over pixels with a sensor depth - the
+    metric of Mapper.py:1146-1182.
+
+Decoder weights are random-init (the pretrained `middle_fine.pt` of the reference is not available offline) and the
+geometry decoder stays fixed as in the reference's configs, so the absolute quality numbers are those of an untrained
+prior; they are reported to show that the loop converges, not as reference accuracy.
+
+    python tools/slam_run.py [--frames 26] [--out gpurun_out/slam_run.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from loopy_slam_amd import slam, config  # noqa: E402
+
+
+def align_rigid(est, gt):
+    """R, t minimising sum |R est_i + t - gt_i|^2 (SVD of the cross-covariance, det-corrected)."""
+    mu_e, mu_g = est.mean(0), gt.mean(0)
+    Wm = (gt - mu_g).T @ (est - mu_e)
+    U, _, Vt = np.linalg.svd(Wm)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    return R, mu_g - R @ mu_e
+
+
+def ate_rmse(est_c2w, gt_c2w):
+    e = est_c2w[:, :3, 3].double().numpy()
+    g = gt_c2w[:, :3, 3].double().numpy()
+    R, t = align_rigid(e, g)
+    err = np.linalg.norm((e @ R.T + t) - g, axis=1)
+    return float(np.sqrt((err ** 2).mean())), float(np.linalg.norm(e - g, axis=1).max())
+
+
+class Preloaded:
+    """Frames rendered before the clock starts (the reference reads them through a DataLoader worker)."""
+
+    def __init__(self, reader):
+        self.frames = [reader[i] for i in range(len(reader))]
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __getitem__(self, i):
+        return self.frames[i]
+
+
+def run(cfg, frames, eng=None, sync=None):
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    ps.frame_reader = Preloaded(ps.frame_reader)
+    sync = sync or torch.cuda.synchronize
+    stamps = []
+
+    def cb(idx, est, gt):
+        sync()
+        stamps.append(time.perf_counter())
+
+    sync()
+    t0 = time.perf_counter()
+    est, gt = ps.run(callback=cb)
+    every = cfg['mapping']['every_frame']
+    per_frame = np.diff(np.array([t0] + stamps))
+    # frame 0 = the initial 1500-iteration mapping; frames 1..every carry one-off costs (solver library start-up of the first
+    # torch.linalg.inv, first allocation of the optimiser buffers): the steady rate is taken from frame every+1 on
+    w0 = every + 1
+    steady = per_frame[w0:]
+    tracked = [per_frame[i] for i in range(w0, len(per_frame)) if i % every != 0 and i != len(per_frame) - 1]
+    mapped = [per_frame[i] for i in range(w0, len(per_frame)) if i % every == 0 or i == len(per_frame) - 1]
+    rmse, worst = ate_rmse(est, gt)
+    l1 = []
+    for i in sorted({0, frames // 2, frames - 1}):
+        _, color, depth, c2w = ps.frame_reader[i]
+        d, _, _ = ps.renderer_map.render_img(ps.npc, ps.shared_decoders, est[i].to(ps.eng.device), ps.eng.device, 'color', gt_depth=depth)
+        m = depth > 0
+        l1.append(float((d.float() - depth)[m].abs().mean()) * 100.0)
+    tl, ml = ps.tracker.last_log, ps.mapper.last_log
+    return {
+        'frames': frames, 'points': ps.npc.pts_num(), 'keyframes': len(ps.mapper.keyframe_list),
+        'frames_per_s': round(len(steady) / float(steady.sum()), 3),
+        'ms_tracked_frame': round(1e3 * float(np.mean(tracked)), 2) if tracked else None,
+        'ms_mapped_frame': round(1e3 * float(np.mean(mapped)), 2) if mapped else None,
+        's_first_frame': round(float(per_frame[0]), 2), 's_warmup_frames': round(float(per_frame[1:w0].sum()), 2),
+        'ate_rmse_cm': round(100 * rmse, 3), 'max_translation_error_cm': round(100 * worst, 3),
+        'depth_l1_cm': [round(x, 3) for x in l1],
+        'track_loss_first_last': [float(tl[0, 0]), float(tl[-1, 0])] if tl is not None else None,
+        'map_loss_first_last': [float(ml[0, 0]), float(ml[-1, 0])] if ml is not None else None,
+        'path_length_cm': round(100 * float((gt[1:, :3, 3] - gt[:-1, :3, 3]).norm(dim=1).sum()), 2),
+        'data': 'synthetic room, random-init decoders',
+        'ms_per_frame': [round(1e3 * float(x), 1) for x in per_frame],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=26)
+    ap.add_argument('--config', default='configs/Synthetic/room.yaml')
+    ap.add_argument('--iters-first', type=int, default=None)
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    cfg = config.load_config(args.config, 'configs/point_slam.yaml')
+    cfg['data']['n_frames'] = args.frames
+    if args.iters_first is not None:
+        cfg['mapping']['iters_first'] = args.iters_first
+    out = run(cfg, args.frames)
+    out['config'] = args.config
+    print(json.dumps(out))
+    if args.out:
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        with open(args.out, 'w') as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
