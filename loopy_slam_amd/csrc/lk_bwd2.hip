@@ -151,7 +151,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     const float a1 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 1], py));
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
-    const float* __restrict__ F = a.Wfrag;
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
     const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
@@ -180,8 +180,8 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     f32x16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_zero16();
-    lk_gemm_frag<4, 4>(hid, F + FM20_FWD, 4, 0, 0, x0, lane);
-    lk_gemm_frag<4, 3>(hid, F + FM20_FWD, 4, 4, 0, x1, lane);
+    lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 0, 0, x0, 0, lane);
+    lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 2, 0, x1, 0, lane);       // units 32..55; registers 12..15 of x1 are zero
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         lk_add_rowvec(hid[nb], W + R_B1, nb * 32, lane);
@@ -200,7 +200,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
         f32x16 out[1];
         out[0] = lk_zero16();
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<1, 4>(out, F + FM21_FWD, 1, 4 * kb, 0, hid[kb], lane);
+        for (int kb = 0; kb < 4; ++kb) lk_gemm_b6<1, 2>(out, FB + FM21_FWDB, 1, 2 * kb, 0, hid[kb], 0, lane);
         lk_add_rowvec(out[0], W + R_B2, 0, lane);
         float part = 0.0f;
 #pragma unroll
@@ -234,13 +234,14 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
     // ---- d hid = (W2^T d out) * softplus'(hid), block by block IN PLACE of hid (64 fewer live registers)
     f32x16 (&dhid)[4] = hid;
+    const LkB8 db0 = lk_split_ct(dout[0], 0), db1 = lk_split_ct(dout[0], 1);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-        f32x16 t[1];
-        t[0] = lk_zero16();
-        lk_gemm_frag<1, 4>(t, F + FM21_TR, 4, 0, nb, dout[0], lane);
+        f32x16 t = lk_zero16();
+        t = lk_mma6(lk_fragb_load(FB + FM21_TRB, 4, 0, nb, lane), db0, t);
+        t = lk_mma6(lk_fragb_load(FB + FM21_TRB, 4, 1, nb, lane), db1, t);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) dhid[nb][q] = t[0][q] * lk_softplus100_grad_from_out(hid[nb][q]);
+        for (int q = 0; q < 16; ++q) dhid[nb][q] = t[q] * lk_softplus100_grad_from_out(hid[nb][q]);
     }
     if (want_w) {
         //   linear1: rows [8P][192] = d hid (128) | x (64)
@@ -264,7 +265,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     f32x16 dx[2];
     dx[0] = lk_zero16(); dx[1] = lk_zero16();
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) lk_gemm_frag<2, 4>(dx, F + FM20_TR, 2, 4 * nb, 0, dhid[nb], lane);
+    for (int nb = 0; nb < 4; ++nb) lk_gemm_b6<2, 2>(dx, FB + FM20_TRB, 2, 2 * nb, 0, dhid[nb], 0, lane);
     float dax = 0.0f, day = 0.0f, daz = 0.0f;        // d loss / d (x_I - p), this lane's share
     const float* B = W + R_EB;
 #pragma unroll
@@ -314,7 +315,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
 }
 
-__global__ __launch_bounds__(256) void k_relpos_bwd(LkRelposBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void k_relpos_bwd(LkRelposBwdArgs a) {
     __shared__ float s_part[4][32];
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const int w = (int)threadIdx.x >> 6;

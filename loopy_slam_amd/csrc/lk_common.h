@@ -8,6 +8,8 @@
 #include "lk_weights.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 lk_bf16x8 __attribute__((ext_vector_type(8)));
 
 #define LK_TWO_PI 6.283185307179586f
 #define LK_FLT_MAX 3.402823466e+38f
@@ -230,6 +232,76 @@ __device__ __forceinline__ void lk_gemm_regs_lds(f32x16& acc, const float4 (&wv)
         acc = lk_mfma(wv[WOFF + g].y, x.y, acc);
         acc = lk_mfma(wv[WOFF + g].z, x.z, acc);
         acc = lk_mfma(wv[WOFF + g].w, x.w, acc);
+    }
+}
+
+// ------------------------------------------------------------------ fp32 products on the bf16 matrix pipe ("bf16x6")
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles for 2 k) and - measured - does not overlap with the VALU
+// work of the other waves of the SIMD: kernel time = MFMA cycles + VALU cycles.  The bf16 pipe is 16x faster per k and
+// co-issues with the VALU.  An fp32 value is EXACTLY hi + mid + lo with three bf16 pieces cut by truncation (8 + 8 + 8
+// significand bits); a.b is taken as the six piece products with i + j <= 2 (the dropped ones are <= 2^-24 |a b|),
+// accumulated in fp32 smallest first: measured max error 1.8e-7 sum|a b| against fp64 (the fp32 MFMA: 2.0e-7).
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles, 16 k) replace eight fp32 MFMAs (64 cycles, 2 k): 2.67x fewer pipe cycles.
+// The k order inside one instruction is free as long as A and B agree, so the 8 values of a lane are the two C/D-row-walk
+// groups (2G, 2G+1) of the CT tile: registers 8G..8G+7, straight from the previous layer's accumulators.
+struct LkB8 { u32x4 p[3]; };
+// upper halves of (a, b) -> one register (low 16 bits = a's bf16)
+__device__ __forceinline__ unsigned lk_pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ LkB8 lk_split8(const float (&v)[8]) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned hb = __float_as_uint(v[i]) & 0xffff0000u;
+        const float r1 = v[i] - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mb);
+        h[i] = hb; m[i] = mb; l[i] = __float_as_uint(r2);
+    }
+    LkB8 s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s.p[0][i] = lk_pack_hi(h[2 * i], h[2 * i + 1]);
+        s.p[1][i] = lk_pack_hi(m[2 * i], m[2 * i + 1]);
+        s.p[2][i] = lk_pack_hi(l[2 * i], l[2 * i + 1]);
+    }
+    return s;
+}
+// registers 8G..8G+7 of a CT tile
+__device__ __forceinline__ LkB8 lk_split_ct(const f32x16& x, int G) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = x[8 * G + i];
+    return lk_split8(v);
+}
+__device__ __forceinline__ f32x16 lk_mfma_b16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(lk_bf16x8, a), __builtin_bit_cast(lk_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 lk_mma6(const LkB8& a, const LkB8& b, f32x16 acc) {
+    acc = lk_mfma_b16(a.p[2], b.p[0], acc);
+    acc = lk_mfma_b16(a.p[0], b.p[2], acc);
+    acc = lk_mfma_b16(a.p[1], b.p[1], acc);
+    acc = lk_mfma_b16(a.p[1], b.p[0], acc);
+    acc = lk_mfma_b16(a.p[0], b.p[1], acc);
+    acc = lk_mfma_b16(a.p[0], b.p[0], acc);
+    return acc;
+}
+// split-fragment block (G, nb) of a matrix: fragb = first block of the matrix form (lkw::FMxx_FWDB / _TRB, uint4 units
+// behind the fp32 fragments), NBT = blocks per G
+__device__ __forceinline__ LkB8 lk_fragb_load(const u32x4* __restrict__ fragb, int NBT, int G, int nb, int lane) {
+    const u32x4* __restrict__ q = fragb + ((size_t)G * NBT + nb) * 192 + lane;
+    LkB8 a;
+    a.p[0] = q[0]; a.p[1] = q[64]; a.p[2] = q[128];
+    return a;
+}
+// acc[nb] += W[nb0 + nb][G0 .. G0+NGG) X  for the NGG 16-k blocks taken from registers of x starting at block XG0
+template <int NB, int NGG>
+__device__ __forceinline__ void lk_gemm_b6(f32x16 (&acc)[NB], const u32x4* __restrict__ fragb, int NBT, int G0, int nb0,
+                                           const f32x16& x, int XG0, int lane) {
+#pragma unroll
+    for (int G = 0; G < NGG; ++G) {
+        const LkB8 b = lk_split_ct(x, XG0 + G);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = lk_mma6(lk_fragb_load(fragb, NBT, G0 + G, nb0 + nb, lane), b, acc[nb]);
     }
 }
 

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     const float a1 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 1], py));
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
-    const float* __restrict__ F = a.Wfrag;
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
     const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
     // X^T tiles: units 0..19 embedding, 20..51 feature channels 0..31, 52..55 zero
     f32x16 x0, x1;
@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     f32x16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_zero16();
-    lk_gemm_frag<4, 4>(hid, F + FM20_FWD, 4, 0, 0, x0, lane);
-    lk_gemm_frag<4, 3>(hid, F + FM20_FWD, 4, 4, 0, x1, lane);
+    lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 0, 0, x0, 0, lane);
+    lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 2, 0, x1, 0, lane);       // units 32..55; registers 12..15 of x1 are zero
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         lk_add_rowvec(hid[nb], W + R_B1, nb * 32, lane);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     f32x16 out[1];
     out[0] = lk_zero16();
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) lk_gemm_frag<1, 4>(out, F + FM21_FWD, 1, 4 * kb, 0, hid[kb], lane);
+    for (int kb = 0; kb < 4; ++kb) lk_gemm_b6<1, 2>(out, FB + FM21_FWDB, 1, 2 * kb, 0, hid[kb], 0, lane);
     lk_add_rowvec(out[0], W + R_B2, 0, lane);
     // c[ch] = sum over the 8 neighbour rows of a sample (8 consecutive lanes) of w * f[ch]
     const bool has = a.nbr_count[sp] >= a.min_nn;

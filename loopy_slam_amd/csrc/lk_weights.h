@@ -68,42 +68,59 @@ constexpr int BLOB_FLOATS = R_B2 + 64;
 //   transposed block (ng, kb): lane l, t ->  W[8*ng + 4*(l>>5) + t][vcol = kb*32 + (l&31)]   (ng-major)
 // "vcol" is a virtual input column: the embedding part of a skip/first layer is padded to a
 // multiple of 32 (colour: 40 -> 64) so that every 32-wide block of dX^T is either embedding or hidden.
-struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwd, tr; };
+struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwd, tr, fwdb, trb; };
+
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 fragments (the operands of the bf16x6 products, lk_common.h::lk_mma6): the same two forms with every weight
+// cut into three bf16 pieces hi + mid + lo (exact).  One block = the 8 k-values a lane feeds to ONE
+// v_mfma_f32_32x32x16_bf16, i.e. the two fp32 k-groups (2G, 2G+1) of the walk above, for the 3 pieces:
+//   block (G, nb) = [piece 0..2][lane 0..63] uint4  (3 KiB contiguous),  offsets below in uint4 units.
+// A skip / first layer's embedding columns form their own run of blocks, zero-padded to a multiple of 16 columns, so
+// that a block never straddles the embedding and the hidden part (their B operands live in different CT tiles).
+constexpr int kb16(int k) { return (k + 15) / 16; }
+constexpr int fwd_blocks16(int ld, int e_real) { return e_real < ld ? kb16(e_real) + kb16(ld - e_real) : kb16(ld); }
 
 
 // fwd size = rows*ld ; tr size = kv*rows
-#define LKW_FM(idx, plain_, rows_, ld_, ereal_, evirt_, kv_, prev_end_) \
-    constexpr int FM##idx##_FWD = prev_end_;                             \
-    constexpr int FM##idx##_TR = FM##idx##_FWD + (rows_) * (ld_);        \
-    constexpr int FM##idx##_END = FM##idx##_TR + (kv_) * (rows_);
+#define LKW_FM(idx, plain_, rows_, ld_, ereal_, evirt_, kv_, prev_)                              \
+    constexpr int FM##idx##_FWD = FM##prev_##_END;                                               \
+    constexpr int FM##idx##_TR = FM##idx##_FWD + (rows_) * (ld_);                                \
+    constexpr int FM##idx##_END = FM##idx##_TR + (kv_) * (rows_);                                \
+    constexpr int FM##idx##_FWDB = FM##prev_##_ENDB;                                             \
+    constexpr int FM##idx##_TRB = FM##idx##_FWDB + fwd_blocks16(ld_, ereal_) * ((rows_) / 32) * 192; \
+    constexpr int FM##idx##_ENDB = FM##idx##_TRB + ((rows_) / 16) * ((kv_) / 32) * 192;
+
+constexpr int FMS_END = 0, FMS_ENDB = 0;
 
 // index:            plain   rows ld            e_real e_virt kv
-LKW_FM(0,  G_W0, HG, EGP,        EGP, EGP, 96,  0)
-LKW_FM(1,  G_W1, HG, HG,         HG,  HG,  32,  FM0_END)
-LKW_FM(2,  G_W2, HG, HG,         HG,  HG,  32,  FM1_END)
-LKW_FM(3,  G_W3, HG, EGP + HG,   128, 128, 128, FM2_END)
-LKW_FM(4,  G_W4, HG, HG,         HG,  HG,  32,  FM3_END)
-LKW_FM(5,  G_U0 + 0 * G_USTRIDE, HG, CF, CF, CF, 32, FM4_END)
-LKW_FM(6,  G_U0 + 1 * G_USTRIDE, HG, CF, CF, CF, 32, FM5_END)
-LKW_FM(7,  G_U0 + 2 * G_USTRIDE, HG, CF, CF, CF, 32, FM6_END)
-LKW_FM(8,  G_U0 + 3 * G_USTRIDE, HG, CF, CF, CF, 32, FM7_END)
-LKW_FM(9,  G_U0 + 4 * G_USTRIDE, HG, CF, CF, CF, 32, FM8_END)
-LKW_FM(10, C_W0, HC, EC,         EC,  64,  64,  FM9_END)
-LKW_FM(11, C_W1, HC, HC,         HC,  HC,  128, FM10_END)
-LKW_FM(12, C_W2, HC, HC,         HC,  HC,  128, FM11_END)
-LKW_FM(13, C_W3, HC, EC + HC,    EC,  64,  192, FM12_END)
-LKW_FM(14, C_W4, HC, HC,         HC,  HC,  128, FM13_END)
-LKW_FM(15, C_U0 + 0 * C_USTRIDE, HC, CF, CF, CF, 32, FM14_END)
-LKW_FM(16, C_U0 + 1 * C_USTRIDE, HC, CF, CF, CF, 32, FM15_END)
-LKW_FM(17, C_U0 + 2 * C_USTRIDE, HC, CF, CF, CF, 32, FM16_END)
-LKW_FM(18, C_U0 + 3 * C_USTRIDE, HC, CF, CF, CF, 32, FM17_END)
-LKW_FM(19, C_U0 + 4 * C_USTRIDE, HC, CF, CF, CF, 32, FM18_END)
-LKW_FM(20, R_W1, HC, KRP,        KRP, 64,  64,  FM19_END)
-LKW_FM(21, R_W2, CF, HC,         HC,  HC,  128, FM20_END)
+LKW_FM(0,  G_W0, HG, EGP,        EGP, EGP, 96,  S)
+LKW_FM(1,  G_W1, HG, HG,         HG,  HG,  32,  0)
+LKW_FM(2,  G_W2, HG, HG,         HG,  HG,  32,  1)
+LKW_FM(3,  G_W3, HG, EGP + HG,   128, 128, 128, 2)
+LKW_FM(4,  G_W4, HG, HG,         HG,  HG,  32,  3)
+LKW_FM(5,  G_U0 + 0 * G_USTRIDE, HG, CF, CF, CF, 32, 4)
+LKW_FM(6,  G_U0 + 1 * G_USTRIDE, HG, CF, CF, CF, 32, 5)
+LKW_FM(7,  G_U0 + 2 * G_USTRIDE, HG, CF, CF, CF, 32, 6)
+LKW_FM(8,  G_U0 + 3 * G_USTRIDE, HG, CF, CF, CF, 32, 7)
+LKW_FM(9,  G_U0 + 4 * G_USTRIDE, HG, CF, CF, CF, 32, 8)
+LKW_FM(10, C_W0, HC, EC,         EC,  64,  64,  9)
+LKW_FM(11, C_W1, HC, HC,         HC,  HC,  128, 10)
+LKW_FM(12, C_W2, HC, HC,         HC,  HC,  128, 11)
+LKW_FM(13, C_W3, HC, EC + HC,    EC,  64,  192, 12)
+LKW_FM(14, C_W4, HC, HC,         HC,  HC,  128, 13)
+LKW_FM(15, C_U0 + 0 * C_USTRIDE, HC, CF, CF, CF, 32, 14)
+LKW_FM(16, C_U0 + 1 * C_USTRIDE, HC, CF, CF, CF, 32, 15)
+LKW_FM(17, C_U0 + 2 * C_USTRIDE, HC, CF, CF, CF, 32, 16)
+LKW_FM(18, C_U0 + 3 * C_USTRIDE, HC, CF, CF, CF, 32, 17)
+LKW_FM(19, C_U0 + 4 * C_USTRIDE, HC, CF, CF, CF, 32, 18)
+LKW_FM(20, R_W1, HC, KRP,        KRP, 64,  64,  19)
+LKW_FM(21, R_W2, CF, HC,         HC,  HC,  128, 20)
 constexpr int FRAG_FLOATS = FM21_END;
+constexpr int FRAGB_U4 = FM21_ENDB;         // uint4 units; the split blob follows the fp32 fragments in the same buffer
 constexpr int N_FRAG_MATS = 22;
 
-#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWD, FM##idx##_TR}
+#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) \
+    {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWD, FM##idx##_TR, FM##idx##_FWDB, FM##idx##_TRB}
 #define LKW_FRAG_TABLE                                                                 \
     LKW_FM_ROW(0,  G_W0, HG, EGP,        EGP, EGP, 96),                                \
     LKW_FM_ROW(1,  G_W1, HG, HG,         HG,  HG,  32),                                \

@@ -67,6 +67,7 @@ uint32_t wave_exchange_u32(uint32_t v, int src_lane);          // returns v of s
 uint64_t wave_ballot(bool p);
 void wave_mfma32x32x2(float a, float b, const float* c, float* d);
 void wave_mfma16x16x4(float a, float b, const float* c, float* d);
+void wave_mfma32x32x16_bf16(const float* a8, const float* b8, const float* c, float* d);
 int lane_id();
 }  // namespace hipemu
 
@@ -138,6 +139,33 @@ static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f
     f32x4_emu d;
     for (int r = 0; r < 4; ++r) d[r] = di[r];
     return d;
+}
+// bf16 MFMA: operands are 8 bf16 per lane (passed as the product's own vector type, widened here)
+typedef __bf16 bf16x8_emu __attribute__((ext_vector_type(8)));
+static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16_emu c, int, int, int) {
+    unsigned short ua[8], ub[8];
+    std::memcpy(ua, &a, 16); std::memcpy(ub, &b, 16);
+    float fa[8], fb[8], ci[16], di[16];
+    for (int e = 0; e < 8; ++e) {
+        unsigned x = (unsigned)ua[e] << 16, y = (unsigned)ub[e] << 16;
+        std::memcpy(&fa[e], &x, 4); std::memcpy(&fb[e], &y, 4);
+    }
+    for (int r = 0; r < 16; ++r) ci[r] = c[r];
+    hipemu::wave_mfma32x32x16_bf16(fa, fb, ci, di);
+    f32x16_emu d;
+    for (int r = 0; r < 16; ++r) d[r] = di[r];
+    return d;
+}
+// v_perm_b32: byte pool {S0 = bytes 7..4, S1 = bytes 3..0}, selector byte n of `sel` picks pool byte (0..7)
+static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long pool = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int n = 0; n < 4; ++n) {
+        const unsigned c = (sel >> (8 * n)) & 0xff;
+        const unsigned byte = c < 8 ? (unsigned)((pool >> (8 * c)) & 0xff) : (c == 0x0c ? 0u : 0xffu);
+        r |= byte << (8 * n);
+    }
+    return r;
 }
 // DPP data movement (v_mov_b32 dpp): quad_perm, row_shl/shr/ror, row_mirror, row_half_mirror, row_bcast15/31.
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {

@@ -39,6 +39,7 @@ struct Wave {
     unsigned gen = 0;
     uint32_t slot[2][64];
     float fa[2][64], fb[2][64];
+    float fa8[2][64][8], fb8[2][64][8];
     uint64_t ballot[2];
 };
 
@@ -136,6 +137,24 @@ void wave_mfma32x32x2(float a, float b, const float* c, float* d) {
         int i = (r & 3) + 8 * (r >> 2) + 4 * h;
         float acc = std::fmaf(w.fa[bf][i], w.fb[bf][j], c[r]);
         d[r] = std::fmaf(w.fa[bf][i + 32], w.fb[bf][j + 32], acc);
+    }
+}
+
+void wave_mfma32x32x16_bf16(const float* a8, const float* b8, const float* c, float* d) {
+    // A: lane l holds A[i=l&31][k=8*(l>>5)+e]; B: B[k=8*(l>>5)+e][j=l&31]; e = 0..7 (bf16 values widened by the caller)
+    Lane& l = g_lanes[g_cur];
+    Wave& w = g_waves[l.wave];
+    if (w.alive != 64) { fprintf(stderr, "hipemu: MFMA with %d live lanes\n", w.alive); abort(); }
+    int bf = w.gen & 1;
+    for (int e = 0; e < 8; ++e) { w.fa8[bf][l.lane][e] = a8[e]; w.fb8[bf][l.lane][e] = b8[e]; }
+    wave_barrier(w);
+    int j = l.lane & 31, h = l.lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int hh = 0; hh < 2; ++hh)
+            for (int e = 0; e < 8; ++e) acc = std::fmaf(w.fa8[bf][i + 32 * hh][e], w.fb8[bf][j + 32 * hh][e], acc);
+        d[r] = acc;
     }
 }
 
