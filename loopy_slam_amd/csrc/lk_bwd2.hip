@@ -210,6 +210,9 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) dout[0][q] *= wgt;
+    // Loads and stores share one in-order counter: a fragment fetched after a store cannot be waited for before that store
+    // has landed.  Every product's fragments are therefore fetched BEFORE the stores that precede it in the data flow
+    // (one block ahead, pinned with scheduling barriers), and the big row stores go last.
     // ---- operands of the streamed weight-gradient reductions that need hid itself
     //   linear2: dW2 = sum_rows (w d c) hid^T = sum_samples d c (sum_j w_j hid_j)^T  -> only the per-SAMPLE weighted
     //            hidden vector Hbar [P][128] and the per-sample weight sum are needed (8x fewer rows, no hid rows)
@@ -217,32 +220,56 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
         float wsum = wgt;
         wsum = lk_sum8(wsum);
         if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float sred = wgt * hid[nb][4 * g + t];
-                    sred = lk_sum8(sred);
-                    v[t] = sred;
-                }
-                if (live && nb_i == 0)
-                    *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
-            }
     }
     // ---- d hid = (W2^T d out) * softplus'(hid), block by block IN PLACE of hid (64 fewer live registers)
     f32x16 (&dhid)[4] = hid;
     const LkB8 db0 = lk_split_ct(dout[0], 0), db1 = lk_split_ct(dout[0], 1);
+    LkB8 fa0 = lk_fragb_load(FB + FM21_TRB, 4, 0, 0, lane), fa1 = lk_fragb_load(FB + FM21_TRB, 4, 1, 0, lane);
+    LkB8 fx[4];                                  // head of the d x product (block 0 of d hid), fetched before the last stores
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         f32x16 t = lk_zero16();
-        t = lk_mma6(lk_fragb_load(FB + FM21_TRB, 4, 0, nb, lane), db0, t);
-        t = lk_mma6(lk_fragb_load(FB + FM21_TRB, 4, 1, nb, lane), db1, t);
+        t = lk_mma6(fa0, db0, t);
+        t = lk_mma6(fa1, db1, t);
+        if (nb < 3) {
+            fa0 = lk_fragb_load(FB + FM21_TRB, 4, 0, nb + 1, lane);
+            fa1 = lk_fragb_load(FB + FM21_TRB, 4, 1, nb + 1, lane);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fx[q] = lk_fragb_load(FB + FM20_TRB, 2, q >> 1, q & 1, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (want_w) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    float sred = wgt * hid[nb][4 * g + tt];
+                    sred = lk_sum8(sred);
+                    v[tt] = sred;
+                }
+                if (live && nb_i == 0)
+                    *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) dhid[nb][q] = t[q] * lk_softplus100_grad_from_out(hid[nb][q]);
     }
+    // ---- d x = W1^T d hid   (virtual 64 input units: 0..19 embedding, 20..51 feature channels)
+    f32x16 dx[2];
+    dx[0] = lk_zero16(); dx[1] = lk_zero16();
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int G = 0; G < 2; ++G) {
+            const LkB8 b = lk_split_ct(dhid[nb], G);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                dx[kb] = lk_mma6(nb == 0 ? fx[2 * G + kb] : lk_fragb_load(FB + FM20_TRB, 2, 2 * nb + G, kb, lane), b, dx[kb]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (want_w) {
         //   linear1: rows [8P][192] = d hid (128) | x (64)
         if (live) {
@@ -261,11 +288,6 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
             }
         }
     }
-    // ---- d x = W1^T d hid   (virtual 64 input units: 0..19 embedding, 20..51 feature channels)
-    f32x16 dx[2];
-    dx[0] = lk_zero16(); dx[1] = lk_zero16();
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) lk_gemm_b6<2, 2>(dx, FB + FM20_TRB, 2, 2 * nb, 0, dhid[nb], 0, lane);
     float dax = 0.0f, day = 0.0f, daz = 0.0f;        // d loss / d (x_I - p), this lane's share
     const float* B = W + R_EB;
 #pragma unroll

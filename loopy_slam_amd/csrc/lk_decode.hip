@@ -76,11 +76,11 @@ __device__ __forceinline__ f32x16 sincos_embed_tile(const float* __restrict__ B,
     return e;
 }
 
-// bias + activation (+ optional save) + fc_c(c): h = act(acc + b) + (U c + u)
+// bias + activation (+ optional save) + fc_c(c): h = act(acc + b) + (U c + u); c arrives as its two split blocks
 template <int NB, bool SOFTPLUS>
 __device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB], const float* __restrict__ bias,
-                                             const float* __restrict__ Ufrag, const float* __restrict__ ubias,
-                                             const f32x16& c, float* __restrict__ save_a, bool live, int lane) {
+                                             const u32x4* __restrict__ UfragB, const float* __restrict__ ubias,
+                                             const LkB8 (&cb)[2], float* __restrict__ save_a, bool live, int lane) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         lk_add_rowvec(acc[nb], bias, nb * 32, lane);
@@ -88,8 +88,9 @@ __device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB], const float* __r
         for (int r = 0; r < 16; ++r) acc[nb][r] = SOFTPLUS ? lk_softplus100(acc[nb][r]) : fmaxf(acc[nb][r], 0.0f);
         if (save_a) ct_store_rows32(save_a + nb * 32, acc[nb], live, lane);
         lk_add_rowvec(acc[nb], ubias, nb * 32, lane);
+#pragma unroll
+        for (int G = 0; G < 2; ++G) acc[nb] = lk_mma6(lk_fragb_load(UfragB, NB, G, nb, lane), cb[G], acc[nb]);
     }
-    lk_gemm_frag<NB, 4>(acc, Ufrag, NB, 0, 0, c, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -121,45 +122,51 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const float* __restrict__ F = a.Wfrag;
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_geo = save ? a.act + (size_t)sp * LK_ACT_GEO_A : nullptr;
-    const f32x16 e0 = geo_embed_tile(W + G_EB, 0, a0, a1, a2, lane);
-    const f32x16 e1 = geo_embed_tile(W + G_EB, 1, a0, a1, a2, lane);
-    const f32x16 e2 = geo_embed_tile(W + G_EB, 2, a0, a1, a2, lane);
-    const f32x16 cg = ct_load_rows32(a.c_geo + (size_t)sp * LK_C, true, lane);
+    // the 96 embedding units and the interpolated feature are B operands twice / five times: split once
+    LkB8 eb[6], cb[2];
+    {
+        const f32x16 e0 = geo_embed_tile(W + G_EB, 0, a0, a1, a2, lane);
+        eb[0] = lk_split_ct(e0, 0); eb[1] = lk_split_ct(e0, 1);
+        const f32x16 e1 = geo_embed_tile(W + G_EB, 1, a0, a1, a2, lane);
+        eb[2] = lk_split_ct(e1, 0); eb[3] = lk_split_ct(e1, 1);
+        const f32x16 e2 = geo_embed_tile(W + G_EB, 2, a0, a1, a2, lane);
+        eb[4] = lk_split_ct(e2, 0); eb[5] = lk_split_ct(e2, 1);
+        const f32x16 cg = ct_load_rows32(a.c_geo + (size_t)sp * LK_C, true, lane);
+        cb[0] = lk_split_ct(cg, 0); cb[1] = lk_split_ct(cg, 1);
+    }
     f32x16 acc[1], hh;
     // layer 0: 93 -> 32
     acc[0] = lk_zero16();
-    lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 0, 0, e0, lane);
-    lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 4, 0, e1, lane);
-    lk_gemm_frag<1, 4>(acc, F + FM0_FWD, 1, 8, 0, e2, lane);
-    layer_finish<1, false>(acc, W + G_B0, F + FM5_FWD, W + G_U0 + a64(HG * CF), cg, act_geo, live, lane);
+#pragma unroll
+    for (int G = 0; G < 6; ++G) acc[0] = lk_mma6(lk_fragb_load(FB + FM0_FWDB, 1, G, 0, lane), eb[G], acc[0]);
+    layer_finish<1, false>(acc, W + G_B0, FB + FM5_FWDB, W + G_U0 + a64(HG * CF), cb, act_geo, live, lane);
     hh = acc[0];
     // layers 1, 2: 32 -> 32
     acc[0] = lk_zero16();
-    lk_gemm_frag<1, 4>(acc, F + FM1_FWD, 1, 0, 0, hh, lane);
-    layer_finish<1, false>(acc, W + G_B1, F + FM6_FWD, W + G_U0 + G_USTRIDE + a64(HG * CF), cg,
+    lk_gemm_b6<1, 2>(acc, FB + FM1_FWDB, 1, 0, 0, hh, 0, lane);
+    layer_finish<1, false>(acc, W + G_B1, FB + FM6_FWDB, W + G_U0 + G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 32 : nullptr, live, lane);
     hh = acc[0];
     acc[0] = lk_zero16();
-    lk_gemm_frag<1, 4>(acc, F + FM2_FWD, 1, 0, 0, hh, lane);
-    layer_finish<1, false>(acc, W + G_B2, F + FM7_FWD, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cg,
+    lk_gemm_b6<1, 2>(acc, FB + FM2_FWDB, 1, 0, 0, hh, 0, lane);
+    layer_finish<1, false>(acc, W + G_B2, FB + FM7_FWDB, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 64 : nullptr, live, lane);
     hh = acc[0];
     // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
     acc[0] = lk_zero16();
-    lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 0, 0, e0, lane);
-    lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 4, 0, e1, lane);
-    lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 8, 0, e2, lane);
-    lk_gemm_frag<1, 4>(acc, F + FM3_FWD, 1, 12, 0, hh, lane);
-    layer_finish<1, false>(acc, W + G_B3, F + FM8_FWD, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cg,
+#pragma unroll
+    for (int G = 0; G < 6; ++G) acc[0] = lk_mma6(lk_fragb_load(FB + FM3_FWDB, 1, G, 0, lane), eb[G], acc[0]);
+    lk_gemm_b6<1, 2>(acc, FB + FM3_FWDB, 1, 6, 0, hh, 0, lane);
+    layer_finish<1, false>(acc, W + G_B3, FB + FM8_FWDB, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 96 : nullptr, live, lane);
     hh = acc[0];
     // layer 4
     acc[0] = lk_zero16();
-    lk_gemm_frag<1, 4>(acc, F + FM4_FWD, 1, 0, 0, hh, lane);
-    layer_finish<1, false>(acc, W + G_B4, F + FM9_FWD, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cg,
+    lk_gemm_b6<1, 2>(acc, FB + FM4_FWDB, 1, 0, 0, hh, 0, lane);
+    layer_finish<1, false>(acc, W + G_B4, FB + FM9_FWDB, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 128 : nullptr, live, lane);
     // output 32 -> 1 on the VALU: each half-wave holds 16 of the 32 units of its sample
     float part = 0.0f;
@@ -181,87 +188,115 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
 // SAME lane id in every wave (the C/D-row walk of lk_gemm_frag), so writes and reads are both lane-contiguous
 // (conflict-free ds_write/read_b128).  Double-buffered: one barrier per layer.
 __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
-                                              float4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */) {
+                                              u32x4 (*s_x)[24 * 64] /* [2][24*64] */, float (*s_o)[3 * 32] /* [4][96] */) {
     const DecSample d = dec_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const float* __restrict__ F = a.Wfrag;
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A : nullptr;
     float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H : nullptr;
-    const f32x16 e0 = sincos_embed_tile<4>(W + C_EB, 20, 0, a0, a1, a2, lane);
-    const f32x16 e1 = sincos_embed_tile<1>(W + C_EB, 20, 1, a0, a1, a2, lane);
-    const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
-    if (save && live && w == 0) {    // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
-        float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
-        ct_store_rows32(erow, e0, true, lane);
-        *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1[0], e1[1], e1[2], e1[3]);
+    // embedding (40 units = blocks 0, 1 and half of 2) and interpolated feature: B operands of two / five products, split once
+    LkB8 eb[3], cb[2];
+    {
+        const f32x16 e0 = sincos_embed_tile<4>(W + C_EB, 20, 0, a0, a1, a2, lane);
+        const f32x16 e1 = sincos_embed_tile<1>(W + C_EB, 20, 1, a0, a1, a2, lane);
+        if (save && live && w == 0) {    // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
+            float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
+            ct_store_rows32(erow, e0, true, lane);
+            *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1[0], e1[1], e1[2], e1[3]);
+        }
+        eb[0] = lk_split_ct(e0, 0); eb[1] = lk_split_ct(e0, 1); eb[2] = lk_split_ct(e1, 0);
+        const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
+        cb[0] = lk_split_ct(cc, 0); cb[1] = lk_split_ct(cc, 1);
     }
-    auto park = [&](const f32x16& t, int buf, int L) {     // own block -> LDS chunks (and the saved h rows)
+    // a block travels to the other waves through LDS as SPLIT pieces (the producer splits once, the four consumers read
+    // bf16): block (w, G), piece p at [((w*2 + G)*3 + p)*64 + lane], lane-contiguous 16-byte accesses both ways
+    // Loads and stores share one in-order counter on this chip: a weight fragment fetched AFTER the activation stores of
+    // a layer cannot be waited for without waiting for those stores too.  So everything a layer's epilogue and the head
+    // of the next product need is fetched BEFORE the stores (wn: first four hidden blocks of the next layer, un: fc_c),
+    // pinned with scheduling barriers; the tail of the product (blocks 4..7) is fetched in line, long after the stores.
+    LkB8 wn[4], un[2];
+    auto prefetch_hidden = [&](const u32x4* fragb, int G0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            s_x[buf][(w * 4 + j) * 64 + lane] = make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
-        if (save) ct_store_rows32(act_col_h + L * 128 + w * 32, t, live, lane);
+        for (int G = 0; G < 4; ++G) wn[G] = lk_fragb_load(fragb, 4, G0 + G, w, lane);
     };
-    // bias + softplus (+ save) + fc_c(c) with prefetched U fragments, for the wave's own 32-unit block
-    auto finish = [&](f32x16& acc, const float* bias, const float4 (&uv)[4], const float* ubias, float* save_a) {
+    auto prefetch_u = [&](const u32x4* ufragb) {
+#pragma unroll
+        for (int G = 0; G < 2; ++G) un[G] = lk_fragb_load(ufragb, 4, G, w, lane);
+    };
+    // acc += W[own block][hidden 128] h with h read from LDS; G0 = first 16-k block of the hidden part in the matrix
+    auto hidden = [&](f32x16& acc, const u32x4* fragb, int G0, int buf) {
+#pragma unroll
+        for (int G = 0; G < 8; ++G) {
+            LkB8 b;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b.p[q] = s_x[buf][(G * 3 + q) * 64 + lane];
+            acc = lk_mma6(G < 4 ? wn[G] : lk_fragb_load(fragb, 4, G0 + G, w, lane), b, acc);
+        }
+    };
+    auto embed = [&](f32x16& acc, const u32x4* fragb) {
+#pragma unroll
+        for (int G = 0; G < 3; ++G) acc = lk_mma6(lk_fragb_load(fragb, 4, G, w, lane), eb[G], acc);
+    };
+    // bias + softplus + fc_c(c) for the wave's own 32-unit block, then ALL stores of the layer: saved a / h rows, LDS park
+    auto finish = [&](f32x16& acc, const float* bias, const float* ubias, float* save_a, int L, int buf) {
         lk_add_rowvec(acc, bias, w * 32, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);
-        if (save_a) ct_store_rows32(save_a + w * 32, acc, live, lane);
+        const f32x16 act = acc;
         lk_add_rowvec(acc, ubias, w * 32, lane);
-        lk_gemm_regs<4>(acc, uv, cc);
+#pragma unroll
+        for (int G = 0; G < 2; ++G) acc = lk_mma6(un[G], cb[G], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (save_a) ct_store_rows32(save_a + w * 32, act, live, lane);
+        if (save) ct_store_rows32(act_col_h + L * 128 + w * 32, acc, live, lane);
+        if (buf >= 0) {
+#pragma unroll
+            for (int G = 0; G < 2; ++G) {
+                const LkB8 b = lk_split_ct(acc, G);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) s_x[buf][((w * 2 + G) * 3 + q) * 64 + lane] = b.p[q];
+            }
+        }
     };
     f32x16 acc;
-    float4 wa[5], wb[16], uv[4];      // wa: embedding groups of layers 0 / 3, wb: the 16 hidden groups, uv: fc_c
     // layer 0: 40 -> 128
-    lk_frag_prefetch<5>(wa, F + FM10_FWD, 4, 0, w, lane);
-    lk_frag_prefetch<4>(uv, F + FM15_FWD, 4, 0, w, lane);
+    prefetch_u(FB + FM15_FWDB);
     acc = lk_zero16();
-    {
-        const float4 (&wa4)[4] = reinterpret_cast<const float4 (&)[4]>(wa);
-        lk_gemm_regs<4>(acc, wa4, e0);
-        const float4 (&wa1)[1] = reinterpret_cast<const float4 (&)[1]>(wa[4]);
-        lk_gemm_regs<1>(acc, wa1, e1);
-    }
-    lk_frag_prefetch<16>(wb, F + FM11_FWD, 4, 0, w, lane);                 // layer 1 weights: in flight during the epilogue
-    finish(acc, W + C_B0, uv, W + C_U0 + a64(HC * CF), act_col_a);
-    park(acc, 0, 0);
-    lk_frag_prefetch<4>(uv, F + FM16_FWD, 4, 0, w, lane);
+    embed(acc, FB + FM10_FWDB);
+    prefetch_hidden(FB + FM11_FWDB, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(acc, W + C_B0, W + C_U0 + a64(HC * CF), act_col_a, 0, 0);
     __syncthreads();
     // layers 1, 2: 128 -> 128
 #pragma unroll
     for (int L = 1; L <= 2; ++L) {
+        prefetch_u(FB + (L == 1 ? FM16_FWDB : FM17_FWDB));
         acc = lk_zero16();
-        lk_gemm_regs_lds<16, 0, 16>(acc, wb, s_x[(L - 1) & 1], lane);
-        if (L == 1) lk_frag_prefetch<16>(wb, F + FM12_FWD, 4, 0, w, lane);
-        else { lk_frag_prefetch<5>(wa, F + FM13_FWD, 4, 0, w, lane); lk_frag_prefetch<16>(wb, F + FM13_FWD, 4, 5, w, lane); }
-        finish(acc, W + (L == 1 ? C_B1 : C_B2), uv, W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + L * 128 : nullptr);
-        park(acc, L & 1, L);
-        lk_frag_prefetch<4>(uv, F + (L == 1 ? FM17_FWD : FM18_FWD), 4, 0, w, lane);
+        hidden(acc, FB + (L == 1 ? FM11_FWDB : FM12_FWDB), 0, (L - 1) & 1);
+        if (L == 1) prefetch_hidden(FB + FM12_FWDB, 0);
+        else prefetch_hidden(FB + FM13_FWDB, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(acc, W + (L == 1 ? C_B1 : C_B2), W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + L * 128 : nullptr, L, L & 1);
         __syncthreads();
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
+    prefetch_u(FB + FM18_FWDB);
     acc = lk_zero16();
-    {
-        const float4 (&wa4)[4] = reinterpret_cast<const float4 (&)[4]>(wa);
-        lk_gemm_regs<4>(acc, wa4, e0);
-        const float4 (&wa1)[1] = reinterpret_cast<const float4 (&)[1]>(wa[4]);
-        lk_gemm_regs<1>(acc, wa1, e1);
-    }
-    lk_gemm_regs_lds<16, 0, 16>(acc, wb, s_x[0], lane);
-    lk_frag_prefetch<16>(wb, F + FM14_FWD, 4, 0, w, lane);
-    finish(acc, W + C_B3, uv, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 3 * 128 : nullptr);
-    park(acc, 1, 3);
-    lk_frag_prefetch<4>(uv, F + FM19_FWD, 4, 0, w, lane);
+    embed(acc, FB + FM13_FWDB);
+    hidden(acc, FB + FM13_FWDB, 3, 0);
+    prefetch_hidden(FB + FM14_FWDB, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(acc, W + C_B3, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 3 * 128 : nullptr, 3, 1);
     __syncthreads();
     // layer 4
+    prefetch_u(FB + FM19_FWDB);
     acc = lk_zero16();
-    lk_gemm_regs_lds<16, 0, 16>(acc, wb, s_x[1], lane);
-    finish(acc, W + C_B4, uv, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 4 * 128 : nullptr);
-    if (save) ct_store_rows32(act_col_h + 4 * 128 + w * 32, acc, live, lane);
+    hidden(acc, FB + FM14_FWDB, 0, 1);
+    finish(acc, W + C_B4, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 4 * 128 : nullptr, 4, -1);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
@@ -301,8 +336,8 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
 // Block roles: the first `n_col_blocks` workgroups are colour tiles (4 waves per tile), the rest run the geometry
 // decoder (4 independent tiles per workgroup).  raw[:, 0:3] and raw[:, 3] are written by the two roles separately;
 // in the geometry stage there are no colour blocks and raw[:, 0:3] is zero-filled by the geometry wave.
-__global__ __launch_bounds__(256) void k_decode_fwd(LkDecodeArgs a, int n_col_blocks) {
-    __shared__ float4 s_x[2][16 * 64];
+__global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col_blocks) {
+    __shared__ u32x4 s_x[2][24 * 64];
     __shared__ float s_o[4][3 * 32];
     const int lane = lk_lane();
     const int w = (int)threadIdx.x >> 6;

@@ -34,22 +34,23 @@ for N in NS:
             i = torch.randint(0, Wd, (R,), generator=g).float().cuda(); j = torch.randint(0, H, (R,), generator=g).float().cuda()
         ro, rd = syn.pixel_rays(c2w, i, j)
         gd = depth[j.long(), i.long()].contiguous()
-        st = core.RenderState(eng, R, cfg.S)
+        SAVE = bool(os.environ.get('PROBE_SAVE'))
+        st = core.RenderState(eng, R, cfg.S, need_act=SAVE) if SAVE else core.RenderState(eng, R, cfg.S)
         for stage in ('geometry', 'color'):
             for _ in range(3):
-                core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage)
+                core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage, save_act=SAVE)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             n = 10
             e0.record()
             for _ in range(n):
-                core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage)
+                core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage, save_act=SAVE)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
             if os.environ.get('PROBE_KERNELS'):
                 kt = profile.KernelTimer(eng, '*'); kt.start()
                 for _ in range(n):
-                    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage)
+                    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, stage, save_act=SAVE)
                 torch.cuda.synchronize()
                 print('      ' + '  '.join(f"{k[2:]}={v['total_ms'] / v['calls'] * 1e3:.1f}us" for k, v in kt.stop().items()))
             print(f'  R={R:7d} rel_pos={int(rel)} {stage:8s}: {ms:8.3f} ms  {R/ms/1e3:9.1f} Mrays/s  valid={int(st.valid_ray.sum())} meanhas={float((st.nbr_count>=2).float().mean()):.2f}')
