@@ -130,3 +130,44 @@ def test_frustum_rows_and_insertion_at_five_million_points():
     assert acc.numel() == 0 and pts.numel() == 0
     acc, pts = optim.add_points(eng, knn, eng.f32(ro + 100.0), eng.f32(rd), eng.f32(gd), 0.04 ** 2, 0.98, 1.02)
     assert acc.numel() == 50_000 and pts.shape == (150_000, 3) and torch.equal(acc.cpu(), torch.arange(50_000, dtype=torch.int32))
+
+
+@pytest.mark.parametrize('R', (3000, 5000, 10000, 40000))
+def test_render_is_deterministic_at_scale(R):
+    """The same forward (saved activations) and the same backward twice give the same bits in every buffer that does not
+    go through float atomics.  Catches what small parity cases cannot: intra-workgroup races and instruction-level
+    hazards that only show with several workgroups per compute unit (a split-bf16 backward once passed every parity
+    test and produced half-tiles of wrong d h in ~1 % of the tiles from 3 000 rays on)."""
+    eng = make_engine('hip')
+    pos, geo, col, knn = _scene(eng, 100_000)
+    blob = core.DecoderBlob(eng).pack(syn.default_weights())
+    cfg = core.RenderCfg()
+    depth, _, c2w = syn.render_frame(7, device='cuda', holes=0.02)
+    g = torch.Generator().manual_seed(R)
+    i = torch.randint(0, I['W'], (R,), generator=g).float().cuda()
+    j = torch.randint(0, I['H'], (R,), generator=g).float().cuda()
+    ro, rd = syn.pixel_rays(c2w, i, j)
+    gd = depth[j.long(), i.long()].contiguous()
+    st = core.RenderState(eng, R, cfg.S, need_act=True)
+    d1, c1 = torch.randn(R, generator=g).cuda(), torch.randn(R, 3, generator=g).cuda()
+    runs = []
+    for rep in range(3):
+        core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, 'color', save_act=True)
+        gs = core.GradState(eng, pos.shape[0], R, blob.n, feats=True, weights=True)
+        core.render_backward(eng, st, gs, d1, c1)
+        torch.cuda.synchronize()
+        runs.append(dict(act=st.act.clone(), raw=st.raw.clone(), depth=st.depth.clone(), color=st.color.clone(),
+                         scratch=gs.scratch.clone(), g_geo=gs.g_geo.clone(), g_col=gs.g_col.clone(), g_w=gs.g_weights.clone()))
+    P = R * cfg.S
+    # scratch regions written by plain stores (lk_api.hip::bwd_layout order): d_raw .. dlogit, then hbar, dfeat, w_sum, d h, rows
+    exact_until = (4 + 32 + 32 + 4 + 4 + 4 + 4 + 8 + 8 + 4) * P
+    for r in runs[1:]:
+        for k in ('act', 'raw', 'depth', 'color'):
+            assert torch.equal(r[k], runs[0][k]), k
+        assert torch.equal(r['scratch'][:exact_until], runs[0]['scratch'][:exact_until])
+        # everything else (partials, gradient rows and the final gradients) to the noise of atomic summation order
+        for k in ('scratch', 'g_geo', 'g_col', 'g_w'):
+            a, b = r[k], runs[0][k]
+            ok = torch.isfinite(a) & torch.isfinite(b)      # unused tail of the scratch is uninitialised
+            scale = float(b[ok].abs().max()) + 1e-12
+            assert float((a[ok] - b[ok]).abs().max()) <= 1e-5 * scale, (k, float((a[ok] - b[ok]).abs().max()), scale)
