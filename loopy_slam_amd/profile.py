@@ -18,7 +18,13 @@ Algorithmic work per unit (DESIGN.md §Kernels states the same figures):
 import ctypes as C
 
 PEAK_F32_MFMA_TFLOPS = 157.3
+# fp32 products as six bf16 piece products on the bf16 matrix pipe (lk_common.h::lk_mma6): dense bf16 peak 2516.6 TFLOP/s
+# (32x32x16 at 32 cycles, 256 CUs x 4 SIMDs x 2.4 GHz) / 6 instructions per fp32-equivalent product block
+PEAK_BF16_MFMA_TFLOPS = 2516.6
+PEAK_F32_VIA_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
+# matrix path of each MFMA-bound kernel: 'f32' = v_mfma_f32_32x32x2_f32, 'bf16x6' = split products
+MFMA_PATH = {'k_decode_fwd': 'bf16x6', 'k_relpos_fwd': 'bf16x6', 'k_relpos_bwd': 'bf16x6', 'k_decode_bwd': 'f32', 'k_wgrad': 'f32'}
 S = 5
 
 MAC = dict(
@@ -95,10 +101,13 @@ def roofline(kstat, budget, kernel):
     n_steps = k['calls'] / model['launches']
     secs = k['total_ms'] * 1e-3
     flops, nbytes = model['flops'] * n_steps, model['bytes'] * n_steps
-    t_mfma, t_hbm = flops / (PEAK_F32_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+    path = MFMA_PATH.get(kernel, 'f32')
+    peak_mfma = PEAK_F32_VIA_BF16X6_TFLOPS if path == 'bf16x6' else PEAK_F32_MFMA_TFLOPS
+    t_mfma, t_hbm = flops / (peak_mfma * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
     out = {'kernel': kernel, 'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'], 'traffic': None}
     if t_mfma >= t_hbm:
-        out.update(bound='mfma', achieved=flops / secs / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s')
+        out.update(bound='mfma', achieved=flops / secs / 1e12, peak=peak_mfma, unit='TFLOP/s', mfma_path=path,
+                   frac_of_f32_mfma_peak=flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS)
     else:
         out.update(bound='hbm', achieved=nbytes / secs / 1e9, peak=PEAK_HBM_GBS, unit='GB/s')
     out['frac'] = out['achieved'] / out['peak']
