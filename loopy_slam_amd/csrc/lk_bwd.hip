@@ -110,13 +110,13 @@ __device__ __forceinline__ BwdSample bwd_sample(const LkDecodeBwdArgs& a, int ti
 // The embedding gradient tiles (tracker mode) are spread evenly: layer 3's two tiles on waves 0,1, layer 0's on
 // waves 2,3; every wave turns its tile into a d p partial and wave 0 adds the four.
 __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int tile, int w, int lane,
-                                                  float4* __restrict__ s_x /* [2][16*64] */, float (*s_o)[3 * 32]) {
+                                                  u32x4* __restrict__ s_x /* [2][24*64] */, float (*s_o)[3 * 32]) {
     const BwdSample d = bwd_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const float* __restrict__ F = a.Wfrag;
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A;
@@ -191,39 +191,77 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     }
     f32x16 dc = lk_zero16(), de = lk_zero16();
     int buf = 0;
-    // weight fragments are fetched one product ahead (lk_frag_prefetch): uv = U_i^T groups of the own units,
-    // wb = the 16 groups of W_i^T for the own output block
-    float4 uv[4], wb[16];
-    lk_frag_prefetch<4>(uv, F + FM19_TR, 1, 4 * w, 0, lane);
-    lk_frag_prefetch<16>(wb, F + FM14_TR, 4, 0, w, lane);
+    // Split-bf16 products (lk_common.h::lk_mma6).  Loads and stores share one in-order counter, so what a layer needs
+    // right after its d h store - un = U_i^T blocks of the own units, av = saved a_i, wn = first four blocks of W_i^T for
+    // the own output block - is fetched BEFORE that store, at the end of the previous layer; blocks 4..7 come in line.
+    LkB8 un[2], wn[4];
+    f32x16 av;
+    auto prefetch = [&](int i) {
+        const u32x4* ut = FB + (i == 0 ? FM15_TRB : i == 1 ? FM16_TRB : i == 2 ? FM17_TRB : i == 3 ? FM18_TRB : FM19_TRB);
+#pragma unroll
+        for (int G = 0; G < 2; ++G) un[G] = lk_fragb_load(ut, 1, 2 * w + G, 0, lane);
+        av = ct_load32(act_col_a + i * 128 + w * 32, lane);
+        if (i >= 1) {
+            const u32x4* wt = FB + (i == 4 ? FM14_TRB : i == 3 ? FM13_TRB : i == 2 ? FM12_TRB : FM11_TRB);
+#pragma unroll
+            for (int G = 0; G < 4; ++G) wn[G] = lk_fragb_load(wt, i == 3 ? 6 : 4, G, i == 3 ? 2 + w : w, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto lds_b = [&](const u32x4* xs, int G) {
+        LkB8 b;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b.p[q] = xs[(G * 3 + q) * 64 + lane];
+        return b;
+    };
+    prefetch(4);
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
-        if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dh, live, lane);
-        lk_gemm_regs<4>(dc, uv, dh);
-        if (i > 0) lk_frag_prefetch<4>(uv, F + (i == 1 ? FM15_TR : i == 2 ? FM16_TR : i == 3 ? FM17_TR : FM18_TR), 1, 4 * w, 0, lane);
-        const f32x16 av = ct_load32(act_col_a + i * 128 + w * 32, lane);
+        // STORE-DATA RULE (measured; tests/test_fullsize_gpu.py::test_render_is_deterministic_at_scale): a global store whose
+        // data registers are the accumulators that the NEXT MFMA chain overwrites came out wrong for half a tile in ~1 % of
+        // the tiles once two workgroups shared a compute unit (the scattered 16-byte row stores queue up in the memory
+        // pipe).  The store therefore reads a copy that stays allocated until the end of the layer.
+        f32x16 dhc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { float t = dh[q]; asm volatile("" : "+v"(t)); dhc[q] = t; }
+        if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dhc, live, lane);
+#pragma unroll
+        for (int G = 0; G < 2; ++G) dc = lk_mma6(un[G], lk_split_ct(dh, G), dc);
 #pragma unroll
         for (int q = 0; q < 16; ++q) dy[q] = dh[q] * lk_softplus100_grad_from_out(av[q]);
         if (i == 0 && !want_p) break;
-        float4* xs = s_x + buf * (16 * 64);
+        u32x4* xs = s_x + buf * (24 * 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xs[(w * 4 + j) * 64 + lane] = make_float4(dy[4 * j], dy[4 * j + 1], dy[4 * j + 2], dy[4 * j + 3]);
+        for (int G = 0; G < 2; ++G) {
+            const LkB8 b = lk_split_ct(dy, G);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xs[((w * 2 + G) * 3 + q) * 64 + lane] = b.p[q];
+        }
         __syncthreads();
         buf ^= 1;
         if (i >= 1) {
+            const u32x4* wt = FB + (i == 4 ? FM14_TRB : i == 3 ? FM13_TRB : i == 2 ? FM12_TRB : FM11_TRB);
+            const int nbt = i == 3 ? 6 : 4, nb = i == 3 ? 2 + w : w;
             dh = lk_zero16();
-            lk_gemm_regs_lds<16, 0, 16>(dh, wb, xs, lane);
-            if (i == 3 && want_p && w < 2) lk_gemm_frag_lds<16>(de, F + FM13_TR, 6, 0, w, xs, lane);
-            if (i == 4) lk_frag_prefetch<16>(wb, F + FM13_TR, 6, 0, 2 + w, lane);
-            else if (i == 3) lk_frag_prefetch<16>(wb, F + FM12_TR, 4, 0, w, lane);
-            else if (i == 2) lk_frag_prefetch<16>(wb, F + FM11_TR, 4, 0, w, lane);
+#pragma unroll
+            for (int G = 0; G < 8; ++G) dh = lk_mma6(G < 4 ? wn[G] : lk_fragb_load(wt, nbt, G, nb, lane), lds_b(xs, G), dh);
+            if (i == 3 && want_p && w < 2) {
+#pragma unroll
+                for (int G = 0; G < 8; ++G) de = lk_mma6(lk_fragb_load(FB + FM13_TRB, 6, G, w, lane), lds_b(xs, G), de);
+            }
+            prefetch(i - 1);
         } else {       // i == 0: only the embedding receives gradient
-            if (w >= 2) lk_gemm_frag_lds<16>(de, F + FM10_TR, 2, 0, w - 2, xs, lane);
+            if (w >= 2) {
+#pragma unroll
+                for (int G = 0; G < 8; ++G) de = lk_mma6(lk_fragb_load(FB + FM10_TRB, 2, G, w - 2, lane), lds_b(xs, G), de);
+            }
         }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" :: "v"(dhc[q]));
     }
     // d c: park the per-wave partials, wave w sums register chunk w of all four -> one float4 per lane
     {
-        float4* xs = s_x + buf * (16 * 64);
+        float4* xs = reinterpret_cast<float4*>(s_x + buf * (24 * 64));
 #pragma unroll
         for (int j = 0; j < 4; ++j) xs[(w * 4 + j) * 64 + lane] = make_float4(dc[4 * j], dc[4 * j + 1], dc[4 * j + 2], dc[4 * j + 3]);
         float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;
@@ -269,7 +307,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const float* __restrict__ F = a.Wfrag;
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_geo = a.act + (size_t)sp * LK_ACT_GEO_A;
@@ -288,23 +326,23 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
         dcg[0] = lk_zero16(); de[0] = lk_zero16(); de[1] = lk_zero16(); de[2] = lk_zero16();
 #pragma unroll
         for (int i = 4; i >= 0; --i) {
-            const float* Utr = F + (i == 0 ? FM5_TR : i == 1 ? FM6_TR : i == 2 ? FM7_TR : i == 3 ? FM8_TR : FM9_TR);
-            lk_gemm_frag<1, 4>(dcg, Utr, 1, 0, 0, dh, lane);
+            const u32x4* Utr = FB + (i == 0 ? FM5_TRB : i == 1 ? FM6_TRB : i == 2 ? FM7_TRB : i == 3 ? FM8_TRB : FM9_TRB);
+            lk_gemm_b6<1, 2>(dcg, Utr, 1, 0, 0, dh, 0, lane);
             const f32x16 av = ct_load32(act_geo + i * 32, lane);
 #pragma unroll
             for (int q = 0; q < 16; ++q) dy[q] = (av[q] > 0.0f) ? dh[q] : 0.0f;
             if (i == 4 || i == 2 || i == 1) {
                 acc1[0] = lk_zero16();
-                lk_gemm_frag<1, 4>(acc1, F + (i == 4 ? FM4_TR : i == 2 ? FM2_TR : FM1_TR), 1, 0, 0, dy, lane);
+                lk_gemm_b6<1, 2>(acc1, FB + (i == 4 ? FM4_TRB : i == 2 ? FM2_TRB : FM1_TRB), 1, 0, 0, dy, 0, lane);
                 dh = acc1[0];
             } else if (i == 3) {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) acc4[kb] = lk_zero16();
-                lk_gemm_frag<4, 4>(acc4, F + FM3_TR, 4, 0, 0, dy, lane);
+                lk_gemm_b6<4, 2>(acc4, FB + FM3_TRB, 4, 0, 0, dy, 0, lane);
                 de[0] = acc4[0]; de[1] = acc4[1]; de[2] = acc4[2];
                 dh = acc4[3];
             } else {
-                lk_gemm_frag<3, 4>(de, F + FM0_TR, 3, 0, 0, dy, lane);
+                lk_gemm_b6<3, 2>(de, FB + FM0_TRB, 3, 0, 0, dy, 0, lane);
             }
         }
         ct_store32(a.dc_geo + (size_t)sp * LK_C, dcg[0], live, lane);
@@ -346,7 +384,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
 // wave -> LDS -> one partial row per workgroup, and summed by k_reduce_partials.
 // Block roles as in k_decode_fwd: the first n_col_blocks workgroups are colour tiles, the rest geometry (4 tiles each).
 __global__ __launch_bounds__(256, 2) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
-    __shared__ float4 s_x[2 * 16 * 64];
+    __shared__ u32x4 s_x[2 * 24 * 64];
     __shared__ float s_o[4][3 * 32];
     const int w = (int)threadIdx.x >> 6;
     if ((int)blockIdx.x < n_col_blocks) {
