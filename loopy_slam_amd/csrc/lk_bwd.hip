@@ -116,7 +116,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A;
@@ -307,7 +307,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_geo = a.act + (size_t)sp * LK_ACT_GEO_A;

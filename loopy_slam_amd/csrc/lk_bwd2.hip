@@ -151,7 +151,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     const float a1 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 1], py));
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
     const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;

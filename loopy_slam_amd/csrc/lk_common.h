@@ -154,85 +154,10 @@ __device__ __forceinline__ f32x16 lk_zero16() {
 // Activations live as "CT tiles": a [32 units x 32 samples] block held in the MFMA C/D layout
 // (lane = sample column, registers = unit rows).  One layer is Y^T = W * X^T with
 //   A operand = W[out = nb*32 + (lane&31)][k],  B operand = X^T[k][sample = lane&31].
-// The reduction index k is walked in the order the C/D layout stores rows: at step (g,t) the
-// low half-wave carries k = 8g+t and the high half k = 8g+4+t — exactly register 4g+t of the
-// CT tile of the previous layer, so a layer's output feeds the next layer's B operand straight
-// from registers (no LDS, no barrier).
-//
-// The A operands come from the FRAGMENT blob (lk_weights.h): block (g, nb) is 64 lanes x 16 B =
-// one contiguous 1-KiB piece holding, for lane l, the four t-consecutive weights it needs, so a
-// wave-wide load touches 8 fully used 128-B lines (a row-major [out][in] matrix would touch 32
-// lines and use a quarter of each).  `frag` = first block of the matrix, NBT = blocks per k-group
-// (= out/32 for the forward form, = virtual_in/32 for the transposed form), g0 = first k-group,
-// nb0 = first output block.  The same routine serves dX^T = W^T dY^T on the transposed fragments.
-template <int NB, int NG>
-__device__ __forceinline__ void lk_gemm_frag(f32x16 (&acc)[NB], const float* __restrict__ frag, int NBT,
-                                             int g0, int nb0, const f32x16& x, int lane) {
-    const float* __restrict__ base = frag + ((size_t)g0 * NBT + nb0) * 256 + lane * 4;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)g * NBT + nb) * 256);
-            acc[nb] = lk_mfma(a.x, x[4 * g + 0], acc[nb]);
-            acc[nb] = lk_mfma(a.y, x[4 * g + 1], acc[nb]);
-            acc[nb] = lk_mfma(a.z, x[4 * g + 2], acc[nb]);
-            acc[nb] = lk_mfma(a.w, x[4 * g + 3], acc[nb]);
-        }
-    }
-}
-
-// Same walk with the B operand parked in LDS as per-lane float4 register chunks: xs[g * 64 + lane] = registers
-// 4g'..4g'+3 of CT tile (g / 4) as written by the lane with the same id in the wave owning that tile.
-template <int NG>
-__device__ __forceinline__ void lk_gemm_frag_lds(f32x16& acc, const float* __restrict__ frag, int NBT, int g0, int nb,
-                                              const float4* __restrict__ xs /* [NG][64] chunks */, int lane) {
-    const float* __restrict__ base = frag + ((size_t)g0 * NBT + nb) * 256 + lane * 4;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const float4 w = *reinterpret_cast<const float4*>(base + (size_t)g * NBT * 256);
-        const float4 x = xs[g * 64 + lane];
-        acc = lk_mfma(w.x, x.x, acc);
-        acc = lk_mfma(w.y, x.y, acc);
-        acc = lk_mfma(w.z, x.z, acc);
-        acc = lk_mfma(w.w, x.w, acc);
-    }
-}
-
-// Explicit weight-fragment prefetch.  The compiler schedules an A-operand load right before the MFMAs that use it
-// (minimal registers): with two or three waves per SIMD that exposes an L2 round trip per k-group.  The layer
-// structure offers free slots instead - the weights of the NEXT product do not depend on activations - so they are
-// fetched into registers early (NG x 16 B per lane) and the position is pinned with a scheduling barrier.
-template <int NG>
-__device__ __forceinline__ void lk_frag_prefetch(float4 (&wv)[NG], const float* __restrict__ frag, int NBT, int g0, int nb, int lane) {
-    const float* __restrict__ base = frag + ((size_t)g0 * NBT + nb) * 256 + lane * 4;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) wv[g] = *reinterpret_cast<const float4*>(base + (size_t)g * NBT * 256);
-    __builtin_amdgcn_sched_barrier(0);
-}
-// acc += W[g0..g0+NG) X with the weights already in registers; x = CT tile in registers (NG <= 4 groups of it)
-template <int NG>
-__device__ __forceinline__ void lk_gemm_regs(f32x16& acc, const float4 (&wv)[NG], const f32x16& x) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        acc = lk_mfma(wv[g].x, x[4 * g + 0], acc);
-        acc = lk_mfma(wv[g].y, x[4 * g + 1], acc);
-        acc = lk_mfma(wv[g].z, x[4 * g + 2], acc);
-        acc = lk_mfma(wv[g].w, x[4 * g + 3], acc);
-    }
-}
-// same with the B operand parked in LDS (see lk_gemm_frag_lds); WOFF = first register of wv to use
-template <int NG, int WOFF, int NW>
-__device__ __forceinline__ void lk_gemm_regs_lds(f32x16& acc, const float4 (&wv)[NW], const float4* __restrict__ xs, int lane) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const float4 x = xs[g * 64 + lane];
-        acc = lk_mfma(wv[WOFF + g].x, x.x, acc);
-        acc = lk_mfma(wv[WOFF + g].y, x.y, acc);
-        acc = lk_mfma(wv[WOFF + g].z, x.z, acc);
-        acc = lk_mfma(wv[WOFF + g].w, x.w, acc);
-    }
-}
+// The reduction index k is walked in the order the C/D layout stores rows: lane half h of register 4g+t holds row
+// 8g + 4h + t, so the registers of the previous layer's accumulator ARE the next layer's B operand (no LDS, no
+// barrier): eight consecutive registers (two row groups) feed one 16-k matrix instruction, the weight fragments are laid
+// out in the same k order (lk_weights.h), and a wave-wide 16-byte fragment load is one contiguous, fully used 1-KiB block.
 
 // ------------------------------------------------------------------ fp32 products on the bf16 matrix pipe ("bf16x6")
 // v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles for 2 k) and - measured - does not overlap with the VALU

@@ -122,7 +122,7 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_geo = save ? a.act + (size_t)sp * LK_ACT_GEO_A : nullptr;
     // the 96 embedding units and the interpolated feature are B operands twice / five times: split once
@@ -194,7 +194,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A : nullptr;
     float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H : nullptr;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     const float a1 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 1], py));
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag + FRAG_FLOATS);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
     const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
     // X^T tiles: units 0..19 embedding, 20..51 feature channels 0..31, 52..55 zero
     f32x16 x0, x1;

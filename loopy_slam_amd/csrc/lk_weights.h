@@ -62,35 +62,29 @@ constexpr int BLOB_FLOATS = R_B2 + 64;
 
 
 // ---------------------------------------------------------------------------------------------
-// Derived "fragment" blob (lk_weights_repack): every GEMM matrix re-laid so that one wave-wide
-// 16-byte load is ONE contiguous, fully used 1-KiB block.
-//   forward   block (kg, nb): lane l, t  ->  W[nb*32 + (l&31)][8*kg + 4*(l>>5) + t]          (kg-major)
-//   transposed block (ng, kb): lane l, t ->  W[8*ng + 4*(l>>5) + t][vcol = kb*32 + (l&31)]   (ng-major)
-// "vcol" is a virtual input column: the embedding part of a skip/first layer is padded to a
-// multiple of 32 (colour: 40 -> 64) so that every 32-wide block of dX^T is either embedding or hidden.
-struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwd, tr, fwdb, trb; };
+// Derived "fragment" blob (lk_weights_repack): every GEMM matrix re-laid in the operand order of the matrix
+// instruction, every weight cut into three bf16 pieces hi + mid + lo (exact; lk_common.h::lk_mma6), in two forms:
+//   forward    block (G, nb): lane l, element i -> W[nb*32 + (l&31)][k(G, l>>5, i)]
+//   transposed block (G, kb): lane l, element i -> W[k(G, l>>5, i)][vcol = kb*32 + (l&31)]
+// with k(G, h, i) = 16 G + 4 h + i (i < 4), 16 G + 8 + 4 h + (i - 4) (i >= 4): the two C/D-row-walk groups (2G, 2G+1) of
+// a CT tile, i.e. registers 8G..8G+7 of the previous layer's accumulators are the matching B operand.
+// One block = the 8 k-values a lane feeds to ONE v_mfma_f32_32x32x16_bf16, for the 3 pieces:
+//   block = [piece 0..2][lane 0..63] uint4  (3 KiB contiguous, three fully used 1-KiB wave loads);  offsets in uint4 units.
+// "vcol" is a virtual input column: the embedding part of a skip/first layer is padded to a multiple of 32 (colour:
+// 40 -> 64) so that every 32-wide block of dX^T is either embedding or hidden.  In the forward form a skip / first
+// layer's embedding columns form their own run of blocks, zero-padded to a multiple of 16 columns, so that a block never
+// straddles the embedding and the hidden part (their B operands live in different CT tiles).
+struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwdb, trb; };
 
-// ---------------------------------------------------------------------------------------------
-// Split-bf16 fragments (the operands of the bf16x6 products, lk_common.h::lk_mma6): the same two forms with every weight
-// cut into three bf16 pieces hi + mid + lo (exact).  One block = the 8 k-values a lane feeds to ONE
-// v_mfma_f32_32x32x16_bf16, i.e. the two fp32 k-groups (2G, 2G+1) of the walk above, for the 3 pieces:
-//   block (G, nb) = [piece 0..2][lane 0..63] uint4  (3 KiB contiguous),  offsets below in uint4 units.
-// A skip / first layer's embedding columns form their own run of blocks, zero-padded to a multiple of 16 columns, so
-// that a block never straddles the embedding and the hidden part (their B operands live in different CT tiles).
 constexpr int kb16(int k) { return (k + 15) / 16; }
 constexpr int fwd_blocks16(int ld, int e_real) { return e_real < ld ? kb16(e_real) + kb16(ld - e_real) : kb16(ld); }
 
-
-// fwd size = rows*ld ; tr size = kv*rows
 #define LKW_FM(idx, plain_, rows_, ld_, ereal_, evirt_, kv_, prev_)                              \
-    constexpr int FM##idx##_FWD = FM##prev_##_END;                                               \
-    constexpr int FM##idx##_TR = FM##idx##_FWD + (rows_) * (ld_);                                \
-    constexpr int FM##idx##_END = FM##idx##_TR + (kv_) * (rows_);                                \
     constexpr int FM##idx##_FWDB = FM##prev_##_ENDB;                                             \
     constexpr int FM##idx##_TRB = FM##idx##_FWDB + fwd_blocks16(ld_, ereal_) * ((rows_) / 32) * 192; \
     constexpr int FM##idx##_ENDB = FM##idx##_TRB + ((rows_) / 16) * ((kv_) / 32) * 192;
 
-constexpr int FMS_END = 0, FMS_ENDB = 0;
+constexpr int FMS_ENDB = 0;
 
 // index:            plain   rows ld            e_real e_virt kv
 LKW_FM(0,  G_W0, HG, EGP,        EGP, EGP, 96,  S)
@@ -115,12 +109,10 @@ LKW_FM(18, C_U0 + 3 * C_USTRIDE, HC, CF, CF, CF, 32, 17)
 LKW_FM(19, C_U0 + 4 * C_USTRIDE, HC, CF, CF, CF, 32, 18)
 LKW_FM(20, R_W1, HC, KRP,        KRP, 64,  64,  19)
 LKW_FM(21, R_W2, CF, HC,         HC,  HC,  128, 20)
-constexpr int FRAG_FLOATS = FM21_END;
-constexpr int FRAGB_U4 = FM21_ENDB;         // uint4 units; the split blob follows the fp32 fragments in the same buffer
+constexpr int FRAGB_U4 = FM21_ENDB;         // uint4 units
 constexpr int N_FRAG_MATS = 22;
 
-#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) \
-    {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWD, FM##idx##_TR, FM##idx##_FWDB, FM##idx##_TRB}
+#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWDB, FM##idx##_TRB}
 #define LKW_FRAG_TABLE                                                                 \
     LKW_FM_ROW(0,  G_W0, HG, EGP,        EGP, EGP, 96),                                \
     LKW_FM_ROW(1,  G_W1, HG, HG,         HG,  HG,  32),                                \
