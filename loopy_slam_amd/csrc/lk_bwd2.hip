@@ -386,7 +386,7 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
 }
 
 template <int NV, int KV, int MODE>
-__device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int j, int n_waves, int lane,
+__device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane,
                                            float* __restrict__ tile) {
     const int i = lane & 31, h = lane >> 5;
     // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
@@ -413,15 +413,15 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
     float bsum[NV];
 #pragma unroll
     for (int b = 0; b < NV; ++b) bsum[b] = 0.0f;
-    // this wave's rows: chunks j, j + n_waves, j + 2 n_waves, ... of WG_CHUNK = 2 * WG_STEPS rows each
+    // this wave's rows: chunks c0, c0 + stride, c0 + 2 stride, ... of WG_CHUNK = 2 * WG_STEPS rows each
     const int rows = J.rows, last = rows - 1;
     const int n_chunks = (rows + WG_CHUNK - 1) / WG_CHUNK;
-    const int my_chunks = (j < n_chunks) ? (n_chunks - j + n_waves - 1) / n_waves : 0;
+    const int my_chunks = (c0 < n_chunks) ? (n_chunks - c0 + stride - 1) / stride : 0;
     WgVec<NV> ra[WG_STEPS], ra2[WG_STEPS];
     WgVec<KV> rb[WG_STEPS];
     float rw[WG_STEPS];
     auto fetch1 = [&](int s, int n) {              // slot s <- row pair s of this wave's n-th chunk (clamped past the end)
-        int row = (j + n * n_waves) * WG_CHUNK + 2 * s + h;
+        int row = (c0 + n * stride) * WG_CHUNK + 2 * s + h;
         row = (row < last && n < my_chunks) ? row : last;
         ra[s] = wg_load<NV>(pA + (size_t)row * lda);
         if (mode == 1) ra2[s] = wg_load<NV>(pA2 + (size_t)row * lda2);
@@ -434,7 +434,7 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 #pragma unroll
     for (int s = 0; s < WG_STEPS; ++s) { fetch1(s, 0); __builtin_amdgcn_sched_barrier(0); }    // issue in slot order
     for (int n = 0; n < my_chunks; ++n) {
-        const int row0 = (j + n * n_waves) * WG_CHUNK;
+        const int row0 = (c0 + n * stride) * WG_CHUNK;
 #pragma unroll
         for (int s = 0; s < WG_STEPS; ++s) {
             const bool ok = row0 + 2 * s + h < rows;
@@ -495,32 +495,36 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 }
 
 template <int NV, int KV>
-__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int j, int n_waves, int lane, float* tile) {
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0>(J, n0, k0, j, n_waves, lane, tile);
-    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1>(J, n0, k0, j, n_waves, lane, tile);
-    else wgrad_unit<NV, KV, 2>(J, n0, k0, j, n_waves, lane, tile);
+__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile) {
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0>(J, n0, k0, c0, stride, lane, tile);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1>(J, n0, k0, c0, stride, lane, tile);
+    else wgrad_unit<NV, KV, 2>(J, n0, k0, c0, stride, lane, tile);
 }
 
-// Wave g of the launch belongs to the unit whose [wave0, wave0 + n_waves) range holds g.  Every unit gets a number of
-// waves proportional to its work (rows x MFMAs per row pair), all of a launch's waves are co-resident (two per SIMD),
-// and wave j of a unit takes the chunks j, j + n_waves, ... of 32 rows: the units sweep the rows at the same speed (the
-// operands several units share are still fetched from HBM once) and every wave finishes at about the same time.
+// XCD-AWARE ROW OWNERSHIP.  Several units read the same rows (the 64-column pieces of one operand, or two jobs sharing
+// d h), and every XCD has its own L2: with a unit's waves spread over the chip a row chunk was fetched from HBM by up to
+// eight L2s (417 MB fetched per launch for 185 MB of operands).  Block b runs on XCD b % 8, so chunk c of the rows is
+// handled ON XCD c % 8 BY EVERY UNIT: each XCD gets the same partition of its 256 wave slots into units (waves in
+// proportion to the unit's work), local wave jl of a unit takes the chunks x + 8 (jl + k W), k = 0, 1, ...  All waves of
+// the launch are co-resident (two per SIMD) and sweep the rows at the same speed, so the re-reads hit the XCD's L2.
 __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     const int lane = lk_lane();
-    const int g = lk_uniform((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6));
-    if (g >= a.n_waves) return;
+    const int x = lk_uniform((int)blockIdx.x & 7);
+    const int l = lk_uniform(((int)blockIdx.x >> 3) * 4 + ((int)threadIdx.x >> 6));      // wave slot inside the XCD
+    if (l >= a.n_waves) return;
     int u = 0;
-    while (u + 1 < a.n_units && g >= a.unit[u + 1].wave0) ++u;        // scalar scan, <= 48 entries
+    while (u + 1 < a.n_units && l >= a.unit[u + 1].wave0) ++u;        // scalar scan, <= 48 entries
     const LkWgradUnit& U = a.unit[u];
     const LkWgradJob& J = a.job[U.job];
-    const int j = g - U.wave0;
-    const int n_chunks = (J.rows + WG_CHUNK - 1) / WG_CHUNK;
-    if (j >= n_chunks) return;                                         // more waves than chunks (tiny problems)
-    float* tile = a.part ? a.part + (size_t)g * LK_WG_TILE : nullptr;
-    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2>(J, U.n0, U.k0, j, U.n_waves, lane, tile);
-    else if (U.nv == 2) wgrad_unit_mode<2, 1>(J, U.n0, U.k0, j, U.n_waves, lane, tile);
-    else if (U.kv == 2) wgrad_unit_mode<1, 2>(J, U.n0, U.k0, j, U.n_waves, lane, tile);
-    else wgrad_unit_mode<1, 1>(J, U.n0, U.k0, j, U.n_waves, lane, tile);
+    const int jl = l - U.wave0;
+    const int c0 = x + 8 * jl, stride = 8 * U.n_waves;
+    // a wave without a chunk (tiny problems) still stores its (zero) tile: the reduction sums all 8 W tiles of the unit
+    float* tile = a.part ? a.part + ((size_t)8 * U.wave0 + 8 * jl + x) * LK_WG_TILE : nullptr;
+    if (!tile && c0 >= (J.rows + WG_CHUNK - 1) / WG_CHUNK) return;
+    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2>(J, U.n0, U.k0, c0, stride, lane, tile);
+    else if (U.nv == 2) wgrad_unit_mode<2, 1>(J, U.n0, U.k0, c0, stride, lane, tile);
+    else if (U.kv == 2) wgrad_unit_mode<1, 2>(J, U.n0, U.k0, c0, stride, lane, tile);
+    else wgrad_unit_mode<1, 1>(J, U.n0, U.k0, c0, stride, lane, tile);
 }
 
 // dW += sum over the unit's waves of the partial tiles (tile order: contiguous reads; every output element is owned by
@@ -535,10 +539,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
     const int idx = (int)blockIdx.y * 32 + e;
     const bool in_acc = idx < nv * kv * 1024, in_bias = idx >= 4 * 16 * 64 && idx < 4 * 16 * 64 + 32 * nv;
     if (!in_acc && !in_bias && (int)blockIdx.y * 32 + 31 >= nv * kv * 1024 && (int)blockIdx.y * 32 < 4 * 16 * 64) return;   // unused blocks of a narrow unit
-    const int n_chunks = (J.rows + WG_CHUNK - 1) / WG_CHUNK;
-    const int nblk = U.n_waves < n_chunks ? U.n_waves : n_chunks;      // waves of the unit that stored a tile
+    const int nblk = 8 * U.n_waves;                                    // every wave of the unit stored a tile
     const size_t stride = LK_WG_TILE;
-    const float* __restrict__ src = a.part + (size_t)U.wave0 * LK_WG_TILE + idx;
+    const float* __restrict__ src = a.part + (size_t)8 * U.wave0 * LK_WG_TILE + idx;
     float s = 0.0f;
     if (in_acc || in_bias) {
 #pragma unroll 4
@@ -601,21 +604,21 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
             }
         }
     }
-    // waves per unit in proportion to its work, LK_WG_MAX_WAVES in total (two per SIMD, all co-resident), at most one
-    // wave per 32-row chunk
+    // wave slots PER XCD (LK_WG_MAX_WAVES / 8 = two per SIMD, all co-resident) in proportion to the unit's work, at most
+    // one per 8 x 32-row chunks (chunk c lives on XCD c % 8, see k_wgrad); wave0 / n_waves are per-XCD numbers
     int next = 0;
     for (int u = 0; u < a.n_units; ++u) {
         LkWgradUnit& U = a.unit[u];
-        const int n_chunks = lk_cdiv(a.job[U.job].rows, WG_CHUNK);
-        int w = (int)((LK_WG_MAX_WAVES - a.n_units) * (work[u] / total)) + 1;
-        if (w > n_chunks) w = n_chunks > 0 ? n_chunks : 1;
+        const int n_chunks_x = lk_cdiv(lk_cdiv(a.job[U.job].rows, WG_CHUNK), 8);
+        int w = (int)((LK_WG_MAX_WAVES / 8 - a.n_units) * (work[u] / total)) + 1;
+        if (w > n_chunks_x) w = n_chunks_x > 0 ? n_chunks_x : 1;
         U.wave0 = next; U.n_waves = w;
         next += w;
     }
     a.n_waves = next;
     {
         LkProfScope prof_(LKK_WGRAD, st);                              // timing scope = k_wgrad alone (as rocprof reports it)
-        hipLaunchKernelGGL(k_wgrad, dim3(lk_cdiv(a.n_waves, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_wgrad, dim3(8 * lk_cdiv(a.n_waves, 4)), dim3(256), 0, st, a);
     }
     if (a.part) hipLaunchKernelGGL(k_wgrad_reduce, dim3(a.n_units, lk_cdiv(LK_WG_TILE, 32)), dim3(256), 0, st, a);
     return LK_OK;

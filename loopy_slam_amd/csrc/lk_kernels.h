@@ -136,11 +136,11 @@ struct LkWgradJob {
 };
 #define LK_WGRAD_MAX_JOBS 16
 #define LK_WGRAD_MAX_UNITS 48
-struct LkWgradUnit { int job, n0, k0; short nv, kv; int wave0, n_waves; };   // columns [n0, n0 + 32 nv) x [k0, k0 + 32 kv) of job; its waves
+struct LkWgradUnit { int job, n0, k0; short nv, kv; int wave0, n_waves; };   // columns [n0, n0 + 32 nv) x [k0, k0 + 32 kv) of job; its wave slots PER XCD
 struct LkWgradArgs {
     LkWgradJob job[LK_WGRAD_MAX_JOBS]; int n_jobs;
     int chunk;                                     // unused (kept for lk_wgrad_single's signature)
-    LkWgradUnit unit[LK_WGRAD_MAX_UNITS]; int n_units, n_waves;   // filled by the launcher
+    LkWgradUnit unit[LK_WGRAD_MAX_UNITS]; int n_units, n_waves;   // filled by the launcher (n_waves: used slots per XCD)
     float* part;                                   // [n_waves][LK_WG_TILE] partial tiles (one per wave), or NULL (atomic flush)
 };
 #define LK_WG_MAX_WAVES 2048                       // waves of one weight-gradient launch: two per SIMD, all co-resident
