@@ -17,8 +17,10 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'libloopyhip.so')
 OBJ = os.path.join(HERE, '_obj')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+# -fno-slp-vectorize: packed fp32 VALU instructions (v_pk_fma_f32 ...) take two issue slots and sit badly beside matrix
+# instructions; the SLP vectoriser creates hundreds of them in the decoder kernels (measured: 0.8 % of the step)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-ffp-contract=off']
+         '-ffp-contract=off', '-fno-slp-vectorize']
 
 
 def _newer(src_list, target):
