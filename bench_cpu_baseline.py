@@ -1,7 +1,8 @@
 """cpu_baseline leg of bench.py: the CPU oracle (oracle/hotpath.py — the torch-CPU restatement of the
 reference path, kind "port") timed on the GPU box's host cores on a BOUNDED sample of the benchmark workload:
-one tracking iteration (1500 rays), one 'geometry' and one 'color' mapping iteration (5000 rays each), each
-= render forward + loss + autograd backward + torch.optim.Adam step, after one untimed warm-up of each.
+half a frame's budget of every iteration type (20 tracking iterations of 1500 rays, 12 'geometry' and 18 'color' mapping
+iterations of 5000 rays; ~10-25 s of CPU work, each type time-bounded), each = render forward + loss + autograd backward +
+torch.optim.Adam step, after one untimed warm-up of each.
 The per-frame time is extrapolated with the budget's iteration counts (40 / 24 / 36).
 This is a reported baseline, never a target, and the only place outside tests/ and smoke() that touches oracle/."""
 import os
@@ -70,14 +71,24 @@ def run(budget, seed=1219):
         opt.step()
         return time.perf_counter() - t0
 
-    track_iter(); t_track = track_iter()
-    map_iter('geometry'); t_geo = map_iter('geometry')
-    map_iter('color'); t_col = map_iter('color')
     n_col = budget.map_iters - budget.map_geo_iters
+
+    def timed(fn, reps, limit_s):
+        """mean time of up to `reps` iterations after one warm-up, stopping early once `limit_s` seconds are spent"""
+        fn()
+        ts = []
+        while len(ts) < reps and sum(ts) < limit_s:
+            ts.append(fn())
+        return sum(ts) / len(ts), len(ts)
+
+    # half of one frame's budget of every iteration type (20 / 12 / 18 of 40 / 24 / 36), bounded to ~25 s in total
+    t_track, n_t = timed(track_iter, max(1, budget.track_iters // 2), 6.0)
+    t_geo, n_g = timed(lambda: map_iter('geometry'), max(1, budget.map_geo_iters // 2), 5.0)
+    t_col, n_c = timed(lambda: map_iter('color'), max(1, n_col // 2), 14.0)
     t_frame = budget.track_iters * t_track + budget.map_geo_iters * t_geo + n_col * t_col
     return {'value': budget.rays_per_frame / t_frame, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 tracking iteration ({budget.track_rays} rays, {t_track:.2f} s) + 1 geometry ({t_geo:.2f} s) + 1 colour '
-                      f'({t_col:.2f} s) mapping iteration ({budget.map_rays} rays each), N={budget.n_points} points, '
+            'sample': f'{n_t} tracking iterations ({budget.track_rays} rays, {t_track:.2f} s each) + {n_g} geometry ({t_geo:.2f} s) + {n_c} colour '
+                      f'({t_col:.2f} s) mapping iterations ({budget.map_rays} rays each), N={budget.n_points} points, '
                       f'extrapolated to the {budget.track_iters}/{budget.map_geo_iters}/{n_col} per-frame budget '
                       f'({t_frame:.1f} s/frame); torch {torch.__version__} CPU, {cores} threads',
             'frames_per_s': 1.0 / t_frame}
