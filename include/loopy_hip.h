@@ -186,6 +186,18 @@ typedef struct {
 } lk_adam_seg;
 int lk_adam_step(const lk_adam_seg* host_segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream);
 
+/* Gradient exchange bucket of the ray-sharded data-parallel step (the all-reduce payload of Mapper.py:722-724's
+ * step = decoder-gradient spans + the feature-gradient rows being optimised): segment i is `n` floats at `data`
+ * (row_index NULL) or the rows data[row_index[k]] of a [*, row_len] table (n = rows * row_len); the bucket is the
+ * concatenation of the segments.  unpack = 0: bucket <- segments, 1: segments <- bucket.  One launch either way. */
+typedef struct lk_copy_seg {
+    float* data;
+    int64_t n;
+    const int32_t* row_index;
+    int32_t row_len;
+} lk_copy_seg;
+int lk_bucket_copy(const lk_copy_seg* host_segs, int32_t n_seg, float* bucket, int32_t unpack, void* stream);
+
 /* ---------------------------------------------------------------- rays / pose / compaction
  * get_camera_from_tensor + get_rays_from_uv (src/common.py:301-343,104-120): cam = (qw,qx,qy,qz,tx,ty,tz). */
 int lk_rays_from_pose(const float* cam7, const float* pix_i, const float* pix_j, int32_t R,

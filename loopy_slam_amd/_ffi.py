@@ -58,6 +58,10 @@ class AdamSeg(C.Structure):
                 ('step', C.c_int32), ('row_index', _fp), ('row_len', C.c_int32), ('zero_grad', C.c_int32)]
 
 
+class CopySeg(C.Structure):
+    _fields_ = [('data', _fp), ('n', C.c_int64), ('row_index', _fp), ('row_len', C.c_int32)]
+
+
 class LoopyError(RuntimeError):
     pass
 
@@ -96,6 +100,7 @@ class LoopyLib:
             ('lk_loss_mapper', [C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_int32, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_loss_tracker', [C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_adam_step', [C.POINTER(AdamSeg), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p], C.c_int),
+            ('lk_bucket_copy', [C.POINTER(CopySeg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
             ('lk_rays_from_pose', [_fp, _fp, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_pose_bwd', [_fp, _fp, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_gather_rays', [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -554,6 +554,41 @@ extern "C" int lk_adam_step(const lk_adam_seg* segs, int32_t n_seg, float beta1,
     return LK_OK;
 }
 
+// ------------------------------------------------------------------ all-reduce bucket pack / unpack
+struct CopySeg { float* data; long long n, off; const int32_t* row_index; int row_len; };
+struct CopyArgs { CopySeg s[LK_ADAM_MAX_SEG]; int n_seg; float* bucket; int unpack; };
+__global__ __launch_bounds__(256) void k_bucket_copy(CopyArgs a) {
+    const CopySeg sg = a.s[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < sg.n; i += (long long)gridDim.x * 256) {
+        long long src = i;
+        if (sg.row_index) { const long long r = i / sg.row_len; src = (long long)sg.row_index[r] * sg.row_len + (i - r * sg.row_len); }
+        if (a.unpack) sg.data[src] = a.bucket[sg.off + i];
+        else a.bucket[sg.off + i] = sg.data[src];
+    }
+}
+extern "C" int lk_bucket_copy(const lk_copy_seg* segs, int32_t n_seg, float* bucket, int32_t unpack, void* stream_) {
+    LK_REQUIRE(n_seg >= 0 && n_seg <= LK_ADAM_MAX_SEG, "lk_bucket_copy: too many segments");
+    if (n_seg == 0) return LK_OK;
+    LK_REQUIRE(segs != nullptr && bucket != nullptr, "lk_bucket_copy: NULL argument");
+    CopyArgs a;
+    memset(&a, 0, sizeof(a));
+    long long off = 0, nmax = 0;
+    for (int i = 0; i < n_seg; ++i) {
+        LK_REQUIRE(segs[i].n >= 0 && (segs[i].n == 0 || segs[i].data), "lk_bucket_copy: bad segment");
+        a.s[i].data = segs[i].data; a.s[i].n = segs[i].n; a.s[i].off = off;
+        a.s[i].row_index = segs[i].row_index; a.s[i].row_len = segs[i].row_len > 0 ? segs[i].row_len : 1;
+        off += segs[i].n;
+        if (segs[i].n > nmax) nmax = segs[i].n;
+    }
+    a.n_seg = n_seg; a.bucket = bucket; a.unpack = unpack;
+    if (nmax == 0) return LK_OK;
+    int gx = lk_cdiv(nmax, 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_bucket_copy, dim3(gx, n_seg), dim3(256), 0, (hipStream_t)stream_, a);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
 extern "C" int lk_rays_from_pose(const float* cam7, const float* pix_i, const float* pix_j, int32_t R,
                                  float fx, float fy, float cx, float cy, float* rays_o, float* rays_d, void* stream_) {
     LK_REQUIRE(R >= 0, "lk_rays_from_pose: R < 0");

@@ -8,6 +8,9 @@ feature-gradient tables restricted to the rows being optimised (row_index), pack
 import torch
 import torch.distributed as dist
 
+from . import _ffi
+from ._ffi import ptr
+
 
 def _merge(ranges, gap=4096):
     """(offset, n) ranges -> few contiguous spans (alignment padding between neighbouring tensors rides along: one copy
@@ -29,28 +32,28 @@ class DistContext:
     def all_reduce_grads(self, mo, stage='color'):
         """mo: steps.MapOptimizer after render_backward.  Sum over ranks exactly what this stage's Adam step consumes:
         the decoder-gradient ranges being stepped (geometry: embedder._B only; colour: + every colour-decoder tensor),
-        g_geo[rows], and in the colour stage g_col[rows] - one bucket, one all-reduce."""
-        gs = mo.gs
-        rows = mo.rows.long() if mo.rows is not None else None
+        g_geo[rows], and in the colour stage g_col[rows] - one bucket, one all-reduce, one pack and one unpack launch
+        (lk_bucket_copy: the torch formulation was eight small kernels per iteration)."""
+        gs, eng = mo.gs, mo.eng
         ranges = _merge(list(mo.geo_dec_ranges) + (list(mo.col_dec_ranges) if stage == 'color' else []))
         tables = [gs.g_geo] + ([gs.g_col] if stage == 'color' else [])
-        parts = [gs.g_weights[o:o + n] for o, n in ranges]
-        parts += [(t.index_select(0, rows) if rows is not None else t).reshape(-1) for t in tables]
-        n = sum(p.numel() for p in parts)
-        if self._bucket is None or self._bucket.numel() != n:
-            self._bucket = torch.empty(n, dtype=torch.float32, device=parts[0].device)
-        torch.cat(parts, out=self._bucket)
-        dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
-        o = 0
-        for off, cnt in ranges:
-            gs.g_weights[off:off + cnt].copy_(self._bucket[o:o + cnt]); o += cnt
-        for t in tables:
-            if rows is not None:
-                k = rows.numel() * t.shape[1]
-                t.index_copy_(0, rows, self._bucket[o:o + k].view(-1, t.shape[1])); o += k
+        segs = (_ffi.CopySeg * (len(ranges) + len(tables)))()
+        n = 0
+        for k, (o, cnt) in enumerate(ranges):
+            segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(gs.g_weights[o:o + cnt]), cnt, None, 1
+            n += cnt
+        for k, t in enumerate(tables, start=len(ranges)):
+            if mo.rows is not None:
+                segs[k].data, segs[k].n = ptr(t), mo.rows.numel() * t.shape[1]
+                segs[k].row_index, segs[k].row_len = ptr(mo.rows), t.shape[1]
             else:
-                k = t.numel()
-                t.view(-1).copy_(self._bucket[o:o + k]); o += k
+                segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(t), t.numel(), None, 1
+            n += segs[k].n
+        if self._bucket is None or self._bucket.numel() != n:
+            self._bucket = torch.empty(n, dtype=torch.float32, device=gs.g_weights.device)
+        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(self._bucket), 0, eng.stream), 'lk_bucket_copy')
+        dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
+        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(self._bucket), 1, eng.stream), 'lk_bucket_copy')
 
     def all_reduce_vec(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

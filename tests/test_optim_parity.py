@@ -169,3 +169,37 @@ def test_inside_mask_and_compact(backend):
         assert k == int(ref_mask.sum())
         assert np.array_equal(idx.cpu().numpy()[:k], torch.nonzero(ref_mask).reshape(-1).numpy())
 
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_bucket_copy_roundtrip(backend):
+    """lk_bucket_copy (the all-reduce bucket of the data-parallel step): pack = concatenation of weight spans and gathered
+    table rows, unpack writes them back - against the torch formulation (index_select / cat / index_copy_)."""
+    import ctypes as C
+    from loopy_slam_amd import _ffi
+    from loopy_slam_amd._ffi import ptr
+    eng = make_engine(backend)
+    g = torch.Generator().manual_seed(5)
+    w = eng.f32(torch.randn(5000, generator=g))
+    ta, tb = eng.f32(torch.randn(300, 32, generator=g)), eng.f32(torch.randn(300, 32, generator=g))
+    rows = torch.randperm(300, generator=g)[:77].sort().values.to(torch.int32).to(eng.device)
+    spans = [(64, 1000), (2048, 1500)]
+    segs = (_ffi.CopySeg * 4)()
+    for k, (o, n) in enumerate(spans):
+        segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(w[o:o + n]), n, None, 1
+    for k, t in ((2, ta), (3, tb)):
+        segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(t), rows.numel() * 32, ptr(rows), 32
+    n = sum(c for _, c in spans) + 2 * rows.numel() * 32
+    bucket = eng.zeros(n)
+    eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, 4, ptr(bucket), 0, eng.stream), 'lk_bucket_copy')
+    ref = torch.cat([w[o:o + c] for o, c in spans] + [t.index_select(0, rows.long()).reshape(-1) for t in (ta, tb)])
+    assert torch.equal(bucket.cpu(), ref.cpu())
+    # unpack twice the bucket: only the addressed spans / rows change
+    w0, ta0 = w.clone(), ta.clone()
+    bucket.mul_(2.0)
+    eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, 4, ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
+    exp_w = w0.clone()
+    for o, c in spans:
+        exp_w[o:o + c] *= 2.0
+    exp_ta = ta0.clone(); exp_ta[rows.long()] *= 2.0
+    assert torch.equal(w.cpu(), exp_w.cpu()) and torch.equal(ta.cpu(), exp_ta.cpu())
