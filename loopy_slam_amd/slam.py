@@ -648,12 +648,16 @@ class SyntheticRoomDataset:
         self.n_img = n_frames or cfg['data'].get('n_frames', 50)
         c = cfg['cam']
         self.intr = dict(H=c['H'], W=c['W'], fx=c['fx'], fy=c['fy'], cx=c['cx'], cy=c['cy'])
+        self.crop_edge = c.get('crop_edge', 0) or 0
 
     def __len__(self):
         return self.n_img
 
     def __getitem__(self, idx):
         d, c, p = synthetic.render_frame(idx, intr=self.intr, device=self.device, holes=0.01, n_poses=2000)   # ~3 mm, 0.2 deg per frame
+        e = self.crop_edge
+        if e > 0:       # the reference's readers crop the frames (src/utils/datasets.py), Point_SLAM.update_cam the intrinsics
+            d, c = d[e:-e, e:-e].contiguous(), c[e:-e, e:-e].contiguous()
         return idx, c, d, p
 
 

@@ -117,7 +117,9 @@ def test_point_slam_dynamic_radius_and_gradient_sampling(backend):
     cfg['use_dynamic_radius'] = True
     cfg['tracking']['sample_with_color_grad'] = True
     cfg['pointcloud'].update(radius_add_max=0.08, radius_add_min=0.02, radius_query_ratio=2, color_grad_threshold=0.15)
+    cfg['cam']['crop_edge'] = 1            # both configs crop the frames (tum.yaml / scannet.yaml): 22 x 30 images, cx, cy shifted
     ps = slam.Point_SLAM(cfg, None, eng=eng)
+    assert (ps.H, ps.W) == (22, 30)
     est, gt = ps.run()
     assert ps.npc.pts_num() > 300 and torch.isfinite(est).all()
     assert float((est[:, :3, 3] - gt[:, :3, 3]).norm(dim=1).max()) < 0.1
