@@ -186,6 +186,22 @@ typedef struct {
 } lk_adam_seg;
 int lk_adam_step(const lk_adam_seg* host_segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream);
 
+/* Exposure encoding (model.encode_exposure, ScanNet): mlp_exposure = Linear(8,128) -> Softplus(100) -> Linear(128,12)
+ * (src/conv_onet/models/decoder.py:534-540) evaluated for F exposure features at once (the keyframes of the mapping window,
+ * Mapper.py:588-607, or the tracker's frame, Tracker.py:329-344): aff [F,12] = (3x3 rot | 3 trans), hid [F,128] kept for
+ * the backward.  lk_exposure_bwd turns d loss / d aff into g = [W1 1024 | b1 128 | W2 1536 | b2 12 | feats F*8].
+ * lk_loss_mapper_exposure is lk_loss_mapper of the colour stage with the per-keyframe affine on the rendered colour LOGITS
+ * (Mapper.py:697-715): out d_logits and g_aff [F,12] besides d_depth and [loss, geo, colour, #masked]. */
+#define LK_EXPOSURE_MAX_F 32
+#define LK_EXPOSURE_GRAD_FLOATS (1024 + 128 + 1536 + 12 + LK_EXPOSURE_MAX_F * 8)
+int lk_exposure_fwd(const float* feats, const float* W1, const float* b1, const float* W2, const float* b2, int32_t F,
+                    float* aff, float* hid, void* stream);
+int lk_exposure_bwd(const float* feats, const float* W1, const float* W2, const float* hid, const float* g_aff, int32_t F,
+                    float* g, void* stream);
+int lk_loss_mapper_exposure(int32_t R, const float* depth, const float* logits, const uint8_t* valid_ray, const float* gt_depth,
+                            const float* gt_color, const int32_t* frame_id, const float* aff, int32_t F, float w_color,
+                            float* d_depth, float* d_logits, float* out_loss, float* g_aff, void* stream);
+
 /* Gradient exchange bucket of the ray-sharded data-parallel step (the all-reduce payload of Mapper.py:722-724's
  * step = decoder-gradient spans + the feature-gradient rows being optimised): segment i is `n` floats at `data`
  * (row_index NULL) or the rows data[row_index[k]] of a [*, row_len] table (n = rows * row_len); the bucket is the

@@ -26,6 +26,7 @@ FLAG_GRAD_RAYS = 1 << 7
 FLAG_ALL_DEPTH_POS = 1 << 8
 FLAG_ZERO_ABSENT = 1 << 9
 
+EXPOSURE_MAX_F = 32
 ADAM_MAX_SEG = 16
 
 _fp = C.c_void_p     # every device pointer crosses the ABI as an integer address
@@ -101,6 +102,9 @@ class LoopyLib:
             ('lk_loss_tracker', [C.c_int32, _fp, _fp, _fp, _fp, _fp, C.c_float, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_adam_step', [C.POINTER(AdamSeg), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p], C.c_int),
             ('lk_bucket_copy', [C.POINTER(CopySeg), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p], C.c_int),
+            ('lk_exposure_fwd', [_fp] * 5 + [C.c_int32, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_exposure_bwd', [_fp] * 5 + [C.c_int32, _fp, C.c_void_p], C.c_int),
+            ('lk_loss_mapper_exposure', [C.c_int32] + [_fp] * 7 + [C.c_int32, C.c_float, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_rays_from_pose', [_fp, _fp, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_pose_bwd', [_fp, _fp, _fp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_gather_rays', [_fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -483,6 +483,134 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
     if (t == 0) *out_thr = thr;
 }
 
+
+// ------------------------------------------------------------------ exposure encoding (ScanNet, model.encode_exposure)
+// mlp_exposure = Linear(8,128) -> Softplus(beta=100) -> Linear(128,12) (decoder.py:534-540): one affine (3x3 | 3) per
+// exposure feature.  F <= LK_EXPOSURE_MAX_F features (keyframes of the mapping window, or the tracker's single frame).
+__global__ __launch_bounds__(256) void k_exposure_fwd(const float* __restrict__ feats, const float* __restrict__ W1,
+                                                      const float* __restrict__ b1, const float* __restrict__ W2,
+                                                      const float* __restrict__ b2, int F, float* __restrict__ aff,
+                                                      float* __restrict__ hid) {
+    __shared__ float s_h[LK_EXPOSURE_MAX_F * 128];
+    for (int e = threadIdx.x; e < F * 128; e += 256) {
+        const int f = e >> 7, u = e & 127;
+        float acc = b1[u];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = fmaf(W1[u * 8 + k], feats[f * 8 + k], acc);
+        const float h = lk_softplus100(acc);
+        s_h[e] = h;
+        hid[e] = h;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < F * 12; e += 256) {
+        const int f = e / 12, o = e - f * 12;
+        float acc = b2[o];
+        for (int u = 0; u < 128; ++u) acc = fmaf(W2[o * 128 + u], s_h[f * 128 + u], acc);
+        aff[e] = acc;
+    }
+}
+
+// gradients of the exposure MLP and features from d loss / d affine [F,12]: g = [W1 1024 | b1 128 | W2 1536 | b2 12 | feats F*8]
+__global__ __launch_bounds__(256) void k_exposure_bwd(const float* __restrict__ feats, const float* __restrict__ W1,
+                                                      const float* __restrict__ W2, const float* __restrict__ hid,
+                                                      const float* __restrict__ g_aff, int F, float* __restrict__ g) {
+    __shared__ float s_ga[LK_EXPOSURE_MAX_F * 12];
+    __shared__ float s_dp[LK_EXPOSURE_MAX_F * 128];      // d loss / d pre-activation
+    for (int e = threadIdx.x; e < F * 12; e += 256) s_ga[e] = g_aff[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < F * 128; e += 256) {
+        const int f = e >> 7, u = e & 127;
+        float dh = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 12; ++o) dh = fmaf(W2[o * 128 + u], s_ga[f * 12 + o], dh);
+        s_dp[e] = dh * lk_softplus100_grad_from_out(hid[e]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += 256) {                  // g W1 [128][8]
+        const int u = e >> 3, k = e & 7;
+        float acc = 0.0f;
+        for (int f = 0; f < F; ++f) acc = fmaf(s_dp[f * 128 + u], feats[f * 8 + k], acc);
+        g[e] = acc;
+    }
+    for (int u = threadIdx.x; u < 128; u += 256) {                   // g b1
+        float acc = 0.0f;
+        for (int f = 0; f < F; ++f) acc += s_dp[f * 128 + u];
+        g[1024 + u] = acc;
+    }
+    for (int e = threadIdx.x; e < 1536; e += 256) {                  // g W2 [12][128]
+        const int o = e >> 7, u = e & 127;
+        float acc = 0.0f;
+        for (int f = 0; f < F; ++f) acc = fmaf(s_ga[f * 12 + o], hid[f * 128 + u], acc);
+        g[1152 + e] = acc;
+    }
+    for (int o = threadIdx.x; o < 12; o += 256) {                    // g b2
+        float acc = 0.0f;
+        for (int f = 0; f < F; ++f) acc += s_ga[f * 12 + o];
+        g[2688 + o] = acc;
+    }
+    for (int e = threadIdx.x; e < F * 8; e += 256) {                 // g feats
+        const int f = e >> 3, k = e & 7;
+        float acc = 0.0f;
+        for (int u = 0; u < 128; ++u) acc = fmaf(W1[u * 8 + k], s_dp[f * 128 + u], acc);
+        g[2700 + e] = acc;
+    }
+}
+
+// Mapper loss of the colour stage with exposure encoding (Mapper.py:691-720): the rays of keyframe f get
+// sigmoid(logits @ rot_f + trans_f); returns d depth, d logits, [loss, geo, colour, #masked] and d loss / d affine [F,12].
+__global__ __launch_bounds__(256) void k_loss_mapper_exposure(int R, const float* __restrict__ depth, const float* __restrict__ logits,
+                                                              const uint8_t* __restrict__ valid, const float* __restrict__ gt_depth,
+                                                              const float* __restrict__ gt_color, const int32_t* __restrict__ frame_id,
+                                                              const float* __restrict__ aff, int F, float w_color,
+                                                              float* __restrict__ d_depth, float* __restrict__ d_logits,
+                                                              float* __restrict__ out, float* __restrict__ g_aff) {
+    __shared__ float s_aff[LK_EXPOSURE_MAX_F * 12], s_g[LK_EXPOSURE_MAX_F * 12], s_sum[3];
+    for (int e = threadIdx.x; e < F * 12; e += 256) { s_aff[e] = aff[e]; s_g[e] = 0.0f; }
+    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0.0f;
+    __syncthreads();
+    float geo = 0.0f, col = 0.0f, cnt = 0.0f;
+    for (int r = blockIdx.x * 256 + (int)threadIdx.x; r < R; r += gridDim.x * 256) {
+        const float d = depth[r], gd = gt_depth[r];
+        const bool m = (gd > 0.0f) && valid[r] && !(d != d);
+        float dd = 0.0f, dl[3] = {0.0f, 0.0f, 0.0f};
+        if (m) {
+            const int f = frame_id ? frame_id[r] : 0;
+            const float* A = s_aff + f * 12;
+            const float l0 = logits[3 * r], l1 = logits[3 * r + 1], l2 = logits[3 * r + 2];
+            float dp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float pre = l0 * A[c] + l1 * A[3 + c] + l2 * A[6 + c] + A[9 + c];      // (logits @ rot)[c] + trans[c]
+                const float y = lk_sigmoid(pre);
+                const float e = y - gt_color[3 * r + c];
+                col += fabsf(e);
+                dp[c] = w_color * sgn(e) * y * (1.0f - y);
+            }
+            geo += fabsf(gd - d);
+            dd = sgn(d - gd);
+            cnt += 1.0f;
+            const float lv[3] = {l0, l1, l2};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dl[i] = A[3 * i] * dp[0] + A[3 * i + 1] * dp[1] + A[3 * i + 2] * dp[2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) atomicAdd(&s_g[f * 12 + 3 * i + c], lv[i] * dp[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&s_g[f * 12 + 9 + c], dp[c]);
+        }
+        d_depth[r] = dd;
+        d_logits[3 * r] = dl[0]; d_logits[3 * r + 1] = dl[1]; d_logits[3 * r + 2] = dl[2];
+    }
+    atomicAdd(&s_sum[0], geo); atomicAdd(&s_sum[1], col); atomicAdd(&s_sum[2], cnt);
+    __syncthreads();
+    for (int e = threadIdx.x; e < F * 12; e += 256) atomicAdd(g_aff + e, s_g[e]);
+    if (threadIdx.x == 0) {
+        atomicAdd(out + 0, s_sum[0] + w_color * s_sum[1]);
+        atomicAdd(out + 1, s_sum[0]); atomicAdd(out + 2, s_sum[1]); atomicAdd(out + 3, s_sum[2]);
+    }
+}
+
 // ------------------------------------------------------------------ host API
 extern "C" int lk_loss_mapper(int32_t R, const float* depth, const float* color, const uint8_t* valid_ray,
                               const float* gt_depth, const float* gt_color, float w_color, int32_t use_color,
@@ -522,6 +650,41 @@ extern "C" int lk_loss_tracker(int32_t R, const float* depth, const float* var, 
     hipLaunchKernelGGL(k_loss_tracker_pass1, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, gt_depth, scratch);
     hipLaunchKernelGGL(k_loss_tracker_pass2, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, color, gt_depth,
                        gt_color, w_color, (int)use_color, (const float*)scratch, d_depth, d_color, out_loss);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+
+extern "C" int lk_exposure_fwd(const float* feats, const float* W1, const float* b1, const float* W2, const float* b2, int32_t F,
+                               float* aff, float* hid, void* stream_) {
+    LK_REQUIRE(F >= 1 && F <= LK_EXPOSURE_MAX_F, "lk_exposure_fwd: F out of range");
+    LK_REQUIRE(feats && W1 && b1 && W2 && b2 && aff && hid, "lk_exposure_fwd: NULL buffer");
+    hipLaunchKernelGGL(k_exposure_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream_, feats, W1, b1, W2, b2, (int)F, aff, hid);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+extern "C" int lk_exposure_bwd(const float* feats, const float* W1, const float* W2, const float* hid, const float* g_aff, int32_t F,
+                               float* g, void* stream_) {
+    LK_REQUIRE(F >= 1 && F <= LK_EXPOSURE_MAX_F, "lk_exposure_bwd: F out of range");
+    LK_REQUIRE(feats && W1 && W2 && hid && g_aff && g, "lk_exposure_bwd: NULL buffer");
+    hipLaunchKernelGGL(k_exposure_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream_, feats, W1, W2, hid, g_aff, (int)F, g);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+extern "C" int lk_loss_mapper_exposure(int32_t R, const float* depth, const float* logits, const uint8_t* valid_ray,
+                                       const float* gt_depth, const float* gt_color, const int32_t* frame_id, const float* aff,
+                                       int32_t F, float w_color, float* d_depth, float* d_logits, float* out_loss, float* g_aff,
+                                       void* stream_) {
+    LK_REQUIRE(R >= 0 && F >= 1 && F <= LK_EXPOSURE_MAX_F && out_loss && g_aff && aff, "lk_loss_mapper_exposure: bad arguments");
+    LK_REQUIRE(R == 0 || (depth && logits && valid_ray && gt_depth && gt_color && d_depth && d_logits), "lk_loss_mapper_exposure: NULL buffer");
+    hipStream_t st = (hipStream_t)stream_;
+    LK_HIP_TRY(hipMemsetAsync(out_loss, 0, 4 * sizeof(float), st));
+    LK_HIP_TRY(hipMemsetAsync(g_aff, 0, (size_t)F * 12 * sizeof(float), st));
+    if (R == 0) return LK_OK;
+    int gx = lk_cdiv(R, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_loss_mapper_exposure, dim3(gx), dim3(256), 0, st, (int)R, depth, logits, valid_ray, gt_depth, gt_color,
+                       frame_id, aff, (int)F, w_color, d_depth, d_logits, out_loss, g_aff);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

@@ -501,6 +501,7 @@ class Mapper:
         for it in range(num_joint_iters):
             stage = 'geometry' if it <= geo_iters else 'color'
             mo.iterate(stage, stack, rnd[it], fid, (0, H, 0, W), intr, H, W, log_row=log[it])
+        mo.finish()
         self.last_log = log
         self.prev_c2w = cur_c2w.clone()
         return None

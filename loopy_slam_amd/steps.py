@@ -15,6 +15,7 @@ synchronisation in the loop:
 import torch
 
 from . import _ffi, core, optim
+from ._ffi import ptr
 
 GEO_DECODER_PARAMS = ('geo_decoder.embedder._B',)      # fix_geo_decoder: True (Mapper.py:537-541)
 COLOR_DECODER_PARAMS = tuple(
@@ -49,6 +50,53 @@ class RayBatch:
         return d
 
 
+class ExposureState:
+    """model.encode_exposure (ScanNet): mlp_exposure (Linear 8->128, Softplus(100), Linear 128->12; decoder.py:534-540) and
+    the exposure features it is applied to - the tracker's frame (Tracker.py:329-344) or the keyframes of the mapping
+    window (Mapper.py:588-607) - evaluated, differentiated and stepped (Adam, lr 1e-3) by kernels: lk_exposure_fwd /
+    lk_exposure_bwd + five lk_adam_step segments.  The torch module's parameters are updated IN PLACE (they stay the
+    owner for state_dict); several features are stacked into one [F,8] buffer and written back by finish()."""
+
+    LR = 0.001
+
+    def __init__(self, eng, mlp, feats):
+        self.eng = eng
+        self.W1, self.b1, self.W2, self.b2 = (mlp[0].weight.data, mlp[0].bias.data, mlp[2].weight.data, mlp[2].bias.data)
+        for t in (self.W1, self.b1, self.W2, self.b2):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        assert tuple(self.W1.shape) == (128, 8) and tuple(self.W2.shape) == (12, 128)
+        self.single = torch.is_tensor(feats)
+        self.orig = [feats] if self.single else list(feats)
+        self.F = len(self.orig)
+        assert 1 <= self.F <= _ffi.EXPOSURE_MAX_F
+        self.feats = feats.data if self.single else torch.stack([f.detach() for f in self.orig]).contiguous()
+        self.aff, self.hid = eng.zeros(self.F, 12), eng.zeros(self.F, 128)
+        self.g_aff = eng.zeros(self.F, 12)
+        self.g = eng.zeros(2700 + self.F * 8)
+
+    def forward(self):
+        e = self.eng
+        e.lib.check(e.lib.dll.lk_exposure_fwd(ptr(self.feats), ptr(self.W1), ptr(self.b1), ptr(self.W2), ptr(self.b2), self.F,
+                                              ptr(self.aff), ptr(self.hid), e.stream), 'lk_exposure_fwd')
+        return self.aff
+
+    def backward(self, g_aff):
+        e = self.eng
+        e.lib.check(e.lib.dll.lk_exposure_bwd(ptr(self.feats), ptr(self.W1), ptr(self.W2), ptr(self.hid), ptr(g_aff), self.F,
+                                              ptr(self.g), e.stream), 'lk_exposure_bwd')
+
+    def adam_segs(self):
+        g, lr = self.g, self.LR
+        return [('xW1', self.W1.view(-1), g[0:1024], lr), ('xb1', self.b1, g[1024:1152], lr), ('xW2', self.W2.view(-1), g[1152:2688], lr),
+                ('xb2', self.b2, g[2688:2700], lr), ('xf', self.feats.view(-1), g[2700:2700 + self.F * 8], lr)]
+
+    def finish(self):
+        if not self.single:
+            with torch.no_grad():
+                for k, t in enumerate(self.orig):
+                    t.copy_(self.feats[k])
+
+
 class MapOptimizer:
     """One optimize_map call: Adam over {decoder params, selected geo rows, selected colour rows}."""
 
@@ -79,8 +127,7 @@ class MapOptimizer:
         self.it = 0
         # exposure = (mlp_exposure torch module, [exposure_feat tensor per frame of the window]) for model.encode_exposure
         # (ScanNet): per-keyframe colour affine applied to the RENDERED colour logits (Mapper.py:697-715)
-        self.exposure = exposure
-        self.exp_opt = None
+        self.exposure = ExposureState(eng, exposure[0], exposure[1]) if exposure is not None else None
 
     def iterate(self, stage, frames, rnd, frame_id, window, intr, H, W, log_row=None):
         """One joint iteration (Mapper.py:576-735).
@@ -94,8 +141,15 @@ class MapOptimizer:
                             self.dec, stage, r2_ray=b.r2_ray, save_act=True, extra_flags=_ffi.FLAG_ZERO_ABSENT,
                             color_logits=self.exposure is not None)
         out4 = log_row if log_row is not None else self._out4()
-        if self.exposure is not None and stage == 'color':
-            self._exposure_loss(st, b, frame_id, out4)
+        xs = self.exposure if stage == 'color' else None
+        if xs is not None:
+            # the renderer returned colour LOGITS; the rays of keyframe f get sigmoid(logits @ rot_f + trans_f)
+            # (Mapper.py:697-715): d depth / d logits for the backward, d loss / d affine for the exposure MLP
+            xs.forward()
+            eng.lib.check(eng.lib.dll.lk_loss_mapper_exposure(self.R, ptr(st.depth), ptr(st.color), ptr(st.valid_ray), ptr(b.gt_depth),
+                                                              ptr(b.gt_color), ptr(frame_id), ptr(xs.aff), xs.F,
+                                                              _ffi.C.c_float(self.w_color), ptr(b.d_depth), ptr(b.d_color), ptr(out4),
+                                                              ptr(xs.g_aff), eng.stream), 'lk_loss_mapper_exposure')
         else:
             optim.loss_mapper(eng, st, b.gt_depth, b.gt_color, self.w_color, stage == 'color', b.d_depth, b.d_color, out4)
         core.render_backward(eng, st, gs, b.d_depth, b.d_color)
@@ -113,6 +167,9 @@ class MapOptimizer:
             segs.append(('geo', self.geo.view(-1), gs.g_geo.view(-1), glr))
             if stage == 'color':
                 segs.append(('col', self.col.view(-1), gs.g_col.view(-1), clr))
+        if xs is not None:
+            xs.backward(xs.g_aff)
+            segs += xs.adam_segs()
         self.adam.step(segs, zero_grad=True)
         if stage == 'color':
             # the geometry stage only moves the embedding matrices (read from the plain blob); the MFMA fragments are
@@ -121,30 +178,10 @@ class MapOptimizer:
         self.it += 1
         return out4
 
-    def _exposure_loss(self, st, b, frame_id, out4):
-        """Colour stage with exposure encoding (Mapper.py:691-720): the renderer returned colour LOGITS; the rays of
-        keyframe f get sigmoid(logits @ rot_f + trans_f), (rot_f | trans_f) = mlp_exposure(exposure_feat_f).  This per-ray
-        epilogue and the tiny exposure MLP run in torch autograd on [R,3] tensors; what leaves it are d depth / d colour
-        logits for lk_render_bwd and an Adam step (lr 1e-3, Mapper.py:600-607) on the exposure features and the MLP."""
-        mlp, feats = self.exposure
-        if self.exp_opt is None:
-            self.exp_opt = torch.optim.Adam([{'params': feats, 'lr': 0.001}, {'params': list(mlp.parameters()), 'lr': 0.001}])
-        depth = st.depth.detach()
-        color = st.color.detach().clone().requires_grad_(True)
-        aff = torch.stack([mlp(f) for f in feats])                               # [F,12]
-        fid = frame_id.long() if frame_id is not None else torch.zeros(color.shape[0], dtype=torch.long, device=color.device)
-        rot, trans = aff[:, :9].reshape(-1, 3, 3)[fid], aff[:, 9:][fid]
-        col = torch.sigmoid(torch.einsum('rc,rcd->rd', color, rot) + trans)
-        m = (b.gt_depth > 0) & st.valid_ray.bool() & (~torch.isnan(depth))
-        geo = torch.abs(b.gt_depth - depth)[m].sum()
-        closs = torch.abs(b.gt_color - col)[m].sum()
-        loss = geo + self.w_color * closs
-        self.exp_opt.zero_grad()
-        (self.w_color * closs).backward()
-        self.exp_opt.step()
-        b.d_color.copy_(color.grad)
-        b.d_depth.copy_(torch.where(m, torch.sign(depth - b.gt_depth), torch.zeros_like(depth)))
-        out4.copy_(torch.stack([loss.detach(), geo.detach(), closs.detach(), m.sum().float()]))
+    def finish(self):
+        """End of the optimize_map call: stacked exposure features go back to the keyframes' tensors."""
+        if self.exposure is not None:
+            self.exposure.finish()
 
     def _out4(self):
         if self.loss_log is None:
@@ -191,9 +228,9 @@ class TrackOptimizer:
         adam = optim.Adam(eng)                  # fresh optimiser per frame (Tracker.py:352)
         # exposure = (mlp_exposure, exposure_feat of this frame): the colour decoder applies sigmoid(rgb @ rot + trans) per
         # sample (decoder.py:534-540); feature and MLP get their own Adam groups at lr 1e-3 (Tracker.py:329-344)
-        exp_opt = None
+        xs = None
         if exposure is not None:
-            exp_opt = torch.optim.Adam([{'params': [exposure[1]], 'lr': 0.001}, {'params': list(exposure[0].parameters()), 'lr': 0.001}])
+            xs = ExposureState(eng, exposure[0], exposure[1])
             if gs.g_affine is None:
                 gs.g_affine = eng.zeros(12)
         log = eng.zeros(iters, 4)
@@ -209,9 +246,8 @@ class TrackOptimizer:
             optim.rays_from_pose(eng, cam, b.pix_i, b.pix_j, intr, b.rays_o, b.rays_d)
             optim.inside_mask(eng, b.gt_depth, None, b.thr, b.scratch_u32, depth_filtered=b.gt_depth)
             aff = None
-            if exposure is not None:
-                aff_t = exposure[0](exposure[1])                                 # [12], torch autograd through the tiny MLP
-                aff = aff_t.detach().float().contiguous()
+            if xs is not None:
+                aff = xs.forward()[0]                                            # [12] = (rot 3x3 | trans 3) of this frame
                 gs.g_affine.zero_()
             core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
                                 self.dec, 'color', tracker=True, r2_ray=b.r2_ray, save_act=True, affine=aff,
@@ -220,16 +256,15 @@ class TrackOptimizer:
                                log[it], b.loss_scratch)
             core.render_backward(eng, st, gs, b.d_depth, b.d_color)
             optim.pose_bwd(eng, cam, b.pix_i, b.pix_j, intr, gs.g_rays_o, gs.g_rays_d, self.g_cam)
-            if exp_opt is not None:
-                exp_opt.zero_grad()
-                aff_t.backward(gs.g_affine.to(aff_t.dtype))
-                exp_opt.step()
             if self.dist is not None:
                 self.dist.all_reduce_vec(self.g_cam)
             if self.separate_lr:                # T: lr, quaternion: 0.2*lr (Tracker.py:317-333)
                 segs = [('T', cam[4:7], self.g_cam[4:7], self.cam_lr), ('q', cam[0:4], self.g_cam[0:4], 0.2 * self.cam_lr)]
             else:
                 segs = [('cam', cam, self.g_cam, self.cam_lr)]
+            if xs is not None:
+                xs.backward(gs.g_affine)
+                segs = segs + xs.adam_segs()
             adam.step(segs)
         best = torch.argmin(log[:, 0])          # Tracker.py:375-377 (first minimum)
         return hist[best].clone(), log

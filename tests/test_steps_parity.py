@@ -282,6 +282,7 @@ def test_exposure_iterations_match_oracle(backend):
     for it in range(iters_m):
         out4 = mo.iterate('color', frames, rnd_m[it].to(eng.device), fid.to(eng.device), (0, HH, 0, WW), INTR, HH, WW)
         km.append(float(out4[0].cpu()))
+    mo.finish()                                     # stacked exposure features -> the keyframes' tensors
     np.testing.assert_allclose(km, om_losses, rtol=5e-4)
     for a, b in zip(fk, fo):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), atol=2e-4)
