@@ -609,7 +609,15 @@ class Tracker:
                 # of them without replacement (common.py:198-234, Tracker.py:126-139) -> flat full-image pixel indices
                 pool = optim.top_grad_pixels(eng, grad, 15 * n_px, win, gt_depth.float().contiguous(), self.depth_limit)
                 n_px = min(n_px, int(pool.numel()))
-                order = torch.rand(self.num_cam_iters, pool.numel(), generator=self.gen).argsort(dim=1)[:, :n_px].to(eng.device)
+                # n distinct positions per iteration = the n largest of a row of uniform draws, generated and selected on the
+                # device that holds the pool (200 x 75 000 draws per frame for the TUM budget: ~100 ms on host threads)
+                if eng.device.type == 'cuda':
+                    if getattr(self, 'gen_dev', None) is None:
+                        self.gen_dev = torch.Generator(device=eng.device).manual_seed(self.cfg.get('setup_seed', 1219) + 5)
+                    u = torch.rand(self.num_cam_iters, pool.numel(), generator=self.gen_dev, device=eng.device)
+                else:
+                    u = torch.rand(self.num_cam_iters, pool.numel(), generator=self.gen)
+                order = u.topk(n_px, dim=1).indices.to(eng.device)
                 rnd = pool[order].contiguous()
                 win_it = (0, self.H, 0, self.W)
             else:
