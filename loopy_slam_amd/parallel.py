@@ -37,7 +37,10 @@ class DistContext:
         gs, eng = mo.gs, mo.eng
         ranges = _merge(list(mo.geo_dec_ranges) + (list(mo.col_dec_ranges) if stage == 'color' else []))
         tables = [gs.g_geo] + ([gs.g_col] if stage == 'color' else [])
-        segs = (_ffi.CopySeg * (len(ranges) + len(tables)))()
+        # exposure encoding: d loss / d affine [F,12] is a sum over rays too and rides in the same bucket (the exposure MLP's
+        # backward and Adam step run after the exchange, on identical inputs on every rank)
+        xs = mo.exposure if stage == 'color' else None
+        segs = (_ffi.CopySeg * (len(ranges) + len(tables) + (1 if xs is not None else 0)))()
         n = 0
         for k, (o, cnt) in enumerate(ranges):
             segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(gs.g_weights[o:o + cnt]), cnt, None, 1
@@ -48,6 +51,10 @@ class DistContext:
                 segs[k].row_index, segs[k].row_len = ptr(mo.rows), t.shape[1]
             else:
                 segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(t), t.numel(), None, 1
+            n += segs[k].n
+        if xs is not None:
+            k = len(ranges) + len(tables)
+            segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(xs.g_aff), xs.g_aff.numel(), None, 1
             n += segs[k].n
         if self._bucket is None or self._bucket.numel() != n:
             self._bucket = torch.empty(n, dtype=torch.float32, device=gs.g_weights.device)

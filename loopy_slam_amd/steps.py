@@ -258,6 +258,8 @@ class TrackOptimizer:
             optim.pose_bwd(eng, cam, b.pix_i, b.pix_j, intr, gs.g_rays_o, gs.g_rays_d, self.g_cam)
             if self.dist is not None:
                 self.dist.all_reduce_vec(self.g_cam)
+                if xs is not None:
+                    self.dist.all_reduce_vec(gs.g_affine)
             if self.separate_lr:                # T: lr, quaternion: 0.2*lr (Tracker.py:317-333)
                 segs = [('T', cam[4:7], self.g_cam[4:7], self.cam_lr), ('q', cam[0:4], self.g_cam[0:4], 0.2 * self.cam_lr)]
             else:
