@@ -48,7 +48,6 @@ struct LkDecodeArgs {
 struct LkRelposArgs {
     int R, S, P, min_nn;
     const float* rays_o; const float* rays_d; const float* z;
-    const float4* sorted_unused;
     const float* pos;                             // [N,3] cloud positions (original order)
     const float* col_feats;                       // [N,32]
     const int32_t* nbr_idx; const float* nbr_w; const int32_t* nbr_count;
