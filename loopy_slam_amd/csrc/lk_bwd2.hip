@@ -179,12 +179,11 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
     f32x16 hid[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_zero16();
+    for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_rowvec_tile(W + R_B1, nb * 32, lane);      // accumulators start from the bias
     lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 0, 0, x0, 0, lane);
     lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 2, 0, x1, 0, lane);       // units 32..55; registers 12..15 of x1 are zero
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-        lk_add_rowvec(hid[nb], W + R_B1, nb * 32, lane);
 #pragma unroll
         for (int q = 0; q < 16; ++q) hid[nb][q] = lk_softplus100(hid[nb][q]);
     }
@@ -198,10 +197,9 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
     if (want_p) {
         f32x16 out[1];
-        out[0] = lk_zero16();
+        out[0] = lk_rowvec_tile(W + R_B2, 0, lane);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) lk_gemm_b6<1, 2>(out, FB + FM21_FWDB, 1, 2 * kb, 0, hid[kb], 0, lane);
-        lk_add_rowvec(out[0], W + R_B2, 0, lane);
         float part = 0.0f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) part = fmaf(dout[0][q], out[0][q], part);

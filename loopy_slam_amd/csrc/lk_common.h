@@ -263,6 +263,18 @@ __device__ __forceinline__ uint64_t lk_dpp_u64(uint64_t v) {
     return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
+// CT tile whose 16 registers are a per-row vector (bias): the start value of an accumulator - the bias add then costs no
+// VALU instruction at all (four 16-byte loads land in the accumulator registers)
+__device__ __forceinline__ f32x16 lk_rowvec_tile(const float* __restrict__ v, int unit0, int lane) {
+    const int h = lane >> 5;
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(v + unit0 + 8 * g + 4 * h);
+        t[4 * g + 0] = b.x; t[4 * g + 1] = b.y; t[4 * g + 2] = b.z; t[4 * g + 3] = b.w;
+    }
+    return t;
+}
 // per-row vector (bias) of a CT tile: v[unit(r,h)] for r = 0..15, unit0 = first unit of the tile
 __device__ __forceinline__ void lk_add_rowvec(f32x16& acc, const float* __restrict__ v, int unit0, int lane) {
     const int h = lane >> 5;

@@ -78,12 +78,11 @@ __device__ __forceinline__ f32x16 sincos_embed_tile(const float* __restrict__ B,
 
 // bias + activation (+ optional save) + fc_c(c): h = act(acc + b) + (U c + u); c arrives as its two split blocks
 template <int NB, bool SOFTPLUS>
-__device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB], const float* __restrict__ bias,
+__device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB],
                                              const u32x4* __restrict__ UfragB, const float* __restrict__ ubias,
                                              const LkB8 (&cb)[2], float* __restrict__ save_a, bool live, int lane) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        lk_add_rowvec(acc[nb], bias, nb * 32, lane);
+    for (int nb = 0; nb < NB; ++nb) {          // acc started from the layer's bias (lk_rowvec_tile)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = SOFTPLUS ? lk_softplus100(acc[nb][r]) : fmaxf(acc[nb][r], 0.0f);
         if (save_a) ct_store_rows32(save_a + nb * 32, acc[nb], live, lane);
@@ -139,34 +138,34 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
     }
     f32x16 acc[1], hh;
     // layer 0: 93 -> 32
-    acc[0] = lk_zero16();
+    acc[0] = lk_rowvec_tile(W + G_B0, 0, lane);
 #pragma unroll
     for (int G = 0; G < 6; ++G) acc[0] = lk_mma6(lk_fragb_load(FB + FM0_FWDB, 1, G, 0, lane), eb[G], acc[0]);
-    layer_finish<1, false>(acc, W + G_B0, FB + FM5_FWDB, W + G_U0 + a64(HG * CF), cb, act_geo, live, lane);
+    layer_finish<1, false>(acc, FB + FM5_FWDB, W + G_U0 + a64(HG * CF), cb, act_geo, live, lane);
     hh = acc[0];
     // layers 1, 2: 32 -> 32
-    acc[0] = lk_zero16();
+    acc[0] = lk_rowvec_tile(W + G_B1, 0, lane);
     lk_gemm_b6<1, 2>(acc, FB + FM1_FWDB, 1, 0, 0, hh, 0, lane);
-    layer_finish<1, false>(acc, W + G_B1, FB + FM6_FWDB, W + G_U0 + G_USTRIDE + a64(HG * CF), cb,
+    layer_finish<1, false>(acc, FB + FM6_FWDB, W + G_U0 + G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 32 : nullptr, live, lane);
     hh = acc[0];
-    acc[0] = lk_zero16();
+    acc[0] = lk_rowvec_tile(W + G_B2, 0, lane);
     lk_gemm_b6<1, 2>(acc, FB + FM2_FWDB, 1, 0, 0, hh, 0, lane);
-    layer_finish<1, false>(acc, W + G_B2, FB + FM7_FWDB, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cb,
+    layer_finish<1, false>(acc, FB + FM7_FWDB, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 64 : nullptr, live, lane);
     hh = acc[0];
     // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
-    acc[0] = lk_zero16();
+    acc[0] = lk_rowvec_tile(W + G_B3, 0, lane);
 #pragma unroll
     for (int G = 0; G < 6; ++G) acc[0] = lk_mma6(lk_fragb_load(FB + FM3_FWDB, 1, G, 0, lane), eb[G], acc[0]);
     lk_gemm_b6<1, 2>(acc, FB + FM3_FWDB, 1, 6, 0, hh, 0, lane);
-    layer_finish<1, false>(acc, W + G_B3, FB + FM8_FWDB, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cb,
+    layer_finish<1, false>(acc, FB + FM8_FWDB, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 96 : nullptr, live, lane);
     hh = acc[0];
     // layer 4
-    acc[0] = lk_zero16();
+    acc[0] = lk_rowvec_tile(W + G_B4, 0, lane);
     lk_gemm_b6<1, 2>(acc, FB + FM4_FWDB, 1, 0, 0, hh, 0, lane);
-    layer_finish<1, false>(acc, W + G_B4, FB + FM9_FWDB, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cb,
+    layer_finish<1, false>(acc, FB + FM9_FWDB, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 128 : nullptr, live, lane);
     // output 32 -> 1 on the VALU: each half-wave holds 16 of the 32 units of its sample
     float part = 0.0f;
@@ -242,10 +241,9 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         for (int G = 0; G < 3; ++G) acc = lk_mma6(lk_fragb_load(fragb, 4, G, w, lane), eb[G], acc);
     };
     // bias + softplus + fc_c(c) for the wave's own 32-unit block, then ALL stores of the layer: saved a / h rows, LDS park
-    auto finish = [&](f32x16& acc, const float* bias, const float* ubias, float* save_a, int L, int buf) {
-        lk_add_rowvec(acc, bias, w * 32, lane);
+    auto finish = [&](f32x16& acc, const float* ubias, float* save_a, int L, int buf) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);
+        for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);          // acc started from the layer's bias
         const f32x16 act = acc;
         lk_add_rowvec(acc, ubias, w * 32, lane);
 #pragma unroll
@@ -265,38 +263,38 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     f32x16 acc;
     // layer 0: 40 -> 128
     prefetch_u(FB + FM15_FWDB);
-    acc = lk_zero16();
+    acc = lk_rowvec_tile(W + C_B0, w * 32, lane);
     embed(acc, FB + FM10_FWDB);
     prefetch_hidden(FB + FM11_FWDB, 0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(acc, W + C_B0, W + C_U0 + a64(HC * CF), act_col_a, 0, 0);
+    finish(acc, W + C_U0 + a64(HC * CF), act_col_a, 0, 0);
     __syncthreads();
     // layers 1, 2: 128 -> 128
 #pragma unroll
     for (int L = 1; L <= 2; ++L) {
         prefetch_u(FB + (L == 1 ? FM16_FWDB : FM17_FWDB));
-        acc = lk_zero16();
+        acc = lk_rowvec_tile(W + (L == 1 ? C_B1 : C_B2), w * 32, lane);
         hidden(acc, FB + (L == 1 ? FM11_FWDB : FM12_FWDB), 0, (L - 1) & 1);
         if (L == 1) prefetch_hidden(FB + FM12_FWDB, 0);
         else prefetch_hidden(FB + FM13_FWDB, 3);
         __builtin_amdgcn_sched_barrier(0);
-        finish(acc, W + (L == 1 ? C_B1 : C_B2), W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + L * 128 : nullptr, L, L & 1);
+        finish(acc, W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + L * 128 : nullptr, L, L & 1);
         __syncthreads();
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
     prefetch_u(FB + FM18_FWDB);
-    acc = lk_zero16();
+    acc = lk_rowvec_tile(W + C_B3, w * 32, lane);
     embed(acc, FB + FM13_FWDB);
     hidden(acc, FB + FM13_FWDB, 3, 0);
     prefetch_hidden(FB + FM14_FWDB, 0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(acc, W + C_B3, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 3 * 128 : nullptr, 3, 1);
+    finish(acc, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 3 * 128 : nullptr, 3, 1);
     __syncthreads();
     // layer 4
     prefetch_u(FB + FM19_FWDB);
-    acc = lk_zero16();
+    acc = lk_rowvec_tile(W + C_B4, w * 32, lane);
     hidden(acc, FB + FM14_FWDB, 0, 1);
-    finish(acc, W + C_B4, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 4 * 128 : nullptr, 4, -1);
+    finish(acc, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 4 * 128 : nullptr, 4, -1);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
@@ -407,20 +405,18 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     }
     f32x16 hid[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_zero16();
+    for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_rowvec_tile(W + R_B1, nb * 32, lane);      // accumulators start from the bias
     lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 0, 0, x0, 0, lane);
     lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 2, 0, x1, 0, lane);       // units 32..55; registers 12..15 of x1 are zero
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-        lk_add_rowvec(hid[nb], W + R_B1, nb * 32, lane);
 #pragma unroll
         for (int q = 0; q < 16; ++q) hid[nb][q] = lk_softplus100(hid[nb][q]);
     }
     f32x16 out[1];
-    out[0] = lk_zero16();
+    out[0] = lk_rowvec_tile(W + R_B2, 0, lane);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) lk_gemm_b6<1, 2>(out, FB + FM21_FWDB, 1, 2 * kb, 0, hid[kb], 0, lane);
-    lk_add_rowvec(out[0], W + R_B2, 0, lane);
     // c[ch] = sum over the 8 neighbour rows of a sample (8 consecutive lanes) of w * f[ch]
     const bool has = a.nbr_count[sp] >= a.min_nn;
     float* __restrict__ crow = a.c_col + (size_t)sp * LK_C;
