@@ -87,6 +87,22 @@ def work_per_step(b):
     return w
 
 
+def pmc_traffic(kernel, path=None):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_rocprof_summary.md, written by
+    tools/summarize_prof.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench; FETCH_SIZE doubled per
+    the gfx950 note of MI355X_MICROARCH.md): (bytes, source) or (None, None).  bench.py cannot collect PMC counters live."""
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r1_rocprof_summary.md')
+    try:
+        for line in open(path):
+            c = [x.strip() for x in line.strip().strip('|').split('|')]
+            if len(c) == 5 and c[0] == kernel:
+                return float(c[3]) * 1e6 + float(c[4]) * 1024.0, 'profiles/r1_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
 def dominant_kernel(kstat):
     return max(kstat.items(), key=lambda kv: kv[1]['total_ms'])[0] if kstat else None
 
@@ -114,6 +130,9 @@ def roofline(kstat, budget, kernel):
     if kernel in ('k_wgrad', 'k_relpos_bwd', 'k_feat_scatter'):
         out['overlap'] = ('k_wgrad runs on a second stream beside k_relpos_bwd / k_feat_scatter: durations are measured while '
                           'they share the chip (LK_SERIAL=1 times every kernel alone)')
+    out['traffic'], src = pmc_traffic(kernel)
+    if src:
+        out['traffic_unit'], out['traffic_source'] = 'bytes per launch (HBM read + write)', src
     out['algorithmic_flops_per_launch_avg'] = flops / k['calls']
     out['algorithmic_bytes_per_launch_avg'] = nbytes / k['calls']
     return out
