@@ -171,3 +171,32 @@ def test_render_is_deterministic_at_scale(R):
             ok = torch.isfinite(a) & torch.isfinite(b)      # unused tail of the scratch is uninitialised
             scale = float(b[ok].abs().max()) + 1e-12
             assert float((a[ok] - b[ok]).abs().max()) <= 1e-5 * scale, (k, float((a[ok] - b[ok]).abs().max()), scale)
+
+
+@pytest.mark.parametrize('R', (1500, 5000, 20000))
+def test_tracker_backward_is_deterministic_at_scale(R):
+    """Tracker mode (gradients w.r.t. the rays: embedding-gradient products, rel-pos output product, interpolation
+    backward): the same forward + backward three times gives the same bits (no float atomics on this path)."""
+    eng = make_engine('hip')
+    pos, geo, col, knn = _scene(eng, 100_000)
+    blob = core.DecoderBlob(eng).pack(syn.default_weights())
+    cfg = core.RenderCfg()
+    depth, _, c2w = syn.render_frame(5, device='cuda', holes=0.02)
+    g = torch.Generator().manual_seed(R + 1)
+    i = torch.randint(0, I['W'], (R,), generator=g).float().cuda()
+    j = torch.randint(0, I['H'], (R,), generator=g).float().cuda()
+    ro, rd = syn.pixel_rays(c2w, i, j)
+    gd = depth[j.long(), i.long()].contiguous()
+    st = core.RenderState(eng, R, cfg.S, need_act=True)
+    d1, c1 = torch.randn(R, generator=g).cuda(), torch.randn(R, 3, generator=g).cuda()
+    runs = []
+    for rep in range(3):
+        core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, 'color', tracker=True, save_act=True)
+        gs = core.GradState(eng, pos.shape[0], R, blob.n, feats=False, weights=False, rays=True)
+        core.render_backward(eng, st, gs, d1, c1)
+        torch.cuda.synchronize()
+        runs.append((st.depth.clone(), st.color.clone(), st.var.clone(), gs.g_rays_o.clone(), gs.g_rays_d.clone()))
+    for r in runs[1:]:
+        for a, b in zip(r, runs[0]):
+            assert torch.equal(a, b)
+    assert float(runs[0][3].abs().max()) > 0 and bool(torch.isfinite(runs[0][4]).all())
