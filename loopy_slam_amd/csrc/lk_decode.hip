@@ -5,12 +5,12 @@
 //              NICER.forward stage dispatch (decoder.py:573-610).
 //
 // Design (CDNA4): a tile is 32 sample points.  Activations are kept TRANSPOSED in the MFMA C/D layout ("CT tile":
-// 32 units x 32 samples, lane = sample column) so that each layer Y^T = W X^T uses v_mfma_f32_32x32x2_f32 with
-// A = weights (16-byte loads of the fragment blob) and B = the previous layer's accumulator registers (see
-// lk_common.h::lk_gemm_frag).  Geometry decoder and rel-pos MLP: one wave per tile, whole network through registers,
-// no LDS, no barrier.  Colour trunk (128 wide): the four waves of a workgroup own 32 output units each and exchange
-// their tiles through LDS as lane-contiguous register chunks (decode_col_wg).  Exact fp32 (fma-chain) arithmetic at
-// the fp32 matrix rate.
+// 32 units x 32 samples, lane = sample column) so that each layer Y^T = W X^T takes A = weights (16-byte loads of the
+// split-bf16 fragment blob) and B = the previous layer's accumulator registers, eight registers per 16-k matrix
+// instruction; every fp32 product is six bf16 piece products on the bf16 pipe (lk_common.h: lk_mma6, fp32-class accuracy).
+// Geometry decoder and rel-pos MLP: one wave per tile, whole network through registers, no LDS, no barrier.  Colour
+// trunk (128 wide): the four waves of a workgroup own 32 output units each and exchange their tiles through LDS as
+// lane-contiguous split pieces (decode_col_wg).
 #include "lk_common.h"
 #include "lk_kernels.h"
 
@@ -180,12 +180,12 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
 }
 
 // ================= colour decoder (hidden 128, softplus beta=100): FOUR waves = one 32-sample tile =================
-// Wave w owns output units [32w, 32w+32) of every layer (one accumulator, 64 MFMAs per 128-wide layer), so a tile's
-// serial MFMA chain is a quarter of the one-wave form and a training batch (a few hundred tiles) spreads over four
-// times as many SIMDs.  The next layer needs all 128 units as its B operand: each wave parks its activated CT tile in
-// LDS as the four float4 register chunks of every lane, [wave][chunk][lane] — the reader of chunk (w', j) is the
-// SAME lane id in every wave (the C/D-row walk of lk_gemm_frag), so writes and reads are both lane-contiguous
-// (conflict-free ds_write/read_b128).  Double-buffered: one barrier per layer.
+// Wave w owns output units [32w, 32w+32) of every layer (one accumulator, 48 matrix instructions per 128-wide layer), so
+// a tile's serial chain is a quarter of the one-wave form and a training batch (a few hundred tiles) spreads over four
+// times as many SIMDs.  The next layer needs all 128 units as its B operand: each wave SPLITS its activated CT tile and
+// parks the bf16 pieces in LDS, [wave][16-k block][piece][lane] — the reader of block (w', G) is the SAME lane id in every
+// wave (the C/D-row walk), so writes and reads are both lane-contiguous (conflict-free ds_write/read_b128).
+// Double-buffered: one barrier per layer.
 __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
                                               u32x4 (*s_x)[24 * 64] /* [2][24*64] */, float (*s_o)[3 * 32] /* [4][96] */) {
     const DecSample d = dec_sample(a, tile, lane);
