@@ -12,6 +12,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -44,6 +46,27 @@ __device__ __forceinline__ Split8 split8(const float (&v)[8]) {
     return s;
 }
 
+struct SplitH { u32x4 p[2]; };
+// fp16 pieces: hi = rtz_f16(x) (pack-convert, 2 values per instruction), lo = rtz_f16(x - hi): 22 significand bits
+__device__ __forceinline__ SplitH split8h(const float (&v)[8]) {
+    SplitH s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * i], v[2 * i + 1]);
+        const float r0 = v[2 * i] - (float)h[0], r1 = v[2 * i + 1] - (float)h[1];
+        const f16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        s.p[0][i] = __builtin_bit_cast(unsigned, h);
+        s.p[1][i] = __builtin_bit_cast(unsigned, l);
+    }
+    return s;
+}
+__device__ __forceinline__ f32x16 mma_h3(const SplitH& a, const SplitH& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.p[1]), __builtin_bit_cast(f16x8, b.p[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.p[0]), __builtin_bit_cast(f16x8, b.p[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.p[0]), __builtin_bit_cast(f16x8, b.p[0]), acc, 0, 0, 0);
+    return acc;
+}
+
 template <int TERMS>
 __device__ __forceinline__ f32x16 mma_split(const Split8& a, const Split8& b, f32x16 acc) {
     // smallest terms first
@@ -71,6 +94,7 @@ __global__ void k_acc(const float* A, const float* B, float* C, int K, int mode)
         for (int k0 = 0; k0 < K; k0 += 16) {
             float av[8], bv[8];
             for (int i = 0; i < 8; ++i) { av[i] = A[n * K + k0 + 8 * h + i]; bv[i] = B[(k0 + 8 * h + i) * 32 + n]; }
+            if (mode == 2) { acc = mma_h3(split8h(av), split8h(bv), acc); continue; }
             const Split8 a = split8(av), b = split8(bv);
             acc = (mode == 6) ? mma_split<6>(a, b, acc) : (mode == 3) ? mma_split<3>(a, b, acc) : mma_split<1>(a, b, acc);
         }
@@ -103,6 +127,24 @@ __global__ __launch_bounds__(256) void k_chain(const float* __restrict__ Wf, con
                         y[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x[kt][4 * g + 2], y[nb], 0, 0, 0);
                         y[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x[kt][4 * g + 3], y[nb], 0, 0, 0);
                     }
+        } else if (MODE == 2) {
+            const u32x4* __restrict__ F = reinterpret_cast<const u32x4*>(Wb) + lane;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int G = 0; G < 2; ++G) {
+                    float bv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bv[i] = x[kt][8 * G + i];
+                    const SplitH b = split8h(bv);
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        SplitH a;
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) a.p[p] = F[(((kt * 2 + G) * NT + nb) * 3 + p) * 64];
+                        y[nb] = mma_h3(a, b, y[nb]);
+                    }
+                }
         } else {
             // split: blob [kt][G][nb][piece][lane] uint4 (8 bf16), pieces pre-split on the host side of the product
             const u32x4* __restrict__ F = reinterpret_cast<const u32x4*>(Wb) + lane;
@@ -156,8 +198,8 @@ int main() {
     CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dB, B.size() * 4)); CK(hipMalloc(&dC, C.size() * 4));
     CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
-    const int modes[4] = {0, 1, 3, 6};
-    for (int mi = 0; mi < 4; ++mi) {
+    const int modes[5] = {0, 1, 3, 6, 2};
+    for (int mi = 0; mi < 5; ++mi) {
         hipLaunchKernelGGL(k_acc, dim3(1), dim3(64), 0, 0, dA, dB, dC, K, modes[mi]);
         CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
         double worst = 0.0, worst_f = 0.0;
@@ -185,6 +227,8 @@ int main() {
         const int blocks = 256 * wps;                   // 4 waves per block -> wps waves per SIMD
         const float a1 = time_chain<1, 0>(Wf, Wb, out, blocks, layers), b1 = time_chain<1, 6>(Wf, Wb, out, blocks, layers), c1 = time_chain<1, 3>(Wf, Wb, out, blocks, layers);
         const float a4 = time_chain<4, 0>(Wf, Wb, out, blocks, layers), b4 = time_chain<4, 6>(Wf, Wb, out, blocks, layers), c4 = time_chain<4, 3>(Wf, Wb, out, blocks, layers);
+        const float h1 = time_chain<1, 2>(Wf, Wb, out, blocks, layers), h4 = time_chain<4, 2>(Wf, Wb, out, blocks, layers);
+        printf("   f16x3: 32-wide %.1f us   128-wide %.1f us\n", h1 * 1e3, h4 * 1e3);
         // cycles per layer per SIMD at 2.4 GHz nominal
         printf("waves/SIMD %d  32-wide layer: fp32 %.1f us  x6 %.1f us  x3 %.1f us   128-wide layer: fp32 %.1f us  x6 %.1f us  x3 %.1f us  (%d layers)\n",
                wps, a1 * 1e3, b1 * 1e3, c1 * 1e3, a4 * 1e3, b4 * 1e3, c4 * 1e3, layers);
