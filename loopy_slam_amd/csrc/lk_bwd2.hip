@@ -180,8 +180,10 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     f32x16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_rowvec_tile(W + R_B1, nb * 32, lane);      // accumulators start from the bias
-    lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 0, 0, x0, 0, lane);
-    lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 2, 0, x1, 0, lane);       // units 32..55; registers 12..15 of x1 are zero
+    // the recomputed forward uses the forward kernels' fp16x3 products (operands of O(1): embedding, features, activations)
+    const u32x4* __restrict__ FH = FB + FRAGB_U4;
+    lk_gemm_h3<4, 2>(hid, FH + FM20_FWDH, 4, 0, 0, x0, 0, lane);
+    lk_gemm_h3<4, 2>(hid, FH + FM20_FWDH, 4, 2, 0, x1, 0, lane);       // units 32..55; registers 12..15 of x1 are zero
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
@@ -199,7 +201,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
         f32x16 out[1];
         out[0] = lk_rowvec_tile(W + R_B2, 0, lane);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) lk_gemm_b6<1, 2>(out, FB + FM21_FWDB, 1, 2 * kb, 0, hid[kb], 0, lane);
+        for (int kb = 0; kb < 4; ++kb) lk_gemm_h3<1, 2>(out, FH + FM21_FWDH, 1, 2 * kb, 0, hid[kb], 0, lane);
         float part = 0.0f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) part = fmaf(dout[0][q], out[0][q], part);

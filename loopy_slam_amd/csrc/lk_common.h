@@ -10,6 +10,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 lk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lk_f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 lk_f16x2 __attribute__((ext_vector_type(2)));
 
 #define LK_TWO_PI 6.283185307179586f
 #define LK_FLT_MAX 3.402823466e+38f
@@ -226,6 +228,59 @@ __device__ __forceinline__ void lk_gemm_b6(f32x16 (&acc)[NB], const u32x4* __res
         const LkB8 b = lk_split_ct(x, XG0 + G);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = lk_mma6(lk_fragb_load(fragb, NBT, G0 + G, nb0 + nb, lane), b, acc[nb]);
+    }
+}
+
+// ------------------------------------------------------------------ forward products as fp16x3
+// Two fp16 pieces per value (hi = rtz_f16(x) by pack-convert, lo = rtz_f16(x - hi): 22 significand bits, 3 VALU
+// instructions per value instead of 5.5) and three products hi.hi + hi.lo + lo.hi: measured 1.7e-7 sum|ab| against fp64 on
+// O(1) data - the same as bf16x6 - at half the matrix instructions.  fp16 has a narrow exponent: the low piece of
+// |x| < 0.1 is a subnormal (absolute error <= 3e-8 per element instead of relative 2^-22) and |x| > 65 504 saturates, which
+// is harmless for the forward operands (Fourier features, interpolated point features, activations, weights: O(1e-3 .. 10))
+// and is why the BACKWARD kernels, whose operands are gradients of arbitrary scale, stay on the bf16 pieces.
+struct LkH8 { u32x4 p[2]; };
+__device__ __forceinline__ LkH8 lk_split8h(const float (&v)[8]) {
+    LkH8 s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const lk_f16x2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * i], v[2 * i + 1]);
+        const float r0 = v[2 * i] - (float)h[0], r1 = v[2 * i + 1] - (float)h[1];
+        const lk_f16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        s.p[0][i] = __builtin_bit_cast(unsigned, h);
+        s.p[1][i] = __builtin_bit_cast(unsigned, l);
+    }
+    return s;
+}
+__device__ __forceinline__ LkH8 lk_split_cth(const f32x16& x, int G) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = x[8 * G + i];
+    return lk_split8h(v);
+}
+__device__ __forceinline__ f32x16 lk_mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lk_f16x8, a), __builtin_bit_cast(lk_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 lk_mma3h(const LkH8& a, const LkH8& b, f32x16 acc) {
+    acc = lk_mfma_f16(a.p[1], b.p[0], acc);
+    acc = lk_mfma_f16(a.p[0], b.p[1], acc);
+    acc = lk_mfma_f16(a.p[0], b.p[0], acc);
+    return acc;
+}
+// fp16 forward-fragment block (G, nb): fragh = first block of the matrix (lkw::FMxx_FWDH, uint4 units behind the bf16 blob)
+__device__ __forceinline__ LkH8 lk_fragh_load(const u32x4* __restrict__ fragh, int NBT, int G, int nb, int lane) {
+    const u32x4* __restrict__ q = fragh + ((size_t)G * NBT + nb) * 128 + lane;
+    LkH8 a;
+    a.p[0] = q[0]; a.p[1] = q[64];
+    return a;
+}
+template <int NB, int NGG>
+__device__ __forceinline__ void lk_gemm_h3(f32x16 (&acc)[NB], const u32x4* __restrict__ fragh, int NBT, int G0, int nb0,
+                                           const f32x16& x, int XG0, int lane) {
+#pragma unroll
+    for (int G = 0; G < NGG; ++G) {
+        const LkH8 b = lk_split_cth(x, XG0 + G);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = lk_mma3h(lk_fragh_load(fragh, NBT, G0 + G, nb0 + nb, lane), b, acc[nb]);
     }
 }
 

@@ -80,7 +80,7 @@ __device__ __forceinline__ f32x16 sincos_embed_tile(const float* __restrict__ B,
 template <int NB, bool SOFTPLUS>
 __device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB],
                                              const u32x4* __restrict__ UfragB, const float* __restrict__ ubias,
-                                             const LkB8 (&cb)[2], float* __restrict__ save_a, bool live, int lane) {
+                                             const LkH8 (&cb)[2], float* __restrict__ save_a, bool live, int lane) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {          // acc started from the layer's bias (lk_rowvec_tile)
 #pragma unroll
@@ -88,7 +88,7 @@ __device__ __forceinline__ void layer_finish(f32x16 (&acc)[NB],
         if (save_a) ct_store_rows32(save_a + nb * 32, acc[nb], live, lane);
         lk_add_rowvec(acc[nb], ubias, nb * 32, lane);
 #pragma unroll
-        for (int G = 0; G < 2; ++G) acc[nb] = lk_mma6(lk_fragb_load(UfragB, NB, G, nb, lane), cb[G], acc[nb]);
+        for (int G = 0; G < 2; ++G) acc[nb] = lk_mma3h(lk_fragh_load(UfragB, NB, G, nb, lane), cb[G], acc[nb]);
     }
 }
 
@@ -121,51 +121,51 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;      // fp16 forward fragments
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_geo = save ? a.act + (size_t)sp * LK_ACT_GEO_A : nullptr;
     // the 96 embedding units and the interpolated feature are B operands twice / five times: split once
-    LkB8 eb[6], cb[2];
+    LkH8 eb[6], cb[2];
     {
         const f32x16 e0 = geo_embed_tile(W + G_EB, 0, a0, a1, a2, lane);
-        eb[0] = lk_split_ct(e0, 0); eb[1] = lk_split_ct(e0, 1);
+        eb[0] = lk_split_cth(e0, 0); eb[1] = lk_split_cth(e0, 1);
         const f32x16 e1 = geo_embed_tile(W + G_EB, 1, a0, a1, a2, lane);
-        eb[2] = lk_split_ct(e1, 0); eb[3] = lk_split_ct(e1, 1);
+        eb[2] = lk_split_cth(e1, 0); eb[3] = lk_split_cth(e1, 1);
         const f32x16 e2 = geo_embed_tile(W + G_EB, 2, a0, a1, a2, lane);
-        eb[4] = lk_split_ct(e2, 0); eb[5] = lk_split_ct(e2, 1);
+        eb[4] = lk_split_cth(e2, 0); eb[5] = lk_split_cth(e2, 1);
         const f32x16 cg = ct_load_rows32(a.c_geo + (size_t)sp * LK_C, true, lane);
-        cb[0] = lk_split_ct(cg, 0); cb[1] = lk_split_ct(cg, 1);
+        cb[0] = lk_split_cth(cg, 0); cb[1] = lk_split_cth(cg, 1);
     }
     f32x16 acc[1], hh;
     // layer 0: 93 -> 32
     acc[0] = lk_rowvec_tile(W + G_B0, 0, lane);
 #pragma unroll
-    for (int G = 0; G < 6; ++G) acc[0] = lk_mma6(lk_fragb_load(FB + FM0_FWDB, 1, G, 0, lane), eb[G], acc[0]);
-    layer_finish<1, false>(acc, FB + FM5_FWDB, W + G_U0 + a64(HG * CF), cb, act_geo, live, lane);
+    for (int G = 0; G < 6; ++G) acc[0] = lk_mma3h(lk_fragh_load(FB + FM0_FWDH, 1, G, 0, lane), eb[G], acc[0]);
+    layer_finish<1, false>(acc, FB + FM5_FWDH, W + G_U0 + a64(HG * CF), cb, act_geo, live, lane);
     hh = acc[0];
     // layers 1, 2: 32 -> 32
     acc[0] = lk_rowvec_tile(W + G_B1, 0, lane);
-    lk_gemm_b6<1, 2>(acc, FB + FM1_FWDB, 1, 0, 0, hh, 0, lane);
-    layer_finish<1, false>(acc, FB + FM6_FWDB, W + G_U0 + G_USTRIDE + a64(HG * CF), cb,
+    lk_gemm_h3<1, 2>(acc, FB + FM1_FWDH, 1, 0, 0, hh, 0, lane);
+    layer_finish<1, false>(acc, FB + FM6_FWDH, W + G_U0 + G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 32 : nullptr, live, lane);
     hh = acc[0];
     acc[0] = lk_rowvec_tile(W + G_B2, 0, lane);
-    lk_gemm_b6<1, 2>(acc, FB + FM2_FWDB, 1, 0, 0, hh, 0, lane);
-    layer_finish<1, false>(acc, FB + FM7_FWDB, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cb,
+    lk_gemm_h3<1, 2>(acc, FB + FM2_FWDH, 1, 0, 0, hh, 0, lane);
+    layer_finish<1, false>(acc, FB + FM7_FWDH, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 64 : nullptr, live, lane);
     hh = acc[0];
     // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
     acc[0] = lk_rowvec_tile(W + G_B3, 0, lane);
 #pragma unroll
-    for (int G = 0; G < 6; ++G) acc[0] = lk_mma6(lk_fragb_load(FB + FM3_FWDB, 1, G, 0, lane), eb[G], acc[0]);
-    lk_gemm_b6<1, 2>(acc, FB + FM3_FWDB, 1, 6, 0, hh, 0, lane);
-    layer_finish<1, false>(acc, FB + FM8_FWDB, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cb,
+    for (int G = 0; G < 6; ++G) acc[0] = lk_mma3h(lk_fragh_load(FB + FM3_FWDH, 1, G, 0, lane), eb[G], acc[0]);
+    lk_gemm_h3<1, 2>(acc, FB + FM3_FWDH, 1, 6, 0, hh, 0, lane);
+    layer_finish<1, false>(acc, FB + FM8_FWDH, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 96 : nullptr, live, lane);
     hh = acc[0];
     // layer 4
     acc[0] = lk_rowvec_tile(W + G_B4, 0, lane);
-    lk_gemm_b6<1, 2>(acc, FB + FM4_FWDB, 1, 0, 0, hh, 0, lane);
-    layer_finish<1, false>(acc, FB + FM9_FWDB, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cb,
+    lk_gemm_h3<1, 2>(acc, FB + FM4_FWDH, 1, 0, 0, hh, 0, lane);
+    layer_finish<1, false>(acc, FB + FM9_FWDH, W + G_U0 + 4 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 128 : nullptr, live, lane);
     // output 32 -> 1 on the VALU: each half-wave holds 16 of the 32 units of its sample
     float part = 0.0f;
@@ -187,18 +187,18 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
 // wave (the C/D-row walk), so writes and reads are both lane-contiguous (conflict-free ds_write/read_b128).
 // Double-buffered: one barrier per layer.
 __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
-                                              u32x4 (*s_x)[24 * 64] /* [2][24*64] */, float (*s_o)[3 * 32] /* [4][96] */) {
+                                              u32x4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */) {
     const DecSample d = dec_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;      // fp16 forward fragments
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A : nullptr;
     float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H : nullptr;
     // embedding (40 units = blocks 0, 1 and half of 2) and interpolated feature: B operands of two / five products, split once
-    LkB8 eb[3], cb[2];
+    LkH8 eb[3], cb[2];
     {
         const f32x16 e0 = sincos_embed_tile<4>(W + C_EB, 20, 0, a0, a1, a2, lane);
         const f32x16 e1 = sincos_embed_tile<1>(W + C_EB, 20, 1, a0, a1, a2, lane);
@@ -207,9 +207,9 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
             ct_store_rows32(erow, e0, true, lane);
             *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1[0], e1[1], e1[2], e1[3]);
         }
-        eb[0] = lk_split_ct(e0, 0); eb[1] = lk_split_ct(e0, 1); eb[2] = lk_split_ct(e1, 0);
+        eb[0] = lk_split_cth(e0, 0); eb[1] = lk_split_cth(e0, 1); eb[2] = lk_split_cth(e1, 0);
         const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
-        cb[0] = lk_split_ct(cc, 0); cb[1] = lk_split_ct(cc, 1);
+        cb[0] = lk_split_cth(cc, 0); cb[1] = lk_split_cth(cc, 1);
     }
     // a block travels to the other waves through LDS as SPLIT pieces (the producer splits once, the four consumers read
     // bf16): block (w, G), piece p at [((w*2 + G)*3 + p)*64 + lane], lane-contiguous 16-byte accesses both ways
@@ -217,28 +217,28 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     // a layer cannot be waited for without waiting for those stores too.  So everything a layer's epilogue and the head
     // of the next product need is fetched BEFORE the stores (wn: first four hidden blocks of the next layer, un: fc_c),
     // pinned with scheduling barriers; the tail of the product (blocks 4..7) is fetched in line, long after the stores.
-    LkB8 wn[4], un[2];
+    LkH8 wn[4], un[2];
     auto prefetch_hidden = [&](const u32x4* fragb, int G0) {
 #pragma unroll
-        for (int G = 0; G < 4; ++G) wn[G] = lk_fragb_load(fragb, 4, G0 + G, w, lane);
+        for (int G = 0; G < 4; ++G) wn[G] = lk_fragh_load(fragb, 4, G0 + G, w, lane);
     };
     auto prefetch_u = [&](const u32x4* ufragb) {
 #pragma unroll
-        for (int G = 0; G < 2; ++G) un[G] = lk_fragb_load(ufragb, 4, G, w, lane);
+        for (int G = 0; G < 2; ++G) un[G] = lk_fragh_load(ufragb, 4, G, w, lane);
     };
     // acc += W[own block][hidden 128] h with h read from LDS; G0 = first 16-k block of the hidden part in the matrix
     auto hidden = [&](f32x16& acc, const u32x4* fragb, int G0, int buf) {
 #pragma unroll
         for (int G = 0; G < 8; ++G) {
-            LkB8 b;
+            LkH8 b;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b.p[q] = s_x[buf][(G * 3 + q) * 64 + lane];
-            acc = lk_mma6(G < 4 ? wn[G] : lk_fragb_load(fragb, 4, G0 + G, w, lane), b, acc);
+            for (int q = 0; q < 2; ++q) b.p[q] = s_x[buf][(G * 2 + q) * 64 + lane];
+            acc = lk_mma3h(G < 4 ? wn[G] : lk_fragh_load(fragb, 4, G0 + G, w, lane), b, acc);
         }
     };
     auto embed = [&](f32x16& acc, const u32x4* fragb) {
 #pragma unroll
-        for (int G = 0; G < 3; ++G) acc = lk_mma6(lk_fragb_load(fragb, 4, G, w, lane), eb[G], acc);
+        for (int G = 0; G < 3; ++G) acc = lk_mma3h(lk_fragh_load(fragb, 4, G, w, lane), eb[G], acc);
     };
     // bias + softplus + fc_c(c) for the wave's own 32-unit block, then ALL stores of the layer: saved a / h rows, LDS park
     auto finish = [&](f32x16& acc, const float* ubias, float* save_a, int L, int buf) {
@@ -247,53 +247,53 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         const f32x16 act = acc;
         lk_add_rowvec(acc, ubias, w * 32, lane);
 #pragma unroll
-        for (int G = 0; G < 2; ++G) acc = lk_mma6(un[G], cb[G], acc);
+        for (int G = 0; G < 2; ++G) acc = lk_mma3h(un[G], cb[G], acc);
         __builtin_amdgcn_sched_barrier(0);
         if (save_a) ct_store_rows32(save_a + w * 32, act, live, lane);
         if (save) ct_store_rows32(act_col_h + L * 128 + w * 32, acc, live, lane);
         if (buf >= 0) {
 #pragma unroll
             for (int G = 0; G < 2; ++G) {
-                const LkB8 b = lk_split_ct(acc, G);
+                const LkH8 b = lk_split_cth(acc, G);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) s_x[buf][((w * 2 + G) * 3 + q) * 64 + lane] = b.p[q];
+                for (int q = 0; q < 2; ++q) s_x[buf][((w * 2 + G) * 2 + q) * 64 + lane] = b.p[q];
             }
         }
     };
     f32x16 acc;
     // layer 0: 40 -> 128
-    prefetch_u(FB + FM15_FWDB);
+    prefetch_u(FB + FM15_FWDH);
     acc = lk_rowvec_tile(W + C_B0, w * 32, lane);
-    embed(acc, FB + FM10_FWDB);
-    prefetch_hidden(FB + FM11_FWDB, 0);
+    embed(acc, FB + FM10_FWDH);
+    prefetch_hidden(FB + FM11_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
     finish(acc, W + C_U0 + a64(HC * CF), act_col_a, 0, 0);
     __syncthreads();
     // layers 1, 2: 128 -> 128
 #pragma unroll
     for (int L = 1; L <= 2; ++L) {
-        prefetch_u(FB + (L == 1 ? FM16_FWDB : FM17_FWDB));
+        prefetch_u(FB + (L == 1 ? FM16_FWDH : FM17_FWDH));
         acc = lk_rowvec_tile(W + (L == 1 ? C_B1 : C_B2), w * 32, lane);
-        hidden(acc, FB + (L == 1 ? FM11_FWDB : FM12_FWDB), 0, (L - 1) & 1);
-        if (L == 1) prefetch_hidden(FB + FM12_FWDB, 0);
-        else prefetch_hidden(FB + FM13_FWDB, 3);
+        hidden(acc, FB + (L == 1 ? FM11_FWDH : FM12_FWDH), 0, (L - 1) & 1);
+        if (L == 1) prefetch_hidden(FB + FM12_FWDH, 0);
+        else prefetch_hidden(FB + FM13_FWDH, 3);
         __builtin_amdgcn_sched_barrier(0);
         finish(acc, W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + L * 128 : nullptr, L, L & 1);
         __syncthreads();
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
-    prefetch_u(FB + FM18_FWDB);
+    prefetch_u(FB + FM18_FWDH);
     acc = lk_rowvec_tile(W + C_B3, w * 32, lane);
-    embed(acc, FB + FM13_FWDB);
-    hidden(acc, FB + FM13_FWDB, 3, 0);
-    prefetch_hidden(FB + FM14_FWDB, 0);
+    embed(acc, FB + FM13_FWDH);
+    hidden(acc, FB + FM13_FWDH, 3, 0);
+    prefetch_hidden(FB + FM14_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
     finish(acc, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 3 * 128 : nullptr, 3, 1);
     __syncthreads();
     // layer 4
-    prefetch_u(FB + FM19_FWDB);
+    prefetch_u(FB + FM19_FWDH);
     acc = lk_rowvec_tile(W + C_B4, w * 32, lane);
-    hidden(acc, FB + FM14_FWDB, 0, 1);
+    hidden(acc, FB + FM14_FWDH, 0, 1);
     finish(acc, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 4 * 128 : nullptr, 4, -1);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
@@ -335,7 +335,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
 // decoder (4 independent tiles per workgroup).  raw[:, 0:3] and raw[:, 3] are written by the two roles separately;
 // in the geometry stage there are no colour blocks and raw[:, 0:3] is zero-filled by the geometry wave.
 __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col_blocks) {
-    __shared__ u32x4 s_x[2][24 * 64];
+    __shared__ u32x4 s_x[2][16 * 64];
     __shared__ float s_o[4][3 * 32];
     const int lane = lk_lane();
     const int w = (int)threadIdx.x >> 6;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     const float a1 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 1], py));
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;      // fp16 forward fragments
     const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
     // X^T tiles: units 0..19 embedding, 20..51 feature channels 0..31, 52..55 zero
     f32x16 x0, x1;
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     f32x16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_rowvec_tile(W + R_B1, nb * 32, lane);      // accumulators start from the bias
-    lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 0, 0, x0, 0, lane);
-    lk_gemm_b6<4, 2>(hid, FB + FM20_FWDB, 4, 2, 0, x1, 0, lane);       // units 32..55; registers 12..15 of x1 are zero
+    lk_gemm_h3<4, 2>(hid, FB + FM20_FWDH, 4, 0, 0, x0, 0, lane);
+    lk_gemm_h3<4, 2>(hid, FB + FM20_FWDH, 4, 2, 0, x1, 0, lane);       // units 32..55; registers 12..15 of x1 are zero
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     f32x16 out[1];
     out[0] = lk_rowvec_tile(W + R_B2, 0, lane);
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) lk_gemm_b6<1, 2>(out, FB + FM21_FWDB, 1, 2 * kb, 0, hid[kb], 0, lane);
+    for (int kb = 0; kb < 4; ++kb) lk_gemm_h3<1, 2>(out, FB + FM21_FWDH, 1, 2 * kb, 0, hid[kb], 0, lane);
     // c[ch] = sum over the 8 neighbour rows of a sample (8 consecutive lanes) of w * f[ch]
     const bool has = a.nbr_count[sp] >= a.min_nn;
     float* __restrict__ crow = a.c_col + (size_t)sp * LK_C;

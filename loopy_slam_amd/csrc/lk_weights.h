@@ -74,7 +74,7 @@ constexpr int BLOB_FLOATS = R_B2 + 64;
 // 40 -> 64) so that every 32-wide block of dX^T is either embedding or hidden.  In the forward form a skip / first
 // layer's embedding columns form their own run of blocks, zero-padded to a multiple of 16 columns, so that a block never
 // straddles the embedding and the hidden part (their B operands live in different CT tiles).
-struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwdb, trb; };
+struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwdb, trb, fwdh; };
 
 constexpr int kb16(int k) { return (k + 15) / 16; }
 constexpr int fwd_blocks16(int ld, int e_real) { return e_real < ld ? kb16(e_real) + kb16(ld - e_real) : kb16(ld); }
@@ -82,9 +82,11 @@ constexpr int fwd_blocks16(int ld, int e_real) { return e_real < ld ? kb16(e_rea
 #define LKW_FM(idx, plain_, rows_, ld_, ereal_, evirt_, kv_, prev_)                              \
     constexpr int FM##idx##_FWDB = FM##prev_##_ENDB;                                             \
     constexpr int FM##idx##_TRB = FM##idx##_FWDB + fwd_blocks16(ld_, ereal_) * ((rows_) / 32) * 192; \
-    constexpr int FM##idx##_ENDB = FM##idx##_TRB + ((rows_) / 16) * ((kv_) / 32) * 192;
+    constexpr int FM##idx##_ENDB = FM##idx##_TRB + ((rows_) / 16) * ((kv_) / 32) * 192;        \
+    constexpr int FM##idx##_FWDH = FM##prev_##_ENDH;                                             \
+    constexpr int FM##idx##_ENDH = FM##idx##_FWDH + fwd_blocks16(ld_, ereal_) * ((rows_) / 32) * 128;
 
-constexpr int FMS_ENDB = 0;
+constexpr int FMS_ENDB = 0, FMS_ENDH = 0;
 
 // index:            plain   rows ld            e_real e_virt kv
 LKW_FM(0,  G_W0, HG, EGP,        EGP, EGP, 96,  S)
@@ -110,9 +112,12 @@ LKW_FM(19, C_U0 + 4 * C_USTRIDE, HC, CF, CF, CF, 32, 18)
 LKW_FM(20, R_W1, HC, KRP,        KRP, 64,  64,  19)
 LKW_FM(21, R_W2, CF, HC,         HC,  HC,  128, 20)
 constexpr int FRAGB_U4 = FM21_ENDB;         // uint4 units
+// Forward fragments once more as TWO fp16 pieces (lk_common.h::lk_mma3h, the forward kernels): block = [piece 0..1][lane]
+// uint4 = 2 KiB, same (G, nb) order; they follow the bf16 blob in the fragment buffer.
+constexpr int FRAGH_U4 = FM21_ENDH;
 constexpr int N_FRAG_MATS = 22;
 
-#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWDB, FM##idx##_TRB}
+#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWDB, FM##idx##_TRB, FM##idx##_FWDH}
 #define LKW_FRAG_TABLE                                                                 \
     LKW_FM_ROW(0,  G_W0, HG, EGP,        EGP, EGP, 96),                                \
     LKW_FM_ROW(1,  G_W1, HG, HG,         HG,  HG,  32),                                \

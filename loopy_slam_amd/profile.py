@@ -22,9 +22,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 # (32x32x16 at 32 cycles, 256 CUs x 4 SIMDs x 2.4 GHz) / 6 instructions per fp32-equivalent product block
 PEAK_BF16_MFMA_TFLOPS = 2516.6
 PEAK_F32_VIA_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# forward kernels: two fp16 pieces, three products (lk_common.h::lk_mma3h) on the same pipe (fp16 rate = bf16 rate)
+PEAK_F32_VIA_F16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
-# matrix path of each MFMA-bound kernel: 'f32' = v_mfma_f32_32x32x2_f32, 'bf16x6' = split products
-MFMA_PATH = {'k_decode_fwd': 'bf16x6', 'k_relpos_fwd': 'bf16x6', 'k_relpos_bwd': 'bf16x6', 'k_decode_bwd': 'f32', 'k_wgrad': 'f32'}
+# matrix path of each MFMA-bound kernel: 'f32' = v_mfma_f32_32x32x2_f32, 'bf16x6' / 'f16x3' = split products
+MFMA_PATH = {'k_decode_fwd': 'f16x3', 'k_relpos_fwd': 'f16x3', 'k_relpos_bwd': 'bf16x6', 'k_decode_bwd': 'bf16x6', 'k_wgrad': 'f32'}
 S = 5
 
 MAC = dict(
@@ -118,7 +120,7 @@ def roofline(kstat, budget, kernel):
     secs = k['total_ms'] * 1e-3
     flops, nbytes = model['flops'] * n_steps, model['bytes'] * n_steps
     path = MFMA_PATH.get(kernel, 'f32')
-    peak_mfma = PEAK_F32_VIA_BF16X6_TFLOPS if path == 'bf16x6' else PEAK_F32_MFMA_TFLOPS
+    peak_mfma = {'bf16x6': PEAK_F32_VIA_BF16X6_TFLOPS, 'f16x3': PEAK_F32_VIA_F16X3_TFLOPS}.get(path, PEAK_F32_MFMA_TFLOPS)
     t_mfma, t_hbm = flops / (peak_mfma * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
     out = {'kernel': kernel, 'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'], 'traffic': None}
     if t_mfma >= t_hbm:

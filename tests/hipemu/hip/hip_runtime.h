@@ -156,6 +156,34 @@ static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8_emu a, b
     for (int r = 0; r < 16; ++r) d[r] = di[r];
     return d;
 }
+// fp16 MFMA (same lane layout as the bf16 form) and the pack-convert used to cut fp32 values into fp16 pieces
+typedef _Float16 f16x8_emu __attribute__((ext_vector_type(8)));
+static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x16_f16(f16x8_emu a, f16x8_emu b, f32x16_emu c, int, int, int) {
+    float fa[8], fb[8], ci[16], di[16];
+    for (int e = 0; e < 8; ++e) { fa[e] = (float)a[e]; fb[e] = (float)b[e]; }
+    for (int r = 0; r < 16; ++r) ci[r] = c[r];
+    hipemu::wave_mfma32x32x16_bf16(fa, fb, ci, di);
+    f32x16_emu d;
+    for (int r = 0; r < 16; ++r) d[r] = di[r];
+    return d;
+}
+typedef __fp16 f16x2_emu __attribute__((ext_vector_type(2)));
+static inline _Float16 hipemu_rtz_f16(float x) {        // round toward zero, saturating (v_cvt_pkrtz_f16_f32)
+    if (x != x) return (_Float16)x;
+    _Float16 h = (_Float16)x;                            // nearest
+    if (std::fabs((float)h) > std::fabs(x) || std::isinf((float)h)) {
+        unsigned short b; std::memcpy(&b, &h, 2);
+        b = (unsigned short)(b - 1);                     // one step toward zero (sign-magnitude encoding)
+        std::memcpy(&h, &b, 2);
+    }
+    return h;
+}
+static inline f16x2_emu __builtin_amdgcn_cvt_pkrtz(float a, float b) {
+    const _Float16 x = hipemu_rtz_f16(a), y = hipemu_rtz_f16(b);
+    f16x2_emu r;
+    std::memcpy(reinterpret_cast<char*>(&r), &x, 2); std::memcpy(reinterpret_cast<char*>(&r) + 2, &y, 2);
+    return r;
+}
 // v_perm_b32: byte pool {S0 = bytes 7..4, S1 = bytes 3..0}, selector byte n of `sel` picks pool byte (0..7)
 static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
     const unsigned long long pool = ((unsigned long long)s0 << 32) | s1;
