@@ -77,7 +77,7 @@ typedef struct {
 int lk_weight_layout(lk_weight_entry* out, int max_entries); /* returns #entries */
 int64_t lk_weight_blob_floats(void);
 /* The GEMM operands are streamed from a derived "fragment" copy of the blob (MFMA operand order, forward + transposed,
- * every weight as three bf16 pieces; opaque to the caller: allocate lk_weight_frag_floats() floats, 16-byte aligned);
+ * every weight as three bf16 pieces, the forward form also as two fp16 pieces; opaque to the caller: allocate lk_weight_frag_floats() floats, 16-byte aligned);
  * refresh it after every change of the master blob (optimiser step, load). */
 int64_t lk_weight_frag_floats(void);
 int lk_weights_repack(const float* blob, float* frag, void* stream);
