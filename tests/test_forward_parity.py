@@ -180,3 +180,23 @@ def test_forward_intermediates_vs_oracle(backend):
     raw = st.raw.cpu().numpy()
     np.testing.assert_allclose(raw[:, 3], o['occ'].numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(raw[:, :3], o['rgb'].numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('scale', (1e-3, 30.0))
+def test_forward_operand_range(backend, scale):
+    """The forward products run on fp16 pieces (lk_common.h: fp16x3): feature tables 30x larger (activations of a few
+    hundred) or 1000x smaller (low pieces deep in the fp16 subnormals) than usual still match the oracle."""
+    eng = make_engine(backend)
+    name = 'replica'
+    g = dict(load(f'g6_render_{name}_map_color'))
+    g['geo'], g['col'] = g['geo'] * np.float32(scale), g['col'] * np.float32(scale)
+    st = run_forward(eng, name, g, 'color')
+    ro, rd, gd, pos, geo, col = tens(g, 'rays_o', 'rays_d', 'gt_depth', 'pos', 'geo', 'col')
+    with torch.no_grad():
+        o = H.render_batch(ocfg(name), ro, rd, gd, pos, geo, col, weights(name), 'color',
+                           noise_geo=torch.from_numpy(g['noise_geo']), noise_col=torch.from_numpy(g['noise_col']))
+    np.testing.assert_allclose(st.depth.cpu().numpy(), o['depth'].numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st.color.cpu().numpy(), o['color'].numpy(), rtol=1e-4, atol=2e-5)
+    raw = st.raw.cpu().numpy()
+    np.testing.assert_allclose(raw[:, 3], o['occ'].numpy(), rtol=1e-4, atol=1e-4 * max(1.0, scale))
