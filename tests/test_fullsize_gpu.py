@@ -132,16 +132,17 @@ def test_frustum_rows_and_insertion_at_five_million_points():
     assert acc.numel() == 50_000 and pts.shape == (150_000, 3) and torch.equal(acc.cpu(), torch.arange(50_000, dtype=torch.int32))
 
 
+@pytest.mark.parametrize('rel_pos', (True, False))
 @pytest.mark.parametrize('R', (3000, 5000, 10000, 40000))
-def test_render_is_deterministic_at_scale(R):
+def test_render_is_deterministic_at_scale(R, rel_pos):
     """The same forward (saved activations) and the same backward twice give the same bits in every buffer that does not
     go through float atomics.  Catches what small parity cases cannot: intra-workgroup races and instruction-level
     hazards that only show with several workgroups per compute unit (a split-bf16 backward once passed every parity
     test and produced half-tiles of wrong d h in ~1 % of the tiles from 3 000 rays on)."""
     eng = make_engine('hip')
     pos, geo, col, knn = _scene(eng, 100_000)
-    blob = core.DecoderBlob(eng).pack(syn.default_weights())
-    cfg = core.RenderCfg()
+    blob = core.DecoderBlob(eng).pack(syn.default_weights(rel_pos=rel_pos))
+    cfg = core.RenderCfg(rel_pos=rel_pos)         # Replica model (rel-pos neighbour MLP) / TUM-ScanNet model (plain colour)
     depth, _, c2w = syn.render_frame(7, device='cuda', holes=0.02)
     g = torch.Generator().manual_seed(R)
     i = torch.randint(0, I['W'], (R,), generator=g).float().cuda()
