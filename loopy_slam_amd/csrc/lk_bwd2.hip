@@ -290,6 +290,17 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
     float dax = 0.0f, day = 0.0f, daz = 0.0f;        // d loss / d (x_I - p), this lane's share
     const float* B = W + R_EB;
+    // d sin = cos, d cos = -sin: the derivative of embedding unit u is (+/-) the FORWARD value of its partner unit u +/- 10,
+    // which x0 already holds - in this lane for 12 of the 20 units, in the lane of the other half-wave for units
+    // 2, 3, 6, 7 / 12, 13, 16, 17 (four exchanges) - instead of twelve more sin / cos evaluations per lane.
+    float fder[12];
+    {
+        const float r0 = __shfl_xor(h ? x0[4] : x0[8], 32), r1 = __shfl_xor(h ? x0[5] : x0[9], 32);
+        const float r2 = __shfl_xor(x0[2], 32), r3 = __shfl_xor(x0[3], 32);
+        fder[0] = x0[6]; fder[1] = x0[7]; fder[2] = r0; fder[3] = r1;                                        // units 0-3 | 4-7
+        fder[4] = h ? -r2 : x0[10]; fder[5] = h ? -r3 : x0[11]; fder[6] = -x0[0]; fder[7] = -x0[1];          // units 8-11 | 12-15
+        fder[8] = -r2; fder[9] = -r3; fder[10] = -x0[4]; fder[11] = -x0[5];                                  // units 16-19 (low half)
+    }
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
@@ -303,11 +314,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
                     const int xi = is_emb ? ((u < 10) ? u : u - 10) : 0;
                     const float b0 = B[xi], b1 = B[10 + xi], b2 = B[20 + xi];
                     float gx = 0.0f;
-                    if (is_emb) {
-                        const float x = lk_fourier_arg(a0, a1, a2, b0, b1, b2);
-                        const float f = (u < 10) ? lk_cosf(x) : -lk_sinf(x);
-                        gx = dx[tile][4 * g + t] * f;
-                    }
+                    if (is_emb) gx = dx[tile][4 * g + t] * fder[4 * g + t];
                     if (want_p) {
                         dax = fmaf(gx * LK_TWO_PI, b0, dax); day = fmaf(gx * LK_TWO_PI, b1, day); daz = fmaf(gx * LK_TWO_PI, b2, daz);
                     }
