@@ -95,6 +95,9 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
 #define LK_FLAG_ZERO_ABSENT   (1u << 9)  /* rays with gt_depth <= 0 are ABSENT (filtered rays of a training batch kept for a
                                            * static shape: the losses ignore them): no far_bb statistics, their samples sit
                                            * between near_end and 0 */
+#define LK_FLAG_MAPPER_LOSS   (1u << 10) /* lk_render_fwd also evaluates the mapper loss of the batch (Mapper.py:691-720, what
+                                           * lk_loss_mapper computes) inside the composite kernel: reads loss_gt_color /
+                                           * loss_w_color, writes d_depth, d_color and loss_out4 = [loss, geo, colour, #masked] */
 
 typedef struct {
     /* ---- sizes */
@@ -148,6 +151,10 @@ typedef struct {
                                   * (the frustum rows being optimised, Mapper.py:498-512) - the others are never read */
     /* ---- backward scratch */
     float* bwd_scratch;         /* lk_render_bwd_scratch_floats(R,S,flags) floats */
+    /* ---- LK_FLAG_MAPPER_LOSS */
+    const float* loss_gt_color;  /* [R,3] */
+    float* loss_out4;            /* [4] */
+    float loss_w_color;
 } lk_render_desc;
 
 int64_t lk_render_act_floats(int32_t R, int32_t S, uint32_t flags);

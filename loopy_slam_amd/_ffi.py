@@ -25,6 +25,7 @@ FLAG_GRAD_WEIGHTS = 1 << 6
 FLAG_GRAD_RAYS = 1 << 7
 FLAG_ALL_DEPTH_POS = 1 << 8
 FLAG_ZERO_ABSENT = 1 << 9
+FLAG_MAPPER_LOSS = 1 << 10
 
 EXPOSURE_MAX_F = 32
 ADAM_MAX_SEG = 16
@@ -51,6 +52,7 @@ class RenderDesc(C.Structure):
         ('d_depth', _fp), ('d_var', _fp), ('d_color', _fp),
         ('g_geo_feats', _fp), ('g_col_feats', _fp), ('g_weights', _fp), ('g_rays_o', _fp), ('g_rays_d', _fp),
         ('g_affine', _fp), ('grad_row_mask', _fp), ('bwd_scratch', _fp),
+        ('loss_gt_color', _fp), ('loss_out4', _fp), ('loss_w_color', C.c_float),
     ]
 
 

@@ -213,7 +213,7 @@ class RenderState:
 
 def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, dec, stage,
               tracker=False, r2_ray=None, noise_geo=None, noise_col=None, affine=None,
-              color_logits=False, save_act=False, stats_chunk=None, extra_flags=0):
+              color_logits=False, save_act=False, stats_chunk=None, extra_flags=0, mapper_loss=None):
     d = RenderDesc()
     R = rays_o.shape[0]
     flags = extra_flags
@@ -239,6 +239,12 @@ def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_f
     d.depth, d.var, d.color, d.valid_ray = ptr(st.depth), ptr(st.var), ptr(st.color), ptr(st.valid_ray)
     d.z, d.nbr_idx, d.nbr_w, d.nbr_count = ptr(st.z), ptr(st.nbr_idx), ptr(st.nbr_w), ptr(st.nbr_count)
     d.c_geo, d.c_col, d.raw, d.far_stats, d.act = ptr(st.c_geo), ptr(st.c_col), ptr(st.raw), ptr(st.far_stats), ptr(st.act)
+    if mapper_loss is not None:     # (gt_color, w_color, d_depth, d_color, out4): lk_loss_mapper fused into the composite kernel
+        gt_color, w_color, d_depth, d_color, out4 = mapper_loss
+        d.flags |= _ffi.FLAG_MAPPER_LOSS
+        d.loss_gt_color, d.loss_w_color, d.loss_out4 = ptr(gt_color), float(w_color), ptr(out4)
+        d.d_depth, d.d_color = ptr(d_depth), ptr(d_color)
+        st.keep_loss = mapper_loss
     st.desc = d
     # keep every tensor referenced by raw pointers alive until the next call
     st.keep = (rays_o, rays_d, gt_depth, r2_ray, pos, geo_feats, col_feats, dec, affine, noise_geo, noise_col)

@@ -158,6 +158,13 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
     ca.R = d->R; ca.S = d->S; ca.min_nn = d->min_nn; ca.coef = d->coef;
     ca.raw = d->raw; ca.z = d->z; ca.nbr_count = d->nbr_count; ca.gt_depth = d->gt_depth;
     ca.depth = d->depth; ca.var = d->var; ca.color = d->color; ca.valid_ray = d->valid_ray;
+    ca.gt_color = nullptr; ca.w_color = 0.0f; ca.use_color = 0; ca.d_depth = nullptr; ca.d_color = nullptr; ca.loss_out = nullptr;
+    if (d->flags & LK_FLAG_MAPPER_LOSS) {
+        LK_REQUIRE(d->loss_out4 && d->d_depth && d->d_color && d->loss_gt_color, "lk_render_fwd: MAPPER_LOSS needs loss_gt_color, loss_out4, d_depth, d_color");
+        LK_HIP_TRY(hipMemsetAsync(d->loss_out4, 0, 4 * sizeof(float), st));
+        ca.gt_color = d->loss_gt_color; ca.w_color = d->loss_w_color; ca.use_color = (d->flags & LK_FLAG_STAGE_COLOR) ? 1 : 0;
+        ca.d_depth = const_cast<float*>(d->d_depth); ca.d_color = const_cast<float*>(d->d_color); ca.loss_out = d->loss_out4;
+    }
     lk_launch_composite(ca, st);
     LK_LAUNCH_CHECK();
     return LK_OK;

@@ -29,6 +29,9 @@ struct LkCompositeArgs {
     float coef;
     const float* raw; const float* z; const int32_t* nbr_count; const float* gt_depth;
     float* depth; float* var; float* color; uint8_t* valid_ray;
+    // fused mapper loss (LK_FLAG_MAPPER_LOSS): NULL loss_out = off
+    const float* gt_color; float w_color; int use_color;
+    float* d_depth; float* d_color; float* loss_out;
 };
 
 // fused decoder forward (register-chained MFMA): raw[P,4] = (rgb | logits, occ)

@@ -121,39 +121,80 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     if (lane_col) *reinterpret_cast<float4*>(a.c_col + (size_t)pidx * LK_C + f4 * 4) = ac;
 }
 
-// One thread per ray: occupancy of unsupported samples := -100, alpha composite, validity.
+// One thread per ray: occupancy of unsupported samples := -100, alpha composite, validity.  With a.loss_out the mapper loss
+// of the batch (Mapper.py:691-720) rides along: per-ray terms and gradients here, one block sum and four atomics per block
+// (a launch at the latency floor leaves every mapping iteration).
 __global__ __launch_bounds__(256) void k_composite(LkCompositeArgs a) {
+    __shared__ float s_red[3][4];
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
-    if (r >= a.R) return;
-    float T = 1.0f, wsum = 0.0f, dsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-    float wv[LK_S_MAX], zv[LK_S_MAX];
-    int nhas = 0;
+    float l_geo = 0.0f, l_col = 0.0f, l_cnt = 0.0f;
+    if (r < a.R) {
+        float T = 1.0f, wsum = 0.0f, dsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+        float wv[LK_S_MAX], zv[LK_S_MAX];
+        int nhas = 0;
 #pragma unroll
-    for (int s = 0; s < LK_S_MAX; ++s) {
-        if (s < a.S) {
-            const int p = r * a.S + s;
-            const float4 raw = *reinterpret_cast<const float4*>(a.raw + (size_t)p * 4);
-            const bool has = a.nbr_count[p] >= a.min_nn;
-            nhas += has ? 1 : 0;
-            const float occ = has ? raw.w : -100.0f;
-            const float alpha = lk_sigmoid(a.coef * occ);
-            const float w = alpha * T;
-            T *= (1.0f - alpha + 1e-10f);
-            const float z = a.z[p];
-            wv[s] = w; zv[s] = z;
-            wsum += w; dsum += w * z;
-            c0 += w * raw.x; c1 += w * raw.y; c2 += w * raw.z;
-        } else { wv[s] = 0.0f; zv[s] = 0.0f; }
+        for (int s = 0; s < LK_S_MAX; ++s) {
+            if (s < a.S) {
+                const int p = r * a.S + s;
+                const float4 raw = *reinterpret_cast<const float4*>(a.raw + (size_t)p * 4);
+                const bool has = a.nbr_count[p] >= a.min_nn;
+                nhas += has ? 1 : 0;
+                const float occ = has ? raw.w : -100.0f;
+                const float alpha = lk_sigmoid(a.coef * occ);
+                const float w = alpha * T;
+                T *= (1.0f - alpha + 1e-10f);
+                const float z = a.z[p];
+                wv[s] = w; zv[s] = z;
+                wsum += w; dsum += w * z;
+                c0 += w * raw.x; c1 += w * raw.y; c2 += w * raw.z;
+            } else { wv[s] = 0.0f; zv[s] = 0.0f; }
+        }
+        const float ws = wsum + 1e-10f;
+        const float depth = dsum / ws;
+        float var = 0.0f;
+#pragma unroll
+        for (int s = 0; s < LK_S_MAX; ++s) { const float t = zv[s] - depth; var += wv[s] * t * t; }
+        const float gd = a.gt_depth[r];
+        const float dout = (gd > 0.0f) ? depth : 0.0f;              // Renderer.py:197-198
+        const bool valid = nhas >= a.S / 2 + 1;                     // decoder.py:259-260
+        const float o0 = c0 / ws, o1 = c1 / ws, o2 = c2 / ws;
+        a.depth[r] = dout;
+        a.var[r] = var;
+        a.color[3 * r] = o0; a.color[3 * r + 1] = o1; a.color[3 * r + 2] = o2;
+        a.valid_ray[r] = valid ? 1 : 0;
+        if (a.loss_out) {
+            const bool m = (gd > 0.0f) && valid && !(dout != dout);
+            float dd = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+            if (m) {
+                l_geo = fabsf(gd - dout);
+                dd = (dout > gd) ? 1.0f : ((dout < gd) ? -1.0f : 0.0f);
+                l_cnt = 1.0f;
+                if (a.use_color) {
+                    const float e0 = o0 - a.gt_color[3 * r], e1 = o1 - a.gt_color[3 * r + 1], e2 = o2 - a.gt_color[3 * r + 2];
+                    l_col = fabsf(e0) + fabsf(e1) + fabsf(e2);
+                    d0 = a.w_color * ((e0 > 0.0f) ? 1.0f : ((e0 < 0.0f) ? -1.0f : 0.0f));
+                    d1 = a.w_color * ((e1 > 0.0f) ? 1.0f : ((e1 < 0.0f) ? -1.0f : 0.0f));
+                    d2 = a.w_color * ((e2 > 0.0f) ? 1.0f : ((e2 < 0.0f) ? -1.0f : 0.0f));
+                }
+            }
+            a.d_depth[r] = dd;
+            a.d_color[3 * r] = d0; a.d_color[3 * r + 1] = d1; a.d_color[3 * r + 2] = d2;
+        }
     }
-    const float ws = wsum + 1e-10f;
-    const float depth = dsum / ws;
-    float var = 0.0f;
+    if (a.loss_out) {
 #pragma unroll
-    for (int s = 0; s < LK_S_MAX; ++s) { const float t = zv[s] - depth; var += wv[s] * t * t; }
-    a.depth[r] = (a.gt_depth[r] > 0.0f) ? depth : 0.0f;        // Renderer.py:197-198
-    a.var[r] = var;
-    a.color[3 * r] = c0 / ws; a.color[3 * r + 1] = c1 / ws; a.color[3 * r + 2] = c2 / ws;
-    a.valid_ray[r] = (nhas >= a.S / 2 + 1) ? 1 : 0;            // decoder.py:259-260
+        for (int o = 32; o > 0; o >>= 1) { l_geo += __shfl_xor(l_geo, o); l_col += __shfl_xor(l_col, o); l_cnt += __shfl_xor(l_cnt, o); }
+        const int w = (int)threadIdx.x >> 6;
+        if (lk_lane() == 0) { s_red[0][w] = l_geo; s_red[1][w] = l_col; s_red[2][w] = l_cnt; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float geo = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+            const float col = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+            const float cnt = (s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3]);
+            atomicAdd(a.loss_out + 0, geo + (a.use_color ? a.w_color * col : 0.0f));
+            atomicAdd(a.loss_out + 1, geo); atomicAdd(a.loss_out + 2, col); atomicAdd(a.loss_out + 3, cnt);
+        }
+    }
 }
 
 int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st) {

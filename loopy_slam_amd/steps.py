@@ -137,11 +137,13 @@ class MapOptimizer:
         depth_stack, color_stack, c2w_stack, r2_stack = frames
         optim.gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, window, intr, b.as_out(), r2_stack)
         optim.inside_mask(eng, b.gt_depth, None, b.thr, b.scratch_u32, depth_filtered=b.gt_depth)
-        core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
-                            self.dec, stage, r2_ray=b.r2_ray, save_act=True, extra_flags=_ffi.FLAG_ZERO_ABSENT,
-                            color_logits=self.exposure is not None)
         out4 = log_row if log_row is not None else self._out4()
         xs = self.exposure if stage == 'color' else None
+        # without exposure encoding the mapper loss (Mapper.py:691-720) is evaluated inside the composite kernel
+        fused = None if xs is not None else (b.gt_color, self.w_color, b.d_depth, b.d_color, out4)
+        core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
+                            self.dec, stage, r2_ray=b.r2_ray, save_act=True, extra_flags=_ffi.FLAG_ZERO_ABSENT,
+                            color_logits=self.exposure is not None, mapper_loss=fused)
         if xs is not None:
             # the renderer returned colour LOGITS; the rays of keyframe f get sigmoid(logits @ rot_f + trans_f)
             # (Mapper.py:697-715): d depth / d logits for the backward, d loss / d affine for the exposure MLP
@@ -150,8 +152,6 @@ class MapOptimizer:
                                                               ptr(b.gt_color), ptr(frame_id), ptr(xs.aff), xs.F,
                                                               _ffi.C.c_float(self.w_color), ptr(b.d_depth), ptr(b.d_color), ptr(out4),
                                                               ptr(xs.g_aff), eng.stream), 'lk_loss_mapper_exposure')
-        else:
-            optim.loss_mapper(eng, st, b.gt_depth, b.gt_color, self.w_color, stage == 'color', b.d_depth, b.d_color, out4)
         core.render_backward(eng, st, gs, b.d_depth, b.d_color)
         if self.dist is not None:
             self.dist.all_reduce_grads(self, stage)
