@@ -98,6 +98,9 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
 #define LK_FLAG_MAPPER_LOSS   (1u << 10) /* lk_render_fwd also evaluates the mapper loss of the batch (Mapper.py:691-720, what
                                            * lk_loss_mapper computes) inside the composite kernel: reads loss_gt_color /
                                            * loss_w_color, writes d_depth, d_color and loss_out4 = [loss, geo, colour, #masked] */
+#define LK_FLAG_UNIT_LOSS_GRADS (1u << 11) /* lk_render_bwd: the caller guarantees |d_depth|, |d_color| <= ~1 (sum-type losses
+                                           * such as the mapper's L1 terms): the colour decoder's backward may then run its
+                                           * products on fp16 pieces with a fixed 2^10 pre-scale instead of bf16 pieces */
 
 typedef struct {
     /* ---- sizes */

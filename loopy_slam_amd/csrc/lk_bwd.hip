@@ -109,14 +109,41 @@ __device__ __forceinline__ BwdSample bwd_sample(const LkDecodeBwdArgs& a, int ti
 //   d h_{i-1}[own] = W_i^T[own, :] d y_i                  (B operand = all four parked blocks)
 // The embedding gradient tiles (tracker mode) are spread evenly: layer 3's two tiles on waves 0,1, layer 0's on
 // waves 2,3; every wave turns its tile into a d p partial and wave 0 adds the four.
+// H16: products on fp16 pieces (lk_mma3h) instead of bf16 pieces (lk_mma6).  Only for unit-scale loss gradients
+// (LK_FLAG_UNIT_LOSS_GRADS, mapper mode): the whole chain d h_4 .. d h_0 is linear in d out, so d out is multiplied by 2^10
+// once (median |d h| 1.5e-4 -> 0.15: both fp16 pieces normal numbers), everything in between is scaled with it, and the
+// stored d h rows / d c are scaled back where they are written (in the copy resp. the final sum: no extra instruction).
+template <bool H16> struct BwdPiece;
+template <> struct BwdPiece<false> {
+    typedef LkB8 T;
+    static constexpr int NP = 3;
+    static __device__ __forceinline__ T split(const f32x16& x, int G) { return lk_split_ct(x, G); }
+    static __device__ __forceinline__ f32x16 mma(const T& a, const T& b, f32x16 c) { return lk_mma6(a, b, c); }
+    static __device__ __forceinline__ T load(const u32x4* f, int NBT, int G, int nb, int lane) { return lk_fragb_load(f, NBT, G, nb, lane); }
+    static __device__ __forceinline__ int tr(int idx) { return FRAG_TRB[idx]; }
+};
+template <> struct BwdPiece<true> {
+    typedef LkH8 T;
+    static constexpr int NP = 2;
+    static __device__ __forceinline__ T split(const f32x16& x, int G) { return lk_split_cth(x, G); }
+    static __device__ __forceinline__ f32x16 mma(const T& a, const T& b, f32x16 c) { return lk_mma3h(a, b, c); }
+    static __device__ __forceinline__ T load(const u32x4* f, int NBT, int G, int nb, int lane) { return lk_fragh_load(f, NBT, G, nb, lane); }
+    static __device__ __forceinline__ int tr(int idx) { return FRAG_TRH[idx]; }
+};
+
+template <bool H16>
 __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int tile, int w, int lane,
                                                   u32x4* __restrict__ s_x /* [2][24*64] */, float (*s_o)[3 * 32]) {
+    typedef BwdPiece<H16> PC;
+    typedef typename PC::T Piece;
+    constexpr int NP = PC::NP;
+    constexpr float SC = H16 ? 1024.0f : 1.0f, ISC = H16 ? 1.0f / 1024.0f : 1.0f;
     const BwdSample d = bwd_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + (H16 ? FRAGB_U4 : 0);
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A;
@@ -180,7 +207,8 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         g0 = t0; g1 = t1; g2 = t2;
     }
     if (want_w && live && h == 0 && w == 0) *reinterpret_cast<float4*>(a.dlogit + (size_t)sp * 4) = make_float4(g0, g1, g2, 0.0f);
-    // dh4[own] = Wo^T d out
+    // dh4[own] = Wo^T d out (H16: times 2^10 from here on)
+    g0 *= SC; g1 *= SC; g2 *= SC;
     f32x16 dh, dy;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -194,24 +222,24 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     // Split-bf16 products (lk_common.h::lk_mma6).  Loads and stores share one in-order counter, so what a layer needs
     // right after its d h store - un = U_i^T blocks of the own units, av = saved a_i, wn = first four blocks of W_i^T for
     // the own output block - is fetched BEFORE that store, at the end of the previous layer; blocks 4..7 come in line.
-    LkB8 un[2], wn[4];
+    Piece un[2], wn[4];
     f32x16 av;
     auto prefetch = [&](int i) {
-        const u32x4* ut = FB + (i == 0 ? FM15_TRB : i == 1 ? FM16_TRB : i == 2 ? FM17_TRB : i == 3 ? FM18_TRB : FM19_TRB);
+        const u32x4* ut = FB + PC::tr(15 + i);
 #pragma unroll
-        for (int G = 0; G < 2; ++G) un[G] = lk_fragb_load(ut, 1, 2 * w + G, 0, lane);
+        for (int G = 0; G < 2; ++G) un[G] = PC::load(ut, 1, 2 * w + G, 0, lane);
         av = ct_load32(act_col_a + i * 128 + w * 32, lane);
         if (i >= 1) {
-            const u32x4* wt = FB + (i == 4 ? FM14_TRB : i == 3 ? FM13_TRB : i == 2 ? FM12_TRB : FM11_TRB);
+            const u32x4* wt = FB + PC::tr(10 + i);
 #pragma unroll
-            for (int G = 0; G < 4; ++G) wn[G] = lk_fragb_load(wt, i == 3 ? 6 : 4, G, i == 3 ? 2 + w : w, lane);
+            for (int G = 0; G < 4; ++G) wn[G] = PC::load(wt, i == 3 ? 6 : 4, G, i == 3 ? 2 + w : w, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto lds_b = [&](const u32x4* xs, int G) {
-        LkB8 b;
+        Piece b;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) b.p[q] = xs[(G * 3 + q) * 64 + lane];
+        for (int q = 0; q < NP; ++q) b.p[q] = xs[(G * NP + q) * 64 + lane];
         return b;
     };
     prefetch(4);
@@ -223,37 +251,37 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         // pipe).  The store therefore reads a copy that stays allocated until the end of the layer.
         f32x16 dhc;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { float t = dh[q]; asm volatile("" : "+v"(t)); dhc[q] = t; }
+        for (int q = 0; q < 16; ++q) { float t = H16 ? dh[q] * ISC : dh[q]; asm volatile("" : "+v"(t)); dhc[q] = t; }
         if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dhc, live, lane);
 #pragma unroll
-        for (int G = 0; G < 2; ++G) dc = lk_mma6(un[G], lk_split_ct(dh, G), dc);
+        for (int G = 0; G < 2; ++G) dc = PC::mma(un[G], PC::split(dh, G), dc);
 #pragma unroll
         for (int q = 0; q < 16; ++q) dy[q] = dh[q] * lk_softplus100_grad_from_out(av[q]);
         if (i == 0 && !want_p) break;
         u32x4* xs = s_x + buf * (24 * 64);
 #pragma unroll
         for (int G = 0; G < 2; ++G) {
-            const LkB8 b = lk_split_ct(dy, G);
+            const Piece b = PC::split(dy, G);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) xs[((w * 2 + G) * 3 + q) * 64 + lane] = b.p[q];
+            for (int q = 0; q < NP; ++q) xs[((w * 2 + G) * NP + q) * 64 + lane] = b.p[q];
         }
         __syncthreads();
         buf ^= 1;
         if (i >= 1) {
-            const u32x4* wt = FB + (i == 4 ? FM14_TRB : i == 3 ? FM13_TRB : i == 2 ? FM12_TRB : FM11_TRB);
+            const u32x4* wt = FB + PC::tr(10 + i);
             const int nbt = i == 3 ? 6 : 4, nb = i == 3 ? 2 + w : w;
             dh = lk_zero16();
 #pragma unroll
-            for (int G = 0; G < 8; ++G) dh = lk_mma6(G < 4 ? wn[G] : lk_fragb_load(wt, nbt, G, nb, lane), lds_b(xs, G), dh);
+            for (int G = 0; G < 8; ++G) dh = PC::mma(G < 4 ? wn[G] : PC::load(wt, nbt, G, nb, lane), lds_b(xs, G), dh);
             if (i == 3 && want_p && w < 2) {
 #pragma unroll
-                for (int G = 0; G < 8; ++G) de = lk_mma6(lk_fragb_load(FB + FM13_TRB, 6, G, w, lane), lds_b(xs, G), de);
+                for (int G = 0; G < 8; ++G) de = PC::mma(PC::load(FB + PC::tr(13), 6, G, w, lane), lds_b(xs, G), de);
             }
             prefetch(i - 1);
         } else {       // i == 0: only the embedding receives gradient
             if (w >= 2) {
 #pragma unroll
-                for (int G = 0; G < 8; ++G) de = lk_mma6(lk_fragb_load(FB + FM10_TRB, 2, G, w - 2, lane), lds_b(xs, G), de);
+                for (int G = 0; G < 8; ++G) de = PC::mma(PC::load(FB + PC::tr(10), 2, G, w - 2, lane), lds_b(xs, G), de);
             }
         }
 #pragma unroll
@@ -288,6 +316,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         const float4 c1 = xs[(1 * 4 + w) * 64 + lane], c2 = xs[(2 * 4 + w) * 64 + lane], c3 = xs[(3 * 4 + w) * 64 + lane];
         c0.x = ((c0.x + c1.x) + c2.x) + c3.x; c0.y = ((c0.y + c1.y) + c2.y) + c3.y;
         c0.z = ((c0.z + c1.z) + c2.z) + c3.z; c0.w = ((c0.w + c1.w) + c2.w) + c3.w;
+        if (H16) { c0.x *= ISC; c0.y *= ISC; c0.z *= ISC; c0.w *= ISC; }
         if (live) *reinterpret_cast<float4*>(a.dc_col + (size_t)sp * LK_C + 8 * w + 4 * h) = c0;
         if (want_p && w == 0 && h == 0 && live) {
             const float x = ((s_o[0][lane] + s_o[1][lane]) + s_o[2][lane]) + s_o[3][lane];
@@ -383,12 +412,13 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
 // wave serialise in the memory-side atomic unit): the embedding-matrix gradient is therefore reduced
 // wave -> LDS -> one partial row per workgroup, and summed by k_reduce_partials.
 // Block roles as in k_decode_fwd: the first n_col_blocks workgroups are colour tiles, the rest geometry (4 tiles each).
+template <bool H16>
 __global__ __launch_bounds__(256, 2) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
     __shared__ u32x4 s_x[2 * 24 * 64];
     __shared__ float s_o[4][3 * 32];
     const int w = (int)threadIdx.x >> 6;
     if ((int)blockIdx.x < n_col_blocks) {
-        decode_bwd_col_wg(a, blockIdx.x, w, lk_lane(), s_x, s_o);
+        decode_bwd_col_wg<H16>(a, blockIdx.x, w, lk_lane(), s_x, s_o);
         return;
     }
     float (*s_part)[3 * EGP] = reinterpret_cast<float (*)[3 * EGP]>(s_x);
@@ -440,6 +470,9 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_BWD, st);
     const int tiles = lk_cdiv(a.P, 32);
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
-    hipLaunchKernelGGL(k_decode_bwd, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
+    // fp16 pieces only for unit-scale loss gradients without ray gradients (mapper mode), see decode_bwd_col_wg
+    const bool h16 = (a.flags & LK_FLAG_UNIT_LOSS_GRADS) && !(a.flags & LK_FLAG_GRAD_RAYS);
+    if (h16) hipLaunchKernelGGL((k_decode_bwd<true>), dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
+    else hipLaunchKernelGGL((k_decode_bwd<false>), dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     return LK_OK;
 }

@@ -74,7 +74,7 @@ constexpr int BLOB_FLOATS = R_B2 + 64;
 // 40 -> 64) so that every 32-wide block of dX^T is either embedding or hidden.  In the forward form a skip / first
 // layer's embedding columns form their own run of blocks, zero-padded to a multiple of 16 columns, so that a block never
 // straddles the embedding and the hidden part (their B operands live in different CT tiles).
-struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwdb, trb, fwdh; };
+struct FragMat { int plain, rows, ld, e_real, e_virt, kv, fwdb, trb, fwdh, trh; };
 
 constexpr int kb16(int k) { return (k + 15) / 16; }
 constexpr int fwd_blocks16(int ld, int e_real) { return e_real < ld ? kb16(e_real) + kb16(ld - e_real) : kb16(ld); }
@@ -84,7 +84,8 @@ constexpr int fwd_blocks16(int ld, int e_real) { return e_real < ld ? kb16(e_rea
     constexpr int FM##idx##_TRB = FM##idx##_FWDB + fwd_blocks16(ld_, ereal_) * ((rows_) / 32) * 192; \
     constexpr int FM##idx##_ENDB = FM##idx##_TRB + ((rows_) / 16) * ((kv_) / 32) * 192;        \
     constexpr int FM##idx##_FWDH = FM##prev_##_ENDH;                                             \
-    constexpr int FM##idx##_ENDH = FM##idx##_FWDH + fwd_blocks16(ld_, ereal_) * ((rows_) / 32) * 128;
+    constexpr int FM##idx##_TRH = FM##idx##_FWDH + fwd_blocks16(ld_, ereal_) * ((rows_) / 32) * 128; \
+    constexpr int FM##idx##_ENDH = FM##idx##_TRH + ((rows_) / 16) * ((kv_) / 32) * 128;
 
 constexpr int FMS_ENDB = 0, FMS_ENDH = 0;
 
@@ -112,12 +113,17 @@ LKW_FM(19, C_U0 + 4 * C_USTRIDE, HC, CF, CF, CF, 32, 18)
 LKW_FM(20, R_W1, HC, KRP,        KRP, 64,  64,  19)
 LKW_FM(21, R_W2, CF, HC,         HC,  HC,  128, 20)
 constexpr int FRAGB_U4 = FM21_ENDB;         // uint4 units
-// Forward fragments once more as TWO fp16 pieces (lk_common.h::lk_mma3h, the forward kernels): block = [piece 0..1][lane]
-// uint4 = 2 KiB, same (G, nb) order; they follow the bf16 blob in the fragment buffer.
+// Both forms once more as TWO fp16 pieces (lk_common.h::lk_mma3h: the forward kernels, and the mapper's backward whose
+// loss gradients have unit scale): block = [piece 0..1][lane] uint4 = 2 KiB, same block order; they follow the bf16 blob.
 constexpr int FRAGH_U4 = FM21_ENDH;
 constexpr int N_FRAG_MATS = 22;
+// transposed-form offsets by matrix index (bf16 pieces / fp16 pieces), for code templated on the piece type
+constexpr int FRAG_TRB[N_FRAG_MATS] = {FM0_TRB, FM1_TRB, FM2_TRB, FM3_TRB, FM4_TRB, FM5_TRB, FM6_TRB, FM7_TRB, FM8_TRB, FM9_TRB, FM10_TRB,
+                                       FM11_TRB, FM12_TRB, FM13_TRB, FM14_TRB, FM15_TRB, FM16_TRB, FM17_TRB, FM18_TRB, FM19_TRB, FM20_TRB, FM21_TRB};
+constexpr int FRAG_TRH[N_FRAG_MATS] = {FM0_TRH, FM1_TRH, FM2_TRH, FM3_TRH, FM4_TRH, FM5_TRH, FM6_TRH, FM7_TRH, FM8_TRH, FM9_TRH, FM10_TRH,
+                                       FM11_TRH, FM12_TRH, FM13_TRH, FM14_TRH, FM15_TRH, FM16_TRH, FM17_TRH, FM18_TRH, FM19_TRH, FM20_TRH, FM21_TRH};
 
-#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWDB, FM##idx##_TRB, FM##idx##_FWDH}
+#define LKW_FM_ROW(idx, plain_, rows_, ld_, ereal_, evirt_, kv_) {plain_, rows_, ld_, ereal_, evirt_, kv_, FM##idx##_FWDB, FM##idx##_TRB, FM##idx##_FWDH, FM##idx##_TRH}
 #define LKW_FRAG_TABLE                                                                 \
     LKW_FM_ROW(0,  G_W0, HG, EGP,        EGP, EGP, 96),                                \
     LKW_FM_ROW(1,  G_W1, HG, HG,         HG,  HG,  32),                                \

@@ -50,7 +50,7 @@ __device__ void repack_split_unit(const float* __restrict__ plain, u32x4* __rest
     q[0] = s.p[0]; q[64] = s.p[1]; q[128] = s.p[2];
 }
 
-// the forward form once more as two fp16 pieces: unit u = (matrix, G, nb, lane)
+// both forms once more as two fp16 pieces: unit u = (matrix form, G, blk, lane)
 __device__ void repack_half_unit(const float* __restrict__ plain, u32x4* __restrict__ fragh, const FragTable& tb, int u) {
     const int blk_all = u >> 6, lane = u & 63;
     const int o4 = blk_all * 128;
@@ -59,19 +59,34 @@ __device__ void repack_half_unit(const float* __restrict__ plain, u32x4* __restr
     for (int q = 1; q < N_FRAG_MATS; ++q) mi = (o4 >= tb.m[q].fwdh) ? q : mi;
     const FragMat M = tb.m[mi];
     const int h = lane >> 5, j = lane & 31;
-    const int blk = (o4 - M.fwdh) / 128;
-    const int NBT = M.rows >> 5;
-    const int G = blk / NBT, nb = blk - G * NBT;
-    const int ksplit = M.e_real < M.ld ? M.e_real : M.ld;
-    const int GE = kb16(ksplit);
-    const int kbase = G < GE ? 16 * G : ksplit + 16 * (G - GE);
-    const int kend = G < GE ? ksplit : M.ld;
-    const int row = nb * 32 + j;
     float v[8];
+    if (o4 < M.trh) {
+        const int blk = (o4 - M.fwdh) / 128;
+        const int NBT = M.rows >> 5;
+        const int G = blk / NBT, nb = blk - G * NBT;
+        const int ksplit = M.e_real < M.ld ? M.e_real : M.ld;
+        const int GE = kb16(ksplit);
+        const int kbase = G < GE ? 16 * G : ksplit + 16 * (G - GE);
+        const int kend = G < GE ? ksplit : M.ld;
+        const int row = nb * 32 + j;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int col = kbase + (i < 4 ? 4 * h + i : 8 + 4 * h + (i - 4));
-        v[i] = col < kend ? plain[M.plain + row * M.ld + col] : 0.0f;
+        for (int i = 0; i < 8; ++i) {
+            const int col = kbase + (i < 4 ? 4 * h + i : 8 + 4 * h + (i - 4));
+            v[i] = col < kend ? plain[M.plain + row * M.ld + col] : 0.0f;
+        }
+    } else {
+        const int blk = (o4 - M.trh) / 128;
+        const int KB = M.kv >> 5;
+        const int G = blk / KB, kb = blk - G * KB;
+        const int vc = kb * 32 + j;
+        int col = -1;
+        if (vc < M.e_real) col = vc;
+        else if (vc >= M.e_virt) col = vc - (M.e_virt - M.e_real);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = 16 * G + (i < 4 ? 4 * h + i : 8 + 4 * h + (i - 4));
+            v[i] = (col >= 0 && col < M.ld) ? plain[M.plain + n * M.ld + col] : 0.0f;
+        }
     }
     const LkH8 s = lk_split8h(v);
     u32x4* __restrict__ q = fragh + o4 + lane;

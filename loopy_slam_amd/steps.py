@@ -142,7 +142,8 @@ class MapOptimizer:
         # without exposure encoding the mapper loss (Mapper.py:691-720) is evaluated inside the composite kernel
         fused = None if xs is not None else (b.gt_color, self.w_color, b.d_depth, b.d_color, out4)
         core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
-                            self.dec, stage, r2_ray=b.r2_ray, save_act=True, extra_flags=_ffi.FLAG_ZERO_ABSENT,
+                            self.dec, stage, r2_ray=b.r2_ray, save_act=True,
+                            extra_flags=_ffi.FLAG_ZERO_ABSENT | _ffi.FLAG_UNIT_LOSS_GRADS,      # L1 sums: |d depth|, |d colour| <= 1
                             color_logits=self.exposure is not None, mapper_loss=fused)
         if xs is not None:
             # the renderer returned colour LOGITS; the rays of keyframe f get sigmoid(logits @ rot_f + trans_f)

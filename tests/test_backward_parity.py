@@ -17,7 +17,7 @@ torch.set_num_threads(1)
 TOL = 2e-4
 
 
-def setup(eng, name, g, stage, tracker=False, affine=None, color_logits=False):
+def setup(eng, name, g, stage, tracker=False, affine=None, color_logits=False, extra_flags=0):
     cfg = rcfg(name)
     W = weights(name)
     dec = core.DecoderBlob(eng).pack(W)
@@ -30,18 +30,22 @@ def setup(eng, name, g, stage, tracker=False, affine=None, color_logits=False):
     nc = eng.f32(g['noise_col']) if 'noise_col' in g else None
     aff = eng.f32(affine) if affine is not None else None
     core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, dec, stage, tracker=tracker, r2_ray=r2,
-                        noise_geo=ng, noise_col=nc, affine=aff, color_logits=color_logits, save_act=True)
+                        noise_geo=ng, noise_col=nc, affine=aff, color_logits=color_logits, save_act=True, extra_flags=extra_flags)
     return cfg, dec, st, pos.shape[0], ro.shape[0]
 
 
 @pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('unit', (False, True))
 @pytest.mark.parametrize('stage', ('geometry', 'color'))
 @pytest.mark.parametrize('name', CFG_NAMES)
-def test_backward_mapper_golden(backend, name, stage):
+def test_backward_mapper_golden(backend, name, stage, unit):
+    """unit: LK_FLAG_UNIT_LOSS_GRADS as the mapper sets it (its L1 loss gradients are +-1 / +-w): the colour decoder's
+    backward then runs on pre-scaled fp16 pieces instead of bf16 pieces - same goldens, same tolerance."""
+    from loopy_slam_amd import _ffi
     eng = make_engine(backend)
     g = load(f'g6_render_{name}_map_{stage}')
     expo = CFG[name]['exposure']
-    cfg, dec, st, N, R = setup(eng, name, g, stage, color_logits=expo)
+    cfg, dec, st, N, R = setup(eng, name, g, stage, color_logits=expo, extra_flags=_ffi.FLAG_UNIT_LOSS_GRADS if unit else 0)
     # host-side loss gradient on the kernel outputs (Mapper.py:691-720)
     depth = st.depth.cpu().clone().requires_grad_(True)
     color = st.color.cpu().clone().requires_grad_(True)

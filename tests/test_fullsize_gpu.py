@@ -132,9 +132,10 @@ def test_frustum_rows_and_insertion_at_five_million_points():
     assert acc.numel() == 50_000 and pts.shape == (150_000, 3) and torch.equal(acc.cpu(), torch.arange(50_000, dtype=torch.int32))
 
 
+@pytest.mark.parametrize('unit', (False, True))
 @pytest.mark.parametrize('rel_pos', (True, False))
 @pytest.mark.parametrize('R', (3000, 5000, 10000, 40000))
-def test_render_is_deterministic_at_scale(R, rel_pos):
+def test_render_is_deterministic_at_scale(R, rel_pos, unit):
     """The same forward (saved activations) and the same backward twice give the same bits in every buffer that does not
     go through float atomics.  Catches what small parity cases cannot: intra-workgroup races and instruction-level
     hazards that only show with several workgroups per compute unit (a split-bf16 backward once passed every parity
@@ -151,9 +152,14 @@ def test_render_is_deterministic_at_scale(R, rel_pos):
     gd = depth[j.long(), i.long()].contiguous()
     st = core.RenderState(eng, R, cfg.S, need_act=True)
     d1, c1 = torch.randn(R, generator=g).cuda(), torch.randn(R, 3, generator=g).cuda()
+    xf = 0
+    if unit:        # the mapper's situation: unit-scale loss gradients, colour backward on pre-scaled fp16 pieces
+        from loopy_slam_amd import _ffi
+        xf = _ffi.FLAG_UNIT_LOSS_GRADS
+        d1, c1 = torch.sign(d1), 0.1 * torch.sign(c1)
     runs = []
     for rep in range(3):
-        core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, 'color', save_act=True)
+        core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo, col, blob, 'color', save_act=True, extra_flags=xf)
         gs = core.GradState(eng, pos.shape[0], R, blob.n, feats=True, weights=True)
         core.render_backward(eng, st, gs, d1, c1)
         torch.cuda.synchronize()
