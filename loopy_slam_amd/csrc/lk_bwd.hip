@@ -113,6 +113,9 @@ __device__ __forceinline__ BwdSample bwd_sample(const LkDecodeBwdArgs& a, int ti
 // (LK_FLAG_UNIT_LOSS_GRADS, mapper mode): the whole chain d h_4 .. d h_0 is linear in d out, so d out is multiplied by 2^10
 // once (median |d h| 1.5e-4 -> 0.15: both fp16 pieces normal numbers), everything in between is scaled with it, and the
 // stored d h rows / d c are scaled back where they are written (in the copy resp. the final sum: no extra instruction).
+#ifndef LK_DH_STORE_MODE
+#define LK_DH_STORE_MODE 1          // product: see the STORE-DATA RULE below; other values are hazard experiments
+#endif
 template <bool H16> struct BwdPiece;
 template <> struct BwdPiece<false> {
     typedef LkB8 T;
@@ -250,9 +253,29 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         // the tiles once two workgroups shared a compute unit (the scattered 16-byte row stores queue up in the memory
         // pipe).  The store therefore reads a copy that stays allocated until the end of the layer.
         f32x16 dhc;
+#if LK_DH_STORE_MODE == 1
 #pragma unroll
         for (int q = 0; q < 16; ++q) { float t = H16 ? dh[q] * ISC : dh[q]; asm volatile("" : "+v"(t)); dhc[q] = t; }
         if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dhc, live, lane);
+#else       // hazard experiments (tools/probe/dh_store_insitu.py): the store reads the live accumulators
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dhc[q] = H16 ? dh[q] * ISC : dh[q];
+#if LK_DH_STORE_MODE == 3
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dhc, live, lane);
+#if LK_DH_STORE_MODE == 2
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#elif LK_DH_STORE_MODE == 4
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
 #pragma unroll
         for (int G = 0; G < 2; ++G) dc = PC::mma(un[G], PC::split(dh, G), dc);
 #pragma unroll
@@ -284,8 +307,10 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
                 for (int G = 0; G < 8; ++G) de = PC::mma(PC::load(FB + PC::tr(10), 2, G, w - 2, lane), lds_b(xs, G), de);
             }
         }
+#if LK_DH_STORE_MODE == 1
 #pragma unroll
         for (int q = 0; q < 16; ++q) asm volatile("" :: "v"(dhc[q]));
+#endif
     }
     // d c: park the per-wave partials, wave w sums register chunk w of all four -> one float4 per lane
     {

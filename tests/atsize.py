@@ -1,0 +1,123 @@
+"""Scenarios and oracle evaluation for the parity tests at the BENCHMARKED sizes (tests/test_parity_at_size.py):
+5 000 / 10 000-ray mapping batches and 1 500 / 5 000-ray tracking batches over a 100 000-point cloud (bench.py's
+workload), forward spot checks at 2 M and 5 M points.  The oracle (oracle/hotpath.py, CPU autograd) finishes such a
+batch in seconds once the neighbour search is done by its KD-tree form (hotpath.knn_tree) - rows where the fp64 tree
+and the fp32 contract could order candidates differently are re-checked with the brute-force contract (knn_exact).
+
+Test infrastructure only."""
+import numpy as np
+import torch
+
+from oracle import hotpath as H
+from loopy_slam_amd import synthetic as syn
+
+I = syn.TUM_INTR
+INTR = (I['fx'], I['fy'], I['cx'], I['cy'])
+_SCENES = {}
+
+
+def scene(N, seed=1219):
+    """(pos, geo, col) CPU tensors of the synthetic room cloud, cached per size."""
+    if (N, seed) not in _SCENES:
+        _SCENES.clear()                     # one big cloud at a time (5 M points = 1.3 GB of features)
+        _SCENES[(N, seed)] = syn.build_cloud(N, device='cpu', seed=seed)
+    return _SCENES[(N, seed)]
+
+
+def ray_batch(R, frame=7, holes=0.0, seed=0, window=None):
+    """R random pixels of synthetic frame `frame`: dict(i, j, rays_o, rays_d, gt_depth, gt_color, c2w) on the CPU."""
+    depth, color, c2w = syn.render_frame(frame, device='cpu', holes=holes)
+    g = torch.Generator().manual_seed(seed * 7919 + R)
+    H0, H1, W0, W1 = window if window is not None else (0, I['H'], 0, I['W'])
+    i = torch.randint(W0, W1, (R,), generator=g).float()
+    j = torch.randint(H0, H1, (R,), generator=g).float()
+    ro, rd = syn.pixel_rays(c2w, i, j)
+    gd = depth[j.long(), i.long()].contiguous()
+    gc = color[j.long(), i.long()].contiguous()
+    return dict(i=i, j=j, rays_o=ro, rays_d=rd, gt_depth=gd, gt_color=gc, c2w=c2w)
+
+
+def ocfg(rel_pos):
+    return H.RenderCfg(S=5, near_surface=0.98, far_surface=1.02, near_end=0.3, coef=0.1, k=8, min_nn=2,
+                       radius_query=0.08, rel_pos=rel_pos)
+
+
+def contract_knn(pos, p, r2, got_idx=None):
+    """The kNN contract at size: KD-tree proposal re-ranked in fp32 (hotpath.knn_tree); where `got_idx` (the kernel's answer)
+    disagrees, the rows are recomputed with the brute-force statement of the contract (hotpath.knn_exact).
+    Returns (d2, idx, count, n_rechecked)."""
+    d2, idx, cnt = H.knn_tree(pos.numpy(), p.numpy(), 8, r2)
+    n_re = 0
+    if got_idx is not None:
+        bad = np.nonzero((np.asarray(got_idx) != idx).any(1))[0]
+        n_re = int(bad.size)
+        if n_re:
+            assert n_re <= 2000, f'{n_re} rows differ from the KD-tree answer: not a tie-break effect'
+            rr = r2 if np.ndim(r2) == 0 else np.asarray(r2)[bad]
+            ed, ei, ec = H.knn_exact(pos.numpy(), p.numpy()[bad], 8, rr)
+            d2[bad], idx[bad], cnt[bad] = ed, ei, ec
+    return d2, idx, cnt, n_re
+
+
+def oracle_mapper(rel_pos, stage, b, pos, geo, col, W, knn, w_color=0.1, grads=True):
+    """Oracle forward + mapper loss (+ autograd).  Returns dict(out=render dict, loss=(loss, geo, col, mask),
+    g_geo, g_col, gW{name: grad})."""
+    names = [k for k in W if k != 'color_decoder.embedder._B']
+    Wr = {k: v.clone().requires_grad_(grads and k in names) for k, v in W.items()}
+    geo_r, col_r = geo.clone().requires_grad_(grads), col.clone().requires_grad_(grads)
+    o = H.render_batch(ocfg(rel_pos), b['rays_o'], b['rays_d'], b['gt_depth'], pos, geo_r, col_r, Wr, stage, knn=knn)
+    loss = H.mapper_loss(o['depth'], o['color'], o['valid_ray'], b['gt_depth'], b['gt_color'], stage, w_color)
+    res = dict(out=o, loss=loss)
+    if grads:
+        loss[0].backward()
+        res['g_geo'] = geo_r.grad
+        res['g_col'] = col_r.grad if col_r.grad is not None else torch.zeros_like(col)
+        res['gW'] = {k: Wr[k].grad for k in names if Wr[k].grad is not None}
+    return res
+
+
+def oracle_tracker(rel_pos, b, cam, pos, geo, col, W, knn, w_color=0.5):
+    """Oracle tracking iteration: rays from the 7-vector pose, render in tracker mode, tracker loss, autograd to the pose
+    (and to the rays).  knn must be the list for these rays."""
+    cam_r = cam.clone().requires_grad_(True)
+    ro, rd = H.rays_from_uv(b['i'], b['j'], H.quat_to_c2w(cam_r), *INTR)
+    ro, rd = ro.contiguous(), rd.contiguous()
+    ro.retain_grad(); rd.retain_grad()
+    o = H.render_batch(ocfg(rel_pos), ro, rd, b['gt_depth'], pos, geo, col, W, 'color', tracker=True, knn=knn)
+    loss = H.tracker_loss(o['depth'], o['var'], o['color'], b['gt_depth'], b['gt_color'], w_color)
+    loss[0].backward()
+    return dict(out=o, loss=loss, g_cam=cam_r.grad, g_rays_o=ro.grad, g_rays_d=rd.grad, rays_o=ro.detach(), rays_d=rd.detach())
+
+
+def errs(a, b):
+    """(max-norm relative error, worst element-wise error relative to |b| + 1e-3 max|b|)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    scale = np.abs(b).max() + 1e-30
+    return float(np.abs(a - b).max() / scale), float((np.abs(a - b) / (np.abs(b) + 1e-3 * scale)).max())
+
+
+def geo_gate_margin(out, pos, geo, W, r2=None):
+    """min over the geometry decoder's ReLU units of |pre-activation|, per sample (decoder.py:274-288).  A sample whose
+    margin is at rounding level can take the other branch of a ReLU in ANY second fp32 implementation: its gradient
+    contribution then differs by a whole term, not by rounding.  The feature rows such samples touch are excluded from
+    the element-wise gradient comparison (and counted)."""
+    import torch.nn.functional as F
+    with torch.no_grad():
+        r2 = torch.tensor(np.float32(0.08 ** 2)) if r2 is None else r2
+        c, _ = H.interpolate(out['p'], pos, geo, out['idx'], out['d2'], r2, out['count'], 2, torch.zeros(geo.shape[1]), False)
+        e = H.fourier(out['p'], W['geo_decoder.embedder._B'], concat=False)
+        h, margin = e, torch.full((e.shape[0],), float('inf'))
+        for i in range(5):
+            pre = F.linear(h, W[f'geo_decoder.pts_linears.{i}.weight'], W[f'geo_decoder.pts_linears.{i}.bias'])
+            margin = torch.minimum(margin, pre.abs().min(dim=1).values)
+            h = F.relu(pre) + F.linear(c, W[f'geo_decoder.fc_c.{i}.weight'], W[f'geo_decoder.fc_c.{i}.bias'])
+            if i == 2:
+                h = torch.cat([e, h], -1)
+    return margin
+
+
+def rows_of_samples(out, sample_mask):
+    """Cloud rows (neighbours) of the flagged samples."""
+    idx = out['idx'][sample_mask]
+    return torch.unique(idx[idx >= 0].long())
