@@ -281,6 +281,80 @@ int lk_top_grad_pixels(const float* grad_mag, int32_t H, int32_t W, int32_t K, i
 int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* depth_filtered, float* out_thr,
                    uint32_t* scratch, void* stream);
 
+/* ---------------------------------------------------------------- per-frame optimisation loops
+ * The launch sequences of the reference's two inner loops as ONE call each, so that the host enqueues a frame's work in
+ * microseconds instead of interpreting ~20 Python statements per iteration (at 1 500-ray tracking batches the Python loop
+ * was slower than the GPU).  Static shapes, no host synchronisation inside; every buffer is the caller's.
+ *
+ * lk_track_frame: Tracker.run's loop body for one frame (src/Tracker.py:313-401) = iters x { pixel gather + rays of the
+ * current pose + inside mask (Tracker.py:142-160), lk_render_fwd in tracker mode, tracker loss (Tracker.py:169-191),
+ * lk_render_bwd w.r.t. the rays, pose gradient, Adam on (T | quaternion) (Tracker.py:317-352) }.  For R <= 8192 the small
+ * steps run as three one-workgroup kernels (batch assembly; composite + loss + composite backward; ray / pose gradient +
+ * Adam) - 9 launches per iteration instead of 16.
+ * render: R, S, the map (knn, pos, tables, weights), scalars, and ALL per-call buffers of lk_render_fwd / lk_render_bwd
+ * (rays_o, rays_d, gt_depth, r2_ray or NULL, outputs, state, act, d_depth, d_color, g_rays_o, g_rays_d, bwd_scratch sized
+ * for flags | TRACKER | STAGE_COLOR | SAVE_ACT | GRAD_RAYS | ZERO_ABSENT); render.flags carries LK_FLAG_REL_POS only. */
+typedef struct {
+    lk_render_desc render;
+    const float* depth_img;     /* [H,W]   */
+    const float* color_img;     /* [H,W,3] */
+    const float* r2_map;        /* [H,W] squared dynamic query radius per pixel, or NULL */
+    int32_t H, W, H0, W0, w;    /* draw q of rnd -> pixel (row H0 + q / w, column W0 + q % w) */
+    float fx, fy, cx, cy;
+    const int32_t* rnd;         /* [iters][R] pixel draws (window pixels, or flat image indices with H0 = W0 = 0, w = W) */
+    float* gt_color;            /* [R,3] */
+    float* pix_i; float* pix_j; /* [R]   */
+    float* thr;                 /* [1]   */
+    uint32_t* scratch_u32;      /* [R]   */
+    float* loss_scratch;        /* [R+8] */
+    float* cam7;                /* [7] in: initial pose (qw,qx,qy,qz,tx,ty,tz); out: pose after the last iteration */
+    float* g_cam7;              /* [7] */
+    float* adam_mv;             /* [14] exp_avg | exp_avg_sq of the pose; zeroed by the call (fresh optimiser per frame) */
+    float lr_T, lr_q;           /* separate_LR: cam_lr and 0.2 cam_lr (Tracker.py:317-333); otherwise both cam_lr */
+    float w_color; int32_t use_color;
+    int32_t hist_post;          /* 0: hist[it] = pose BEFORE iteration it (separate_LR: the candidate is a detached copy);
+                                   1: pose AFTER its update (one leaf tensor stepped in place, Tracker.py:375-377) */
+    float* hist;                /* [iters][7] candidate poses */
+    float* log;                 /* [iters][4] loss, geo, colour, #masked rays per iteration */
+    int32_t iters;
+} lk_track_desc;
+int lk_track_frame(const lk_track_desc* d, void* stream);
+
+/* lk_map_frame: the joint iterations [it_begin, it_end) of one Mapper.optimize_map call (src/Mapper.py:576-735, no exposure
+ * encoding) = per iteration { multi-keyframe ray gather, inside mask, lk_render_fwd with the fused mapper loss, lk_render_bwd,
+ * Adam over {decoder spans, geometry rows, colour rows}, fragment repack in stage 'color' }.  Iteration it runs stage
+ * 'geometry' iff it < n_geo_iters.  phases: 1 = forward/backward only, 2 = optimiser step only, 3 = both (a ray-sharded
+ * multi-GPU caller all-reduces the gradients between phase 1 and phase 2 of every iteration).
+ * render: as for lk_track_frame (flags: LK_FLAG_REL_POS, + LK_FLAG_UNIT_LOSS_GRADS if wanted; g_geo_feats, g_col_feats,
+ * g_weights, grad_row_mask, bwd_scratch sized for STAGE_COLOR | SAVE_ACT | GRAD_FEATS | GRAD_WEIGHTS). */
+#define LK_MAX_SPANS 8
+typedef struct { int64_t offset, n; } lk_blob_span;       /* floats [offset, offset + n) of the weight blob */
+typedef struct {
+    lk_render_desc render;
+    const float* depth_stack; const float* color_stack; const float* c2w_stack; int32_t c2w_stride;
+    const float* r2_map_stack;  /* or NULL */
+    const int32_t* frame_id;    /* [R] keyframe of every ray */
+    const int32_t* rnd;         /* [iters][R] */
+    int32_t H, W, H0, W0, w;
+    float fx, fy, cx, cy;
+    float* gt_color; float* thr; uint32_t* scratch_u32;
+    float w_color;
+    float* log;                 /* [iters][4] */
+    /* optimiser (a fresh Adam per optimize_map call, Mapper.py:570: the caller zeroes the state buffers) */
+    float* weights_rw;          /* = render.weights, writable */
+    float* weights_frag_rw;     /* = render.weights_frag, writable */
+    float* geo_feats_rw; float* col_feats_rw;     /* = render.geo_feats / col_feats, writable */
+    const int32_t* rows;        /* [n_rows] rows being optimised, or NULL = all N rows (then n_rows = N) */
+    int64_t n_rows;
+    float* adam_rows;           /* [4][n_rows*32]: exp_avg, exp_avg_sq of the geometry rows, then of the colour rows */
+    lk_blob_span geo_dec[LK_MAX_SPANS]; int32_t n_geo_dec;   /* decoder spans stepped in both stages (embedder._B) */
+    lk_blob_span col_dec[LK_MAX_SPANS]; int32_t n_col_dec;   /* decoder spans stepped in stage 'color' */
+    float* adam_dec;            /* [2][lk_weight_blob_floats()]: exp_avg | exp_avg_sq, blob-shaped */
+    float lr[2][3];             /* [stage: geometry, colour][decoders, geometry rows, colour rows] (configs mapping.stage.*) */
+    int32_t iters, n_geo_iters;
+} lk_map_desc;
+int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t phases, void* stream);
+
 /* ---------------------------------------------------------------- weight-gradient building block
  * dW[n][k] += sum_rows A'[row][n] * B[row][k], db[n] += sum_rows A'[row][n] (db may be NULL); row-major operands.
  * a_mode 0: A' = A;  1: A' = A * softplus100'(A2) with A2 the activation OUTPUT;  2: A' = A2[row] * A[row>>3]

@@ -66,6 +66,47 @@ class CopySeg(C.Structure):
     _fields_ = [('data', _fp), ('n', C.c_int64), ('row_index', _fp), ('row_len', C.c_int32)]
 
 
+MAX_SPANS = 8
+
+
+class BlobSpan(C.Structure):
+    _fields_ = [('offset', C.c_int64), ('n', C.c_int64)]
+
+
+class TrackDesc(C.Structure):
+    """lk_track_desc (include/loopy_hip.h)."""
+    _fields_ = [
+        ('render', RenderDesc),
+        ('depth_img', _fp), ('color_img', _fp), ('r2_map', _fp),
+        ('H', C.c_int32), ('W', C.c_int32), ('H0', C.c_int32), ('W0', C.c_int32), ('w', C.c_int32),
+        ('fx', C.c_float), ('fy', C.c_float), ('cx', C.c_float), ('cy', C.c_float),
+        ('rnd', _fp), ('gt_color', _fp), ('pix_i', _fp), ('pix_j', _fp), ('thr', _fp), ('scratch_u32', _fp), ('loss_scratch', _fp),
+        ('cam7', _fp), ('g_cam7', _fp), ('adam_mv', _fp),
+        ('lr_T', C.c_float), ('lr_q', C.c_float), ('w_color', C.c_float), ('use_color', C.c_int32), ('hist_post', C.c_int32),
+        ('hist', _fp), ('log', _fp), ('iters', C.c_int32),
+    ]
+
+
+class MapDesc(C.Structure):
+    """lk_map_desc (include/loopy_hip.h)."""
+    _fields_ = [
+        ('render', RenderDesc),
+        ('depth_stack', _fp), ('color_stack', _fp), ('c2w_stack', _fp), ('c2w_stride', C.c_int32), ('r2_map_stack', _fp),
+        ('frame_id', _fp), ('rnd', _fp),
+        ('H', C.c_int32), ('W', C.c_int32), ('H0', C.c_int32), ('W0', C.c_int32), ('w', C.c_int32),
+        ('fx', C.c_float), ('fy', C.c_float), ('cx', C.c_float), ('cy', C.c_float),
+        ('gt_color', _fp), ('thr', _fp), ('scratch_u32', _fp),
+        ('w_color', C.c_float), ('log', _fp),
+        ('weights_rw', _fp), ('weights_frag_rw', _fp), ('geo_feats_rw', _fp), ('col_feats_rw', _fp),
+        ('rows', _fp), ('n_rows', C.c_int64), ('adam_rows', _fp),
+        ('geo_dec', BlobSpan * MAX_SPANS), ('n_geo_dec', C.c_int32),
+        ('col_dec', BlobSpan * MAX_SPANS), ('n_col_dec', C.c_int32),
+        ('adam_dec', _fp),
+        ('lr', (C.c_float * 3) * 2),
+        ('iters', C.c_int32), ('n_geo_iters', C.c_int32),
+    ]
+
+
 class LoopyError(RuntimeError):
     pass
 
@@ -125,6 +166,8 @@ class LoopyLib:
             ('lk_profile_begin', [C.c_char_p], C.c_int),
             ('lk_profile_end', [C.c_char_p, C.c_int], C.c_int),
             ('lk_compact', [_fp, C.c_int32, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_track_frame', [C.POINTER(TrackDesc), C.c_void_p], C.c_int),
+            ('lk_map_frame', [C.POINTER(MapDesc), C.c_int32, C.c_int32, C.c_int32, C.c_void_p], C.c_int),
             ('lk_inside_mask', [_fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
         ):
             if hasattr(d, name):

@@ -17,10 +17,14 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'libloopyhip.so')
 OBJ = os.path.join(HERE, '_obj')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-# -fno-slp-vectorize: packed fp32 VALU instructions (v_pk_fma_f32 ...) take two issue slots and sit badly beside matrix
-# instructions; the SLP vectoriser creates hundreds of them in the decoder kernels (measured: 0.8 % of the step)
+# NO PACKED FP32 (target feature packed-fp32-ops off, and no SLP vectoriser to ask for it): with v_pk_{mul,add,fma}_f32 in
+# k_decode_bwd one register of the wave came out wrong in lanes 48-63 in 1-2 % of the tiles as soon as two workgroups shared a
+# compute unit; the SAME instruction stream with every packed instruction rewritten into its two scalar halves is clean
+# (DESIGN.md §3 "packed fp32", tools/probe/make_hist_variants.sh).  tests/test_product_hygiene.py disassembles the library
+# and fails if a packed fp32 instruction is in it.  (They also take two issue slots beside the matrix instructions: 0.8 % of
+# the step.)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-ffp-contract=off', '-fno-slp-vectorize']
+         '-ffp-contract=off', '-fno-slp-vectorize', '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
 def _newer(src_list, target):

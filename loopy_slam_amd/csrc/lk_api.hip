@@ -94,6 +94,36 @@ extern "C" int64_t lk_render_act_floats(int32_t R, int32_t S, uint32_t flags) {
     return (int64_t)R * S * LK_ACT_FLOATS_PER_SAMPLE;
 }
 
+// ------------------------------------------------------------------ backward scratch layout
+namespace {
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, wg_part, total; };
+BwdLayout bwd_layout(int64_t P, uint32_t flags) {
+    BwdLayout L;
+    int64_t o = 0;
+    L.d_raw = o; o += 4 * P;
+    L.dc_geo = o; o += 32 * P;
+    L.dc_col = o; o += 32 * P;
+    L.dp_embed = o; o += 4 * P;
+    L.dp_embed_col = o; o += 4 * P;
+    L.dp_rel = o; o += 4 * P;
+    L.dp_total = o; o += 4 * P;
+    L.dw_rel = o; o += 8 * P;
+    L.w_eff = o; o += 8 * P;
+    L.dlogit = o; o += 4 * P;
+    L.part_bg = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 32), 4) * 288;
+    L.part_br = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 4), 4) * 32;
+    const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    L.hbar = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 128 * P;
+    L.dfeat = o; if (color && (flags & LK_FLAG_REL_POS) && (flags & LK_FLAG_GRAD_FEATS)) o += 8 * 32 * P;
+    L.w_sum = o; o += P;
+    L.dh_col = o; if (color && gw) o += 640 * P;
+    L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 192 * P;
+    L.wg_part = o; if (color && gw) o += lk_wgrad_part_floats(P, (flags & LK_FLAG_REL_POS) != 0);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
 // ------------------------------------------------------------------ render forward
 static int check_desc(const lk_render_desc* d, const char* who) {
     if (!d) { lk_set_error("%s: NULL descriptor", who); return LK_ERR_ARG; }
@@ -114,12 +144,13 @@ static int check_desc(const lk_render_desc* d, const char* who) {
     return LK_OK;
 }
 
-extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
+extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
+
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
     int rc = check_desc(d, "lk_render_fwd");
     if (rc != LK_OK) return rc;
     if (d->R == 0) return LK_OK;
     LK_REQUIRE(d->depth && d->var && d->color && d->valid_ray, "lk_render_fwd: NULL output buffer");
-    hipStream_t st = (hipStream_t)stream_;
     const int P = d->R * d->S;
     const bool all_pos = (d->flags & (LK_FLAG_ALL_DEPTH_POS | LK_FLAG_ZERO_ABSENT)) != 0;
     if (!all_pos) {
@@ -154,14 +185,19 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
     da.raw = d->raw; da.act = d->act;
     lk_launch_decode_fwd(da, st);
 
+    if (skip & LK_SKIP_COMPOSITE) { LK_LAUNCH_CHECK(); return LK_OK; }     // the caller composites (fused loss kernel, lk_loop.hip)
     LkCompositeArgs ca;
     ca.R = d->R; ca.S = d->S; ca.min_nn = d->min_nn; ca.coef = d->coef;
     ca.raw = d->raw; ca.z = d->z; ca.nbr_count = d->nbr_count; ca.gt_depth = d->gt_depth;
     ca.depth = d->depth; ca.var = d->var; ca.color = d->color; ca.valid_ray = d->valid_ray;
-    ca.gt_color = nullptr; ca.w_color = 0.0f; ca.use_color = 0; ca.d_depth = nullptr; ca.d_color = nullptr; ca.loss_out = nullptr;
+    ca.gt_color = nullptr; ca.w_color = 0.0f; ca.use_color = 0; ca.d_depth = nullptr; ca.d_color = nullptr; ca.loss_out = nullptr; ca.d_raw = nullptr;
     if (d->flags & LK_FLAG_MAPPER_LOSS) {
         LK_REQUIRE(d->loss_out4 && d->d_depth && d->d_color && d->loss_gt_color, "lk_render_fwd: MAPPER_LOSS needs loss_gt_color, loss_out4, d_depth, d_color");
-        LK_HIP_TRY(hipMemsetAsync(d->loss_out4, 0, 4 * sizeof(float), st));
+        if (!(skip & LK_LOSS_PREZEROED)) LK_HIP_TRY(hipMemsetAsync(d->loss_out4, 0, 4 * sizeof(float), st));
+        if (skip & LK_FUSE_COMPOSITE_BWD) {       // the loss gradient is final: d raw right away (one launch less per iteration)
+            LK_REQUIRE(d->bwd_scratch != nullptr, "lk_render_fwd: fused composite backward needs bwd_scratch");
+            ca.d_raw = d->bwd_scratch + bwd_layout((int64_t)P, d->flags).d_raw;
+        }
         ca.gt_color = d->loss_gt_color; ca.w_color = d->loss_w_color; ca.use_color = (d->flags & LK_FLAG_STAGE_COLOR) ? 1 : 0;
         ca.d_depth = const_cast<float*>(d->d_depth); ca.d_color = const_cast<float*>(d->d_color); ca.loss_out = d->loss_out4;
     }
@@ -171,34 +207,6 @@ extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
 }
 
 // ------------------------------------------------------------------ render backward
-namespace {
-struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, wg_part, total; };
-BwdLayout bwd_layout(int64_t P, uint32_t flags) {
-    BwdLayout L;
-    int64_t o = 0;
-    L.d_raw = o; o += 4 * P;
-    L.dc_geo = o; o += 32 * P;
-    L.dc_col = o; o += 32 * P;
-    L.dp_embed = o; o += 4 * P;
-    L.dp_embed_col = o; o += 4 * P;
-    L.dp_rel = o; o += 4 * P;
-    L.dp_total = o; o += 4 * P;
-    L.dw_rel = o; o += 8 * P;
-    L.w_eff = o; o += 8 * P;
-    L.dlogit = o; o += 4 * P;
-    L.part_bg = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 32), 4) * 288;
-    L.part_br = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 4), 4) * 32;
-    const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0;
-    L.hbar = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 128 * P;
-    L.dfeat = o; if (color && (flags & LK_FLAG_REL_POS) && (flags & LK_FLAG_GRAD_FEATS)) o += 8 * 32 * P;
-    L.w_sum = o; o += P;
-    L.dh_col = o; if (color && gw) o += 640 * P;
-    L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 192 * P;
-    L.wg_part = o; if (color && gw) o += lk_wgrad_part_floats(P, (flags & LK_FLAG_REL_POS) != 0);
-    L.total = o;
-    return L;
-}
-}  // namespace
 
 
 extern "C" int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t flags) {
@@ -223,7 +231,16 @@ SideStream& side_stream() {
 }
 }  // namespace
 
-extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
+extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) { return lk_render_bwd_impl(d, (hipStream_t)stream_, 0); }
+
+LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags) {
+    const BwdLayout L = bwd_layout(P, flags);
+    LkBwdOffsets o;
+    o.d_raw = L.d_raw; o.dp_total = L.dp_total;
+    return o;
+}
+
+int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
     int rc = check_desc(d, "lk_render_bwd");
     if (rc != LK_OK) return rc;
     if (d->R == 0) return LK_OK;
@@ -236,7 +253,6 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     LK_REQUIRE(!gw || d->g_weights, "lk_render_bwd: GRAD_WEIGHTS needs g_weights");
     LK_REQUIRE(!gr || (d->g_rays_o && d->g_rays_d && d->pos), "lk_render_bwd: GRAD_RAYS needs g_rays_o/g_rays_d/pos");
     LK_REQUIRE(!color || d->d_color, "lk_render_bwd: colour stage needs d_color");
-    hipStream_t st = (hipStream_t)stream_;
     const int P = d->R * d->S;
     const BwdLayout L = bwd_layout(P, flags);
     float* S0 = d->bwd_scratch;
@@ -246,7 +262,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
     cb.raw = d->raw; cb.z = d->z; cb.nbr_count = d->nbr_count; cb.gt_depth = d->gt_depth;
     cb.d_depth = d->d_depth; cb.d_var = d->d_var; cb.d_color = color ? d->d_color : nullptr;
     cb.d_raw = S0 + L.d_raw;
-    lk_launch_composite_bwd(cb, st);
+    if (!(skip & LK_SKIP_COMPOSITE_BWD)) lk_launch_composite_bwd(cb, st);
 
     LkDecodeBwdArgs db;
     db.R = d->R; db.S = d->S; db.P = P; db.flags = flags;
@@ -337,7 +353,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
         ib.g_geo_feats = d->g_geo_feats; ib.g_col_feats = d->g_col_feats; ib.dp_total = S0 + L.dp_total;
         lk_launch_interp_bwd(ib, st);
     }
-    if (gr) {
+    if (gr && !(skip & LK_SKIP_RAYS_BWD)) {
         LkRaysBwdArgs rr;
         rr.R = d->R; rr.S = d->S; rr.z = d->z; rr.dp_total = S0 + L.dp_total; rr.g_rays_o = d->g_rays_o; rr.g_rays_d = d->g_rays_d;
         lk_launch_rays_bwd(rr, st);

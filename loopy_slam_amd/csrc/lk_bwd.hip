@@ -5,6 +5,7 @@
 // weight fragments: dX^T = W^T dY^T, the dY CT tile being the B operand.
 #include "lk_common.h"
 #include "lk_kernels.h"
+#include "lk_composite_dev.h"
 
 using namespace lkw;
 
@@ -12,54 +13,9 @@ using namespace lkw;
 __global__ __launch_bounds__(256) void k_composite_bwd(LkCompositeBwdArgs a) {
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
     if (r >= a.R) return;
-    float al[LK_S_MAX], be[LK_S_MAX], Tt[LK_S_MAX], wv[LK_S_MAX], zv[LK_S_MAX], cr[LK_S_MAX], cg[LK_S_MAX], cb[LK_S_MAX];
-    float T = 1.0f, wsum = 0.0f, dsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-#pragma unroll
-    for (int s = 0; s < LK_S_MAX; ++s) {
-        al[s] = be[s] = Tt[s] = wv[s] = zv[s] = cr[s] = cg[s] = cb[s] = 0.0f;
-        if (s < a.S) {
-            const int p = r * a.S + s;
-            const float4 raw = *reinterpret_cast<const float4*>(a.raw + (size_t)p * 4);
-            const bool has = a.nbr_count[p] >= a.min_nn;
-            const float occ = has ? raw.w : -100.0f;
-            const float alpha = lk_sigmoid(a.coef * occ);
-            al[s] = alpha; Tt[s] = T; be[s] = 1.0f - alpha + 1e-10f;
-            const float w = alpha * T;
-            T *= be[s];
-            wv[s] = w; zv[s] = a.z[p];
-            cr[s] = raw.x; cg[s] = raw.y; cb[s] = raw.z;
-            wsum += w; dsum += w * zv[s];
-            c0 += w * raw.x; c1 += w * raw.y; c2 += w * raw.z;
-        }
-    }
-    const float W = wsum + 1e-10f;
-    const float depth = dsum / W;
-    const float col0 = c0 / W, col1 = c1 / W, col2 = c2 / W;
-    const float gvar = a.d_var ? a.d_var[r] : 0.0f;
-    float gdep = (a.gt_depth[r] > 0.0f) ? a.d_depth[r] : 0.0f;          // depth of zero-depth rays is overwritten
-    float dvar_ddepth = 0.0f;
-#pragma unroll
-    for (int s = 0; s < LK_S_MAX; ++s) dvar_ddepth += -2.0f * wv[s] * (zv[s] - depth);
-    gdep += gvar * dvar_ddepth;
-    const float g0 = a.d_color ? a.d_color[3 * r] : 0.0f, g1 = a.d_color ? a.d_color[3 * r + 1] : 0.0f,
-                g2 = a.d_color ? a.d_color[3 * r + 2] : 0.0f;
-    float gw[LK_S_MAX];
-#pragma unroll
-    for (int s = 0; s < LK_S_MAX; ++s) {
-        const float dz = zv[s] - depth;
-        gw[s] = (gdep * dz + g0 * (cr[s] - col0) + g1 * (cg[s] - col1) + g2 * (cb[s] - col2)) / W + gvar * dz * dz;
-    }
-    float suffix = 0.0f;                                                // sum_{u>s} gw_u w_u
-#pragma unroll
-    for (int s = LK_S_MAX - 1; s >= 0; --s) {
-        if (s < a.S) {
-            const float galpha = gw[s] * Tt[s] - suffix / be[s];
-            const float gocc = galpha * al[s] * (1.0f - al[s]) * a.coef;
-            suffix += gw[s] * wv[s];
-            const float k = wv[s] / W;
-            *reinterpret_cast<float4*>(a.d_raw + (size_t)(r * a.S + s) * 4) = make_float4(g0 * k, g1 * k, g2 * k, gocc);
-        }
-    }
+    lk_composite_bwd_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, a.gt_depth[r], a.d_depth[r], a.d_var ? a.d_var[r] : 0.0f,
+                         a.d_color ? a.d_color[3 * r] : 0.0f, a.d_color ? a.d_color[3 * r + 1] : 0.0f, a.d_color ? a.d_color[3 * r + 2] : 0.0f,
+                         a.d_raw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -113,9 +69,6 @@ __device__ __forceinline__ BwdSample bwd_sample(const LkDecodeBwdArgs& a, int ti
 // (LK_FLAG_UNIT_LOSS_GRADS, mapper mode): the whole chain d h_4 .. d h_0 is linear in d out, so d out is multiplied by 2^10
 // once (median |d h| 1.5e-4 -> 0.15: both fp16 pieces normal numbers), everything in between is scaled with it, and the
 // stored d h rows / d c are scaled back where they are written (in the copy resp. the final sum: no extra instruction).
-#ifndef LK_DH_STORE_MODE
-#define LK_DH_STORE_MODE 1          // product: see the STORE-DATA RULE below; other values are hazard experiments
-#endif
 template <bool H16> struct BwdPiece;
 template <> struct BwdPiece<false> {
     typedef LkB8 T;
@@ -248,34 +201,19 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     prefetch(4);
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
-        // STORE-DATA RULE (measured; tests/test_fullsize_gpu.py::test_render_is_deterministic_at_scale): a global store whose
-        // data registers are the accumulators that the NEXT MFMA chain overwrites came out wrong for half a tile in ~1 % of
-        // the tiles once two workgroups shared a compute unit (the scattered 16-byte row stores queue up in the memory
-        // pipe).  The store therefore reads a copy that stays allocated until the end of the layer.
-        f32x16 dhc;
-#if LK_DH_STORE_MODE == 1
+        // (Round 1 stored a register COPY of d h here, believing that the row stores must not read the accumulators the next
+        // product overwrites.  The cause was elsewhere: the copy happened to stop the SLP vectoriser from turning the
+        // d h = Wo^T d out expression into packed-fp32 instructions, and it is those that corrupt lanes 48-63 of a register
+        // when two workgroups share a compute unit - see build.py and DESIGN.md §3.  The library is built without them;
+        // the stores read the accumulators directly.)
+        if (want_w) {
+            f32x16 dhs = dh;
+            if (H16) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { float t = H16 ? dh[q] * ISC : dh[q]; asm volatile("" : "+v"(t)); dhc[q] = t; }
-        if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dhc, live, lane);
-#else       // hazard experiments (tools/probe/dh_store_insitu.py): the store reads the live accumulators
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dhc[q] = H16 ? dh[q] * ISC : dh[q];
-#if LK_DH_STORE_MODE == 3
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (want_w) ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dhc, live, lane);
-#if LK_DH_STORE_MODE == 2
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#elif LK_DH_STORE_MODE == 4
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
+                for (int q = 0; q < 16; ++q) dhs[q] = dh[q] * ISC;
+            }
+            ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dhs, live, lane);
+        }
 #pragma unroll
         for (int G = 0; G < 2; ++G) dc = PC::mma(un[G], PC::split(dh, G), dc);
 #pragma unroll
@@ -307,10 +245,6 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
                 for (int G = 0; G < 8; ++G) de = PC::mma(PC::load(FB + PC::tr(10), 2, G, w - 2, lane), lds_b(xs, G), de);
             }
         }
-#if LK_DH_STORE_MODE == 1
-#pragma unroll
-        for (int q = 0; q < 16; ++q) asm volatile("" :: "v"(dhc[q]));
-#endif
     }
     // d c: park the per-wave partials, wave w sums register chunk w of all four -> one float4 per lane
     {

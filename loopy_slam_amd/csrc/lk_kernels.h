@@ -32,6 +32,7 @@ struct LkCompositeArgs {
     // fused mapper loss (LK_FLAG_MAPPER_LOSS): NULL loss_out = off
     const float* gt_color; float w_color; int use_color;
     float* d_depth; float* d_color; float* loss_out;
+    float* d_raw;                                  // with loss_out: also the composite BACKWARD of the loss gradient (d raw [P,4]), or NULL
 };
 
 // fused decoder forward (register-chained MFMA): raw[P,4] = (rgb | logits, occ)
@@ -149,6 +150,13 @@ struct LkWgradArgs {
 #define LK_WG_TILE (4 * 16 * 64 + 64)              // floats per tile: accumulators [block][reg][lane] + bias sums
 // floats of LkWgradArgs::part (one tile per wave, whatever the problem size)
 inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_WAVES * LK_WG_TILE; }
+
+// lk_render_fwd / lk_render_bwd with parts of their launch sequence left to the caller (the fused per-frame loops, lk_loop.hip)
+enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, LK_FUSE_COMPOSITE_BWD = 8, LK_LOSS_PREZEROED = 16 };
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip);
+int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip);
+struct LkBwdOffsets { int64_t d_raw, dp_total; };
+LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch
 
 int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st);
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st);

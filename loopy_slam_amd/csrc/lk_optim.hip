@@ -5,6 +5,7 @@
 //   inside-mask threshold (median / max) and stable ballot + prefix-sum compaction
 //   (Tracker.py:153-160, Mapper.py:674-681, common.py:249-255).
 #include "lk_common.h"
+#include "lk_mask_dev.h"
 
 #include <math.h>
 #include <string.h>
@@ -342,20 +343,13 @@ __global__ __launch_bounds__(1024) void k_compact(const uint8_t* __restrict__ ma
 }
 
 // ------------------------------------------------------------------ inside mask: thr = min(10*median(d>0), 1.2*max)
-// Median = 4-pass radix select over the bit patterns of the positive depths (single 1024-thread workgroup).
-// REG = true (n <= LK_MASK_REG_MAX): the values stay in registers between the passes; otherwise they are re-read from
-// `scratch`.  The top byte of a depth takes a handful of values, so in the first pass the histogram is built with
-// one LDS add per (wave, distinct byte) instead of one same-address add per ray.
-#define LK_MASK_REG_MAX 8192
+// (single 1024-thread workgroup; the threshold search itself is lk_mask_dev.h::lk_inside_thr)
 template <bool REG>
 __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n, uint8_t* __restrict__ mask, float* depth_filtered,
                                                       float* __restrict__ out_thr, uint32_t* __restrict__ scratch) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_rank, s_cnt, s_maxbits;
-    constexpr int VPT = LK_MASK_REG_MAX / 1024;
-    const int t = threadIdx.x, lane = t & 63;
-    if (t == 0) { s_cnt = 0; s_maxbits = 0; }
-    __syncthreads();
+    __shared__ LkMaskShared S;
+    constexpr int VPT = LK_MASK_VPT;
+    const int t = threadIdx.x;
     unsigned u[VPT];
     unsigned mycnt = 0, mymax = 0;
     if (REG) {
@@ -367,6 +361,8 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
             if (u[q]) { ++mycnt; mymax = max(mymax, u[q]); }
         }
     } else {
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) u[q] = 0u;
         for (int i = t; i < n; i += 1024) {
             const float d = depth[i];
             const unsigned v = (d > 0.0f) ? __float_as_uint(d) : 0u;
@@ -374,93 +370,13 @@ __global__ __launch_bounds__(1024) void k_inside_mask(const float* depth, int n,
             if (v) { ++mycnt; mymax = max(mymax, v); }
         }
     }
-    // one LDS atomic per WAVE (1024 same-address atomics cost microseconds)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mycnt += __shfl_xor(mycnt, o); mymax = max(mymax, (unsigned)__shfl_xor((int)mymax, o)); }
-    if (lane == 0) { atomicAdd(&s_cnt, mycnt); atomicMax(&s_maxbits, mymax); }
-    __syncthreads();
-    const unsigned m = s_cnt;
-    if (m == 0) {
+    bool any;
+    const float thr = lk_inside_thr<REG>(u, scratch, n, mycnt, mymax, S, &any);
+    if (!any) {
         for (int i = t; i < n; i += 1024) { if (mask) mask[i] = 0; if (depth_filtered) depth_filtered[i] = 0.0f; }
         if (t == 0) *out_thr = 0.0f;
         return;
     }
-    // Shortcut: thr = min(10*median, 1.2*max) is 1.2*max unless the median itself satisfies fl(10 v) < fl(1.2 max); that
-    // predicate is monotone in v, so the (lower) median at rank (m-1)/2 satisfies it iff MORE than (m-1)/2 values do -
-    // one counting pass instead of the 4-pass radix select (depth images: median ~ max/2, the select almost never runs).
-    const float mx12 = __fmul_rn(1.2f, __uint_as_float(s_maxbits));
-    {
-        unsigned below = 0;
-        if (REG) {
-#pragma unroll
-            for (int q = 0; q < VPT; ++q) below += (u[q] && __fmul_rn(10.0f, __uint_as_float(u[q])) < mx12) ? 1u : 0u;
-        } else {
-            for (int i = t; i < n; i += 1024) { const unsigned v = scratch[i]; below += (v && __fmul_rn(10.0f, __uint_as_float(v)) < mx12) ? 1u : 0u; }
-        }
-        if (t == 0) s_rank = 0;
-        __syncthreads();
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
-        if (lane == 0) atomicAdd(&s_rank, below);
-        __syncthreads();
-    }
-    const bool need_median = s_rank > (m - 1) / 2;                    // block-uniform
-    __syncthreads();
-    if (t == 0) { s_prefix = 0; s_rank = (m - 1) / 2; }              // torch.median: lower of the two middle values
-    __syncthreads();
-    for (int shift = 24; need_median && shift >= 0; shift -= 8) {
-        if (t < 256) hist[t] = 0;
-        __syncthreads();
-        const unsigned prefix = s_prefix;
-        const unsigned himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
-        if (REG) {
-#pragma unroll
-            for (int q = 0; q < VPT; ++q) {
-                const bool on = u[q] && (u[q] & himask) == prefix;
-                const unsigned digit = (u[q] >> shift) & 255u;
-                if (shift == 24) {      // all lanes walk the loop together (wave-uniform trip count)
-                    unsigned long long pending = __ballot(on);
-                    while (pending) {
-                        const int leader = __ffsll((long long)pending) - 1;
-                        const unsigned dl = __shfl(digit, leader);
-                        const unsigned long long same = __ballot(on && digit == dl);
-                        if (lane == leader) atomicAdd(&hist[dl], (unsigned)__popcll(same));
-                        pending &= ~same;
-                    }
-                } else if (on) {
-                    atomicAdd(&hist[digit], 1u);
-                }
-            }
-        } else {
-            for (int i = t; i < n; i += 1024) {
-                const unsigned v = scratch[i];
-                if (v && (v & himask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
-            }
-        }
-        __syncthreads();
-        // locate the bin that holds the wanted rank: wave 0 scans the 256-bin histogram (4 bins per lane)
-        if (t < 64) {
-            const unsigned rank = s_rank;                   // every lane reads before the (later) single write
-            const unsigned h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
-            const unsigned tot = h0 + h1 + h2 + h3;
-            unsigned incl = tot;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned nbv = __shfl_up(incl, o);
-                if (t >= o) incl += nbv;
-            }
-            const unsigned excl = incl - tot;
-            if (rank >= excl && rank < incl) {              // exactly one lane
-                unsigned r = rank - excl, b = 4 * t;
-                if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
-                s_rank = r;
-                s_prefix = prefix | (b << shift);
-            }
-        }
-        __syncthreads();
-    }
-    const float med = __uint_as_float(s_prefix);
-    const float thr = need_median ? fminf(__fmul_rn(10.0f, med), mx12) : mx12;
     if (REG) {
 #pragma unroll
         for (int q = 0; q < VPT; ++q) {

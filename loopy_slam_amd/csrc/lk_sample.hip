@@ -7,6 +7,7 @@
 #include "lk_common.h"
 #include "lk_knn_dev.h"
 #include "lk_kernels.h"
+#include "lk_composite_dev.h"
 
 // torch.linspace(start, end, steps)[i] (symmetric evaluation, aten RangeFactories)
 __device__ __forceinline__ float lk_linspace(float start, float end, int steps, int i) {
@@ -129,37 +130,12 @@ __global__ __launch_bounds__(256) void k_composite(LkCompositeArgs a) {
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
     float l_geo = 0.0f, l_col = 0.0f, l_cnt = 0.0f;
     if (r < a.R) {
-        float T = 1.0f, wsum = 0.0f, dsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
-        float wv[LK_S_MAX], zv[LK_S_MAX];
-        int nhas = 0;
-#pragma unroll
-        for (int s = 0; s < LK_S_MAX; ++s) {
-            if (s < a.S) {
-                const int p = r * a.S + s;
-                const float4 raw = *reinterpret_cast<const float4*>(a.raw + (size_t)p * 4);
-                const bool has = a.nbr_count[p] >= a.min_nn;
-                nhas += has ? 1 : 0;
-                const float occ = has ? raw.w : -100.0f;
-                const float alpha = lk_sigmoid(a.coef * occ);
-                const float w = alpha * T;
-                T *= (1.0f - alpha + 1e-10f);
-                const float z = a.z[p];
-                wv[s] = w; zv[s] = z;
-                wsum += w; dsum += w * z;
-                c0 += w * raw.x; c1 += w * raw.y; c2 += w * raw.z;
-            } else { wv[s] = 0.0f; zv[s] = 0.0f; }
-        }
-        const float ws = wsum + 1e-10f;
-        const float depth = dsum / ws;
-        float var = 0.0f;
-#pragma unroll
-        for (int s = 0; s < LK_S_MAX; ++s) { const float t = zv[s] - depth; var += wv[s] * t * t; }
         const float gd = a.gt_depth[r];
-        const float dout = (gd > 0.0f) ? depth : 0.0f;              // Renderer.py:197-198
-        const bool valid = nhas >= a.S / 2 + 1;                     // decoder.py:259-260
-        const float o0 = c0 / ws, o1 = c1 / ws, o2 = c2 / ws;
+        const LkRayOut ro = lk_composite_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, gd);
+        const float dout = ro.depth, o0 = ro.c0, o1 = ro.c1, o2 = ro.c2;
+        const bool valid = ro.valid;
         a.depth[r] = dout;
-        a.var[r] = var;
+        a.var[r] = ro.var;
         a.color[3 * r] = o0; a.color[3 * r + 1] = o1; a.color[3 * r + 2] = o2;
         a.valid_ray[r] = valid ? 1 : 0;
         if (a.loss_out) {
@@ -179,6 +155,7 @@ __global__ __launch_bounds__(256) void k_composite(LkCompositeArgs a) {
             }
             a.d_depth[r] = dd;
             a.d_color[3 * r] = d0; a.d_color[3 * r + 1] = d1; a.d_color[3 * r + 2] = d2;
+            if (a.d_raw) lk_composite_bwd_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, gd, dd, 0.0f, d0, d1, d2, a.d_raw);
         }
     }
     if (a.loss_out) {

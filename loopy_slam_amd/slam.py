@@ -498,9 +498,8 @@ class Mapper:
         rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen, dtype=torch.int32).to(eng.device)
         log = eng.zeros(num_joint_iters, 4)
         geo_iters = self.geo_iter_first if init else int(num_joint_iters * self.geo_iter_ratio)
-        for it in range(num_joint_iters):
-            stage = 'geometry' if it <= geo_iters else 'color'
-            mo.iterate(stage, stack, rnd[it], fid, (0, H, 0, W), intr, H, W, log_row=log[it])
+        # stage 'geometry' while joint_iter <= geo_iters (Mapper.py:594-597)
+        mo.run(num_joint_iters, min(num_joint_iters, geo_iters + 1), stack, rnd, fid, (0, H, 0, W), intr, H, W, log)
         mo.finish()
         self.last_log = log
         self.prev_c2w = cur_c2w.clone()

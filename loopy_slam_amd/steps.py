@@ -125,6 +125,8 @@ class MapOptimizer:
         self.loss_log = None
         self.dist = dist
         self.it = 0
+        self.native_loop = True                 # lk_map_frame; False = one launch sequence per statement (iterate)
+        self._nat, self._nat_dirty = None, False    # Adam state of the native loop: [4][n_rows*32] rows, [2][blob] decoders
         # exposure = (mlp_exposure torch module, [exposure_feat tensor per frame of the window]) for model.encode_exposure
         # (ScanNet): per-keyframe colour affine applied to the RENDERED colour logits (Mapper.py:697-715)
         self.exposure = ExposureState(eng, exposure[0], exposure[1]) if exposure is not None else None
@@ -179,6 +181,73 @@ class MapOptimizer:
         self.it += 1
         return out4
 
+    def run(self, n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log):
+        """All joint iterations of one optimize_map call (Mapper.py:576-735): iteration it runs stage 'geometry' iff
+        it < n_geo_iters.  rnd_all int32 [n_iters, R]; log [n_iters, 4].  Without exposure encoding this is lk_map_frame - one
+        C-ABI call for the whole loop single-GPU, two calls per iteration around the gradient all-reduce multi-GPU; with
+        exposure encoding the per-statement path (iterate)."""
+        if self.exposure is not None or not self.native_loop:
+            for it in range(n_iters):
+                self.iterate('geometry' if it < n_geo_iters else 'color', frames, rnd_all[it], frame_id, window, intr, H, W, log_row=log[it])
+            return log
+        eng, b, st, gs = self.eng, self.batch, self.st, self.gs
+        depth_stack, color_stack, c2w_stack, r2_stack = frames
+        core.fill_desc(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col, self.dec, 'color',
+                       r2_ray=b.r2_ray, save_act=True)
+        flags = st.desc.flags | _ffi.FLAG_GRAD_FEATS | _ffi.FLAG_GRAD_WEIGHTS
+        need = int(eng.lib.dll.lk_render_bwd_scratch_floats(self.R, self.cfg.S, flags))
+        if gs.scratch is None or gs.scratch.numel() < need:
+            gs.scratch = eng.empty(max(1, need))
+        d = _ffi.MapDesc()
+        C = _ffi.C
+        C.memmove(C.byref(d.render), C.byref(st.desc), C.sizeof(_ffi.RenderDesc))
+        r = d.render
+        r.flags = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | _ffi.FLAG_UNIT_LOSS_GRADS      # L1 sums: |d depth|, |d colour| <= 1
+        r.d_depth, r.d_color = ptr(b.d_depth), ptr(b.d_color)
+        r.g_geo_feats, r.g_col_feats, r.g_weights = ptr(gs.g_geo), ptr(gs.g_col), ptr(gs.g_weights)
+        r.grad_row_mask, r.bwd_scratch = ptr(gs.row_mask), ptr(gs.scratch)
+        H0, H1, W0, W1 = window
+        d.depth_stack, d.color_stack, d.c2w_stack, d.c2w_stride = ptr(depth_stack), ptr(color_stack), ptr(c2w_stack), c2w_stack.shape[-2] * 4
+        d.r2_map_stack, d.frame_id = ptr(r2_stack), ptr(frame_id)
+        rnd_all = rnd_all.contiguous()
+        assert rnd_all.dtype == torch.int32 and rnd_all.shape[0] >= n_iters and rnd_all.shape[1] == self.R and log.is_contiguous()
+        d.rnd = ptr(rnd_all)
+        d.H, d.W, d.H0, d.W0, d.w = H, W, H0, W0, W1 - W0
+        d.fx, d.fy, d.cx, d.cy = intr
+        d.gt_color, d.thr, d.scratch_u32 = ptr(b.gt_color), ptr(b.thr), ptr(b.scratch_u32)
+        d.w_color, d.log = self.w_color, ptr(log)
+        d.weights_rw, d.weights_frag_rw = ptr(self.dec.blob), ptr(self.dec.frag)
+        d.geo_feats_rw, d.col_feats_rw = ptr(self.geo), ptr(self.col)
+        n_rows = self.rows.numel() if self.rows is not None else self.geo.shape[0]
+        d.rows, d.n_rows = ptr(self.rows), n_rows
+        if self._nat is None or self._nat[0].numel() != 4 * n_rows * 32:
+            self._nat = (eng.zeros(4 * n_rows * 32), eng.zeros(2 * self.dec.n))
+        elif self._nat_dirty:
+            self._nat[0].zero_(); self._nat[1].zero_()
+        self._nat_dirty = True
+        d.adam_rows, d.adam_dec = ptr(self._nat[0]), ptr(self._nat[1])
+        assert len(self.geo_dec_ranges) <= _ffi.MAX_SPANS and len(self.col_dec_ranges) <= _ffi.MAX_SPANS
+        for k, (o, n) in enumerate(self.geo_dec_ranges):
+            d.geo_dec[k].offset, d.geo_dec[k].n = o, n
+        for k, (o, n) in enumerate(self.col_dec_ranges):
+            d.col_dec[k].offset, d.col_dec[k].n = o, n
+        d.n_geo_dec, d.n_col_dec = len(self.geo_dec_ranges), len(self.col_dec_ranges)
+        for si, stage in enumerate(('geometry', 'color')):
+            for k in range(3):
+                d.lr[si][k] = self.lrs[stage][k]
+        d.iters, d.n_geo_iters = n_iters, n_geo_iters
+        self._keep_native = (depth_stack, color_stack, c2w_stack, r2_stack, frame_id, rnd_all, log)
+        dll = eng.lib.dll
+        if self.dist is None:
+            eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n_iters, 3, eng.stream), 'lk_map_frame')
+        else:
+            for it in range(n_iters):
+                eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 1, eng.stream), 'lk_map_frame')
+                self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color')
+                eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 2, eng.stream), 'lk_map_frame')
+        self.it += n_iters
+        return log
+
     def finish(self):
         """End of the optimize_map call: stacked exposure features go back to the keyframes' tensors."""
         if self.exposure is not None:
@@ -197,6 +266,7 @@ class MapOptimizer:
         self.gs.row_mask = row_mask
         self.adam = optim.Adam(self.eng)
         self.gs.zero_()
+        self._nat_dirty = True                  # fresh optimiser: the native loop's state is re-zeroed (or re-sized) on its next run
 
     def begin_frame(self):
         """Gradient tables start from zero; rows outside `row_index` may collect (never consumed) scatter
@@ -219,6 +289,7 @@ class TrackOptimizer:
         self.g_cam = eng.zeros(7)
         self.eye = None
         self.dist = dist                        # ray-sharded tracking: the 7 pose gradients are summed over ranks
+        self.native_loop = True                 # lk_track_frame (one call per frame); False = one launch sequence per statement
 
     def track(self, cam7_init, depth_img, color_img, iters, window, intr, rnd_all, r2_map=None, exposure=None):
         """Tracker.run loop body for one frame (Tracker.py:313-401).  cam7_init: [7] device tensor.
@@ -236,12 +307,18 @@ class TrackOptimizer:
                 gs.g_affine = eng.zeros(12)
         log = eng.zeros(iters, 4)
         hist = eng.empty(iters, 7)
+        if xs is None and self.dist is None and self.native_loop:
+            # the whole loop as ONE C-ABI call (lk_track_frame): no interpreter between the launches
+            self._track_native(cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log)
+            best = torch.argmin(log[:, 0])      # Tracker.py:375-377 (first minimum)
+            return hist[best].clone(), log
         if self.eye is None:
             self.eye = torch.eye(4, device=eng.device).reshape(1, 4, 4).contiguous()
         dstack, cstack = depth_img.reshape(1, H, W), color_img.reshape(1, H, W, 3)
         r2s = r2_map.reshape(1, H, W) if r2_map is not None else None
         for it in range(iters):
-            hist[it].copy_(cam)
+            if self.separate_lr:
+                hist[it].copy_(cam)             # candidate = detached copy of the pose BEFORE the step (Tracker.py:363-377)
             # pixels, depth, colour (identity pose: only the image gathers are used), then rays of the CURRENT pose
             optim.gather_rays(eng, dstack, cstack, self.eye, None, rnd_all[it], H, W, window, intr, b.as_out(), r2s)
             optim.rays_from_pose(eng, cam, b.pix_i, b.pix_j, intr, b.rays_o, b.rays_d)
@@ -269,5 +346,41 @@ class TrackOptimizer:
                 xs.backward(gs.g_affine)
                 segs = segs + xs.adam_segs()
             adam.step(segs)
+            if not self.separate_lr:
+                hist[it].copy_(cam)             # one leaf tensor stepped in place: the candidate is the pose AFTER the update
         best = torch.argmin(log[:, 0])          # Tracker.py:375-377 (first minimum)
         return hist[best].clone(), log
+
+    def _track_native(self, cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log):
+        """lk_track_frame: descriptor of the render buffers + the loop's own buffers (all owned here)."""
+        eng, b, st, gs = self.eng, self.batch, self.st, self.gs
+        H, W = depth_img.shape
+        H0, H1, W0, W1 = window
+        core.fill_desc(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col, self.dec, 'color',
+                       tracker=True, r2_ray=b.r2_ray, save_act=True, extra_flags=_ffi.FLAG_ZERO_ABSENT)
+        flags = st.desc.flags | _ffi.FLAG_GRAD_RAYS
+        need = int(eng.lib.dll.lk_render_bwd_scratch_floats(self.R, self.cfg.S, flags))
+        if gs.scratch is None or gs.scratch.numel() < need:
+            gs.scratch = eng.empty(max(1, need))
+        d = _ffi.TrackDesc()
+        C = _ffi.C
+        C.memmove(C.byref(d.render), C.byref(st.desc), C.sizeof(_ffi.RenderDesc))
+        r = d.render
+        r.flags = _ffi.FLAG_REL_POS if self.cfg.rel_pos else 0
+        r.d_depth, r.d_color = ptr(b.d_depth), ptr(b.d_color)
+        r.g_rays_o, r.g_rays_d, r.bwd_scratch = ptr(gs.g_rays_o), ptr(gs.g_rays_d), ptr(gs.scratch)
+        d.depth_img, d.color_img, d.r2_map = ptr(depth_img), ptr(color_img), ptr(r2_map)
+        d.H, d.W, d.H0, d.W0, d.w = H, W, H0, W0, W1 - W0
+        d.fx, d.fy, d.cx, d.cy = intr
+        rnd_all = rnd_all.contiguous()
+        assert rnd_all.dtype == torch.int32 and rnd_all.shape[0] >= iters and rnd_all.shape[1] == self.R
+        d.rnd, d.gt_color, d.pix_i, d.pix_j = ptr(rnd_all), ptr(b.gt_color), ptr(b.pix_i), ptr(b.pix_j)
+        d.thr, d.scratch_u32, d.loss_scratch = ptr(b.thr), ptr(b.scratch_u32), ptr(b.loss_scratch)
+        if getattr(self, 'adam_mv', None) is None:
+            self.adam_mv = eng.zeros(14)
+        d.cam7, d.g_cam7, d.adam_mv = ptr(cam), ptr(self.g_cam), ptr(self.adam_mv)
+        d.lr_T, d.lr_q = self.cam_lr, (0.2 * self.cam_lr if self.separate_lr else self.cam_lr)
+        d.w_color, d.use_color, d.hist_post = self.w_color, int(bool(self.use_color)), int(not self.separate_lr)
+        d.hist, d.log, d.iters = ptr(hist), ptr(log), iters
+        self._keep_native = (depth_img, color_img, r2_map, rnd_all, cam, hist, log)
+        eng.lib.check(eng.lib.dll.lk_track_frame(C.byref(d), eng.stream), 'lk_track_frame')

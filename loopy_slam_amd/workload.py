@@ -91,8 +91,6 @@ class FrameWorkload:
         self.rows, row_mask = optim.frustum_rows(eng, self.pos, self.c2w_stack[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
                                                  return_mask=True)
         self.mapper.new_frame(self.rows, row_mask)
-        for it in range(b.map_iters):
-            stage = 'geometry' if it < b.map_geo_iters else 'color'
-            self.mapper.iterate(stage, self.frames, rnd_m[it], fid, (0, H, 0, W), self.intr, H, W, log_row=self.map_log[it])
+        self.mapper.run(b.map_iters, b.map_geo_iters, self.frames, rnd_m, fid, (0, H, 0, W), self.intr, H, W, self.map_log)
         self.frame_no += 1
         return best, tlog, self.map_log

@@ -59,9 +59,10 @@ def contract_knn(pos, p, r2, got_idx=None):
     return d2, idx, cnt, n_re
 
 
-def oracle_mapper(rel_pos, stage, b, pos, geo, col, W, knn, w_color=0.1, grads=True):
+def oracle_mapper(rel_pos, stage, b, pos, geo, col, W, knn, w_color=0.1, grads=True, exclude=None):
     """Oracle forward + mapper loss (+ autograd).  Returns dict(out=render dict, loss=(loss, geo, col, mask),
-    g_geo, g_col, gW{name: grad})."""
+    g_geo, g_col, gW{name: grad}).  exclude: bool [R] rays left out of the loss that is differentiated (their loss
+    gradient is zeroed on the kernel side too): rays on a branch point of the graph, see branch_point_rays."""
     names = [k for k in W if k != 'color_decoder.embedder._B']
     Wr = {k: v.clone().requires_grad_(grads and k in names) for k, v in W.items()}
     geo_r, col_r = geo.clone().requires_grad_(grads), col.clone().requires_grad_(grads)
@@ -69,14 +70,15 @@ def oracle_mapper(rel_pos, stage, b, pos, geo, col, W, knn, w_color=0.1, grads=T
     loss = H.mapper_loss(o['depth'], o['color'], o['valid_ray'], b['gt_depth'], b['gt_color'], stage, w_color)
     res = dict(out=o, loss=loss)
     if grads:
-        loss[0].backward()
+        lb = loss if exclude is None else H.mapper_loss(o['depth'], o['color'], o['valid_ray'] & ~exclude, b['gt_depth'], b['gt_color'], stage, w_color)
+        lb[0].backward()
         res['g_geo'] = geo_r.grad
         res['g_col'] = col_r.grad if col_r.grad is not None else torch.zeros_like(col)
         res['gW'] = {k: Wr[k].grad for k in names if Wr[k].grad is not None}
     return res
 
 
-def oracle_tracker(rel_pos, b, cam, pos, geo, col, W, knn, w_color=0.5):
+def oracle_tracker(rel_pos, b, cam, pos, geo, col, W, knn, w_color=0.5, exclude=None):
     """Oracle tracking iteration: rays from the 7-vector pose, render in tracker mode, tracker loss, autograd to the pose
     (and to the rays).  knn must be the list for these rays."""
     cam_r = cam.clone().requires_grad_(True)
@@ -85,7 +87,12 @@ def oracle_tracker(rel_pos, b, cam, pos, geo, col, W, knn, w_color=0.5):
     ro.retain_grad(); rd.retain_grad()
     o = H.render_batch(ocfg(rel_pos), ro, rd, b['gt_depth'], pos, geo, col, W, 'color', tracker=True, knn=knn)
     loss = H.tracker_loss(o['depth'], o['var'], o['color'], b['gt_depth'], b['gt_color'], w_color)
-    loss[0].backward()
+    if exclude is None:
+        loss[0].backward()
+    else:           # the same loss with the excluded rays' terms removed (mask and mean are those of the full batch)
+        m = loss[3] & ~exclude
+        tmp = torch.abs(b['gt_depth'] - o['depth']) / torch.sqrt(o['var'].detach() + 1e-10)
+        (torch.clamp(tmp, min=0.0, max=1e3)[m].sum() + w_color * torch.abs(b['gt_color'] - o['color'])[m].sum()).backward()
     return dict(out=o, loss=loss, g_cam=cam_r.grad, g_rays_o=ro.grad, g_rays_d=rd.grad, rays_o=ro.detach(), rays_d=rd.detach())
 
 
@@ -121,3 +128,25 @@ def rows_of_samples(out, sample_mask):
     """Cloud rows (neighbours) of the flagged samples."""
     idx = out['idx'][sample_mask]
     return torch.unique(idx[idx >= 0].long())
+
+
+def branch_point_rays(out, b, pos, geo, W, tracker_loss=None, tol=2e-6):
+    """bool [R]: rays whose gradient is not comparable between two fp32 implementations because they sit on a branch point
+    of the graph at rounding level - a geometry-decoder ReLU with |pre-activation| < tol in one of their samples
+    (geo_gate_margin), an L1 term with |depth - gt| < tol, or (tracker) a residual within 1e-5 relative of the loss mask's
+    threshold 10 * mean or of the 1e3 clamp (Tracker.py:177-183).  Their loss gradient is zeroed on both sides; the count is
+    recorded and bounded by the tests."""
+    R = b['gt_depth'].shape[0]
+    margin = geo_gate_margin(out, pos, geo, W)
+    rays = (margin < tol).reshape(R, -1).any(1)
+    rays |= (out['depth'].detach() - b['gt_depth']).abs() < tol
+    if tracker_loss is not None:
+        # tracker mode recomputes D from the positions and drops neighbours with D > r^2 (decoder.py:191-198): a neighbour within
+        # rounding of the radius is in or out depending on the summation order of the squared distance
+        r2 = np.float32(0.08 ** 2)
+        near_edge = ((out['d2'] - r2).abs() < 4e-6 * r2) & (out['idx'] >= 0)
+        rays |= near_edge.any(1).reshape(R, -1).any(1)
+        tmp = torch.abs(b['gt_depth'] - out['depth'].detach()) / torch.sqrt(out['var'].detach() + 1e-10)
+        thr = 10 * tmp.mean()
+        rays |= ((tmp - thr).abs() < 1e-5 * thr) | ((tmp - 1e3).abs() < 1e-2)
+    return rays, float(margin.min())

@@ -88,23 +88,6 @@ def _check_grad(name, got, ref, case, skip_rows=None):
     assert e_el <= TOL_GRAD_EL, (case, name, e_el)
 
 
-def _gate_rows(r, b, pos, geo, W, case, extra_ray_mask=None):
-    """Feature rows touched by samples that sit on a branch point of the graph at rounding level: a geometry-decoder ReLU
-    whose pre-activation is within 2e-6 of zero, or (L1 losses) a ray whose |depth - gt| is within 1e-6 - there the two
-    implementations may legitimately take different branches (see atsize.geo_gate_margin)."""
-    o = r['out']
-    margin = A.geo_gate_margin(o, pos, geo, W)
-    amb = margin < 2e-6
-    ray_amb = (o['depth'].detach() - b['gt_depth']).abs() < 1e-6
-    if extra_ray_mask is not None:
-        ray_amb = ray_amb | extra_ray_mask
-    amb = amb | ray_amb.repeat_interleave(5)
-    rows = A.rows_of_samples(o, amb)
-    _record(case, gate_samples=int(amb.sum()), gate_rows=int(rows.numel()), relu_margin_min=float(margin.min()))
-    assert int(amb.sum()) <= 40, 'too many samples at branch points: the margin test is not what explains the differences'
-    return rows
-
-
 @pytest.mark.parametrize('unit', (False, True))
 @pytest.mark.parametrize('stage', ('geometry', 'color'))
 @pytest.mark.parametrize('model,R', (('replica', 5000), ('tum', 10000)))
@@ -124,23 +107,31 @@ def test_mapper_iteration_vs_oracle_at_bench_size(model, R, stage, unit):
     xf = _ffi.FLAG_ZERO_ABSENT | (_ffi.FLAG_UNIT_LOSS_GRADS if unit else 0)
     core.render_forward(eng, cfg, st, ro, rd, gd, knn, dpos, dgeo, dcol, dec, stage, save_act=True, extra_flags=xf,
                         mapper_loss=(gc, 0.1, d_depth, d_color, out4))
-    gs = core.GradState(eng, pos.shape[0], R, dec.n, feats=True, weights=True)
-    core.render_backward(eng, st, gs, d_depth, d_color)
     torch.cuda.synchronize()
     kn = _check_knn_and_z(st, b, pos, case)
-    r = A.oracle_mapper(rel, stage, b, pos, geo, col, W, kn)
-    _check_forward(st, r['out'], case, b['gt_depth'])
-    loss, lgeo, lcol, m = r['loss']
+    r0 = A.oracle_mapper(rel, stage, b, pos, geo, col, W, kn, grads=False)
+    _check_forward(st, r0['out'], case, b['gt_depth'])
+    loss, lgeo, lcol, m = r0['loss']
     o4 = out4.cpu().numpy()
     _record(case, loss_rel=abs(o4[0] - float(loss)) / abs(float(loss)), masked=int(m.sum()))
     assert abs(o4[0] - float(loss)) <= TOL_OUT * abs(float(loss))
     assert abs(o4[1] - float(lgeo)) <= TOL_OUT * abs(float(lgeo)) and int(o4[3]) == int(m.sum())
     if stage == 'color':
         assert abs(o4[2] - float(lcol)) <= TOL_OUT * abs(float(lcol))
-    skip = _gate_rows(r, b, pos, geo, W, case)
-    _check_grad('geo_feats', gs.g_geo.cpu(), r['g_geo'], case, skip_rows=skip)
+    # rays on a branch point of the graph (ReLU gate / L1 kink at rounding level) get a zero loss gradient on both sides
+    bp, margin = A.branch_point_rays(r0['out'], b, pos, geo, W)
+    _record(case, branch_point_rays=int(bp.sum()), relu_margin_min=margin)
+    assert int(bp.sum()) <= 20
+    if int(bp.sum()):
+        d_depth[bp.to(eng.device)] = 0.0
+        d_color[bp.to(eng.device)] = 0.0
+    gs = core.GradState(eng, pos.shape[0], R, dec.n, feats=True, weights=True)
+    core.render_backward(eng, st, gs, d_depth, d_color)
+    torch.cuda.synchronize()
+    r = A.oracle_mapper(rel, stage, b, pos, geo, col, W, kn, exclude=bp)
+    _check_grad('geo_feats', gs.g_geo.cpu(), r['g_geo'], case)
     if stage == 'color':
-        _check_grad('col_feats', gs.g_col.cpu(), r['g_col'], case, skip_rows=skip)
+        _check_grad('col_feats', gs.g_col.cpu(), r['g_col'], case)
     gW = dec.unpack(gs.g_weights)
     n = 0
     for name, ref in r['gW'].items():
@@ -173,10 +164,6 @@ def test_tracker_iteration_vs_oracle_at_bench_size(model, R):
                         extra_flags=_ffi.FLAG_ZERO_ABSENT)
     d_depth, d_color, out4 = eng.empty(R), eng.empty(R, 3), eng.zeros(4)
     optim.loss_tracker(eng, st, gd, gc, 0.5, True, d_depth, d_color, out4, eng.empty(R + 8))
-    gs = core.GradState(eng, pos.shape[0], R, dec.n, feats=False, weights=False, rays=True)
-    core.render_backward(eng, st, gs, d_depth, d_color)
-    g_cam = eng.zeros(7)
-    optim.pose_bwd(eng, dcam, pi, pj, A.INTR, gs.g_rays_o, gs.g_rays_d, g_cam)
     torch.cuda.synchronize()
     # the oracle renders the rays of ITS pose function; the kernel's rays must agree to fp32 rounding for the lists to match
     bo = dict(b)
@@ -184,20 +171,28 @@ def test_tracker_iteration_vs_oracle_at_bench_size(model, R):
     np.testing.assert_allclose(rd.cpu().numpy(), rd_o.numpy(), rtol=2e-6, atol=1e-7)
     bo['rays_o'], bo['rays_d'] = ro.cpu(), rd.cpu()               # neighbour lists of the kernel's own rays
     kn = _check_knn_and_z(st, bo, pos, case)
-    r = A.oracle_tracker(rel, b, cam, pos, geo, col, W, kn)
-    _check_forward(st, r['out'], case, b['gt_depth'])
-    loss, lgeo, lcol, m = r['loss']
+    with torch.no_grad():
+        o0 = H.render_batch(A.ocfg(rel), ro_o, rd_o, b['gt_depth'], pos, geo, col, W, 'color', tracker=True, knn=kn)
+    _check_forward(st, o0, case, b['gt_depth'])
+    loss, lgeo, lcol, m = H.tracker_loss(o0['depth'], o0['var'], o0['color'], b['gt_depth'], b['gt_color'], 0.5)
     o4 = out4.cpu().numpy()
     _record(case, loss_rel=abs(o4[0] - float(loss)) / abs(float(loss)), masked=int(m.sum()))
     assert int(o4[3]) == int(m.sum())
     assert abs(o4[0] - float(loss)) <= TOL_OUT * abs(float(loss))
-    # rays with a sample on a ReLU branch point (see _gate_rows) or on the edge of the loss mask are compared separately
-    margin = A.geo_gate_margin(r['out'], pos, geo, W)
-    gate_rays = torch.nonzero((margin < 2e-6).reshape(R, 5).any(1)).reshape(-1)
-    _record(case, gate_rays=int(gate_rays.numel()), relu_margin_min=float(margin.min()))
-    assert gate_rays.numel() <= 10
-    _check_grad('rays_o', gs.g_rays_o.cpu(), r['g_rays_o'], case, skip_rows=gate_rays)
-    _check_grad('rays_d', gs.g_rays_d.cpu(), r['g_rays_d'], case, skip_rows=gate_rays)
+    bp, margin = A.branch_point_rays(o0, b, pos, geo, W, tracker_loss=True)
+    _record(case, branch_point_rays=int(bp.sum()), relu_margin_min=margin)
+    assert int(bp.sum()) <= 20
+    if int(bp.sum()):
+        d_depth[bp.to(eng.device)] = 0.0
+        d_color[bp.to(eng.device)] = 0.0
+    gs = core.GradState(eng, pos.shape[0], R, dec.n, feats=False, weights=False, rays=True)
+    core.render_backward(eng, st, gs, d_depth, d_color)
+    g_cam = eng.zeros(7)
+    optim.pose_bwd(eng, dcam, pi, pj, A.INTR, gs.g_rays_o, gs.g_rays_d, g_cam)
+    torch.cuda.synchronize()
+    r = A.oracle_tracker(rel, b, cam, pos, geo, col, W, kn, exclude=bp)
+    _check_grad('rays_o', gs.g_rays_o.cpu(), r['g_rays_o'], case)
+    _check_grad('rays_d', gs.g_rays_d.cpu(), r['g_rays_d'], case)
     _check_grad('cam', g_cam.cpu(), r['g_cam'], case)
 
 

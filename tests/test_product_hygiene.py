@@ -55,3 +55,32 @@ def test_missing_library_message():
     from loopy_slam_amd import _ffi
     with pytest.raises(_ffi.LoopyError, match='no CPU fallback'):
         _ffi.LoopyLib('/nonexistent/libloopyhip.so')
+
+
+def test_library_has_no_packed_fp32_instructions():
+    """gfx950's packed fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32) corrupted lanes
+    48-63 of a register in k_decode_bwd when two workgroups shared a compute unit (reproduced from history by
+    tools/probe/make_hist_variants.sh).  The library is built with the packed-fp32-ops target feature off; this test
+    disassembles every code object inside libloopyhip.so and fails if one slipped in (new flags, a new compiler)."""
+    import subprocess
+    objdump, objcopy = '/opt/rocm/lib/llvm/bin/llvm-objdump', '/opt/rocm/lib/llvm/bin/llvm-objcopy'
+    if not (os.path.exists(objdump) and os.path.exists(objcopy)):
+        pytest.skip('ROCm LLVM binutils not installed')
+    from loopy_slam_amd.csrc import build
+    lib_path = build.build()
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, 'fat.bin')
+        subprocess.run([objcopy, '--dump-section=.hip_fatbin=' + fat, lib_path], check=True)
+        blob = open(fat, 'rb').read()
+        offs = [m.start() for m in re.finditer(b'\x7fELF', blob)]
+        assert len(offs) >= 6                        # one code object per .hip translation unit
+        found, n_insts = [], 0
+        for k, o in enumerate(offs):
+            co = os.path.join(tmp, 'co.elf')
+            open(co, 'wb').write(blob[o:offs[k + 1] if k + 1 < len(offs) else len(blob)])
+            dis = subprocess.run([objdump, '-d', co], capture_output=True, text=True).stdout
+            n_insts += len(re.findall(r'\bv_mfma_f32_32x32x16_(f16|bf16)\b', dis))
+            found += re.findall(r'\bv_pk_(?:mul|add|fma)_f32\b|\bv_pk_mov_b32\b', dis)
+        assert n_insts > 100                         # the disassembly really is the kernels
+        assert not found, f'{len(found)} packed fp32 instructions in libloopyhip.so: {sorted(set(found))}'

@@ -46,8 +46,10 @@ def oracle_rays(c2w, depth_img, color_img, rnd):
 
 
 @pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('native', (True, False))
 @pytest.mark.parametrize('rel_pos', (True, False))
-def test_map_iterations_match_oracle(backend, rel_pos):
+def test_map_iterations_match_oracle(backend, rel_pos, native):
+    """native: the whole loop as ONE lk_map_frame call (MapOptimizer.run); else one launch sequence per statement (iterate)."""
     eng = make_engine(backend)
     c2w, depth_img, color_img, pos, geo, col = mini_scene()
     W = syn.default_weights(seed=7)
@@ -95,9 +97,14 @@ def test_map_iterations_match_oracle(backend, rel_pos):
     frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
     fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
     k_losses = []
-    for it in range(iters):
-        out4 = mo.iterate(stages[it], frames, rnd_all[it].to(eng.device), fid, (0, HH, 0, WW), INTR, HH, WW)
-        k_losses.append(float(out4[0].cpu()))
+    if native:
+        log = eng.zeros(iters, 4)
+        mo.run(iters, 1, frames, rnd_all.to(eng.device), fid, (0, HH, 0, WW), INTR, HH, WW, log)
+        k_losses = [float(x) for x in log[:, 0].cpu()]
+    else:
+        for it in range(iters):
+            out4 = mo.iterate(stages[it], frames, rnd_all[it].to(eng.device), fid, (0, HH, 0, WW), INTR, HH, WW)
+            k_losses.append(float(out4[0].cpu()))
     np.testing.assert_allclose(k_losses, o_losses, rtol=2e-4)
     r = rows.long()
     # selected rows moved by Adam, the others untouched
@@ -128,7 +135,11 @@ def test_map_iterations_match_oracle(backend, rel_pos):
 
 
 @pytest.mark.parametrize('backend', backends())
-def test_track_iterations_match_oracle(backend):
+@pytest.mark.parametrize('native,separate', ((True, True), (False, True), (True, False), (False, False)))
+def test_track_iterations_match_oracle(backend, native, separate):
+    """native: the loop as ONE lk_track_frame call (fused one-workgroup kernels for batch assembly / loss / pose update);
+    separate: tracking.separate_LR - two Adam groups and the candidate pose taken BEFORE the step (Replica); otherwise one
+    leaf tensor stepped in place, the candidate is the pose AFTER the step (TUM / ScanNet; Tracker.py:334-377)."""
     eng = make_engine(backend)
     c2w, depth_img, color_img, pos, geo, col = mini_scene(1)
     W = syn.default_weights(seed=8)
@@ -143,11 +154,14 @@ def test_track_iterations_match_oracle(backend):
     ocfg = H.RenderCfg(rel_pos=True)
     q = cam0[:4].clone().requires_grad_(True)
     T = cam0[4:].clone().requires_grad_(True)
-    opt = torch.optim.Adam([{'params': [T], 'lr': lr}, {'params': [q], 'lr': 0.2 * lr}])
+    cam_leaf = cam0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{'params': [T], 'lr': lr}, {'params': [q], 'lr': 0.2 * lr}]) if separate else \
+        torch.optim.Adam([{'params': [cam_leaf], 'lr': lr}])
     o_losses, o_cams = [], []
     for it in range(iters):
-        cam = torch.cat([q, T])
-        o_cams.append(cam.detach().clone())
+        cam = torch.cat([q, T]) if separate else cam_leaf
+        if separate:
+            o_cams.append(cam.detach().clone())
         opt.zero_grad()
         rr = rnd_all[it]
         i = (win[2] + rr % w_w).float()
@@ -162,6 +176,8 @@ def test_track_iterations_match_oracle(backend):
         loss, _, _, _ = H.tracker_loss(out['depth'], out['var'], out['color'], gd[keep], gc[keep], 0.5)
         loss.backward()
         opt.step()
+        if not separate:
+            o_cams.append(cam_leaf.detach().clone())
         o_losses.append(loss.item())
     # ---------------- kernels
     cfg = core.RenderCfg(rel_pos=True)
@@ -169,7 +185,8 @@ def test_track_iterations_match_oracle(backend):
     pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo), eng.f32(col)
     knn = core.KnnIndex(eng, capacity=pos.shape[0])
     knn.build(pos_d)
-    to = steps.TrackOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, R, lr, separate_lr=True, w_color=0.5)
+    to = steps.TrackOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, R, lr, separate_lr=separate, w_color=0.5)
+    to.native_loop = native
     best, log = to.track(eng.f32(cam0), eng.f32(depth_img), eng.f32(color_img), iters, win, INTR, rnd_all.to(eng.device))
     np.testing.assert_allclose(log[:, 0].cpu().numpy(), o_losses, rtol=5e-4)
     k = int(np.argmin(o_losses))

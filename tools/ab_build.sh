@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p ab /tmp/ab_obj_$name
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -fno-slp-vectorize -Iinclude"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops -Iinclude"
 pids=()
 for s in loopy_slam_amd/csrc/*.hip; do
   o=/tmp/ab_obj_$name/$(basename ${s%.hip}).o

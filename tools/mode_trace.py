@@ -36,9 +36,11 @@ def main():
         fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(eng.device)
         wl.mapper.begin_frame()
 
+        log = eng.zeros(args.iters, 4)
+
         def fn():
-            for it in range(args.iters):
-                wl.mapper.iterate(stage, wl.frames, rnd[it], fid, (0, H, 0, W), wl.intr, H, W, log_row=wl.map_log[it % b.map_iters])
+            wl.mapper.new_frame(wl.rows, None)
+            wl.mapper.run(args.iters, args.iters if stage == 'geometry' else 0, wl.frames, rnd, fid, (0, H, 0, W), wl.intr, H, W, log)
     fn()
     torch.cuda.synchronize()
     for _ in range(args.repeat):

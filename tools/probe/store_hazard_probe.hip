@@ -134,6 +134,74 @@ __global__ __launch_bounds__(256) void k_probe(float* buf) {
                     : "memory", CLOB, "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127",
                       "v128", "v129", "v130", "v131");
             }
+        } else if (MODE >= 6) {
+            // Packed fp32 VALU ops (v_pk_add_f32 & co.: TWO passes over the wave, the SLP vectoriser creates them).  The failing
+            // build computed d h of the last layer with chains of them (built without -fno-slp-vectorize) and showed ONE wrong
+            // register in lanes 48-63.
+            //   MODE 6 / 7: WAR on the SOURCES of a packed op - v_pk_add_f32 reads v[120:121]; WAIT wait states later a plain
+            //               VALU (6: two v_mov, 7: v_lshl_add_u64, the instruction of the failing code) overwrites them.
+            //   MODE 8:     RAW packed result -> global_store data.   MODE 9: RAW packed result -> v_mov (VALU) -> store.
+            const float onef = 1.0f;
+            const unsigned long long junk = 0x7fc000007fc00000ull, zero64 = 0ull;
+            if (MODE == 6 || MODE == 7) {
+                asm volatile(
+                    FILL("%[neg]")
+                    "v_mov_b32 v120, %[good]\n v_mov_b32 v121, %[good]\n v_mov_b32 v122, %[one]\n v_mov_b32 v123, %[one]\n"
+                    "s_nop 7\n"
+                    "v_pk_add_f32 v[124:125], v[122:123], v[120:121]\n"
+                    ".rept %[wt]\n"
+                    "s_nop 0\n"
+                    ".endr\n"
+                    ".if %[mode] == 6\n"
+                    "v_mov_b32 v121, %[neg]\n v_mov_b32 v120, %[neg]\n"
+                    ".else\n"
+                    "v_lshl_add_u64 v[120:121], %[junk], 0, %[zero]\n"
+                    ".endif\n"
+                    "s_nop 15\n"
+                    ".irp r,100,101,102,103,104,105,106,107\n v_mov_b32 v\\r, v124\n .endr\n"
+                    ".irp r,108,109,110,111,112,113,114,115\n v_mov_b32 v\\r, v125\n .endr\n"
+                    "s_nop 7\n"
+                    STORES
+                    "s_waitcnt vmcnt(0)\n"
+                    :: [p] "v"(p), [good] "v"(good), [neg] "v"(neg), [one] "v"(onef), [junk] "v"(junk), [zero] "v"(zero64), [wt] "n"(WAIT), [mode] "n"(MODE)
+                    : "memory", CLOB, "v120", "v121", "v122", "v123", "v124", "v125");
+            } else if (MODE == 8) {
+                asm volatile(
+                    FILL("%[neg]")
+                    "v_mov_b32 v120, %[good]\n v_mov_b32 v121, %[good]\n v_mov_b32 v122, %[one]\n v_mov_b32 v123, %[one]\n"
+                    "s_nop 7\n"
+                    ".irp r,100,102,104,106,108,110,112,114\n v_pk_add_f32 v[\\r:\\r+1], v[122:123], v[120:121]\n .endr\n"
+                    ".rept %[wt]\n"
+                    "s_nop 0\n"
+                    ".endr\n"
+                    "global_store_dwordx4 %[p], v[112:115], off offset:96\n"
+                    "global_store_dwordx4 %[p], v[108:111], off offset:64\n"
+                    "global_store_dwordx4 %[p], v[104:107], off offset:32\n"
+                    "global_store_dwordx4 %[p], v[100:103], off\n"
+                    "s_waitcnt vmcnt(0)\n"
+                    :: [p] "v"(p), [good] "v"(good), [neg] "v"(neg), [one] "v"(onef), [wt] "n"(WAIT)
+                    : "memory", CLOB, "v120", "v121", "v122", "v123");
+            } else {
+                asm volatile(
+                    FILL("%[neg]")
+                    ".irp r,132,133,134,135,136,137,138,139,140,141,142,143,144,145,146,147\n v_mov_b32 v\\r, %[neg]\n .endr\n"
+                    "v_mov_b32 v120, %[good]\n v_mov_b32 v121, %[good]\n v_mov_b32 v122, %[one]\n v_mov_b32 v123, %[one]\n"
+                    "s_nop 7\n"
+                    ".irp r,100,102,104,106,108,110,112,114\n v_pk_add_f32 v[\\r:\\r+1], v[122:123], v[120:121]\n .endr\n"
+                    ".rept %[wt]\n"
+                    "s_nop 0\n"
+                    ".endr\n"
+                    ".irp r,15,14,13,12,11,10,9,8,7,6,5,4,3,2,1,0\n v_mov_b32 v[132+\\r], v[100+\\r]\n .endr\n"
+                    "s_nop 7\n"
+                    "global_store_dwordx4 %[p], v[132:135], off\n"
+                    "global_store_dwordx4 %[p], v[136:139], off offset:32\n"
+                    "global_store_dwordx4 %[p], v[140:143], off offset:64\n"
+                    "global_store_dwordx4 %[p], v[144:147], off offset:96\n"
+                    "s_waitcnt vmcnt(0)\n"
+                    :: [p] "v"(p), [good] "v"(good), [neg] "v"(neg), [one] "v"(onef), [wt] "n"(WAIT)
+                    : "memory", CLOB, "v120", "v121", "v122", "v123", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139",
+                      "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147");
+            }
         } else {
             asm volatile(
                 FILL("%[good]")
@@ -152,7 +220,7 @@ __global__ void k_check(const float* buf, long n, int mode, unsigned long long* 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % ROW_FLOATS);
         const int it = col / 32;
-        const float expect = (mode == 0 ? 16.0f : mode >= 4 ? 64.0f : 1.0f) * (float)(it + 1);
+        const float expect = mode >= 6 ? (float)(it + 2) : (mode == 0 ? 16.0f : mode >= 4 ? 64.0f : 1.0f) * (float)(it + 1);
         if (buf[i] != expect) {
             atomicAdd(bad, 1ull);
             // which sample column (= lane & 31) of the wave's 32-row tile was it?
@@ -174,7 +242,8 @@ static void run(float* buf, unsigned long long* cnt, int wps) {
     CK(hipDeviceSynchronize());
     unsigned long long h[2];
     CK(hipMemcpy(h, cnt, 16, hipMemcpyDeviceToHost));
-    const char* names[6] = {"RAW mfma->store", "WAR store->valu", "WAR store->mfma", "WAR store->vmcnt(0)->valu", "RAW 4-mfma chain->store", "RAW 4-mfma->v_mov->store"};
+    const char* names[10] = {"RAW mfma->store", "WAR store->valu", "WAR store->mfma", "WAR store->vmcnt(0)->valu", "RAW 4-mfma chain->store", "RAW 4-mfma->v_mov->store",
+                             "WAR pk_add srcs<-v_mov", "WAR pk_add srcs<-lshl_add_u64", "RAW pk_add->store", "RAW pk_add->v_mov->store"};
     printf("  %-26s wait %2d, %d waves/SIMD: wrong elements %10llu of %ld (%.4f %%), in sample columns 16-31: %llu\n",
            names[MODE], WAIT, wps, h[0], n, 100.0 * (double)h[0] / (double)n, h[1]);
     fflush(stdout);
@@ -197,6 +266,10 @@ int main() {
         run<4, 0>(buf, cnt, wps); run<4, 4>(buf, cnt, wps); run<4, 8>(buf, cnt, wps); run<4, 12>(buf, cnt, wps); run<4, 16>(buf, cnt, wps);
         run<4, 20>(buf, cnt, wps); run<4, 32>(buf, cnt, wps); run<4, 64>(buf, cnt, wps); run<4, 128>(buf, cnt, wps);
         run<5, 0>(buf, cnt, wps); run<5, 4>(buf, cnt, wps); run<5, 12>(buf, cnt, wps);
+        run<6, 0>(buf, cnt, wps); run<6, 1>(buf, cnt, wps); run<6, 2>(buf, cnt, wps); run<6, 4>(buf, cnt, wps);
+        run<7, 0>(buf, cnt, wps); run<7, 1>(buf, cnt, wps); run<7, 2>(buf, cnt, wps); run<7, 4>(buf, cnt, wps);
+        run<8, 0>(buf, cnt, wps); run<8, 1>(buf, cnt, wps); run<8, 2>(buf, cnt, wps); run<8, 4>(buf, cnt, wps);
+        run<9, 0>(buf, cnt, wps); run<9, 1>(buf, cnt, wps); run<9, 2>(buf, cnt, wps); run<9, 4>(buf, cnt, wps);
     }
     return 0;
 }
