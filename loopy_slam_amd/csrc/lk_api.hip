@@ -100,25 +100,27 @@ struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col,
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
-    L.d_raw = o; o += 4 * P;
-    L.dc_geo = o; o += 32 * P;
-    L.dc_col = o; o += 32 * P;
-    L.dp_embed = o; o += 4 * P;
-    L.dp_embed_col = o; o += 4 * P;
-    L.dp_rel = o; o += 4 * P;
-    L.dp_total = o; o += 4 * P;
-    L.dw_rel = o; o += 8 * P;
-    L.w_eff = o; o += 8 * P;
-    L.dlogit = o; o += 4 * P;
-    L.part_bg = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 32), 4) * 288;
-    L.part_br = o; o += (int64_t)lk_cdiv(lk_cdiv(P, 4), 4) * 32;
+    // every region starts on a 16-byte boundary whatever P is (float4 accesses; P = R*S need not be a multiple of 4)
+    auto al = [](int64_t x) { return (x + 3) / 4 * 4; };
+    L.d_raw = o; o += al(4 * P);
+    L.dc_geo = o; o += al(32 * P);
+    L.dc_col = o; o += al(32 * P);
+    L.dp_embed = o; o += al(4 * P);
+    L.dp_embed_col = o; o += al(4 * P);
+    L.dp_rel = o; o += al(4 * P);
+    L.dp_total = o; o += al(4 * P);
+    L.dw_rel = o; o += al(8 * P);
+    L.w_eff = o; o += al(8 * P);
+    L.dlogit = o; o += al(4 * P);
+    L.part_bg = o; o += al((int64_t)lk_cdiv(lk_cdiv(P, 32), 4) * 288);
+    L.part_br = o; o += al((int64_t)lk_cdiv(lk_cdiv(P, 4), 4) * 32);
     const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0;
-    L.hbar = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 128 * P;
-    L.dfeat = o; if (color && (flags & LK_FLAG_REL_POS) && (flags & LK_FLAG_GRAD_FEATS)) o += 8 * 32 * P;
-    L.w_sum = o; o += P;
-    L.dh_col = o; if (color && gw) o += 640 * P;
-    L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += 8 * 192 * P;
-    L.wg_part = o; if (color && gw) o += lk_wgrad_part_floats(P, (flags & LK_FLAG_REL_POS) != 0);
+    L.hbar = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += al(128 * P);
+    L.dfeat = o; if (color && (flags & LK_FLAG_REL_POS) && (flags & LK_FLAG_GRAD_FEATS)) o += al(8 * 32 * P);
+    L.w_sum = o; o += al(P);
+    L.dh_col = o; if (color && gw) o += al(640 * P);
+    L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += al(8 * 192 * P);
+    L.wg_part = o; if (color && gw) o += al(lk_wgrad_part_floats(P, (flags & LK_FLAG_REL_POS) != 0));
     L.total = o;
     return L;
 }

@@ -391,6 +391,13 @@ class Mapper:
         self.mapping_window_size, self.w_color_loss = m['mapping_window_size'], m['w_color_loss']
         self.frustum_feature_selection, self.frustum_edge = m['frustum_feature_selection'], m['frustum_edge']
         self.filter_before_add_points = m['filter_before_add_points']
+        self.pixels_based_on_color_grad = m.get('pixels_based_on_color_grad', 0)
+        self.color_refine, self.fix_color_decoder = m.get('color_refine', False), m.get('fix_color_decoder', False)
+        self.keyframe_selection_method = m.get('keyframe_selection_method', 'overlap')
+        self.BA, self.ckpt_freq = m.get('BA', False), m.get('ckpt_freq', 500)
+        self.keep_refine_settings = False       # the reference leaves the refinement settings on (its mapper exits right after)
+        self.logger = None                      # slam.Logger, attached by the caller that wants checkpoints
+        self.last_add_counts, self.last_frame_pts_add, self.last_num_joint_iters = [], 0, 0
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self.keyframe_list, self.keyframe_dict = [], []
         self.gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219) + 7)
@@ -438,6 +445,58 @@ class Mapper:
         perm = torch.randperm(len(scored), generator=self.gen).tolist()
         return [scored[i] for i in perm[:k]]
 
+    # -- point insertion of a mapped frame (Mapper.py:421-482)
+    def _pixel_rays(self, flat, cur_c2w, gt_depth, gt_color, r2_add_map):
+        """Rays of flat image indices with a positive depth (get_samples(depth_filter=True), common.py:237-259)."""
+        W = self.W
+        i, j = (flat % W).float(), torch.div(flat, W, rounding_mode='floor').float()
+        ro, rd = get_rays_from_uv(i, j, cur_c2w, self.H, W, self.fx, self.fy, self.cx, self.cy)
+        gd = gt_depth.reshape(-1)[flat]
+        keep = gd > 0
+        dyn = torch.sqrt(r2_add_map.reshape(-1)[flat][keep]) if r2_add_map is not None else None
+        return ro[keep], rd[keep], gd[keep], gt_color.reshape(-1, 3)[flat][keep], dyn
+
+    def draw_add_pixels(self, idx, gt_depth, gt_color, grad_mag=None):
+        """The pixel draws of one frame's insertion passes as flat image indices: 'main' (pixels_adding, scaled on the first
+        frame by the median depth, Mapper.py:421-425), 'overlap' (1000, Mapper.py:443-446) and 'grad' - n of the 5n highest
+        colour-gradient pixels without replacement, sorted (get_samples_with_pixel_grad, common.py:175-196, 262-298)."""
+        H, W, dev = self.H, self.W, self.eng.device
+        n_main = self.pixels_adding
+        if idx == 0:
+            n_main = int(torch.clamp(self.pixels_adding * ((gt_depth.median() / 2.5) ** 2), min=self.pixels_adding,
+                                     max=self.pixels_adding * 3).int().item())
+        draws = {'main': torch.randint(0, H * W, (n_main,), generator=self.gen).to(dev),
+                 'overlap': torch.randint(0, H * W, (1000,), generator=self.gen).to(dev)}
+        n = self.pixels_based_on_color_grad
+        if n > 0:
+            if grad_mag is None:
+                grad_mag = frame_radius_maps(self.eng, self.cfg, gt_color)[0]
+            pool = optim.top_grad_pixels(self.eng, grad_mag, 5 * n, (0, H, 0, W))
+            pick = torch.randperm(int(pool.numel()), generator=self.gen)[:n].to(dev)
+            draws['grad'] = torch.sort(pool[pick].long()).values
+        return draws
+
+    def add_points_for_frame(self, idx, gt_color, gt_depth, cur_c2w, r2_add_map=None, draws=None, grad_mag=None):
+        """Mapper.py:421-482: the non-overlapping area first (surface points outside the previous view), then 1000 more
+        samples for holes INSIDE it, then the high colour-gradient pixels with radius_min (is_pts_grad).  Returns
+        (frame_pts_add, per-pass counts)."""
+        npc = self.npc
+        draws = draws if draws is not None else self.draw_add_pixels(idx, gt_depth, gt_color, grad_mag)
+        counts = []
+        ro, rd, gd, gc, dyn = self._pixel_rays(draws['main'].long(), cur_c2w, gt_depth, gt_color, r2_add_map)
+        if self.filter_before_add_points and idx != 0 and self.prev_c2w is not None:
+            out = self.filter_point_before_add(ro, rd, gd, self.prev_c2w)
+            counts.append(npc.add_neural_points(ro[out], rd[out], gd[out], gc[out], dynamic_radius=dyn[out] if dyn is not None else None))
+            ro, rd, gd, gc, dyn = self._pixel_rays(draws['overlap'].long(), cur_c2w, gt_depth, gt_color, r2_add_map)
+            out = self.filter_point_before_add(ro, rd, gd, self.prev_c2w)
+            counts.append(npc.add_neural_points(ro[~out], rd[~out], gd[~out], gc[~out], dynamic_radius=dyn[~out] if dyn is not None else None))
+        else:
+            counts.append(npc.add_neural_points(ro, rd, gd, gc, dynamic_radius=dyn))
+        if self.pixels_based_on_color_grad > 0 and 'grad' in draws:
+            ro, rd, gd, gc, dyn = self._pixel_rays(draws['grad'].long(), cur_c2w, gt_depth, gt_color, r2_add_map)
+            counts.append(npc.add_neural_points(ro, rd, gd, gc, is_pts_grad=True, dynamic_radius=dyn))
+        return int(sum(counts)), [int(c) for c in counts]
+
     # -- one optimize_map call (Mapper.py:347-807)
     def optimize_map(self, num_joint_iters, idx, cur_gt_color, cur_gt_depth, gt_cur_c2w, keyframe_dict, keyframe_list,
                      cur_c2w, color_refine=False, new_fragment=False):
@@ -445,54 +504,63 @@ class Mapper:
         H, W = self.H, self.W
         intr = (self.fx, self.fy, self.cx, self.cy)
         init = idx == 0
-        # 1. keyframes of the window (overlap selection + the most recent keyframe + the current frame)
+        if self.BA:
+            raise NotImplementedError('mapping.BA: True (camera group of the mapper, Mapper.py:541-566) is off in every reference config and not built')
+        # 1. keyframes of the window
+        segments = self.keyframe_selection_method == 'segments'
         sel = []
         if len(keyframe_dict) > 0:
-            sel = self.keyframe_selection_overlap(cur_gt_color, cur_gt_depth, cur_c2w, keyframe_dict[:-1], self.mapping_window_size - 2)
-            if len(keyframe_list) > 0:
+            if segments:
+                # final refinement (Mapper.py:398-406): the reference optimises over one keyframe per map FRAGMENT (loop-closure
+                # bookkeeping, out of scope here); this single-segment build spreads the same budget over its keyframes
+                n_kf = min(len(keyframe_dict), max(1, 2 * self.mapping_window_size - 1))
+                sel = sorted(set(int(round(x)) for x in np.linspace(0, len(keyframe_dict) - 1, n_kf)))
+            elif self.keyframe_selection_method == 'global':
+                num = self.mapping_window_size - 2
+                sel = list(range(max(0, len(keyframe_dict) - 1 - num), len(keyframe_dict) - 1))
+            else:
+                sel = self.keyframe_selection_overlap(cur_gt_color, cur_gt_depth, cur_c2w, keyframe_dict[:-1], self.mapping_window_size - 2)
+            if len(keyframe_list) > 0 and not segments:
                 sel = sel + [len(keyframe_dict) - 1]
         frames_d = [keyframe_dict[k]['depth'] for k in sel] + [cur_gt_depth]
         frames_c = [keyframe_dict[k]['color'] for k in sel] + [cur_gt_color]
         frames_p = [keyframe_dict[k]['est_c2w'] for k in sel] + [cur_c2w]
-        r2_add_map = r2_query_map = None
+        grad_mag = r2_add_map = r2_query_map = None
         if self.use_dynamic_radius:                 # per-pixel radii of the current frame (Mapper.py:854-872)
-            _, r2_add_map, r2_query_map = frame_radius_maps(eng, cfg, cur_gt_color)
+            grad_mag, r2_add_map, r2_query_map = frame_radius_maps(eng, cfg, cur_gt_color)
             self.cur_r2_query = r2_query_map
         frames_r = ([keyframe_dict[k]['r2_query'] for k in sel] + [r2_query_map]) if self.use_dynamic_radius else None
         exposure = None
-        if self.slam.encode_exposure:               # per-keyframe exposure features + the current frame's (Mapper.py:588-607)
+        if self.slam.encode_exposure:               # per-keyframe exposure features + the current frame's (Mapper.py:494-496, 588-607)
             self.cur_exposure_feat = self.slam.exposure_feat.detach().clone().requires_grad_(True)
             exposure = (self.decoders.mlp_exposure, [keyframe_dict[k]['exposure_feat'] for k in sel] + [self.cur_exposure_feat])
-        # 2. add neural points seen by the current frame (Mapper.py:429-482)
-        ro, rd, gd, gc, i, j = get_samples(0, H, 0, W, self.pixels_adding, H, W, *intr, cur_c2w, cur_gt_depth, cur_gt_color,
-                                           eng.device, depth_filter=True, return_index=True, generator=None)
-        dyn = torch.sqrt(r2_add_map[j.long(), i.long()]) if r2_add_map is not None else None
-        if not init and self.filter_before_add_points and self.prev_c2w is not None:
-            keep = self.filter_point_before_add(ro, rd, gd, self.prev_c2w)
-            ro, rd, gd, gc = ro[keep], rd[keep], gd[keep], gc[keep]
-            dyn = dyn[keep] if dyn is not None else None
-        frame_pts_add = npc.add_neural_points(ro, rd, gd, gc, dynamic_radius=dyn)
-        # 3. rows to optimise
+        # 2. add neural points seen by the current frame (Mapper.py:421-482)
+        frame_pts_add = 0
+        if not color_refine:
+            frame_pts_add, self.last_add_counts = self.add_points_for_frame(idx, cur_gt_color, cur_gt_depth, cur_c2w, r2_add_map,
+                                                                           grad_mag=grad_mag)
+        # 3. rows to optimise (Mapper.py:498-520)
         rows = row_mask = None
-        if self.frustum_feature_selection and not color_refine:
+        if self.frustum_feature_selection:
             rows, row_mask = self.get_mask_from_c2w(cur_c2w, cur_gt_depth, return_mask=True)
         # 4. iteration count (Mapper.py:572-574)
         if idx > 0 and not color_refine:
             num_joint_iters = int(np.clip(int(num_joint_iters * frame_pts_add / 300), int(self.min_iter_ratio * num_joint_iters),
                                           2 * num_joint_iters))
+        self.last_num_joint_iters, self.last_frame_pts_add = num_joint_iters, frame_pts_add
         stage_cfg = cfg['mapping']['init' if init else 'stage']
         lrs = {s: (stage_cfg[s]['decoders_lr'], stage_cfg[s]['geometry_lr'], stage_cfg[s]['color_lr']) for s in ('geometry', 'color')}
         F = len(frames_d)
-        pix = self.mapping_pixels // F
+        pix = (self.mapping_pixels // 10) if segments else (self.mapping_pixels // F)       # Mapper.py:417-418
         R = pix * F
         rcfg = render_cfg_from(cfg, cfg['rendering']['sigmoid_coef_mapper'])
         mo = steps.MapOptimizer(eng, rcfg, self.decoders.dec, npc.knn, npc.cloud_pos(), npc.get_geo_feats(), npc.get_col_feats(),
                                 rows, R, lrs, w_color=self.w_color_loss, dynamic_radius=self.use_dynamic_radius,
-                                dist=getattr(self.slam, 'dist', None), exposure=exposure)
+                                fix_color_decoder=self.fix_color_decoder, dist=getattr(self.slam, 'dist', None), exposure=exposure)
         mo.begin_frame()
         mo.gs.row_mask = row_mask               # the backward only scatters into the rows being optimised
         stack = (torch.stack(frames_d).contiguous(), torch.stack(frames_c).contiguous(),
-                 torch.stack([p.float() for p in frames_p]).contiguous(),
+                 torch.stack([p.float().to(eng.device) for p in frames_p]).contiguous(),
                  torch.stack(frames_r).contiguous() if frames_r is not None else None)
         fid = torch.arange(F, dtype=torch.int32).repeat_interleave(pix).to(eng.device)
         rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen, dtype=torch.int32).to(eng.device)
@@ -501,25 +569,66 @@ class Mapper:
         # stage 'geometry' while joint_iter <= geo_iters (Mapper.py:594-597)
         mo.run(num_joint_iters, min(num_joint_iters, geo_iters + 1), stack, rnd, fid, (0, H, 0, W), intr, H, W, log)
         mo.finish()
+        if self.slam.encode_exposure:           # the optimised feature of this frame is what the tracker starts from (Mapper.py:799)
+            self.slam.exposure_feat = self.cur_exposure_feat.detach().clone()
         self.last_log = log
-        self.prev_c2w = cur_c2w.clone()
         return None
 
     def map_frame(self, idx, gt_color, gt_depth, gt_c2w, cur_c2w=None):
         """One mapped frame: the body of Mapper.run's loop (Mapper.py:835-1037) minus I/O and visualisation."""
-        cur_c2w = cur_c2w if cur_c2w is not None else self.slam.estimate_c2w_list[idx].to(self.eng.device)
-        iters = self.iters_first if idx == 0 else self.num_joint_iters
-        self.optimize_map(iters, idx, gt_color, gt_depth, gt_c2w, self.keyframe_dict, self.keyframe_list, cur_c2w)
-        if idx % self.keyframe_every == 0 or idx == self.slam.n_img - 2:
+        slam, cfg = self.slam, self.cfg
+        cur_c2w = cur_c2w if cur_c2w is not None else slam.estimate_c2w_list[idx].to(self.eng.device)
+        init = idx == 0
+        last = idx == slam.n_img - 1
+        color_refine = bool(last and self.color_refine and not init)
+        num_joint_iters, outer = (self.iters_first if init else self.num_joint_iters), 1
+        saved = None
+        if not init:
+            self.mapping_window_size = cfg['mapping']['mapping_window_size'] * (2 if slam.n_img > 4000 else 1)
+            if color_refine:
+                # end of the sequence (Mapper.py:884-897): every row of the map is trainable, only the features move (the colour
+                # decoder is frozen), ten times the iterations in five calls over a doubled window
+                saved = (self.mapping_window_size, self.geo_iter_ratio, self.fix_color_decoder, self.frustum_feature_selection,
+                         self.keyframe_selection_method)
+                outer = 5
+                self.mapping_window_size *= 2
+                self.geo_iter_ratio = 0.4
+                num_joint_iters *= 10
+                self.fix_color_decoder, self.frustum_feature_selection, self.keyframe_selection_method = True, False, 'segments'
+        num_joint_iters //= outer
+        for _ in range(outer):
+            self.optimize_map(num_joint_iters, idx, gt_color, gt_depth, gt_c2w, self.keyframe_dict, self.keyframe_list, cur_c2w,
+                              color_refine=color_refine)
+        if saved is not None and not self.keep_refine_settings:
+            (self.mapping_window_size, self.geo_iter_ratio, self.fix_color_decoder, self.frustum_feature_selection,
+             self.keyframe_selection_method) = saved
+        if (idx % self.keyframe_every == 0 or idx == slam.n_img - 2) and idx not in self.keyframe_list:
             self.keyframe_list.append(idx)
             self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': gt_color, 'depth': gt_depth, 'est_c2w': cur_c2w.clone(),
                                        'r2_query': getattr(self, 'cur_r2_query', None),
-                                       'exposure_feat': getattr(self, 'cur_exposure_feat', None)})
-        self.slam.mapping_idx[0] = idx
+                                       'exposure_feat': self.cur_exposure_feat.detach() if self.slam.encode_exposure else None})
+        self.prev_c2w = cur_c2w.clone()         # Mapper.py:1001
+        slam.mapping_idx[0] = idx
         return self.last_log
 
-    def run(self, time_string=None):
-        raise NotImplementedError('Point_SLAM.run drives map_frame / track_frame in one process')
+    def run(self, time_string=None, tracker=None, n_frames=None, callback=None):
+        """Mapper.run (Mapper.py:808-1049) in the single-process form: the reference's mapper blocks on a pipe until the tracker
+        has posed the next frame to map (frame 0, every `every_frame`-th, the last); here the loop itself asks the tracker
+        (Tracker.track_frame) for every frame in between, in order, and maps when the reference's mapper would wake up."""
+        slam = self.slam
+        tracker = tracker if tracker is not None else slam.tracker
+        n = n_frames or slam.n_img
+        for i in range(n):
+            idx, color, depth, c2w = slam.frame_reader[i]
+            est = tracker.track_frame(idx, color, depth, c2w)
+            if idx == 0 or idx % self.every_frame == 0 or idx == n - 1:
+                self.map_frame(idx, color, depth, c2w, cur_c2w=est)
+                if self.logger is not None and ((idx > 0 and idx % self.ckpt_freq == 0) or idx == n - 1):
+                    self.logger.log(idx, self.keyframe_dict, self.keyframe_list, npc=self.npc,
+                                    exposure_feat=None, last_log=(idx == n - 1))
+            if callback:
+                callback(idx, est, c2w)
+        return slam.estimate_c2w_list[:n], slam.gt_c2w_list[:n]
 
 
 def frame_radius_maps(eng, cfg, color):
@@ -545,6 +654,11 @@ class Tracker:
         self.gt_camera = t.get('gt_camera', False)
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self.sample_with_color_grad, self.depth_limit = t.get('sample_with_color_grad', False), t.get('depth_limit', False)
+        if not t.get('handle_dynamic', True):
+            raise NotImplementedError('tracking.handle_dynamic: False (median-of-residual mask, Tracker.py:177-179) is not built; every '
+                                      'reference config uses the uncertainty-normalised mask')
+        if self.depth_limit and not self.sample_with_color_grad:
+            raise NotImplementedError('tracking.depth_limit without sample_with_color_grad (Tracker.py:142-146) is not built')
         self.gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219) + 3)
         self.last_log = None
 
@@ -643,8 +757,11 @@ class Tracker:
         slam.idx[0] = idx
         return c2w
 
-    def run(self, time_string=None):
-        raise NotImplementedError('Point_SLAM.run drives map_frame / track_frame in one process')
+    def run(self, time_string=None, mapper=None, n_frames=None, callback=None):
+        """Tracker.run (Tracker.py:214-427) in the single-process form: the reference's tracker waits on a pipe for the mapper
+        after frame 0 and after every `every_frame`-th frame; here the same interleaving is one loop (Mapper.run), entered from
+        either side."""
+        return (mapper if mapper is not None else self.slam.mapper).run(time_string, tracker=self, n_frames=n_frames, callback=callback)
 
 
 # ============================================================================================ Point_SLAM
@@ -706,16 +823,7 @@ class Point_SLAM:
     def run(self, n_frames=None, callback=None):
         """Alternate tracking (every frame) and mapping (frame 0 and every `every_frame`-th), as the reference's
         two processes do through their pipe (Tracker.py:272-273,417-418; Mapper.py:836-842)."""
-        n = n_frames or self.n_img
-        every = self.cfg['mapping']['every_frame']
-        for i in range(n):
-            idx, color, depth, c2w = self.frame_reader[i]
-            est = self.tracker.track_frame(idx, color, depth, c2w)
-            if idx == 0 or idx % every == 0 or idx == n - 1:
-                self.mapper.map_frame(idx, color, depth, c2w, cur_c2w=est)
-            if callback:
-                callback(idx, est, c2w)
-        return self.estimate_c2w_list[:n], self.gt_c2w_list[:n]
+        return self.mapper.run(tracker=self.tracker, n_frames=n_frames, callback=callback)
 
 
 # ============================================================================================ checkpoints
@@ -779,6 +887,16 @@ class Logger:
         slam_obj.gt_c2w_list[:] = ck['gt_c2w_list']
         slam_obj.estimate_c2w_list[:] = ck['estimate_c2w_list']
         slam_obj.mapper.keyframe_list = list(ck['keyframe_list'])
-        slam_obj.mapper.keyframe_dict = [{k: (v.to(eng.device) if torch.is_tensor(v) else v) for k, v in kf.items()}
-                                         for kf in ck['keyframe_dict']]
+        kfs = []
+        for kf in ck['keyframe_dict']:
+            kf = {k: (v.to(eng.device) if torch.is_tensor(v) else v) for k, v in kf.items()}
+            if 'r2_query' not in kf and kf.get('dynamic_r_query') is not None:
+                # a checkpoint written by the reference: per-pixel RADIUS (float64); the kernels take its square in float32
+                kf['r2_query'] = (kf['dynamic_r_query'].double() ** 2).float().contiguous()
+            kfs.append(kf)
+        slam_obj.mapper.keyframe_dict = kfs
+        if 'geo_feats' not in ck and n:
+            import warnings
+            warnings.warn(f'{path}: no geo_feats / col_feats in this checkpoint (the reference only writes them with last_log): '
+                          'the feature tables of the restored map are zero')
         return ck['idx']

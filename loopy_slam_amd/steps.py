@@ -53,8 +53,8 @@ class RayBatch:
 class ExposureState:
     """model.encode_exposure (ScanNet): mlp_exposure (Linear 8->128, Softplus(100), Linear 128->12; decoder.py:534-540) and
     the exposure features it is applied to - the tracker's frame (Tracker.py:329-344) or the keyframes of the mapping
-    window (Mapper.py:588-607) - evaluated, differentiated and stepped (Adam, lr 1e-3) by kernels: lk_exposure_fwd /
-    lk_exposure_bwd + five lk_adam_step segments.  The torch module's parameters are updated IN PLACE (they stay the
+    window (Mapper.py:588-607) - evaluated, differentiated and stepped by kernels: lk_exposure_fwd / lk_exposure_bwd + up to five
+    lk_adam_step segments (which of them step, and at which rate: adam_segs).  The torch module's parameters are updated IN PLACE (they stay the
     owner for state_dict); several features are stacked into one [F,8] buffer and written back by finish()."""
 
     LR = 0.001
@@ -85,10 +85,23 @@ class ExposureState:
         e.lib.check(e.lib.dll.lk_exposure_bwd(ptr(self.feats), ptr(self.W1), ptr(self.W2), ptr(self.hid), ptr(g_aff), self.F,
                                               ptr(self.g), e.stream), 'lk_exposure_bwd')
 
-    def adam_segs(self):
+    def adam_segs(self, mlp_lr=None, only_last_feature=False):
+        """Tracker (Tracker.py:329-344): the frame's feature and mlp_exposure both at lr 1e-3 (defaults).
+        Mapper (Mapper.py:524-570): mlp_exposure is part of color_decoder.parameters() - it steps at the stage's decoders_lr
+        (mlp_lr; None = frozen with fix_color_decoder) - and ONLY the current frame's feature (the last one of the window) is an
+        Adam parameter (lr 1e-3); the keyframes' features are constants."""
         g, lr = self.g, self.LR
-        return [('xW1', self.W1.view(-1), g[0:1024], lr), ('xb1', self.b1, g[1024:1152], lr), ('xW2', self.W2.view(-1), g[1152:2688], lr),
-                ('xb2', self.b2, g[2688:2700], lr), ('xf', self.feats.view(-1), g[2700:2700 + self.F * 8], lr)]
+        segs = []
+        if mlp_lr is not False:
+            ml = lr if mlp_lr is None else mlp_lr
+            segs += [('xW1', self.W1.view(-1), g[0:1024], ml), ('xb1', self.b1, g[1024:1152], ml), ('xW2', self.W2.view(-1), g[1152:2688], ml),
+                     ('xb2', self.b2, g[2688:2700], ml)]
+        if only_last_feature:
+            k = self.F - 1
+            segs.append(('xf', self.feats.view(-1)[8 * k:8 * k + 8], g[2700 + 8 * k:2700 + 8 * k + 8], lr))
+        else:
+            segs.append(('xf', self.feats.view(-1), g[2700:2700 + self.F * 8], lr))
+        return segs
 
     def finish(self):
         if not self.single:
@@ -120,6 +133,7 @@ class MapOptimizer:
             ['color_decoder.embedder_rel_pos._B']
         if not cfg.rel_pos:
             cnames = [n for n in cnames if 'mlp_col_neighbor' not in n and 'embedder_rel_pos' not in n]
+        self.fix_color_decoder = fix_color_decoder
         self.geo_dec_ranges = dec.param_ranges(list(GEO_DECODER_PARAMS))
         self.col_dec_ranges = dec.param_ranges(cnames)
         self.loss_log = None
@@ -172,7 +186,7 @@ class MapOptimizer:
                 segs.append(('col', self.col.view(-1), gs.g_col.view(-1), clr))
         if xs is not None:
             xs.backward(xs.g_aff)
-            segs += xs.adam_segs()
+            segs += xs.adam_segs(mlp_lr=False if self.fix_color_decoder else dlr, only_last_feature=True)
         self.adam.step(segs, zero_grad=True)
         if stage == 'color':
             # the geometry stage only moves the embedding matrices (read from the plain blob); the MFMA fragments are

@@ -533,3 +533,86 @@ def sample_near_pcl(rays_o, rays_d, near, far, num, cloud_pos, radius_query, int
         c = np.nonzero(sup[r])[0]
         z[r] = np.linspace(sect[c[0]], sect[c[1]], num=num)          # item[0], item[1]: the first TWO supported probes
     return z.astype(np.float32), invalid
+
+
+# ------------------------------------------------------------------ point-insertion schedule of a mapped frame
+def filter_point_before_add(rays_o, rays_d, gt_depth, prev_c2w, fx, fy, cx, cy, H, W):
+    """Mapper.filter_point_before_add (src/Mapper.py:137-163): True for rays whose surface point falls OUTSIDE the image of
+    the previously mapped pose.  float32 world->camera product, float64 intrinsics product, uv cast to float32."""
+    pts = (torch.as_tensor(rays_o) + torch.as_tensor(rays_d) * torch.as_tensor(gt_depth)[:, None]).reshape(-1, 3).numpy().astype(np.float32)
+    w2c = np.linalg.inv(np.asarray(prev_c2w, np.float32))
+    homo = np.concatenate([pts, np.ones_like(pts[:, :1])], axis=1).reshape(-1, 4, 1)
+    cam = (w2c @ homo)[:, :3]
+    K = np.array([[fx, .0, cx], [.0, fy, cy], [.0, .0, 1.0]])
+    cam[:, 0] *= -1
+    uv = K @ cam
+    z = uv[:, -1:] + 1e-5
+    uv = (uv[:, :2] / z).astype(np.float32)[..., 0]
+    inside = (uv[:, 0] < W) & (uv[:, 0] > 0) & (uv[:, 1] < H) & (uv[:, 1] > 0)
+    return torch.from_numpy(~inside)
+
+
+def first_frame_add_count(gt_depth_img, pixels_adding):
+    """idx == 0: clamp(pixels_adding * (median(depth) / 2.5)^2, pixels_adding, 3 pixels_adding) (Mapper.py:421-425);
+    torch.median = lower median over the whole image, zeros included."""
+    d = torch.as_tensor(gt_depth_img, dtype=torch.float32)
+    return int(torch.clamp(pixels_adding * ((d.median() / 2.5) ** 2), min=pixels_adding, max=pixels_adding * 3).int().item())
+
+
+def mapping_iterations(num_joint_iters, frame_pts_add, min_iter_ratio):
+    """idx > 0: clip(int(iters * added / 300), int(min_iter_ratio * iters), 2 iters) (Mapper.py:572-574)."""
+    return int(np.clip(int(num_joint_iters * frame_pts_add / 300), int(min_iter_ratio * num_joint_iters), 2 * num_joint_iters))
+
+
+def add_points_schedule(idx, depth_img, color_img, c2w, prev_c2w, cloud_pos, intr, cfg, draws, r_add_map=None):
+    """The insertion passes of one mapped frame (src/Mapper.py:421-482) on explicit pixel draws:
+      idx == 0 (or filter_before_add_points off): ONE pass over `draws['main']` (first_frame_add_count of them for idx == 0);
+      idx > 0: the main draws restricted to surface points OUTSIDE the previous view, then `draws['overlap']` (1000 pixels)
+               restricted to points INSIDE it - holes in already seen areas get refilled;
+      pixels_based_on_color_grad > 0: `draws['grad']` (flat indices of high-gradient pixels, sorted) with is_pts_grad
+               (radius_min instead of radius_add unless a dynamic radius map is given).
+    Every pass tests against the cloud INCLUDING the points of the passes before it (add_neural_points re-indexes).
+    cfg: dict(pixels_adding, pixels_grad, radius_add, radius_min, near, far, filter_before).  draws are flat indices into
+    the H x W image.  Returns (frame_pts_add, per-pass accepted counts, grown cloud [N', 3])."""
+    fx, fy, cx, cy = intr
+    depth = torch.as_tensor(depth_img, dtype=torch.float32)
+    Hh, Ww = depth.shape
+    cloud = torch.as_tensor(cloud_pos, dtype=torch.float32).reshape(-1, 3)
+    counts = []
+
+    def rays(flat):
+        flat = torch.as_tensor(flat).long()
+        i, j = (flat % Ww).float(), torch.div(flat, Ww, rounding_mode='floor').float()
+        ro, rd = rays_from_uv(i, j, torch.as_tensor(c2w, dtype=torch.float32), fx, fy, cx, cy)
+        gd = depth.reshape(-1)[flat]
+        keep = gd > 0                                          # get_samples(depth_filter=True)
+        r = None if r_add_map is None else torch.as_tensor(r_add_map).reshape(-1)[flat][keep]
+        return ro[keep], rd[keep], gd[keep], r
+
+    def insert(ro, rd, gd, r, pts_grad):
+        nonlocal cloud
+        if ro.shape[0] == 0:
+            counts.append(0)
+            return
+        if r is not None:
+            r2 = (r.double() ** 2).float().numpy()
+        else:
+            r2 = np.float32((cfg['radius_min'] if pts_grad else cfg['radius_add']) ** 2)
+        acc, pts = add_points(ro, rd, gd, cloud.numpy(), r2, cfg['near'], cfg['far'])
+        cloud = torch.cat([cloud, pts])
+        counts.append(int(acc.shape[0]))
+
+    n_main = first_frame_add_count(depth, cfg['pixels_adding']) if idx == 0 else cfg['pixels_adding']
+    ro, rd, gd, r = rays(draws['main'][:n_main])
+    if cfg['filter_before'] and idx != 0:
+        out = filter_point_before_add(ro, rd, gd, prev_c2w, fx, fy, cx, cy, Hh, Ww)
+        insert(ro[out], rd[out], gd[out], None if r is None else r[out], False)
+        ro, rd, gd, r = rays(draws['overlap'])
+        out = filter_point_before_add(ro, rd, gd, prev_c2w, fx, fy, cx, cy, Hh, Ww)
+        insert(ro[~out], rd[~out], gd[~out], None if r is None else r[~out], False)
+    else:
+        insert(ro, rd, gd, r, False)
+    if cfg['pixels_grad'] > 0:
+        ro, rd, gd, r = rays(draws['grad'])
+        insert(ro, rd, gd, r, True)
+    return sum(counts), counts, cloud

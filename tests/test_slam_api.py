@@ -195,3 +195,121 @@ def test_point_slam_exposure_config(backend):
     assert float(ps.exposure_feat.abs().max()) > 0 and float(kfs[0]['exposure_feat'].detach().abs().max()) > 0       # both moved off zero
     assert float((ps.shared_decoders.mlp_exposure[2].bias.detach() - w0).abs().max()) > 0
     assert torch.isfinite(ps.mapper.last_log.cpu()).all() and torch.isfinite(ps.tracker.last_log.cpu()).all()
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_add_points_schedule_matches_oracle(backend):
+    """Mapper.optimize_map's insertion passes (src/Mapper.py:421-482): first-frame count scaling, non-overlapping area,
+    1000 overlap samples, colour-gradient pixels with radius_min - accepted counts per pass, frame_pts_add, the grown cloud
+    (bit for bit) and the iteration count derived from it (Mapper.py:572-574) against the oracle restatement on the SAME
+    pixel draws."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['mapping'].update(pixels_adding=300, pixels_based_on_color_grad=40, iters=6)
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    mp, pc = ps.mapper, cfg['pointcloud']
+    ocfg = dict(pixels_adding=300, pixels_grad=40, radius_add=pc['radius_add'], radius_min=pc['radius_min'],
+                near=pc['near_end_surface'], far=pc['far_end_surface'], filter_before=True)
+    intr = (ps.fx, ps.fy, ps.cx, ps.cy)
+    prev = None
+    for idx in (0, 2):
+        _, color, depth, c2w = ps.frame_reader[idx]
+        draws = mp.draw_add_pixels(idx, depth, color)
+        if idx == 0:
+            assert draws['main'].numel() == H.first_frame_add_count(depth.cpu(), 300) and 300 <= draws['main'].numel() <= 900
+        # the gradient pool draw: n distinct pixels among the 5n largest gradient magnitudes, sorted (common.py:175-196)
+        g = H.color_grad_mag(color.cpu().numpy())
+        pool = set(H.top_grad_pixels(g, 5 * 40, (0, ps.H, 0, ps.W)).tolist())
+        gd_ = draws['grad'].cpu().tolist()
+        assert len(gd_) == 40 == len(set(gd_)) and gd_ == sorted(gd_) and set(gd_) <= pool
+        before = ps.npc.cloud_pos().cpu().clone()
+        total, counts = mp.add_points_for_frame(idx, color, depth, c2w, draws=draws)
+        o_total, o_counts, o_cloud = H.add_points_schedule(idx, depth.cpu(), color.cpu(), c2w.cpu(), prev, before, intr, ocfg,
+                                                           {k: v.cpu() for k, v in draws.items()})
+        assert counts == o_counts and total == o_total, (idx, counts, o_counts)
+        assert len(counts) == (2 if idx == 0 else 3) and total > 0
+        assert torch.equal(ps.npc.cloud_pos().cpu(), o_cloud)
+        mp.prev_c2w = c2w.clone()
+        prev = c2w.cpu()
+    # the iteration count of a mapped frame follows from what was added (and is clipped on both sides)
+    _, color, depth, c2w = ps.frame_reader[3]
+    n0 = ps.npc.pts_num()
+    mp.optimize_map(6, 3, color, depth, c2w, mp.keyframe_dict, mp.keyframe_list, c2w)
+    assert mp.last_frame_pts_add == (ps.npc.pts_num() - n0) // 3 == sum(mp.last_add_counts)
+    assert mp.last_num_joint_iters == H.mapping_iterations(6, mp.last_frame_pts_add, cfg['mapping']['min_iter_ratio'])
+    assert tuple(mp.last_log.shape) == (mp.last_num_joint_iters, 4)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_final_refinement_optimises_the_whole_map(backend):
+    """mapping.color_refine (Mapper.py:884-897): on the last frame every row of the map is trainable (no frustum selection),
+    the colour decoder is frozen, ten times the iterations in five optimize_map calls, no points are added."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['mapping'].update(iters=2, color_refine=True)
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    calls = []
+    orig = ps.mapper.optimize_map
+
+    def spy(num_joint_iters, idx, *a, **k):
+        n0 = ps.npc.pts_num()
+        geo0 = ps.npc.get_geo_feats().clone()
+        w0 = ps.shared_decoders.dec.blob.clone()
+        r = orig(num_joint_iters, idx, *a, **k)
+        moved = (ps.npc.get_geo_feats()[:n0] != geo0).any(1)
+        calls.append(dict(idx=idx, iters=num_joint_iters, refine=k.get('color_refine', False), added=ps.npc.pts_num() - n0,
+                          frac_moved=float(moved.float().mean()), w_moved=int((ps.shared_decoders.dec.blob != w0).sum())))
+        return r
+    ps.mapper.optimize_map = spy
+    ps.run()
+    last = [c for c in calls if c['idx'] == 3]
+    assert len(last) == 5 and all(c['refine'] and c['iters'] == 2 * 10 // 5 and c['added'] == 0 for c in last)
+    # rows far outside the last frustum moved too; only the two embedding matrices of the decoders may change (fix_color_decoder)
+    assert min(c['frac_moved'] for c in last) > 0.5
+    normal = [c for c in calls if c['idx'] == 0][0]         # first frame: iters_first with colour iterations, all decoder weights move
+    assert not normal['refine'] and normal['w_moved'] > 1000 and max(c['w_moved'] for c in last) <= 3 * 96 + 30
+
+
+def test_get_tensor_from_camera_matches_reference_golden():
+    """common.get_tensor_from_camera (src/common.py:354-379) - the product function, not the oracle's - against the
+    reference's outputs captured in tests/golden/g3_pose.npz, and its round trip through get_camera_from_tensor."""
+    from loopy_slam_amd import common
+    from util import load
+    g = load('g3_pose')                   # cams -> c2w by the reference's get_camera_from_tensor, back = its get_tensor_from_camera(c2w)
+    c2w, ref = torch.from_numpy(g['c2w']), g['back']
+    for k in range(c2w.shape[0]):
+        m = torch.eye(4)
+        m[:3] = c2w[k]
+        cam = common.get_tensor_from_camera(m)
+        assert cam.dtype == torch.float32 and cam.shape == (7,)
+        np.testing.assert_allclose(cam.numpy(), ref[k], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(common.get_camera_from_tensor(cam).numpy(), m[:3].numpy(), rtol=0, atol=2e-6)
+        tq = common.get_tensor_from_camera(m, Tquad=True)
+        assert torch.equal(tq[:3], cam[4:]) and torch.equal(tq[3:], cam[:4])
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_load_reference_shaped_checkpoint(backend, tmp_path):
+    """A checkpoint as the REFERENCE writes it mid-run (src/utils/Logger.py:20-65): keyframes carry `dynamic_r_query` (a radius,
+    float64) instead of our squared float32 map, and there are no feature tables - load() converts the former and warns about
+    the latter."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['use_dynamic_radius'] = True
+    cfg['pointcloud'].update(radius_add_max=0.08, radius_add_min=0.02, radius_query_ratio=2, color_grad_threshold=0.15)
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    ps.run(n_frames=3)
+    lg = slam.Logger(cfg, None, ps.mapper, ckptsdir=str(tmp_path))
+    path = lg.log(2, ps.mapper.keyframe_dict, ps.mapper.keyframe_list, npc=ps.npc, last_log=False)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    for kf in ck['keyframe_dict']:
+        kf['dynamic_r_query'] = torch.sqrt(kf.pop('r2_query').double())
+    torch.save(ck, path, _use_new_zipfile_serialization=False)
+    ps2 = slam.Point_SLAM(cfg, None, eng=eng)
+    with pytest.warns(UserWarning, match='no geo_feats'):
+        assert slam.Logger.load(path, ps2) == 2
+    for a, b in zip(ps2.mapper.keyframe_dict, ps.mapper.keyframe_dict):
+        np.testing.assert_allclose(a['r2_query'].cpu().numpy(), b['r2_query'].cpu().numpy(), rtol=2e-7)
+    _, color, depth, c2w = ps.frame_reader[3]
+    ps2.tracker.track_frame(3, color, depth, c2w)
+    ps2.mapper.map_frame(3, color, depth, c2w)                    # would raise KeyError: 'r2_query' without the conversion

@@ -266,8 +266,10 @@ def test_exposure_iterations_match_oracle(backend):
         Wm[n].requires_grad_(True)
     geo_p, col_p = geo[rows.long()].clone().requires_grad_(True), col[rows.long()].clone().requires_grad_(True)
     fo = [f.clone().requires_grad_(True) for f in feats0]
-    opt = torch.optim.Adam([{'params': [Wm[n] for n in train], 'lr': 0.005}, {'params': [geo_p], 'lr': 0.005}, {'params': [col_p], 'lr': 0.005},
-                            {'params': fo, 'lr': 0.001}, {'params': [v for k, v in Wm.items() if 'mlp_exposure' in k], 'lr': 0.001}])
+    # Mapper.py:524-570: mlp_exposure belongs to color_decoder.parameters() (decoders_lr of the stage); only the CURRENT frame's
+    # exposure feature (the last of the window) is an Adam parameter (lr 1e-3), the keyframe's is a constant
+    opt = torch.optim.Adam([{'params': [Wm[n] for n in train] + [v for k, v in Wm.items() if 'mlp_exposure' in k], 'lr': 0.005},
+                            {'params': [geo_p], 'lr': 0.005}, {'params': [col_p], 'lr': 0.005}, {'params': [fo[-1]], 'lr': 0.001}])
     om_losses = []
     mcfg = H.RenderCfg(rel_pos=False, exposure=True)
     for it in range(iters_m):
@@ -303,3 +305,6 @@ def test_exposure_iterations_match_oracle(backend):
     np.testing.assert_allclose(km, om_losses, rtol=5e-4)
     for a, b in zip(fk, fo):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), atol=2e-4)
+    assert torch.equal(fk[0].detach().cpu(), feats0[0])                                     # the keyframe's feature is a constant
+    assert float((fk[1].detach().cpu() - feats0[1]).abs().max()) > 1e-4                    # the current frame's moved
+    np.testing.assert_allclose(mlp2[2].bias.detach().cpu().numpy(), Wm['color_decoder.mlp_exposure.linear2.bias'].detach().numpy(), atol=3e-4)
