@@ -1,5 +1,5 @@
-"""YAML configuration with the reference's `inherit_from` recursive merge (src/config.py:10-56) and
-`get_model` (src/config.py:60-74 -> src/conv_onet/config.py:4-22)."""
+"""YAML configuration: a chain of files linked by `inherit_from`, merged key by key with the most specific file winning
+(the reference's semantics, src/config.py:10-56), and `get_model` (src/config.py:60-74 -> src/conv_onet/config.py:4-22)."""
 import os
 
 import yaml
@@ -7,32 +7,39 @@ import yaml
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _resolve(path):
-    return path if os.path.isabs(path) or os.path.exists(path) else os.path.join(_ROOT, path)
+def _read(path):
+    if not (os.path.isabs(path) or os.path.exists(path)):
+        path = os.path.join(_ROOT, path)
+    with open(path, 'r') as f:
+        return yaml.full_load(f) or {}
 
 
 def update_recursive(dst, src):
-    for k, v in src.items():
-        if k not in dst:
-            dst[k] = dict()
-        if isinstance(v, dict):
-            update_recursive(dst[k], v)
-        else:
-            dst[k] = v
+    """Deep merge of `src` into `dst` in place: nested mappings are merged, everything else is overwritten."""
+    stack = [(dst, src)]
+    while stack:
+        into, frm = stack.pop()
+        for key, val in frm.items():
+            if isinstance(val, dict):
+                if not isinstance(into.get(key), dict):
+                    into[key] = {}
+                stack.append((into[key], val))
+            else:
+                into[key] = val
+    return dst
 
 
 def load_config(path, default_path=None):
-    with open(_resolve(path), 'r') as f:
-        special = yaml.full_load(f)
-    parent = special.get('inherit_from')
-    if parent is not None:
-        cfg = load_config(parent, default_path)
-    elif default_path is not None:
-        with open(_resolve(default_path), 'r') as f:
-            cfg = yaml.full_load(f)
-    else:
-        cfg = dict()
-    update_recursive(cfg, special)
+    """Follow `inherit_from` from `path` to the root of the chain (the root falls back on `default_path`), then merge from the
+    most general file down to `path`."""
+    chain, nxt = [], path
+    while nxt is not None:
+        doc = _read(nxt)
+        chain.append(doc)
+        nxt = doc.get('inherit_from')
+    cfg = _read(default_path) if default_path is not None else {}
+    for doc in reversed(chain):
+        update_recursive(cfg, doc)
     return cfg
 
 

@@ -28,6 +28,8 @@ class DistContext:
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
         self._bucket = None
+        self._touched = None
+        self._keep = None
 
     def all_reduce_grads(self, mo, stage='color'):
         """mo: steps.MapOptimizer after render_backward.  Sum over ranks exactly what this stage's Adam step consumes:
@@ -45,13 +47,12 @@ class DistContext:
         for k, (o, cnt) in enumerate(ranges):
             segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(gs.g_weights[o:o + cnt]), cnt, None, 1
             n += cnt
+        rows = mo.rows if mo.rows is not None else self.touched_rows(mo)
         for k, t in enumerate(tables, start=len(ranges)):
-            if mo.rows is not None:
-                segs[k].data, segs[k].n = ptr(t), mo.rows.numel() * t.shape[1]
-                segs[k].row_index, segs[k].row_len = ptr(mo.rows), t.shape[1]
-            else:
-                segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(t), t.numel(), None, 1
+            segs[k].data, segs[k].n = ptr(t), rows.numel() * t.shape[1]
+            segs[k].row_index, segs[k].row_len = ptr(rows), t.shape[1]
             n += segs[k].n
+        self._keep = rows
         if xs is not None:
             k = len(ranges) + len(tables)
             segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(xs.g_aff), xs.g_aff.numel(), None, 1
@@ -61,6 +62,23 @@ class DistContext:
         eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(self._bucket), 0, eng.stream), 'lk_bucket_copy')
         dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
         eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(self._bucket), 1, eng.stream), 'lk_bucket_copy')
+
+    def touched_rows(self, mo):
+        """Whole-map optimisation (rows = None: the final refinement, Mapper.py:884-897): a batch of R rays touches at most
+        8 R S rows of the N-row tables, the rest of both gradient tables is exactly zero on every rank.  Exchanging the tables
+        themselves would be 256 B x N per iteration (1.28 GB at 5 M points); instead the ranks agree on the UNION of
+        the rows they touched - one MAX all-reduce of an N-byte flag vector (5 MB) - and only those rows ride in the bucket.
+        Returns the sorted int32 row list (identical on every rank)."""
+        st = mo.st
+        N = mo.geo.shape[0]
+        if self._touched is None or self._touched.numel() != N:
+            self._touched = torch.zeros(N, dtype=torch.uint8, device=mo.geo.device)
+        else:
+            self._touched.zero_()
+        idx = st.nbr_idx.reshape(-1)
+        self._touched[idx[idx >= 0].long()] = 1
+        dist.all_reduce(self._touched, op=dist.ReduceOp.MAX)
+        return torch.nonzero(self._touched).reshape(-1).to(torch.int32)
 
     def all_reduce_vec(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

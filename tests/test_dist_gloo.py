@@ -22,7 +22,7 @@ LRS = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
 STAGES = ['geometry', 'color']
 
 
-def build(eng, R_batch, dctx):
+def build(eng, R_batch, dctx, all_rows=False):
     from loopy_slam_amd import core, steps, synthetic as syn
     from test_steps_parity import mini_scene
     c2w, depth_img, color_img, pos, geo, col = mini_scene(3)
@@ -33,7 +33,7 @@ def build(eng, R_batch, dctx):
     knn = core.KnnIndex(eng, capacity=pos.shape[0])
     knn.build(pos_d)
     rows = torch.arange(0, pos.shape[0], 3, dtype=torch.int32)
-    mo = steps.MapOptimizer(eng, core.RenderCfg(rel_pos=True), dec, knn, pos_d, geo_d, col_d, rows.to(eng.device), R_batch, LRS,
+    mo = steps.MapOptimizer(eng, core.RenderCfg(rel_pos=True), dec, knn, pos_d, geo_d, col_d, None if all_rows else rows.to(eng.device), R_batch, LRS,
                             w_color=0.1, dist=dctx)
     mo.begin_frame()
     frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
@@ -45,16 +45,16 @@ def draws():
     return torch.randint(0, HH * WW, (ITERS, 2, R), generator=g, dtype=torch.int32)
 
 
-def worker(rank, port, q):
+def worker(rank, port, q, all_rows=False):
     try:
-        _worker(rank, port, q)
+        _worker(rank, port, q, all_rows)
     except Exception:                                   # surface the reason in the parent instead of a bare exit code
         import traceback
         q.put(('error', rank, traceback.format_exc()))
         raise
 
 
-def _worker(rank, port, q):
+def _worker(rank, port, q, all_rows=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.set_num_threads(1)
@@ -62,15 +62,21 @@ def _worker(rank, port, q):
     from loopy_slam_amd import parallel
     from util import make_engine
     eng = make_engine('emu')
-    mo, frames, dec, geo_d, col_d = build(eng, R, parallel.DistContext(rank, 2))
+    mo, frames, dec, geo_d, col_d = build(eng, R, parallel.DistContext(rank, 2), all_rows)
     rnd = draws()
     fid = torch.zeros(R, dtype=torch.int32)
     losses = []
-    for it in range(ITERS):
-        out4 = mo.iterate(STAGES[it], frames, rnd[it, rank].contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
-        t = out4.clone()
-        dist.all_reduce(t)
-        losses.append(float(t[0]))
+    if all_rows:        # the native loop (lk_map_frame) split around the exchange, whole-map rows: touched-row bucket
+        log = torch.zeros(ITERS, 4)
+        mo.run(ITERS, 1, frames, rnd[:, rank].contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW, log)
+        dist.all_reduce(log)
+        losses = [float(x) for x in log[:, 0]]
+    else:
+        for it in range(ITERS):
+            out4 = mo.iterate(STAGES[it], frames, rnd[it, rank].contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
+            t = out4.clone()
+            dist.all_reduce(t)
+            losses.append(float(t[0]))
     if rank == 0:
         q.put((losses, dec.blob.clone(), geo_d.clone(), col_d.clone()))
     else:
@@ -79,11 +85,14 @@ def _worker(rank, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_grad_allreduce_matches_single_process():
+@pytest.mark.parametrize('all_rows', (False, True))
+def test_two_rank_grad_allreduce_matches_single_process(all_rows):
+    """all_rows: every row of the map is a parameter (final refinement) - the ranks exchange the union of the touched rows, and
+    both sides run the native loop (lk_map_frame, split around the all-reduce on the two-rank side)."""
     from util import make_engine
     torch.set_num_threads(1)
     eng = make_engine('emu')
-    mo, frames, dec, geo_d, col_d = build(eng, 2 * R, None)
+    mo, frames, dec, geo_d, col_d = build(eng, 2 * R, None, all_rows)
     rnd = draws()
     fid = torch.zeros(2 * R, dtype=torch.int32)
     ref_losses = []
@@ -98,7 +107,7 @@ def test_two_rank_grad_allreduce_matches_single_process():
         s.close()
         ctx = mp.get_context('spawn')
         q = ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, port, q)) for r in range(2)]
+        procs = [ctx.Process(target=worker, args=(r, port, q, all_rows)) for r in range(2)]
         for p in procs:
             p.start()
         try:

@@ -226,3 +226,88 @@ def test_forward_spot_check_vs_oracle(N, rel_pos):
         o = H.render_batch(A.ocfg(rel_pos), b['rays_o'], b['rays_d'], b['gt_depth'], pos, geo, col, W, 'color', knn=kn)
     _check_forward(st, o, case, b['gt_depth'])
     assert int((b['gt_depth'] == 0).sum()) > 100          # the zero-depth sampling branch was exercised
+
+
+def test_whole_map_refinement_iterations_at_5m_points():
+    """BASELINE config 5 (ScanNet scene0054, ~5 M points): the final refinement optimises EVERY row of the map with the colour
+    decoder frozen (Mapper.py:884-897) - lk_map_frame with rows = NULL, 10 000-ray batches.  Three iterations (one geometry,
+    two colour) against an oracle loop with torch.optim.Adam whose parameters are the rows those batches touch (all other rows
+    have an exactly zero gradient, which Adam leaves in place), then a 10-iteration call for the counts / finiteness."""
+    from loopy_slam_amd import steps
+    N, R, iters = 5_000_000, 10_000, 3
+    eng = make_engine('hip')
+    (pos, geo, col, W), (dpos, dgeo, dcol, knn, dec) = _gpu_scene(eng, N, False)
+    lrs = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
+    cfg = core.RenderCfg(rel_pos=False)
+    Hh, Ww = A.I['H'], A.I['W']
+    frames_cpu = [syn.render_frame(k, device='cpu', holes=0.0) for k in (3, 9)]
+    stack = (eng.f32(torch.stack([f[0] for f in frames_cpu])), eng.f32(torch.stack([f[1] for f in frames_cpu])),
+             eng.f32(torch.stack([f[2] for f in frames_cpu])), None)
+    g = torch.Generator().manual_seed(54)
+    rnd = torch.randint(0, Hh * Ww, (10, R), generator=g, dtype=torch.int32)
+    fid = (torch.arange(R) // (R // 2)).to(torch.int32)
+    geo0, col0, blob0 = dgeo.clone(), dcol.clone(), dec.blob.clone()
+    mo = steps.MapOptimizer(eng, cfg, dec, knn, dpos, dgeo, dcol, None, R, lrs, w_color=0.1, fix_color_decoder=True)
+    mo.begin_frame()
+    log = eng.zeros(iters, 4)
+    mo.run(iters, 1, stack, rnd[:iters].to(eng.device), fid.to(eng.device), (0, Hh, 0, Ww), A.INTR, Hh, Ww, log)
+    torch.cuda.synchronize()
+    # ---- oracle loop on the touched rows
+    ocfg = A.ocfg(False)
+    batches, touched = [], []
+    for it in range(iters):
+        px = rnd[it].long()
+        i, j = (px % Ww).float(), (px // Ww).float()
+        ro = torch.empty(R, 3); rd = torch.empty(R, 3); gd = torch.empty(R); gc = torch.empty(R, 3)
+        for f in range(2):
+            m = fid == f
+            o_, d_ = H.rays_from_uv(i[m], j[m], frames_cpu[f][2], *A.INTR)
+            ro[m], rd[m] = o_, d_
+            gd[m] = frames_cpu[f][0].reshape(-1)[px[m]]
+            gc[m] = frames_cpu[f][1].reshape(-1, 3)[px[m]]
+        z, _ = H.sample_z(gd, 0.98, 1.02, 0.3, 5)
+        kn = A.contract_knn(pos, H.sample_points(ro, rd, z), np.float32(0.08 ** 2))[:3]
+        batches.append((ro, rd, gd, gc, kn))
+        touched.append(torch.from_numpy(kn[1][kn[1] >= 0]).long())
+    U = torch.unique(torch.cat(touched))
+    remap = torch.full((N,), -1, dtype=torch.long)
+    remap[U] = torch.arange(U.numel())
+    geo_p, col_p = geo[U].clone().requires_grad_(True), col[U].clone().requires_grad_(True)
+    Wt = {k: v.clone() for k, v in W.items()}
+    Wt['geo_decoder.embedder._B'].requires_grad_(True)             # fix_color_decoder: only the embedding matrices stay trainable
+    opt = torch.optim.Adam([{'params': [Wt['geo_decoder.embedder._B']], 'lr': 0}, {'params': [geo_p], 'lr': 0}, {'params': [col_p], 'lr': 0}])
+    o_losses = []
+    for it in range(iters):
+        stage = 'geometry' if it < 1 else 'color'
+        for gi in range(3):
+            opt.param_groups[gi]['lr'] = lrs[stage][gi]
+        opt.zero_grad()
+        ro, rd, gd, gc, kn = batches[it]
+        kn_l = (kn[0], np.where(kn[1] >= 0, remap[torch.from_numpy(np.maximum(kn[1], 0)).long()].numpy(), -1).astype(np.int32), kn[2])
+        out = H.render_batch(ocfg, ro, rd, gd, pos[U], geo_p, col_p, Wt, stage, knn=kn_l)
+        loss = H.mapper_loss(out['depth'], out['color'], out['valid_ray'], gd, gc, stage, 0.1)[0]
+        loss.backward()
+        opt.step()
+        o_losses.append(float(loss))
+    k_losses = log[:, 0].cpu().numpy()
+    _record('refine-5M', losses_rel=float(np.abs(k_losses - np.array(o_losses)).max() / max(o_losses)), touched_rows=int(U.numel()))
+    np.testing.assert_allclose(k_losses, o_losses, rtol=2e-4)
+    # untouched rows: bit-identical; touched rows: Adam's sign-like first steps bound the tail (tests/test_steps_parity.py)
+    other = torch.ones(N, dtype=torch.bool); other[U] = False
+    assert torch.equal(dgeo.cpu()[other], geo[other]) and torch.equal(dcol.cpu()[other], col[other])
+    for mine, ref, lr in ((dgeo.cpu()[U], geo_p.detach(), 0.03), (dcol.cpu()[U], col_p.detach(), 0.005)):
+        err = (mine - ref).abs().reshape(-1)
+        assert float(torch.quantile(err[:4_000_000], 0.99)) < 2e-5 and float(err.max()) < 2.0 * lr * iters
+    assert float((dgeo.cpu()[U] - geo[U]).abs().max()) > 1e-3
+    # the colour decoder did not move (only embedder._B may)
+    moved = torch.nonzero(dec.blob != blob0).reshape(-1)
+    o_b, n_b = dec.segment('geo_decoder.embedder._B')
+    assert moved.numel() > 0 and int(moved.min()) >= o_b and int(moved.max()) < o_b + n_b
+    # ---- the full 10-iteration refinement call of one optimize_map (geo_iter_ratio 0.4 -> 5 geometry iterations)
+    mo2 = steps.MapOptimizer(eng, cfg, dec, knn, dpos, dgeo, dcol, None, R, lrs, w_color=0.1, fix_color_decoder=True)
+    mo2.begin_frame()
+    log2 = eng.zeros(10, 4)
+    mo2.run(10, 5, stack, rnd.to(eng.device), fid.to(eng.device), (0, Hh, 0, Ww), A.INTR, Hh, Ww, log2)
+    l2 = log2.cpu()
+    _record('refine-5M', geo_loss_per_ray_first=float(l2[0, 1] / l2[0, 3]), geo_loss_per_ray_last_geo_iter=float(l2[4, 1] / l2[4, 3]))
+    assert torch.isfinite(l2).all() and float(l2[:, 3].min()) > 0.9 * R and float(l2[5:, 2].min()) > 0 and float(l2[:5, 2].max()) == 0
