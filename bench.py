@@ -27,6 +27,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--points', type=int, default=100_000)
+    ap.add_argument('--strong', action='store_true',
+                    help='strong scaling: the per-frame ray budget is SPLIT over the ranks (R / N rays per rank and iteration) instead of '
+                         'every rank bringing a full batch; frames/s then is the per-frame rate the "x6 at 8 GPUs" target speaks of')
     args = ap.parse_args()
 
     import torch
@@ -52,6 +55,9 @@ def main():
         dctx = parallel.DistContext(rank, world)
     eng = core.Engine()
     budget = workload.Budget(n_points=args.points)
+    if args.strong and world > 1:
+        budget.track_rays = max(32, budget.track_rays // world)
+        budget.map_rays = max(32, budget.map_rays // world)
     wl = workload.FrameWorkload(eng, budget, dist=dctx)
 
     def barrier():
@@ -80,26 +86,49 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kstat = prof.stop()
+    # the same kernel alone on the chip: one more untimed step with the library's second stream switched off
+    eng.lib.check(eng.lib.dll.lk_set_serial(1), 'lk_set_serial')
+    barrier()
+    prof_s = profile.KernelTimer(eng, dominant)
+    prof_s.start()
+    wl.step()
+    barrier()
+    kstat_serial = prof_s.stop()
+    eng.lib.check(eng.lib.dll.lk_set_serial(0), 'lk_set_serial')
     if world > 1:
         t = torch.tensor([dt], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rays_per_step = budget.rays_per_frame
-    total_rays = rays_per_step * args.steps * world
+    total_rays = rays_per_step * args.steps * world       # whole-job: every rank brings rays_per_step rays per step
     out = {
         'metric': 'rays/s (track+map, Replica room0 per-frame budget, 640x480 synthetic RGB-D)',
         'value': total_rays / dt, 'unit': 'rays/s',
-        'frames_per_s': args.steps * world / dt,
+        # every rank works on the SAME frame (the ranks share one map and sum their gradients): a step is one frame whatever N is
+        'frames_per_s': args.steps / dt,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if (args.strong and world > 1) else 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32 (decoder products as split products on the 16-bit matrix pipe: fp16x3 forward, bf16x6 / pre-scaled fp16x3 backward, '
+                 'fp32 accumulate; weight gradients fp32 MFMA)',
+        'data': 'synthetic',
         'config': {'workload': 'Replica room0 budget: 40 track it x 1500 rays + 60 map it x 5000 rays per frame '
                                '(24 geometry + 36 colour) on the frustum rows of the mapped frame, S=5, k=8, C=32, rel-pos colour MLP, '
                                f'N={budget.n_points} points, 640x480 synthetic room',
-                   'rays_per_step': rays_per_step, 'parallelism': f'dp{world} (ray-sharded, grad all-reduce)'},
+                   'rays_per_step': rays_per_step, 'rays_per_step_all_ranks': rays_per_step * world,
+                   'parallelism': f'dp{world} (ray-sharded, grad all-reduce)'},
     }
     if rank == 0:
         out['roofline'] = profile.roofline(kstat, budget, dominant)
+        ser = profile.roofline(kstat_serial, budget, dominant)
+        if out['roofline'] is not None and ser is not None:
+            out['roofline']['serial'] = {k: ser[k] for k in ('avg_launch_us', 'achieved', 'frac') if k in ser}
+            out['roofline']['serial']['note'] = 'same kernel with the side stream off (lk_set_serial): nothing else shares the chip'
+        # north_star: fraction of the HBM roofline of the whole step (11.1 KB/ray forward, +20.5 KB/ray backward with the
+        # feature-gradient scatter; tracking iterations have no scatter: 2 x 11.1 KB/ray)
+        step_bytes = world * (budget.map_iters * budget.map_rays * 31.6e3 + budget.track_iters * budget.track_rays * 22.2e3)
+        out['hbm_frac_whole_step'] = step_bytes * args.steps / dt / (world * profile.PEAK_HBM_GBS * 1e9)
+        out['host_cores'] = os.cpu_count()
         out['kernel_ms_per_step'] = {k: round(v['total_ms'], 3) for k, v in sorted(kall.items(), key=lambda kv: -kv[1]['total_ms'])}
         if not args.no_cpu_baseline:
             import bench_cpu_baseline

@@ -17,7 +17,8 @@ def run(budget, seed=1219):
     from loopy_slam_amd.common import get_tensor_from_camera
     # small-matrix torch-CPU ops stop scaling (and collapse from oversubscription) beyond a few tens of threads:
     # 256 threads measured 170x slower than 8 on this path, so the baseline uses at most 16 host threads
-    cores = min(os.cpu_count() or 1, 16)
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(seed)
     W = {k: v.clone() for k, v in syn.default_weights(seed, rel_pos=budget.rel_pos).items()}
@@ -86,9 +87,9 @@ def run(budget, seed=1219):
     t_geo, n_g = timed(lambda: map_iter('geometry'), max(1, budget.map_geo_iters // 2), 5.0)
     t_col, n_c = timed(lambda: map_iter('color'), max(1, n_col // 2), 14.0)
     t_frame = budget.track_iters * t_track + budget.map_geo_iters * t_geo + n_col * t_col
-    return {'value': budget.rays_per_frame / t_frame, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+    return {'value': budget.rays_per_frame / t_frame, 'unit': 'rays/s', 'cores': cores, 'host_cores': host_cores, 'kind': 'port',
             'sample': f'{n_t} tracking iterations ({budget.track_rays} rays, {t_track:.2f} s each) + {n_g} geometry ({t_geo:.2f} s) + {n_c} colour '
                       f'({t_col:.2f} s) mapping iterations ({budget.map_rays} rays each), N={budget.n_points} points, '
                       f'extrapolated to the {budget.track_iters}/{budget.map_geo_iters}/{n_col} per-frame budget '
-                      f'({t_frame:.1f} s/frame); torch {torch.__version__} CPU, {cores} threads',
+                      f'({t_frame:.1f} s/frame); torch {torch.__version__} CPU, {cores} threads of the host\'s {host_cores} cores',
             'frames_per_s': 1.0 / t_frame}

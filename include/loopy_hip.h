@@ -12,7 +12,8 @@
  *  - every call returns 0 on success, <0 on error (lk_last_error() gives the message,
  *    thread-local); nothing throws across the ABI;
  *  - kernels are enqueued on `stream` (a hipStream_t; torch.cuda.current_stream().cuda_stream)
- *    and never synchronise the device;
+ *    and never synchronise the device; lk_render_bwd additionally forks part of its work onto ONE library-owned
+ *    non-blocking stream and joins it back with events before it returns (see lk_set_serial);
  *  - fp32 everywhere; indices int32; R rays, S samples/ray (<= 8), P = R*S points in
  *    ray-major order (point r*S+s), k = 8 neighbours, C = 32 channels, N cloud points.
  */
@@ -317,7 +318,13 @@ typedef struct {
     float* hist;                /* [iters][7] candidate poses */
     float* log;                 /* [iters][4] loss, geo, colour, #masked rays per iteration */
     int32_t iters;
+    float* work;                /* lk_track_work_floats(R, S, iters) floats: with it (and R <= 8192) every iteration's pixels, colours,
+                                   radii and inside mask are assembled by ONE launch up front and the small steps of an iteration run
+                                   fused (9 launches per iteration instead of 16); gt_color / pix_i / pix_j / thr / scratch_u32 /
+                                   loss_scratch and render.g_rays_o / g_rays_d are then not used and may be NULL.  NULL: the
+                                   per-iteration launch sequence */
 } lk_track_desc;
+int64_t lk_track_work_floats(int32_t R, int32_t S, int32_t iters);
 int lk_track_frame(const lk_track_desc* d, void* stream);
 
 /* lk_map_frame: the joint iterations [it_begin, it_end) of one Mapper.optimize_map call (src/Mapper.py:576-735, no exposure
@@ -352,7 +359,11 @@ typedef struct {
     float* adam_dec;            /* [2][lk_weight_blob_floats()]: exp_avg | exp_avg_sq, blob-shaped */
     float lr[2][3];             /* [stage: geometry, colour][decoders, geometry rows, colour rows] (configs mapping.stage.*) */
     int32_t iters, n_geo_iters;
+    float* work;                /* lk_map_work_floats(R, iters) floats, or NULL: as lk_track_desc.work - the batches (pixels, rays, colours,
+                                   radii, inside masks) of all `iters` iterations are assembled by one launch of the call that starts at
+                                   it_begin = 0 (gt_color / thr / scratch_u32 and render.rays_o / rays_d / gt_depth are then unused) */
 } lk_map_desc;
+int64_t lk_map_work_floats(int32_t R, int32_t iters);
 int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t phases, void* stream);
 
 /* ---------------------------------------------------------------- weight-gradient building block
@@ -369,6 +380,11 @@ int lk_wgrad_single(const float* A, int32_t lda, int32_t a_mode, const float* A2
  * (names: comma-separated, e.g. "k_decode_bwd", or "*").  lk_profile_end synchronises those events and writes
  * "name calls total_ms" lines into buf.  Used by bench.py for the roofline figure. */
 int lk_profile_begin(const char* names);
+/* lk_render_bwd runs the decoder weight-gradient reductions on a second, library-owned HIP stream beside the rel-pos backward and
+ * the feature scatter (fork / join with events on the caller's stream: the caller sees one ordered stream).  on != 0 keeps
+ * everything on the caller's stream - per-kernel durations are then those of a kernel running alone (measurement; the
+ * environment variable LK_SERIAL sets the initial state). */
+int lk_set_serial(int32_t on);
 int lk_profile_end(char* buf, int cap);
 
 #ifdef __cplusplus

@@ -83,7 +83,7 @@ class TrackDesc(C.Structure):
         ('rnd', _fp), ('gt_color', _fp), ('pix_i', _fp), ('pix_j', _fp), ('thr', _fp), ('scratch_u32', _fp), ('loss_scratch', _fp),
         ('cam7', _fp), ('g_cam7', _fp), ('adam_mv', _fp),
         ('lr_T', C.c_float), ('lr_q', C.c_float), ('w_color', C.c_float), ('use_color', C.c_int32), ('hist_post', C.c_int32),
-        ('hist', _fp), ('log', _fp), ('iters', C.c_int32),
+        ('hist', _fp), ('log', _fp), ('iters', C.c_int32), ('work', _fp),
     ]
 
 
@@ -103,7 +103,7 @@ class MapDesc(C.Structure):
         ('col_dec', BlobSpan * MAX_SPANS), ('n_col_dec', C.c_int32),
         ('adam_dec', _fp),
         ('lr', (C.c_float * 3) * 2),
-        ('iters', C.c_int32), ('n_geo_iters', C.c_int32),
+        ('iters', C.c_int32), ('n_geo_iters', C.c_int32), ('work', _fp),
     ]
 
 
@@ -166,6 +166,9 @@ class LoopyLib:
             ('lk_profile_begin', [C.c_char_p], C.c_int),
             ('lk_profile_end', [C.c_char_p, C.c_int], C.c_int),
             ('lk_compact', [_fp, C.c_int32, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_set_serial', [C.c_int32], C.c_int),
+            ('lk_track_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
+            ('lk_map_work_floats', [C.c_int32, C.c_int32], C.c_int64),
             ('lk_track_frame', [C.POINTER(TrackDesc), C.c_void_p], C.c_int),
             ('lk_map_frame', [C.POINTER(MapDesc), C.c_int32, C.c_int32, C.c_int32, C.c_void_p], C.c_int),
             ('lk_inside_mask', [_fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),

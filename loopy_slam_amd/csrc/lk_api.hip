@@ -218,11 +218,12 @@ extern "C" int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t f
 // Second stream for the weight-gradient reductions: they only consume what decode_bwd / relpos_bwd saved, so they run
 // beside the rel-pos backward and the feature scatter (fork / join with events; created once per process).
 namespace {
+int g_serial = -1;            // -1: not decided yet (environment LK_SERIAL), 0 / 1: set by lk_set_serial
 struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; bool ok = false; };
 SideStream& side_stream() {
-    static SideStream s;
-    static const bool serial = getenv("LK_SERIAL") != nullptr;     // debugging switch: one stream, clean per-kernel timing
-    if (serial) return s;
+    static SideStream s, none;
+    if (g_serial < 0) g_serial = getenv("LK_SERIAL") != nullptr ? 1 : 0;
+    if (g_serial) return none;                                       // one stream: clean per-kernel timing
     if (!s.st) {
         s.ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
@@ -233,7 +234,9 @@ SideStream& side_stream() {
 }
 }  // namespace
 
-extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) { return lk_render_bwd_impl(d, (hipStream_t)stream_, 0); }
+extern "C" int lk_set_serial(int32_t on) { g_serial = on ? 1 : 0; return LK_OK; }
+
+extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) { return lk_render_bwd_impl(d, (hipStream_t)stream_, 0, nullptr); }
 
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags) {
     const BwdLayout L = bwd_layout(P, flags);
@@ -242,7 +245,7 @@ LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags) {
     return o;
 }
 
-int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
+int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex) {
     int rc = check_desc(d, "lk_render_bwd");
     if (rc != LK_OK) return rc;
     if (d->R == 0) return LK_OK;
@@ -253,7 +256,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
     const bool gf = (flags & LK_FLAG_GRAD_FEATS) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0, gr = (flags & LK_FLAG_GRAD_RAYS) != 0;
     LK_REQUIRE(!gf || (d->g_geo_feats && (!color || d->g_col_feats)), "lk_render_bwd: GRAD_FEATS needs g_geo_feats/g_col_feats");
     LK_REQUIRE(!gw || d->g_weights, "lk_render_bwd: GRAD_WEIGHTS needs g_weights");
-    LK_REQUIRE(!gr || (d->g_rays_o && d->g_rays_d && d->pos), "lk_render_bwd: GRAD_RAYS needs g_rays_o/g_rays_d/pos");
+    LK_REQUIRE(!gr || (((skip & LK_SKIP_RAYS_BWD) || (d->g_rays_o && d->g_rays_d)) && d->pos), "lk_render_bwd: GRAD_RAYS needs g_rays_o/g_rays_d/pos");
     LK_REQUIRE(!color || d->d_color, "lk_render_bwd: colour stage needs d_color");
     const int P = d->R * d->S;
     const BwdLayout L = bwd_layout(P, flags);
@@ -353,6 +356,9 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
         ib.dw_rel = relpos ? S0 + L.dw_rel : nullptr;
         ib.dp_embed = S0 + L.dp_embed; ib.dp_embed_col = color ? S0 + L.dp_embed_col : nullptr; ib.dp_rel = relpos ? S0 + L.dp_rel : nullptr;
         ib.g_geo_feats = d->g_geo_feats; ib.g_col_feats = d->g_col_feats; ib.dp_total = S0 + L.dp_total;
+        ib.pose_part = ex ? ex->pose_part : nullptr;
+        if (ex) { ib.pix_i = ex->pix_i; ib.pix_j = ex->pix_j; ib.fx = ex->fx; ib.fy = ex->fy; ib.cx = ex->cx; ib.cy = ex->cy; }
+        else { ib.pix_i = ib.pix_j = nullptr; ib.fx = ib.fy = 1.0f; ib.cx = ib.cy = 0.0f; }
         lk_launch_interp_bwd(ib, st);
     }
     if (gr && !(skip & LK_SKIP_RAYS_BWD)) {

@@ -87,6 +87,30 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
         if (color && relpos && a.dp_rel) { const float4 e = *reinterpret_cast<const float4*>(a.dp_rel + (size_t)pidx * 4); dpx += e.x; dpy += e.y; dpz += e.z; }
         *reinterpret_cast<float4*>(a.dp_total + (size_t)pidx * 4) = make_float4(dpx, dpy, dpz, 0.0f);
     }
+    if (a.pose_part) {
+        // tracking loop: the pose gradient needs G[c][k] = sum_rays (sum_s d p_c z) dir_k and T[c] = sum d p_c (k_pose_bwd); a sample
+        // contributes d p_c z dir_k / d p_c, summed here over the 32 samples of the workgroup (one lane per sample carries it)
+        __shared__ float s_pp[4][12];
+        float v[12];
+        const bool mine = live && sub == 0;
+        const float d0 = mine ? (a.pix_i[r] - a.cx) / a.fx : 0.0f, d1 = mine ? -(a.pix_j[r] - a.cy) / a.fy : 0.0f, d2 = mine ? -1.0f : 0.0f;
+        const float gx = mine ? dpx : 0.0f, gy = mine ? dpy : 0.0f, gz = mine ? dpz : 0.0f;
+        const float zx = gx * z, zy = gy * z, zz = gz * z;
+        v[0] = zx * d0; v[1] = zx * d1; v[2] = zx * d2; v[3] = zy * d0; v[4] = zy * d1; v[5] = zy * d2; v[6] = zz * d0; v[7] = zz * d1; v[8] = zz * d2;
+        v[9] = gx; v[10] = gy; v[11] = gz;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+#pragma unroll
+            for (int o = 32; o >= 8; o >>= 1) v[q] += __shfl_xor(v[q], o);          // lanes 0, 8, .., 56 hold the samples of the wave
+        }
+        const int wv = (int)threadIdx.x >> 6;
+        if (lk_lane() == 0) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) s_pp[wv][q] = v[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) a.pose_part[(size_t)blockIdx.x * 12 + threadIdx.x] = (s_pp[0][threadIdx.x] + s_pp[1][threadIdx.x]) + (s_pp[2][threadIdx.x] + s_pp[3][threadIdx.x]);
+    }
 }
 
 // Feature-gradient scatter: one half-wave (32 lanes = the 32 channels = one 128-B line) per (sample, neighbour),

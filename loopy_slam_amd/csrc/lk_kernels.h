@@ -94,7 +94,14 @@ struct LkInterpBwdArgs {
     const float* dp_embed; const float* dp_embed_col; const float* dp_rel;    // [P,4] or NULL
     float* g_geo_feats; float* g_col_feats;        // [N,32] accumulated
     float* dp_total;                               // [P,4] (GRAD_RAYS)
+    // optional (tracking loop): per-workgroup partial sums of the pose gradient's 12 ray moments, see LkBwdExtra
+    float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
 };
+// Extras of the fused tracking loop for lk_render_bwd_impl: with pose_part the interpolation backward also reduces, per
+// workgroup of 32 samples, G[c][k] = sum d p_c z dir_k (9) and T[c] = sum d p_c (3) - what k_pose_bwd sums over the rays -
+// into pose_part[block][12]; lk_bwd_pose_parts(P) blocks.
+struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy; };
+inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
     int P, min_nn;
@@ -154,7 +161,7 @@ inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_W
 // lk_render_fwd / lk_render_bwd with parts of their launch sequence left to the caller (the fused per-frame loops, lk_loop.hip)
 enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, LK_FUSE_COMPOSITE_BWD = 8, LK_LOSS_PREZEROED = 16 };
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip);
-int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip);
+int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total; };
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch
 

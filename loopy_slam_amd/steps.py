@@ -140,6 +140,7 @@ class MapOptimizer:
         self.dist = dist
         self.it = 0
         self.native_loop = True                 # lk_map_frame; False = one launch sequence per statement (iterate)
+        self._work = None
         self._nat, self._nat_dirty = None, False    # Adam state of the native loop: [4][n_rows*32] rows, [2][blob] decoders
         # exposure = (mlp_exposure torch module, [exposure_feat tensor per frame of the window]) for model.encode_exposure
         # (ScanNet): per-keyframe colour affine applied to the RENDERED colour logits (Mapper.py:697-715)
@@ -250,6 +251,10 @@ class MapOptimizer:
             for k in range(3):
                 d.lr[si][k] = self.lrs[stage][k]
         d.iters, d.n_geo_iters = n_iters, n_geo_iters
+        need = int(eng.lib.dll.lk_map_work_floats(self.R, n_iters)) if self.R <= 8192 else 0
+        if need and (self._work is None or self._work.numel() < need):
+            self._work = eng.empty(need)
+        d.work = ptr(self._work) if need else 0
         self._keep_native = (depth_stack, color_stack, c2w_stack, r2_stack, frame_id, rnd_all, log)
         dll = eng.lib.dll
         if self.dist is None:
@@ -396,5 +401,9 @@ class TrackOptimizer:
         d.lr_T, d.lr_q = self.cam_lr, (0.2 * self.cam_lr if self.separate_lr else self.cam_lr)
         d.w_color, d.use_color, d.hist_post = self.w_color, int(bool(self.use_color)), int(not self.separate_lr)
         d.hist, d.log, d.iters = ptr(hist), ptr(log), iters
+        need = int(eng.lib.dll.lk_track_work_floats(self.R, self.cfg.S, iters)) if self.R <= 8192 else 0
+        if need and (getattr(self, '_work', None) is None or self._work.numel() < need):
+            self._work = eng.empty(need)
+        d.work = ptr(self._work) if need else 0
         self._keep_native = (depth_img, color_img, r2_map, rnd_all, cam, hist, log)
         eng.lib.check(eng.lib.dll.lk_track_frame(C.byref(d), eng.stream), 'lk_track_frame')
