@@ -194,7 +194,7 @@ struct LkTrackFinalArgs {
 // pose gradient from the ray moments (k_pose_bwd's formulas), Adam on (T | q) (Tracker.py:317-352), the candidate pose log,
 // and the rays of the updated pose for the next iteration's pixels (get_rays_from_uv) - one workgroup, a few microseconds
 __global__ __launch_bounds__(1024) void k_track_final(LkTrackFinalArgs a) {
-    __shared__ float sh[16];
+    __shared__ float s_w[16][12];
     __shared__ float acc[12];
     __shared__ float s_cam[7];
     const int t = threadIdx.x;
@@ -207,7 +207,21 @@ __global__ __launch_bounds__(1024) void k_track_final(LkTrackFinalArgs a) {
             for (int q = 0; q < 12; ++q) v12[q] += a.pose_part[(size_t)b * 12 + q];
         }
 #pragma unroll
-        for (int q = 0; q < 12; ++q) { const float s = lp_block_sum_1024(v12[q], sh); if (t == 0) acc[q] = s; }
+        for (int q = 0; q < 12; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v12[q] += __shfl_xor(v12[q], o);
+        }
+        if (lk_lane() == 0) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) s_w[t >> 6][q] = v12[q];
+        }
+        __syncthreads();
+        if (t < 12) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s += s_w[w][t];
+            acc[t] = s;
+        }
         __syncthreads();
         if (t == 0) {
             float* cam = a.cam;

@@ -90,16 +90,16 @@ def work_per_step(b):
 
 
 def pmc_traffic(kernel, path=None):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_rocprof_summary.md, written by
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r2_rocprof_summary.md, written by
     tools/summarize_prof.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench; FETCH_SIZE doubled per
     the gfx950 note of MI355X_MICROARCH.md): (bytes, source) or (None, None).  bench.py cannot collect PMC counters live."""
     import os
-    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r1_rocprof_summary.md')
+    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r2_rocprof_summary.md')
     try:
         for line in open(path):
             c = [x.strip() for x in line.strip().strip('|').split('|')]
             if len(c) == 5 and c[0] == kernel:
-                return float(c[3]) * 1e6 + float(c[4]) * 1024.0, 'profiles/r1_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
+                return float(c[3]) * 1e6 + float(c[4]) * 1024.0, 'profiles/r2_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
     except (OSError, ValueError):
         pass
     return None, None

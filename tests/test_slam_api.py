@@ -228,7 +228,11 @@ def test_add_points_schedule_matches_oracle(backend):
                                                            {k: v.cpu() for k, v in draws.items()})
         assert counts == o_counts and total == o_total, (idx, counts, o_counts)
         assert len(counts) == (2 if idx == 0 else 3) and total > 0
-        assert torch.equal(ps.npc.cloud_pos().cpu(), o_cloud)
+        # same points; the rays of the draws are torch expressions on the engine's device (bit-identical to the oracle's on the CPU
+        # back-end, a rounding apart on the GPU where torch sums the three products of a direction in another order)
+        if backend == 'emu':
+            assert torch.equal(ps.npc.cloud_pos().cpu(), o_cloud)
+        np.testing.assert_allclose(ps.npc.cloud_pos().cpu().numpy(), o_cloud.numpy(), rtol=0, atol=2e-6)
         mp.prev_c2w = c2w.clone()
         prev = c2w.cpu()
     # the iteration count of a mapped frame follows from what was added (and is clipped on both sides)

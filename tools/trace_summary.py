@@ -3,7 +3,7 @@
 
     python tools/trace_summary.py <dir with *_kernel_trace.csv> [label]
 
-An iteration = from one k_gather_rays (k_track_prep in the fused tracking loop) dispatch to the next.  Reports, as medians over the last iterations of the trace:
+An iteration = from one k_sample_interp dispatch (the first launch of every iteration type) to the next.  Reports, as medians over the last iterations of the trace:
 the period (start to start), the sum of kernel durations, the idle time between kernels on the critical stream, and every
 kernel's duration / share.  Writes markdown to stdout."""
 import collections
@@ -26,8 +26,7 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')))
     rows.sort()
-    first = 'k_track_prep' if any(r[2].startswith('k_track_prep') for r in rows) else 'k_gather_rays'
-    starts = [i for i, r in enumerate(rows) if r[2].startswith(first)]
+    starts = [i for i, r in enumerate(rows) if r[2].startswith('k_sample_interp')]      # first launch of every iteration
     if len(starts) < 8:
         print('too few iterations in the trace')
         return
