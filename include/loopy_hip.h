@@ -55,6 +55,11 @@ int lk_knn_destroy(lk_knn_t h);
  * until the next build (the grid keeps its own sorted copy; pos itself is not read by queries). */
 int lk_knn_build(lk_knn_t h, const float* pos, int64_t N, void* stream);
 int64_t lk_knn_size(lk_knn_t h);
+/* Grow the indexed cloud by M points (they get the indices lk_knn_size() .. + M - 1): NeuralPointCloud.add_neural_points'
+ * index.add (src/neural_point.py:1623-1627).  A uniform grid has no cheap in-place insert - this is lk_knn_build over
+ * (points recovered from the grid's sorted copy | pos_new): O(N + M), device only, the handle keeps its own position buffer
+ * from the first call on.  A caller that holds the grown position array anyway (NeuralPointCloud does) calls lk_knn_build. */
+int lk_knn_append(lk_knn_t h, const float* pos_new, int64_t M, void* stream);
 /* r2_per_query may be NULL (then r2_scalar is used for every query). */
 int lk_knn_query(lk_knn_t h, const float* q, int64_t P, float r2_scalar, const float* r2_per_query,
                  float* out_d2 /*[P,8]*/, int32_t* out_idx /*[P,8]*/, int32_t* out_count /*[P]*/,

@@ -129,6 +129,7 @@ class LoopyLib:
         d.lk_knn_create.argtypes = [C.c_float, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]
         d.lk_knn_destroy.argtypes = [C.c_void_p]
         d.lk_knn_build.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_void_p]
+        d.lk_knn_append.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_void_p]
         d.lk_knn_size.argtypes = [C.c_void_p]
         d.lk_knn_size.restype = C.c_int64
         d.lk_knn_query.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_float, _fp, _fp, _fp, _fp, C.c_void_p]

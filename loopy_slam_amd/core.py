@@ -80,6 +80,13 @@ class KnnIndex:
         self._pos = pos
         self.eng.lib.check(self.eng.lib.dll.lk_knn_build(self.h, ptr(pos), pos.shape[0], self.eng.stream), 'lk_knn_build')
 
+    def append(self, pos_new):
+        """lk_knn_append: index M more points behind the existing ones (the handle rebuilds from its own copy)."""
+        pos_new = pos_new.contiguous()
+        assert pos_new.dtype == torch.float32 and pos_new.device == self.eng.device
+        self._keep_new = pos_new
+        self.eng.lib.check(self.eng.lib.dll.lk_knn_append(self.h, ptr(pos_new), pos_new.shape[0], self.eng.stream), 'lk_knn_append')
+
     @property
     def n(self):
         return int(self.eng.lib.dll.lk_knn_size(self.h))

@@ -62,6 +62,7 @@ struct lk_knn_s {
     int32_t* cell_of;      // [capacity]
     int32_t* rank_of;      // [capacity]
     int32_t* block_sums;   // scan scratch
+    float* pos_own = nullptr;   // [capacity][3] original-order copy, allocated by the first lk_knn_append
     int32_t n_scan_blocks;
 };
 

@@ -233,6 +233,7 @@ extern "C" int lk_knn_destroy(lk_knn_t h) {
     if (h->cell_of) (void)hipFree(h->cell_of);
     if (h->rank_of) (void)hipFree(h->rank_of);
     if (h->block_sums) (void)hipFree(h->block_sums);
+    if (h->pos_own) (void)hipFree(h->pos_own);
     delete h;
     return LK_OK;
 }
@@ -264,6 +265,30 @@ extern "C" int lk_knn_build(lk_knn_t h, const float* pos, int64_t N, void* strea
     }
     LK_LAUNCH_CHECK();
     return LK_OK;
+}
+
+// un-sort: original-order positions back out of the grid's sorted copy (for lk_knn_append)
+__global__ __launch_bounds__(256) void k_unsort(const float4* __restrict__ sorted, int n, float* __restrict__ pos) {
+    const int i = blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= n) return;
+    const float4 p = sorted[i];
+    const int idx = __float_as_int(p.w);
+    pos[3 * (size_t)idx] = p.x; pos[3 * (size_t)idx + 1] = p.y; pos[3 * (size_t)idx + 2] = p.z;
+}
+
+extern "C" int lk_knn_append(lk_knn_t h, const float* pos_new, int64_t M, void* stream_) {
+    LK_REQUIRE(h != nullptr, "lk_knn_append: NULL handle");
+    LK_REQUIRE(M >= 0 && h->n + M <= h->capacity, "lk_knn_append: the grown cloud exceeds the capacity given to lk_knn_create");
+    if (M == 0) return LK_OK;
+    LK_REQUIRE(pos_new != nullptr, "lk_knn_append: pos_new is NULL");
+    hipStream_t st = (hipStream_t)stream_;
+    if (!h->pos_own) LK_HIP_TRY(hipMalloc((void**)&h->pos_own, sizeof(float) * 3 * (size_t)h->capacity));
+    const int n = (int)h->n;
+    // the grid keeps no original-order copy: recover it from the sorted one (x, y, z, index), put the new points behind it
+    // (indices n .. n + M - 1) and run the O(N) counting-sort build over the grown array
+    if (n > 0) hipLaunchKernelGGL(k_unsort, dim3(lk_cdiv(n, 256)), dim3(256), 0, st, h->sorted, n, h->pos_own);
+    LK_HIP_TRY(hipMemcpyAsync(h->pos_own + 3 * (size_t)n, pos_new, sizeof(float) * 3 * (size_t)M, hipMemcpyDeviceToDevice, st));
+    return lk_knn_build(h, h->pos_own, h->n + M, st);
 }
 
 extern "C" int lk_knn_query(lk_knn_t h, const float* q, int64_t P, float r2_scalar, const float* r2_per_query,

@@ -86,6 +86,30 @@ def test_knn_edge_cases(backend):
     assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(cnt.cpu().numpy(), oc)
 
 
+@pytest.mark.parametrize('backend', backends())
+def test_knn_append_equals_build(backend):
+    """lk_knn_append (index.add of add_neural_points): appending in three pieces answers every query exactly as one build over
+    the whole array - indices refer to the concatenated order."""
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(9)
+    pts = torch.rand(3000, 3, generator=gen) * 2 - 1
+    q = torch.rand(500, 3, generator=gen) * 2 - 1
+    a = core.KnnIndex(eng, capacity=4000, cell_size=0.08)
+    a.build(eng.f32(pts))
+    b = core.KnnIndex(eng, capacity=4000, cell_size=0.08)
+    b.build(eng.f32(pts[:1200]))
+    b.append(eng.f32(pts[1200:1201]))
+    b.append(eng.f32(pts[1201:2500]))
+    b.append(eng.f32(pts[2500:]))
+    assert b.n == 3000
+    for r2 in (0.0064, 0.04):
+        da, ia, ca = a.query(eng.f32(q), r2)
+        db, ib, cb = b.query(eng.f32(q), r2)
+        assert torch.equal(ia, ib) and torch.equal(da, db) and torch.equal(ca, cb)
+    od, oi, oc = H.knn_exact(pts.numpy(), q.numpy(), 8, np.float32(0.04))
+    assert np.array_equal(ib.cpu().numpy(), oi)
+
+
 # ------------------------------------------------------------------ weights blob round trip
 @pytest.mark.parametrize('backend', backends())
 def test_weight_blob_roundtrip(backend):
