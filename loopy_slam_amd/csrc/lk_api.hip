@@ -96,7 +96,7 @@ extern "C" int64_t lk_render_act_floats(int32_t R, int32_t S, uint32_t flags) {
 
 // ------------------------------------------------------------------ backward scratch layout
 namespace {
-struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, wg_part, total; };
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, dw1_part, wg_part, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -119,7 +119,10 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.dfeat = o; if (color && (flags & LK_FLAG_REL_POS) && (flags & LK_FLAG_GRAD_FEATS)) o += al(8 * 32 * P);
     L.w_sum = o; o += al(P);
     L.dh_col = o; if (color && gw) o += al(640 * P);
-    L.rows = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += al(8 * 192 * P);
+    // linear1 of the rel-pos MLP: neighbour rows for k_wgrad, or (mapper mode) the workgroup tiles of k_relpos_bwd_fused
+    const bool rp_w = color && gw && (flags & LK_FLAG_REL_POS), fused = rp_w && lk_relpos_fused(flags);
+    L.rows = o; if (rp_w && !fused) o += al(8 * 192 * P);
+    L.dw1_part = o; if (fused) o += al((int64_t)lk_relpos_bwd_parts((int)P) * 128 * 64);
     L.wg_part = o; if (color && gw) o += al(lk_wgrad_part_floats(P, (flags & LK_FLAG_REL_POS) != 0));
     L.total = o;
     return L;
@@ -333,10 +336,11 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         rb.g_col_feats = d->g_col_feats; rb.g_weights = d->g_weights;
         rb.dw_rel = S0 + L.dw_rel; rb.dp_rel = S0 + L.dp_rel; rb.rows = S0 + L.rows; rb.w_eff = S0 + L.w_eff;
         rb.dfeat = S0 + L.dfeat;
-        rb.part_br = S0 + L.part_br; rb.hbar = S0 + L.hbar; rb.w_sum = S0 + L.w_sum;
+        rb.part_br = S0 + L.part_br; rb.hbar = S0 + L.hbar; rb.w_sum = S0 + L.w_sum; rb.dw1_part = S0 + L.dw1_part;
         lk_launch_relpos_bwd(rb, st);
         if (forked) { (void)hipEventRecord(ss.mid, st); (void)hipStreamWaitEvent(wst, ss.mid, 0); }
-        if (gw) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
+        if (gw) lk_launch_reduce_partials(S0 + L.part_br, lk_relpos_fused(flags) ? lk_relpos_bwd_parts(P) : lk_cdiv(lk_cdiv(P, 4), 4), 32,
+                                          d->g_weights + R_EB, st);
     }
 
     if (gf) {
@@ -371,16 +375,22 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         {
             LkWgradArgs wr;
             memset(&wr, 0, sizeof(wr));
-            const float* rows = S0 + L.rows;
-            LkWgradJob& J1 = wr.job[0];       // linear1 [128][52]: rows = neighbour rows, A = d hid, B = x
-            J1.A = rows; J1.lda = 192; J1.a_mode = 0; J1.B = rows + 128; J1.ldb = 192;
-            J1.N = HC; J1.K = KR; J1.rows = 8 * P; J1.dW = G + R_W1; J1.ldw = KRP; J1.db = G + R_B1;
-            LkWgradJob& J2 = wr.job[1];       // linear2 [32][128]: rows = SAMPLES, A = (sum_j w_j) * d c, B = sum_j w_j hid_j
+            const bool fused = lk_relpos_fused(flags);
+            int nj = 0;
+            if (fused) {                      // linear1 was reduced inside k_relpos_bwd_fused: add the workgroup tiles
+                lk_launch_dw1_reduce(S0 + L.dw1_part, lk_relpos_bwd_parts(P), G + R_W1, G + R_B1, wst);
+            } else {
+                const float* rows = S0 + L.rows;
+                LkWgradJob& J1 = wr.job[nj++];    // linear1 [128][52]: rows = neighbour rows, A = d hid, B = x
+                J1.A = rows; J1.lda = 192; J1.a_mode = 0; J1.B = rows + 128; J1.ldb = 192;
+                J1.N = HC; J1.K = KR; J1.rows = 8 * P; J1.dW = G + R_W1; J1.ldw = KRP; J1.db = G + R_B1;
+            }
+            LkWgradJob& J2 = wr.job[nj++];    // linear2 [32][128]: rows = SAMPLES, A = (sum_j w_j) * d c, B = sum_j w_j hid_j
             J2.A = S0 + L.dc_col; J2.lda = LK_C; J2.a_mode = 2; J2.A2 = S0 + L.w_sum; J2.lda2 = 1;
             J2.B = S0 + L.hbar; J2.ldb = 128;
             J2.N = CF; J2.K = HC; J2.rows = P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
-            wr.n_jobs = 2; wr.chunk = 0; wr.part = S0 + L.wg_part;
-            lk_launch_wgrad(wr, 8 * P, wst);
+            wr.n_jobs = nj; wr.chunk = 0; wr.part = S0 + L.wg_part;
+            lk_launch_wgrad(wr, fused ? P : 8 * P, wst);
         }
     }
     if (forked) { (void)hipEventRecord(ss.join, wst); (void)hipStreamWaitEvent(st, ss.join, 0); }

@@ -387,6 +387,321 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd(LkRelposBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// FUSED MAPPER VARIANT (lk_relpos_fused(flags): weight gradients wanted, unit-scale loss gradients, no ray gradients).
+// The plain kernel above hands linear1's weight gradient to k_wgrad through `rows` - 6 KB written per sample and read back
+// 1.4 times: two thirds of the HBM traffic of a mapper 'color' iteration.  Here
+//     dW1[u][i] = sum_rows d hid[u][row] * x[i][row]
+// is taken inside the kernel.  Both operands live as CT tiles (lane = row), the reduction index of a matrix instruction
+// is the one index that is NOT a lane, so the tile has to be turned: the fp16 piece registers that the other products
+// need anyway (x: the forward recompute, d hid: the d x product) are also written to a per-wave LDS image [piece][unit][row]
+// with two-byte stores (no extra VALU work) and read back as 16-byte A / B operands - 8 consecutive rows of one unit per
+// lane.  The 16-byte chunk of rows c of unit u sits at chunk c ^ (u >> 2 & 3): the 16 lanes an LDS read serves together then
+// hit 16 different 16-byte slots of the 256-byte bank row.  Input unit 52 of the x image is the constant 1: column 52 of the
+// product is the bias gradient.  The images of the four waves of a workgroup (4 x 32 rows) are consumed TOGETHER: after a
+// barrier wave w owns one 32 x 32 block of the product - hidden block 2 p + (w >> 1), input block w & 1, in the two phases
+// p = 0, 1 (d hid is staged two blocks at a time: that is what fits twice into the 160 KB of a compute unit) - and walks the
+// 128 staged rows with 24 matrix instructions per phase into two accumulators it keeps in REGISTERS for the whole kernel.
+// (A first version added every wave's tile into one LDS tile with float atomics: ds_add_f32 retires about one lane every two
+// cycles, the kernel ran three times slower than the one it replaces.)  Workgroups are persistent (grid <= 2 per compute
+// unit) and store their 128 x 64 tile once, k_dw1_reduce adds the <= 512 partial tiles: fixed summation order, no atomics.
+// All products run on scaled fp16 pieces (d out * 2^10, as in decode_bwd_col_wg<true>): half the matrix instructions and
+// 3 instead of 5.5 VALU instructions per split value of the bf16 path.
+#define RPF_XU 56                                            // staged input units: 0..51 real, 52 = 1, 53..55 = 0
+#define RPF_DU 64                                            // staged d hid units: two 32-unit blocks at a time
+#define RPF_STAGE_HALVES ((2 * RPF_XU + 2 * RPF_DU) * 32)    // per wave: x pieces [2][56][32] + d hid pieces [2][64][32]
+#define RPF_SC 1024.0f
+#define RPF_ISC (1.0f / 1024.0f)
+
+// lane-dependent parts of the image addresses (in halves), computed once per wave: everything else is a compile-time constant
+struct RpfLane {
+    int wr[2];        // store slot of (unit 4 h, this lane's row) for units with (unit >> 2 & 3) == (2 k + h) & 3, k = 0, 1
+    int rd_j[2];      // operand slot of unit (lane & 31), row half kk = 0, 1
+    int rd_x[2];      // operand slot of input unit 32 + (lane & 31), clamped to the zero unit 55
+};
+__device__ __forceinline__ RpfLane rpf_lane(int lane) {
+    const int h = lane >> 5, row = lane & 31;
+    RpfLane L;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) L.wr[k] = 4 * h * 32 + ((((row >> 3) ^ (2 * k + h)) & 3) << 3) + (row & 7);
+    const int xu = (32 + row < RPF_XU) ? 32 + row : RPF_XU - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        L.rd_j[kk] = row * 32 + ((((2 * kk + h) ^ (row >> 2)) & 3) << 3);
+        L.rd_x[kk] = xu * 32 + ((((2 * kk + h) ^ (xu >> 2)) & 3) << 3);
+    }
+    return L;
+}
+// the piece registers of CT-tile registers 8G..8G+7 (lk_split_cth: register j = units u, u + 1 of this lane's row) -> images;
+// unit u = unit0 + 2 (j & 1) + 8 (2 G + (j >> 1)) + 4 h sits at chunk (row >> 3) ^ (u >> 2 & 3) = (row >> 3) ^ (2 (j >> 1) + h & 3)
+__device__ __forceinline__ void rpf_stage(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, const LkH8& b, int G, int unit0,
+                                          int n_units, const RpfLane& L, int h) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = unit0 + 2 * (j & 1) + 8 * (2 * G + (j >> 1));                  // compile-time part of the unit
+        if (c + 4 < n_units || (c < n_units && h == 0)) {                            // unit c + 4 h (and its odd partner) exists
+            const int s = c * 32 + L.wr[j >> 1];
+            hi[s] = (uint16_t)(b.p[0][j] & 0xffffu); hi[s + 32] = (uint16_t)(b.p[0][j] >> 16);
+            lo[s] = (uint16_t)(b.p[1][j] & 0xffffu); lo[s + 32] = (uint16_t)(b.p[1][j] >> 16);
+        }
+    }
+}
+// matrix-instruction operand at a lane slot of RpfLane: 8 consecutive rows of one unit
+__device__ __forceinline__ u32x4 rpf_operand(const uint16_t* __restrict__ img, int slot) {
+    return *reinterpret_cast<const u32x4*>(img + slot);
+}
+
+__device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, int sample0, float* __restrict__ part,
+                                                      uint16_t* __restrict__ stage_wg, int w, f32x16 (&acc)[2]) {
+    const int lane = lk_opaque(lk_lane());            // per tile: see lk_opaque
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const int sample = sample0 + (j >> 3);
+    const bool live = sample < a.P;
+    const int sp = live ? sample : a.P - 1;
+    const int nb_i = j & 7;
+    const int r = sp / a.S;
+    const float z = a.z[sp];
+    const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
+    const float py = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
+    const float pz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
+    int idx = a.nbr_idx[(size_t)sp * LK_K + nb_i];
+    const bool has = a.nbr_count[sp] >= a.min_nn;
+    const float wgt = (idx >= 0 && has && live) ? a.nbr_w[(size_t)sp * LK_K + nb_i] : 0.0f;
+    if (idx < 0) idx = 0;
+    const float a0 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx], px));
+    const float a1 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 1], py));
+    const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
+    const float* __restrict__ W = a.W;
+    const u32x4* __restrict__ FH = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;
+    const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
+    uint16_t* __restrict__ stage = stage_wg + w * RPF_STAGE_HALVES;
+    uint16_t* __restrict__ xt_hi = stage;
+    uint16_t* __restrict__ xt_lo = stage + RPF_XU * 32;
+    uint16_t* __restrict__ dt_hi = stage + 2 * RPF_XU * 32;
+    uint16_t* __restrict__ dt_lo = dt_hi + RPF_DU * 32;
+    const RpfLane RL = rpf_lane(lane);
+    // ---- recompute the forward of this tile; the fp16 pieces of x go to the LDS image on the way
+    f32x16 x0, x1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int u0 = 8 * g + 4 * h;
+        if (u0 < ER) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x0[4 * g + t] = rp_embed_unit(W + R_EB, u0 + t, a0, a1, a2);
+        } else {
+            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            x0[4 * g] = v.x; x0[4 * g + 1] = v.y; x0[4 * g + 2] = v.z; x0[4 * g + 3] = v.w;
+        }
+    }
+    x1 = lk_zero16();
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int u0 = 32 + 8 * g + 4 * h;
+        if (u0 < KR) {
+            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            x1[4 * g] = v.x; x1[4 * g + 1] = v.y; x1[4 * g + 2] = v.z; x1[4 * g + 3] = v.w;
+        }
+    }
+    // derivative of embedding unit u = (+/-) the forward value of its partner unit u +/- 10 (see relpos_bwd_wave): taken now,
+    // x0 is dead after the forward products
+    float fder[12];
+    {
+        const float r0 = __shfl_xor(h ? x0[4] : x0[8], 32), r1 = __shfl_xor(h ? x0[5] : x0[9], 32);
+        const float r2 = __shfl_xor(x0[2], 32), r3 = __shfl_xor(x0[3], 32);
+        fder[0] = x0[6]; fder[1] = x0[7]; fder[2] = r0; fder[3] = r1;
+        fder[4] = h ? -r2 : x0[10]; fder[5] = h ? -r3 : x0[11]; fder[6] = -x0[0]; fder[7] = -x0[1];
+        fder[8] = -r2; fder[9] = -r3; fder[10] = -x0[4]; fder[11] = -x0[5];
+    }
+    f32x16 hid[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_rowvec_tile(W + R_B1, nb * 32, lane);
+    {   // weight fragments one 16-unit block ahead of the products (pinned: the scheduler would otherwise fetch all four at once)
+        LkH8 fr[4], nx[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) fr[nb] = lk_fragh_load(FH + FM20_FWDH, 4, 0, nb, lane);
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const LkH8 b = lk_split_cth(G < 2 ? x0 : x1, G & 1);
+            rpf_stage(xt_hi, xt_lo, b, G & 1, G < 2 ? 0 : 32, KR, RL, h);
+            if (G < 3) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) nx[nb] = lk_fragh_load(FH + FM20_FWDH, 4, G + 1, nb, lane);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_mma3h(fr[nb], b, hid[nb]);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) fr[nb] = nx[nb];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hid[nb][q] = lk_softplus100(hid[nb][q]);
+    }
+    // ---- d out = w * d c * 2^10
+    f32x16 dout;
+    const float* dcrow = a.dc_col + (size_t)sp * LK_C;
+    const float wsc = wgt * RPF_SC;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(dcrow + 8 * g + 4 * h);
+        dout[4 * g] = v.x * wsc; dout[4 * g + 1] = v.y * wsc; dout[4 * g + 2] = v.z * wsc; dout[4 * g + 3] = v.w * wsc;
+    }
+    {   // linear2 is reduced per SAMPLE (see relpos_bwd_wave): weight sum and weighted hidden vector
+        const float wsum = lk_sum8(wgt);
+        if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
+    }
+    // ---- d hid = (W2^T d out) * softplus'(hid), block by block in place of hid
+    f32x16 (&dhid)[4] = hid;
+    const LkH8 db0 = lk_split_cth(dout, 0), db1 = lk_split_cth(dout, 1);
+    LkH8 fa0 = lk_fragh_load(FH + FM21_TRH, 4, 0, 0, lane), fa1 = lk_fragh_load(FH + FM21_TRH, 4, 1, 0, lane);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        f32x16 t = lk_zero16();
+        t = lk_mma3h(fa0, db0, t);
+        t = lk_mma3h(fa1, db1, t);
+        if (nb < 3) {
+            fa0 = lk_fragh_load(FH + FM21_TRH, 4, 0, nb + 1, lane);
+            fa1 = lk_fragh_load(FH + FM21_TRH, 4, 1, nb + 1, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) v[tt] = lk_sum8(wgt * hid[nb][4 * g + tt]);
+            if (live && nb_i == 0)
+                *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dhid[nb][q] = t[q] * lk_softplus100_grad_from_out(hid[nb][q]);
+    }
+    // ---- d x = W1^T d hid and, block by block of d hid, dW1[block] += d hid[block] (x)^T through the LDS images
+    f32x16 dx[2];
+    dx[0] = lk_zero16(); dx[1] = lk_zero16();
+    LkH8 fx[4];                                           // W1^T fragments of one d hid block, fetched one block ahead
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fx[q] = lk_fragh_load(FH + FM20_TRH, 2, q >> 1, q & 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int G = 0; G < 2; ++G) {
+            const LkH8 b = lk_split_cth(dhid[nb], G);
+            rpf_stage(dt_hi, dt_lo, b, G, 32 * (nb & 1), RPF_DU, RL, h);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) dx[kb] = lk_mma3h(fx[2 * G + kb], b, dx[kb]);
+        }
+        if (nb < 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fx[q] = lk_fragh_load(FH + FM20_TRH, 2, 2 * (nb + 1) + (q >> 1), q & 1, lane);
+        }
+        if (nb & 1) {
+            // phase p = nb >> 1: blocks 2 p, 2 p + 1 of every wave's d hid are staged.  This wave's block of the product:
+            // hidden units 32 (2 p + (w >> 1)) .., input units 32 (w & 1) .., over the rows of all four waves.
+            __syncthreads();
+            const int p = nb >> 1;
+            const int da = 32 * 32 * (w >> 1);                               // second staged block = units 32..63 of the image
+#pragma unroll
+            for (int src = 0; src < 4; ++src) {
+                const uint16_t* __restrict__ sx = stage_wg + src * RPF_STAGE_HALVES;
+                const uint16_t* __restrict__ sd = sx + 2 * RPF_XU * 32;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int xs = (w & 1) ? RL.rd_x[kk] : RL.rd_j[kk];     // input units 56..63 do not exist: the zero unit 55
+                    const u32x4 ah = rpf_operand(sd, da + RL.rd_j[kk]), al = rpf_operand(sd + RPF_DU * 32, da + RL.rd_j[kk]);
+                    const u32x4 bh = rpf_operand(sx, xs), bl = rpf_operand(sx + RPF_XU * 32, xs);
+                    acc[p] = lk_mfma_f16(al, bh, acc[p]);
+                    acc[p] = lk_mfma_f16(ah, bl, acc[p]);
+                    acc[p] = lk_mfma_f16(ah, bh, acc[p]);
+                }
+            }
+            __syncthreads();                             // everyone has read the images before they are overwritten
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- d B (Fourier matrix) and the d feature rows, from d x / 2^10
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int u0 = 32 * tile + 8 * g + 4 * h;
+            const bool is_emb = u0 < ER;
+            if (tile == 0 && g < 3) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int u = u0 + t;
+                    const int xi = is_emb ? ((u < 10) ? u : u - 10) : 0;
+                    float gx = 0.0f;
+                    if (is_emb) gx = dx[tile][4 * g + t] * RPF_ISC * fder[4 * g + t];
+                    const float s0 = lk_half_wave_sum(gx * a0), s1 = lk_half_wave_sum(gx * a1), s2 = lk_half_wave_sum(gx * a2);
+                    if ((lane & 31) == LK_HWS_LANE && is_emb) {
+                        atomicAdd(part + xi, s0);
+                        atomicAdd(part + 10 + xi, s1);
+                        atomicAdd(part + 20 + xi, s2);
+                    }
+                }
+            }
+            if (!is_emb && u0 < KR) {
+                if ((a.flags & LK_FLAG_GRAD_FEATS) && live)
+                    *reinterpret_cast<float4*>(a.dfeat + ((size_t)sp * 8 + nb_i) * LK_C + (u0 - ER)) =
+                        make_float4(dx[tile][4 * g] * RPF_ISC, dx[tile][4 * g + 1] * RPF_ISC, dx[tile][4 * g + 2] * RPF_ISC, dx[tile][4 * g + 3] * RPF_ISC);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) {
+    __shared__ float s_part[4][32];
+    __shared__ __attribute__((aligned(16))) uint16_t s_stage[4 * RPF_STAGE_HALVES];
+    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    if (threadIdx.x < 128) (&s_part[0][0])[threadIdx.x] = 0.0f;
+    {   // input units 52..55 of the wave's x image: the constant 1 (bias column) and three zero units; never rewritten
+        uint16_t* xt = s_stage + w * RPF_STAGE_HALVES;
+        for (int i = lane; i < 2 * 4 * 32; i += 64) {
+            const int piece = i >> 7, u = KR + ((i >> 5) & 3);
+            xt[piece * RPF_XU * 32 + u * 32 + (i & 31)] = (piece == 0 && u == KR) ? (uint16_t)0x3C00u : (uint16_t)0;
+        }
+    }
+    f32x16 acc[2];
+    acc[0] = lk_zero16(); acc[1] = lk_zero16();
+    __syncthreads();
+    // every wave runs every tile of the workgroup (barriers inside); rows past the end are dead lanes with weight 0
+    for (int t = (int)blockIdx.x; t * 16 < a.P; t += (int)gridDim.x)
+        relpos_bwd_wave_fused(a, (t * 4 + w) * 4, s_part[w], s_stage, w, acc);
+    __syncthreads();
+    if (threadIdx.x < 32)
+        a.part_br[(size_t)blockIdx.x * 32 + threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] +
+                                                             s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+    // accumulator p of wave w: hidden units 32 (2 p + (w >> 1)) + row(q, h), input units 32 (w & 1) + (lane & 31)
+    float* __restrict__ out = a.dw1_part + (size_t)blockIdx.x * (128 * 64);
+    const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out[(32 * (2 * p + (w >> 1)) + lk_frag_row(q, h)) * 64 + 32 * (w & 1) + j] = acc[p][q] * RPF_ISC;
+}
+
+// dW1[n][k] += sum over the workgroup tiles of k_relpos_bwd_fused ([n_parts][128][64]; column 52 = the bias gradient).
+// 32 consecutive elements x 8 partial lanes per workgroup; every output has one owner: no atomics.
+__global__ __launch_bounds__(256) void k_dw1_reduce(const float* __restrict__ part, int n_parts, float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float sh[8][32];
+    const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
+    const int o = (int)blockIdx.x * 32 + e;
+    const float* __restrict__ src = part + o;
+    float s = 0.0f;
+#pragma unroll 4
+    for (int y = q; y < n_parts; y += 8) s += src[(size_t)y * (128 * 64)];
+    sh[q][e] = s;
+    __syncthreads();
+    if (q != 0) return;
+    s = ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) + ((sh[4][e] + sh[5][e]) + (sh[6][e] + sh[7][e]));
+    const int n = o >> 6, k = o & 63;
+    if (k < KR) dW[(size_t)n * KRP + k] += s;
+    else if (k == KR) db[n] += s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // dW[n][k] += sum_rows A'[row][n] * B[row][k]  for every decoder matrix (one "job" each): a reduction GEMM with a
 // small output (<= 128 x 168) and a very long reduction (the rows = samples or neighbour rows).
 //
@@ -608,10 +923,16 @@ int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_rays_bwd, dim3(lk_cdiv(a.R, 256)), dim3(256), 0, st, a);
     return LK_OK;
 }
+int lk_relpos_bwd_parts(int P) { const int n = lk_cdiv(lk_cdiv(P, 4), 4); return n < LK_RPF_MAX_PARTS ? n : LK_RPF_MAX_PARTS; }
 int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_RELPOS_BWD, st);
     const int waves = lk_cdiv(a.P, 4);
-    hipLaunchKernelGGL(k_relpos_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    if (lk_relpos_fused(a.flags)) hipLaunchKernelGGL(k_relpos_bwd_fused, dim3(lk_relpos_bwd_parts(a.P)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_relpos_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    return LK_OK;
+}
+int lk_launch_dw1_reduce(const float* part, int n_parts, float* dW, float* db, hipStream_t st) {
+    hipLaunchKernelGGL(k_dw1_reduce, dim3(128 * 64 / 32), dim3(256), 0, st, part, n_parts, dW, db);
     return LK_OK;
 }
 int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {

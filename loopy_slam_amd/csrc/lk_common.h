@@ -138,6 +138,11 @@ __device__ __forceinline__ float lk_cosf(float x) {
     return ((q + 1) & 2) ? -v : v;
 }
 
+// A value the optimiser cannot see through (constraint "v": a VGPR on the device, a vector register in the CPU test build).
+// Inside a persistent-workgroup loop it makes what is derived from it loop-VARIANT: the 64-bit addresses of a few dozen weight
+// fragment blocks are then formed where they are used instead of being hoisted out of the loop and spilled.
+__device__ __forceinline__ int lk_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // C/D-fragment bookkeeping of v_mfma_f32_32x32x2_f32: lane l, register r holds
 // row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 __device__ __forceinline__ int lk_frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

@@ -131,7 +131,16 @@ struct LkRelposBwdArgs {
     float* dfeat;                                  // [8P][32] d loss / d feature row per neighbour (GRAD_FEATS)
     float* w_eff;                                  // [8P] weight actually applied to each neighbour row
     float* part_br;                                // [n_blocks][32] per-workgroup partial sums of d embedder_rel_pos._B
+    float* dw1_part;                               // [n_blocks][128][64] per-workgroup d linear1 tiles (fused variant, lk_relpos_fused)
 };
+// k_relpos_bwd_fused (lk_bwd2.hip): linear1's weight gradient inside the rel-pos backward - mapper mode only (scaled fp16 pieces
+// need unit-scale loss gradients; the ray-gradient products stay on the plain kernel)
+#define LK_RPF_MAX_PARTS 512                       // persistent workgroups: two per compute unit
+static inline bool lk_relpos_fused(unsigned flags) {
+    return (flags & LK_FLAG_GRAD_WEIGHTS) && (flags & LK_FLAG_UNIT_LOSS_GRADS) && !(flags & LK_FLAG_GRAD_RAYS);
+}
+int lk_relpos_bwd_parts(int P);                    // workgroups = partial tiles of the fused variant
+int lk_launch_dw1_reduce(const float* part, int n_parts, float* dW, float* db, hipStream_t st);
 
 // weight gradients: dW[n][k] += sum_rows A[row][n] * B[row][k]  (one wave per (job, column unit, row chunk))
 struct LkWgradJob {

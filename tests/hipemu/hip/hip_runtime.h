@@ -220,6 +220,8 @@ static inline float __builtin_amdgcn_logf(float v) { return ::log2f(v); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+// compiler-level wave barrier on the device; here the point where every lane's LDS accesses so far have happened
+static inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_ballot(true); }
 
 // ---- math (round-to-nearest, never contracted)
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
