@@ -159,7 +159,9 @@ typedef struct {
     const uint8_t* grad_row_mask; /* [N] or NULL: feature-row gradients are produced only for rows with a non-zero byte
                                   * (the frustum rows being optimised, Mapper.py:498-512) - the others are never read */
     /* ---- backward scratch */
-    float* bwd_scratch;         /* lk_render_bwd_scratch_floats(R,S,flags) floats */
+    float* bwd_scratch;         /* lk_render_bwd_scratch_floats(R,S,flags) floats - the layout depends on `flags`: size it with the
+                                 * flags of the call that uses it */
+    int64_t bwd_scratch_cap;    /* floats available at bwd_scratch; checked against the layout of the call (0 = unchecked) */
     /* ---- LK_FLAG_MAPPER_LOSS */
     const float* loss_gt_color;  /* [R,3] */
     float* loss_out4;            /* [4] */

@@ -52,7 +52,7 @@ class RenderDesc(C.Structure):
         ('raw', _fp), ('far_stats', _fp), ('act', _fp),
         ('d_depth', _fp), ('d_var', _fp), ('d_color', _fp),
         ('g_geo_feats', _fp), ('g_col_feats', _fp), ('g_weights', _fp), ('g_rays_o', _fp), ('g_rays_d', _fp),
-        ('g_affine', _fp), ('grad_row_mask', _fp), ('bwd_scratch', _fp),
+        ('g_affine', _fp), ('grad_row_mask', _fp), ('bwd_scratch', _fp), ('bwd_scratch_cap', C.c_int64),
         ('loss_gt_color', _fp), ('loss_out4', _fp), ('loss_w_color', C.c_float),
     ]
 

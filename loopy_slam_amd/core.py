@@ -254,7 +254,7 @@ def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_f
         st.keep_loss = mapper_loss
     st.desc = d
     # keep every tensor referenced by raw pointers alive until the next call
-    st.keep = (rays_o, rays_d, gt_depth, r2_ray, pos, geo_feats, col_feats, dec, affine, noise_geo, noise_col)
+    st.keep = (rays_o, rays_d, gt_depth, r2_ray, pos, geo_feats, col_feats, dec, affine, noise_geo, noise_col, knn)      # knn: the backward uses the handle too
     return d
 
 
@@ -304,7 +304,7 @@ def render_backward(eng, st, gs, d_depth, d_color=None, d_var=None):
     d.g_geo_feats, d.g_col_feats, d.g_weights = ptr(gs.g_geo), ptr(gs.g_col), ptr(gs.g_weights)
     d.g_rays_o, d.g_rays_d, d.g_affine = ptr(gs.g_rays_o), ptr(gs.g_rays_d), ptr(gs.g_affine)
     d.grad_row_mask = ptr(gs.row_mask)
-    d.bwd_scratch = ptr(gs.scratch)
+    d.bwd_scratch, d.bwd_scratch_cap = ptr(gs.scratch), gs.scratch.numel()
     st.keep_bwd = (d_depth, d_color, d_var)
     eng.lib.check(eng.lib.dll.lk_render_bwd(C.byref(d), eng.stream), 'lk_render_bwd')
     return gs

@@ -96,7 +96,7 @@ extern "C" int64_t lk_render_act_floats(int32_t R, int32_t S, uint32_t flags) {
 
 // ------------------------------------------------------------------ backward scratch layout
 namespace {
-struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, dw1_part, wg_part, total; };
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, dw1_part, dw2_part, wg_part, seg_rank, seg_list, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -123,7 +123,10 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     const bool rp_w = color && gw && (flags & LK_FLAG_REL_POS), fused = rp_w && lk_relpos_fused(flags);
     L.rows = o; if (rp_w && !fused) o += al(8 * 192 * P);
     L.dw1_part = o; if (fused) o += al((int64_t)lk_relpos_bwd_parts((int)P) * 128 * 64);
+    L.dw2_part = o; if (fused) o += al(lk_dw2_part_floats((int)P));
     L.wg_part = o; if (color && gw) o += al(lk_wgrad_part_floats(P, (flags & LK_FLAG_REL_POS) != 0));
+    L.seg_rank = o; if (flags & LK_FLAG_GRAD_FEATS) o += al(8 * P);
+    L.seg_list = o; if (flags & LK_FLAG_GRAD_FEATS) o += al(8 * P);
     L.total = o;
     return L;
 }
@@ -149,6 +152,12 @@ static int check_desc(const lk_render_desc* d, const char* who) {
     return LK_OK;
 }
 
+// rows of the batch counting-sorted by point for the feature-gradient gather (k_seg_count .. k_seg_place, lk_bwd2.hip): on the
+// second stream when there is one (it needs nothing but the neighbour indices), the caller's stream waits for `link` later
+namespace { struct SideStream; SideStream& side_stream(); }
+static void seg_args(const lk_render_desc* d, int P, LkFeatScatterArgs& fs);
+static int seg_sort_async(const lk_render_desc* d, int P, hipStream_t st);
+
 extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
 
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
@@ -172,6 +181,11 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
     sa.min_nn = d->min_nn;
     sa.z = d->z; sa.nbr_idx = d->nbr_idx; sa.nbr_w = d->nbr_w; sa.nbr_count = d->nbr_count; sa.c_geo = d->c_geo; sa.c_col = d->c_col;
     lk_launch_sample_interp(sa, st);
+    if ((skip & LK_FUSE_COMPOSITE_BWD) && (d->flags & LK_FLAG_GRAD_FEATS) && d->bwd_scratch) {
+        // the backward of this forward follows (lk_map_frame): sort its rows by point now, beside the decoders
+        const int rc2 = seg_sort_async(d, P, st);
+        if (rc2 != LK_OK) return rc2;
+    }
 
     const bool color = (d->flags & LK_FLAG_STAGE_COLOR) != 0;
     if (color && (d->flags & LK_FLAG_REL_POS)) {
@@ -222,7 +236,7 @@ extern "C" int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t f
 // beside the rel-pos backward and the feature scatter (fork / join with events; created once per process).
 namespace {
 int g_serial = -1;            // -1: not decided yet (environment LK_SERIAL), 0 / 1: set by lk_set_serial
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr; bool ok = false; };
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr, fork0 = nullptr, link = nullptr; bool ok = false; };
 SideStream& side_stream() {
     static SideStream s, none;
     if (g_serial < 0) g_serial = getenv("LK_SERIAL") != nullptr ? 1 : 0;
@@ -231,13 +245,34 @@ SideStream& side_stream() {
         s.ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&s.mid, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+               hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.fork0, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.link, hipEventDisableTiming) == hipSuccess;
     }
     return s;
 }
 }  // namespace
 
 extern "C" int lk_set_serial(int32_t on) { g_serial = on ? 1 : 0; return LK_OK; }
+
+static void seg_args(const lk_render_desc* d, int P, LkFeatScatterArgs& fs) {
+    const BwdLayout L = bwd_layout(P, d->flags);
+    memset(&fs, 0, sizeof(fs));
+    fs.P = P; fs.min_nn = d->min_nn; fs.nbr_idx = d->nbr_idx; fs.nbr_w = d->nbr_w; fs.nbr_count = d->nbr_count;
+    fs.row_mask = d->grad_row_mask; fs.seg_cnt = d->knn->seg_cnt; fs.seg_sums = d->knn->seg_sums; fs.N = (int)d->knn->n;
+    fs.seg_rank = reinterpret_cast<int32_t*>(d->bwd_scratch + L.seg_rank); fs.seg_list = reinterpret_cast<int32_t*>(d->bwd_scratch + L.seg_list);
+}
+static int seg_sort_async(const lk_render_desc* d, int P, hipStream_t st) {
+    LkFeatScatterArgs fs;
+    seg_args(d, P, fs);
+    SideStream& ss = side_stream();
+    if (!ss.ok) return lk_launch_seg_sort(fs, st);
+    (void)hipEventRecord(ss.fork0, st);
+    (void)hipStreamWaitEvent(ss.st, ss.fork0, 0);
+    const int rc = lk_launch_seg_sort(fs, ss.st);
+    (void)hipEventRecord(ss.link, ss.st);
+    return rc;
+}
 
 extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) { return lk_render_bwd_impl(d, (hipStream_t)stream_, 0, nullptr); }
 
@@ -263,7 +298,16 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     LK_REQUIRE(!color || d->d_color, "lk_render_bwd: colour stage needs d_color");
     const int P = d->R * d->S;
     const BwdLayout L = bwd_layout(P, flags);
+    LK_REQUIRE(d->bwd_scratch_cap == 0 || d->bwd_scratch_cap >= L.total, "lk_render_bwd: bwd_scratch is smaller than lk_render_bwd_scratch_floats(R, S, flags) for the flags of this call");
     float* S0 = d->bwd_scratch;
+
+    SideStream& ss = side_stream();
+    LkFeatScatterArgs fs;
+    seg_args(d, P, fs);
+    if (gf && !(skip & LK_SEG_SORTED)) {
+        const int rc2 = seg_sort_async(d, P, st);
+        if (rc2 != LK_OK) return rc2;
+    }
 
     LkCompositeBwdArgs cb;
     cb.R = d->R; cb.S = d->S; cb.min_nn = d->min_nn; cb.coef = d->coef;
@@ -282,7 +326,6 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     lk_launch_decode_bwd(db, st);
     if (gw) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
-    SideStream& ss = side_stream();
     const bool forked = gw && color && ss.ok;
     hipStream_t wst = st;                      // stream of the weight-gradient launches
     if (forked) {
@@ -344,10 +387,9 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     }
 
     if (gf) {
-        LkFeatScatterArgs fs;
-        fs.P = P; fs.min_nn = d->min_nn; fs.nbr_idx = d->nbr_idx; fs.nbr_w = d->nbr_w; fs.nbr_count = d->nbr_count;
         fs.dc_geo = S0 + L.dc_geo; fs.dc_col = (color && !relpos) ? S0 + L.dc_col : nullptr; fs.dfeat = relpos ? S0 + L.dfeat : nullptr;
-        fs.g_geo_feats = d->g_geo_feats; fs.g_col_feats = d->g_col_feats; fs.row_mask = d->grad_row_mask;
+        fs.g_geo_feats = d->g_geo_feats; fs.g_col_feats = d->g_col_feats;
+        if (ss.ok) (void)hipStreamWaitEvent(st, ss.link, 0);
         lk_launch_feat_scatter(fs, st);
     }
     if (gr) {
@@ -372,25 +414,26 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     }
     if (gw && relpos) {
         float* G = d->g_weights;
-        {
+        if (lk_relpos_fused(flags)) {
+            // linear1 was reduced inside k_relpos_bwd_fused (workgroup tiles), linear2 = samples x (wsum d c) (x) Hbar: two small launches
+            LkRelposBwdArgs rb;
+            memset(&rb, 0, sizeof(rb));
+            rb.P = P; rb.dc_col = S0 + L.dc_col; rb.w_sum = S0 + L.w_sum; rb.hbar = S0 + L.hbar; rb.dw1_part = S0 + L.dw1_part;
+            // on the caller's stream: after the fused kernel and the gather it has room, the weight-gradient stream is the longer one
+            lk_launch_rp_wgrad_tail(rb, S0 + L.dw2_part, G + R_W1, G + R_B1, G + R_W2, G + R_B2, st);
+        } else {
             LkWgradArgs wr;
             memset(&wr, 0, sizeof(wr));
-            const bool fused = lk_relpos_fused(flags);
-            int nj = 0;
-            if (fused) {                      // linear1 was reduced inside k_relpos_bwd_fused: add the workgroup tiles
-                lk_launch_dw1_reduce(S0 + L.dw1_part, lk_relpos_bwd_parts(P), G + R_W1, G + R_B1, wst);
-            } else {
-                const float* rows = S0 + L.rows;
-                LkWgradJob& J1 = wr.job[nj++];    // linear1 [128][52]: rows = neighbour rows, A = d hid, B = x
-                J1.A = rows; J1.lda = 192; J1.a_mode = 0; J1.B = rows + 128; J1.ldb = 192;
-                J1.N = HC; J1.K = KR; J1.rows = 8 * P; J1.dW = G + R_W1; J1.ldw = KRP; J1.db = G + R_B1;
-            }
-            LkWgradJob& J2 = wr.job[nj++];    // linear2 [32][128]: rows = SAMPLES, A = (sum_j w_j) * d c, B = sum_j w_j hid_j
+            const float* rows = S0 + L.rows;
+            LkWgradJob& J1 = wr.job[0];       // linear1 [128][52]: rows = neighbour rows, A = d hid, B = x
+            J1.A = rows; J1.lda = 192; J1.a_mode = 0; J1.B = rows + 128; J1.ldb = 192;
+            J1.N = HC; J1.K = KR; J1.rows = 8 * P; J1.dW = G + R_W1; J1.ldw = KRP; J1.db = G + R_B1;
+            LkWgradJob& J2 = wr.job[1];       // linear2 [32][128]: rows = SAMPLES, A = (sum_j w_j) * d c, B = sum_j w_j hid_j
             J2.A = S0 + L.dc_col; J2.lda = LK_C; J2.a_mode = 2; J2.A2 = S0 + L.w_sum; J2.lda2 = 1;
             J2.B = S0 + L.hbar; J2.ldb = 128;
             J2.N = CF; J2.K = HC; J2.rows = P; J2.dW = G + R_W2; J2.ldw = HC; J2.db = G + R_B2;
-            wr.n_jobs = nj; wr.chunk = 0; wr.part = S0 + L.wg_part;
-            lk_launch_wgrad(wr, fused ? P : 8 * P, wst);
+            wr.n_jobs = 2; wr.chunk = 0; wr.part = S0 + L.wg_part;
+            lk_launch_wgrad(wr, 8 * P, wst);
         }
     }
     if (forked) { (void)hipEventRecord(ss.join, wst); (void)hipStreamWaitEvent(st, ss.join, 0); }

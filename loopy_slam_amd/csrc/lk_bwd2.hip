@@ -132,6 +132,72 @@ __global__ __launch_bounds__(256) void k_feat_scatter(LkFeatScatterArgs a) {
     else if (a.dc_col) atomicAdd(a.g_col_feats + (size_t)idx * LK_C + c, w * a.dc_col[(size_t)s * LK_C + c]);
 }
 
+// The same sums with a fraction of the atomics.  A mapper batch touches few points many times (5 000 rays x 5 samples x 8
+// neighbours = 197 k rows on 15 k points of the benchmark frame: 12.7 rows per point), and the atomic scatter pays for every
+// row twice (two tables) at the memory-side atomic rate, with the adds of a point serialised on its line.  The rows are
+// counting-sorted by point - k_seg_count (rank of the row among the rows of its point), an exclusive scan of the per-point
+// counts, k_seg_place - which only needs the neighbour indices: it runs on the second stream beside the decoders.
+// k_feat_gather then gives every half-wave (32 channels) 16 consecutive rows of the sorted list: the rows of a point are
+// added in registers and flushed with ONE atomic per run (runs can continue in the next chunk) - about 27 k flushes instead
+// of 197 k, every half-wave with the same amount of work (a per-point linked list walked by its first row was slower than
+// the atomics: the longest chain sets the time).
+__global__ __launch_bounds__(256) void k_seg_count(LkFeatScatterArgs a) {
+    const long long row = (long long)blockIdx.x * 256 + (int)threadIdx.x;
+    if (row >= (long long)a.P * LK_K) return;
+    const int s = (int)(row >> 3);
+    const int idx = a.nbr_idx[row];
+    int rk = -1;
+    if (idx >= 0 && a.nbr_w[row] != 0.0f && a.nbr_count[s] >= a.min_nn && (!a.row_mask || a.row_mask[idx]))
+        rk = atomicAdd(a.seg_cnt + idx, 1);
+    a.seg_rank[row] = rk;
+}
+__global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
+    const long long row = (long long)blockIdx.x * 256 + (int)threadIdx.x;
+    if (row >= (long long)a.P * LK_K) return;
+    const int rk = a.seg_rank[row];
+    if (rk >= 0) a.seg_list[a.seg_cnt[a.nbr_idx[row]] + rk] = (int)row;
+}
+
+#define LK_GATHER_CHUNK 16
+__global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
+    const int c = (int)threadIdx.x & 31;
+    const long long i0 = ((long long)blockIdx.x * 8 + ((int)threadIdx.x >> 5)) * LK_GATHER_CHUNK;
+    const int total = a.seg_cnt[a.N];
+    if (i0 >= total) return;
+    const int n = min(LK_GATHER_CHUNK, (int)(total - i0));
+    const bool col = a.dfeat != nullptr || a.dc_col != nullptr;
+    int cur = -1;
+    float sg = 0.0f, sc = 0.0f;
+    for (int b = 0; b < n; b += 4) {                       // four rows per step: their loads are independent
+        int row[4], idx[4];
+        float vg[4], vc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row[u] = a.seg_list[i0 + min(b + u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            idx[u] = a.nbr_idx[row[u]];
+            const float w = a.nbr_w[row[u]];
+            const int s = row[u] >> 3;
+            vg[u] = w * a.dc_geo[(size_t)s * LK_C + c];
+            vc[u] = a.dfeat ? a.dfeat[(size_t)row[u] * LK_C + c] : (a.dc_col ? w * a.dc_col[(size_t)s * LK_C + c] : 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (b + u >= n) break;
+            if (idx[u] != cur) {
+                if (cur >= 0) {
+                    atomicAdd(a.g_geo_feats + (size_t)cur * LK_C + c, sg);
+                    if (col) atomicAdd(a.g_col_feats + (size_t)cur * LK_C + c, sc);
+                }
+                cur = idx[u]; sg = 0.0f; sc = 0.0f;
+            }
+            sg += vg[u]; sc += vc[u];
+        }
+    }
+    atomicAdd(a.g_geo_feats + (size_t)cur * LK_C + c, sg);
+    if (col) atomicAdd(a.g_col_feats + (size_t)cur * LK_C + c, sc);
+}
+
 __global__ __launch_bounds__(256) void k_rays_bwd(LkRaysBwdArgs a) {
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
     if (r >= a.R) return;
@@ -682,23 +748,86 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) 
         for (int q = 0; q < 16; ++q) out[(32 * (2 * p + (w >> 1)) + lk_frag_row(q, h)) * 64 + 32 * (w & 1) + j] = acc[p][q] * RPF_ISC;
 }
 
-// dW1[n][k] += sum over the workgroup tiles of k_relpos_bwd_fused ([n_parts][128][64]; column 52 = the bias gradient).
-// 32 consecutive elements x 8 partial lanes per workgroup; every output has one owner: no atomics.
-__global__ __launch_bounds__(256) void k_dw1_reduce(const float* __restrict__ part, int n_parts, float* __restrict__ dW, float* __restrict__ db) {
+// linear2 of the rel-pos MLP in the fused variant: dW2[n][k] = sum_samples (wsum_s d c_s[n]) Hbar_s[k], db2[n] = sum_s wsum_s d c_s[n]
+// ([32][128] + [32] outputs, P samples: 0.2 GFLOP - too small for the k_wgrad + k_wgrad_reduce pair, whose two launches cost
+// 50 us on the weight-gradient stream).  A workgroup stages 64 samples in LDS with coalesced 16-byte loads (the walk over the
+// samples is otherwise a chain of dependent load latencies), then thread t adds them into output row n = t >> 3, columns
+// 16 (t & 7) .. + 15, and stores a [32][129] partial tile (column 128 = bias), summed by k_rp_reduce.
+#define LK_DW2_PARTS 512
+#define LK_DW2_TILE (32 * 129)
+#define LK_DW2_SAMPLES 64
+__global__ __launch_bounds__(256) void k_dw2_hbar(const float* __restrict__ dc, const float* __restrict__ w_sum, const float* __restrict__ hbar,
+                                                  int P, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float s_h[LK_DW2_SAMPLES][128];
+    __shared__ float s_a[LK_DW2_SAMPLES][33];
+    const int t = (int)threadIdx.x, n = t >> 3, k0 = 16 * (t & 7);
+    float acc[16], bsum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int s0 = (int)blockIdx.x * LK_DW2_SAMPLES; s0 < P; s0 += (int)gridDim.x * LK_DW2_SAMPLES) {
+        const int ns = min(LK_DW2_SAMPLES, P - s0);
+        __syncthreads();
+        // Hbar rows: ns x 32 float4, thread t takes every 256th; A' = wsum * d c: ns x 32 floats
+#pragma unroll
+        for (int q = 0; q < LK_DW2_SAMPLES * 32 / 256; ++q) {
+            const int e = q * 256 + t, sm = e >> 5;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float av = 0.0f;
+            if (sm < ns) {
+                v = reinterpret_cast<const float4*>(hbar + (size_t)(s0 + sm) * 128)[e & 31];
+                av = w_sum[s0 + sm] * dc[(size_t)(s0 + sm) * LK_C + (e & 31)];
+            }
+            reinterpret_cast<float4*>(&s_h[sm][0])[e & 31] = v;
+            s_a[sm][e & 31] = av;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int sm = 0; sm < LK_DW2_SAMPLES; ++sm) {
+            const float av = s_a[sm][n];
+            const float4* __restrict__ hb = reinterpret_cast<const float4*>(&s_h[sm][k0]);
+            bsum += av;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = hb[q];
+                acc[4 * q] = fmaf(av, v.x, acc[4 * q]); acc[4 * q + 1] = fmaf(av, v.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(av, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(av, v.w, acc[4 * q + 3]);
+            }
+        }
+    }
+    float* __restrict__ out = part + (size_t)blockIdx.x * LK_DW2_TILE + n * 129;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[k0 + i] = acc[i];
+    if (k0 == 0) out[128] = bsum;
+}
+
+// Sums of the partial tiles of the fused variant: linear1 [n1][128][64] (column 52 = bias) from k_relpos_bwd_fused, linear2
+// [n2][32][129] (column 128 = bias) from k_dw2_hbar.  32 consecutive elements x 8 partial lanes per workgroup; every output has one
+// owner: no atomics, fixed order.
+__global__ __launch_bounds__(256) void k_rp_reduce(const float* __restrict__ part1, int n1, const float* __restrict__ part2, int n2,
+                                                   float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2) {
     __shared__ float sh[8][32];
     const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
-    const int o = (int)blockIdx.x * 32 + e;
-    const float* __restrict__ src = part + o;
+    const bool second = (int)blockIdx.x >= 128 * 64 / 32;
+    const int o = ((int)blockIdx.x - (second ? 128 * 64 / 32 : 0)) * 32 + e;
+    const int tile = second ? LK_DW2_TILE : 128 * 64, n_parts = second ? n2 : n1;
+    const bool in = o < tile;
+    const float* __restrict__ src = (second ? part2 : part1) + (in ? o : 0);
     float s = 0.0f;
 #pragma unroll 4
-    for (int y = q; y < n_parts; y += 8) s += src[(size_t)y * (128 * 64)];
+    for (int y = q; y < n_parts; y += 8) s += src[(size_t)y * tile];
     sh[q][e] = s;
     __syncthreads();
-    if (q != 0) return;
+    if (q != 0 || !in) return;
     s = ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) + ((sh[4][e] + sh[5][e]) + (sh[6][e] + sh[7][e]));
-    const int n = o >> 6, k = o & 63;
-    if (k < KR) dW[(size_t)n * KRP + k] += s;
-    else if (k == KR) db[n] += s;
+    if (!second) {
+        const int n = o >> 6, k = o & 63;
+        if (k < KR) dW1[(size_t)n * KRP + k] += s;
+        else if (k == KR) db1[n] += s;
+    } else {
+        const int n = o / 129, k = o - n * 129;
+        if (k < 128) dW2[(size_t)n * 128 + k] += s;
+        else db2[n] += s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -915,7 +1044,16 @@ int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
 }
 int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_FEAT_SCATTER, st);
-    hipLaunchKernelGGL(k_feat_scatter, dim3(lk_cdiv((long long)a.P * LK_K, 8)), dim3(256), 0, st, a);
+    if (a.seg_cnt) hipLaunchKernelGGL(k_feat_gather, dim3(lk_cdiv((long long)a.P * LK_K, 8 * LK_GATHER_CHUNK)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_feat_scatter, dim3(lk_cdiv((long long)a.P * LK_K, 8)), dim3(256), 0, st, a);
+    return LK_OK;
+}
+int lk_launch_seg_sort(const LkFeatScatterArgs& a, hipStream_t st) {
+    const int nb = lk_cdiv((long long)a.P * LK_K, 256);
+    LK_HIP_TRY(hipMemsetAsync(a.seg_cnt, 0, sizeof(int32_t) * (size_t)(a.N + 1), st));
+    hipLaunchKernelGGL(k_seg_count, dim3(nb), dim3(256), 0, st, a);
+    lk_launch_scan_i32(a.seg_cnt, a.seg_sums, a.N + 1, st);
+    hipLaunchKernelGGL(k_seg_place, dim3(nb), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st) {
@@ -931,8 +1069,13 @@ int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL(k_relpos_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;
 }
-int lk_launch_dw1_reduce(const float* part, int n_parts, float* dW, float* db, hipStream_t st) {
-    hipLaunchKernelGGL(k_dw1_reduce, dim3(128 * 64 / 32), dim3(256), 0, st, part, n_parts, dW, db);
+int lk_dw2_parts(int P) { const int n = lk_cdiv(P, LK_DW2_SAMPLES); return n < 1 ? 1 : (n < LK_DW2_PARTS ? n : LK_DW2_PARTS); }
+int64_t lk_dw2_part_floats(int P) { return (int64_t)lk_dw2_parts(P) * LK_DW2_TILE; }
+int lk_launch_rp_wgrad_tail(const LkRelposBwdArgs& a, float* dw2_part, float* dW1, float* db1, float* dW2, float* db2, hipStream_t st) {
+    const int n2 = lk_dw2_parts(a.P);
+    hipLaunchKernelGGL(k_dw2_hbar, dim3(n2), dim3(256), 0, st, a.dc_col, a.w_sum, a.hbar, a.P, dw2_part);
+    hipLaunchKernelGGL(k_rp_reduce, dim3(128 * 64 / 32 + lk_cdiv(LK_DW2_TILE, 32)), dim3(256), 0, st, a.dw1_part, lk_relpos_bwd_parts(a.P),
+                       dw2_part, n2, dW1, db1, dW2, db2);
     return LK_OK;
 }
 int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {

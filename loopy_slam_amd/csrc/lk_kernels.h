@@ -109,7 +109,15 @@ struct LkFeatScatterArgs {
     const float* dc_geo; const float* dc_col; const float* dfeat;
     float* g_geo_feats; float* g_col_feats;
     const uint8_t* row_mask;                       // [N] or NULL: scatter only into rows flagged non-zero
+    // counting sort of the rows by point (lk_launch_seg_sort) -> gather without per-row atomics; seg_cnt == NULL: atomic scatter
+    int32_t* seg_cnt;                              // [N + 1] (lk_knn_s::seg_cnt) rows per point, then their exclusive offsets; [N] = rows in the list
+    int32_t* seg_sums;                             // scan scratch (lk_knn_s::seg_sums)
+    int32_t* seg_rank;                             // [8P] rank of the row among the rows of its point, -1 = row takes no part
+    int32_t* seg_list;                             // [8P] rows ordered by point
+    int N;
 };
+int lk_launch_seg_sort(const LkFeatScatterArgs& a, hipStream_t st);
+int lk_launch_scan_i32(int32_t* data, int32_t* block_sums, int total, hipStream_t st);
 
 struct LkRaysBwdArgs { int R, S; const float* z; const float* dp_total; float* g_rays_o; float* g_rays_d; };
 
@@ -140,7 +148,9 @@ static inline bool lk_relpos_fused(unsigned flags) {
     return (flags & LK_FLAG_GRAD_WEIGHTS) && (flags & LK_FLAG_UNIT_LOSS_GRADS) && !(flags & LK_FLAG_GRAD_RAYS);
 }
 int lk_relpos_bwd_parts(int P);                    // workgroups = partial tiles of the fused variant
-int lk_launch_dw1_reduce(const float* part, int n_parts, float* dW, float* db, hipStream_t st);
+// linear2 partial tiles (k_dw2_hbar) + the sums of both matrices' tiles (k_rp_reduce); dw2_part: lk_dw2_part_floats(P) floats
+int64_t lk_dw2_part_floats(int P);
+int lk_launch_rp_wgrad_tail(const LkRelposBwdArgs& a, float* dw2_part, float* dW1, float* db1, float* dW2, float* db2, hipStream_t st);
 
 // weight gradients: dW[n][k] += sum_rows A[row][n] * B[row][k]  (one wave per (job, column unit, row chunk))
 struct LkWgradJob {
@@ -168,7 +178,8 @@ struct LkWgradArgs {
 inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_WAVES * LK_WG_TILE; }
 
 // lk_render_fwd / lk_render_bwd with parts of their launch sequence left to the caller (the fused per-frame loops, lk_loop.hip)
-enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, LK_FUSE_COMPOSITE_BWD = 8, LK_LOSS_PREZEROED = 16 };
+enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, LK_FUSE_COMPOSITE_BWD = 8, LK_LOSS_PREZEROED = 16,
+       LK_SEG_SORTED = 32 /* bwd: the forward (LK_FUSE_COMPOSITE_BWD + GRAD_FEATS) already sorted the rows by point */ };
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip);
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total; };

@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256) void k_count(const float* __restrict__ pos, in
 }
 
 // in-place exclusive scan of (ncells+1) counts: block-local scan + block totals
+// (g == NULL: the length is the host-known `total_host` - lk_launch_scan_i32)
 __global__ __launch_bounds__(256) void k_scan_block(int32_t* __restrict__ data, int32_t* __restrict__ block_sums,
-                                                    const LkGrid* __restrict__ g) {
+                                                    const LkGrid* __restrict__ g, int total_host) {
     __shared__ int wsum[4];
-    const int total = g->ncells + 1;
+    const int total = g ? g->ncells + 1 : total_host;
     const int base = blockIdx.x * SCAN_ITEMS;
     if (base >= total) return;                       // uniform per block
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(256) void k_scan_block(int32_t* __restrict__ data, 
 }
 
 // exclusive scan of the block totals (single block, 256 at a time with a running carry)
-__global__ __launch_bounds__(256) void k_scan_sums(int32_t* __restrict__ block_sums, const LkGrid* __restrict__ g) {
+__global__ __launch_bounds__(256) void k_scan_sums(int32_t* __restrict__ block_sums, const LkGrid* __restrict__ g, int total_host) {
     __shared__ int wsum[4];
     __shared__ int carry;
-    const int nb = (g->ncells + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    const int nb = ((g ? g->ncells + 1 : total_host) + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (t == 0) carry = 0;
     __syncthreads();
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(256) void k_scan_sums(int32_t* __restrict__ block_s
 }
 
 __global__ __launch_bounds__(256) void k_scan_add(int32_t* __restrict__ data, const int32_t* __restrict__ block_sums,
-                                                  const LkGrid* __restrict__ g) {
-    const int total = g->ncells + 1;
+                                                  const LkGrid* __restrict__ g, int total_host) {
+    const int total = g ? g->ncells + 1 : total_host;
     const int base = blockIdx.x * SCAN_ITEMS;
     if (base >= total) return;
     const int off = block_sums[blockIdx.x];
@@ -196,6 +197,17 @@ __global__ __launch_bounds__(256) void k_knn_query(const LkGrid* __restrict__ g,
 }
 
 // ------------------------------------------------------------------ host API
+// in-place exclusive scan of `total` int32 counts (block_sums: lk_cdiv(total, 1024) + 256 ints of scratch)
+int lk_launch_scan_i32(int32_t* data, int32_t* block_sums, int total, hipStream_t st) {
+    const int nb = lk_cdiv(total, SCAN_ITEMS);
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, st, data, block_sums, (const LkGrid*)nullptr, total);
+    if (nb > 1) {
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, block_sums, (const LkGrid*)nullptr, total);
+        hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, st, data, (const int32_t*)block_sums, (const LkGrid*)nullptr, total);
+    }
+    return LK_OK;
+}
+
 extern "C" int lk_knn_create(float cell_size, int64_t capacity_points, int64_t max_cells, lk_knn_t* out) {
     LK_REQUIRE(out != nullptr, "lk_knn_create: out is NULL");
     LK_REQUIRE(cell_size > 0.0f, "lk_knn_create: cell_size must be > 0");
@@ -215,6 +227,8 @@ extern "C" int lk_knn_create(float cell_size, int64_t capacity_points, int64_t m
     if (e == hipSuccess) e = hipMalloc((void**)&h->cell_of, sizeof(int32_t) * (size_t)capacity_points);
     if (e == hipSuccess) e = hipMalloc((void**)&h->rank_of, sizeof(int32_t) * (size_t)capacity_points);
     if (e == hipSuccess) e = hipMalloc((void**)&h->block_sums, sizeof(int32_t) * (size_t)(h->n_scan_blocks + 256));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_cnt, sizeof(int32_t) * (size_t)(capacity_points + 1 + SCAN_ITEMS));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_sums, sizeof(int32_t) * (size_t)(lk_cdiv(capacity_points + 1, SCAN_ITEMS) + 256));
     if (e == hipSuccess) e = hipMemset(h->grid, 0, sizeof(LkGrid));
     if (e != hipSuccess) {
         lk_set_error("lk_knn_create: allocation failed: %s", hipGetErrorString(e));
@@ -234,6 +248,8 @@ extern "C" int lk_knn_destroy(lk_knn_t h) {
     if (h->rank_of) (void)hipFree(h->rank_of);
     if (h->block_sums) (void)hipFree(h->block_sums);
     if (h->pos_own) (void)hipFree(h->pos_own);
+    if (h->seg_cnt) (void)hipFree(h->seg_cnt);
+    if (h->seg_sums) (void)hipFree(h->seg_sums);
     delete h;
     return LK_OK;
 }
@@ -257,9 +273,9 @@ extern "C" int lk_knn_build(lk_knn_t h, const float* pos, int64_t N, void* strea
         hipLaunchKernelGGL(k_zero_counts, dim3(2048), dim3(256), 0, st, h->cell_start, h->grid);
         hipLaunchKernelGGL(k_count, dim3(lk_cdiv(n, 256)), dim3(256), 0, st, pos, n, h->grid, h->cell_start,
                            h->cell_of, h->rank_of);
-        hipLaunchKernelGGL(k_scan_block, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->block_sums, h->grid);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, h->block_sums, h->grid);
-        hipLaunchKernelGGL(k_scan_add, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->block_sums, h->grid);
+        hipLaunchKernelGGL(k_scan_block, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->block_sums, h->grid, 0);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, h->block_sums, h->grid, 0);
+        hipLaunchKernelGGL(k_scan_add, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->block_sums, h->grid, 0);
         hipLaunchKernelGGL(k_scatter, dim3(lk_cdiv(n, 256)), dim3(256), 0, st, pos, n, h->cell_start, h->cell_of,
                            h->rank_of, h->sorted);
     }

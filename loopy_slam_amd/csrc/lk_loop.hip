@@ -485,7 +485,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             // the loss gradient is final when the composite kernel has written it: its backward rides in the same launch
             rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? LK_LOSS_PREZEROED : 0));
             if (rc != LK_OK) return rc;
-            rc = lk_render_bwd_impl(&rd, st, LK_SKIP_COMPOSITE_BWD);
+            rc = lk_render_bwd_impl(&rd, st, LK_SKIP_COMPOSITE_BWD | LK_SEG_SORTED);
             if (rc != LK_OK) return rc;
         }
         if (phases & 2) {

@@ -209,8 +209,10 @@ class MapOptimizer:
         depth_stack, color_stack, c2w_stack, r2_stack = frames
         core.fill_desc(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col, self.dec, 'color',
                        r2_ray=b.r2_ray, save_act=True)
-        flags = st.desc.flags | _ffi.FLAG_GRAD_FEATS | _ffi.FLAG_GRAD_WEIGHTS
-        need = int(eng.lib.dll.lk_render_bwd_scratch_floats(self.R, self.cfg.S, flags))
+        # the scratch layout depends on the flags: size it with exactly the words lk_map_frame renders with, in both stages
+        base = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | _ffi.FLAG_UNIT_LOSS_GRADS | _ffi.FLAG_SAVE_ACT | _ffi.FLAG_GRAD_FEATS | \
+            _ffi.FLAG_GRAD_WEIGHTS | _ffi.FLAG_ZERO_ABSENT | _ffi.FLAG_MAPPER_LOSS
+        need = max(int(eng.lib.dll.lk_render_bwd_scratch_floats(self.R, self.cfg.S, base | extra)) for extra in (0, _ffi.FLAG_STAGE_COLOR))
         if gs.scratch is None or gs.scratch.numel() < need:
             gs.scratch = eng.empty(max(1, need))
         d = _ffi.MapDesc()
@@ -220,7 +222,7 @@ class MapOptimizer:
         r.flags = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | _ffi.FLAG_UNIT_LOSS_GRADS      # L1 sums: |d depth|, |d colour| <= 1
         r.d_depth, r.d_color = ptr(b.d_depth), ptr(b.d_color)
         r.g_geo_feats, r.g_col_feats, r.g_weights = ptr(gs.g_geo), ptr(gs.g_col), ptr(gs.g_weights)
-        r.grad_row_mask, r.bwd_scratch = ptr(gs.row_mask), ptr(gs.scratch)
+        r.grad_row_mask, r.bwd_scratch, r.bwd_scratch_cap = ptr(gs.row_mask), ptr(gs.scratch), gs.scratch.numel()
         H0, H1, W0, W1 = window
         d.depth_stack, d.color_stack, d.c2w_stack, d.c2w_stride = ptr(depth_stack), ptr(color_stack), ptr(c2w_stack), c2w_stack.shape[-2] * 4
         d.r2_map_stack, d.frame_id = ptr(r2_stack), ptr(frame_id)
@@ -387,7 +389,7 @@ class TrackOptimizer:
         r = d.render
         r.flags = _ffi.FLAG_REL_POS if self.cfg.rel_pos else 0
         r.d_depth, r.d_color = ptr(b.d_depth), ptr(b.d_color)
-        r.g_rays_o, r.g_rays_d, r.bwd_scratch = ptr(gs.g_rays_o), ptr(gs.g_rays_d), ptr(gs.scratch)
+        r.g_rays_o, r.g_rays_d, r.bwd_scratch, r.bwd_scratch_cap = ptr(gs.g_rays_o), ptr(gs.g_rays_d), ptr(gs.scratch), gs.scratch.numel()
         d.depth_img, d.color_img, d.r2_map = ptr(depth_img), ptr(color_img), ptr(r2_map)
         d.H, d.W, d.H0, d.W0, d.w = H, W, H0, W0, W1 - W0
         d.fx, d.fy, d.cx, d.cy = intr

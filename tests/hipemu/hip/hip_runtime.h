@@ -251,9 +251,10 @@ template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 
 // ---- host API
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : 2; }
+namespace hipemu { void* guarded_alloc(size_t n); void guarded_free(void* p); }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = hipemu::guarded_alloc(n); return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
-static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipFree(void* p) { hipemu::guarded_free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }

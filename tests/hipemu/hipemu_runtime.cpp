@@ -233,3 +233,30 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 }
 
 }  // namespace hipemu
+
+// ---- device allocations with a canary behind the requested size: a kernel writing past its buffer aborts the test run at
+// hipFree with the size of the offending allocation instead of corrupting the host heap
+#include <map>
+namespace hipemu {
+static std::map<void*, size_t>& alloc_map() { static std::map<void*, size_t> m; return m; }
+static const size_t GUARD = 1024;
+void* guarded_alloc(size_t n) {
+    const size_t tot = (n + GUARD + 255) / 256 * 256 + 256;
+    char* p = (char*)std::aligned_alloc(256, tot);
+    if (!p) return nullptr;
+    std::memset(p + n, 0xA5, GUARD);
+    alloc_map()[p] = n;
+    return p;
+}
+void guarded_free(void* p) {
+    if (!p) return;
+    auto it = alloc_map().find(p);
+    if (it != alloc_map().end()) {
+        const unsigned char* g = (const unsigned char*)p + it->second;
+        for (size_t i = 0; i < GUARD; ++i)
+            if (g[i] != 0xA5) { std::fprintf(stderr, "hipemu: write past the end of a %zu-byte device allocation (offset +%zu)\n", it->second, i); std::abort(); }
+        alloc_map().erase(it);
+    }
+    std::free(p);
+}
+}  // namespace hipemu
