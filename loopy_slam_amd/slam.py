@@ -24,9 +24,17 @@ from .common import get_camera_from_tensor, get_tensor_from_camera, get_rays, ge
 
 
 def _inv_pose(c2w, device):
-    """world->camera of a 4x4 pose: inverted on the host in float64 (a device solver call costs a library start-up and a
-    launch chain for 16 numbers), returned as float32 on `device`."""
-    return torch.linalg.inv(c2w.detach().double().cpu()).float().to(device)
+    """world->camera of 4x4 poses ([4,4] or [K,4,4]) on `device`, no host round trip.  The reference inverts the general
+    matrix (np.linalg.inv / torch.inverse, Mapper.py:173, 247); estimated and ground-truth poses are rigid, so the inverse is
+    [R^T | -R^T t] - a transpose and one small product instead of a solver launch chain per keyframe; evaluated in float64
+    it agrees with the general inverse to the float32 rounding of the result (tests/test_slam_api.py)."""
+    c = c2w.detach().to(device=device, dtype=torch.float64)
+    Rt = c[..., :3, :3].transpose(-1, -2)
+    w2c = torch.zeros_like(c)
+    w2c[..., :3, :3] = Rt
+    w2c[..., :3, 3] = -(Rt @ c[..., :3, 3:4])[..., 0]
+    w2c[..., 3, 3] = 1.0
+    return w2c.float()
 
 
 def render_cfg_from(cfg, coef):
@@ -171,7 +179,8 @@ class NeuralPointCloud:
         self.near_end_surface, self.far_end_surface = pc['near_end_surface'], pc['far_end_surface']
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self._cell = max(pc['radius_query'], 1e-3)
-        self._gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219))
+        # feature initialisation draws on the device (Philox): no host RNG + upload per insertion
+        self._gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219))
         self._alloc(capacity)
         self.n = 0
         self._input_pos, self._input_rgb = [], []
@@ -289,8 +298,9 @@ class NeuralPointCloud:
         if k:
             self._grow(self.n + k)
             self._pos[self.n:self.n + k] = pts
-            self._geo[self.n:self.n + k] = (torch.randn(k, 32, generator=self._gen) * 0.1).to(self.eng.device)
-            self._col[self.n:self.n + k] = (torch.randn(k, 32, generator=self._gen) * 0.1).to(self.eng.device)
+            # neural_point.py:1608-1614: normal(0, 0.1) features for the new points
+            self._geo[self.n:self.n + k] = torch.randn(k, 32, generator=self._gen, device=self.eng.device) * 0.1
+            self._col[self.n:self.n + k] = torch.randn(k, 32, generator=self._gen, device=self.eng.device) * 0.1
             self.n += k
             self.knn.build(self._pos[:self.n])             # counting-sort rebuild on the device (no IVF re-training)
         return n_acc
@@ -424,6 +434,20 @@ class Mapper:
         inside = (u < self.W) & (u > 0) & (v < self.H) & (v > 0)
         return ~inside
 
+    def overlap_fractions(self, pts, est_c2ws):
+        """Fraction of the points [n,3] that project inside every keyframe's image minus a 20-pixel edge, in front of the camera
+        (Mapper.py:250-270) - all keyframes in one batched projection on the device (the reference loops over them on the host with
+        a numpy inverse each).  As in the reference this projection does NOT mirror x (the flip is commented out there, unlike
+        get_mask_from_c2w / filter_point_before_add) and tests z + 1e-5 < 0."""
+        dev = self.eng.device
+        w2c = _inv_pose(torch.stack([c.to(dev).float() for c in est_c2ws]), dev)                       # [K,4,4]
+        cam = torch.einsum('kij,nj->kni', w2c[:, :3, :3], pts) + w2c[:, None, :3, 3]
+        z = cam[..., 2] + 1e-5
+        u = (self.fx * cam[..., 0] + self.cx * cam[..., 2]) / z
+        v = (self.fy * cam[..., 1] + self.cy * cam[..., 2]) / z
+        m = (u < self.W - 20) & (u > 20) & (v < self.H - 20) & (v > 20) & (z < 0)
+        return m.float().mean(dim=1)
+
     def keyframe_selection_overlap(self, gt_color, gt_depth, c2w, keyframe_dict, k, N_samples=8, pixels=200):
         """Keyframes that see the current frame's points, random k of them (Mapper.py:219-282)."""
         dev = self.eng.device
@@ -432,16 +456,12 @@ class Mapper:
         t = torch.linspace(0., 1., N_samples, device=dev)
         z = gd[:, None] * 0.8 * (1 - t) + (gd[:, None] + 0.5) * t
         pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(-1, 3)
-        scored = []
-        for kid, kf in enumerate(keyframe_dict):
-            w2c = _inv_pose(kf['est_c2w'], dev)
-            cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
-            zc = cam[:, 2] + 1e-5
-            u = (self.fx * -cam[:, 0] + self.cx * cam[:, 2]) / zc
-            v = (self.fy * cam[:, 1] + self.cy * cam[:, 2]) / zc
-            m = (u < self.W - 20) & (u > 20) & (v < self.H - 20) & (v > 20) & (cam[:, 2] < 0)
-            scored.append((float(m.float().mean()), kid))
-        scored = [kid for p, kid in sorted(scored, reverse=True) if p > 0.0]
+        if len(keyframe_dict) == 0:
+            return []
+        frac = self.overlap_fractions(pts, [kf['est_c2w'] for kf in keyframe_dict]).cpu().tolist()   # one transfer for all keyframes
+        # sorted by overlap (stable, as Python's sorted on the reference's dicts), then a random k of those with any overlap
+        order = sorted(range(len(frac)), key=lambda i: frac[i], reverse=True)
+        scored = [i for i in order if frac[i] > 0.0]
         perm = torch.randperm(len(scored), generator=self.gen).tolist()
         return [scored[i] for i in perm[:k]]
 

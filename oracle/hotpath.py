@@ -616,3 +616,25 @@ def add_points_schedule(idx, depth_img, color_img, c2w, prev_c2w, cloud_pos, int
         ro, rd, gd, r = rays(draws['grad'])
         insert(ro, rd, gd, r, True)
     return sum(counts), counts, cloud
+
+
+def keyframe_overlap_fractions(vertices, est_c2ws, fx, fy, cx, cy, H, W):
+    """percent_inside of src/Mapper.py:250-270 for every keyframe pose, statement by statement in numpy: w2c = inv(c2w), homogeneous
+    product, K @ cam (x NOT mirrored - the flip is commented out in this function of the reference), z = uv_z + 1e-5, float32 uv,
+    20-pixel edge, z < 0."""
+    vertices = np.asarray(vertices, dtype=np.float32)
+    out = []
+    for c2w in est_c2ws:
+        w2c = np.linalg.inv(np.asarray(c2w, dtype=np.float32))
+        ones = np.ones_like(vertices[:, 0]).reshape(-1, 1)
+        homo = np.concatenate([vertices, ones], axis=1).reshape(-1, 4, 1)
+        cam = (w2c @ homo)[:, :3]
+        K = np.array([[fx, .0, cx], [.0, fy, cy], [.0, .0, 1.0]]).reshape(3, 3)
+        uv = K @ cam
+        z = uv[:, -1:] + 1e-5
+        uv = (uv[:, :2] / z).astype(np.float32)
+        edge = 20
+        mask = (uv[:, 0] < W - edge) * (uv[:, 0] > edge) * (uv[:, 1] < H - edge) * (uv[:, 1] > edge)
+        mask = mask & (z[:, :, 0] < 0)
+        out.append(mask.reshape(-1).sum() / uv.shape[0])
+    return np.asarray(out)

@@ -317,3 +317,40 @@ def test_load_reference_shaped_checkpoint(backend, tmp_path):
     _, color, depth, c2w = ps.frame_reader[3]
     ps2.tracker.track_frame(3, color, depth, c2w)
     ps2.mapper.map_frame(3, color, depth, c2w)                    # would raise KeyError: 'r2_query' without the conversion
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_keyframe_overlap_matches_oracle(backend):
+    """Mapper.keyframe_selection_overlap (f3): the batched device projection with the closed-form rigid inverse gives the overlap
+    fractions of the reference's per-keyframe numpy loop (oracle.keyframe_overlap_fractions, Mapper.py:250-270) - at most the few
+    points that sit on a threshold may flip - and the same ranking; _inv_pose equals the general float64 inverse."""
+    from loopy_slam_amd import synthetic as syn
+    S = slam
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    mp = slam.Point_SLAM(cfg, None, eng=eng).mapper
+    dev = eng.device
+    intr = syn.TUM_INTR                                            # the 20-pixel edge needs a real image size
+    mp.H, mp.W, mp.fx, mp.fy, mp.cx, mp.cy = (intr[k] for k in ('H', 'W', 'fx', 'fy', 'cx', 'cy'))
+    poses = [syn.loop_pose(i, 40, 'cpu') for i in (0, 3, 7, 12, 20, 33)]
+    poses.append(syn.loop_pose(20, 40, 'cpu') @ torch.diag(torch.tensor([1., 1., -1., 1.])))       # a camera looking the other way
+    for c in poses:
+        ref = torch.linalg.inv(c.double())
+        assert torch.allclose(S._inv_pose(c, dev).cpu().double(), ref, atol=2e-6)
+    depth, color, c2w = syn.render_frame(5, intr=intr, device='cpu', holes=0.02, n_poses=40)
+    g = torch.Generator().manual_seed(3)
+    flat = torch.randint(0, depth.numel(), (300,), generator=g)
+    Wd = depth.shape[1]
+    ro, rd = H.rays_from_uv((flat % Wd).float(), (flat // Wd).float(), c2w, mp.fx, mp.fy, mp.cx, mp.cy)
+    gd = depth.reshape(-1)[flat]
+    keep = gd > 0
+    ro, rd, gd = ro[keep], rd[keep], gd[keep]
+    t = torch.linspace(0., 1., 8)
+    z = gd[:, None] * 0.8 * (1 - t) + (gd[:, None] + 0.5) * t
+    pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(-1, 3)
+    want = H.keyframe_overlap_fractions(pts.numpy(), [p.numpy() for p in poses], mp.fx, mp.fy, mp.cx, mp.cy, mp.H, mp.W)
+    got = mp.overlap_fractions(pts.to(dev), poses).cpu().numpy()
+    assert np.abs(got - want).max() <= 3.0 / pts.shape[0], (got, want)
+    assert want.max() > 0.5 and want.min() == 0.0                # the case covers seen and unseen keyframes
+    sel = mp.keyframe_selection_overlap(color.to(dev), depth.to(dev), c2w.to(dev), [{'est_c2w': p.to(dev)} for p in poses], 3)
+    assert len(sel) == 3 and all(want[i] > 0 for i in sel)
