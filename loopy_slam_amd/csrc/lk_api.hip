@@ -324,7 +324,11 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dh_col = S0 + L.dh_col; db.dlogit = S0 + L.dlogit;
     db.dp_embed = S0 + L.dp_embed; db.dp_embed_col = S0 + L.dp_embed_col; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.part_bg = S0 + L.part_bg;
     lk_launch_decode_bwd(db, st);
-    if (gw) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
+    // mapper 'color' backward with one weight-gradient launch: every partial-sum reduction is deferred to ONE launch at the end
+    const bool defer = gw && color && (!relpos || lk_relpos_fused(flags));
+    LkWgradArgs wdef;
+    wdef.n_units = 0; wdef.part = nullptr;
+    if (gw && !defer) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
     const bool forked = gw && color && ss.ok;
     hipStream_t wst = st;                      // stream of the weight-gradient launches
@@ -367,7 +371,8 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
         }
         wa.n_jobs = nj; wa.chunk = 0; wa.part = S0 + L.wg_part;
-        lk_launch_wgrad(wa, P, wst);
+        wa.h16 = (flags & LK_FLAG_UNIT_LOSS_GRADS) && !gr ? 1 : 0;
+        lk_launch_wgrad(wa, P, wst, defer ? &wdef : nullptr);
     }
 
     if (relpos) {
@@ -382,8 +387,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         rb.part_br = S0 + L.part_br; rb.hbar = S0 + L.hbar; rb.w_sum = S0 + L.w_sum; rb.dw1_part = S0 + L.dw1_part;
         lk_launch_relpos_bwd(rb, st);
         if (forked) { (void)hipEventRecord(ss.mid, st); (void)hipStreamWaitEvent(wst, ss.mid, 0); }
-        if (gw) lk_launch_reduce_partials(S0 + L.part_br, lk_relpos_fused(flags) ? lk_relpos_bwd_parts(P) : lk_cdiv(lk_cdiv(P, 4), 4), 32,
-                                          d->g_weights + R_EB, st);
+        if (gw && !defer) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
     }
 
     if (gf) {
@@ -420,7 +424,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             memset(&rb, 0, sizeof(rb));
             rb.P = P; rb.dc_col = S0 + L.dc_col; rb.w_sum = S0 + L.w_sum; rb.hbar = S0 + L.hbar; rb.dw1_part = S0 + L.dw1_part;
             // on the caller's stream: after the fused kernel and the gather it has room, the weight-gradient stream is the longer one
-            lk_launch_rp_wgrad_tail(rb, S0 + L.dw2_part, G + R_W1, G + R_B1, G + R_W2, G + R_B2, st);
+            lk_launch_rp_wgrad_tail(rb, S0 + L.dw2_part, nullptr, nullptr, nullptr, nullptr, st);
         } else {
             LkWgradArgs wr;
             memset(&wr, 0, sizeof(wr));
@@ -437,6 +441,19 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         }
     }
     if (forked) { (void)hipEventRecord(ss.join, wst); (void)hipStreamWaitEvent(st, ss.join, 0); }
+    if (defer) {
+        float* G = d->g_weights;
+        LkBwdReduceArgs r;
+        memset(&r, 0, sizeof(r));
+        const bool with_rp = relpos;          // (defer && relpos) == the fused variant
+        if (with_rp) {
+            r.part1 = S0 + L.dw1_part; r.n1 = lk_relpos_bwd_parts(P); r.part2 = S0 + L.dw2_part; r.n2 = lk_dw2_parts(P);
+            r.dW1 = G + R_W1; r.db1 = G + R_B1; r.dW2 = G + R_W2; r.db2 = G + R_B2;
+            r.part_br = S0 + L.part_br; r.n_br = lk_relpos_bwd_parts(P); r.out_br = G + R_EB;
+        }
+        r.part_bg = S0 + L.part_bg; r.n_bg = lk_cdiv(lk_cdiv(P, 32), 4); r.out_bg = G + G_EB;
+        lk_launch_bwd_reduce(wdef, r, with_rp, st);
+    }
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

@@ -803,12 +803,12 @@ __global__ __launch_bounds__(256) void k_dw2_hbar(const float* __restrict__ dc, 
 // Sums of the partial tiles of the fused variant: linear1 [n1][128][64] (column 52 = bias) from k_relpos_bwd_fused, linear2
 // [n2][32][129] (column 128 = bias) from k_dw2_hbar.  32 consecutive elements x 8 partial lanes per workgroup; every output has one
 // owner: no atomics, fixed order.
-__global__ __launch_bounds__(256) void k_rp_reduce(const float* __restrict__ part1, int n1, const float* __restrict__ part2, int n2,
-                                                   float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2) {
-    __shared__ float sh[8][32];
+__device__ __forceinline__ void rp_reduce_body(const float* __restrict__ part1, int n1, const float* __restrict__ part2, int n2,
+                                               float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                               int bx, float (*sh)[32]) {
     const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
-    const bool second = (int)blockIdx.x >= 128 * 64 / 32;
-    const int o = ((int)blockIdx.x - (second ? 128 * 64 / 32 : 0)) * 32 + e;
+    const bool second = bx >= 128 * 64 / 32;
+    const int o = (bx - (second ? 128 * 64 / 32 : 0)) * 32 + e;
     const int tile = second ? LK_DW2_TILE : 128 * 64, n_parts = second ? n2 : n1;
     const bool in = o < tile;
     const float* __restrict__ src = (second ? part2 : part1) + (in ? o : 0);
@@ -828,6 +828,12 @@ __global__ __launch_bounds__(256) void k_rp_reduce(const float* __restrict__ par
         if (k < 128) dW2[(size_t)n * 128 + k] += s;
         else db2[n] += s;
     }
+}
+#define LK_RP_REDUCE_BLOCKS (128 * 64 / 32 + (LK_DW2_TILE + 31) / 32)
+__global__ __launch_bounds__(256) void k_rp_reduce(const float* __restrict__ part1, int n1, const float* __restrict__ part2, int n2,
+                                                   float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2) {
+    __shared__ float sh[8][32];
+    rp_reduce_body(part1, n1, part2, n2, dW1, db1, dW2, db2, (int)blockIdx.x, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -860,7 +866,13 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
     return r;
 }
 
-template <int NV, int KV, int MODE>
+// H16 (mapper mode, LkWgradArgs::h16): the product runs on the 16-bit matrix pipe.  Eight consecutive ring slots ARE the
+// operands of one v_mfma_f32_32x32x16_f16 as they stand: the lane of half h holds rows 2 j + h, j = 0..7, of its column - any
+// order of the 16 reduction indices is as good as another when A and B agree - so the loaded values are only cut into fp16
+// pieces (hi + lo, lk_split8h; A' times 2^10 first: unit-scale loss gradients put d h around 1e-4) and multiplied with three
+// instructions of 32 cycles per 16 rows instead of eight fp32 instructions of 64 cycles, which did not overlap with the
+// VALU work either.  The tile is scaled back when it is stored.
+template <int NV, int KV, int MODE, bool H16>
 __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane,
                                            float* __restrict__ tile) {
     const int i = lane & 31, h = lane >> 5;
@@ -908,8 +920,44 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
     // flight behind the MFMAs.  Refills past the end re-read the last row (clamped address) and are masked when consumed.
 #pragma unroll
     for (int s = 0; s < WG_STEPS; ++s) { fetch1(s, 0); __builtin_amdgcn_sched_barrier(0); }    // issue in slot order
+    constexpr float SCALE = H16 ? 1024.0f : 1.0f, ISCALE = H16 ? 1.0f / 1024.0f : 1.0f;
     for (int n = 0; n < my_chunks; ++n) {
         const int row0 = (c0 + n * stride) * WG_CHUNK;
+        if (H16) {
+#pragma unroll
+            for (int g8 = 0; g8 < WG_STEPS / 8; ++g8) {
+                LkH8 ap[NV], bp[KV];
+#pragma unroll
+                for (int b = 0; b < NV; ++b) {
+                    float v8[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int sl = 8 * g8 + jj;
+                        const bool ok = row0 + 2 * sl + h < rows;
+                        float f = SCALE;
+                        if (mode == 1) f = SCALE * lk_softplus100_grad_from_out(ra2[sl].v[b]);
+                        if (mode == 2) f = SCALE * rw[sl];
+                        v8[jj] = (ok && nok[b]) ? ra[sl].v[b] * f : 0.0f;
+                        bsum[b] += v8[jj];
+                    }
+                    ap[b] = lk_split8h(v8);
+                }
+#pragma unroll
+                for (int b = 0; b < KV; ++b) {
+                    float v8[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) v8[jj] = rb[8 * g8 + jj].v[b];
+                    bp[b] = lk_split8h(v8);
+                }
+#pragma unroll
+                for (int bn = 0; bn < NV; ++bn)
+#pragma unroll
+                    for (int bk = 0; bk < KV; ++bk) acc[bn][bk] = lk_mma3h(ap[bn], bp[bk], acc[bn][bk]);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) { fetch1(8 * g8 + jj, n + 1); __builtin_amdgcn_sched_barrier(0); }
+            }
+            continue;
+        }
 #pragma unroll
         for (int s = 0; s < WG_STEPS; ++s) {
             const bool ok = row0 + 2 * s + h < rows;
@@ -938,11 +986,11 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 #pragma unroll
             for (int bk = 0; bk < KV; ++bk)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tile[((bn * KV + bk) * 16 + r) * 64 + lane] = acc[bn][bk][r];
+                for (int r = 0; r < 16; ++r) tile[((bn * KV + bk) * 16 + r) * 64 + lane] = acc[bn][bk][r] * ISCALE;
         if (k0 == 0) {
 #pragma unroll
             for (int b = 0; b < NV; ++b) {
-                const float v = bsum[b] + __shfl_xor(bsum[b], 32);
+                const float v = (bsum[b] + __shfl_xor(bsum[b], 32)) * ISCALE;
                 if (h == 0) tile[4 * 16 * 64 + NV * i + b] = v;
             }
         }
@@ -957,23 +1005,23 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nn = n0 + NV * lk_frag_row(r, h) + bn;
-                if (nn < J.N) atomicAdd(J.dW + (size_t)nn * J.ldw + kcol + bk, acc[bn][bk][r]);
+                if (nn < J.N) atomicAdd(J.dW + (size_t)nn * J.ldw + kcol + bk, acc[bn][bk][r] * ISCALE);
             }
         }
     if (J.db && k0 == 0) {
 #pragma unroll
         for (int b = 0; b < NV; ++b) {
-            const float v = bsum[b] + __shfl_xor(bsum[b], 32);
+            const float v = (bsum[b] + __shfl_xor(bsum[b], 32)) * ISCALE;
             if (h == 0 && nok[b]) atomicAdd(J.db + ncol + b, v);
         }
     }
 }
 
-template <int NV, int KV>
+template <int NV, int KV, bool H16>
 __device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile) {
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0>(J, n0, k0, c0, stride, lane, tile);
-    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1>(J, n0, k0, c0, stride, lane, tile);
-    else wgrad_unit<NV, KV, 2>(J, n0, k0, c0, stride, lane, tile);
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile);
+    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile);
 }
 
 // XCD-AWARE ROW OWNERSHIP.  Several units read the same rows (the 64-column pieces of one operand, or two jobs sharing
@@ -982,6 +1030,7 @@ __device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int
 // handled ON XCD c % 8 BY EVERY UNIT: each XCD gets the same partition of its 256 wave slots into units (waves in
 // proportion to the unit's work), local wave jl of a unit takes the chunks x + 8 (jl + k W), k = 0, 1, ...  All waves of
 // the launch are co-resident (two per SIMD) and sweep the rows at the same speed, so the re-reads hit the XCD's L2.
+template <bool H16>
 __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     const int lane = lk_lane();
     const int x = lk_uniform((int)blockIdx.x & 7);
@@ -996,24 +1045,23 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     // a wave without a chunk (tiny problems) still stores its (zero) tile: the reduction sums all 8 W tiles of the unit
     float* tile = a.part ? a.part + ((size_t)8 * U.wave0 + 8 * jl + x) * LK_WG_TILE : nullptr;
     if (!tile && c0 >= (J.rows + WG_CHUNK - 1) / WG_CHUNK) return;
-    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2>(J, U.n0, U.k0, c0, stride, lane, tile);
-    else if (U.nv == 2) wgrad_unit_mode<2, 1>(J, U.n0, U.k0, c0, stride, lane, tile);
-    else if (U.kv == 2) wgrad_unit_mode<1, 2>(J, U.n0, U.k0, c0, stride, lane, tile);
-    else wgrad_unit_mode<1, 1>(J, U.n0, U.k0, c0, stride, lane, tile);
+    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile);
+    else if (U.nv == 2) wgrad_unit_mode<2, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile);
+    else if (U.kv == 2) wgrad_unit_mode<1, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile);
+    else wgrad_unit_mode<1, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile);
 }
 
 // dW += sum over the unit's waves of the partial tiles (tile order: contiguous reads; every output element is owned by
 // exactly one thread, so the read-modify-write of dW needs no atomics and the result is run-to-run reproducible).
-__global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
-    __shared__ float sh[8][32];
-    const LkWgradUnit& U = a.unit[blockIdx.x];
+__device__ __forceinline__ void wgrad_reduce_body(const LkWgradArgs& a, int bx, int by, float (*sh)[32]) {
+    const LkWgradUnit& U = a.unit[bx];
     const LkWgradJob& J = a.job[U.job];
     const int nv = U.nv, kv = U.kv;
     // 32 consecutive tile elements x 8 row-block lanes per workgroup
     const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
-    const int idx = (int)blockIdx.y * 32 + e;
+    const int idx = by * 32 + e;
     const bool in_acc = idx < nv * kv * 1024, in_bias = idx >= 4 * 16 * 64 && idx < 4 * 16 * 64 + 32 * nv;
-    if (!in_acc && !in_bias && (int)blockIdx.y * 32 + 31 >= nv * kv * 1024 && (int)blockIdx.y * 32 < 4 * 16 * 64) return;   // unused blocks of a narrow unit
+    if (!in_acc && !in_bias && by * 32 + 31 >= nv * kv * 1024 && by * 32 < 4 * 16 * 64) return;   // unused blocks of a narrow unit
     const int nblk = 8 * U.n_waves;                                    // every wave of the unit stored a tile
     const size_t stride = LK_WG_TILE;
     const float* __restrict__ src = a.part + (size_t)8 * U.wave0 * LK_WG_TILE + idx;
@@ -1035,6 +1083,45 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
         const int tcol = idx - 4 * 16 * 64;
         if (J.db && U.k0 == 0 && U.n0 + tcol < J.N) J.db[U.n0 + tcol] += s;
     }
+}
+__global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
+    __shared__ float sh[8][32];
+    wgrad_reduce_body(a, (int)blockIdx.x, (int)blockIdx.y, sh);
+}
+
+// column sums of a partial table [n_parts][width] into out[width] (+=), 32 columns per workgroup, one owner per column
+__device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out, int bx, float (*sh)[32]) {
+    const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
+    const int col = bx * 32 + e;
+    float s = 0.0f;
+    if (col < width) {
+#pragma unroll 4
+        for (int y = q; y < n_parts; y += 8) s += part[(size_t)y * width + col];
+    }
+    sh[q][e] = s;
+    __syncthreads();
+    if (q == 0 && col < width) out[col] += ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) + ((sh[4][e] + sh[5][e]) + (sh[6][e] + sh[7][e]));
+}
+
+// EVERY partial-sum reduction of a mapper 'color' backward in one launch after the two streams have joined (they were five
+// launches of 5-10 us each on the critical path): the k_wgrad tiles, the linear1 / linear2 tiles of the fused rel-pos variant,
+// the Fourier-matrix partials of the two decoders.  Blocks [0, b_wg) | [b_wg, b_rp) | [b_rp, b_pg) | [b_pg, b_pr).
+__global__ __launch_bounds__(256) void k_bwd_reduce(LkWgradArgs wa, LkBwdReduceArgs r) {
+    __shared__ float sh[8][32];
+    const int b = (int)blockIdx.x;
+    if (b < r.b_wg) wgrad_reduce_body(wa, b / r.ny, b % r.ny, sh);
+    else if (b < r.b_rp) rp_reduce_body(r.part1, r.n1, r.part2, r.n2, r.dW1, r.db1, r.dW2, r.db2, b - r.b_wg, sh);
+    else if (b < r.b_pg) col_reduce_body(r.part_bg, r.n_bg, 288, r.out_bg, b - r.b_rp, sh);
+    else col_reduce_body(r.part_br, r.n_br, 32, r.out_br, b - r.b_pg, sh);
+}
+int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st) {
+    r.ny = lk_cdiv(LK_WG_TILE, 32);
+    r.b_wg = wa.part && wa.n_units > 0 ? wa.n_units * r.ny : 0;
+    r.b_rp = r.b_wg + (with_rp ? LK_RP_REDUCE_BLOCKS : 0);
+    r.b_pg = r.b_rp + (r.part_bg ? lk_cdiv(288, 32) : 0);
+    r.b_pr = r.b_pg + (r.part_br ? 1 : 0);
+    if (r.b_pr > 0) hipLaunchKernelGGL(k_bwd_reduce, dim3(r.b_pr), dim3(256), 0, st, wa, r);
+    return LK_OK;
 }
 
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
@@ -1074,11 +1161,13 @@ int64_t lk_dw2_part_floats(int P) { return (int64_t)lk_dw2_parts(P) * LK_DW2_TIL
 int lk_launch_rp_wgrad_tail(const LkRelposBwdArgs& a, float* dw2_part, float* dW1, float* db1, float* dW2, float* db2, hipStream_t st) {
     const int n2 = lk_dw2_parts(a.P);
     hipLaunchKernelGGL(k_dw2_hbar, dim3(n2), dim3(256), 0, st, a.dc_col, a.w_sum, a.hbar, a.P, dw2_part);
+    if (!dW1) return LK_OK;                             // the sums ride in k_bwd_reduce
     hipLaunchKernelGGL(k_rp_reduce, dim3(128 * 64 / 32 + lk_cdiv(LK_DW2_TILE, 32)), dim3(256), 0, st, a.dw1_part, lk_relpos_bwd_parts(a.P),
                        dw2_part, n2, dW1, db1, dW2, db2);
     return LK_OK;
 }
-int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
+int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st, LkWgradArgs* deferred) {
+    if (deferred) deferred->n_units = 0;
     if (a_in.n_jobs == 0 || max_rows <= 0) return LK_OK;
     LkWgradArgs a = a_in;
     // cut every job into (N piece) x (K piece) units of 32 or 64 columns
@@ -1113,8 +1202,10 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st) {
     a.n_waves = next;
     {
         LkProfScope prof_(LKK_WGRAD, st);                              // timing scope = k_wgrad alone (as rocprof reports it)
-        hipLaunchKernelGGL(k_wgrad, dim3(8 * lk_cdiv(a.n_waves, 4)), dim3(256), 0, st, a);
+        if (a.h16) hipLaunchKernelGGL(k_wgrad<true>, dim3(8 * lk_cdiv(a.n_waves, 4)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_wgrad<false>, dim3(8 * lk_cdiv(a.n_waves, 4)), dim3(256), 0, st, a);
     }
+    if (deferred) { *deferred = a; return LK_OK; }     // the tiles are summed later (k_bwd_reduce)
     if (a.part) hipLaunchKernelGGL(k_wgrad_reduce, dim3(a.n_units, lk_cdiv(LK_WG_TILE, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }

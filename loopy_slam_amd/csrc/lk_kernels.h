@@ -171,6 +171,7 @@ struct LkWgradArgs {
     int chunk;                                     // unused (kept for lk_wgrad_single's signature)
     LkWgradUnit unit[LK_WGRAD_MAX_UNITS]; int n_units, n_waves;   // filled by the launcher (n_waves: used slots per XCD)
     float* part;                                   // [n_waves][LK_WG_TILE] partial tiles (one per wave), or NULL (atomic flush)
+    int h16;                                       // products on scaled fp16 pieces (unit-scale loss gradients only)
 };
 #define LK_WG_MAX_WAVES 2048                       // waves of one weight-gradient launch: two per SIMD, all co-resident
 #define LK_WG_TILE (4 * 16 * 64 + 64)              // floats per tile: accumulators [block][reg][lane] + bias sums
@@ -191,7 +192,16 @@ int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st);
 int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st);
 int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st);
 int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st);
-int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st);
+int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st, LkWgradArgs* deferred = nullptr);   // deferred: skip the tile sums, return the unit table
+// all partial-sum reductions of one backward in one launch (k_bwd_reduce, lk_bwd2.hip); block ranges are filled by the launcher
+struct LkBwdReduceArgs {
+    int b_wg, ny, b_rp, b_pg, b_pr;
+    const float* part1; int n1; const float* part2; int n2; float* dW1; float* db1; float* dW2; float* db2;
+    const float* part_bg; int n_bg; float* out_bg;
+    const float* part_br; int n_br; float* out_br;
+};
+int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st);
+int lk_dw2_parts(int P);
 int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st);
 
 int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st);
