@@ -156,7 +156,7 @@ static int check_desc(const lk_render_desc* d, const char* who) {
 // second stream when there is one (it needs nothing but the neighbour indices), the caller's stream waits for `link` later
 namespace { struct SideStream; SideStream& side_stream(); }
 static void seg_args(const lk_render_desc* d, int P, LkFeatScatterArgs& fs);
-static int seg_sort_async(const lk_render_desc* d, int P, hipStream_t st);
+static int seg_sort_async(const lk_render_desc* d, int P, bool counted, hipStream_t st);
 
 extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
 
@@ -180,10 +180,16 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
     sa.near_surface = d->near_surface; sa.far_surface = d->far_surface; sa.near_end = d->near_end; sa.r2_static = d->r2_static;
     sa.min_nn = d->min_nn;
     sa.z = d->z; sa.nbr_idx = d->nbr_idx; sa.nbr_w = d->nbr_w; sa.nbr_count = d->nbr_count; sa.c_geo = d->c_geo; sa.c_col = d->c_col;
+    const bool presort = (skip & LK_FUSE_COMPOSITE_BWD) && (d->flags & LK_FLAG_GRAD_FEATS) && d->bwd_scratch;
+    sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr;
+    if (presort) {       // the backward of this forward follows (lk_map_frame): its rows are counted per point by the sampler ...
+        LkFeatScatterArgs fs;
+        seg_args(d, P, fs);
+        sa.seg_cnt = fs.seg_cnt; sa.seg_rank = fs.seg_rank; sa.row_mask = fs.row_mask;
+    }
     lk_launch_sample_interp(sa, st);
-    if ((skip & LK_FUSE_COMPOSITE_BWD) && (d->flags & LK_FLAG_GRAD_FEATS) && d->bwd_scratch) {
-        // the backward of this forward follows (lk_map_frame): sort its rows by point now, beside the decoders
-        const int rc2 = seg_sort_async(d, P, st);
+    if (presort) {       // ... and sorted beside the decoders
+        const int rc2 = seg_sort_async(d, P, true, st);
         if (rc2 != LK_OK) return rc2;
     }
 
@@ -259,17 +265,17 @@ static void seg_args(const lk_render_desc* d, int P, LkFeatScatterArgs& fs) {
     const BwdLayout L = bwd_layout(P, d->flags);
     memset(&fs, 0, sizeof(fs));
     fs.P = P; fs.min_nn = d->min_nn; fs.nbr_idx = d->nbr_idx; fs.nbr_w = d->nbr_w; fs.nbr_count = d->nbr_count;
-    fs.row_mask = d->grad_row_mask; fs.seg_cnt = d->knn->seg_cnt; fs.seg_sums = d->knn->seg_sums; fs.N = (int)d->knn->n;
+    fs.row_mask = d->grad_row_mask; fs.seg_cnt = d->knn->seg_cnt; fs.seg_off = d->knn->seg_off; fs.seg_sums = d->knn->seg_sums; fs.N = (int)d->knn->n;
     fs.seg_rank = reinterpret_cast<int32_t*>(d->bwd_scratch + L.seg_rank); fs.seg_list = reinterpret_cast<int32_t*>(d->bwd_scratch + L.seg_list);
 }
-static int seg_sort_async(const lk_render_desc* d, int P, hipStream_t st) {
+static int seg_sort_async(const lk_render_desc* d, int P, bool counted, hipStream_t st) {
     LkFeatScatterArgs fs;
     seg_args(d, P, fs);
     SideStream& ss = side_stream();
-    if (!ss.ok) return lk_launch_seg_sort(fs, st);
+    if (!ss.ok) return lk_launch_seg_sort(fs, counted, st);
     (void)hipEventRecord(ss.fork0, st);
     (void)hipStreamWaitEvent(ss.st, ss.fork0, 0);
-    const int rc = lk_launch_seg_sort(fs, ss.st);
+    const int rc = lk_launch_seg_sort(fs, counted, ss.st);
     (void)hipEventRecord(ss.link, ss.st);
     return rc;
 }
@@ -305,7 +311,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     LkFeatScatterArgs fs;
     seg_args(d, P, fs);
     if (gf && !(skip & LK_SEG_SORTED)) {
-        const int rc2 = seg_sort_async(d, P, st);
+        const int rc2 = seg_sort_async(d, P, false, st);
         if (rc2 != LK_OK) return rc2;
     }
 

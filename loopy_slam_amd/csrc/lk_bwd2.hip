@@ -135,8 +135,9 @@ __global__ __launch_bounds__(256) void k_feat_scatter(LkFeatScatterArgs a) {
 // The same sums with a fraction of the atomics.  A mapper batch touches few points many times (5 000 rays x 5 samples x 8
 // neighbours = 197 k rows on 15 k points of the benchmark frame: 12.7 rows per point), and the atomic scatter pays for every
 // row twice (two tables) at the memory-side atomic rate, with the adds of a point serialised on its line.  The rows are
-// counting-sorted by point - k_seg_count (rank of the row among the rows of its point), an exclusive scan of the per-point
-// counts, k_seg_place - which only needs the neighbour indices: it runs on the second stream beside the decoders.
+// counting-sorted by point - k_seg_count (rank of the row among the rows of its point; inside k_sample_interp when the forward
+// knows that this backward follows), an exclusive scan of the per-point counts that also clears them, k_seg_place - which only
+// needs the neighbour indices: it runs on the second stream beside the decoders.
 // k_feat_gather then gives every half-wave (32 channels) 16 consecutive rows of the sorted list: the rows of a point are
 // added in registers and flushed with ONE atomic per run (runs can continue in the next chunk) - about 27 k flushes instead
 // of 197 k, every half-wave with the same amount of work (a per-point linked list walked by its first row was slower than
@@ -155,14 +156,14 @@ __global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
     const long long row = (long long)blockIdx.x * 256 + (int)threadIdx.x;
     if (row >= (long long)a.P * LK_K) return;
     const int rk = a.seg_rank[row];
-    if (rk >= 0) a.seg_list[a.seg_cnt[a.nbr_idx[row]] + rk] = (int)row;
+    if (rk >= 0) a.seg_list[a.seg_off[a.nbr_idx[row]] + rk] = (int)row;
 }
 
 #define LK_GATHER_CHUNK 16
 __global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
     const int c = (int)threadIdx.x & 31;
     const long long i0 = ((long long)blockIdx.x * 8 + ((int)threadIdx.x >> 5)) * LK_GATHER_CHUNK;
-    const int total = a.seg_cnt[a.N];
+    const int total = a.seg_off[a.N];
     if (i0 >= total) return;
     const int n = min(LK_GATHER_CHUNK, (int)(total - i0));
     const bool col = a.dfeat != nullptr || a.dc_col != nullptr;
@@ -1135,11 +1136,11 @@ int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL(k_feat_scatter, dim3(lk_cdiv((long long)a.P * LK_K, 8)), dim3(256), 0, st, a);
     return LK_OK;
 }
-int lk_launch_seg_sort(const LkFeatScatterArgs& a, hipStream_t st) {
+int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st) {
     const int nb = lk_cdiv((long long)a.P * LK_K, 256);
-    LK_HIP_TRY(hipMemsetAsync(a.seg_cnt, 0, sizeof(int32_t) * (size_t)(a.N + 1), st));
-    hipLaunchKernelGGL(k_seg_count, dim3(nb), dim3(256), 0, st, a);
-    lk_launch_scan_i32(a.seg_cnt, a.seg_sums, a.N + 1, st);
+    // seg_cnt is zero on entry: the scan of the previous sort cleared what that sort had counted
+    if (!counted) hipLaunchKernelGGL(k_seg_count, dim3(nb), dim3(256), 0, st, a);
+    lk_launch_scan_i32(a.seg_cnt, a.seg_off, a.seg_sums, a.N + 1, st);
     hipLaunchKernelGGL(k_seg_place, dim3(nb), dim3(256), 0, st, a);
     return LK_OK;
 }

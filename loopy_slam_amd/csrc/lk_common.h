@@ -63,7 +63,8 @@ struct lk_knn_s {
     int32_t* rank_of;      // [capacity]
     int32_t* block_sums;   // scan scratch
     float* pos_own = nullptr;   // [capacity][3] original-order copy, allocated by the first lk_knn_append
-    int32_t* seg_cnt = nullptr;    // [capacity + 1] rows per point -> exclusive offsets: the feature-gradient gather of lk_render_bwd
+    int32_t* seg_cnt = nullptr;    // [capacity + 1] rows per point (zero between calls): the feature-gradient gather of lk_render_bwd
+    int32_t* seg_off = nullptr;    // [capacity + 1] their exclusive offsets
     int32_t* seg_sums = nullptr;   // scan scratch of seg_cnt
     int32_t n_scan_blocks;
 };

@@ -22,6 +22,8 @@ struct LkSampleArgs {
     float near_surface, far_surface, near_end, r2_static;
     int min_nn;
     float* z; int32_t* nbr_idx; float* nbr_w; int32_t* nbr_count; float* c_geo; float* c_col;
+    // rows counted per point on the way (first pass of the backward's counting sort, see k_seg_count); seg_cnt == NULL: off
+    int32_t* seg_cnt; int32_t* seg_rank; const uint8_t* row_mask;
 };
 
 struct LkCompositeArgs {
@@ -82,6 +84,15 @@ struct LkDecodeBwdArgs {
     float* part_bg;                                // [n_blocks][288] per-workgroup partial sums of d embedder._B (GRAD_WEIGHTS)
 };
 
+struct LkTrackFinalArgs {
+    int R, n_part;
+    float fx, fy, cx, cy;
+    const float* pose_part;                                        // [n_part][12] from k_interp_bwd
+    float* cam; float* g_cam; float* adam_mv; float* hist_pre; float* hist_post;      // hist rows or NULL
+    float step_T, step_q, bc2_sqrt, beta1, beta2, eps;            // lr / bias_correction1 per group, sqrt(bias_correction2)
+    const float* next_pix_i; const float* next_pix_j; float* rays_o; float* rays_d;   // rays of the NEXT iteration's pixels, or NULL
+    int do_update;                                                 // 0: only the rays of `cam` (before the first iteration)
+};
 // interpolation backward: feature-row scatter (+ tracker: weights -> distances -> positions)
 struct LkInterpBwdArgs {
     int R, S, P, min_nn;
@@ -110,14 +121,15 @@ struct LkFeatScatterArgs {
     float* g_geo_feats; float* g_col_feats;
     const uint8_t* row_mask;                       // [N] or NULL: scatter only into rows flagged non-zero
     // counting sort of the rows by point (lk_launch_seg_sort) -> gather without per-row atomics; seg_cnt == NULL: atomic scatter
-    int32_t* seg_cnt;                              // [N + 1] (lk_knn_s::seg_cnt) rows per point, then their exclusive offsets; [N] = rows in the list
+    int32_t* seg_cnt;                              // [N + 1] (lk_knn_s::seg_cnt) rows per point: zero between calls (the scan clears it)
+    int32_t* seg_off;                              // [N + 1] (lk_knn_s::seg_off) exclusive offsets of the points' rows; [N] = rows in the list
     int32_t* seg_sums;                             // scan scratch (lk_knn_s::seg_sums)
     int32_t* seg_rank;                             // [8P] rank of the row among the rows of its point, -1 = row takes no part
     int32_t* seg_list;                             // [8P] rows ordered by point
     int N;
 };
-int lk_launch_seg_sort(const LkFeatScatterArgs& a, hipStream_t st);
-int lk_launch_scan_i32(int32_t* data, int32_t* block_sums, int total, hipStream_t st);
+int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st);        // counted: k_sample_interp already ran the count pass
+int lk_launch_scan_i32(int32_t* data, int32_t* out, int32_t* block_sums, int total, hipStream_t st);   // out != data: data is cleared
 
 struct LkRaysBwdArgs { int R, S; const float* z; const float* dp_total; float* g_rays_o; float* g_rays_d; };
 

@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void k_count(const float* __restrict__ pos, in
 
 // in-place exclusive scan of (ncells+1) counts: block-local scan + block totals
 // (g == NULL: the length is the host-known `total_host` - lk_launch_scan_i32)
-__global__ __launch_bounds__(256) void k_scan_block(int32_t* __restrict__ data, int32_t* __restrict__ block_sums,
+// (out != data: the offsets go to `out` and the counts in `data` are cleared on the way - a counter array that is zero again
+// when its offsets exist needs no memset before its next use)
+__global__ __launch_bounds__(256) void k_scan_block(int32_t* data, int32_t* out, int32_t* __restrict__ block_sums,
                                                     const LkGrid* __restrict__ g, int total_host) {
     __shared__ int wsum[4];
     const int total = g ? g->ncells + 1 : total_host;
@@ -112,7 +114,10 @@ __global__ __launch_bounds__(256) void k_scan_block(int32_t* __restrict__ data, 
     int run = woff + incl - s;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if (idx + q < total) data[idx + q] = run;
+        if (idx + q < total) {
+            out[idx + q] = run;
+            if (out != data) data[idx + q] = 0;
+        }
         run += v[q];
     }
     if (t == 255) block_sums[blockIdx.x] = woff + incl;
@@ -198,12 +203,12 @@ __global__ __launch_bounds__(256) void k_knn_query(const LkGrid* __restrict__ g,
 
 // ------------------------------------------------------------------ host API
 // in-place exclusive scan of `total` int32 counts (block_sums: lk_cdiv(total, 1024) + 256 ints of scratch)
-int lk_launch_scan_i32(int32_t* data, int32_t* block_sums, int total, hipStream_t st) {
+int lk_launch_scan_i32(int32_t* data, int32_t* out, int32_t* block_sums, int total, hipStream_t st) {
     const int nb = lk_cdiv(total, SCAN_ITEMS);
-    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, st, data, block_sums, (const LkGrid*)nullptr, total);
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, st, data, out, block_sums, (const LkGrid*)nullptr, total);
     if (nb > 1) {
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, block_sums, (const LkGrid*)nullptr, total);
-        hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, st, data, (const int32_t*)block_sums, (const LkGrid*)nullptr, total);
+        hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, st, out, (const int32_t*)block_sums, (const LkGrid*)nullptr, total);
     }
     return LK_OK;
 }
@@ -228,6 +233,8 @@ extern "C" int lk_knn_create(float cell_size, int64_t capacity_points, int64_t m
     if (e == hipSuccess) e = hipMalloc((void**)&h->rank_of, sizeof(int32_t) * (size_t)capacity_points);
     if (e == hipSuccess) e = hipMalloc((void**)&h->block_sums, sizeof(int32_t) * (size_t)(h->n_scan_blocks + 256));
     if (e == hipSuccess) e = hipMalloc((void**)&h->seg_cnt, sizeof(int32_t) * (size_t)(capacity_points + 1 + SCAN_ITEMS));
+    if (e == hipSuccess) e = hipMemset(h->seg_cnt, 0, sizeof(int32_t) * (size_t)(capacity_points + 1 + SCAN_ITEMS));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_off, sizeof(int32_t) * (size_t)(capacity_points + 1 + SCAN_ITEMS));
     if (e == hipSuccess) e = hipMalloc((void**)&h->seg_sums, sizeof(int32_t) * (size_t)(lk_cdiv(capacity_points + 1, SCAN_ITEMS) + 256));
     if (e == hipSuccess) e = hipMemset(h->grid, 0, sizeof(LkGrid));
     if (e != hipSuccess) {
@@ -249,6 +256,7 @@ extern "C" int lk_knn_destroy(lk_knn_t h) {
     if (h->block_sums) (void)hipFree(h->block_sums);
     if (h->pos_own) (void)hipFree(h->pos_own);
     if (h->seg_cnt) (void)hipFree(h->seg_cnt);
+    if (h->seg_off) (void)hipFree(h->seg_off);
     if (h->seg_sums) (void)hipFree(h->seg_sums);
     delete h;
     return LK_OK;
@@ -273,7 +281,7 @@ extern "C" int lk_knn_build(lk_knn_t h, const float* pos, int64_t N, void* strea
         hipLaunchKernelGGL(k_zero_counts, dim3(2048), dim3(256), 0, st, h->cell_start, h->grid);
         hipLaunchKernelGGL(k_count, dim3(lk_cdiv(n, 256)), dim3(256), 0, st, pos, n, h->grid, h->cell_start,
                            h->cell_of, h->rank_of);
-        hipLaunchKernelGGL(k_scan_block, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->block_sums, h->grid, 0);
+        hipLaunchKernelGGL(k_scan_block, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->cell_start, h->block_sums, h->grid, 0);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, h->block_sums, h->grid, 0);
         hipLaunchKernelGGL(k_scan_add, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->block_sums, h->grid, 0);
         hipLaunchKernelGGL(k_scatter, dim3(lk_cdiv(n, 256)), dim3(256), 0, st, pos, n, h->cell_start, h->cell_of,

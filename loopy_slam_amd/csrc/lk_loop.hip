@@ -15,6 +15,7 @@
 #include "lk_kernels.h"
 #include "lk_composite_dev.h"
 #include "lk_mask_dev.h"
+#include "lk_track_dev.h"
 
 #include <math.h>
 #include <string.h>
@@ -36,14 +37,6 @@ __device__ __forceinline__ float lp_block_sum_1024(float v, float* sh /*[16]*/) 
     return s;
 }
 __device__ __forceinline__ float lp_sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
-__device__ __forceinline__ void lp_quat_rot(const float* __restrict__ cam, float (&Rm)[9]) {       // common.py:301-324
-    const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
-    const float s = 2.0f / (qr * qr + qi * qi + qj * qj + qk * qk);
-    Rm[0] = 1.0f - s * (qj * qj + qk * qk); Rm[1] = s * (qi * qj - qk * qr); Rm[2] = s * (qi * qk + qj * qr);
-    Rm[3] = s * (qi * qj + qk * qr); Rm[4] = 1.0f - s * (qi * qi + qk * qk); Rm[5] = s * (qj * qk - qi * qr);
-    Rm[6] = s * (qi * qk - qj * qr); Rm[7] = s * (qj * qk + qi * qr); Rm[8] = 1.0f - s * (qi * qi + qj * qj);
-}
-
 // ------------------------------------------------------------------ k_pregather
 // Batch assembly of ALL iterations of a frame in one launch (workgroup b = iteration b): pixel gather (get_samples,
 // common.py:237-259), inside mask (Tracker.py:153-160 / Mapper.py:674-681: rejected rays become absent, gt_depth = 0) and - for
@@ -181,96 +174,8 @@ __global__ __launch_bounds__(256) void k_track_loss2(LkTrackLossArgs a, int n_pa
     }
 }
 
-// ------------------------------------------------------------------ k_track_final
-struct LkTrackFinalArgs {
-    int R, n_part;
-    float fx, fy, cx, cy;
-    const float* pose_part;                                        // [n_part][12] from k_interp_bwd
-    float* cam; float* g_cam; float* adam_mv; float* hist_pre; float* hist_post;      // hist rows or NULL
-    float step_T, step_q, bc2_sqrt, beta1, beta2, eps;            // lr / bias_correction1 per group, sqrt(bias_correction2)
-    const float* next_pix_i; const float* next_pix_j; float* rays_o; float* rays_d;   // rays of the NEXT iteration's pixels, or NULL
-    int do_update;                                                 // 0: only the rays of `cam` (before the first iteration)
-};
-// pose gradient from the ray moments (k_pose_bwd's formulas), Adam on (T | q) (Tracker.py:317-352), the candidate pose log,
-// and the rays of the updated pose for the next iteration's pixels (get_rays_from_uv) - one workgroup, a few microseconds
-__global__ __launch_bounds__(1024) void k_track_final(LkTrackFinalArgs a) {
-    __shared__ float s_w[16][12];
-    __shared__ float acc[12];
-    __shared__ float s_cam[7];
-    const int t = threadIdx.x;
-    if (a.do_update) {
-        float v12[12];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) v12[q] = 0.0f;
-        for (int b = t; b < a.n_part; b += 1024) {
-#pragma unroll
-            for (int q = 0; q < 12; ++q) v12[q] += a.pose_part[(size_t)b * 12 + q];
-        }
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v12[q] += __shfl_xor(v12[q], o);
-        }
-        if (lk_lane() == 0) {
-#pragma unroll
-            for (int q = 0; q < 12; ++q) s_w[t >> 6][q] = v12[q];
-        }
-        __syncthreads();
-        if (t < 12) {
-            float s = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) s += s_w[w][t];
-            acc[t] = s;
-        }
-        __syncthreads();
-        if (t == 0) {
-            float* cam = a.cam;
-            const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
-            const float N = qr * qr + qi * qi + qj * qj + qk * qk, s = 2.0f / N;
-            const float P[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
-                                qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr,
-                                qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)};
-            float gp = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) gp += acc[q] * P[q];
-            const float* g = acc;
-            const float dPr = g[1] * (-qk) + g[2] * qj + g[3] * qk + g[5] * (-qi) + g[6] * (-qj) + g[7] * qi;
-            const float dPi = g[1] * qj + g[2] * qk + g[3] * qj + g[4] * (-2.0f * qi) + g[5] * (-qr) + g[6] * qk + g[7] * qr + g[8] * (-2.0f * qi);
-            const float dPj = g[0] * (-2.0f * qj) + g[1] * qi + g[2] * qr + g[3] * qi + g[5] * qk + g[6] * (-qr) + g[7] * qk + g[8] * (-2.0f * qj);
-            const float dPk = g[0] * (-2.0f * qk) + g[1] * (-qr) + g[2] * qi + g[3] * qr + g[4] * (-2.0f * qk) + g[5] * qj + g[6] * qi + g[7] * qj;
-            const float ds = -s * s;
-            float gc[7];
-            gc[0] = ds * qr * gp + s * dPr; gc[1] = ds * qi * gp + s * dPi; gc[2] = ds * qj * gp + s * dPj; gc[3] = ds * qk * gp + s * dPk;
-            gc[4] = acc[9]; gc[5] = acc[10]; gc[6] = acc[11];
-#pragma unroll
-            for (int e = 0; e < 7; ++e) {        // torch.optim.Adam, group T: elements 4..6, group q: 0..3 (as k_adam)
-                if (a.hist_pre) a.hist_pre[e] = cam[e];
-                a.g_cam[e] = gc[e];
-                const float m = a.adam_mv[e] * a.beta1 + (1.0f - a.beta1) * gc[e];
-                const float v = a.adam_mv[7 + e] * a.beta2 + (1.0f - a.beta2) * (gc[e] * gc[e]);
-                const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-                a.adam_mv[e] = m; a.adam_mv[7 + e] = v;
-                const float p = cam[e] - (e < 4 ? a.step_q : a.step_T) * (m / denom);
-                cam[e] = p;
-                if (a.hist_post) a.hist_post[e] = p;
-            }
-        }
-        __syncthreads();
-    }
-    if (!a.rays_o) return;
-    if (t < 7) s_cam[t] = a.cam[t];
-    __syncthreads();
-    float Rm[9];
-    lp_quat_rot(s_cam, Rm);
-    for (int r = t; r < a.R; r += 1024) {
-        const float d0 = (a.next_pix_i[r] - a.cx) / a.fx, d1 = -(a.next_pix_j[r] - a.cy) / a.fy, d2 = -1.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            a.rays_d[3 * r + c] = (d0 * Rm[3 * c] + d1 * Rm[3 * c + 1]) + d2 * Rm[3 * c + 2];
-            a.rays_o[3 * r + c] = s_cam[4 + c];
-        }
-    }
-}
+// ------------------------------------------------------------------ k_track_final (body: lk_track_dev.h)
+__global__ __launch_bounds__(1024) void k_track_final(LkTrackFinalArgs a) { lk_track_final_body<16>(a); }
 
 // ------------------------------------------------------------------ lk_track_frame
 namespace {
@@ -400,6 +305,8 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         rc = lk_render_bwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE_BWD | LK_SKIP_RAYS_BWD) : 0, fused ? &ex : nullptr);
         if (rc != LK_OK) return rc;
         // ---- pose gradient + Adam (Tracker.py:317-352: group T at cam_lr, group q at 0.2 cam_lr when separate_LR)
+        // (letting the workgroup of k_interp_bwd that finishes last run this step saved the launch and cost more: every workgroup
+        // pays a device-scope release fence for the hand-over, 139 -> 151 us per iteration)
         float step_T, step_q, bc2s;
         adam_scalars(d->lr_T, it + 1, beta1, beta2, &step_T, &bc2s);
         adam_scalars(d->lr_q, it + 1, beta1, beta2, &step_q, &bc2s);
@@ -410,7 +317,8 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             fa.rays_o = more ? const_cast<float*>(rd.rays_o) : nullptr; fa.rays_d = const_cast<float*>(rd.rays_d);
             fa.next_pix_i = W0 + wk.pix_i + (size_t)(it + 1) * R * (more ? 1 : 0); fa.next_pix_j = W0 + wk.pix_j + (size_t)(it + 1) * R * (more ? 1 : 0);
             hipLaunchKernelGGL(k_track_final, dim3(1), dim3(1024), 0, st, fa);
-        } else {
+        }
+        if (!fused) {
             rc = lk_pose_bwd(d->cam7, d->pix_i, d->pix_j, R, d->fx, d->fy, d->cx, d->cy, rd.g_rays_o, rd.g_rays_d, d->g_cam7, st);
             if (rc != LK_OK) return rc;
             lk_adam_seg seg[2];

@@ -91,6 +91,12 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
             a.nbr_w[(size_t)pidx * LK_K + sub] = wj;
         }
         if (sub == 0) { a.nbr_count[pidx] = count; a.z[pidx] = z; }
+        // first pass of the backward's counting sort of the rows by point (k_seg_count, lk_bwd2.hip), while the indices are here
+        if (a.seg_cnt && sub < LK_K) {
+            int rk = -1;
+            if (ij >= 0 && wj != 0.0f && count >= a.min_nn && (!a.row_mask || a.row_mask[ij])) rk = atomicAdd(a.seg_cnt + ij, 1);
+            a.seg_rank[(size_t)pidx * LK_K + sub] = rk;
+        }
     }
     const bool do_col = (a.flags & LK_FLAG_STAGE_COLOR) && !(a.flags & LK_FLAG_REL_POS);
     // gather: with 8 lanes per point every lane serves one float4 of BOTH tables; with 16 lanes the low 8 lanes

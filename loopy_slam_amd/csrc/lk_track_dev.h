@@ -1,0 +1,98 @@
+// Device code of the tracking loop's pose step (lk_loop.hip): quaternion -> rotation, gradient from the ray moments, Adam,
+// rays of the next batch.
+#pragma once
+#include "lk_common.h"
+#include "lk_kernels.h"
+
+__device__ __forceinline__ void lp_quat_rot(const float* __restrict__ cam, float (&Rm)[9]) {       // common.py:301-324
+    const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
+    const float s = 2.0f / (qr * qr + qi * qi + qj * qj + qk * qk);
+    Rm[0] = 1.0f - s * (qj * qj + qk * qk); Rm[1] = s * (qi * qj - qk * qr); Rm[2] = s * (qi * qk + qj * qr);
+    Rm[3] = s * (qi * qj + qk * qr); Rm[4] = 1.0f - s * (qi * qi + qk * qk); Rm[5] = s * (qj * qk - qi * qr);
+    Rm[6] = s * (qi * qk - qj * qr); Rm[7] = s * (qj * qk + qi * qr); Rm[8] = 1.0f - s * (qi * qi + qj * qj);
+}
+
+
+// pose gradient from the ray moments (k_pose_bwd's formulas), Adam on (T | q) (Tracker.py:317-352), the candidate pose log,
+// and the rays of the updated pose for the next iteration's pixels (get_rays_from_uv) - one workgroup, a few microseconds
+// NW = waves of the calling workgroup (all of its threads call)
+template <int NW>
+__device__ __forceinline__ void lk_track_final_body(const LkTrackFinalArgs& a) {
+    __shared__ float s_w[NW][12];
+    __shared__ float acc[12];
+    __shared__ float s_cam[7];
+    const int t = threadIdx.x;
+    if (a.do_update) {
+        float v12[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) v12[q] = 0.0f;
+        for (int b = t; b < a.n_part; b += 64 * NW) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) v12[q] += a.pose_part[(size_t)b * 12 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v12[q] += __shfl_xor(v12[q], o);
+        }
+        if (lk_lane() == 0) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) s_w[t >> 6][q] = v12[q];
+        }
+        __syncthreads();
+        if (t < 12) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += s_w[w][t];
+            acc[t] = s;
+        }
+        __syncthreads();
+        if (t == 0) {
+            float* cam = a.cam;
+            const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
+            const float N = qr * qr + qi * qi + qj * qj + qk * qk, s = 2.0f / N;
+            const float P[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
+                                qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr,
+                                qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)};
+            float gp = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) gp += acc[q] * P[q];
+            const float* g = acc;
+            const float dPr = g[1] * (-qk) + g[2] * qj + g[3] * qk + g[5] * (-qi) + g[6] * (-qj) + g[7] * qi;
+            const float dPi = g[1] * qj + g[2] * qk + g[3] * qj + g[4] * (-2.0f * qi) + g[5] * (-qr) + g[6] * qk + g[7] * qr + g[8] * (-2.0f * qi);
+            const float dPj = g[0] * (-2.0f * qj) + g[1] * qi + g[2] * qr + g[3] * qi + g[5] * qk + g[6] * (-qr) + g[7] * qk + g[8] * (-2.0f * qj);
+            const float dPk = g[0] * (-2.0f * qk) + g[1] * (-qr) + g[2] * qi + g[3] * qr + g[4] * (-2.0f * qk) + g[5] * qj + g[6] * qi + g[7] * qj;
+            const float ds = -s * s;
+            float gc[7];
+            gc[0] = ds * qr * gp + s * dPr; gc[1] = ds * qi * gp + s * dPi; gc[2] = ds * qj * gp + s * dPj; gc[3] = ds * qk * gp + s * dPk;
+            gc[4] = acc[9]; gc[5] = acc[10]; gc[6] = acc[11];
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {        // torch.optim.Adam, group T: elements 4..6, group q: 0..3 (as k_adam)
+                if (a.hist_pre) a.hist_pre[e] = cam[e];
+                a.g_cam[e] = gc[e];
+                const float m = a.adam_mv[e] * a.beta1 + (1.0f - a.beta1) * gc[e];
+                const float v = a.adam_mv[7 + e] * a.beta2 + (1.0f - a.beta2) * (gc[e] * gc[e]);
+                const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+                a.adam_mv[e] = m; a.adam_mv[7 + e] = v;
+                const float p = cam[e] - (e < 4 ? a.step_q : a.step_T) * (m / denom);
+                cam[e] = p;
+                if (a.hist_post) a.hist_post[e] = p;
+            }
+        }
+        __syncthreads();
+    }
+    if (!a.rays_o) return;
+    if (t < 7) s_cam[t] = a.cam[t];
+    __syncthreads();
+    float Rm[9];
+    lp_quat_rot(s_cam, Rm);
+    for (int r = t; r < a.R; r += 64 * NW) {
+        const float d0 = (a.next_pix_i[r] - a.cx) / a.fx, d1 = -(a.next_pix_j[r] - a.cy) / a.fy, d2 = -1.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.rays_d[3 * r + c] = (d0 * Rm[3 * c] + d1 * Rm[3 * c + 1]) + d2 * Rm[3 * c + 2];
+            a.rays_o[3 * r + c] = s_cam[4 + c];
+        }
+    }
+}
+
