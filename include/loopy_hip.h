@@ -366,11 +366,14 @@ typedef struct {
     float* adam_dec;            /* [2][lk_weight_blob_floats()]: exp_avg | exp_avg_sq, blob-shaped */
     float lr[2][3];             /* [stage: geometry, colour][decoders, geometry rows, colour rows] (configs mapping.stage.*) */
     int32_t iters, n_geo_iters;
-    float* work;                /* lk_map_work_floats(R, iters) floats, or NULL: as lk_track_desc.work - the batches (pixels, rays, colours,
+    float* work;                /* lk_map_work_floats(R, S, iters) floats, or NULL: as lk_track_desc.work - the batches (pixels, rays, colours,
                                    radii, inside masks) of all `iters` iterations are assembled by one launch of the call that starts at
                                    it_begin = 0 (gt_color / thr / scratch_u32 and render.rays_o / rays_d / gt_depth are then unused) */
 } lk_map_desc;
-int64_t lk_map_work_floats(int32_t R, int32_t iters);
+int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters);
+/* float offset inside `work` of the neighbour lists lk_map_frame keeps per iteration: int32 [iters][R*S][8] (what a data-parallel
+ * caller needs to agree on the touched rows of an iteration, loopy_slam_amd/parallel.py) */
+int64_t lk_map_work_nbr_idx(int32_t R, int32_t S, int32_t iters);
 int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t phases, void* stream);
 
 /* ---------------------------------------------------------------- weight-gradient building block

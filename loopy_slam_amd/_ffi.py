@@ -169,7 +169,8 @@ class LoopyLib:
             ('lk_compact', [_fp, C.c_int32, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_set_serial', [C.c_int32], C.c_int),
             ('lk_track_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
-            ('lk_map_work_floats', [C.c_int32, C.c_int32], C.c_int64),
+            ('lk_map_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
+            ('lk_map_work_nbr_idx', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
             ('lk_track_frame', [C.POINTER(TrackDesc), C.c_void_p], C.c_int),
             ('lk_map_frame', [C.POINTER(MapDesc), C.c_int32, C.c_int32, C.c_int32, C.c_void_p], C.c_int),
             ('lk_inside_mask', [_fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),

@@ -158,6 +158,29 @@ namespace { struct SideStream; SideStream& side_stream(); }
 static void seg_args(const lk_render_desc* d, int P, LkFeatScatterArgs& fs);
 static int seg_sort_async(const lk_render_desc* d, int P, bool counted, hipStream_t st);
 
+static void fill_sample_args(const lk_render_desc* d, int P, bool all_pos, LkSampleArgs& sa) {
+    sa.R = d->R; sa.S = d->S; sa.P = P; sa.stats_chunk = d->stats_chunk; sa.flags = d->flags;
+    sa.rays_o = d->rays_o; sa.rays_d = d->rays_d; sa.gt_depth = d->gt_depth; sa.r2_ray = d->r2_ray;
+    sa.far_stats = all_pos ? nullptr : d->far_stats;
+    sa.grid = d->knn->grid; sa.sorted = d->knn->sorted; sa.cell_start = d->knn->cell_start;
+    sa.geo_feats = d->geo_feats; sa.col_feats = d->col_feats; sa.noise_geo = d->noise_geo; sa.noise_col = d->noise_col;
+    sa.near_surface = d->near_surface; sa.far_surface = d->far_surface; sa.near_end = d->near_end; sa.r2_static = d->r2_static;
+    sa.min_nn = d->min_nn;
+    sa.z = d->z; sa.nbr_idx = d->nbr_idx; sa.nbr_w = d->nbr_w; sa.nbr_count = d->nbr_count; sa.c_geo = d->c_geo; sa.c_col = d->c_col;
+    sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr;
+}
+// z and the neighbour lists of a batch (the part of the sampler that does not read the feature tables); needs ZERO_ABSENT /
+// ALL_DEPTH_POS batches (no far_bb statistics)
+int lk_presample(const lk_render_desc* d, hipStream_t st) {
+    LK_REQUIRE(d && d->knn && d->rays_o && d->rays_d && d->gt_depth && d->z && d->nbr_idx && d->nbr_w && d->nbr_count, "lk_presample: NULL buffer");
+    LK_REQUIRE(d->flags & (LK_FLAG_ALL_DEPTH_POS | LK_FLAG_ZERO_ABSENT), "lk_presample: needs ALL_DEPTH_POS / ZERO_ABSENT");
+    LK_REQUIRE((int64_t)d->R * d->S < (1ll << 31), "lk_presample: R*S too large");
+    if (d->R == 0) return LK_OK;
+    LkSampleArgs sa;
+    fill_sample_args(d, d->R * d->S, true, sa);
+    return lk_launch_sample_interp(sa, st, 1);
+}
+
 extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
 
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
@@ -172,22 +195,14 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
         lk_launch_depth_stats(d->gt_depth, d->R, d->stats_chunk, d->far_stats, st);
     }
     LkSampleArgs sa;
-    sa.R = d->R; sa.S = d->S; sa.P = P; sa.stats_chunk = d->stats_chunk; sa.flags = d->flags;
-    sa.rays_o = d->rays_o; sa.rays_d = d->rays_d; sa.gt_depth = d->gt_depth; sa.r2_ray = d->r2_ray;
-    sa.far_stats = all_pos ? nullptr : d->far_stats;
-    sa.grid = d->knn->grid; sa.sorted = d->knn->sorted; sa.cell_start = d->knn->cell_start;
-    sa.geo_feats = d->geo_feats; sa.col_feats = d->col_feats; sa.noise_geo = d->noise_geo; sa.noise_col = d->noise_col;
-    sa.near_surface = d->near_surface; sa.far_surface = d->far_surface; sa.near_end = d->near_end; sa.r2_static = d->r2_static;
-    sa.min_nn = d->min_nn;
-    sa.z = d->z; sa.nbr_idx = d->nbr_idx; sa.nbr_w = d->nbr_w; sa.nbr_count = d->nbr_count; sa.c_geo = d->c_geo; sa.c_col = d->c_col;
+    fill_sample_args(d, P, all_pos, sa);
     const bool presort = (skip & LK_FUSE_COMPOSITE_BWD) && (d->flags & LK_FLAG_GRAD_FEATS) && d->bwd_scratch;
-    sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr;
     if (presort) {       // the backward of this forward follows (lk_map_frame): its rows are counted per point by the sampler ...
         LkFeatScatterArgs fs;
         seg_args(d, P, fs);
         sa.seg_cnt = fs.seg_cnt; sa.seg_rank = fs.seg_rank; sa.row_mask = fs.row_mask;
     }
-    lk_launch_sample_interp(sa, st);
+    lk_launch_sample_interp(sa, st, (skip & LK_PRESAMPLED) ? 2 : 0);
     if (presort) {       // ... and sorted beside the decoders
         const int rc2 = seg_sort_async(d, P, true, st);
         if (rc2 != LK_OK) return rc2;
@@ -260,6 +275,7 @@ SideStream& side_stream() {
 }  // namespace
 
 extern "C" int lk_set_serial(int32_t on) { g_serial = on ? 1 : 0; return LK_OK; }
+bool lk_serial_mode() { if (g_serial < 0) g_serial = getenv("LK_SERIAL") != nullptr ? 1 : 0; return g_serial != 0; }
 
 static void seg_args(const lk_render_desc* d, int P, LkFeatScatterArgs& fs) {
     const BwdLayout L = bwd_layout(P, d->flags);

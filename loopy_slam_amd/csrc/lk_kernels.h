@@ -192,7 +192,10 @@ inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_W
 
 // lk_render_fwd / lk_render_bwd with parts of their launch sequence left to the caller (the fused per-frame loops, lk_loop.hip)
 enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, LK_FUSE_COMPOSITE_BWD = 8, LK_LOSS_PREZEROED = 16,
-       LK_SEG_SORTED = 32 /* bwd: the forward (LK_FUSE_COMPOSITE_BWD + GRAD_FEATS) already sorted the rows by point */ };
+       LK_SEG_SORTED = 32 /* bwd: the forward (LK_FUSE_COMPOSITE_BWD + GRAD_FEATS) already sorted the rows by point */,
+       LK_PRESAMPLED = 64 /* fwd: z / nbr_idx / nbr_w / nbr_count are given (lk_presample), only interpolate */ };
+int lk_presample(const lk_render_desc* d, hipStream_t st);
+bool lk_serial_mode();                                      // LK_SERIAL / lk_set_serial: one stream only      // the search of a batch: z and the neighbour lists
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip);
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total; };
@@ -217,7 +220,7 @@ int lk_dw2_parts(int P);
 int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st);
 
 int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st);
-int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st);
+int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode = 0);     // 1: search only, 2: interpolation of given lists
 int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st);
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st);
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st);

@@ -201,8 +201,8 @@ TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     w.total = o;
     return w;
 }
-struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, total; };
-MapWork map_work(int64_t R, int64_t iters) {
+struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, z, nbr_idx, nbr_w, nbr_count, total; };
+MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     MapWork w;
     int64_t o = 0;
     w.rays_o = o; o += al4(iters * R * 3);
@@ -211,13 +211,36 @@ MapWork map_work(int64_t R, int64_t iters) {
     w.gt_color = o; o += al4(iters * R * 3);
     w.r2_ray = o; o += al4(iters * R);
     w.thr = o; o += al4(iters);
+    // the search results of every iteration (lk_presample on the third stream): [iters][P], [iters][P][8]
+    const int64_t P = R * S;
+    w.z = o; o += al4(iters * P);
+    w.nbr_idx = o; o += al4(iters * P * LK_K);
+    w.nbr_w = o; o += al4(iters * P * LK_K);
+    w.nbr_count = o; o += al4(iters * P);
     w.total = o;
     return w;
+}
+// Third stream: the neighbour search of a mapping call's iterations runs ahead of the iterations themselves (it reads the rays
+// and the positions, nothing the iterations write), in up to LK_PRE_CHUNKS launches with an event each.
+#define LK_PRE_CHUNKS 16
+struct PreStream { hipStream_t st = nullptr; hipEvent_t e0 = nullptr; hipEvent_t ev[LK_PRE_CHUNKS] = {}; bool ok = false; };
+PreStream& pre_stream() {
+    static PreStream s, none;
+    if (lk_serial_mode()) return none;
+    if (!s.st) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        s.ok = hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, lo) == hipSuccess &&
+               hipEventCreateWithFlags(&s.e0, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < LK_PRE_CHUNKS && s.ok; ++i) s.ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
+    }
+    return s;
 }
 }  // namespace
 
 extern "C" int64_t lk_track_work_floats(int32_t R, int32_t S, int32_t iters) { return track_work(R, S, iters).total; }
-extern "C" int64_t lk_map_work_floats(int32_t R, int32_t iters) { return map_work(R, iters).total; }
+extern "C" int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters) { return map_work(R, S, iters).total; }
+extern "C" int64_t lk_map_work_nbr_idx(int32_t R, int32_t S, int32_t iters) { return map_work(R, S, iters).nbr_idx; }
 
 extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     LK_REQUIRE(d != nullptr, "lk_track_frame: NULL descriptor");
@@ -352,7 +375,9 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
     const int64_t nb = lk_weight_blob_floats();
     const int64_t nrow = d->n_rows * LK_C;
-    const MapWork wk = map_work(R, d->iters);
+    const MapWork wk = map_work(R, d->render.S, d->iters);
+    const int64_t Pn = (int64_t)R * d->render.S;
+    const int pre_chunk = lk_cdiv(d->iters, LK_PRE_CHUNKS) < 6 ? 6 : lk_cdiv(d->iters, LK_PRE_CHUNKS);       // iterations per search launch
     float* W0 = d->work;
     if (pre && it_begin == 0 && (phases & 1)) {
         // pixels, rays, colours, radii and the inside mask of EVERY iteration of this optimize_map call in one launch; it also
@@ -366,6 +391,24 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         pa.rays_o = W0 + wk.rays_o; pa.rays_d = W0 + wk.rays_d; pa.gt_depth = W0 + wk.gt_depth; pa.gt_color = W0 + wk.gt_color;
         pa.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray : nullptr; pa.thr = W0 + wk.thr; pa.zero4 = d->log;
         hipLaunchKernelGGL(k_pregather, dim3(d->iters), dim3(1024), 0, st, pa);
+        // neighbour search of every iteration, a few iterations per launch, ahead of the loop on the low-priority third stream
+        PreStream& ps = pre_stream();
+        hipStream_t pst = ps.ok ? ps.st : st;
+        if (ps.ok) { (void)hipEventRecord(ps.e0, st); (void)hipStreamWaitEvent(pst, ps.e0, 0); }
+        for (int c0 = 0, c = 0; c0 < d->iters; c0 += pre_chunk, ++c) {
+            const int nc = d->iters - c0 < pre_chunk ? d->iters - c0 : pre_chunk;
+            lk_render_desc sd = d->render;
+            sd.flags = (d->render.flags & LK_FLAG_REL_POS) | LK_FLAG_ZERO_ABSENT;
+            sd.R = nc * R; sd.stats_chunk = sd.R;
+            sd.rays_o = W0 + wk.rays_o + (size_t)c0 * R * 3; sd.rays_d = W0 + wk.rays_d + (size_t)c0 * R * 3;
+            sd.gt_depth = W0 + wk.gt_depth + (size_t)c0 * R;
+            sd.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray + (size_t)c0 * R : nullptr;
+            sd.z = W0 + wk.z + (size_t)c0 * Pn; sd.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)c0 * Pn;
+            sd.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)c0 * Pn * LK_K; sd.nbr_w = W0 + wk.nbr_w + (size_t)c0 * Pn * LK_K;
+            const int rc = lk_presample(&sd, pst);
+            if (rc != LK_OK) return rc;
+            if (ps.ok) (void)hipEventRecord(ps.ev[c], pst);
+        }
     }
     for (int it = it_begin; it < it_end; ++it) {
         const bool color = it >= d->n_geo_iters;
@@ -378,6 +421,12 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             rd.rays_o = W0 + wk.rays_o + (size_t)it * R * 3; rd.rays_d = W0 + wk.rays_d + (size_t)it * R * 3;
             rd.gt_depth = W0 + wk.gt_depth + (size_t)it * R; rd.loss_gt_color = W0 + wk.gt_color + (size_t)it * R * 3;
             if (rd.r2_ray) rd.r2_ray = W0 + wk.r2_ray + (size_t)it * R;
+            rd.z = W0 + wk.z + (size_t)it * Pn; rd.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)it * Pn;
+            rd.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)it * Pn * LK_K; rd.nbr_w = W0 + wk.nbr_w + (size_t)it * Pn * LK_K;
+            if ((phases & 1) && (it % pre_chunk == 0 || it == it_begin)) {
+                PreStream& ps = pre_stream();
+                if (ps.ok) (void)hipStreamWaitEvent(st, ps.ev[it / pre_chunk], 0);
+            }
         }
         if (phases & 1) {
             int rc;
@@ -391,7 +440,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 if (rc != LK_OK) return rc;
             }
             // the loss gradient is final when the composite kernel has written it: its backward rides in the same launch
-            rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? LK_LOSS_PREZEROED : 0));
+            rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0));
             if (rc != LK_OK) return rc;
             rc = lk_render_bwd_impl(&rd, st, LK_SKIP_COMPOSITE_BWD | LK_SEG_SORTED);
             if (rc != LK_OK) return rc;

@@ -42,15 +42,30 @@ __global__ __launch_bounds__(256) void k_depth_stats(const float* __restrict__ g
 // cooperative exact top-8 within the radius, normalised weights, then lane `sub` gathers its float4
 // of each of the 8 neighbour rows (8 lanes x 16 B = one 128-B feature row per load instruction).
 // T = lanes per sample point (8: large batches; 16: training batches, halves each lane's serial candidate chain)
-template <int T>
+// MODE 0: search + interpolation.  The search depends on the rays and the positions only - not on what a mapping call optimises -
+// so lk_map_frame runs it for ALL its iterations ahead of time on a third stream (MODE 1: lists only) and every iteration starts
+// with MODE 2 (lists given: interpolation of the current features, the backward's row count).
+template <int T, int MODE>
 __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     const int sub = (int)threadIdx.x & (T - 1);
     const int p_raw = blockIdx.x * (256 / T) + (int)threadIdx.x / T;
     const bool live = p_raw < a.P;
     const int pidx = live ? p_raw : a.P - 1;           // dead groups shadow the last point, never store
     const int r = pidx / a.S, s = pidx - r * a.S;
+    float d[LK_K], w[LK_K];
+    int id[LK_K];
+    int count = 0;
+    float z = 0.0f;
+    if (MODE == 2) {
+        const int4 i0 = *reinterpret_cast<const int4*>(a.nbr_idx + (size_t)pidx * LK_K);
+        const int4 i1 = *reinterpret_cast<const int4*>(a.nbr_idx + (size_t)pidx * LK_K + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(a.nbr_w + (size_t)pidx * LK_K);
+        const float4 w1 = *reinterpret_cast<const float4*>(a.nbr_w + (size_t)pidx * LK_K + 4);
+        id[0] = i0.x; id[1] = i0.y; id[2] = i0.z; id[3] = i0.w; id[4] = i1.x; id[5] = i1.y; id[6] = i1.z; id[7] = i1.w;
+        w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+        count = a.nbr_count[pidx];
+    } else {
     const float gt = a.gt_depth[r];
-    float z;
     if (gt > 0.0f) {
         const float t = lk_linspace(0.0f, 1.0f, a.S, s);
         z = __fadd_rn(__fmul_rn(__fmul_rn(a.near_surface, gt), __fsub_rn(1.0f, t)),
@@ -63,12 +78,9 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     const float qy = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
     const float qz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
     const float r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
-    float d[LK_K], w[LK_K];
-    int id[LK_K];
     lk_knn_scan_coop<T>(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, sub, d, id);
     // w = 1/(D+1e-10), zero outside the radius, L1-normalised (decoder.py:210-220)
     float wsum = 0.0f;
-    int count = 0;
 #pragma unroll
     for (int j = 0; j < LK_K; ++j) {
         const bool in = id[j] >= 0 && d[j] <= r2;
@@ -79,6 +91,7 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     const float inv = 1.0f / fmaxf(wsum, 1e-12f);
 #pragma unroll
     for (int j = 0; j < LK_K; ++j) w[j] = w[j] * inv;
+    }
     if (!live) return;
     // lane `sub` publishes neighbour slot `sub`
     {
@@ -86,11 +99,14 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
         int ij = id[0];
 #pragma unroll
         for (int j = 1; j < LK_K; ++j) { wj = (sub == j) ? w[j] : wj; ij = (sub == j) ? id[j] : ij; }
-        if (sub < LK_K) {
-            a.nbr_idx[(size_t)pidx * LK_K + sub] = ij;
-            a.nbr_w[(size_t)pidx * LK_K + sub] = wj;
+        if (MODE != 2) {
+            if (sub < LK_K) {
+                a.nbr_idx[(size_t)pidx * LK_K + sub] = ij;
+                a.nbr_w[(size_t)pidx * LK_K + sub] = wj;
+            }
+            if (sub == 0) { a.nbr_count[pidx] = count; a.z[pidx] = z; }
         }
-        if (sub == 0) { a.nbr_count[pidx] = count; a.z[pidx] = z; }
+        if (MODE == 1) return;
         // first pass of the backward's counting sort of the rows by point (k_seg_count, lk_bwd2.hip), while the indices are here
         if (a.seg_cnt && sub < LK_K) {
             int rk = -1;
@@ -185,10 +201,22 @@ int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hip
     hipLaunchKernelGGL(k_depth_stats, dim3(lk_cdiv(R, chunk)), dim3(256), 0, st, gt, R, chunk, far_out);
     return LK_OK;
 }
-int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st) {
+int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode) {
+    if (mode == 1) {         // lists only, ahead of time: not one of the timed per-iteration launches
+        if (a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16, 1>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_sample_interp<8, 1>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
+        return LK_OK;
+    }
     LkProfScope prof_(LKK_SAMPLE_INTERP, st);
-    if (a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_sample_interp<8>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
+    if (mode == 2) {
+        // with rel-pos colour features only the geometry rows are interpolated here: 8 lanes per point are enough
+        const bool two = (a.flags & LK_FLAG_STAGE_COLOR) && !(a.flags & LK_FLAG_REL_POS);
+        if (two && a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16, 2>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_sample_interp<8, 2>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
+        return LK_OK;
+    }
+    if (a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16, 0>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_sample_interp<8, 0>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st) {

@@ -69,13 +69,12 @@ class DistContext:
         themselves would be 256 B x N per iteration (1.28 GB at 5 M points); instead the ranks agree on the UNION of
         the rows they touched - one MAX all-reduce of an N-byte flag vector (5 MB) - and only those rows ride in the bucket.
         Returns the sorted int32 row list (identical on every rank)."""
-        st = mo.st
         N = mo.geo.shape[0]
         if self._touched is None or self._touched.numel() != N:
             self._touched = torch.zeros(N, dtype=torch.uint8, device=mo.geo.device)
         else:
             self._touched.zero_()
-        idx = st.nbr_idx.reshape(-1)
+        idx = mo.current_nbr_idx().reshape(-1)
         self._touched[idx[idx >= 0].long()] = 1
         dist.all_reduce(self._touched, op=dist.ReduceOp.MAX)
         return torch.nonzero(self._touched).reshape(-1).to(torch.int32)

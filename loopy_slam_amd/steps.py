@@ -253,21 +253,32 @@ class MapOptimizer:
             for k in range(3):
                 d.lr[si][k] = self.lrs[stage][k]
         d.iters, d.n_geo_iters = n_iters, n_geo_iters
-        need = int(eng.lib.dll.lk_map_work_floats(self.R, n_iters)) if self.R <= 8192 else 0
+        need = int(eng.lib.dll.lk_map_work_floats(self.R, self.cfg.S, n_iters)) if self.R <= 8192 else 0
         if need and (self._work is None or self._work.numel() < need):
             self._work = eng.empty(need)
         d.work = ptr(self._work) if need else 0
+        self._nat_lists = (int(eng.lib.dll.lk_map_work_nbr_idx(self.R, self.cfg.S, n_iters)), n_iters) if need else None
         self._keep_native = (depth_stack, color_stack, c2w_stack, r2_stack, frame_id, rnd_all, log)
         dll = eng.lib.dll
         if self.dist is None:
             eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n_iters, 3, eng.stream), 'lk_map_frame')
         else:
             for it in range(n_iters):
+                self._nat_it = it
                 eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 1, eng.stream), 'lk_map_frame')
                 self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color')
                 eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 2, eng.stream), 'lk_map_frame')
         self.it += n_iters
         return log
+
+    def current_nbr_idx(self):
+        """Neighbour lists [R*S, 8] (int32) of the iteration whose gradients are being exchanged: lk_map_frame keeps the lists of
+        every iteration in its work buffer (the search runs ahead of the loop); the per-statement path has them in the state."""
+        if getattr(self, '_nat_lists', None) is not None and self.native_loop and self.exposure is None:
+            off, _ = self._nat_lists
+            P8 = self.R * self.cfg.S * 8
+            return self._work[off + self._nat_it * P8: off + (self._nat_it + 1) * P8].view(torch.int32)
+        return self.st.nbr_idx
 
     def finish(self):
         """End of the optimize_map call: stacked exposure features go back to the keyframes' tensors."""
