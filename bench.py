@@ -110,7 +110,7 @@ def main():
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if (args.strong and world > 1) else 'weak',
         'vs_baseline': None,
         'dtype': 'f32 (decoder products as split products on the 16-bit matrix pipe: fp16x3 forward, bf16x6 / pre-scaled fp16x3 backward, '
-                 'fp32 accumulate; weight gradients fp32 MFMA)',
+                 'fp32 accumulate; weight gradients on pre-scaled fp16x3 too)',
         'data': 'synthetic',
         'config': {'workload': 'Replica room0 budget: 40 track it x 1500 rays + 60 map it x 5000 rays per frame '
                                '(24 geometry + 36 colour) on the frustum rows of the mapped frame, S=5, k=8, C=32, rel-pos colour MLP, '
@@ -129,6 +129,14 @@ def main():
         step_bytes = world * (budget.map_iters * budget.map_rays * 31.6e3 + budget.track_iters * budget.track_rays * 22.2e3)
         out['hbm_frac_whole_step'] = step_bytes * args.steps / dt / (world * profile.PEAK_HBM_GBS * 1e9)
         out['host_cores'] = os.cpu_count()
+        # every timed kernel against its own roof, from the profiled warm-up step (events around every launch, so slightly slower
+        # than the timed region): the dominant kernel changes with small shifts - k_wgrad and k_decode_bwd are within 2 % of each other
+        out['roofline_all_kernels'] = []
+        for kn in sorted(kall, key=lambda k: -kall[k]['total_ms']):
+            rk = profile.roofline(kall, budget, kn)
+            if rk is not None:
+                out['roofline_all_kernels'].append({k: (round(rk[k], 4) if isinstance(rk[k], float) else rk[k])
+                                                    for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us') if k in rk})
         out['kernel_ms_per_step'] = {k: round(v['total_ms'], 3) for k, v in sorted(kall.items(), key=lambda kv: -kv[1]['total_ms'])}
         if not args.no_cpu_baseline:
             import bench_cpu_baseline

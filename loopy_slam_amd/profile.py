@@ -8,12 +8,14 @@ Algorithmic work per unit (DESIGN.md §Kernels states the same figures):
     decode bwd   (backward-data) geometry 15 392 ; colour 86 400 (+ 10 240 embedding columns in tracker mode)
     rel-pos fwd  8 neighbours x (128x52 + 32x128) = 86 016 ;  bwd 8 x (128x52 fwd + 32x128 + 128x52 bwd) = 139 264
                  (+ 8 x 32x128 for the recomputed output in tracker mode)
-    wgrad        colour matrices 96 640 ; rel-pos matrices 86 016
+    wgrad        colour matrices 96 640 (k_wgrad); the rel-pos matrices ride in k_relpos_bwd_fused (linear1, 8 x 128x52) and
+                 k_dw2_hbar (linear2 from the per-sample Hbar, 32x128) in mapper mode
   bytes per SAMPLE POINT
     sample/interpolate  8 x 128 B feature rows per decoder gathered + 128 B written per decoder + 80 B
                         neighbour list/weights/count/z  (the grid candidate scan is extra, not counted)
     feature scatter     8 x 128 B read-modify-write per decoder + the gradient rows read (k_feat_scatter)
-    weight gradients    7 984 B of saved rows per sample (colour launch), 6 788 B (rel-pos launch)
+    weight gradients    7 984 B of saved rows per sample (k_wgrad: colour trunk)
+    rel-pos backward    mapper mode: 8 x 128 B feature-row gradients + 512 B Hbar + 4 B written per sample (no neighbour rows)
 """
 import ctypes as C
 
@@ -26,7 +28,9 @@ PEAK_F32_VIA_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_F32_VIA_F16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
 # matrix path of each MFMA-bound kernel: 'f32' = v_mfma_f32_32x32x2_f32, 'bf16x6' / 'f16x3' = split products
-MFMA_PATH = {'k_decode_fwd': 'f16x3', 'k_relpos_fwd': 'f16x3', 'k_relpos_bwd': 'bf16x6', 'k_decode_bwd': 'bf16x6', 'k_wgrad': 'f32'}
+# (k_relpos_bwd / k_decode_bwd: scaled fp16 pieces in mapper mode, bf16 pieces in tracker mode - work_per_step splits their flops;
+# k_wgrad: scaled fp16 pieces in mapper mode, its only caller in the benchmark)
+MFMA_PATH = {'k_decode_fwd': 'f16x3', 'k_relpos_fwd': 'f16x3', 'k_relpos_bwd': 'bf16x6', 'k_decode_bwd': 'bf16x6', 'k_wgrad': 'f16x3'}
 S = 5
 
 MAC = dict(
@@ -34,7 +38,7 @@ MAC = dict(
     dec_bwd_geo=3 * 32 * 32 + 32 * 128 + 32 * 96 + 5 * 32 * 32 + 32,
     dec_bwd_col=3 * 128 * 128 + 128 * 128 + 5 * 128 * 32 + 3 * 128, dec_bwd_track_extra=2 * 128 * 40,
     rel_fwd=8 * (128 * 52 + 32 * 128), rel_bwd=8 * (2 * 128 * 52 + 32 * 128), rel_bwd_track_extra=8 * 32 * 128,
-    wgrad_col=96640, wgrad_rel=8 * (128 * 52 + 32 * 128),
+    wgrad_col=96640, rel_dw1=8 * 128 * 52,
 )
 
 
@@ -64,16 +68,18 @@ def work_per_step(b):
     fl = lambda macs: 2.0 * macs
     feat_rows = 8 * 128
     # bytes per sample read by the weight-gradient reductions: d h (640) + a (640) + layer inputs h0..h3 (512) + e (40)
-    # + c (32) + h4 (128) + d logit (4) floats; rel-pos launch: 8 neighbour rows x 192 floats + Hbar (128) + d c (32) + 1
-    wg_bytes_col, wg_bytes_rel = 4.0 * (640 + 640 + 512 + 40 + 32 + 128 + 4), 4.0 * (8 * 192 + 128 + 32 + 1)
+    # + c (32) + h4 (128) + d logit (4) floats
+    wg_bytes_col = 4.0 * (640 + 640 + 512 + 40 + 32 + 128 + 4)
     w = {
         'k_decode_fwd': dict(flops=fl(n_geo * Pm * MAC['dec_fwd_geo'] + (n_col * Pm + n_trk * Pt) * (MAC['dec_fwd_geo'] + MAC['dec_fwd_col'])),
                              bytes=0.0, launches=b.map_iters + n_trk),
         'k_decode_bwd': dict(flops=fl(n_geo * Pm * MAC['dec_bwd_geo'] + n_col * Pm * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col']) +
                                       n_trk * Pt * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col'] + MAC['dec_bwd_track_extra'])),
+                             flops_by_path={'f16x3': fl(n_col * Pm * MAC['dec_bwd_col']),
+                                            'bf16x6': fl((n_geo + n_col) * Pm * MAC['dec_bwd_geo'] +
+                                                         n_trk * Pt * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col'] + MAC['dec_bwd_track_extra']))},
                              bytes=0.0, launches=b.map_iters + n_trk),
-        'k_wgrad': dict(flops=fl(n_col * Pm * (MAC['wgrad_col'] + rel * MAC['wgrad_rel'])),
-                        bytes=n_col * Pm * (wg_bytes_col + rel * wg_bytes_rel), launches=n_col * (1 + rel)),
+        'k_wgrad': dict(flops=fl(n_col * Pm * MAC['wgrad_col']), bytes=n_col * Pm * wg_bytes_col, launches=n_col),
         'k_sample_interp': dict(flops=0.0, bytes=float(n_geo * Pm * (feat_rows + 128 + 80) + n_col * Pm * ((2 - rel) * (feat_rows + 128) + 80) +
                                                        n_trk * Pt * ((2 - rel) * (feat_rows + 128) + 80)), launches=b.map_iters + n_trk),
         # feature-gradient scatter (mapper only): per table 8 x 128 B read-modify-write (+ 8 x 128 B of per-neighbour
@@ -83,9 +89,11 @@ def work_per_step(b):
     }
     if rel:
         w['k_relpos_fwd'] = dict(flops=fl((n_col * Pm + n_trk * Pt) * MAC['rel_fwd']), bytes=0.0, launches=n_col + n_trk)
-        w['k_relpos_bwd'] = dict(flops=fl(n_col * Pm * MAC['rel_bwd'] + n_trk * Pt * (MAC['rel_bwd'] + MAC['rel_bwd_track_extra'])),
-                                 # mapper: rows [8][192] + d feat [8][32] + Hbar [128] floats written per sample
-                                 bytes=n_col * Pm * 4.0 * (8 * 192 + 8 * 32 + 128), launches=n_col + n_trk)
+        w['k_relpos_bwd'] = dict(flops=fl(n_col * Pm * (MAC['rel_bwd'] + MAC['rel_dw1']) + n_trk * Pt * (MAC['rel_bwd'] + MAC['rel_bwd_track_extra'])),
+                                 flops_by_path={'f16x3': fl(n_col * Pm * (MAC['rel_bwd'] + MAC['rel_dw1'])),
+                                                'bf16x6': fl(n_trk * Pt * (MAC['rel_bwd'] + MAC['rel_bwd_track_extra']))},
+                                 # mapper: d feat [8][32] + Hbar [128] + weight sum written per sample
+                                 bytes=n_col * Pm * 4.0 * (8 * 32 + 128 + 1), launches=n_col + n_trk)
     return w
 
 
@@ -96,10 +104,14 @@ def pmc_traffic(kernel, path=None):
     import os
     path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r2_rocprof_summary.md')
     try:
+        tot_n, tot_b = 0, 0.0
         for line in open(path):
             c = [x.strip() for x in line.strip().strip('|').split('|')]
-            if len(c) == 5 and c[0] == kernel:
-                return float(c[3]) * 1e6 + float(c[4]) * 1024.0, 'profiles/r2_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
+            if len(c) == 5 and c[0].split('<')[0] == kernel and c[1].isdigit():         # template variants: launch-weighted mean
+                tot_n += int(c[1])
+                tot_b += int(c[1]) * (float(c[3]) * 1e6 + float(c[4]) * 1024.0)
+        if tot_n:
+            return tot_b / tot_n, 'profiles/r2_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
     except (OSError, ValueError):
         pass
     return None, None
@@ -120,8 +132,14 @@ def roofline(kstat, budget, kernel):
     secs = k['total_ms'] * 1e-3
     flops, nbytes = model['flops'] * n_steps, model['bytes'] * n_steps
     path = MFMA_PATH.get(kernel, 'f32')
-    peak_mfma = {'bf16x6': PEAK_F32_VIA_BF16X6_TFLOPS, 'f16x3': PEAK_F32_VIA_F16X3_TFLOPS}.get(path, PEAK_F32_MFMA_TFLOPS)
-    t_mfma, t_hbm = flops / (peak_mfma * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+    peaks = {'bf16x6': PEAK_F32_VIA_BF16X6_TFLOPS, 'f16x3': PEAK_F32_VIA_F16X3_TFLOPS, 'f32': PEAK_F32_MFMA_TFLOPS}
+    peak_mfma = peaks.get(path, PEAK_F32_MFMA_TFLOPS)
+    t_mfma = flops / (peak_mfma * 1e12)
+    if model.get('flops_by_path'):        # launches on different piece types: the roof is the time-weighted blend
+        t_mfma = sum(f * n_steps / (peaks[p] * 1e12) for p, f in model['flops_by_path'].items())
+        peak_mfma = flops / t_mfma / 1e12 if t_mfma > 0 else peak_mfma
+        path = '+'.join(sorted(p for p, f in model['flops_by_path'].items() if f > 0))
+    t_hbm = nbytes / (PEAK_HBM_GBS * 1e9)
     out = {'kernel': kernel, 'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'], 'traffic': None}
     if t_mfma >= t_hbm:
         out.update(bound='mfma', achieved=flops / secs / 1e12, peak=peak_mfma, unit='TFLOP/s', mfma_path=path,

@@ -1,12 +1,12 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25 > gpurun_out/gpu_tests.log
-tail -2 gpurun_out/gpu_tests.log
-for k in 1 2 3; do
-python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print('overlap %.2f ms/step' % d['ms_per_step'], {k[2:]: round(v, 2) for k, v in d['kernel_ms_per_step'].items()})"
-done
-for m in geo color track; do python tools/mode_trace.py $m 40 --repeat 3 2>&1 | tail -1; done
+bash tools/profile_round.sh r2 2>&1 | tail -6
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rm -rf gpurun_out/prof_r2_sq
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/prof_r2_sq -o b -- env LK_SERIAL=1 $B > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/prof_r2_sq > gpurun_out/pmc_sq_r2.txt 2>&1; head -30 gpurun_out/pmc_sq_r2.txt | cut -c1-220
+find gpurun_out/prof_r2_sq -type f ! -name "b_counter_collection.csv" -delete
+bash tools/gpu_trace_modes.sh r2f > /dev/null 2>&1
+grep -E "^period|^###" gpurun_out/trace_r2f.md
+du -sh gpurun_out/prof_r2_*

@@ -21,7 +21,7 @@ lines = [f'# rocprofv3 summary, round tag {tag}', '',
          '(kernel table = profiles/%s_kernel_stats.csv; durations in ns).' % tag, '',
          '| kernel | calls | avg us | % |', '|---|---|---|---|']
 for r in list(csv.DictReader(open(os.path.join(dst, f'{tag}_kernel_stats.csv'))))[:24]:
-    lines.append(f"| {r['Name'].split('(')[0]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    lines.append(f"| {r['Name'].split('(')[0].replace('void ', '')} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
 lines += ['', '## HBM traffic (PMC, separate passes: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each with `--kernel-trace` only)', '',
           'Counter unit = KiB per dispatch.  Per /opt/skills/guides/MI355X_MICROARCH.md §HBM, FETCH_SIZE on gfx950 reports half of the bytes of',
           'wide coalesced reads: the "read (corrected)" column doubles it; WRITE_SIZE is uncalibrated there and quoted as is.', '',
@@ -31,11 +31,11 @@ for cname, d in (('FETCH_SIZE', 'fetch'), ('WRITE_SIZE', 'write')):
     a = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(os.path.join(src, f'prof_{src_tag}_{d}', 'b_counter_collection.csv'))):
         if r['Counter_Name'] == cname:
-            k = r['Kernel_Name'].split('(')[0]
+            k = r['Kernel_Name'].split('(')[0].replace('void ', '')
             a[k][0] += 1
             a[k][1] += float(r['Counter_Value'])
     agg[cname] = a
-for k, (n, v) in sorted(agg['FETCH_SIZE'].items(), key=lambda kv: -kv[1][1])[:16]:
+for k, (n, v) in sorted(agg['FETCH_SIZE'].items(), key=lambda kv: -kv[1][1])[:24]:
     if not k.startswith('k_'):
         continue
     w = agg['WRITE_SIZE'].get(k, [1, 0.0])

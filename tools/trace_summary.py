@@ -67,7 +67,8 @@ def main():
     print('| kernel | launches / iteration | us / iteration | share of period |')
     print('|---|---|---|---|')
     for n, v in sorted(per.items(), key=lambda kv: -med(kv[1])):
-        print(f'| {n[:60]} | {med(cnt[n]):.0f} | {med(v) / 1e3:.1f} | {100 * med(v) / period:.1f} % |')
+        once = '' if len(v) >= 0.9 * len(its) else f' (only in {len(v)} of {len(its)} iterations: medians over those)'
+        print(f'| {n[:60]}{once} | {med(cnt[n]):.0f} | {med(v) / 1e3:.1f} | {100 * med(v) / period:.1f} % |')
     print()
 
 
