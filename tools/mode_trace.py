@@ -20,9 +20,12 @@ def main():
     ap.add_argument('iters', type=int, nargs='?', default=40)
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--repeat', type=int, default=3)
+    ap.add_argument('--rays', type=int, default=0, help='override the mapping batch size')
     args = ap.parse_args()
     eng = core.Engine()
     b = workload.Budget(n_points=args.points)
+    if args.rays:
+        b.map_rays = args.rays
     wl = workload.FrameWorkload(eng, b)
     H, W = wl.H, wl.W
     e = min(b.ignore_edge, H // 4)
