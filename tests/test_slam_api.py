@@ -17,8 +17,8 @@ def mini_cfg():
     cfg = config.load_config('configs/Synthetic/room.yaml', 'configs/point_slam.yaml')
     cfg = copy.deepcopy(cfg)
     cfg['cam'].update(H=24, W=32, fx=26.0, fy=26.0, cx=15.5, cy=11.5)
-    cfg['tracking'].update(ignore_edge_W=2, ignore_edge_H=2, pixels=64, iters=4)
-    cfg['mapping'].update(pixels=96, pixels_adding=400, iters=4, iters_first=8, geo_iter_first=3, every_frame=2, keyframe_every=2,
+    cfg['tracking'].update(ignore_edge_W=2, ignore_edge_H=2, pixels=48, iters=3)
+    cfg['mapping'].update(pixels=64, pixels_adding=400, iters=3, iters_first=6, geo_iter_first=2, every_frame=2, keyframe_every=2,
                           mapping_window_size=4)
     cfg['pointcloud'].update(radius_add=0.12, radius_query=0.24, radius_min=0.06)     # coarse image -> coarser cloud
     cfg['data']['n_frames'] = 4
@@ -250,7 +250,7 @@ def test_final_refinement_optimises_the_whole_map(backend):
     the colour decoder is frozen, ten times the iterations in five optimize_map calls, no points are added."""
     eng = make_engine(backend)
     cfg = mini_cfg()
-    cfg['mapping'].update(iters=2, color_refine=True)
+    cfg['mapping'].update(iters=2, color_refine=True, pixels=96, iters_first=8, geo_iter_first=3)
     ps = slam.Point_SLAM(cfg, None, eng=eng)
     calls = []
     orig = ps.mapper.optimize_map
