@@ -110,6 +110,8 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
 #define LK_FLAG_UNIT_LOSS_GRADS (1u << 11) /* lk_render_bwd: the caller guarantees |d_depth|, |d_color| <= ~1 (sum-type losses
                                            * such as the mapper's L1 terms): the colour decoder's backward may then run its
                                            * products on fp16 pieces with a fixed 2^10 pre-scale instead of bf16 pieces */
+#define LK_FLAG_Z_GIVEN       (1u << 12) /* lk_render_fwd: rays with gt_depth <= 0 take their S sample depths from `z` as the caller filled
+                                         * it (rendering.sample_near_pcl, Renderer.py:152-160) instead of linspace(near_end, far_bb) */
 
 typedef struct {
     /* ---- sizes */

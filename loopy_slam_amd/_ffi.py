@@ -26,6 +26,7 @@ FLAG_GRAD_RAYS = 1 << 7
 FLAG_ALL_DEPTH_POS = 1 << 8
 FLAG_ZERO_ABSENT = 1 << 9
 FLAG_MAPPER_LOSS = 1 << 10
+FLAG_Z_GIVEN = 1 << 12
 FLAG_UNIT_LOSS_GRADS = 1 << 11
 
 EXPOSURE_MAX_F = 32

@@ -220,7 +220,7 @@ class RenderState:
 
 def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_feats, dec, stage,
               tracker=False, r2_ray=None, noise_geo=None, noise_col=None, affine=None,
-              color_logits=False, save_act=False, stats_chunk=None, extra_flags=0, mapper_loss=None):
+              color_logits=False, save_act=False, stats_chunk=None, extra_flags=0, mapper_loss=None, z_given=None):
     d = RenderDesc()
     R = rays_o.shape[0]
     flags = extra_flags
@@ -234,6 +234,9 @@ def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_f
         flags |= _ffi.FLAG_COLOR_LOGITS
     if save_act:
         flags |= _ffi.FLAG_SAVE_ACT
+    if z_given is not None:          # [R,S] sample depths for the rays without a depth reading (rows of the others are ignored)
+        st.z.copy_(z_given.reshape(st.z.shape))
+        flags |= _ffi.FLAG_Z_GIVEN
     d.R, d.S, d.flags = R, cfg.S, flags
     d.stats_chunk = int(stats_chunk) if stats_chunk else max(1, R)
     d.rays_o, d.rays_d, d.gt_depth, d.r2_ray = ptr(rays_o), ptr(rays_d), ptr(gt_depth), ptr(r2_ray)

@@ -231,6 +231,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
     ca.raw = d->raw; ca.z = d->z; ca.nbr_count = d->nbr_count; ca.gt_depth = d->gt_depth;
     ca.depth = d->depth; ca.var = d->var; ca.color = d->color; ca.valid_ray = d->valid_ray;
     ca.gt_color = nullptr; ca.w_color = 0.0f; ca.use_color = 0; ca.d_depth = nullptr; ca.d_color = nullptr; ca.loss_out = nullptr; ca.d_raw = nullptr;
+    ca.keep_depth = (d->flags & LK_FLAG_Z_GIVEN) ? 1 : 0;
     if (d->flags & LK_FLAG_MAPPER_LOSS) {
         LK_REQUIRE(d->loss_out4 && d->d_depth && d->d_color && d->loss_gt_color, "lk_render_fwd: MAPPER_LOSS needs loss_gt_color, loss_out4, d_depth, d_color");
         if (!(skip & LK_LOSS_PREZEROED)) LK_HIP_TRY(hipMemsetAsync(d->loss_out4, 0, 4 * sizeof(float), st));
@@ -335,7 +336,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     cb.R = d->R; cb.S = d->S; cb.min_nn = d->min_nn; cb.coef = d->coef;
     cb.raw = d->raw; cb.z = d->z; cb.nbr_count = d->nbr_count; cb.gt_depth = d->gt_depth;
     cb.d_depth = d->d_depth; cb.d_var = d->d_var; cb.d_color = color ? d->d_color : nullptr;
-    cb.d_raw = S0 + L.d_raw;
+    cb.d_raw = S0 + L.d_raw; cb.keep_depth = (flags & LK_FLAG_Z_GIVEN) ? 1 : 0;
     if (!(skip & LK_SKIP_COMPOSITE_BWD)) lk_launch_composite_bwd(cb, st);
 
     LkDecodeBwdArgs db;

@@ -13,7 +13,7 @@ using namespace lkw;
 __global__ __launch_bounds__(256) void k_composite_bwd(LkCompositeBwdArgs a) {
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
     if (r >= a.R) return;
-    lk_composite_bwd_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, a.gt_depth[r], a.d_depth[r], a.d_var ? a.d_var[r] : 0.0f,
+    lk_composite_bwd_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, a.keep_depth ? 1.0f : a.gt_depth[r], a.d_depth[r], a.d_var ? a.d_var[r] : 0.0f,
                          a.d_color ? a.d_color[3 * r] : 0.0f, a.d_color ? a.d_color[3 * r + 1] : 0.0f, a.d_color ? a.d_color[3 * r + 2] : 0.0f,
                          a.d_raw);
 }

@@ -35,6 +35,7 @@ struct LkCompositeArgs {
     const float* gt_color; float w_color; int use_color;
     float* d_depth; float* d_color; float* loss_out;
     float* d_raw;                                  // with loss_out: also the composite BACKWARD of the loss gradient (d raw [P,4]), or NULL
+    int keep_depth;                                // LK_FLAG_Z_GIVEN: the depth of rays without a reading is NOT zeroed (Renderer.py:197-198)
 };
 
 // fused decoder forward (register-chained MFMA): raw[P,4] = (rgb | logits, occ)
@@ -67,6 +68,7 @@ struct LkCompositeBwdArgs {
     const float* raw; const float* z; const int32_t* nbr_count; const float* gt_depth;
     const float* d_depth; const float* d_var; const float* d_color;
     float* d_raw;                                  // [P,4]
+    int keep_depth;                                // as LkCompositeArgs
 };
 
 struct LkDecodeBwdArgs {

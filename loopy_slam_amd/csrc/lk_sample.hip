@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
         const float t = lk_linspace(0.0f, 1.0f, a.S, s);
         z = __fadd_rn(__fmul_rn(__fmul_rn(a.near_surface, gt), __fsub_rn(1.0f, t)),
                       __fmul_rn(__fmul_rn(a.far_surface, gt), t));
+    } else if (a.flags & LK_FLAG_Z_GIVEN) {
+        z = a.z[pidx];                                  // placed by the caller (sample_near_pcl, Renderer.py:152-160)
     } else {
         const float far = a.far_stats ? a.far_stats[r / a.stats_chunk] : 0.0f;
         z = lk_linspace(a.near_end, far, a.S, s);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void k_composite(LkCompositeArgs a) {
     float l_geo = 0.0f, l_col = 0.0f, l_cnt = 0.0f;
     if (r < a.R) {
         const float gd = a.gt_depth[r];
-        const LkRayOut ro = lk_composite_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, gd);
+        const LkRayOut ro = lk_composite_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, a.keep_depth ? 1.0f : gd);
         const float dout = ro.depth, o0 = ro.c0, o1 = ro.c1, o2 = ro.c2;
         const bool valid = ro.valid;
         a.depth[r] = dout;

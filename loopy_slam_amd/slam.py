@@ -312,13 +312,13 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, geo_feats, col_feats, blob, affine, pack):
-        eng, cfg, knn, pos, dec, gt_depth, stage, tracker, r2, logits, chunk = pack
+        eng, cfg, knn, pos, dec, gt_depth, stage, tracker, r2, logits, chunk, z_given = pack
         R = rays_o.shape[0]
         st = core.RenderState(eng, R, cfg.S, need_act=True)
         core.render_forward(eng, cfg, st, rays_o.detach().contiguous(), rays_d.detach().contiguous(), gt_depth, knn, pos,
                             geo_feats.detach(), col_feats.detach(), dec, stage, tracker=tracker, r2_ray=r2,
                             affine=affine.detach().contiguous() if affine is not None else None, color_logits=logits,
-                            save_act=True, stats_chunk=chunk)
+                            save_act=True, stats_chunk=chunk, z_given=z_given)
         ctx.pack, ctx.st = pack, st
         ctx.needs = (rays_o.requires_grad or rays_d.requires_grad, geo_feats.requires_grad or col_feats.requires_grad,
                      blob.requires_grad, affine is not None and affine.requires_grad)
@@ -344,10 +344,8 @@ class Renderer:
         self.N_surface = cfg['rendering']['N_surface']
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self.sigmoid_coefficient = cfg['rendering']['sigmoid_coef_mapper']     # set externally like the reference
-        if cfg['rendering'].get('sample_near_pcl', False):
-            # off in every reference config (replica/tum/scannet.yaml); NeuralPointCloud.sample_near_pcl exists, but the fused
-            # sampler takes its z for depth-less rays from far_bb only
-            raise NotImplementedError('rendering.sample_near_pcl: True is not wired into the fused render (lk_render_fwd)')
+        # off in every reference config (replica/tum/scannet.yaml): depth-less rays then sample where the cloud is (Renderer.py:152-160)
+        self.sample_near_pcl = bool(cfg['rendering'].get('sample_near_pcl', False))
         self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
 
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None, npc_geo_feats=None,
@@ -367,9 +365,24 @@ class Renderer:
         aff = decoders.exposure_affine(exposure_feat)
         logits = decoders.encode_exposure and exposure_feat is None
         blob = decoders.dec.blob
-        pack = (eng, cfg, npc.knn, pos.contiguous(), decoders.dec, gt_depth, stage, is_tracker, r2, logits, _stats_chunk)
+        z_given, not_near = None, None
+        if self.sample_near_pcl and bool((gt_depth <= 0).any()):
+            # Renderer.py:102-122, 152-160: far of the batch, then the probe of the cloud along the rays without a reading (host round
+            # trips as in the reference: this path is off in every config); their rows of z go to the sampler (LK_FLAG_Z_GIVEN)
+            far_bb = torch.minimum(5 * gt_depth.mean(), torch.max(gt_depth * 1.2))
+            far = torch.clamp(far_bb, 0, torch.max(gt_depth * 1.2)) if float(gt_depth.max()) > 0 else far_bb
+            zero = torch.nonzero(gt_depth <= 0).reshape(-1)
+            z0, inv = npc.sample_near_pcl(rays_o[zero].detach(), rays_d[zero].detach(), cfg.near_end, float(far), cfg.S)
+            z_given = eng.zeros(R, cfg.S)
+            z_given[zero] = z0
+            not_near = zero[inv]
+        pack = (eng, cfg, npc.knn, pos.contiguous(), decoders.dec, gt_depth, stage, is_tracker, r2, logits, _stats_chunk, z_given)
         depth, var, color, valid = _RenderFn.apply(rays_o.float(), rays_d.float(), geo, col, blob, aff, pack)
-        return depth, var, color, valid.bool()
+        valid = valid.bool()
+        if not_near is not None and not_near.numel():
+            valid = valid.clone()
+            valid[not_near] = False                       # valid_ray_mask & mask_rays_near_pcl (Renderer.py:194-195)
+        return depth, var, color, valid
 
     def render_img(self, npc, decoders, c2w, device, stage, gt_depth=None, npc_geo_feats=None, npc_col_feats=None,
                    dynamic_r_query=None, cloud_pos=None, exposure_feat=None):

@@ -280,14 +280,23 @@ def relpos_params(W):
 
 def render_batch(cfg, rays_o, rays_d, gt_depth, pos, geo_feats, col_feats, W, stage,
                  tracker=False, r2_ray=None, noise_geo=None, noise_col=None, affine=None,
-                 color_sigmoid=True, knn=None):
+                 color_sigmoid=True, knn=None, near_pcl=False):
     """Renderer.render_batch_ray (Renderer.py:71-201) + NICER.forward (decoder.py:573-610).
+    near_pcl: rendering.sample_near_pcl - the rays without a depth reading sample where the cloud is (Renderer.py:152-160) and the
+    ones that find no cloud are masked out of valid_ray (Renderer.py:194-195).
 
     Returns dict(depth, var, color, valid_ray, has, z, idx, d2, count, w).
     r2_ray: per-ray squared query radius [R] (dynamic radius) or None (static).
     """
     R, S, C = rays_o.shape[0], cfg.S, geo_feats.shape[1]
-    z, _ = sample_z(gt_depth, cfg.near_surface, cfg.far_surface, cfg.near_end, S)
+    z, far = sample_z(gt_depth, cfg.near_surface, cfg.far_surface, cfg.near_end, S)
+    not_near = None
+    if near_pcl and bool((gt_depth.reshape(-1) <= 0).any()):
+        zero = torch.nonzero(gt_depth.reshape(-1) <= 0).reshape(-1)
+        z0, inv = sample_near_pcl(rays_o[zero].detach(), rays_d[zero].detach(), cfg.near_end, float(far), S, pos.detach().numpy(), cfg.radius_query)
+        z = z.clone()
+        z[zero] = torch.from_numpy(z0)
+        not_near = zero[torch.from_numpy(inv)]
     p = sample_points(rays_o, rays_d, z)
     if r2_ray is None:
         r2 = torch.tensor(np.float32(cfg.radius_query ** 2))
@@ -318,7 +327,11 @@ def render_batch(cfg, rays_o, rays_d, gt_depth, pos, geo_feats, col_feats, W, st
     # un-recorded in-place write; autograd still routes the gradient to the original logit.
     occ_eff = torch.where(has, occ, occ + (-100.0 - occ).detach())
     depth, var, color, w = composite(occ_eff.reshape(R, S), rgb.reshape(R, S, 3), z, cfg.coef)
-    depth = torch.where(gt_depth.reshape(-1) > 0, depth, torch.zeros_like(depth))   # Renderer.py:197-198
+    if not near_pcl:
+        depth = torch.where(gt_depth.reshape(-1) > 0, depth, torch.zeros_like(depth))   # Renderer.py:197-198
+    if not_near is not None:
+        valid_ray = valid_ray.clone()
+        valid_ray[not_near] = False                                                 # Renderer.py:194-195
     return dict(depth=depth, var=var, color=color, valid_ray=valid_ray, has=has, z=z, p=p,
                 idx=idx, d2=d2, count=count, w=w, occ=occ, rgb=rgb)
 

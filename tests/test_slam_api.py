@@ -354,3 +354,42 @@ def test_keyframe_overlap_matches_oracle(backend):
     assert want.max() > 0.5 and want.min() == 0.0                # the case covers seen and unseen keyframes
     sel = mp.keyframe_selection_overlap(color.to(dev), depth.to(dev), c2w.to(dev), [{'est_c2w': p.to(dev)} for p in poses], 3)
     assert len(sel) == 3 and all(want[i] > 0 for i in sel)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_render_with_sample_near_pcl_matches_oracle(backend):
+    """rendering.sample_near_pcl (a21, Renderer.py:152-160, 194-198): rays without a depth reading take their sample depths from the
+    probe of the cloud along the ray (LK_FLAG_Z_GIVEN), keep their rendered depth, and the ones that find no cloud are not valid;
+    forward and gradients against the oracle on a batch that mixes rays with and without a reading."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['rendering']['sample_near_pcl'] = True
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    idx, color, depth, c2w = ps.frame_reader[0]
+    ps.tracker.track_frame(0, color, depth, c2w)
+    ps.mapper.map_frame(0, color, depth, c2w, cur_c2w=c2w)
+    npc, dec = ps.npc, ps.shared_decoders
+    assert ps.renderer.sample_near_pcl
+    g = torch.Generator().manual_seed(1)
+    ii = torch.randint(2, 30, (48,), generator=g).float()
+    jj = torch.randint(2, 22, (48,), generator=g).float()
+    ro, rd = H.rays_from_uv(ii, jj, c2w.cpu(), 26.0, 26.0, 15.5, 11.5)
+    gd = depth.cpu()[jj.long(), ii.long()].clone()
+    gd[::3] = 0.0                                           # a third of the rays has no reading
+    rd[0] = -rd[0]                                          # ... and this one looks away from the cloud: not near it
+    geo = npc.get_geo_feats().clone().requires_grad_(True)
+    ps.renderer.sigmoid_coefficient = 0.1
+    d, u, c, valid = ps.renderer.render_batch_ray(npc, dec, eng.f32(rd), eng.f32(ro), eng.device, 'color', gt_depth=eng.f32(gd),
+                                                   npc_geo_feats=geo)
+    ((d * 1.3).sum() + (c * c).sum()).backward()
+    W = {k: v for k, v in dec.dec.unpack().items()}
+    go = npc.get_geo_feats().cpu().clone().requires_grad_(True)
+    ocfg = H.RenderCfg(radius_query=cfg['pointcloud']['radius_query'], rel_pos=cfg['model']['encode_rel_pos_in_col'])
+    out = H.render_batch(ocfg, ro, rd, gd, npc.cloud_pos().cpu(), go, npc.get_col_feats().cpu(), W, 'color', near_pcl=True)
+    ((out['depth'] * 1.3).sum() + (out['color'] * out['color']).sum()).backward()
+    assert np.array_equal(valid.cpu().numpy(), out['valid_ray'].numpy()) and not bool(valid[0]) and bool(valid[3::3].any())
+    zero = gd <= 0
+    assert float(out['depth'].detach()[zero].abs().max()) > 0.1     # the depth of the rays without a reading is rendered, not zeroed
+    np.testing.assert_allclose(d.detach().cpu().numpy(), out['depth'].detach().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(c.detach().cpu().numpy(), out['color'].detach().numpy(), rtol=1e-4, atol=2e-5)
+    assert float((geo.grad.cpu() - go.grad).abs().max()) < 2e-4 * float(go.grad.abs().max())
