@@ -197,7 +197,11 @@ enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, L
        LK_SEG_SORTED = 32 /* bwd: the forward (LK_FUSE_COMPOSITE_BWD + GRAD_FEATS) already sorted the rows by point */,
        LK_PRESAMPLED = 64 /* fwd: z / nbr_idx / nbr_w / nbr_count are given (lk_presample), only interpolate */ };
 int lk_presample(const lk_render_desc* d, hipStream_t st);
-bool lk_serial_mode();                                      // LK_SERIAL / lk_set_serial: one stream only      // the search of a batch: z and the neighbour lists
+bool lk_serial_mode();                                      // LK_SERIAL / lk_set_serial: one stream only
+// library-owned low-priority third stream (lk_map_frame's search ahead of the loop; small independent launches of the backward)
+#define LK_PRE_CHUNKS 16
+struct LkAuxStream { hipStream_t st = nullptr; hipEvent_t e0 = nullptr; hipEvent_t ev[LK_PRE_CHUNKS] = {}; hipEvent_t e1 = nullptr, e2 = nullptr; bool ok = false; };
+LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour lists
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip);
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total; };

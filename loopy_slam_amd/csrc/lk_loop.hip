@@ -220,22 +220,10 @@ MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     w.total = o;
     return w;
 }
-// Third stream: the neighbour search of a mapping call's iterations runs ahead of the iterations themselves (it reads the rays
-// and the positions, nothing the iterations write), in up to LK_PRE_CHUNKS launches with an event each.
-#define LK_PRE_CHUNKS 16
-struct PreStream { hipStream_t st = nullptr; hipEvent_t e0 = nullptr; hipEvent_t ev[LK_PRE_CHUNKS] = {}; bool ok = false; };
-PreStream& pre_stream() {
-    static PreStream s, none;
-    if (lk_serial_mode()) return none;
-    if (!s.st) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        s.ok = hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, lo) == hipSuccess &&
-               hipEventCreateWithFlags(&s.e0, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < LK_PRE_CHUNKS && s.ok; ++i) s.ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
-    }
-    return s;
-}
+// Third stream (lk_aux_stream, lk_api.hip): the neighbour search of a mapping call's iterations runs ahead of the iterations
+// themselves (it reads the rays and the positions, nothing the iterations write), in up to LK_PRE_CHUNKS launches with an event each.
+typedef LkAuxStream PreStream;
+PreStream& pre_stream() { return lk_aux_stream(); }
 }  // namespace
 
 extern "C" int64_t lk_track_work_floats(int32_t R, int32_t S, int32_t iters) { return track_work(R, S, iters).total; }
