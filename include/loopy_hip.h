@@ -112,6 +112,8 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
                                            * products on fp16 pieces with a fixed 2^10 pre-scale instead of bf16 pieces */
 #define LK_FLAG_Z_GIVEN       (1u << 12) /* lk_render_fwd: rays with gt_depth <= 0 take their S sample depths from `z` as the caller filled
                                          * it (rendering.sample_near_pcl, Renderer.py:152-160) instead of linspace(near_end, far_bb) */
+#define LK_FLAG_FEATS_F16     (1u << 13) /* opt-in storage format: geo_feats / col_feats point at IEEE half tables [N,32] (64-byte rows; BASELINE
+                                         * config 5 'fp16 features').  Everything computed from them, and their gradients, stays fp32 */
 
 typedef struct {
     /* ---- sizes */
@@ -206,6 +208,7 @@ typedef struct {
                                                  (frustum-selected feature rows updated in place in the full table) */
     int32_t row_len;
     int32_t zero_grad;                        /* clear the consumed gradient entries */
+    int32_t p_f16;                            /* p is an IEEE half array (LK_FLAG_FEATS_F16 tables): read as fp32, stepped, rounded to nearest */
 } lk_adam_seg;
 int lk_adam_step(const lk_adam_seg* host_segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream);
 

@@ -27,6 +27,7 @@ FLAG_ALL_DEPTH_POS = 1 << 8
 FLAG_ZERO_ABSENT = 1 << 9
 FLAG_MAPPER_LOSS = 1 << 10
 FLAG_Z_GIVEN = 1 << 12
+FLAG_FEATS_F16 = 1 << 13
 FLAG_UNIT_LOSS_GRADS = 1 << 11
 
 EXPOSURE_MAX_F = 32
@@ -60,7 +61,7 @@ class RenderDesc(C.Structure):
 
 class AdamSeg(C.Structure):
     _fields_ = [('p', _fp), ('g', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int64), ('lr', C.c_float),
-                ('step', C.c_int32), ('row_index', _fp), ('row_len', C.c_int32), ('zero_grad', C.c_int32)]
+                ('step', C.c_int32), ('row_index', _fp), ('row_len', C.c_int32), ('zero_grad', C.c_int32), ('p_f16', C.c_int32)]
 
 
 class CopySeg(C.Structure):

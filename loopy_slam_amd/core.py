@@ -234,6 +234,9 @@ def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_f
         flags |= _ffi.FLAG_COLOR_LOGITS
     if save_act:
         flags |= _ffi.FLAG_SAVE_ACT
+    if geo_feats.dtype == torch.float16:             # opt-in half feature tables: both tables have the same format
+        assert col_feats is None or col_feats.dtype == torch.float16
+        flags |= _ffi.FLAG_FEATS_F16
     if z_given is not None:          # [R,S] sample depths for the rays without a depth reading (rows of the others are ignored)
         st.z.copy_(z_given.reshape(st.z.shape))
         flags |= _ffi.FLAG_Z_GIVEN

@@ -213,7 +213,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
         LkRelposArgs ra;
         ra.R = d->R; ra.S = d->S; ra.P = P; ra.min_nn = d->min_nn;
         ra.rays_o = d->rays_o; ra.rays_d = d->rays_d; ra.z = d->z;
-        ra.pos = d->pos; ra.col_feats = d->col_feats;
+        ra.pos = d->pos; ra.col_feats = d->col_feats; ra.feats_f16 = (d->flags & LK_FLAG_FEATS_F16) ? 1 : 0;
         ra.nbr_idx = d->nbr_idx; ra.nbr_w = d->nbr_w; ra.nbr_count = d->nbr_count;
         ra.W = d->weights; ra.Wfrag = d->weights_frag; ra.noise_col = d->noise_col; ra.c_col = d->c_col;
         lk_launch_relpos_fwd(ra, st);

@@ -39,10 +39,10 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
     for (int j = 0; j < LK_K; ++j) {
         float part = 0.0f;
         if (has && w[j] != 0.0f) {
-            const float4 g = *reinterpret_cast<const float4*>(a.geo_feats + (size_t)id[j] * LK_C + sub * 4);
+            const float4 g = lk_feat4(a.geo_feats, (a.flags & LK_FLAG_FEATS_F16) != 0, (size_t)id[j] * LK_C + sub * 4);
             part = dcg.x * g.x + dcg.y * g.y + dcg.z * g.z + dcg.w * g.w;
             if (do_col) {
-                const float4 c = *reinterpret_cast<const float4*>(a.col_feats + (size_t)id[j] * LK_C + sub * 4);
+                const float4 c = lk_feat4(a.col_feats, (a.flags & LK_FLAG_FEATS_F16) != 0, (size_t)id[j] * LK_C + sub * 4);
                 part += dcc.x * c.x + dcc.y * c.y + dcc.z * c.z + dcc.w * c.w;
             }
         }
@@ -221,6 +221,7 @@ __device__ __forceinline__ float rp_embed_unit(const float* __restrict__ B, int 
     return (u < 10) ? lk_sinf(x) : lk_cosf(x);
 }
 
+template <bool F16>          // F16: half feature tables (LK_FLAG_FEATS_F16) - a template, the kernel has no register to spare for a branch
 __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sample0, float* __restrict__ part) {
     const int lane = lk_lane();
     const int h = lane >> 5;
@@ -243,7 +244,8 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
     const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
-    const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
+    const size_t frow = (size_t)idx * LK_C;
+    constexpr bool f16 = F16;
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     // ---- recompute the forward of this tile
@@ -255,7 +257,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
 #pragma unroll
             for (int t = 0; t < 4; ++t) x0[4 * g + t] = rp_embed_unit(W + R_EB, u0 + t, a0, a1, a2);
         } else {
-            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            const float4 v = lk_feat4(a.col_feats, f16, frow + (u0 - ER));
             x0[4 * g] = v.x; x0[4 * g + 1] = v.y; x0[4 * g + 2] = v.z; x0[4 * g + 3] = v.w;
         }
     }
@@ -264,7 +266,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     for (int g = 0; g < 3; ++g) {
         const int u0 = 32 + 8 * g + 4 * h;
         if (u0 < KR) {
-            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            const float4 v = lk_feat4(a.col_feats, f16, frow + (u0 - ER));
             x1[4 * g] = v.x; x1[4 * g + 1] = v.y; x1[4 * g + 2] = v.z; x1[4 * g + 3] = v.w;
         }
     }
@@ -435,6 +437,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void k_relpos_bwd(LkRelposBwdArgs a) {
     __shared__ float s_part[4][32];
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd(LkRelposBwdArgs a) {
         __syncthreads();
     }
     const int sample0 = (blockIdx.x * 4 + w) * 4;
-    if (sample0 < a.P) relpos_bwd_wave(a, sample0, s_part[w]);
+    if (sample0 < a.P) relpos_bwd_wave<F16>(a, sample0, s_part[w]);
     if (want_w) {
         __syncthreads();
         if (threadIdx.x < 32)
@@ -540,7 +543,8 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
     const u32x4* __restrict__ FH = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;
-    const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
+    const size_t frow = (size_t)idx * LK_C;
+    const bool f16 = (a.flags & LK_FLAG_FEATS_F16) != 0;
     uint16_t* __restrict__ stage = stage_wg + w * RPF_STAGE_HALVES;
     uint16_t* __restrict__ xt_hi = stage;
     uint16_t* __restrict__ xt_lo = stage + RPF_XU * 32;
@@ -556,7 +560,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
 #pragma unroll
             for (int t = 0; t < 4; ++t) x0[4 * g + t] = rp_embed_unit(W + R_EB, u0 + t, a0, a1, a2);
         } else {
-            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            const float4 v = lk_feat4(a.col_feats, f16, frow + (u0 - ER));
             x0[4 * g] = v.x; x0[4 * g + 1] = v.y; x0[4 * g + 2] = v.z; x0[4 * g + 3] = v.w;
         }
     }
@@ -565,7 +569,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
     for (int g = 0; g < 3; ++g) {
         const int u0 = 32 + 8 * g + 4 * h;
         if (u0 < KR) {
-            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            const float4 v = lk_feat4(a.col_feats, f16, frow + (u0 - ER));
             x1[4 * g] = v.x; x1[4 * g + 1] = v.y; x1[4 * g + 2] = v.z; x1[4 * g + 3] = v.w;
         }
     }
@@ -1154,7 +1158,8 @@ int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_RELPOS_BWD, st);
     const int waves = lk_cdiv(a.P, 4);
     if (lk_relpos_fused(a.flags)) hipLaunchKernelGGL(k_relpos_bwd_fused, dim3(lk_relpos_bwd_parts(a.P)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_relpos_bwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    else if (a.flags & LK_FLAG_FEATS_F16) hipLaunchKernelGGL(k_relpos_bwd<true>, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_relpos_bwd<false>, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_dw2_parts(int P) { const int n = lk_cdiv(P, LK_DW2_SAMPLES); return n < 1 ? 1 : (n < LK_DW2_PARTS ? n : LK_DW2_PARTS); }

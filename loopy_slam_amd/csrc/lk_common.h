@@ -146,6 +146,15 @@ __device__ __forceinline__ float lk_cosf(float x) {
 // fragment blocks are then formed where they are used instead of being hoisted out of the loop and spilled.
 __device__ __forceinline__ int lk_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+// Four consecutive channels of a feature row, element index e (a multiple of 4) into the table: fp32 tables, or - opt-in,
+// LK_FLAG_FEATS_F16 - IEEE half tables (8 bytes, exact conversion).  `f16` is uniform over the launch.
+__device__ __forceinline__ float4 lk_feat4(const float* __restrict__ table, bool f16, size_t e) {
+    if (!f16) return *reinterpret_cast<const float4*>(table + e);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(table) + e);
+    const lk_f16x2 a = __builtin_bit_cast(lk_f16x2, u.x), b = __builtin_bit_cast(lk_f16x2, u.y);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+
 // C/D-fragment bookkeeping of v_mfma_f32_32x32x2_f32: lane l, register r holds
 // row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 __device__ __forceinline__ int lk_frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

@@ -380,7 +380,8 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
     const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;      // fp16 forward fragments
-    const float* __restrict__ frow = a.col_feats + (size_t)idx * LK_C;
+    const size_t frow = (size_t)idx * LK_C;
+    const bool f16 = a.feats_f16 != 0;
     // X^T tiles: units 0..19 embedding, 20..51 feature channels 0..31, 52..55 zero
     f32x16 x0, x1;
 #pragma unroll
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) x0[4 * g + t] = sincos_embed_unit(W + R_EB, 10, u0 + t, a0, a1, a2);
         } else {
-            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            const float4 v = lk_feat4(a.col_feats, f16, frow + (u0 - ER));
             x0[4 * g] = v.x; x0[4 * g + 1] = v.y; x0[4 * g + 2] = v.z; x0[4 * g + 3] = v.w;
         }
     }
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     for (int g = 0; g < 3; ++g) {
         const int u0 = 32 + 8 * g + 4 * h;
         if (u0 < KR) {
-            const float4 v = *reinterpret_cast<const float4*>(frow + (u0 - ER));
+            const float4 v = lk_feat4(a.col_feats, f16, frow + (u0 - ER));
             x1[4 * g] = v.x; x1[4 * g + 1] = v.y; x1[4 * g + 2] = v.z; x1[4 * g + 3] = v.w;
         }
     }

@@ -60,6 +60,7 @@ struct LkRelposArgs {
     const int32_t* nbr_idx; const float* nbr_w; const int32_t* nbr_count;
     const float* W; const float* Wfrag; const float* noise_col;
     float* c_col;                                 // [P,32]
+    int feats_f16;                                // LK_FLAG_FEATS_F16
 };
 
 struct LkCompositeBwdArgs {

@@ -239,7 +239,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
                "lk_track_frame: the render descriptor needs d_depth/d_color, bwd_scratch and act");
     hipStream_t st = (hipStream_t)stream_;
     lk_render_desc rd = d->render;
-    rd.flags = (d->render.flags & LK_FLAG_REL_POS) | LK_FLAG_STAGE_COLOR | LK_FLAG_TRACKER | LK_FLAG_SAVE_ACT | LK_FLAG_GRAD_RAYS | LK_FLAG_ZERO_ABSENT;
+    rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_FEATS_F16)) | LK_FLAG_STAGE_COLOR | LK_FLAG_TRACKER | LK_FLAG_SAVE_ACT | LK_FLAG_GRAD_RAYS | LK_FLAG_ZERO_ABSENT;
     rd.stats_chunk = rd.R > 0 ? rd.R : 1;
     rd.g_geo_feats = nullptr; rd.g_col_feats = nullptr; rd.g_weights = nullptr;
     const int R = rd.R, S = rd.S, iters = d->iters;
@@ -401,7 +401,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     for (int it = it_begin; it < it_end; ++it) {
         const bool color = it >= d->n_geo_iters;
         lk_render_desc rd = d->render;
-        rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_UNIT_LOSS_GRADS)) | (color ? LK_FLAG_STAGE_COLOR : 0) | LK_FLAG_SAVE_ACT |
+        rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_UNIT_LOSS_GRADS | LK_FLAG_FEATS_F16)) | (color ? LK_FLAG_STAGE_COLOR : 0) | LK_FLAG_SAVE_ACT |
                    LK_FLAG_GRAD_FEATS | LK_FLAG_GRAD_WEIGHTS | LK_FLAG_ZERO_ABSENT | LK_FLAG_MAPPER_LOSS;
         rd.stats_chunk = R;
         rd.loss_gt_color = d->gt_color; rd.loss_w_color = d->w_color; rd.loss_out4 = d->log + (size_t)it * 4;
@@ -451,12 +451,13 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             {
                 lk_adam_seg& s = seg[ns++];
                 s.p = d->geo_feats_rw; s.g = rd.g_geo_feats; s.m = d->adam_rows; s.v = d->adam_rows + nrow; s.n = nrow; s.lr = lr[1]; s.step = it + 1;
-                s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1;
+                s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1; s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
             }
             if (color) {
                 lk_adam_seg& s = seg[ns++];
                 s.p = d->col_feats_rw; s.g = rd.g_col_feats; s.m = d->adam_rows + 2 * nrow; s.v = d->adam_rows + 3 * nrow; s.n = nrow; s.lr = lr[2];
                 s.step = it - d->n_geo_iters + 1; s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1;
+                s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
             }
             int rc = lk_adam_step(seg, ns, beta1, beta2, eps, st);
             if (rc != LK_OK) return rc;

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(1024) void k_loss_tracker_1wg(int R, const float* _
 // ------------------------------------------------------------------ Adam
 struct AdamSegDev {
     float* p; float* g; float* m; float* v; long long n; float step_size, bc2_sqrt;
-    const int32_t* row_index; int row_len; int zero_grad;
+    const int32_t* row_index; int row_len; int zero_grad; int p_f16;
 };
 struct AdamArgs { AdamSegDev s[LK_ADAM_MAX_SEG]; int n_seg; float beta1, beta2, eps; };
 
@@ -243,7 +243,12 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
         const float denom = sqrtf(v) / S.bc2_sqrt + a.eps;  // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
         S.m[i] = m;
         S.v[i] = v;
-        S.p[e] = S.p[e] - S.step_size * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-lr/bias_correction1)
+        if (S.p_f16) {                                      // half table: fp32 step, stored rounded to nearest
+            _Float16* ph = reinterpret_cast<_Float16*>(S.p) + e;
+            *ph = (_Float16)((float)*ph - S.step_size * (m / denom));
+        } else {
+            S.p[e] = S.p[e] - S.step_size * (m / denom);    // param.addcdiv_(exp_avg, denom, value=-lr/bias_correction1)
+        }
         if (S.zero_grad) S.g[e] = 0.0f;
     }
 }
@@ -620,6 +625,7 @@ extern "C" int lk_adam_step(const lk_adam_seg* segs, int32_t n_seg, float beta1,
         a.s[i].p = segs[i].p; a.s[i].g = segs[i].g; a.s[i].m = segs[i].m; a.s[i].v = segs[i].v; a.s[i].n = segs[i].n;
         a.s[i].row_index = segs[i].row_index; a.s[i].row_len = segs[i].row_len > 0 ? segs[i].row_len : 1;
         a.s[i].zero_grad = segs[i].zero_grad;
+        a.s[i].p_f16 = segs[i].p_f16;
         a.s[i].step_size = (float)((double)segs[i].lr / bc1);
         a.s[i].bc2_sqrt = (float)sqrt(bc2);
         if (segs[i].n > nmax) nmax = segs[i].n;

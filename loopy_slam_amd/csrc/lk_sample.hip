@@ -123,17 +123,18 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     const bool lane_geo = (T == 8) || sub < 8;
     const bool lane_col = do_col && ((T == 8) || sub >= 8);
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ac = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool f16 = (a.flags & LK_FLAG_FEATS_F16) != 0;
     if (count >= a.min_nn) {
 #pragma unroll
         for (int j = 0; j < LK_K; ++j) {
             if (w[j] != 0.0f) {
                 const float wj = w[j];
                 if (lane_geo) {
-                    const float4 g = *reinterpret_cast<const float4*>(a.geo_feats + (size_t)id[j] * LK_C + f4 * 4);
+                    const float4 g = lk_feat4(a.geo_feats, f16, (size_t)id[j] * LK_C + f4 * 4);
                     ag.x = fmaf(wj, g.x, ag.x); ag.y = fmaf(wj, g.y, ag.y); ag.z = fmaf(wj, g.z, ag.z); ag.w = fmaf(wj, g.w, ag.w);
                 }
                 if (lane_col) {
-                    const float4 c = *reinterpret_cast<const float4*>(a.col_feats + (size_t)id[j] * LK_C + f4 * 4);
+                    const float4 c = lk_feat4(a.col_feats, f16, (size_t)id[j] * LK_C + f4 * 4);
                     ac.x = fmaf(wj, c.x, ac.x); ac.y = fmaf(wj, c.y, ac.y); ac.z = fmaf(wj, c.z, ac.z); ac.w = fmaf(wj, c.w, ac.w);
                 }
             }

@@ -55,6 +55,7 @@ class Adam:
             arr[k].n, arr[k].lr, arr[k].step = n, lr, st['step']
             arr[k].row_index, arr[k].row_len = ptr(rows), (p.shape[1] if rows is not None else 1)
             arr[k].zero_grad = int(bool(zero_grad))
+            arr[k].p_f16 = int(p.dtype == torch.float16)
             keep.append((p, g, rows))
         self.eng.lib.check(self.eng.lib.dll.lk_adam_step(arr, len(segs), C.c_float(self.beta1), C.c_float(self.beta2),
                                                          C.c_float(self.eps), self.eng.stream), 'lk_adam_step')

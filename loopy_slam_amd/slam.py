@@ -178,6 +178,10 @@ class NeuralPointCloud:
         self.radius_mesh = pc.get('radius_mesh', pc['radius_query'])
         self.near_end_surface, self.far_end_surface = pc['near_end_surface'], pc['far_end_surface']
         self.use_dynamic_radius = cfg['use_dynamic_radius']
+        # storage format of the two feature tables: 'float32' (the reference), or opt-in 'float16' (BASELINE config 5: half the bytes
+        # of a whole-map optimisation; every value computed from the tables and every gradient stays fp32, Adam steps in fp32 and
+        # rounds the stored value to nearest - LK_FLAG_FEATS_F16)
+        self.feat_dtype = {'float32': torch.float32, 'float16': torch.float16}[pc.get('feature_dtype', 'float32')]
         self._cell = max(pc['radius_query'], 1e-3)
         # feature initialisation draws on the device (Philox): no host RNG + upload per insertion
         self._gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219))
@@ -188,7 +192,8 @@ class NeuralPointCloud:
     def _alloc(self, cap):
         e = self.eng
         self.capacity = int(cap)
-        self._pos, self._geo, self._col = e.zeros(cap, 3), e.zeros(cap, 32), e.zeros(cap, 32)
+        self._pos = e.zeros(cap, 3)
+        self._geo, self._col = e.zeros(cap, 32, dtype=self.feat_dtype), e.zeros(cap, 32, dtype=self.feat_dtype)
         self.knn = core.KnnIndex(e, self.capacity, cell_size=self._cell)
 
     def _grow(self, need):
@@ -219,15 +224,15 @@ class NeuralPointCloud:
 
     def update_geo_feats(self, feats, indices=None, end=False):
         if indices is not None:
-            self._geo[:self.n][torch.as_tensor(indices, device=self.eng.device).long()] = feats.detach()
+            self._geo[:self.n][torch.as_tensor(indices, device=self.eng.device).long()] = feats.detach().to(self.feat_dtype)
         elif feats.data_ptr() != self._geo.data_ptr():
-            self._geo[:self.n] = feats.detach()
+            self._geo[:self.n] = feats.detach().to(self.feat_dtype)
 
     def update_col_feats(self, feats, indices=None, end=False):
         if indices is not None:
-            self._col[:self.n][torch.as_tensor(indices, device=self.eng.device).long()] = feats.detach()
+            self._col[:self.n][torch.as_tensor(indices, device=self.eng.device).long()] = feats.detach().to(self.feat_dtype)
         elif feats.data_ptr() != self._col.data_ptr():
-            self._col[:self.n] = feats.detach()
+            self._col[:self.n] = feats.detach().to(self.feat_dtype)
 
     def pts_num(self):
         return self.n
@@ -299,8 +304,8 @@ class NeuralPointCloud:
             self._grow(self.n + k)
             self._pos[self.n:self.n + k] = pts
             # neural_point.py:1608-1614: normal(0, 0.1) features for the new points
-            self._geo[self.n:self.n + k] = torch.randn(k, 32, generator=self._gen, device=self.eng.device) * 0.1
-            self._col[self.n:self.n + k] = torch.randn(k, 32, generator=self._gen, device=self.eng.device) * 0.1
+            self._geo[self.n:self.n + k] = (torch.randn(k, 32, generator=self._gen, device=self.eng.device) * 0.1).to(self.feat_dtype)
+            self._col[self.n:self.n + k] = (torch.randn(k, 32, generator=self._gen, device=self.eng.device) * 0.1).to(self.feat_dtype)
             self.n += k
             self.knn.build(self._pos[:self.n])             # counting-sort rebuild on the device (no IVF re-training)
         return n_acc
@@ -323,6 +328,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.needs = (rays_o.requires_grad or rays_d.requires_grad, geo_feats.requires_grad or col_feats.requires_grad,
                      blob.requires_grad, affine is not None and affine.requires_grad)
         ctx.N = geo_feats.shape[0]
+        ctx.feat_dtype = geo_feats.dtype
         ctx.mark_non_differentiable(st.valid_ray)
         return st.depth, st.var, st.color, st.valid_ray
 
@@ -334,7 +340,8 @@ class _RenderFn(torch.autograd.Function):
         gs = core.GradState(eng, ctx.N, R, dec.n, feats=feats, weights=weights, rays=rays, affine=aff)
         z = lambda t, *s: eng.zeros(*s) if t is None else t.contiguous()
         core.render_backward(eng, ctx.st, gs, z(g_depth, R), z(g_color, R, 3), z(g_var, R))
-        return (gs.g_rays_o, gs.g_rays_d, gs.g_geo, gs.g_col, gs.g_weights, gs.g_affine, None)
+        cast = (lambda t: t) if ctx.feat_dtype == torch.float32 else (lambda t: None if t is None else t.to(ctx.feat_dtype))   # half tables
+        return (gs.g_rays_o, gs.g_rays_d, cast(gs.g_geo), cast(gs.g_col), gs.g_weights, gs.g_affine, None)
 
 
 class Renderer:
@@ -892,8 +899,8 @@ class Logger:
             'exposure_feat_all': torch.stack([cpu(e) for e in exposure_feat], dim=0) if exposure_feat is not None else None,
         }
         if last_log:
-            ck['geo_feats'] = cpu(npc.get_geo_feats(end=True))
-            ck['col_feats'] = cpu(npc.get_col_feats(end=True))
+            ck['geo_feats'] = cpu(npc.get_geo_feats(end=True)).float()         # the reference's tools read fp32 tables whatever the storage format
+            ck['col_feats'] = cpu(npc.get_col_feats(end=True)).float()
         # the colour embedding matrix is not part of the reference's state_dict (decoder.py:32); keep it beside it
         ck['color_embedder_B'] = cpu(self.decoders.color_embedder_B()) if hasattr(self.decoders, 'color_embedder_B') else None
         torch.save(ck, path, _use_new_zipfile_serialization=False)
@@ -909,8 +916,8 @@ class Logger:
         npc._grow(n)
         npc._pos[:n] = pos.to(eng.device)
         if 'geo_feats' in ck:
-            npc._geo[:n] = ck['geo_feats'].to(eng.device)
-            npc._col[:n] = ck['col_feats'].to(eng.device)
+            npc._geo[:n] = ck['geo_feats'].to(eng.device).to(npc.feat_dtype)
+            npc._col[:n] = ck['col_feats'].to(eng.device).to(npc.feat_dtype)
         npc.n = n
         if n:
             npc.knn.build(npc._pos[:n])

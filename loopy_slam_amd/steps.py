@@ -220,6 +220,8 @@ class MapOptimizer:
         C.memmove(C.byref(d.render), C.byref(st.desc), C.sizeof(_ffi.RenderDesc))
         r = d.render
         r.flags = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | _ffi.FLAG_UNIT_LOSS_GRADS      # L1 sums: |d depth|, |d colour| <= 1
+        if self.geo.dtype == torch.float16:
+            r.flags |= _ffi.FLAG_FEATS_F16
         r.d_depth, r.d_color = ptr(b.d_depth), ptr(b.d_color)
         r.g_geo_feats, r.g_col_feats, r.g_weights = ptr(gs.g_geo), ptr(gs.g_col), ptr(gs.g_weights)
         r.grad_row_mask, r.bwd_scratch, r.bwd_scratch_cap = ptr(gs.row_mask), ptr(gs.scratch), gs.scratch.numel()
@@ -398,7 +400,7 @@ class TrackOptimizer:
         C = _ffi.C
         C.memmove(C.byref(d.render), C.byref(st.desc), C.sizeof(_ffi.RenderDesc))
         r = d.render
-        r.flags = _ffi.FLAG_REL_POS if self.cfg.rel_pos else 0
+        r.flags = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | (_ffi.FLAG_FEATS_F16 if self.geo.dtype == torch.float16 else 0)
         r.d_depth, r.d_color = ptr(b.d_depth), ptr(b.d_color)
         r.g_rays_o, r.g_rays_d, r.bwd_scratch, r.bwd_scratch_cap = ptr(gs.g_rays_o), ptr(gs.g_rays_d), ptr(gs.scratch), gs.scratch.numel()
         d.depth_img, d.color_img, d.r2_map = ptr(depth_img), ptr(color_img), ptr(r2_map)

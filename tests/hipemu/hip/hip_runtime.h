@@ -49,6 +49,7 @@ struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
+struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
