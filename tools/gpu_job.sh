@@ -1,12 +1,10 @@
 #!/bin/bash
+# scratch GPU job (gpurun -- 'bash tools/gpu_job.sh'): full GPU test suite, smoke, then the bench line
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25 > gpurun_out/gpu_tests.log
-tail -2 gpurun_out/gpu_tests.log
-for k in 1 2 3; do
-python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print('overlap %.2f ms/step' % d['ms_per_step'], {k[2:]: round(v, 2) for k, v in d['kernel_ms_per_step'].items()})"
-done
-for m in geo color track; do python tools/mode_trace.py $m 40 --repeat 3 2>&1 | tail -1; done
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/gpu_tests.log
+tail -3 gpurun_out/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/bench_r2.json 2> gpurun_out/bench_r2.err
+tail -c 700 gpurun_out/bench_r2.json
