@@ -82,6 +82,13 @@ def run(cfg, frames, eng=None, sync=None):
     steady = per_frame[w0:]
     tracked = [per_frame[i] for i in range(w0, len(per_frame)) if i % every != 0 and i != len(per_frame) - 1]
     mapped = [per_frame[i] for i in range(w0, len(per_frame)) if i % every == 0 or i == len(per_frame) - 1]
+    # the last frame carries the final whole-map refinement when mapping.color_refine is on (Mapper.py:884-897, ten times the
+    # iterations), the first mapped frames follow the reference's rule iterations ~ points added (Mapper.py:572-574: up to 2x while
+    # the map is still growing): the steady figures leave both out
+    refine = bool(cfg['mapping'].get('color_refine', False))
+    s0 = 3 * every
+    body = per_frame[s0:len(per_frame) - (1 if refine else 0)]
+    mapped_steady = [per_frame[i] for i in range(s0, len(per_frame) - (1 if refine else 0)) if i % every == 0]
     rmse, worst = ate_rmse(est, gt)
     l1 = []
     for i in sorted({0, frames // 2, frames - 1}):
@@ -95,6 +102,9 @@ def run(cfg, frames, eng=None, sync=None):
         'frames_per_s': round(len(steady) / float(steady.sum()), 3),
         'ms_tracked_frame': round(1e3 * float(np.mean(tracked)), 2) if tracked else None,
         'ms_mapped_frame': round(1e3 * float(np.mean(mapped)), 2) if mapped else None,
+        'steady_frames_per_s': round(len(body) / float(body.sum()), 3) if len(body) else None,
+        'ms_mapped_frame_steady': round(1e3 * float(np.mean(mapped_steady)), 2) if mapped_steady else None,
+        'ms_final_refinement': round(1e3 * float(per_frame[-1]), 1) if refine else None,
         's_first_frame': round(float(per_frame[0]), 2), 's_warmup_frames': round(float(per_frame[1:w0].sum()), 2),
         'ate_rmse_cm': round(100 * rmse, 3), 'max_translation_error_cm': round(100 * worst, 3),
         'depth_l1_cm': [round(x, 3) for x in l1],
