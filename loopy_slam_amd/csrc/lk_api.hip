@@ -196,7 +196,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
     }
     LkSampleArgs sa;
     fill_sample_args(d, P, all_pos, sa);
-    const bool presort = (skip & LK_FUSE_COMPOSITE_BWD) && (d->flags & LK_FLAG_GRAD_FEATS) && d->bwd_scratch;
+    const bool presort = (skip & LK_FUSE_COMPOSITE_BWD) && (d->flags & LK_FLAG_GRAD_FEATS) && d->bwd_scratch && !(skip & LK_SEG_SORTED);
     if (presort) {       // the backward of this forward follows (lk_map_frame): its rows are counted per point by the sampler ...
         LkFeatScatterArgs fs;
         seg_args(d, P, fs);
@@ -430,7 +430,8 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     if (gf) {
         fs.dc_geo = S0 + L.dc_geo; fs.dc_col = (color && !relpos) ? S0 + L.dc_col : nullptr; fs.dfeat = relpos ? S0 + L.dfeat : nullptr;
         fs.g_geo_feats = d->g_geo_feats; fs.g_col_feats = d->g_col_feats;
-        if (ss.ok) (void)hipStreamWaitEvent(st, ss.link, 0);
+        if (ex && ex->seg_list) { fs.seg_list = ex->seg_list; fs.seg_total = ex->seg_total; }      // sorted ahead of the loop (lk_map_frame)
+        else if (ss.ok) (void)hipStreamWaitEvent(st, ss.link, 0);
         lk_launch_feat_scatter(fs, st);
     }
     if (gr) {

@@ -157,13 +157,14 @@ __global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
     if (row >= (long long)a.P * LK_K) return;
     const int rk = a.seg_rank[row];
     if (rk >= 0) a.seg_list[a.seg_off[a.nbr_idx[row]] + rk] = (int)row;
+    if (row == 0 && a.seg_total) *a.seg_total = a.seg_off[a.N];
 }
 
 #define LK_GATHER_CHUNK 16
 __global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
     const int c = (int)threadIdx.x & 31;
     const long long i0 = ((long long)blockIdx.x * 8 + ((int)threadIdx.x >> 5)) * LK_GATHER_CHUNK;
-    const int total = a.seg_off[a.N];
+    const int total = a.seg_total ? *a.seg_total : a.seg_off[a.N];
     if (i0 >= total) return;
     const int n = min(LK_GATHER_CHUNK, (int)(total - i0));
     const bool col = a.dfeat != nullptr || a.dc_col != nullptr;

@@ -114,7 +114,8 @@ struct LkInterpBwdArgs {
 // Extras of the fused tracking loop for lk_render_bwd_impl: with pose_part the interpolation backward also reduces, per
 // workgroup of 32 samples, G[c][k] = sum d p_c z dir_k (9) and T[c] = sum d p_c (3) - what k_pose_bwd sums over the rays -
 // into pose_part[block][12]; lk_bwd_pose_parts(P) blocks.
-struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy; };
+struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
+                    int32_t* seg_list; int32_t* seg_total; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
@@ -129,6 +130,7 @@ struct LkFeatScatterArgs {
     int32_t* seg_sums;                             // scan scratch (lk_knn_s::seg_sums)
     int32_t* seg_rank;                             // [8P] rank of the row among the rows of its point, -1 = row takes no part
     int32_t* seg_list;                             // [8P] rows ordered by point
+    int32_t* seg_total;                            // [1] number of rows in seg_list, written by k_seg_place (NULL: seg_off[N])
     int N;
 };
 int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st);        // counted: k_sample_interp already ran the count pass

@@ -201,7 +201,7 @@ TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     w.total = o;
     return w;
 }
-struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, z, nbr_idx, nbr_w, nbr_count, total; };
+struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, total; };
 MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     MapWork w;
     int64_t o = 0;
@@ -217,6 +217,10 @@ MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     w.nbr_idx = o; o += al4(iters * P * LK_K);
     w.nbr_w = o; o += al4(iters * P * LK_K);
     w.nbr_count = o; o += al4(iters * P);
+    // the rows of every iteration sorted by point (feature-gradient gather), also ahead of the loop: [iters][8P] + [iters] + scratch [8P]
+    w.seg_list = o; o += al4(iters * P * LK_K);
+    w.seg_total = o; o += al4(iters);
+    w.seg_rank = o; o += al4(P * LK_K);
     w.total = o;
     return w;
 }
@@ -379,24 +383,47 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         pa.rays_o = W0 + wk.rays_o; pa.rays_d = W0 + wk.rays_d; pa.gt_depth = W0 + wk.gt_depth; pa.gt_color = W0 + wk.gt_color;
         pa.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray : nullptr; pa.thr = W0 + wk.thr; pa.zero4 = d->log;
         hipLaunchKernelGGL(k_pregather, dim3(d->iters), dim3(1024), 0, st, pa);
-        // neighbour search of every iteration, a few iterations per launch, ahead of the loop on the low-priority third stream
+    }
+    // Ahead of the loop, on the low-priority third stream, a few iterations per chunk: the neighbour search (one launch per chunk) and,
+    // per iteration, the counting sort of its rows by point for the feature-gradient gather (count, scan, place: lk_bwd2.hip) - both read
+    // the rays, the positions and the row mask only.  Chunk c + 1 is enqueued when the loop reaches chunk c.
+    const bool sort_ahead = pre && d->render.g_geo_feats != nullptr;
+    auto enqueue_chunk = [&](int c) -> int {
+        const int c0 = c * pre_chunk;
+        if (c0 >= d->iters) return LK_OK;
         PreStream& ps = pre_stream();
         hipStream_t pst = ps.ok ? ps.st : st;
-        if (ps.ok) { (void)hipEventRecord(ps.e0, st); (void)hipStreamWaitEvent(pst, ps.e0, 0); }
-        for (int c0 = 0, c = 0; c0 < d->iters; c0 += pre_chunk, ++c) {
-            const int nc = d->iters - c0 < pre_chunk ? d->iters - c0 : pre_chunk;
-            lk_render_desc sd = d->render;
-            sd.flags = (d->render.flags & LK_FLAG_REL_POS) | LK_FLAG_ZERO_ABSENT;
-            sd.R = nc * R; sd.stats_chunk = sd.R;
-            sd.rays_o = W0 + wk.rays_o + (size_t)c0 * R * 3; sd.rays_d = W0 + wk.rays_d + (size_t)c0 * R * 3;
-            sd.gt_depth = W0 + wk.gt_depth + (size_t)c0 * R;
-            sd.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray + (size_t)c0 * R : nullptr;
-            sd.z = W0 + wk.z + (size_t)c0 * Pn; sd.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)c0 * Pn;
-            sd.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)c0 * Pn * LK_K; sd.nbr_w = W0 + wk.nbr_w + (size_t)c0 * Pn * LK_K;
-            const int rc = lk_presample(&sd, pst);
+        if (ps.ok && c == 0) { (void)hipEventRecord(ps.e0, st); (void)hipStreamWaitEvent(pst, ps.e0, 0); }     // after k_pregather
+        const int nc = d->iters - c0 < pre_chunk ? d->iters - c0 : pre_chunk;
+        lk_render_desc sd = d->render;
+        sd.flags = (d->render.flags & LK_FLAG_REL_POS) | LK_FLAG_ZERO_ABSENT;
+        sd.R = nc * R; sd.stats_chunk = sd.R;
+        sd.rays_o = W0 + wk.rays_o + (size_t)c0 * R * 3; sd.rays_d = W0 + wk.rays_d + (size_t)c0 * R * 3;
+        sd.gt_depth = W0 + wk.gt_depth + (size_t)c0 * R;
+        sd.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray + (size_t)c0 * R : nullptr;
+        sd.z = W0 + wk.z + (size_t)c0 * Pn; sd.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)c0 * Pn;
+        sd.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)c0 * Pn * LK_K; sd.nbr_w = W0 + wk.nbr_w + (size_t)c0 * Pn * LK_K;
+        int rc = lk_presample(&sd, pst);
+        if (rc != LK_OK) return rc;
+        for (int it = c0; sort_ahead && it < c0 + nc; ++it) {
+            LkFeatScatterArgs fs;
+            memset(&fs, 0, sizeof(fs));
+            fs.P = (int)Pn; fs.min_nn = d->render.min_nn; fs.row_mask = d->render.grad_row_mask; fs.N = (int)d->render.knn->n;
+            fs.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)it * Pn * LK_K; fs.nbr_w = W0 + wk.nbr_w + (size_t)it * Pn * LK_K;
+            fs.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)it * Pn;
+            fs.seg_cnt = d->render.knn->seg_cnt; fs.seg_off = d->render.knn->seg_off; fs.seg_sums = d->render.knn->seg_sums;
+            fs.seg_rank = reinterpret_cast<int32_t*>(W0 + wk.seg_rank);
+            fs.seg_list = reinterpret_cast<int32_t*>(W0 + wk.seg_list) + (size_t)it * Pn * LK_K;
+            fs.seg_total = reinterpret_cast<int32_t*>(W0 + wk.seg_total) + it;
+            rc = lk_launch_seg_sort(fs, false, pst);
             if (rc != LK_OK) return rc;
-            if (ps.ok) (void)hipEventRecord(ps.ev[c], pst);
         }
+        if (ps.ok) (void)hipEventRecord(ps.ev[c % LK_PRE_CHUNKS], pst);
+        return LK_OK;
+    };
+    if (pre && it_begin == 0 && (phases & 1)) {
+        const int rc = enqueue_chunk(0);
+        if (rc != LK_OK) return rc;
     }
     for (int it = it_begin; it < it_end; ++it) {
         const bool color = it >= d->n_geo_iters;
@@ -411,9 +438,13 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             if (rd.r2_ray) rd.r2_ray = W0 + wk.r2_ray + (size_t)it * R;
             rd.z = W0 + wk.z + (size_t)it * Pn; rd.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)it * Pn;
             rd.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)it * Pn * LK_K; rd.nbr_w = W0 + wk.nbr_w + (size_t)it * Pn * LK_K;
+            if ((phases & 1) && it % pre_chunk == 0) {       // entering chunk c: enqueue chunk c + 1, then wait for chunk c
+                const int rc = enqueue_chunk(it / pre_chunk + 1);
+                if (rc != LK_OK) return rc;
+            }
             if ((phases & 1) && (it % pre_chunk == 0 || it == it_begin)) {
                 PreStream& ps = pre_stream();
-                if (ps.ok) (void)hipStreamWaitEvent(st, ps.ev[it / pre_chunk], 0);
+                if (ps.ok) (void)hipStreamWaitEvent(st, ps.ev[(it / pre_chunk) % LK_PRE_CHUNKS], 0);
             }
         }
         if (phases & 1) {
@@ -428,9 +459,15 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 if (rc != LK_OK) return rc;
             }
             // the loss gradient is final when the composite kernel has written it: its backward rides in the same launch
-            rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0));
+            rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0));
             if (rc != LK_OK) return rc;
-            rc = lk_render_bwd_impl(&rd, st, LK_SKIP_COMPOSITE_BWD | LK_SEG_SORTED);
+            LkBwdExtra ex;
+            memset(&ex, 0, sizeof(ex));
+            if (sort_ahead) {
+                ex.seg_list = reinterpret_cast<int32_t*>(W0 + wk.seg_list) + (size_t)it * Pn * LK_K;
+                ex.seg_total = reinterpret_cast<int32_t*>(W0 + wk.seg_total) + it;
+            }
+            rc = lk_render_bwd_impl(&rd, st, LK_SKIP_COMPOSITE_BWD | LK_SEG_SORTED, sort_ahead ? &ex : nullptr);
             if (rc != LK_OK) return rc;
         }
         if (phases & 2) {
