@@ -160,7 +160,9 @@ class MapOptimizer:
         fused = None if xs is not None else (b.gt_color, self.w_color, b.d_depth, b.d_color, out4)
         core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
                             self.dec, stage, r2_ray=b.r2_ray, save_act=True,
-                            extra_flags=_ffi.FLAG_ZERO_ABSENT | _ffi.FLAG_UNIT_LOSS_GRADS,      # L1 sums: |d depth|, |d colour| <= 1
+                            # L1 sums: |d depth| = 1, |d colour| = w - unit scale, the backward may use fp16 pieces.  NOT with exposure
+                            # encoding: there d logits = w sigma' A with a LEARNED 3x3 A per keyframe, nothing bounds it
+                            extra_flags=_ffi.FLAG_ZERO_ABSENT | (_ffi.FLAG_UNIT_LOSS_GRADS if self.exposure is None else 0),
                             color_logits=self.exposure is not None, mapper_loss=fused)
         if xs is not None:
             # the renderer returned colour LOGITS; the rays of keyframe f get sigmoid(logits @ rot_f + trans_f)

@@ -127,9 +127,9 @@ def test_weight_blob_roundtrip(backend):
 
 
 # ------------------------------------------------------------------ end-to-end forward vs golden + oracle
-def run_forward(eng, name, g, stage, tracker=False, affine=None, color_logits=False, stats_chunk=None):
+def run_forward(eng, name, g, stage, tracker=False, affine=None, color_logits=False, stats_chunk=None, W=None):
     cfg = rcfg(name)
-    W = weights(name)
+    W = weights(name) if W is None else W
     blob = core.DecoderBlob(eng).pack(W)
     ro, rd, gd, pos, geo, col = [eng.f32(x) for x in tens(g, 'rays_o', 'rays_d', 'gt_depth', 'pos', 'geo', 'col')]
     knn = core.KnnIndex(eng, capacity=pos.shape[0])
@@ -207,20 +207,24 @@ def test_forward_intermediates_vs_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', backends())
-@pytest.mark.parametrize('scale', (1e-3, 30.0))
-def test_forward_operand_range(backend, scale):
+@pytest.mark.parametrize('scale,wscale', ((1e-3, 1.0), (30.0, 1.0), (10.0, 3.0), (1.0, 0.1)))
+def test_forward_operand_range(backend, scale, wscale):
     """The forward products run on fp16 pieces (lk_common.h: fp16x3): feature tables 30x larger (activations of a few
-    hundred) or 1000x smaller (low pieces deep in the fp16 subnormals) than usual still match the oracle."""
+    hundred), 1000x smaller (low pieces deep in the fp16 subnormals), larger / smaller decoder matrices (every weight matrix of both
+    decoders and the rel-pos MLP times 3 with 10x features: activations of ~1e4, a sixth of fp16's range; times 0.1) still match the
+    oracle.  The hard limit is fp16's 65 504 for any single operand (feature, activation or weight)."""
     eng = make_engine(backend)
     name = 'replica'
     g = dict(load(f'g6_render_{name}_map_color'))
     g['geo'], g['col'] = g['geo'] * np.float32(scale), g['col'] * np.float32(scale)
-    st = run_forward(eng, name, g, 'color')
+    W = {k: (v * wscale if (v.dim() == 2 and not k.endswith('_B')) else v.clone()) for k, v in weights(name).items()}
+    st = run_forward(eng, name, g, 'color', W=W)
     ro, rd, gd, pos, geo, col = tens(g, 'rays_o', 'rays_d', 'gt_depth', 'pos', 'geo', 'col')
     with torch.no_grad():
-        o = H.render_batch(ocfg(name), ro, rd, gd, pos, geo, col, weights(name), 'color',
+        o = H.render_batch(ocfg(name), ro, rd, gd, pos, geo, col, W, 'color',
                            noise_geo=torch.from_numpy(g['noise_geo']), noise_col=torch.from_numpy(g['noise_col']))
     np.testing.assert_allclose(st.depth.cpu().numpy(), o['depth'].numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(st.color.cpu().numpy(), o['color'].numpy(), rtol=1e-4, atol=2e-5)
     raw = st.raw.cpu().numpy()
-    np.testing.assert_allclose(raw[:, 3], o['occ'].numpy(), rtol=1e-4, atol=1e-4 * max(1.0, scale))
+    amax = float(np.abs(o['occ'].numpy()).max())
+    np.testing.assert_allclose(raw[:, 3], o['occ'].numpy(), rtol=1e-4, atol=1e-4 * max(1.0, scale, 1e-2 * amax))
