@@ -430,7 +430,8 @@ class Mapper:
         self.last_add_counts, self.last_frame_pts_add, self.last_num_joint_iters = [], 0, 0
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self.keyframe_list, self.keyframe_dict = [], []
-        self.gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219) + 7)
+        # draws on the device, like the reference's select_uv (common.py:156-172): no host RNG + upload between GPU launches
+        self.gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219) + 7)
         self.prev_c2w = None
         self.last_log = None
 
@@ -482,7 +483,7 @@ class Mapper:
         # sorted by overlap (stable, as Python's sorted on the reference's dicts), then a random k of those with any overlap
         order = sorted(range(len(frac)), key=lambda i: frac[i], reverse=True)
         scored = [i for i in order if frac[i] > 0.0]
-        perm = torch.randperm(len(scored), generator=self.gen).tolist()
+        perm = torch.randperm(len(scored), generator=self.gen, device=self.eng.device).tolist()
         return [scored[i] for i in perm[:k]]
 
     # -- point insertion of a mapped frame (Mapper.py:421-482)
@@ -505,14 +506,14 @@ class Mapper:
         if idx == 0:
             n_main = int(torch.clamp(self.pixels_adding * ((gt_depth.median() / 2.5) ** 2), min=self.pixels_adding,
                                      max=self.pixels_adding * 3).int().item())
-        draws = {'main': torch.randint(0, H * W, (n_main,), generator=self.gen).to(dev),
-                 'overlap': torch.randint(0, H * W, (1000,), generator=self.gen).to(dev)}
+        draws = {'main': torch.randint(0, H * W, (n_main,), generator=self.gen, device=dev),
+                 'overlap': torch.randint(0, H * W, (1000,), generator=self.gen, device=dev)}
         n = self.pixels_based_on_color_grad
         if n > 0:
             if grad_mag is None:
                 grad_mag = frame_radius_maps(self.eng, self.cfg, gt_color)[0]
             pool = optim.top_grad_pixels(self.eng, grad_mag, 5 * n, (0, H, 0, W))
-            pick = torch.randperm(int(pool.numel()), generator=self.gen)[:n].to(dev)
+            pick = torch.randperm(int(pool.numel()), generator=self.gen, device=dev)[:n]
             draws['grad'] = torch.sort(pool[pick].long()).values
         return draws
 
@@ -603,7 +604,7 @@ class Mapper:
                  torch.stack([p.float().to(eng.device) for p in frames_p]).contiguous(),
                  torch.stack(frames_r).contiguous() if frames_r is not None else None)
         fid = torch.arange(F, dtype=torch.int32).repeat_interleave(pix).to(eng.device)
-        rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen, dtype=torch.int32).to(eng.device)
+        rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen, dtype=torch.int32, device=eng.device)
         log = eng.zeros(num_joint_iters, 4)
         geo_iters = self.geo_iter_first if init else int(num_joint_iters * self.geo_iter_ratio)
         # stage 'geometry' while joint_iter <= geo_iters (Mapper.py:594-597)
@@ -699,7 +700,7 @@ class Tracker:
                                       'reference config uses the uncertainty-normalised mask')
         if self.depth_limit and not self.sample_with_color_grad:
             raise NotImplementedError('tracking.depth_limit without sample_with_color_grad (Tracker.py:142-146) is not built')
-        self.gen = torch.Generator(device='cpu').manual_seed(cfg.get('setup_seed', 1219) + 3)
+        self.gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219) + 3)      # device draws (select_uv)
         self.last_log = None
 
     def set_pipe(self, pipe):
@@ -764,18 +765,13 @@ class Tracker:
                 n_px = min(n_px, int(pool.numel()))
                 # n distinct positions per iteration = the n largest of a row of uniform draws, generated and selected on the
                 # device that holds the pool (200 x 75 000 draws per frame for the TUM budget: ~100 ms on host threads)
-                if eng.device.type == 'cuda':
-                    if getattr(self, 'gen_dev', None) is None:
-                        self.gen_dev = torch.Generator(device=eng.device).manual_seed(self.cfg.get('setup_seed', 1219) + 5)
-                    u = torch.rand(self.num_cam_iters, pool.numel(), generator=self.gen_dev, device=eng.device)
-                else:
-                    u = torch.rand(self.num_cam_iters, pool.numel(), generator=self.gen)
+                u = torch.rand(self.num_cam_iters, pool.numel(), generator=self.gen, device=eng.device)
                 order = u.topk(n_px, dim=1).indices.to(eng.device)
                 rnd = pool[order].contiguous()
                 win_it = (0, self.H, 0, self.W)
             else:
                 n = (win[1] - win[0]) * (win[3] - win[2])
-                rnd = torch.randint(0, n, (self.num_cam_iters, n_px), generator=self.gen, dtype=torch.int32).to(eng.device)
+                rnd = torch.randint(0, n, (self.num_cam_iters, n_px), generator=self.gen, dtype=torch.int32, device=eng.device)
                 win_it = win
             to = steps.TrackOptimizer(eng, rcfg, self.decoders.dec, self.npc.knn, self.npc.cloud_pos(), self.npc.get_geo_feats(),
                                       self.npc.get_col_feats(), n_px, self.cam_lr, separate_lr=self.separate_LR,

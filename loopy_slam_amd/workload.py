@@ -69,13 +69,16 @@ class FrameWorkload:
                                          b.map_rays, MAP_LRS, w_color=0.1, dist=dist)
         self.tracker = steps.TrackOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col,
                                             b.track_rays, b.cam_lr, separate_lr=True, w_color=0.5, dist=dist)
-        self.gen = torch.Generator(device='cpu').manual_seed(seed + (dist.rank if dist is not None else 0))
+        # pixel draws happen on the device, as the reference's do (select_uv: torch.randint(..., device=device), common.py:156-172):
+        # 300 000 host-side draws + their upload cost 0.9 ms of a 22 ms step with the GPU idle
+        self.gen = torch.Generator(device=dev).manual_seed(seed + (dist.rank if dist is not None else 0))
+        self._fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(dev)      # pixels // window frames each
         self.cam0 = get_tensor_from_camera(self.c2w_stack[0]).to(dev)
         self.map_log = eng.zeros(b.map_iters, 4)
         self.frame_no = 0
 
     def _draws(self, iters, R, n):
-        return torch.randint(0, n, (iters, R), generator=self.gen, dtype=torch.int32).to(self.eng.device)
+        return torch.randint(0, n, (iters, R), generator=self.gen, dtype=torch.int32, device=self.eng.device)
 
     def step(self):
         """One frame-equivalent: 40 tracking iterations + 60 mapping iterations (24 geometry + 36 colour)."""
@@ -87,7 +90,7 @@ class FrameWorkload:
         k = self.frame_no % b.window
         best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win, self.intr, rnd_t)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
-        fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(eng.device)      # pixels // window frames each
+        fid = self._fid
         self.rows, row_mask = optim.frustum_rows(eng, self.pos, self.c2w_stack[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
                                                  return_mask=True)
         self.mapper.new_frame(self.rows, row_mask)

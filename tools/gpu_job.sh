@@ -9,4 +9,5 @@ python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print('overlap %.2f ms/step' % d['ms_per_step'], {k[2:]: round(v, 2) for k, v in d['kernel_ms_per_step'].items()})"
 done
-for m in geo color track; do python tools/mode_trace.py $m 40 --repeat 3 2>&1 | tail -1; done
+python tools/probe/step_phases.py 2>&1 | tail -2
+timeout 600 python tools/slam_run.py --frames 51 --out gpurun_out/r2_slam_run.json 2>&1 | tail -1 | cut -c1-300

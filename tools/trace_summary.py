@@ -26,7 +26,8 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if r[2].startswith('k_sample_interp')]      # first launch of every iteration
+    # first launch of every iteration: the sampler (not its search-only form <T, 1>, which lk_map_frame runs ahead of the loop)
+    starts = [i for i, r in enumerate(rows) if r[2].startswith('k_sample_interp') and not r[2].rstrip().endswith(', 1>')]
     if len(starts) < 8:
         print('too few iterations in the trace')
         return
