@@ -281,9 +281,9 @@ LkAuxStream& lk_aux_stream() {
     static LkAuxStream s, none;
     if (lk_serial_mode()) return none;
     if (!s.st) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        s.ok = hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, lo) == hipSuccess &&
+        // default priority: on a low-priority queue every launch of the chain waited 40-180 us for its dispatch while the chip sat idle
+        // (the loop's first iterations wait for this stream)
+        s.ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&s.e0, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&s.e1, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&s.e2, hipEventDisableTiming) == hipSuccess;

@@ -369,7 +369,11 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     const int64_t nrow = d->n_rows * LK_C;
     const MapWork wk = map_work(R, d->render.S, d->iters);
     const int64_t Pn = (int64_t)R * d->render.S;
-    const int pre_chunk = lk_cdiv(d->iters, LK_PRE_CHUNKS) < 6 ? 6 : lk_cdiv(d->iters, LK_PRE_CHUNKS);       // iterations per search launch
+    // iterations per chunk of the work that runs ahead; chunk 0 is the first iteration alone (the loop waits for it), chunk c >= 1
+    // starts at iteration 1 + (c - 1) pre_chunk
+    const int pre_chunk = lk_cdiv(d->iters, LK_PRE_CHUNKS - 1) < 6 ? 6 : lk_cdiv(d->iters, LK_PRE_CHUNKS - 1);
+    auto chunk_start = [&](int c) { return c == 0 ? 0 : 1 + (c - 1) * pre_chunk; };
+    auto chunk_of = [&](int it) { return it == 0 ? 0 : 1 + (it - 1) / pre_chunk; };
     float* W0 = d->work;
     if (pre && it_begin == 0 && (phases & 1)) {
         // pixels, rays, colours, radii and the inside mask of EVERY iteration of this optimize_map call in one launch; it also
@@ -389,12 +393,12 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     // the rays, the positions and the row mask only.  Chunk c + 1 is enqueued when the loop reaches chunk c.
     const bool sort_ahead = pre && d->render.g_geo_feats != nullptr;
     auto enqueue_chunk = [&](int c) -> int {
-        const int c0 = c * pre_chunk;
+        const int c0 = chunk_start(c);
         if (c0 >= d->iters) return LK_OK;
         PreStream& ps = pre_stream();
         hipStream_t pst = ps.ok ? ps.st : st;
         if (ps.ok && c == 0) { (void)hipEventRecord(ps.e0, st); (void)hipStreamWaitEvent(pst, ps.e0, 0); }     // after k_pregather
-        const int nc = d->iters - c0 < pre_chunk ? d->iters - c0 : pre_chunk;
+        const int c1 = chunk_start(c + 1) < d->iters ? chunk_start(c + 1) : d->iters, nc = c1 - c0;
         lk_render_desc sd = d->render;
         sd.flags = (d->render.flags & LK_FLAG_REL_POS) | LK_FLAG_ZERO_ABSENT;
         sd.R = nc * R; sd.stats_chunk = sd.R;
@@ -438,13 +442,14 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             if (rd.r2_ray) rd.r2_ray = W0 + wk.r2_ray + (size_t)it * R;
             rd.z = W0 + wk.z + (size_t)it * Pn; rd.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)it * Pn;
             rd.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)it * Pn * LK_K; rd.nbr_w = W0 + wk.nbr_w + (size_t)it * Pn * LK_K;
-            if ((phases & 1) && it % pre_chunk == 0) {       // entering chunk c: enqueue chunk c + 1, then wait for chunk c
-                const int rc = enqueue_chunk(it / pre_chunk + 1);
+            const int ck = chunk_of(it);
+            if ((phases & 1) && it == chunk_start(ck)) {     // entering chunk ck: enqueue chunk ck + 1, then wait for chunk ck
+                const int rc = enqueue_chunk(ck + 1);
                 if (rc != LK_OK) return rc;
             }
-            if ((phases & 1) && (it % pre_chunk == 0 || it == it_begin)) {
+            if ((phases & 1) && (it == chunk_start(ck) || it == it_begin)) {
                 PreStream& ps = pre_stream();
-                if (ps.ok) (void)hipStreamWaitEvent(st, ps.ev[(it / pre_chunk) % LK_PRE_CHUNKS], 0);
+                if (ps.ok) (void)hipStreamWaitEvent(st, ps.ev[ck % LK_PRE_CHUNKS], 0);
             }
         }
         if (phases & 1) {

@@ -7,7 +7,9 @@ tail -2 gpurun_out/gpu_tests.log
 for k in 1 2 3; do
 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('overlap %.2f ms/step' % d['ms_per_step'], {k[2:]: round(v, 2) for k, v in d['kernel_ms_per_step'].items()})"
+d = json.loads(sys.stdin.read()); print('overlap %.2f ms/step' % d['ms_per_step'])"
 done
 python tools/probe/step_phases.py 2>&1 | tail -2
-timeout 600 python tools/slam_run.py --frames 51 --out gpurun_out/r2_slam_run.json 2>&1 | tail -1 | cut -c1-300
+rm -rf /tmp/trb
+rocprofv3 --kernel-trace --output-format csv -d /tmp/trb -o t -- python bench.py --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
+python tools/trace_gaps.py /tmp/trb 15 | head -14
