@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd(LkRelposBwdArgs a) {
 // 128 staged rows with 24 matrix instructions per phase into two accumulators it keeps in REGISTERS for the whole kernel.
 // (A first version added every wave's tile into one LDS tile with float atomics: ds_add_f32 retires about one lane every two
 // cycles, the kernel ran three times slower than the one it replaces.)  Workgroups are persistent (grid <= 2 per compute
-// unit) and store their 128 x 64 tile once, k_dw1_reduce adds the <= 512 partial tiles: fixed summation order, no atomics.
+// unit) and store their 128 x 64 tile once, k_bwd_reduce (k_rp_reduce) adds the <= 512 partial tiles: fixed summation order, no atomics.
 // All products run on scaled fp16 pieces (d out * 2^10, as in decode_bwd_col_wg<true>): half the matrix instructions and
 // 3 instead of 5.5 VALU instructions per split value of the bf16 path.
 #define RPF_XU 56                                            // staged input units: 0..51 real, 52 = 1, 53..55 = 0

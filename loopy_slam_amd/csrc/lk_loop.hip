@@ -10,7 +10,7 @@
 //   k_track_final      pose gradient, Adam on the 7 pose parameters, candidate log, rays of the next iteration
 // 16 -> 9 launches per tracking iteration, 11 -> 8 per geometry iteration (a launch of a trivial kernel costs ~5 us on the
 // GPU's front end however little it does; single-workgroup fusions of the same steps were measured SLOWER: one compute unit
-// cannot keep enough scattered loads in flight - profiles/r2_notes.md).
+// cannot keep enough scattered loads in flight - DESIGN.md section 7).
 #include "lk_common.h"
 #include "lk_kernels.h"
 #include "lk_composite_dev.h"
