@@ -167,7 +167,7 @@ static void fill_sample_args(const lk_render_desc* d, int P, bool all_pos, LkSam
     sa.near_surface = d->near_surface; sa.far_surface = d->far_surface; sa.near_end = d->near_end; sa.r2_static = d->r2_static;
     sa.min_nn = d->min_nn;
     sa.z = d->z; sa.nbr_idx = d->nbr_idx; sa.nbr_w = d->nbr_w; sa.nbr_count = d->nbr_count; sa.c_geo = d->c_geo; sa.c_col = d->c_col;
-    sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr;
+    sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr; sa.live_rays = nullptr;
 }
 // z and the neighbour lists of a batch (the part of the sampler that does not read the feature tables); needs ZERO_ABSENT /
 // ALL_DEPTH_POS batches (no far_bb statistics)
@@ -183,7 +183,7 @@ int lk_presample(const lk_render_desc* d, hipStream_t st) {
 
 extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
 
-int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays) {
     int rc = check_desc(d, "lk_render_fwd");
     if (rc != LK_OK) return rc;
     if (d->R == 0) return LK_OK;
@@ -202,6 +202,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
         seg_args(d, P, fs);
         sa.seg_cnt = fs.seg_cnt; sa.seg_rank = fs.seg_rank; sa.row_mask = fs.row_mask;
     }
+    sa.live_rays = live_rays;
     lk_launch_sample_interp(sa, st, (skip & LK_PRESAMPLED) ? 2 : 0);
     if (presort) {       // ... and sorted beside the decoders
         const int rc2 = seg_sort_async(d, P, true, st);
@@ -213,7 +214,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip) {
         LkRelposArgs ra;
         ra.R = d->R; ra.S = d->S; ra.P = P; ra.min_nn = d->min_nn;
         ra.rays_o = d->rays_o; ra.rays_d = d->rays_d; ra.z = d->z;
-        ra.pos = d->pos; ra.col_feats = d->col_feats; ra.feats_f16 = (d->flags & LK_FLAG_FEATS_F16) ? 1 : 0;
+        ra.pos = d->pos; ra.col_feats = d->col_feats; ra.feats_f16 = (d->flags & LK_FLAG_FEATS_F16) ? 1 : 0; ra.live_rays = live_rays;
         ra.nbr_idx = d->nbr_idx; ra.nbr_w = d->nbr_w; ra.nbr_count = d->nbr_count;
         ra.W = d->weights; ra.Wfrag = d->weights_frag; ra.noise_col = d->noise_col; ra.c_col = d->c_col;
         lk_launch_relpos_fwd(ra, st);
@@ -422,6 +423,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         rb.dw_rel = S0 + L.dw_rel; rb.dp_rel = S0 + L.dp_rel; rb.rows = S0 + L.rows; rb.w_eff = S0 + L.w_eff;
         rb.dfeat = S0 + L.dfeat;
         rb.part_br = S0 + L.part_br; rb.hbar = S0 + L.hbar; rb.w_sum = S0 + L.w_sum; rb.dw1_part = S0 + L.dw1_part;
+        rb.live_rays = (ex && lk_relpos_fused(flags)) ? ex->live_rays : nullptr;
         lk_launch_relpos_bwd(rb, st);
         if (forked) { (void)hipEventRecord(ss.mid, st); (void)hipStreamWaitEvent(wst, ss.mid, 0); }
         if (gw && !defer) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
@@ -460,7 +462,8 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             // linear1 was reduced inside k_relpos_bwd_fused (workgroup tiles), linear2 = samples x (wsum d c) (x) Hbar: two small launches
             LkRelposBwdArgs rb;
             memset(&rb, 0, sizeof(rb));
-            rb.P = P; rb.dc_col = S0 + L.dc_col; rb.w_sum = S0 + L.w_sum; rb.hbar = S0 + L.hbar; rb.dw1_part = S0 + L.dw1_part;
+            rb.P = P; rb.S = d->S; rb.dc_col = S0 + L.dc_col; rb.w_sum = S0 + L.w_sum; rb.hbar = S0 + L.hbar; rb.dw1_part = S0 + L.dw1_part;
+            rb.live_rays = ex ? ex->live_rays : nullptr;
             // on the caller's stream: after the fused kernel and the gather it has room, the weight-gradient stream is the longer one
             // (on the third stream beside the gather: no gain, 399 -> 409 us per colour iteration)
             lk_launch_rp_wgrad_tail(rb, S0 + L.dw2_part, nullptr, nullptr, nullptr, nullptr, st);

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void k_seg_count(LkFeatScatterArgs a) {
     const int s = (int)(row >> 3);
     const int idx = a.nbr_idx[row];
     int rk = -1;
-    if (idx >= 0 && a.nbr_w[row] != 0.0f && a.nbr_count[s] >= a.min_nn && (!a.row_mask || a.row_mask[idx]))
+    const bool skipped = a.live_rays && s >= *a.live_rays * a.S;              // ray without a reading: its rows carry no gradient
+    if (!skipped && idx >= 0 && a.nbr_w[row] != 0.0f && a.nbr_count[s] >= a.min_nn && (!a.row_mask || a.row_mask[idx]))
         rk = atomicAdd(a.seg_cnt + idx, 1);
     a.seg_rank[row] = rk;
 }
@@ -521,14 +522,14 @@ __device__ __forceinline__ u32x4 rpf_operand(const uint16_t* __restrict__ img, i
     return *reinterpret_cast<const u32x4*>(img + slot);
 }
 
-__device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, int sample0, float* __restrict__ part,
+__device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, int sample0, int P_live, float* __restrict__ part,
                                                       uint16_t* __restrict__ stage_wg, int w, f32x16 (&acc)[2]) {
     const int lane = lk_opaque(lk_lane());            // per tile: see lk_opaque
     const int h = lane >> 5;
     const int j = lane & 31;
     const int sample = sample0 + (j >> 3);
-    const bool live = sample < a.P;
-    const int sp = live ? sample : a.P - 1;
+    const bool live = sample < P_live;
+    const int sp = live ? sample : P_live - 1;
     const int nb_i = j & 7;
     const int r = sp / a.S;
     const float z = a.z[sp];
@@ -739,8 +740,9 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) 
     acc[0] = lk_zero16(); acc[1] = lk_zero16();
     __syncthreads();
     // every wave runs every tile of the workgroup (barriers inside); rows past the end are dead lanes with weight 0
-    for (int t = (int)blockIdx.x; t * 16 < a.P; t += (int)gridDim.x)
-        relpos_bwd_wave_fused(a, (t * 4 + w) * 4, s_part[w], s_stage, w, acc);
+    const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;       // the rays without a reading sit behind the prefix
+    for (int t = (int)blockIdx.x; t * 16 < P_live; t += (int)gridDim.x)
+        relpos_bwd_wave_fused(a, (t * 4 + w) * 4, P_live, s_part[w], s_stage, w, acc);
     __syncthreads();
     if (threadIdx.x < 32)
         a.part_br[(size_t)blockIdx.x * 32 + threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] +
@@ -763,7 +765,8 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) 
 #define LK_DW2_TILE (32 * 129)
 #define LK_DW2_SAMPLES 64
 __global__ __launch_bounds__(256) void k_dw2_hbar(const float* __restrict__ dc, const float* __restrict__ w_sum, const float* __restrict__ hbar,
-                                                  int P, float* __restrict__ part) {
+                                                  int P_all, const int32_t* __restrict__ live_rays, int S, float* __restrict__ part) {
+    const int P = live_rays ? min(P_all, *live_rays * S) : P_all;
     __shared__ __attribute__((aligned(16))) float s_h[LK_DW2_SAMPLES][128];
     __shared__ float s_a[LK_DW2_SAMPLES][33];
     const int t = (int)threadIdx.x, n = t >> 3, k0 = 16 * (t & 7);
@@ -1167,7 +1170,7 @@ int lk_dw2_parts(int P) { const int n = lk_cdiv(P, LK_DW2_SAMPLES); return n < 1
 int64_t lk_dw2_part_floats(int P) { return (int64_t)lk_dw2_parts(P) * LK_DW2_TILE; }
 int lk_launch_rp_wgrad_tail(const LkRelposBwdArgs& a, float* dw2_part, float* dW1, float* db1, float* dW2, float* db2, hipStream_t st) {
     const int n2 = lk_dw2_parts(a.P);
-    hipLaunchKernelGGL(k_dw2_hbar, dim3(n2), dim3(256), 0, st, a.dc_col, a.w_sum, a.hbar, a.P, dw2_part);
+    hipLaunchKernelGGL(k_dw2_hbar, dim3(n2), dim3(256), 0, st, a.dc_col, a.w_sum, a.hbar, a.P, a.live_rays, a.S, dw2_part);
     if (!dW1) return LK_OK;                             // the sums ride in k_bwd_reduce
     hipLaunchKernelGGL(k_rp_reduce, dim3(128 * 64 / 32 + lk_cdiv(LK_DW2_TILE, 32)), dim3(256), 0, st, a.dw1_part, lk_relpos_bwd_parts(a.P),
                        dw2_part, n2, dW1, db1, dW2, db2);

@@ -359,12 +359,13 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
     const int lane = lk_lane();
     const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
     const int sample0 = wave * 4;
-    if (sample0 >= a.P) return;
+    const int P = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;      // rays without a reading sit behind the live prefix: skipped
+    if (sample0 >= P) return;
     const int h = lane >> 5;
     const int j = lane & 31;                    // row of the tile: sample j>>3, neighbour j&7
     const int sample = sample0 + (j >> 3);
-    const bool live = sample < a.P;
-    const int sp = live ? sample : a.P - 1;
+    const bool live = sample < P;
+    const int sp = live ? sample : P - 1;
     const int nb_i = j & 7;
     const int r = sp / a.S;
     const float z = a.z[sp];

@@ -24,6 +24,7 @@ struct LkSampleArgs {
     float* z; int32_t* nbr_idx; float* nbr_w; int32_t* nbr_count; float* c_geo; float* c_col;
     // rows counted per point on the way (first pass of the backward's counting sort, see k_seg_count); seg_cnt == NULL: off
     int32_t* seg_cnt; int32_t* seg_rank; const uint8_t* row_mask;
+    const int32_t* live_rays;                     // see LkRelposArgs: with it the sampler gives the skipped samples their colour feature (noise)
 };
 
 struct LkCompositeArgs {
@@ -61,6 +62,8 @@ struct LkRelposArgs {
     const float* W; const float* Wfrag; const float* noise_col;
     float* c_col;                                 // [P,32]
     int feats_f16;                                // LK_FLAG_FEATS_F16
+    const int32_t* live_rays;                     // [1] or NULL: only the first *live_rays rays of the batch have a depth reading (k_pregather
+                                                  // partitions the mapper's batches); the samples of the others are not processed
 };
 
 struct LkCompositeBwdArgs {
@@ -115,7 +118,7 @@ struct LkInterpBwdArgs {
 // workgroup of 32 samples, G[c][k] = sum d p_c z dir_k (9) and T[c] = sum d p_c (3) - what k_pose_bwd sums over the rays -
 // into pose_part[block][12]; lk_bwd_pose_parts(P) blocks.
 struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
-                    int32_t* seg_list; int32_t* seg_total; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
+                    int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
@@ -131,6 +134,7 @@ struct LkFeatScatterArgs {
     int32_t* seg_rank;                             // [8P] rank of the row among the rows of its point, -1 = row takes no part
     int32_t* seg_list;                             // [8P] rows ordered by point
     int32_t* seg_total;                            // [1] number of rows in seg_list, written by k_seg_place (NULL: seg_off[N])
+    const int32_t* live_rays; int S;               // rows of rays >= *live_rays take no part (NULL: all)
     int N;
 };
 int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st);        // counted: k_sample_interp already ran the count pass
@@ -157,6 +161,7 @@ struct LkRelposBwdArgs {
     float* w_eff;                                  // [8P] weight actually applied to each neighbour row
     float* part_br;                                // [n_blocks][32] per-workgroup partial sums of d embedder_rel_pos._B
     float* dw1_part;                               // [n_blocks][128][64] per-workgroup d linear1 tiles (fused variant, lk_relpos_fused)
+    const int32_t* live_rays;                      // as LkRelposArgs (fused variant only)
 };
 // k_relpos_bwd_fused (lk_bwd2.hip): linear1's weight gradient inside the rel-pos backward - mapper mode only (scaled fp16 pieces
 // need unit-scale loss gradients; the ray-gradient products stay on the plain kernel)
@@ -205,7 +210,7 @@ bool lk_serial_mode();                                      // LK_SERIAL / lk_se
 #define LK_PRE_CHUNKS 16
 struct LkAuxStream { hipStream_t st = nullptr; hipEvent_t e0 = nullptr; hipEvent_t ev[LK_PRE_CHUNKS] = {}; hipEvent_t e1 = nullptr, e2 = nullptr; bool ok = false; };
 LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour lists
-int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip);
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr);
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total; };
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch

@@ -145,6 +145,11 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     }
     if (lane_geo) *reinterpret_cast<float4*>(a.c_geo + (size_t)pidx * LK_C + f4 * 4) = ag;
     if (lane_col) *reinterpret_cast<float4*>(a.c_col + (size_t)pidx * LK_C + f4 * 4) = ac;
+    // rel-pos colour features come from k_relpos_fwd, which does not visit the rays behind the live prefix: give their samples a defined
+    // (finite) feature here - the noise vector of unsupported samples - so that what the decoder computes for them stays finite
+    if (a.live_rays && (a.flags & LK_FLAG_STAGE_COLOR) && (a.flags & LK_FLAG_REL_POS) && r >= *a.live_rays && lane_geo)
+        *reinterpret_cast<float4*>(a.c_col + (size_t)pidx * LK_C + f4 * 4) =
+            a.noise_col ? *reinterpret_cast<const float4*>(a.noise_col + f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // One thread per ray: occupancy of unsupported samples := -100, alpha composite, validity.  With a.loss_out the mapper loss

@@ -7,9 +7,6 @@ tail -2 gpurun_out/gpu_tests.log
 for k in 1 2 3; do
 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('overlap %.2f ms/step' % d['ms_per_step'])"
+d = json.loads(sys.stdin.read()); print('overlap %.2f ms/step' % d['ms_per_step'], {k[2:]: round(v, 2) for k, v in d['kernel_ms_per_step'].items()})"
 done
-python tools/probe/step_phases.py 2>&1 | tail -2
-rm -rf /tmp/trb
-rocprofv3 --kernel-trace --output-format csv -d /tmp/trb -o t -- python bench.py --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
-python tools/trace_gaps.py /tmp/trb 15 | head -14
+for m in geo color track; do python tools/mode_trace.py $m 40 --repeat 3 2>&1 | tail -1; done
