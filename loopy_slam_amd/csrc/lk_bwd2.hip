@@ -1,6 +1,6 @@
 // Backward, part 2:
 //   k_interp_bwd    tracker mode: gradient through the interpolation weights to the sample position (decoder.py:191-229)
-//   k_feat_scatter  d c_geo / d c_col / per-neighbour rows -> scatter-add into the feature-row gradients
+//   k_seg_* / k_feat_gather  d c_geo / d c_col / per-neighbour rows -> feature-row gradients (rows sorted by point, one atomic per run)
 //   k_rays_bwd      d p -> d rays_o, d rays_d
 //   k_relpos_bwd    backward of the relative-position neighbour MLP (decoder.py:477-488)
 //   k_wgrad(+_reduce)  all decoder weight gradients as streamed MFMA reductions over the sample rows
@@ -113,26 +113,12 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
     }
 }
 
-// Feature-gradient scatter: one half-wave (32 lanes = the 32 channels = one 128-B line) per (sample, neighbour),
-// so every wave-wide atomic touches two full lines instead of up to 64 scattered ones (measured 2x-5x faster).
+// Feature-row gradients:
 //   geometry rows:            g_geo[idx] += w * d c_geo[sample]
 //   colour rows, no rel-pos:  g_col[idx] += w * d c_col[sample]
 //   colour rows, rel-pos:     g_col[idx] += d feat[sample, neighbour]   (from k_relpos_bwd)
-__global__ __launch_bounds__(256) void k_feat_scatter(LkFeatScatterArgs a) {
-    const long long row = (long long)blockIdx.x * 8 + ((int)threadIdx.x >> 5);
-    const int c = (int)threadIdx.x & 31;
-    if (row >= (long long)a.P * LK_K) return;
-    const int s = (int)(row >> 3);
-    const int idx = a.nbr_idx[row];
-    const float w = a.nbr_w[row];
-    if (idx < 0 || w == 0.0f || a.nbr_count[s] < a.min_nn) return;
-    if (a.row_mask && !a.row_mask[idx]) return;         // row not being optimised: its gradient is never consumed
-    atomicAdd(a.g_geo_feats + (size_t)idx * LK_C + c, w * a.dc_geo[(size_t)s * LK_C + c]);
-    if (a.dfeat) atomicAdd(a.g_col_feats + (size_t)idx * LK_C + c, a.dfeat[(size_t)row * LK_C + c]);
-    else if (a.dc_col) atomicAdd(a.g_col_feats + (size_t)idx * LK_C + c, w * a.dc_col[(size_t)s * LK_C + c]);
-}
-
-// The same sums with a fraction of the atomics.  A mapper batch touches few points many times (5 000 rays x 5 samples x 8
+// Round 1 scattered them with one half-wave (32 channels = one 128-byte line) per (sample, neighbour) and an atomic per lane.
+// Now: the same sums with a fraction of the atomics.  A mapper batch touches few points many times (5 000 rays x 5 samples x 8
 // neighbours = 197 k rows on 15 k points of the benchmark frame: 12.7 rows per point), and the atomic scatter pays for every
 // row twice (two tables) at the memory-side atomic rate, with the adds of a point serialised on its line.  The rows are
 // counting-sorted by point - k_seg_count (rank of the row among the rows of its point; inside k_sample_interp when the forward
@@ -423,7 +409,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
                     }
                 }
             }
-            if (!is_emb && u0 < KR) {     // d feature row of this neighbour: scattered by k_feat_scatter (line-coalesced atomics)
+            if (!is_emb && u0 < KR) {     // d feature row of this neighbour: summed per point by k_feat_gather
                 if ((a.flags & LK_FLAG_GRAD_FEATS) && live)
                     *reinterpret_cast<float4*>(a.dfeat + ((size_t)sp * 8 + nb_i) * LK_C + (u0 - ER)) =
                         make_float4(dx[tile][4 * g], dx[tile][4 * g + 1], dx[tile][4 * g + 2], dx[tile][4 * g + 3]);
@@ -1140,8 +1126,7 @@ int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
 }
 int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_FEAT_SCATTER, st);
-    if (a.seg_cnt) hipLaunchKernelGGL(k_feat_gather, dim3(lk_cdiv((long long)a.P * LK_K, 8 * LK_GATHER_CHUNK)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_feat_scatter, dim3(lk_cdiv((long long)a.P * LK_K, 8)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_feat_gather, dim3(lk_cdiv((long long)a.P * LK_K, 8 * LK_GATHER_CHUNK)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st) {

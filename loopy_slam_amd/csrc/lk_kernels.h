@@ -127,7 +127,7 @@ struct LkFeatScatterArgs {
     const float* dc_geo; const float* dc_col; const float* dfeat;
     float* g_geo_feats; float* g_col_feats;
     const uint8_t* row_mask;                       // [N] or NULL: scatter only into rows flagged non-zero
-    // counting sort of the rows by point (lk_launch_seg_sort) -> gather without per-row atomics; seg_cnt == NULL: atomic scatter
+    // counting sort of the rows by point (lk_launch_seg_sort) -> gather without per-row atomics
     int32_t* seg_cnt;                              // [N + 1] (lk_knn_s::seg_cnt) rows per point: zero between calls (the scan clears it)
     int32_t* seg_off;                              // [N + 1] (lk_knn_s::seg_off) exclusive offsets of the points' rows; [N] = rows in the list
     int32_t* seg_sums;                             // scan scratch (lk_knn_s::seg_sums)

@@ -13,7 +13,7 @@ Algorithmic work per unit (DESIGN.md §Kernels states the same figures):
   bytes per SAMPLE POINT
     sample/interpolate  8 x 128 B feature rows per decoder gathered + 128 B written per decoder + 80 B
                         neighbour list/weights/count/z  (the grid candidate scan is extra, not counted)
-    feature scatter     8 x 128 B read-modify-write per decoder + the gradient rows read (k_feat_scatter)
+    feature scatter     8 x 128 B read-modify-write per decoder + the gradient rows read (k_feat_gather)
     weight gradients    7 984 B of saved rows per sample (k_wgrad: colour trunk)
     rel-pos backward    mapper mode: 8 x 128 B feature-row gradients + 512 B Hbar + 4 B written per sample (no neighbour rows)
 """
@@ -84,7 +84,7 @@ def work_per_step(b):
                                                        n_trk * Pt * ((2 - rel) * (feat_rows + 128) + 80)), launches=b.map_iters + n_trk),
         # feature-gradient scatter (mapper only): per table 8 x 128 B read-modify-write (+ 8 x 128 B of per-neighbour
         # gradients read in rel-pos mode, else the 128-B d c row) + 64 B of neighbour ids / weights
-        'k_feat_scatter': dict(flops=0.0, bytes=float(b.map_iters * Pm * (2 * feat_rows + 128 + 64) +
+        'k_feat_gather': dict(flops=0.0, bytes=float(b.map_iters * Pm * (2 * feat_rows + 128 + 64) +
                                                       n_col * Pm * (2 * feat_rows + (feat_rows if rel else 128))), launches=b.map_iters),
     }
     if rel:
@@ -147,8 +147,8 @@ def roofline(kstat, budget, kernel):
     else:
         out.update(bound='hbm', achieved=nbytes / secs / 1e9, peak=PEAK_HBM_GBS, unit='GB/s')
     out['frac'] = out['achieved'] / out['peak']
-    if kernel in ('k_wgrad', 'k_relpos_bwd', 'k_feat_scatter'):
-        out['overlap'] = ('k_wgrad runs on a second stream beside k_relpos_bwd / k_feat_scatter: durations are measured while '
+    if kernel in ('k_wgrad', 'k_relpos_bwd', 'k_feat_gather'):
+        out['overlap'] = ('k_wgrad runs on a second stream beside k_relpos_bwd / k_feat_gather: durations are measured while '
                           'they share the chip (LK_SERIAL=1 times every kernel alone)')
     out['traffic'], src = pmc_traffic(kernel)
     if src:
