@@ -466,7 +466,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             rb.live_rays = ex ? ex->live_rays : nullptr;
             // on the caller's stream: after the fused kernel and the gather it has room, the weight-gradient stream is the longer one
             // (on the third stream beside the gather: no gain, 399 -> 409 us per colour iteration)
-            lk_launch_rp_wgrad_tail(rb, S0 + L.dw2_part, nullptr, nullptr, nullptr, nullptr, st);
+            lk_launch_dw2_hbar(rb, S0 + L.dw2_part, st);
         } else {
             LkWgradArgs wr;
             memset(&wr, 0, sizeof(wr));

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd(LkRelposBwdArgs a) {
 // 128 staged rows with 24 matrix instructions per phase into two accumulators it keeps in REGISTERS for the whole kernel.
 // (A first version added every wave's tile into one LDS tile with float atomics: ds_add_f32 retires about one lane every two
 // cycles, the kernel ran three times slower than the one it replaces.)  Workgroups are persistent (grid <= 2 per compute
-// unit) and store their 128 x 64 tile once, k_bwd_reduce (k_rp_reduce) adds the <= 512 partial tiles: fixed summation order, no atomics.
+// unit) and store their 128 x 64 tile once, k_bwd_reduce adds the <= 512 partial tiles: fixed summation order, no atomics.
 // All products run on scaled fp16 pieces (d out * 2^10, as in decode_bwd_col_wg<true>): half the matrix instructions and
 // 3 instead of 5.5 VALU instructions per split value of the bf16 path.
 #define RPF_XU 56                                            // staged input units: 0..51 real, 52 = 1, 53..55 = 0
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) 
 // ([32][128] + [32] outputs, P samples: 0.2 GFLOP - too small for the k_wgrad + k_wgrad_reduce pair, whose two launches cost
 // 50 us on the weight-gradient stream).  A workgroup stages 64 samples in LDS with coalesced 16-byte loads (the walk over the
 // samples is otherwise a chain of dependent load latencies), then thread t adds them into output row n = t >> 3, columns
-// 16 (t & 7) .. + 15, and stores a [32][129] partial tile (column 128 = bias), summed by k_rp_reduce.
+// 16 (t & 7) .. + 15, and stores a [32][129] partial tile (column 128 = bias), summed by k_bwd_reduce.
 #define LK_DW2_PARTS 512
 #define LK_DW2_TILE (32 * 129)
 #define LK_DW2_SAMPLES 64
@@ -795,8 +795,8 @@ __global__ __launch_bounds__(256) void k_dw2_hbar(const float* __restrict__ dc, 
     if (k0 == 0) out[128] = bsum;
 }
 
-// Sums of the partial tiles of the fused variant: linear1 [n1][128][64] (column 52 = bias) from k_relpos_bwd_fused, linear2
-// [n2][32][129] (column 128 = bias) from k_dw2_hbar.  32 consecutive elements x 8 partial lanes per workgroup; every output has one
+// Sums of the partial tiles of the fused variant (a part of k_bwd_reduce): linear1 [n1][128][64] (column 52 = bias) from
+// k_relpos_bwd_fused, linear2 [n2][32][129] (column 128 = bias) from k_dw2_hbar.  32 consecutive elements x 8 partial lanes per workgroup; every output has one
 // owner: no atomics, fixed order.
 __device__ __forceinline__ void rp_reduce_body(const float* __restrict__ part1, int n1, const float* __restrict__ part2, int n2,
                                                float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
@@ -825,11 +825,6 @@ __device__ __forceinline__ void rp_reduce_body(const float* __restrict__ part1, 
     }
 }
 #define LK_RP_REDUCE_BLOCKS (128 * 64 / 32 + (LK_DW2_TILE + 31) / 32)
-__global__ __launch_bounds__(256) void k_rp_reduce(const float* __restrict__ part1, int n1, const float* __restrict__ part2, int n2,
-                                                   float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2) {
-    __shared__ float sh[8][32];
-    rp_reduce_body(part1, n1, part2, n2, dW1, db1, dW2, db2, (int)blockIdx.x, sh);
-}
 
 // ---------------------------------------------------------------------------------------------
 // dW[n][k] += sum_rows A'[row][n] * B[row][k]  for every decoder matrix (one "job" each): a reduction GEMM with a
@@ -1153,12 +1148,8 @@ int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
 }
 int lk_dw2_parts(int P) { const int n = lk_cdiv(P, LK_DW2_SAMPLES); return n < 1 ? 1 : (n < LK_DW2_PARTS ? n : LK_DW2_PARTS); }
 int64_t lk_dw2_part_floats(int P) { return (int64_t)lk_dw2_parts(P) * LK_DW2_TILE; }
-int lk_launch_rp_wgrad_tail(const LkRelposBwdArgs& a, float* dw2_part, float* dW1, float* db1, float* dW2, float* db2, hipStream_t st) {
-    const int n2 = lk_dw2_parts(a.P);
-    hipLaunchKernelGGL(k_dw2_hbar, dim3(n2), dim3(256), 0, st, a.dc_col, a.w_sum, a.hbar, a.P, a.live_rays, a.S, dw2_part);
-    if (!dW1) return LK_OK;                             // the sums ride in k_bwd_reduce
-    hipLaunchKernelGGL(k_rp_reduce, dim3(128 * 64 / 32 + lk_cdiv(LK_DW2_TILE, 32)), dim3(256), 0, st, a.dw1_part, lk_relpos_bwd_parts(a.P),
-                       dw2_part, n2, dW1, db1, dW2, db2);
+int lk_launch_dw2_hbar(const LkRelposBwdArgs& a, float* dw2_part, hipStream_t st) {       // its tiles are summed by k_bwd_reduce
+    hipLaunchKernelGGL(k_dw2_hbar, dim3(lk_dw2_parts(a.P)), dim3(256), 0, st, a.dc_col, a.w_sum, a.hbar, a.P, a.live_rays, a.S, dw2_part);
     return LK_OK;
 }
 int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st, LkWgradArgs* deferred) {

@@ -170,9 +170,9 @@ static inline bool lk_relpos_fused(unsigned flags) {
     return (flags & LK_FLAG_GRAD_WEIGHTS) && (flags & LK_FLAG_UNIT_LOSS_GRADS) && !(flags & LK_FLAG_GRAD_RAYS);
 }
 int lk_relpos_bwd_parts(int P);                    // workgroups = partial tiles of the fused variant
-// linear2 partial tiles (k_dw2_hbar) + the sums of both matrices' tiles (k_rp_reduce); dw2_part: lk_dw2_part_floats(P) floats
+// linear2 partial tiles (k_dw2_hbar); dw2_part: lk_dw2_part_floats(P) floats
 int64_t lk_dw2_part_floats(int P);
-int lk_launch_rp_wgrad_tail(const LkRelposBwdArgs& a, float* dw2_part, float* dW1, float* db1, float* dW2, float* db2, hipStream_t st);
+int lk_launch_dw2_hbar(const LkRelposBwdArgs& a, float* dw2_part, hipStream_t st);
 
 // weight gradients: dW[n][k] += sum_rows A[row][n] * B[row][k]  (one wave per (job, column unit, row chunk))
 struct LkWgradJob {
