@@ -390,22 +390,22 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         const int w_ld[5] = {EC, HC, HC, EC + HC, HC};
         for (int i = 0; i < 5; ++i) {
             LkWgradJob& J = wa.job[nj++];
-            J.A = dh + i * 128; J.lda = 640; J.a_mode = 1; J.A2 = act_a + i * 128; J.lda2 = LK_ACT_COL_A;
+            J.A = dh + LK_COL_LAYER(P, i); J.lda = 128; J.a_mode = 1; J.A2 = act_a + LK_COL_LAYER(P, i); J.lda2 = 128;
             if (i == 0) { J.B = act_e; J.ldb = LK_ACT_COL_E; }
-            else if (i == 3) { J.B = act_e; J.ldb = LK_ACT_COL_E; J.B2 = act_h + 2 * 128; J.ldb2 = LK_ACT_COL_H; J.k_split = EC; }
-            else { J.B = act_h + (i - 1) * 128; J.ldb = LK_ACT_COL_H; }
+            else if (i == 3) { J.B = act_e; J.ldb = LK_ACT_COL_E; J.B2 = act_h + LK_COL_LAYER(P, 2); J.ldb2 = 128; J.k_split = EC; }
+            else { J.B = act_h + LK_COL_LAYER(P, i - 1); J.ldb = 128; }
             J.N = HC; J.K = w_ld[i]; J.rows = P; J.dW = G + w_off[i]; J.ldw = w_ld[i]; J.db = G + b_off[i];
         }
         for (int i = 0; i < 5; ++i) {
             LkWgradJob& J = wa.job[nj++];
-            J.A = dh + i * 128; J.lda = 640; J.a_mode = 0;
+            J.A = dh + LK_COL_LAYER(P, i); J.lda = 128; J.a_mode = 0;
             J.B = d->c_col; J.ldb = LK_C;
             J.N = HC; J.K = CF; J.rows = P; J.dW = G + C_U0 + i * C_USTRIDE; J.ldw = CF; J.db = G + C_U0 + i * C_USTRIDE + a64(HC * CF);
         }
         {
             LkWgradJob& J = wa.job[nj++];
             J.A = S0 + L.dlogit; J.lda = 4; J.a_mode = 0;
-            J.B = act_h + 4 * 128; J.ldb = LK_ACT_COL_H;
+            J.B = act_h + LK_COL_LAYER(P, 4); J.ldb = 128;
             J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
         }
         wa.n_jobs = nj; wa.chunk = 0; wa.part = S0 + L.wg_part;

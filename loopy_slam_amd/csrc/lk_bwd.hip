@@ -102,8 +102,8 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + (H16 ? FRAGB_U4 : 0);
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
-    const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A;
-    const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H;
+    const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128;            // layer-major: + LK_COL_LAYER(P, layer)
+    const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128;
     float4 draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
     if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
     float g0 = draw.x, g1 = draw.y, g2 = draw.z;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     if (a.affine) {                                              // out' = out @ A + t  (decoder.py:536-539)
         if (a.g_affine) {
             // recompute the pre-affine output o = Wo h4 + bo: per-wave partial over its units, summed by wave 0
-            const f32x16 h4 = ct_load32(act_col_h + 4 * 128 + w * 32, lane);
+            const f32x16 h4 = ct_load32(act_col_h + LK_COL_LAYER(a.P, 4) + w * 32, lane);
             float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -184,7 +184,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         const u32x4* ut = FB + PC::tr(15 + i);
 #pragma unroll
         for (int G = 0; G < 2; ++G) un[G] = PC::load(ut, 1, 2 * w + G, 0, lane);
-        av = ct_load32(act_col_a + i * 128 + w * 32, lane);
+        av = ct_load32(act_col_a + LK_COL_LAYER(a.P, i) + w * 32, lane);
         if (i >= 1) {
             const u32x4* wt = FB + PC::tr(10 + i);
 #pragma unroll
@@ -212,7 +212,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
 #pragma unroll
                 for (int q = 0; q < 16; ++q) dhs[q] = dh[q] * ISC;
             }
-            ct_store32(a.dh_col + (size_t)sp * 640 + i * 128 + w * 32, dhs, live, lane);
+            ct_store32(a.dh_col + LK_COL_LAYER(a.P, i) + (size_t)sp * 128 + w * 32, dhs, live, lane);
         }
 #pragma unroll
         for (int G = 0; G < 2; ++G) dc = PC::mma(un[G], PC::split(dh, G), dc);

@@ -195,8 +195,9 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     const float* __restrict__ W = a.W;
     const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;      // fp16 forward fragments
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
-    float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * LK_ACT_COL_A : nullptr;
-    float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * LK_ACT_COL_H : nullptr;
+    // this sample's row of layer 0; layer L is LK_COL_LAYER(P, L) floats further (layer-major, lk_kernels.h)
+    float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128 : nullptr;
+    float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128 : nullptr;
     // embedding (40 units = blocks 0, 1 and half of 2) and interpolated feature: B operands of two / five products, split once
     LkH8 eb[3], cb[2];
     {
@@ -250,7 +251,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         for (int G = 0; G < 2; ++G) acc = lk_mma3h(un[G], cb[G], acc);
         __builtin_amdgcn_sched_barrier(0);
         if (save_a) ct_store_rows32(save_a + w * 32, act, live, lane);
-        if (save) ct_store_rows32(act_col_h + L * 128 + w * 32, acc, live, lane);
+        if (save) ct_store_rows32(act_col_h + LK_COL_LAYER(a.P, L) + w * 32, acc, live, lane);
         if (buf >= 0) {
 #pragma unroll
             for (int G = 0; G < 2; ++G) {
@@ -278,7 +279,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         if (L == 1) prefetch_hidden(FB + FM12_FWDH, 0);
         else prefetch_hidden(FB + FM13_FWDH, 3);
         __builtin_amdgcn_sched_barrier(0);
-        finish(acc, W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + L * 128 : nullptr, L, L & 1);
+        finish(acc, W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + LK_COL_LAYER(a.P, L) : nullptr, L, L & 1);
         __syncthreads();
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
@@ -288,13 +289,13 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     hidden(acc, FB + FM13_FWDH, 3, 0);
     prefetch_hidden(FB + FM14_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(acc, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 3 * 128 : nullptr, 3, 1);
+    finish(acc, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + LK_COL_LAYER(a.P, 3) : nullptr, 3, 1);
     __syncthreads();
     // layer 4
     prefetch_u(FB + FM19_FWDH);
     acc = lk_rowvec_tile(W + C_B4, w * 32, lane);
     hidden(acc, FB + FM14_FWDH, 0, 1);
-    finish(acc, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + 4 * 128 : nullptr, 4, -1);
+    finish(acc, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + LK_COL_LAYER(a.P, 4) : nullptr, 4, -1);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll

@@ -247,3 +247,7 @@ int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st);
 #define LK_ACT_COL_H (5 * 128)
 #define LK_ACT_COL_E 40       // colour Fourier embedding (input of layers 0 and 3)
 #define LK_ACT_FLOATS_PER_SAMPLE (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H + LK_ACT_COL_E)
+// The colour trunk's saved activations (a_i, h_i) and its d h_i rows are LAYER-MAJOR, [layer][P][128]: a job of the weight-gradient
+// reduction then streams one contiguous [P][128] array (512-byte pieces of 2.5-KB rows cost it a third of its bandwidth), and the 32
+// samples x 128 bytes a wave of the decoders stores per layer sit 512 bytes apart instead of 2 560.
+#define LK_COL_LAYER(P, layer) ((size_t)(layer) * (size_t)(P) * 128)
