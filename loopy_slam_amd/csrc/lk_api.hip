@@ -96,7 +96,7 @@ extern "C" int64_t lk_render_act_floats(int32_t R, int32_t S, uint32_t flags) {
 
 // ------------------------------------------------------------------ backward scratch layout
 namespace {
-struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dh_col, rows, dw1_part, dw2_part, wg_part, seg_rank, seg_list, total; };
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dy_col, rows, dw1_part, dw2_part, wg_part, seg_rank, seg_list, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -118,7 +118,7 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.hbar = o; if (color && gw && (flags & LK_FLAG_REL_POS)) o += al(128 * P);
     L.dfeat = o; if (color && (flags & LK_FLAG_REL_POS) && (flags & LK_FLAG_GRAD_FEATS)) o += al(8 * 32 * P);
     L.w_sum = o; o += al(P);
-    L.dh_col = o; if (color && gw) o += al(640 * P);
+    L.dy_col = o; if (color && gw) o += al(640 * P);
     // linear1 of the rel-pos MLP: neighbour rows for k_wgrad, or (mapper mode) the workgroup tiles of k_relpos_bwd_fused
     const bool rp_w = color && gw && (flags & LK_FLAG_REL_POS), fused = rp_w && lk_relpos_fused(flags);
     L.rows = o; if (rp_w && !fused) o += al(8 * 192 * P);
@@ -359,7 +359,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.rays_o = d->rays_o; db.rays_d = d->rays_d; db.z = d->z;
     db.W = d->weights; db.Wfrag = d->weights_frag; db.affine = d->affine;
     db.act = d->act; db.raw = d->raw; db.d_raw = S0 + L.d_raw;
-    db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dh_col = S0 + L.dh_col; db.dlogit = S0 + L.dlogit;
+    db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dy_col = S0 + L.dy_col; db.dlogit = S0 + L.dlogit;
     db.dp_embed = S0 + L.dp_embed; db.dp_embed_col = S0 + L.dp_embed_col; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.part_bg = S0 + L.part_bg;
     lk_launch_decode_bwd(db, st);
     // mapper 'color' backward with one weight-gradient launch: every partial-sum reduction is deferred to ONE launch at the end
@@ -378,35 +378,41 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     if (gw && color) {
         // colour decoder weight gradients as streamed reductions over the saved rows (geometry decoder weights
         // other than embedder._B are frozen in every reference config: mapping.fix_geo_decoder = True)
-        const float* act_a = d->act + (size_t)P * LK_ACT_GEO_A;
         const float* act_h = d->act + (size_t)P * (LK_ACT_GEO_A + LK_ACT_COL_A);
         const float* act_e = d->act + (size_t)P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H);
-        const float* dh = S0 + L.dh_col;
+        const float* dy = S0 + L.dy_col;           // d y_i = d h_i * softplus'(a_i), [layer][P][128]
         float* G = d->g_weights;
         LkWgradArgs wa;
         memset(&wa, 0, sizeof(wa));
         int nj = 0;
         const int w_off[5] = {C_W0, C_W1, C_W2, C_W3, C_W4}, b_off[5] = {C_B0, C_B1, C_B2, C_B3, C_B4};
         const int w_ld[5] = {EC, HC, HC, EC + HC, HC};
+        // c as auxiliary columns of job `src`: M = A^T c and the bias sums finish fc_c layer `layer` (LkFcPost, lk_kernels.h)
+        auto fc_from = [&](LkWgradJob& J, int src, int layer, const float* Wsrc, int rows_u, int ldw, int off) {
+            J.k_aux = J.K;
+            if (J.B2) { J.B3 = d->c_col; J.ldb3 = LK_C; J.k_split2 = J.K; }
+            else { J.B2 = d->c_col; J.ldb2 = LK_C; J.k_split = J.K; }
+            J.K += CF;
+            LkFcPost& F = wa.fc[wa.n_fc++];
+            F.src_job = src; F.rows_u = rows_u; F.ldw = ldw; F.off = off; F.W = Wsrc;
+            F.dU = G + C_U0 + layer * C_USTRIDE; F.du = F.dU + a64(HC * CF);
+        };
         for (int i = 0; i < 5; ++i) {
             LkWgradJob& J = wa.job[nj++];
-            J.A = dh + LK_COL_LAYER(P, i); J.lda = 128; J.a_mode = 1; J.A2 = act_a + LK_COL_LAYER(P, i); J.lda2 = 128;
+            J.A = dy + LK_COL_LAYER(P, i); J.lda = 128; J.a_mode = 0;
             if (i == 0) { J.B = act_e; J.ldb = LK_ACT_COL_E; }
             else if (i == 3) { J.B = act_e; J.ldb = LK_ACT_COL_E; J.B2 = act_h + LK_COL_LAYER(P, 2); J.ldb2 = 128; J.k_split = EC; }
             else { J.B = act_h + LK_COL_LAYER(P, i - 1); J.ldb = 128; }
             J.N = HC; J.K = w_ld[i]; J.rows = P; J.dW = G + w_off[i]; J.ldw = w_ld[i]; J.db = G + b_off[i];
-        }
-        for (int i = 0; i < 5; ++i) {
-            LkWgradJob& J = wa.job[nj++];
-            J.A = dh + LK_COL_LAYER(P, i); J.lda = 128; J.a_mode = 0;
-            J.B = d->c_col; J.ldb = LK_C;
-            J.N = HC; J.K = CF; J.rows = P; J.dW = G + C_U0 + i * C_USTRIDE; J.ldw = CF; J.db = G + C_U0 + i * C_USTRIDE + a64(HC * CF);
+            // d h_{i-1} = (hidden columns of W_i)^T d y_i
+            if (i >= 1) fc_from(J, nj - 1, i - 1, d->weights + w_off[i], HC, w_ld[i], i == 3 ? EC : 0);
         }
         {
             LkWgradJob& J = wa.job[nj++];
             J.A = S0 + L.dlogit; J.lda = 4; J.a_mode = 0;
             J.B = act_h + LK_COL_LAYER(P, 4); J.ldb = 128;
             J.N = 3; J.K = HC; J.rows = P; J.dW = G + C_WO; J.ldw = HC; J.db = G + C_BO;
+            fc_from(J, nj - 1, 4, d->weights + C_WO, 3, HC, 0);      // d h_4 = Wo^T d out
         }
         wa.n_jobs = nj; wa.chunk = 0; wa.part = S0 + L.wg_part;
         wa.h16 = (flags & LK_FLAG_UNIT_LOSS_GRADS) && !gr ? 1 : 0;

@@ -176,7 +176,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     f32x16 dc = lk_zero16(), de = lk_zero16();
     int buf = 0;
     // Split-bf16 products (lk_common.h::lk_mma6).  Loads and stores share one in-order counter, so what a layer needs
-    // right after its d h store - un = U_i^T blocks of the own units, av = saved a_i, wn = first four blocks of W_i^T for
+    // right after its d y store - un = U_i^T blocks of the own units, av = saved a_i, wn = first four blocks of W_i^T for
     // the own output block - is fetched BEFORE that store, at the end of the previous layer; blocks 4..7 come in line.
     Piece un[2], wn[4];
     f32x16 av;
@@ -201,23 +201,23 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     prefetch(4);
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
-        // (Round 1 stored a register COPY of d h here, believing that the row stores must not read the accumulators the next
-        // product overwrites.  The cause was elsewhere: the copy happened to stop the SLP vectoriser from turning the
-        // d h = Wo^T d out expression into packed-fp32 instructions, and it is those that corrupt lanes 48-63 of a register
-        // when two workgroups share a compute unit - see build.py and DESIGN.md §3.  The library is built without them;
-        // the stores read the accumulators directly.)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dy[q] = dh[q] * lk_softplus100_grad_from_out(av[q]);
+        // d y_i rows for the weight-gradient jobs (W_i and, through the auxiliary columns of job i, U_{i-1}: lk_kernels.h LkFcPost).
+        // (Round 1 stored a register COPY of its rows, believing that the stores must not read registers the next product
+        // overwrites.  The cause was elsewhere: the copy happened to stop the SLP vectoriser from turning d h = Wo^T d out into
+        // packed-fp32 instructions, and it is those that corrupt lanes 48-63 of a register when two workgroups share a compute
+        // unit - see build.py and DESIGN.md §3.  The library is built without them.)
         if (want_w) {
-            f32x16 dhs = dh;
+            f32x16 dys = dy;
             if (H16) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) dhs[q] = dh[q] * ISC;
+                for (int q = 0; q < 16; ++q) dys[q] = dy[q] * ISC;
             }
-            ct_store32(a.dh_col + LK_COL_LAYER(a.P, i) + (size_t)sp * 128 + w * 32, dhs, live, lane);
+            ct_store32(a.dy_col + LK_COL_LAYER(a.P, i) + (size_t)sp * 128 + w * 32, dys, live, lane);
         }
 #pragma unroll
         for (int G = 0; G < 2; ++G) dc = PC::mma(un[G], PC::split(dh, G), dc);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dy[q] = dh[q] * lk_softplus100_grad_from_out(av[q]);
         if (i == 0 && !want_p) break;
         u32x4* xs = s_x + buf * (24 * 64);
 #pragma unroll

@@ -842,7 +842,9 @@ __device__ __forceinline__ void rp_reduce_body(const float* __restrict__ part1, 
 // tile to a partial buffer with plain coalesced stores and k_wgrad_reduce sums the tiles (no atomics, reproducible).
 // The four waves of a workgroup are four consecutive UNITS of the same row chunk, and the grid walks units fastest:
 // the pieces of A / A2 / B that several units need are fetched from HBM once and re-read from L1/L2.
+#ifndef WG_STEPS
 #define WG_STEPS 16
+#endif
 #define WG_CHUNK (2 * WG_STEPS)                     // rows per chunk = one ring of row pairs
 
 template <int V> struct WgVec;
@@ -878,7 +880,8 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
     const float* __restrict__ pA2 = (MODE == 1) ? J.A2 + ncl : J.A2;
     const float* __restrict__ pB;
     int ldb;
-    if (J.B2 && kcol >= J.k_split) { pB = J.B2 + (kcol - J.k_split); ldb = J.ldb2; }
+    if (J.B3 && kcol >= J.k_split2) { pB = J.B3 + (kok[0] ? kcol - J.k_split2 : 0); ldb = J.ldb3; }
+    else if (J.B2 && kcol >= J.k_split) { pB = J.B2 + (kcol - J.k_split); ldb = J.ldb2; }
     else { pB = J.B + (kok[0] ? kcol : 0); ldb = J.ldb; }
     const int lda = J.lda, lda2 = J.lda2;
     constexpr int mode = MODE;
@@ -991,7 +994,7 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
     for (int bn = 0; bn < NV; ++bn)
 #pragma unroll
         for (int bk = 0; bk < KV; ++bk) {
-            if (!kok[bk]) continue;
+            if (!kok[bk] || (J.k_aux && kcol + bk >= J.k_aux)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nn = n0 + NV * lk_frag_row(r, h) + bn;
@@ -1009,9 +1012,13 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 
 template <int NV, int KV, bool H16>
 __device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile) {
+#ifdef LK_PROBE_WG_MODE0        // timing probe (tools/ab_build.sh): only the plain form, so that a deeper ring fits the register file
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile);
+#else
     if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile);
     else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile);
     else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile);
+#endif
 }
 
 // XCD-AWARE ROW OWNERSHIP.  Several units read the same rows (the 64-column pieces of one operand, or two jobs sharing
@@ -1068,7 +1075,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const LkWgradArgs& a, int bx, 
         const int blk = idx >> 10, r = (idx >> 6) & 15, lane = idx & 63, h = lane >> 5, j = lane & 31;
         const int bn = blk / kv, bk = blk - bn * kv;
         const int nn = U.n0 + nv * lk_frag_row(r, h) + bn, k = U.k0 + kv * j + bk;
-        if (nn < J.N && k < J.K) J.dW[(size_t)nn * J.ldw + k] += s;
+        if (nn < J.N && k < (J.k_aux ? J.k_aux : J.K)) J.dW[(size_t)nn * J.ldw + k] += s;     // auxiliary columns: fc_post_body
     } else if (in_bias) {
         const int tcol = idx - 4 * 16 * 64;
         if (J.db && U.k0 == 0 && U.n0 + tcol < J.N) J.db[U.n0 + tcol] += s;
@@ -1077,6 +1084,83 @@ __device__ __forceinline__ void wgrad_reduce_body(const LkWgradArgs& a, int bx, 
 __global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
     __shared__ float sh[8][32];
     wgrad_reduce_body(a, (int)blockIdx.x, (int)blockIdx.y, sh);
+}
+
+// fc_c gradients from the auxiliary columns (lk_kernels.h LkFcPost): block (f, kc) sums the partial tiles of column kc of
+// M = d y^T c (block kc = 32: of db = sum d y) of job fc[f].src_job itself - the tile sums of the same launch are not visible
+// yet - and adds W^T M[:, kc] (W^T db): one owner per output element, no atomics, reproducible.  The block is a chain of two
+// memory round trips (the tiles sit 16 KB apart, W's column walks its rows), so every load of a phase is issued before the first
+// is used: thread (e, g) sums the tiles y = g, g + 4, ... of element e; thread (v, uh) takes 64 rows of W.
+#define LK_FC_POST_COLS 33
+#define LK_FC_MAX_TILES 16            // loads in flight per thread: 8 n_waves <= 64 tiles of a unit over four thread groups
+struct LkFcPostLds { float part[4][128]; float m[128]; float half[2][128]; };
+__device__ __forceinline__ void fc_post_body(const LkWgradArgs& a, int f, int kc, LkFcPostLds& sh) {
+    const LkFcPost& F = a.fc[f];
+    const LkWgradJob& J = a.job[F.src_job];
+    const int t = (int)threadIdx.x;
+    const bool bias = kc == 32;
+    // phase 1: m[n] = column kc of M (or db), n = 0 .. 127
+    {
+        const int g = t >> 6, e = t & 63;                       // e = (bn, r, h): row n0 + nv * frag_row(r, h) + bn of the unit
+        float s2[2] = {0.0f, 0.0f};
+        int which = 0;
+        for (int u = 0; u < a.n_units && which < 2; ++u) {
+            const LkWgradUnit& U = a.unit[u];
+            if (U.job != F.src_job || U.k0 != (bias ? 0 : J.k_aux)) continue;
+            const int nblk = 8 * U.n_waves, nv = U.nv;
+            const float* __restrict__ src = a.part + (size_t)8 * U.wave0 * LK_WG_TILE;
+            const int bn = e >> 5, r = (e >> 1) & 15, h = e & 1;
+            // bias: element e = column e of the tile's bias section (row n0 + e)
+            const int off = bias ? 4 * 16 * 64 + e : (bn * 16 + r) * 64 + h * 32 + kc;
+            float s = 0.0f;
+            for (int y0 = 0; y0 < nblk; y0 += 4 * LK_FC_MAX_TILES) {          // one pass at the benchmark's sizes
+                float v[LK_FC_MAX_TILES];
+#pragma unroll
+                for (int q = 0; q < LK_FC_MAX_TILES; ++q) {
+                    const int y = y0 + g + 4 * q;
+                    v[q] = (y < nblk && e < 32 * nv) ? src[(size_t)y * LK_WG_TILE + off] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < LK_FC_MAX_TILES; ++q) s += v[q];
+            }
+            s2[which++] = s;
+        }
+        sh.part[g][e] = s2[0]; sh.part[g][64 + e] = s2[1];
+    }
+    __syncthreads();
+    if (t < 128) {
+        // units in table order: n0 = 0 then n0 = 64 (nv = 2), or the single nv = 1 unit of the output job
+        const int which = t >> 6, e = t & 63;
+        const float s = ((sh.part[0][t] + sh.part[1][t]) + sh.part[2][t]) + sh.part[3][t];
+        const int nv = J.N > 32 ? 2 : 1;
+        int n;
+        if (bias) n = 64 * which + e;
+        else { const int bn = e >> 5, r = (e >> 1) & 15, h = e & 1; n = 64 * which + nv * lk_frag_row(r, h) + bn; }
+        const bool ok = (nv == 2 || (which == 0 && e < 32)) && n < 128;
+        if (ok) sh.m[n] = (n < J.N) ? s : 0.0f;
+    }
+    if (J.N <= 32 && t >= 32 && t < 128) sh.m[t] = 0.0f;
+    __syncthreads();
+    // phase 2: out[v] += sum_u W[u][off + v] m[u]
+    const int v = t & 127, uh = t >> 7;
+    const int u0 = uh * 64, u1 = F.rows_u < u0 + 64 ? F.rows_u : u0 + 64;
+    const float* __restrict__ Wv = F.W + F.off + v;
+    float w[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) w[q] = (u0 + q < u1) ? Wv[(size_t)(u0 + q) * F.ldw] : 0.0f;
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) acc = fmaf(w[q], sh.m[u0 + q], acc);
+    sh.half[uh][v] = acc;
+    __syncthreads();
+    if (t < 128) {
+        const float r = sh.half[0][t] + sh.half[1][t];
+        if (bias) F.du[t] += r; else F.dU[(size_t)t * 32 + kc] += r;
+    }
+}
+__global__ __launch_bounds__(256) void k_fc_post(LkWgradArgs a) {
+    __shared__ LkFcPostLds sh;
+    fc_post_body(a, (int)blockIdx.x / LK_FC_POST_COLS, (int)blockIdx.x % LK_FC_POST_COLS, sh);
 }
 
 // column sums of a partial table [n_parts][width] into out[width] (+=), 32 columns per workgroup, one owner per column
@@ -1098,7 +1182,11 @@ __device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, 
 // the Fourier-matrix partials of the two decoders.  Blocks [0, b_wg) | [b_wg, b_rp) | [b_rp, b_pg) | [b_pg, b_pr).
 __global__ __launch_bounds__(256) void k_bwd_reduce(LkWgradArgs wa, LkBwdReduceArgs r) {
     __shared__ float sh[8][32];
-    const int b = (int)blockIdx.x;
+    __shared__ LkFcPostLds sh_fc;
+    // the fc_c blocks are two dependent memory round trips long: first in the grid, or they start when the tile sums retire
+    const int n_fc = r.b_fc - r.b_pr;
+    if ((int)blockIdx.x < n_fc) { fc_post_body(wa, (int)blockIdx.x / LK_FC_POST_COLS, (int)blockIdx.x % LK_FC_POST_COLS, sh_fc); return; }
+    const int b = (int)blockIdx.x - n_fc;
     if (b < r.b_wg) wgrad_reduce_body(wa, b / r.ny, b % r.ny, sh);
     else if (b < r.b_rp) rp_reduce_body(r.part1, r.n1, r.part2, r.n2, r.dW1, r.db1, r.dW2, r.db2, b - r.b_wg, sh);
     else if (b < r.b_pg) col_reduce_body(r.part_bg, r.n_bg, 288, r.out_bg, b - r.b_rp, sh);
@@ -1110,7 +1198,8 @@ int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp,
     r.b_rp = r.b_wg + (with_rp ? LK_RP_REDUCE_BLOCKS : 0);
     r.b_pg = r.b_rp + (r.part_bg ? lk_cdiv(288, 32) : 0);
     r.b_pr = r.b_pg + (r.part_br ? 1 : 0);
-    if (r.b_pr > 0) hipLaunchKernelGGL(k_bwd_reduce, dim3(r.b_pr), dim3(256), 0, st, wa, r);
+    r.b_fc = r.b_pr + (r.b_wg > 0 ? wa.n_fc * LK_FC_POST_COLS : 0);
+    if (r.b_fc > 0) hipLaunchKernelGGL(k_bwd_reduce, dim3(r.b_fc), dim3(256), 0, st, wa, r);
     return LK_OK;
 }
 
@@ -1155,6 +1244,7 @@ int lk_launch_dw2_hbar(const LkRelposBwdArgs& a, float* dw2_part, hipStream_t st
 int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st, LkWgradArgs* deferred) {
     if (deferred) deferred->n_units = 0;
     if (a_in.n_jobs == 0 || max_rows <= 0) return LK_OK;
+    if (a_in.n_fc > 0 && !a_in.part) return LK_ERR_ARG;     // the auxiliary columns exist as partial tiles only
     LkWgradArgs a = a_in;
     // cut every job into (N piece) x (K piece) units of 32 or 64 columns
     a.n_units = 0;
@@ -1163,13 +1253,18 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st, LkWgr
         const LkWgradJob& J = a.job[j];
         for (int n0 = 0; n0 < J.N; n0 += 64) {
             const int nv = (J.N - n0 > 32) ? 2 : 1;
-            for (int k0 = 0; k0 < J.K; k0 += 64) {
-                const int kv = (J.K - k0 > 32) ? 2 : 1;
+            const int k_main = J.k_aux ? J.k_aux : J.K;     // the auxiliary columns are a k piece of their own (fc_post_body finds it by k0)
+            for (int k0 = 0; k0 < J.K; k0 += (k0 < k_main && k0 + 64 > k_main) ? k_main - k0 : 64) {
+                const int k_end = k0 < k_main ? k_main : J.K;
+                const int kv = (k_end - k0 > 32) ? 2 : 1;
                 if (a.n_units >= LK_WGRAD_MAX_UNITS) return LK_ERR_ARG;
                 LkWgradUnit& U = a.unit[a.n_units];
                 U.job = j; U.n0 = n0; U.k0 = k0; U.nv = nv; U.kv = kv;
                 // cost of a row pair: the MFMAs plus about one MFMA's worth of loads / element-wise work
-                work[a.n_units] = (double)J.rows * (nv * kv + (J.a_mode == 1 ? 1.0 : 0.5));
+                // cost of a row pair = the columns the wave loads (measured: with the wave slots in proportion to nv * kv + 0.5,
+                // "the matrix instructions", the narrow units trailed the sweep of the wide ones that read the same rows, their
+                // re-reads missed the XCD's L2 and the launch took 62 us instead of 50)
+                work[a.n_units] = (double)J.rows * (nv + kv);
                 total += work[a.n_units++];
             }
         }
@@ -1193,5 +1288,6 @@ int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st, LkWgr
     }
     if (deferred) { *deferred = a; return LK_OK; }     // the tiles are summed later (k_bwd_reduce)
     if (a.part) hipLaunchKernelGGL(k_wgrad_reduce, dim3(a.n_units, lk_cdiv(LK_WG_TILE, 32)), dim3(256), 0, st, a);
+    if (a.part && a.n_fc > 0) hipLaunchKernelGGL(k_fc_post, dim3(a.n_fc * LK_FC_POST_COLS), dim3(256), 0, st, a);
     return LK_OK;
 }

@@ -82,7 +82,7 @@ struct LkDecodeBwdArgs {
     const float* W; const float* Wfrag; const float* affine;
     const float* act; const float* raw; const float* d_raw;
     float* dc_geo; float* dc_col;                  // [P,32]
-    float* dh_col;                                 // [P,640] (GRAD_WEIGHTS)
+    float* dy_col;                                 // [5][P][128] d y_i = d h_i * softplus'(a_i): the rows the weight-gradient jobs stream (GRAD_WEIGHTS)
     float* dlogit;                                 // [P,4]   (GRAD_WEIGHTS)
     float* dp_embed;                               // [P,4]   (GRAD_RAYS) geometry-decoder embedding path
     float* dp_embed_col;                           // [P,4]   (GRAD_RAYS, colour stage) colour-decoder embedding path
@@ -180,13 +180,26 @@ struct LkWgradJob {
     const float* A2; int lda2;
     const float* B; int ldb;
     const float* B2; int ldb2; int k_split;        // optional second source for columns k >= k_split
-    int N, K;                                      // logical sizes (N <= 128, K <= 168)
+    const float* B3; int ldb3; int k_split2;       // optional third source for columns k >= k_split2 (> k_split)
+    int k_aux;                                     // > 0: columns k >= k_aux are not part of dW (their tiles feed fc_post_body only)
+    int N, K;                                      // logical sizes (N <= 128, K <= 200 with the auxiliary columns)
     int rows;
     float* dW; int ldw;                            // plain blob matrix [N][ldw]
     float* db;                                     // bias gradient [N] or NULL
 };
-#define LK_WGRAD_MAX_JOBS 16
+#define LK_WGRAD_MAX_JOBS 12
 #define LK_WGRAD_MAX_UNITS 48
+// fc_c weight gradients of the colour trunk WITHOUT their own reduction over the samples.  h_i = a_i + U_i c + u_i and
+// d h_i = W_{i+1}^T d y_{i+1} (hidden columns of W_{i+1}; d h_4 = Wo^T d out), so
+//   dU_i = sum_s d h_i[s] (x) c[s] = W_{i+1}^T (sum_s d y_{i+1}[s] (x) c[s]) = W_{i+1}^T M_{i+1},   du_i = W_{i+1}^T db_{i+1}:
+// the job that streams d y_{i+1} anyway carries c as 32 auxiliary B columns (M_{i+1}, [128][32]) and a 128 x 128 x 32 product per
+// layer finishes the job (fc_post_body) - the d h_i rows are neither stored by k_decode_bwd nor streamed a second time
+// (64 MB written and read per 5 000-ray batch, a third of the weight-gradient kernel's HBM bytes).
+struct LkFcPost {
+    int src_job, rows_u, ldw, off;                 // M / db of job src_job ([rows_u][32], [rows_u]); W[u][off + v], row stride ldw
+    const float* W;
+    float* dU; float* du;                          // [128][32] += W^T M, [128] += W^T db
+};
 struct LkWgradUnit { int job, n0, k0; short nv, kv; int wave0, n_waves; };   // columns [n0, n0 + 32 nv) x [k0, k0 + 32 kv) of job; its wave slots PER XCD
 struct LkWgradArgs {
     LkWgradJob job[LK_WGRAD_MAX_JOBS]; int n_jobs;
@@ -194,7 +207,9 @@ struct LkWgradArgs {
     LkWgradUnit unit[LK_WGRAD_MAX_UNITS]; int n_units, n_waves;   // filled by the launcher (n_waves: used slots per XCD)
     float* part;                                   // [n_waves][LK_WG_TILE] partial tiles (one per wave), or NULL (atomic flush)
     int h16;                                       // products on scaled fp16 pieces (unit-scale loss gradients only)
+    LkFcPost fc[5]; int n_fc;                      // fc_c gradients finished from the auxiliary columns (needs `part`)
 };
+static_assert(sizeof(LkWgradArgs) <= 3600, "LkWgradArgs travels as a kernel argument next to LkBwdReduceArgs (4 KB limit)");
 #define LK_WG_MAX_WAVES 2048                       // waves of one weight-gradient launch: two per SIMD, all co-resident
 #define LK_WG_TILE (4 * 16 * 64 + 64)              // floats per tile: accumulators [block][reg][lane] + bias sums
 // floats of LkWgradArgs::part (one tile per wave, whatever the problem size)
@@ -224,7 +239,7 @@ int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st);
 int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st, LkWgradArgs* deferred = nullptr);   // deferred: skip the tile sums, return the unit table
 // all partial-sum reductions of one backward in one launch (k_bwd_reduce, lk_bwd2.hip); block ranges are filled by the launcher
 struct LkBwdReduceArgs {
-    int b_wg, ny, b_rp, b_pg, b_pr;
+    int b_wg, ny, b_rp, b_pg, b_pr, b_fc;
     const float* part1; int n1; const float* part2; int n2; float* dW1; float* db1; float* dW2; float* db2;
     const float* part_bg; int n_bg; float* out_bg;
     const float* part_br; int n_br; float* out_br;

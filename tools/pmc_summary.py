@@ -10,7 +10,7 @@ for r in csv.DictReader(open(f)):
     cnt[k].add(r['Dispatch_Id'])
 names = sorted({c for k in agg for c in agg[k]})
 print('kernel'.ljust(28), 'n'.rjust(5), ' '.join(n[-18:].rjust(18) for n in names))
-key = 'SQ_WAVE_CYCLES' if 'SQ_WAVE_CYCLES' in names else ('SQ_INSTS_VMEM_RD' if 'SQ_INSTS_VMEM_RD' in names else names[0])
+key = 'GRBM_GUI_ACTIVE' if 'GRBM_GUI_ACTIVE' in names else 'SQ_WAVE_CYCLES' if 'SQ_WAVE_CYCLES' in names else ('SQ_INSTS_VMEM_RD' if 'SQ_INSTS_VMEM_RD' in names else names[0])
 for k in sorted(agg, key=lambda k: -agg[k].get(key, 0)):
     if not k.startswith(('k_', 'void k_')):
         continue
