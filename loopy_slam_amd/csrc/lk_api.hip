@@ -168,16 +168,21 @@ static void fill_sample_args(const lk_render_desc* d, int P, bool all_pos, LkSam
     sa.min_nn = d->min_nn;
     sa.z = d->z; sa.nbr_idx = d->nbr_idx; sa.nbr_w = d->nbr_w; sa.nbr_count = d->nbr_count; sa.c_geo = d->c_geo; sa.c_col = d->c_col;
     sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr; sa.live_rays = nullptr;
+    sa.seg_P = 0; sa.seg_cnt_stride = 0; sa.seg_live = nullptr;
 }
 // z and the neighbour lists of a batch (the part of the sampler that does not read the feature tables); needs ZERO_ABSENT /
 // ALL_DEPTH_POS batches (no far_bb statistics)
-int lk_presample(const lk_render_desc* d, hipStream_t st) {
+int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount* cnt) {
     LK_REQUIRE(d && d->knn && d->rays_o && d->rays_d && d->gt_depth && d->z && d->nbr_idx && d->nbr_w && d->nbr_count, "lk_presample: NULL buffer");
     LK_REQUIRE(d->flags & (LK_FLAG_ALL_DEPTH_POS | LK_FLAG_ZERO_ABSENT), "lk_presample: needs ALL_DEPTH_POS / ZERO_ABSENT");
     LK_REQUIRE((int64_t)d->R * d->S < (1ll << 31), "lk_presample: R*S too large");
     if (d->R == 0) return LK_OK;
     LkSampleArgs sa;
     fill_sample_args(d, d->R * d->S, true, sa);
+    if (cnt) {
+        sa.seg_cnt = d->knn->seg_cnt; sa.seg_cnt_stride = d->knn->seg_stride; sa.seg_rank = cnt->seg_rank; sa.row_mask = d->grad_row_mask;
+        sa.seg_P = cnt->P_iter; sa.seg_live = cnt->live_rays;
+    }
     return lk_launch_sample_interp(sa, st, 1);
 }
 

@@ -131,20 +131,25 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
 __global__ __launch_bounds__(256) void k_seg_count(LkFeatScatterArgs a) {
     const long long row = (long long)blockIdx.x * 256 + (int)threadIdx.x;
     if (row >= (long long)a.P * LK_K) return;
+    const int y = (int)blockIdx.y;                           // batch member (consecutive iterations)
+    const long long grow = (long long)y * a.P * LK_K + row;
     const int s = (int)(row >> 3);
-    const int idx = a.nbr_idx[row];
+    const int idx = a.nbr_idx[grow];
     int rk = -1;
-    const bool skipped = a.live_rays && s >= *a.live_rays * a.S;              // ray without a reading: its rows carry no gradient
-    if (!skipped && idx >= 0 && a.nbr_w[row] != 0.0f && a.nbr_count[s] >= a.min_nn && (!a.row_mask || a.row_mask[idx]))
-        rk = atomicAdd(a.seg_cnt + idx, 1);
-    a.seg_rank[row] = rk;
+    const bool skipped = a.live_rays && s >= a.live_rays[y] * a.S;              // ray without a reading: its rows carry no gradient
+    if (!skipped && idx >= 0 && a.nbr_w[grow] != 0.0f && a.nbr_count[(size_t)y * a.P + s] >= a.min_nn && (!a.row_mask || a.row_mask[idx]))
+        rk = atomicAdd(a.seg_cnt + (size_t)y * a.cnt_stride + idx, 1);
+    a.seg_rank[grow] = rk;
 }
 __global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
     const long long row = (long long)blockIdx.x * 256 + (int)threadIdx.x;
     if (row >= (long long)a.P * LK_K) return;
-    const int rk = a.seg_rank[row];
-    if (rk >= 0) a.seg_list[a.seg_off[a.nbr_idx[row]] + rk] = (int)row;
-    if (row == 0 && a.seg_total) *a.seg_total = a.seg_off[a.N];
+    const int y = (int)blockIdx.y;
+    const long long base = (long long)y * a.P * LK_K;
+    const int32_t* __restrict__ off = a.seg_off + (size_t)y * a.cnt_stride;
+    const int rk = a.seg_rank[base + row];
+    if (rk >= 0) a.seg_list[base + off[a.nbr_idx[base + row]] + rk] = (int)row;
+    if (row == 0 && a.seg_total) a.seg_total[y] = off[a.N];
 }
 
 #define LK_GATHER_CHUNK 16
@@ -1213,12 +1218,12 @@ int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_feat_gather, dim3(lk_cdiv((long long)a.P * LK_K, 8 * LK_GATHER_CHUNK)), dim3(256), 0, st, a);
     return LK_OK;
 }
-int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st) {
+int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st, int batch) {
     const int nb = lk_cdiv((long long)a.P * LK_K, 256);
     // seg_cnt is zero on entry: the scan of the previous sort cleared what that sort had counted
-    if (!counted) hipLaunchKernelGGL(k_seg_count, dim3(nb), dim3(256), 0, st, a);
-    lk_launch_scan_i32(a.seg_cnt, a.seg_off, a.seg_sums, a.N + 1, st);
-    hipLaunchKernelGGL(k_seg_place, dim3(nb), dim3(256), 0, st, a);
+    if (!counted) hipLaunchKernelGGL(k_seg_count, dim3(nb, batch), dim3(256), 0, st, a);
+    lk_launch_scan_i32(a.seg_cnt, a.seg_off, a.seg_sums, a.N + 1, st, batch, a.cnt_stride, a.sums_stride);
+    hipLaunchKernelGGL(k_seg_place, dim3(nb, batch), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st) {

@@ -51,6 +51,7 @@ struct LkGrid {
     int min_enc[3], max_enc[3];   // order-preserving int encodings of the AABB (reduction scratch)
 };
 
+#define LK_SEG_BATCH 8
 struct lk_knn_s {
     float cell_size;
     int64_t capacity;      // points
@@ -63,6 +64,7 @@ struct lk_knn_s {
     int32_t* rank_of;      // [capacity]
     int32_t* block_sums;   // scan scratch
     float* pos_own = nullptr;   // [capacity][3] original-order copy, allocated by the first lk_knn_append
+    int seg_stride = 0, seg_sums_stride = 0;   // ints per batch member of the three arrays below (LK_SEG_BATCH members: lk_map_frame sorts the rows of several iterations per launch)
     int32_t* seg_cnt = nullptr;    // [capacity + 1] rows per point (zero between calls): the feature-gradient gather of lk_render_bwd
     int32_t* seg_off = nullptr;    // [capacity + 1] their exclusive offsets
     int32_t* seg_sums = nullptr;   // scan scratch of seg_cnt

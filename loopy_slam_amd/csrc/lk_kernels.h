@@ -24,6 +24,9 @@ struct LkSampleArgs {
     float* z; int32_t* nbr_idx; float* nbr_w; int32_t* nbr_count; float* c_geo; float* c_col;
     // rows counted per point on the way (first pass of the backward's counting sort, see k_seg_count); seg_cnt == NULL: off
     int32_t* seg_cnt; int32_t* seg_rank; const uint8_t* row_mask;
+    // search-only launches over several iterations (lk_map_frame's chunks): sample p belongs to iteration y = p / seg_P and counts into
+    // seg_cnt + y * seg_cnt_stride; rays behind the live prefix seg_live[y] of their iteration are left out (0 / NULL: one batch)
+    int seg_P, seg_cnt_stride; const int32_t* seg_live;
     const int32_t* live_rays;                     // see LkRelposArgs: with it the sampler gives the skipped samples their colour feature (noise)
 };
 
@@ -134,11 +137,15 @@ struct LkFeatScatterArgs {
     int32_t* seg_rank;                             // [8P] rank of the row among the rows of its point, -1 = row takes no part
     int32_t* seg_list;                             // [8P] rows ordered by point
     int32_t* seg_total;                            // [1] number of rows in seg_list, written by k_seg_place (NULL: seg_off[N])
+    // a batch of sorts in one launch (blockIdx.y; lk_map_frame sorts the rows of several iterations ahead of its loop): member y reads
+    // nbr_* / live_rays / seg_total of iteration y (consecutive arrays) and uses seg_cnt / seg_off + y * cnt_stride, seg_sums + y * sums_stride
+    int cnt_stride, sums_stride;
     const int32_t* live_rays; int S;               // rows of rays >= *live_rays take no part (NULL: all)
     int N;
 };
-int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st);        // counted: k_sample_interp already ran the count pass
-int lk_launch_scan_i32(int32_t* data, int32_t* out, int32_t* block_sums, int total, hipStream_t st);   // out != data: data is cleared
+int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st, int batch = 1);        // counted: k_sample_interp already ran the count pass
+int lk_launch_scan_i32(int32_t* data, int32_t* out, int32_t* block_sums, int total, hipStream_t st,
+                       int batch = 1, int dstride = 0, int sstride = 0);   // out != data: data is cleared; batch members y at + y * stride
 
 struct LkRaysBwdArgs { int R, S; const float* z; const float* dp_total; float* g_rays_o; float* g_rays_d; };
 
@@ -219,7 +226,9 @@ inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_W
 enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, LK_FUSE_COMPOSITE_BWD = 8, LK_LOSS_PREZEROED = 16,
        LK_SEG_SORTED = 32 /* bwd: the forward (LK_FUSE_COMPOSITE_BWD + GRAD_FEATS) already sorted the rows by point */,
        LK_PRESAMPLED = 64 /* fwd: z / nbr_idx / nbr_w / nbr_count are given (lk_presample), only interpolate */ };
-int lk_presample(const lk_render_desc* d, hipStream_t st);
+// cnt: the batch holds n iterations of P_iter samples each (n <= LK_SEG_BATCH); their rows are counted per point on the way
+struct LkPresampleCount { int P_iter; int32_t* seg_rank; const int32_t* live_rays; };
+int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount* cnt = nullptr);
 bool lk_serial_mode();                                      // LK_SERIAL / lk_set_serial: one stream only
 // library-owned low-priority third stream (lk_map_frame's search ahead of the loop; small independent launches of the backward)
 #define LK_PRE_CHUNKS 16

@@ -89,9 +89,11 @@ __global__ __launch_bounds__(256) void k_count(const float* __restrict__ pos, in
 // (g == NULL: the length is the host-known `total_host` - lk_launch_scan_i32)
 // (out != data: the offsets go to `out` and the counts in `data` are cleared on the way - a counter array that is zero again
 // when its offsets exist needs no memset before its next use)
+// (gridDim.y > 1: a batch of independent scans, member y at data + y * dstride / block_sums + y * sstride)
 __global__ __launch_bounds__(256) void k_scan_block(int32_t* data, int32_t* out, int32_t* __restrict__ block_sums,
-                                                    const LkGrid* __restrict__ g, int total_host) {
+                                                    const LkGrid* __restrict__ g, int total_host, int dstride, int sstride) {
     __shared__ int wsum[4];
+    data += (size_t)blockIdx.y * dstride; out += (size_t)blockIdx.y * dstride; block_sums += (size_t)blockIdx.y * sstride;
     const int total = g ? g->ncells + 1 : total_host;
     const int base = blockIdx.x * SCAN_ITEMS;
     if (base >= total) return;                       // uniform per block
@@ -124,9 +126,10 @@ __global__ __launch_bounds__(256) void k_scan_block(int32_t* data, int32_t* out,
 }
 
 // exclusive scan of the block totals (single block, 256 at a time with a running carry)
-__global__ __launch_bounds__(256) void k_scan_sums(int32_t* __restrict__ block_sums, const LkGrid* __restrict__ g, int total_host) {
+__global__ __launch_bounds__(256) void k_scan_sums(int32_t* __restrict__ block_sums, const LkGrid* __restrict__ g, int total_host, int sstride) {
     __shared__ int wsum[4];
     __shared__ int carry;
+    block_sums += (size_t)blockIdx.x * sstride;              // one workgroup per batch member
     const int nb = ((g ? g->ncells + 1 : total_host) + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (t == 0) carry = 0;
@@ -152,7 +155,8 @@ __global__ __launch_bounds__(256) void k_scan_sums(int32_t* __restrict__ block_s
 }
 
 __global__ __launch_bounds__(256) void k_scan_add(int32_t* __restrict__ data, const int32_t* __restrict__ block_sums,
-                                                  const LkGrid* __restrict__ g, int total_host) {
+                                                  const LkGrid* __restrict__ g, int total_host, int dstride, int sstride) {
+    data += (size_t)blockIdx.y * dstride; block_sums += (size_t)blockIdx.y * sstride;
     const int total = g ? g->ncells + 1 : total_host;
     const int base = blockIdx.x * SCAN_ITEMS;
     if (base >= total) return;
@@ -203,12 +207,12 @@ __global__ __launch_bounds__(256) void k_knn_query(const LkGrid* __restrict__ g,
 
 // ------------------------------------------------------------------ host API
 // in-place exclusive scan of `total` int32 counts (block_sums: lk_cdiv(total, 1024) + 256 ints of scratch)
-int lk_launch_scan_i32(int32_t* data, int32_t* out, int32_t* block_sums, int total, hipStream_t st) {
+int lk_launch_scan_i32(int32_t* data, int32_t* out, int32_t* block_sums, int total, hipStream_t st, int batch, int dstride, int sstride) {
     const int nb = lk_cdiv(total, SCAN_ITEMS);
-    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, st, data, out, block_sums, (const LkGrid*)nullptr, total);
+    hipLaunchKernelGGL(k_scan_block, dim3(nb, batch), dim3(256), 0, st, data, out, block_sums, (const LkGrid*)nullptr, total, dstride, sstride);
     if (nb > 1) {
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, block_sums, (const LkGrid*)nullptr, total);
-        hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, st, out, (const int32_t*)block_sums, (const LkGrid*)nullptr, total);
+        hipLaunchKernelGGL(k_scan_sums, dim3(batch), dim3(256), 0, st, block_sums, (const LkGrid*)nullptr, total, sstride);
+        hipLaunchKernelGGL(k_scan_add, dim3(nb, batch), dim3(256), 0, st, out, (const int32_t*)block_sums, (const LkGrid*)nullptr, total, dstride, sstride);
     }
     return LK_OK;
 }
@@ -225,6 +229,7 @@ extern "C" int lk_knn_create(float cell_size, int64_t capacity_points, int64_t m
     h->max_cells = max_cells;
     h->n = 0;
     h->n_scan_blocks = lk_cdiv(max_cells + 1, SCAN_ITEMS);
+    h->seg_stride = (int)(capacity_points + 1 + SCAN_ITEMS); h->seg_sums_stride = (int)(lk_cdiv(capacity_points + 1, SCAN_ITEMS) + 256);
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc((void**)&h->grid, sizeof(LkGrid));
     if (e == hipSuccess) e = hipMalloc((void**)&h->sorted, sizeof(float4) * (size_t)capacity_points);
@@ -232,10 +237,10 @@ extern "C" int lk_knn_create(float cell_size, int64_t capacity_points, int64_t m
     if (e == hipSuccess) e = hipMalloc((void**)&h->cell_of, sizeof(int32_t) * (size_t)capacity_points);
     if (e == hipSuccess) e = hipMalloc((void**)&h->rank_of, sizeof(int32_t) * (size_t)capacity_points);
     if (e == hipSuccess) e = hipMalloc((void**)&h->block_sums, sizeof(int32_t) * (size_t)(h->n_scan_blocks + 256));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_cnt, sizeof(int32_t) * (size_t)(capacity_points + 1 + SCAN_ITEMS));
-    if (e == hipSuccess) e = hipMemset(h->seg_cnt, 0, sizeof(int32_t) * (size_t)(capacity_points + 1 + SCAN_ITEMS));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_off, sizeof(int32_t) * (size_t)(capacity_points + 1 + SCAN_ITEMS));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_sums, sizeof(int32_t) * (size_t)(lk_cdiv(capacity_points + 1, SCAN_ITEMS) + 256));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_cnt, sizeof(int32_t) * (size_t)h->seg_stride * LK_SEG_BATCH);
+    if (e == hipSuccess) e = hipMemset(h->seg_cnt, 0, sizeof(int32_t) * (size_t)h->seg_stride * LK_SEG_BATCH);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_off, sizeof(int32_t) * (size_t)h->seg_stride * LK_SEG_BATCH);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->seg_sums, sizeof(int32_t) * (size_t)h->seg_sums_stride * LK_SEG_BATCH);
     if (e == hipSuccess) e = hipMemset(h->grid, 0, sizeof(LkGrid));
     if (e != hipSuccess) {
         lk_set_error("lk_knn_create: allocation failed: %s", hipGetErrorString(e));
@@ -281,9 +286,9 @@ extern "C" int lk_knn_build(lk_knn_t h, const float* pos, int64_t N, void* strea
         hipLaunchKernelGGL(k_zero_counts, dim3(2048), dim3(256), 0, st, h->cell_start, h->grid);
         hipLaunchKernelGGL(k_count, dim3(lk_cdiv(n, 256)), dim3(256), 0, st, pos, n, h->grid, h->cell_start,
                            h->cell_of, h->rank_of);
-        hipLaunchKernelGGL(k_scan_block, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->cell_start, h->block_sums, h->grid, 0);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, h->block_sums, h->grid, 0);
-        hipLaunchKernelGGL(k_scan_add, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->block_sums, h->grid, 0);
+        hipLaunchKernelGGL(k_scan_block, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->cell_start, h->block_sums, h->grid, 0, 0, 0);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, h->block_sums, h->grid, 0, 0);
+        hipLaunchKernelGGL(k_scan_add, dim3(h->n_scan_blocks), dim3(256), 0, st, h->cell_start, h->block_sums, h->grid, 0, 0, 0);
         hipLaunchKernelGGL(k_scatter, dim3(lk_cdiv(n, 256)), dim3(256), 0, st, pos, n, h->cell_start, h->cell_of,
                            h->rank_of, h->sorted);
     }

@@ -273,7 +273,7 @@ MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     // the rows of every iteration sorted by point (feature-gradient gather), also ahead of the loop: [iters][8P] + [iters] + scratch [8P]
     w.seg_list = o; o += al4(iters * P * LK_K);
     w.seg_total = o; o += al4(iters);
-    w.seg_rank = o; o += al4(P * LK_K);
+    w.seg_rank = o; o += al4(P * LK_K * LK_SEG_BATCH);        // the rows of up to LK_SEG_BATCH iterations are sorted per launch
     w.total = o;
     return w;
 }
@@ -461,20 +461,27 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         sd.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray + (size_t)c0 * R : nullptr;
         sd.z = W0 + wk.z + (size_t)c0 * Pn; sd.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)c0 * Pn;
         sd.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)c0 * Pn * LK_K; sd.nbr_w = W0 + wk.nbr_w + (size_t)c0 * Pn * LK_K;
-        int rc = lk_presample(&sd, pst);
+        const bool counted = sort_ahead && nc <= LK_SEG_BATCH;       // the search counts the rows per point of its iterations on the way
+        LkPresampleCount pc;
+        pc.P_iter = (int)Pn; pc.seg_rank = reinterpret_cast<int32_t*>(W0 + wk.seg_rank); pc.live_rays = reinterpret_cast<const int32_t*>(W0 + wk.n_live) + c0;
+        sd.grad_row_mask = d->render.grad_row_mask;
+        int rc = lk_presample(&sd, pst, counted ? &pc : nullptr);
         if (rc != LK_OK) return rc;
-        for (int it = c0; sort_ahead && it < c0 + nc; ++it) {
+        for (int it = c0; sort_ahead && it < c0 + nc; it += LK_SEG_BATCH) {       // batches of consecutive iterations: five launches each
+            const int nbatch = c0 + nc - it < LK_SEG_BATCH ? c0 + nc - it : LK_SEG_BATCH;
+            const lk_knn_s* kn = d->render.knn;
             LkFeatScatterArgs fs;
             memset(&fs, 0, sizeof(fs));
-            fs.P = (int)Pn; fs.min_nn = d->render.min_nn; fs.row_mask = d->render.grad_row_mask; fs.N = (int)d->render.knn->n;
+            fs.P = (int)Pn; fs.min_nn = d->render.min_nn; fs.row_mask = d->render.grad_row_mask; fs.N = (int)kn->n;
             fs.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)it * Pn * LK_K; fs.nbr_w = W0 + wk.nbr_w + (size_t)it * Pn * LK_K;
             fs.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)it * Pn;
-            fs.seg_cnt = d->render.knn->seg_cnt; fs.seg_off = d->render.knn->seg_off; fs.seg_sums = d->render.knn->seg_sums;
+            fs.seg_cnt = kn->seg_cnt; fs.seg_off = kn->seg_off; fs.seg_sums = kn->seg_sums;
+            fs.cnt_stride = kn->seg_stride; fs.sums_stride = kn->seg_sums_stride;
             fs.seg_rank = reinterpret_cast<int32_t*>(W0 + wk.seg_rank);
             fs.seg_list = reinterpret_cast<int32_t*>(W0 + wk.seg_list) + (size_t)it * Pn * LK_K;
             fs.seg_total = reinterpret_cast<int32_t*>(W0 + wk.seg_total) + it;
             fs.live_rays = reinterpret_cast<const int32_t*>(W0 + wk.n_live) + it; fs.S = d->render.S;
-            rc = lk_launch_seg_sort(fs, false, pst);
+            rc = lk_launch_seg_sort(fs, counted, pst, nbatch);
             if (rc != LK_OK) return rc;
         }
         if (ps.ok) (void)hipEventRecord(ps.ev[c % LK_PRE_CHUNKS], pst);

@@ -108,7 +108,17 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
             }
             if (sub == 0) { a.nbr_count[pidx] = count; a.z[pidx] = z; }
         }
-        if (MODE == 1) return;
+        if (MODE == 1) {      // lists only; the rows of every iteration of the chunk are counted per point on the way (k_seg_count's test)
+            if (a.seg_cnt && sub < LK_K) {
+                const int y = a.seg_P ? pidx / a.seg_P : 0;
+                const bool skipped = a.seg_live && r - y * (a.seg_P / a.S) >= a.seg_live[y];
+                int rk = -1;
+                if (!skipped && ij >= 0 && wj != 0.0f && count >= a.min_nn && (!a.row_mask || a.row_mask[ij]))
+                    rk = atomicAdd(a.seg_cnt + (size_t)y * a.seg_cnt_stride + ij, 1);
+                a.seg_rank[(size_t)pidx * LK_K + sub] = rk;
+            }
+            return;
+        }
         // first pass of the backward's counting sort of the rows by point (k_seg_count, lk_bwd2.hip), while the indices are here
         if (a.seg_cnt && sub < LK_K) {
             int rk = -1;
