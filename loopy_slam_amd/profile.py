@@ -8,13 +8,15 @@ Algorithmic work per unit (DESIGN.md §Kernels states the same figures):
     decode bwd   (backward-data) geometry 15 392 ; colour 86 400 (+ 10 240 embedding columns in tracker mode)
     rel-pos fwd  8 neighbours x (128x52 + 32x128) = 86 016 ;  bwd 8 x (128x52 fwd + 32x128 + 128x52 bwd) = 139 264
                  (+ 8 x 32x128 for the recomputed output in tracker mode)
-    wgrad        colour matrices 96 640 (k_wgrad); the rel-pos matrices ride in k_relpos_bwd_fused (linear1, 8 x 128x52) and
+    wgrad        colour matrices 92 640 (k_wgrad: W_0..W_4, Wo and the 32 auxiliary columns M_i = d y_i^T c of four trunk jobs and the
+                 output job, from which the reduction launch forms the fc_c gradients); the rel-pos matrices ride in
+                 k_relpos_bwd_fused (linear1, 8 x 128x52) and
                  k_dw2_hbar (linear2 from the per-sample Hbar, 32x128) in mapper mode
   bytes per SAMPLE POINT
     sample/interpolate  8 x 128 B feature rows per decoder gathered + 128 B written per decoder + 80 B
                         neighbour list/weights/count/z  (the grid candidate scan is extra, not counted)
     feature scatter     8 x 128 B read-modify-write per decoder + the gradient rows read (k_feat_gather)
-    weight gradients    7 984 B of saved rows per sample (k_wgrad: colour trunk)
+    weight gradients    5 424 B of saved rows per sample (k_wgrad: d y 640 + layer inputs 512 + e 40 + c 32 + h4 128 + d logit 4 floats)
     rel-pos backward    mapper mode: 8 x 128 B feature-row gradients + 512 B Hbar + 4 B written per sample (no neighbour rows)
 """
 import ctypes as C
@@ -38,7 +40,7 @@ MAC = dict(
     dec_bwd_geo=3 * 32 * 32 + 32 * 128 + 32 * 96 + 5 * 32 * 32 + 32,
     dec_bwd_col=3 * 128 * 128 + 128 * 128 + 5 * 128 * 32 + 3 * 128, dec_bwd_track_extra=2 * 128 * 40,
     rel_fwd=8 * (128 * 52 + 32 * 128), rel_bwd=8 * (2 * 128 * 52 + 32 * 128), rel_bwd_track_extra=8 * 32 * 128,
-    wgrad_col=96640, rel_dw1=8 * 128 * 52,
+    wgrad_col=128 * 40 + 3 * 128 * 128 + 128 * 168 + 3 * 128 + 4 * 128 * 32 + 3 * 32, rel_dw1=8 * 128 * 52,
 )
 
 
@@ -67,9 +69,9 @@ def work_per_step(b):
     rel = 1 if b.rel_pos else 0
     fl = lambda macs: 2.0 * macs
     feat_rows = 8 * 128
-    # bytes per sample read by the weight-gradient reductions: d h (640) + a (640) + layer inputs h0..h3 (512) + e (40)
-    # + c (32) + h4 (128) + d logit (4) floats
-    wg_bytes_col = 4.0 * (640 + 640 + 512 + 40 + 32 + 128 + 4)
+    # bytes per sample read by the weight-gradient reductions: d y (640) + layer inputs h0..h3 (512) + e (40) + c (32) + h4 (128)
+    # + d logit (4) floats
+    wg_bytes_col = 4.0 * (640 + 512 + 40 + 32 + 128 + 4)
     w = {
         'k_decode_fwd': dict(flops=fl(n_geo * Pm * MAC['dec_fwd_geo'] + (n_col * Pm + n_trk * Pt) * (MAC['dec_fwd_geo'] + MAC['dec_fwd_col'])),
                              bytes=0.0, launches=b.map_iters + n_trk),
