@@ -5,6 +5,7 @@
 //              MLP_*.get_feature_at_pos (src/conv_onet/models/decoder.py:180-231, 431-492),
 //              raw2outputs_nerf_color (src/common.py:382-422), Renderer.py:184-200.
 #include "lk_common.h"
+#define LK_SEARCH_WGS 512
 #include "lk_knn_dev.h"
 #include "lk_kernels.h"
 #include "lk_composite_dev.h"
@@ -46,9 +47,9 @@ __global__ __launch_bounds__(256) void k_depth_stats(const float* __restrict__ g
 // so lk_map_frame runs it for ALL its iterations ahead of time on a third stream (MODE 1: lists only) and every iteration starts
 // with MODE 2 (lists given: interpolation of the current features, the backward's row count).
 template <int T, int MODE>
-__global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
+__device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int block) {
     const int sub = (int)threadIdx.x & (T - 1);
-    const int p_raw = blockIdx.x * (256 / T) + (int)threadIdx.x / T;
+    const int p_raw = block * (256 / T) + (int)threadIdx.x / T;
     const bool live = p_raw < a.P;
     const int pidx = live ? p_raw : a.P - 1;           // dead groups shadow the last point, never store
     const int r = pidx / a.S, s = pidx - r * a.S;
@@ -162,6 +163,20 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
             a.noise_col ? *reinterpret_cast<const float4*>(a.noise_col + f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// MODE 1 (the look-ahead search of lk_map_frame, beside the iterations of the previous chunk) runs as a BOUNDED grid that walks its
+// sample groups: a chunk is 150 000 samples = 18 750 waves, and launched as such it takes every wave slot of the chip for ~110 us -
+// the iteration running beside it took 170 us instead of 78.  With at most LK_SEARCH_WGS workgroups (two per compute unit) the
+// search leaves three quarters of the slots to the loop's kernels, which are small ('geometry': 782 waves per launch).
+template <int T, int MODE>
+__global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
+    if (MODE == 1) {
+        const int nblk = (a.P + 256 / T - 1) / (256 / T);
+        for (int b = (int)blockIdx.x; b < nblk; b += (int)gridDim.x) sample_interp_block<T, MODE>(a, b);
+    } else {
+        sample_interp_block<T, MODE>(a, (int)blockIdx.x);
+    }
+}
+
 // One thread per ray: occupancy of unsupported samples := -100, alpha composite, validity.  With a.loss_out the mapper loss
 // of the batch (Mapper.py:691-720) rides along: per-ray terms and gradients here, one block sum and four atomics per block
 // (a launch at the latency floor leaves every mapping iteration).
@@ -221,8 +236,10 @@ int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hip
 }
 int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode) {
     if (mode == 1) {         // lists only, ahead of time: not one of the timed per-iteration launches
-        if (a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16, 1>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_sample_interp<8, 1>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
+        const int cap = LK_SEARCH_WGS;      // measured: 256 / 512 / 1024 / unbounded -> map call 15.4 / 15.0 / 15.4 / 15.3 ms
+        auto grid = [&](int per) { const int n = lk_cdiv(a.P, per); return n < cap ? n : cap; };
+        if (a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16, 1>), dim3(grid(16)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_sample_interp<8, 1>), dim3(grid(32)), dim3(256), 0, st, a);
         return LK_OK;
     }
     LkProfScope prof_(LKK_SAMPLE_INTERP, st);
