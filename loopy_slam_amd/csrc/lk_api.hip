@@ -371,7 +371,9 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     const bool defer = gw && color && (!relpos || lk_relpos_fused(flags));
     LkWgradArgs wdef;
     wdef.n_units = 0; wdef.part = nullptr;
-    if (gw && !defer) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
+    // the Fourier-matrix partials of k_decode_bwd: summed by a rider of the gather launch when there is one, else by their own launch
+    const bool bg_rides = gw && !defer && gf;
+    if (gw && !defer && !bg_rides) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
     const bool forked = gw && color && ss.ok;
     hipStream_t wst = st;                      // stream of the weight-gradient launches
@@ -445,6 +447,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         fs.g_geo_feats = d->g_geo_feats; fs.g_col_feats = d->g_col_feats;
         if (ex && ex->seg_list) { fs.seg_list = ex->seg_list; fs.seg_total = ex->seg_total; }      // sorted ahead of the loop (lk_map_frame)
         else if (ss.ok) (void)hipStreamWaitEvent(st, ss.link, 0);
+        if (bg_rides) { fs.red_part = S0 + L.part_bg; fs.red_n = lk_cdiv(lk_cdiv(P, 32), 4); fs.red_width = 288; fs.red_out = d->g_weights + G_EB; }
         lk_launch_feat_scatter(fs, st);
     }
     if (gr) {

@@ -153,7 +153,13 @@ __global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
 }
 
 #define LK_GATHER_CHUNK 16
+__device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out, int bx, float (*sh)[32]);
 __global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
+    if (a.red_part && (int)blockIdx.x >= a.red_block0) {     // rider: column sums of a partial table of the kernel before (one launch less)
+        __shared__ float sh[8][32];
+        col_reduce_body(a.red_part, a.red_n, a.red_width, a.red_out, (int)blockIdx.x - a.red_block0, sh);
+        return;
+    }
     const int c = (int)threadIdx.x & 31;
     const long long i0 = ((long long)blockIdx.x * 8 + ((int)threadIdx.x >> 5)) * LK_GATHER_CHUNK;
     const int total = a.seg_total ? *a.seg_total : a.seg_off[a.N];
@@ -1215,7 +1221,9 @@ int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
 }
 int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_FEAT_SCATTER, st);
-    hipLaunchKernelGGL(k_feat_gather, dim3(lk_cdiv((long long)a.P * LK_K, 8 * LK_GATHER_CHUNK)), dim3(256), 0, st, a);
+    LkFeatScatterArgs b = a;
+    b.red_block0 = lk_cdiv((long long)a.P * LK_K, 8 * LK_GATHER_CHUNK);
+    hipLaunchKernelGGL(k_feat_gather, dim3(b.red_block0 + (a.red_part ? lk_cdiv(a.red_width, 32) : 0)), dim3(256), 0, st, b);
     return LK_OK;
 }
 int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st, int batch) {

@@ -140,6 +140,8 @@ struct LkFeatScatterArgs {
     // a batch of sorts in one launch (blockIdx.y; lk_map_frame sorts the rows of several iterations ahead of its loop): member y reads
     // nbr_* / live_rays / seg_total of iteration y (consecutive arrays) and uses seg_cnt / seg_off + y * cnt_stride, seg_sums + y * sums_stride
     int cnt_stride, sums_stride;
+    // k_feat_gather rider: out[width] += column sums of part[n][width] (the geometry Fourier-matrix partials of k_decode_bwd), blocks >= red_block0
+    const float* red_part; int red_n, red_width, red_block0; float* red_out;
     const int32_t* live_rays; int S;               // rows of rays >= *live_rays take no part (NULL: all)
     int N;
 };
