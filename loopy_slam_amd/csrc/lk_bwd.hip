@@ -87,7 +87,9 @@ template <> struct BwdPiece<true> {
     static __device__ __forceinline__ int tr(int idx) { return FRAG_TRH[idx]; }
 };
 
-template <bool H16>
+// DEEP: as in the forward (lk_decode.hip) - launches whose tiles are all resident at once fetch more blocks of W_i^T ahead
+// (all eight; the register count of the kernel is set by its geometry role)
+template <bool H16, bool DEEP>
 __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int tile, int w, int lane,
                                                   u32x4* __restrict__ s_x /* [2][24*64] */, float (*s_o)[3 * 32]) {
     typedef BwdPiece<H16> PC;
@@ -178,7 +180,8 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     // Split-bf16 products (lk_common.h::lk_mma6).  Loads and stores share one in-order counter, so what a layer needs
     // right after its d y store - un = U_i^T blocks of the own units, av = saved a_i, wn = first four blocks of W_i^T for
     // the own output block - is fetched BEFORE that store, at the end of the previous layer; blocks 4..7 come in line.
-    Piece un[2], wn[4];
+    constexpr int NPF = DEEP ? 8 : 4;
+    Piece un[2], wn[NPF];
     f32x16 av;
     auto prefetch = [&](int i) {
         const u32x4* ut = FB + PC::tr(15 + i);
@@ -188,7 +191,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         if (i >= 1) {
             const u32x4* wt = FB + PC::tr(10 + i);
 #pragma unroll
-            for (int G = 0; G < 4; ++G) wn[G] = PC::load(wt, i == 3 ? 6 : 4, G, i == 3 ? 2 + w : w, lane);
+            for (int G = 0; G < NPF; ++G) wn[G] = PC::load(wt, i == 3 ? 6 : 4, G, i == 3 ? 2 + w : w, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -233,7 +236,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
             const int nbt = i == 3 ? 6 : 4, nb = i == 3 ? 2 + w : w;
             dh = lk_zero16();
 #pragma unroll
-            for (int G = 0; G < 8; ++G) dh = PC::mma(G < 4 ? wn[G] : PC::load(wt, nbt, G, nb, lane), lds_b(xs, G), dh);
+            for (int G = 0; G < 8; ++G) dh = PC::mma(G < NPF ? wn[G] : PC::load(wt, nbt, G, nb, lane), lds_b(xs, G), dh);
             if (i == 3 && want_p && w < 2) {
 #pragma unroll
                 for (int G = 0; G < 8; ++G) de = PC::mma(PC::load(FB + PC::tr(13), 6, G, w, lane), lds_b(xs, G), de);
@@ -371,13 +374,13 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
 // wave serialise in the memory-side atomic unit): the embedding-matrix gradient is therefore reduced
 // wave -> LDS -> one partial row per workgroup, and summed by k_reduce_partials.
 // Block roles as in k_decode_fwd: the first n_col_blocks workgroups are colour tiles, the rest geometry (4 tiles each).
-template <bool H16>
+template <bool H16, bool DEEP>
 __global__ __launch_bounds__(256, 2) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
     __shared__ u32x4 s_x[2 * 24 * 64];
     __shared__ float s_o[4][3 * 32];
     const int w = (int)threadIdx.x >> 6;
     if ((int)blockIdx.x < n_col_blocks) {
-        decode_bwd_col_wg<H16>(a, blockIdx.x, w, lk_lane(), s_x, s_o);
+        decode_bwd_col_wg<H16, DEEP>(a, blockIdx.x, w, lk_lane(), s_x, s_o);
         return;
     }
     float (*s_part)[3 * EGP] = reinterpret_cast<float (*)[3 * EGP]>(s_x);
@@ -431,7 +434,11 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
     // fp16 pieces only for unit-scale loss gradients without ray gradients (mapper mode), see decode_bwd_col_wg
     const bool h16 = (a.flags & LK_FLAG_UNIT_LOSS_GRADS) && !(a.flags & LK_FLAG_GRAD_RAYS);
-    if (h16) hipLaunchKernelGGL((k_decode_bwd<true>), dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
-    else hipLaunchKernelGGL((k_decode_bwd<false>), dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
+    const bool deep = n_col > 0 && n_col <= 512;
+    const dim3 grid(n_col + lk_cdiv(tiles, 4));
+    if (h16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true>), grid, dim3(256), 0, st, a, n_col);
+    else if (h16) hipLaunchKernelGGL((k_decode_bwd<true, false>), grid, dim3(256), 0, st, a, n_col);
+    else if (deep) hipLaunchKernelGGL((k_decode_bwd<false, true>), grid, dim3(256), 0, st, a, n_col);
+    else hipLaunchKernelGGL((k_decode_bwd<false, false>), grid, dim3(256), 0, st, a, n_col);
     return LK_OK;
 }

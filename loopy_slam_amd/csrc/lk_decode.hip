@@ -179,6 +179,13 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
     if (live && h == 0) a.raw[(size_t)d.sample * 4 + 3] = part + W[G_BO];
 }
 
+#ifdef LK_PROBE_CLK      // timing probe (tools/probe/decode_clock.py): shader-clock stamps of the first workgroups' waves at the phase boundaries
+__device__ unsigned long long lk_dbg_clk[8 * 4 * 32];
+#define LK_CLK(i) do { __builtin_amdgcn_sched_barrier(0); if (tile < 8 && lane == 0) lk_dbg_clk[(tile * 4 + w) * 32 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int lk_debug_clk_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(lk_dbg_clk), sizeof(lk_dbg_clk)); }
+#else
+#define LK_CLK(i)
+#endif
 // ================= colour decoder (hidden 128, softplus beta=100): FOUR waves = one 32-sample tile =================
 // Wave w owns output units [32w, 32w+32) of every layer (one accumulator, 48 matrix instructions per 128-wide layer), so
 // a tile's serial chain is a quarter of the one-wave form and a training batch (a few hundred tiles) spreads over four
@@ -186,8 +193,37 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
 // parks the bf16 pieces in LDS, [wave][16-k block][piece][lane] — the reader of block (w', G) is the SAME lane id in every
 // wave (the C/D-row walk), so writes and reads are both lane-contiguous (conflict-free ds_write/read_b128).
 // Double-buffered: one barrier per layer.
+// s_bias: the ten bias vectors of the trunk (b_0..b_4, u_0..u_4), staged once per workgroup: fetched in line they were two global
+// loads per layer, each waiting behind the weight fragments prefetched just before them (loads return in order) - 1-2 k cycles of
+// a 9 k-cycle layer (tools/probe/decode_clock.py).
+__device__ __forceinline__ f32x16 ct_bias_lds(const float* __restrict__ v, int unit0, int lane) {
+    const int h = lane >> 5;
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(v + unit0 + 8 * g + 4 * h);
+        t[4 * g + 0] = b.x; t[4 * g + 1] = b.y; t[4 * g + 2] = b.z; t[4 * g + 3] = b.w;
+    }
+    return t;
+}
+// DEEP (launches whose tiles are all resident at two workgroups per compute unit - the tracker's 235 tiles): ALL eight hidden blocks of
+// the next layer (and the three embedding blocks of layer 3) are fetched before the stores of the current one, 40 registers more;
+// with one tile per compute unit nothing else hides the L2 round trip of the in-line blocks (decode_clock.py: 2.5-5 k cycles per
+// product phase for 1 k cycles of matrix instructions).
+template <bool DEEP>
 __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
-                                              u32x4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */) {
+                                              u32x4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */,
+                                              float (*s_bias)[128] /* [10][128] */) {
+    LK_CLK(0);
+    {
+        const int t = (int)threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = q * 256 + t, j = e >> 7, u = e & 127;           // vector j: b_j (j < 5) or u_(j-5)
+            const int b_off[5] = {C_B0, C_B1, C_B2, C_B3, C_B4};
+            s_bias[j][u] = a.W[j < 5 ? b_off[j] + u : C_U0 + (j - 5) * C_USTRIDE + a64(HC * CF) + u];
+        }
+    }
     const DecSample d = dec_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
     const bool live = d.live;
@@ -218,10 +254,15 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     // a layer cannot be waited for without waiting for those stores too.  So everything a layer's epilogue and the head
     // of the next product need is fetched BEFORE the stores (wn: first four hidden blocks of the next layer, un: fc_c),
     // pinned with scheduling barriers; the tail of the product (blocks 4..7) is fetched in line, long after the stores.
-    LkH8 wn[4], un[2];
+    constexpr int NPF = DEEP ? 8 : 4;
+    LkH8 wn[NPF], un[2], we[DEEP ? 3 : 1];
     auto prefetch_hidden = [&](const u32x4* fragb, int G0) {
 #pragma unroll
-        for (int G = 0; G < 4; ++G) wn[G] = lk_fragh_load(fragb, 4, G0 + G, w, lane);
+        for (int G = 0; G < NPF; ++G) wn[G] = lk_fragh_load(fragb, 4, G0 + G, w, lane);
+        if (DEEP && G0 == 3) {
+#pragma unroll
+            for (int G = 0; G < 3; ++G) we[G] = lk_fragh_load(fragb, 4, G, w, lane);
+        }
     };
     auto prefetch_u = [&](const u32x4* ufragb) {
 #pragma unroll
@@ -234,19 +275,23 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
             LkH8 b;
 #pragma unroll
             for (int q = 0; q < 2; ++q) b.p[q] = s_x[buf][(G * 2 + q) * 64 + lane];
-            acc = lk_mma3h(G < 4 ? wn[G] : lk_fragh_load(fragb, 4, G0 + G, w, lane), b, acc);
+            acc = lk_mma3h(G < NPF ? wn[G] : lk_fragh_load(fragb, 4, G0 + G, w, lane), b, acc);
         }
     };
-    auto embed = [&](f32x16& acc, const u32x4* fragb) {
+    auto embed = [&](f32x16& acc, const u32x4* fragb, bool fetched) {
 #pragma unroll
-        for (int G = 0; G < 3; ++G) acc = lk_mma3h(lk_fragh_load(fragb, 4, G, w, lane), eb[G], acc);
+        for (int G = 0; G < 3; ++G) acc = lk_mma3h((DEEP && fetched) ? we[G] : lk_fragh_load(fragb, 4, G, w, lane), eb[G], acc);
     };
     // bias + softplus + fc_c(c) for the wave's own 32-unit block, then ALL stores of the layer: saved a / h rows, LDS park
-    auto finish = [&](f32x16& acc, const float* ubias, float* save_a, int L, int buf) {
+    auto finish = [&](f32x16& acc, float* save_a, int L, int buf) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);          // acc started from the layer's bias
         const f32x16 act = acc;
-        lk_add_rowvec(acc, ubias, w * 32, lane);
+        {
+            const f32x16 ub = ct_bias_lds(s_bias[5 + L], w * 32, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += ub[r];
+        }
 #pragma unroll
         for (int G = 0; G < 2; ++G) acc = lk_mma3h(un[G], cb[G], acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -262,40 +307,53 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         }
     };
     f32x16 acc;
+    LK_CLK(1);
     // layer 0: 40 -> 128
     prefetch_u(FB + FM15_FWDH);
-    acc = lk_rowvec_tile(W + C_B0, w * 32, lane);
-    embed(acc, FB + FM10_FWDH);
+    __syncthreads();                                   // s_bias is complete (the first use of any of it)
+    acc = ct_bias_lds(s_bias[0], w * 32, lane);
+    embed(acc, FB + FM10_FWDH, false);
     prefetch_hidden(FB + FM11_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(acc, W + C_U0 + a64(HC * CF), act_col_a, 0, 0);
+    LK_CLK(2);
+    finish(acc, act_col_a, 0, 0);
+    LK_CLK(3);
     __syncthreads();
+    LK_CLK(4);
     // layers 1, 2: 128 -> 128
 #pragma unroll
     for (int L = 1; L <= 2; ++L) {
         prefetch_u(FB + (L == 1 ? FM16_FWDH : FM17_FWDH));
-        acc = lk_rowvec_tile(W + (L == 1 ? C_B1 : C_B2), w * 32, lane);
+        acc = ct_bias_lds(s_bias[L], w * 32, lane);
         hidden(acc, FB + (L == 1 ? FM11_FWDH : FM12_FWDH), 0, (L - 1) & 1);
         if (L == 1) prefetch_hidden(FB + FM12_FWDH, 0);
         else prefetch_hidden(FB + FM13_FWDH, 3);
         __builtin_amdgcn_sched_barrier(0);
-        finish(acc, W + C_U0 + L * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + LK_COL_LAYER(a.P, L) : nullptr, L, L & 1);
+        LK_CLK(2 + 3 * L);
+        finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, L) : nullptr, L, L & 1);
+        LK_CLK(3 + 3 * L);
         __syncthreads();
+        LK_CLK(4 + 3 * L);
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
     prefetch_u(FB + FM18_FWDH);
-    acc = lk_rowvec_tile(W + C_B3, w * 32, lane);
-    embed(acc, FB + FM13_FWDH);
+    acc = ct_bias_lds(s_bias[3], w * 32, lane);
+    embed(acc, FB + FM13_FWDH, true);
     hidden(acc, FB + FM13_FWDH, 3, 0);
     prefetch_hidden(FB + FM14_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(acc, W + C_U0 + 3 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + LK_COL_LAYER(a.P, 3) : nullptr, 3, 1);
+    LK_CLK(11);
+    finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, 3) : nullptr, 3, 1);
+    LK_CLK(12);
     __syncthreads();
+    LK_CLK(13);
     // layer 4
     prefetch_u(FB + FM19_FWDH);
-    acc = lk_rowvec_tile(W + C_B4, w * 32, lane);
+    acc = ct_bias_lds(s_bias[4], w * 32, lane);
     hidden(acc, FB + FM14_FWDH, 0, 1);
-    finish(acc, W + C_U0 + 4 * C_USTRIDE + a64(HC * CF), act_col_a ? act_col_a + LK_COL_LAYER(a.P, 4) : nullptr, 4, -1);
+    LK_CLK(14);
+    finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, 4) : nullptr, 4, -1);
+    LK_CLK(15);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
@@ -330,18 +388,21 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
             out[0] = o0; out[1] = o1; out[2] = o2;
         }
     }
+    LK_CLK(16);
 }
 
 // Block roles: the first `n_col_blocks` workgroups are colour tiles (4 waves per tile), the rest run the geometry
 // decoder (4 independent tiles per workgroup).  raw[:, 0:3] and raw[:, 3] are written by the two roles separately;
 // in the geometry stage there are no colour blocks and raw[:, 0:3] is zero-filled by the geometry wave.
+template <bool DEEP>
 __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col_blocks) {
     __shared__ u32x4 s_x[2][16 * 64];
     __shared__ float s_o[4][3 * 32];
+    __shared__ float s_bias[10][128];
     const int lane = lk_lane();
     const int w = (int)threadIdx.x >> 6;
     if ((int)blockIdx.x < n_col_blocks) {
-        decode_col_wg(a, blockIdx.x, w, lane, s_x, s_o);
+        decode_col_wg<DEEP>(a, blockIdx.x, w, lane, s_x, s_o, s_bias);
         return;
     }
     const int tile = ((int)blockIdx.x - n_col_blocks) * 4 + w;
@@ -445,7 +506,8 @@ int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
     const int tiles = lk_cdiv(a.P, 32);
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
-    hipLaunchKernelGGL(k_decode_fwd, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
+    if (n_col > 0 && n_col <= 512) hipLaunchKernelGGL(k_decode_fwd<true>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
+    else hipLaunchKernelGGL(k_decode_fwd<false>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     return LK_OK;
 }
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {
