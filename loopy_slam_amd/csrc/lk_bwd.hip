@@ -434,7 +434,7 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
     // fp16 pieces only for unit-scale loss gradients without ray gradients (mapper mode), see decode_bwd_col_wg
     const bool h16 = (a.flags & LK_FLAG_UNIT_LOSS_GRADS) && !(a.flags & LK_FLAG_GRAD_RAYS);
-    const bool deep = n_col > 0 && n_col <= 512;
+    const bool deep = n_col > 0 && n_col <= LK_DEEP_MAX_TILES;
     const dim3 grid(n_col + lk_cdiv(tiles, 4));
     if (h16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true>), grid, dim3(256), 0, st, a, n_col);
     else if (h16) hipLaunchKernelGGL((k_decode_bwd<true, false>), grid, dim3(256), 0, st, a, n_col);

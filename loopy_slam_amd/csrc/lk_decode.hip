@@ -506,7 +506,7 @@ int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
     const int tiles = lk_cdiv(a.P, 32);
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
-    if (n_col > 0 && n_col <= 512) hipLaunchKernelGGL(k_decode_fwd<true>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
+    if (n_col > 0 && n_col <= LK_DEEP_MAX_TILES_FWD) hipLaunchKernelGGL(k_decode_fwd<true>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     else hipLaunchKernelGGL(k_decode_fwd<false>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     return LK_OK;
 }

@@ -276,4 +276,11 @@ int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st);
 // The colour trunk's saved activations (a_i, h_i) and its d h_i rows are LAYER-MAJOR, [layer][P][128]: a job of the weight-gradient
 // reduction then streams one contiguous [P][128] array (512-byte pieces of 2.5-KB rows cost it a third of its bandwidth), and the 32
 // samples x 128 bytes a wave of the decoders stores per layer sit 512 bytes apart instead of 2 560.
+// colour tiles up to which the decoders take their deep-prefetch form (lk_decode.hip / lk_bwd.hip)
+#ifndef LK_DEEP_MAX_TILES
+#define LK_DEEP_MAX_TILES 512
+#endif
+#ifndef LK_DEEP_MAX_TILES_FWD
+#define LK_DEEP_MAX_TILES_FWD 512
+#endif
 #define LK_COL_LAYER(P, layer) ((size_t)(layer) * (size_t)(P) * 128)
