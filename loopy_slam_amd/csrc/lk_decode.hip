@@ -234,19 +234,49 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     // this sample's row of layer 0; layer L is LK_COL_LAYER(P, L) floats further (layer-major, lk_kernels.h)
     float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128 : nullptr;
     float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128 : nullptr;
-    // embedding (40 units = blocks 0, 1 and half of 2) and interpolated feature: B operands of two / five products, split once
+    // embedding (40 units = blocks 0, 1 and a quarter of 2) and interpolated feature: B operands of two / five products, split once.
+    // The forty sin / cos values are the same for the four waves: wave w evaluates register group g = w of block 0 (units 8 w + 4 h + t),
+    // wave 3 also block 1's four, and the fp16 pieces travel through s_x[1] (an activation buffer from layer 1's epilogue on, two
+    // barriers later) - 4 to 8 evaluations per lane instead of 20, a fifth of the kernel's VALU instructions.
     LkH8 eb[3], cb[2];
     {
-        const f32x16 e0 = sincos_embed_tile<4>(W + C_EB, 20, 0, a0, a1, a2, lane);
-        const f32x16 e1 = sincos_embed_tile<1>(W + C_EB, 20, 1, a0, a1, a2, lane);
-        if (save && live && w == 0) {    // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
-            float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
-            ct_store_rows32(erow, e0, true, lane);
-            *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1[0], e1[1], e1[2], e1[3]);
+        float ev[4], e1v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ev[t] = sincos_embed_unit(W + C_EB, 20, 8 * w + 4 * h + t, a0, a1, a2);
+        if (w == 3) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) e1v[t] = sincos_embed_unit(W + C_EB, 20, 32 + 4 * h + t, a0, a1, a2);
         }
-        eb[0] = lk_split_cth(e0, 0); eb[1] = lk_split_cth(e0, 1); eb[2] = lk_split_cth(e1, 0);
+        if (save && live) {              // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
+            float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
+            *reinterpret_cast<float4*>(erow + 8 * w + 4 * h) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+            if (w == 3) *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1v[0], e1v[1], e1v[2], e1v[3]);
+        }
+        // the same cut as lk_split8h: hi = rtz_f16 of the pair, lo = rtz_f16 of the remainders
+        auto cut2 = [&](float x, float y, unsigned& hi, unsigned& lo) {
+            const lk_f16x2 hh = __builtin_amdgcn_cvt_pkrtz(x, y);
+            const lk_f16x2 ll = __builtin_amdgcn_cvt_pkrtz(x - (float)hh[0], y - (float)hh[1]);
+            hi = __builtin_bit_cast(unsigned, hh); lo = __builtin_bit_cast(unsigned, ll);
+        };
+        unsigned* se = reinterpret_cast<unsigned*>(s_x[1]);
+        unsigned hi0, lo0, hi1, lo1;
+        cut2(ev[0], ev[1], hi0, lo0); cut2(ev[2], ev[3], hi1, lo1);
+        const int G = w >> 1, c0 = 2 * (w & 1);
+        *reinterpret_cast<uint2*>(se + ((G * 2 + 0) * 64 + lane) * 4 + c0) = make_uint2(hi0, hi1);
+        *reinterpret_cast<uint2*>(se + ((G * 2 + 1) * 64 + lane) * 4 + c0) = make_uint2(lo0, lo1);
+        if (w == 3) {
+            cut2(e1v[0], e1v[1], hi0, lo0); cut2(e1v[2], e1v[3], hi1, lo1);
+            s_x[1][(2 * 2 + 0) * 64 + lane] = u32x4{hi0, hi1, 0u, 0u};
+            s_x[1][(2 * 2 + 1) * 64 + lane] = u32x4{lo0, lo1, 0u, 0u};
+        }
         const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
         cb[0] = lk_split_cth(cc, 0); cb[1] = lk_split_cth(cc, 1);
+    }
+    __syncthreads();                                   // the embedding pieces and s_bias are complete
+#pragma unroll
+    for (int G = 0; G < 3; ++G) {
+        eb[G].p[0] = s_x[1][(G * 2 + 0) * 64 + lane];
+        eb[G].p[1] = s_x[1][(G * 2 + 1) * 64 + lane];
     }
     // a block travels to the other waves through LDS as SPLIT pieces (the producer splits once, the four consumers read
     // bf16): block (w, G), piece p at [((w*2 + G)*3 + p)*64 + lane], lane-contiguous 16-byte accesses both ways
@@ -310,7 +340,6 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     LK_CLK(1);
     // layer 0: 40 -> 128
     prefetch_u(FB + FM15_FWDH);
-    __syncthreads();                                   // s_bias is complete (the first use of any of it)
     acc = ct_bias_lds(s_bias[0], w * 32, lane);
     embed(acc, FB + FM10_FWDH, false);
     prefetch_hidden(FB + FM11_FWDH, 0);

@@ -53,6 +53,7 @@ struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
