@@ -134,6 +134,49 @@ def test_map_iterations_match_oracle(backend, rel_pos, native):
         assert float(err.max()) <= 2e-4 * max(1.0, float(W[n].abs().max())) + 2.0 * moved, (n, float(err.max()), moved)
 
 
+@pytest.mark.gpu
+def test_long_map_call_matches_the_statement_path():
+    """130 iterations in ONE lk_map_frame call: the look-ahead chunks are then nine iterations long - more than one batch of the
+    batched row sort (LK_SEG_BATCH = 8), rows counted by k_seg_count instead of inside the search - and the third stream runs
+    fourteen chunks ahead of the loop.  Reference: the same iterations as one launch sequence per statement (MapOptimizer.iterate:
+    search, count and sort inside every iteration).  Small learning rates keep the two fp32 trajectories together."""
+    eng = make_engine('hip')
+    c2w, depth_img, color_img, pos, geo, col = mini_scene()
+    W = syn.default_weights(seed=7)
+    R, iters, n_geo = 96, 130, 40
+    g = torch.Generator().manual_seed(5)
+    rnd_all = torch.randint(0, HH * WW, (iters, R), generator=g, dtype=torch.int32).to(eng.device)
+    rows = torch.arange(0, pos.shape[0], 2, dtype=torch.int32).to(eng.device)
+    lrs = {'geometry': (1e-4, 1e-3, 0.0), 'color': (2e-4, 2e-4, 2e-4)}
+    frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
+    fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
+    res = {}
+    for native in (True, False):
+        cfg = core.RenderCfg(rel_pos=True)
+        dec = core.DecoderBlob(eng).pack(W)
+        pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
+        knn = core.KnnIndex(eng, capacity=pos.shape[0])
+        knn.build(pos_d)
+        mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, rows, R, lrs, w_color=0.1)
+        mo.begin_frame()
+        if native:
+            log = eng.zeros(iters, 4)
+            mo.run(iters, n_geo, frames, rnd_all, fid, (0, HH, 0, WW), INTR, HH, WW, log)
+            losses = log[:, 0].cpu().numpy().copy()
+        else:
+            losses = np.array([float(mo.iterate('geometry' if it < n_geo else 'color', frames, rnd_all[it], fid, (0, HH, 0, WW), INTR, HH, WW)[0].cpu())
+                               for it in range(iters)])
+        res[native] = (losses, geo_d.cpu().clone(), col_d.cpu().clone(), {k: v.clone() for k, v in dec.unpack().items()})
+    la, lb = res[True][0], res[False][0]
+    assert np.isfinite(la).all() and la[-1] != la[n_geo]
+    np.testing.assert_allclose(la, lb, rtol=2e-3)
+    for i in (1, 2):
+        err = (res[True][i] - res[False][i]).abs()
+        assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-4 and float(err.max()) < 0.02, (i, float(err.max()))
+    for n, w in res[True][3].items():
+        assert float((w - res[False][3][n]).abs().max()) <= 2e-3 * max(1.0, float(w.abs().max())), n
+
+
 @pytest.mark.parametrize('backend', backends())
 @pytest.mark.parametrize('native,separate', ((True, True), (False, True), (True, False), (False, False)))
 def test_track_iterations_match_oracle(backend, native, separate):
