@@ -14,7 +14,7 @@
  *  - kernels are enqueued on `stream` (a hipStream_t; torch.cuda.current_stream().cuda_stream)
  *    and never synchronise the device; lk_render_bwd (and lk_render_fwd inside lk_map_frame) additionally fork part of their
  *    work onto ONE library-owned non-blocking stream, and lk_map_frame runs the neighbour search of its iterations ahead on a
- *    library-owned low-priority stream; both are joined back into `stream` with events, so results are complete in stream
+ *    library-owned third stream; both are joined back into `stream` with events, so results are complete in stream
  *    order (see lk_set_serial to switch them off).  These streams and the per-point scratch of an lk_knn_t are shared state:
  *    concurrent calls from several host threads must be ordered by the caller;
  *  - fp32 everywhere; indices int32; R rays, S samples/ray (<= 8), P = R*S points in

@@ -232,7 +232,7 @@ enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, L
 struct LkPresampleCount { int P_iter; int32_t* seg_rank; const int32_t* live_rays; };
 int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount* cnt = nullptr);
 bool lk_serial_mode();                                      // LK_SERIAL / lk_set_serial: one stream only
-// library-owned low-priority third stream (lk_map_frame's search ahead of the loop; small independent launches of the backward)
+// library-owned third stream (lk_map_frame's search ahead of the loop; small independent launches of the backward)
 #define LK_PRE_CHUNKS 16
 struct LkAuxStream { hipStream_t st = nullptr; hipEvent_t e0 = nullptr; hipEvent_t ev[LK_PRE_CHUNKS] = {}; hipEvent_t e1 = nullptr, e2 = nullptr; bool ok = false; };
 LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour lists

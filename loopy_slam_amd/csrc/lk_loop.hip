@@ -442,7 +442,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         pa.n_live = reinterpret_cast<int32_t*>(W0 + wk.n_live);
         hipLaunchKernelGGL(k_pregather, dim3(d->iters), dim3(1024), 0, st, pa);
     }
-    // Ahead of the loop, on the low-priority third stream, a few iterations per chunk: the neighbour search (one launch per chunk) and,
+    // Ahead of the loop, on the third stream, a few iterations per chunk: the neighbour search (one launch per chunk) and,
     // per iteration, the counting sort of its rows by point for the feature-gradient gather (count, scan, place: lk_bwd2.hip) - both read
     // the rays, the positions and the row mask only.  Chunk c + 1 is enqueued when the loop reaches chunk c.
     const bool sort_ahead = pre && d->render.g_geo_feats != nullptr;
