@@ -27,6 +27,8 @@ struct LkSampleArgs {
     // search-only launches over several iterations (lk_map_frame's chunks): sample p belongs to iteration y = p / seg_P and counts into
     // seg_cnt + y * seg_cnt_stride; rays behind the live prefix seg_live[y] of their iteration are left out (0 / NULL: one batch)
     int seg_P, seg_cnt_stride; const int32_t* seg_live;
+    // interpolation-only launches (mode 2): fragment repack of plain -> frag as a rider (k_interp_repack); NULL: none
+    const float* rp_plain; float* rp_frag; int rp_block0;
     const int32_t* live_rays;                     // see LkRelposArgs: with it the sampler gives the skipped samples their colour feature (noise)
 };
 
@@ -236,7 +238,8 @@ bool lk_serial_mode();                                      // LK_SERIAL / lk_se
 #define LK_PRE_CHUNKS 16
 struct LkAuxStream { hipStream_t st = nullptr; hipEvent_t e0 = nullptr; hipEvent_t ev[LK_PRE_CHUNKS] = {}; hipEvent_t e1 = nullptr, e2 = nullptr; bool ok = false; };
 LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour lists
-int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr);
+// repack_frag: with LK_PRESAMPLED, the interpolation launch also repacks d->weights into this fragment buffer (= d->weights_frag, writable)
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr, float* repack_frag = nullptr);
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total; };
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch

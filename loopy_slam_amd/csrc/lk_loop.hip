@@ -491,6 +491,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         const int rc = enqueue_chunk(0);
         if (rc != LK_OK) return rc;
     }
+    bool repack_pending = false;
     for (int it = it_begin; it < it_end; ++it) {
         const bool color = it >= d->n_geo_iters;
         lk_render_desc rd = d->render;
@@ -527,7 +528,10 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             }
             // the loss gradient is final when the composite kernel has written it: its backward rides in the same launch
             const int32_t* live = pre ? reinterpret_cast<const int32_t*>(W0 + wk.n_live) + it : nullptr;
-            rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0), live);
+            // the fragment repack of the iteration before rides in this iteration's interpolation launch (see the end of the loop body)
+            rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0), live,
+                                    repack_pending ? d->weights_frag_rw : nullptr);
+            repack_pending = false;
             if (rc != LK_OK) return rc;
             LkBwdExtra ex;
             memset(&ex, 0, sizeof(ex));
@@ -568,8 +572,12 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             int rc = lk_adam_step(seg, ns, beta1, beta2, eps, st);
             if (rc != LK_OK) return rc;
             if (color) {        // the matrix fragments are copies of the colour-decoder matrices, which only move in this stage
-                rc = lk_weights_repack(d->weights_rw, d->weights_frag_rw, st);
-                if (rc != LK_OK) return rc;
+                // (rd.weights == weights_rw: the next iteration's forward reads what this step wrote)
+                if (pre && (phases & 3) == 3 && it + 1 < it_end && d->render.weights == d->weights_rw) repack_pending = true;
+                else {
+                    rc = lk_weights_repack(d->weights_rw, d->weights_frag_rw, st);
+                    if (rc != LK_OK) return rc;
+                }
             }
         }
     }

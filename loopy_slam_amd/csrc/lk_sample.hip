@@ -5,6 +5,7 @@
 //              MLP_*.get_feature_at_pos (src/conv_onet/models/decoder.py:180-231, 431-492),
 //              raw2outputs_nerf_color (src/common.py:382-422), Renderer.py:184-200.
 #include "lk_common.h"
+#include "lk_weights_dev.h"
 #define LK_SEARCH_WGS 512
 #include "lk_knn_dev.h"
 #include "lk_kernels.h"
@@ -177,6 +178,19 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     }
 }
 
+// The interpolation launch of a mapping iteration with the fragment repack of the iteration BEFORE as a rider (blocks >= rp_block0):
+// both depend on that iteration's Adam step and on nothing of each other, and the repack's consumers come later in the stream - one
+// dispatch (9 us of kernel plus its gap) less per 'color' iteration.
+template <int T>
+__global__ __launch_bounds__(256) void k_interp_repack(LkSampleArgs a, FragTable tb) {
+    if ((int)blockIdx.x >= a.rp_block0) {
+        const int u = ((int)blockIdx.x - a.rp_block0) * 256 + (int)threadIdx.x;
+        if (u < LK_REPACK_UNITS) repack_unit(a.rp_plain, reinterpret_cast<u32x4*>(a.rp_frag), tb, u);
+        return;
+    }
+    sample_interp_block<T, 2>(a, (int)blockIdx.x);
+}
+
 // One thread per ray: occupancy of unsupported samples := -100, alpha composite, validity.  With a.loss_out the mapper loss
 // of the batch (Mapper.py:691-720) rides along: per-ray terms and gradients here, one block sum and four atomics per block
 // (a launch at the latency floor leaves every mapping iteration).
@@ -246,6 +260,15 @@ int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode) {
     if (mode == 2) {
         // with rel-pos colour features only the geometry rows are interpolated here: 8 lanes per point are enough
         const bool two = (a.flags & LK_FLAG_STAGE_COLOR) && !(a.flags & LK_FLAG_REL_POS);
+        if (a.rp_plain) {
+            LkSampleArgs b = a;
+            const bool wide = two && a.P <= (1 << 16);
+            b.rp_block0 = lk_cdiv(a.P, wide ? 16 : 32);
+            const dim3 grid(b.rp_block0 + lk_cdiv(LK_REPACK_UNITS, 256));
+            if (wide) hipLaunchKernelGGL((k_interp_repack<16>), grid, dim3(256), 0, st, b, lk_frag_table());
+            else hipLaunchKernelGGL((k_interp_repack<8>), grid, dim3(256), 0, st, b, lk_frag_table());
+            return LK_OK;
+        }
         if (two && a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16, 2>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_sample_interp<8, 2>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
         return LK_OK;

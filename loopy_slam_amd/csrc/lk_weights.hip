@@ -1,103 +1,10 @@
 // Fragment repack of the decoder weights (see lk_weights.h): plain master blob -> MFMA-operand-ordered split-bf16 copies
 // (forward and transposed) that the render kernels stream with fully coalesced 16-byte loads.  Runs once per optimiser
 // step (108k parameters; a few microseconds).
-#include "lk_common.h"
-
-using namespace lkw;
-
-struct FragTable { FragMat m[N_FRAG_MATS]; };
-
-// one lane-block element of the split-bf16 fragments: unit u = (matrix form, G, blk, lane), 8 weights -> 3 x 16 B
-__device__ void repack_split_unit(const float* __restrict__ plain, u32x4* __restrict__ fragb, const FragTable& tb, int u) {
-    const int blk_all = u >> 6, lane = u & 63;
-    const int o4 = blk_all * 192;                      // uint4 offset of the block
-    int mi = 0;
-#pragma unroll 1
-    for (int q = 1; q < N_FRAG_MATS; ++q) mi = (o4 >= tb.m[q].fwdb) ? q : mi;
-    const FragMat M = tb.m[mi];
-    const int h = lane >> 5, j = lane & 31;
-    float v[8];
-    if (o4 < M.trb) {                                  // forward: [G][nb], embedding run padded to 16 columns
-        const int blk = (o4 - M.fwdb) / 192;
-        const int NBT = M.rows >> 5;
-        const int G = blk / NBT, nb = blk - G * NBT;
-        const int ksplit = M.e_real < M.ld ? M.e_real : M.ld;
-        const int GE = kb16(ksplit);
-        const int kbase = G < GE ? 16 * G : ksplit + 16 * (G - GE);
-        const int kend = G < GE ? ksplit : M.ld;
-        const int row = nb * 32 + j;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int col = kbase + (i < 4 ? 4 * h + i : 8 + 4 * h + (i - 4));
-            v[i] = col < kend ? plain[M.plain + row * M.ld + col] : 0.0f;
-        }
-    } else {                                           // transposed: [G over the layer's outputs][kb over virtual inputs]
-        const int blk = (o4 - M.trb) / 192;
-        const int KB = M.kv >> 5;
-        const int G = blk / KB, kb = blk - G * KB;
-        const int vc = kb * 32 + j;
-        int col = -1;
-        if (vc < M.e_real) col = vc;
-        else if (vc >= M.e_virt) col = vc - (M.e_virt - M.e_real);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = 16 * G + (i < 4 ? 4 * h + i : 8 + 4 * h + (i - 4));
-            v[i] = (col >= 0 && col < M.ld) ? plain[M.plain + n * M.ld + col] : 0.0f;
-        }
-    }
-    const LkB8 s = lk_split8(v);
-    u32x4* __restrict__ q = fragb + o4 + lane;
-    q[0] = s.p[0]; q[64] = s.p[1]; q[128] = s.p[2];
-}
-
-// both forms once more as two fp16 pieces: unit u = (matrix form, G, blk, lane)
-__device__ void repack_half_unit(const float* __restrict__ plain, u32x4* __restrict__ fragh, const FragTable& tb, int u) {
-    const int blk_all = u >> 6, lane = u & 63;
-    const int o4 = blk_all * 128;
-    int mi = 0;
-#pragma unroll 1
-    for (int q = 1; q < N_FRAG_MATS; ++q) mi = (o4 >= tb.m[q].fwdh) ? q : mi;
-    const FragMat M = tb.m[mi];
-    const int h = lane >> 5, j = lane & 31;
-    float v[8];
-    if (o4 < M.trh) {
-        const int blk = (o4 - M.fwdh) / 128;
-        const int NBT = M.rows >> 5;
-        const int G = blk / NBT, nb = blk - G * NBT;
-        const int ksplit = M.e_real < M.ld ? M.e_real : M.ld;
-        const int GE = kb16(ksplit);
-        const int kbase = G < GE ? 16 * G : ksplit + 16 * (G - GE);
-        const int kend = G < GE ? ksplit : M.ld;
-        const int row = nb * 32 + j;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int col = kbase + (i < 4 ? 4 * h + i : 8 + 4 * h + (i - 4));
-            v[i] = col < kend ? plain[M.plain + row * M.ld + col] : 0.0f;
-        }
-    } else {
-        const int blk = (o4 - M.trh) / 128;
-        const int KB = M.kv >> 5;
-        const int G = blk / KB, kb = blk - G * KB;
-        const int vc = kb * 32 + j;
-        int col = -1;
-        if (vc < M.e_real) col = vc;
-        else if (vc >= M.e_virt) col = vc - (M.e_virt - M.e_real);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = 16 * G + (i < 4 ? 4 * h + i : 8 + 4 * h + (i - 4));
-            v[i] = (col >= 0 && col < M.ld) ? plain[M.plain + n * M.ld + col] : 0.0f;
-        }
-    }
-    const LkH8 s = lk_split8h(v);
-    u32x4* __restrict__ q = fragh + o4 + lane;
-    q[0] = s.p[0]; q[64] = s.p[1];
-}
+#include "lk_weights_dev.h"
 
 __global__ __launch_bounds__(256) void k_weights_repack(const float* __restrict__ plain, u32x4* __restrict__ fragb, FragTable tb) {
-    for (int u = blockIdx.x * 256 + (int)threadIdx.x; u < FRAGB_U4 / 3 + FRAGH_U4 / 2; u += gridDim.x * 256) {
-        if (u < FRAGB_U4 / 3) repack_split_unit(plain, fragb, tb, u);
-        else repack_half_unit(plain, fragb + FRAGB_U4, tb, u - FRAGB_U4 / 3);
-    }
+    for (int u = blockIdx.x * 256 + (int)threadIdx.x; u < LK_REPACK_UNITS; u += gridDim.x * 256) repack_unit(plain, fragb, tb, u);
 }
 
 // floats of the fragment buffer the caller allocates (opaque derived data: 3 x 16 B per lane-block element)
@@ -105,10 +12,8 @@ extern "C" int64_t lk_weight_frag_floats(void) { return 4 * ((int64_t)FRAGB_U4 +
 
 extern "C" int lk_weights_repack(const float* plain, float* frag, void* stream_) {
     LK_REQUIRE(plain && frag, "lk_weights_repack: NULL buffer");
-    static const FragMat rows[N_FRAG_MATS] = {LKW_FRAG_TABLE};
-    FragTable tb;
-    for (int i = 0; i < N_FRAG_MATS; ++i) tb.m[i] = rows[i];
-    hipLaunchKernelGGL(k_weights_repack, dim3(lk_cdiv(FRAGB_U4 / 3 + FRAGH_U4 / 2, 256)), dim3(256), 0, (hipStream_t)stream_, plain,
+    const FragTable tb = lk_frag_table();
+    hipLaunchKernelGGL(k_weights_repack, dim3(lk_cdiv(LK_REPACK_UNITS, 256)), dim3(256), 0, (hipStream_t)stream_, plain,
                        reinterpret_cast<u32x4*>(frag), tb);
     LK_LAUNCH_CHECK();
     return LK_OK;
