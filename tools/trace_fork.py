@@ -8,7 +8,7 @@ for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', ''), r.get('Queue_Id', '?')))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2].startswith('k_sample_interp') and not r[2].rstrip().endswith(', 1>')]
+starts = [i for i, r in enumerate(rows) if r[2].startswith('k_interp_repack') or (r[2].startswith('k_sample_interp') and not r[2].rstrip().endswith(', 1>'))]
 a, b = starts[-8], starts[-7]
 t0 = rows[a][0]
 for s, e, n, q in rows[a:b]:
