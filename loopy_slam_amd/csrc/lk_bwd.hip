@@ -1,6 +1,6 @@
 // Backward of the render graph (autograd of Renderer.render_batch_ray: Mapper.py:722, Tracker.py:193).
 //   k_composite_bwd   d(depth,var,color) -> d raw[P,4]                        (common.py:408-421)
-//   k_decode_bwd      d raw -> d c_geo, d c_col, d h_i (for wgrad), d p, d B_g  (decoder.py:263-288, 513-546)
+//   k_decode_bwd      d raw -> d c_geo, d c_col, d y_i rows (for k_wgrad), d p, d B_g  (decoder.py:263-288, 513-546)
 // Same register-chained scheme as the forward (CT tiles, bf16x6 products: lk_common.h) on the TRANSPOSED
 // weight fragments: dX^T = W^T dY^T, the dY CT tile being the B operand.
 #include "lk_common.h"

@@ -3,7 +3,9 @@
 //   k_seg_* / k_feat_gather  d c_geo / d c_col / per-neighbour rows -> feature-row gradients (rows sorted by point, one atomic per run)
 //   k_rays_bwd      d p -> d rays_o, d rays_d
 //   k_relpos_bwd    backward of the relative-position neighbour MLP (decoder.py:477-488)
-//   k_wgrad(+_reduce)  all decoder weight gradients as streamed MFMA reductions over the sample rows
+//   k_relpos_bwd_fused / k_dw2_hbar   mapper mode: the same backward with linear1's / linear2's weight gradients inside
+//   k_wgrad(+_reduce)  colour-trunk weight gradients as streamed MFMA reductions over the sample rows
+//   k_bwd_reduce    every partial-sum reduction of a mapper 'color' backward + the fc_c products (fc_post_body) in one launch
 #include "lk_common.h"
 #include "lk_kernels.h"
 
