@@ -169,7 +169,7 @@ static void fill_sample_args(const lk_render_desc* d, int P, bool all_pos, LkSam
     sa.z = d->z; sa.nbr_idx = d->nbr_idx; sa.nbr_w = d->nbr_w; sa.nbr_count = d->nbr_count; sa.c_geo = d->c_geo; sa.c_col = d->c_col;
     sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr; sa.live_rays = nullptr;
     sa.seg_P = 0; sa.seg_cnt_stride = 0; sa.seg_live = nullptr;
-    sa.rp_plain = nullptr; sa.rp_frag = nullptr; sa.rp_block0 = 0;
+    sa.rp_plain = nullptr; sa.rp_frag = nullptr; sa.rp_block0 = 0; sa.rp_copy_dst = nullptr; sa.rp_copy_n = 0; sa.rp_block1 = 0;
 }
 // z and the neighbour lists of a batch (the part of the sampler that does not read the feature tables); needs ZERO_ABSENT /
 // ALL_DEPTH_POS batches (no far_bb statistics)
@@ -189,7 +189,7 @@ int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount
 
 extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
 
-int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays, float* repack_frag) {
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays, const LkRepackRider* repack) {
     int rc = check_desc(d, "lk_render_fwd");
     if (rc != LK_OK) return rc;
     if (d->R == 0) return LK_OK;
@@ -209,8 +209,11 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         sa.seg_cnt = fs.seg_cnt; sa.seg_rank = fs.seg_rank; sa.row_mask = fs.row_mask;
     }
     sa.live_rays = live_rays;
-    LK_REQUIRE(!repack_frag || (skip & LK_PRESAMPLED), "lk_render_fwd: the repack rider needs a presampled batch");
-    if (repack_frag) { sa.rp_plain = d->weights; sa.rp_frag = repack_frag; }
+    LK_REQUIRE(!repack || (skip & LK_PRESAMPLED), "lk_render_fwd: the repack rider needs a presampled batch");
+    if (repack) {
+        sa.rp_plain = repack->src ? repack->src : d->weights; sa.rp_frag = repack->frag;
+        if (repack->copy_dst && repack->src) { sa.rp_copy_dst = repack->copy_dst; sa.rp_copy_n = repack->copy_n; }
+    }
     lk_launch_sample_interp(sa, st, (skip & LK_PRESAMPLED) ? 2 : 0);
     if (presort) {       // ... and sorted beside the decoders
         const int rc2 = seg_sort_async(d, P, true, st);
@@ -511,7 +514,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             r.part_br = S0 + L.part_br; r.n_br = lk_relpos_bwd_parts(P); r.out_br = G + R_EB;
         }
         r.part_bg = S0 + L.part_bg; r.n_bg = lk_cdiv(lk_cdiv(P, 32), 4); r.out_bg = G + G_EB;
-        lk_launch_bwd_reduce(wdef, r, with_rp, st);
+        lk_launch_bwd_reduce(wdef, r, with_rp, st, ex ? ex->step : nullptr);
     }
     LK_LAUNCH_CHECK();
     return LK_OK;

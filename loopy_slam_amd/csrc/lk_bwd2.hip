@@ -8,6 +8,7 @@
 //   k_bwd_reduce    every partial-sum reduction of a mapper 'color' backward + the fc_c products (fc_post_body) in one launch
 #include "lk_common.h"
 #include "lk_kernels.h"
+#include "lk_adam_dev.h"
 
 using namespace lkw;
 
@@ -155,11 +156,13 @@ __global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
 }
 
 #define LK_GATHER_CHUNK 16
-__device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out, int bx, float (*sh)[32]);
+__device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out, int bx, float (*sh)[32],
+                                                const LkStepRider& sr);
 __global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
     if (a.red_part && (int)blockIdx.x >= a.red_block0) {     // rider: column sums of a partial table of the kernel before (one launch less)
         __shared__ float sh[8][32];
-        col_reduce_body(a.red_part, a.red_n, a.red_width, a.red_out, (int)blockIdx.x - a.red_block0, sh);
+        LkStepRider none; none.n_span = 0;
+        col_reduce_body(a.red_part, a.red_n, a.red_width, a.red_out, (int)blockIdx.x - a.red_block0, sh, none);
         return;
     }
     const int c = (int)threadIdx.x & 31;
@@ -811,9 +814,28 @@ __global__ __launch_bounds__(256) void k_dw2_hbar(const float* __restrict__ dc, 
 // Sums of the partial tiles of the fused variant (a part of k_bwd_reduce): linear1 [n1][128][64] (column 52 = bias) from
 // k_relpos_bwd_fused, linear2 [n2][32][129] (column 128 = bias) from k_dw2_hbar.  32 consecutive elements x 8 partial lanes per workgroup; every output has one
 // owner: no atomics, fixed order.
+// Final write of a decoder gradient element by its one owner: plain accumulation, or (step rider, lk_kernels.h) the Adam step of the
+// element right here when it belongs to a stepped span
+__device__ __forceinline__ void grad_commit(float* __restrict__ gptr, float s, const LkStepRider& sr) {
+    if (sr.n_span > 0) {
+        const long long off = gptr - sr.g;
+        for (int q = 0; q < sr.n_span; ++q) {
+            const LkStepSpan sp = sr.span[q];
+            if (off >= sp.off && off < (long long)sp.off + sp.n) {
+                const float g = *gptr + s;
+                float m = sr.m[off], v = sr.v[off];
+                sr.w_next[off] = lk_adam_elem(sr.p[off], g, m, v, sr.beta1, sr.beta2, sr.eps, sp.step_size, sp.bc2_sqrt);
+                sr.m[off] = m; sr.v[off] = v;
+                *gptr = 0.0f;
+                return;
+            }
+        }
+    }
+    *gptr += s;
+}
 __device__ __forceinline__ void rp_reduce_body(const float* __restrict__ part1, int n1, const float* __restrict__ part2, int n2,
                                                float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
-                                               int bx, float (*sh)[32]) {
+                                               int bx, float (*sh)[32], const LkStepRider& sr) {
     const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
     const bool second = bx >= 128 * 64 / 32;
     const int o = (bx - (second ? 128 * 64 / 32 : 0)) * 32 + e;
@@ -829,12 +851,12 @@ __device__ __forceinline__ void rp_reduce_body(const float* __restrict__ part1, 
     s = ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) + ((sh[4][e] + sh[5][e]) + (sh[6][e] + sh[7][e]));
     if (!second) {
         const int n = o >> 6, k = o & 63;
-        if (k < KR) dW1[(size_t)n * KRP + k] += s;
-        else if (k == KR) db1[n] += s;
+        if (k < KR) grad_commit(dW1 + (size_t)n * KRP + k, s, sr);
+        else if (k == KR) grad_commit(db1 + n, s, sr);
     } else {
         const int n = o / 129, k = o - n * 129;
-        if (k < 128) dW2[(size_t)n * 128 + k] += s;
-        else db2[n] += s;
+        if (k < 128) grad_commit(dW2 + (size_t)n * 128 + k, s, sr);
+        else grad_commit(db2 + n, s, sr);
     }
 }
 #define LK_RP_REDUCE_BLOCKS (128 * 64 / 32 + (LK_DW2_TILE + 31) / 32)
@@ -1063,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
 
 // dW += sum over the unit's waves of the partial tiles (tile order: contiguous reads; every output element is owned by
 // exactly one thread, so the read-modify-write of dW needs no atomics and the result is run-to-run reproducible).
-__device__ __forceinline__ void wgrad_reduce_body(const LkWgradArgs& a, int bx, int by, float (*sh)[32]) {
+__device__ __forceinline__ void wgrad_reduce_body(const LkWgradArgs& a, int bx, int by, float (*sh)[32], const LkStepRider& sr) {
     const LkWgradUnit& U = a.unit[bx];
     const LkWgradJob& J = a.job[U.job];
     const int nv = U.nv, kv = U.kv;
@@ -1088,15 +1110,16 @@ __device__ __forceinline__ void wgrad_reduce_body(const LkWgradArgs& a, int bx, 
         const int blk = idx >> 10, r = (idx >> 6) & 15, lane = idx & 63, h = lane >> 5, j = lane & 31;
         const int bn = blk / kv, bk = blk - bn * kv;
         const int nn = U.n0 + nv * lk_frag_row(r, h) + bn, k = U.k0 + kv * j + bk;
-        if (nn < J.N && k < (J.k_aux ? J.k_aux : J.K)) J.dW[(size_t)nn * J.ldw + k] += s;     // auxiliary columns: fc_post_body
+        if (nn < J.N && k < (J.k_aux ? J.k_aux : J.K)) grad_commit(J.dW + (size_t)nn * J.ldw + k, s, sr);     // auxiliary columns: fc_post_body
     } else if (in_bias) {
         const int tcol = idx - 4 * 16 * 64;
-        if (J.db && U.k0 == 0 && U.n0 + tcol < J.N) J.db[U.n0 + tcol] += s;
+        if (J.db && U.k0 == 0 && U.n0 + tcol < J.N) grad_commit(J.db + U.n0 + tcol, s, sr);
     }
 }
 __global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
     __shared__ float sh[8][32];
-    wgrad_reduce_body(a, (int)blockIdx.x, (int)blockIdx.y, sh);
+    LkStepRider none; none.n_span = 0;
+    wgrad_reduce_body(a, (int)blockIdx.x, (int)blockIdx.y, sh, none);
 }
 
 // fc_c gradients from the auxiliary columns (lk_kernels.h LkFcPost): block (f, kc) sums the partial tiles of column kc of
@@ -1107,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(LkWgradArgs a) {
 #define LK_FC_POST_COLS 33
 #define LK_FC_MAX_TILES 16            // loads in flight per thread: 8 n_waves <= 64 tiles of a unit over four thread groups
 struct LkFcPostLds { float part[4][128]; float m[128]; float half[2][128]; };
-__device__ __forceinline__ void fc_post_body(const LkWgradArgs& a, int f, int kc, LkFcPostLds& sh) {
+__device__ __forceinline__ void fc_post_body(const LkWgradArgs& a, int f, int kc, LkFcPostLds& sh, const LkStepRider& sr) {
     const LkFcPost& F = a.fc[f];
     const LkWgradJob& J = a.job[F.src_job];
     const int t = (int)threadIdx.x;
@@ -1168,16 +1191,18 @@ __device__ __forceinline__ void fc_post_body(const LkWgradArgs& a, int f, int kc
     __syncthreads();
     if (t < 128) {
         const float r = sh.half[0][t] + sh.half[1][t];
-        if (bias) F.du[t] += r; else F.dU[(size_t)t * 32 + kc] += r;
+        if (bias) grad_commit(F.du + t, r, sr); else grad_commit(F.dU + (size_t)t * 32 + kc, r, sr);
     }
 }
 __global__ __launch_bounds__(256) void k_fc_post(LkWgradArgs a) {
     __shared__ LkFcPostLds sh;
-    fc_post_body(a, (int)blockIdx.x / LK_FC_POST_COLS, (int)blockIdx.x % LK_FC_POST_COLS, sh);
+    LkStepRider none; none.n_span = 0;
+    fc_post_body(a, (int)blockIdx.x / LK_FC_POST_COLS, (int)blockIdx.x % LK_FC_POST_COLS, sh, none);
 }
 
 // column sums of a partial table [n_parts][width] into out[width] (+=), 32 columns per workgroup, one owner per column
-__device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out, int bx, float (*sh)[32]) {
+__device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out, int bx, float (*sh)[32],
+                                                const LkStepRider& sr) {
     const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
     const int col = bx * 32 + e;
     float s = 0.0f;
@@ -1187,32 +1212,41 @@ __device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, 
     }
     sh[q][e] = s;
     __syncthreads();
-    if (q == 0 && col < width) out[col] += ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) + ((sh[4][e] + sh[5][e]) + (sh[6][e] + sh[7][e]));
+    if (q == 0 && col < width) grad_commit(out + col, ((sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e])) + ((sh[4][e] + sh[5][e]) + (sh[6][e] + sh[7][e])), sr);
 }
 
 // EVERY partial-sum reduction of a mapper 'color' backward in one launch after the two streams have joined (they were five
 // launches of 5-10 us each on the critical path): the k_wgrad tiles, the linear1 / linear2 tiles of the fused rel-pos variant,
 // the Fourier-matrix partials of the two decoders.  Blocks [0, b_wg) | [b_wg, b_rp) | [b_rp, b_pg) | [b_pg, b_pr).
-__global__ __launch_bounds__(256) void k_bwd_reduce(LkWgradArgs wa, LkBwdReduceArgs r) {
+__global__ __launch_bounds__(256) void k_bwd_reduce(LkWgradArgs wa, LkBwdReduceArgs r, LkStepRider step) {
     __shared__ float sh[8][32];
     __shared__ LkFcPostLds sh_fc;
+    const LkStepRider& sr = step;
     // the fc_c blocks are two dependent memory round trips long: first in the grid, or they start when the tile sums retire
     const int n_fc = r.b_fc - r.b_pr;
-    if ((int)blockIdx.x < n_fc) { fc_post_body(wa, (int)blockIdx.x / LK_FC_POST_COLS, (int)blockIdx.x % LK_FC_POST_COLS, sh_fc); return; }
+    if ((int)blockIdx.x < n_fc) { fc_post_body(wa, (int)blockIdx.x / LK_FC_POST_COLS, (int)blockIdx.x % LK_FC_POST_COLS, sh_fc, sr); return; }
     const int b = (int)blockIdx.x - n_fc;
-    if (b < r.b_wg) wgrad_reduce_body(wa, b / r.ny, b % r.ny, sh);
-    else if (b < r.b_rp) rp_reduce_body(r.part1, r.n1, r.part2, r.n2, r.dW1, r.db1, r.dW2, r.db2, b - r.b_wg, sh);
-    else if (b < r.b_pg) col_reduce_body(r.part_bg, r.n_bg, 288, r.out_bg, b - r.b_rp, sh);
-    else col_reduce_body(r.part_br, r.n_br, 32, r.out_br, b - r.b_pg, sh);
+    if (b < r.b_wg) wgrad_reduce_body(wa, b / r.ny, b % r.ny, sh, sr);
+    else if (b < r.b_rp) rp_reduce_body(r.part1, r.n1, r.part2, r.n2, r.dW1, r.db1, r.dW2, r.db2, b - r.b_wg, sh, sr);
+    else if (b < r.b_pg) col_reduce_body(r.part_bg, r.n_bg, 288, r.out_bg, b - r.b_rp, sh, sr);
+    else if (b < r.b_pr) col_reduce_body(r.part_br, r.n_br, 32, r.out_br, b - r.b_pg, sh, sr);
+    else {      // feature-row Adam segments (final since the gather): the step rider's extra blocks
+        const int q = b - r.b_pr;
+        if (q < step.feat_gx) lk_adam_seg_block(step.feat[0], step.beta1, step.beta2, step.eps, q, step.feat_gx);
+        else lk_adam_seg_block(step.feat[1], step.beta1, step.beta2, step.eps, q - step.feat_gx, step.feat_gx);
+    }
 }
-int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st) {
+int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st, const LkStepRider* step) {
     r.ny = lk_cdiv(LK_WG_TILE, 32);
     r.b_wg = wa.part && wa.n_units > 0 ? wa.n_units * r.ny : 0;
     r.b_rp = r.b_wg + (with_rp ? LK_RP_REDUCE_BLOCKS : 0);
     r.b_pg = r.b_rp + (r.part_bg ? lk_cdiv(288, 32) : 0);
     r.b_pr = r.b_pg + (r.part_br ? 1 : 0);
     r.b_fc = r.b_pr + (r.b_wg > 0 ? wa.n_fc * LK_FC_POST_COLS : 0);
-    if (r.b_fc > 0) hipLaunchKernelGGL(k_bwd_reduce, dim3(r.b_fc), dim3(256), 0, st, wa, r);
+    LkStepRider sr;
+    if (step) sr = *step; else sr = LkStepRider{};
+    r.b_ad = r.b_fc + (sr.n_span > 0 ? sr.n_feat * sr.feat_gx : 0);
+    if (r.b_ad > 0) hipLaunchKernelGGL(k_bwd_reduce, dim3(r.b_ad), dim3(256), 0, st, wa, r, sr);
     return LK_OK;
 }
 

@@ -29,6 +29,7 @@ struct LkSampleArgs {
     int seg_P, seg_cnt_stride; const int32_t* seg_live;
     // interpolation-only launches (mode 2): fragment repack of plain -> frag as a rider (k_interp_repack); NULL: none
     const float* rp_plain; float* rp_frag; int rp_block0;
+    float* rp_copy_dst; int rp_copy_n, rp_block1;   // blocks >= rp_block1: rp_copy_dst[0 .. n) = rp_plain[..] (the stepped blob of the step rider, LkStepRider::w_next)
     const int32_t* live_rays;                     // see LkRelposArgs: with it the sampler gives the skipped samples their colour feature (noise)
 };
 
@@ -122,8 +123,26 @@ struct LkInterpBwdArgs {
 // Extras of the fused tracking loop for lk_render_bwd_impl: with pose_part the interpolation backward also reduces, per
 // workgroup of 32 samples, G[c][k] = sum d p_c z dir_k (9) and T[c] = sum d p_c (3) - what k_pose_bwd sums over the rays -
 // into pose_part[block][12]; lk_bwd_pose_parts(P) blocks.
+// ---- optimiser step (lk_optim.hip / lk_adam_dev.h)
+struct AdamSegDev {
+    float* p; float* g; float* m; float* v; long long n; float step_size, bc2_sqrt;
+    const int32_t* row_index; int row_len; int zero_grad; int p_f16;
+};
+// The Adam step of a mapper 'color' iteration as a rider of its reduction launch (lk_map_frame with no gradient exchange between the
+// backward and the step): every decoder gradient element has exactly ONE owner thread in k_bwd_reduce, which steps the element as
+// soon as it has its sum (new value -> w_next: the master blob is read by the fc_c blocks of the same launch and stays as it was
+// until the next iteration's interpolation launch copies w_next over it), and the feature-row segments - final since the gather -
+// run as extra blocks.  One dispatch (11 us + its gap) less per iteration.
+struct LkStepSpan { int off, n; float step_size, bc2_sqrt; };
+struct LkStepRider {
+    int n_span;                                    // decoder spans (offsets into the blob); 0 = no rider
+    LkStepSpan span[16];
+    float* g; const float* p; float* w_next; float* m; float* v;     // blob-shaped arrays
+    float beta1, beta2, eps;
+    AdamSegDev feat[2]; int n_feat, feat_gx;       // feature-row segments: n_feat * feat_gx extra blocks
+};
 struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
-                    int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
+                    int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
@@ -238,8 +257,10 @@ bool lk_serial_mode();                                      // LK_SERIAL / lk_se
 #define LK_PRE_CHUNKS 16
 struct LkAuxStream { hipStream_t st = nullptr; hipEvent_t e0 = nullptr; hipEvent_t ev[LK_PRE_CHUNKS] = {}; hipEvent_t e1 = nullptr, e2 = nullptr; bool ok = false; };
 LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour lists
-// repack_frag: with LK_PRESAMPLED, the interpolation launch also repacks d->weights into this fragment buffer (= d->weights_frag, writable)
-int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr, float* repack_frag = nullptr);
+// rider of the interpolation launch (LK_PRESAMPLED only): repack `src` (NULL: d->weights) into the fragment buffer `frag` (= d->weights_frag,
+// writable) and, with copy_dst, copy src[0 .. copy_n) over copy_dst (= d->weights, writable) - the blob stepped by the step rider
+struct LkRepackRider { float* frag; const float* src; float* copy_dst; int copy_n; };
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr, const LkRepackRider* repack = nullptr);
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total; };
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch
@@ -253,12 +274,12 @@ int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st);
 int lk_launch_wgrad(const LkWgradArgs& a, int max_rows, hipStream_t st, LkWgradArgs* deferred = nullptr);   // deferred: skip the tile sums, return the unit table
 // all partial-sum reductions of one backward in one launch (k_bwd_reduce, lk_bwd2.hip); block ranges are filled by the launcher
 struct LkBwdReduceArgs {
-    int b_wg, ny, b_rp, b_pg, b_pr, b_fc;
+    int b_wg, ny, b_rp, b_pg, b_pr, b_fc, b_ad;
     const float* part1; int n1; const float* part2; int n2; float* dW1; float* db1; float* dW2; float* db2;
     const float* part_bg; int n_bg; float* out_bg;
     const float* part_br; int n_br; float* out_br;
 };
-int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st);
+int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st, const LkStepRider* step = nullptr);
 int lk_dw2_parts(int P);
 int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st);
 

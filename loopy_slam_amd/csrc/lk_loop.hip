@@ -253,7 +253,7 @@ TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     w.total = o;
     return w;
 }
-struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, n_live, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, total; };
+struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, n_live, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, w_next, total; };
 MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     MapWork w;
     int64_t o = 0;
@@ -274,6 +274,7 @@ MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     w.seg_list = o; o += al4(iters * P * LK_K);
     w.seg_total = o; o += al4(iters);
     w.seg_rank = o; o += al4(P * LK_K * LK_SEG_BATCH);        // the rows of up to LK_SEG_BATCH iterations are sorted per launch
+    w.w_next = o; o += al4(lk_weight_blob_floats());          // the decoder blob as stepped by the step rider (LkStepRider::w_next)
     w.total = o;
     return w;
 }
@@ -491,9 +492,42 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         const int rc = enqueue_chunk(0);
         if (rc != LK_OK) return rc;
     }
-    bool repack_pending = false;
+    // the optimiser segments of iteration `it` (torch.optim.Adam: parameters without a gradient are skipped and keep their own step
+    // count - the colour decoder and the colour rows first step in the first 'color' iteration, Mapper.py:588-607, 722-724)
+    auto build_segs = [&](int it, bool color, lk_adam_seg* seg, int& ns) -> bool {
+        const float* lr = d->lr[color ? 1 : 0];
+        ns = 0;
+        auto dec_seg = [&](const lk_blob_span& sp, int step) {
+            lk_adam_seg& s = seg[ns++];
+            s.p = d->weights_rw + sp.offset; s.g = d->render.g_weights + sp.offset; s.m = d->adam_dec + sp.offset; s.v = d->adam_dec + nb + sp.offset;
+            s.n = sp.n; s.lr = lr[0]; s.step = step; s.zero_grad = 1;
+        };
+        for (int k = 0; k < d->n_geo_dec; ++k) dec_seg(d->geo_dec[k], it + 1);
+        if (color) for (int k = 0; k < d->n_col_dec; ++k) dec_seg(d->col_dec[k], it - d->n_geo_iters + 1);
+        if (ns + 2 > LK_ADAM_MAX_SEG) return false;
+        {
+            lk_adam_seg& s = seg[ns++];
+            s.p = d->geo_feats_rw; s.g = d->render.g_geo_feats; s.m = d->adam_rows; s.v = d->adam_rows + nrow; s.n = nrow; s.lr = lr[1]; s.step = it + 1;
+            s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1; s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
+        }
+        if (color) {
+            lk_adam_seg& s = seg[ns++];
+            s.p = d->col_feats_rw; s.g = d->render.g_col_feats; s.m = d->adam_rows + 2 * nrow; s.v = d->adam_rows + 3 * nrow; s.n = nrow; s.lr = lr[2];
+            s.step = it - d->n_geo_iters + 1; s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1;
+            s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
+        }
+        return true;
+    };
+    bool repack_pending = false, stepped_pending = false;
+    // Step rider (LkStepRider, lk_kernels.h): in a 'color' iteration that is followed by another one in this call, with no gradient
+    // exchange in between (phases == 3), the Adam step happens inside the reduction launch of the backward
+    const bool rider_ok = pre && (phases & 3) == 3 && d->render.weights == d->weights_rw && d->render.g_weights != nullptr &&
+                          (!(d->render.flags & LK_FLAG_REL_POS) || lk_relpos_fused(d->render.flags | LK_FLAG_GRAD_WEIGHTS)) &&
+                          d->n_geo_dec + d->n_col_dec <= 16 && nb < (1ll << 31);
+    bool w_next_ready = false;
     for (int it = it_begin; it < it_end; ++it) {
         const bool color = it >= d->n_geo_iters;
+        const bool use_rider = rider_ok && color && it + 1 < it_end && d->n_col_dec > 0;
         lk_render_desc rd = d->render;
         rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_UNIT_LOSS_GRADS | LK_FLAG_FEATS_F16)) | (color ? LK_FLAG_STAGE_COLOR : 0) | LK_FLAG_SAVE_ACT |
                    LK_FLAG_GRAD_FEATS | LK_FLAG_GRAD_WEIGHTS | LK_FLAG_ZERO_ABSENT | LK_FLAG_MAPPER_LOSS;
@@ -529,9 +563,12 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             // the loss gradient is final when the composite kernel has written it: its backward rides in the same launch
             const int32_t* live = pre ? reinterpret_cast<const int32_t*>(W0 + wk.n_live) + it : nullptr;
             // the fragment repack of the iteration before rides in this iteration's interpolation launch (see the end of the loop body)
+            LkRepackRider rr;
+            rr.frag = d->weights_frag_rw; rr.src = stepped_pending ? W0 + wk.w_next : nullptr;
+            rr.copy_dst = stepped_pending ? d->weights_rw : nullptr; rr.copy_n = (int)nb;
             rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0), live,
-                                    repack_pending ? d->weights_frag_rw : nullptr);
-            repack_pending = false;
+                                    (repack_pending || stepped_pending) ? &rr : nullptr);
+            repack_pending = false; stepped_pending = false;
             if (rc != LK_OK) return rc;
             LkBwdExtra ex;
             memset(&ex, 0, sizeof(ex));
@@ -540,34 +577,47 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 ex.seg_total = reinterpret_cast<int32_t*>(W0 + wk.seg_total) + it;
             }
             ex.live_rays = live;
+            LkStepRider sr;
+            if (use_rider) {
+                lk_adam_seg seg[LK_ADAM_MAX_SEG];
+                memset(seg, 0, sizeof(seg));
+                int ns = 0;
+                LK_REQUIRE(build_segs(it, color, seg, ns), "lk_map_frame: too many optimiser segments");
+                memset(&sr, 0, sizeof(sr));
+                sr.g = d->render.g_weights; sr.p = d->weights_rw; sr.w_next = W0 + wk.w_next; sr.m = d->adam_dec; sr.v = d->adam_dec + nb;
+                sr.beta1 = beta1; sr.beta2 = beta2; sr.eps = eps;
+                long long nmax = 0;
+                for (int q = 0; q < ns; ++q) {
+                    const double bc1 = 1.0 - pow((double)beta1, (double)seg[q].step), bc2 = 1.0 - pow((double)beta2, (double)seg[q].step);
+                    const float step_size = (float)((double)seg[q].lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+                    if (q < ns - 2) {       // decoder span
+                        LkStepSpan& sp = sr.span[sr.n_span++];
+                        sp.off = (int)(seg[q].p - d->weights_rw); sp.n = (int)seg[q].n; sp.step_size = step_size; sp.bc2_sqrt = bc2_sqrt;
+                    } else {                // the two feature-row segments
+                        AdamSegDev& f = sr.feat[sr.n_feat++];
+                        f.p = seg[q].p; f.g = seg[q].g; f.m = seg[q].m; f.v = seg[q].v; f.n = seg[q].n; f.step_size = step_size; f.bc2_sqrt = bc2_sqrt;
+                        f.row_index = seg[q].row_index; f.row_len = seg[q].row_len > 0 ? seg[q].row_len : 1; f.zero_grad = seg[q].zero_grad; f.p_f16 = seg[q].p_f16;
+                        if (seg[q].n > nmax) nmax = seg[q].n;
+                    }
+                }
+                sr.feat_gx = (int)(nmax > 0 ? (lk_cdiv(nmax, 256) > 2048 ? 2048 : lk_cdiv(nmax, 256)) : 1);
+                if (!w_next_ready) {        // elements outside the stepped spans ride through the copy-back unchanged
+                    LK_HIP_TRY(hipMemcpyAsync(W0 + wk.w_next, d->weights_rw, sizeof(float) * (size_t)nb, hipMemcpyDeviceToDevice, st));
+                    w_next_ready = true;
+                }
+                ex.step = &sr;
+            }
             rc = lk_render_bwd_impl(&rd, st, LK_SKIP_COMPOSITE_BWD | LK_SEG_SORTED, pre ? &ex : nullptr);
             if (rc != LK_OK) return rc;
         }
         if (phases & 2) {
-            // torch.optim.Adam: parameters without a gradient are skipped and keep their own step count - the colour decoder and
-            // the colour rows first step in the first 'color' iteration (Mapper.py:588-607, 722-724)
-            const float* lr = d->lr[color ? 1 : 0];
             lk_adam_seg seg[LK_ADAM_MAX_SEG];
             memset(seg, 0, sizeof(seg));
             int ns = 0;
-            auto dec_seg = [&](const lk_blob_span& sp, int step) {
-                lk_adam_seg& s = seg[ns++];
-                s.p = d->weights_rw + sp.offset; s.g = rd.g_weights + sp.offset; s.m = d->adam_dec + sp.offset; s.v = d->adam_dec + nb + sp.offset;
-                s.n = sp.n; s.lr = lr[0]; s.step = step; s.zero_grad = 1;
-            };
-            for (int k = 0; k < d->n_geo_dec; ++k) dec_seg(d->geo_dec[k], it + 1);
-            if (color) for (int k = 0; k < d->n_col_dec; ++k) dec_seg(d->col_dec[k], it - d->n_geo_iters + 1);
-            LK_REQUIRE(ns + 2 <= LK_ADAM_MAX_SEG, "lk_map_frame: too many optimiser segments");
-            {
-                lk_adam_seg& s = seg[ns++];
-                s.p = d->geo_feats_rw; s.g = rd.g_geo_feats; s.m = d->adam_rows; s.v = d->adam_rows + nrow; s.n = nrow; s.lr = lr[1]; s.step = it + 1;
-                s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1; s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
-            }
-            if (color) {
-                lk_adam_seg& s = seg[ns++];
-                s.p = d->col_feats_rw; s.g = rd.g_col_feats; s.m = d->adam_rows + 2 * nrow; s.v = d->adam_rows + 3 * nrow; s.n = nrow; s.lr = lr[2];
-                s.step = it - d->n_geo_iters + 1; s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1;
-                s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
+            LK_REQUIRE(build_segs(it, color, seg, ns), "lk_map_frame: too many optimiser segments");
+            if (use_rider) {        // stepped inside k_bwd_reduce; the next iteration's interpolation launch copies the blob back and repacks
+                stepped_pending = true;
+                continue;
             }
             int rc = lk_adam_step(seg, ns, beta1, beta2, eps, st);
             if (rc != LK_OK) return rc;

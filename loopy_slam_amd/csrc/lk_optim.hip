@@ -6,6 +6,7 @@
 //   (Tracker.py:153-160, Mapper.py:674-681, common.py:249-255).
 #include "lk_common.h"
 #include "lk_mask_dev.h"
+#include "lk_adam_dev.h"
 
 #include <math.h>
 #include <string.h>
@@ -219,38 +220,11 @@ __global__ __launch_bounds__(1024) void k_loss_tracker_1wg(int R, const float* _
 }
 
 // ------------------------------------------------------------------ Adam
-struct AdamSegDev {
-    float* p; float* g; float* m; float* v; long long n; float step_size, bc2_sqrt;
-    const int32_t* row_index; int row_len; int zero_grad; int p_f16;
-};
 struct AdamArgs { AdamSegDev s[LK_ADAM_MAX_SEG]; int n_seg; float beta1, beta2, eps; };
 
-// Element i of a segment is p[i] — or, with a row index (frustum-selected feature rows optimised in place in
-// the full table, Mapper.py:498-512,578-586), p[row_index[i / row_len] * row_len + i % row_len]; m and v are
-// always compact.  zero_grad clears the consumed gradient so the next iteration's scatter-add starts from 0.
+// (element arithmetic and the per-segment block body: lk_adam_dev.h - k_bwd_reduce carries the same step as a rider)
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-    const AdamSegDev S = a.s[blockIdx.y];
-    const float b1 = a.beta1, b2 = a.beta2, om1 = 1.0f - a.beta1, om2 = 1.0f - a.beta2;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < S.n; i += (long long)gridDim.x * 256) {
-        long long e = i;
-        if (S.row_index) {
-            const long long row = i / S.row_len;
-            e = (long long)S.row_index[row] * S.row_len + (i - row * S.row_len);
-        }
-        const float g = S.g[e];
-        const float m = S.m[i] * b1 + om1 * g;              // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
-        const float v = S.v[i] * b2 + om2 * (g * g);        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-        const float denom = sqrtf(v) / S.bc2_sqrt + a.eps;  // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
-        S.m[i] = m;
-        S.v[i] = v;
-        if (S.p_f16) {                                      // half table: fp32 step, stored rounded to nearest
-            _Float16* ph = reinterpret_cast<_Float16*>(S.p) + e;
-            *ph = (_Float16)((float)*ph - S.step_size * (m / denom));
-        } else {
-            S.p[e] = S.p[e] - S.step_size * (m / denom);    // param.addcdiv_(exp_avg, denom, value=-lr/bias_correction1)
-        }
-        if (S.zero_grad) S.g[e] = 0.0f;
-    }
+    lk_adam_seg_block(a.s[blockIdx.y], a.beta1, a.beta2, a.eps, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------ pose -> rays

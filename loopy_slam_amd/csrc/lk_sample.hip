@@ -183,6 +183,12 @@ __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
 // dispatch (9 us of kernel plus its gap) less per 'color' iteration.
 template <int T>
 __global__ __launch_bounds__(256) void k_interp_repack(LkSampleArgs a, FragTable tb) {
+    if (a.rp_copy_dst && (int)blockIdx.x >= a.rp_block1) {      // the stepped blob over the master blob (nobody reads the master in this launch)
+        const int i = (((int)blockIdx.x - a.rp_block1) * 256 + (int)threadIdx.x) * 4;
+        if (i + 3 < a.rp_copy_n) *reinterpret_cast<float4*>(a.rp_copy_dst + i) = *reinterpret_cast<const float4*>(a.rp_plain + i);
+        else for (int k = i; k < a.rp_copy_n; ++k) a.rp_copy_dst[k] = a.rp_plain[k];
+        return;
+    }
     if ((int)blockIdx.x >= a.rp_block0) {
         const int u = ((int)blockIdx.x - a.rp_block0) * 256 + (int)threadIdx.x;
         if (u < LK_REPACK_UNITS) repack_unit(a.rp_plain, reinterpret_cast<u32x4*>(a.rp_frag), tb, u);
@@ -264,7 +270,8 @@ int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode) {
             LkSampleArgs b = a;
             const bool wide = two && a.P <= (1 << 16);
             b.rp_block0 = lk_cdiv(a.P, wide ? 16 : 32);
-            const dim3 grid(b.rp_block0 + lk_cdiv(LK_REPACK_UNITS, 256));
+            b.rp_block1 = b.rp_block0 + lk_cdiv(LK_REPACK_UNITS, 256);
+            const dim3 grid(b.rp_block1 + (b.rp_copy_dst ? lk_cdiv(b.rp_copy_n, 1024) : 0));
             if (wide) hipLaunchKernelGGL((k_interp_repack<16>), grid, dim3(256), 0, st, b, lk_frag_table());
             else hipLaunchKernelGGL((k_interp_repack<8>), grid, dim3(256), 0, st, b, lk_frag_table());
             return LK_OK;
