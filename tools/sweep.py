@@ -3,8 +3,8 @@
 
     python tools/sweep.py [--points 100000,500000,2000000] [--md profiles/r1_sweep.md]
 
-Modes: render (forward only, full image = Renderer.render_img), map-geometry / map-color (one joint mapping iteration:
-batch assembly, forward, loss, backward, Adam), track (one tracking iteration).  Everything resident in HBM, HIP-event
+Modes: render (forward only, full image = Renderer.render_img), map-geometry / map-color (one joint mapping iteration of a
+24-iteration lk_map_frame call: batch assembly, search, forward, loss, backward, Adam), track (one tracking iteration).  Everything resident in HBM, HIP-event
 timing of `iters` back-to-back iterations after a warm-up.  'HBM frac' = 11.1 KB/ray (forward
 algorithmic bytes) x rays/s / 8 TB/s, quoted for the forward-only mode as the north star asks; the forward is
 compute-bound (100-180 FLOP/B), so the fp32 matrix fraction (forward FLOPs/ray x rays/s / 157.3 TFLOP/s) is beside it.
@@ -47,15 +47,12 @@ def main():
                 e = min(b.ignore_edge, H // 4)
                 win = (e, H - e, e, W - e)
                 fid = (torch.arange(mr, dtype=torch.int32) % b.window).to(eng.device)
-                rnd_m = wl._draws(8, mr, H * W)
-                wl.mapper.begin_frame()
-                it = [0]
-
-                def map_it(stage):
-                    wl.mapper.iterate(stage, wl.frames, rnd_m[it[0] % 8], fid, (0, H, 0, W), wl.intr, H, W, log_row=wl.map_log[0])
-                    it[0] += 1
-                for stage in ('geometry', 'color'):
-                    ms = timed(lambda: map_it(stage), 10)
+                n_it = 24
+                rnd_m = wl._draws(n_it, mr, H * W)
+                log = eng.zeros(n_it, 4)
+                # the mapping loop as the product runs it: ONE lk_map_frame call of n_it iterations of one stage
+                for stage, n_geo in (('geometry', n_it), ('color', 0)):
+                    ms = timed(lambda: wl.mapper.run(n_it, n_geo, wl.frames, rnd_m, fid, (0, H, 0, W), wl.intr, H, W, log), 3, warm=1) / n_it
                     rows.append((cfgname, N, f'map-{stage}', mr, ms, mr / ms * 1e3, None))
                 rnd_t = wl._draws(10, tr, (win[1] - win[0]) * (win[3] - win[2]))
                 ms = timed(lambda: wl.tracker.track(wl.cam0, wl.depth_stack[0], wl.color_stack[0], 10, win, wl.intr, rnd_t), 2, warm=1) / 10
@@ -78,7 +75,7 @@ def main():
     print(out)
     if args.md:
         with open(args.md, 'w') as f:
-            f.write('# Round-1 measurement grid (SURVEY §8d), one MI355X, synthetic 640x480 room, fp32\n\n'
+            f.write('# Measurement grid (SURVEY §8d), one MI355X, synthetic 640x480 room, fp32 (map modes: per iteration of a 24-iteration lk_map_frame call)\n\n'
                     '`python tools/sweep.py` - HIP-event timing, everything resident in HBM.  Point clouds above 1e5 points put\n'
                     'proportionally more points into the same 108 m^2 of surfaces (no de-duplication), so the radius search\n'
                     'scans proportionally more candidates: the N axis is a stress axis for the kNN, not a typical map.\n\n' + out + '\n')
