@@ -33,6 +33,14 @@ __device__ __forceinline__ void lk_top8_insert(uint64_t (&k)[LK_K], uint64_t key
     k[0] = key < k[0] ? key : k[0];
 }
 
+// a candidate enters the insertion network only if it is inside the radius AND ahead of the list's current last entry (the order is
+// total, so this is exactly "belongs to the 8 smallest so far"): in a dense cloud most in-radius candidates arrive when the list is
+// already full of nearer ones, and the 8-stage network is the search's largest VALU item
+__device__ __forceinline__ void lk_top8_offer(uint64_t (&k)[LK_K], float d2, float r2, int idx) {
+    const uint64_t key = lk_key(d2, idx);
+    if (d2 <= r2 && key < k[LK_K - 1]) lk_top8_insert(k, key);
+}
+
 // one butterfly round: my ascending 8-list against the partner's, keep the 8 smallest, re-sort (see the merge note below)
 template <int CTRL>
 __device__ __forceinline__ void lk_knn_merge_round(uint64_t (&k)[LK_K]) {
@@ -112,7 +120,7 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
     for (int i = 0; i < LK_ROWS; ++i) {
         if (rs[i] < re[i]) {
             const float d2 = lk_dist2(qx, qy, qz, c[i].x, c[i].y, c[i].z);
-            if (d2 <= r2) lk_top8_insert(k, lk_key(d2, __float_as_int(c[i].w)));
+            lk_top8_offer(k, d2, r2, __float_as_int(c[i].w));
         }
     }
 #pragma unroll
@@ -121,7 +129,7 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
         for (int t = rs[i] + T; t < re[i]; t += T) {
             const float4 p = sorted[t];
             const float d2 = lk_dist2(qx, qy, qz, p.x, p.y, p.z);
-            if (d2 <= r2) lk_top8_insert(k, lk_key(d2, __float_as_int(p.w)));
+            lk_top8_offer(k, d2, r2, __float_as_int(p.w));
         }
     }
     if (nrows > LK_ROWS) {          // cells smaller than the radius: plain row walk
@@ -136,7 +144,7 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
                 for (int t = s + sub; t < e; t += T) {
                     const float4 p = sorted[t];
                     const float d2 = lk_dist2(qx, qy, qz, p.x, p.y, p.z);
-                    if (d2 <= r2) lk_top8_insert(k, lk_key(d2, __float_as_int(p.w)));
+                    lk_top8_offer(k, d2, r2, __float_as_int(p.w));
                 }
             }
         }
