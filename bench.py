@@ -32,6 +32,19 @@ def main():
                          'every rank bringing a full batch; frames/s then is the per-frame rate the "x6 at 8 GPUs" target speaks of')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU) the way the driver's torchrun line does and
+        # hand its exit code back; rank 0 of that job prints the JSON line
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
     from loopy_slam_amd import core, workload, parallel, profile
@@ -42,6 +55,11 @@ def main():
     # testing hooks for a 1-GPU box: all ranks on device 0 over gloo (RCCL refuses two ranks on one device)
     one_dev = os.environ.get('LOOPY_DIST_ONE_DEVICE') == '1'
     backend = os.environ.get('LOOPY_DIST_BACKEND', 'nccl')
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
+    if world > 1 and not one_dev and torch.cuda.device_count() < world:
+        raise SystemExit(f'bench.py: {world} ranks need {world} GPUs, {torch.cuda.device_count()} visible '
+                         '(LOOPY_DIST_ONE_DEVICE=1 LOOPY_DIST_BACKEND=gloo puts every rank on device 0 - a functional check, not a measurement)')
     if one_dev:
         local = 0
     torch.cuda.set_device(local)
@@ -56,8 +74,7 @@ def main():
     eng = core.Engine()
     budget = workload.Budget(n_points=args.points)
     if args.strong and world > 1:
-        budget.track_rays = max(32, budget.track_rays // world)
-        budget.map_rays = max(32, budget.map_rays // world)
+        budget.map_rays = max(32, budget.map_rays // world)          # tracking is replicated (not sharded) in either mode
     wl = workload.FrameWorkload(eng, budget, dist=dctx)
 
     def barrier():
@@ -100,9 +117,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rays_per_step = budget.rays_per_frame
-    total_rays = rays_per_step * args.steps * world       # whole-job: every rank brings rays_per_step rays per step
+    # whole-job rays of a step: every rank brings its own mapping rays; the tracking iterations are REPLICATED on the ranks (the same
+    # rays everywhere, no exchange - steps.TrackOptimizer), so they count once however many ranks repeat them
+    map_rays_step, track_rays_step = budget.map_iters * budget.map_rays, budget.track_iters * budget.track_rays
+    rays_all = map_rays_step * world + track_rays_step
+    total_rays = rays_all * args.steps
     out = {
-        'metric': 'rays/s (track+map, Replica room0 per-frame budget, 640x480 synthetic RGB-D)',
+        'metric': 'rays/s (track+map, Replica room0 per-frame budget, 640x480 synthetic RGB-D)' +
+                  ('' if world == 1 else (', strong scaling: the frame budget split over the ranks' if args.strong else
+                                          ', weak scaling: every rank brings a full frame budget of rays to the shared map')),
         'value': total_rays / dt, 'unit': 'rays/s',
         # every rank works on the SAME frame (the ranks share one map and sum their gradients): a step is one frame whatever N is
         'frames_per_s': args.steps / dt,
@@ -115,8 +138,8 @@ def main():
         'config': {'workload': 'Replica room0 budget: 40 track it x 1500 rays + 60 map it x 5000 rays per frame '
                                '(24 geometry + 36 colour) on the frustum rows of the mapped frame, S=5, k=8, C=32, rel-pos colour MLP, '
                                f'N={budget.n_points} points, 640x480 synthetic room',
-                   'rays_per_step': rays_per_step, 'rays_per_step_all_ranks': rays_per_step * world,
-                   'parallelism': f'dp{world} (ray-sharded, grad all-reduce)'},
+                   'rays_per_step': rays_per_step, 'rays_per_step_all_ranks': rays_all,
+                   'parallelism': f'dp{world} (mapping ray-sharded with one gradient all-reduce per iteration; tracking replicated)'},
     }
     if rank == 0:
         out['roofline'] = profile.roofline(kstat, budget, dominant)

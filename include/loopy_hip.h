@@ -260,6 +260,13 @@ int lk_pose_bwd(const float* cam7, const float* pix_i, const float* pix_j, int32
                 float* g_cam7, void* stream);
 /* Stable stream compaction (wave ballot + prefix sum): out_index[0..count) = i with mask[i]!=0. */
 int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, void* stream);
+/* lk_compact for masks of millions of entries (many-workgroup count / scan / scatter; same result).  block_scratch:
+ * ceil(n / 256) ints. */
+int lk_compact_large(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, int32_t* block_scratch, void* stream);
+/* Rows of the [N,32] feature tables a batch's neighbour lists refer to: flags[i] = 1 for every 0 <= nbr_idx[j] = i < N, j < n
+ * (flags is cleared by the caller).  When the whole map is optimised (final refinement, Mapper.py:884-897; BASELINE config 5)
+ * a ray-sharded multi-GPU step exchanges the gradient rows of the union of the ranks' flags only. */
+int lk_touch_rows(const int32_t* nbr_idx, int64_t n, uint8_t* flags, int32_t N, void* stream);
 /* ---------------------------------------------------------------- map maintenance around the hot loop
  * Frustum row selection, Mapper.get_mask_from_c2w (src/Mapper.py:165-217): out_index[0..*out_count) = ascending indices
  * of the points of pos[N,3] that project inside the image of the pose (cropped by `edge` pixels, negative = enlarged)
@@ -383,6 +390,10 @@ int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters);
  * caller needs to agree on the touched rows of an iteration, loopy_slam_amd/parallel.py) */
 int64_t lk_map_work_nbr_idx(int32_t R, int32_t S, int32_t iters);
 int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t phases, void* stream);
+/* Makes `stream` wait until the neighbour lists of iteration `it` (work + lk_map_work_nbr_idx) are written: lk_map_frame
+ * searches ahead of its loop on a library-owned stream.  Valid after the phase-1 call of iteration it - 1 (or it) of the same
+ * optimize_map call has returned. */
+int lk_map_wait_lists(const lk_map_desc* d, int32_t it, void* stream);
 
 /* ---------------------------------------------------------------- weight-gradient building block
  * dW[n][k] += sum_rows A'[row][n] * B[row][k], db[n] += sum_rows A'[row][n] (db may be NULL); row-major operands.

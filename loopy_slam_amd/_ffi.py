@@ -176,6 +176,9 @@ class LoopyLib:
             ('lk_track_frame', [C.POINTER(TrackDesc), C.c_void_p], C.c_int),
             ('lk_map_frame', [C.POINTER(MapDesc), C.c_int32, C.c_int32, C.c_int32, C.c_void_p], C.c_int),
             ('lk_inside_mask', [_fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_compact_large', [_fp, C.c_int32, _fp, _fp, _fp, C.c_void_p], C.c_int),
+            ('lk_touch_rows', [_fp, C.c_int64, _fp, C.c_int32, C.c_void_p], C.c_int),
+            ('lk_map_wait_lists', [C.POINTER(MapDesc), C.c_int32, C.c_void_p], C.c_int),
         ):
             if hasattr(d, name):
                 fn = getattr(d, name)

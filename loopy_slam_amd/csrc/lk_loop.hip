@@ -281,6 +281,7 @@ MapWork map_work(int64_t R, int64_t S, int64_t iters) {
 // Third stream (lk_aux_stream, lk_api.hip): the neighbour search of a mapping call's iterations runs ahead of the iterations
 // themselves (it reads the rays and the positions, nothing the iterations write), in up to LK_PRE_CHUNKS launches with an event each.
 typedef LkAuxStream PreStream;
+int map_pre_chunk(int iters) { const int c = lk_cdiv(iters, LK_PRE_CHUNKS - 1); return c < 6 ? 6 : c; }
 PreStream& pre_stream() { return lk_aux_stream(); }
 }  // namespace
 
@@ -425,7 +426,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     const int64_t Pn = (int64_t)R * d->render.S;
     // iterations per chunk of the work that runs ahead; chunk 0 is the first iteration alone (the loop waits for it), chunk c >= 1
     // starts at iteration 1 + (c - 1) pre_chunk
-    const int pre_chunk = lk_cdiv(d->iters, LK_PRE_CHUNKS - 1) < 6 ? 6 : lk_cdiv(d->iters, LK_PRE_CHUNKS - 1);
+    const int pre_chunk = map_pre_chunk(d->iters);
     auto chunk_start = [&](int c) { return c == 0 ? 0 : 1 + (c - 1) * pre_chunk; };
     auto chunk_of = [&](int it) { return it == 0 ? 0 : 1 + (it - 1) / pre_chunk; };
     float* W0 = d->work;
@@ -632,5 +633,16 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         }
     }
     LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
+// The look-ahead chunk that holds iteration `it` has been enqueued (see the header): `stream` waits for its event.
+extern "C" int lk_map_wait_lists(const lk_map_desc* d, int32_t it, void* stream_) {
+    LK_REQUIRE(d != nullptr && it >= 0 && it < d->iters, "lk_map_wait_lists: bad arguments");
+    PreStream& ps = pre_stream();
+    if (!ps.ok || d->work == nullptr || d->render.R > LK_MASK_REG_MAX) return LK_OK;      // no look-ahead: the lists are written in the call's stream order
+    const int pre_chunk = map_pre_chunk(d->iters);
+    const int ck = it == 0 ? 0 : 1 + (it - 1) / pre_chunk;
+    LK_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, ps.ev[ck % LK_PRE_CHUNKS], 0));
     return LK_OK;
 }

@@ -738,6 +738,35 @@ extern "C" int lk_compact(const uint8_t* mask, int32_t n, int32_t* out_index, in
     return LK_OK;
 }
 
+// ------------------------------------------------------------------ rows a batch touches (whole-map optimisation, data parallel)
+// flags[i] = 1 for every point i that appears in the batch's neighbour lists: with every row of the map a parameter (final
+// refinement, Mapper.py:884-897) a batch of R rays touches <= 8 R S of the N rows; the ranks of a ray-sharded step exchange the
+// gradient rows of the UNION of their flags only (loopy_slam_amd/parallel.py).  The caller clears `flags`.
+__global__ __launch_bounds__(256) void k_touch_rows(const int32_t* __restrict__ nbr_idx, long long n, uint8_t* __restrict__ flags, int N) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int j = nbr_idx[i];
+        if (j >= 0 && j < N) flags[j] = 1;
+    }
+}
+extern "C" int lk_touch_rows(const int32_t* nbr_idx, int64_t n, uint8_t* flags, int32_t N, void* stream_) {
+    LK_REQUIRE(n >= 0 && N >= 0, "lk_touch_rows: bad sizes");
+    if (n == 0 || N == 0) return LK_OK;
+    LK_REQUIRE(nbr_idx && flags, "lk_touch_rows: NULL buffer");
+    int gx = lk_cdiv(n, 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_touch_rows, dim3(gx), dim3(256), 0, (hipStream_t)stream_, nbr_idx, (long long)n, flags, (int)N);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+extern "C" int lk_compact_large(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, int32_t* block_scratch, void* stream_) {
+    LK_REQUIRE(n >= 0 && out_count, "lk_compact_large: bad arguments");
+    LK_REQUIRE(n == 0 || (mask && out_index && block_scratch), "lk_compact_large: NULL buffer");
+    if (n <= 16384) lk_launch_compact(mask, n, out_index, out_count, (hipStream_t)stream_);
+    else lk_launch_compact_mb(mask, n, out_index, out_count, block_scratch, (hipStream_t)stream_);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
 extern "C" int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* depth_filtered, float* out_thr,
                               uint32_t* scratch, void* stream_) {
     LK_REQUIRE(n >= 0 && out_thr, "lk_inside_mask: bad arguments");

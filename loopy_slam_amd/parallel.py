@@ -4,7 +4,14 @@ The hot path shards by rays: every rank holds the full map (pos
 tables, decoder blob, Adam state), renders / back-propagates its own ray shard, and the gradients — sums over
 rays — are added across ranks with ONE all-reduce per iteration; the identical Adam step then runs on every
 rank, so no parameter broadcast is needed.  The all-reduce payload is the decoder-gradient blob plus the two
-feature-gradient tables restricted to the rows being optimised (row_index), packed into one bucket."""
+feature-gradient tables restricted to the rows being optimised (row_index), packed into one bucket.
+
+No host synchronisation of the launch stream inside an iteration: when the whole map is optimised the row list of an
+iteration (the union of the rows the ranks' batches touch) is agreed ONE ITERATION AHEAD on a side stream
+(lk_map_frame's neighbour search runs ahead of its loop, so the lists of iteration it + 1 exist while iteration it
+renders), and the host only ever waits for that side stream's event."""
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -24,14 +31,57 @@ def _merge(ranges, gap=4096):
     return out
 
 
+class _RowAgreement:
+    """One in-flight agreement on the touched rows of an iteration: device list + count on its way to pinned host memory."""
+
+    def __init__(self, eng, N):
+        dev = eng.device
+        self.flags = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.rows = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scratch = torch.empty((N + 255) // 256 + 1, dtype=torch.int32, device=dev)
+        self.count_host = torch.zeros(1, dtype=torch.int32)
+        if dev.type == 'cuda':
+            self.count_host = self.count_host.pin_memory()
+        self.event = torch.cuda.Event() if dev.type == 'cuda' else None
+        self.it = -1
+
+
 class DistContext:
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
         self._bucket = None
-        self._touched = None
         self._keep = None
+        self._agree = {}            # slot (it & 1) -> _RowAgreement
+        self._side = None
+        self._main_ev = None
 
-    def all_reduce_grads(self, mo, stage='color'):
+    # ------------------------------------------------------------------ collectives
+    def _all_reduce(self, t, op):
+        """dist.all_reduce; on a backend without device collectives (gloo with HIP tensors: the 2-ranks-on-one-GPU test
+        hook - RCCL refuses two ranks on one device) the tensor is staged through the host."""
+        if t.is_cuda and dist.get_backend() != 'nccl':
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def broadcast(self, t, src=0):
+        if t.is_cuda and dist.get_backend() != 'nccl':
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src)
+        return t
+
+    def all_reduce_vec(self, t):
+        self._all_reduce(t, dist.ReduceOp.SUM)
+        return t
+
+    # ------------------------------------------------------------------ gradient bucket
+    def all_reduce_grads(self, mo, stage='color', it=None):
         """mo: steps.MapOptimizer after render_backward.  Sum over ranks exactly what this stage's Adam step consumes:
         the decoder-gradient ranges being stepped (geometry: embedder._B only; colour: + every colour-decoder tensor),
         g_geo[rows], and in the colour stage g_col[rows] - one bucket, one all-reduce, one pack and one unpack launch
@@ -47,7 +97,7 @@ class DistContext:
         for k, (o, cnt) in enumerate(ranges):
             segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(gs.g_weights[o:o + cnt]), cnt, None, 1
             n += cnt
-        rows = mo.rows if mo.rows is not None else self.touched_rows(mo)
+        rows = mo.rows if mo.rows is not None else self.touched_rows(mo, it)
         for k, t in enumerate(tables, start=len(ranges)):
             segs[k].data, segs[k].n = ptr(t), rows.numel() * t.shape[1]
             segs[k].row_index, segs[k].row_len = ptr(rows), t.shape[1]
@@ -57,28 +107,67 @@ class DistContext:
             k = len(ranges) + len(tables)
             segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(xs.g_aff), xs.g_aff.numel(), None, 1
             n += segs[k].n
-        if self._bucket is None or self._bucket.numel() != n:
-            self._bucket = torch.empty(n, dtype=torch.float32, device=gs.g_weights.device)
-        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(self._bucket), 0, eng.stream), 'lk_bucket_copy')
-        dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
-        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(self._bucket), 1, eng.stream), 'lk_bucket_copy')
+        if self._bucket is None or self._bucket.numel() < n:
+            self._bucket = torch.empty(max(n, 2 * (self._bucket.numel() if self._bucket is not None else 0)),
+                                       dtype=torch.float32, device=gs.g_weights.device)
+        bucket = self._bucket[:n]
+        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 0, eng.stream), 'lk_bucket_copy')
+        self._all_reduce(bucket, dist.ReduceOp.SUM)
+        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
 
-    def touched_rows(self, mo):
-        """Whole-map optimisation (rows = None: the final refinement, Mapper.py:884-897): a batch of R rays touches at most
-        8 R S rows of the N-row tables, the rest of both gradient tables is exactly zero on every rank.  Exchanging the tables
-        themselves would be 256 B x N per iteration (1.28 GB at 5 M points); instead the ranks agree on the UNION of
-        the rows they touched - one MAX all-reduce of an N-byte flag vector (5 MB) - and only those rows ride in the bucket.
-        Returns the sorted int32 row list (identical on every rank)."""
+    # ------------------------------------------------------------------ touched rows (whole-map optimisation)
+    def _enqueue_agreement(self, mo, it, idx):
+        """Enqueue, on the current stream: flags of the rows iteration `it`'s lists touch -> MAX over the ranks -> compaction
+        -> the count on its way to the host.  Whole-map optimisation (rows = None: the final refinement, Mapper.py:884-897):
+        a batch of R rays touches at most 8 R S rows of the N-row tables, the rest of both gradient tables is exactly zero
+        on every rank.  Exchanging the tables themselves would be 256 B x N per iteration (1.28 GB at 5 M points, SURVEY
+        §8e); instead the ranks agree on the UNION of the rows they touched - one MAX all-reduce of an N-byte flag vector
+        (5 MB) - and only those rows ride in the bucket."""
+        eng = mo.eng
         N = mo.geo.shape[0]
-        if self._touched is None or self._touched.numel() != N:
-            self._touched = torch.zeros(N, dtype=torch.uint8, device=mo.geo.device)
-        else:
-            self._touched.zero_()
-        idx = mo.current_nbr_idx().reshape(-1)
-        self._touched[idx[idx >= 0].long()] = 1
-        dist.all_reduce(self._touched, op=dist.ReduceOp.MAX)
-        return torch.nonzero(self._touched).reshape(-1).to(torch.int32)
+        ag = self._agree.get(it & 1)
+        if ag is None or ag.flags.numel() != N:
+            ag = self._agree[it & 1] = _RowAgreement(eng, N)
+        ag.it = it
+        ag.flags.zero_()
+        dll = eng.lib.dll
+        eng.lib.check(dll.lk_touch_rows(ptr(idx), idx.numel(), ptr(ag.flags), N, eng.stream), 'lk_touch_rows')
+        self._all_reduce(ag.flags, dist.ReduceOp.MAX)
+        eng.lib.check(dll.lk_compact_large(ptr(ag.flags), N, ptr(ag.rows), ptr(ag.count), ptr(ag.scratch), eng.stream), 'lk_compact_large')
+        ag.count_host.copy_(ag.count, non_blocking=True)
+        if ag.event is not None:
+            ag.event.record(torch.cuda.current_stream(eng.device))
+        return ag
 
-    def all_reduce_vec(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return t
+    def prefetch_touched(self, mo, it):
+        """Called right after the phase-1 call of iteration it - 1 has been enqueued: agree on iteration `it`'s rows on the side
+        stream, beside that iteration's render."""
+        eng = mo.eng
+        if eng.device.type != 'cuda':
+            self._enqueue_agreement(mo, it, mo.nbr_idx_of(it))
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(eng.device)
+            self._main_ev = torch.cuda.Event()
+        main = torch.cuda.current_stream(eng.device)
+        self._main_ev.record(main)                  # serial mode of the library: the lists are written in the main stream's order
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(self._main_ev)
+            mo.wait_lists(it)                       # look-ahead mode: they are written on the library's third stream
+            self._enqueue_agreement(mo, it, mo.nbr_idx_of(it))
+
+    def touched_rows(self, mo, it=None):
+        """Sorted int32 row list (identical on every rank) of iteration `it`: the prefetched agreement if there is one - the
+        host waits for the SIDE stream's event only, the launch stream keeps its queue - else (first iteration of a call, or
+        the per-statement path whose lists exist only after its own forward) computed in line with one read-back."""
+        ag = self._agree.get(it & 1) if it is not None else None
+        if ag is not None and ag.it == it:
+            if ag.event is not None:
+                ag.event.synchronize()
+                torch.cuda.current_stream(mo.eng.device).wait_event(ag.event)
+        else:
+            ag = self._enqueue_agreement(mo, it if it is not None else 0, mo.nbr_idx_of(it))
+            if ag.event is not None:
+                ag.event.synchronize()
+        ag.it = -1
+        return ag.rows[:int(ag.count_host.item())]

@@ -174,7 +174,7 @@ class MapOptimizer:
                                                               ptr(xs.g_aff), eng.stream), 'lk_loss_mapper_exposure')
         core.render_backward(eng, st, gs, b.d_depth, b.d_color)
         if self.dist is not None:
-            self.dist.all_reduce_grads(self, stage)
+            self.dist.all_reduce_grads(self, stage, it=None)
         dlr, glr, clr = self.lrs[stage]
         segs = [(('gdec', k), self.dec.blob[o:o + n], gs.g_weights[o:o + n], dlr) for k, (o, n) in enumerate(self.geo_dec_ranges)]
         if stage == 'color':
@@ -267,22 +267,29 @@ class MapOptimizer:
         if self.dist is None:
             eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n_iters, 3, eng.stream), 'lk_map_frame')
         else:
+            self._nat_desc = d
             for it in range(n_iters):
-                self._nat_it = it
                 eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 1, eng.stream), 'lk_map_frame')
-                self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color')
+                if self.rows is None and it + 1 < n_iters and self._nat_lists is not None:
+                    self.dist.prefetch_touched(self, it + 1)        # next iteration's row list, agreed beside this iteration's render
+                self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color', it=it)
                 eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 2, eng.stream), 'lk_map_frame')
         self.it += n_iters
         return log
 
-    def current_nbr_idx(self):
-        """Neighbour lists [R*S, 8] (int32) of the iteration whose gradients are being exchanged: lk_map_frame keeps the lists of
-        every iteration in its work buffer (the search runs ahead of the loop); the per-statement path has them in the state."""
-        if getattr(self, '_nat_lists', None) is not None and self.native_loop and self.exposure is None:
+    def nbr_idx_of(self, it=None):
+        """Neighbour lists [R*S, 8] (int32) of iteration `it` of the running lk_map_frame call (it keeps the lists of every iteration
+        in its work buffer: the search runs ahead of the loop); it = None, or the per-statement path: the lists in the state."""
+        if it is not None and getattr(self, '_nat_lists', None) is not None and self.native_loop:
             off, _ = self._nat_lists
             P8 = self.R * self.cfg.S * 8
-            return self._work[off + self._nat_it * P8: off + (self._nat_it + 1) * P8].view(torch.int32)
+            return self._work[off + it * P8: off + (it + 1) * P8].view(torch.int32)
         return self.st.nbr_idx
+
+    def wait_lists(self, it):
+        """The current stream waits until lk_map_frame's look-ahead search has written iteration `it`'s lists."""
+        if getattr(self, '_nat_desc', None) is not None and getattr(self, '_nat_lists', None) is not None:
+            self.eng.lib.check(self.eng.lib.dll.lk_map_wait_lists(_ffi.C.byref(self._nat_desc), it, self.eng.stream), 'lk_map_wait_lists')
 
     def finish(self):
         """End of the optimize_map call: stacked exposure features go back to the keyframes' tensors."""
@@ -324,7 +331,12 @@ class TrackOptimizer:
         self.gs = core.GradState(eng, geo_feats.shape[0], R, dec.n, feats=False, weights=False, rays=True)
         self.g_cam = eng.zeros(7)
         self.eye = None
-        self.dist = dist                        # ray-sharded tracking: the 7 pose gradients are summed over ranks
+        # Multi-GPU: tracking is REPLICATED, not sharded.  An iteration at the reference's batch (1 500-5 000 rays) sits at the
+        # dependent-launch latency floor (~130 us for ~6 us of matrix work): a shard of it is no faster, and a
+        # per-iteration all-reduce of the 7 pose gradients (>= 30 us over RCCL) would only add to the chain.  Every rank runs the same
+        # native loop on the same draws against its replica of the map; rank 0's result is broadcast once per frame so that the
+        # ranks cannot drift apart through the loss log's float atomics (the candidate choice, Tracker.py:375-377).
+        self.dist = dist
         self.native_loop = True                 # lk_track_frame (one call per frame); False = one launch sequence per statement
 
     def track(self, cam7_init, depth_img, color_img, iters, window, intr, rnd_all, r2_map=None, exposure=None):
@@ -343,11 +355,11 @@ class TrackOptimizer:
                 gs.g_affine = eng.zeros(12)
         log = eng.zeros(iters, 4)
         hist = eng.empty(iters, 7)
-        if xs is None and self.dist is None and self.native_loop:
+        if xs is None and self.native_loop:
             # the whole loop as ONE C-ABI call (lk_track_frame): no interpreter between the launches
             self._track_native(cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log)
             best = torch.argmin(log[:, 0])      # Tracker.py:375-377 (first minimum)
-            return hist[best].clone(), log
+            return self._agree(hist[best].clone()), log
         if self.eye is None:
             self.eye = torch.eye(4, device=eng.device).reshape(1, 4, 4).contiguous()
         dstack, cstack = depth_img.reshape(1, H, W), color_img.reshape(1, H, W, 3)
@@ -370,10 +382,6 @@ class TrackOptimizer:
                                log[it], b.loss_scratch)
             core.render_backward(eng, st, gs, b.d_depth, b.d_color)
             optim.pose_bwd(eng, cam, b.pix_i, b.pix_j, intr, gs.g_rays_o, gs.g_rays_d, self.g_cam)
-            if self.dist is not None:
-                self.dist.all_reduce_vec(self.g_cam)
-                if xs is not None:
-                    self.dist.all_reduce_vec(gs.g_affine)
             if self.separate_lr:                # T: lr, quaternion: 0.2*lr (Tracker.py:317-333)
                 segs = [('T', cam[4:7], self.g_cam[4:7], self.cam_lr), ('q', cam[0:4], self.g_cam[0:4], 0.2 * self.cam_lr)]
             else:
@@ -385,7 +393,13 @@ class TrackOptimizer:
             if not self.separate_lr:
                 hist[it].copy_(cam)             # one leaf tensor stepped in place: the candidate is the pose AFTER the update
         best = torch.argmin(log[:, 0])          # Tracker.py:375-377 (first minimum)
-        return hist[best].clone(), log
+        return self._agree(hist[best].clone()), log
+
+    def _agree(self, cam7):
+        """Replicated tracking: every rank continues from rank 0's pose."""
+        if self.dist is not None:
+            self.dist.broadcast(cam7, src=0)
+        return cam7
 
     def _track_native(self, cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log):
         """lk_track_frame: descriptor of the render buffers + the loop's own buffers (all owned here)."""

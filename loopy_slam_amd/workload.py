@@ -71,14 +71,17 @@ class FrameWorkload:
                                             b.track_rays, b.cam_lr, separate_lr=True, w_color=0.5, dist=dist)
         # pixel draws happen on the device, as the reference's do (select_uv: torch.randint(..., device=device), common.py:156-172):
         # 300 000 host-side draws + their upload cost 0.9 ms of a 22 ms step with the GPU idle
+        # (multi-GPU: the mapping draws differ per rank - every rank renders its own rays of the shared iteration - the tracking draws
+        # are the same everywhere: tracking is replicated, steps.TrackOptimizer)
         self.gen = torch.Generator(device=dev).manual_seed(seed + (dist.rank if dist is not None else 0))
+        self.gen_track = torch.Generator(device=dev).manual_seed(seed + 7919)
         self._fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(dev)      # pixels // window frames each
         self.cam0 = get_tensor_from_camera(self.c2w_stack[0]).to(dev)
         self.map_log = eng.zeros(b.map_iters, 4)
         self.frame_no = 0
 
-    def _draws(self, iters, R, n):
-        return torch.randint(0, n, (iters, R), generator=self.gen, dtype=torch.int32, device=self.eng.device)
+    def _draws(self, iters, R, n, gen=None):
+        return torch.randint(0, n, (iters, R), generator=gen or self.gen, dtype=torch.int32, device=self.eng.device)
 
     def step(self):
         """One frame-equivalent: 40 tracking iterations + 60 mapping iterations (24 geometry + 36 colour)."""
@@ -86,7 +89,7 @@ class FrameWorkload:
         H, W = self.H, self.W
         e = min(b.ignore_edge, H // 4)
         win = (e, H - e, e, W - e)
-        rnd_t = self._draws(b.track_iters, b.track_rays, (win[1] - win[0]) * (win[3] - win[2]))
+        rnd_t = self._draws(b.track_iters, b.track_rays, (win[1] - win[0]) * (win[3] - win[2]), self.gen_track)
         k = self.frame_no % b.window
         best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win, self.intr, rnd_t)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)

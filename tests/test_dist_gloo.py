@@ -1,6 +1,9 @@
-"""Multi-GPU path on CPU: world_size 2, gloo.  Ray-sharded data parallel — every rank renders/back-propagates its
-shard, ONE all-reduce sums {decoder-blob, selected feature-row} gradients, the same Adam step runs everywhere
-(loopy_slam_amd/parallel.py).  Checked against a single process that sees both shards in one batch."""
+"""Multi-GPU path, world_size 2 over gloo: on the CPU emulator, and (-m gpu) with BOTH RANKS ON ONE MI355X through the real
+library (RCCL refuses two ranks on one device, so the collectives are staged through the host there; everything else - the
+kernels, lk_map_frame split in phases around the exchange, the side-stream row agreement - is the production path).
+Ray-sharded data parallel — every rank renders/back-propagates its shard, ONE all-reduce sums {decoder-blob, selected
+feature-row} gradients, the same Adam step runs everywhere (loopy_slam_amd/parallel.py).  Checked against a single process that
+sees both shards in one batch."""
 import os
 import socket
 import sys
@@ -17,9 +20,9 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 HH, WW = 24, 32
 INTR = (40.0, 40.0, 15.5, 11.5)
-R, ITERS = 64, 2
+R, ITERS = 64, 3
 LRS = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
-STAGES = ['geometry', 'color']
+STAGES = ['geometry', 'color', 'color']
 
 
 def build(eng, R_batch, dctx, all_rows=False):
@@ -45,56 +48,62 @@ def draws():
     return torch.randint(0, HH * WW, (ITERS, 2, R), generator=g, dtype=torch.int32)
 
 
-def worker(rank, port, q, all_rows=False):
+def worker(rank, port, q, all_rows=False, native=True, backend='emu'):
     try:
-        _worker(rank, port, q, all_rows)
+        _worker(rank, port, q, all_rows, native, backend)
     except Exception:                                   # surface the reason in the parent instead of a bare exit code
         import traceback
         q.put(('error', rank, traceback.format_exc()))
         raise
 
 
-def _worker(rank, port, q, all_rows=False):
+def _worker(rank, port, q, all_rows, native, backend):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=2)
     from loopy_slam_amd import parallel
     from util import make_engine
-    eng = make_engine('emu')
+    eng = make_engine(backend)
     mo, frames, dec, geo_d, col_d = build(eng, R, parallel.DistContext(rank, 2), all_rows)
-    rnd = draws()
-    fid = torch.zeros(R, dtype=torch.int32)
+    rnd = draws().to(eng.device)
+    fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
     losses = []
-    if all_rows:        # the native loop (lk_map_frame) split around the exchange, whole-map rows: touched-row bucket
-        log = torch.zeros(ITERS, 4)
+    if native:          # the native loop (lk_map_frame) split around the exchange; all_rows: touched-row bucket, agreed one iteration ahead
+        log = eng.zeros(ITERS, 4)
         mo.run(ITERS, 1, frames, rnd[:, rank].contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW, log)
+        log = log.cpu()
         dist.all_reduce(log)
         losses = [float(x) for x in log[:, 0]]
     else:
         for it in range(ITERS):
             out4 = mo.iterate(STAGES[it], frames, rnd[it, rank].contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
-            t = out4.clone()
+            t = out4.cpu().clone()
             dist.all_reduce(t)
             losses.append(float(t[0]))
     if rank == 0:
-        q.put((losses, dec.blob.clone(), geo_d.clone(), col_d.clone()))
+        q.put((losses, dec.blob.cpu().clone(), geo_d.cpu().clone(), col_d.cpu().clone()))
     else:
-        q.put((losses, dec.blob.clone(), None, None))
+        q.put((losses, dec.blob.cpu().clone(), None, None))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('all_rows', (False, True))
-def test_two_rank_grad_allreduce_matches_single_process(all_rows):
-    """all_rows: every row of the map is a parameter (final refinement) - the ranks exchange the union of the touched rows, and
-    both sides run the native loop (lk_map_frame, split around the all-reduce on the two-rank side)."""
+from util import backends  # noqa: E402
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('all_rows,native', ((False, False), (False, True), (True, True)))
+def test_two_rank_grad_allreduce_matches_single_process(all_rows, native, backend):
+    """native: the two-rank side runs lk_map_frame split in phases 1 / 2 around the all-reduce (else the per-statement path).
+    all_rows: every row of the map is a parameter (final refinement) - the ranks exchange the union of the touched rows, agreed
+    one iteration ahead on a side stream.  backend hip: both ranks on cuda:0."""
     from util import make_engine
     torch.set_num_threads(1)
-    eng = make_engine('emu')
+    eng = make_engine(backend)
     mo, frames, dec, geo_d, col_d = build(eng, 2 * R, None, all_rows)
-    rnd = draws()
-    fid = torch.zeros(2 * R, dtype=torch.int32)
+    rnd = draws().to(eng.device)
+    fid = torch.zeros(2 * R, dtype=torch.int32, device=eng.device)
     ref_losses = []
     for it in range(ITERS):
         out4 = mo.iterate(STAGES[it], frames, rnd[it].reshape(-1).contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
@@ -107,7 +116,7 @@ def test_two_rank_grad_allreduce_matches_single_process(all_rows):
         s.close()
         ctx = mp.get_context('spawn')
         q = ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, port, q, all_rows)) for r in range(2)]
+        procs = [ctx.Process(target=worker, args=(r, port, q, all_rows, native, backend)) for r in range(2)]
         for p in procs:
             p.start()
         try:
@@ -127,7 +136,8 @@ def test_two_rank_grad_allreduce_matches_single_process(all_rows):
     other = [r for r in res if r[2] is None][0]
     np.testing.assert_allclose(full[0], ref_losses, rtol=1e-5)
     assert torch.equal(full[1], other[1])                                   # identical parameters on both ranks
-    np.testing.assert_allclose(full[1].numpy(), dec.blob.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(full[1].numpy(), dec.blob.cpu().numpy(), rtol=0, atol=2e-5)
+    geo_d, col_d = geo_d.cpu(), col_d.cpu()
     err = (full[2] - geo_d).abs()
     assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.015
     err = (full[3] - col_d).abs()
