@@ -369,6 +369,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             if (rc != LK_OK) return rc;
         }
         LkBwdExtra ex;
+        memset(&ex, 0, sizeof(ex));
         ex.pose_part = fused ? W0 + wk.pose_part : nullptr;
         ex.pix_i = W0 ? W0 + wk.pix_i + (size_t)it * R : nullptr; ex.pix_j = W0 ? W0 + wk.pix_j + (size_t)it * R : nullptr;
         ex.fx = d->fx; ex.fy = d->fy; ex.cx = d->cx; ex.cy = d->cy;

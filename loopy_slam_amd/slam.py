@@ -434,6 +434,9 @@ class Mapper:
         self.gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219) + 7)
         self.prev_c2w = None
         self.last_log = None
+        # the optimised exposure feature of every optimize_map call (Mapper.py:800, 827): checkpointed (Mapper.py:1028-1031) and read
+        # back by the final refinement and the evaluation renders (Mapper.py:394, 1111)
+        self.exposure_feat_all = [] if slam.encode_exposure else None
 
     def set_pipe(self, pipe):
         self.pipe = pipe
@@ -612,6 +615,7 @@ class Mapper:
         mo.finish()
         if self.slam.encode_exposure:           # the optimised feature of this frame is what the tracker starts from (Mapper.py:799)
             self.slam.exposure_feat = self.cur_exposure_feat.detach().clone()
+            self.exposure_feat_all.append(self.cur_exposure_feat.detach().cpu())          # Mapper.py:800
         self.last_log = log
         return None
 
@@ -643,7 +647,8 @@ class Mapper:
         if saved is not None and not self.keep_refine_settings:
             (self.mapping_window_size, self.geo_iter_ratio, self.fix_color_decoder, self.frustum_feature_selection,
              self.keyframe_selection_method) = saved
-        if (idx % self.keyframe_every == 0 or idx == slam.n_img - 2) and idx not in self.keyframe_list:
+        # (no keyframe from a frame whose ground-truth pose is not finite - ScanNet has -inf poses, Mapper.py:982)
+        if (idx % self.keyframe_every == 0 or idx == slam.n_img - 2) and idx not in self.keyframe_list and bool(torch.isfinite(gt_c2w).all()):
             self.keyframe_list.append(idx)
             self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': gt_color, 'depth': gt_depth, 'est_c2w': cur_c2w.clone(),
                                        'r2_query': getattr(self, 'cur_r2_query', None),
@@ -666,7 +671,7 @@ class Mapper:
                 self.map_frame(idx, color, depth, c2w, cur_c2w=est)
                 if self.logger is not None and ((idx > 0 and idx % self.ckpt_freq == 0) or idx == n - 1):
                     self.logger.log(idx, self.keyframe_dict, self.keyframe_list, npc=self.npc,
-                                    exposure_feat=None, last_log=(idx == n - 1))
+                                    exposure_feat=self.exposure_feat_all, last_log=(idx == n - 1))
             if callback:
                 callback(idx, est, c2w)
         return slam.estimate_c2w_list[:n], slam.gt_c2w_list[:n]
@@ -892,7 +897,7 @@ class Logger:
             'selected_keyframes': selected_keyframes if selected_keyframes is not None else {},
             'idx': idx,
             'fragments': [],
-            'exposure_feat_all': torch.stack([cpu(e) for e in exposure_feat], dim=0) if exposure_feat is not None else None,
+            'exposure_feat_all': torch.stack([cpu(e) for e in exposure_feat], dim=0) if exposure_feat else None,
         }
         if last_log:
             ck['geo_feats'] = cpu(npc.get_geo_feats(end=True)).float()         # the reference's tools read fp32 tables whatever the storage format
@@ -931,6 +936,11 @@ class Logger:
                 kf['r2_query'] = (kf['dynamic_r_query'].double() ** 2).float().contiguous()
             kfs.append(kf)
         slam_obj.mapper.keyframe_dict = kfs
+        if slam_obj.encode_exposure:            # per-mapped-frame exposure features (Mapper.py:394, 1111; get_mesh_tsdf_fusion.py:44-46)
+            xa = ck.get('exposure_feat_all')
+            slam_obj.mapper.exposure_feat_all = [e.clone() for e in xa] if xa is not None else []
+            if xa is not None and len(xa):
+                slam_obj.exposure_feat = xa[-1].to(eng.device).clone()
         if 'geo_feats' not in ck and n:
             import warnings
             warnings.warn(f'{path}: no geo_feats / col_feats in this checkpoint (the reference only writes them with last_log): '

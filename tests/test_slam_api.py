@@ -2,6 +2,8 @@
 Miniature synthetic room so the emulator back-end finishes in seconds; the gpu back-end runs the same."""
 import copy
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -156,6 +158,38 @@ def test_checkpoint_roundtrip_reference_format(backend, tmp_path):
     d1, u1, c1 = ps.renderer.render_img(ps.npc, ps.shared_decoders, c2w, eng.device, 'color', gt_depth=depth)
     d2, u2, c2 = ps2.renderer.render_img(ps2.npc, ps2.shared_decoders, c2w, eng.device, 'color', gt_depth=depth)
     assert torch.equal(d1.cpu(), d2.cpu()) and torch.equal(c1.cpu(), c2.cpu())
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_exposure_features_are_checkpointed(backend, tmp_path):
+    """model.encode_exposure: the mapper keeps the optimised exposure feature of every optimize_map call (Mapper.py:800, 827),
+    Mapper.run hands the list to the Logger (Mapper.py:1028-1031), and Logger.load restores it (Mapper.py:394, 1111;
+    get_mesh_tsdf_fusion.py:44-46).  A keyframe is not inserted for a frame whose ground-truth pose is not finite (Mapper.py:982)."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['model']['encode_exposure'] = True
+    cfg['mapping']['ckpt_freq'] = 2
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    ps.mapper.logger = slam.Logger(cfg, None, ps.mapper, ckptsdir=str(tmp_path))
+    ps.run()
+    n_mapped = sum(1 for i in range(ps.n_img) if i == 0 or i % ps.mapper.every_frame == 0 or i == ps.n_img - 1)
+    xa = ps.mapper.exposure_feat_all
+    assert len(xa) >= n_mapped and all(tuple(e.shape) == (cfg['model']['exposure_dim'],) for e in xa)
+    assert float(torch.stack(xa).abs().max()) > 0                          # the feature moved off its zero start
+    path = os.path.join(str(tmp_path), '{:05d}.tar'.format(ps.n_img - 1))
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert ck['exposure_feat_all'] is not None and torch.equal(ck['exposure_feat_all'], torch.stack(xa))
+    ps2 = slam.Point_SLAM(cfg, None, eng=eng)
+    slam.Logger.load(path, ps2)
+    assert len(ps2.mapper.exposure_feat_all) == len(xa) and torch.equal(ps2.mapper.exposure_feat_all[-1], xa[-1])
+    assert torch.equal(ps2.exposure_feat.cpu(), xa[-1])
+    # non-finite ground-truth pose: the frame is mapped, but never becomes a keyframe
+    ps3 = slam.Point_SLAM(mini_cfg(), None, eng=eng)
+    idx, color, depth, c2w = ps3.frame_reader[0]
+    ps3.tracker.track_frame(0, color, depth, c2w)
+    bad = c2w.clone(); bad[0, 3] = float('-inf')
+    ps3.mapper.map_frame(0, color, depth, bad, cur_c2w=c2w)
+    assert ps3.mapper.keyframe_list == []
 
 
 @pytest.mark.parametrize('backend', backends())
