@@ -126,3 +126,69 @@ def test_top_grad_pixels(backend):
     ref = H.top_grad_pixels(q.numpy(), 2000, win, depth.numpy())
     got = optim.top_grad_pixels(eng, eng.f32(q), 2000, win, eng.f32(depth))
     assert np.array_equal(got.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ against the REFERENCE's own outputs (G9-G12: its methods run on stand-ins)
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('case', ('static', 'grad', 'dynamic', 'empty'))
+def test_add_points_matches_reference_golden(backend, case):
+    """lk_add_points / NeuralPointCloud.add_neural_points vs what the reference's add_neural_points produced
+    (neural_point.py:1557-1631): accepted count, the three points per accepted ray bit for bit, input_pos / input_rgb."""
+    from loopy_slam_amd import slam
+    from test_slam_api import mini_cfg
+    from util import load
+    g = load('g9_add_points')
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['pointcloud'].update(radius_add=float(g['radius_add']), radius_min=float(g['radius_min']), radius_query=0.08)
+    npc = slam.NeuralPointCloud(cfg, eng=eng, capacity=4096)
+    cloud = torch.from_numpy(g['cloud'])
+    n0 = 0 if case == 'empty' else cloud.shape[0]
+    if n0:
+        npc._grow(n0); npc._pos[:n0] = eng.f32(cloud); npc.n = n0
+        npc.knn.build(npc._pos[:n0])
+    kw = {}
+    if case == 'grad':
+        kw['is_pts_grad'] = True
+    if case == 'dynamic':
+        kw['dynamic_radius'] = torch.from_numpy(g['dynamic_radius']).to(eng.device)
+    n_acc = npc.add_neural_points(eng.f32(g['rays_o']), eng.f32(g['rays_d']), eng.f32(g[f'{case}_depth']), eng.f32(g['gt_color']), **kw)
+    assert int(n_acc) == int(g[f'{case}_count']) and npc.pts_num() == int(g[f'{case}_index_size'])
+    assert np.array_equal(npc.cloud_pos()[n0:].cpu().numpy(), g[f'{case}_new_points'])
+    assert np.array_equal(npc.input_pos().cpu().numpy(), g[f'{case}_input_pos'])
+    np.testing.assert_allclose(npc.input_rgb().cpu().numpy(), g[f'{case}_input_rgb'], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_mapper_filter_overlap_and_near_pcl_match_reference_golden(backend):
+    """slam.Mapper.filter_point_before_add (Mapper.py:137-163), the batched keyframe overlap (Mapper.py:250-270) and
+    NeuralPointCloud.sample_near_pcl (neural_point.py:1734-1786) vs the reference's outputs."""
+    from loopy_slam_amd import slam
+    from test_slam_api import mini_cfg
+    from util import load
+    eng = make_engine(backend)
+    g = load('g11_filter_before_add')
+    cfg = mini_cfg()
+    cfg['cam'].update(H=int(g['HW'][0]), W=int(g['HW'][1]), fx=float(g['intr'][0]), fy=float(g['intr'][1]), cx=float(g['intr'][2]), cy=float(g['intr'][3]),
+                      crop_edge=0)
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    out = ps.mapper.filter_point_before_add(eng.f32(g['rays_o']), eng.f32(g['rays_d']), eng.f32(g['gt_depth']), torch.from_numpy(g['prev_c2w']))
+    # fp32 closed-form inverse here, numpy inverse + a float64 intrinsics product there: a point ON the image border may flip
+    assert int((out.cpu().numpy() != g['outside']).sum()) <= 1
+    g = load('g12_keyframe_overlap')
+    ro, rd, gd = (eng.f32(g[k]) for k in ('rays_o', 'rays_d', 'gt_depth'))
+    t = torch.linspace(0., 1., int(g['N_samples']), device=eng.device)
+    z = gd[:, None] * 0.8 * (1 - t) + (gd[:, None] + 0.5) * t
+    pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(-1, 3)
+    frac = ps.mapper.overlap_fractions(pts, [torch.from_numpy(c) for c in g['est_c2ws']]).cpu().numpy()
+    np.testing.assert_allclose(frac, g['percent_inside'], rtol=0, atol=1.5 / pts.shape[0])        # border points: at most one each way
+    assert np.array_equal(frac > 0, g['percent_inside'] > 0)
+    g = load('g10_sample_near_pcl')
+    cfg = mini_cfg()
+    cfg['pointcloud']['radius_query'] = float(g['radius_query'])
+    npc = slam.NeuralPointCloud(cfg, eng=eng, capacity=4096)
+    n = g['cloud'].shape[0]
+    npc._grow(n); npc._pos[:n] = eng.f32(g['cloud']); npc.n = n
+    npc.knn.build(npc._pos[:n])
+    z, inv = npc.sample_near_pcl(eng.f32(g['rays_o']), eng.f32(g['rays_d']), float(g['near']), float(g['far']), int(g['num']))
+    assert np.array_equal(inv.cpu().numpy(), g['invalid']) and np.array_equal(z.cpu().numpy(), g['z'])

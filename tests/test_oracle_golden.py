@@ -259,3 +259,53 @@ def test_g8_adam():
             H.adam_step(P[t], grads[t], M[t], V[t], lrs[t], steps[t])
         for t, k in enumerate(('dec', 'geo', 'col')):
             np.testing.assert_allclose(P[t].numpy(), g[k][it], rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ G9-G12 map maintenance (reference methods run on stand-ins)
+@pytest.mark.parametrize('case', ('static', 'grad', 'dynamic', 'empty'))
+def test_g9_add_points(case):
+    """oracle.add_points vs NeuralPointCloud.add_neural_points (neural_point.py:1557-1631) with the radius rules of its
+    find_neighbors_faiss call (step 'add': radius_add, radius_min for gradient points, per-ray dynamic radius)."""
+    g = load('g9_add_points')
+    ro, rd, cloud = tens(g, 'rays_o', 'rays_d', 'cloud')
+    gd = torch.from_numpy(g[f'{case}_depth'])
+    if case == 'dynamic':
+        r2 = (torch.from_numpy(g['dynamic_radius']) ** 2).float().numpy()         # f64 square, then fp32 (the ABI's radius format)
+    else:
+        r2 = np.float32(float(g['radius_min' if case == 'grad' else 'radius_add']) ** 2)
+    acc, pts = H.add_points(ro, rd, gd, cloud[:0] if case == 'empty' else cloud, r2, float(g['near_surface']), float(g['far_surface']), 3)
+    assert acc.numel() == int(g[f'{case}_count']) and int(g[f'{case}_index_size']) == (0 if case == 'empty' else cloud.shape[0]) + pts.shape[0]
+    assert np.array_equal(pts.numpy(), g[f'{case}_new_points'])                   # same expression, same order: bit for bit
+    surf = ro[acc.long()] + rd[acc.long()] * gd[acc.long(), None]
+    assert np.array_equal(surf.numpy(), g[f'{case}_input_pos'])
+    np.testing.assert_allclose((torch.from_numpy(g['gt_color'])[acc.long()] * 255).numpy(), g[f'{case}_input_rgb'], rtol=0, atol=1e-4)
+
+
+def test_g10_sample_near_pcl():
+    g = load('g10_sample_near_pcl')
+    z, invalid = H.sample_near_pcl(g['rays_o'], g['rays_d'], float(g['near']), float(g['far']), int(g['num']), g['cloud'], float(g['radius_query']))
+    assert np.array_equal(invalid, g['invalid']) and 0 < invalid.sum() < invalid.size
+    assert np.array_equal(z, g['z'])
+    assert (np.abs(z[~invalid] - z[invalid][0]).max(axis=1) > 0.1).any()          # some rays really moved their samples to the cloud
+
+
+def test_g11_filter_point_before_add():
+    g = load('g11_filter_before_add')
+    fx, fy, cx, cy = (float(x) for x in g['intr'])
+    out = H.filter_point_before_add(*tens(g, 'rays_o', 'rays_d', 'gt_depth'), g['prev_c2w'], fx, fy, cx, cy, int(g['HW'][0]), int(g['HW'][1]))
+    assert np.array_equal(out.numpy(), g['outside']) and 0.1 < g['outside'].mean() < 0.9
+
+
+def test_g12_keyframe_overlap():
+    """percent_inside of every keyframe as Mapper.keyframe_selection_overlap computes it (Mapper.py:250-270), on the rays the
+    reference drew; the keyframes it selects are those with a non-zero overlap."""
+    g = load('g12_keyframe_overlap')
+    ro, rd, gd = tens(g, 'rays_o', 'rays_d', 'gt_depth')
+    t = torch.linspace(0., 1., steps=int(g['N_samples']))
+    dd = gd.reshape(-1, 1).repeat(1, int(g['N_samples']))
+    z = (dd * 0.8) * (1. - t) + (dd + 0.5) * t
+    pts = (ro[..., None, :] + rd[..., None, :] * z[..., :, None]).reshape(-1, 3).numpy()
+    fx, fy, cx, cy = (float(x) for x in g['intr'])
+    frac = H.keyframe_overlap_fractions(pts, g['est_c2ws'], fx, fy, cx, cy, int(g['HW'][0]), int(g['HW'][1]))
+    np.testing.assert_allclose(frac, g['percent_inside'], rtol=0, atol=1e-12)
+    assert sorted(np.nonzero(frac > 0)[0].tolist()) == g['selected'].tolist() and (frac == 0).any()

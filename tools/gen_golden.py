@@ -20,6 +20,12 @@ Fixtures:
                      Tracker.py:169-191 (those are inline in the reference, so the
                      generator evaluates the same expressions on the reference's outputs)
   g8_adam            torch.optim.Adam trajectories with the stage lr schedule
+  g9_add_points      NeuralPointCloud.add_neural_points (+ its find_neighbors_faiss radius rules)  (neural_point.py:1557-1631,1659-1708)
+  g10_sample_near_pcl  NeuralPointCloud.sample_near_pcl           (neural_point.py:1734-1786)
+  g11_filter_before_add  Mapper.filter_point_before_add           (Mapper.py:137-163)
+  g12_keyframe_overlap   Mapper.keyframe_selection_overlap        (Mapper.py:219-282)
+G9-G12 call the reference's methods UNBOUND on stand-in objects: the classes themselves need faiss-gpu, pydbow3 and the datasets to
+construct, the methods are plain torch / numpy.  The stand-in index answers `search` exactly (FAISS-IVF itself stays unpinned).
 """
 import os
 import sys
@@ -426,6 +432,181 @@ def g8_adam():
          n_geo_stage=np.int32(8))
 
 
+# ------------------------------------------------------------------ G9-G12: map maintenance, reference methods on stand-ins
+class ExactIndex:
+    """Stand-in for the FAISS IVF index of NeuralPointCloud: exact squared-L2 top-k over the stored points, FAISS's
+    conventions (ascending D, missing slots D = FLT_MAX / I = -1, is_trained)."""
+
+    def __init__(self, pos=None):
+        self.pos = torch.zeros(0, 3) if pos is None else pos.float().clone()
+        self.is_trained = self.pos.shape[0] > 0
+
+    def train(self, x):
+        self.is_trained = True
+
+    def add(self, x):
+        self.pos = torch.cat([self.pos, torch.as_tensor(x).float().reshape(-1, 3)], 0)
+
+    def search(self, q, k):
+        q = q.reshape(-1, 3).float()
+        n = self.pos.shape[0]
+        d = q[:, None, :] - self.pos[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        kk = min(k, n)
+        D, I = torch.topk(d2, kk, dim=1, largest=False, sorted=True)
+        if kk < k:
+            D = torch.cat([D, torch.full((q.shape[0], k - kk), float(np.finfo(np.float32).max))], 1)
+            I = torch.cat([I, torch.full((q.shape[0], k - kk), -1, dtype=I.dtype)], 1)
+        return D, I
+
+
+def npc_standin(NPC, cfg, pos):
+    """An object with the attributes NeuralPointCloud.__init__ reads from the config (neural_point.py:30-90) that the three
+    methods touch; find_neighbors_faiss is the REFERENCE's own method bound to it."""
+    import types
+    pc = cfg['pointcloud']
+    o = types.SimpleNamespace()
+    o.device = 'cpu'
+    o.c_dim, o.nn_num = cfg['model']['c_dim'], pc['nn_num']
+    o.radius_add, o.radius_min, o.radius_query, o.radius_mesh = pc['radius_add'], pc['radius_min'], pc['radius_query'], pc.get('radius_mesh', 0.08)
+    o.N_add, o.near_end_surface, o.far_end_surface = pc['N_add'], pc['near_end_surface'], pc['far_end_surface']
+    o.fix_interval_when_add_along_ray = pc.get('fix_interval_when_add_along_ray', False)
+    o.segment_strategy = 'rot_trans'
+    o._input_pos, o._input_rgb, o._pts_num = [], [], 0
+    o.index = ExactIndex(pos)
+    o.captured = {}
+    o.check_index = lambda method=None, idx=None, cur_c2w=None: False
+    o.update_fragments = lambda **kw: o.captured.update(kw)
+    o.get_cloud_pos = lambda end=False: o.index.pos.tolist()
+    o.find_neighbors_faiss = types.MethodType(NPC.find_neighbors_faiss, o)
+    return o
+
+
+def g9_add_points(cfg):
+    import src.neural_point as npm
+    NPC = npm.NeuralPointCloud
+    g = torch.Generator().manual_seed(SEED + 9)
+    n = 400
+    ro = torch.tensor([0.2, -0.1, 0.3]).repeat(n, 1)
+    rd = torch.cat([torch.rand(n, 2, generator=g) * 1.2 - 0.6, -torch.ones(n, 1)], 1)
+    gd = 1.0 + 2.0 * torch.rand(n, generator=g)
+    gc = torch.rand(n, 3, generator=g)
+    # existing cloud: near the surface points of about half of the rays, at distances around the three radii
+    surf = ro + rd * gd[:, None]
+    pick = torch.randperm(n, generator=g)[: n // 2]
+    dirs = torch.nn.functional.normalize(torch.randn(pick.numel(), 3, generator=g), dim=1)
+    dist = torch.rand(pick.numel(), 1, generator=g) * 0.1                      # 0 .. 0.1 m: straddles radius_min 0.02, radius_add 0.04, 0.08
+    cloud = torch.cat([surf[pick] + dirs * dist, torch.rand(300, 3, generator=g) * 6 - 3], 0)
+    out = dict(rays_o=ro, rays_d=rd, gt_color=gc, cloud=cloud)
+    gd_holes = gd.clone(); gd_holes[::17] = 0.0                                # rays without a depth reading are dropped first
+    dyn = (0.02 + 0.06 * torch.rand(n, generator=g)).double()                  # per-ray dynamic radius_add (float64, Mapper.py:854-872)
+    cases = {'static': dict(depth=gd_holes, kw={}), 'grad': dict(depth=gd_holes, kw=dict(is_pts_grad=True)),
+             'dynamic': dict(depth=gd, kw=dict(dynamic_radius=dyn)), 'empty': dict(depth=gd_holes, kw={}, empty=True)}
+    for name, c in cases.items():
+        o = npc_standin(NPC, cfg, None if c.get('empty') else cloud)
+        torch.manual_seed(3)
+        ret = NPC.add_neural_points(o, ro.clone(), rd.clone(), c['depth'].clone(), gc.clone(), **c['kw'])
+        out[f'{name}_depth'] = c['depth']
+        out[f'{name}_count'] = np.int64(int(ret))
+        out[f'{name}_new_points'] = o.captured['npc']                          # what update_fragments receives as the new neural points
+        out[f'{name}_input_pos'] = torch.tensor(o._input_pos, dtype=torch.float32).reshape(-1, 3)
+        out[f'{name}_input_rgb'] = torch.tensor(o._input_rgb, dtype=torch.float32).reshape(-1, 3)
+        out[f'{name}_index_size'] = np.int64(o.index.pos.shape[0])
+    out['dynamic_radius'] = dyn
+    out['radius_add'], out['radius_min'] = np.float64(cfg['pointcloud']['radius_add']), np.float64(cfg['pointcloud']['radius_min'])
+    out['near_surface'], out['far_surface'] = np.float64(cfg['pointcloud']['near_end_surface']), np.float64(cfg['pointcloud']['far_end_surface'])
+    save('g9_add_points', **out)
+
+
+def g10_sample_near_pcl(cfg):
+    import src.neural_point as npm
+    NPC = npm.NeuralPointCloud
+    g = torch.Generator().manual_seed(SEED + 10)
+    wall = torch.cat([torch.rand(2500, 2, generator=g) * 4 - 2, torch.full((2500, 1), 2.0)], 1)       # a wall at z = 2
+    wall2 = torch.cat([torch.rand(900, 2, generator=g) * 4 - 2, torch.full((900, 1), 3.1)], 1)        # a sparser one behind it
+    cloud = torch.cat([wall, wall2], 0) + 0.01 * torch.randn(3400, 3, generator=g)
+    n = 60
+    ro = torch.zeros(n, 3)
+    rd = torch.cat([torch.rand(n, 2, generator=g) * 0.8 - 0.4, torch.ones(n, 1)], 1)
+    rd[:6, 2] = -1.0                                                            # looking away from the cloud: invalid rays
+    o = npc_standin(NPC, cfg, cloud)
+    near, far, num = 0.3, torch.tensor(4.0), 5
+    z, invalid = NPC.sample_near_pcl(o, ro, rd, near, far, num)
+    save('g10_sample_near_pcl', rays_o=ro, rays_d=rd, cloud=cloud, near=np.float64(near), far=np.float64(4.0), num=np.int64(num),
+         radius_query=np.float64(cfg['pointcloud']['radius_query']), z=z, invalid=invalid)
+
+
+def mapper_standin(cam):
+    import types
+    o = types.SimpleNamespace()
+    o.device = 'cpu'
+    o.H, o.W, o.fx, o.fy, o.cx, o.cy = cam['H'], cam['W'], cam['fx'], cam['fy'], cam['cx'], cam['cy']
+    return o
+
+
+def _pose(g, yaw, t):
+    """c2w looking down -z, rotated by `yaw` about y, at position t (the dataset convention after the readers' flip)."""
+    c, s_ = math.cos(yaw), math.sin(yaw)
+    M = torch.eye(4)
+    M[:3, :3] = torch.tensor([[c, 0., s_], [0., 1., 0.], [-s_, 0., c]])
+    M[:3, 3] = torch.tensor(t)
+    return M
+
+
+def g11_filter_before_add(ref, cfg):
+    import src.Mapper as M
+    cam = cfg['cam']
+    g = torch.Generator().manual_seed(SEED + 11)
+    o = mapper_standin(cam)
+    cur, prev = _pose(g, 0.25, [0.1, 0.0, 0.2]), _pose(g, -0.15, [0.0, 0.05, 0.0])
+    n = 500
+    i = torch.randint(0, cam['W'], (n,), generator=g).float()
+    j = torch.randint(0, cam['H'], (n,), generator=g).float()
+    ro, rd = ref.common.get_rays_from_uv(i, j, cur, cam['H'], cam['W'], cam['fx'], cam['fy'], cam['cx'], cam['cy'], 'cpu')
+    gd = 0.5 + 3.0 * torch.rand(n, generator=g)
+    mask = M.Mapper.filter_point_before_add(o, ro, rd, gd, prev)
+    save('g11_filter_before_add', rays_o=ro, rays_d=rd, gt_depth=gd, prev_c2w=prev, cur_c2w=cur, outside=mask,
+         intr=np.array([cam['fx'], cam['fy'], cam['cx'], cam['cy']], np.float64), HW=np.array([cam['H'], cam['W']], np.int64))
+
+
+def g12_keyframe_overlap(ref, cfg):
+    import builtins
+    import src.Mapper as M
+    cam = cfg['cam']
+    H, W = cam['H'], cam['W']
+    g = torch.Generator().manual_seed(SEED + 12)
+    o = mapper_standin(cam)
+    cur = _pose(g, 0.1, [0.0, 0.0, 0.0])
+    yaws = [0.0, 0.3, 0.8, 1.6, 3.0, -0.5, 0.12]
+    kfs = [{'est_c2w': _pose(g, y, [0.2 * k - 0.5, 0.03 * k, 0.1 * k])} for k, y in enumerate(yaws)]
+    depth = 1.5 + torch.rand(H, W, generator=g)
+    depth[::9, ::7] = 0.0
+    color = torch.rand(H, W, 3, generator=g)
+    rec = {}
+    orig_get_samples = M.get_samples
+
+    def rec_samples(*a, **k):                       # the reference's own draw, recorded (its pixels come from the global RNG)
+        r = orig_get_samples(*a, **k)
+        rec['rays_o'], rec['rays_d'], rec['gt_depth'] = r[0].clone(), r[1].clone(), r[2].clone()
+        return r
+
+    def rec_sorted(lst, **k):                       # percent_inside of every keyframe, as handed to sorted() (Mapper.py:274-275)
+        rec['percent'] = [float(d['percent_inside']) for d in lst]
+        return builtins.sorted(lst, **k)
+    M.get_samples, M.sorted = rec_samples, rec_sorted
+    try:
+        torch.manual_seed(SEED)
+        np.random.seed(SEED)
+        sel = M.Mapper.keyframe_selection_overlap(o, color, depth, cur, kfs, k=len(kfs))
+    finally:
+        M.get_samples = orig_get_samples
+        del M.sorted
+    save('g12_keyframe_overlap', rays_o=rec['rays_o'], rays_d=rec['rays_d'], gt_depth=rec['gt_depth'],
+         est_c2ws=torch.stack([kf['est_c2w'] for kf in kfs]), percent_inside=np.asarray(rec['percent'], np.float64),
+         selected=np.asarray(sorted(int(x) for x in sel), np.int64), N_samples=np.int64(8),
+         intr=np.array([cam['fx'], cam['fy'], cam['cx'], cam['cy']], np.float64), HW=np.array([H, W], np.int64))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)            # deterministic reductions
@@ -438,7 +619,21 @@ def main():
         print('g4-6', name)
         g456(ref, name, cfg)
     print('g8'); g8_adam()
+    maintenance(ref, cfgs)
+
+
+def maintenance(ref, cfgs):
+    print('g9-12')
+    g9_add_points(cfgs['replica'])
+    g10_sample_near_pcl(cfgs['replica'])
+    g11_filter_before_add(ref, cfgs['tum'])
+    g12_keyframe_overlap(ref, cfgs['tum'])
 
 
 if __name__ == '__main__':
-    main()
+    if '--maintenance-only' in sys.argv:            # G9-G12 alone (the other fixtures are unchanged)
+        torch.set_num_threads(1)
+        _ref = import_reference()
+        maintenance(_ref, {k: load_cfg(_ref, v) for k, v in CFGS.items()})
+    else:
+        main()
