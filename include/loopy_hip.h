@@ -304,6 +304,24 @@ int lk_top_grad_pixels(const float* grad_mag, int32_t H, int32_t W, int32_t K, i
 int lk_inside_mask(const float* depth, int32_t n, uint8_t* mask, float* depth_filtered, float* out_thr,
                    uint32_t* scratch, void* stream);
 
+/* Exposure encoding inside the per-frame loops (lk_track_frame / lk_map_frame): everything lk_exposure_fwd / _bwd and the Adam groups of
+ * mlp_exposure and the exposure features need (Tracker.py:329-344; Mapper.py:524-570, 588-607), all caller-owned.  Per iteration the
+ * loops run ONE small launch for it: backward of the MLP from g_aff, Adam on its tensors and on the trainable features, forward with
+ * the stepped values for the next iteration, g_aff cleared. */
+typedef struct {
+    float* feats;               /* [F,8] exposure features (tracker: F = 1; mapper: the keyframes of the window, the current frame last) */
+    float* W1; float* b1; float* W2; float* b2;      /* mlp_exposure: [128,8], [128], [12,128], [12] - stepped in place */
+    int32_t F;                  /* 1 .. LK_EXPOSURE_MAX_F */
+    float* aff;                 /* [F,12] */
+    float* hid;                 /* [F,128] */
+    float* g_aff;               /* [F,12] d loss / d aff of the iteration (accumulated by the loss / decoder kernels) */
+    float* g;                   /* [LK_EXPOSURE_GRAD_FLOATS] layout of lk_exposure_bwd */
+    float* adam;                /* [2][LK_EXPOSURE_GRAD_FLOATS] exp_avg | exp_avg_sq in the layout of g; zeroed by the caller (fresh optimiser) */
+    float lr_mlp;               /* Adam rate of the four MLP tensors (tracker 1e-3; mapper: decoders_lr of stage 'color'); < 0: frozen */
+    float lr_feat;              /* Adam rate of the trainable features (1e-3) */
+    int32_t feat_first, feat_count;      /* features [feat_first, feat_first + feat_count) are Adam parameters (mapper: only the last) */
+} lk_exposure_desc;
+
 /* ---------------------------------------------------------------- per-frame optimisation loops
  * The launch sequences of the reference's two inner loops as ONE call each, so that the host enqueues a frame's work in
  * microseconds instead of interpreting ~20 Python statements per iteration (at 1 500-ray tracking batches the Python loop
@@ -345,12 +363,13 @@ typedef struct {
                                    fused (9 launches per iteration instead of 16); gt_color / pix_i / pix_j / thr / scratch_u32 /
                                    loss_scratch and render.g_rays_o / g_rays_d are then not used and may be NULL.  NULL: the
                                    per-iteration launch sequence */
+    const lk_exposure_desc* exposure;   /* model.encode_exposure (HOST pointer) or NULL: the frame's affine is applied per sample inside the
+                                   colour decoder (decoder.py:534-540); feature and MLP are stepped every iteration (Tracker.py:329-344) */
 } lk_track_desc;
 int64_t lk_track_work_floats(int32_t R, int32_t S, int32_t iters);
 int lk_track_frame(const lk_track_desc* d, void* stream);
 
-/* lk_map_frame: the joint iterations [it_begin, it_end) of one Mapper.optimize_map call (src/Mapper.py:576-735, no exposure
- * encoding) = per iteration { multi-keyframe ray gather, inside mask, lk_render_fwd with the fused mapper loss, lk_render_bwd,
+/* lk_map_frame: the joint iterations [it_begin, it_end) of one Mapper.optimize_map call (src/Mapper.py:576-735) = per iteration { multi-keyframe ray gather, inside mask, lk_render_fwd with the fused mapper loss, lk_render_bwd,
  * Adam over {decoder spans, geometry rows, colour rows}, fragment repack in stage 'color' }.  Iteration it runs stage
  * 'geometry' iff it < n_geo_iters.  phases: 1 = forward/backward only, 2 = optimiser step only, 3 = both (a ray-sharded
  * multi-GPU caller all-reduces the gradients between phase 1 and phase 2 of every iteration).
@@ -384,6 +403,9 @@ typedef struct {
     float* work;                /* lk_map_work_floats(R, S, iters) floats, or NULL: as lk_track_desc.work - the batches (pixels, rays, colours,
                                    radii, inside masks) of all `iters` iterations are assembled by one launch of the call that starts at
                                    it_begin = 0 (gt_color / thr / scratch_u32 and render.rays_o / rays_d / gt_depth are then unused) */
+    const lk_exposure_desc* exposure;   /* model.encode_exposure (HOST pointer) or NULL: the 'color' iterations render colour LOGITS and the loss
+                                   applies sigmoid(logits @ rot_f + trans_f) of the ray's keyframe f = frame_id (Mapper.py:697-715);
+                                   needs `work`; bwd_scratch sized WITHOUT LK_FLAG_UNIT_LOSS_GRADS (d logits = w sigma' A is unbounded) */
 } lk_map_desc;
 int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters);
 /* float offset inside `work` of the neighbour lists lk_map_frame keeps per iteration: int32 [iters][R*S][8] (what a data-parallel

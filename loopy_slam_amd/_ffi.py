@@ -75,6 +75,16 @@ class BlobSpan(C.Structure):
     _fields_ = [('offset', C.c_int64), ('n', C.c_int64)]
 
 
+EXPOSURE_GRAD_FLOATS = 1024 + 128 + 1536 + 12 + EXPOSURE_MAX_F * 8
+
+
+class ExposureDesc(C.Structure):
+    """lk_exposure_desc (include/loopy_hip.h)."""
+    _fields_ = [('feats', _fp), ('W1', _fp), ('b1', _fp), ('W2', _fp), ('b2', _fp), ('F', C.c_int32),
+                ('aff', _fp), ('hid', _fp), ('g_aff', _fp), ('g', _fp), ('adam', _fp),
+                ('lr_mlp', C.c_float), ('lr_feat', C.c_float), ('feat_first', C.c_int32), ('feat_count', C.c_int32)]
+
+
 class TrackDesc(C.Structure):
     """lk_track_desc (include/loopy_hip.h)."""
     _fields_ = [
@@ -85,7 +95,7 @@ class TrackDesc(C.Structure):
         ('rnd', _fp), ('gt_color', _fp), ('pix_i', _fp), ('pix_j', _fp), ('thr', _fp), ('scratch_u32', _fp), ('loss_scratch', _fp),
         ('cam7', _fp), ('g_cam7', _fp), ('adam_mv', _fp),
         ('lr_T', C.c_float), ('lr_q', C.c_float), ('w_color', C.c_float), ('use_color', C.c_int32), ('hist_post', C.c_int32),
-        ('hist', _fp), ('log', _fp), ('iters', C.c_int32), ('work', _fp),
+        ('hist', _fp), ('log', _fp), ('iters', C.c_int32), ('work', _fp), ('exposure', C.POINTER(ExposureDesc)),
     ]
 
 
@@ -105,7 +115,7 @@ class MapDesc(C.Structure):
         ('col_dec', BlobSpan * MAX_SPANS), ('n_col_dec', C.c_int32),
         ('adam_dec', _fp),
         ('lr', (C.c_float * 3) * 2),
-        ('iters', C.c_int32), ('n_geo_iters', C.c_int32), ('work', _fp),
+        ('iters', C.c_int32), ('n_geo_iters', C.c_int32), ('work', _fp), ('exposure', C.POINTER(ExposureDesc)),
     ]
 
 

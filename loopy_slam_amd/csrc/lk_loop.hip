@@ -22,6 +22,11 @@
 
 using namespace lkw;
 
+int lk_launch_exposure_step(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, hipStream_t st);      // lk_optim.hip
+int lk_launch_loss_mapper_exposure(int R, const float* depth, const float* logits, const uint8_t* valid_ray, const float* gt_depth,
+                                   const float* gt_color, const int32_t* frame_id, const float* aff, int F, float w_color,
+                                   float* d_depth, float* d_logits, float* out_loss, float* g_aff, hipStream_t st);
+
 #define LK_TRACK_FUSED_MAX_R LK_MASK_REG_MAX          // rays a single workgroup keeps in registers (8 per thread)
 
 // ------------------------------------------------------------------ helpers
@@ -50,6 +55,7 @@ struct LkPregatherArgs {
     float* rays_o; float* rays_d;                         // [iters][R][3], or NULL (tracker: the rays follow the pose)
     float* gt_depth; float* gt_color; float* pix_i; float* pix_j; float* r2_ray; float* thr;       // [iters][R] (x3), thr [iters]
     float* zero4;                                         // [iters][4] rows to clear (loss sums accumulated with atomics), or NULL
+    int32_t* frame_out;                                   // [iters][R] keyframe of every ray of the assembled (partitioned) batch, or NULL
     int32_t* n_live;                                      // [iters] or NULL.  With it the batch is PARTITIONED: the rays that keep a depth reading
                                                           // (in draw order) come first, the rejected ones behind them, n_live[it] = their number
 };
@@ -63,6 +69,7 @@ __device__ __forceinline__ void pregather_ray(const LkPregatherArgs& a, size_t b
     gc[0] = a.color[3 * pix]; gc[1] = a.color[3 * pix + 1]; gc[2] = a.color[3 * pix + 2];
     if (a.r2_ray) a.r2_ray[base + dst] = a.r2_map ? a.r2_map[pix] : 0.0f;
     if (a.pix_i) { a.pix_i[base + dst] = (float)i; a.pix_j[base + dst] = (float)j; }
+    if (a.frame_out) a.frame_out[base + dst] = f;
     if (a.rays_o) {
         const float* M = a.c2w + (size_t)f * a.c2w_stride;             // row-major [3 or 4][4]
         const float d0 = ((float)i - a.cx) / a.fx, d1 = -((float)j - a.cy) / a.fy, d2 = -1.0f;
@@ -253,7 +260,7 @@ TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     w.total = o;
     return w;
 }
-struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, n_live, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, w_next, total; };
+struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, n_live, frame_id, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, w_next, total; };
 MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     MapWork w;
     int64_t o = 0;
@@ -264,6 +271,7 @@ MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     w.r2_ray = o; o += al4(iters * R);
     w.thr = o; o += al4(iters);
     w.n_live = o; o += al4(iters);                       // int32: rays of the iteration that keep a depth reading (they come first)
+    w.frame_id = o; o += al4(iters * R);                 // int32: keyframe of every ray AFTER the partition (exposure encoding: affine per keyframe)
     // the search results of every iteration (lk_presample on the third stream): [iters][P], [iters][P][8]
     const int64_t P = R * S;
     w.z = o; o += al4(iters * P);
@@ -301,6 +309,11 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_FEATS_F16)) | LK_FLAG_STAGE_COLOR | LK_FLAG_TRACKER | LK_FLAG_SAVE_ACT | LK_FLAG_GRAD_RAYS | LK_FLAG_ZERO_ABSENT;
     rd.stats_chunk = rd.R > 0 ? rd.R : 1;
     rd.g_geo_feats = nullptr; rd.g_col_feats = nullptr; rd.g_weights = nullptr;
+    // exposure encoding (decoder.py:534-540, Tracker.py:329-344): the frame's affine inside the colour decoder, its gradient from the
+    // decoder backward, feature + MLP stepped once per iteration
+    const lk_exposure_desc* xd = d->exposure;
+    LK_REQUIRE(!xd || xd->F == 1, "lk_track_frame: the tracker has ONE exposure feature (this frame's)");
+    if (xd) { rd.affine = xd->aff; rd.g_affine = xd->g_aff; }
     const int R = rd.R, S = rd.S, iters = d->iters;
     const bool fused = R <= LK_TRACK_FUSED_MAX_R && d->work != nullptr;
     if (!fused) LK_REQUIRE(d->gt_color && d->pix_i && d->pix_j && d->thr && d->scratch_u32 && d->loss_scratch && d->render.g_rays_o && d->render.g_rays_d,
@@ -329,6 +342,10 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         fa.rays_o = const_cast<float*>(rd.rays_o); fa.rays_d = const_cast<float*>(rd.rays_d);
         fa.next_pix_i = W0 + wk.pix_i; fa.next_pix_j = W0 + wk.pix_j; fa.do_update = 0;
         hipLaunchKernelGGL(k_track_final, dim3(1), dim3(1024), 0, st, fa);
+    }
+    if (xd) {
+        const int rc = lk_launch_exposure_step(*xd, 2, 1, beta1, beta2, eps, st);
+        if (rc != LK_OK) return rc;
     }
     for (int it = 0; it < iters; ++it) {
         const int32_t* rnd = d->rnd + (size_t)it * R;
@@ -375,6 +392,10 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         ex.fx = d->fx; ex.fy = d->fy; ex.cx = d->cx; ex.cy = d->cy;
         rc = lk_render_bwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE_BWD | LK_SKIP_RAYS_BWD) : 0, fused ? &ex : nullptr);
         if (rc != LK_OK) return rc;
+        if (xd) {
+            rc = lk_launch_exposure_step(*xd, 3, it + 1, beta1, beta2, eps, st);
+            if (rc != LK_OK) return rc;
+        }
         // ---- pose gradient + Adam (Tracker.py:317-352: group T at cam_lr, group q at 0.2 cam_lr when separate_LR)
         // (letting the workgroup of k_interp_bwd that finishes last run this step saved the launch and cost more: every workgroup
         // pays a device-scope release fence for the hand-over, 139 -> 151 us per iteration)
@@ -420,6 +441,9 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     const int R = d->render.R;
     const bool pre = d->work != nullptr && R <= LK_MASK_REG_MAX;
     if (!pre) LK_REQUIRE(d->gt_color && d->thr && d->scratch_u32, "lk_map_frame: without `work` (or above 8192 rays) the per-iteration batch buffers are needed");
+    // exposure encoding (Mapper.py:588-607, 697-715): the 'color' iterations render logits, the loss applies the keyframe's affine
+    const lk_exposure_desc* xd = d->exposure;
+    LK_REQUIRE(!xd || (pre && d->frame_id), "lk_map_frame: exposure encoding needs `work` (<= 8192 rays) and frame_id");
     const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
     const int64_t nb = lk_weight_blob_floats();
     const int64_t nrow = d->n_rows * LK_C;
@@ -443,6 +467,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         pa.rays_o = W0 + wk.rays_o; pa.rays_d = W0 + wk.rays_d; pa.gt_depth = W0 + wk.gt_depth; pa.gt_color = W0 + wk.gt_color;
         pa.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray : nullptr; pa.thr = W0 + wk.thr; pa.zero4 = d->log;
         pa.n_live = reinterpret_cast<int32_t*>(W0 + wk.n_live);
+        if (xd) pa.frame_out = reinterpret_cast<int32_t*>(W0 + wk.frame_id);
         hipLaunchKernelGGL(k_pregather, dim3(d->iters), dim3(1024), 0, st, pa);
     }
     // Ahead of the loop, on the third stream, a few iterations per chunk: the neighbour search (one launch per chunk) and,
@@ -523,16 +548,20 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     bool repack_pending = false, stepped_pending = false;
     // Step rider (LkStepRider, lk_kernels.h): in a 'color' iteration that is followed by another one in this call, with no gradient
     // exchange in between (phases == 3), the Adam step happens inside the reduction launch of the backward
-    const bool rider_ok = pre && (phases & 3) == 3 && d->render.weights == d->weights_rw && d->render.g_weights != nullptr &&
+    const bool rider_ok = pre && !xd && (phases & 3) == 3 && d->render.weights == d->weights_rw && d->render.g_weights != nullptr &&
                           (!(d->render.flags & LK_FLAG_REL_POS) || lk_relpos_fused(d->render.flags | LK_FLAG_GRAD_WEIGHTS)) &&
                           d->n_geo_dec + d->n_col_dec <= 16 && nb < (1ll << 31);
     bool w_next_ready = false;
+    bool x_fwd_done = it_begin > d->n_geo_iters;          // a later call of a phase-split sequence: the step launch of the iteration before did the forward
     for (int it = it_begin; it < it_end; ++it) {
         const bool color = it >= d->n_geo_iters;
         const bool use_rider = rider_ok && color && it + 1 < it_end && d->n_col_dec > 0;
         lk_render_desc rd = d->render;
+        const bool xit = xd != nullptr && color;            // this iteration's loss is the exposure variant (its own launch after the composite)
         rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_UNIT_LOSS_GRADS | LK_FLAG_FEATS_F16)) | (color ? LK_FLAG_STAGE_COLOR : 0) | LK_FLAG_SAVE_ACT |
                    LK_FLAG_GRAD_FEATS | LK_FLAG_GRAD_WEIGHTS | LK_FLAG_ZERO_ABSENT | LK_FLAG_MAPPER_LOSS;
+        if (xd) rd.flags &= ~LK_FLAG_UNIT_LOSS_GRADS;        // d logits = w sigma' A with a learned A: nothing bounds it (both stages: one scratch layout)
+        if (xit) rd.flags = (rd.flags & ~LK_FLAG_MAPPER_LOSS) | LK_FLAG_COLOR_LOGITS;
         rd.stats_chunk = R;
         rd.loss_gt_color = d->gt_color; rd.loss_w_color = d->w_color; rd.loss_out4 = d->log + (size_t)it * 4;
         if (pre) {
@@ -568,10 +597,22 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             LkRepackRider rr;
             rr.frag = d->weights_frag_rw; rr.src = stepped_pending ? W0 + wk.w_next : nullptr;
             rr.copy_dst = stepped_pending ? d->weights_rw : nullptr; rr.copy_n = (int)nb;
-            rc = lk_render_fwd_impl(&rd, st, LK_FUSE_COMPOSITE_BWD | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0), live,
+            if (xit && it == (d->n_geo_iters > it_begin ? d->n_geo_iters : it_begin) && !x_fwd_done) {
+                // affines of the window's keyframes for the first 'color' iteration of this call (later ones: the step launch below)
+                rc = lk_launch_exposure_step(*xd, 2, 1, beta1, beta2, eps, st);
+                if (rc != LK_OK) return rc;
+            }
+            x_fwd_done = x_fwd_done || xit;
+            rc = lk_render_fwd_impl(&rd, st, (xit ? 0 : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0), live,
                                     (repack_pending || stepped_pending) ? &rr : nullptr);
             repack_pending = false; stepped_pending = false;
             if (rc != LK_OK) return rc;
+            if (xit) {          // Mapper.py:697-715 on the rendered logits: d depth, d logits, loss row, d loss / d affine
+                rc = lk_launch_loss_mapper_exposure(R, rd.depth, rd.color, rd.valid_ray, rd.gt_depth, rd.loss_gt_color,
+                                                    reinterpret_cast<const int32_t*>(W0 + wk.frame_id) + (size_t)it * R, xd->aff, xd->F, d->w_color,
+                                                    const_cast<float*>(rd.d_depth), const_cast<float*>(rd.d_color), rd.loss_out4, xd->g_aff, st);
+                if (rc != LK_OK) return rc;
+            }
             LkBwdExtra ex;
             memset(&ex, 0, sizeof(ex));
             if (sort_ahead) {
@@ -609,7 +650,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 }
                 ex.step = &sr;
             }
-            rc = lk_render_bwd_impl(&rd, st, LK_SKIP_COMPOSITE_BWD | LK_SEG_SORTED, pre ? &ex : nullptr);
+            rc = lk_render_bwd_impl(&rd, st, (xit ? 0 : LK_SKIP_COMPOSITE_BWD) | LK_SEG_SORTED, pre ? &ex : nullptr);
             if (rc != LK_OK) return rc;
         }
         if (phases & 2) {
@@ -623,6 +664,10 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             }
             int rc = lk_adam_step(seg, ns, beta1, beta2, eps, st);
             if (rc != LK_OK) return rc;
+            if (xit) {          // exposure MLP backward + its Adam groups + the affines of the next iteration, one launch
+                rc = lk_launch_exposure_step(*xd, 3, it - d->n_geo_iters + 1, beta1, beta2, eps, st);
+                if (rc != LK_OK) return rc;
+            }
             if (color) {        // the matrix fragments are copies of the colour-decoder matrices, which only move in this stage
                 // (rd.weights == weights_rw: the next iteration's forward reads what this step wrote)
                 if (pre && (phases & 3) == 3 && it + 1 < it_end && d->render.weights == d->weights_rw) repack_pending = true;

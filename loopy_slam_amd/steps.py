@@ -72,7 +72,22 @@ class ExposureState:
         self.feats = feats.data if self.single else torch.stack([f.detach() for f in self.orig]).contiguous()
         self.aff, self.hid = eng.zeros(self.F, 12), eng.zeros(self.F, 128)
         self.g_aff = eng.zeros(self.F, 12)
-        self.g = eng.zeros(2700 + self.F * 8)
+        self.g = eng.zeros(_ffi.EXPOSURE_GRAD_FLOATS)
+        self._desc = None
+
+    def desc(self, lr_mlp, lr_feat=None, only_last_feature=False):
+        """lk_exposure_desc for the native loops (lk_track_frame / lk_map_frame): a fresh Adam state in the layout of `g`.
+        lr_mlp None: the MLP is frozen."""
+        d = _ffi.ExposureDesc()
+        d.feats, d.W1, d.b1, d.W2, d.b2, d.F = ptr(self.feats), ptr(self.W1), ptr(self.b1), ptr(self.W2), ptr(self.b2), self.F
+        d.aff, d.hid, d.g_aff, d.g = ptr(self.aff), ptr(self.hid), ptr(self.g_aff), ptr(self.g)
+        self.adam_mv = self.eng.zeros(2 * _ffi.EXPOSURE_GRAD_FLOATS)
+        d.adam = ptr(self.adam_mv)
+        d.lr_mlp = -1.0 if lr_mlp is None else float(lr_mlp)
+        d.lr_feat = self.LR if lr_feat is None else float(lr_feat)
+        d.feat_first, d.feat_count = (self.F - 1, 1) if only_last_feature else (0, self.F)
+        self._desc = d
+        return d
 
     def forward(self):
         e = self.eng
@@ -203,7 +218,7 @@ class MapOptimizer:
         it < n_geo_iters.  rnd_all int32 [n_iters, R]; log [n_iters, 4].  Without exposure encoding this is lk_map_frame - one
         C-ABI call for the whole loop single-GPU, two calls per iteration around the gradient all-reduce multi-GPU; with
         exposure encoding the per-statement path (iterate)."""
-        if self.exposure is not None or not self.native_loop:
+        if not self.native_loop or (self.exposure is not None and self.R > 8192):
             for it in range(n_iters):
                 self.iterate('geometry' if it < n_geo_iters else 'color', frames, rnd_all[it], frame_id, window, intr, H, W, log_row=log[it])
             return log
@@ -212,7 +227,8 @@ class MapOptimizer:
         core.fill_desc(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col, self.dec, 'color',
                        r2_ray=b.r2_ray, save_act=True)
         # the scratch layout depends on the flags: size it with exactly the words lk_map_frame renders with, in both stages
-        base = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | _ffi.FLAG_UNIT_LOSS_GRADS | _ffi.FLAG_SAVE_ACT | _ffi.FLAG_GRAD_FEATS | \
+        unit = _ffi.FLAG_UNIT_LOSS_GRADS if self.exposure is None else 0       # with exposure encoding the loss gradients are not unit scale
+        base = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | unit | _ffi.FLAG_SAVE_ACT | _ffi.FLAG_GRAD_FEATS | \
             _ffi.FLAG_GRAD_WEIGHTS | _ffi.FLAG_ZERO_ABSENT | _ffi.FLAG_MAPPER_LOSS
         need = max(int(eng.lib.dll.lk_render_bwd_scratch_floats(self.R, self.cfg.S, base | extra)) for extra in (0, _ffi.FLAG_STAGE_COLOR))
         if gs.scratch is None or gs.scratch.numel() < need:
@@ -221,7 +237,7 @@ class MapOptimizer:
         C = _ffi.C
         C.memmove(C.byref(d.render), C.byref(st.desc), C.sizeof(_ffi.RenderDesc))
         r = d.render
-        r.flags = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | _ffi.FLAG_UNIT_LOSS_GRADS      # L1 sums: |d depth|, |d colour| <= 1
+        r.flags = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | unit      # L1 sums: |d depth|, |d colour| <= 1
         if self.geo.dtype == torch.float16:
             r.flags |= _ffi.FLAG_FEATS_F16
         r.d_depth, r.d_color = ptr(b.d_depth), ptr(b.d_color)
@@ -257,6 +273,11 @@ class MapOptimizer:
             for k in range(3):
                 d.lr[si][k] = self.lrs[stage][k]
         d.iters, d.n_geo_iters = n_iters, n_geo_iters
+        if self.exposure is not None:
+            # Mapper.py:524-570: mlp_exposure steps with the colour decoder (decoders_lr of stage 'color', frozen with it), of the window's
+            # exposure features only the current frame's (the last) is an Adam parameter
+            xd = self.exposure.desc(None if self.fix_color_decoder else self.lrs['color'][0], only_last_feature=True)
+            d.exposure = C.pointer(xd)
         need = int(eng.lib.dll.lk_map_work_floats(self.R, self.cfg.S, n_iters)) if self.R <= 8192 else 0
         if need and (self._work is None or self._work.numel() < need):
             self._work = eng.empty(need)
@@ -355,9 +376,9 @@ class TrackOptimizer:
                 gs.g_affine = eng.zeros(12)
         log = eng.zeros(iters, 4)
         hist = eng.empty(iters, 7)
-        if xs is None and self.native_loop:
+        if self.native_loop:
             # the whole loop as ONE C-ABI call (lk_track_frame): no interpreter between the launches
-            self._track_native(cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log)
+            self._track_native(cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log, xs)
             best = torch.argmin(log[:, 0])      # Tracker.py:375-377 (first minimum)
             return self._agree(hist[best].clone()), log
         if self.eye is None:
@@ -401,7 +422,7 @@ class TrackOptimizer:
             self.dist.broadcast(cam7, src=0)
         return cam7
 
-    def _track_native(self, cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log):
+    def _track_native(self, cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log, xs=None):
         """lk_track_frame: descriptor of the render buffers + the loop's own buffers (all owned here)."""
         eng, b, st, gs = self.eng, self.batch, self.st, self.gs
         H, W = depth_img.shape
@@ -436,5 +457,7 @@ class TrackOptimizer:
         if need and (getattr(self, '_work', None) is None or self._work.numel() < need):
             self._work = eng.empty(need)
         d.work = ptr(self._work) if need else 0
-        self._keep_native = (depth_img, color_img, r2_map, rnd_all, cam, hist, log)
+        if xs is not None:              # Tracker.py:329-344: the frame's feature and mlp_exposure, both at lr 1e-3
+            d.exposure = C.pointer(xs.desc(ExposureState.LR))
+        self._keep_native = (depth_img, color_img, r2_map, rnd_all, cam, hist, log, xs)
         eng.lib.check(eng.lib.dll.lk_track_frame(C.byref(d), eng.stream), 'lk_track_frame')

@@ -130,21 +130,21 @@ def rows_of_samples(out, sample_mask):
     return torch.unique(idx[idx >= 0].long())
 
 
-def branch_point_rays(out, b, pos, geo, W, tracker_loss=None, tol=2e-6):
+def branch_point_rays(out, b, pos, geo, W, tracker_loss=None, tol=2e-6, r2=None):
     """bool [R]: rays whose gradient is not comparable between two fp32 implementations because they sit on a branch point
     of the graph at rounding level - a geometry-decoder ReLU with |pre-activation| < tol in one of their samples
     (geo_gate_margin), an L1 term with |depth - gt| < tol, or (tracker) a residual within 1e-5 relative of the loss mask's
     threshold 10 * mean or of the 1e3 clamp (Tracker.py:177-183).  Their loss gradient is zeroed on both sides; the count is
     recorded and bounded by the tests."""
     R = b['gt_depth'].shape[0]
-    margin = geo_gate_margin(out, pos, geo, W)
+    margin = geo_gate_margin(out, pos, geo, W, r2=r2)          # r2: per-sample squared radius [P] (dynamic radius) or None = 0.08^2
     rays = (margin < tol).reshape(R, -1).any(1)
     rays |= (out['depth'].detach() - b['gt_depth']).abs() < tol
     if tracker_loss is not None:
         # tracker mode recomputes D from the positions and drops neighbours with D > r^2 (decoder.py:191-198): a neighbour within
         # rounding of the radius is in or out depending on the summation order of the squared distance
-        r2 = np.float32(0.08 ** 2)
-        near_edge = ((out['d2'] - r2).abs() < 4e-6 * r2) & (out['idx'] >= 0)
+        r2e = torch.tensor(np.float32(0.08 ** 2)) if r2 is None else torch.as_tensor(r2).reshape(-1, 1)
+        near_edge = ((out['d2'] - r2e).abs() < 4e-6 * r2e) & (out['idx'] >= 0)
         rays |= near_edge.any(1).reshape(R, -1).any(1)
         tmp = torch.abs(b['gt_depth'] - out['depth'].detach()) / torch.sqrt(out['var'].detach() + 1e-10)
         thr = 10 * tmp.mean()

@@ -81,10 +81,11 @@ def _worker(rank, port, q, all_rows, native, backend):
             t = out4.cpu().clone()
             dist.all_reduce(t)
             losses.append(float(t[0]))
+    # numpy arrays travel through the queue by value (a tensor travels as a handle the receiver must fetch while the sender lives)
     if rank == 0:
-        q.put((losses, dec.blob.cpu().clone(), geo_d.cpu().clone(), col_d.cpu().clone()))
+        q.put((losses, dec.blob.cpu().numpy().copy(), geo_d.cpu().numpy().copy(), col_d.cpu().numpy().copy()))
     else:
-        q.put((losses, dec.blob.cpu().clone(), None, None))
+        q.put((losses, dec.blob.cpu().numpy().copy(), None, None))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -132,6 +133,7 @@ def test_two_rank_grad_allreduce_matches_single_process(all_rows, native, backen
             break
         if attempt == 1:
             raise AssertionError(f'workers failed: {errs} exit codes {[p.exitcode for p in procs]}')
+    res = [tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in r) for r in res]
     full = [r for r in res if r[2] is not None][0]
     other = [r for r in res if r[2] is None][0]
     np.testing.assert_allclose(full[0], ref_losses, rtol=1e-5)

@@ -245,11 +245,13 @@ def _exposure_module(W):
     return m
 
 
+@pytest.mark.parametrize('native', (True, False))
 @pytest.mark.parametrize('backend', backends())
-def test_exposure_iterations_match_oracle(backend):
+def test_exposure_iterations_match_oracle(backend, native):
     """model.encode_exposure (ScanNet): tracker iterations with the decoder-side per-sample affine of the frame's
     exposure feature (Tracker.py:329-344), then mapper colour iterations with the per-keyframe affine on the rendered
-    logits (Mapper.py:697-715) - exposure features and MLP optimised at lr 1e-3, against oracle loops."""
+    logits (Mapper.py:697-715) - exposure features and MLP optimised at lr 1e-3, against oracle loops.  native: the loops as
+    single C-ABI calls (lk_track_frame / lk_map_frame with an lk_exposure_desc), else the per-statement path."""
     eng = make_engine(backend)
     c2w, depth_img, color_img, pos, geo, col = mini_scene(2)
     W = syn.default_weights(seed=4, rel_pos=False, exposure=True)
@@ -290,6 +292,7 @@ def test_exposure_iterations_match_oracle(backend):
     mlp = _exposure_module(W).to(eng.device)
     feat_k = eng.f32(feat0).clone().requires_grad_(True)
     to = steps.TrackOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, R, lr, separate_lr=False, w_color=0.5)
+    to.native_loop = native
     best, log = to.track(eng.f32(cam0), eng.f32(depth_img), eng.f32(color_img), iters, win, INTR, rnd_all.to(eng.device),
                          exposure=(mlp, feat_k))
     np.testing.assert_allclose(log[:, 0].cpu().numpy(), o_losses, rtol=5e-4)
@@ -341,9 +344,15 @@ def test_exposure_iterations_match_oracle(backend):
     frames = (eng.f32(depth_img).reshape(1, HH, WW).repeat(2, 1, 1), eng.f32(color_img).reshape(1, HH, WW, 3).repeat(2, 1, 1, 1),
               eng.f32(c2w).reshape(1, 4, 4).repeat(2, 1, 1), None)
     km = []
-    for it in range(iters_m):
-        out4 = mo.iterate('color', frames, rnd_m[it].to(eng.device), fid.to(eng.device), (0, HH, 0, WW), INTR, HH, WW)
-        km.append(float(out4[0].cpu()))
+    if native:
+        mlog = eng.zeros(iters_m, 4)
+        mo.run(iters_m, 0, frames, rnd_m.to(eng.device), fid.to(eng.device), (0, HH, 0, WW), INTR, HH, WW, mlog)
+        km = [float(x) for x in mlog[:, 0].cpu()]
+    else:
+        mo.native_loop = False
+        for it in range(iters_m):
+            out4 = mo.iterate('color', frames, rnd_m[it].to(eng.device), fid.to(eng.device), (0, HH, 0, WW), INTR, HH, WW)
+            km.append(float(out4[0].cpu()))
     mo.finish()                                     # stacked exposure features -> the keyframes' tensors
     np.testing.assert_allclose(km, om_losses, rtol=5e-4)
     for a, b in zip(fk, fo):
