@@ -234,7 +234,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     da.R = d->R; da.S = d->S; da.P = P; da.flags = d->flags;
     da.rays_o = d->rays_o; da.rays_d = d->rays_d; da.z = d->z;
     da.c_geo = d->c_geo; da.c_col = d->c_col; da.W = d->weights; da.Wfrag = d->weights_frag; da.affine = d->affine;
-    da.raw = d->raw; da.act = d->act;
+    da.raw = d->raw; da.act = d->act; da.live_rays = live_rays;
     lk_launch_decode_fwd(da, st);
 
     if (skip & LK_SKIP_COMPOSITE) { LK_LAUNCH_CHECK(); return LK_OK; }     // the caller composites (fused loss kernel, lk_loop.hip)
@@ -372,6 +372,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.act = d->act; db.raw = d->raw; db.d_raw = S0 + L.d_raw;
     db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dy_col = S0 + L.dy_col; db.dlogit = S0 + L.dlogit;
     db.dp_embed = S0 + L.dp_embed; db.dp_embed_col = S0 + L.dp_embed_col; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.part_bg = S0 + L.part_bg;
+    db.live_rays = ex ? ex->live_rays : nullptr;
     lk_launch_decode_bwd(db, st);
     // mapper 'color' backward with one weight-gradient launch: every partial-sum reduction is deferred to ONE launch at the end
     const bool defer = gw && color && (!relpos || lk_relpos_fused(flags));
@@ -429,6 +430,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         }
         wa.n_jobs = nj; wa.chunk = 0; wa.part = S0 + L.wg_part;
         wa.h16 = (flags & LK_FLAG_UNIT_LOSS_GRADS) && !gr ? 1 : 0;
+        wa.live_rays = ex ? ex->live_rays : nullptr; wa.S = d->S;
         lk_launch_wgrad(wa, P, wst, defer ? &wdef : nullptr);
     }
 

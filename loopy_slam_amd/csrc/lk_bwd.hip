@@ -374,12 +374,17 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
 // wave serialise in the memory-side atomic unit): the embedding-matrix gradient is therefore reduced
 // wave -> LDS -> one partial row per workgroup, and summed by k_reduce_partials.
 // Block roles as in k_decode_fwd: the first n_col_blocks workgroups are colour tiles, the rest geometry (4 tiles each).
+#ifndef LK_DBWD_MINB
+#define LK_DBWD_MINB 2
+#endif
 template <bool H16, bool DEEP>
-__global__ __launch_bounds__(256, 2) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
+__global__ __launch_bounds__(256, LK_DBWD_MINB) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
     __shared__ u32x4 s_x[2 * 24 * 64];
     __shared__ float s_o[4][3 * 32];
     const int w = (int)threadIdx.x >> 6;
+    const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;       // as k_decode_fwd
     if ((int)blockIdx.x < n_col_blocks) {
+        if ((int)blockIdx.x * 32 >= P_live) return;
         decode_bwd_col_wg<H16, DEEP>(a, blockIdx.x, w, lk_lane(), s_x, s_o);
         return;
     }
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_decode_bwd(LkDecodeBwdArgs a, int n_
         __syncthreads();
     }
     const int tile = gb * 4 + w;
-    if (tile * 32 < a.P) decode_bwd_geo_wave(a, tile, s_part[w]);
+    if (tile * 32 < P_live) decode_bwd_geo_wave(a, tile, s_part[w]);
     if (want_w) {
         __syncthreads();
         for (int e = threadIdx.x; e < 3 * EGP; e += 256)

@@ -901,7 +901,7 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
 // VALU work either.  The tile is scaled back when it is stored.
 template <int NV, int KV, int MODE, bool H16>
 __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane,
-                                           float* __restrict__ tile) {
+                                           float* __restrict__ tile, int rows) {
     const int i = lane & 31, h = lane >> 5;
     // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
     const int ncol = n0 + NV * i, kcol = k0 + KV * i;
@@ -929,7 +929,7 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 #pragma unroll
     for (int b = 0; b < NV; ++b) bsum[b] = 0.0f;
     // this wave's rows: chunks c0, c0 + stride, c0 + 2 stride, ... of WG_CHUNK = 2 * WG_STEPS rows each
-    const int rows = J.rows, last = rows - 1;
+    const int last = rows > 0 ? rows - 1 : 0;            // rows: J.rows, or the live prefix of a partitioned batch
     const int n_chunks = (rows + WG_CHUNK - 1) / WG_CHUNK;
     const int my_chunks = (c0 < n_chunks) ? (n_chunks - c0 + stride - 1) / stride : 0;
     WgVec<NV> ra[WG_STEPS], ra2[WG_STEPS];
@@ -1046,13 +1046,13 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 }
 
 template <int NV, int KV, bool H16>
-__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile) {
+__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile, int rows) {
 #ifdef LK_PROBE_WG_MODE0        // timing probe (tools/ab_build.sh): only the plain form, so that a deeper ring fits the register file
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile);
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows);
 #else
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile);
-    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile);
-    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile);
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile, rows);
+    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile, rows);
 #endif
 }
 
@@ -1076,11 +1076,13 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     const int c0 = x + 8 * jl, stride = 8 * U.n_waves;
     // a wave without a chunk (tiny problems) still stores its (zero) tile: the reduction sums all 8 W tiles of the unit
     float* tile = a.part ? a.part + ((size_t)8 * U.wave0 + 8 * jl + x) * LK_WG_TILE : nullptr;
-    if (!tile && c0 >= (J.rows + WG_CHUNK - 1) / WG_CHUNK) return;
-    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile);
-    else if (U.nv == 2) wgrad_unit_mode<2, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile);
-    else if (U.kv == 2) wgrad_unit_mode<1, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile);
-    else wgrad_unit_mode<1, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile);
+    // rows behind the live prefix of a partitioned batch were not written by their producers (k_decode_bwd skips those tiles)
+    const int rows = a.live_rays ? min(J.rows, lk_uniform(*a.live_rays) * a.S) : J.rows;
+    if (!tile && c0 >= (rows + WG_CHUNK - 1) / WG_CHUNK) return;
+    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows);
+    else if (U.nv == 2) wgrad_unit_mode<2, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows);
+    else if (U.kv == 2) wgrad_unit_mode<1, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows);
+    else wgrad_unit_mode<1, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows);
 }
 
 // dW += sum over the unit's waves of the partial tiles (tile order: contiguous reads; every output element is owned by

@@ -430,12 +430,14 @@ __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col
     __shared__ float s_bias[10][128];
     const int lane = lk_lane();
     const int w = (int)threadIdx.x >> 6;
+    const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;       // samples of rays with a depth reading (they come first)
     if ((int)blockIdx.x < n_col_blocks) {
+        if ((int)blockIdx.x * 32 >= P_live) return;
         decode_col_wg<DEEP>(a, blockIdx.x, w, lane, s_x, s_o, s_bias);
         return;
     }
     const int tile = ((int)blockIdx.x - n_col_blocks) * 4 + w;
-    if (tile * 32 >= a.P) return;
+    if (tile * 32 >= P_live) return;
     decode_geo_wave(a, tile, lane);
     if (n_col_blocks == 0) {
         const int sample = tile * 32 + (lane & 31);

@@ -56,6 +56,8 @@ struct LkDecodeArgs {
     const float* affine;                          // [12] or NULL
     float* raw;                                   // [P,4]
     float* act;                                   // SAVE_ACT scratch or NULL
+    const int32_t* live_rays;                     // as LkRelposArgs: tiles behind the live prefix of a partitioned batch are not decoded (the
+                                                  // reference never renders those rays: they are filtered out before the render, Mapper.py:645-681)
 };
 
 // relative-position neighbour MLP (colour features, Replica config)
@@ -94,6 +96,7 @@ struct LkDecodeBwdArgs {
     float* dp_embed_col;                           // [P,4]   (GRAD_RAYS, colour stage) colour-decoder embedding path
     float* g_weights; float* g_affine;
     float* part_bg;                                // [n_blocks][288] per-workgroup partial sums of d embedder._B (GRAD_WEIGHTS)
+    const int32_t* live_rays;                      // as LkDecodeArgs
 };
 
 struct LkTrackFinalArgs {
@@ -238,6 +241,7 @@ struct LkWgradArgs {
     float* part;                                   // [n_waves][LK_WG_TILE] partial tiles (one per wave), or NULL (atomic flush)
     int h16;                                       // products on scaled fp16 pieces (unit-scale loss gradients only)
     LkFcPost fc[5]; int n_fc;                      // fc_c gradients finished from the auxiliary columns (needs `part`)
+    const int32_t* live_rays; int S;               // rows >= *live_rays * S of every job are not read (their producers skipped them), or NULL
 };
 static_assert(sizeof(LkWgradArgs) <= 3600, "LkWgradArgs travels as a kernel argument next to LkBwdReduceArgs (4 KB limit)");
 #define LK_WG_MAX_WAVES 2048                       // waves of one weight-gradient launch: two per SIMD, all co-resident
