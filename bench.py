@@ -76,6 +76,7 @@ def main():
     if args.strong and world > 1:
         budget.map_rays = max(32, budget.map_rays // world)          # tracking is replicated (not sharded) in either mode
     wl = workload.FrameWorkload(eng, budget, dist=dctx)
+    cloud0 = tuple(t[:wl.n].cpu() for t in (wl.pos, wl.geo, wl.col)) if (rank == 0 and not args.no_cpu_baseline) else None
 
     def barrier():
         if world > 1:
@@ -112,10 +113,22 @@ def main():
     barrier()
     kstat_serial = prof_s.stop()
     eng.lib.check(eng.lib.dll.lk_set_serial(0), 'lk_set_serial')
+    # the same step with the once-per-mapped-frame work the reference does beside its iterations (every 5th frame: insertion of 6 000
+    # pixels through the radius test + feature rows + index rebuild, Mapper.py:421-482; the full-frame render, Mapper.py:966-969)
+    n_full = 2 * budget.every_frame
+    wl.frame_no = 0
+    wl.step(full=True)                  # untimed: first-use allocations of the full-frame render state
+    wl.frame_no = 0
+    barrier()
+    t0f = time.perf_counter()
+    for _ in range(n_full):
+        wl.step(full=True)
+    barrier()
+    dt_full = time.perf_counter() - t0f
     if world > 1:
-        t = torch.tensor([dt], device='cuda')
+        t = torch.tensor([dt, dt_full], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_full = float(t[0].item()), float(t[1].item())
     rays_per_step = budget.rays_per_frame
     # whole-job rays of a step: every rank brings its own mapping rays; the tracking iterations are REPLICATED on the ranks (the same
     # rays everywhere, no exchange - steps.TrackOptimizer), so they count once however many ranks repeat them
@@ -129,6 +142,10 @@ def main():
         'value': total_rays / dt, 'unit': 'rays/s',
         # every rank works on the SAME frame (the ranks share one map and sum their gradients): a step is one frame whatever N is
         'frames_per_s': args.steps / dt,
+        # ... and with a mapped frame's point insertion + index rebuild + full-frame render every 5th step (Mapper.py:421-482, 966-969)
+        'frames_per_s_full': n_full / dt_full, 'ms_per_step_full': 1e3 * dt_full / n_full,
+        'full_step': f'{n_full} steps, every {budget.every_frame}th also inserts {budget.pixels_adding} pixels (lk_add_points + feature rows + lk_knn_build) and '
+                     f'renders the 640x480 frame (307 200 rays); {wl.n_added} points added, map {wl.n} points',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if (args.strong and world > 1) else 'weak',
         'vs_baseline': None,
@@ -137,7 +154,7 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'Replica room0 budget: 40 track it x 1500 rays + 60 map it x 5000 rays per frame '
                                '(24 geometry + 36 colour) on the frustum rows of the mapped frame, S=5, k=8, C=32, rel-pos colour MLP, '
-                               f'N={budget.n_points} points, 640x480 synthetic room',
+                               f'N={budget.n_points} points ' + ('laid down by radius-de-duplicated insertion (lk_add_points, r_add 0.04)' if budget.online_cloud else '(random pixels of 24 views)') + ', 640x480 synthetic room',
                    'rays_per_step': rays_per_step, 'rays_per_step_all_ranks': rays_all,
                    'parallelism': f'dp{world} (mapping ray-sharded with one gradient all-reduce per iteration; tracking replicated)'},
     }
@@ -163,7 +180,7 @@ def main():
         out['kernel_ms_per_step'] = {k: round(v['total_ms'], 3) for k, v in sorted(kall.items(), key=lambda kv: -kv[1]['total_ms'])}
         if not args.no_cpu_baseline:
             import bench_cpu_baseline
-            out['cpu_baseline'] = bench_cpu_baseline.run(budget)
+            out['cpu_baseline'] = bench_cpu_baseline.run(budget, cloud=cloud0)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -96,6 +96,62 @@ def build_cloud(n_points, device='cpu', seed=1219, intr=TUM_INTR, n_views=24, c_
     return pos.to(device), geo.to(device), col.to(device)
 
 
+ROOM_PITCH = 8.0          # metres between the rooms of a multi-room map (x axis): the walls of neighbouring rooms are 2 m apart
+
+
+def room_offset(room, device='cpu'):
+    return torch.tensor([ROOM_PITCH * room, 0.0, 0.0], device=device)
+
+
+def pose_in_room(c2w, room):
+    """The pose moved into room `room` of a multi-room map: every room is the same closed box, so the frame it sees is the base frame."""
+    out = c2w.clone()
+    out[:3, 3] += room_offset(room, c2w.device)
+    return out
+
+
+def build_cloud_online(eng, n_points, seed=1219, intr=TUM_INTR, c_dim=32, pixels_per_call=6000, points_per_room=100_000):
+    """The map an online run leaves behind: points inserted the way NeuralPointCloud.add_neural_points does
+    (src/neural_point.py:1557-1631) - pixels of the loop's views through the radius test against the cloud built so far
+    (lk_add_points, radius_add 0.04, mapping.pixels_adding = 6 000 pixels per call as on Replica), three points per accepted ray at
+    (0.98, 1.0, 1.02) x depth - until ~points_per_room points (~ 900 per m^2 of the 108 m^2 room: what the reference's 6 000 pixels per mapped frame
+    converge to).  Larger maps are MORE ROOMS at the same density (copies of the room ROOM_PITCH apart with their own features):
+    N grows with the explored area, the way a long ScanNet sequence grows its map - not by packing more points into one room.
+    Returns (pos [N,3], geo [N,C], col [N,C], n_rooms) on eng.device."""
+    from . import core, optim
+    dev = eng.device
+    n_rooms = max(1, int(round(n_points / points_per_room)))
+    target = (n_points // n_rooms) // 3 * 3
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    cap = target + 3 * pixels_per_call
+    knn = core.KnnIndex(eng, capacity=cap)
+    pos = torch.empty(cap, 3, device=dev)
+    n, view, stall = 0, 0, 0
+    r2 = float(torch.tensor(0.04 ** 2, dtype=torch.float32))          # pointcloud.radius_add, squared in fp32 as the ABI takes it
+    while n < target and stall < 400:
+        c2w = loop_pose(view % 200, 200, 'cpu')
+        view += 7                                          # successive calls look from well separated poses of the loop
+        i = torch.rand(pixels_per_call, generator=g) * (intr['W'] - 1)
+        j = torch.rand(pixels_per_call, generator=g) * (intr['H'] - 1)
+        ro, rd = pixel_rays(c2w, i, j, intr)
+        d = room_depth(ro, rd)
+        _, pts = optim.add_points(eng, knn if n > 0 else None, ro.to(dev), rd.to(dev), d.to(dev), r2, 0.98, 1.02, 3)
+        k = min(int(pts.shape[0]), target - n)
+        k -= k % 3
+        stall = stall + 1 if k == 0 else 0
+        if k:
+            pos[n:n + k] = pts[:k]
+            n += k
+            knn.build(pos[:n])
+    base = pos[:n].clone()
+    knn.close()
+    allpos = torch.cat([base + room_offset(r, dev) for r in range(n_rooms)], 0).contiguous()
+    gd = torch.Generator(device=dev).manual_seed(seed + 1)
+    geo = 0.1 * torch.randn(allpos.shape[0], c_dim, generator=gd, device=dev)
+    col = 0.1 * torch.randn(allpos.shape[0], c_dim, generator=gd, device=dev)
+    return allpos, geo, col, n_rooms
+
+
 def default_weights(seed=1219, rel_pos=True, exposure=False):
     """Random-init decoder weights with the reference's shapes and init scheme
     (xavier_uniform(relu gain) trunk, default nn.Linear fc_c, B ~ N(0, scale^2); decoder.py:84-93,145-170,386-420)."""

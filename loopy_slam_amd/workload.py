@@ -29,6 +29,10 @@ class Budget:
     cam_lr: float = 0.002
     rel_pos: bool = True
     frustum_edge: int = -4                # mapping.frustum_edge (configs/point_slam.yaml:67)
+    online_cloud: bool = True             # the map as an online run builds it (radius-de-duplicated insertion, one room per 100 k points:
+                                          # synthetic.build_cloud_online); False: random pixels of 24 views packed into one room
+    every_frame: int = 5                  # mapping.every_frame: the full step inserts points / re-indexes / renders the frame every 5th frame
+    pixels_adding: int = 6000             # mapping.pixels_adding
 
     @property
     def rays_per_frame(self):
@@ -49,22 +53,34 @@ class FrameWorkload:
         self.H, self.W = syn.TUM_INTR['H'], syn.TUM_INTR['W']
         self.cfg = core.RenderCfg(rel_pos=b.rel_pos)
         self.dec = core.DecoderBlob(eng).pack(syn.default_weights(seed, rel_pos=b.rel_pos))
-        pos, geo, col = syn.build_cloud(b.n_points, device='cpu', seed=seed)
-        self.pos, self.geo, self.col = pos.to(dev), geo.to(dev), col.to(dev)
-        self.knn = core.KnnIndex(eng, capacity=b.n_points)
-        self.knn.build(self.pos)
-        # keyframe window: stacked depth / colour / pose
+        if b.online_cloud:
+            pos, geo, col, self.n_rooms = syn.build_cloud_online(eng, b.n_points, seed=seed)
+        else:
+            pos, geo, col = (t.to(dev) for t in syn.build_cloud(b.n_points, device='cpu', seed=seed))
+            self.n_rooms = 1
+        # tables at a fixed capacity (the full step keeps inserting points, NeuralPointCloud-style); rows >= n are never indexed
+        self.n = int(pos.shape[0])
+        b.n_points = self.n
+        self.capacity = self.n + 40 * 3 * b.pixels_adding
+        self.pos, self.geo, self.col = eng.zeros(self.capacity, 3), eng.zeros(self.capacity, 32), eng.zeros(self.capacity, 32)
+        self.pos[:self.n], self.geo[:self.n], self.col[:self.n] = pos, geo, col
+        del pos, geo, col
+        self.knn = core.KnnIndex(eng, capacity=self.capacity)
+        self.knn.build(self.pos[:self.n])
+        # keyframe window: stacked depth / colour / pose; the camera works in the LAST room of a multi-room map (the part of the map
+        # it does not see is dead weight for the index and the tables, as in a long sequence)
+        room = self.n_rooms - 1
         ds, cs, ps = [], [], []
         for k in range(b.window):
             d, c, p = syn.render_frame(3 * k, device=dev, holes=0.02, seed=seed)
-            ds.append(d); cs.append(c); ps.append(p)
+            ds.append(d); cs.append(c); ps.append(syn.pose_in_room(p, room))
         self.depth_stack = torch.stack(ds).contiguous()
         self.color_stack = torch.stack(cs).contiguous()
         self.c2w_stack = torch.stack(ps).contiguous()
         self.frames = (self.depth_stack, self.color_stack, self.c2w_stack, None)
         # rows optimised by the mapper = frustum selection of the frame being mapped (Mapper.py:165-217, 498-512),
         # recomputed at every step like the reference does at every optimize_map call
-        self.rows = optim.frustum_rows(eng, self.pos, self.c2w_stack[0], self.depth_stack[0], self.intr, self.H, self.W, b.frustum_edge)
+        self.rows = optim.frustum_rows(eng, self.pos[:self.n], self.c2w_stack[0], self.depth_stack[0], self.intr, self.H, self.W, b.frustum_edge)
         self.mapper = steps.MapOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col, self.rows,
                                          b.map_rays, MAP_LRS, w_color=0.1, dist=dist)
         self.tracker = steps.TrackOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col,
@@ -79,12 +95,49 @@ class FrameWorkload:
         self.cam0 = get_tensor_from_camera(self.c2w_stack[0]).to(dev)
         self.map_log = eng.zeros(b.map_iters, 4)
         self.frame_no = 0
+        self.img_state = None               # RenderState of the full-frame render (full step)
+        self.n_added = 0
 
     def _draws(self, iters, R, n, gen=None):
         return torch.randint(0, n, (iters, R), generator=gen or self.gen, dtype=torch.int32, device=self.eng.device)
 
-    def step(self):
-        """One frame-equivalent: 40 tracking iterations + 60 mapping iterations (24 geometry + 36 colour)."""
+    def mapped_frame_extras(self, k):
+        """What a MAPPED frame does around its iterations (every `every_frame`-th frame): point insertion of `pixels_adding`
+        random pixels with the radius test against the current map + feature rows for the new points + index rebuild
+        (Mapper.py:421-482, neural_point.py:1557-1631), and the full-frame render after the optimisation
+        (Renderer.render_img, Mapper.py:966-969)."""
+        b, eng = self.b, self.eng
+        H, W = self.H, self.W
+        px = torch.randint(0, H * W, (b.pixels_adding,), generator=self.gen, device=eng.device)
+        i, j = (px % W).float(), torch.div(px, W, rounding_mode='floor').float()
+        ro, rd = syn.pixel_rays(self.c2w_stack[k], i, j)
+        gd = self.depth_stack[k].reshape(-1)[px]
+        _, pts = optim.add_points(eng, self.knn, ro, rd, gd, float(torch.tensor(0.04 ** 2, dtype=torch.float32)), 0.98, 1.02, 3)
+        m = min(int(pts.shape[0]), self.capacity - self.n)
+        if m:
+            self.pos[self.n:self.n + m] = pts[:m]
+            self.geo[self.n:self.n + m] = 0.1 * torch.randn(m, 32, generator=self.gen, device=eng.device)
+            self.col[self.n:self.n + m] = 0.1 * torch.randn(m, 32, generator=self.gen, device=eng.device)
+            self.n += m
+            self.n_added += m
+            self.knn.build(self.pos[:self.n])
+
+    def render_frame(self, k):
+        """Renderer.render_img of keyframe k: all H*W rays in one fused pass."""
+        eng, H, W = self.eng, self.H, self.W
+        if self.img_state is None:
+            jj, ii = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=eng.device), torch.arange(W, dtype=torch.float32, device=eng.device), indexing='ij')
+            self._img_ij = (ii.reshape(-1).contiguous(), jj.reshape(-1).contiguous())
+            self.img_state = core.RenderState(eng, H * W, self.cfg.S)
+        ro, rd = syn.pixel_rays(self.c2w_stack[k], *self._img_ij)
+        gd = self.depth_stack[k].reshape(-1).contiguous()
+        core.render_forward(eng, self.cfg, self.img_state, ro, rd, gd, self.knn, self.pos, self.geo, self.col, self.dec, 'color', stats_chunk=3000)
+        return self.img_state
+
+    def step(self, full=False):
+        """One frame-equivalent: 40 tracking iterations + 60 mapping iterations (24 geometry + 36 colour).  full: every
+        `every_frame`-th step is a MAPPED frame and also runs mapped_frame_extras / render_frame - the work the reference does
+        once per mapped frame beside its 300 iterations (their 60-per-frame share is in every step)."""
         b, eng = self.b, self.eng
         H, W = self.H, self.W
         e = min(b.ignore_edge, H // 4)
@@ -92,11 +145,16 @@ class FrameWorkload:
         rnd_t = self._draws(b.track_iters, b.track_rays, (win[1] - win[0]) * (win[3] - win[2]), self.gen_track)
         k = self.frame_no % b.window
         best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win, self.intr, rnd_t)
+        mapped = full and self.frame_no % b.every_frame == 0
+        if mapped:
+            self.mapped_frame_extras(k)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
         fid = self._fid
-        self.rows, row_mask = optim.frustum_rows(eng, self.pos, self.c2w_stack[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
+        self.rows, row_mask = optim.frustum_rows(eng, self.pos[:self.n], self.c2w_stack[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
                                                  return_mask=True)
         self.mapper.new_frame(self.rows, row_mask)
         self.mapper.run(b.map_iters, b.map_geo_iters, self.frames, rnd_m, fid, (0, H, 0, W), self.intr, H, W, self.map_log)
+        if mapped:
+            self.render_frame(k)
         self.frame_no += 1
         return best, tlog, self.map_log
