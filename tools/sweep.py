@@ -30,18 +30,20 @@ def timed(fn, iters, warm=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--points', default='100000,500000,2000000')
+    ap.add_argument('--points', default='100000,500000,2000000,5000000')
+    ap.add_argument('--dense', default='2000000', help='sizes that are ALSO measured as over-dense stress clouds (all points in one room)')
     ap.add_argument('--md', default=None)
     args = ap.parse_args()
     eng = core.Engine()
     rows = []
-    for N in [int(x) for x in args.points.split(',')]:
+    sizes = [(int(x), True) for x in args.points.split(',')] + [(int(x), False) for x in args.dense.split(',') if x]
+    for N, online in sizes:
         for rel in (True, False):
-            cfgname = 'Replica (rel-pos MLP)' if rel else 'TUM/ScanNet (plain colour)'
+            cfgname = ('Replica (rel-pos MLP)' if rel else 'TUM/ScanNet (plain colour)') + ('' if online else ' - STRESS: one room')
             for (tr, mr) in ((1500, 5000), (5000, 10000)):
                 if rel != (tr == 1500):
                     continue                      # Replica budget with the rel-pos model, TUM/ScanNet budget without
-                b = workload.Budget(n_points=N, track_rays=tr, map_rays=mr, rel_pos=rel)
+                b = workload.Budget(n_points=N, track_rays=tr, map_rays=mr, rel_pos=rel, online_cloud=online)
                 wl = workload.FrameWorkload(eng, b)
                 H, W = wl.H, wl.W
                 e = min(b.ignore_edge, H // 4)
@@ -53,10 +55,10 @@ def main():
                 # the mapping loop as the product runs it: ONE lk_map_frame call of n_it iterations of one stage
                 for stage, n_geo in (('geometry', n_it), ('color', 0)):
                     ms = timed(lambda: wl.mapper.run(n_it, n_geo, wl.frames, rnd_m, fid, (0, H, 0, W), wl.intr, H, W, log), 3, warm=1) / n_it
-                    rows.append((cfgname, N, f'map-{stage}', mr, ms, mr / ms * 1e3, None))
+                    rows.append((cfgname, wl.n, f'map-{stage}', mr, ms, mr / ms * 1e3, None))
                 rnd_t = wl._draws(10, tr, (win[1] - win[0]) * (win[3] - win[2]))
                 ms = timed(lambda: wl.tracker.track(wl.cam0, wl.depth_stack[0], wl.color_stack[0], 10, win, wl.intr, rnd_t), 2, warm=1) / 10
-                rows.append((cfgname, N, 'track', tr, ms, tr / ms * 1e3, None))
+                rows.append((cfgname, wl.n, 'track', tr, ms, tr / ms * 1e3, None))
                 # forward only, full image
                 R = H * W
                 jj, ii = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
@@ -65,7 +67,7 @@ def main():
                 st = core.RenderState(eng, R, wl.cfg.S)
                 ms = timed(lambda: core.render_forward(eng, wl.cfg, st, ro, rd, gd, wl.knn, wl.pos, wl.geo, wl.col, wl.dec, 'color'), 5)
                 flop_ray = 1.99e6 if rel else 1.13e6          # BASELINE.md §3, forward FLOPs per ray
-                rows.append((cfgname, N, 'render (fwd)', R, ms, R / ms * 1e3, (11.1e3 * R / (ms * 1e-3) / 8e12, flop_ray * R / (ms * 1e-3) / 157.3e12)))
+                rows.append((cfgname, wl.n, 'render (fwd)', R, ms, R / ms * 1e3, (11.1e3 * R / (ms * 1e-3) / 8e12, flop_ray * R / (ms * 1e-3) / 157.3e12)))
                 del wl, st
                 torch.cuda.empty_cache()
     lines = ['| config | N points | mode | rays / iteration | ms / iteration | M rays/s | HBM frac (11.1 KB/ray) | fp32-MFMA frac (1.99 / 1.13 MFLOP/ray) |', '|---|---|---|---|---|---|---|---|']
@@ -75,10 +77,12 @@ def main():
     print(out)
     if args.md:
         with open(args.md, 'w') as f:
-            f.write('# Measurement grid (SURVEY §8d), one MI355X, synthetic 640x480 room, fp32 (map modes: per iteration of a 24-iteration lk_map_frame call)\n\n'
-                    '`python tools/sweep.py` - HIP-event timing, everything resident in HBM.  Point clouds above 1e5 points put\n'
-                    'proportionally more points into the same 108 m^2 of surfaces (no de-duplication), so the radius search\n'
-                    'scans proportionally more candidates: the N axis is a stress axis for the kNN, not a typical map.\n\n' + out + '\n')
+            f.write('# Measurement grid (SURVEY §8d), one MI355X, synthetic 640x480 rooms, fp32 (map modes: per iteration of a 24-iteration lk_map_frame call)\n\n'
+                    '`python tools/sweep.py` - HIP-event timing, everything resident in HBM.  Maps are laid down the way an online run does it\n'
+                    '(synthetic.build_cloud_online: radius-de-duplicated insertion with lk_add_points, ~900 points per m^2 of surface) and grow\n'
+                    'with the EXPLORED AREA: one 6 x 4 x 3 m room per 100 000 points (the camera works in the last room), as a long sequence grows\n'
+                    'its map.  Rows marked STRESS pack all points into one room instead (random pixels, no de-duplication: 20x the density an\n'
+                    'online map can reach at radius_add 0.04) - a stress axis for the radius search, not a map the system produces.\n\n' + out + '\n')
 
 
 if __name__ == '__main__':
