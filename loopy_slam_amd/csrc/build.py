@@ -66,7 +66,10 @@ def build(force=False, verbose=False):
         raise RuntimeError('hipcc failed')
     open(stamp, 'w').write(cur)
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + '.o') for s in srcs]
-    if force or jobs or _newer(objs, OUT):
+    relink = force or bool(jobs) or _newer(objs, OUT)
+    print(f'loopy_slam_amd build: {len(jobs)} of {len(srcs)} sources compiled with {os.path.basename(HIPCC)} --offload-arch=gfx950 '
+          f'({"relinked" if relink else "up to date"}: {os.path.relpath(OUT, os.path.dirname(PKG))})', flush=True)
+    if relink:
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

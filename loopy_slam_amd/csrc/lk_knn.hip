@@ -275,6 +275,15 @@ extern "C" int lk_knn_build(lk_knn_t h, const float* pos, int64_t N, void* strea
     LK_REQUIRE(N == 0 || pos != nullptr, "lk_knn_build: pos is NULL");
     hipStream_t st = (hipStream_t)stream_;
     const int n = (int)N;
+    // The per-point row counters of the feature-gradient sort are zero BETWEEN sorts by construction (the scan clears what a sort counted).
+    // A sort that never reached its scan - a launch that failed midway, an lk_map_frame sequence abandoned before its look-ahead chunk was
+    // consumed - would leave counts behind that the next sort silently adds to: a rebuild of the index is the point where no sort is in
+    // flight in the caller's stream order, so the counters of the rows in use are cleared here (a few tens of microseconds at 5 M points).
+    if (h->seg_cnt) {
+        const int64_t used = (int64_t)(h->n > N ? h->n : N) + 1;
+        for (int y = 0; y < LK_SEG_BATCH; ++y)
+            LK_HIP_TRY(hipMemsetAsync(h->seg_cnt + (size_t)y * h->seg_stride, 0, sizeof(int32_t) * (size_t)used, st));
+    }
     h->n = N;
     hipLaunchKernelGGL(k_grid_reset, dim3(1), dim3(64), 0, st, h->grid);
     if (n > 0) {

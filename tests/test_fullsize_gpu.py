@@ -207,3 +207,20 @@ def test_tracker_backward_is_deterministic_at_scale(R):
         for a, b in zip(r, runs[0]):
             assert torch.equal(a, b)
     assert float(runs[0][3].abs().max()) > 0 and bool(torch.isfinite(runs[0][4]).all())
+
+
+@pytest.mark.parametrize('unit', (False, True))
+def test_decoder_backward_rows_repeat_bit_for_bit(unit):
+    """The in-situ probe of the round-1 'store-data' corruption (tools/probe/dh_store_insitu.py, DESIGN.md section 3: packed-fp32
+    instructions in k_decode_bwd put wrong values into lanes 48-63 of one register in ~1 % of the tiles once two workgroups shared
+    a compute unit), kept as a test of the PRODUCT library: four repeats of the same 40 000-ray colour backward, zero d h / d c rows
+    may differ - for the bf16-piece and the pre-scaled fp16-piece form of the kernel."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('dh_store_insitu', os.path.join(root, 'tools', 'probe', 'dh_store_insitu.py'))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    from loopy_slam_amd import _ffi
+    bad_dc, bad_dh, cols = probe.run(_ffi.LIB_PATH, 40000, unit)
+    assert bad_dc == 0 and bad_dh == 0, (bad_dc, bad_dh, cols)
