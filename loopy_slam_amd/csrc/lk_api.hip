@@ -221,6 +221,12 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     }
 
     const bool color = (d->flags & LK_FLAG_STAGE_COLOR) != 0;
+    LkDecodeArgs da;
+    da.R = d->R; da.S = d->S; da.P = P; da.flags = d->flags;
+    da.rays_o = d->rays_o; da.rays_d = d->rays_d; da.z = d->z;
+    da.c_geo = d->c_geo; da.c_col = d->c_col; da.W = d->weights; da.Wfrag = d->weights_frag; da.affine = d->affine;
+    da.raw = d->raw; da.act = d->act; da.live_rays = live_rays;
+    const bool fuse_small = (skip & LK_FUSE_SMALL) && lk_relpos_decode_fusable(da);
     if (color && (d->flags & LK_FLAG_REL_POS)) {
         LkRelposArgs ra;
         ra.R = d->R; ra.S = d->S; ra.P = P; ra.min_nn = d->min_nn;
@@ -228,14 +234,10 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         ra.pos = d->pos; ra.col_feats = d->col_feats; ra.feats_f16 = (d->flags & LK_FLAG_FEATS_F16) ? 1 : 0; ra.live_rays = live_rays;
         ra.nbr_idx = d->nbr_idx; ra.nbr_w = d->nbr_w; ra.nbr_count = d->nbr_count;
         ra.W = d->weights; ra.Wfrag = d->weights_frag; ra.noise_col = d->noise_col; ra.c_col = d->c_col;
-        lk_launch_relpos_fwd(ra, st);
+        if (fuse_small) lk_launch_relpos_decode_fwd(ra, da, st);
+        else lk_launch_relpos_fwd(ra, st);
     }
-    LkDecodeArgs da;
-    da.R = d->R; da.S = d->S; da.P = P; da.flags = d->flags;
-    da.rays_o = d->rays_o; da.rays_d = d->rays_d; da.z = d->z;
-    da.c_geo = d->c_geo; da.c_col = d->c_col; da.W = d->weights; da.Wfrag = d->weights_frag; da.affine = d->affine;
-    da.raw = d->raw; da.act = d->act; da.live_rays = live_rays;
-    lk_launch_decode_fwd(da, st);
+    if (!fuse_small) lk_launch_decode_fwd(da, st);
 
     if (skip & LK_SKIP_COMPOSITE) { LK_LAUNCH_CHECK(); return LK_OK; }     // the caller composites (fused loss kernel, lk_loop.hip)
     LkCompositeArgs ca;
@@ -365,6 +367,10 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     cb.d_raw = S0 + L.d_raw; cb.keep_depth = (flags & LK_FLAG_Z_GIVEN) ? 1 : 0;
     if (!(skip & LK_SKIP_COMPOSITE_BWD)) lk_launch_composite_bwd(cb, st);
 
+    // tracker-sized batches: rel-pos backward + interpolation backward in one launch (k_relpos_interp_bwd)
+    const bool fuse_small = (skip & LK_FUSE_SMALL) && relpos && gr && !gw && !gf && lk_cdiv(P, 32) <= LK_DEEP_MAX_TILES;
+    bool fuse_rb = false;
+    LkRelposBwdArgs rb_fused;
     LkDecodeBwdArgs db;
     db.R = d->R; db.S = d->S; db.P = P; db.flags = flags;
     db.rays_o = d->rays_o; db.rays_d = d->rays_d; db.z = d->z;
@@ -445,7 +451,9 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         rb.dfeat = S0 + L.dfeat;
         rb.part_br = S0 + L.part_br; rb.hbar = S0 + L.hbar; rb.w_sum = S0 + L.w_sum; rb.dw1_part = S0 + L.dw1_part;
         rb.live_rays = (ex && lk_relpos_fused(flags)) ? ex->live_rays : nullptr;
-        lk_launch_relpos_bwd(rb, st);
+        fuse_rb = fuse_small;                   // launched together with the interpolation backward below
+        if (fuse_rb) rb_fused = rb;
+        else lk_launch_relpos_bwd(rb, st);
         if (forked) { (void)hipEventRecord(ss.mid, st); (void)hipStreamWaitEvent(wst, ss.mid, 0); }
         if (gw && !defer) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
     }
@@ -471,7 +479,8 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         ib.pose_part = ex ? ex->pose_part : nullptr;
         if (ex) { ib.pix_i = ex->pix_i; ib.pix_j = ex->pix_j; ib.fx = ex->fx; ib.fy = ex->fy; ib.cx = ex->cx; ib.cy = ex->cy; }
         else { ib.pix_i = ib.pix_j = nullptr; ib.fx = ib.fy = 1.0f; ib.cx = ib.cy = 0.0f; }
-        lk_launch_interp_bwd(ib, st);
+        if (fuse_rb) lk_launch_relpos_interp_bwd(rb_fused, ib, st);
+        else lk_launch_interp_bwd(ib, st);
     }
     if (gr && !(skip & LK_SKIP_RAYS_BWD)) {
         LkRaysBwdArgs rr;

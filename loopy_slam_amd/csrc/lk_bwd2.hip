@@ -13,9 +13,10 @@
 using namespace lkw;
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
+// one workgroup-sized block of 32 samples, 256 threads (8 per sample); `block` = index of the 32-sample block
+__device__ __forceinline__ void interp_bwd_block(const LkInterpBwdArgs& a, int block) {
     const int sub = (int)threadIdx.x & 7;
-    const int p_raw = blockIdx.x * 32 + ((int)threadIdx.x >> 3);
+    const int p_raw = block * 32 + ((int)threadIdx.x >> 3);
     const bool live = p_raw < a.P;
     const int pidx = live ? p_raw : a.P - 1;
     const bool has = a.nbr_count[pidx] >= a.min_nn;
@@ -112,9 +113,10 @@ __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) {
             for (int q = 0; q < 12; ++q) s_pp[wv][q] = v[q];
         }
         __syncthreads();
-        if (threadIdx.x < 12) a.pose_part[(size_t)blockIdx.x * 12 + threadIdx.x] = (s_pp[0][threadIdx.x] + s_pp[1][threadIdx.x]) + (s_pp[2][threadIdx.x] + s_pp[3][threadIdx.x]);
+        if (threadIdx.x < 12) a.pose_part[(size_t)block * 12 + threadIdx.x] = (s_pp[0][threadIdx.x] + s_pp[1][threadIdx.x]) + (s_pp[2][threadIdx.x] + s_pp[3][threadIdx.x]);
     }
 }
+__global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) { interp_bwd_block(a, (int)blockIdx.x); }
 
 // Feature-row gradients:
 //   geometry rows:            g_geo[idx] += w * d c_geo[sample]
@@ -458,6 +460,20 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd(LkRelposBwdArgs a) {
             a.part_br[(size_t)blockIdx.x * 32 + threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] +
                                                                  s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
     }
+}
+
+// Tracker-sized batches (lk_track_frame): the rel-pos backward and the interpolation backward of a 32-sample block in ONE launch - eight
+// waves run the rel-pos backward (4 samples each, as k_relpos_bwd), one barrier, waves 4..7 leave, waves 0..3 are k_interp_bwd's block.
+// No weight gradients here (the tracker optimises the pose only).
+template <bool F16>
+__global__ __launch_bounds__(512) void k_relpos_interp_bwd(LkRelposBwdArgs rb, LkInterpBwdArgs ib) {
+    __shared__ float s_dummy[32];
+    const int w = (int)threadIdx.x >> 6;
+    const int sample0 = (int)blockIdx.x * 32 + 4 * w;
+    if (sample0 < rb.P) relpos_bwd_wave<F16>(rb, sample0, s_dummy);
+    __syncthreads();                                   // d w_rel / d p_rel of the block are written
+    if (w >= 4) return;
+    interp_bwd_block(ib, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1252,6 +1268,12 @@ int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp,
     return LK_OK;
 }
 
+int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs& ib, hipStream_t st) {
+    LkProfScope prof_(LKK_RELPOS_BWD, st);
+    if (rb.flags & LK_FLAG_FEATS_F16) hipLaunchKernelGGL(k_relpos_interp_bwd<true>, dim3(lk_cdiv(rb.P, 32)), dim3(512), 0, st, rb, ib);
+    else hipLaunchKernelGGL(k_relpos_interp_bwd<false>, dim3(lk_cdiv(rb.P, 32)), dim3(512), 0, st, rb, ib);
+    return LK_OK;
+}
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_INTERP_BWD, st);
     hipLaunchKernelGGL(k_interp_bwd, dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);

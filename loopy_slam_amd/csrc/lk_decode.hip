@@ -448,12 +448,8 @@ __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col
 // ---------------------------------------------------------------------------------------------
 // Relative-position neighbour MLP: one wave = 32 neighbour rows = 4 samples x 8 neighbours.
 //   x_j = [sin(2 pi D_j B_r), cos(2 pi D_j B_r), F[I_j]] (52) -> 128 softplus100 -> 32;  c = sum_j w_j f_j
-__global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
+__device__ __forceinline__ void relpos_fwd_wave(const LkRelposArgs& a, int sample0, int P) {
     const int lane = lk_lane();
-    const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    const int sample0 = wave * 4;
-    const int P = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;      // rays without a reading sit behind the live prefix: skipped
-    if (sample0 >= P) return;
     const int h = lane >> 5;
     const int j = lane & 31;                    // row of the tile: sample j>>3, neighbour j&7
     const int sample = sample0 + (j >> 3);
@@ -532,6 +528,35 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
+    const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int sample0 = wave * 4;
+    const int P = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;      // rays without a reading sit behind the live prefix: skipped
+    if (sample0 >= P) return;
+    relpos_fwd_wave(a, sample0, P);
+}
+
+// Rel-pos neighbour MLP + both decoders in ONE launch (the tracker's batches: every kernel of an iteration is a single partial round
+// of the chip, so a launch boundary costs its fixed ~6 us - dispatch, an L2-cold start, the drain - for nothing).  A colour workgroup is
+// EIGHT waves: all eight run the rel-pos MLP of the tile's 32 samples (4 samples = 32 neighbour rows per wave, as k_relpos_fwd), meet at
+// one barrier, then waves 0..3 decode the tile's colour as decode_col_wg does, wave 4 runs the geometry decoder of the SAME tile (no
+// barriers in it) and waves 5..7 leave - a barrier only counts the waves still alive.  One workgroup per tile and nothing else in the
+// grid: an eight-wave workgroup at this register count fills a compute unit, and a tracking batch (235 tiles) must not need a second round.
+template <bool DEEP>
+__global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDecodeArgs a) {
+    __shared__ u32x4 s_x[2][16 * 64];
+    __shared__ float s_o[4][3 * 32];
+    __shared__ float s_bias[10][128];
+    const int lane = lk_lane();
+    const int w = (int)threadIdx.x >> 6;
+    const int tile = (int)blockIdx.x;
+    const int sample0 = tile * 32 + 4 * w;
+    if (sample0 < ra.P) relpos_fwd_wave(ra, sample0, ra.P);
+    __syncthreads();                               // the tile's c_col rows are written
+    if (w > 4) return;
+    if (w == 4) { decode_geo_wave(a, tile, lane); return; }
+    decode_col_wg<DEEP>(a, tile, w, lane, s_x, s_o, s_bias);
+}
 
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
@@ -539,6 +564,17 @@ int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
     if (n_col > 0 && n_col <= LK_DEEP_MAX_TILES_FWD) hipLaunchKernelGGL(k_decode_fwd<true>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     else hipLaunchKernelGGL(k_decode_fwd<false>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
+    return LK_OK;
+}
+// tracker-sized colour batches with the rel-pos MLP (lk_track_frame): see k_relpos_decode_fwd
+bool lk_relpos_decode_fusable(const LkDecodeArgs& a) {
+    const int tiles = lk_cdiv(a.P, 32);
+    return (a.flags & LK_FLAG_STAGE_COLOR) && (a.flags & LK_FLAG_REL_POS) && tiles > 0 && tiles <= LK_DEEP_MAX_TILES_FWD && a.live_rays == nullptr;
+}
+int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, hipStream_t st) {
+    LkProfScope prof_(LKK_DECODE_FWD, st);
+    const int tiles = lk_cdiv(a.P, 32);
+    hipLaunchKernelGGL(k_relpos_decode_fwd<true>, dim3(tiles), dim3(512), 0, st, ra, a);
     return LK_OK;
 }
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {

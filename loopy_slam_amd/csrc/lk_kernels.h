@@ -252,7 +252,8 @@ inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_W
 // lk_render_fwd / lk_render_bwd with parts of their launch sequence left to the caller (the fused per-frame loops, lk_loop.hip)
 enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, LK_FUSE_COMPOSITE_BWD = 8, LK_LOSS_PREZEROED = 16,
        LK_SEG_SORTED = 32 /* bwd: the forward (LK_FUSE_COMPOSITE_BWD + GRAD_FEATS) already sorted the rows by point */,
-       LK_PRESAMPLED = 64 /* fwd: z / nbr_idx / nbr_w / nbr_count are given (lk_presample), only interpolate */ };
+       LK_PRESAMPLED = 64 /* fwd: z / nbr_idx / nbr_w / nbr_count are given (lk_presample), only interpolate */,
+       LK_FUSE_SMALL = 128 /* tracker-sized batches: rel-pos MLP + decoders in one launch (fwd), rel-pos backward + interpolation backward in one (bwd) */ };
 // cnt: the batch holds n iterations of P_iter samples each (n <= LK_SEG_BATCH); their rows are counted per point on the way
 struct LkPresampleCount { int P_iter; int32_t* seg_rank; const int32_t* live_rays; };
 int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount* cnt = nullptr);
@@ -292,6 +293,9 @@ int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode = 0)
 int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st);
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st);
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st);
+bool lk_relpos_decode_fusable(const LkDecodeArgs& a);
+int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, hipStream_t st);       // k_relpos_fwd + k_decode_fwd in one launch
+int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs& ib, hipStream_t st);  // k_relpos_bwd + k_interp_bwd in one launch
 
 // activation scratch layout (floats per sample), SAVE_ACT
 //   [P][160] geometry a_i | [P][640] colour a_i | [P][640] colour h_i | [P][40] colour embedding  (i = 0..4)

@@ -369,7 +369,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             if (rc != LK_OK) return rc;
         }
         // ---- forward, loss, backward
-        int rc = lk_render_fwd_impl(&rd, st, fused ? LK_SKIP_COMPOSITE : 0);
+        int rc = lk_render_fwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE | LK_FUSE_SMALL) : 0);
         if (rc != LK_OK) return rc;
         if (fused) {
             LkTrackLossArgs la;
@@ -390,7 +390,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         ex.pose_part = fused ? W0 + wk.pose_part : nullptr;
         ex.pix_i = W0 ? W0 + wk.pix_i + (size_t)it * R : nullptr; ex.pix_j = W0 ? W0 + wk.pix_j + (size_t)it * R : nullptr;
         ex.fx = d->fx; ex.fy = d->fy; ex.cx = d->cx; ex.cy = d->cy;
-        rc = lk_render_bwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE_BWD | LK_SKIP_RAYS_BWD) : 0, fused ? &ex : nullptr);
+        rc = lk_render_bwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE_BWD | LK_SKIP_RAYS_BWD | LK_FUSE_SMALL) : 0, fused ? &ex : nullptr);
         if (rc != LK_OK) return rc;
         if (xd) {
             rc = lk_launch_exposure_step(*xd, 3, it + 1, beta1, beta2, eps, st);

@@ -1,7 +1,8 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-for k in 1 2; do
-for v in 0 1 -1; do
-LK_SIDE_PRIO=$v python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print('prio $v: %.2f ms/step' % d['ms_per_step'], {k[2:]: round(x, 2) for k, x in list(d['kernel_ms_per_step'].items())[:6]})"
-done; done
+cp loopy_slam_amd/libloopyhip.so /tmp/keep.so
+timeout 600 python -m pytest tests/test_steps_parity.py tests/test_slam_api.py -m gpu -x -q -k "track or slam_runs or exposure" 2>&1 | tail -3
+for v in live fuse0 fuse1 live fuse1; do
+cp ab/lib_$v.so loopy_slam_amd/libloopyhip.so
+python tools/mode_trace.py track 40 --repeat 4 2>/dev/null | tail -2 | sed "s/^/$v /"
+done
+cp /tmp/keep.so loopy_slam_amd/libloopyhip.so
