@@ -917,7 +917,7 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
 // VALU work either.  The tile is scaled back when it is stored.
 template <int NV, int KV, int MODE, bool H16>
 __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane,
-                                           float* __restrict__ tile, int rows) {
+                                           float* __restrict__ tile, int rows, bool aux_t = false) {
     const int i = lane & 31, h = lane >> 5;
     // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
     const int ncol = n0 + NV * i, kcol = k0 + KV * i;
@@ -1024,6 +1024,16 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
             __builtin_amdgcn_sched_barrier(0);          // keep consume(s) -> refill(s) order: the ring IS the schedule
         }
     }
+    if (tile && aux_t && KV == 1) {
+        // the auxiliary columns (M = d y^T c, LkFcPost): stored TRANSPOSED, [column kc][row n of the unit], because their only reader
+        // (fc_post_body) sums ONE column over the tiles - in the lane-major layout below that was one float out of every 128-byte line,
+        // and the 33 column blocks of a layer fetched the same lines 33 times (86 MB per launch for 2.6 MB of tiles)
+#pragma unroll
+        for (int bn = 0; bn < NV; ++bn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[i * 64 + NV * lk_frag_row(r, h) + bn] = acc[bn][0][r] * ISCALE;
+        return;
+    }
     if (tile) {        // partial tile [block (bn,bk)][register r][lane] + bias sums: 256-byte coalesced stores
 #pragma unroll
         for (int bn = 0; bn < NV; ++bn)
@@ -1063,12 +1073,13 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 
 template <int NV, int KV, bool H16>
 __device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile, int rows) {
+    const bool aux_t = J.k_aux > 0 && k0 >= J.k_aux;
 #ifdef LK_PROBE_WG_MODE0        // timing probe (tools/ab_build.sh): only the plain form, so that a deeper ring fits the register file
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows);
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t);
 #else
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows);
-    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile, rows);
-    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile, rows);
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t);
+    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t);
 #endif
 }
 
@@ -1107,6 +1118,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const LkWgradArgs& a, int bx, 
     const LkWgradUnit& U = a.unit[bx];
     const LkWgradJob& J = a.job[U.job];
     const int nv = U.nv, kv = U.kv;
+    if (J.k_aux > 0 && U.k0 >= J.k_aux) return;          // auxiliary columns: not part of dW, summed by fc_post_body (transposed tiles)
     // 32 consecutive tile elements x 8 row-block lanes per workgroup
     const int e = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
     const int idx = by * 32 + e;
@@ -1163,9 +1175,8 @@ __device__ __forceinline__ void fc_post_body(const LkWgradArgs& a, int f, int kc
             if (U.job != F.src_job || U.k0 != (bias ? 0 : J.k_aux)) continue;
             const int nblk = 8 * U.n_waves, nv = U.nv;
             const float* __restrict__ src = a.part + (size_t)8 * U.wave0 * LK_WG_TILE;
-            const int bn = e >> 5, r = (e >> 1) & 15, h = e & 1;
-            // bias: element e = column e of the tile's bias section (row n0 + e)
-            const int off = bias ? 4 * 16 * 64 + e : (bn * 16 + r) * 64 + h * 32 + kc;
+            // bias: element e = column e of the tile's bias section (row n0 + e); column kc of M: the transposed tile [kc][row e of the unit]
+            const int off = bias ? 4 * 16 * 64 + e : kc * 64 + e;
             float s = 0.0f;
             for (int y0 = 0; y0 < nblk; y0 += 4 * LK_FC_MAX_TILES) {          // one pass at the benchmark's sizes
                 float v[LK_FC_MAX_TILES];
@@ -1187,9 +1198,7 @@ __device__ __forceinline__ void fc_post_body(const LkWgradArgs& a, int f, int kc
         const int which = t >> 6, e = t & 63;
         const float s = ((sh.part[0][t] + sh.part[1][t]) + sh.part[2][t]) + sh.part[3][t];
         const int nv = J.N > 32 ? 2 : 1;
-        int n;
-        if (bias) n = 64 * which + e;
-        else { const int bn = e >> 5, r = (e >> 1) & 15, h = e & 1; n = 64 * which + nv * lk_frag_row(r, h) + bn; }
+        const int n = 64 * which + e;
         const bool ok = (nv == 2 || (which == 0 && e < 32)) && n < 128;
         if (ok) sh.m[n] = (n < J.N) ? s : 0.0f;
     }
