@@ -80,10 +80,10 @@ __device__ __forceinline__ void pregather_ray(const LkPregatherArgs& a, size_t b
         }
     }
 }
+template <int VPT>
 __global__ __launch_bounds__(1024) void k_pregather(LkPregatherArgs a) {
     __shared__ LkMaskShared S;
-    __shared__ int s_wave[LK_MASK_VPT][16];               // kept rays per (ray group q, wave)
-    constexpr int VPT = LK_MASK_VPT;
+    __shared__ int s_wave[VPT][16];                       // kept rays per (ray group q, wave)
     const int t = threadIdx.x, it = blockIdx.x;
     const size_t base = (size_t)it * a.R;
     if (a.zero4 && t < 4) a.zero4[(size_t)it * 4 + t] = 0.0f;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(1024) void k_pregather(LkPregatherArgs a) {
         }
     }
     bool any;
-    const float thr = lk_inside_thr<true>(u, nullptr, a.R, mycnt, mymax, S, &any);
+    const float thr = lk_inside_thr<true, VPT>(u, nullptr, a.R, mycnt, mymax, S, &any);
     if (t == 0 && a.thr) a.thr[it] = any ? thr : 0.0f;
     bool keep[VPT];
 #pragma unroll
@@ -335,7 +335,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         pa.fx = d->fx; pa.fy = d->fy; pa.cx = d->cx; pa.cy = d->cy;
         pa.gt_depth = W0 + wk.gt_depth; pa.gt_color = W0 + wk.gt_color; pa.pix_i = W0 + wk.pix_i; pa.pix_j = W0 + wk.pix_j;
         pa.r2_ray = rd.r2_ray ? W0 + wk.r2_ray : nullptr; pa.thr = W0 + wk.thr;
-        hipLaunchKernelGGL(k_pregather, dim3(iters), dim3(1024), 0, st, pa);
+        hipLaunchKernelGGL(k_pregather<LK_MASK_VPT>, dim3(iters), dim3(1024), 0, st, pa);
         fa.R = R; fa.n_part = n_pose; fa.fx = d->fx; fa.fy = d->fy; fa.cx = d->cx; fa.cy = d->cy;
         fa.pose_part = W0 + wk.pose_part; fa.cam = d->cam7; fa.g_cam = d->g_cam7; fa.adam_mv = d->adam_mv;
         fa.beta1 = beta1; fa.beta2 = beta2; fa.eps = eps;
@@ -439,11 +439,11 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                d->render.bwd_scratch && d->render.act, "lk_map_frame: the render descriptor needs gradient buffers, d_depth/d_color, bwd_scratch and act");
     hipStream_t st = (hipStream_t)stream_;
     const int R = d->render.R;
-    const bool pre = d->work != nullptr && R <= LK_MASK_REG_MAX;
-    if (!pre) LK_REQUIRE(d->gt_color && d->thr && d->scratch_u32, "lk_map_frame: without `work` (or above 8192 rays) the per-iteration batch buffers are needed");
+    const bool pre = d->work != nullptr && R <= LK_LOOP_MAX_R;
+    if (!pre) LK_REQUIRE(d->gt_color && d->thr && d->scratch_u32, "lk_map_frame: without `work` (or above 16384 rays) the per-iteration batch buffers are needed");
     // exposure encoding (Mapper.py:588-607, 697-715): the 'color' iterations render logits, the loss applies the keyframe's affine
     const lk_exposure_desc* xd = d->exposure;
-    LK_REQUIRE(!xd || (pre && d->frame_id), "lk_map_frame: exposure encoding needs `work` (<= 8192 rays) and frame_id");
+    LK_REQUIRE(!xd || (pre && d->frame_id), "lk_map_frame: exposure encoding needs `work` (<= 16384 rays) and frame_id");
     const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
     const int64_t nb = lk_weight_blob_floats();
     const int64_t nrow = d->n_rows * LK_C;
@@ -468,7 +468,8 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         pa.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray : nullptr; pa.thr = W0 + wk.thr; pa.zero4 = d->log;
         pa.n_live = reinterpret_cast<int32_t*>(W0 + wk.n_live);
         if (xd) pa.frame_out = reinterpret_cast<int32_t*>(W0 + wk.frame_id);
-        hipLaunchKernelGGL(k_pregather, dim3(d->iters), dim3(1024), 0, st, pa);
+        if (R <= LK_MASK_REG_MAX) hipLaunchKernelGGL(k_pregather<LK_MASK_VPT>, dim3(d->iters), dim3(1024), 0, st, pa);
+        else hipLaunchKernelGGL(k_pregather<LK_LOOP_MAX_R / 1024>, dim3(d->iters), dim3(1024), 0, st, pa);
     }
     // Ahead of the loop, on the third stream, a few iterations per chunk: the neighbour search (one launch per chunk) and,
     // per iteration, the counting sort of its rows by point for the feature-gradient gather (count, scan, place: lk_bwd2.hip) - both read
@@ -686,7 +687,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
 extern "C" int lk_map_wait_lists(const lk_map_desc* d, int32_t it, void* stream_) {
     LK_REQUIRE(d != nullptr && it >= 0 && it < d->iters, "lk_map_wait_lists: bad arguments");
     PreStream& ps = pre_stream();
-    if (!ps.ok || d->work == nullptr || d->render.R > LK_MASK_REG_MAX) return LK_OK;      // no look-ahead: the lists are written in the call's stream order
+    if (!ps.ok || d->work == nullptr || d->render.R > LK_LOOP_MAX_R) return LK_OK;      // no look-ahead: the lists are written in the call's stream order
     const int pre_chunk = map_pre_chunk(d->iters);
     const int ck = it == 0 ? 0 : 1 + (it - 1) / pre_chunk;
     LK_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_, ps.ev[ck % LK_PRE_CHUNKS], 0));

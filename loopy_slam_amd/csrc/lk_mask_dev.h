@@ -9,14 +9,16 @@
 
 #define LK_MASK_REG_MAX 8192
 #define LK_MASK_VPT (LK_MASK_REG_MAX / 1024)
+// the batch-assembly kernel of the per-frame loops also comes in a 16-values-per-thread form (k_pregather<16>: the 10 000-ray mapping
+// batches of the TUM / ScanNet configs)
+#define LK_LOOP_MAX_R 16384
 struct LkMaskShared { unsigned hist[256]; unsigned s_prefix, s_rank, s_cnt, s_maxbits; };
 
 // u[q] = bit pattern of depth (t + 1024 q) if positive else 0 (REG) / scratch[i] likewise (!REG); mycnt / mymax = this
 // thread's count of positive depths and their largest bit pattern.  Returns thr; *any = false if no depth is positive.
-template <bool REG>
-__device__ __forceinline__ float lk_inside_thr(const unsigned (&u)[LK_MASK_VPT], const uint32_t* __restrict__ scratch, int n,
+template <bool REG, int VPT = LK_MASK_VPT>
+__device__ __forceinline__ float lk_inside_thr(const unsigned (&u)[VPT], const uint32_t* __restrict__ scratch, int n,
                                                unsigned mycnt, unsigned mymax, LkMaskShared& S, bool* any) {
-    constexpr int VPT = LK_MASK_VPT;
     const int t = threadIdx.x, lane = t & 63;
     if (t == 0) { S.s_cnt = 0; S.s_maxbits = 0; }
     __syncthreads();

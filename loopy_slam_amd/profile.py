@@ -73,7 +73,9 @@ def work_per_step(b):
     # + d logit (4) floats
     wg_bytes_col = 4.0 * (640 + 512 + 40 + 32 + 128 + 4)
     w = {
-        'k_decode_fwd': dict(flops=fl(n_geo * Pm * MAC['dec_fwd_geo'] + (n_col * Pm + n_trk * Pt) * (MAC['dec_fwd_geo'] + MAC['dec_fwd_col'])),
+        # (the tracker's launches are k_relpos_decode_fwd: the rel-pos MLP of their samples runs in the same launch, timed under this name)
+        'k_decode_fwd': dict(flops=fl(n_geo * Pm * MAC['dec_fwd_geo'] + (n_col * Pm + n_trk * Pt) * (MAC['dec_fwd_geo'] + MAC['dec_fwd_col']) +
+                                      rel * n_trk * Pt * MAC['rel_fwd']),
                              bytes=0.0, launches=b.map_iters + n_trk),
         'k_decode_bwd': dict(flops=fl(n_geo * Pm * MAC['dec_bwd_geo'] + n_col * Pm * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col']) +
                                       n_trk * Pt * (MAC['dec_bwd_geo'] + MAC['dec_bwd_col'] + MAC['dec_bwd_track_extra'])),
@@ -90,7 +92,7 @@ def work_per_step(b):
                                                       n_col * Pm * (2 * feat_rows + (feat_rows if rel else 128))), launches=b.map_iters),
     }
     if rel:
-        w['k_relpos_fwd'] = dict(flops=fl((n_col * Pm + n_trk * Pt) * MAC['rel_fwd']), bytes=0.0, launches=n_col + n_trk)
+        w['k_relpos_fwd'] = dict(flops=fl(n_col * Pm * MAC['rel_fwd']), bytes=0.0, launches=n_col)      # mapper launches only (see k_decode_fwd)
         w['k_relpos_bwd'] = dict(flops=fl(n_col * Pm * (MAC['rel_bwd'] + MAC['rel_dw1']) + n_trk * Pt * (MAC['rel_bwd'] + MAC['rel_bwd_track_extra'])),
                                  flops_by_path={'f16x3': fl(n_col * Pm * (MAC['rel_bwd'] + MAC['rel_dw1'])),
                                                 'bf16x6': fl(n_trk * Pt * (MAC['rel_bwd'] + MAC['rel_bwd_track_extra']))},
@@ -100,11 +102,11 @@ def work_per_step(b):
 
 
 def pmc_traffic(kernel, path=None):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r2_rocprof_summary.md, written by
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r3_rocprof_summary.md, written by
     tools/summarize_prof.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench; FETCH_SIZE doubled per
     the gfx950 note of MI355X_MICROARCH.md): (bytes, source) or (None, None).  bench.py cannot collect PMC counters live."""
     import os
-    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r2_rocprof_summary.md')
+    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r3_rocprof_summary.md')
     try:
         tot_n, tot_b = 0, 0.0
         for line in open(path):
@@ -113,7 +115,7 @@ def pmc_traffic(kernel, path=None):
                 tot_n += int(c[1])
                 tot_b += int(c[1]) * (float(c[3]) * 1e6 + float(c[4]) * 1024.0)
         if tot_n:
-            return tot_b / tot_n, 'profiles/r2_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
+            return tot_b / tot_n, 'profiles/r3_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
     except (OSError, ValueError):
         pass
     return None, None

@@ -432,6 +432,13 @@ class Mapper:
         self.keyframe_list, self.keyframe_dict = [], []
         # draws on the device, like the reference's select_uv (common.py:156-172): no host RNG + upload between GPU launches
         self.gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219) + 7)
+        # Multi-GPU (slam.dist, loopy_slam_amd/parallel.py): everything that changes the MAP or the window - insertion pixels, keyframe
+        # selection, new feature rows - draws from `gen`, seeded alike on every rank (replicated work keeps the replicas identical); the
+        # pixels of the joint iterations draw from `gen_rays`, seeded per rank: every rank renders its own mapping_pixels / world rays of
+        # the shared iteration and the gradients are summed (the loss is a sum over rays, Mapper.py:693-720)
+        dist = getattr(slam, 'dist', None)
+        self.gen_rays = self.gen if dist is None else \
+            torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219) + 7 + 1000 * (1 + dist.rank))
         self.prev_c2w = None
         self.last_log = None
         # the optimised exposure feature of every optimize_map call (Mapper.py:800, 827): checkpointed (Mapper.py:1028-1031) and read
@@ -596,6 +603,9 @@ class Mapper:
         lrs = {s: (stage_cfg[s]['decoders_lr'], stage_cfg[s]['geometry_lr'], stage_cfg[s]['color_lr']) for s in ('geometry', 'color')}
         F = len(frames_d)
         pix = (self.mapping_pixels // 10) if segments else (self.mapping_pixels // F)       # Mapper.py:417-418
+        dist = getattr(self.slam, 'dist', None)
+        if dist is not None:                        # the reference's batch, split over the ranks
+            pix = max(1, pix // dist.world)
         R = pix * F
         rcfg = render_cfg_from(cfg, cfg['rendering']['sigmoid_coef_mapper'])
         mo = steps.MapOptimizer(eng, rcfg, self.decoders.dec, npc.knn, npc.cloud_pos(), npc.get_geo_feats(), npc.get_col_feats(),
@@ -607,7 +617,7 @@ class Mapper:
                  torch.stack([p.float().to(eng.device) for p in frames_p]).contiguous(),
                  torch.stack(frames_r).contiguous() if frames_r is not None else None)
         fid = torch.arange(F, dtype=torch.int32).repeat_interleave(pix).to(eng.device)
-        rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen, dtype=torch.int32, device=eng.device)
+        rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen_rays, dtype=torch.int32, device=eng.device)
         log = eng.zeros(num_joint_iters, 4)
         geo_iters = self.geo_iter_first if init else int(num_joint_iters * self.geo_iter_ratio)
         # stage 'geometry' while joint_iter <= geo_iters (Mapper.py:594-597)
@@ -781,7 +791,7 @@ class Tracker:
             to = steps.TrackOptimizer(eng, rcfg, self.decoders.dec, self.npc.knn, self.npc.cloud_pos(), self.npc.get_geo_feats(),
                                       self.npc.get_col_feats(), n_px, self.cam_lr, separate_lr=self.separate_LR,
                                       w_color=self.w_color_loss, use_color=self.use_color_in_tracking,
-                                      dynamic_radius=r2_query is not None)
+                                      dynamic_radius=r2_query is not None, dist=getattr(slam, 'dist', None))
             exposure = None
             if slam.encode_exposure:                # this frame's exposure feature starts from the shared one (Tracker.py:280-283)
                 self.exposure_feat = slam.exposure_feat.detach().clone().requires_grad_(True)

@@ -218,7 +218,7 @@ class MapOptimizer:
         it < n_geo_iters.  rnd_all int32 [n_iters, R]; log [n_iters, 4].  Without exposure encoding this is lk_map_frame - one
         C-ABI call for the whole loop single-GPU, two calls per iteration around the gradient all-reduce multi-GPU; with
         exposure encoding the per-statement path (iterate)."""
-        if not self.native_loop or (self.exposure is not None and self.R > 8192):
+        if not self.native_loop or (self.exposure is not None and self.R > 16384):
             for it in range(n_iters):
                 self.iterate('geometry' if it < n_geo_iters else 'color', frames, rnd_all[it], frame_id, window, intr, H, W, log_row=log[it])
             return log
@@ -278,7 +278,7 @@ class MapOptimizer:
             # exposure features only the current frame's (the last) is an Adam parameter
             xd = self.exposure.desc(None if self.fix_color_decoder else self.lrs['color'][0], only_last_feature=True)
             d.exposure = C.pointer(xd)
-        need = int(eng.lib.dll.lk_map_work_floats(self.R, self.cfg.S, n_iters)) if self.R <= 8192 else 0
+        need = int(eng.lib.dll.lk_map_work_floats(self.R, self.cfg.S, n_iters)) if self.R <= 16384 else 0
         if need and (self._work is None or self._work.numel() < need):
             self._work = eng.empty(need)
         d.work = ptr(self._work) if need else 0

@@ -90,7 +90,7 @@ class FrameWorkload:
         # (multi-GPU: the mapping draws differ per rank - every rank renders its own rays of the shared iteration - the tracking draws
         # are the same everywhere: tracking is replicated, steps.TrackOptimizer)
         self.gen = torch.Generator(device=dev).manual_seed(seed + (dist.rank if dist is not None else 0))
-        self.gen_track = torch.Generator(device=dev).manual_seed(seed + 7919)
+        self.gen_track = torch.Generator(device=dev).manual_seed(seed + 7919)          # shared by the ranks: tracking draws, insertion
         self._fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(dev)      # pixels // window frames each
         self.cam0 = get_tensor_from_camera(self.c2w_stack[0]).to(dev)
         self.map_log = eng.zeros(b.map_iters, 4)
@@ -108,7 +108,8 @@ class FrameWorkload:
         (Renderer.render_img, Mapper.py:966-969)."""
         b, eng = self.b, self.eng
         H, W = self.H, self.W
-        px = torch.randint(0, H * W, (b.pixels_adding,), generator=self.gen, device=eng.device)
+        # (multi-GPU: insertion is REPLICATED work - the same pixels and feature draws on every rank keep the map replicas identical, SURVEY 8e)
+        px = torch.randint(0, H * W, (b.pixels_adding,), generator=self.gen_track, device=eng.device)
         i, j = (px % W).float(), torch.div(px, W, rounding_mode='floor').float()
         ro, rd = syn.pixel_rays(self.c2w_stack[k], i, j)
         gd = self.depth_stack[k].reshape(-1)[px]
@@ -116,8 +117,8 @@ class FrameWorkload:
         m = min(int(pts.shape[0]), self.capacity - self.n)
         if m:
             self.pos[self.n:self.n + m] = pts[:m]
-            self.geo[self.n:self.n + m] = 0.1 * torch.randn(m, 32, generator=self.gen, device=eng.device)
-            self.col[self.n:self.n + m] = 0.1 * torch.randn(m, 32, generator=self.gen, device=eng.device)
+            self.geo[self.n:self.n + m] = 0.1 * torch.randn(m, 32, generator=self.gen_track, device=eng.device)
+            self.col[self.n:self.n + m] = 0.1 * torch.randn(m, 32, generator=self.gen_track, device=eng.device)
             self.n += m
             self.n_added += m
             self.knn.build(self.pos[:self.n])
