@@ -52,6 +52,7 @@ class DistContext:
         self.rank, self.world = rank, world
         self._bucket = None
         self._keep = None
+        self._seg_cache = None
         self._agree = {}            # slot (it & 1) -> _RowAgreement
         self._side = None
         self._main_ev = None
@@ -87,6 +88,17 @@ class DistContext:
         g_geo[rows], and in the colour stage g_col[rows] - one bucket, one all-reduce, one pack and one unpack launch
         (lk_bucket_copy: the torch formulation was eight small kernels per iteration)."""
         gs, eng = mo.gs, mo.eng
+        rows = mo.rows if mo.rows is not None else self.touched_rows(mo, it)
+        # the segment table of a stage is the same for every iteration of an optimize_map call (same buffers, same row list): built
+        # once - at 72-us 'geometry' iterations the interpreter time of rebuilding it per iteration was the longer side
+        key = (stage, rows.data_ptr(), rows.numel(), gs.g_weights.data_ptr(), gs.g_geo.data_ptr(), id(mo.exposure))
+        if self._seg_cache is not None and self._seg_cache[0] == key:
+            _, segs, n = self._seg_cache
+            bucket = self._bucket[:n]
+            eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 0, eng.stream), 'lk_bucket_copy')
+            self._all_reduce(bucket, dist.ReduceOp.SUM)
+            eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
+            return
         ranges = _merge(list(mo.geo_dec_ranges) + (list(mo.col_dec_ranges) if stage == 'color' else []))
         tables = [gs.g_geo] + ([gs.g_col] if stage == 'color' else [])
         # exposure encoding: d loss / d affine [F,12] is a sum over rays too and rides in the same bucket (the exposure MLP's
@@ -97,7 +109,6 @@ class DistContext:
         for k, (o, cnt) in enumerate(ranges):
             segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(gs.g_weights[o:o + cnt]), cnt, None, 1
             n += cnt
-        rows = mo.rows if mo.rows is not None else self.touched_rows(mo, it)
         for k, t in enumerate(tables, start=len(ranges)):
             segs[k].data, segs[k].n = ptr(t), rows.numel() * t.shape[1]
             segs[k].row_index, segs[k].row_len = ptr(rows), t.shape[1]
@@ -111,6 +122,7 @@ class DistContext:
             self._bucket = torch.empty(max(n, 2 * (self._bucket.numel() if self._bucket is not None else 0)),
                                        dtype=torch.float32, device=gs.g_weights.device)
         bucket = self._bucket[:n]
+        self._seg_cache = (key, segs, n) if mo.rows is not None else None       # touched-row lists change every iteration
         eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 0, eng.stream), 'lk_bucket_copy')
         self._all_reduce(bucket, dist.ReduceOp.SUM)
         eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
