@@ -76,7 +76,15 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
     for (int j = 0; j < LK_K; ++j) k[j] = LK_KEY_EMPTY;
     const float ox = G->ox, oy = G->oy, oz = G->oz, inv = G->inv_cell;
     const int dx = G->dx, dy = G->dy, dz = G->dz;
-    const float r = sqrtf(r2) * 1.0001f + 1e-6f;       // box slightly inflated: never misses a cell
+    const float rfull = sqrtf(r2) * 1.0001f + 1e-6f;   // box slightly inflated: never misses a cell
+    // Radius well above the cell edge (the dynamic query radius of the TUM / ScanNet configs goes up to 0.16 over 0.08-m cells: 5 x 5 rows
+    // of cells, 125 cells): TWO PHASES, still exact.  Phase 1 scans the box of half-width b just under one cell edge - at most 3 x 3 rows,
+    // the fast path below - which holds every point within distance b of the query; if the list is full and its last entry is nearer
+    // than b, no point outside that box can enter it (its squared distance exceeds b^2 in one coordinate alone) and the search is over -
+    // the usual case next to a surface.  Otherwise phase 2 walks the rest of the full box (the cells phase 1 has seen are skipped).
+    const float cellf = G->cell;
+    const bool big = rfull > cellf * 1.05f;
+    const float r = big ? cellf * 0.9999f - 1e-6f : rfull;
     bool any = G->n > 0;
     // query box entirely outside the grid -> no neighbour
     any = any && !((qx + r - ox) * inv < 0.0f || (qx - r - ox) * inv >= (float)dx);
@@ -159,6 +167,51 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
     lk_knn_merge_round<0x4E>(k);
     lk_knn_merge_round<0x141>(k);
     if (T == 16) lk_knn_merge_round<0x140>(k);
+    if (big) {
+        // every lane of the group holds the same list here, so the decision is group-uniform
+        const float rho2 = r * r * (1.0f - 1e-6f);
+        const bool done = k[LK_K - 1] != LK_KEY_EMPTY && __uint_as_float((uint32_t)(k[LK_K - 1] >> 32)) <= rho2;
+        if (!done) {
+            if (sub != 0) {          // one copy of the phase-1 list survives: the merge below must not meet a candidate twice
+#pragma unroll
+                for (int j = 0; j < LK_K; ++j) k[j] = LK_KEY_EMPTY;
+            }
+            bool anyf = G->n > 0;
+            anyf = anyf && !((qx + rfull - ox) * inv < 0.0f || (qx - rfull - ox) * inv >= (float)dx);
+            anyf = anyf && !((qy + rfull - oy) * inv < 0.0f || (qy - rfull - oy) * inv >= (float)dy);
+            anyf = anyf && !((qz + rfull - oz) * inv < 0.0f || (qz - rfull - oz) * inv >= (float)dz);
+            if (anyf) {
+                const int fx0 = lk_cell_coord(qx - rfull, ox, inv, dx), fx1 = lk_cell_coord(qx + rfull, ox, inv, dx);
+                const int fy0 = lk_cell_coord(qy - rfull, oy, inv, dy), fy1 = lk_cell_coord(qy + rfull, oy, inv, dy);
+                const int fz0 = lk_cell_coord(qz - rfull, oz, inv, dz), fz1 = lk_cell_coord(qz + rfull, oz, inv, dz);
+                auto walk = [&](int row, int xa, int xb) {
+                    if (xa > xb) return;
+                    const int s = cell_start[row + xa];
+                    const int e = cell_start[row + xb + 1];
+#pragma unroll 1
+                    for (int t = s + sub; t < e; t += T) {
+                        const float4 p = sorted[t];
+                        const float d2 = lk_dist2(qx, qy, qz, p.x, p.y, p.z);
+                        lk_top8_offer(k, d2, r2, __float_as_int(p.w));
+                    }
+                };
+#pragma unroll 1
+                for (int iz = fz0; iz <= fz1; ++iz) {
+#pragma unroll 1
+                    for (int iy = fy0; iy <= fy1; ++iy) {
+                        const int row = (iz * dy + iy) * dx;
+                        const bool seen = any && iz >= iz0 && iz <= iz1 && iy >= iy0 && iy <= iy1;     // phase 1 scanned [ix0, ix1] of this row
+                        if (!seen) walk(row, fx0, fx1);
+                        else { walk(row, fx0, ix0 - 1); walk(row, ix1 + 1, fx1); }
+                    }
+                }
+            }
+            lk_knn_merge_round<0xB1>(k);
+            lk_knn_merge_round<0x4E>(k);
+            lk_knn_merge_round<0x141>(k);
+            if (T == 16) lk_knn_merge_round<0x140>(k);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < LK_K; ++j) { d[j] = __uint_as_float((uint32_t)(k[j] >> 32)); id[j] = (int)(uint32_t)k[j]; }
 }

@@ -87,6 +87,38 @@ def test_knn_edge_cases(backend):
 
 
 @pytest.mark.parametrize('backend', backends())
+def test_knn_two_phase_search_is_exact(backend):
+    """Radii above the cell edge (dynamic query radii up to 0.16 over 0.08-m cells) take the two-phase search of lk_knn_scan_coop:
+    the 3 x 3 x 3 cells first, the outer shell only where the list is not yet closed.  Dense sheets (phase 1 closes the list), sparse
+    clutter (phase 2 must run), points exactly ON the covered-radius sphere and beyond it, queries on cell boundaries, per-query
+    radii on both sides of the switch - indices, distances and counts bit for bit against the brute-force contract."""
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(11)
+    sheet = torch.cat([torch.rand(6000, 2, generator=gen) * 2 - 1, 0.002 * torch.randn(6000, 1, generator=gen)], 1)      # ~1500 points / m^2 at z = 0
+    clutter = torch.rand(400, 3, generator=gen) * 2 - 1                                                                  # sparse everywhere else
+    q0 = torch.tensor([[0.24, 0.16, 0.4]])                                                                              # a corner of the 0.08 grid lattice
+    ring = q0 + torch.nn.functional.normalize(torch.randn(40, 3, generator=gen), dim=1) * torch.linspace(0.075, 0.16, 40)[:, None]
+    pts = torch.cat([sheet, clutter, ring])
+    q = torch.cat([torch.cat([torch.rand(500, 2, generator=gen) * 1.8 - 0.9, 0.05 * torch.randn(500, 1, generator=gen)], 1),   # near the sheet
+                   torch.rand(500, 3, generator=gen) * 2 - 1,                                                               # anywhere
+                   q0, q0 + 1e-6, torch.tensor([[0.08, 0.08, 0.08], [-0.16, 0.0, 0.24]])])
+    knn = core.KnnIndex(eng, capacity=pts.shape[0], cell_size=0.08)
+    knn.build(eng.f32(pts))
+    # the grid's origin is the cloud's min corner: shift the lattice queries onto its cell boundaries
+    r_per = 0.04 + 0.26 * torch.rand(q.shape[0], generator=gen)
+    for r2 in ((r_per ** 2).float(), np.float32(0.16 ** 2), np.float32(0.0841 ** 2), np.float32(0.084 ** 2), np.float32(0.3 ** 2)):
+        per = torch.is_tensor(r2)
+        od, oi, oc = H.knn_exact(pts.numpy(), q.numpy(), 8, r2.numpy() if per else r2)
+        d2, idx, cnt = knn.query(eng.f32(q), eng.f32(r2) if per else float(r2))
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.array_equal(d2.cpu().numpy(), od)
+        assert np.array_equal(cnt.cpu().numpy(), oc)
+    # both outcomes occur: lists closed inside one cell edge, and lists that needed the shell
+    full_near = (od[:, 7] <= np.float32(0.0799 ** 2)).sum()
+    assert 100 < full_near < q.shape[0] - 100
+
+
+@pytest.mark.parametrize('backend', backends())
 def test_knn_append_equals_build(backend):
     """lk_knn_append (index.add of add_neural_points): appending in three pieces answers every query exactly as one build over
     the whole array - indices refer to the concatenated order."""
