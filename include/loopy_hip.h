@@ -107,9 +107,11 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
 #define LK_FLAG_MAPPER_LOSS   (1u << 10) /* lk_render_fwd also evaluates the mapper loss of the batch (Mapper.py:691-720, what
                                            * lk_loss_mapper computes) inside the composite kernel: reads loss_gt_color /
                                            * loss_w_color, writes d_depth, d_color and loss_out4 = [loss, geo, colour, #masked] */
-#define LK_FLAG_UNIT_LOSS_GRADS (1u << 11) /* lk_render_bwd: the caller guarantees |d_depth|, |d_color| <= ~1 (sum-type losses
-                                           * such as the mapper's L1 terms): the colour decoder's backward may then run its
-                                           * products on fp16 pieces with a fixed 2^10 pre-scale instead of bf16 pieces */
+#define LK_FLAG_UNIT_LOSS_GRADS (1u << 11) /* lk_render_bwd: the caller guarantees |d_color| <= ~1 (sum-type losses such as the mapper's
+                                           * and the tracker's L1 colour terms; without ray gradients also |d_depth| <= ~1): the colour
+                                           * decoder's backward may then run its products on fp16 pieces with a fixed 2^10 pre-scale
+                                           * instead of bf16 pieces.  d_depth reaches the geometry decoder only, whose backward ignores
+                                           * the flag */
 #define LK_FLAG_Z_GIVEN       (1u << 12) /* lk_render_fwd: rays with gt_depth <= 0 take their S sample depths from `z` as the caller filled
                                          * it (rendering.sample_near_pcl, Renderer.py:152-160) instead of linspace(near_end, far_bb) */
 #define LK_FLAG_FEATS_F16     (1u << 13) /* opt-in storage format: geo_feats / col_feats point at IEEE half tables [N,32] (64-byte rows; BASELINE

@@ -284,7 +284,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
             const float x = ((s_o[0][lane] + s_o[1][lane]) + s_o[2][lane]) + s_o[3][lane];
             const float y = ((s_o[0][32 + lane] + s_o[1][32 + lane]) + s_o[2][32 + lane]) + s_o[3][32 + lane];
             const float z = ((s_o[0][64 + lane] + s_o[1][64 + lane]) + s_o[2][64 + lane]) + s_o[3][64 + lane];
-            *reinterpret_cast<float4*>(a.dp_embed_col + (size_t)sp * 4) = make_float4(x, y, z, 0.0f);
+            *reinterpret_cast<float4*>(a.dp_embed_col + (size_t)sp * 4) = make_float4(x * ISC, y * ISC, z * ISC, 0.0f);      // d e was formed from the scaled d y
         }
     }
 }
@@ -437,8 +437,10 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_BWD, st);
     const int tiles = lk_cdiv(a.P, 32);
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
-    // fp16 pieces only for unit-scale loss gradients without ray gradients (mapper mode), see decode_bwd_col_wg
-    const bool h16 = (a.flags & LK_FLAG_UNIT_LOSS_GRADS) && !(a.flags & LK_FLAG_GRAD_RAYS);
+    // fp16 pieces only where the COLOUR loss gradients have unit scale (see decode_bwd_col_wg): the mapper's L1 sums, and the tracker's
+    // loss too - its d colour is w_color sgn(.), only its d depth = 1 / sqrt(var) is unbounded, and that reaches the geometry decoder
+    // alone (d raw[:, 3]), whose backward stays on bf16 pieces
+    const bool h16 = (a.flags & LK_FLAG_UNIT_LOSS_GRADS) != 0;
     const bool deep = n_col > 0 && n_col <= LK_DEEP_MAX_TILES;
     const dim3 grid(n_col + lk_cdiv(tiles, 4));
     if (h16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true>), grid, dim3(256), 0, st, a, n_col);

@@ -307,6 +307,9 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     lk_render_desc rd = d->render;
     rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_FEATS_F16)) | LK_FLAG_STAGE_COLOR | LK_FLAG_TRACKER | LK_FLAG_SAVE_ACT | LK_FLAG_GRAD_RAYS | LK_FLAG_ZERO_ABSENT;
+    // the tracker's colour loss gradient is w_color sgn(.) (Tracker.py:183-191): unit scale, so the colour decoder's backward may run on
+    // pre-scaled fp16 pieces; NOT with exposure encoding - there d out passes through the learned 3 x 3 affine first
+    if (d->exposure == nullptr && fabsf(d->w_color) <= 4.0f) rd.flags |= LK_FLAG_UNIT_LOSS_GRADS;
     rd.stats_chunk = rd.R > 0 ? rd.R : 1;
     rd.g_geo_feats = nullptr; rd.g_col_feats = nullptr; rd.g_weights = nullptr;
     // exposure encoding (decoder.py:534-540, Tracker.py:329-344): the frame's affine inside the colour decoder, its gradient from the

@@ -147,12 +147,15 @@ def test_mapper_iteration_vs_oracle_at_bench_size(model, R, stage, unit):
     assert n >= (1 if stage == 'geometry' else (27 if rel else 22))
 
 
+@pytest.mark.parametrize('unit', (False, True))
 @pytest.mark.parametrize('model,R', (('replica', 1500), ('tum', 5000)))
-def test_tracker_iteration_vs_oracle_at_bench_size(model, R):
+def test_tracker_iteration_vs_oracle_at_bench_size(model, R, unit):
     """One tracking iteration (Tracker.py:142-195): rays of the pose, render in tracker mode, uncertainty-normalised loss,
-    gradient back to the 7-vector pose."""
+    gradient back to the 7-vector pose.  unit: LK_FLAG_UNIT_LOSS_GRADS as lk_track_frame sets it - the tracker's colour loss gradient is
+    w_color sgn(.), so the colour decoder's backward (ray-gradient products included) runs on pre-scaled fp16 pieces; d depth = 1 / sqrt(var)
+    is NOT unit scale and must not matter: it only reaches the geometry decoder."""
     rel = model == 'replica'
-    case = f'track-{model}-R{R}'
+    case = f'track-{model}-R{R}' + ('-unit' if unit else '')
     eng = make_engine('hip')
     (pos, geo, col, W), (dpos, dgeo, dcol, knn, dec) = _gpu_scene(eng, 100_000, rel)
     b = A.ray_batch(R, frame=5, holes=0.0, seed=2, window=(100, I_H() - 100, 100, I_W() - 100))
@@ -164,7 +167,7 @@ def test_tracker_iteration_vs_oracle_at_bench_size(model, R):
     optim.rays_from_pose(eng, dcam, pi, pj, A.INTR, ro, rd)
     gd, gc = eng.f32(b['gt_depth']), eng.f32(b['gt_color'])
     core.render_forward(eng, cfg, st, ro, rd, gd, knn, dpos, dgeo, dcol, dec, 'color', tracker=True, save_act=True,
-                        extra_flags=_ffi.FLAG_ZERO_ABSENT)
+                        extra_flags=_ffi.FLAG_ZERO_ABSENT | (_ffi.FLAG_UNIT_LOSS_GRADS if unit else 0))
     d_depth, d_color, out4 = eng.empty(R), eng.empty(R, 3), eng.zeros(4)
     optim.loss_tracker(eng, st, gd, gc, 0.5, True, d_depth, d_color, out4, eng.empty(R + 8))
     torch.cuda.synchronize()
