@@ -322,6 +322,10 @@ typedef struct {
     float lr_mlp;               /* Adam rate of the four MLP tensors (tracker 1e-3; mapper: decoders_lr of stage 'color'); < 0: frozen */
     float lr_feat;              /* Adam rate of the trainable features (1e-3) */
     int32_t feat_first, feat_count;      /* features [feat_first, feat_first + feat_count) are Adam parameters (mapper: only the last) */
+    float* bwd_scale;           /* [1] or NULL.  With it the colour decoder's backward and the weight-gradient reductions of the loops run on
+                                   pre-scaled fp16 pieces as under LK_FLAG_UNIT_LOSS_GRADS although the loss gradient passes through the
+                                   LEARNED affines: every forward of the MLP stores here the power of two that maps 3 max|A| into (0.5, 1]
+                                   - the bound of |d out| relative to the plain colour loss - and the kernels apply it on top of their 2^10 */
 } lk_exposure_desc;
 
 /* ---------------------------------------------------------------- per-frame optimisation loops

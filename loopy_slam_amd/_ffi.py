@@ -82,7 +82,7 @@ class ExposureDesc(C.Structure):
     """lk_exposure_desc (include/loopy_hip.h)."""
     _fields_ = [('feats', _fp), ('W1', _fp), ('b1', _fp), ('W2', _fp), ('b2', _fp), ('F', C.c_int32),
                 ('aff', _fp), ('hid', _fp), ('g_aff', _fp), ('g', _fp), ('adam', _fp),
-                ('lr_mlp', C.c_float), ('lr_feat', C.c_float), ('feat_first', C.c_int32), ('feat_count', C.c_int32)]
+                ('lr_mlp', C.c_float), ('lr_feat', C.c_float), ('feat_first', C.c_int32), ('feat_count', C.c_int32), ('bwd_scale', _fp)]
 
 
 class TrackDesc(C.Structure):

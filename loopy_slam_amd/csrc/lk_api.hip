@@ -379,6 +379,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dy_col = S0 + L.dy_col; db.dlogit = S0 + L.dlogit;
     db.dp_embed = S0 + L.dp_embed; db.dp_embed_col = S0 + L.dp_embed_col; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.part_bg = S0 + L.part_bg;
     db.live_rays = ex ? ex->live_rays : nullptr;
+    db.dscale = ex ? ex->dscale : nullptr;
     lk_launch_decode_bwd(db, st);
     // mapper 'color' backward with one weight-gradient launch: every partial-sum reduction is deferred to ONE launch at the end
     const bool defer = gw && color && (!relpos || lk_relpos_fused(flags));
@@ -436,7 +437,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         }
         wa.n_jobs = nj; wa.chunk = 0; wa.part = S0 + L.wg_part;
         wa.h16 = (flags & LK_FLAG_UNIT_LOSS_GRADS) && !gr ? 1 : 0;
-        wa.live_rays = ex ? ex->live_rays : nullptr; wa.S = d->S;
+        wa.live_rays = ex ? ex->live_rays : nullptr; wa.S = d->S; wa.dscale = ex ? ex->dscale : nullptr;
         lk_launch_wgrad(wa, P, wst, defer ? &wdef : nullptr);
     }
 

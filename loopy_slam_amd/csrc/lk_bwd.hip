@@ -95,7 +95,9 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     typedef BwdPiece<H16> PC;
     typedef typename PC::T Piece;
     constexpr int NP = PC::NP;
-    constexpr float SC = H16 ? 1024.0f : 1.0f, ISC = H16 ? 1.0f / 1024.0f : 1.0f;
+    // (a.dscale: a power of two from the device, exact in both directions)
+    const float ds = (H16 && a.dscale) ? *a.dscale : 1.0f;
+    const float SC = H16 ? 1024.0f * ds : 1.0f, ISC = H16 ? (1.0f / 1024.0f) / ds : 1.0f;
     const BwdSample d = bwd_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
     const bool live = d.live;

@@ -917,7 +917,7 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
 // VALU work either.  The tile is scaled back when it is stored.
 template <int NV, int KV, int MODE, bool H16>
 __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane,
-                                           float* __restrict__ tile, int rows, bool aux_t = false) {
+                                           float* __restrict__ tile, int rows, bool aux_t = false, float dsc = 1.0f) {
     const int i = lane & 31, h = lane >> 5;
     // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
     const int ncol = n0 + NV * i, kcol = k0 + KV * i;
@@ -964,7 +964,7 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
     // flight behind the MFMAs.  Refills past the end re-read the last row (clamped address) and are masked when consumed.
 #pragma unroll
     for (int s = 0; s < WG_STEPS; ++s) { fetch1(s, 0); __builtin_amdgcn_sched_barrier(0); }    // issue in slot order
-    constexpr float SCALE = H16 ? 1024.0f : 1.0f, ISCALE = H16 ? 1.0f / 1024.0f : 1.0f;
+    const float SCALE = H16 ? 1024.0f * dsc : 1.0f, ISCALE = H16 ? (1.0f / 1024.0f) / dsc : 1.0f;       // dsc: LkWgradArgs::dscale, a power of two
     for (int n = 0; n < my_chunks; ++n) {
         const int row0 = (c0 + n * stride) * WG_CHUNK;
         if (H16) {
@@ -1072,14 +1072,14 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 }
 
 template <int NV, int KV, bool H16>
-__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile, int rows) {
+__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile, int rows, float dsc) {
     const bool aux_t = J.k_aux > 0 && k0 >= J.k_aux;
 #ifdef LK_PROBE_WG_MODE0        // timing probe (tools/ab_build.sh): only the plain form, so that a deeper ring fits the register file
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t);
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
 #else
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t);
-    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t);
-    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t);
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
+    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
 #endif
 }
 
@@ -1105,11 +1105,12 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     float* tile = a.part ? a.part + ((size_t)8 * U.wave0 + 8 * jl + x) * LK_WG_TILE : nullptr;
     // rows behind the live prefix of a partitioned batch were not written by their producers (k_decode_bwd skips those tiles)
     const int rows = a.live_rays ? min(J.rows, lk_uniform(*a.live_rays) * a.S) : J.rows;
+    const float dsc = (H16 && a.dscale) ? *a.dscale : 1.0f;
     if (!tile && c0 >= (rows + WG_CHUNK - 1) / WG_CHUNK) return;
-    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows);
-    else if (U.nv == 2) wgrad_unit_mode<2, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows);
-    else if (U.kv == 2) wgrad_unit_mode<1, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows);
-    else wgrad_unit_mode<1, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows);
+    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc);
+    else if (U.nv == 2) wgrad_unit_mode<2, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc);
+    else if (U.kv == 2) wgrad_unit_mode<1, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc);
+    else wgrad_unit_mode<1, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc);
 }
 
 // dW += sum over the unit's waves of the partial tiles (tile order: contiguous reads; every output element is owned by

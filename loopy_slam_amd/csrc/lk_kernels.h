@@ -97,6 +97,8 @@ struct LkDecodeBwdArgs {
     float* g_weights; float* g_affine;
     float* part_bg;                                // [n_blocks][288] per-workgroup partial sums of d embedder._B (GRAD_WEIGHTS)
     const int32_t* live_rays;                      // as LkDecodeArgs
+    const float* dscale;                           // [1] device-side power of two on top of the fp16-piece form's 2^10 pre-scale (exposure encoding:
+                                                   // the loss gradient is scaled by a LEARNED affine, lk_exposure_desc::bwd_scale), or NULL = 1
 };
 
 struct LkTrackFinalArgs {
@@ -145,7 +147,7 @@ struct LkStepRider {
     AdamSegDev feat[2]; int n_feat, feat_gx;       // feature-row segments: n_feat * feat_gx extra blocks
 };
 struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
-                    int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
+                    int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
@@ -242,6 +244,7 @@ struct LkWgradArgs {
     int h16;                                       // products on scaled fp16 pieces (unit-scale loss gradients only)
     LkFcPost fc[5]; int n_fc;                      // fc_c gradients finished from the auxiliary columns (needs `part`)
     const int32_t* live_rays; int S;               // rows >= *live_rays * S of every job are not read (their producers skipped them), or NULL
+    const float* dscale;                           // as LkDecodeBwdArgs (h16 only)
 };
 static_assert(sizeof(LkWgradArgs) <= 3600, "LkWgradArgs travels as a kernel argument next to LkBwdReduceArgs (4 KB limit)");
 #define LK_WG_MAX_WAVES 2048                       // waves of one weight-gradient launch: two per SIMD, all co-resident

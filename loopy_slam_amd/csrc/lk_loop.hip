@@ -308,8 +308,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     lk_render_desc rd = d->render;
     rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_FEATS_F16)) | LK_FLAG_STAGE_COLOR | LK_FLAG_TRACKER | LK_FLAG_SAVE_ACT | LK_FLAG_GRAD_RAYS | LK_FLAG_ZERO_ABSENT;
     // the tracker's colour loss gradient is w_color sgn(.) (Tracker.py:183-191): unit scale, so the colour decoder's backward may run on
-    // pre-scaled fp16 pieces; NOT with exposure encoding - there d out passes through the learned 3 x 3 affine first
-    if (d->exposure == nullptr && fabsf(d->w_color) <= 4.0f) rd.flags |= LK_FLAG_UNIT_LOSS_GRADS;
+    // pre-scaled fp16 pieces (LK_FLAG_UNIT_LOSS_GRADS is added below, once `fused` is known)
     rd.stats_chunk = rd.R > 0 ? rd.R : 1;
     rd.g_geo_feats = nullptr; rd.g_col_feats = nullptr; rd.g_weights = nullptr;
     // exposure encoding (decoder.py:534-540, Tracker.py:329-344): the frame's affine inside the colour decoder, its gradient from the
@@ -319,6 +318,9 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     if (xd) { rd.affine = xd->aff; rd.g_affine = xd->g_aff; }
     const int R = rd.R, S = rd.S, iters = d->iters;
     const bool fused = R <= LK_TRACK_FUSED_MAX_R && d->work != nullptr;
+    // (with exposure encoding d out passes through the learned affine first: unit scale only relative to xd->bwd_scale, which the fused
+    // sequence hands to the kernels)
+    if ((xd == nullptr || (xd->bwd_scale && fused)) && fabsf(d->w_color) <= 4.0f) rd.flags |= LK_FLAG_UNIT_LOSS_GRADS;
     if (!fused) LK_REQUIRE(d->gt_color && d->pix_i && d->pix_j && d->thr && d->scratch_u32 && d->loss_scratch && d->render.g_rays_o && d->render.g_rays_d,
                            "lk_track_frame: without `work` (or above 8192 rays) the per-iteration batch buffers and g_rays_o/g_rays_d are needed");
     const LkBwdOffsets off = lk_bwd_offsets((int64_t)R * S, rd.flags);
@@ -391,6 +393,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         LkBwdExtra ex;
         memset(&ex, 0, sizeof(ex));
         ex.pose_part = fused ? W0 + wk.pose_part : nullptr;
+        ex.dscale = (xd && (rd.flags & LK_FLAG_UNIT_LOSS_GRADS)) ? xd->bwd_scale : nullptr;
         ex.pix_i = W0 ? W0 + wk.pix_i + (size_t)it * R : nullptr; ex.pix_j = W0 ? W0 + wk.pix_j + (size_t)it * R : nullptr;
         ex.fx = d->fx; ex.fy = d->fy; ex.cx = d->cx; ex.cy = d->cy;
         rc = lk_render_bwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE_BWD | LK_SKIP_RAYS_BWD | LK_FUSE_SMALL) : 0, fused ? &ex : nullptr);
@@ -564,7 +567,11 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         const bool xit = xd != nullptr && color;            // this iteration's loss is the exposure variant (its own launch after the composite)
         rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_UNIT_LOSS_GRADS | LK_FLAG_FEATS_F16)) | (color ? LK_FLAG_STAGE_COLOR : 0) | LK_FLAG_SAVE_ACT |
                    LK_FLAG_GRAD_FEATS | LK_FLAG_GRAD_WEIGHTS | LK_FLAG_ZERO_ABSENT | LK_FLAG_MAPPER_LOSS;
-        if (xd) rd.flags &= ~LK_FLAG_UNIT_LOSS_GRADS;        // d logits = w sigma' A with a learned A: nothing bounds it (both stages: one scratch layout)
+        // d logits = w sigma' A with a LEARNED A: unit scale only relative to the power of two the exposure step keeps in xd->bwd_scale (the
+        // kernels apply it on top of their 2^10); without that cell, or with the rel-pos MLP (its fused backward has no such hook): bf16 pieces
+        const bool x_unit = xd && xd->bwd_scale && !(d->render.flags & LK_FLAG_REL_POS);
+        if (xd && !x_unit) rd.flags &= ~LK_FLAG_UNIT_LOSS_GRADS;
+        if (x_unit) rd.flags |= LK_FLAG_UNIT_LOSS_GRADS;
         if (xit) rd.flags = (rd.flags & ~LK_FLAG_MAPPER_LOSS) | LK_FLAG_COLOR_LOGITS;
         rd.stats_chunk = R;
         rd.loss_gt_color = d->gt_color; rd.loss_w_color = d->w_color; rd.loss_out4 = d->log + (size_t)it * 4;
@@ -624,6 +631,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 ex.seg_total = reinterpret_cast<int32_t*>(W0 + wk.seg_total) + it;
             }
             ex.live_rays = live;
+            ex.dscale = (xd && (rd.flags & LK_FLAG_UNIT_LOSS_GRADS)) ? xd->bwd_scale : nullptr;
             LkStepRider sr;
             if (use_rider) {
                 lk_adam_seg seg[LK_ADAM_MAX_SEG];

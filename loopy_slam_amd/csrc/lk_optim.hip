@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_loss_mapper_exposure(int R, const float
 // values (k_exposure_fwd) for the next iteration, g_aff cleared.  mode bit 0: backward + step, bit 1: forward (+ clear).
 struct ExposureStepArgs {
     float* feats; float* W1; float* b1; float* W2; float* b2; int F;
-    float* aff; float* hid; float* g_aff; float* g; float* m; float* v;
+    float* aff; float* hid; float* g_aff; float* g; float* m; float* v; float* bwd_scale;
     float step_mlp, step_feat, bc2_sqrt, beta1, beta2, eps;      // lr / bias_correction1 per group (step_mlp < 0: frozen), sqrt(bias_correction2)
     int feat_first, feat_count, mode;
 };
@@ -586,6 +586,8 @@ __global__ __launch_bounds__(256) void k_exposure_step(ExposureStepArgs a) {
         __syncthreads();
     }
     if (a.mode & 2) {
+        __shared__ unsigned s_amax;
+        if (t == 0) s_amax = 0u;
         float* s_h = s_dp;
         for (int e = t; e < F * 128; e += 256) {
             const int f = e >> 7, u = e & 127;
@@ -603,6 +605,18 @@ __global__ __launch_bounds__(256) void k_exposure_step(ExposureStepArgs a) {
             for (int u = 0; u < 128; ++u) acc = fmaf(a.W2[o * 128 + u], s_h[f * 128 + u], acc);
             a.aff[e] = acc;
             a.g_aff[e] = 0.0f;
+            if (o < 9 && a.bwd_scale) atomicMax(&s_amax, __float_as_uint(fabsf(acc)));       // the 3 x 3 part (positive floats order like their bits)
+        }
+        if (a.bwd_scale) {
+            __syncthreads();
+            if (t == 0) {
+                // |d out| <= (0.25 w_color) x (row / column sum of |A|) <= (0.25 w_color) x 3 max|A|: the power of two that brings 3 max|A| into (0.5, 1]
+                const float bound = 3.0f * __uint_as_float(s_amax);
+                int ex = 0;
+                if (bound > 0.0f && bound < 3.0e38f) { (void)frexpf(bound, &ex); }       // bound = m 2^ex, m in [0.5, 1)
+                ex = ex > 40 ? 40 : (ex < -40 ? -40 : ex);
+                *a.bwd_scale = ldexpf(1.0f, -ex);
+            }
         }
     }
 }
@@ -613,7 +627,7 @@ int lk_launch_exposure_step(const lk_exposure_desc& x, int mode, int step, float
     LK_REQUIRE(x.feat_first >= 0 && x.feat_count >= 0 && x.feat_first + x.feat_count <= x.F, "exposure: bad trainable feature range");
     ExposureStepArgs a;
     a.feats = x.feats; a.W1 = x.W1; a.b1 = x.b1; a.W2 = x.W2; a.b2 = x.b2; a.F = x.F;
-    a.aff = x.aff; a.hid = x.hid; a.g_aff = x.g_aff; a.g = x.g; a.m = x.adam; a.v = x.adam + LK_EXPOSURE_GRAD_FLOATS;
+    a.aff = x.aff; a.hid = x.hid; a.g_aff = x.g_aff; a.g = x.g; a.m = x.adam; a.v = x.adam + LK_EXPOSURE_GRAD_FLOATS; a.bwd_scale = x.bwd_scale;
     const int s1 = step < 1 ? 1 : step;
     const double bc1 = 1.0 - pow((double)beta1, (double)s1), bc2 = 1.0 - pow((double)beta2, (double)s1);
     a.step_mlp = x.lr_mlp < 0.0f ? -1.0f : (float)((double)x.lr_mlp / bc1);

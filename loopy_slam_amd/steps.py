@@ -86,6 +86,8 @@ class ExposureState:
         d.lr_mlp = -1.0 if lr_mlp is None else float(lr_mlp)
         d.lr_feat = self.LR if lr_feat is None else float(lr_feat)
         d.feat_first, d.feat_count = (self.F - 1, 1) if only_last_feature else (0, self.F)
+        self.bwd_scale = self.eng.zeros(1) + 1.0         # kept current by every forward of the MLP inside the loops
+        d.bwd_scale = ptr(self.bwd_scale)
         self._desc = d
         return d
 

@@ -315,3 +315,57 @@ def test_forward_with_half_tables_at_5m_points():
         o = H.render_batch(_ocfg(dict(m, exposure=False)), b['rays_o'][keep], b['rays_d'][keep], b['gt_depth'][keep], pos, geo_h.float(), col_h.float(),
                            W, 'color', r2_ray=b['r2'][keep], knn=kn)
     _fwd_check(st, o, keep, case)
+
+
+def test_scannet_loops_fp16_pieces_with_device_scale_match_bf16_statement_path():
+    """Exposure encoding inside the native loops runs the colour decoder's backward and the weight-gradient reductions on pre-scaled fp16
+    pieces although the loss gradient passes through the LEARNED affines: the exposure step keeps a power of two on the device
+    (lk_exposure_desc::bwd_scale) that the kernels apply on top of their 2^10.  At 10 000 rays over four keyframes: three colour
+    iterations of lk_map_frame against the per-statement path (bf16 pieces, no scale) from the same start - losses, the exposure
+    feature and the decoder after the steps - with affines scaled to 0.05x and 30x of their start so that the scale cell matters."""
+    m = MODELS['scannet']
+    R, F, iters = 10_000, 4, 3
+    eng = make_engine('hip')
+    pos, geo, col = A.scene(100_000)
+    W0 = syn.default_weights(rel_pos=False, exposure=True)
+    lrs = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
+    dpos = eng.f32(pos)
+    knn = core.KnnIndex(eng, capacity=pos.shape[0]); knn.build(dpos)
+    frames_cpu = [syn.render_frame(k, device='cpu', holes=0.02) for k in (3, 7, 12, 18)]
+    stack = (eng.f32(torch.stack([f[0] for f in frames_cpu])), eng.f32(torch.stack([f[1] for f in frames_cpu])),
+             eng.f32(torch.stack([f[2] for f in frames_cpu])),
+             torch.stack([optim.radius_maps(eng, eng.f32(f[1]), 0.15, 0.08, 0.02, 2.0)[2] for f in frames_cpu]).contiguous())
+    gen = torch.Generator().manual_seed(77)
+    rnd = torch.randint(0, A.I['H'] * A.I['W'], (iters, R), generator=gen, dtype=torch.int32).to(eng.device)
+    fid = (torch.arange(R) * F // R).to(torch.int32).to(eng.device)
+    rows = torch.arange(0, pos.shape[0], 2, dtype=torch.int32).to(eng.device)
+    cfg = core.RenderCfg(rel_pos=False, near_surface=m['near'], far_surface=m['far'], exposure=True)
+    feats0 = [0.3 * torch.randn(8, generator=gen) for _ in range(F)]
+    for gain in (0.05, 30.0):
+        W = {k: v.clone() for k, v in W0.items()}
+        W['color_decoder.mlp_exposure.linear2.bias'] = W['color_decoder.mlp_exposure.linear2.bias'] * gain
+        W['color_decoder.mlp_exposure.linear2.weight'] = W['color_decoder.mlp_exposure.linear2.weight'] * gain
+        res = {}
+        for native in (True, False):
+            dec = core.DecoderBlob(eng).pack(W)
+            dgeo, dcol = eng.f32(geo).clone(), eng.f32(col).clone()
+            mlp = _exposure_module(W).to(eng.device)
+            fk = [eng.f32(f).clone().requires_grad_(True) for f in feats0]
+            mo = steps.MapOptimizer(eng, cfg, dec, knn, dpos, dgeo, dcol, rows, R, lrs, w_color=0.1, dynamic_radius=True, exposure=(mlp, fk))
+            mo.native_loop = native
+            mo.begin_frame()
+            log = eng.zeros(iters, 4)
+            mo.run(iters, 0, stack, rnd, fid, (0, A.I['H'], 0, A.I['W']), A.INTR, A.I['H'], A.I['W'], log)
+            mo.finish()
+            torch.cuda.synchronize()
+            if native:
+                scale = float(mo.exposure.bwd_scale.cpu())
+                assert scale != 1.0 and abs(np.log2(scale) - round(np.log2(scale))) < 1e-6, scale        # a power of two that moved
+            res[native] = (log[:, 0].cpu().numpy().copy(), fk[-1].detach().cpu().clone(), dec.blob.cpu().clone(), mlp[2].bias.detach().cpu().clone())
+        ln, ls = res[True][0], res[False][0]
+        _record(f'scannet-loops-fp16-scale-gain{gain}', loss_rel=float(np.abs(ln - ls).max() / np.abs(ls).max()), bwd_scale=scale)
+        np.testing.assert_allclose(ln, ls, rtol=2e-5)
+        np.testing.assert_allclose(res[True][1].numpy(), res[False][1].numpy(), atol=2e-5)                  # the current frame's exposure feature
+        np.testing.assert_allclose(res[True][3].numpy(), res[False][3].numpy(), atol=2e-4 * max(1.0, gain))
+        d = (res[True][2] - res[False][2]).abs()
+        assert float(torch.quantile(d, 0.999)) < 2e-5 and float(d.max()) < 2 * 0.005 * iters + 1e-6        # Adam's sign-like first steps bound the tail
