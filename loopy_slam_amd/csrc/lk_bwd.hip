@@ -291,9 +291,55 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     }
 }
 
+// Embedding gradient of the geometry decoder, d e = W_3[:, embedding]^T d y_3 + W_0^T d y_0, one 32-unit block at a time (one accumulator
+// tile alive; the loop is not unrolled - three copies of the 48 cosines and 144 reductions are code nobody needs):
+// e_u = sin(x_u): ge_u = de_u cos(x_u);  WW: dB[i][u] += sum_s ge_u a_i(s) (-> part);  WP: dp_i += ge_u 2 pi B[i][u]
+template <bool WP, bool WW>
+__device__ __forceinline__ void geo_embed_bwd(const u32x4* __restrict__ FB, const float* __restrict__ B, const u32x4* __restrict__ park,
+                                              const LkB8 (&y0)[2], float a0, float a1, float a2, float& dpx, float& dpy, float& dpz,
+                                              float* __restrict__ part, int lane) {
+    const int h = lane >> 5;
+#pragma unroll 1
+    for (int tile = 0; tile < 3; ++tile) {
+        f32x16 de = lk_zero16();
+#pragma unroll
+        for (int G = 0; G < 2; ++G) {
+            LkB8 b;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b.p[q] = park[(G * 3 + q) * 64 + lane];
+            de = lk_mma6(lk_fragb_load(FB + FM3_TRB, 4, G, tile, lane), b, de);
+        }
+#pragma unroll
+        for (int G = 0; G < 2; ++G) de = lk_mma6(lk_fragb_load(FB + FM0_TRB, 3, G, tile, lane), y0[G], de);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int u0 = 32 * tile + 8 * g + 4 * h;
+            const float4 b0 = *reinterpret_cast<const float4*>(B + u0);
+            const float4 b1 = *reinterpret_cast<const float4*>(B + EGP + u0);
+            const float4 b2 = *reinterpret_cast<const float4*>(B + 2 * EGP + u0);
+            const float bb0[4] = {b0.x, b0.y, b0.z, b0.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w}, bb2[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int u = u0 + t;
+                float ge = de[4 * g + t] * lk_cosf(lk_fourier_arg(a0, a1, a2, bb0[t], bb1[t], bb2[t]));
+                if (u >= EG) ge = 0.0f;                      // padding units of the last block
+                if (WP) {
+                    const float gx = ge * LK_TWO_PI;
+                    dpx = fmaf(gx, bb0[t], dpx); dpy = fmaf(gx, bb1[t], dpy); dpz = fmaf(gx, bb2[t], dpz);
+                }
+                if (WW) {
+                    const float s0 = lk_half_wave_sum(ge * a0), s1 = lk_half_wave_sum(ge * a1), s2 = lk_half_wave_sum(ge * a2);
+                    if ((lane & 31) == LK_HWS_LANE) { part[u] = s0; part[EGP + u] = s1; part[2 * EGP + u] = s2; }
+                }
+            }
+        }
+    }
+}
+
 // ================= geometry decoder backward: one wave = one 32-sample tile =================
 // part = this wave's [3][96] slice of the workgroup's d B_g partial sums (LDS)
-__device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, int tile, float* __restrict__ part) {
+// park = this wave's 6 x 64 u32x4 of LDS for the pieces of d y_3
+__device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, int tile, float* __restrict__ part, u32x4* __restrict__ park) {
     const int lane = lk_lane();
     const BwdSample d = bwd_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
@@ -310,13 +356,13 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
     // ================= geometry decoder =================
     {
         const float docc = draw.w;
-        f32x16 dh, dy, dcg[1], de[3], acc1[1], acc4[4];
+        f32x16 dh, dy, dcg[1], acc1[1];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 wo = *reinterpret_cast<const float4*>(W + G_WO + 8 * g + 4 * h);
             dh[4 * g] = wo.x * docc; dh[4 * g + 1] = wo.y * docc; dh[4 * g + 2] = wo.z * docc; dh[4 * g + 3] = wo.w * docc;
         }
-        dcg[0] = lk_zero16(); de[0] = lk_zero16(); de[1] = lk_zero16(); de[2] = lk_zero16();
+        dcg[0] = lk_zero16();
 #pragma unroll
         for (int i = 4; i >= 0; --i) {
             const u32x4* Utr = FB + (i == 0 ? FM5_TRB : i == 1 ? FM6_TRB : i == 2 ? FM7_TRB : i == 3 ? FM8_TRB : FM9_TRB);
@@ -329,42 +375,32 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
                 lk_gemm_b6<1, 2>(acc1, FB + (i == 4 ? FM4_TRB : i == 2 ? FM2_TRB : FM1_TRB), 1, 0, 0, dy, 0, lane);
                 dh = acc1[0];
             } else if (i == 3) {
+                // layer 3 reads [embedding | h_2]: only the h_2 block of W_3^T d y_3 is needed now.  The three embedding blocks are
+                // formed at the end, in front of layer 0's (same products in the same order - bit-identical), from the pieces of d y_3
+                // parked in LDS: three accumulator tiles less are alive through layers 2..0, which is what lets the kernel run at
+                // three waves per SIMD
+                acc1[0] = lk_zero16();
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) acc4[kb] = lk_zero16();
-                lk_gemm_b6<4, 2>(acc4, FB + FM3_TRB, 4, 0, 0, dy, 0, lane);
-                de[0] = acc4[0]; de[1] = acc4[1]; de[2] = acc4[2];
-                dh = acc4[3];
-            } else {
-                lk_gemm_b6<3, 2>(de, FB + FM0_TRB, 3, 0, 0, dy, 0, lane);
+                for (int G = 0; G < 2; ++G) {
+                    const LkB8 b = lk_split_ct(dy, G);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) park[(G * 3 + q) * 64 + lane] = b.p[q];
+                    acc1[0] = lk_mma6(lk_fragb_load(FB + FM3_TRB, 4, G, 3, lane), b, acc1[0]);
+                }
+                dh = acc1[0];
             }
+            // i == 0: only the embedding receives gradient (below)
+            __builtin_amdgcn_sched_barrier(0);      // keeps the fragment loads of the layers below from being hoisted to the top (registers)
         }
         ct_store32(a.dc_geo + (size_t)sp * LK_C, dcg[0], live, lane);
+        // Embedding gradient d e = W_3[:, embedding]^T d y_3 + W_0^T d y_0, one 32-unit block at a time (one accumulator tile alive):
         // e_u = sin(x_u): ge_u = de_u cos(x_u);  dB[i][u] += sum_s ge_u a_i(s);  dp_i += ge_u 2 pi B[i][u]
-        const float* B = W + G_EB;
-#pragma unroll
-        for (int tile = 0; tile < 3; ++tile)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int u0 = 32 * tile + 8 * g + 4 * h;
-                const float4 b0 = *reinterpret_cast<const float4*>(B + u0);
-                const float4 b1 = *reinterpret_cast<const float4*>(B + EGP + u0);
-                const float4 b2 = *reinterpret_cast<const float4*>(B + 2 * EGP + u0);
-                const float bb0[4] = {b0.x, b0.y, b0.z, b0.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w}, bb2[4] = {b2.x, b2.y, b2.z, b2.w};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int u = u0 + t;
-                    float ge = 0.0f;
-                    if (u < EG) ge = de[tile][4 * g + t] * lk_cosf(lk_fourier_arg(a0, a1, a2, bb0[t], bb1[t], bb2[t]));
-                    if (want_p) {
-                        const float gx = ge * LK_TWO_PI;
-                        dpx = fmaf(gx, bb0[t], dpx); dpy = fmaf(gx, bb1[t], dpy); dpz = fmaf(gx, bb2[t], dpz);
-                    }
-                    if (want_w) {
-                        const float s0 = lk_half_wave_sum(ge * a0), s1 = lk_half_wave_sum(ge * a1), s2 = lk_half_wave_sum(ge * a2);
-                        if ((lane & 31) == LK_HWS_LANE) { part[u] = s0; part[EGP + u] = s1; part[2 * EGP + u] = s2; }
-                    }
-                }
-            }
+        const LkB8 y0[2] = {lk_split_ct(dy, 0), lk_split_ct(dy, 1)};
+        // (the flags select the form once, outside the loop: with `if (want_p)` per value the compiler sinks the whole d p chain - and with it
+        // all 48 ge values and the 144 entries of B they need - to the end of the kernel: 216 registers instead of ~130)
+        if (want_p && !want_w) geo_embed_bwd<true, false>(FB, W + G_EB, park, y0, a0, a1, a2, dpx, dpy, dpz, part, lane);
+        else if (want_w && !want_p) geo_embed_bwd<false, true>(FB, W + G_EB, park, y0, a0, a1, a2, dpx, dpy, dpz, part, lane);
+        else geo_embed_bwd<true, true>(FB, W + G_EB, park, y0, a0, a1, a2, dpx, dpy, dpz, part, lane);
     }
     if (want_p) {
         dpx += __shfl_xor(dpx, 32); dpy += __shfl_xor(dpy, 32); dpz += __shfl_xor(dpz, 32);
@@ -375,7 +411,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
 // Hot-address atomics are the slowest thing this chip does (a few hundred distinct addresses hit by every
 // wave serialise in the memory-side atomic unit): the embedding-matrix gradient is therefore reduced
 // wave -> LDS -> one partial row per workgroup, and summed by k_reduce_partials.
-// Block roles as in k_decode_fwd: the first n_col_blocks workgroups are colour tiles, the rest geometry (4 tiles each).
+// Block roles as in k_decode_fwd: n_col_blocks colour tiles and the geometry workgroups (4 tiles each), geometry first in the grid.
 #ifndef LK_DBWD_MINB
 #define LK_DBWD_MINB 2
 #endif
@@ -385,20 +421,24 @@ __global__ __launch_bounds__(256, LK_DBWD_MINB) void k_decode_bwd(LkDecodeBwdArg
     __shared__ float s_o[4][3 * 32];
     const int w = (int)threadIdx.x >> 6;
     const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;       // as k_decode_fwd
-    if ((int)blockIdx.x < n_col_blocks) {
-        if ((int)blockIdx.x * 32 >= P_live) return;
-        decode_bwd_col_wg<H16, DEEP>(a, blockIdx.x, w, lk_lane(), s_x, s_o);
+    // geometry workgroups FIRST in the grid: a geometry tile is one wave's 20-us chain - dispatched behind the colour tiles (as in rounds 1-2)
+    // those chains were the launch's tail on a nearly empty chip; in front they run beside the colour tiles (5 000 rays: 60 -> 55 us)
+    const int n_geo_blocks = (int)gridDim.x - n_col_blocks;
+    const int bid = (int)blockIdx.x < n_geo_blocks ? n_col_blocks + (int)blockIdx.x : (int)blockIdx.x - n_geo_blocks;
+    if (bid < n_col_blocks) {
+        if (bid * 32 >= P_live) return;
+        decode_bwd_col_wg<H16, DEEP>(a, bid, w, lk_lane(), s_x, s_o);
         return;
     }
     float (*s_part)[3 * EGP] = reinterpret_cast<float (*)[3 * EGP]>(s_x);
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
-    const int gb = (int)blockIdx.x - n_col_blocks;
+    const int gb = bid - n_col_blocks;
     if (want_w) {
         for (int e = threadIdx.x; e < 4 * 3 * EGP; e += 256) (&s_part[0][0])[e] = 0.0f;
         __syncthreads();
     }
     const int tile = gb * 4 + w;
-    if (tile * 32 < P_live) decode_bwd_geo_wave(a, tile, s_part[w]);
+    if (tile * 32 < P_live) decode_bwd_geo_wave(a, tile, s_part[w], s_x + 512 + w * (6 * 64));       // (s_part ends at s_x[288])
     if (want_w) {
         __syncthreads();
         for (int e = threadIdx.x; e < 3 * EGP; e += 256)

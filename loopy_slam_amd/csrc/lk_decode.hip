@@ -420,8 +420,8 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     LK_CLK(16);
 }
 
-// Block roles: the first `n_col_blocks` workgroups are colour tiles (4 waves per tile), the rest run the geometry
-// decoder (4 independent tiles per workgroup).  raw[:, 0:3] and raw[:, 3] are written by the two roles separately;
+// Block roles: `n_col_blocks` workgroups are colour tiles (4 waves per tile), the others run the geometry
+// decoder (4 independent tiles per workgroup) and come FIRST in the grid.  raw[:, 0:3] and raw[:, 3] are written by the two roles separately;
 // in the geometry stage there are no colour blocks and raw[:, 0:3] is zero-filled by the geometry wave.
 template <bool DEEP>
 __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col_blocks) {
@@ -431,12 +431,15 @@ __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col
     const int lane = lk_lane();
     const int w = (int)threadIdx.x >> 6;
     const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;       // samples of rays with a depth reading (they come first)
-    if ((int)blockIdx.x < n_col_blocks) {
-        if ((int)blockIdx.x * 32 >= P_live) return;
-        decode_col_wg<DEEP>(a, blockIdx.x, w, lane, s_x, s_o, s_bias);
+    // geometry workgroups first in the grid (one-wave chains, the longest of the launch: behind the colour tiles they were its tail)
+    const int n_geo_blocks = (int)gridDim.x - n_col_blocks;
+    const int bid = (int)blockIdx.x < n_geo_blocks ? n_col_blocks + (int)blockIdx.x : (int)blockIdx.x - n_geo_blocks;
+    if (bid < n_col_blocks) {
+        if (bid * 32 >= P_live) return;
+        decode_col_wg<DEEP>(a, bid, w, lane, s_x, s_o, s_bias);
         return;
     }
-    const int tile = ((int)blockIdx.x - n_col_blocks) * 4 + w;
+    const int tile = (bid - n_col_blocks) * 4 + w;
     if (tile * 32 >= P_live) return;
     decode_geo_wave(a, tile, lane);
     if (n_col_blocks == 0) {

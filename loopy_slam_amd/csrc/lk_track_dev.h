@@ -22,6 +22,23 @@ __device__ __forceinline__ void lk_track_final_body(const LkTrackFinalArgs& a) {
     __shared__ float acc[12];
     __shared__ float s_cam[7];
     const int t = threadIdx.x;
+    // Issued first, used last: the pixels of the next batch (and, in thread 0, the pose and its moments) do not depend on the partial sums -
+    // their round trip runs beside the reduction instead of behind it (the launch is a chain of dependent round trips, nothing else)
+    constexpr int RPT = 8;                                 // rays per thread: R <= 8192 in the fused loop (LK_MASK_REG_MAX)
+    float npi[RPT], npj[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = t + 64 * NW * q;
+        const bool on = a.rays_o != nullptr && r < a.R;
+        npi[q] = on ? a.next_pix_i[r] : 0.0f; npj[q] = on ? a.next_pix_j[r] : 0.0f;
+    }
+    float cam0[7], mv0[14];
+    if (t == 0) {
+#pragma unroll
+        for (int e = 0; e < 7; ++e) cam0[e] = a.cam[e];
+#pragma unroll
+        for (int e = 0; e < 14; ++e) mv0[e] = a.do_update ? a.adam_mv[e] : 0.0f;
+    }
     if (a.do_update) {
         float v12[12];
 #pragma unroll
@@ -49,7 +66,7 @@ __device__ __forceinline__ void lk_track_final_body(const LkTrackFinalArgs& a) {
         __syncthreads();
         if (t == 0) {
             float* cam = a.cam;
-            const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
+            const float qr = cam0[0], qi = cam0[1], qj = cam0[2], qk = cam0[3];
             const float N = qr * qr + qi * qi + qj * qj + qk * qk, s = 2.0f / N;
             const float P[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
                                 qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr,
@@ -68,31 +85,37 @@ __device__ __forceinline__ void lk_track_final_body(const LkTrackFinalArgs& a) {
             gc[4] = acc[9]; gc[5] = acc[10]; gc[6] = acc[11];
 #pragma unroll
             for (int e = 0; e < 7; ++e) {        // torch.optim.Adam, group T: elements 4..6, group q: 0..3 (as k_adam)
-                if (a.hist_pre) a.hist_pre[e] = cam[e];
+                if (a.hist_pre) a.hist_pre[e] = cam0[e];
                 a.g_cam[e] = gc[e];
-                const float m = a.adam_mv[e] * a.beta1 + (1.0f - a.beta1) * gc[e];
-                const float v = a.adam_mv[7 + e] * a.beta2 + (1.0f - a.beta2) * (gc[e] * gc[e]);
+                const float m = mv0[e] * a.beta1 + (1.0f - a.beta1) * gc[e];
+                const float v = mv0[7 + e] * a.beta2 + (1.0f - a.beta2) * (gc[e] * gc[e]);
                 const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
                 a.adam_mv[e] = m; a.adam_mv[7 + e] = v;
-                const float p = cam[e] - (e < 4 ? a.step_q : a.step_T) * (m / denom);
+                const float p = cam0[e] - (e < 4 ? a.step_q : a.step_T) * (m / denom);
                 cam[e] = p;
+                cam0[e] = p;
                 if (a.hist_post) a.hist_post[e] = p;
             }
         }
-        __syncthreads();
     }
     if (!a.rays_o) return;
-    if (t < 7) s_cam[t] = a.cam[t];
+    if (t == 0) {
+#pragma unroll
+        for (int e = 0; e < 7; ++e) s_cam[e] = cam0[e];        // the stepped pose (before the first iteration: the initial one)
+    }
     __syncthreads();
     float Rm[9];
     lp_quat_rot(s_cam, Rm);
-    for (int r = t; r < a.R; r += 64 * NW) {
-        const float d0 = (a.next_pix_i[r] - a.cx) / a.fx, d1 = -(a.next_pix_j[r] - a.cy) / a.fy, d2 = -1.0f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            a.rays_d[3 * r + c] = (d0 * Rm[3 * c] + d1 * Rm[3 * c + 1]) + d2 * Rm[3 * c + 2];
-            a.rays_o[3 * r + c] = s_cam[4 + c];
+    for (int q = 0; q < RPT; ++q) {
+        const int r = t + 64 * NW * q;
+        if (r < a.R) {
+            const float d0 = (npi[q] - a.cx) / a.fx, d1 = -(npj[q] - a.cy) / a.fy, d2 = -1.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a.rays_d[3 * r + c] = (d0 * Rm[3 * c] + d1 * Rm[3 * c + 1]) + d2 * Rm[3 * c + 2];
+                a.rays_o[3 * r + c] = s_cam[4 + c];
+            }
         }
     }
 }
-
