@@ -443,6 +443,10 @@ int lk_profile_begin(const char* names);
  * environment variable LK_SERIAL sets the initial state). */
 int lk_set_serial(int32_t on);
 int lk_profile_end(char* buf, int cap);
+/* Measurement: resident 256-thread workgroups per compute unit of the five MLP kernels, as the runtime computes them from the
+ * registers and LDS of the loaded code objects (hipOccupancyMaxActiveBlocksPerMultiprocessor): out[0..4] = k_decode_fwd,
+ * k_decode_bwd (mapper form), k_relpos_fwd, k_relpos_bwd_fused, k_wgrad.  Needs a device. */
+int lk_debug_occupancy(int32_t out[5]);
 
 #ifdef __cplusplus
 }

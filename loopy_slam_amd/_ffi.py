@@ -180,6 +180,7 @@ class LoopyLib:
             ('lk_profile_end', [C.c_char_p, C.c_int], C.c_int),
             ('lk_compact', [_fp, C.c_int32, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_set_serial', [C.c_int32], C.c_int),
+            ('lk_debug_occupancy', [C.POINTER(C.c_int32)], C.c_int),
             ('lk_track_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
             ('lk_map_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
             ('lk_map_work_nbr_idx', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),

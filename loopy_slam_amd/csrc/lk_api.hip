@@ -290,6 +290,12 @@ SideStream& side_stream() {
 }  // namespace
 
 extern "C" int lk_set_serial(int32_t on) { g_serial = on ? 1 : 0; return LK_OK; }
+extern "C" int lk_debug_occupancy(int32_t out[5]) {
+    LK_REQUIRE(out != nullptr, "lk_debug_occupancy: out is null");
+    out[0] = lk_occupancy_decode_fwd(); out[1] = lk_occupancy_decode_bwd(); out[2] = lk_occupancy_relpos_fwd();
+    out[3] = lk_occupancy_relpos_bwd_fused(); out[4] = lk_occupancy_wgrad();
+    return LK_OK;
+}
 bool lk_serial_mode() { if (g_serial < 0) g_serial = getenv("LK_SERIAL") != nullptr ? 1 : 0; return g_serial != 0; }
 LkAuxStream& lk_aux_stream() {
     static LkAuxStream s, none;

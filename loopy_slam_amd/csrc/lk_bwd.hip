@@ -491,3 +491,8 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((k_decode_bwd<false, false>), grid, dim3(256), 0, st, a, n_col);
     return LK_OK;
 }
+int lk_occupancy_decode_bwd() {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_decode_bwd<true, false>, 256, 0);
+    return n;
+}

@@ -1324,6 +1324,16 @@ int lk_launch_dw2_hbar(const LkRelposBwdArgs& a, float* dw2_part, hipStream_t st
     hipLaunchKernelGGL(k_dw2_hbar, dim3(lk_dw2_parts(a.P)), dim3(256), 0, st, a.dc_col, a.w_sum, a.hbar, a.P, a.live_rays, a.S, dw2_part);
     return LK_OK;
 }
+int lk_occupancy_relpos_bwd_fused() {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_relpos_bwd_fused, 256, 0);
+    return n;
+}
+int lk_occupancy_wgrad() {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wgrad<true>, 256, 0);
+    return n;
+}
 int lk_launch_wgrad(const LkWgradArgs& a_in, int max_rows, hipStream_t st, LkWgradArgs* deferred) {
     if (deferred) deferred->n_units = 0;
     if (a_in.n_jobs == 0 || max_rows <= 0) return LK_OK;

@@ -569,6 +569,16 @@ int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL(k_decode_fwd<false>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     return LK_OK;
 }
+int lk_occupancy_decode_fwd() {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_decode_fwd<false>, 256, 0);
+    return n;
+}
+int lk_occupancy_relpos_fwd() {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_relpos_fwd, 256, 0);
+    return n;
+}
 // tracker-sized colour batches with the rel-pos MLP (lk_track_frame): see k_relpos_decode_fwd
 bool lk_relpos_decode_fusable(const LkDecodeArgs& a) {
     const int tiles = lk_cdiv(a.P, 32);

@@ -319,3 +319,10 @@ int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs
 #define LK_DEEP_MAX_TILES_FWD 512
 #endif
 #define LK_COL_LAYER(P, layer) ((size_t)(layer) * (size_t)(P) * 128)
+
+// resident 256-thread workgroups per compute unit as the runtime computes them (registers, LDS): lk_debug_occupancy
+int lk_occupancy_decode_fwd();
+int lk_occupancy_relpos_fwd();
+int lk_occupancy_decode_bwd();
+int lk_occupancy_relpos_bwd_fused();
+int lk_occupancy_wgrad();

@@ -224,3 +224,16 @@ def test_decoder_backward_rows_repeat_bit_for_bit(unit):
     from loopy_slam_amd import _ffi
     bad_dc, bad_dh, cols = probe.run(_ffi.LIB_PATH, 40000, unit)
     assert bad_dc == 0 and bad_dh == 0, (bad_dc, bad_dh, cols)
+
+
+def test_mlp_kernels_resident_workgroups():
+    """What the runtime makes of the kernels' registers and LDS (lk_debug_occupancy): the decoders and the rel-pos forward run three
+    256-thread workgroups per compute unit, the fused rel-pos backward (two LDS operand images) and the streaming weight-gradient kernel two.
+    tests/test_product_hygiene.py::test_mlp_kernels_keep_their_register_budget is the CPU-side guard of the same numbers."""
+    import ctypes as C
+    eng = make_engine('hip')
+    out = (C.c_int32 * 5)()
+    assert eng.lib.dll.lk_debug_occupancy(out) == 0
+    fwd, bwd, rel_fwd, rel_bwd, wgrad = list(out)
+    assert fwd >= 3 and bwd >= 3 and rel_fwd >= 3, list(out)
+    assert rel_bwd >= 2 and wgrad >= 2, list(out)

@@ -84,3 +84,65 @@ def test_library_has_no_packed_fp32_instructions():
             found += re.findall(r'\bv_pk_(?:mul|add|fma)_f32\b|\bv_pk_mov_b32\b', dis)
         assert n_insts > 100                         # the disassembly really is the kernels
         assert not found, f'{len(found)} packed fp32 instructions in libloopyhip.so: {sorted(set(found))}'
+
+
+def _code_object_notes():
+    """[(kernel name, {vgpr_count, vgpr_spill_count, private_segment_fixed_size, group_segment_fixed_size})] of every kernel in libloopyhip.so
+    (the AMDGPU metadata notes of its code objects)."""
+    import subprocess
+    import tempfile
+    objcopy, readelf = '/opt/rocm/lib/llvm/bin/llvm-objcopy', '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    if not (os.path.exists(objcopy) and os.path.exists(readelf)):
+        pytest.skip('ROCm LLVM binutils not installed')
+    from loopy_slam_amd.csrc import build
+    lib_path = build.build()
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, 'fat.bin')
+        subprocess.run([objcopy, '--dump-section=.hip_fatbin=' + fat, lib_path], check=True)
+        blob = open(fat, 'rb').read()
+        offs = [m.start() for m in re.finditer(b'\x7fELF', blob)]
+        for k, o in enumerate(offs):
+            co = os.path.join(tmp, 'co.elf')
+            open(co, 'wb').write(blob[o:offs[k + 1] if k + 1 < len(offs) else len(blob)])
+            notes = subprocess.run([readelf, '--notes', co], capture_output=True, text=True).stdout
+            cur = {}
+            for line in notes.splitlines():
+                m = re.match(r'\s+-?\s*\.(\w+):\s+(.*)', line)
+                if not m:
+                    continue
+                key, val = m.group(1), m.group(2).strip()
+                if key in ('vgpr_count', 'vgpr_spill_count', 'private_segment_fixed_size', 'group_segment_fixed_size'):
+                    cur[key] = int(val)
+                elif key == 'name' and val.startswith('_Z') and not val.endswith('.kd'):
+                    cur['name'] = val
+                elif key == 'wavefront_size':           # last key of a kernel's entry
+                    if 'name' in cur:
+                        out.append((cur.pop('name'), cur))
+                    cur = {}
+    return out
+
+
+def test_mlp_kernels_keep_their_register_budget():
+    """The decoder kernels run three workgroups per compute unit only below 168 registers per lane, and a spill in any of the per-sample
+    kernels is a performance bug (round 3: the compiler had sunk the geometry decoder's d p chain to the end of k_decode_bwd and kept 190
+    values alive for it - 209 registers, two workgroups per unit).  Only k_pregather (one launch per frame, 1 024-thread workgroups =
+    128 registers) is allowed to spill."""
+    notes = _code_object_notes()
+    assert len(notes) > 60
+    by = {}
+    for name, d in notes:
+        by.setdefault(name, d)
+    spilled = sorted(n for n, d in by.items() if d.get('vgpr_spill_count', 0) > 0 and 'k_pregather' not in n)
+    assert not spilled, spilled
+    budget = {'_Z12k_decode_bwdILb1ELb0EEv15LkDecodeBwdArgsi': 168,     # mapper form: three workgroups per unit
+              '_Z12k_decode_fwdILb0EEv12LkDecodeArgsi': 168,
+              '_Z12k_relpos_fwd12LkRelposArgs': 168,
+              '_Z18k_relpos_bwd_fused15LkRelposBwdArgs': 256,            # two per unit (LDS-bound anyway)
+              '_Z7k_wgradILb1EEv11LkWgradArgs': 256}
+    for name, cap in budget.items():
+        assert name in by, name
+        assert by[name]['vgpr_count'] <= cap, (name, by[name])
+    # LDS: three decoder workgroups must fit the 160 KB of a compute unit
+    assert 3 * by['_Z12k_decode_bwdILb1ELb0EEv15LkDecodeBwdArgsi']['group_segment_fixed_size'] <= 160 * 1024
+    assert 3 * by['_Z12k_decode_fwdILb0EEv12LkDecodeArgsi']['group_segment_fixed_size'] <= 160 * 1024
