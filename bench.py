@@ -125,10 +125,24 @@ def main():
         wl.step(full=True)
     barrier()
     dt_full = time.perf_counter() - t0f
+    # PCIe-inclusive: the C ABI takes DEVICE pointers, so a caller that receives its RGB-D frames in host memory uploads one frame
+    # (640 x 480 fp32 depth + RGB = 4.9 MB) per step; the same timed steps with that upload from pinned memory in front of each
+    # (reported beside `value`, never as `value`)
+    host_d, host_c = wl.depth_stack.cpu().pin_memory(), wl.color_stack.cpu().pin_memory()      # every frame of the window: contents unchanged
+    wl.frame_no = 0
+    barrier()
+    t0h = time.perf_counter()
+    for _ in range(args.steps):
+        k = wl.frame_no % budget.window
+        wl.depth_stack[k].copy_(host_d[k], non_blocking=True)
+        wl.color_stack[k].copy_(host_c[k], non_blocking=True)
+        wl.step()
+    barrier()
+    dt_host = time.perf_counter() - t0h
     if world > 1:
-        t = torch.tensor([dt, dt_full], device='cuda')
+        t = torch.tensor([dt, dt_full, dt_host], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_full = float(t[0].item()), float(t[1].item())
+        dt, dt_full, dt_host = float(t[0].item()), float(t[1].item()), float(t[2].item())
     rays_per_step = budget.rays_per_frame
     # whole-job rays of a step: every rank brings its own mapping rays; the tracking iterations are REPLICATED on the ranks (the same
     # rays everywhere, no exchange - steps.TrackOptimizer), so they count once however many ranks repeat them
@@ -146,6 +160,8 @@ def main():
         'frames_per_s_full': n_full / dt_full, 'ms_per_step_full': 1e3 * dt_full / n_full,
         'full_step': f'{n_full} steps, every {budget.every_frame}th also inserts {budget.pixels_adding} pixels (lk_add_points + feature rows + lk_knn_build) and '
                      f'renders the 640x480 frame (307 200 rays); {wl.n_added} points added, map {wl.n} points',
+        'ms_per_step_host_frames': 1e3 * dt_host / args.steps,
+        'host_frames': 'the same steps with one RGB-D frame (4.9 MB, pinned host memory) uploaded over PCIe in front of each - the boundary takes device pointers',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if (args.strong and world > 1) else 'weak',
         'vs_baseline': None,
