@@ -96,7 +96,7 @@ extern "C" int64_t lk_render_act_floats(int32_t R, int32_t S, uint32_t flags) {
 
 // ------------------------------------------------------------------ backward scratch layout
 namespace {
-struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, part_bg, part_br, hbar, w_sum, dy_col, rows, dw1_part, dw2_part, wg_part, seg_rank, seg_list, total; };
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, aff_part, part_bg, part_br, hbar, w_sum, dy_col, rows, dw1_part, dw2_part, wg_part, seg_rank, seg_list, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -112,6 +112,7 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.dw_rel = o; o += al(8 * P);
     L.w_eff = o; o += al(8 * P);
     L.dlogit = o; o += al(4 * P);
+    L.aff_part = o; o += al((int64_t)lk_cdiv(P, 32) * 12);         // per-tile sums of the exposure affine's gradient (k_decode_bwd)
     L.part_bg = o; o += al((int64_t)lk_cdiv(lk_cdiv(P, 32), 4) * 288);
     L.part_br = o; o += al((int64_t)lk_cdiv(lk_cdiv(P, 4), 4) * 32);
     const bool color = (flags & LK_FLAG_STAGE_COLOR) != 0, gw = (flags & LK_FLAG_GRAD_WEIGHTS) != 0;
@@ -336,7 +337,7 @@ extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) { return lk
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags) {
     const BwdLayout L = bwd_layout(P, flags);
     LkBwdOffsets o;
-    o.d_raw = L.d_raw; o.dp_total = L.dp_total;
+    o.d_raw = L.d_raw; o.dp_total = L.dp_total; o.aff_part = L.aff_part;
     return o;
 }
 
@@ -383,10 +384,12 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.W = d->weights; db.Wfrag = d->weights_frag; db.affine = d->affine;
     db.act = d->act; db.raw = d->raw; db.d_raw = S0 + L.d_raw;
     db.dc_geo = S0 + L.dc_geo; db.dc_col = S0 + L.dc_col; db.dy_col = S0 + L.dy_col; db.dlogit = S0 + L.dlogit;
-    db.dp_embed = S0 + L.dp_embed; db.dp_embed_col = S0 + L.dp_embed_col; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.part_bg = S0 + L.part_bg;
+    db.dp_embed = S0 + L.dp_embed; db.dp_embed_col = S0 + L.dp_embed_col; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.g_affine_part = S0 + L.aff_part; db.part_bg = S0 + L.part_bg;
     db.live_rays = ex ? ex->live_rays : nullptr;
     db.dscale = ex ? ex->dscale : nullptr;
     lk_launch_decode_bwd(db, st);
+    // d affine: the colour tiles stored their 12 sums, one small launch adds them into g_affine (49 adds per address instead of 782)
+    if (color && d->affine && d->g_affine && !(skip & LK_SKIP_AFF_REDUCE)) lk_launch_reduce_partials(S0 + L.aff_part, lk_cdiv(P, 32), 12, d->g_affine, st);
     // mapper 'color' backward with one weight-gradient launch: every partial-sum reduction is deferred to ONE launch at the end
     const bool defer = gw && color && (!relpos || lk_relpos_fused(flags));
     LkWgradArgs wdef;

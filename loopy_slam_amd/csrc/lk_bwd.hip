@@ -150,12 +150,12 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         const float v = lk_half_wave_sum(oo[c3] * gm[m]);
-                        if (lane == LK_HWS_LANE) atomicAdd(a.g_affine + c3 * 3 + m, v);
+                        if (lane == LK_HWS_LANE) a.g_affine_part[(size_t)tile * 12 + c3 * 3 + m] = v;
                     }
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     const float v = lk_half_wave_sum(gm[m]);
-                    if (lane == LK_HWS_LANE) atomicAdd(a.g_affine + 9 + m, v);
+                    if (lane == LK_HWS_LANE) a.g_affine_part[(size_t)tile * 12 + 9 + m] = v;
                 }
             }
             __syncthreads();                                     // s_o is reused for the d p partials
@@ -426,7 +426,10 @@ __global__ __launch_bounds__(256, LK_DBWD_MINB) void k_decode_bwd(LkDecodeBwdArg
     const int n_geo_blocks = (int)gridDim.x - n_col_blocks;
     const int bid = (int)blockIdx.x < n_geo_blocks ? n_col_blocks + (int)blockIdx.x : (int)blockIdx.x - n_geo_blocks;
     if (bid < n_col_blocks) {
-        if (bid * 32 >= P_live) return;
+        if (bid * 32 >= P_live) {       // a skipped tile contributes zero to the per-tile sums of d affine
+            if (a.affine && a.g_affine && threadIdx.x < 12) a.g_affine_part[(size_t)bid * 12 + threadIdx.x] = 0.0f;
+            return;
+        }
         decode_bwd_col_wg<H16, DEEP>(a, bid, w, lk_lane(), s_x, s_o);
         return;
     }

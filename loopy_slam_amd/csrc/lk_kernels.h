@@ -95,6 +95,9 @@ struct LkDecodeBwdArgs {
     float* dp_embed;                               // [P,4]   (GRAD_RAYS) geometry-decoder embedding path
     float* dp_embed_col;                           // [P,4]   (GRAD_RAYS, colour stage) colour-decoder embedding path
     float* g_weights; float* g_affine;
+    float* g_affine_part;           // [colour tiles][12] per-tile sums of d affine (g_affine != NULL): summed by the caller of the launch
+                                    // (lk_launch_reduce_partials, or k_exposure_step in the tracking loop) - 782 tiles x 12 atomics on
+                                    // twelve addresses took 108 us per 5 000-ray launch
     float* part_bg;                                // [n_blocks][288] per-workgroup partial sums of d embedder._B (GRAD_WEIGHTS)
     const int32_t* live_rays;                      // as LkDecodeArgs
     const float* dscale;                           // [1] device-side power of two on top of the fp16-piece form's 2^10 pre-scale (exposure encoding:
@@ -256,6 +259,7 @@ inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_W
 enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, LK_FUSE_COMPOSITE_BWD = 8, LK_LOSS_PREZEROED = 16,
        LK_SEG_SORTED = 32 /* bwd: the forward (LK_FUSE_COMPOSITE_BWD + GRAD_FEATS) already sorted the rows by point */,
        LK_PRESAMPLED = 64 /* fwd: z / nbr_idx / nbr_w / nbr_count are given (lk_presample), only interpolate */,
+       LK_SKIP_AFF_REDUCE = 256 /* bwd: the caller sums the per-tile d affine partials itself (k_track_final's exposure workgroup) */,
        LK_FUSE_SMALL = 128 /* tracker-sized batches: rel-pos MLP + decoders in one launch (fwd), rel-pos backward + interpolation backward in one (bwd) */ };
 // cnt: the batch holds n iterations of P_iter samples each (n <= LK_SEG_BATCH); their rows are counted per point on the way
 struct LkPresampleCount { int P_iter; int32_t* seg_rank; const int32_t* live_rays; };
@@ -270,7 +274,7 @@ LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour
 struct LkRepackRider { float* frag; const float* src; float* copy_dst; int copy_n; };
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr, const LkRepackRider* repack = nullptr);
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
-struct LkBwdOffsets { int64_t d_raw, dp_total; };
+struct LkBwdOffsets { int64_t d_raw, dp_total, aff_part; };
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch
 
 int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st);

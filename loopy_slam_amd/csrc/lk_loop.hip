@@ -16,6 +16,7 @@
 #include "lk_composite_dev.h"
 #include "lk_mask_dev.h"
 #include "lk_track_dev.h"
+#include "lk_exposure_dev.h"
 
 #include <math.h>
 #include <string.h>
@@ -23,6 +24,7 @@
 using namespace lkw;
 
 int lk_launch_exposure_step(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, hipStream_t st);      // lk_optim.hip
+int lk_exposure_step_args(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, ExposureStepArgs* out);
 int lk_launch_loss_mapper_exposure(int R, const float* depth, const float* logits, const uint8_t* valid_ray, const float* gt_depth,
                                    const float* gt_color, const int32_t* frame_id, const float* aff, int F, float w_color,
                                    float* d_depth, float* d_logits, float* out_loss, float* g_aff, hipStream_t st);
@@ -234,7 +236,13 @@ __global__ __launch_bounds__(256) void k_track_loss2(LkTrackLossArgs a, int n_pa
 }
 
 // ------------------------------------------------------------------ k_track_final (body: lk_track_dev.h)
-__global__ __launch_bounds__(1024) void k_track_final(LkTrackFinalArgs a) { lk_track_final_body<16>(a); }
+// With exposure encoding the launch has a second workgroup: the exposure step of the iteration (backward of the 8 -> 128 -> 12 MLP from the
+// per-tile sums of d affine, Adam, forward with the stepped values) - it depends on the decoder backward only, as the pose step does on the
+// interpolation backward, and two more launches on the iteration's chain (13 + 5 us) are gone
+__global__ __launch_bounds__(1024) void k_track_final(LkTrackFinalArgs a, ExposureStepArgs xa, const float* __restrict__ aff_part, int n_aff_part) {
+    if (blockIdx.x == 1) { lk_exposure_step_body(xa, aff_part, n_aff_part); return; }
+    lk_track_final_body<16>(a);
+}
 
 // ------------------------------------------------------------------ lk_track_frame
 namespace {
@@ -346,9 +354,14 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         fa.beta1 = beta1; fa.beta2 = beta2; fa.eps = eps;
         fa.rays_o = const_cast<float*>(rd.rays_o); fa.rays_d = const_cast<float*>(rd.rays_d);
         fa.next_pix_i = W0 + wk.pix_i; fa.next_pix_j = W0 + wk.pix_j; fa.do_update = 0;
-        hipLaunchKernelGGL(k_track_final, dim3(1), dim3(1024), 0, st, fa);
-    }
-    if (xd) {
+        ExposureStepArgs xa;
+        memset(&xa, 0, sizeof(xa));
+        if (xd) {       // the exposure forward of the first iteration rides as the launch's second workgroup
+            const int rc = lk_exposure_step_args(*xd, 2, 1, beta1, beta2, eps, &xa);
+            if (rc != LK_OK) return rc;
+        }
+        hipLaunchKernelGGL(k_track_final, dim3(xd ? 2 : 1), dim3(1024), 0, st, fa, xa, (const float*)nullptr, 0);
+    } else if (xd) {
         const int rc = lk_launch_exposure_step(*xd, 2, 1, beta1, beta2, eps, st);
         if (rc != LK_OK) return rc;
     }
@@ -396,9 +409,9 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         ex.dscale = (xd && (rd.flags & LK_FLAG_UNIT_LOSS_GRADS)) ? xd->bwd_scale : nullptr;
         ex.pix_i = W0 ? W0 + wk.pix_i + (size_t)it * R : nullptr; ex.pix_j = W0 ? W0 + wk.pix_j + (size_t)it * R : nullptr;
         ex.fx = d->fx; ex.fy = d->fy; ex.cx = d->cx; ex.cy = d->cy;
-        rc = lk_render_bwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE_BWD | LK_SKIP_RAYS_BWD | LK_FUSE_SMALL) : 0, fused ? &ex : nullptr);
+        rc = lk_render_bwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE_BWD | LK_SKIP_RAYS_BWD | LK_FUSE_SMALL | (xd ? LK_SKIP_AFF_REDUCE : 0)) : 0, fused ? &ex : nullptr);
         if (rc != LK_OK) return rc;
-        if (xd) {
+        if (xd && !fused) {
             rc = lk_launch_exposure_step(*xd, 3, it + 1, beta1, beta2, eps, st);
             if (rc != LK_OK) return rc;
         }
@@ -414,7 +427,14 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             const bool more = it + 1 < iters;
             fa.rays_o = more ? const_cast<float*>(rd.rays_o) : nullptr; fa.rays_d = const_cast<float*>(rd.rays_d);
             fa.next_pix_i = W0 + wk.pix_i + (size_t)(it + 1) * R * (more ? 1 : 0); fa.next_pix_j = W0 + wk.pix_j + (size_t)(it + 1) * R * (more ? 1 : 0);
-            hipLaunchKernelGGL(k_track_final, dim3(1), dim3(1024), 0, st, fa);
+            ExposureStepArgs xa;
+            memset(&xa, 0, sizeof(xa));
+            if (xd) {
+                rc = lk_exposure_step_args(*xd, 3, it + 1, beta1, beta2, eps, &xa);
+                if (rc != LK_OK) return rc;
+            }
+            hipLaunchKernelGGL(k_track_final, dim3(xd ? 2 : 1), dim3(1024), 0, st, fa, xa,
+                               xd ? (const float*)(rd.bwd_scratch + off.aff_part) : (const float*)nullptr, xd ? lk_cdiv(R * S, 32) : 0);
         }
         if (!fused) {
             rc = lk_pose_bwd(d->cam7, d->pix_i, d->pix_j, R, d->fx, d->fy, d->cx, d->cy, rd.g_rays_o, rd.g_rays_d, d->g_cam7, st);

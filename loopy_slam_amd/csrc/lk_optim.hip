@@ -506,122 +506,10 @@ __global__ __launch_bounds__(256) void k_loss_mapper_exposure(int R, const float
     }
 }
 
-// One launch per iteration of the per-frame loops (lk_exposure_desc, include/loopy_hip.h): backward of the exposure MLP from g_aff
-// (the body of k_exposure_bwd, gradients kept in g), Adam on the MLP's tensors and on the trainable features, forward with the stepped
-// values (k_exposure_fwd) for the next iteration, g_aff cleared.  mode bit 0: backward + step, bit 1: forward (+ clear).
-struct ExposureStepArgs {
-    float* feats; float* W1; float* b1; float* W2; float* b2; int F;
-    float* aff; float* hid; float* g_aff; float* g; float* m; float* v; float* bwd_scale;
-    float step_mlp, step_feat, bc2_sqrt, beta1, beta2, eps;      // lr / bias_correction1 per group (step_mlp < 0: frozen), sqrt(bias_correction2)
-    int feat_first, feat_count, mode;
-};
-__global__ __launch_bounds__(256) void k_exposure_step(ExposureStepArgs a) {
-    __shared__ float s_ga[LK_EXPOSURE_MAX_F * 12];
-    __shared__ float s_dp[LK_EXPOSURE_MAX_F * 128];
-    const int F = a.F, t = threadIdx.x;
-    if (a.mode & 1) {
-        for (int e = t; e < F * 12; e += 256) s_ga[e] = a.g_aff[e];
-        __syncthreads();
-        for (int e = t; e < F * 128; e += 256) {
-            const int f = e >> 7, u = e & 127;
-            float dh = 0.0f;
-#pragma unroll
-            for (int o = 0; o < 12; ++o) dh = fmaf(a.W2[o * 128 + u], s_ga[f * 12 + o], dh);
-            s_dp[e] = dh * lk_softplus100_grad_from_out(a.hid[e]);
-        }
-        __syncthreads();
-        // every gradient element is formed and consumed by the same thread; the feature gradients read W1 BEFORE it is stepped
-        float gfeat[(LK_EXPOSURE_MAX_F * 8 + 255) / 256];
-#pragma unroll
-        for (int q = 0; q < (LK_EXPOSURE_MAX_F * 8 + 255) / 256; ++q) {
-            const int e = t + 256 * q;
-            float acc = 0.0f;
-            if (e < F * 8) {
-                const int f = e >> 3, k = e & 7;
-                for (int u = 0; u < 128; ++u) acc = fmaf(a.W1[u * 8 + k], s_dp[f * 128 + u], acc);
-                a.g[2700 + e] = acc;
-            }
-            gfeat[q] = acc;
-        }
-        __syncthreads();
-        const bool mlp = a.step_mlp >= 0.0f;
-        auto step = [&](float* p, int gi, float gval, float step_size) {
-            float m = a.m[gi], v = a.v[gi];
-            *p = lk_adam_elem(*p, gval, m, v, a.beta1, a.beta2, a.eps, step_size, a.bc2_sqrt);
-            a.m[gi] = m; a.v[gi] = v;
-        };
-        for (int e = t; e < 1024; e += 256) {                       // W1 [128][8]
-            const int u = e >> 3, k = e & 7;
-            float acc = 0.0f;
-            for (int f = 0; f < F; ++f) acc = fmaf(s_dp[f * 128 + u], a.feats[f * 8 + k], acc);
-            a.g[e] = acc;
-            if (mlp) step(a.W1 + e, e, acc, a.step_mlp);
-        }
-        for (int u = t; u < 128; u += 256) {                        // b1
-            float acc = 0.0f;
-            for (int f = 0; f < F; ++f) acc += s_dp[f * 128 + u];
-            a.g[1024 + u] = acc;
-            if (mlp) step(a.b1 + u, 1024 + u, acc, a.step_mlp);
-        }
-        for (int e = t; e < 1536; e += 256) {                       // W2 [12][128]
-            const int o = e >> 7, u = e & 127;
-            float acc = 0.0f;
-            for (int f = 0; f < F; ++f) acc = fmaf(s_ga[f * 12 + o], a.hid[f * 128 + u], acc);
-            a.g[1152 + e] = acc;
-            if (mlp) step(a.W2 + e, 1152 + e, acc, a.step_mlp);
-        }
-        for (int o = t; o < 12; o += 256) {                         // b2
-            float acc = 0.0f;
-            for (int f = 0; f < F; ++f) acc += s_ga[f * 12 + o];
-            a.g[2688 + o] = acc;
-            if (mlp) step(a.b2 + o, 2688 + o, acc, a.step_mlp);
-        }
-        __syncthreads();                                            // W1's gradient read the features: step them last
-#pragma unroll
-        for (int q = 0; q < (LK_EXPOSURE_MAX_F * 8 + 255) / 256; ++q) {
-            const int e = t + 256 * q;
-            if (e < F * 8 && (e >> 3) >= a.feat_first && (e >> 3) < a.feat_first + a.feat_count) step(a.feats + e, 2700 + e, gfeat[q], a.step_feat);
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    if (a.mode & 2) {
-        __shared__ unsigned s_amax;
-        if (t == 0) s_amax = 0u;
-        float* s_h = s_dp;
-        for (int e = t; e < F * 128; e += 256) {
-            const int f = e >> 7, u = e & 127;
-            float acc = a.b1[u];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc = fmaf(a.W1[u * 8 + k], a.feats[f * 8 + k], acc);
-            const float h = lk_softplus100(acc);
-            s_h[e] = h;
-            a.hid[e] = h;
-        }
-        __syncthreads();
-        for (int e = t; e < F * 12; e += 256) {
-            const int f = e / 12, o = e - f * 12;
-            float acc = a.b2[o];
-            for (int u = 0; u < 128; ++u) acc = fmaf(a.W2[o * 128 + u], s_h[f * 128 + u], acc);
-            a.aff[e] = acc;
-            a.g_aff[e] = 0.0f;
-            if (o < 9 && a.bwd_scale) atomicMax(&s_amax, __float_as_uint(fabsf(acc)));       // the 3 x 3 part (positive floats order like their bits)
-        }
-        if (a.bwd_scale) {
-            __syncthreads();
-            if (t == 0) {
-                // |d out| <= (0.25 w_color) x (row / column sum of |A|) <= (0.25 w_color) x 3 max|A|: the power of two that brings 3 max|A| into (0.5, 1]
-                const float bound = 3.0f * __uint_as_float(s_amax);
-                int ex = 0;
-                if (bound > 0.0f && bound < 3.0e38f) { (void)frexpf(bound, &ex); }       // bound = m 2^ex, m in [0.5, 1)
-                ex = ex > 40 ? 40 : (ex < -40 ? -40 : ex);
-                *a.bwd_scale = ldexpf(1.0f, -ex);
-            }
-        }
-    }
-}
+#include "lk_exposure_dev.h"
+__global__ __launch_bounds__(256) void k_exposure_step(ExposureStepArgs a) { lk_exposure_step_body(a, nullptr, 0); }
 // step: 1-based Adam step of the exposure groups (they first step in the first iteration that uses them)
-int lk_launch_exposure_step(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, hipStream_t st) {
+int lk_exposure_step_args(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, ExposureStepArgs* out) {
     LK_REQUIRE(x.F >= 1 && x.F <= LK_EXPOSURE_MAX_F, "exposure: F out of range");
     LK_REQUIRE(x.feats && x.W1 && x.b1 && x.W2 && x.b2 && x.aff && x.hid && x.g_aff && x.g && x.adam, "exposure: NULL buffer in lk_exposure_desc");
     LK_REQUIRE(x.feat_first >= 0 && x.feat_count >= 0 && x.feat_first + x.feat_count <= x.F, "exposure: bad trainable feature range");
@@ -634,6 +522,13 @@ int lk_launch_exposure_step(const lk_exposure_desc& x, int mode, int step, float
     a.step_feat = (float)((double)x.lr_feat / bc1);
     a.bc2_sqrt = (float)sqrt(bc2); a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.feat_first = x.feat_first; a.feat_count = x.feat_count; a.mode = mode;
+    *out = a;
+    return LK_OK;
+}
+int lk_launch_exposure_step(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, hipStream_t st) {
+    ExposureStepArgs a;
+    const int rc = lk_exposure_step_args(x, mode, step, beta1, beta2, eps, &a);
+    if (rc != LK_OK) return rc;
     hipLaunchKernelGGL(k_exposure_step, dim3(1), dim3(256), 0, st, a);
     return LK_OK;
 }

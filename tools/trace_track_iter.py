@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Per-kernel medians of the steady TRACKING iterations inside a rocprofv3 --kernel-trace of tools/slam_run.py (any config): an iteration
+is what lies between two consecutive k_track_final launches less than 2 ms apart.
+
+    rocprofv3 --kernel-trace --output-format csv -d DIR -o b -- python tools/slam_run.py --frames 13 --config CFG --out /tmp/x.json
+    python tools/trace_track_iter.py DIR"""
+import collections
+import csv
+import glob
+import statistics
+import sys
+
+f = glob.glob(sys.argv[1] + '/**/b_kernel_trace.csv', recursive=True)[0]
+rows = []
+for r in csv.DictReader(open(f)):
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')))
+rows.sort()
+marks = [i for i, r in enumerate(rows) if r[2] == 'k_track_final']
+periods, per = [], collections.defaultdict(list)
+cnt = collections.defaultdict(list)
+for a, b in zip(marks[:-1], marks[1:]):
+    p = rows[b][0] - rows[a][0]
+    if p > 2_000_000 or b - a > 40:
+        continue
+    periods.append(p)
+    c = collections.Counter()
+    for s, e, n in rows[a + 1:b + 1]:
+        per[n].append(e - s); c[n] += 1
+    for n, k in c.items():
+        cnt[n].append(k)
+periods = periods[len(periods) // 2:]          # the later frames: steady state
+print(f'{len(periods)} iterations, median period {statistics.median(periods) / 1e3:.1f} us')
+tot = 0.0
+for n, v in sorted(per.items(), key=lambda kv: -statistics.median(kv[1]) * statistics.median(cnt[kv[0]])):
+    m, k = statistics.median(v) / 1e3, statistics.median(cnt[n])
+    if len(v) < len(periods) // 4:
+        continue
+    tot += m * k
+    print(f'  {n[:60]:60s} x{k:g}  {m:7.1f} us')
+print(f'  sum of medians {tot:.1f} us')
