@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Per-kernel medians of the steady TRACKING iterations inside a rocprofv3 --kernel-trace of tools/slam_run.py (any config): an iteration
-is what lies between two consecutive k_track_final launches less than 2 ms apart.
+"""Per-kernel medians of the steady iterations inside a rocprofv3 --kernel-trace of tools/slam_run.py (any config): an iteration
+is what lies between two consecutive launches of a marker kernel less than 2 ms apart - k_track_final (tracking, the default),
+k_bwd_reduce (mapping, stage 'color'), k_adam (mapping, stage 'geometry').
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -o b -- python tools/slam_run.py --frames 13 --config CFG --out /tmp/x.json
-    python tools/trace_track_iter.py DIR"""
+    python tools/trace_track_iter.py DIR [marker]"""
 import collections
 import csv
 import glob
@@ -15,7 +16,8 @@ rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if r[2] == 'k_track_final']
+marker = sys.argv[2] if len(sys.argv) > 2 else 'k_track_final'
+marks = [i for i, r in enumerate(rows) if r[2] == marker]
 periods, per = [], collections.defaultdict(list)
 cnt = collections.defaultdict(list)
 for a, b in zip(marks[:-1], marks[1:]):
@@ -29,7 +31,7 @@ for a, b in zip(marks[:-1], marks[1:]):
     for n, k in c.items():
         cnt[n].append(k)
 periods = periods[len(periods) // 2:]          # the later frames: steady state
-print(f'{len(periods)} iterations, median period {statistics.median(periods) / 1e3:.1f} us')
+print(f'{marker}: {len(periods)} iterations, median period {statistics.median(periods) / 1e3:.1f} us')
 tot = 0.0
 for n, v in sorted(per.items(), key=lambda kv: -statistics.median(kv[1]) * statistics.median(cnt[kv[0]])):
     m, k = statistics.median(v) / 1e3, statistics.median(cnt[n])
