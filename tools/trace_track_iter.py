@@ -18,24 +18,26 @@ for r in csv.DictReader(open(f)):
 rows.sort()
 marker = sys.argv[2] if len(sys.argv) > 2 else 'k_track_final'
 marks = [i for i, r in enumerate(rows) if r[2] == marker]
-periods, per = [], collections.defaultdict(list)
-cnt = collections.defaultdict(list)
+its = []                                       # (period, {kernel: [durations]}) per iteration
 for a, b in zip(marks[:-1], marks[1:]):
     p = rows[b][0] - rows[a][0]
-    if p > 2_000_000 or b - a > 40:
+    if p > 2_000_000 or b - a > 60:
         continue
-    periods.append(p)
-    c = collections.Counter()
+    d = collections.defaultdict(list)
     for s, e, n in rows[a + 1:b + 1]:
-        per[n].append(e - s); c[n] += 1
-    for n, k in c.items():
-        cnt[n].append(k)
-periods = periods[len(periods) // 2:]          # the later frames: steady state
+        d[n].append(e - s)
+    its.append((p, d))
+its = its[int(len(its) * 0.6):]                # the later frames: steady state (the first mapped frame runs 5x the iterations on a small map)
+periods = [p for p, _ in its]
+per, cnt = collections.defaultdict(list), collections.defaultdict(list)
+for _, d in its:
+    for n, v in d.items():
+        per[n] += v; cnt[n].append(len(v))
 print(f'{marker}: {len(periods)} iterations, median period {statistics.median(periods) / 1e3:.1f} us')
 tot = 0.0
 for n, v in sorted(per.items(), key=lambda kv: -statistics.median(kv[1]) * statistics.median(cnt[kv[0]])):
     m, k = statistics.median(v) / 1e3, statistics.median(cnt[n])
-    if len(v) < len(periods) // 4:
+    if len(cnt[n]) < len(periods) // 2:
         continue
     tot += m * k
     print(f'  {n[:60]:60s} x{k:g}  {m:7.1f} us')
