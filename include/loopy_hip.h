@@ -116,6 +116,11 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
                                          * it (rendering.sample_near_pcl, Renderer.py:152-160) instead of linspace(near_end, far_bb) */
 #define LK_FLAG_FEATS_F16     (1u << 13) /* opt-in storage format: geo_feats / col_feats point at IEEE half tables [N,32] (64-byte rows; BASELINE
                                          * config 5 'fp16 features').  Everything computed from them, and their gradients, stays fp32 */
+#define LK_FLAG_EMBED_GRADS_ONLY (1u << 14) /* lk_render_bwd, with LK_FLAG_GRAD_WEIGHTS: of the decoder blob only the Fourier matrices
+                                           geo_decoder.embedder._B and (REL_POS) color_decoder.embedder_rel_pos._B receive gradients - the
+                                           colour decoder's and the rel-pos MLP's matrices are frozen (Mapper.py:531-541 with
+                                           fix_color_decoder, the end-of-sequence refinement): no weight-gradient rows are written and no
+                                           weight-gradient reduction is launched; the rest of g_weights is left untouched */
 
 typedef struct {
     /* ---- sizes */

@@ -29,6 +29,7 @@ FLAG_MAPPER_LOSS = 1 << 10
 FLAG_Z_GIVEN = 1 << 12
 FLAG_FEATS_F16 = 1 << 13
 FLAG_UNIT_LOSS_GRADS = 1 << 11
+FLAG_EMBED_GRADS_ONLY = 1 << 14
 
 EXPOSURE_MAX_F = 32
 ADAM_MAX_SEG = 16

@@ -391,21 +391,23 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     // d affine: the colour tiles stored their 12 sums, one small launch adds them into g_affine (49 adds per address instead of 782)
     if (color && d->affine && d->g_affine && !(skip & LK_SKIP_AFF_REDUCE)) lk_launch_reduce_partials(S0 + L.aff_part, lk_cdiv(P, 32), 12, d->g_affine, st);
     // mapper 'color' backward with one weight-gradient launch: every partial-sum reduction is deferred to ONE launch at the end
-    const bool defer = gw && color && (!relpos || lk_relpos_fused(flags));
+    // gwf: the colour decoder's / rel-pos MLP's matrices want gradients too (not only the Fourier matrices, LK_FLAG_EMBED_GRADS_ONLY)
+    const bool gwf = gw && !(flags & LK_FLAG_EMBED_GRADS_ONLY);
+    const bool defer = gwf && color && (!relpos || lk_relpos_fused(flags));
     LkWgradArgs wdef;
     wdef.n_units = 0; wdef.part = nullptr;
     // the Fourier-matrix partials of k_decode_bwd: summed by a rider of the gather launch when there is one, else by their own launch
     const bool bg_rides = gw && !defer && gf;
     if (gw && !defer && !bg_rides) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
-    const bool forked = gw && color && ss.ok;
+    const bool forked = gwf && color && ss.ok;
     hipStream_t wst = st;                      // stream of the weight-gradient launches
     if (forked) {
         (void)hipEventRecord(ss.fork, st);
         (void)hipStreamWaitEvent(ss.st, ss.fork, 0);
         wst = ss.st;
     }
-    if (gw && color) {
+    if (gwf && color) {
         // colour decoder weight gradients as streamed reductions over the saved rows (geometry decoder weights
         // other than embedder._B are frozen in every reference config: mapping.fix_geo_decoder = True)
         const float* act_h = d->act + (size_t)P * (LK_ACT_GEO_A + LK_ACT_COL_A);
@@ -465,7 +467,9 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         if (fuse_rb) rb_fused = rb;
         else lk_launch_relpos_bwd(rb, st);
         if (forked) { (void)hipEventRecord(ss.mid, st); (void)hipStreamWaitEvent(wst, ss.mid, 0); }
-        if (gw && !defer) lk_launch_reduce_partials(S0 + L.part_br, lk_cdiv(lk_cdiv(P, 4), 4), 32, d->g_weights + R_EB, st);
+        // (the fused kernel - kept in the embedding-only mode, where its linear1 tiles go unused - leaves one partial row per workgroup)
+        if (gw && !defer) lk_launch_reduce_partials(S0 + L.part_br, lk_relpos_fused(flags) ? lk_relpos_bwd_parts(P) : lk_cdiv(lk_cdiv(P, 4), 4), 32,
+                                                    d->g_weights + R_EB, st);
     }
 
     if (gf) {
@@ -497,7 +501,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         rr.R = d->R; rr.S = d->S; rr.z = d->z; rr.dp_total = S0 + L.dp_total; rr.g_rays_o = d->g_rays_o; rr.g_rays_d = d->g_rays_d;
         lk_launch_rays_bwd(rr, st);
     }
-    if (gw && relpos) {
+    if (gwf && relpos) {
         float* G = d->g_weights;
         if (lk_relpos_fused(flags)) {
             // linear1 was reduced inside k_relpos_bwd_fused (workgroup tiles), linear2 = samples x (wsum d c) (x) Hbar: two small launches

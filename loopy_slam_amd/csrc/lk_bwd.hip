@@ -104,7 +104,8 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
     const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + (H16 ? FRAGB_U4 : 0);
-    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    // (the colour trunk has no trainable Fourier matrix: with LK_FLAG_EMBED_GRADS_ONLY nothing here is a weight-gradient operand)
+    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0 && !(a.flags & LK_FLAG_EMBED_GRADS_ONLY);
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128;            // layer-major: + LK_COL_LAYER(P, layer)
     const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128;

@@ -578,15 +578,20 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     const bool rider_ok = pre && !xd && (phases & 3) == 3 && d->render.weights == d->weights_rw && d->render.g_weights != nullptr &&
                           (!(d->render.flags & LK_FLAG_REL_POS) || lk_relpos_fused(d->render.flags | LK_FLAG_GRAD_WEIGHTS)) &&
                           d->n_geo_dec + d->n_col_dec <= 16 && nb < (1ll << 31);
+    // fix_color_decoder (the end-of-sequence refinement, Mapper.py:531-535): of the colour-stage spans only embedder_rel_pos._B is left (or
+    // nothing) - the backward then skips the weight-gradient rows and reductions, and the matrix fragments never change
+    bool embed_only = true;
+    for (int k = 0; k < d->n_col_dec; ++k)
+        embed_only = embed_only && d->col_dec[k].offset >= R_EB && d->col_dec[k].offset + d->col_dec[k].n <= R_EB + 3 * 10;
     bool w_next_ready = false;
     bool x_fwd_done = it_begin > d->n_geo_iters;          // a later call of a phase-split sequence: the step launch of the iteration before did the forward
     for (int it = it_begin; it < it_end; ++it) {
         const bool color = it >= d->n_geo_iters;
-        const bool use_rider = rider_ok && color && it + 1 < it_end && d->n_col_dec > 0;
+        const bool use_rider = rider_ok && !embed_only && color && it + 1 < it_end && d->n_col_dec > 0;
         lk_render_desc rd = d->render;
         const bool xit = xd != nullptr && color;            // this iteration's loss is the exposure variant (its own launch after the composite)
         rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_UNIT_LOSS_GRADS | LK_FLAG_FEATS_F16)) | (color ? LK_FLAG_STAGE_COLOR : 0) | LK_FLAG_SAVE_ACT |
-                   LK_FLAG_GRAD_FEATS | LK_FLAG_GRAD_WEIGHTS | LK_FLAG_ZERO_ABSENT | LK_FLAG_MAPPER_LOSS;
+                   LK_FLAG_GRAD_FEATS | LK_FLAG_GRAD_WEIGHTS | LK_FLAG_ZERO_ABSENT | LK_FLAG_MAPPER_LOSS | (embed_only && color ? LK_FLAG_EMBED_GRADS_ONLY : 0);
         // d logits = w sigma' A with a LEARNED A: unit scale only relative to the power of two the exposure step keeps in xd->bwd_scale (the
         // kernels apply it on top of their 2^10); without that cell, or with the rel-pos MLP (its fused backward has no such hook): bf16 pieces
         const bool x_unit = xd && xd->bwd_scale && !(d->render.flags & LK_FLAG_REL_POS);
@@ -700,7 +705,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 rc = lk_launch_exposure_step(*xd, 3, it - d->n_geo_iters + 1, beta1, beta2, eps, st);
                 if (rc != LK_OK) return rc;
             }
-            if (color) {        // the matrix fragments are copies of the colour-decoder matrices, which only move in this stage
+            if (color && !embed_only) {        // the matrix fragments are copies of the colour-decoder matrices, which only move in this stage
                 // (rd.weights == weights_rw: the next iteration's forward reads what this step wrote)
                 if (pre && (phases & 3) == 3 && it + 1 < it_end && d->render.weights == d->weights_rw) repack_pending = true;
                 else {

@@ -46,9 +46,9 @@ def oracle_rays(c2w, depth_img, color_img, rnd):
 
 
 @pytest.mark.parametrize('backend', backends())
-@pytest.mark.parametrize('native', (True, False))
+@pytest.mark.parametrize('native,frozen', ((True, False), (False, False), (True, True)))
 @pytest.mark.parametrize('rel_pos', (True, False))
-def test_map_iterations_match_oracle(backend, rel_pos, native):
+def test_map_iterations_match_oracle(backend, rel_pos, native, frozen):
     """native: the whole loop as ONE lk_map_frame call (MapOptimizer.run); else one launch sequence per statement (iterate)."""
     eng = make_engine(backend)
     c2w, depth_img, color_img, pos, geo, col = mini_scene()
@@ -62,7 +62,10 @@ def test_map_iterations_match_oracle(backend, rel_pos, native):
     # ---------------- oracle loop (reference semantics: params = clones of the selected rows)
     ocfg = H.RenderCfg(rel_pos=rel_pos)
     Wt = {k: v.clone() for k, v in W.items()}
-    dec_names = list(steps.GEO_DECODER_PARAMS) + [n for n in steps.COLOR_DECODER_PARAMS]
+    # frozen = fix_color_decoder (the end-of-sequence refinement, Mapper.py:531-541): of the decoders only the Fourier matrices stay
+    # trainable - lk_map_frame then renders its backward with LK_FLAG_EMBED_GRADS_ONLY (no weight-gradient rows, no reduction launches)
+    dec_names = list(steps.GEO_DECODER_PARAMS) + ([n for n in steps.COLOR_DECODER_PARAMS] if not frozen else
+                                                  (['color_decoder.embedder_rel_pos._B'] if rel_pos else []))
     for n in dec_names:
         Wt[n].requires_grad_(True)
     geo_o, col_o = geo.clone(), col.clone()
@@ -92,7 +95,7 @@ def test_map_iterations_match_oracle(backend, rel_pos, native):
     pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
     knn = core.KnnIndex(eng, capacity=pos.shape[0])
     knn.build(pos_d)
-    mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, rows.to(eng.device), R, lrs, w_color=0.1)
+    mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, rows.to(eng.device), R, lrs, w_color=0.1, fix_color_decoder=frozen)
     mo.begin_frame()
     frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
     fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
@@ -121,6 +124,10 @@ def test_map_iterations_match_oracle(backend, rel_pos, native):
         assert float(torch.quantile(err, 0.999)) < 0.02 * lr, float(torch.quantile(err, 0.999))
         assert float(err.max()) < 2.0 * lr * iters, float(err.max())
     Wk = dec.unpack()
+    if frozen:          # the frozen matrices are bit for bit what they were
+        for n in steps.COLOR_DECODER_PARAMS:
+            if n in Wk and n not in dec_names:
+                assert torch.equal(Wk[n].reshape(W[n].shape), W[n]), n
     for n in dec_names:
         if n not in Wk:
             continue
