@@ -540,6 +540,9 @@ __device__ __forceinline__ u32x4 rpf_operand(const uint16_t* __restrict__ img, i
     return *reinterpret_cast<const u32x4*>(img + slot);
 }
 
+// WG = false (LK_FLAG_EMBED_GRADS_ONLY: the MLP's matrices are frozen, only the Fourier matrix and the feature rows get gradients): no
+// LDS images, no linear1 blocks, no per-sample Hbar / weight-sum rows, no barriers - the same d x / d feature / d B arithmetic.
+template <bool WG>
 __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, int sample0, int P_live, float* __restrict__ part,
                                                       uint16_t* __restrict__ stage_wg, int w, f32x16 (&acc)[2]) {
     const int lane = lk_opaque(lk_lane());            // per tile: see lk_opaque
@@ -613,7 +616,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
             const LkH8 b = lk_split_cth(G < 2 ? x0 : x1, G & 1);
-            rpf_stage(xt_hi, xt_lo, b, G & 1, G < 2 ? 0 : 32, KR, RL, h);
+            if (WG) rpf_stage(xt_hi, xt_lo, b, G & 1, G < 2 ? 0 : 32, KR, RL, h);
             if (G < 3) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) nx[nb] = lk_fragh_load(FH + FM20_FWDH, 4, G + 1, nb, lane);
@@ -639,7 +642,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
         const float4 v = *reinterpret_cast<const float4*>(dcrow + 8 * g + 4 * h);
         dout[4 * g] = v.x * wsc; dout[4 * g + 1] = v.y * wsc; dout[4 * g + 2] = v.z * wsc; dout[4 * g + 3] = v.w * wsc;
     }
-    {   // linear2 is reduced per SAMPLE (see relpos_bwd_wave): weight sum and weighted hidden vector
+    if (WG) {   // linear2 is reduced per SAMPLE (see relpos_bwd_wave): weight sum and weighted hidden vector
         const float wsum = lk_sum8(wgt);
         if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
     }
@@ -657,13 +660,15 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
             fa1 = lk_fragh_load(FH + FM21_TRH, 4, 1, nb + 1, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (WG) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v[4];
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) v[tt] = lk_sum8(wgt * hid[nb][4 * g + tt]);
-            if (live && nb_i == 0)
-                *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+                for (int tt = 0; tt < 4; ++tt) v[tt] = lk_sum8(wgt * hid[nb][4 * g + tt]);
+                if (live && nb_i == 0)
+                    *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) dhid[nb][q] = t[q] * lk_softplus100_grad_from_out(hid[nb][q]);
@@ -680,7 +685,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
 #pragma unroll
         for (int G = 0; G < 2; ++G) {
             const LkH8 b = lk_split_cth(dhid[nb], G);
-            rpf_stage(dt_hi, dt_lo, b, G, 32 * (nb & 1), RPF_DU, RL, h);
+            if (WG) rpf_stage(dt_hi, dt_lo, b, G, 32 * (nb & 1), RPF_DU, RL, h);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) dx[kb] = lk_mma3h(fx[2 * G + kb], b, dx[kb]);
         }
@@ -688,7 +693,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) fx[q] = lk_fragh_load(FH + FM20_TRH, 2, 2 * (nb + 1) + (q >> 1), q & 1, lane);
         }
-        if (nb & 1) {
+        if (WG && (nb & 1)) {
             // phase p = nb >> 1: blocks 2 p, 2 p + 1 of every wave's d hid are staged.  This wave's block of the product:
             // hidden units 32 (2 p + (w >> 1)) .., input units 32 (w & 1) .., over the rows of all four waves.
             __syncthreads();
@@ -742,12 +747,13 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
         }
 }
 
+template <bool WG>
 __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) {
     __shared__ float s_part[4][32];
-    __shared__ __attribute__((aligned(16))) uint16_t s_stage[4 * RPF_STAGE_HALVES];
+    __shared__ __attribute__((aligned(16))) uint16_t s_stage[WG ? 4 * RPF_STAGE_HALVES : 8];
     const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     if (threadIdx.x < 128) (&s_part[0][0])[threadIdx.x] = 0.0f;
-    {   // input units 52..55 of the wave's x image: the constant 1 (bias column) and three zero units; never rewritten
+    if (WG) {   // input units 52..55 of the wave's x image: the constant 1 (bias column) and three zero units; never rewritten
         uint16_t* xt = s_stage + w * RPF_STAGE_HALVES;
         for (int i = lane; i < 2 * 4 * 32; i += 64) {
             const int piece = i >> 7, u = KR + ((i >> 5) & 3);
@@ -760,11 +766,12 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) 
     // every wave runs every tile of the workgroup (barriers inside); rows past the end are dead lanes with weight 0
     const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;       // the rays without a reading sit behind the prefix
     for (int t = (int)blockIdx.x; t * 16 < P_live; t += (int)gridDim.x)
-        relpos_bwd_wave_fused(a, (t * 4 + w) * 4, P_live, s_part[w], s_stage, w, acc);
+        relpos_bwd_wave_fused<WG>(a, (t * 4 + w) * 4, P_live, s_part[w], s_stage, w, acc);
     __syncthreads();
     if (threadIdx.x < 32)
         a.part_br[(size_t)blockIdx.x * 32 + threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] +
                                                              s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+    if (!WG) return;
     // accumulator p of wave w: hidden units 32 (2 p + (w >> 1)) + row(q, h), input units 32 (w & 1) + (lane & 31)
     float* __restrict__ out = a.dw1_part + (size_t)blockIdx.x * (128 * 64);
     const int h = lane >> 5, j = lane & 31;
@@ -1313,7 +1320,8 @@ int lk_relpos_bwd_parts(int P) { const int n = lk_cdiv(lk_cdiv(P, 4), 4); return
 int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_RELPOS_BWD, st);
     const int waves = lk_cdiv(a.P, 4);
-    if (lk_relpos_fused(a.flags)) hipLaunchKernelGGL(k_relpos_bwd_fused, dim3(lk_relpos_bwd_parts(a.P)), dim3(256), 0, st, a);
+    if (lk_relpos_fused(a.flags) && (a.flags & LK_FLAG_EMBED_GRADS_ONLY)) hipLaunchKernelGGL(k_relpos_bwd_fused<false>, dim3(lk_relpos_bwd_parts(a.P)), dim3(256), 0, st, a);
+    else if (lk_relpos_fused(a.flags)) hipLaunchKernelGGL(k_relpos_bwd_fused<true>, dim3(lk_relpos_bwd_parts(a.P)), dim3(256), 0, st, a);
     else if (a.flags & LK_FLAG_FEATS_F16) hipLaunchKernelGGL(k_relpos_bwd<true>, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_relpos_bwd<false>, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;
@@ -1326,7 +1334,7 @@ int lk_launch_dw2_hbar(const LkRelposBwdArgs& a, float* dw2_part, hipStream_t st
 }
 int lk_occupancy_relpos_bwd_fused() {
     int n = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_relpos_bwd_fused, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_relpos_bwd_fused<true>, 256, 0);
     return n;
 }
 int lk_occupancy_wgrad() {
