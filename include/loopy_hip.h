@@ -216,6 +216,10 @@ typedef struct {
     int32_t row_len;
     int32_t zero_grad;                        /* clear the consumed gradient entries */
     int32_t p_f16;                            /* p is an IEEE half array (LK_FLAG_FEATS_F16 tables): read as fp32, stepped, rounded to nearest */
+    const uint8_t* row_flags;                 /* optional (row_index must be NULL, n a multiple of row_len): [n / row_len] bytes, only the rows
+                                                 with a non-zero flag are stepped.  Exact whenever the skipped rows have a zero gradient and zero
+                                                 moments (Adam leaves such an element bit for bit where it is): whole-map refinement over millions
+                                                 of rows of which an optimize_map call touches a few per cent (lk_map_frame sets the flags) */
 } lk_adam_seg;
 int lk_adam_step(const lk_adam_seg* host_segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream);
 

@@ -62,7 +62,8 @@ class RenderDesc(C.Structure):
 
 class AdamSeg(C.Structure):
     _fields_ = [('p', _fp), ('g', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int64), ('lr', C.c_float),
-                ('step', C.c_int32), ('row_index', _fp), ('row_len', C.c_int32), ('zero_grad', C.c_int32), ('p_f16', C.c_int32)]
+                ('step', C.c_int32), ('row_index', _fp), ('row_len', C.c_int32), ('zero_grad', C.c_int32), ('p_f16', C.c_int32),
+                ('row_flags', _fp)]
 
 
 class CopySeg(C.Structure):

@@ -477,6 +477,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         fs.g_geo_feats = d->g_geo_feats; fs.g_col_feats = d->g_col_feats;
         if (ex && ex->seg_list) { fs.seg_list = ex->seg_list; fs.seg_total = ex->seg_total; }      // sorted ahead of the loop (lk_map_frame)
         else if (ss.ok) (void)hipStreamWaitEvent(st, ss.link, 0);
+        fs.act_flag = ex ? ex->act_flag : nullptr;
         if (bg_rides) { fs.red_part = S0 + L.part_bg; fs.red_n = lk_cdiv(lk_cdiv(P, 32), 4); fs.red_width = 288; fs.red_out = d->g_weights + G_EB; }
         lk_launch_feat_scatter(fs, st);
     }

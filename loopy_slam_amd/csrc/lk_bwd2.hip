@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
                 if (cur >= 0) {
                     atomicAdd(a.g_geo_feats + (size_t)cur * LK_C + c, sg);
                     if (col) atomicAdd(a.g_col_feats + (size_t)cur * LK_C + c, sc);
+                    if (a.act_flag && c == 0) a.act_flag[cur] = 1;
                 }
                 cur = idx[u]; sg = 0.0f; sc = 0.0f;
             }
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
     }
     atomicAdd(a.g_geo_feats + (size_t)cur * LK_C + c, sg);
     if (col) atomicAdd(a.g_col_feats + (size_t)cur * LK_C + c, sc);
+    if (a.act_flag && c == 0) a.act_flag[cur] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_rays_bwd(LkRaysBwdArgs a) {

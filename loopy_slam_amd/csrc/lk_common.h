@@ -68,6 +68,8 @@ struct lk_knn_s {
     int32_t* seg_cnt = nullptr;    // [capacity + 1] rows per point (zero between calls): the feature-gradient gather of lk_render_bwd
     int32_t* seg_off = nullptr;    // [capacity + 1] their exclusive offsets
     int32_t* seg_sums = nullptr;   // scan scratch of seg_cnt
+    uint8_t* act_flag = nullptr;   // [capacity] rows that received a gradient in the running optimize_map call (lk_map_frame, rows = NULL:
+                                   // whole-map refinement steps only these rows, lk_adam_seg::row_flags); cleared at the call's first iteration
     int32_t n_scan_blocks;
 };
 

@@ -135,6 +135,7 @@ struct LkInterpBwdArgs {
 struct AdamSegDev {
     float* p; float* g; float* m; float* v; long long n; float step_size, bc2_sqrt;
     const int32_t* row_index; int row_len; int zero_grad; int p_f16;
+    const uint8_t* row_flags;                      // or NULL: only flagged rows are stepped (lk_adam_seg::row_flags)
 };
 // The Adam step of a mapper 'color' iteration as a rider of its reduction launch (lk_map_frame with no gradient exchange between the
 // backward and the step): every decoder gradient element has exactly ONE owner thread in k_bwd_reduce, which steps the element as
@@ -150,7 +151,8 @@ struct LkStepRider {
     AdamSegDev feat[2]; int n_feat, feat_gx;       // feature-row segments: n_feat * feat_gx extra blocks
 };
 struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
-                    int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
+                    int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale;
+                    uint8_t* act_flag; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
@@ -173,6 +175,7 @@ struct LkFeatScatterArgs {
     const float* red_part; int red_n, red_width, red_block0; float* red_out;
     const int32_t* live_rays; int S;               // rows of rays >= *live_rays take no part (NULL: all)
     int N;
+    uint8_t* act_flag;                             // or NULL: k_feat_gather flags every point it adds a gradient to (lk_knn_s::act_flag)
 };
 int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st, int batch = 1);        // counted: k_sample_interp already ran the count pass
 int lk_launch_scan_i32(int32_t* data, int32_t* out, int32_t* block_sums, int total, hipStream_t st,

@@ -473,6 +473,14 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
     const int64_t nb = lk_weight_blob_floats();
     const int64_t nrow = d->n_rows * LK_C;
+    // Whole-map refinement (rows = NULL: every row of the tables is a parameter, Mapper.py:884-897): Adam only visits the rows that have
+    // received a gradient since the call's first iteration - the gather flags them (lk_knn_s::act_flag), the step reads the flags.  A row
+    // that never got a gradient has zero moments, and Adam leaves such a row bit for bit where it is: the result is the dense step's, at
+    // 5 M points for 5 MB of flags + the touched rows instead of 10 GB per iteration.  (Not between the phases of a data-parallel
+    // caller: rows touched by the other ranks only would be missed.)
+    lk_knn_s* kn_h = d->render.knn;
+    const bool act_rows = d->rows == nullptr && (phases & 3) == 3 && kn_h->act_flag != nullptr && d->n_rows <= kn_h->capacity;
+    if (act_rows && it_begin == 0) LK_HIP_TRY(hipMemsetAsync(kn_h->act_flag, 0, (size_t)d->n_rows, st));
     const MapWork wk = map_work(R, d->render.S, d->iters);
     const int64_t Pn = (int64_t)R * d->render.S;
     // iterations per chunk of the work that runs ahead; chunk 0 is the first iteration alone (the loop waits for it), chunk c >= 1
@@ -563,12 +571,14 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             lk_adam_seg& s = seg[ns++];
             s.p = d->geo_feats_rw; s.g = d->render.g_geo_feats; s.m = d->adam_rows; s.v = d->adam_rows + nrow; s.n = nrow; s.lr = lr[1]; s.step = it + 1;
             s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1; s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
+            if (act_rows) { s.row_len = LK_C; s.row_flags = kn_h->act_flag; }
         }
         if (color) {
             lk_adam_seg& s = seg[ns++];
             s.p = d->col_feats_rw; s.g = d->render.g_col_feats; s.m = d->adam_rows + 2 * nrow; s.v = d->adam_rows + 3 * nrow; s.n = nrow; s.lr = lr[2];
             s.step = it - d->n_geo_iters + 1; s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1;
             s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
+            if (act_rows) { s.row_len = LK_C; s.row_flags = kn_h->act_flag; }
         }
         return true;
     };
@@ -656,6 +666,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 ex.seg_total = reinterpret_cast<int32_t*>(W0 + wk.seg_total) + it;
             }
             ex.live_rays = live;
+            ex.act_flag = act_rows ? kn_h->act_flag : nullptr;
             ex.dscale = (xd && (rd.flags & LK_FLAG_UNIT_LOSS_GRADS)) ? xd->bwd_scale : nullptr;
             LkStepRider sr;
             if (use_rider) {
@@ -677,6 +688,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                         AdamSegDev& f = sr.feat[sr.n_feat++];
                         f.p = seg[q].p; f.g = seg[q].g; f.m = seg[q].m; f.v = seg[q].v; f.n = seg[q].n; f.step_size = step_size; f.bc2_sqrt = bc2_sqrt;
                         f.row_index = seg[q].row_index; f.row_len = seg[q].row_len > 0 ? seg[q].row_len : 1; f.zero_grad = seg[q].zero_grad; f.p_f16 = seg[q].p_f16;
+                        f.row_flags = seg[q].row_flags;
                         if (seg[q].n > nmax) nmax = seg[q].n;
                     }
                 }

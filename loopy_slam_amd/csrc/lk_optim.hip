@@ -638,6 +638,9 @@ extern "C" int lk_adam_step(const lk_adam_seg* segs, int32_t n_seg, float beta1,
         a.s[i].row_index = segs[i].row_index; a.s[i].row_len = segs[i].row_len > 0 ? segs[i].row_len : 1;
         a.s[i].zero_grad = segs[i].zero_grad;
         a.s[i].p_f16 = segs[i].p_f16;
+        a.s[i].row_flags = segs[i].row_flags;
+        LK_REQUIRE(!segs[i].row_flags || (!segs[i].row_index && a.s[i].row_len <= 64 && segs[i].n % a.s[i].row_len == 0),
+                   "lk_adam_step: row_flags need row_index == NULL, row_len <= 64 and n a multiple of row_len");
         a.s[i].step_size = (float)((double)segs[i].lr / bc1);
         a.s[i].bc2_sqrt = (float)sqrt(bc2);
         if (segs[i].n > nmax) nmax = segs[i].n;

@@ -46,17 +46,19 @@ def oracle_rays(c2w, depth_img, color_img, rnd):
 
 
 @pytest.mark.parametrize('backend', backends())
-@pytest.mark.parametrize('native,frozen', ((True, False), (False, False), (True, True)))
+@pytest.mark.parametrize('native,frozen,all_rows', ((True, False, False), (False, False, False), (True, True, False), (True, True, True)))
 @pytest.mark.parametrize('rel_pos', (True, False))
-def test_map_iterations_match_oracle(backend, rel_pos, native, frozen):
-    """native: the whole loop as ONE lk_map_frame call (MapOptimizer.run); else one launch sequence per statement (iterate)."""
+def test_map_iterations_match_oracle(backend, rel_pos, native, frozen, all_rows):
+    """native: the whole loop as ONE lk_map_frame call (MapOptimizer.run); else one launch sequence per statement (iterate).
+    all_rows: the whole-map refinement - rows = NULL, every row a parameter; lk_map_frame then steps only the rows its gathers have flagged
+    (lk_adam_seg::row_flags), which must equal torch.optim.Adam over the whole tables."""
     eng = make_engine(backend)
     c2w, depth_img, color_img, pos, geo, col = mini_scene()
     W = syn.default_weights(seed=7)
     R, iters = 96, 3
     g = torch.Generator().manual_seed(11)
     rnd_all = torch.randint(0, HH * WW, (iters, R), generator=g, dtype=torch.int32)
-    rows = torch.arange(0, pos.shape[0], 2, dtype=torch.int32)               # "frustum" = every other point
+    rows = torch.arange(0, pos.shape[0], 1 if all_rows else 2, dtype=torch.int32)               # "frustum" = every other point
     lrs = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
     stages = ['geometry', 'color', 'color']
     # ---------------- oracle loop (reference semantics: params = clones of the selected rows)
@@ -95,7 +97,8 @@ def test_map_iterations_match_oracle(backend, rel_pos, native, frozen):
     pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
     knn = core.KnnIndex(eng, capacity=pos.shape[0])
     knn.build(pos_d)
-    mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, rows.to(eng.device), R, lrs, w_color=0.1, fix_color_decoder=frozen)
+    mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, None if all_rows else rows.to(eng.device), R, lrs, w_color=0.1,
+                            fix_color_decoder=frozen)
     mo.begin_frame()
     frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
     fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
@@ -112,6 +115,10 @@ def test_map_iterations_match_oracle(backend, rel_pos, native, frozen):
     r = rows.long()
     # selected rows moved by Adam, the others untouched
     assert float((geo_d.cpu()[r] - geo[r]).abs().max()) > 1e-3
+    if all_rows:        # rows no batch touched: exactly where they were (zero gradient, zero moments), on both sides
+        still = (geo_p.detach() == geo).all(1) & (col_p.detach() == col).all(1)
+        assert 0 < int(still.sum()) < still.numel()
+        assert torch.equal(geo_d.cpu()[still], geo[still]) and torch.equal(col_d.cpu()[still], col[still])
     other = torch.ones(pos.shape[0], dtype=torch.bool); other[r] = False
     assert torch.equal(geo_d.cpu()[other], geo[other]) and torch.equal(col_d.cpu()[other], col[other])
     # Adam's first steps are sign-like (lr * g / (|g| + 1e-8)): entries whose gradient is of the order of eps
