@@ -278,6 +278,10 @@ int lk_compact_large(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t
  * (flags is cleared by the caller).  When the whole map is optimised (final refinement, Mapper.py:884-897; BASELINE config 5)
  * a ray-sharded multi-GPU step exchanges the gradient rows of the union of the ranks' flags only. */
 int lk_touch_rows(const int32_t* nbr_idx, int64_t n, uint8_t* flags, int32_t N, void* stream);
+/* ORs flags[0..n) into the index's per-row flags of the running optimize_map call (rows whose Adam state may be non-zero: lk_map_frame
+ * with rows == NULL steps only these; it clears them at the call's first iteration and sets the rows its own batches touch).  A
+ * data-parallel caller passes the MAX-reduced flags of lk_touch_rows: rows only another rank touched receive gradient through the exchange. */
+int lk_knn_flag_rows(lk_knn_t knn, const uint8_t* flags, int64_t n, void* stream);
 /* ---------------------------------------------------------------- map maintenance around the hot loop
  * Frustum row selection, Mapper.get_mask_from_c2w (src/Mapper.py:165-217): out_index[0..*out_count) = ascending indices
  * of the points of pos[N,3] that project inside the image of the pose (cropped by `edge` pixels, negative = enlarged)
@@ -421,6 +425,9 @@ typedef struct {
     const lk_exposure_desc* exposure;   /* model.encode_exposure (HOST pointer) or NULL: the 'color' iterations render colour LOGITS and the loss
                                    applies sigmoid(logits @ rot_f + trans_f) of the ray's keyframe f = frame_id (Mapper.py:697-715);
                                    needs `work`; bwd_scratch sized WITHOUT LK_FLAG_UNIT_LOSS_GRADS (d logits = w sigma' A is unbounded) */
+    int32_t union_rows_flagged; /* rows == NULL, phase-split (data-parallel) callers: non-zero = between phase 1 and phase 2 of every iteration
+                                   the caller ORs the union of the rows ALL ranks touched into the index's row flags (lk_knn_flag_rows); the
+                                   step then visits the flagged rows only, as the single-process call does on its own (0: dense step) */
 } lk_map_desc;
 int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters);
 /* float offset inside `work` of the neighbour lists lk_map_frame keeps per iteration: int32 [iters][R*S][8] (what a data-parallel

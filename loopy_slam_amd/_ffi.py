@@ -118,6 +118,7 @@ class MapDesc(C.Structure):
         ('adam_dec', _fp),
         ('lr', (C.c_float * 3) * 2),
         ('iters', C.c_int32), ('n_geo_iters', C.c_int32), ('work', _fp), ('exposure', C.POINTER(ExposureDesc)),
+        ('union_rows_flagged', C.c_int32),
     ]
 
 
@@ -191,6 +192,7 @@ class LoopyLib:
             ('lk_inside_mask', [_fp, C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_compact_large', [_fp, C.c_int32, _fp, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_touch_rows', [_fp, C.c_int64, _fp, C.c_int32, C.c_void_p], C.c_int),
+            ('lk_knn_flag_rows', [C.c_void_p, _fp, C.c_int64, C.c_void_p], C.c_int),
             ('lk_map_wait_lists', [C.POINTER(MapDesc), C.c_int32, C.c_void_p], C.c_int),
         ):
             if hasattr(d, name):

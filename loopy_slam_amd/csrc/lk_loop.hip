@@ -476,11 +476,11 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     // Whole-map refinement (rows = NULL: every row of the tables is a parameter, Mapper.py:884-897): Adam only visits the rows that have
     // received a gradient since the call's first iteration - the gather flags them (lk_knn_s::act_flag), the step reads the flags.  A row
     // that never got a gradient has zero moments, and Adam leaves such a row bit for bit where it is: the result is the dense step's, at
-    // 5 M points for 5 MB of flags + the touched rows instead of 10 GB per iteration.  (Not between the phases of a data-parallel
-    // caller: rows touched by the other ranks only would be missed.)
+    // 5 M points for 5 MB of flags + the touched rows instead of 10 GB per iteration.  (Between the phases of a data-parallel caller only
+    // if it adds the rows the OTHER ranks touched, lk_knn_flag_rows / union_rows_flagged: they receive gradient through the exchange.)
     lk_knn_s* kn_h = d->render.knn;
-    const bool act_rows = d->rows == nullptr && (phases & 3) == 3 && kn_h->act_flag != nullptr && d->n_rows <= kn_h->capacity;
-    if (act_rows && it_begin == 0) LK_HIP_TRY(hipMemsetAsync(kn_h->act_flag, 0, (size_t)d->n_rows, st));
+    const bool act_rows = d->rows == nullptr && ((phases & 3) == 3 || d->union_rows_flagged) && kn_h->act_flag != nullptr && d->n_rows <= kn_h->capacity;
+    if (act_rows && it_begin == 0 && (phases & 1)) LK_HIP_TRY(hipMemsetAsync(kn_h->act_flag, 0, (size_t)d->n_rows, st));
     const MapWork wk = map_work(R, d->render.S, d->iters);
     const int64_t Pn = (int64_t)R * d->render.S;
     // iterations per chunk of the work that runs ahead; chunk 0 is the first iteration alone (the loop waits for it), chunk c >= 1

@@ -799,6 +799,20 @@ extern "C" int lk_touch_rows(const int32_t* nbr_idx, int64_t n, uint8_t* flags, 
     LK_LAUNCH_CHECK();
     return LK_OK;
 }
+__global__ __launch_bounds__(256) void k_or_flags(const uint8_t* __restrict__ src, long long n, uint8_t* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        if (src[i]) dst[i] = 1;
+}
+extern "C" int lk_knn_flag_rows(lk_knn_t knn, const uint8_t* flags, int64_t n, void* stream_) {
+    LK_REQUIRE(knn != nullptr && n >= 0 && n <= knn->capacity, "lk_knn_flag_rows: bad arguments");
+    if (n == 0) return LK_OK;
+    LK_REQUIRE(flags != nullptr && knn->act_flag != nullptr, "lk_knn_flag_rows: NULL buffer");
+    int gx = lk_cdiv(n, 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_or_flags, dim3(gx), dim3(256), 0, (hipStream_t)stream_, flags, (long long)n, knn->act_flag);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
 extern "C" int lk_compact_large(const uint8_t* mask, int32_t n, int32_t* out_index, int32_t* out_count, int32_t* block_scratch, void* stream_) {
     LK_REQUIRE(n >= 0 && out_count, "lk_compact_large: bad arguments");
     LK_REQUIRE(n == 0 || (mask && out_index && block_scratch), "lk_compact_large: NULL buffer");

@@ -182,4 +182,14 @@ class DistContext:
             if ag.event is not None:
                 ag.event.synchronize()
         ag.it = -1
+        self._last_ag = ag
         return ag.rows[:int(ag.count_host.item())]
+
+    def flag_union(self, mo):
+        """After the exchange of a whole-map iteration: the rows ANY rank touched join the index's row flags (lk_knn_flag_rows), so that
+        lk_map_frame's step visits them - a row only another rank touched has just received its gradient through the all-reduce."""
+        ag = getattr(self, '_last_ag', None)
+        if ag is None:
+            return
+        eng = mo.eng
+        eng.lib.check(eng.lib.dll.lk_knn_flag_rows(mo.knn.h, ptr(ag.flags), ag.flags.numel(), eng.stream), 'lk_knn_flag_rows')

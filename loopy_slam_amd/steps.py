@@ -284,6 +284,7 @@ class MapOptimizer:
         if need and (self._work is None or self._work.numel() < need):
             self._work = eng.empty(need)
         d.work = ptr(self._work) if need else 0
+        d.union_rows_flagged = 1 if (self.dist is not None and self.rows is None and self.geo.shape[0] <= self.knn.capacity) else 0
         self._nat_lists = (int(eng.lib.dll.lk_map_work_nbr_idx(self.R, self.cfg.S, n_iters)), n_iters) if need else None
         self._keep_native = (depth_stack, color_stack, c2w_stack, r2_stack, frame_id, rnd_all, log)
         dll = eng.lib.dll
@@ -296,6 +297,8 @@ class MapOptimizer:
                 if self.rows is None and it + 1 < n_iters and self._nat_lists is not None:
                     self.dist.prefetch_touched(self, it + 1)        # next iteration's row list, agreed beside this iteration's render
                 self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color', it=it)
+                if self.rows is None:
+                    self.dist.flag_union(self)      # rows touched by any rank: what the step of a whole-map iteration visits
                 eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 2, eng.stream), 'lk_map_frame')
         self.it += n_iters
         return log
