@@ -169,7 +169,7 @@ static void fill_sample_args(const lk_render_desc* d, int P, bool all_pos, LkSam
     sa.min_nn = d->min_nn;
     sa.z = d->z; sa.nbr_idx = d->nbr_idx; sa.nbr_w = d->nbr_w; sa.nbr_count = d->nbr_count; sa.c_geo = d->c_geo; sa.c_col = d->c_col;
     sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr; sa.live_rays = nullptr;
-    sa.seg_P = 0; sa.seg_cnt_stride = 0; sa.seg_live = nullptr;
+    sa.seg_P = 0; sa.seg_cnt_stride = 0; sa.seg_live = nullptr; sa.seg_key = nullptr;
     sa.rp_plain = nullptr; sa.rp_frag = nullptr; sa.rp_block0 = 0; sa.rp_copy_dst = nullptr; sa.rp_copy_n = 0; sa.rp_block1 = 0;
 }
 // z and the neighbour lists of a batch (the part of the sampler that does not read the feature tables); needs ZERO_ABSENT /
@@ -183,7 +183,7 @@ int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount
     fill_sample_args(d, d->R * d->S, true, sa);
     if (cnt) {
         sa.seg_cnt = d->knn->seg_cnt; sa.seg_cnt_stride = d->knn->seg_stride; sa.seg_rank = cnt->seg_rank; sa.row_mask = d->grad_row_mask;
-        sa.seg_P = cnt->P_iter; sa.seg_live = cnt->live_rays;
+        sa.seg_P = cnt->P_iter; sa.seg_live = cnt->live_rays; sa.seg_key = cnt->key_of;
     }
     return lk_launch_sample_interp(sa, st, 1);
 }

@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void k_seg_count(LkFeatScatterArgs a) {
     const int idx = a.nbr_idx[grow];
     int rk = -1;
     const bool skipped = a.live_rays && s >= a.live_rays[y] * a.S;              // ray without a reading: its rows carry no gradient
-    if (!skipped && idx >= 0 && a.nbr_w[grow] != 0.0f && a.nbr_count[(size_t)y * a.P + s] >= a.min_nn && (!a.row_mask || a.row_mask[idx]))
-        rk = atomicAdd(a.seg_cnt + (size_t)y * a.cnt_stride + idx, 1);
+    if (!skipped && idx >= 0 && a.nbr_w[grow] != 0.0f && a.nbr_count[(size_t)y * a.P + s] >= a.min_nn && (!a.row_mask || a.row_mask[idx])) {
+        const int key = a.key_of ? a.key_of[idx] : idx;
+        if (key >= 0) rk = atomicAdd(a.seg_cnt + (size_t)y * a.cnt_stride + key, 1);
+    }
     a.seg_rank[grow] = rk;
 }
 __global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
@@ -153,7 +155,10 @@ __global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
     const long long base = (long long)y * a.P * LK_K;
     const int32_t* __restrict__ off = a.seg_off + (size_t)y * a.cnt_stride;
     const int rk = a.seg_rank[base + row];
-    if (rk >= 0) a.seg_list[base + off[a.nbr_idx[base + row]] + rk] = (int)row;
+    if (rk >= 0) {
+        const int idx = a.nbr_idx[base + row];
+        a.seg_list[base + off[a.key_of ? a.key_of[idx] : idx] + rk] = (int)row;
+    }
     if (row == 0 && a.seg_total) a.seg_total[y] = off[a.N];
 }
 

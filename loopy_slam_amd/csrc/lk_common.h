@@ -68,6 +68,8 @@ struct lk_knn_s {
     int32_t* seg_cnt = nullptr;    // [capacity + 1] rows per point (zero between calls): the feature-gradient gather of lk_render_bwd
     int32_t* seg_off = nullptr;    // [capacity + 1] their exclusive offsets
     int32_t* seg_sums = nullptr;   // scan scratch of seg_cnt
+    int32_t* row_rank = nullptr;   // [capacity] lk_map_frame with a row list: position of a point in that list, -1 = not optimised - the KEY of the
+                                   // look-ahead row sort (its counters and scans then cover n_rows keys instead of all N points)
     uint8_t* act_flag = nullptr;   // [capacity] rows that received a gradient in the running optimize_map call (lk_map_frame, rows = NULL:
                                    // whole-map refinement steps only these rows, lk_adam_seg::row_flags); cleared at the call's first iteration
     int32_t n_scan_blocks;

@@ -27,6 +27,7 @@ struct LkSampleArgs {
     // search-only launches over several iterations (lk_map_frame's chunks): sample p belongs to iteration y = p / seg_P and counts into
     // seg_cnt + y * seg_cnt_stride; rays behind the live prefix seg_live[y] of their iteration are left out (0 / NULL: one batch)
     int seg_P, seg_cnt_stride; const int32_t* seg_live;
+    const int32_t* seg_key;                        // or NULL: as LkFeatScatterArgs::key_of
     // interpolation-only launches (mode 2): fragment repack of plain -> frag as a rider (k_interp_repack); NULL: none
     const float* rp_plain; float* rp_frag; int rp_block0;
     float* rp_copy_dst; int rp_copy_n, rp_block1;   // blocks >= rp_block1: rp_copy_dst[0 .. n) = rp_plain[..] (the stepped blob of the step rider, LkStepRider::w_next)
@@ -176,6 +177,8 @@ struct LkFeatScatterArgs {
     const int32_t* live_rays; int S;               // rows of rays >= *live_rays take no part (NULL: all)
     int N;
     uint8_t* act_flag;                             // or NULL: k_feat_gather flags every point it adds a gradient to (lk_knn_s::act_flag)
+    const int32_t* key_of;                         // or NULL (key = point index, N = points): sort key of a point, < 0 = the point's rows take no part;
+                                                   // N = number of keys (lk_knn_s::row_rank: the optimised rows of lk_map_frame)
 };
 int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st, int batch = 1);        // counted: k_sample_interp already ran the count pass
 int lk_launch_scan_i32(int32_t* data, int32_t* out, int32_t* block_sums, int total, hipStream_t st,
@@ -265,7 +268,7 @@ enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, L
        LK_SKIP_AFF_REDUCE = 256 /* bwd: the caller sums the per-tile d affine partials itself (k_track_final's exposure workgroup) */,
        LK_FUSE_SMALL = 128 /* tracker-sized batches: rel-pos MLP + decoders in one launch (fwd), rel-pos backward + interpolation backward in one (bwd) */ };
 // cnt: the batch holds n iterations of P_iter samples each (n <= LK_SEG_BATCH); their rows are counted per point on the way
-struct LkPresampleCount { int P_iter; int32_t* seg_rank; const int32_t* live_rays; };
+struct LkPresampleCount { int P_iter; int32_t* seg_rank; const int32_t* live_rays; const int32_t* key_of; };
 int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount* cnt = nullptr);
 bool lk_serial_mode();                                      // LK_SERIAL / lk_set_serial: one stream only
 // library-owned third stream (lk_map_frame's search ahead of the loop; small independent launches of the backward)

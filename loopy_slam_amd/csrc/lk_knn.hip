@@ -241,6 +241,7 @@ extern "C" int lk_knn_create(float cell_size, int64_t capacity_points, int64_t m
     if (e == hipSuccess) e = hipMemset(h->seg_cnt, 0, sizeof(int32_t) * (size_t)h->seg_stride * LK_SEG_BATCH);
     if (e == hipSuccess) e = hipMalloc((void**)&h->seg_off, sizeof(int32_t) * (size_t)h->seg_stride * LK_SEG_BATCH);
     if (e == hipSuccess) e = hipMalloc((void**)&h->seg_sums, sizeof(int32_t) * (size_t)h->seg_sums_stride * LK_SEG_BATCH);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->row_rank, sizeof(int32_t) * (size_t)capacity_points);
     if (e == hipSuccess) e = hipMalloc((void**)&h->act_flag, (size_t)capacity_points + 64);
     if (e == hipSuccess) e = hipMemset(h->act_flag, 0, (size_t)capacity_points + 64);
     if (e == hipSuccess) e = hipMemset(h->grid, 0, sizeof(LkGrid));
@@ -266,6 +267,7 @@ extern "C" int lk_knn_destroy(lk_knn_t h) {
     if (h->seg_off) (void)hipFree(h->seg_off);
     if (h->seg_sums) (void)hipFree(h->seg_sums);
     if (h->act_flag) (void)hipFree(h->act_flag);
+    if (h->row_rank) (void)hipFree(h->row_rank);
     delete h;
     return LK_OK;
 }

@@ -115,8 +115,10 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
                 const int y = a.seg_P ? pidx / a.seg_P : 0;
                 const bool skipped = a.seg_live && r - y * (a.seg_P / a.S) >= a.seg_live[y];
                 int rk = -1;
-                if (!skipped && ij >= 0 && wj != 0.0f && count >= a.min_nn && (!a.row_mask || a.row_mask[ij]))
-                    rk = atomicAdd(a.seg_cnt + (size_t)y * a.seg_cnt_stride + ij, 1);
+                if (!skipped && ij >= 0 && wj != 0.0f && count >= a.min_nn && (!a.row_mask || a.row_mask[ij])) {
+                    const int key = a.seg_key ? a.seg_key[ij] : ij;
+                    if (key >= 0) rk = atomicAdd(a.seg_cnt + (size_t)y * a.seg_cnt_stride + key, 1);
+                }
                 a.seg_rank[(size_t)pidx * LK_K + sub] = rk;
             }
             return;
