@@ -25,6 +25,7 @@ using namespace lkw;
 
 int lk_launch_exposure_step(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, hipStream_t st);      // lk_optim.hip
 int lk_exposure_step_args(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, ExposureStepArgs* out);
+int lk_adam_step_x(const lk_adam_seg* segs, int32_t n_seg, float beta1, float beta2, float eps, const ExposureStepArgs* xa, void* stream_);
 int lk_launch_loss_mapper_exposure(int R, const float* depth, const float* logits, const uint8_t* valid_ray, const float* gt_depth,
                                    const float* gt_color, const int32_t* frame_id, const float* aff, int F, float w_color,
                                    float* d_depth, float* d_logits, float* out_loss, float* g_aff, hipStream_t st);
@@ -725,12 +726,16 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 stepped_pending = true;
                 continue;
             }
-            int rc = lk_adam_step(seg, ns, beta1, beta2, eps, st);
-            if (rc != LK_OK) return rc;
-            if (xit) {          // exposure MLP backward + its Adam groups + the affines of the next iteration, one launch
-                rc = lk_launch_exposure_step(*xd, 3, it - d->n_geo_iters + 1, beta1, beta2, eps, st);
+            int rc;
+            if (xit) {          // exposure MLP backward + its Adam groups + the affines of the next iteration: one more block of the Adam launch
+                ExposureStepArgs xa;
+                rc = lk_exposure_step_args(*xd, 3, it - d->n_geo_iters + 1, beta1, beta2, eps, &xa);
                 if (rc != LK_OK) return rc;
+                rc = lk_adam_step_x(seg, ns, beta1, beta2, eps, &xa, st);
+            } else {
+                rc = lk_adam_step(seg, ns, beta1, beta2, eps, st);
             }
+            if (rc != LK_OK) return rc;
             if (color && !embed_only) {        // the matrix fragments are copies of the colour-decoder matrices, which only move in this stage
                 // (rd.weights == weights_rw: the next iteration's forward reads what this step wrote)
                 if (pre && (phases & 3) == 3 && it + 1 < it_end && d->render.weights == d->weights_rw) repack_pending = true;

@@ -7,6 +7,7 @@
 #include "lk_common.h"
 #include "lk_mask_dev.h"
 #include "lk_adam_dev.h"
+#include "lk_exposure_dev.h"
 
 #include <math.h>
 #include <string.h>
@@ -224,6 +225,15 @@ struct AdamArgs { AdamSegDev s[LK_ADAM_MAX_SEG]; int n_seg; float beta1, beta2, 
 
 // (element arithmetic and the per-segment block body: lk_adam_dev.h - k_bwd_reduce carries the same step as a rider)
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
+    lk_adam_seg_block(a.s[blockIdx.y], a.beta1, a.beta2, a.eps, (int)blockIdx.x, (int)gridDim.x);
+}
+// the same launch with one more row of blocks: block (0, n_seg) is the exposure step of the mapping iteration (lk_map_frame with
+// exposure encoding: it depends on the loss kernel's d affine only, and was a launch of its own behind this one)
+__global__ __launch_bounds__(256) void k_adam_x(AdamArgs a, ExposureStepArgs xa) {
+    if ((int)blockIdx.y == a.n_seg) {
+        if (blockIdx.x == 0) lk_exposure_step_body(xa, nullptr, 0);
+        return;
+    }
     lk_adam_seg_block(a.s[blockIdx.y], a.beta1, a.beta2, a.eps, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -506,7 +516,6 @@ __global__ __launch_bounds__(256) void k_loss_mapper_exposure(int R, const float
     }
 }
 
-#include "lk_exposure_dev.h"
 __global__ __launch_bounds__(256) void k_exposure_step(ExposureStepArgs a) { lk_exposure_step_body(a, nullptr, 0); }
 // step: 1-based Adam step of the exposure groups (they first step in the first iteration that uses them)
 int lk_exposure_step_args(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, ExposureStepArgs* out) {
@@ -622,9 +631,13 @@ extern "C" int lk_loss_mapper_exposure(int32_t R, const float* depth, const floa
     return LK_OK;
 }
 
+int lk_adam_step_x(const lk_adam_seg* segs, int32_t n_seg, float beta1, float beta2, float eps, const ExposureStepArgs* xa, void* stream_);
 extern "C" int lk_adam_step(const lk_adam_seg* segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream_) {
+    return lk_adam_step_x(segs, n_seg, beta1, beta2, eps, nullptr, stream_);
+}
+int lk_adam_step_x(const lk_adam_seg* segs, int32_t n_seg, float beta1, float beta2, float eps, const ExposureStepArgs* xa, void* stream_) {
     LK_REQUIRE(n_seg >= 0 && n_seg <= LK_ADAM_MAX_SEG, "lk_adam_step: too many segments");
-    if (n_seg == 0) return LK_OK;
+    if (n_seg == 0 && !xa) return LK_OK;
     LK_REQUIRE(segs != nullptr, "lk_adam_step: NULL segments");
     AdamArgs a;
     memset(&a, 0, sizeof(a));
@@ -646,10 +659,12 @@ extern "C" int lk_adam_step(const lk_adam_seg* segs, int32_t n_seg, float beta1,
         if (segs[i].n > nmax) nmax = segs[i].n;
     }
     a.n_seg = n_seg; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    if (nmax == 0) return LK_OK;
+    if (nmax == 0 && !xa) return LK_OK;
     int gx = lk_cdiv(nmax, 256);
     if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(k_adam, dim3(gx, n_seg), dim3(256), 0, (hipStream_t)stream_, a);
+    if (gx < 1) gx = 1;
+    if (xa) hipLaunchKernelGGL(k_adam_x, dim3(gx, n_seg + 1), dim3(256), 0, (hipStream_t)stream_, a, *xa);
+    else hipLaunchKernelGGL(k_adam, dim3(gx, n_seg), dim3(256), 0, (hipStream_t)stream_, a);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }
