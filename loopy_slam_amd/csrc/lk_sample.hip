@@ -256,6 +256,11 @@ int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hip
     hipLaunchKernelGGL(k_depth_stats, dim3(lk_cdiv(R, chunk)), dim3(256), 0, st, gt, R, chunk, far_out);
     return LK_OK;
 }
+// samples up to which the search + interpolation launch gives a query 16 lanes (above: 8).  Measured on the 5 000-ray tracker batches of the
+// TUM / ScanNet configs (25 000 samples): 8 lanes 33.2-33.9 ms per tracked frame, 16 lanes 34.1-35.2; the 1 500-ray batches (7 500 samples) keep 16
+#ifndef LK_T16_MAX_P
+#define LK_T16_MAX_P (1 << 14)
+#endif
 int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode) {
     if (mode == 1) {         // lists only, ahead of time: not one of the timed per-iteration launches
         const int cap = LK_SEARCH_WGS;      // measured: 256 / 512 / 1024 / unbounded -> map call 15.4 / 15.0 / 15.4 / 15.3 ms
@@ -282,7 +287,7 @@ int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode) {
         else hipLaunchKernelGGL((k_sample_interp<8, 2>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
         return LK_OK;
     }
-    if (a.P <= (1 << 16)) hipLaunchKernelGGL((k_sample_interp<16, 0>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
+    if (a.P <= LK_T16_MAX_P) hipLaunchKernelGGL((k_sample_interp<16, 0>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_sample_interp<8, 0>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }
