@@ -349,6 +349,131 @@ __global__ __launch_bounds__(1024) void k_top_grad(const float* __restrict__ gra
     if (t == 0) *out_count = s_out;
 }
 
+// ---- the same pool with MANY workgroups (images above 16 384 pixels).  One workgroup walks a 640 x 480 image six times and pays an LDS atomic
+// per pixel and pass on ONE compute unit: 0.9 ms per tracked frame of the TUM / ScanNet configs.  Here every pass is a launch over
+// LK_TG_WGS slices: per-slice LDS histograms added into a global 256-bin histogram per pass (every later launch re-derives the
+// selected prefix from the histograms itself - 64 lanes, a 256-entry scan per pass), per-slice counts of "above the K-th value" /
+// "equal to it", the membership mask with the ties ranked in pixel order across the slices, and the library's many-block compaction
+// (ascending indices).  Same pool, bit for bit.
+#define LK_TG_WGS 256
+struct TgScratch { unsigned* hist; unsigned* above; unsigned* ties; uint8_t* mask; int32_t* blocks; size_t mask_cap; };
+static TgScratch& tg_scratch() { static TgScratch s = {nullptr, nullptr, nullptr, nullptr, nullptr, 0}; return s; }
+
+// prefix (bit pattern so far) and rank (ascending rank inside the candidates) after `passes` radix passes; called by wave 0, all 64 lanes
+__device__ __forceinline__ void tg_select(const unsigned* __restrict__ hist_all, int passes, unsigned rank0, unsigned& prefix, unsigned& rank) {
+    const int t = lk_lane();
+    prefix = 0u; rank = rank0;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 24 - 8 * p;
+        const unsigned* hist = hist_all + 256 * p;
+        const unsigned h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+        const unsigned tot = h0 + h1 + h2 + h3;
+        unsigned incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned nbv = __shfl_up(incl, o);
+            if (t >= o) incl += nbv;
+        }
+        const unsigned excl = incl - tot;
+        unsigned r = 0, b = 0;
+        const bool mine = rank >= excl && rank < incl;
+        if (mine) {
+            r = rank - excl; b = 4 * t;
+            if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
+        }
+        const unsigned long long who = __ballot(mine);
+        const int src = __ffsll((long long)who) - 1;
+        rank = __shfl(r, src);
+        prefix |= __shfl(b, src) << shift;
+    }
+}
+__global__ __launch_bounds__(256) void k_tg_hist(const float* __restrict__ grad, int n, int K, int pass, int slice, unsigned* __restrict__ hist_all) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix;
+    const int t = threadIdx.x;
+    hist[t] = 0;
+    if (t < 64) {
+        unsigned prefix, rank;
+        tg_select(hist_all, pass, (unsigned)(n - K), prefix, rank);
+        if (t == 0) s_prefix = prefix;
+    }
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    const unsigned prefix = s_prefix, himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    const int i0 = blockIdx.x * slice, i1 = min(n, i0 + slice);
+    for (int i = i0 + t; i < i1; i += 256) {
+        const unsigned u = __float_as_uint(grad[i]);
+        if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (hist[t]) atomicAdd(hist_all + 256 * pass + t, hist[t]);
+}
+__global__ __launch_bounds__(256) void k_tg_count(const float* __restrict__ grad, int n, int K, int slice, const unsigned* __restrict__ hist_all,
+                                                  unsigned* __restrict__ above, unsigned* __restrict__ ties) {
+    __shared__ unsigned s_kth, s_a, s_t;
+    const int t = threadIdx.x;
+    if (t < 64) {
+        unsigned prefix, rank;
+        tg_select(hist_all, 4, (unsigned)(n - K), prefix, rank);
+        if (t == 0) { s_kth = prefix; s_a = 0; s_t = 0; }
+    }
+    __syncthreads();
+    const unsigned kth = s_kth;
+    const int i0 = blockIdx.x * slice, i1 = min(n, i0 + slice);
+    unsigned ca = 0, ct = 0;
+    for (int i = i0 + t; i < i1; i += 256) {
+        const unsigned u = __float_as_uint(grad[i]);
+        ca += u > kth ? 1u : 0u; ct += u == kth ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ca += __shfl_xor(ca, o); ct += __shfl_xor(ct, o); }
+    if (lk_lane() == 0) { atomicAdd(&s_a, ca); atomicAdd(&s_t, ct); }
+    __syncthreads();
+    if (t == 0) { above[blockIdx.x] = s_a; ties[blockIdx.x] = s_t; }
+}
+__global__ __launch_bounds__(256) void k_tg_mask(const float* __restrict__ grad, int n, int K, int W, int H0, int H1, int W0, int W1,
+                                                 const float* __restrict__ depth, int depth_limit, int slice, const unsigned* __restrict__ hist_all,
+                                                 const unsigned* __restrict__ above, const unsigned* __restrict__ ties, uint8_t* __restrict__ mask) {
+    __shared__ unsigned s_kth, s_above, s_before;
+    __shared__ int wa[4];
+    __shared__ int s_seen;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < 64) {
+        unsigned prefix, rank;
+        tg_select(hist_all, 4, (unsigned)(n - K), prefix, rank);
+        // pixels above the cut in the whole image; ties in the slices before this one
+        unsigned a = 0, b = 0;
+        for (int q = t; q < (int)gridDim.x; q += 64) { a += above[q]; if (q < (int)blockIdx.x) b += ties[q]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (t == 0) { s_kth = prefix; s_above = a; s_before = b; s_seen = 0; }
+    }
+    __syncthreads();
+    const unsigned kth = s_kth;
+    const int ties_needed = K - (int)s_above;
+    const int i0 = blockIdx.x * slice, i1 = min(n, i0 + slice);
+    for (int c0 = i0; c0 < i1; c0 += 256) {             // `slice` is a multiple of 256: the chunks keep pixel order
+        const int i = c0 + t;
+        const unsigned u = (i < i1) ? __float_as_uint(grad[i]) : 0u;
+        const bool tie = (i < i1) && u == kth;
+        const unsigned long long bt = __ballot(tie);
+        if (lane == 0) wa[w] = __popcll(bt);
+        __syncthreads();
+        int tie_rank = (int)s_before + s_seen + __popcll(bt & ((1ull << lane) - 1ull));
+        for (int q = 0; q < w; ++q) tie_rank += wa[q];
+        bool member = (i < i1) && (u > kth || (tie && tie_rank < ties_needed));
+        if (member) {
+            const int y = i / W, x = i - y * W;
+            member = y >= H0 && y < H1 && x >= W0 && x < W1;
+            if (member && depth) { const float d = depth[i]; member = d > 0.0f && (!depth_limit || d <= 5.0f); }
+        }
+        if (i < i1) mask[i] = member ? 1 : 0;
+        __syncthreads();
+        if (t == 0) s_seen += wa[0] + wa[1] + wa[2] + wa[3];
+        __syncthreads();
+    }
+}
+
 extern "C" int lk_top_grad_pixels(const float* grad_mag, int32_t H, int32_t W, int32_t K, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
                                   const float* depth, int32_t depth_limit, int32_t* out_index, int32_t* out_count, void* stream_) {
     LK_REQUIRE(H > 0 && W > 0 && grad_mag && out_index && out_count && K >= 0, "lk_top_grad_pixels: bad arguments");
@@ -356,8 +481,35 @@ extern "C" int lk_top_grad_pixels(const float* grad_mag, int32_t H, int32_t W, i
     if (K > n) K = n;
     hipStream_t st = (hipStream_t)stream_;
     if (K == 0) { LK_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(int32_t), st)); return LK_OK; }
-    hipLaunchKernelGGL(k_top_grad, dim3(1), dim3(1024), 0, st, grad_mag, n, (int)K, (int)W, (int)H0, (int)H1, (int)W0, (int)W1,
-                       depth, (int)depth_limit, out_index, out_count);
+    if (n <= 16384) {
+        hipLaunchKernelGGL(k_top_grad, dim3(1), dim3(1024), 0, st, grad_mag, n, (int)K, (int)W, (int)H0, (int)H1, (int)W0, (int)W1,
+                           depth, (int)depth_limit, out_index, out_count);
+        LK_LAUNCH_CHECK();
+        return LK_OK;
+    }
+    // library-owned scratch (grown on demand; like the library's streams it is shared state: one call at a time)
+    TgScratch& ts = tg_scratch();
+    if (!ts.hist) {
+        LK_HIP_TRY(hipMalloc((void**)&ts.hist, sizeof(unsigned) * (4 * 256 + 2 * LK_TG_WGS)));
+        ts.above = ts.hist + 4 * 256; ts.ties = ts.above + LK_TG_WGS;
+    }
+    if (ts.mask_cap < (size_t)n) {
+        LK_HIP_TRY(hipStreamSynchronize(st));           // (first frame of a resolution only) nobody may still read the old buffers
+        if (ts.mask) (void)hipFree(ts.mask);
+        if (ts.blocks) (void)hipFree(ts.blocks);
+        ts.mask = nullptr; ts.blocks = nullptr; ts.mask_cap = 0;
+        LK_HIP_TRY(hipMalloc((void**)&ts.mask, (size_t)n + 256));
+        LK_HIP_TRY(hipMalloc((void**)&ts.blocks, sizeof(int32_t) * ((size_t)lk_cdiv(n, 256) + 2)));
+        ts.mask_cap = (size_t)n;
+    }
+    const int slice = lk_cdiv(lk_cdiv(n, LK_TG_WGS), 256) * 256;
+    const int G = lk_cdiv(n, slice);
+    LK_HIP_TRY(hipMemsetAsync(ts.hist, 0, sizeof(unsigned) * 4 * 256, st));
+    for (int pass = 0; pass < 4; ++pass) hipLaunchKernelGGL(k_tg_hist, dim3(G), dim3(256), 0, st, grad_mag, n, (int)K, pass, slice, ts.hist);
+    hipLaunchKernelGGL(k_tg_count, dim3(G), dim3(256), 0, st, grad_mag, n, (int)K, slice, ts.hist, ts.above, ts.ties);
+    hipLaunchKernelGGL(k_tg_mask, dim3(G), dim3(256), 0, st, grad_mag, n, (int)K, (int)W, (int)H0, (int)H1, (int)W0, (int)W1, depth, (int)depth_limit,
+                       slice, ts.hist, ts.above, ts.ties, ts.mask);
+    lk_launch_compact_mb(ts.mask, n, out_index, out_count, ts.blocks, st);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

@@ -106,12 +106,14 @@ def test_radius_maps(backend):
     assert float(ra.min()) == np.float32(0.02 ** 2) and float(ra.max()) == np.float32(0.08 ** 2)
 
 
+@pytest.mark.parametrize('size', ((96, 128), (192, 176)))
 @pytest.mark.parametrize('backend', backends())
-def test_top_grad_pixels(backend):
+def test_top_grad_pixels(backend, size):
     """pool = top-K magnitudes of the whole image, then window + depth filters; K larger than the number of non-zero
-    gradients (cut inside the zero ties), K = all pixels, K = 0, the depth_limit variant, no depth."""
+    gradients (cut inside the zero ties), K = all pixels, K = 0, the depth_limit variant, no depth.  Two image sizes: up to 16 384 pixels
+    one workgroup does everything, above that the many-workgroup passes (histograms per slice, tie ranks across the slices, compaction)."""
     eng = make_engine(backend)
-    color, depth = _textured_frame(2)
+    color, depth = _textured_frame(2, *size)
     Hh, Ww = depth.shape
     g_ref = H.color_grad_mag(color.numpy()).astype(np.float32)
     g = eng.f32(torch.from_numpy(g_ref))
