@@ -40,15 +40,21 @@ __device__ __forceinline__ void ct_store32(float* __restrict__ row, const f32x16
 // Sample coordinates shared by both roles
 struct BwdSample {
     int sample, sp, h;
-    bool live;
+    bool live, store;       // live: carries gradient (loads come from sample sp);  store: a sample of the batch - its rows are written (zeros if !live)
     float a0, a1, a2;
 };
 __device__ __forceinline__ BwdSample bwd_sample(const LkDecodeBwdArgs& a, int tile, int lane) {
     BwdSample d;
     d.sample = tile * 32 + (lane & 31);
-    d.live = d.sample < a.P;
+    // live = carries gradient: samples of rays behind the live prefix of a partitioned batch sit in the last processed tile too.  Their loss
+    // gradient is zero, but their d raw is formed from what the forward left in raw for them - for a ray whose samples straddle into a SKIPPED
+    // tile that is stale memory, and 0 x NaN is NaN: such a lane took the tile's Fourier-matrix partial sums with it (found by poisoning the
+    // test buffers: a -1 index table freed and reused as a float buffer is NaN bit patterns)
+    const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;
+    d.live = d.sample < P_live;
+    d.store = d.sample < a.P;
     d.h = lane >> 5;
-    d.sp = d.live ? d.sample : a.P - 1;
+    d.sp = d.live ? d.sample : P_live - 1;            // (a processed sample: what the dead lanes load is defined)
     const int r = d.sp / a.S;
     const float z = a.z[d.sp];
     const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
@@ -167,7 +173,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         const float t2 = g0 * A[6] + g1 * A[7] + g2 * A[8];
         g0 = t0; g1 = t1; g2 = t2;
     }
-    if (want_w && live && h == 0 && w == 0) *reinterpret_cast<float4*>(a.dlogit + (size_t)sp * 4) = make_float4(g0, g1, g2, 0.0f);
+    if (want_w && d.store && h == 0 && w == 0) *reinterpret_cast<float4*>(a.dlogit + (size_t)d.sample * 4) = make_float4(g0, g1, g2, 0.0f);
     // dh4[own] = Wo^T d out (H16: times 2^10 from here on)
     g0 *= SC; g1 *= SC; g2 *= SC;
     f32x16 dh, dy;
@@ -220,7 +226,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
 #pragma unroll
                 for (int q = 0; q < 16; ++q) dys[q] = dy[q] * ISC;
             }
-            ct_store32(a.dy_col + LK_COL_LAYER(a.P, i) + (size_t)sp * 128 + w * 32, dys, live, lane);
+            ct_store32(a.dy_col + LK_COL_LAYER(a.P, i) + (size_t)d.sample * 128 + w * 32, dys, d.store, lane);
         }
 #pragma unroll
         for (int G = 0; G < 2; ++G) dc = PC::mma(un[G], PC::split(dh, G), dc);
@@ -282,12 +288,12 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         c0.x = ((c0.x + c1.x) + c2.x) + c3.x; c0.y = ((c0.y + c1.y) + c2.y) + c3.y;
         c0.z = ((c0.z + c1.z) + c2.z) + c3.z; c0.w = ((c0.w + c1.w) + c2.w) + c3.w;
         if (H16) { c0.x *= ISC; c0.y *= ISC; c0.z *= ISC; c0.w *= ISC; }
-        if (live) *reinterpret_cast<float4*>(a.dc_col + (size_t)sp * LK_C + 8 * w + 4 * h) = c0;
-        if (want_p && w == 0 && h == 0 && live) {
+        if (d.store) *reinterpret_cast<float4*>(a.dc_col + (size_t)d.sample * LK_C + 8 * w + 4 * h) = c0;
+        if (want_p && w == 0 && h == 0 && d.store) {
             const float x = ((s_o[0][lane] + s_o[1][lane]) + s_o[2][lane]) + s_o[3][lane];
             const float y = ((s_o[0][32 + lane] + s_o[1][32 + lane]) + s_o[2][32 + lane]) + s_o[3][32 + lane];
             const float z = ((s_o[0][64 + lane] + s_o[1][64 + lane]) + s_o[2][64 + lane]) + s_o[3][64 + lane];
-            *reinterpret_cast<float4*>(a.dp_embed_col + (size_t)sp * 4) = make_float4(x * ISC, y * ISC, z * ISC, 0.0f);      // d e was formed from the scaled d y
+            *reinterpret_cast<float4*>(a.dp_embed_col + (size_t)d.sample * 4) = make_float4(x * ISC, y * ISC, z * ISC, 0.0f);      // d e was formed from the scaled d y
         }
     }
 }
@@ -393,7 +399,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
             // i == 0: only the embedding receives gradient (below)
             __builtin_amdgcn_sched_barrier(0);      // keeps the fragment loads of the layers below from being hoisted to the top (registers)
         }
-        ct_store32(a.dc_geo + (size_t)sp * LK_C, dcg[0], live, lane);
+        ct_store32(a.dc_geo + (size_t)d.sample * LK_C, dcg[0], d.store, lane);
         // Embedding gradient d e = W_3[:, embedding]^T d y_3 + W_0^T d y_0, one 32-unit block at a time (one accumulator tile alive):
         // e_u = sin(x_u): ge_u = de_u cos(x_u);  dB[i][u] += sum_s ge_u a_i(s);  dp_i += ge_u 2 pi B[i][u]
         const LkB8 y0[2] = {lk_split_ct(dy, 0), lk_split_ct(dy, 1)};
@@ -405,7 +411,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
     }
     if (want_p) {
         dpx += __shfl_xor(dpx, 32); dpy += __shfl_xor(dpy, 32); dpz += __shfl_xor(dpz, 32);
-        if (live && h == 0) *reinterpret_cast<float4*>(a.dp_embed + (size_t)sp * 4) = make_float4(dpx, dpy, dpz, 0.0f);
+        if (d.store && h == 0) *reinterpret_cast<float4*>(a.dp_embed + (size_t)d.sample * 4) = make_float4(dpx, dpy, dpz, 0.0f);
     }
 }
 

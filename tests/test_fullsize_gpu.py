@@ -170,8 +170,9 @@ def test_render_is_deterministic_at_scale(R, rel_pos, unit):
     exact_until = (4 + 32 + 32 + 4 + 4 + 4 + 4 + 8 + 8 + 4) * P
     for r in runs[1:]:
         for k in ('act', 'raw', 'depth', 'color'):
-            assert torch.equal(r[k], runs[0][k]), k
-        assert torch.equal(r['scratch'][:exact_until], runs[0]['scratch'][:exact_until])
+            assert torch.equal(r[k].view(torch.int32), runs[0][k].view(torch.int32)), k
+        # (bit patterns: regions this mode never writes hold the NaN the tests poison uninitialised buffers with, tests/conftest.py)
+        assert torch.equal(r['scratch'][:exact_until].view(torch.int32), runs[0]['scratch'][:exact_until].view(torch.int32))
         # everything else (partials, gradient rows and the final gradients) to the noise of atomic summation order
         for k in ('scratch', 'g_geo', 'g_col', 'g_w'):
             a, b = r[k], runs[0][k]
