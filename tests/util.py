@@ -51,7 +51,8 @@ def make_engine(backend):
     if 'lib' not in _EMU:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipemu'))
         import build_emu
-        _EMU['lib'] = _ffi.LoopyLib(build_emu.build())
+        # LOOPY_EMU_LIB: another build of the same emulator sources (e.g. with -fsanitize=address, tools/emu_asan.sh)
+        _EMU['lib'] = _ffi.LoopyLib(os.environ.get('LOOPY_EMU_LIB') or build_emu.build())
     return core.Engine(lib=_EMU['lib'], device='cpu')
 
 
