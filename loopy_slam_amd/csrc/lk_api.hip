@@ -190,7 +190,7 @@ int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount
 
 extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
 
-int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays, const LkRepackRider* repack) {
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays, const LkRepackRider* repack, const LkTrackFinalArgs* pose) {
     int rc = check_desc(d, "lk_render_fwd");
     if (rc != LK_OK) return rc;
     if (d->R == 0) return LK_OK;
@@ -215,7 +215,8 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         sa.rp_plain = repack->src ? repack->src : d->weights; sa.rp_frag = repack->frag;
         if (repack->copy_dst && repack->src) { sa.rp_copy_dst = repack->copy_dst; sa.rp_copy_n = repack->copy_n; }
     }
-    lk_launch_sample_interp(sa, st, (skip & LK_PRESAMPLED) ? 2 : 0);
+    LK_REQUIRE(!pose || !(skip & LK_PRESAMPLED), "lk_render_fwd: the pose prologue belongs to the search launch");
+    lk_launch_sample_interp(sa, st, (skip & LK_PRESAMPLED) ? 2 : 0, pose);
     if (presort) {       // ... and sorted beside the decoders
         const int rc2 = seg_sort_async(d, P, true, st);
         if (rc2 != LK_OK) return rc2;

@@ -113,6 +113,8 @@ struct LkTrackFinalArgs {
     float step_T, step_q, bc2_sqrt, beta1, beta2, eps;            // lr / bias_correction1 per group, sqrt(bias_correction2)
     const float* next_pix_i; const float* next_pix_j; float* rays_o; float* rays_d;   // rays of the NEXT iteration's pixels, or NULL
     int do_update;                                                 // 0: only the rays of `cam` (before the first iteration)
+    const float* cam_in; const float* mv_in;                       // or NULL: the pose / moments are read from here and written to cam / adam_mv
+                                                                   // (the step as the prologue of the next iteration's search: every workgroup reads, one writes)
 };
 // interpolation backward: feature-row scatter (+ tracker: weights -> distances -> positions)
 struct LkInterpBwdArgs {
@@ -278,7 +280,8 @@ LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour
 // rider of the interpolation launch (LK_PRESAMPLED only): repack `src` (NULL: d->weights) into the fragment buffer `frag` (= d->weights_frag,
 // writable) and, with copy_dst, copy src[0 .. copy_n) over copy_dst (= d->weights, writable) - the blob stepped by the step rider
 struct LkRepackRider { float* frag; const float* src; float* copy_dst; int copy_n; };
-int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr, const LkRepackRider* repack = nullptr);
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr, const LkRepackRider* repack = nullptr,
+                       const LkTrackFinalArgs* pose = nullptr);       // pose: the tracking loop's pose step as the prologue of the search launch
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total, aff_part; };
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch
@@ -302,7 +305,7 @@ int lk_dw2_parts(int P);
 int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st);
 
 int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st);
-int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode = 0);     // 1: search only, 2: interpolation of given lists
+int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode = 0, const LkTrackFinalArgs* pose = nullptr);     // 1: search only, 2: interpolation of given lists; pose: k_sample_interp_pose
 int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st);
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st);
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st);

@@ -258,7 +258,7 @@ void adam_scalars(float lr, int step, float beta1, float beta2, float* step_size
     *bc2_sqrt = (float)sqrt(bc2);
 }
 int64_t al4(int64_t x) { return (x + 3) / 4 * 4; }
-struct TrackWork { int64_t gt_depth, gt_color, pix_i, pix_j, r2_ray, thr, resid, loss_part, pose_part, total; };
+struct TrackWork { int64_t gt_depth, gt_color, pix_i, pix_j, r2_ray, thr, resid, loss_part, pose_part, ring, total; };
 TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     TrackWork w;
     int64_t o = 0;
@@ -271,6 +271,7 @@ TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     w.resid = o; o += al4(R);
     w.loss_part = o; o += al4(2 * ((R + 255) / 256));
     w.pose_part = o; o += al4(12 * (int64_t)lk_bwd_pose_parts(R * S));
+    w.ring = o; o += 48;              // two poses [2][8] and their Adam moments [2][16]: the pose step as the prologue of the next search launch
     w.total = o;
     return w;
 }
@@ -332,6 +333,9 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     if (xd) { rd.affine = xd->aff; rd.g_affine = xd->g_aff; }
     const int R = rd.R, S = rd.S, iters = d->iters;
     const bool fused = R <= LK_TRACK_FUSED_MAX_R && d->work != nullptr;
+    // the pose step of an iteration as the prologue of the NEXT iteration's search launch (with exposure encoding the step keeps its own launch:
+    // the exposure workgroup rides in it)
+    const bool prologue = fused && d->exposure == nullptr && getenv("LK_NO_POSE_PROLOGUE") == nullptr;
     // (with exposure encoding d out passes through the learned affine first: unit scale only relative to xd->bwd_scale, which the fused
     // sequence hands to the kernels)
     if ((xd == nullptr || (xd->bwd_scale && fused)) && fabsf(d->w_color) <= 4.0f) rd.flags |= LK_FLAG_UNIT_LOSS_GRADS;
@@ -367,6 +371,10 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             if (rc != LK_OK) return rc;
         }
         hipLaunchKernelGGL(k_track_final, dim3(xd ? 2 : 1), dim3(1024), 0, st, fa, xa, (const float*)nullptr, 0);
+        if (prologue) {      // pose ring: slot 0 = the initial pose with zero moments
+            LK_HIP_TRY(hipMemcpyAsync(W0 + wk.ring, d->cam7, 7 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            LK_HIP_TRY(hipMemsetAsync(W0 + wk.ring + 16, 0, 32 * sizeof(float), st));
+        }
     } else if (xd) {
         const int rc = lk_launch_exposure_step(*xd, 2, 1, beta1, beta2, eps, st);
         if (rc != LK_OK) return rc;
@@ -393,7 +401,21 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             if (rc != LK_OK) return rc;
         }
         // ---- forward, loss, backward
-        int rc = lk_render_fwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE | LK_FUSE_SMALL) : 0);
+        // the pose step of the iteration before as the prologue of this iteration's search (k_sample_interp_pose): pose it - 1 -> it
+        LkTrackFinalArgs pa = fa;
+        if (prologue && it > 0) {
+            float sT, sq, b2;
+            adam_scalars(d->lr_T, it, beta1, beta2, &sT, &b2);
+            adam_scalars(d->lr_q, it, beta1, beta2, &sq, &b2);
+            float* hrow = d->hist + (size_t)(it - 1) * 7;
+            pa.step_T = sT; pa.step_q = sq; pa.bc2_sqrt = b2; pa.do_update = 1;
+            pa.hist_pre = d->hist_post ? nullptr : hrow; pa.hist_post = d->hist_post ? hrow : nullptr;
+            pa.cam_in = W0 + wk.ring + 8 * ((it - 1) & 1); pa.cam = W0 + wk.ring + 8 * (it & 1);
+            pa.mv_in = W0 + wk.ring + 16 + 16 * ((it - 1) & 1); pa.adam_mv = W0 + wk.ring + 16 + 16 * (it & 1);
+            pa.rays_o = const_cast<float*>(rd.rays_o); pa.rays_d = const_cast<float*>(rd.rays_d);
+            pa.next_pix_i = W0 + wk.pix_i + (size_t)it * R; pa.next_pix_j = W0 + wk.pix_j + (size_t)it * R;
+        }
+        int rc = lk_render_fwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE | LK_FUSE_SMALL) : 0, nullptr, nullptr, (prologue && it > 0) ? &pa : nullptr);
         if (rc != LK_OK) return rc;
         if (fused) {
             LkTrackLossArgs la;
@@ -427,7 +449,12 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         float step_T, step_q, bc2s;
         adam_scalars(d->lr_T, it + 1, beta1, beta2, &step_T, &bc2s);
         adam_scalars(d->lr_q, it + 1, beta1, beta2, &step_q, &bc2s);
-        if (fused) {
+        if (fused && prologue && it + 1 < iters) {
+            // (the step of this iteration runs inside the next iteration's search launch)
+        } else if (fused) {
+            if (prologue) {      // the last step: from the ring into the caller's pose and moments
+                fa.cam_in = W0 + wk.ring + 8 * (it & 1); fa.mv_in = W0 + wk.ring + 16 + 16 * (it & 1);
+            }
             fa.step_T = step_T; fa.step_q = step_q; fa.bc2_sqrt = bc2s; fa.do_update = 1;
             fa.hist_pre = d->hist_post ? nullptr : hist_row; fa.hist_post = d->hist_post ? hist_row : nullptr;
             const bool more = it + 1 < iters;

@@ -9,6 +9,7 @@
 #define LK_SEARCH_WGS 512
 #include "lk_knn_dev.h"
 #include "lk_kernels.h"
+#include "lk_track_dev.h"
 #include "lk_composite_dev.h"
 
 // torch.linspace(start, end, steps)[i] (symmetric evaluation, aten RangeFactories)
@@ -47,8 +48,11 @@ __global__ __launch_bounds__(256) void k_depth_stats(const float* __restrict__ g
 // MODE 0: search + interpolation.  The search depends on the rays and the positions only - not on what a mapping call optimises -
 // so lk_map_frame runs it for ALL its iterations ahead of time on a third stream (MODE 1: lists only) and every iteration starts
 // with MODE 2 (lists given: interpolation of the current features, the backward's row count).
-template <int T, int MODE>
-__device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int block) {
+// POSE (tracking loop, MODE 0): the rays are not read but derived from the pose s_cam[7] (LDS: the pose step of the iteration before ran as
+// this launch's prologue, k_sample_interp_pose) and the batch's pixels, with k_track_final's arithmetic; the group of a ray's first
+// sample also stores them for the kernels behind this one.
+template <int T, int MODE, bool POSE = false>
+__device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int block, const LkTrackFinalArgs* f = nullptr, const float* s_cam = nullptr) {
     const int sub = (int)threadIdx.x & (T - 1);
     const int p_raw = block * (256 / T) + (int)threadIdx.x / T;
     const bool live = p_raw < a.P;
@@ -78,9 +82,27 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
         const float far = a.far_stats ? a.far_stats[r / a.stats_chunk] : 0.0f;
         z = lk_linspace(a.near_end, far, a.S, s);
     }
-    const float qx = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
-    const float qy = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
-    const float qz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
+    float o3[3], d3[3];
+    if (POSE) {
+        float Rm[9];
+        lp_quat_rot(s_cam, Rm);
+        const float d0 = (f->next_pix_i[r] - f->cx) / f->fx, d1 = -(f->next_pix_j[r] - f->cy) / f->fy, d2 = -1.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            d3[c] = (d0 * Rm[3 * c] + d1 * Rm[3 * c + 1]) + d2 * Rm[3 * c + 2];
+            o3[c] = s_cam[4 + c];
+        }
+        if (live && s == 0 && sub == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { f->rays_d[3 * r + c] = d3[c]; f->rays_o[3 * r + c] = o3[c]; }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o3[c] = a.rays_o[3 * r + c]; d3[c] = a.rays_d[3 * r + c]; }
+    }
+    const float qx = lk_madd_rn(o3[0], d3[0], z);
+    const float qy = lk_madd_rn(o3[1], d3[1], z);
+    const float qz = lk_madd_rn(o3[2], d3[2], z);
     const float r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
     lk_knn_scan_coop<T>(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, sub, d, id);
     // w = 1/(D+1e-10), zero outside the radius, L1-normalised (decoder.py:210-220)
@@ -170,6 +192,16 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
 // sample groups: a chunk is 150 000 samples = 18 750 waves, and launched as such it takes every wave slot of the chip for ~110 us -
 // the iteration running beside it took 170 us instead of 78.  With at most LK_SEARCH_WGS workgroups (two per compute unit) the
 // search leaves three quarters of the slots to the loop's kernels, which are small ('geometry': 782 waves per launch).
+// Tracking loop: the pose step of the iteration BEFORE as the prologue of this iteration's search - every workgroup reduces the ray
+// moments and steps the pose for itself (the same arithmetic in the same order: the same pose everywhere), workgroup 0 also stores
+// pose, moments, gradient and log row (into the OTHER pose buffer: the others are still reading this one).  One launch (8-11 us of
+// dependent latency) less per tracking iteration.
+template <int T>
+__global__ __launch_bounds__(256) void k_sample_interp_pose(LkSampleArgs a, LkTrackFinalArgs f) {
+    __shared__ float s_cam[7];
+    lk_track_pose_step<4>(f, s_cam, blockIdx.x == 0);
+    sample_interp_block<T, 0, true>(a, (int)blockIdx.x, &f, s_cam);
+}
 template <int T, int MODE>
 __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
     if (MODE == 1) {
@@ -261,7 +293,13 @@ int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hip
 #ifndef LK_T16_MAX_P
 #define LK_T16_MAX_P (1 << 14)
 #endif
-int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode) {
+int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode, const LkTrackFinalArgs* pose) {
+    if (pose) {         // tracking loop, mode 0
+        LkProfScope prof_(LKK_SAMPLE_INTERP, st);
+        if (a.P <= LK_T16_MAX_P) hipLaunchKernelGGL((k_sample_interp_pose<16>), dim3(lk_cdiv(a.P, 16)), dim3(256), 0, st, a, *pose);
+        else hipLaunchKernelGGL((k_sample_interp_pose<8>), dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a, *pose);
+        return LK_OK;
+    }
     if (mode == 1) {         // lists only, ahead of time: not one of the timed per-iteration launches
         const int cap = LK_SEARCH_WGS;      // measured: 256 / 512 / 1024 / unbounded -> map call 15.4 / 15.0 / 15.4 / 15.3 ms
         auto grid = [&](int per) { const int n = lk_cdiv(a.P, per); return n < cap ? n : cap; };

@@ -13,31 +13,22 @@ __device__ __forceinline__ void lp_quat_rot(const float* __restrict__ cam, float
 }
 
 
-// pose gradient from the ray moments (k_pose_bwd's formulas), Adam on (T | q) (Tracker.py:317-352), the candidate pose log,
-// and the rays of the updated pose for the next iteration's pixels (get_rays_from_uv) - one workgroup, a few microseconds
-// NW = waves of the calling workgroup (all of its threads call)
+// pose gradient from the ray moments (k_pose_bwd's formulas), Adam on (T | q) (Tracker.py:317-352), the candidate pose log - by a whole
+// workgroup of NW waves (all of its threads call); the stepped pose (do_update = 0: the pose as it is) is left in s_cam[7] (LDS) behind a barrier.
+// write: store the pose, its moments, the gradient and the log row (exactly one workgroup of a launch does).
 template <int NW>
-__device__ __forceinline__ void lk_track_final_body(const LkTrackFinalArgs& a) {
+__device__ __forceinline__ void lk_track_pose_step(const LkTrackFinalArgs& a, float* __restrict__ s_cam, bool write) {
     __shared__ float s_w[NW][12];
     __shared__ float acc[12];
-    __shared__ float s_cam[7];
     const int t = threadIdx.x;
-    // Issued first, used last: the pixels of the next batch (and, in thread 0, the pose and its moments) do not depend on the partial sums -
-    // their round trip runs beside the reduction instead of behind it (the launch is a chain of dependent round trips, nothing else)
-    constexpr int RPT = 8;                                 // rays per thread: R <= 8192 in the fused loop (LK_MASK_REG_MAX)
-    float npi[RPT], npj[RPT];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int r = t + 64 * NW * q;
-        const bool on = a.rays_o != nullptr && r < a.R;
-        npi[q] = on ? a.next_pix_i[r] : 0.0f; npj[q] = on ? a.next_pix_j[r] : 0.0f;
-    }
     float cam0[7], mv0[14];
-    if (t == 0) {
+    if (t == 0) {       // issued first: these do not depend on the partial sums
+        const float* ci = a.cam_in ? a.cam_in : a.cam;
+        const float* mi = a.mv_in ? a.mv_in : a.adam_mv;
 #pragma unroll
-        for (int e = 0; e < 7; ++e) cam0[e] = a.cam[e];
+        for (int e = 0; e < 7; ++e) cam0[e] = ci[e];
 #pragma unroll
-        for (int e = 0; e < 14; ++e) mv0[e] = a.do_update ? a.adam_mv[e] : 0.0f;
+        for (int e = 0; e < 14; ++e) mv0[e] = a.do_update ? mi[e] : 0.0f;
     }
     if (a.do_update) {
         float v12[12];
@@ -65,7 +56,6 @@ __device__ __forceinline__ void lk_track_final_body(const LkTrackFinalArgs& a) {
         }
         __syncthreads();
         if (t == 0) {
-            float* cam = a.cam;
             const float qr = cam0[0], qi = cam0[1], qj = cam0[2], qk = cam0[3];
             const float N = qr * qr + qi * qi + qj * qj + qk * qk, s = 2.0f / N;
             const float P[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
@@ -85,25 +75,43 @@ __device__ __forceinline__ void lk_track_final_body(const LkTrackFinalArgs& a) {
             gc[4] = acc[9]; gc[5] = acc[10]; gc[6] = acc[11];
 #pragma unroll
             for (int e = 0; e < 7; ++e) {        // torch.optim.Adam, group T: elements 4..6, group q: 0..3 (as k_adam)
-                if (a.hist_pre) a.hist_pre[e] = cam0[e];
-                a.g_cam[e] = gc[e];
+                if (write && a.hist_pre) a.hist_pre[e] = cam0[e];
+                if (write) a.g_cam[e] = gc[e];
                 const float m = mv0[e] * a.beta1 + (1.0f - a.beta1) * gc[e];
                 const float v = mv0[7 + e] * a.beta2 + (1.0f - a.beta2) * (gc[e] * gc[e]);
                 const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-                a.adam_mv[e] = m; a.adam_mv[7 + e] = v;
+                if (write) { a.adam_mv[e] = m; a.adam_mv[7 + e] = v; }
                 const float p = cam0[e] - (e < 4 ? a.step_q : a.step_T) * (m / denom);
-                cam[e] = p;
+                if (write) a.cam[e] = p;
                 cam0[e] = p;
-                if (a.hist_post) a.hist_post[e] = p;
+                if (write && a.hist_post) a.hist_post[e] = p;
             }
         }
     }
-    if (!a.rays_o) return;
     if (t == 0) {
 #pragma unroll
-        for (int e = 0; e < 7; ++e) s_cam[e] = cam0[e];        // the stepped pose (before the first iteration: the initial one)
+        for (int e = 0; e < 7; ++e) s_cam[e] = cam0[e];        // the stepped pose (do_update = 0: the pose as it is)
     }
     __syncthreads();
+}
+
+// ... and the rays of that pose for the next iteration's pixels (get_rays_from_uv): k_track_final, one workgroup, a few microseconds
+template <int NW>
+__device__ __forceinline__ void lk_track_final_body(const LkTrackFinalArgs& a) {
+    __shared__ float s_cam[7];
+    const int t = threadIdx.x;
+    // Issued first, used last: the pixels of the next batch do not depend on the partial sums - their round trip runs beside the
+    // reduction instead of behind it (the launch is a chain of dependent round trips, nothing else)
+    constexpr int RPT = 8;                                 // rays per thread: R <= 8192 in the fused loop (LK_MASK_REG_MAX)
+    float npi[RPT], npj[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = t + 64 * NW * q;
+        const bool on = a.rays_o != nullptr && r < a.R;
+        npi[q] = on ? a.next_pix_i[r] : 0.0f; npj[q] = on ? a.next_pix_j[r] : 0.0f;
+    }
+    lk_track_pose_step<NW>(a, s_cam, true);
+    if (!a.rays_o) return;
     float Rm[9];
     lp_quat_rot(s_cam, Rm);
 #pragma unroll
