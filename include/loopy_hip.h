@@ -195,7 +195,12 @@ int lk_render_bwd(const lk_render_desc* d, void* stream);
  *   loss = sum|gt-depth| + w_color*sum|gt_color-color| (colour term only if use_color).
  * Tracker (src/Tracker.py:169-191): u = |gt-depth|/sqrt(var+1e-10); mask = u < 10*mean(u) & gt>0 & !nan;
  *   loss = sum clamp(u,0,1e3) + w_color*sum|gt_color-color|.
+ *   lk_loss_tracker's use_color is a flag word: LK_TRACK_USE_COLOR (the colour term takes part in the loss and its gradient) and
+ *   LK_TRACK_MEDIAN_MASK (tracking.handle_dynamic: False, Tracker.py:177-179: mask = |gt-depth| < 10*median(|gt-depth|) & gt>0 & !nan,
+ *   torch.median = the lower middle value, NaN if any residual is NaN; the loss terms are unchanged).
  * out_loss[0..3] = {loss, geo_loss, color_loss, #masked rays}; d_depth/d_color are overwritten. */
+#define LK_TRACK_USE_COLOR   1
+#define LK_TRACK_MEDIAN_MASK 2
 int lk_loss_mapper(int32_t R, const float* depth, const float* color, const uint8_t* valid_ray,
                    const float* gt_depth, const float* gt_color, float w_color, int32_t use_color,
                    float* d_depth, float* d_color, float* out_loss, void* stream);
@@ -371,7 +376,7 @@ typedef struct {
     float* g_cam7;              /* [7] */
     float* adam_mv;             /* [14] exp_avg | exp_avg_sq of the pose; zeroed by the call (fresh optimiser per frame) */
     float lr_T, lr_q;           /* separate_LR: cam_lr and 0.2 cam_lr (Tracker.py:317-333); otherwise both cam_lr */
-    float w_color; int32_t use_color;
+    float w_color; int32_t use_color;   /* flag word as for lk_loss_tracker: LK_TRACK_USE_COLOR | LK_TRACK_MEDIAN_MASK */
     int32_t hist_post;          /* 0: hist[it] = pose BEFORE iteration it (separate_LR: the candidate is a detached copy);
                                    1: pose AFTER its update (one leaf tensor stepped in place, Tracker.py:375-377) */
     float* hist;                /* [iters][7] candidate poses */

@@ -169,8 +169,9 @@ struct LkTrackLossArgs {
     const float* raw; const float* z; const int32_t* nbr_count; const float* gt_depth; const float* gt_color;
     float* depth; float* var; float* color; uint8_t* valid_ray;
     float* d_depth; float* d_color; float* d_raw; float* out4;
-    float* resid;                 // [R] normalised residual of every ray
-    float* part;                  // [blocks][2] per-workgroup (sum of residuals, #present rays)
+    float* resid;                 // [R] normalised residual of every ray (median: |gt - depth|, sign bit set for an absent ray)
+    float* part;                  // [blocks][2] per-workgroup (sum of residuals, #present rays); median: part[0] = 10 x the median
+    int median;                   // tracking.handle_dynamic: False (LK_TRACK_MEDIAN_MASK): k_track_median runs between the two passes
 };
 // pass 1: raw2outputs_nerf_color (common.py:382-422) + the uncertainty-normalised residual of every ray and its block sums
 __global__ __launch_bounds__(256) void k_track_composite(LkTrackLossArgs a) {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_track_composite(LkTrackLossArgs a) {
         const bool present = gd > 0.0f;                    // absent rays take no part in the mean (filtered before the render)
         tv = present ? fabsf(gd - o.depth) / sqrtf(o.var + 1e-10f) : 0.0f;
         cv = present ? 1.0f : 0.0f;
-        a.resid[r] = tv;
+        a.resid[r] = a.median ? (present ? fabsf(gd - o.depth) : -1.0f) : tv;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { tv += __shfl_xor(tv, o); cv += __shfl_xor(cv, o); }
@@ -200,16 +201,27 @@ __global__ __launch_bounds__(256) void k_track_composite(LkTrackLossArgs a) {
 }
 // pass 2: mask by 10 x the batch mean (every workgroup re-sums the <= 64 block partials in the same order: same threshold
 // everywhere), loss terms (Tracker.py:169-191), d depth / d colour and the composite's backward for them
+__global__ __launch_bounds__(1024) void k_track_median(LkTrackLossArgs a) {
+    __shared__ LkMedianShared S;
+    const float thr = lk_block_median10(a.resid, a.R, S);
+    if (threadIdx.x == 0) a.part[0] = thr;
+}
 __global__ __launch_bounds__(256) void k_track_loss2(LkTrackLossArgs a, int n_part) {
     __shared__ float sh[3][4];
-    float tsum = 0.0f, csum = 0.0f;
-    for (int b = 0; b < n_part; ++b) { tsum += a.part[2 * b]; csum += a.part[2 * b + 1]; }
-    const float thr = 10.0f * (tsum / fmaxf(csum, 1.0f));
+    float thr;
+    if (a.median) {
+        thr = a.part[0];
+    } else {
+        float tsum = 0.0f, csum = 0.0f;
+        for (int b = 0; b < n_part; ++b) { tsum += a.part[2 * b]; csum += a.part[2 * b + 1]; }
+        thr = 10.0f * (tsum / fmaxf(csum, 1.0f));
+    }
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
     float geo = 0.0f, col = 0.0f, cnt = 0.0f;
     if (r < a.R) {
-        const float d = a.depth[r], v = a.var[r], g = a.gt_depth[r], tt = a.resid[r];
-        const bool m = (tt < thr) && (g > 0.0f) && !(d != d) && !(v != v);
+        const float d = a.depth[r], v = a.var[r], g = a.gt_depth[r], tm = a.resid[r];
+        const float tt = a.median ? fabsf(g - d) / sqrtf(v + 1e-10f) : tm;          // the loss term stays uncertainty-normalised
+        const bool m = (tm < thr) && (g > 0.0f) && !(d != d) && !(v != v);
         float dd = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
         if (m) {
             geo = fminf(fmaxf(tt, 0.0f), 1e3f);
@@ -419,12 +431,14 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         if (rc != LK_OK) return rc;
         if (fused) {
             LkTrackLossArgs la;
-            la.R = R; la.S = S; la.min_nn = rd.min_nn; la.coef = rd.coef; la.w_color = d->w_color; la.use_color = d->use_color;
+            la.R = R; la.S = S; la.min_nn = rd.min_nn; la.coef = rd.coef; la.w_color = d->w_color;
+            la.use_color = d->use_color & LK_TRACK_USE_COLOR; la.median = (d->use_color & LK_TRACK_MEDIAN_MASK) ? 1 : 0;
             la.raw = rd.raw; la.z = rd.z; la.nbr_count = rd.nbr_count; la.gt_depth = rd.gt_depth; la.gt_color = gt_color;
             la.depth = rd.depth; la.var = rd.var; la.color = rd.color; la.valid_ray = rd.valid_ray;
             la.d_depth = const_cast<float*>(rd.d_depth); la.d_color = const_cast<float*>(rd.d_color);
             la.d_raw = rd.bwd_scratch + off.d_raw; la.out4 = log_row; la.resid = W0 + wk.resid; la.part = W0 + wk.loss_part;
             hipLaunchKernelGGL(k_track_composite, dim3(n_lp), dim3(256), 0, st, la);
+            if (la.median) hipLaunchKernelGGL(k_track_median, dim3(1), dim3(1024), 0, st, la);
             hipLaunchKernelGGL(k_track_loss2, dim3(n_lp), dim3(256), 0, st, la, n_lp);
         } else {
             rc = lk_loss_tracker(R, rd.depth, rd.var, rd.color, rd.gt_depth, d->gt_color, d->w_color, d->use_color,

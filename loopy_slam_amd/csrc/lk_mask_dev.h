@@ -107,3 +107,73 @@ __device__ __forceinline__ float lk_inside_thr(const unsigned (&u)[VPT], const u
     const float med = __uint_as_float(S.s_prefix);
     return need_median ? fminf(__fmul_rn(10.0f, med), mx12) : mx12;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// tracking.handle_dynamic: False (Tracker.py:177-179): the outlier mask of the tracker loss is |gt - depth| < 10 * median(|gt - depth|)
+// instead of the uncertainty-normalised residual against 10 x its mean.  resid[i] >= 0 (or NaN) for a present ray, sign bit set for
+// an absent one (gt_depth <= 0: the reference filters those before it renders).  ONE 1024-thread workgroup: 4-pass radix select
+// over the bit patterns (non-negative floats order as unsigned integers), values re-read from memory in every pass.
+// torch.median: the LOWER of the two middle values (rank (m - 1) / 2), NaN if any element is NaN (the mask is then empty).
+// No present ray: 0 (empty mask).
+struct LkMedianShared { unsigned hist[256]; unsigned s_prefix, s_rank, s_cnt, s_nan; };
+__device__ __forceinline__ float lk_block_median10(const float* __restrict__ resid, int n, LkMedianShared& S) {
+    const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
+    if (t == 0) { S.s_cnt = 0; S.s_nan = 0; }
+    __syncthreads();
+    unsigned cnt = 0, nan = 0;
+    for (int i = t; i < n; i += nt) {
+        const unsigned v = __float_as_uint(resid[i]);
+        if (!(v & 0x80000000u)) { ++cnt; nan += (v > 0x7f800000u) ? 1u : 0u; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); nan += __shfl_xor(nan, o); }
+    if (lane == 0) { atomicAdd(&S.s_cnt, cnt); atomicAdd(&S.s_nan, nan); }
+    __syncthreads();
+    const unsigned m = S.s_cnt;
+    if (m == 0) return 0.0f;
+    if (S.s_nan != 0) return __uint_as_float(0x7fc00000u);
+    __syncthreads();
+    if (t == 0) { S.s_prefix = 0; S.s_rank = (m - 1) / 2; }
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = t; b < 256; b += nt) S.hist[b] = 0;
+        __syncthreads();
+        const unsigned prefix = S.s_prefix;
+        const unsigned himask = (shift == 24) ? 0u : (0xffffffffu << (shift + 8));
+        for (int i0 = 0; i0 < n; i0 += nt) {         // workgroup-uniform trip count: every lane takes part in the ballots
+            const unsigned v = (i0 + t < n) ? __float_as_uint(resid[i0 + t]) : 0x80000000u;
+            const bool on = !(v & 0x80000000u) && (v & himask) == prefix;
+            const unsigned digit = (v >> shift) & 255u;
+            // one LDS add per (wave, distinct digit): residuals share their top bytes, same-address adds would serialise
+            unsigned long long pending = __ballot(on);
+            while (pending) {
+                const int leader = __ffsll((long long)pending) - 1;
+                const unsigned dl = __shfl(digit, leader);
+                const unsigned long long same = __ballot(on && digit == dl);
+                if (lane == leader) atomicAdd(&S.hist[dl], (unsigned)__popcll(same));
+                pending &= ~same;
+            }
+        }
+        __syncthreads();
+        if (t < 64) {
+            const unsigned rank = S.s_rank;
+            const unsigned h0 = S.hist[4 * t], h1 = S.hist[4 * t + 1], h2 = S.hist[4 * t + 2], h3 = S.hist[4 * t + 3];
+            const unsigned tot = h0 + h1 + h2 + h3;
+            unsigned incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned nbv = __shfl_up(incl, o);
+                if (t >= o) incl += nbv;
+            }
+            const unsigned excl = incl - tot;
+            if (rank >= excl && rank < incl) {
+                unsigned r = rank - excl, b = 4 * t;
+                if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
+                S.s_rank = r;
+                S.s_prefix = prefix | (b << shift);
+            }
+        }
+        __syncthreads();
+    }
+    return __fmul_rn(10.0f, __uint_as_float(S.s_prefix));
+}

@@ -63,10 +63,17 @@ __global__ __launch_bounds__(256) void k_loss_mapper(int R, const float* __restr
 }
 
 // ------------------------------------------------------------------ tracker loss (two passes: mean of the normalised residual)
+// MEDIAN (tracking.handle_dynamic: False, Tracker.py:177-179): scratch[r] = |gt - depth| (sign bit set for an absent ray), no sums;
+// k_loss_tracker_median then leaves 10 x the median in scratch[R] and pass 2 masks by it
+template <bool MEDIAN>
 __global__ __launch_bounds__(256) void k_loss_tracker_pass1(int R, const float* __restrict__ depth, const float* __restrict__ var,
                                                             const float* __restrict__ gt_depth, float* __restrict__ scratch) {
     __shared__ float sh[4];
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
+    if (MEDIAN) {
+        if (r < R) scratch[r] = (gt_depth[r] > 0.0f) ? fabsf(gt_depth[r] - depth[r]) : -1.0f;
+        return;
+    }
     // Rays with gt_depth <= 0 are "absent": the reference filters them out BEFORE rendering
     // (get_samples depth_filter + inside mask, Tracker.py:142-160), so they take no part in the mean.
     float t = 0.0f, c = 0.0f;
@@ -81,6 +88,13 @@ __global__ __launch_bounds__(256) void k_loss_tracker_pass1(int R, const float* 
     if (threadIdx.x == 0) { atomicAdd(scratch + R, t); atomicAdd(scratch + R + 1, c); }
 }
 
+__global__ __launch_bounds__(1024) void k_loss_tracker_median(int R, float* __restrict__ scratch) {
+    __shared__ LkMedianShared S;
+    const float thr = lk_block_median10(scratch, R, S);
+    if (threadIdx.x == 0) scratch[R] = thr;
+}
+
+template <bool MEDIAN>
 __global__ __launch_bounds__(256) void k_loss_tracker_pass2(int R, const float* __restrict__ depth, const float* __restrict__ var,
                                                             const float* __restrict__ color, const float* __restrict__ gt_depth,
                                                             const float* __restrict__ gt_color, float w_color, int use_color,
@@ -88,11 +102,13 @@ __global__ __launch_bounds__(256) void k_loss_tracker_pass2(int R, const float* 
                                                             float* __restrict__ d_color, float* __restrict__ out) {
     __shared__ float sh[4];
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
-    const float thr = 10.0f * (scratch[R] / fmaxf(scratch[R + 1], 1.0f));
+    const float thr = MEDIAN ? scratch[R] : 10.0f * (scratch[R] / fmaxf(scratch[R + 1], 1.0f));
     float geo = 0.0f, col = 0.0f, cnt = 0.0f;
     if (r < R) {
-        const float d = depth[r], v = var[r], g = gt_depth[r], t = scratch[r];
-        const bool m = (t < thr) && (g > 0.0f) && !(d != d) && !(v != v);
+        const float d = depth[r], v = var[r], g = gt_depth[r];
+        const float t = MEDIAN ? fabsf(g - d) / sqrtf(v + 1e-10f) : scratch[r];     // the loss term stays uncertainty-normalised
+        const float tm = MEDIAN ? scratch[r] : t;                                   // what the mask compares
+        const bool m = (tm < thr) && (g > 0.0f) && !(d != d) && !(v != v);
         float dd = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
         if (m) {
             geo = fminf(fmaxf(t, 0.0f), 1e3f);
@@ -167,36 +183,46 @@ __global__ __launch_bounds__(1024) void k_loss_mapper_1wg(int R, const float* __
     }
 }
 
+// MEDIAN: the mask compares |gt - depth| with 10 x its median (handle_dynamic: False); the residuals go through `scratch` [R] for the select
+template <bool MEDIAN>
 __global__ __launch_bounds__(1024) void k_loss_tracker_1wg(int R, const float* __restrict__ depth, const float* __restrict__ var,
                                                            const float* __restrict__ color, const float* __restrict__ gt_depth,
                                                            const float* __restrict__ gt_color, float w_color, int use_color,
                                                            float* __restrict__ d_depth, float* __restrict__ d_color,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ scratch) {
     __shared__ float sh[16];
+    __shared__ LkMedianShared S;
     constexpr int VPT = LK_LOSS_1WG_MAX / 1024;
-    float tv[VPT];
+    float tv[VPT], tm[VPT];
     float tsum = 0.0f, csum = 0.0f;
 #pragma unroll
     for (int q = 0; q < VPT; ++q) {
         const int r = (int)threadIdx.x + 1024 * q;
-        tv[q] = 0.0f;
+        tv[q] = 0.0f; tm[q] = 0.0f;
         if (r < R) {
             const bool present = gt_depth[r] > 0.0f;     // absent rays take no part in the mean (see pass1 above)
             tv[q] = present ? fabsf(gt_depth[r] - depth[r]) / sqrtf(var[r] + 1e-10f) : 0.0f;
             tsum += tv[q];
             csum += present ? 1.0f : 0.0f;
+            if (MEDIAN) { tm[q] = present ? fabsf(gt_depth[r] - depth[r]) : -1.0f; scratch[r] = tm[q]; }
         }
     }
-    tsum = block_sum_1024(tsum, sh);
-    csum = block_sum_1024(csum, sh);
-    const float thr = 10.0f * (tsum / fmaxf(csum, 1.0f));
+    float thr;
+    if (MEDIAN) {
+        __syncthreads();                                   // the workgroup's own stores to scratch
+        thr = lk_block_median10(scratch, R, S);
+    } else {
+        tsum = block_sum_1024(tsum, sh);
+        csum = block_sum_1024(csum, sh);
+        thr = 10.0f * (tsum / fmaxf(csum, 1.0f));
+    }
     float geo = 0.0f, col = 0.0f, cnt = 0.0f;
 #pragma unroll
     for (int q = 0; q < VPT; ++q) {
         const int r = (int)threadIdx.x + 1024 * q;
         if (r < R) {
             const float d = depth[r], v = var[r], g = gt_depth[r], t = tv[q];
-            const bool m = (t < thr) && (g > 0.0f) && !(d != d) && !(v != v);
+            const bool m = ((MEDIAN ? tm[q] : t) < thr) && (g > 0.0f) && !(d != d) && !(v != v);
             float dd = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
             if (m) {
                 geo += fminf(fmaxf(t, 0.0f), 1e3f);
@@ -580,18 +606,31 @@ extern "C" int lk_loss_tracker(int32_t R, const float* depth, const float* var, 
     LK_REQUIRE(R >= 0 && out_loss && scratch, "lk_loss_tracker: bad arguments");
     hipStream_t st = (hipStream_t)stream_;
     LK_REQUIRE(R == 0 || (depth && var && color && gt_depth && gt_color && d_depth && d_color), "lk_loss_tracker: NULL buffer");
+    const bool median = (use_color & LK_TRACK_MEDIAN_MASK) != 0;
+    use_color &= LK_TRACK_USE_COLOR;
     if (R > 0 && R <= LK_LOSS_1WG_MAX) {
-        hipLaunchKernelGGL(k_loss_tracker_1wg, dim3(1), dim3(1024), 0, st, (int)R, depth, var, color, gt_depth, gt_color,
-                           w_color, (int)use_color, d_depth, d_color, out_loss);
+        if (median)
+            hipLaunchKernelGGL(k_loss_tracker_1wg<true>, dim3(1), dim3(1024), 0, st, (int)R, depth, var, color, gt_depth, gt_color,
+                               w_color, (int)use_color, d_depth, d_color, out_loss, scratch);
+        else
+            hipLaunchKernelGGL(k_loss_tracker_1wg<false>, dim3(1), dim3(1024), 0, st, (int)R, depth, var, color, gt_depth, gt_color,
+                               w_color, (int)use_color, d_depth, d_color, out_loss, scratch);
         LK_LAUNCH_CHECK();
         return LK_OK;
     }
     LK_HIP_TRY(hipMemsetAsync(out_loss, 0, 4 * sizeof(float), st));
     if (R == 0) return LK_OK;
-    LK_HIP_TRY(hipMemsetAsync(scratch + R, 0, 2 * sizeof(float), st));
-    hipLaunchKernelGGL(k_loss_tracker_pass1, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, gt_depth, scratch);
-    hipLaunchKernelGGL(k_loss_tracker_pass2, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, color, gt_depth,
-                       gt_color, w_color, (int)use_color, (const float*)scratch, d_depth, d_color, out_loss);
+    if (median) {
+        hipLaunchKernelGGL(k_loss_tracker_pass1<true>, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, gt_depth, scratch);
+        hipLaunchKernelGGL(k_loss_tracker_median, dim3(1), dim3(1024), 0, st, (int)R, scratch);
+        hipLaunchKernelGGL(k_loss_tracker_pass2<true>, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, color, gt_depth,
+                           gt_color, w_color, (int)use_color, (const float*)scratch, d_depth, d_color, out_loss);
+    } else {
+        LK_HIP_TRY(hipMemsetAsync(scratch + R, 0, 2 * sizeof(float), st));
+        hipLaunchKernelGGL(k_loss_tracker_pass1<false>, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, gt_depth, scratch);
+        hipLaunchKernelGGL(k_loss_tracker_pass2<false>, dim3(lk_cdiv(R, 256)), dim3(256), 0, st, (int)R, depth, var, color, gt_depth,
+                           gt_color, w_color, (int)use_color, (const float*)scratch, d_depth, d_color, out_loss);
+    }
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

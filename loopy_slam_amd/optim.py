@@ -17,11 +17,19 @@ def loss_mapper(eng, st, gt_depth, gt_color, w_color, use_color, d_depth, d_colo
                                              ptr(d_depth), ptr(d_color), ptr(out4), eng.stream), 'lk_loss_mapper')
 
 
-def loss_tracker(eng, st, gt_depth, gt_color, w_color, use_color, d_depth, d_color, out4, scratch):
-    """Tracker.py:169-191 (handle_dynamic).  scratch: R+8 floats."""
+TRACK_USE_COLOR, TRACK_MEDIAN_MASK = 1, 2          # include/loopy_hip.h: flag word of lk_loss_tracker / lk_track_desc::use_color
+
+
+def track_loss_flags(use_color, handle_dynamic=True):
+    return (TRACK_USE_COLOR if use_color else 0) | (0 if handle_dynamic else TRACK_MEDIAN_MASK)
+
+
+def loss_tracker(eng, st, gt_depth, gt_color, w_color, use_color, d_depth, d_color, out4, scratch, handle_dynamic=True):
+    """Tracker.py:169-191.  handle_dynamic False: the mask compares |gt - depth| with 10 x its median (Tracker.py:177-179).
+    scratch: R+8 floats."""
     R = gt_depth.shape[0]
     eng.lib.check(eng.lib.dll.lk_loss_tracker(R, ptr(st.depth), ptr(st.var), ptr(st.color), ptr(gt_depth), ptr(gt_color),
-                                              C.c_float(w_color), int(bool(use_color)), ptr(d_depth), ptr(d_color),
+                                              C.c_float(w_color), track_loss_flags(use_color, handle_dynamic), ptr(d_depth), ptr(d_color),
                                               ptr(out4), ptr(scratch), eng.stream), 'lk_loss_tracker')
 
 

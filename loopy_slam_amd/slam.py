@@ -710,9 +710,7 @@ class Tracker:
         self.gt_camera = t.get('gt_camera', False)
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self.sample_with_color_grad, self.depth_limit = t.get('sample_with_color_grad', False), t.get('depth_limit', False)
-        if not t.get('handle_dynamic', True):
-            raise NotImplementedError('tracking.handle_dynamic: False (median-of-residual mask, Tracker.py:177-179) is not built; every '
-                                      'reference config uses the uncertainty-normalised mask')
+        self.handle_dynamic = t.get('handle_dynamic', True)       # False: median-of-residual outlier mask (Tracker.py:177-179)
         if self.depth_limit and not self.sample_with_color_grad:
             raise NotImplementedError('tracking.depth_limit without sample_with_color_grad (Tracker.py:142-146) is not built')
         self.gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219) + 3)      # device draws (select_uv)
@@ -791,7 +789,8 @@ class Tracker:
             to = steps.TrackOptimizer(eng, rcfg, self.decoders.dec, self.npc.knn, self.npc.cloud_pos(), self.npc.get_geo_feats(),
                                       self.npc.get_col_feats(), n_px, self.cam_lr, separate_lr=self.separate_LR,
                                       w_color=self.w_color_loss, use_color=self.use_color_in_tracking,
-                                      dynamic_radius=r2_query is not None, dist=getattr(slam, 'dist', None))
+                                      dynamic_radius=r2_query is not None, dist=getattr(slam, 'dist', None),
+                                      handle_dynamic=self.handle_dynamic)
             exposure = None
             if slam.encode_exposure:                # this frame's exposure feature starts from the shared one (Tracker.py:280-283)
                 self.exposure_feat = slam.exposure_feat.detach().clone().requires_grad_(True)

@@ -347,11 +347,12 @@ class TrackOptimizer:
     """Pose optimisation of one frame: Adam over the 7-vector (quaternion wxyz, translation)."""
 
     def __init__(self, eng, cfg, dec, knn, pos, geo_feats, col_feats, R, cam_lr, separate_lr=True, w_color=0.5,
-                 use_color=True, dynamic_radius=False, dist=None):
+                 use_color=True, dynamic_radius=False, dist=None, handle_dynamic=True):
         self.eng, self.cfg, self.dec, self.knn = eng, cfg, dec, knn
         self.pos, self.geo, self.col = pos, geo_feats, col_feats
         self.R, self.cam_lr, self.separate_lr = R, cam_lr, separate_lr
         self.w_color, self.use_color = w_color, use_color
+        self.handle_dynamic = handle_dynamic    # False: median-of-residual outlier mask (Tracker.py:177-179)
         self.batch = RayBatch(eng, R, dynamic_radius)
         self.st = core.RenderState(eng, R, cfg.S, need_act=True)
         self.gs = core.GradState(eng, geo_feats.shape[0], R, dec.n, feats=False, weights=False, rays=True)
@@ -405,7 +406,7 @@ class TrackOptimizer:
                                 self.dec, 'color', tracker=True, r2_ray=b.r2_ray, save_act=True, affine=aff,
                                 extra_flags=_ffi.FLAG_ZERO_ABSENT)
             optim.loss_tracker(eng, st, b.gt_depth, b.gt_color, self.w_color, self.use_color, b.d_depth, b.d_color,
-                               log[it], b.loss_scratch)
+                               log[it], b.loss_scratch, handle_dynamic=self.handle_dynamic)
             core.render_backward(eng, st, gs, b.d_depth, b.d_color)
             optim.pose_bwd(eng, cam, b.pix_i, b.pix_j, intr, gs.g_rays_o, gs.g_rays_d, self.g_cam)
             if self.separate_lr:                # T: lr, quaternion: 0.2*lr (Tracker.py:317-333)
@@ -456,7 +457,7 @@ class TrackOptimizer:
             self.adam_mv = eng.zeros(14)
         d.cam7, d.g_cam7, d.adam_mv = ptr(cam), ptr(self.g_cam), ptr(self.adam_mv)
         d.lr_T, d.lr_q = self.cam_lr, (0.2 * self.cam_lr if self.separate_lr else self.cam_lr)
-        d.w_color, d.use_color, d.hist_post = self.w_color, int(bool(self.use_color)), int(not self.separate_lr)
+        d.w_color, d.use_color, d.hist_post = self.w_color, optim.track_loss_flags(self.use_color, self.handle_dynamic), int(not self.separate_lr)
         d.hist, d.log, d.iters = ptr(hist), ptr(log), iters
         need = int(eng.lib.dll.lk_track_work_floats(self.R, self.cfg.S, iters)) if self.R <= 8192 else 0
         if need and (getattr(self, '_work', None) is None or self._work.numel() < need):

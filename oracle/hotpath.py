@@ -345,12 +345,17 @@ def mapper_loss(depth, color, valid_ray, gt_depth, gt_color, stage, w_color):
     return geo + w_color * col, geo, col, m
 
 
-def tracker_loss(depth, var, color, gt_depth, gt_color, w_color, use_color=True):
-    """Tracker.py:169-191 (handle_dynamic=True): uncertainty-normalised L1 + colour L1."""
+def tracker_loss(depth, var, color, gt_depth, gt_color, w_color, use_color=True, handle_dynamic=True):
+    """Tracker.py:169-191: uncertainty-normalised L1 + colour L1; the outlier mask compares the normalised residual with 10 x its
+    mean (handle_dynamic, the default of every config) or |gt - depth| with 10 x its median (Tracker.py:177-179)."""
     unc = var.detach()
     nan_mask = (~torch.isnan(depth)) & (~torch.isnan(unc))
     tmp = torch.abs(gt_depth - depth) / torch.sqrt(unc + 1e-10)
-    m = (tmp < 10 * tmp.mean()) & (gt_depth > 0) & nan_mask
+    if handle_dynamic:
+        m = (tmp < 10 * tmp.mean()) & (gt_depth > 0) & nan_mask
+    else:
+        t2 = torch.abs(gt_depth - depth)
+        m = (t2 < 10 * t2.median()) & (gt_depth > 0) & nan_mask
     geo = torch.clamp(tmp, min=0.0, max=1e3)[m].sum()
     col = torch.abs(gt_color - color)[m].sum()
     loss = geo + w_color * col if use_color else geo

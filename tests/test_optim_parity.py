@@ -105,6 +105,52 @@ def test_losses_large_batch(backend):
     assert float(dd.cpu()[~keep].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('R', (1, 2, 777, 20000))
+@pytest.mark.parametrize('backend', backends())
+def test_loss_tracker_median_mask(backend, R):
+    """tracking.handle_dynamic: False (Tracker.py:177-179): mask = |gt - depth| < 10 * median(|gt - depth|) (torch.median: the lower
+    middle value), loss terms unchanged.  One-workgroup form (R <= 16 384) and the three-launch form; absent rays (gt 0) are not part
+    of the reference's batch; outliers that the mask must reject; ties at the median; a NaN residual empties the mask."""
+    eng = make_engine(backend)
+    gen = torch.Generator().manual_seed(100 + R)
+    gd = torch.rand(R, generator=gen) * 3 + 0.5
+    if R > 2:
+        gd[torch.rand(R, generator=gen) < 0.05] = 0.0
+    depth = gd + 0.01 * torch.randn(R, generator=gen)
+    out_l = torch.rand(R, generator=gen) < 0.06
+    depth[out_l] = depth[out_l] + 0.7                                        # far beyond 10 x the median residual
+    if R > 100:
+        depth[10:60] = gd[10:60] + 0.0078125                                  # ties (exactly representable residuals)
+    var = torch.rand(R, generator=gen) * 0.01 + 1e-4
+    color, gc = torch.rand(R, 3, generator=gen), torch.rand(R, 3, generator=gen)
+    keep = gd > 0
+    for with_nan in (False, True):
+        dep = depth.clone()
+        if with_nan:
+            if R < 3:
+                continue
+            dep[int(torch.nonzero(keep)[1])] = float('nan')
+        st = _fake_state(eng, dep, var, color, torch.ones(R, dtype=torch.bool))
+        dd, dc, out, scr = eng.empty(R), eng.empty(R, 3), eng.empty(4), eng.empty(R + 8)
+        optim.loss_tracker(eng, st, eng.f32(gd), eng.f32(gc), 0.5, True, dd, dc, out, scr, handle_dynamic=False)
+        o = out.cpu().numpy()
+        if not bool(keep.any()):
+            assert o[3] == 0
+            continue
+        dl, cl = dep[keep].clone().requires_grad_(True), color[keep].clone().requires_grad_(True)
+        loss, geo, col, m = H.tracker_loss(dl, var[keep], cl, gd[keep], gc[keep], 0.5, handle_dynamic=False)
+        assert o[3] == int(m.sum())
+        if with_nan:
+            assert o[3] == 0 and o[0] == 0.0 and float(dd.cpu().abs().max()) == 0.0
+            continue
+        loss.backward()
+        assert int(m.sum()) < int(keep.sum()) or R < 20                       # the mask bites
+        assert abs(o[0] - loss.item()) <= 2e-5 * abs(loss.item()) and abs(o[1] - geo.item()) <= 2e-5 * abs(geo.item())
+        np.testing.assert_allclose(dd.cpu().numpy()[keep.numpy()], dl.grad.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(dc.cpu().numpy()[keep.numpy()], cl.grad.numpy(), atol=1e-7)
+        assert float(dd.cpu()[~keep].abs().max() if bool((~keep).any()) else 0.0) == 0.0
+
+
 @pytest.mark.parametrize('backend', backends())
 def test_adam_matches_torch_trajectory(backend):
     """G8: 20 steps, 3 tensors, lr switch geometry->colour, a tensor without gradient in stage 1."""

@@ -192,11 +192,13 @@ def test_long_map_call_matches_the_statement_path():
 
 
 @pytest.mark.parametrize('backend', backends())
-@pytest.mark.parametrize('native,separate', ((True, True), (False, True), (True, False), (False, False)))
-def test_track_iterations_match_oracle(backend, native, separate):
+@pytest.mark.parametrize('native,separate,handle_dynamic', ((True, True, True), (False, True, True), (True, False, True), (False, False, True),
+                                                            (True, True, False), (False, False, False)))
+def test_track_iterations_match_oracle(backend, native, separate, handle_dynamic):
     """native: the loop as ONE lk_track_frame call (fused one-workgroup kernels for batch assembly / loss / pose update);
     separate: tracking.separate_LR - two Adam groups and the candidate pose taken BEFORE the step (Replica); otherwise one
-    leaf tensor stepped in place, the candidate is the pose AFTER the step (TUM / ScanNet; Tracker.py:334-377)."""
+    leaf tensor stepped in place, the candidate is the pose AFTER the step (TUM / ScanNet; Tracker.py:334-377);
+    handle_dynamic False: the median-of-residual outlier mask (Tracker.py:177-179; a few depth pixels are pushed out so that it bites)."""
     eng = make_engine(backend)
     c2w, depth_img, color_img, pos, geo, col = mini_scene(1)
     W = syn.default_weights(seed=8)
@@ -214,7 +216,11 @@ def test_track_iterations_match_oracle(backend, native, separate):
     cam_leaf = cam0.clone().requires_grad_(True)
     opt = torch.optim.Adam([{'params': [T], 'lr': lr}, {'params': [q], 'lr': 0.2 * lr}]) if separate else \
         torch.optim.Adam([{'params': [cam_leaf], 'lr': lr}])
-    o_losses, o_cams = [], []
+    o_losses, o_cams, o_masked = [], [], []
+    if not handle_dynamic:          # depth outliers (a moving object in front of the wall) that 10 x the median residual rejects
+        gen_o = torch.Generator().manual_seed(5)
+        hit = torch.rand(depth_img.shape, generator=gen_o) < 0.04
+        depth_img = torch.where(hit & (depth_img > 0), depth_img * 0.8, depth_img)
     for it in range(iters):
         cam = torch.cat([q, T]) if separate else cam_leaf
         if separate:
@@ -230,7 +236,8 @@ def test_track_iterations_match_oracle(backend, native, separate):
         keep = gd > 0
         keep = keep & (gd <= H.inside_threshold(gd[keep]))
         out = H.render_batch(ocfg, ro[keep], rd[keep], gd[keep], pos, geo, col, W, 'color', tracker=True)
-        loss, _, _, _ = H.tracker_loss(out['depth'], out['var'], out['color'], gd[keep], gc[keep], 0.5)
+        loss, _, _, m_o = H.tracker_loss(out['depth'], out['var'], out['color'], gd[keep], gc[keep], 0.5, handle_dynamic=handle_dynamic)
+        o_masked.append(int(m_o.sum()))
         loss.backward()
         opt.step()
         if not separate:
@@ -242,10 +249,13 @@ def test_track_iterations_match_oracle(backend, native, separate):
     pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo), eng.f32(col)
     knn = core.KnnIndex(eng, capacity=pos.shape[0])
     knn.build(pos_d)
-    to = steps.TrackOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, R, lr, separate_lr=separate, w_color=0.5)
+    to = steps.TrackOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, R, lr, separate_lr=separate, w_color=0.5, handle_dynamic=handle_dynamic)
     to.native_loop = native
     best, log = to.track(eng.f32(cam0), eng.f32(depth_img), eng.f32(color_img), iters, win, INTR, rnd_all.to(eng.device))
     np.testing.assert_allclose(log[:, 0].cpu().numpy(), o_losses, rtol=5e-4)
+    assert log[:, 3].cpu().numpy().astype(int).tolist() == o_masked
+    if not handle_dynamic:
+        assert min(o_masked) < R - 2          # the mask did reject rays
     k = int(np.argmin(o_losses))
     np.testing.assert_allclose(best.cpu().numpy(), o_cams[k].numpy(), rtol=0, atol=2e-5)
 
