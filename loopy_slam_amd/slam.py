@@ -424,7 +424,8 @@ class Mapper:
         self.pixels_based_on_color_grad = m.get('pixels_based_on_color_grad', 0)
         self.color_refine, self.fix_color_decoder = m.get('color_refine', False), m.get('fix_color_decoder', False)
         self.keyframe_selection_method = m.get('keyframe_selection_method', 'overlap')
-        self.BA, self.ckpt_freq = m.get('BA', False), m.get('ckpt_freq', 500)
+        # bundle adjustment (Mapper.py:82-83, 957-962): off until the run has more than four keyframes, then as the config says
+        self.BA, self.BA_cfg, self.BA_cam_lr, self.ckpt_freq = False, m.get('BA', False), m.get('BA_cam_lr', 0.0002), m.get('ckpt_freq', 500)
         self.keep_refine_settings = False       # the reference leaves the refinement settings on (its mapper exits right after)
         self.logger = None                      # slam.Logger, attached by the caller that wants checkpoints
         self.last_add_counts, self.last_frame_pts_add, self.last_num_joint_iters = [], 0, 0
@@ -555,8 +556,6 @@ class Mapper:
         H, W = self.H, self.W
         intr = (self.fx, self.fy, self.cx, self.cy)
         init = idx == 0
-        if self.BA:
-            raise NotImplementedError('mapping.BA: True (camera group of the mapper, Mapper.py:541-566) is off in every reference config and not built')
         # 1. keyframes of the window
         segments = self.keyframe_selection_method == 'segments'
         sel = []
@@ -613,13 +612,23 @@ class Mapper:
                                 fix_color_decoder=self.fix_color_decoder, dist=getattr(self.slam, 'dist', None), exposure=exposure)
         mo.begin_frame()
         mo.gs.row_mask = row_mask               # the backward only scatters into the rows being optimised
+        geo_iters = self.geo_iter_first if init else int(num_joint_iters * self.geo_iter_ratio)
+        ba_cams = ba_train = None
+        if self.BA:
+            # Mapper.py:541-566: the window's poses as 7-vectors in a fourth Adam group; the oldest keyframe stays fixed against drift
+            # (Mapper.py:401, 547-548).  lr = BA_cam_lr while (geo_iter_ratio + 0.2) n <= it <= (geo_iter_ratio + 0.3) n, else 0
+            # (Mapper.py:602-607).  The loop then runs on the per-statement path (steps.MapOptimizer.enable_ba)
+            oldest = min(sel) if (len(keyframe_list) > 0 and not segments and len(sel) > 0) else None
+            ba_train = [oldest is None or k != oldest for k in sel] + [True]
+            ba_cams = torch.stack([get_tensor_from_camera(p) for p in frames_p]).float().to(eng.device).contiguous()
+            lo, hi = num_joint_iters * (self.geo_iter_ratio + 0.2), num_joint_iters * (self.geo_iter_ratio + 0.3)
+            mo.enable_ba(ba_cams, ba_train, lambda it: self.BA_cam_lr if lo <= it <= hi else 0.0)
         stack = (torch.stack(frames_d).contiguous(), torch.stack(frames_c).contiguous(),
                  torch.stack([p.float().to(eng.device) for p in frames_p]).contiguous(),
                  torch.stack(frames_r).contiguous() if frames_r is not None else None)
         fid = torch.arange(F, dtype=torch.int32).repeat_interleave(pix).to(eng.device)
         rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen_rays, dtype=torch.int32, device=eng.device)
         log = eng.zeros(num_joint_iters, 4)
-        geo_iters = self.geo_iter_first if init else int(num_joint_iters * self.geo_iter_ratio)
         # stage 'geometry' while joint_iter <= geo_iters (Mapper.py:594-597)
         mo.run(num_joint_iters, min(num_joint_iters, geo_iters + 1), stack, rnd, fid, (0, H, 0, W), intr, H, W, log)
         mo.finish()
@@ -627,6 +636,13 @@ class Mapper:
             self.slam.exposure_feat = self.cur_exposure_feat.detach().clone()
             self.exposure_feat_all.append(self.cur_exposure_feat.detach().cpu())          # Mapper.py:800
         self.last_log = log
+        if ba_cams is not None:                 # put the optimised poses back (Mapper.py:782-797)
+            bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=eng.device)
+            new = [torch.cat([get_camera_from_tensor(c), bottom], 0) for c in ba_cams]
+            for f, k in enumerate(sel):
+                if ba_train[f]:
+                    keyframe_dict[k]['est_c2w'] = new[f].to(keyframe_dict[k]['est_c2w']).clone()
+            return new[-1].to(cur_c2w).clone()
         return None
 
     def map_frame(self, idx, gt_color, gt_depth, gt_c2w, cur_c2w=None):
@@ -652,8 +668,12 @@ class Mapper:
                 self.fix_color_decoder, self.frustum_feature_selection, self.keyframe_selection_method = True, False, 'segments'
         num_joint_iters //= outer
         for _ in range(outer):
-            self.optimize_map(num_joint_iters, idx, gt_color, gt_depth, gt_c2w, self.keyframe_dict, self.keyframe_list, cur_c2w,
-                              color_refine=color_refine)
+            self.BA = bool(len(self.keyframe_list) > 4 and self.BA_cfg)          # start BA when having enough keyframes (Mapper.py:957-958)
+            ret = self.optimize_map(num_joint_iters, idx, gt_color, gt_depth, gt_c2w, self.keyframe_dict, self.keyframe_list, cur_c2w,
+                                    color_refine=color_refine)
+            if self.BA:                         # Mapper.py:962-964
+                cur_c2w = ret
+                slam.estimate_c2w_list[idx] = cur_c2w.detach().cpu()
         if saved is not None and not self.keep_refine_settings:
             (self.mapping_window_size, self.geo_iter_ratio, self.fix_color_decoder, self.frustum_feature_selection,
              self.keyframe_selection_method) = saved

@@ -162,6 +162,22 @@ class MapOptimizer:
         # exposure = (mlp_exposure torch module, [exposure_feat tensor per frame of the window]) for model.encode_exposure
         # (ScanNet): per-keyframe colour affine applied to the RENDERED colour logits (Mapper.py:697-715)
         self.exposure = ExposureState(eng, exposure[0], exposure[1]) if exposure is not None else None
+        self.ba = None
+
+    def enable_ba(self, cams7, trainable, lr_of_iteration):
+        """mapping.BA (Mapper.py:541-566): the poses of the window's frames join the optimiser as unnormalised-quaternion 7-vectors
+        (one Adam group, lr BA_cam_lr inside the schedule's window and 0 outside, Mapper.py:602-607), the batch is rendered with
+        is_tracker=True (Mapper.py:685: the interpolation weights become functions of the sample positions) and the rays of frame f
+        are rebuilt from cams7[f] in every iteration (Mapper.py:629-643).  The rays of a batch are grouped by frame (frame_id
+        ascending, equal counts).
+        cams7: [F,7] device tensor (stepped in place); trainable: F bools - the oldest keyframe stays fixed (Mapper.py:547-548) and
+        keeps the rays of its pose MATRIX; lr_of_iteration: it -> lr of the camera group.  Per-statement path only."""
+        eng = self.eng
+        F = cams7.shape[0]
+        assert cams7.is_contiguous() and cams7.shape == (F, 7) and len(trainable) == F and self.R % F == 0
+        self.ba = dict(cams=cams7, g=eng.zeros(F, 7), trainable=[bool(t) for t in trainable], pix=self.R // F, lr=lr_of_iteration)
+        if self.gs.g_rays_o is None:
+            self.gs.g_rays_o, self.gs.g_rays_d = eng.zeros(self.R, 3), eng.zeros(self.R, 3)
 
     def iterate(self, stage, frames, rnd, frame_id, window, intr, H, W, log_row=None):
         """One joint iteration (Mapper.py:576-735).
@@ -171,12 +187,19 @@ class MapOptimizer:
         depth_stack, color_stack, c2w_stack, r2_stack = frames
         optim.gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, window, intr, b.as_out(), r2_stack)
         optim.inside_mask(eng, b.gt_depth, None, b.thr, b.scratch_u32, depth_filtered=b.gt_depth)
+        ba = self.ba
+        if ba is not None:              # rays of the trainable frames from their 7-vectors (get_camera_from_tensor, Mapper.py:629-643)
+            n = ba['pix']
+            for f, tr in enumerate(ba['trainable']):
+                if tr:
+                    sl = slice(f * n, (f + 1) * n)
+                    optim.rays_from_pose(eng, ba['cams'][f], b.pix_i[sl], b.pix_j[sl], intr, b.rays_o[sl], b.rays_d[sl])
         out4 = log_row if log_row is not None else self._out4()
         xs = self.exposure if stage == 'color' else None
         # without exposure encoding the mapper loss (Mapper.py:691-720) is evaluated inside the composite kernel
         fused = None if xs is not None else (b.gt_color, self.w_color, b.d_depth, b.d_color, out4)
         core.render_forward(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col,
-                            self.dec, stage, r2_ray=b.r2_ray, save_act=True,
+                            self.dec, stage, r2_ray=b.r2_ray, save_act=True, tracker=ba is not None,
                             # L1 sums: |d depth| = 1, |d colour| = w - unit scale, the backward may use fp16 pieces.  NOT with exposure
                             # encoding: there d logits = w sigma' A with a LEARNED 3x3 A per keyframe, nothing bounds it
                             extra_flags=_ffi.FLAG_ZERO_ABSENT | (_ffi.FLAG_UNIT_LOSS_GRADS if self.exposure is None else 0),
@@ -190,8 +213,16 @@ class MapOptimizer:
                                                               _ffi.C.c_float(self.w_color), ptr(b.d_depth), ptr(b.d_color), ptr(out4),
                                                               ptr(xs.g_aff), eng.stream), 'lk_loss_mapper_exposure')
         core.render_backward(eng, st, gs, b.d_depth, b.d_color)
+        if ba is not None:              # d rays -> d pose of every trainable frame (rows of the fixed frame stay zero: Adam leaves it)
+            n = ba['pix']
+            for f, tr in enumerate(ba['trainable']):
+                if tr:
+                    sl = slice(f * n, (f + 1) * n)
+                    optim.pose_bwd(eng, ba['cams'][f], b.pix_i[sl], b.pix_j[sl], intr, gs.g_rays_o[sl], gs.g_rays_d[sl], ba['g'][f])
         if self.dist is not None:
             self.dist.all_reduce_grads(self, stage, it=None)
+            if ba is not None:
+                self.dist.all_reduce_vec(ba['g'])
         dlr, glr, clr = self.lrs[stage]
         segs = [(('gdec', k), self.dec.blob[o:o + n], gs.g_weights[o:o + n], dlr) for k, (o, n) in enumerate(self.geo_dec_ranges)]
         if stage == 'color':
@@ -207,6 +238,8 @@ class MapOptimizer:
         if xs is not None:
             xs.backward(xs.g_aff)
             segs += xs.adam_segs(mlp_lr=False if self.fix_color_decoder else dlr, only_last_feature=True)
+        if ba is not None:              # one group for all camera tensors (Mapper.py:565-566); elementwise, so one segment
+            segs.append(('cams', ba['cams'].view(-1), ba['g'].view(-1), float(ba['lr'](self.it))))
         self.adam.step(segs, zero_grad=True)
         if stage == 'color':
             # the geometry stage only moves the embedding matrices (read from the plain blob); the MFMA fragments are
@@ -220,7 +253,7 @@ class MapOptimizer:
         it < n_geo_iters.  rnd_all int32 [n_iters, R]; log [n_iters, 4].  Without exposure encoding this is lk_map_frame - one
         C-ABI call for the whole loop single-GPU, two calls per iteration around the gradient all-reduce multi-GPU; with
         exposure encoding the per-statement path (iterate)."""
-        if not self.native_loop or (self.exposure is not None and self.R > 16384):
+        if not self.native_loop or self.ba is not None or (self.exposure is not None and self.R > 16384):
             for it in range(n_iters):
                 self.iterate('geometry' if it < n_geo_iters else 'color', frames, rnd_all[it], frame_id, window, intr, H, W, log_row=log[it])
             return log

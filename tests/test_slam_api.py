@@ -279,6 +279,46 @@ def test_add_points_schedule_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', backends())
+def test_bundle_adjustment_in_the_mapper(backend):
+    """mapping.BA: True (Mapper.py:541-566, 782-797, 957-964): off until the run holds more than four keyframes; then the window's
+    poses (but the oldest keyframe's) are optimised with the map, written back into the keyframes, and the mapped frame's estimate is
+    replaced by the optimised pose.  handle_dynamic: False rides along (the tracker's median mask)."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['mapping'].update(BA=True, BA_cam_lr=0.002, every_frame=1, keyframe_every=1, iters=10, color_refine=False, mapping_window_size=4,
+                          keyframe_selection_method='global')
+    cfg['tracking'].update(handle_dynamic=False)
+    cfg['data']['n_frames'] = 7
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    seen = []
+    orig = ps.mapper.optimize_map
+
+    def spy(num_joint_iters, idx, *a, **k):
+        kd = a[3]                                   # keyframe_dict
+        before = [d['est_c2w'].clone() for d in kd]
+        r = orig(num_joint_iters, idx, *a, **k)
+        moved = [bool((d['est_c2w'] != b).any()) for d, b in zip(kd, before)]
+        seen.append(dict(idx=idx, ba=ps.mapper.BA, n_kf=len(before), moved=moved, ret=r, cur=a[5].clone()))
+        return r
+    ps.mapper.optimize_map = spy
+    est, gt = ps.run()
+    assert [c['ba'] for c in seen] == [c['n_kf'] > 4 for c in seen] and any(c['ba'] for c in seen) and not seen[0]['ba']
+    for c in seen:
+        if not c['ba']:
+            assert c['ret'] is None and not any(c['moved'])
+            continue
+        assert sum(c['moved']) == 2                                          # window of 3 keyframes: the oldest of them stays fixed
+        assert c['moved'].index(True) == c['n_kf'] - 2
+        assert c['ret'] is not None and tuple(c['ret'].shape) == (4, 4)
+        d = float((c['ret'][:3, 3] - c['cur'][:3, 3]).abs().max())
+        assert 0.0 < d < 0.05                                                 # the frame's pose moved, by Adam-sized steps
+        assert torch.allclose(est[c['idx']], c['ret'].cpu(), atol=0)
+        R3 = c['ret'][:3, :3]
+        assert float((R3 @ R3.T - torch.eye(3, device=R3.device)).abs().max()) < 1e-5
+    assert torch.isfinite(est).all() and float((est[:, :3, 3] - gt[:, :3, 3]).norm(dim=1).max()) < 0.1
+
+
+@pytest.mark.parametrize('backend', backends())
 def test_final_refinement_optimises_the_whole_map(backend):
     """mapping.color_refine (Mapper.py:884-897): on the last frame every row of the map is trainable (no frustum selection),
     the colour decoder is frozen, ten times the iterations in five optimize_map calls, no points are added."""

@@ -192,6 +192,100 @@ def test_long_map_call_matches_the_statement_path():
 
 
 @pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('rel_pos', (True, False))
+def test_map_iterations_with_ba_match_oracle(backend, rel_pos):
+    """mapping.BA (Mapper.py:541-566, 602-607, 629-643, 685, 782-797): three frames in the window, the oldest fixed, the other two
+    poses optimised as 7-vectors in one more Adam group whose lr is non-zero in a window of the colour iterations only (moments
+    accumulate from the first iteration on, as torch.optim.Adam does at lr 0); the batch is rendered with is_tracker=True.  Losses,
+    poses, feature rows and decoder weights against an autograd + torch.optim.Adam loop over the oracle's render."""
+    eng = make_engine(backend)
+    c2w, depth_img, color_img, pos, geo, col = mini_scene(3)
+    W = syn.default_weights(seed=9)
+    F, n, iters = 3, 40, 4
+    R = F * n
+    g = torch.Generator().manual_seed(21)
+    rnd_all = torch.randint(0, HH * WW, (iters, R), generator=g, dtype=torch.int32)
+    rows = torch.arange(0, pos.shape[0], 2, dtype=torch.int32)
+    lrs = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
+    stages = ['geometry', 'color', 'color', 'color']
+    cam_lr = lambda it: 0.002 if it in (1, 2) else 0.0
+    cam_c = H.c2w_to_cam(c2w)
+    offs = [torch.zeros(7), torch.tensor([0.0, 0.003, -0.002, 0.001, 0.004, -0.002, 0.003]), torch.tensor([0.0, -0.002, 0.002, 0.002, -0.003, 0.004, -0.002])]
+    cams0 = torch.stack([cam_c + o for o in offs])
+    c2w_stack = torch.stack([torch.cat([H.quat_to_c2w(c), torch.tensor([[0.0, 0.0, 0.0, 1.0]])]) for c in cams0])
+    trainable = [False, True, True]
+    # ---------------- oracle loop
+    ocfg = H.RenderCfg(rel_pos=rel_pos)
+    Wt = {k: v.clone() for k, v in W.items()}
+    dec_names = list(steps.GEO_DECODER_PARAMS) + [nm for nm in steps.COLOR_DECODER_PARAMS if nm in Wt and (rel_pos or ('mlp_col_neighbor' not in nm and 'embedder_rel_pos' not in nm))]
+    for nm in dec_names:
+        Wt[nm].requires_grad_(True)
+    geo_p, col_p = geo[rows.long()].clone().requires_grad_(True), col[rows.long()].clone().requires_grad_(True)
+    cam_p = [cams0[f].clone().requires_grad_(True) for f in range(F) if trainable[f]]
+    opt = torch.optim.Adam([{'params': [Wt[nm] for nm in dec_names], 'lr': 0}, {'params': [geo_p], 'lr': 0}, {'params': [col_p], 'lr': 0},
+                            {'params': cam_p, 'lr': 0}])
+    o_losses = []
+    for it in range(iters):
+        stage = stages[it]
+        for gi in range(3):
+            opt.param_groups[gi]['lr'] = lrs[stage][gi]
+        opt.param_groups[3]['lr'] = cam_lr(it)
+        opt.zero_grad()
+        geo_t = geo.clone(); geo_t[rows.long()] = geo_p
+        col_t = col.clone(); col_t[rows.long()] = col_p
+        ros, rds, gds, gcs = [], [], [], []
+        k = 0
+        for f in range(F):
+            rr = rnd_all[it, f * n:(f + 1) * n]
+            if trainable[f]:
+                pose = H.quat_to_c2w(cam_p[k]); k += 1
+            else:
+                pose = c2w_stack[f]
+            ro, rd = H.rays_from_uv((rr % WW).float(), (rr // WW).float(), pose, *INTR)
+            ros.append(ro); rds.append(rd)
+            gds.append(depth_img.reshape(-1)[rr.long()]); gcs.append(color_img.reshape(-1, 3)[rr.long()])
+        ro, rd, gd, gc = torch.cat(ros), torch.cat(rds), torch.cat(gds), torch.cat(gcs)
+        keep = gd > 0
+        keep = keep & (gd <= H.inside_threshold(gd[keep]))
+        out = H.render_batch(ocfg, ro[keep], rd[keep], gd[keep], pos, geo_t, col_t, Wt, stage, tracker=True)
+        loss, _, _, _ = H.mapper_loss(out['depth'], out['color'], out['valid_ray'], gd[keep], gc[keep], stage, 0.1)
+        loss.backward()
+        opt.step()
+        o_losses.append(loss.item())
+    # ---------------- kernels (per-statement path: BA is not part of lk_map_frame)
+    cfg = core.RenderCfg(rel_pos=rel_pos)
+    dec = core.DecoderBlob(eng).pack(W)
+    pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
+    knn = core.KnnIndex(eng, capacity=pos.shape[0]); knn.build(pos_d)
+    mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, rows.to(eng.device), R, lrs, w_color=0.1)
+    mo.begin_frame()
+    cams_d = eng.f32(cams0).clone().contiguous()
+    mo.enable_ba(cams_d, trainable, cam_lr)
+    frames = (eng.f32(depth_img).reshape(1, HH, WW).repeat(F, 1, 1).contiguous(), eng.f32(color_img).reshape(1, HH, WW, 3).repeat(F, 1, 1, 1).contiguous(),
+              eng.f32(c2w_stack).contiguous(), None)
+    fid = torch.arange(F, dtype=torch.int32).repeat_interleave(n).to(eng.device)
+    log = eng.zeros(iters, 4)
+    mo.run(iters, 1, frames, rnd_all.to(eng.device), fid, (0, HH, 0, WW), INTR, HH, WW, log)
+    np.testing.assert_allclose(log[:, 0].cpu().numpy(), o_losses, rtol=2e-4)
+    cams_k = cams_d.cpu()
+    assert torch.equal(cams_k[0], cams0[0])                                   # the oldest frame is fixed
+    k = 0
+    for f in range(F):
+        if trainable[f]:
+            moved = float((cam_p[k].detach() - cams0[f]).abs().max())
+            assert moved > 1e-3                                               # two steps of 2e-3 (Adam's first steps are sign-like)
+            np.testing.assert_allclose(cams_k[f].numpy(), cam_p[k].detach().numpy(), rtol=0, atol=2e-5)
+            k += 1
+    r = rows.long()
+    for mine, ref in ((geo_d.cpu()[r], geo_p.detach()), (col_d.cpu()[r], col_p.detach())):
+        err = (mine - ref).abs().reshape(-1)
+        assert float(torch.quantile(err, 0.99)) < 5e-5 and float(err.max()) < 0.03, (float(torch.quantile(err, 0.99)), float(err.max()))
+    Wk = dec.unpack()
+    for nm in dec_names:
+        assert float((Wk[nm].reshape(Wt[nm].shape) - Wt[nm].detach()).abs().max()) <= 2e-3 * max(1.0, float(Wt[nm].detach().abs().max())), nm
+
+
+@pytest.mark.parametrize('backend', backends())
 @pytest.mark.parametrize('native,separate,handle_dynamic', ((True, True, True), (False, True, True), (True, False, True), (False, False, True),
                                                             (True, True, False), (False, False, False)))
 def test_track_iterations_match_oracle(backend, native, separate, handle_dynamic):
