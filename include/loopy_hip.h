@@ -122,6 +122,11 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
                                            fix_color_decoder, the end-of-sequence refinement): no weight-gradient rows are written and no
                                            weight-gradient reduction is launched; the rest of g_weights is left untouched */
 
+#define LK_FLAG_GRAD_GEO_DECODER (1u << 15) /* lk_render_bwd, with LK_FLAG_GRAD_WEIGHTS: the geometry decoder's matrices and biases receive
+                                           gradients too (mapping.fix_geo_decoder: False, Mapper.py:524-526; every reference config keeps
+                                           them frozen and trains geo_decoder.embedder._B alone) - one more launch that redoes the 32-wide
+                                           backward chain per sample in plain fp32 from the saved activations (lk_geo_wgrad.hip) */
+
 typedef struct {
     /* ---- sizes */
     int32_t R, S;

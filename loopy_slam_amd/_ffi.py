@@ -30,6 +30,7 @@ FLAG_Z_GIVEN = 1 << 12
 FLAG_FEATS_F16 = 1 << 13
 FLAG_UNIT_LOSS_GRADS = 1 << 11
 FLAG_EMBED_GRADS_ONLY = 1 << 14
+FLAG_GRAD_GEO_DECODER = 1 << 15
 
 EXPOSURE_MAX_F = 32
 ADAM_MAX_SEG = 16

@@ -181,13 +181,17 @@ class DecoderBlob:
         n = e['rows'] * e['ld']
         return e['offset'], n
 
-    def param_ranges(self, names):
-        """Merge the blob ranges of `names` into maximal contiguous (offset, length) runs."""
+    def param_ranges(self, names, bridge_padding=False):
+        """Merge the blob ranges of `names` into maximal contiguous (offset, length) runs.
+        bridge_padding: two ranges separated by alignment padding only (no other tensor of the layout starts in the gap) become one -
+        the padding floats of the blob and of its gradient are zero and stay zero under Adam."""
         rng = sorted(self.segment(n) for n in names)
+        others = sorted(self.segment(n)[0] for n in self.layout if n not in names)
         out = []
         for off, n in rng:
-            if out and out[-1][0] + out[-1][1] == off:
-                out[-1] = (out[-1][0], out[-1][1] + n)
+            end = out[-1][0] + out[-1][1] if out else None
+            if out and (end == off or (bridge_padding and end < off and not any(end <= o < off for o in others))):
+                out[-1] = (out[-1][0], off + n - out[-1][0])
             else:
                 out.append((off, n))
         return out
@@ -282,6 +286,7 @@ class GradState:
         self.g_rays_d = eng.zeros(R, 3) if rays else None
         self.g_affine = eng.zeros(12) if affine else None
         self.row_mask = None            # uint8 [N]: restrict the feature-row gradients to these rows (frustum selection)
+        self.geo_decoder = False        # True: g_weights also receives the geometry decoder's matrices / biases (fix_geo_decoder: False)
         self.scratch = None
 
     def zero_(self):
@@ -295,11 +300,11 @@ def render_backward(eng, st, gs, d_depth, d_color=None, d_var=None):
     Which gradients are produced is decided by the buffers present in `gs`."""
     d = st.desc
     assert d is not None and (d.flags & _ffi.FLAG_SAVE_ACT), 'run render_forward(..., save_act=True) first'
-    flags = d.flags & ~(_ffi.FLAG_GRAD_FEATS | _ffi.FLAG_GRAD_WEIGHTS | _ffi.FLAG_GRAD_RAYS)
+    flags = d.flags & ~(_ffi.FLAG_GRAD_FEATS | _ffi.FLAG_GRAD_WEIGHTS | _ffi.FLAG_GRAD_RAYS | _ffi.FLAG_GRAD_GEO_DECODER)
     if gs.g_geo is not None:
         flags |= _ffi.FLAG_GRAD_FEATS
     if gs.g_weights is not None:
-        flags |= _ffi.FLAG_GRAD_WEIGHTS
+        flags |= _ffi.FLAG_GRAD_WEIGHTS | (_ffi.FLAG_GRAD_GEO_DECODER if gs.geo_decoder else 0)
     if gs.g_rays_o is not None:
         flags |= _ffi.FLAG_GRAD_RAYS
     d.flags = flags

@@ -96,7 +96,7 @@ extern "C" int64_t lk_render_act_floats(int32_t R, int32_t S, uint32_t flags) {
 
 // ------------------------------------------------------------------ backward scratch layout
 namespace {
-struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, aff_part, part_bg, part_br, hbar, w_sum, dy_col, rows, dw1_part, dw2_part, wg_part, seg_rank, seg_list, total; };
+struct BwdLayout { int64_t dfeat, d_raw, dc_geo, dc_col, dp_embed, dp_embed_col, dp_rel, dp_total, dw_rel, w_eff, dlogit, aff_part, part_bg, part_br, hbar, w_sum, dy_col, rows, dw1_part, dw2_part, wg_part, geo_part, seg_rank, seg_list, total; };
 BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     BwdLayout L;
     int64_t o = 0;
@@ -126,6 +126,7 @@ BwdLayout bwd_layout(int64_t P, uint32_t flags) {
     L.dw1_part = o; if (fused) o += al((int64_t)lk_relpos_bwd_parts((int)P) * 128 * 64);
     L.dw2_part = o; if (fused) o += al(lk_dw2_part_floats((int)P));
     L.wg_part = o; if (color && gw) o += al(lk_wgrad_part_floats(P, (flags & LK_FLAG_REL_POS) != 0));
+    L.geo_part = o; if (gw && (flags & LK_FLAG_GRAD_GEO_DECODER)) o += al(lk_geo_wgrad_part_floats((int)P));
     L.seg_rank = o; if (flags & LK_FLAG_GRAD_FEATS) o += al(8 * P);
     L.seg_list = o; if (flags & LK_FLAG_GRAD_FEATS) o += al(8 * P);
     L.total = o;
@@ -389,6 +390,11 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.live_rays = ex ? ex->live_rays : nullptr;
     db.dscale = ex ? ex->dscale : nullptr;
     lk_launch_decode_bwd(db, st);
+    if (gw && (flags & LK_FLAG_GRAD_GEO_DECODER)) {      // mapping.fix_geo_decoder: False - the geometry decoder's own matrices and biases
+        LK_REQUIRE(!(flags & LK_FLAG_EMBED_GRADS_ONLY) && !(ex && ex->live_rays), "lk_render_bwd: GRAD_GEO_DECODER is a per-statement option (no EMBED_GRADS_ONLY, no partitioned batch)");
+        rc = lk_launch_geo_wgrad(P, d->S, d->rays_o, d->rays_d, d->z, d->weights, d->act, d->c_geo, S0 + L.d_raw, S0 + L.geo_part, d->g_weights, st);
+        if (rc != LK_OK) return rc;
+    }
     // d affine: the colour tiles stored their 12 sums, one small launch adds them into g_affine (49 adds per address instead of 782)
     if (color && d->affine && d->g_affine && !(skip & LK_SKIP_AFF_REDUCE)) lk_launch_reduce_partials(S0 + L.aff_part, lk_cdiv(P, 32), 12, d->g_affine, st);
     // mapper 'color' backward with one weight-gradient launch: every partial-sum reduction is deferred to ONE launch at the end

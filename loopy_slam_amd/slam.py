@@ -423,6 +423,7 @@ class Mapper:
         self.filter_before_add_points = m['filter_before_add_points']
         self.pixels_based_on_color_grad = m.get('pixels_based_on_color_grad', 0)
         self.color_refine, self.fix_color_decoder = m.get('color_refine', False), m.get('fix_color_decoder', False)
+        self.fix_geo_decoder = m.get('fix_geo_decoder', True)       # False: the geometry decoder's matrices are trained too (Mapper.py:524-526)
         self.keyframe_selection_method = m.get('keyframe_selection_method', 'overlap')
         # bundle adjustment (Mapper.py:82-83, 957-962): off until the run has more than four keyframes, then as the config says
         self.BA, self.BA_cfg, self.BA_cam_lr, self.ckpt_freq = False, m.get('BA', False), m.get('BA_cam_lr', 0.0002), m.get('ckpt_freq', 500)
@@ -609,7 +610,8 @@ class Mapper:
         rcfg = render_cfg_from(cfg, cfg['rendering']['sigmoid_coef_mapper'])
         mo = steps.MapOptimizer(eng, rcfg, self.decoders.dec, npc.knn, npc.cloud_pos(), npc.get_geo_feats(), npc.get_col_feats(),
                                 rows, R, lrs, w_color=self.w_color_loss, dynamic_radius=self.use_dynamic_radius,
-                                fix_color_decoder=self.fix_color_decoder, dist=getattr(self.slam, 'dist', None), exposure=exposure)
+                                fix_color_decoder=self.fix_color_decoder, dist=getattr(self.slam, 'dist', None), exposure=exposure,
+                                fix_geo_decoder=self.fix_geo_decoder)
         mo.begin_frame()
         mo.gs.row_mask = row_mask               # the backward only scatters into the rows being optimised
         geo_iters = self.geo_iter_first if init else int(num_joint_iters * self.geo_iter_ratio)

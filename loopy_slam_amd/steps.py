@@ -18,6 +18,13 @@ from . import _ffi, core, optim
 from ._ffi import ptr
 
 GEO_DECODER_PARAMS = ('geo_decoder.embedder._B',)      # fix_geo_decoder: True (Mapper.py:537-541)
+# fix_geo_decoder: False (Mapper.py:524-526): geo_decoder.parameters() - of those the ones the forward uses (the module also owns an
+# unused mlp_col_neighbor / embedder_rel_pos, which never receive a gradient: torch's Adam skips them)
+GEO_DECODER_ALL_PARAMS = tuple(
+    ['geo_decoder.embedder._B'] +
+    [f'geo_decoder.pts_linears.{i}.{w}' for i in range(5) for w in ('weight', 'bias')] +
+    [f'geo_decoder.fc_c.{i}.{w}' for i in range(5) for w in ('weight', 'bias')] +
+    ['geo_decoder.output_linear.weight', 'geo_decoder.output_linear.bias'])
 COLOR_DECODER_PARAMS = tuple(
     [f'color_decoder.pts_linears.{i}.{w}' for i in range(5) for w in ('weight', 'bias')] +
     [f'color_decoder.fc_c.{i}.{w}' for i in range(5) for w in ('weight', 'bias')] +
@@ -131,7 +138,7 @@ class MapOptimizer:
     """One optimize_map call: Adam over {decoder params, selected geo rows, selected colour rows}."""
 
     def __init__(self, eng, cfg, dec, knn, pos, geo_feats, col_feats, row_index, R, lrs, w_color=0.1,
-                 dynamic_radius=False, fix_color_decoder=False, dist=None, exposure=None):
+                 dynamic_radius=False, fix_color_decoder=False, dist=None, exposure=None, fix_geo_decoder=True):
         """row_index: int32 [n_f] rows being optimised (frustum selection, Mapper.py:498-512) or None = all rows.
         lrs: dict stage -> (decoders_lr, geometry_lr, color_lr)  (configs mapping.stage.*)."""
         self.eng, self.cfg, self.dec, self.knn = eng, cfg, dec, knn
@@ -151,7 +158,11 @@ class MapOptimizer:
         if not cfg.rel_pos:
             cnames = [n for n in cnames if 'mlp_col_neighbor' not in n and 'embedder_rel_pos' not in n]
         self.fix_color_decoder = fix_color_decoder
-        self.geo_dec_ranges = dec.param_ranges(list(GEO_DECODER_PARAMS))
+        # fix_geo_decoder False: the geometry decoder's own matrices join the decoder group (one more backward launch, per-statement path)
+        self.fix_geo_decoder = fix_geo_decoder
+        self.gs.geo_decoder = not fix_geo_decoder
+        self.geo_dec_ranges = dec.param_ranges(list(GEO_DECODER_PARAMS if fix_geo_decoder else GEO_DECODER_ALL_PARAMS),
+                                               bridge_padding=not fix_geo_decoder)
         self.col_dec_ranges = dec.param_ranges(cnames)
         self.loss_log = None
         self.dist = dist
@@ -241,9 +252,10 @@ class MapOptimizer:
         if ba is not None:              # one group for all camera tensors (Mapper.py:565-566); elementwise, so one segment
             segs.append(('cams', ba['cams'].view(-1), ba['g'].view(-1), float(ba['lr'](self.it))))
         self.adam.step(segs, zero_grad=True)
-        if stage == 'color':
+        if stage == 'color' or not self.fix_geo_decoder:
             # the geometry stage only moves the embedding matrices (read from the plain blob); the MFMA fragments are
-            # copies of the colour-decoder matrices, which only change in the colour stage
+            # copies of the colour-decoder matrices, which only change in the colour stage (and of the geometry decoder's, which
+            # only change without fix_geo_decoder)
             self.dec.repack()
         self.it += 1
         return out4
@@ -253,7 +265,7 @@ class MapOptimizer:
         it < n_geo_iters.  rnd_all int32 [n_iters, R]; log [n_iters, 4].  Without exposure encoding this is lk_map_frame - one
         C-ABI call for the whole loop single-GPU, two calls per iteration around the gradient all-reduce multi-GPU; with
         exposure encoding the per-statement path (iterate)."""
-        if not self.native_loop or self.ba is not None or (self.exposure is not None and self.R > 16384):
+        if not self.native_loop or self.ba is not None or not self.fix_geo_decoder or (self.exposure is not None and self.R > 16384):
             for it in range(n_iters):
                 self.iterate('geometry' if it < n_geo_iters else 'color', frames, rnd_all[it], frame_id, window, intr, H, W, log_row=log[it])
             return log

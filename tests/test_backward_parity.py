@@ -35,12 +35,14 @@ def setup(eng, name, g, stage, tracker=False, affine=None, color_logits=False, e
 
 
 @pytest.mark.parametrize('backend', backends())
-@pytest.mark.parametrize('unit', (False, True))
+@pytest.mark.parametrize('unit,geo_dec', ((False, False), (True, False), (True, True)))
 @pytest.mark.parametrize('stage', ('geometry', 'color'))
 @pytest.mark.parametrize('name', CFG_NAMES)
-def test_backward_mapper_golden(backend, name, stage, unit):
+def test_backward_mapper_golden(backend, name, stage, unit, geo_dec):
     """unit: LK_FLAG_UNIT_LOSS_GRADS as the mapper sets it (its L1 loss gradients are +-1 / +-w): the colour decoder's
-    backward then runs on pre-scaled fp16 pieces instead of bf16 pieces - same goldens, same tolerance."""
+    backward then runs on pre-scaled fp16 pieces instead of bf16 pieces - same goldens, same tolerance.
+    geo_dec: LK_FLAG_GRAD_GEO_DECODER (mapping.fix_geo_decoder: False) - the geometry decoder's matrices and biases against the
+    reference's autograd too."""
     from loopy_slam_amd import _ffi
     eng = make_engine(backend)
     g = load(f'g6_render_{name}_map_{stage}')
@@ -59,12 +61,13 @@ def test_backward_mapper_golden(backend, name, stage, unit):
     assert abs(loss.item() - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
     loss.backward()
     gs = core.GradState(eng, N, R, dec.n, feats=True, weights=True)
+    gs.geo_decoder = geo_dec
     core.render_backward(eng, st, gs, eng.f32(depth.grad), eng.f32(color.grad if color.grad is not None else torch.zeros(R, 3)))
     assert relerr(gs.g_geo.cpu(), g['grad_geo']) < TOL
     if 'grad_col' in g:
         assert relerr(gs.g_col.cpu(), g['grad_col']) < TOL
     gW = dec.unpack(gs.g_weights)
-    checked = 0
+    checked = n_geo = 0
     for k, gv in g.items():
         if not k.startswith('gradW.'):
             continue
@@ -72,11 +75,15 @@ def test_backward_mapper_golden(backend, name, stage, unit):
         if nm not in gW:
             continue          # exposure MLP lives on the host side
         if nm.startswith('geo_decoder.') and nm != 'geo_decoder.embedder._B':
-            continue          # frozen in every reference config (mapping.fix_geo_decoder: True, Mapper.py:537-541)
+            if not geo_dec:   # frozen in every reference config (mapping.fix_geo_decoder: True, Mapper.py:537-541): nothing is written
+                assert float(gW[nm].abs().max()) == 0.0, nm
+                continue
+            n_geo += 1
         e = relerr(gW[nm].reshape(gv.shape), gv)
         assert e < TOL, (nm, e)
         checked += 1
     assert checked >= (1 if stage == 'geometry' else 20)
+    assert n_geo == (22 if geo_dec else 0)        # 5 x (W, b) + 5 x (U, u) + (w_o, b_o)
 
 
 @pytest.mark.parametrize('backend', backends())

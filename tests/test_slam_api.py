@@ -282,11 +282,12 @@ def test_add_points_schedule_matches_oracle(backend):
 def test_bundle_adjustment_in_the_mapper(backend):
     """mapping.BA: True (Mapper.py:541-566, 782-797, 957-964): off until the run holds more than four keyframes; then the window's
     poses (but the oldest keyframe's) are optimised with the map, written back into the keyframes, and the mapped frame's estimate is
-    replaced by the optimised pose.  handle_dynamic: False rides along (the tracker's median mask)."""
+    replaced by the optimised pose.  handle_dynamic: False rides along (the tracker's median mask), and so does fix_geo_decoder: False
+    (the geometry decoder's own matrices move)."""
     eng = make_engine(backend)
     cfg = mini_cfg()
     cfg['mapping'].update(BA=True, BA_cam_lr=0.002, every_frame=1, keyframe_every=1, iters=10, color_refine=False, mapping_window_size=4,
-                          keyframe_selection_method='global')
+                          keyframe_selection_method='global', fix_geo_decoder=False)
     cfg['tracking'].update(handle_dynamic=False)
     cfg['data']['n_frames'] = 7
     ps = slam.Point_SLAM(cfg, None, eng=eng)
@@ -301,7 +302,9 @@ def test_bundle_adjustment_in_the_mapper(backend):
         seen.append(dict(idx=idx, ba=ps.mapper.BA, n_kf=len(before), moved=moved, ret=r, cur=a[5].clone()))
         return r
     ps.mapper.optimize_map = spy
+    w_geo0 = ps.shared_decoders.dec.unpack()['geo_decoder.pts_linears.1.weight'].clone()
     est, gt = ps.run()
+    assert float((ps.shared_decoders.dec.unpack()['geo_decoder.pts_linears.1.weight'] - w_geo0).abs().max()) > 1e-4
     assert [c['ba'] for c in seen] == [c['n_kf'] > 4 for c in seen] and any(c['ba'] for c in seen) and not seen[0]['ba']
     for c in seen:
         if not c['ba']:

@@ -46,10 +46,13 @@ def oracle_rays(c2w, depth_img, color_img, rnd):
 
 
 @pytest.mark.parametrize('backend', backends())
-@pytest.mark.parametrize('native,frozen,all_rows', ((True, False, False), (False, False, False), (True, True, False), (True, True, True)))
+@pytest.mark.parametrize('native,frozen,all_rows,geo_free', ((True, False, False, False), (False, False, False, False), (True, True, False, False),
+                                                              (True, True, True, False), (True, False, False, True)))
 @pytest.mark.parametrize('rel_pos', (True, False))
-def test_map_iterations_match_oracle(backend, rel_pos, native, frozen, all_rows):
+def test_map_iterations_match_oracle(backend, rel_pos, native, frozen, all_rows, geo_free):
     """native: the whole loop as ONE lk_map_frame call (MapOptimizer.run); else one launch sequence per statement (iterate).
+    geo_free: mapping.fix_geo_decoder False (Mapper.py:524-526) - the geometry decoder's matrices are trained too (run() then takes
+    the per-statement path by itself).
     all_rows: the whole-map refinement - rows = NULL, every row a parameter; lk_map_frame then steps only the rows its gathers have flagged
     (lk_adam_seg::row_flags), which must equal torch.optim.Adam over the whole tables."""
     eng = make_engine(backend)
@@ -66,8 +69,8 @@ def test_map_iterations_match_oracle(backend, rel_pos, native, frozen, all_rows)
     Wt = {k: v.clone() for k, v in W.items()}
     # frozen = fix_color_decoder (the end-of-sequence refinement, Mapper.py:531-541): of the decoders only the Fourier matrices stay
     # trainable - lk_map_frame then renders its backward with LK_FLAG_EMBED_GRADS_ONLY (no weight-gradient rows, no reduction launches)
-    dec_names = list(steps.GEO_DECODER_PARAMS) + ([n for n in steps.COLOR_DECODER_PARAMS] if not frozen else
-                                                  (['color_decoder.embedder_rel_pos._B'] if rel_pos else []))
+    dec_names = list(steps.GEO_DECODER_ALL_PARAMS if geo_free else steps.GEO_DECODER_PARAMS) + \
+        ([n for n in steps.COLOR_DECODER_PARAMS] if not frozen else (['color_decoder.embedder_rel_pos._B'] if rel_pos else []))
     for n in dec_names:
         Wt[n].requires_grad_(True)
     geo_o, col_o = geo.clone(), col.clone()
@@ -98,7 +101,7 @@ def test_map_iterations_match_oracle(backend, rel_pos, native, frozen, all_rows)
     knn = core.KnnIndex(eng, capacity=pos.shape[0])
     knn.build(pos_d)
     mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, None if all_rows else rows.to(eng.device), R, lrs, w_color=0.1,
-                            fix_color_decoder=frozen)
+                            fix_color_decoder=frozen, fix_geo_decoder=not geo_free)
     mo.begin_frame()
     frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
     fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
