@@ -733,8 +733,6 @@ class Tracker:
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self.sample_with_color_grad, self.depth_limit = t.get('sample_with_color_grad', False), t.get('depth_limit', False)
         self.handle_dynamic = t.get('handle_dynamic', True)       # False: median-of-residual outlier mask (Tracker.py:177-179)
-        if self.depth_limit and not self.sample_with_color_grad:
-            raise NotImplementedError('tracking.depth_limit without sample_with_color_grad (Tracker.py:142-146) is not built')
         self.gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219) + 3)      # device draws (select_uv)
         self.last_log = None
 
@@ -752,14 +750,18 @@ class Tracker:
         c2w = get_camera_from_tensor(camera_tensor)
         ro, rd, gd, gc, i, j = get_samples(self.ignore_edge_H, H - self.ignore_edge_H, self.ignore_edge_W, W - self.ignore_edge_W,
                                            batch_size, H, W, self.fx, self.fy, self.cx, self.cy, c2w, gt_depth, gt_color, dev,
-                                           depth_filter=True, return_index=True)
+                                           depth_filter=True, return_index=True, depth_limit=5.0 if self.depth_limit else None)
         with torch.no_grad():
             inside = gd <= torch.minimum(10 * gd.median(), 1.2 * gd.max())
         ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
         depth, unc, color, _ = self.renderer.render_batch_ray(self.npc, self.decoders, rd, ro, dev, 'color', gt_depth=gd, is_tracker=True)
         unc = unc.detach()
         tmp = torch.abs(gd - depth) / torch.sqrt(unc + 1e-10)
-        mask = (tmp < 10 * tmp.mean()) & (gd > 0) & (~torch.isnan(depth)) & (~torch.isnan(unc))
+        if self.handle_dynamic:
+            mask = (tmp < 10 * tmp.mean()) & (gd > 0) & (~torch.isnan(depth)) & (~torch.isnan(unc))
+        else:                                       # Tracker.py:177-179
+            t2 = torch.abs(gd - depth)
+            mask = (t2 < 10 * t2.median()) & (gd > 0) & (~torch.isnan(depth)) & (~torch.isnan(unc))
         geo_loss = torch.clamp(tmp, min=0.0, max=1e3)[mask].sum()
         color_loss = torch.abs(gc - color)[mask].sum()
         loss = geo_loss + (self.w_color_loss * color_loss if self.use_color_in_tracking else 0.0)
@@ -808,6 +810,11 @@ class Tracker:
                 n = (win[1] - win[0]) * (win[3] - win[2])
                 rnd = torch.randint(0, n, (self.num_cam_iters, n_px), generator=self.gen, dtype=torch.int32, device=eng.device)
                 win_it = win
+            track_depth = gt_depth
+            if self.depth_limit and not self.sample_with_color_grad:
+                # get_samples(depth_filter=True, depth_limit=5.0) (Tracker.py:142-146, common.py:249-252): draws whose depth reading is
+                # 5 m or beyond are dropped like the ones without a reading - a zero reading IS "dropped" to the loop (absent ray)
+                track_depth = torch.where(gt_depth < 5.0, gt_depth, torch.zeros_like(gt_depth))
             to = steps.TrackOptimizer(eng, rcfg, self.decoders.dec, self.npc.knn, self.npc.cloud_pos(), self.npc.get_geo_feats(),
                                       self.npc.get_col_feats(), n_px, self.cam_lr, separate_lr=self.separate_LR,
                                       w_color=self.w_color_loss, use_color=self.use_color_in_tracking,
@@ -817,7 +824,7 @@ class Tracker:
             if slam.encode_exposure:                # this frame's exposure feature starts from the shared one (Tracker.py:280-283)
                 self.exposure_feat = slam.exposure_feat.detach().clone().requires_grad_(True)
                 exposure = (self.decoders.mlp_exposure, self.exposure_feat)
-            best, log = to.track(cam, gt_depth, gt_color, self.num_cam_iters, win_it, (self.fx, self.fy, self.cx, self.cy), rnd,
+            best, log = to.track(cam, track_depth, gt_color, self.num_cam_iters, win_it, (self.fx, self.fy, self.cx, self.cy), rnd,
                                  r2_map=r2_query, exposure=exposure)
             if slam.encode_exposure:
                 slam.exposure_feat = self.exposure_feat.detach().clone()           # Tracker.py:412-414

@@ -279,6 +279,33 @@ def test_add_points_schedule_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', backends())
+def test_tracking_depth_limit_without_gradient_sampling(backend):
+    """tracking.depth_limit with uniform pixel draws (Tracker.py:142-146, common.py:249-252): readings of 5 m and beyond are dropped
+    like missing ones - the loop's masked-ray count equals the count over the limited image."""
+    eng = make_engine(backend)
+    cfg = mini_cfg()
+    cfg['tracking'].update(depth_limit=True, sample_with_color_grad=False, iters=2)
+    ps = slam.Point_SLAM(cfg, None, eng=eng)
+    _, color, depth, c2w = ps.frame_reader[0]
+    ps.tracker.track_frame(0, color, depth, c2w)
+    ps.mapper.map_frame(0, color, depth, c2w, cur_c2w=c2w)
+    _, color1, depth1, c2w1 = ps.frame_reader[1]
+    far = depth1.clone()
+    far[::2, ::3] = 6.5                              # a third of a half of the pixels beyond the limit
+    counts = {}
+    for name, img in (('limited', far), ('plain', depth1)):
+        ps.tracker.gen.manual_seed(77)
+        ps.tracker.track_frame(1, color1, img, c2w1)
+        counts[name] = ps.tracker.last_log[:, 3].cpu()
+    n_px = cfg['tracking']['pixels']
+    assert float(counts['limited'].max()) < 0.95 * float(counts['plain'].min()) and float(counts['limited'].min()) > 0.5 * n_px
+    # without the option the far readings take part (and the inside mask / outlier mask may or may not drop them)
+    cfg2 = mini_cfg()
+    cfg2['tracking'].update(depth_limit=False, iters=2)
+    assert slam.Point_SLAM(cfg2, None, eng=eng).tracker.depth_limit is False
+
+
+@pytest.mark.parametrize('backend', backends())
 def test_bundle_adjustment_in_the_mapper(backend):
     """mapping.BA: True (Mapper.py:541-566, 782-797, 957-964): off until the run holds more than four keyframes; then the window's
     poses (but the oldest keyframe's) are optimised with the map, written back into the keyframes, and the mapped frame's estimate is
