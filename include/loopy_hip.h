@@ -443,6 +443,10 @@ int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters);
 /* float offset inside `work` of the neighbour lists lk_map_frame keeps per iteration: int32 [iters][R*S][8] (what a data-parallel
  * caller needs to agree on the touched rows of an iteration, loopy_slam_amd/parallel.py) */
 int64_t lk_map_work_nbr_idx(int32_t R, int32_t S, int32_t iters);
+/* One render / backward sequence per kNN handle at a time: the handle owns the row counters of the gradient sort (zero between calls: the
+ * scan that consumes them clears them) and lk_map_frame's look-ahead search and sort run on a library-owned stream.  The call with
+ * it_begin = 0 joins that stream before it touches `work`; after an ERROR return from lk_map_frame / lk_render_bwd the counters may be
+ * stale - lk_knn_build (which clears them) before the handle renders a backward again. */
 int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t phases, void* stream);
 /* Makes `stream` wait until the neighbour lists of iteration `it` (work + lk_map_work_nbr_idx) are written: lk_map_frame
  * searches ahead of its loop on a library-owned stream.  Valid after the phase-1 call of iteration it - 1 (or it) of the same

@@ -537,6 +537,14 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     auto chunk_of = [&](int it) { return it == 0 ? 0 : 1 + (it - 1) / pre_chunk; };
     float* W0 = d->work;
     if (pre && it_begin == 0 && (phases & 1)) {
+        // A call that starts an optimize_map call joins the look-ahead stream first: an earlier call that stopped before its last enqueued
+        // chunk was consumed (an error between the phases of a data-parallel caller, a range that ends early) may still be searching and
+        // sorting there - reading the `work` buffer this call's k_pregather overwrites and holding the index's row counters mid-sort.
+        // With an idle look-ahead stream the wait is satisfied at once.
+        PreStream& pj = pre_stream();
+        if (pj.ok) { (void)hipEventRecord(pj.e1, pj.st); (void)hipStreamWaitEvent(st, pj.e1, 0); }
+    }
+    if (pre && it_begin == 0 && (phases & 1)) {
         // pixels, rays, colours, radii and the inside mask of EVERY iteration of this optimize_map call in one launch; it also
         // clears the loss rows the composite kernels accumulate into
         LkPregatherArgs pa;
