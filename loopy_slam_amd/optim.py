@@ -108,11 +108,13 @@ def gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, w
 
 def frustum_rows(eng, pos, c2w, depth, intr, H, W, edge, return_mask=False):
     """Mapper.get_mask_from_c2w on the device (lk_frustum_rows): int32 tensor of the selected row indices, ascending
-    (and, with return_mask, the uint8 [N] membership flags).  One host sync (the count) - once per mapped frame."""
+    (and, with return_mask, the uint8 [N] membership flags).  One host sync (the count) - once per mapped frame; a second one if
+    c2w lives on the device (the inverse is taken on the host, as the reference does: pass the host copy of the pose when there is one)."""
     import numpy as np
     fx, fy, cx, cy = intr
     N = pos.shape[0]
-    w2c = np.linalg.inv(c2w.detach().cpu().numpy().astype(np.float32)).astype(np.float32)     # float32 like the reference
+    c2w_h = c2w if isinstance(c2w, np.ndarray) else c2w.detach().cpu().numpy()
+    w2c = np.linalg.inv(c2w_h.astype(np.float32)).astype(np.float32)     # float32 like the reference
     w12 = (C.c_float * 12)(*[float(x) for x in w2c[:3, :4].reshape(-1)])
     out = eng.empty(max(N, 1), dtype=torch.int32)
     cnt = eng.empty(1, dtype=torch.int32)

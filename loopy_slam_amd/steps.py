@@ -431,7 +431,7 @@ class TrackOptimizer:
             # the whole loop as ONE C-ABI call (lk_track_frame): no interpreter between the launches
             self._track_native(cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log, xs)
             best = torch.argmin(log[:, 0])      # Tracker.py:375-377 (first minimum)
-            return self._agree(hist[best].clone()), log
+            return self._agree(hist.index_select(0, best.reshape(1))[0]), log   # (hist[best] would read `best` back: a host sync)
         if self.eye is None:
             self.eye = torch.eye(4, device=eng.device).reshape(1, 4, 4).contiguous()
         dstack, cstack = depth_img.reshape(1, H, W), color_img.reshape(1, H, W, 3)
@@ -465,7 +465,7 @@ class TrackOptimizer:
             if not self.separate_lr:
                 hist[it].copy_(cam)             # one leaf tensor stepped in place: the candidate is the pose AFTER the update
         best = torch.argmin(log[:, 0])          # Tracker.py:375-377 (first minimum)
-        return self._agree(hist[best].clone()), log
+        return self._agree(hist.index_select(0, best.reshape(1))[0]), log
 
     def _agree(self, cam7):
         """Replicated tracking: every rank continues from rank 0's pose."""

@@ -77,6 +77,7 @@ class FrameWorkload:
         self.depth_stack = torch.stack(ds).contiguous()
         self.color_stack = torch.stack(cs).contiguous()
         self.c2w_stack = torch.stack(ps).contiguous()
+        self.c2w_host = [p.detach().cpu().numpy() for p in ps]      # the mapped frame's pose is known to the host (frustum selection)
         self.frames = (self.depth_stack, self.color_stack, self.c2w_stack, None)
         # rows optimised by the mapper = frustum selection of the frame being mapped (Mapper.py:165-217, 498-512),
         # recomputed at every step like the reference does at every optimize_map call
@@ -151,7 +152,7 @@ class FrameWorkload:
             self.mapped_frame_extras(k)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
         fid = self._fid
-        self.rows, row_mask = optim.frustum_rows(eng, self.pos[:self.n], self.c2w_stack[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
+        self.rows, row_mask = optim.frustum_rows(eng, self.pos[:self.n], self.c2w_host[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
                                                  return_mask=True)
         self.mapper.new_frame(self.rows, row_mask)
         self.mapper.run(b.map_iters, b.map_geo_iters, self.frames, rnd_m, fid, (0, H, 0, W), self.intr, H, W, self.map_log)

@@ -144,3 +144,70 @@ def test_two_rank_grad_allreduce_matches_single_process(all_rows, native, backen
     assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.015
     err = (full[3] - col_d).abs()
     assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.0025
+
+
+def _rccl_worker(port, q, all_rows):
+    try:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        from loopy_slam_amd import parallel
+        from util import make_engine
+        eng = make_engine('hip')
+        dctx = parallel.DistContext(0, 1)
+        mo, frames, dec, geo_d, col_d = build(eng, 2 * R, dctx, all_rows)
+        rnd = draws().to(eng.device)
+        fid = torch.zeros(2 * R, dtype=torch.int32, device=eng.device)
+        log = eng.zeros(ITERS, 4)
+        mo.run(ITERS, 1, frames, rnd.reshape(ITERS, -1).contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW, log)
+        # the tracker's pose broadcast and a vector sum go over the same communicator
+        v = torch.arange(7, dtype=torch.float32, device=eng.device)
+        dctx.broadcast(v, src=0)
+        dctx.all_reduce_vec(v)
+        torch.cuda.synchronize()
+        q.put(([float(x) for x in log[:, 0].cpu()], dec.blob.cpu().numpy().copy(), geo_d.cpu().numpy().copy(), col_d.cpu().numpy().copy(),
+               v.cpu().numpy().copy(), dist.get_backend()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(('error', traceback.format_exc()))
+        raise
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('all_rows', (False, True))
+def test_rccl_collectives_on_the_launch_stream(all_rows):
+    """The production exchange on the production backend: ONE rank, backend 'nccl' (= RCCL), the native loop split in phases around
+    dist.all_reduce of the gradient bucket on DEVICE memory (no host staging), the uint8 MAX agreement on the touched rows and the
+    pose broadcast.  A sum over one rank is the identity, so parameters and losses must equal the plain single-process loop - what
+    this pins on hardware is that RCCL loads, takes the library's buffers and orders itself against the launch stream on both sides
+    of the collective.  (Two or more ranks need as many GPUs: RCCL refuses two ranks on one device - the 2-rank logic runs over gloo
+    above, the 8-rank curve is the driver's.)"""
+    from util import make_engine
+    eng = make_engine('hip')
+    mo, frames, dec, geo_d, col_d = build(eng, 2 * R, None, all_rows)
+    rnd = draws().to(eng.device)
+    fid = torch.zeros(2 * R, dtype=torch.int32, device=eng.device)
+    log = eng.zeros(ITERS, 4)
+    mo.run(ITERS, 1, frames, rnd.reshape(ITERS, -1).contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW, log)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q, all_rows))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    if p.is_alive():
+        p.kill()
+    assert res[0] != 'error', res[1]
+    assert p.exitcode == 0 and res[5] == 'nccl'
+    np.testing.assert_allclose(res[0], log[:, 0].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(res[1], dec.blob.cpu().numpy(), rtol=0, atol=2e-6)
+    # (feature rows: float atomics order inside the gather is the only source of difference between two runs of the same loop)
+    assert float(np.abs(res[2] - geo_d.cpu().numpy()).max()) < 1e-4 and float(np.abs(res[3] - col_d.cpu().numpy()).max()) < 1e-4
+    np.testing.assert_array_equal(res[4], np.arange(7, dtype=np.float32))
