@@ -301,23 +301,26 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
 // Embedding gradient of the geometry decoder, d e = W_3[:, embedding]^T d y_3 + W_0^T d y_0, one 32-unit block at a time (one accumulator
 // tile alive; the loop is not unrolled - three copies of the 48 cosines and 144 reductions are code nobody needs):
 // e_u = sin(x_u): ge_u = de_u cos(x_u);  WW: dB[i][u] += sum_s ge_u a_i(s) (-> part);  WP: dp_i += ge_u 2 pi B[i][u]
-template <bool WP, bool WW>
+// GH16: the pieces are fp16 pairs of the 2^10-scaled chain (decode_bwd_geo_wave); isc scales d e back
+template <bool WP, bool WW, bool GH16>
 __device__ __forceinline__ void geo_embed_bwd(const u32x4* __restrict__ FB, const float* __restrict__ B, const u32x4* __restrict__ park,
-                                              const LkB8 (&y0)[2], float a0, float a1, float a2, float& dpx, float& dpy, float& dpz,
-                                              float* __restrict__ part, int lane) {
+                                              const typename BwdPiece<GH16>::T (&y0)[2], float isc, float a0, float a1, float a2,
+                                              float& dpx, float& dpy, float& dpz, float* __restrict__ part, int lane) {
+    typedef BwdPiece<GH16> PC;
+    constexpr int NP = PC::NP;
     const int h = lane >> 5;
 #pragma unroll 1
     for (int tile = 0; tile < 3; ++tile) {
         f32x16 de = lk_zero16();
 #pragma unroll
         for (int G = 0; G < 2; ++G) {
-            LkB8 b;
+            typename PC::T b;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b.p[q] = park[(G * 3 + q) * 64 + lane];
-            de = lk_mma6(lk_fragb_load(FB + FM3_TRB, 4, G, tile, lane), b, de);
+            for (int q = 0; q < NP; ++q) b.p[q] = park[(G * NP + q) * 64 + lane];
+            de = PC::mma(PC::load(FB + PC::tr(3), 4, G, tile, lane), b, de);
         }
 #pragma unroll
-        for (int G = 0; G < 2; ++G) de = lk_mma6(lk_fragb_load(FB + FM0_TRB, 3, G, tile, lane), y0[G], de);
+        for (int G = 0; G < 2; ++G) de = PC::mma(PC::load(FB + PC::tr(0), 3, G, tile, lane), y0[G], de);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int u0 = 32 * tile + 8 * g + 4 * h;
@@ -328,7 +331,7 @@ __device__ __forceinline__ void geo_embed_bwd(const u32x4* __restrict__ FB, cons
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int u = u0 + t;
-                float ge = de[4 * g + t] * lk_cosf(lk_fourier_arg(a0, a1, a2, bb0[t], bb1[t], bb2[t]));
+                float ge = (GH16 ? de[4 * g + t] * isc : de[4 * g + t]) * lk_cosf(lk_fourier_arg(a0, a1, a2, bb0[t], bb1[t], bb2[t]));
                 if (u >= EG) ge = 0.0f;                      // padding units of the last block
                 if (WP) {
                     const float gx = ge * LK_TWO_PI;
@@ -346,14 +349,23 @@ __device__ __forceinline__ void geo_embed_bwd(const u32x4* __restrict__ FB, cons
 // ================= geometry decoder backward: one wave = one 32-sample tile =================
 // part = this wave's [3][96] slice of the workgroup's d B_g partial sums (LDS)
 // park = this wave's 6 x 64 u32x4 of LDS for the pieces of d y_3
+// GH16: products on fp16 pieces, as the colour trunk's H16 - only where d occ is bounded: the mapper's L1 depth term has unit
+// gradients (LK_FLAG_UNIT_LOSS_GRADS without ray gradients), so d occ = d depth . d depth / d occ + d colour . d colour / d occ is at most
+// of the order of the sample spacing.  The chain is linear in d occ: d occ is multiplied by 2^10 once, d c and d e are scaled back where
+// they leave the chain.  Half the matrix instructions of the wave's dependent chain (three per product instead of six).
+template <bool GH16>
 __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, int tile, float* __restrict__ part, u32x4* __restrict__ park) {
+    typedef BwdPiece<GH16> PC;
+    typedef typename PC::T Piece;
+    constexpr int NP = PC::NP;
+    constexpr float SC = GH16 ? 1024.0f : 1.0f, ISC = GH16 ? 1.0f / 1024.0f : 1.0f;
     const int lane = lk_lane();
     const BwdSample d = bwd_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + (GH16 ? FRAGB_U4 : 0);
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_geo = a.act + (size_t)sp * LK_ACT_GEO_A;
@@ -362,52 +374,60 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
     float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;                     // this lane's share of dL/dp (embedding path)
     // ================= geometry decoder =================
     {
-        const float docc = draw.w;
-        f32x16 dh, dy, dcg[1], acc1[1];
+        const float docc = GH16 ? draw.w * SC : draw.w;
+        f32x16 dh, dy, dcg, acc1;
+        auto gemm2 = [&](f32x16& acc, const u32x4* fr, const f32x16& x) {        // acc += M^T x over the two 16-k blocks of a 32-wide x
+#pragma unroll
+            for (int G = 0; G < 2; ++G) acc = PC::mma(PC::load(fr, 1, G, 0, lane), PC::split(x, G), acc);
+        };
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 wo = *reinterpret_cast<const float4*>(W + G_WO + 8 * g + 4 * h);
             dh[4 * g] = wo.x * docc; dh[4 * g + 1] = wo.y * docc; dh[4 * g + 2] = wo.z * docc; dh[4 * g + 3] = wo.w * docc;
         }
-        dcg[0] = lk_zero16();
+        dcg = lk_zero16();
 #pragma unroll
         for (int i = 4; i >= 0; --i) {
-            const u32x4* Utr = FB + (i == 0 ? FM5_TRB : i == 1 ? FM6_TRB : i == 2 ? FM7_TRB : i == 3 ? FM8_TRB : FM9_TRB);
-            lk_gemm_b6<1, 2>(dcg, Utr, 1, 0, 0, dh, 0, lane);
+            const u32x4* Utr = FB + PC::tr(5 + i);
+            gemm2(dcg, Utr, dh);
             const f32x16 av = ct_load32(act_geo + i * 32, lane);
 #pragma unroll
             for (int q = 0; q < 16; ++q) dy[q] = (av[q] > 0.0f) ? dh[q] : 0.0f;
             if (i == 4 || i == 2 || i == 1) {
-                acc1[0] = lk_zero16();
-                lk_gemm_b6<1, 2>(acc1, FB + (i == 4 ? FM4_TRB : i == 2 ? FM2_TRB : FM1_TRB), 1, 0, 0, dy, 0, lane);
-                dh = acc1[0];
+                acc1 = lk_zero16();
+                gemm2(acc1, FB + PC::tr(i), dy);
+                dh = acc1;
             } else if (i == 3) {
                 // layer 3 reads [embedding | h_2]: only the h_2 block of W_3^T d y_3 is needed now.  The three embedding blocks are
                 // formed at the end, in front of layer 0's (same products in the same order - bit-identical), from the pieces of d y_3
                 // parked in LDS: three accumulator tiles less are alive through layers 2..0, which is what lets the kernel run at
                 // three waves per SIMD
-                acc1[0] = lk_zero16();
+                acc1 = lk_zero16();
 #pragma unroll
                 for (int G = 0; G < 2; ++G) {
-                    const LkB8 b = lk_split_ct(dy, G);
+                    const Piece b = PC::split(dy, G);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) park[(G * 3 + q) * 64 + lane] = b.p[q];
-                    acc1[0] = lk_mma6(lk_fragb_load(FB + FM3_TRB, 4, G, 3, lane), b, acc1[0]);
+                    for (int q = 0; q < NP; ++q) park[(G * NP + q) * 64 + lane] = b.p[q];
+                    acc1 = PC::mma(PC::load(FB + PC::tr(3), 4, G, 3, lane), b, acc1);
                 }
-                dh = acc1[0];
+                dh = acc1;
             }
             // i == 0: only the embedding receives gradient (below)
             __builtin_amdgcn_sched_barrier(0);      // keeps the fragment loads of the layers below from being hoisted to the top (registers)
         }
-        ct_store32(a.dc_geo + (size_t)d.sample * LK_C, dcg[0], d.store, lane);
+        if (GH16) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dcg[q] *= ISC;
+        }
+        ct_store32(a.dc_geo + (size_t)d.sample * LK_C, dcg, d.store, lane);
         // Embedding gradient d e = W_3[:, embedding]^T d y_3 + W_0^T d y_0, one 32-unit block at a time (one accumulator tile alive):
         // e_u = sin(x_u): ge_u = de_u cos(x_u);  dB[i][u] += sum_s ge_u a_i(s);  dp_i += ge_u 2 pi B[i][u]
-        const LkB8 y0[2] = {lk_split_ct(dy, 0), lk_split_ct(dy, 1)};
+        const Piece y0[2] = {PC::split(dy, 0), PC::split(dy, 1)};
         // (the flags select the form once, outside the loop: with `if (want_p)` per value the compiler sinks the whole d p chain - and with it
         // all 48 ge values and the 144 entries of B they need - to the end of the kernel: 216 registers instead of ~130)
-        if (want_p && !want_w) geo_embed_bwd<true, false>(FB, W + G_EB, park, y0, a0, a1, a2, dpx, dpy, dpz, part, lane);
-        else if (want_w && !want_p) geo_embed_bwd<false, true>(FB, W + G_EB, park, y0, a0, a1, a2, dpx, dpy, dpz, part, lane);
-        else geo_embed_bwd<true, true>(FB, W + G_EB, park, y0, a0, a1, a2, dpx, dpy, dpz, part, lane);
+        if (want_p && !want_w) geo_embed_bwd<true, false, GH16>(FB, W + G_EB, park, y0, ISC, a0, a1, a2, dpx, dpy, dpz, part, lane);
+        else if (want_w && !want_p) geo_embed_bwd<false, true, GH16>(FB, W + G_EB, park, y0, ISC, a0, a1, a2, dpx, dpy, dpz, part, lane);
+        else geo_embed_bwd<true, true, GH16>(FB, W + G_EB, park, y0, ISC, a0, a1, a2, dpx, dpy, dpz, part, lane);
     }
     if (want_p) {
         dpx += __shfl_xor(dpx, 32); dpy += __shfl_xor(dpy, 32); dpz += __shfl_xor(dpz, 32);
@@ -422,7 +442,8 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
 #ifndef LK_DBWD_MINB
 #define LK_DBWD_MINB 2
 #endif
-template <bool H16, bool DEEP>
+// GH16: the geometry role on fp16 pieces too (launcher: unit-scale loss gradients and no ray gradients - the mapper's iterations)
+template <bool H16, bool DEEP, bool GH16 = false>
 __global__ __launch_bounds__(256, LK_DBWD_MINB) void k_decode_bwd(LkDecodeBwdArgs a, int n_col_blocks) {
     __shared__ u32x4 s_x[2 * 24 * 64];
     __shared__ float s_o[4][3 * 32];
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(256, LK_DBWD_MINB) void k_decode_bwd(LkDecodeBwdArg
         __syncthreads();
     }
     const int tile = gb * 4 + w;
-    if (tile * 32 < P_live) decode_bwd_geo_wave(a, tile, s_part[w], s_x + 512 + w * (6 * 64));       // (s_part ends at s_x[288])
+    if (tile * 32 < P_live) decode_bwd_geo_wave<GH16>(a, tile, s_part[w], s_x + 512 + w * (6 * 64));       // (s_part ends at s_x[288])
     if (want_w) {
         __syncthreads();
         for (int e = threadIdx.x; e < 3 * EGP; e += 256)
@@ -485,6 +506,8 @@ int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_composite_bwd, dim3(lk_cdiv(a.R, 256)), dim3(256), 0, st, a);
     return LK_OK;
 }
+// LK_GEO_BWD_BF16=1 keeps the geometry role on bf16 pieces everywhere (A/B timing, accuracy comparisons)
+static bool lk_geo_bf16_forced() { static const bool f = getenv("LK_GEO_BWD_BF16") != nullptr; return f; }
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_BWD, st);
     const int tiles = lk_cdiv(a.P, 32);
@@ -495,7 +518,12 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     const bool h16 = (a.flags & LK_FLAG_UNIT_LOSS_GRADS) != 0;
     const bool deep = n_col > 0 && n_col <= LK_DEEP_MAX_TILES;
     const dim3 grid(n_col + lk_cdiv(tiles, 4));
-    if (h16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true>), grid, dim3(256), 0, st, a, n_col);
+    // the geometry decoder's backward follows where d depth is bounded as well: unit-scale loss gradients WITHOUT ray gradients (with them
+    // the caller is the tracker, whose d depth = 1 / sqrt(var) is not)
+    const bool gh16 = h16 && !(a.flags & LK_FLAG_GRAD_RAYS) && !lk_geo_bf16_forced();
+    if (gh16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true, true>), grid, dim3(256), 0, st, a, n_col);
+    else if (gh16) hipLaunchKernelGGL((k_decode_bwd<true, false, true>), grid, dim3(256), 0, st, a, n_col);
+    else if (h16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true>), grid, dim3(256), 0, st, a, n_col);
     else if (h16) hipLaunchKernelGGL((k_decode_bwd<true, false>), grid, dim3(256), 0, st, a, n_col);
     else if (deep) hipLaunchKernelGGL((k_decode_bwd<false, true>), grid, dim3(256), 0, st, a, n_col);
     else hipLaunchKernelGGL((k_decode_bwd<false, false>), grid, dim3(256), 0, st, a, n_col);
@@ -503,6 +531,6 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
 }
 int lk_occupancy_decode_bwd() {
     int n = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_decode_bwd<true, false>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_decode_bwd<true, false, true>, 256, 0);
     return n;
 }
