@@ -240,9 +240,10 @@ def test_ba_mode_backward_at_bench_size(model, R, unit):
     # The ray gradients of THIS loss (d depth = +-1 on every ray) are sums over 40 neighbour terms per ray that cancel to a few per cent of
     # their size: measured 0.9-1.4e-4 max-norm / 2.2-3.2e-2 element-wise, IDENTICAL for bf16 and fp16 pieces (so not a piece effect), while the
     # fp32 oracle's own distance to its float64 evaluation on these two tensors is 0.8-1.2e-2 (tools/probe/oracle_noise_ba.py).  Twice the
-    # common bars; feature rows and weights of the same backward stay on the common ones.
-    _check_grad('rays_o', gs.g_rays_o.cpu(), g_ro, case, tol=2 * TOL_GRAD, tol_el=2 * TOL_GRAD_EL)
-    _check_grad('rays_d', gs.g_rays_d.cpu(), g_rd, case, tol=2 * TOL_GRAD, tol_el=2 * TOL_GRAD_EL)
+    # common bars would hold on the boxes seen so far; three times, because the oracle's noise moves with the HOST's torch kernels (the note at
+    # TOL_GRAD) - feature rows and weights of the same backward stay on the common bars.
+    _check_grad('rays_o', gs.g_rays_o.cpu(), g_ro, case, tol=3 * TOL_GRAD, tol_el=3 * TOL_GRAD_EL)
+    _check_grad('rays_d', gs.g_rays_d.cpu(), g_rd, case, tol=3 * TOL_GRAD, tol_el=3 * TOL_GRAD_EL)
     gW = dec.unpack(gs.g_weights)
     n = 0
     for name, ref in gWo.items():
