@@ -64,6 +64,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dctx = None
+    # LOOPY_DIST_FORCE=1 with one rank: the data-parallel code path (lk_map_frame split in phases around a real RCCL all-reduce, bucket
+    # pack / unpack, replicated tracking's broadcast) on ONE GPU - what the exchange machinery costs before any second GPU is involved
+    force_dist = world == 1 and os.environ.get('LOOPY_DIST_FORCE') == '1'
+    if force_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group(backend, rank=0, world_size=1, **({'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}))
+        dctx = parallel.DistContext(0, 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -198,7 +206,7 @@ def main():
             import bench_cpu_baseline
             out['cpu_baseline'] = bench_cpu_baseline.run(budget, cloud=cloud0)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
