@@ -63,6 +63,9 @@ def main():
     if one_dev:
         local = 0
     torch.cuda.set_device(local)
+    # before the process group: the library's side streams take their hardware queues first (lk_streams_init; a side stream that lands on the
+    # launch stream's queue behind torch's / RCCL's streams serialises the weight-gradient fork of every 'color' iteration)
+    eng = core.Engine()
     dctx = None
     # LOOPY_DIST_FORCE=1 with one rank: the data-parallel code path (lk_map_frame split in phases around a real RCCL all-reduce, bucket
     # pack / unpack, replicated tracking's broadcast) on ONE GPU - what the exchange machinery costs before any second GPU is involved
@@ -79,7 +82,6 @@ def main():
         else:
             dist.init_process_group(backend)
         dctx = parallel.DistContext(rank, world)
-    eng = core.Engine()
     budget = workload.Budget(n_points=args.points)
     if args.strong and world > 1:
         budget.map_rays = max(32, budget.map_rays // world)          # tracking is replicated (not sharded) in either mode

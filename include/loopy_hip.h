@@ -230,6 +230,8 @@ typedef struct {
                                                  with a non-zero flag are stepped.  Exact whenever the skipped rows have a zero gradient and zero
                                                  moments (Adam leaves such an element bit for bit where it is): whole-map refinement over millions
                                                  of rows of which an optimize_map call touches a few per cent (lk_map_frame sets the flags) */
+    int32_t g_compact;                        /* with row_index: g is indexed like m and v (element i), not like p - the gradient rows arrive
+                                                 compact in row-list order (a data-parallel caller's all-reduced bucket); zero_grad is ignored */
 } lk_adam_seg;
 int lk_adam_step(const lk_adam_seg* host_segs, int32_t n_seg, float beta1, float beta2, float eps, void* stream);
 
@@ -252,7 +254,8 @@ int lk_loss_mapper_exposure(int32_t R, const float* depth, const float* logits, 
 /* Gradient exchange bucket of the ray-sharded data-parallel step (the all-reduce payload of Mapper.py:722-724's
  * step = decoder-gradient spans + the feature-gradient rows being optimised): segment i is `n` floats at `data`
  * (row_index NULL) or the rows data[row_index[k]] of a [*, row_len] table (n = rows * row_len); the bucket is the
- * concatenation of the segments.  unpack = 0: bucket <- segments, 1: segments <- bucket.  One launch either way. */
+ * concatenation of the segments.  unpack = 0: bucket <- segments, 1: segments <- bucket, 2: bucket <- segments and the copied source
+ * elements are cleared (for lk_map_desc::grad_bucket: the step then reads the bucket and nothing is unpacked).  One launch either way. */
 typedef struct lk_copy_seg {
     float* data;
     int64_t n;
@@ -435,6 +438,13 @@ typedef struct {
     const lk_exposure_desc* exposure;   /* model.encode_exposure (HOST pointer) or NULL: the 'color' iterations render colour LOGITS and the loss
                                    applies sigmoid(logits @ rot_f + trans_f) of the ray's keyframe f = frame_id (Mapper.py:697-715);
                                    needs `work`; bwd_scratch sized WITHOUT LK_FLAG_UNIT_LOSS_GRADS (d logits = w sigma' A is unbounded) */
+    const float* grad_bucket;   /* phase-2 calls of a data-parallel caller (rows != NULL, no exposure): the all-reduced gradient bucket or NULL.  With
+                                   it the step reads its gradients from the bucket itself - decoder span k of the geometry / colour list at float
+                                   offset bucket_geo_dec[k] / bucket_col_dec[k], the optimised rows of the two tables compact (row-list order) at
+                                   bucket_geo_rows / bucket_col_rows - and no unpack launch is needed; the caller packs with lk_bucket_copy mode 2
+                                   (copy + clear the source: what the step's zero_grad would have done) */
+    int64_t bucket_geo_dec[LK_MAX_SPANS], bucket_col_dec[LK_MAX_SPANS];
+    int64_t bucket_geo_rows, bucket_col_rows;
     int32_t union_rows_flagged; /* rows == NULL, phase-split (data-parallel) callers: non-zero = between phase 1 and phase 2 of every iteration
                                    the caller ORs the union of the rows ALL ranks touched into the index's row flags (lk_knn_flag_rows); the
                                    step then visits the flagged rows only, as the single-process call does on its own (0: dense step) */
@@ -447,6 +457,9 @@ int64_t lk_map_work_nbr_idx(int32_t R, int32_t S, int32_t iters);
  * scan that consumes them clears them) and lk_map_frame's look-ahead search and sort run on a library-owned stream.  The call with
  * it_begin = 0 joins that stream before it touches `work`; after an ERROR return from lk_map_frame / lk_render_bwd the counters may be
  * stale - lk_knn_build (which clears them) before the handle renders a backward again. */
+/* Phase-split callers (phases 1, then 2, per iteration): the phase-2 call of a 'color' iteration that is not the call's last leaves the
+ * fragment repack to the phase-1 call of the NEXT iteration (it rides in that call's interpolation launch, as in the unsplit loop) - the
+ * iterations of an optimize_map call must be issued in order, each phase 1 followed by its phase 2. */
 int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t phases, void* stream);
 /* Makes `stream` wait until the neighbour lists of iteration `it` (work + lk_map_work_nbr_idx) are written: lk_map_frame
  * searches ahead of its loop on a library-owned stream.  Valid after the phase-1 call of iteration it - 1 (or it) of the same
@@ -472,6 +485,10 @@ int lk_profile_begin(const char* names);
  * everything on the caller's stream - per-kernel durations are then those of a kernel running alone (measurement; the
  * environment variable LK_SERIAL sets the initial state). */
 int lk_set_serial(int32_t on);
+/* Creates the library's side streams now (they are otherwise created at their first use).  Call right after choosing the device and BEFORE
+ * anything that creates many streams of its own (torch.distributed process groups, RCCL): the runtime multiplexes streams onto a few hardware
+ * queues in creation order, and a side stream that shares the launch stream's queue serialises the backward's fork. */
+int lk_streams_init(void);
 int lk_profile_end(char* buf, int cap);
 /* Measurement: resident 256-thread workgroups per compute unit of the five MLP kernels, as the runtime computes them from the
  * registers and LDS of the loaded code objects (hipOccupancyMaxActiveBlocksPerMultiprocessor): out[0..4] = k_decode_fwd,

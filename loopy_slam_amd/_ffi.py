@@ -64,7 +64,7 @@ class RenderDesc(C.Structure):
 class AdamSeg(C.Structure):
     _fields_ = [('p', _fp), ('g', _fp), ('m', _fp), ('v', _fp), ('n', C.c_int64), ('lr', C.c_float),
                 ('step', C.c_int32), ('row_index', _fp), ('row_len', C.c_int32), ('zero_grad', C.c_int32), ('p_f16', C.c_int32),
-                ('row_flags', _fp)]
+                ('row_flags', _fp), ('g_compact', C.c_int32)]
 
 
 class CopySeg(C.Structure):
@@ -119,6 +119,8 @@ class MapDesc(C.Structure):
         ('adam_dec', _fp),
         ('lr', (C.c_float * 3) * 2),
         ('iters', C.c_int32), ('n_geo_iters', C.c_int32), ('work', _fp), ('exposure', C.POINTER(ExposureDesc)),
+        ('grad_bucket', _fp), ('bucket_geo_dec', C.c_int64 * MAX_SPANS), ('bucket_col_dec', C.c_int64 * MAX_SPANS),
+        ('bucket_geo_rows', C.c_int64), ('bucket_col_rows', C.c_int64),
         ('union_rows_flagged', C.c_int32),
     ]
 
@@ -184,6 +186,7 @@ class LoopyLib:
             ('lk_profile_end', [C.c_char_p, C.c_int], C.c_int),
             ('lk_compact', [_fp, C.c_int32, _fp, _fp, C.c_void_p], C.c_int),
             ('lk_set_serial', [C.c_int32], C.c_int),
+            ('lk_streams_init', [], C.c_int),
             ('lk_debug_occupancy', [C.POINTER(C.c_int32)], C.c_int),
             ('lk_track_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
             ('lk_map_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),

@@ -27,6 +27,10 @@ class Engine:
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         self.device = torch.device(device)
+        if self.device.type == 'cuda':
+            # the library's side streams take their hardware queues now, before a process group / RCCL creates its own (lk_streams_init)
+            with torch.cuda.device(self.device):
+                self.lib.check(self.lib.dll.lk_streams_init(), 'lk_streams_init')
 
     @property
     def stream(self):

@@ -16,7 +16,7 @@ __device__ __forceinline__ float lk_adam_elem(float p, float g, float& m, float&
 // the full table, Mapper.py:498-512,578-586), p[row_index[i / row_len] * row_len + i % row_len]; m and v are
 // always compact.  zero_grad clears the consumed gradient so the next iteration's scatter-add starts from 0.
 __device__ __forceinline__ void lk_adam_one(const AdamSegDev& S, long long i, long long e, float b1, float b2, float eps) {
-    const float g = S.g[e];
+    const float g = S.g[S.g_compact ? i : e];
     float m = S.m[i], v = S.v[i];
     if (S.p_f16) {                                      // half table: fp32 step, stored rounded to nearest
         _Float16* ph = reinterpret_cast<_Float16*>(S.p) + e;
@@ -26,7 +26,7 @@ __device__ __forceinline__ void lk_adam_one(const AdamSegDev& S, long long i, lo
     }
     S.m[i] = m;
     S.v[i] = v;
-    if (S.zero_grad) S.g[e] = 0.0f;
+    if (S.zero_grad && !S.g_compact) S.g[e] = 0.0f;
 }
 // Flagged rows (lk_adam_seg::row_flags): a wave reads the flags of 64 consecutive rows with one coalesced load, then walks the set bits
 // of the ballot - rows of up to 64 elements, one per half-wave when row_len <= 32 (the feature tables: 32).  A 5 M-row table of which a

@@ -293,6 +293,18 @@ SideStream& side_stream() {
 }  // namespace
 
 extern "C" int lk_set_serial(int32_t on) { g_serial = on ? 1 : 0; return LK_OK; }
+// Creates the library's two streams NOW instead of at their first use.  The runtime hands its few hardware queues to streams as they are
+// created: a process that first creates dozens of other streams (torch's stream pool comes into being with the first collective of a
+// process group, RCCL brings its own) and only then renders can find the library's side stream on the SAME hardware queue as the launch
+// stream - the weight-gradient fork of every 'color' iteration then runs serialised behind 12-us barrier packets (measured: 370 instead of
+// 308 us per iteration, tools/trace_window.py).  Call it right after the device is chosen; core.Engine does.
+extern "C" int lk_streams_init(void) {
+    if (lk_serial_mode()) return LK_OK;
+    SideStream& s = side_stream();
+    LkAuxStream& a = lk_aux_stream();
+    LK_REQUIRE(s.ok && a.ok, "lk_streams_init: stream / event creation failed");
+    return LK_OK;
+}
 extern "C" int lk_debug_occupancy(int32_t out[5]) {
     LK_REQUIRE(out != nullptr, "lk_debug_occupancy: out is null");
     out[0] = lk_occupancy_decode_fwd(); out[1] = lk_occupancy_decode_bwd(); out[2] = lk_occupancy_relpos_fwd();

@@ -139,6 +139,7 @@ struct AdamSegDev {
     float* p; float* g; float* m; float* v; long long n; float step_size, bc2_sqrt;
     const int32_t* row_index; int row_len; int zero_grad; int p_f16;
     const uint8_t* row_flags;                      // or NULL: only flagged rows are stepped (lk_adam_seg::row_flags)
+    int g_compact;                                 // g indexed like m / v (lk_adam_seg::g_compact)
 };
 // The Adam step of a mapper 'color' iteration as a rider of its reduction launch (lk_map_frame with no gradient exchange between the
 // backward and the step): every decoder gradient element has exactly ONE owner thread in k_bwd_reduce, which steps the element as

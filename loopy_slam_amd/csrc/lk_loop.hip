@@ -713,8 +713,11 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 if (rc != LK_OK) return rc;
             }
             x_fwd_done = x_fwd_done || xit;
+            // phase-split caller: the step of 'color' iteration it - 1 (its own call) moved the colour decoder and left the repack to this launch
+            const bool split_repack = pre && (phases & 3) == 1 && it == it_begin && it > d->n_geo_iters && !embed_only && d->n_col_dec > 0 &&
+                                      d->render.weights == d->weights_rw;
             rc = lk_render_fwd_impl(&rd, st, (xit ? 0 : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0), live,
-                                    (repack_pending || stepped_pending) ? &rr : nullptr);
+                                    (repack_pending || stepped_pending || split_repack) ? &rr : nullptr);
             repack_pending = false; stepped_pending = false;
             if (rc != LK_OK) return rc;
             if (xit) {          // Mapper.py:697-715 on the rendered logits: d depth, d logits, loss row, d loss / d affine
@@ -752,7 +755,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                         AdamSegDev& f = sr.feat[sr.n_feat++];
                         f.p = seg[q].p; f.g = seg[q].g; f.m = seg[q].m; f.v = seg[q].v; f.n = seg[q].n; f.step_size = step_size; f.bc2_sqrt = bc2_sqrt;
                         f.row_index = seg[q].row_index; f.row_len = seg[q].row_len > 0 ? seg[q].row_len : 1; f.zero_grad = seg[q].zero_grad; f.p_f16 = seg[q].p_f16;
-                        f.row_flags = seg[q].row_flags;
+                        f.row_flags = seg[q].row_flags; f.g_compact = seg[q].g_compact;
                         if (seg[q].n > nmax) nmax = seg[q].n;
                     }
                 }
@@ -771,6 +774,17 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             memset(seg, 0, sizeof(seg));
             int ns = 0;
             LK_REQUIRE(build_segs(it, color, seg, ns), "lk_map_frame: too many optimiser segments");
+            if (d->grad_bucket && (phases & 3) == 2) {
+                // data-parallel caller: the summed gradients are in its all-reduce bucket - decoder spans at their bucket offsets, the optimised
+                // rows compact in row-list order - and the step reads them there (no unpack launch; the pack cleared the sources)
+                LK_REQUIRE(d->rows != nullptr && !xd, "lk_map_frame: grad_bucket needs a row list and no exposure encoding");
+                int q = 0;
+                for (int k = 0; k < d->n_geo_dec; ++k, ++q) { seg[q].g = const_cast<float*>(d->grad_bucket) + d->bucket_geo_dec[k]; seg[q].zero_grad = 0; }
+                if (color) for (int k = 0; k < d->n_col_dec; ++k, ++q) { seg[q].g = const_cast<float*>(d->grad_bucket) + d->bucket_col_dec[k]; seg[q].zero_grad = 0; }
+                seg[q].g = const_cast<float*>(d->grad_bucket) + d->bucket_geo_rows; seg[q].g_compact = 1; seg[q].zero_grad = 0; ++q;
+                if (color) { seg[q].g = const_cast<float*>(d->grad_bucket) + d->bucket_col_rows; seg[q].g_compact = 1; seg[q].zero_grad = 0; ++q; }
+                LK_REQUIRE(q == ns, "lk_map_frame: segment order changed under grad_bucket");
+            }
             if (use_rider) {        // stepped inside k_bwd_reduce; the next iteration's interpolation launch copies the blob back and repacks
                 stepped_pending = true;
                 continue;
@@ -788,7 +802,9 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             if (color && !embed_only) {        // the matrix fragments are copies of the colour-decoder matrices, which only move in this stage
                 // (rd.weights == weights_rw: the next iteration's forward reads what this step wrote)
                 if (pre && (phases & 3) == 3 && it + 1 < it_end && d->render.weights == d->weights_rw) repack_pending = true;
-                else {
+                else if (pre && (phases & 3) == 2 && it + 1 < d->iters && d->render.weights == d->weights_rw) {
+                    // phase-split caller: the phase-1 call of iteration it + 1 repacks in its interpolation launch (split_repack below)
+                } else {
                     rc = lk_weights_repack(d->weights_rw, d->weights_frag_rw, st);
                     if (rc != LK_OK) return rc;
                 }

@@ -688,7 +688,7 @@ int lk_adam_step_x(const lk_adam_seg* segs, int32_t n_seg, float beta1, float be
         const double bc2 = 1.0 - pow((double)beta2, (double)segs[i].step);
         a.s[i].p = segs[i].p; a.s[i].g = segs[i].g; a.s[i].m = segs[i].m; a.s[i].v = segs[i].v; a.s[i].n = segs[i].n;
         a.s[i].row_index = segs[i].row_index; a.s[i].row_len = segs[i].row_len > 0 ? segs[i].row_len : 1;
-        a.s[i].zero_grad = segs[i].zero_grad;
+        a.s[i].zero_grad = segs[i].zero_grad; a.s[i].g_compact = segs[i].g_compact;
         a.s[i].p_f16 = segs[i].p_f16;
         a.s[i].row_flags = segs[i].row_flags;
         LK_REQUIRE(!segs[i].row_flags || (!segs[i].row_index && a.s[i].row_len <= 64 && segs[i].n % a.s[i].row_len == 0),
@@ -716,8 +716,11 @@ __global__ __launch_bounds__(256) void k_bucket_copy(CopyArgs a) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < sg.n; i += (long long)gridDim.x * 256) {
         long long src = i;
         if (sg.row_index) { const long long r = i / sg.row_len; src = (long long)sg.row_index[r] * sg.row_len + (i - r * sg.row_len); }
-        if (a.unpack) sg.data[src] = a.bucket[sg.off + i];
-        else a.bucket[sg.off + i] = sg.data[src];
+        if (a.unpack == 1) sg.data[src] = a.bucket[sg.off + i];
+        else {
+            a.bucket[sg.off + i] = sg.data[src];
+            if (a.unpack == 2) sg.data[src] = 0.0f;
+        }
     }
 }
 extern "C" int lk_bucket_copy(const lk_copy_seg* segs, int32_t n_seg, float* bucket, int32_t unpack, void* stream_) {

@@ -82,22 +82,31 @@ class DistContext:
         return t
 
     # ------------------------------------------------------------------ gradient bucket
-    def all_reduce_grads(self, mo, stage='color', it=None):
+    def all_reduce_grads(self, mo, stage='color', it=None, desc=None):
         """mo: steps.MapOptimizer after render_backward.  Sum over ranks exactly what this stage's Adam step consumes:
         the decoder-gradient ranges being stepped (geometry: embedder._B only; colour: + every colour-decoder tensor),
         g_geo[rows], and in the colour stage g_col[rows] - one bucket, one all-reduce, one pack and one unpack launch
-        (lk_bucket_copy: the torch formulation was eight small kernels per iteration)."""
+        (lk_bucket_copy: the torch formulation was eight small kernels per iteration).
+        desc: the lk_map_desc of a phase-split lk_map_frame loop over a row list without exposure encoding - the step of the phase-2
+        call then reads the summed gradients from the bucket itself (lk_map_desc::grad_bucket): the pack clears its sources
+        (lk_bucket_copy mode 2) and nothing is unpacked."""
         gs, eng = mo.gs, mo.eng
+        direct = desc is not None and mo.rows is not None and (mo.exposure is None)
+        if desc is not None and not direct:
+            desc.grad_bucket = None
         rows = mo.rows if mo.rows is not None else self.touched_rows(mo, it)
         # the segment table of a stage is the same for every iteration of an optimize_map call (same buffers, same row list): built
         # once - at 72-us 'geometry' iterations the interpreter time of rebuilding it per iteration was the longer side
         key = (stage, rows.data_ptr(), rows.numel(), gs.g_weights.data_ptr(), gs.g_geo.data_ptr(), id(mo.exposure))
         if self._seg_cache is not None and self._seg_cache[0] == key:
-            _, segs, n = self._seg_cache
+            _, segs, n, offs = self._seg_cache
             bucket = self._bucket[:n]
-            eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 0, eng.stream), 'lk_bucket_copy')
+            eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 2 if direct else 0, eng.stream), 'lk_bucket_copy')
             self._all_reduce(bucket, dist.ReduceOp.SUM)
-            eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
+            if direct:
+                self._point_desc_at_bucket(mo, desc, stage, bucket, offs)
+            else:
+                eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
             return
         ranges = _merge(list(mo.geo_dec_ranges) + (list(mo.col_dec_ranges) if stage == 'color' else []))
         tables = [gs.g_geo] + ([gs.g_col] if stage == 'color' else [])
@@ -106,12 +115,15 @@ class DistContext:
         xs = mo.exposure if stage == 'color' else None
         segs = (_ffi.CopySeg * (len(ranges) + len(tables) + (1 if xs is not None else 0)))()
         n = 0
+        offs = dict(ranges=[], tables=[])          # where every segment starts in the bucket (floats)
         for k, (o, cnt) in enumerate(ranges):
             segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(gs.g_weights[o:o + cnt]), cnt, None, 1
+            offs['ranges'].append((o, cnt, n))
             n += cnt
         for k, t in enumerate(tables, start=len(ranges)):
             segs[k].data, segs[k].n = ptr(t), rows.numel() * t.shape[1]
             segs[k].row_index, segs[k].row_len = ptr(rows), t.shape[1]
+            offs['tables'].append(n)
             n += segs[k].n
         self._keep = rows
         if xs is not None:
@@ -122,10 +134,30 @@ class DistContext:
             self._bucket = torch.empty(max(n, 2 * (self._bucket.numel() if self._bucket is not None else 0)),
                                        dtype=torch.float32, device=gs.g_weights.device)
         bucket = self._bucket[:n]
-        self._seg_cache = (key, segs, n) if mo.rows is not None else None       # touched-row lists change every iteration
-        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 0, eng.stream), 'lk_bucket_copy')
+        self._seg_cache = (key, segs, n, offs) if mo.rows is not None else None       # touched-row lists change every iteration
+        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 2 if direct else 0, eng.stream), 'lk_bucket_copy')
         self._all_reduce(bucket, dist.ReduceOp.SUM)
-        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
+        if direct:
+            self._point_desc_at_bucket(mo, desc, stage, bucket, offs)
+        else:
+            eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
+
+    @staticmethod
+    def _point_desc_at_bucket(mo, desc, stage, bucket, offs):
+        """lk_map_desc::grad_bucket and the bucket offsets of every span / table of this stage's step."""
+        def bucket_off(span_off):
+            for o, cnt, b in offs['ranges']:
+                if o <= span_off < o + cnt:
+                    return b + (span_off - o)
+            raise AssertionError('decoder span outside the bucket')
+        desc.grad_bucket = ptr(bucket)
+        for k, (o, _) in enumerate(mo.geo_dec_ranges):
+            desc.bucket_geo_dec[k] = bucket_off(o)
+        if stage == 'color':
+            for k, (o, _) in enumerate(mo.col_dec_ranges):
+                desc.bucket_col_dec[k] = bucket_off(o)
+        desc.bucket_geo_rows = offs['tables'][0]
+        desc.bucket_col_rows = offs['tables'][1] if len(offs['tables']) > 1 else 0
 
     # ------------------------------------------------------------------ touched rows (whole-map optimisation)
     def _enqueue_agreement(self, mo, it, idx):

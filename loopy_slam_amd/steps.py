@@ -341,7 +341,7 @@ class MapOptimizer:
                 eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 1, eng.stream), 'lk_map_frame')
                 if self.rows is None and it + 1 < n_iters and self._nat_lists is not None:
                     self.dist.prefetch_touched(self, it + 1)        # next iteration's row list, agreed beside this iteration's render
-                self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color', it=it)
+                self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color', it=it, desc=d)
                 if self.rows is None:
                     self.dist.flag_union(self)      # rows touched by any rank: what the step of a whole-map iteration visits
                 eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 2, eng.stream), 'lk_map_frame')

@@ -151,10 +151,10 @@ def _rccl_worker(port, q, all_rows):
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
         torch.cuda.set_device(0)
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
         from loopy_slam_amd import parallel
         from util import make_engine
-        eng = make_engine('hip')
+        eng = make_engine('hip')                 # before the process group: the library's streams take their hardware queues first
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
         dctx = parallel.DistContext(0, 1)
         mo, frames, dec, geo_d, col_d = build(eng, 2 * R, dctx, all_rows)
         rnd = draws().to(eng.device)

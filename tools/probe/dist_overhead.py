@@ -9,8 +9,8 @@ from loopy_slam_amd import core, workload, parallel
 
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29531')
 torch.cuda.set_device(0)
+eng = core.Engine()          # before the process group (lk_streams_init)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-eng = core.Engine()
 T = collections.defaultdict(float)
 
 def timed(obj, name, key):
