@@ -57,6 +57,10 @@ def main():
     backend = os.environ.get('LOOPY_DIST_BACKEND', 'nccl')
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
+    if rank != 0:
+        # rank 0 prints the ONE JSON line; whatever a library of another rank writes to its stdout (this RCCL build prints a version banner
+        # when its buffers are flushed at exit) must not land behind it in the launcher's merged output
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world > 1 and not one_dev and torch.cuda.device_count() < world:
         raise SystemExit(f'bench.py: {world} ranks need {world} GPUs, {torch.cuda.device_count()} visible '
                          '(LOOPY_DIST_ONE_DEVICE=1 LOOPY_DIST_BACKEND=gloo puts every rank on device 0 - a functional check, not a measurement)')
@@ -207,9 +211,17 @@ def main():
         if not args.no_cpu_baseline:
             import bench_cpu_baseline
             out['cpu_baseline'] = bench_cpu_baseline.run(budget, cloud=cloud0)
-        print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: C-level buffers first (RCCL's banner sits in libc's buffer until flushed)
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
