@@ -485,7 +485,10 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         fuse_rb = fuse_small;                   // launched together with the interpolation backward below
         if (fuse_rb) rb_fused = rb;
         else lk_launch_relpos_bwd(rb, st);
-        if (forked) { (void)hipEventRecord(ss.mid, st); (void)hipStreamWaitEvent(wst, ss.mid, 0); }
+        // the weight-gradient stream waits for the rel-pos backward only where it consumes its rows (the unfused linear1 / linear2 jobs below): in
+        // the fused form nothing on that stream depends on it, and the event record on the caller's stream is a 6-7 us bubble between the rel-pos
+        // backward and the gather of every 'color' iteration (tools/trace_window.py)
+        if (forked && !lk_relpos_fused(flags)) { (void)hipEventRecord(ss.mid, st); (void)hipStreamWaitEvent(wst, ss.mid, 0); }
         // (the fused kernel - kept in the embedding-only mode, where its linear1 tiles go unused - leaves one partial row per workgroup)
         if (gw && !defer) lk_launch_reduce_partials(S0 + L.part_br, lk_relpos_fused(flags) ? lk_relpos_bwd_parts(P) : lk_cdiv(lk_cdiv(P, 4), 4), 32,
                                                     d->g_weights + R_EB, st);
