@@ -448,6 +448,11 @@ typedef struct {
     int32_t union_rows_flagged; /* rows == NULL, phase-split (data-parallel) callers: non-zero = between phase 1 and phase 2 of every iteration
                                    the caller ORs the union of the rows ALL ranks touched into the index's row flags (lk_knn_flag_rows); the
                                    step then visits the flagged rows only, as the single-process call does on its own (0: dense step) */
+    int32_t it_offset;          /* a long optimize_map call may be issued as consecutive SEGMENTS, one descriptor each: this one covers the
+                                   iterations it_offset .. it_offset + iters - 1 of the call (rnd, log and work are the segment's own; iters
+                                   sizes them), n_geo_iters stays the call's GLOBAL count, the optimiser state (adam_rows, adam_dec) carries
+                                   over and the step counts continue.  The work buffer then holds one segment's batches and neighbour
+                                   lists instead of the whole call's (26 floats per sample and iteration).  0 for an unsegmented call */
 } lk_map_desc;
 int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters);
 /* float offset inside `work` of the neighbour lists lk_map_frame keeps per iteration: int32 [iters][R*S][8] (what a data-parallel

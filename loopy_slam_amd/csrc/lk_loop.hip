@@ -505,6 +505,10 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     LK_REQUIRE(it_begin >= 0 && it_end <= d->iters && it_begin <= it_end && (phases & 3), "lk_map_frame: bad iteration range / phases");
     LK_REQUIRE(d->n_geo_dec >= 0 && d->n_geo_dec <= LK_MAX_SPANS && d->n_col_dec >= 0 && d->n_col_dec <= LK_MAX_SPANS, "lk_map_frame: too many spans");
     if (it_begin == it_end || d->render.R == 0) return LK_OK;
+    // a segment of a longer optimize_map call (lk_map_desc::it_offset): local iteration `it` is the call's iteration goff + it; the first
+    // 'color' iteration has the local index n_geo_l (<= 0: the whole segment is 'color')
+    LK_REQUIRE(d->it_offset >= 0, "lk_map_frame: negative it_offset");
+    const int goff = d->it_offset, n_geo_l = d->n_geo_iters - goff;
     LK_REQUIRE(d->depth_stack && d->color_stack && d->c2w_stack && d->rnd && d->log, "lk_map_frame: NULL batch buffer");
     LK_REQUIRE(d->weights_rw && d->weights_frag_rw && d->geo_feats_rw && d->col_feats_rw && d->adam_rows && d->adam_dec && d->n_rows >= 0,
                "lk_map_frame: NULL optimiser buffer");
@@ -527,7 +531,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     // if it adds the rows the OTHER ranks touched, lk_knn_flag_rows / union_rows_flagged: they receive gradient through the exchange.)
     lk_knn_s* kn_h = d->render.knn;
     const bool act_rows = d->rows == nullptr && ((phases & 3) == 3 || d->union_rows_flagged) && kn_h->act_flag != nullptr && d->n_rows <= kn_h->capacity;
-    if (act_rows && it_begin == 0 && (phases & 1)) LK_HIP_TRY(hipMemsetAsync(kn_h->act_flag, 0, (size_t)d->n_rows, st));
+    if (act_rows && it_begin == 0 && goff == 0 && (phases & 1)) LK_HIP_TRY(hipMemsetAsync(kn_h->act_flag, 0, (size_t)d->n_rows, st));
     const MapWork wk = map_work(R, d->render.S, d->iters);
     const int64_t Pn = (int64_t)R * d->render.S;
     // iterations per chunk of the work that runs ahead; chunk 0 is the first iteration alone (the loop waits for it), chunk c >= 1
@@ -628,19 +632,19 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             s.p = d->weights_rw + sp.offset; s.g = d->render.g_weights + sp.offset; s.m = d->adam_dec + sp.offset; s.v = d->adam_dec + nb + sp.offset;
             s.n = sp.n; s.lr = lr[0]; s.step = step; s.zero_grad = 1;
         };
-        for (int k = 0; k < d->n_geo_dec; ++k) dec_seg(d->geo_dec[k], it + 1);
-        if (color) for (int k = 0; k < d->n_col_dec; ++k) dec_seg(d->col_dec[k], it - d->n_geo_iters + 1);
+        for (int k = 0; k < d->n_geo_dec; ++k) dec_seg(d->geo_dec[k], goff + it + 1);
+        if (color) for (int k = 0; k < d->n_col_dec; ++k) dec_seg(d->col_dec[k], it - n_geo_l + 1);
         if (ns + 2 > LK_ADAM_MAX_SEG) return false;
         {
             lk_adam_seg& s = seg[ns++];
-            s.p = d->geo_feats_rw; s.g = d->render.g_geo_feats; s.m = d->adam_rows; s.v = d->adam_rows + nrow; s.n = nrow; s.lr = lr[1]; s.step = it + 1;
+            s.p = d->geo_feats_rw; s.g = d->render.g_geo_feats; s.m = d->adam_rows; s.v = d->adam_rows + nrow; s.n = nrow; s.lr = lr[1]; s.step = goff + it + 1;
             s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1; s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
             if (act_rows) { s.row_len = LK_C; s.row_flags = kn_h->act_flag; }
         }
         if (color) {
             lk_adam_seg& s = seg[ns++];
             s.p = d->col_feats_rw; s.g = d->render.g_col_feats; s.m = d->adam_rows + 2 * nrow; s.v = d->adam_rows + 3 * nrow; s.n = nrow; s.lr = lr[2];
-            s.step = it - d->n_geo_iters + 1; s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1;
+            s.step = it - n_geo_l + 1; s.row_index = d->rows; s.row_len = d->rows ? LK_C : 1; s.zero_grad = 1;
             s.p_f16 = (d->render.flags & LK_FLAG_FEATS_F16) ? 1 : 0;
             if (act_rows) { s.row_len = LK_C; s.row_flags = kn_h->act_flag; }
         }
@@ -658,9 +662,9 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     for (int k = 0; k < d->n_col_dec; ++k)
         embed_only = embed_only && d->col_dec[k].offset >= R_EB && d->col_dec[k].offset + d->col_dec[k].n <= R_EB + 3 * 10;
     bool w_next_ready = false;
-    bool x_fwd_done = it_begin > d->n_geo_iters;          // a later call of a phase-split sequence: the step launch of the iteration before did the forward
+    bool x_fwd_done = it_begin > n_geo_l;          // a later call of a phase-split sequence: the step launch of the iteration before did the forward
     for (int it = it_begin; it < it_end; ++it) {
-        const bool color = it >= d->n_geo_iters;
+        const bool color = it >= n_geo_l;
         const bool use_rider = rider_ok && !embed_only && color && it + 1 < it_end && d->n_col_dec > 0;
         lk_render_desc rd = d->render;
         const bool xit = xd != nullptr && color;            // this iteration's loss is the exposure variant (its own launch after the composite)
@@ -707,14 +711,14 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             LkRepackRider rr;
             rr.frag = d->weights_frag_rw; rr.src = stepped_pending ? W0 + wk.w_next : nullptr;
             rr.copy_dst = stepped_pending ? d->weights_rw : nullptr; rr.copy_n = (int)nb;
-            if (xit && it == (d->n_geo_iters > it_begin ? d->n_geo_iters : it_begin) && !x_fwd_done) {
+            if (xit && it == (n_geo_l > it_begin ? n_geo_l : it_begin) && !x_fwd_done) {
                 // affines of the window's keyframes for the first 'color' iteration of this call (later ones: the step launch below)
                 rc = lk_launch_exposure_step(*xd, 2, 1, beta1, beta2, eps, st);
                 if (rc != LK_OK) return rc;
             }
             x_fwd_done = x_fwd_done || xit;
             // phase-split caller: the step of 'color' iteration it - 1 (its own call) moved the colour decoder and left the repack to this launch
-            const bool split_repack = pre && (phases & 3) == 1 && it == it_begin && it > d->n_geo_iters && !embed_only && d->n_col_dec > 0 &&
+            const bool split_repack = pre && (phases & 3) == 1 && it == it_begin && it > n_geo_l && !embed_only && d->n_col_dec > 0 &&
                                       d->render.weights == d->weights_rw;
             rc = lk_render_fwd_impl(&rd, st, (xit ? 0 : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0), live,
                                     (repack_pending || stepped_pending || split_repack) ? &rr : nullptr);
@@ -792,7 +796,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             int rc;
             if (xit) {          // exposure MLP backward + its Adam groups + the affines of the next iteration: one more block of the Adam launch
                 ExposureStepArgs xa;
-                rc = lk_exposure_step_args(*xd, 3, it - d->n_geo_iters + 1, beta1, beta2, eps, &xa);
+                rc = lk_exposure_step_args(*xd, 3, it - n_geo_l + 1, beta1, beta2, eps, &xa);
                 if (rc != LK_OK) return rc;
                 rc = lk_adam_step_x(seg, ns, beta1, beta2, eps, &xa, st);
             } else {

@@ -168,6 +168,10 @@ class MapOptimizer:
         self.dist = dist
         self.it = 0
         self.native_loop = True                 # lk_map_frame; False = one launch sequence per statement (iterate)
+        # a call of more iterations than this is issued as consecutive segments (lk_map_desc::it_offset): the work buffer holds one
+        # segment's batches and neighbour lists (26 floats per sample and iteration) instead of the whole call's - 3 GB for the 600
+        # iterations x 10 000 rays of a ScanNet refinement call.  Single-process loop only (a data-parallel caller walks iteration by iteration)
+        self.max_call_iters = 128
         self._work = None
         self._nat, self._nat_dirty = None, False    # Adam state of the native loop: [4][n_rows*32] rows, [2][blob] decoders
         # exposure = (mlp_exposure torch module, [exposure_feat tensor per frame of the window]) for model.encode_exposure
@@ -325,7 +329,9 @@ class MapOptimizer:
             # exposure features only the current frame's (the last) is an Adam parameter
             xd = self.exposure.desc(None if self.fix_color_decoder else self.lrs['color'][0], only_last_feature=True)
             d.exposure = C.pointer(xd)
-        need = int(eng.lib.dll.lk_map_work_floats(self.R, self.cfg.S, n_iters)) if self.R <= 16384 else 0
+        seg_iters = n_iters if (self.dist is not None or n_iters <= self.max_call_iters) else self.max_call_iters
+        d.iters = seg_iters
+        need = int(eng.lib.dll.lk_map_work_floats(self.R, self.cfg.S, seg_iters)) if self.R <= 16384 else 0
         if need and (self._work is None or self._work.numel() < need):
             self._work = eng.empty(need)
         d.work = ptr(self._work) if need else 0
@@ -334,7 +340,11 @@ class MapOptimizer:
         self._keep_native = (depth_stack, color_stack, c2w_stack, r2_stack, frame_id, rnd_all, log)
         dll = eng.lib.dll
         if self.dist is None:
-            eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n_iters, 3, eng.stream), 'lk_map_frame')
+            for s0 in range(0, n_iters, seg_iters):         # (one pass unless the call is longer than max_call_iters)
+                n = min(seg_iters, n_iters - s0)
+                d.it_offset, d.iters = s0, n
+                d.rnd, d.log = ptr(rnd_all[s0:]), ptr(log[s0:])
+                eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n, 3, eng.stream), 'lk_map_frame')
         else:
             self._nat_desc = d
             for it in range(n_iters):

@@ -195,6 +195,51 @@ def test_long_map_call_matches_the_statement_path():
 
 
 @pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('exposure', (False, True))
+def test_segmented_map_call_equals_the_unsegmented_one(backend, exposure):
+    """A call longer than MapOptimizer.max_call_iters is issued as consecutive lk_map_frame segments (lk_map_desc::it_offset: the work buffer
+    holds one segment's batches and lists): seven iterations, the stage change inside the second segment, in segments of three against one
+    call - Adam's step counts and moments carry over, the losses and every parameter agree."""
+    eng = make_engine(backend)
+    c2w, depth_img, color_img, pos, geo, col = mini_scene(4)
+    W = syn.default_weights(seed=5, rel_pos=not exposure, exposure=exposure)
+    R, iters, n_geo = 64, 7, 4
+    g = torch.Generator().manual_seed(33)
+    rnd_all = torch.randint(0, HH * WW, (iters, R), generator=g, dtype=torch.int32).to(eng.device)
+    rows = torch.arange(0, pos.shape[0], 2, dtype=torch.int32).to(eng.device)
+    lrs = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
+    frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
+    fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
+    res = {}
+    for seg in (128, 3):
+        cfg = core.RenderCfg(rel_pos=not exposure, exposure=exposure)
+        dec = core.DecoderBlob(eng).pack(W)
+        pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
+        knn = core.KnnIndex(eng, capacity=pos.shape[0]); knn.build(pos_d)
+        xp = None
+        if exposure:
+            mlp = _exposure_module(W).to(eng.device)
+            feat = (0.2 * torch.ones(8)).to(eng.device).requires_grad_(True)
+            xp = (mlp, [feat])
+        mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, rows, R, lrs, w_color=0.1, exposure=xp)
+        mo.max_call_iters = seg
+        mo.begin_frame()
+        log = eng.zeros(iters, 4)
+        mo.run(iters, n_geo, frames, rnd_all, fid, (0, HH, 0, WW), INTR, HH, WW, log)
+        mo.finish()
+        res[seg] = (log.cpu().clone(), geo_d.cpu().clone(), col_d.cpu().clone(), dec.blob.cpu().clone(),
+                    feat.detach().cpu().clone() if exposure else None)
+    a, b = res[128], res[3]
+    np.testing.assert_allclose(b[0].numpy(), a[0].numpy(), rtol=1e-6, atol=1e-7)
+    assert float((a[1] - geo).abs().max()) > 1e-3                                     # the rows did move
+    for k in (1, 2, 3):
+        np.testing.assert_allclose(b[k].numpy(), a[k].numpy(), rtol=0, atol=2e-6)
+    if exposure:
+        np.testing.assert_allclose(b[4].numpy(), a[4].numpy(), rtol=0, atol=2e-6)
+        assert float((a[4] - 0.2).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize('backend', backends())
 @pytest.mark.parametrize('rel_pos', (True, False))
 def test_map_iterations_with_ba_match_oracle(backend, rel_pos):
     """mapping.BA (Mapper.py:541-566, 602-607, 629-643, 685, 782-797): three frames in the window, the oldest fixed, the other two
