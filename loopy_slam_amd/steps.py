@@ -12,6 +12,8 @@ synchronisation in the loop:
     (Mapper.py:578-586,727-735), with torch.optim.Adam's dense semantics on exactly those rows;
   * the tracker's best-loss candidate (Tracker.py:375-377) is chosen at the end from a device-side log.
 """
+import os
+
 import torch
 
 from . import _ffi, core, optim
@@ -170,8 +172,10 @@ class MapOptimizer:
         self.native_loop = True                 # lk_map_frame; False = one launch sequence per statement (iterate)
         # a call of more iterations than this is issued as consecutive segments (lk_map_desc::it_offset): the work buffer holds one
         # segment's batches and neighbour lists (26 floats per sample and iteration) instead of the whole call's - 3 GB for the 600
-        # iterations x 10 000 rays of a ScanNet refinement call.  Single-process loop only (a data-parallel caller walks iteration by iteration)
-        self.max_call_iters = 128
+        # iterations x 10 000 rays of a ScanNet refinement call.  Single-process loop only (a data-parallel caller walks iteration by iteration).
+        # 384: the 300-iteration calls of a mapped frame stay in one piece - every further segment pays one fill of the look-ahead pipeline
+        # (measured at 128: 75.7 instead of 74.65 ms per mapped Replica frame, three alternating pairs)
+        self.max_call_iters = int(os.environ.get('LOOPY_MAX_CALL_ITERS', '384'))
         self._work = None
         self._nat, self._nat_dirty = None, False    # Adam state of the native loop: [4][n_rows*32] rows, [2][blob] decoders
         # exposure = (mlp_exposure torch module, [exposure_feat tensor per frame of the window]) for model.encode_exposure
