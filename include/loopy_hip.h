@@ -453,8 +453,15 @@ typedef struct {
                                    sizes them), n_geo_iters stays the call's GLOBAL count, the optimiser state (adam_rows, adam_dec) carries
                                    over and the step counts continue.  The work buffer then holds one segment's batches and neighbour
                                    lists instead of the whole call's (26 floats per sample and iteration).  0 for an unsegmented call */
+    int32_t batches_ready;      /* non-zero: lk_map_prepare has already assembled this descriptor's batches (see there) */
 } lk_map_desc;
 int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters);
+/* The batch assembly of lk_map_frame's first call (pixels, rays, colours, radii, inside masks of all `iters` iterations: one launch) AHEAD of
+ * that call: it reads the batch inputs of the descriptor only (stacks, frame_id, rnd, window, intrinsics, render.R / S / r2_ray, work, iters,
+ * log, exposure) - not the row list, not the map.  A caller whose row list comes out of a device-side selection with a count read-back
+ * (Mapper.get_mask_from_c2w -> lk_frustum_rows) enqueues this BEFORE the read-back, so that the device assembles batches while the host
+ * waits and fills in the rest of the descriptor; the lk_map_frame call then carries batches_ready = 1. */
+int lk_map_prepare(const lk_map_desc* d, void* stream);
 /* float offset inside `work` of the neighbour lists lk_map_frame keeps per iteration: int32 [iters][R*S][8] (what a data-parallel
  * caller needs to agree on the touched rows of an iteration, loopy_slam_amd/parallel.py) */
 int64_t lk_map_work_nbr_idx(int32_t R, int32_t S, int32_t iters);

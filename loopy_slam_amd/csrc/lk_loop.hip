@@ -500,6 +500,50 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
 }
 
 // ------------------------------------------------------------------ lk_map_frame
+// Start of an optimize_map call (or of a segment of one): join the look-ahead stream, then assemble the batches of every iteration.
+// Neither step reads the optimised rows, the map or the decoders - lk_map_prepare can run it before the caller knows its row list.
+static void map_join_and_pregather(const lk_map_desc* d, const MapWork& wk, int R, const lk_exposure_desc* xd, hipStream_t st) {
+    float* W0 = d->work;
+    {
+        // A call that starts an optimize_map call joins the look-ahead stream first: an earlier call that stopped before its last enqueued
+        // chunk was consumed (an error between the phases of a data-parallel caller, a range that ends early) may still be searching and
+        // sorting there - reading the `work` buffer this call's k_pregather overwrites and holding the index's row counters mid-sort.
+        // With an idle look-ahead stream the wait is satisfied at once.
+        PreStream& pj = pre_stream();
+        if (pj.ok) { (void)hipEventRecord(pj.e1, pj.st); (void)hipStreamWaitEvent(st, pj.e1, 0); }
+    }
+    {
+        // pixels, rays, colours, radii and the inside mask of EVERY iteration of this optimize_map call in one launch; it also
+        // clears the loss rows the composite kernels accumulate into
+        LkPregatherArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.depth = d->depth_stack; pa.color = d->color_stack; pa.c2w = d->c2w_stack; pa.c2w_stride = d->c2w_stride; pa.r2_map = d->r2_map_stack;
+        pa.frame_id = d->frame_id; pa.rnd = d->rnd;
+        pa.R = R; pa.H = d->H; pa.W = d->W; pa.H0 = d->H0; pa.W0 = d->W0; pa.w = d->w;
+        pa.fx = d->fx; pa.fy = d->fy; pa.cx = d->cx; pa.cy = d->cy;
+        pa.rays_o = W0 + wk.rays_o; pa.rays_d = W0 + wk.rays_d; pa.gt_depth = W0 + wk.gt_depth; pa.gt_color = W0 + wk.gt_color;
+        pa.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray : nullptr; pa.thr = W0 + wk.thr; pa.zero4 = d->log;
+        pa.n_live = reinterpret_cast<int32_t*>(W0 + wk.n_live);
+        if (xd) pa.frame_out = reinterpret_cast<int32_t*>(W0 + wk.frame_id);
+        if (R <= LK_MASK_REG_MAX) hipLaunchKernelGGL(k_pregather<LK_MASK_VPT>, dim3(d->iters), dim3(1024), 0, st, pa);
+        else hipLaunchKernelGGL(k_pregather<LK_LOOP_MAX_R / 1024>, dim3(d->iters), dim3(1024), 0, st, pa);
+    }
+}
+// The batch assembly of an optimize_map call (or of its first segment) ahead of the call itself: d needs the batch inputs (stacks, frame_id,
+// rnd, window, intrinsics), render.R / S / r2_ray, work, iters, log and exposure - NOT rows, the optimiser buffers or the gradient buffers.
+// The lk_map_frame call that follows (same descriptor values, batches_ready = 1, it_begin = 0) skips its own assembly.
+extern "C" int lk_map_prepare(const lk_map_desc* d, void* stream_) {
+    LK_REQUIRE(d != nullptr && d->iters >= 0 && d->render.R >= 0, "lk_map_prepare: bad descriptor");
+    if (d->iters == 0 || d->render.R == 0) return LK_OK;
+    LK_REQUIRE(d->work != nullptr && d->render.R <= LK_LOOP_MAX_R, "lk_map_prepare: needs `work` and at most 16384 rays");
+    LK_REQUIRE(d->depth_stack && d->color_stack && d->c2w_stack && d->rnd && d->log, "lk_map_prepare: NULL batch buffer");
+    LK_REQUIRE(!d->exposure || d->frame_id, "lk_map_prepare: exposure encoding needs frame_id");
+    const MapWork wk = map_work(d->render.R, d->render.S, d->iters);
+    map_join_and_pregather(d, wk, d->render.R, d->exposure, (hipStream_t)stream_);
+    LK_LAUNCH_CHECK();
+    return LK_OK;
+}
+
 extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t phases, void* stream_) {
     LK_REQUIRE(d != nullptr, "lk_map_frame: NULL descriptor");
     LK_REQUIRE(it_begin >= 0 && it_end <= d->iters && it_begin <= it_end && (phases & 3), "lk_map_frame: bad iteration range / phases");
@@ -540,30 +584,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     auto chunk_start = [&](int c) { return c == 0 ? 0 : 1 + (c - 1) * pre_chunk; };
     auto chunk_of = [&](int it) { return it == 0 ? 0 : 1 + (it - 1) / pre_chunk; };
     float* W0 = d->work;
-    if (pre && it_begin == 0 && (phases & 1)) {
-        // A call that starts an optimize_map call joins the look-ahead stream first: an earlier call that stopped before its last enqueued
-        // chunk was consumed (an error between the phases of a data-parallel caller, a range that ends early) may still be searching and
-        // sorting there - reading the `work` buffer this call's k_pregather overwrites and holding the index's row counters mid-sort.
-        // With an idle look-ahead stream the wait is satisfied at once.
-        PreStream& pj = pre_stream();
-        if (pj.ok) { (void)hipEventRecord(pj.e1, pj.st); (void)hipStreamWaitEvent(st, pj.e1, 0); }
-    }
-    if (pre && it_begin == 0 && (phases & 1)) {
-        // pixels, rays, colours, radii and the inside mask of EVERY iteration of this optimize_map call in one launch; it also
-        // clears the loss rows the composite kernels accumulate into
-        LkPregatherArgs pa;
-        memset(&pa, 0, sizeof(pa));
-        pa.depth = d->depth_stack; pa.color = d->color_stack; pa.c2w = d->c2w_stack; pa.c2w_stride = d->c2w_stride; pa.r2_map = d->r2_map_stack;
-        pa.frame_id = d->frame_id; pa.rnd = d->rnd;
-        pa.R = R; pa.H = d->H; pa.W = d->W; pa.H0 = d->H0; pa.W0 = d->W0; pa.w = d->w;
-        pa.fx = d->fx; pa.fy = d->fy; pa.cx = d->cx; pa.cy = d->cy;
-        pa.rays_o = W0 + wk.rays_o; pa.rays_d = W0 + wk.rays_d; pa.gt_depth = W0 + wk.gt_depth; pa.gt_color = W0 + wk.gt_color;
-        pa.r2_ray = d->render.r2_ray ? W0 + wk.r2_ray : nullptr; pa.thr = W0 + wk.thr; pa.zero4 = d->log;
-        pa.n_live = reinterpret_cast<int32_t*>(W0 + wk.n_live);
-        if (xd) pa.frame_out = reinterpret_cast<int32_t*>(W0 + wk.frame_id);
-        if (R <= LK_MASK_REG_MAX) hipLaunchKernelGGL(k_pregather<LK_MASK_VPT>, dim3(d->iters), dim3(1024), 0, st, pa);
-        else hipLaunchKernelGGL(k_pregather<LK_LOOP_MAX_R / 1024>, dim3(d->iters), dim3(1024), 0, st, pa);
-    }
+    if (pre && it_begin == 0 && (phases & 1) && !d->batches_ready) map_join_and_pregather(d, wk, R, xd, st);
     // Ahead of the loop, on the third stream, a few iterations per chunk: the neighbour search (one launch per chunk) and,
     // per iteration, the counting sort of its rows by point for the feature-gradient gather (count, scan, place: lk_bwd2.hip) - both read
     // the rays, the positions and the row mask only.  Chunk c + 1 is enqueued when the loop reaches chunk c.

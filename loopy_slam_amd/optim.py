@@ -106,7 +106,7 @@ def gather_rays(eng, depth_stack, color_stack, c2w_stack, frame_id, rnd, H, W, w
                   'lk_gather_rays')
 
 
-def frustum_rows(eng, pos, c2w, depth, intr, H, W, edge, return_mask=False):
+def frustum_rows(eng, pos, c2w, depth, intr, H, W, edge, return_mask=False, pending=False):
     """Mapper.get_mask_from_c2w on the device (lk_frustum_rows): int32 tensor of the selected row indices, ascending
     (and, with return_mask, the uint8 [N] membership flags).  One host sync (the count) - once per mapped frame; a second one if
     c2w lives on the device (the inverse is taken on the host, as the reference does: pass the host copy of the pose when there is one)."""
@@ -124,8 +124,32 @@ def frustum_rows(eng, pos, c2w, depth, intr, H, W, edge, return_mask=False):
     eng.lib.check(eng.lib.dll.lk_frustum_rows(ptr(pos), N, w12, ptr(depth), H, W, C.c_float(fx), C.c_float(fy), C.c_float(cx),
                                               C.c_float(cy), int(edge), ptr(sd), ptr(sm), ptr(smax), ptr(out), ptr(cnt),
                                               eng.stream), 'lk_frustum_rows')
+    if pending:
+        return _PendingRows(eng, out, cnt, sm[:N], return_mask)
     rows = out[:int(cnt.item())]
     return (rows, sm[:N]) if return_mask else rows
+
+
+class _PendingRows:
+    """frustum_rows(..., pending=True): the selection is enqueued and its count is on its way to pinned host memory; finish() waits for
+    THAT copy only - whatever the caller enqueues in between (MapOptimizer.prepare: table fills, the call's batch assembly) runs on the
+    device while the host waits for the count and builds its descriptors."""
+
+    def __init__(self, eng, out, cnt, mask, return_mask):
+        self.out, self.mask, self.return_mask = out, mask, return_mask
+        if cnt.is_cuda:
+            self.host = torch.empty(1, dtype=torch.int32).pin_memory()
+            self.host.copy_(cnt, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(eng.device))
+        else:
+            self.host, self.event = cnt, None
+
+    def finish(self):
+        if self.event is not None:
+            self.event.synchronize()
+        rows = self.out[:int(self.host[0])]
+        return (rows, self.mask) if self.return_mask else rows
 
 
 def add_points(eng, knn, rays_o, rays_d, gt_depth, r2, near_surface, far_surface, n_add=3):

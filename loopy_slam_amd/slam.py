@@ -451,10 +451,11 @@ class Mapper:
         self.pipe = pipe
 
     # -- frustum feature selection (Mapper.py:165-217): project every point, bilinear depth lookup, z test
-    def get_mask_from_c2w(self, c2w, depth, return_mask=False):
-        """Frustum feature selection (Mapper.py:165-217) on the device: lk_frustum_rows."""
+    def get_mask_from_c2w(self, c2w, depth, return_mask=False, pending=False):
+        """Frustum feature selection (Mapper.py:165-217) on the device: lk_frustum_rows.  pending: the selection is enqueued and the result
+        object's finish() waits for its count (optim._PendingRows)."""
         return optim.frustum_rows(self.eng, self.npc.cloud_pos(), c2w, depth.float().contiguous(), (self.fx, self.fy, self.cx, self.cy),
-                                  self.H, self.W, self.frustum_edge, return_mask=return_mask)
+                                  self.H, self.W, self.frustum_edge, return_mask=return_mask, pending=pending)
 
     def filter_point_before_add(self, rays_o, rays_d, gt_depth, prev_c2w):
         pts = rays_o + rays_d * gt_depth[:, None]
@@ -590,10 +591,8 @@ class Mapper:
         if not color_refine:
             frame_pts_add, self.last_add_counts = self.add_points_for_frame(idx, cur_gt_color, cur_gt_depth, cur_c2w, r2_add_map,
                                                                            grad_mag=grad_mag)
-        # 3. rows to optimise (Mapper.py:498-520)
-        rows = row_mask = None
-        if self.frustum_feature_selection:
-            rows, row_mask = self.get_mask_from_c2w(cur_c2w, cur_gt_depth, return_mask=True)
+        # 3. rows to optimise (Mapper.py:498-520): selected further down, AFTER the call's batch assembly has been enqueued - the selection
+        # ends in a count read-back, and neither the gradient-table fills nor the assembly depend on it (MapOptimizer.prepare)
         # 4. iteration count (Mapper.py:572-574)
         if idx > 0 and not color_refine:
             num_joint_iters = int(np.clip(int(num_joint_iters * frame_pts_add / 300), int(self.min_iter_ratio * num_joint_iters),
@@ -609,11 +608,9 @@ class Mapper:
         R = pix * F
         rcfg = render_cfg_from(cfg, cfg['rendering']['sigmoid_coef_mapper'])
         mo = steps.MapOptimizer(eng, rcfg, self.decoders.dec, npc.knn, npc.cloud_pos(), npc.get_geo_feats(), npc.get_col_feats(),
-                                rows, R, lrs, w_color=self.w_color_loss, dynamic_radius=self.use_dynamic_radius,
+                                None, R, lrs, w_color=self.w_color_loss, dynamic_radius=self.use_dynamic_radius,
                                 fix_color_decoder=self.fix_color_decoder, dist=getattr(self.slam, 'dist', None), exposure=exposure,
-                                fix_geo_decoder=self.fix_geo_decoder)
-        mo.begin_frame()
-        mo.gs.row_mask = row_mask               # the backward only scatters into the rows being optimised
+                                fix_geo_decoder=self.fix_geo_decoder)          # (its gradient tables are allocated zeroed)
         geo_iters = self.geo_iter_first if init else int(num_joint_iters * self.geo_iter_ratio)
         ba_cams = ba_train = None
         if self.BA:
@@ -632,7 +629,15 @@ class Mapper:
         rnd = torch.randint(0, H * W, (num_joint_iters, R), generator=self.gen_rays, dtype=torch.int32, device=eng.device)
         log = eng.zeros(num_joint_iters, 4)
         # stage 'geometry' while joint_iter <= geo_iters (Mapper.py:594-597)
-        mo.run(num_joint_iters, min(num_joint_iters, geo_iters + 1), stack, rnd, fid, (0, H, 0, W), intr, H, W, log)
+        n_geo = min(num_joint_iters, geo_iters + 1)
+        # order on the stream: the selection, its count on the way to the host, THEN the fills and the batch assembly of the call
+        sel_rows = self.get_mask_from_c2w(cur_c2w, cur_gt_depth, return_mask=True, pending=True) if self.frustum_feature_selection else None
+        mo.prepare(num_joint_iters, n_geo, stack, rnd, fid, (0, H, 0, W), intr, H, W, log)
+        rows = row_mask = None
+        if sel_rows is not None:
+            rows, row_mask = sel_rows.finish()
+        mo.new_frame(rows, row_mask, zero=False)            # the backward only scatters into the rows being optimised
+        mo.run(num_joint_iters, n_geo, stack, rnd, fid, (0, H, 0, W), intr, H, W, log)
         mo.finish()
         if self.slam.encode_exposure:           # the optimised feature of this frame is what the tracker starts from (Mapper.py:799)
             self.slam.exposure_feat = self.cur_exposure_feat.detach().clone()

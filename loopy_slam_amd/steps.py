@@ -178,6 +178,7 @@ class MapOptimizer:
         self.max_call_iters = int(os.environ.get('LOOPY_MAX_CALL_ITERS', '384'))
         self._work = None
         self._nat, self._nat_dirty = None, False    # Adam state of the native loop: [4][n_rows*32] rows, [2][blob] decoders
+        self._prepared = None                       # (n_iters, draws, log, work) of a prepare() that run() may build on
         # exposure = (mlp_exposure torch module, [exposure_feat tensor per frame of the window]) for model.encode_exposure
         # (ScanNet): per-keyframe colour affine applied to the RENDERED colour logits (Mapper.py:697-715)
         self.exposure = ExposureState(eng, exposure[0], exposure[1]) if exposure is not None else None
@@ -273,10 +274,56 @@ class MapOptimizer:
         it < n_geo_iters.  rnd_all int32 [n_iters, R]; log [n_iters, 4].  Without exposure encoding this is lk_map_frame - one
         C-ABI call for the whole loop single-GPU, two calls per iteration around the gradient all-reduce multi-GPU; with
         exposure encoding the per-statement path (iterate)."""
-        if not self.native_loop or self.ba is not None or not self.fix_geo_decoder or (self.exposure is not None and self.R > 16384):
+        if not self._takes_native_loop():
             for it in range(n_iters):
                 self.iterate('geometry' if it < n_geo_iters else 'color', frames, rnd_all[it], frame_id, window, intr, H, W, log_row=log[it])
             return log
+        eng = self.eng
+        d, seg_iters = self._native_desc(n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log)
+        C = _ffi.C
+        dll = eng.lib.dll
+        prepared, self._prepared = self._prepared, None
+        if self.dist is None:
+            for s0 in range(0, n_iters, seg_iters):         # (one pass unless the call is longer than max_call_iters)
+                n = min(seg_iters, n_iters - s0)
+                d.it_offset, d.iters = s0, n
+                d.rnd, d.log = ptr(rnd_all[s0:]), ptr(log[s0:])
+                # the first segment's batches may have been assembled ahead of the row selection (prepare)
+                d.batches_ready = 1 if (s0 == 0 and prepared == (n_iters, rnd_all.data_ptr(), log.data_ptr(), (self._work.data_ptr() if self._work is not None else 0))) else 0
+                eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n, 3, eng.stream), 'lk_map_frame')
+        else:
+            self._nat_desc = d
+            for it in range(n_iters):
+                eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 1, eng.stream), 'lk_map_frame')
+                if self.rows is None and it + 1 < n_iters and self._nat_lists is not None:
+                    self.dist.prefetch_touched(self, it + 1)        # next iteration's row list, agreed beside this iteration's render
+                self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color', it=it, desc=d)
+                if self.rows is None:
+                    self.dist.flag_union(self)      # rows touched by any rank: what the step of a whole-map iteration visits
+                eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 2, eng.stream), 'lk_map_frame')
+        self.it += n_iters
+        return log
+
+    def _takes_native_loop(self):
+        return self.native_loop and self.ba is None and self.fix_geo_decoder and not (self.exposure is not None and self.R > 16384)
+
+    def prepare(self, n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log):
+        """The row-independent head of run(): clears the gradient tables and assembles the batches of the call (lk_map_prepare) - for a
+        caller whose row list comes out of a device-side selection with a count read-back (Mapper.get_mask_from_c2w): issued BEFORE the
+        read-back, the device works through the fills and the assembly while the host waits and builds the descriptor.  run() with the
+        same arguments follows (new_frame(..., zero=False) in between).  No-op on the paths that have no batch assembly."""
+        self._prepared = None
+        if not self._takes_native_loop() or self.dist is not None or self.R > 16384 or os.environ.get('LOOPY_NO_PREPARE') == '1':
+            return False
+        self.gs.zero_()
+        d, seg_iters = self._native_desc(n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log, rows_known=False)
+        d.iters, d.it_offset = min(seg_iters, n_iters), 0
+        self.eng.lib.check(self.eng.lib.dll.lk_map_prepare(_ffi.C.byref(d), self.eng.stream), 'lk_map_prepare')
+        self._prepared = (n_iters, rnd_all.data_ptr(), log.data_ptr(), (self._work.data_ptr() if self._work is not None else 0))
+        return True
+
+    def _native_desc(self, n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log, rows_known=True):
+        """lk_map_desc of an optimize_map call + the segment length.  rows_known False (prepare): the optimiser-state part is left out."""
         eng, b, st, gs = self.eng, self.batch, self.st, self.gs
         depth_stack, color_stack, c2w_stack, r2_stack = frames
         core.fill_desc(eng, self.cfg, st, b.rays_o, b.rays_d, b.gt_depth, self.knn, self.pos, self.geo, self.col, self.dec, 'color',
@@ -312,12 +359,13 @@ class MapOptimizer:
         d.geo_feats_rw, d.col_feats_rw = ptr(self.geo), ptr(self.col)
         n_rows = self.rows.numel() if self.rows is not None else self.geo.shape[0]
         d.rows, d.n_rows = ptr(self.rows), n_rows
-        if self._nat is None or self._nat[0].numel() != 4 * n_rows * 32:
-            self._nat = (eng.zeros(4 * n_rows * 32), eng.zeros(2 * self.dec.n))
-        elif self._nat_dirty:
-            self._nat[0].zero_(); self._nat[1].zero_()
-        self._nat_dirty = True
-        d.adam_rows, d.adam_dec = ptr(self._nat[0]), ptr(self._nat[1])
+        if rows_known:
+            if self._nat is None or self._nat[0].numel() != 4 * n_rows * 32:
+                self._nat = (eng.zeros(4 * n_rows * 32), eng.zeros(2 * self.dec.n))
+            elif self._nat_dirty:
+                self._nat[0].zero_(); self._nat[1].zero_()
+            self._nat_dirty = True
+            d.adam_rows, d.adam_dec = ptr(self._nat[0]), ptr(self._nat[1])
         assert len(self.geo_dec_ranges) <= _ffi.MAX_SPANS and len(self.col_dec_ranges) <= _ffi.MAX_SPANS
         for k, (o, n) in enumerate(self.geo_dec_ranges):
             d.geo_dec[k].offset, d.geo_dec[k].n = o, n
@@ -342,25 +390,7 @@ class MapOptimizer:
         d.union_rows_flagged = 1 if (self.dist is not None and self.rows is None and self.geo.shape[0] <= self.knn.capacity) else 0
         self._nat_lists = (int(eng.lib.dll.lk_map_work_nbr_idx(self.R, self.cfg.S, n_iters)), n_iters) if need else None
         self._keep_native = (depth_stack, color_stack, c2w_stack, r2_stack, frame_id, rnd_all, log)
-        dll = eng.lib.dll
-        if self.dist is None:
-            for s0 in range(0, n_iters, seg_iters):         # (one pass unless the call is longer than max_call_iters)
-                n = min(seg_iters, n_iters - s0)
-                d.it_offset, d.iters = s0, n
-                d.rnd, d.log = ptr(rnd_all[s0:]), ptr(log[s0:])
-                eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n, 3, eng.stream), 'lk_map_frame')
-        else:
-            self._nat_desc = d
-            for it in range(n_iters):
-                eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 1, eng.stream), 'lk_map_frame')
-                if self.rows is None and it + 1 < n_iters and self._nat_lists is not None:
-                    self.dist.prefetch_touched(self, it + 1)        # next iteration's row list, agreed beside this iteration's render
-                self.dist.all_reduce_grads(self, 'geometry' if it < n_geo_iters else 'color', it=it, desc=d)
-                if self.rows is None:
-                    self.dist.flag_union(self)      # rows touched by any rank: what the step of a whole-map iteration visits
-                eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 2, eng.stream), 'lk_map_frame')
-        self.it += n_iters
-        return log
+        return d, seg_iters
 
     def nbr_idx_of(self, it=None):
         """Neighbour lists [R*S, 8] (int32) of iteration `it` of the running lk_map_frame call (it keeps the lists of every iteration
@@ -386,14 +416,15 @@ class MapOptimizer:
             self.loss_log = self.eng.zeros(4)
         return self.loss_log
 
-    def new_frame(self, row_index, row_mask=None):
+    def new_frame(self, row_index, row_mask=None, zero=True):
         """Start of an optimize_map call: the frustum rows of the new frame (Mapper.py:498-512), a fresh Adam
-        (Mapper.py:570) and clean gradient tables.  row_mask (uint8 [N], 1 on the rows of row_index) lets the backward
-        skip the scatter into rows nobody optimises."""
+        (Mapper.py:570) and clean gradient tables (zero=False: prepare() has cleared them already).  row_mask (uint8 [N], 1 on the
+        rows of row_index) lets the backward skip the scatter into rows nobody optimises."""
         self.rows = row_index
         self.gs.row_mask = row_mask
         self.adam = optim.Adam(self.eng)
-        self.gs.zero_()
+        if zero:
+            self.gs.zero_()
         self._nat_dirty = True                  # fresh optimiser: the native loop's state is re-zeroed (or re-sized) on its next run
 
     def begin_frame(self):

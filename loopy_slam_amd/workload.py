@@ -152,9 +152,14 @@ class FrameWorkload:
             self.mapped_frame_extras(k)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
         fid = self._fid
-        self.rows, row_mask = optim.frustum_rows(eng, self.pos[:self.n], self.c2w_host[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
-                                                 return_mask=True)
-        self.mapper.new_frame(self.rows, row_mask)
+        # the gradient-table fills and the batch assembly of the mapping call do not depend on the selected rows: enqueued before the
+        # selection's count read-back, the device works through them while the host waits and builds the call (MapOptimizer.prepare)
+        # (order on the stream: selection, count on its way to the host, THEN fills + assembly - the host waits for the count alone)
+        sel = optim.frustum_rows(eng, self.pos[:self.n], self.c2w_host[k], self.depth_stack[k], self.intr, H, W, b.frustum_edge,
+                                 return_mask=True, pending=True)
+        prepared = self.mapper.prepare(b.map_iters, b.map_geo_iters, self.frames, rnd_m, fid, (0, H, 0, W), self.intr, H, W, self.map_log)
+        self.rows, row_mask = sel.finish()
+        self.mapper.new_frame(self.rows, row_mask, zero=not prepared)
         self.mapper.run(b.map_iters, b.map_geo_iters, self.frames, rnd_m, fid, (0, H, 0, W), self.intr, H, W, self.map_log)
         if mapped:
             self.render_frame(k)

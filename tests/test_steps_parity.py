@@ -196,6 +196,54 @@ def test_long_map_call_matches_the_statement_path():
 
 @pytest.mark.parametrize('backend', backends())
 @pytest.mark.parametrize('exposure', (False, True))
+def test_prepared_map_call_equals_the_plain_one(backend, exposure):
+    """MapOptimizer.prepare (lk_map_prepare: gradient-table fills + the batch assembly of the call enqueued BEFORE the row selection's count
+    read-back) followed by new_frame(zero=False) + run gives what new_frame + run gives; a prepare whose arguments do not match the run
+    (other draws) is ignored."""
+    eng = make_engine(backend)
+    c2w, depth_img, color_img, pos, geo, col = mini_scene(6)
+    W = syn.default_weights(seed=3, rel_pos=not exposure, exposure=exposure)
+    R, iters, n_geo = 64, 4, 2
+    g = torch.Generator().manual_seed(44)
+    rnd_all = torch.randint(0, HH * WW, (iters, R), generator=g, dtype=torch.int32).to(eng.device)
+    rnd_other = torch.randint(0, HH * WW, (iters, R), generator=g, dtype=torch.int32).to(eng.device)
+    rows = torch.arange(0, pos.shape[0], 2, dtype=torch.int32).to(eng.device)
+    mask = torch.zeros(pos.shape[0], dtype=torch.uint8); mask[::2] = 1
+    mask = mask.to(eng.device)
+    lrs = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
+    frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
+    fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
+    res = {}
+    for mode in ('plain', 'prepared', 'stale'):
+        cfg = core.RenderCfg(rel_pos=not exposure, exposure=exposure)
+        dec = core.DecoderBlob(eng).pack(W)
+        pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
+        knn = core.KnnIndex(eng, capacity=pos.shape[0]); knn.build(pos_d)
+        xp = None
+        if exposure:
+            xp = (_exposure_module(W).to(eng.device), [(0.2 * torch.ones(8)).to(eng.device).requires_grad_(True)])
+        mo = steps.MapOptimizer(eng, cfg, dec, knn, pos_d, geo_d, col_d, None, R, lrs, w_color=0.1, exposure=xp)
+        log = eng.zeros(iters, 4)
+        args = (iters, n_geo, frames, rnd_all, fid, (0, HH, 0, WW), INTR, HH, WW, log)
+        if mode == 'plain':
+            mo.new_frame(rows, mask)
+        else:
+            ok = mo.prepare(*(args if mode == 'prepared' else (iters, n_geo, frames, rnd_other, fid, (0, HH, 0, WW), INTR, HH, WW, log)))
+            assert ok
+            mo.new_frame(rows, mask, zero=False)
+        mo.run(*args)
+        mo.finish()
+        res[mode] = (log.cpu().clone(), geo_d.cpu().clone(), col_d.cpu().clone(), dec.blob.cpu().clone())
+    for mode in ('prepared', 'stale'):
+        np.testing.assert_allclose(res[mode][0].numpy(), res['plain'][0].numpy(), rtol=1e-6, atol=1e-7)
+        for k in (1, 2, 3):
+            err = (res[mode][k] - res['plain'][k]).abs().reshape(-1)
+            assert float(torch.quantile(err, 0.999)) < 2e-6 and float(err.max()) < 0.02 * 0.03, (mode, k, float(err.max()))
+    assert float((res['plain'][1] - geo).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('exposure', (False, True))
 def test_segmented_map_call_equals_the_unsegmented_one(backend, exposure):
     """A call longer than MapOptimizer.max_call_iters is issued as consecutive lk_map_frame segments (lk_map_desc::it_offset: the work buffer
     holds one segment's batches and lists): seven iterations, the stage change inside the second segment, in segments of three against one
