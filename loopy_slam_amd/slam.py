@@ -110,6 +110,12 @@ class NICER:
         if strict and (unexpected or missing):
             raise RuntimeError(f'load_state_dict: missing {missing}, unexpected {unexpected}')
         for k, v in sd.items():
+            if (k in cur and tuple(torch.as_tensor(v).shape) != tuple(cur[k].shape)) or \
+                    (k in self.extra and tuple(torch.as_tensor(v).shape) != tuple(self.extra[k].shape)):
+                # torch raises on a size mismatch with or without `strict` (torch.nn.Module.load_state_dict)
+                raise RuntimeError(f'load_state_dict: size mismatch for {k}: {tuple(torch.as_tensor(v).shape)} in the checkpoint, '
+                                   f'{tuple((cur[k] if k in cur else self.extra[k]).shape)} in the model')
+        for k, v in sd.items():
             if k in cur:
                 cur[k] = torch.as_tensor(v).float()
             elif k in self.extra:
@@ -486,7 +492,7 @@ class Mapper:
         """Keyframes that see the current frame's points, random k of them (Mapper.py:219-282)."""
         dev = self.eng.device
         ro, rd, gd, _ = get_samples(0, self.H, 0, self.W, pixels, self.H, self.W, self.fx, self.fy, self.cx, self.cy, c2w,
-                                    gt_depth, gt_color, dev, depth_filter=True)
+                                    gt_depth, gt_color, dev, depth_filter=True, generator=self.gen)     # (the replicas of a multi-GPU run draw alike)
         t = torch.linspace(0., 1., N_samples, device=dev)
         z = gd[:, None] * 0.8 * (1 - t) + (gd[:, None] + 0.5) * t
         pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(-1, 3)
@@ -711,6 +717,9 @@ class Mapper:
                                     exposure_feat=self.exposure_feat_all, last_log=(idx == n - 1))
             if callback:
                 callback(idx, est, c2w)
+            if self.cfg.get('stop') and idx != 0 and idx % self.cfg['stop'] == 0:       # Tracker.py:423, Mapper.py:1048 (run.py --stop)
+                n = idx + 1
+                break
         return slam.estimate_c2w_list[:n], slam.gt_c2w_list[:n]
 
 
@@ -779,7 +788,7 @@ class Tracker:
     def track_frame(self, idx, gt_color, gt_depth, gt_c2w):
         """Pose of frame idx (Tracker.py:281-409)."""
         slam, eng = self.slam, self.eng
-        if idx == 0 or self.gt_camera:
+        if idx <= 1 or self.gt_camera:       # the first TWO frames keep the given pose (Tracker.py:297: `if idx <= 1 or self.gt_camera`)
             c2w = gt_c2w.clone()
         else:
             pre = slam.estimate_c2w_list[idx - 1].float()           # pose bookkeeping lives on the host (4x4 algebra)
@@ -858,12 +867,15 @@ class SyntheticRoomDataset:
         c = cfg['cam']
         self.intr = dict(H=c['H'], W=c['W'], fx=c['fx'], fy=c['fy'], cx=c['cx'], cy=c['cy'])
         self.crop_edge = c.get('crop_edge', 0) or 0
+        # data.motion: 'loop' = the slow closed loop (3 mm, 0.2 degrees per frame: throughput runs), 'handheld' = 1-2 cm and 0.5-1.2 degrees
+        # per frame with a changing velocity (synthetic.handheld_pose: the accuracy runs, where the tracker has to do something)
+        self.motion = cfg['data'].get('motion', 'loop')
 
     def __len__(self):
         return self.n_img
 
     def __getitem__(self, idx):
-        d, c, p = synthetic.render_frame(idx, intr=self.intr, device=self.device, holes=0.01, n_poses=2000)   # ~3 mm, 0.2 deg per frame
+        d, c, p = synthetic.render_frame(idx, intr=self.intr, device=self.device, holes=0.01, n_poses=2000, motion=self.motion)
         e = self.crop_edge
         if e > 0:       # the reference's readers crop the frames (src/utils/datasets.py), Point_SLAM.update_cam the intrinsics
             d, c = d[e:-e, e:-e].contiguous(), c[e:-e, e:-e].contiguous()
@@ -878,7 +890,10 @@ class Point_SLAM:
         c = cfg['cam']
         self.H, self.W, self.fx, self.fy, self.cx, self.cy = c['H'], c['W'], c['fx'], c['fy'], c['cx'], c['cy']
         self.update_cam()
+        if 'stop' not in cfg:                   # run.py --stop n (Point_SLAM.py:70-73): both loops return after frame n
+            cfg['stop'] = getattr(args, 'stop', None)
         self.shared_decoders = NICER(cfg, eng=self.eng)
+        self.load_pretrain(cfg)                 # Point_SLAM.py:94
         self.frame_reader = dataset if dataset is not None else SyntheticRoomDataset(cfg, self.eng.device)
         self.n_img = len(self.frame_reader)
         self.estimate_c2w_list = torch.zeros((self.n_img, 4, 4))
@@ -894,6 +909,38 @@ class Point_SLAM:
         self.renderer_map = Renderer(cfg, args, self)
         self.mapper = Mapper(cfg, args, self)
         self.tracker = Tracker(cfg, args, self)
+
+    def load_pretrain(self, cfg, color=None):
+        """The pretrained ConvONet checkpoint's middle-level decoder becomes the geometry decoder (Point_SLAM.py:177-209): of
+        ckpt['model'] the keys that contain 'decoder' and not 'encoder'; 'decoder.coarse.<name>' -> geo_decoder.<name>
+        (load_state_dict(strict=False): names the decoder does not have are ignored, a size mismatch raises), 'decoder.fine.*' is
+        collected and unused as in the reference.  color: optional checkpoint of a run whose 'decoder_state_dict' holds
+        'color_decoder.*' entries for the colour decoder (Point_SLAM.py:198-209).
+        Every shipped config freezes the geometry decoder (mapping.fix_geo_decoder), so without this file the system runs on a
+        random geometry prior: a missing file is reported loudly and the run continues on the random-init decoders (the reference
+        would stop in torch.load; no pretrained file exists offline).  Returns the names loaded into the geometry decoder."""
+        path = (cfg.get('pretrained_decoders') or {}).get('middle_fine')
+        self.pretrained_loaded = []
+        if not path or not os.path.exists(path):
+            import warnings
+            warnings.warn(f'pretrained_decoders.middle_fine = {path!r} not found: the geometry decoder keeps its random initialisation '
+                          '(Point_SLAM.load_pretrain)')
+            return self.pretrained_loaded
+        ckpt = torch.load(path, map_location='cpu', weights_only=False)
+        middle, fine = {}, {}
+        for key, val in ckpt['model'].items():
+            if ('decoder' in key) and ('encoder' not in key):
+                if 'coarse' in key:
+                    middle[key[8 + 7:]] = val           # strip 'decoder.' + 'coarse.'
+                elif 'fine' in key:
+                    fine[key[8 + 5:]] = val
+        have = set(self.shared_decoders.geo_decoder.state_dict())
+        self.shared_decoders.geo_decoder.load_state_dict(middle, strict=False)
+        self.pretrained_loaded = sorted(k for k in middle if k in have)
+        if color:
+            dec = torch.load(color, map_location='cpu', weights_only=False)['decoder_state_dict']
+            self.shared_decoders.color_decoder.load_state_dict({k[14:]: v for k, v in dec.items() if 'color' in k}, strict=False)
+        return self.pretrained_loaded
 
     def update_cam(self):
         """crop_edge shifts the principal point and shrinks the image (Point_SLAM.py:155-175)."""

@@ -32,6 +32,34 @@ def loop_pose(k, n=200, device='cpu'):
     return c2w.to(device)
 
 
+def handheld_pose(k, n=600, device='cpu'):
+    """Pose k of a hand-held walk along the loop: loop_pose(k, n) (n = 600: 0.6 degrees of yaw and 0.6-0.9 cm per frame) plus a
+    smooth sway of the camera centre (sinusoids of 7-13 frame periods, 1-1.5 cm) and of its orientation (0.5-0.6 degrees about two
+    camera axes) - per-frame motion of 1-2 cm and 0.5-1.2 degrees like a Replica / TUM sequence, and a velocity that CHANGES from frame
+    to frame: a constant-velocity prediction from the two previous true poses misses the pose by about 1 cm and 0.4 degrees, which
+    is what the tracker has to remove (tests/oracle_slam.py: prior_only_metrics)."""
+    c2w = loop_pose(k, n, 'cpu').double()
+    t = float(k)
+    sway = torch.tensor([0.012 * math.sin(2 * math.pi * t / 11.0 + 0.3) + 0.008 * math.sin(2 * math.pi * t / 7.0 + 1.1),
+                         0.010 * math.sin(2 * math.pi * t / 13.0 + 2.0) + 0.008 * math.cos(2 * math.pi * t / 7.5),
+                         0.015 * math.sin(2 * math.pi * t / 9.0 + 0.7)], dtype=torch.float64)
+    a = math.radians(0.6) * math.sin(2 * math.pi * t / 9.0 + 1.3)          # about the camera's x axis (pitch)
+    b = math.radians(0.5) * math.sin(2 * math.pi * t / 8.0 + 0.2)          # about the camera's y axis (yaw)
+    Rx = torch.tensor([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]], dtype=torch.float64)
+    Ry = torch.tensor([[math.cos(b), 0, math.sin(b)], [0, 1, 0], [-math.sin(b), 0, math.cos(b)]], dtype=torch.float64)
+    out = c2w.clone()
+    out[:3, :3] = c2w[:3, :3] @ Ry @ Rx
+    out[:3, 3] = c2w[:3, 3] + sway
+    return out.float().to(device)
+
+
+def sequence_pose(k, motion='loop', n_poses=200, device='cpu'):
+    """Pose k of a synthetic sequence: 'loop' = loop_pose(k, n_poses), 'handheld' = handheld_pose(k) (data.motion of the config)."""
+    if motion == 'handheld':
+        return handheld_pose(k, device=device)
+    return loop_pose(k, n_poses, device)
+
+
 def pixel_rays(c2w, i, j, intr=TUM_INTR):
     """get_rays_from_uv convention (src/common.py:104-120): i = column, j = row, un-normalised d."""
     dirs = torch.stack([(i - intr['cx']) / intr['fx'], -(j - intr['cy']) / intr['fy'], -torch.ones_like(i)], -1)
@@ -60,10 +88,10 @@ def room_color(points):
     return torch.stack([r, g, b], -1).clamp(0, 1).float()
 
 
-def render_frame(k, intr=TUM_INTR, holes=0.02, device='cpu', seed=1219, n_poses=200):
+def render_frame(k, intr=TUM_INTR, holes=0.02, device='cpu', seed=1219, n_poses=200, motion='loop'):
     """Synthetic RGB-D frame k: (depth [H,W], color [H,W,3], c2w [4,4])."""
     H, W = intr['H'], intr['W']
-    c2w = loop_pose(k, n_poses, device)
+    c2w = sequence_pose(k, motion, n_poses, device)
     jj, ii = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
                             torch.arange(W, device=device, dtype=torch.float32), indexing='ij')
     ro, rd = pixel_rays(c2w, ii.reshape(-1), jj.reshape(-1), intr)

@@ -377,16 +377,18 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     return p
 
 
-def knn_tree(points, queries, k, r2):
+def knn_tree(points, queries, k, r2, tree=None):
     """Same contract as knn_exact for large clouds (CPU baseline timing): a KD-tree proposes the k nearest
     within the radius, distances are then recomputed in fp32 with the contract's formula and re-ordered by
-    (d2, index).  (Only differs from knn_exact if fp64 and fp32 orderings disagree at the k-th neighbour.)"""
+    (d2, index).  (Only differs from knn_exact if fp64 and fp32 orderings disagree at the k-th neighbour.)
+    tree: a cKDTree already built over `points` as float64 (a caller that searches one cloud many times)."""
     from scipy.spatial import cKDTree
     pts = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(-1, 3))
     q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(-1, 3))
     P = q.shape[0]
     r2a = np.broadcast_to(np.asarray(r2, dtype=np.float32).reshape(-1), (P,)) if np.ndim(r2) else np.full((P,), np.float32(r2), np.float32)
-    tree = cKDTree(pts.astype(np.float64))
+    if tree is None:
+        tree = cKDTree(pts.astype(np.float64))
     rmax = float(np.sqrt(r2a.max())) * 1.001
     _, ii = tree.query(q.astype(np.float64), k=k, distance_upper_bound=rmax, workers=-1)
     ok = ii < pts.shape[0]

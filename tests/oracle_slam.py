@@ -1,0 +1,472 @@
+"""TEST INFRASTRUCTURE ONLY: the reference's per-frame SLAM loop (track every frame, map every `every_frame`-th) chained from the
+CPU oracle's pieces (oracle/hotpath.py) with torch autograd and torch.optim.Adam - the end-to-end counterpart of
+loopy_slam_amd.slam.Point_SLAM for trajectory-level comparisons (ATE RMSE, rendered-depth L1), BASELINE config 1
+("Replica room0, 50 frames, 500 rays/iter, CPU PyTorch reference path").
+
+What it restates (paths relative to /root/reference):
+  * Tracker.run body            src/Tracker.py:281-409   (first two frames keep the given pose, constant-speed initialisation, quaternion
+                                                           hemisphere, Adam groups T: lr / quaternion: 0.2 lr, candidate = pose of the lowest loss)
+  * optimize_cam_in_batch       src/Tracker.py:102-197   (window draws, depth filter, inside mask, tracker-mode render, loss)
+  * Mapper.run body             src/Mapper.py:835-1049   (iteration budget, final refinement switches, keyframe bookkeeping, prev_c2w)
+  * Mapper.optimize_map         src/Mapper.py:347-807    (keyframe window, insertion schedule, frustum rows, iteration count from the points
+                                                           added, stage learning rates, fresh Adam over {decoders, geometry rows, colour rows,
+                                                           exposure feature}, joint iterations, write-back)
+  * keyframe_selection_overlap  src/Mapper.py:219-282
+  * evaluation                  src/tools/eval_ate.py:44-79,195-234 (Horn alignment, translational RMSE), src/Mapper.py:1146-1182 (depth L1 of
+                                                           re-rendered frames over pixels with a sensor depth)
+
+The random draws are consumed in the ORDER the product consumes them, from CPU generators seeded like the product's device generators
+(Mapper: seed + 7, Tracker: seed + 3, new feature rows: seed).  Against the product on the host emulator (device = cpu) the two pipelines
+therefore see identical pixels and feature rows and can be compared pose for pose while the fp32 trajectories stay together
+(tests/test_accuracy.py); on the GPU the device generator draws differently, the trajectories are two samples of the same
+process and only the METRICS are comparable.
+
+Out of scope, as in the product: loop closure / fragments ('segments' keyframes are this build's own single-segment spread), BA, the
+image pre-passes that need absent libraries are the oracle's own restatements (H.radius_maps, H.top_grad_pixels)."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import hotpath as H
+
+GEO_TRAINABLE = ('geo_decoder.embedder._B',)                       # fix_geo_decoder: True (Mapper.py:537-541)
+COLOR_TRAINABLE = tuple(
+    [f'color_decoder.pts_linears.{i}.{w}' for i in range(5) for w in ('weight', 'bias')] +
+    [f'color_decoder.fc_c.{i}.{w}' for i in range(5) for w in ('weight', 'bias')] +
+    ['color_decoder.output_linear.weight', 'color_decoder.output_linear.bias',
+     'color_decoder.embedder_rel_pos._B',
+     'color_decoder.mlp_col_neighbor.linear1.weight', 'color_decoder.mlp_col_neighbor.linear1.bias',
+     'color_decoder.mlp_col_neighbor.linear2.weight', 'color_decoder.mlp_col_neighbor.linear2.bias'])
+EXPOSURE_PARAMS = tuple(f'color_decoder.mlp_exposure.linear{i}.{w}' for i in (1, 2) for w in ('weight', 'bias'))
+
+
+# ------------------------------------------------------------------------------------------------ evaluation
+def horn_align(model, data):
+    """Rotation, translation that map `model` [n,3] onto `data` [n,3] (closed form of Horn; eval_ate.py:44-79)."""
+    model, data = np.asarray(model, np.float64).T, np.asarray(data, np.float64).T
+    mc, dc = model - model.mean(1, keepdims=True), data - data.mean(1, keepdims=True)
+    Wm = mc @ dc.T
+    U, _, Vh = np.linalg.svd(Wm.T)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vh) < 0:
+        S[2, 2] = -1
+    rot = U @ S @ Vh
+    trans = data.mean(1, keepdims=True) - rot @ model.mean(1, keepdims=True)
+    err = np.sqrt(((rot @ model + trans - data) ** 2).sum(0))
+    return rot, trans, err
+
+
+def ate_rmse(est_c2w, gt_c2w):
+    """absolute_translational_error.rmse of eval_ate.py:195-234 over the camera centres, after alignment (metres)."""
+    est = torch.as_tensor(est_c2w)[:, :3, 3].double().numpy()
+    gt = torch.as_tensor(gt_c2w)[:, :3, 3].double().numpy()
+    _, _, err = horn_align(est, gt)
+    return float(np.sqrt(np.dot(err, err) / len(err)))
+
+
+def rotation_error_deg(est_c2w, gt_c2w):
+    """Mean angle (degrees) between estimated and true orientation (no alignment) - reported beside the ATE, not a reference metric."""
+    R = torch.as_tensor(est_c2w)[:, :3, :3].double().transpose(1, 2) @ torch.as_tensor(gt_c2w)[:, :3, :3].double()
+    c = ((R.diagonal(dim1=1, dim2=2).sum(1) - 1) / 2).clamp(-1, 1)
+    return float(torch.rad2deg(torch.acos(c)).mean())
+
+
+def prior_only_metrics(gt_c2w):
+    """What a tracker that does NOTHING scores on a sequence, two ways:
+      one_step        every frame k >= 2 predicted with the constant-speed rule from the TRUE poses k-1, k-2 (Tracker.py:301-305): the error
+                      the tracker has to remove per frame, as an ATE over the sequence;
+      dead_reckoning  the rule applied to its own predictions from frame 2 on (what the pipeline does with zero tracking iterations)."""
+    gt = torch.as_tensor(gt_c2w).double()
+    n = gt.shape[0]
+    one, dead = gt.clone(), gt.clone()
+    for k in range(2, n):
+        one[k] = gt[k - 1] @ torch.linalg.inv(gt[k - 2]) @ gt[k - 1]
+        dead[k] = dead[k - 1] @ torch.linalg.inv(dead[k - 2]) @ dead[k - 1]
+    return {'one_step_ate_cm': 100 * ate_rmse(one, gt), 'dead_reckoning_ate_cm': 100 * ate_rmse(dead, gt),
+            'one_step_rot_deg': rotation_error_deg(one, gt)}
+
+
+# ------------------------------------------------------------------------------------------------ the loop
+class OracleSLAM:
+    """cfg: the resolved config dict (configs/*.yaml over configs/point_slam.yaml).  frames: sequence of (idx, color [H,W,3], depth [H,W],
+    c2w [4,4]) CPU float32 tensors (already cropped, as the product's reader hands them over).  weights: initial decoder dict in the oracle's
+    naming (default: the product's random-init scheme under cfg.setup_seed)."""
+
+    def __init__(self, cfg, frames, weights=None, log=None):
+        from loopy_slam_amd import synthetic          # (random-init scheme only: no kernels)
+        self.cfg, self.frames, self.n_img = cfg, frames, len(frames)
+        c = cfg['cam']
+        e = c.get('crop_edge', 0) or 0
+        self.H, self.W = c['H'] - 2 * e, c['W'] - 2 * e
+        self.intr = (c['fx'], c['fy'], c['cx'] - e, c['cy'] - e)
+        seed = cfg.get('setup_seed', 1219)
+        m, t, pc, r = cfg['mapping'], cfg['tracking'], cfg['pointcloud'], cfg['rendering']
+        self.rel_pos, self.exposure_on = cfg['model']['encode_rel_pos_in_col'], cfg['model']['encode_exposure']
+        W0 = weights if weights is not None else synthetic.default_weights(seed, rel_pos=self.rel_pos, exposure=self.exposure_on)
+        self.Wt = {k: v.clone().float() for k, v in W0.items()}
+        self.rcfg = lambda coef: H.RenderCfg(S=r['N_surface'], near_surface=r['near_end_surface'], far_surface=r['far_end_surface'],
+                                             near_end=r['near_end'], coef=coef, min_nn=pc['min_nn_num'], radius_query=pc['radius_query'],
+                                             rel_pos=self.rel_pos, exposure=self.exposure_on)
+        self.gen_map = torch.Generator().manual_seed(seed + 7)
+        self.gen_track = torch.Generator().manual_seed(seed + 3)
+        self.gen_feat = torch.Generator().manual_seed(seed)
+        self.pos, self.geo, self.col = torch.zeros(0, 3), torch.zeros(0, 32), torch.zeros(0, 32)
+        self._tree = None
+        self.dynamic = cfg['use_dynamic_radius']
+        self.est = torch.zeros(self.n_img, 4, 4)
+        self.gt = torch.zeros(self.n_img, 4, 4)
+        self.keyframe_list, self.keyframe_dict = [], []
+        self.prev_c2w = None
+        self.exposure_feat = torch.zeros(cfg['model']['exposure_dim']) if self.exposure_on else None
+        self.exposure_feat_all = []
+        self.log = log or (lambda *a: None)
+        self.track_log, self.map_log = [], []
+        # mutable switches of Mapper.run (final refinement, Mapper.py:884-897)
+        self.window = m['mapping_window_size']
+        self.geo_iter_ratio = m['geo_iter_ratio']
+        self.fix_color_decoder = m.get('fix_color_decoder', False)
+        self.frustum_selection = m['frustum_feature_selection']
+        self.kf_method = m.get('keyframe_selection_method', 'overlap')
+
+    # ---- neighbour search with one KD-tree per map state
+    def knn(self, p, r2):
+        from scipy.spatial import cKDTree
+        if self._tree is None or self._tree[0] != self.pos.shape[0]:
+            self._tree = (self.pos.shape[0], cKDTree(self.pos.numpy().astype(np.float64)))
+        return H.knn_tree(self.pos.numpy(), p, 8, r2, tree=self._tree[1])
+
+    def render(self, rcfg, ro, rd, gd, geo, col, W, stage, tracker=False, r2_ray=None, affine=None, color_sigmoid=True):
+        z, _ = H.sample_z(gd, rcfg.near_surface, rcfg.far_surface, rcfg.near_end, rcfg.S)
+        p = H.sample_points(ro.detach(), rd.detach(), z).numpy()
+        r2 = np.float32(rcfg.radius_query ** 2) if r2_ray is None else r2_ray.float().reshape(-1, 1).repeat(1, rcfg.S).reshape(-1).numpy()
+        return H.render_batch(rcfg, ro, rd, gd, self.pos, geo, col, W, stage, tracker=tracker, r2_ray=r2_ray, affine=affine,
+                              color_sigmoid=color_sigmoid, knn=self.knn(p, r2))
+
+    def radius_maps(self, color):
+        pc = self.cfg['pointcloud']
+        g, r_add, r_query = H.radius_maps(color.numpy(), pc['radius_add_max'], pc['radius_add_min'], pc['radius_query_ratio'],
+                                          pc['color_grad_threshold'])
+        return g, torch.from_numpy(r_add), torch.from_numpy(r_query)
+
+    # ---- tracking (Tracker.py:281-409)
+    def track_frame(self, idx, color, depth, gt_c2w):
+        t = self.cfg['tracking']
+        if idx <= 1 or t.get('gt_camera', False):
+            c2w = gt_c2w.clone()
+        else:
+            pre = self.est[idx - 1].float()
+            if t['const_speed_assumption'] and idx - 2 >= 0:
+                init = (pre @ torch.linalg.inv(self.est[idx - 2].float())) @ pre
+            else:
+                init = pre
+            cam = H.c2w_to_cam(init)
+            gt_cam = H.c2w_to_cam(gt_c2w)
+            if float(torch.dot(cam[:4], gt_cam[:4])) < 0:
+                cam[:4] *= -1
+            c2w = torch.eye(4)
+            c2w[:3] = H.quat_to_c2w(self._optimize_pose(cam, color, depth)).detach()
+        self.est[idx], self.gt[idx] = c2w.detach(), gt_c2w.detach()
+        return c2w
+
+    def _optimize_pose(self, cam, color, depth):
+        t = self.cfg['tracking']
+        H_, W_ = self.H, self.W
+        fx, fy, cx, cy = self.intr
+        iters, n_px, lr = t['iters'], t['pixels'], t['lr']
+        He, We = t['ignore_edge_H'], t['ignore_edge_W']
+        rcfg = self.rcfg(self.cfg['rendering']['sigmoid_coef_tracker'])
+        r2_map = None
+        grad = None
+        if self.dynamic or t.get('sample_with_color_grad', False):
+            grad, _, r_query = self.radius_maps(color)
+            r2_map = (r_query.double() ** 2).float() if self.dynamic else None
+        if t.get('sample_with_color_grad', False):
+            # pool of the 15 n highest-gradient pixels inside the window with a usable depth; n of them per iteration without replacement
+            # (common.py:198-234, Tracker.py:126-139) - drawn as the product draws them: the n largest of a row of uniforms
+            pool = torch.from_numpy(H.top_grad_pixels(grad, 15 * n_px, (He, H_ - He, We, W_ - We), depth.numpy(), t.get('depth_limit', False))).long()
+            n_px = min(n_px, int(pool.numel()))
+            u = torch.rand(iters, pool.numel(), generator=self.gen_track)
+            flat_all = pool[u.topk(n_px, dim=1).indices]
+            win = (0, H_, 0, W_)
+        else:
+            win = (He, H_ - He, We, W_ - We)
+            flat_all = torch.randint(0, (win[1] - win[0]) * (win[3] - win[2]), (iters, n_px), generator=self.gen_track, dtype=torch.int32).long()
+        depth_t = depth
+        if t.get('depth_limit', False) and not t.get('sample_with_color_grad', False):
+            depth_t = torch.where(depth < 5.0, depth, torch.zeros_like(depth))          # get_samples(depth_limit=5.0), common.py:249-252
+        sep = t['separate_LR']
+        W = dict(self.Wt)
+        params = []
+        if sep:
+            T = cam[4:].clone().requires_grad_(True)
+            q = cam[:4].clone().requires_grad_(True)
+            params = [{'params': [T], 'lr': lr}, {'params': [q], 'lr': 0.2 * lr}]
+        else:
+            cam_v = cam.clone().requires_grad_(True)
+            params = [{'params': [cam_v], 'lr': lr}]
+        xfeat = None
+        if self.exposure_on:
+            xfeat = self.exposure_feat.clone().requires_grad_(True)
+            for n in EXPOSURE_PARAMS:
+                W[n] = self.Wt[n].clone().requires_grad_(True)
+            params += [{'params': [xfeat], 'lr': 0.001}, {'params': [W[n] for n in EXPOSURE_PARAMS], 'lr': 0.001}]
+        opt = torch.optim.Adam(params)
+        best, best_loss = None, 1e20
+        w = win[3] - win[2]
+        losses = []
+        for it in range(iters):
+            cam_t = torch.cat([q, T]) if sep else cam_v
+            opt.zero_grad()
+            c2w = H.quat_to_c2w(cam_t)
+            fl = flat_all[it]
+            i = (win[2] + fl % w).float()
+            j = (win[0] + torch.div(fl, w, rounding_mode='floor')).float()
+            ro, rd = H.rays_from_uv(i, j, c2w, fx, fy, cx, cy)
+            gd = depth_t[j.long(), i.long()]
+            gc = color[j.long(), i.long()]
+            keep = gd > 0
+            keep = keep & (gd <= H.inside_threshold(gd[keep]))
+            r2 = r2_map[j.long(), i.long()][keep] if r2_map is not None else None
+            aff = H.exposure_affine(W, xfeat) if xfeat is not None else None
+            out = self.render(rcfg, ro[keep], rd[keep], gd[keep], self.geo, self.col, W, 'color', tracker=True, r2_ray=r2, affine=aff)
+            loss, _, _, _ = H.tracker_loss(out['depth'], out['var'], out['color'], gd[keep], gc[keep], t['w_color_loss'],
+                                           t['use_color_in_tracking'], t.get('handle_dynamic', True))
+            before = cam_t.detach().clone()
+            loss.backward()
+            opt.step()
+            lv = float(loss)
+            losses.append(lv)
+            cand = before if sep else cam_v.detach().clone()        # separate_LR: the concatenation made BEFORE the step (Tracker.py:363-377)
+            if lv < best_loss:
+                best_loss, best = lv, cand
+        if xfeat is not None:
+            self.exposure_feat = xfeat.detach().clone()
+            for n in EXPOSURE_PARAMS:
+                self.Wt[n] = W[n].detach().clone()
+        self.track_log.append((losses[0], best_loss))
+        return best
+
+    # ---- keyframes of the window (Mapper.py:219-282, 372-405)
+    def _select_keyframes(self, color, depth, c2w):
+        kd = self.keyframe_dict
+        if len(kd) == 0:
+            return []
+        if self.kf_method == 'segments':            # this build's single-segment spread (slam.Mapper.optimize_map)
+            n_kf = min(len(kd), max(1, 2 * self.window - 1))
+            return sorted(set(int(round(x)) for x in np.linspace(0, len(kd) - 1, n_kf)))
+        if self.kf_method == 'global':
+            num = self.window - 2
+            sel = list(range(max(0, len(kd) - 1 - num), len(kd) - 1))
+        else:
+            sel = self._overlap(color, depth, c2w, kd[:-1], self.window - 2)
+        if len(self.keyframe_list) > 0:
+            sel = sel + [len(kd) - 1]
+        return sel
+
+    def _overlap(self, color, depth, c2w, kd, k, N_samples=8, pixels=200):
+        fx, fy, cx, cy = self.intr
+        idx = torch.randint(self.H * self.W, (pixels,), generator=self.gen_map)
+        i, j = (idx % self.W).float(), torch.div(idx, self.W, rounding_mode='floor').float()
+        gd = depth[j.long(), i.long()]
+        ro, rd = H.rays_from_uv(i, j, c2w, fx, fy, cx, cy)
+        keep = gd > 0
+        ro, rd, gd = ro[keep], rd[keep], gd[keep]
+        t = torch.linspace(0., 1., N_samples)
+        z = gd[:, None] * 0.8 * (1 - t) + (gd[:, None] + 0.5) * t
+        pts = (ro[:, None, :] + rd[:, None, :] * z[..., None]).reshape(-1, 3)
+        if len(kd) == 0:
+            return []
+        frac = H.keyframe_overlap_fractions(pts.numpy(), [kf['est_c2w'].numpy() for kf in kd], fx, fy, cx, cy, self.H, self.W).tolist()
+        order = sorted(range(len(frac)), key=lambda q: frac[q], reverse=True)
+        scored = [q for q in order if frac[q] > 0.0]
+        perm = torch.randperm(len(scored), generator=self.gen_map).tolist()
+        return [scored[q] for q in perm[:k]]
+
+    # ---- insertion (Mapper.py:421-482 through H.add_points_schedule), new rows N(0, 0.1) (neural_point.py:1608-1617)
+    def _add_points(self, idx, color, depth, c2w, r_add_map, grad_mag):
+        m, pc = self.cfg['mapping'], self.cfg['pointcloud']
+        HW = self.H * self.W
+        n_main = H.first_frame_add_count(depth, m['pixels_adding']) if idx == 0 else m['pixels_adding']
+        draws = {'main': torch.randint(0, HW, (n_main,), generator=self.gen_map),
+                 'overlap': torch.randint(0, HW, (1000,), generator=self.gen_map)}
+        n_grad = m.get('pixels_based_on_color_grad', 0)
+        if n_grad > 0:
+            pool = torch.from_numpy(H.top_grad_pixels(grad_mag, 5 * n_grad, (0, self.H, 0, self.W)))
+            pick = torch.randperm(int(pool.numel()), generator=self.gen_map)[:n_grad]
+            draws['grad'] = torch.sort(pool[pick].long()).values
+        cfg_add = dict(pixels_adding=m['pixels_adding'], pixels_grad=n_grad, radius_add=pc['radius_add'], radius_min=pc['radius_min'],
+                       near=pc['near_end_surface'], far=pc['far_end_surface'],
+                       filter_before=bool(m['filter_before_add_points'] and self.prev_c2w is not None))
+        n0 = self.pos.shape[0]
+        total, counts, cloud = H.add_points_schedule(idx, depth, color, c2w, self.prev_c2w if self.prev_c2w is not None else c2w, self.pos,
+                                                     self.intr, cfg_add, draws, r_add_map=r_add_map)
+        # the product draws the two feature blocks of every pass that added points (geo, then col) from one generator
+        geo, col = [self.geo], [self.col]
+        for cnt in counts:
+            if cnt > 0:
+                geo.append(torch.randn(3 * cnt, 32, generator=self.gen_feat) * 0.1)
+                col.append(torch.randn(3 * cnt, 32, generator=self.gen_feat) * 0.1)
+        self.pos, self.geo, self.col = cloud.contiguous(), torch.cat(geo), torch.cat(col)
+        assert self.pos.shape[0] == self.geo.shape[0] == n0 + 3 * total
+        return total, counts
+
+    # ---- one optimize_map call (Mapper.py:347-807)
+    def optimize_map(self, num_joint_iters, idx, color, depth, cur_c2w, color_refine=False):
+        cfg, m = self.cfg, self.cfg['mapping']
+        fx, fy, cx, cy = self.intr
+        init = idx == 0
+        segments = self.kf_method == 'segments'
+        sel = self._select_keyframes(color, depth, cur_c2w)
+        kd = self.keyframe_dict
+        grad_mag = r_add_map = r_query_map = None
+        if self.dynamic:
+            grad_mag, r_add_map, r_query_map = self.radius_maps(color)
+            self.cur_r_query = r_query_map
+        frames = [(kd[k]['depth'], kd[k]['color'], kd[k]['est_c2w'], kd[k].get('r_query')) for k in sel] + [(depth, color, cur_c2w, r_query_map)]
+        xfeats = None
+        W = dict(self.Wt)
+        if self.exposure_on:
+            cur_x = self.exposure_feat.clone().requires_grad_(True)
+            xfeats = [kd[k]['exposure_feat'] for k in sel] + [cur_x]
+        frame_pts_add = 0
+        if not color_refine:
+            frame_pts_add, self.last_add_counts = self._add_points(idx, color, depth, cur_c2w, r_add_map, grad_mag)
+        if idx > 0 and not color_refine:
+            num_joint_iters = H.mapping_iterations(num_joint_iters, frame_pts_add, m['min_iter_ratio'])
+        stage_cfg = m['init' if init else 'stage']
+        F = len(frames)
+        pix = (m['pixels'] // 10) if segments else (m['pixels'] // F)
+        R = pix * F
+        fid = torch.arange(F).repeat_interleave(pix)
+        rnd = torch.randint(0, self.H * self.W, (num_joint_iters, R), generator=self.gen_map, dtype=torch.int32).long()
+        geo_iters = m['geo_iter_first'] if init else int(num_joint_iters * self.geo_iter_ratio)
+        # rows to optimise (Mapper.py:498-520)
+        if self.frustum_selection:
+            rows = torch.from_numpy(H.frustum_rows(self.pos.numpy(), cur_c2w.numpy(), depth.numpy(), fx, fy, cx, cy, self.H, self.W,
+                                                   m['frustum_edge'])).long()
+        else:
+            rows = torch.arange(self.pos.shape[0])
+        geo_p = self.geo[rows].clone().requires_grad_(True)
+        col_p = self.col[rows].clone().requires_grad_(True)
+        dec_names = list(GEO_TRAINABLE)
+        if not self.fix_color_decoder:
+            dec_names += [n for n in COLOR_TRAINABLE if n in W and (self.rel_pos or ('mlp_col_neighbor' not in n and 'embedder_rel_pos' not in n))]
+            if self.exposure_on:
+                dec_names += list(EXPOSURE_PARAMS)
+        elif self.rel_pos:
+            dec_names += ['color_decoder.embedder_rel_pos._B']
+        for n in dec_names:
+            W[n] = self.Wt[n].clone().requires_grad_(True)
+        groups = [{'params': [W[n] for n in dec_names], 'lr': 0}, {'params': [geo_p], 'lr': 0}, {'params': [col_p], 'lr': 0}]
+        if self.exposure_on:
+            groups.append({'params': [cur_x], 'lr': 0.001})
+        opt = torch.optim.Adam(groups)
+        rcfg = self.rcfg(cfg['rendering']['sigmoid_coef_mapper'])
+        dstack = torch.stack([f[0] for f in frames]).reshape(F, -1)
+        cstack = torch.stack([f[1] for f in frames]).reshape(F, -1, 3)
+        pstack = torch.stack([f[2].float() for f in frames])
+        rstack = torch.stack([(f[3].double() ** 2).float() for f in frames]).reshape(F, -1) if self.dynamic else None
+        losses = []
+        for it in range(num_joint_iters):
+            stage = 'geometry' if it <= geo_iters else 'color'
+            for gi, key in enumerate(('decoders_lr', 'geometry_lr', 'color_lr')):
+                opt.param_groups[gi]['lr'] = stage_cfg[stage][key]
+            opt.zero_grad()
+            geo_t = self.geo.index_put((rows,), geo_p)
+            col_t = self.col.index_put((rows,), col_p)
+            fl = rnd[it]
+            i, j = (fl % self.W).float(), torch.div(fl, self.W, rounding_mode='floor').float()
+            dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1)
+            Rm = pstack[fid]                                                    # [R,4,4]
+            rd = torch.sum(dirs[:, None, :] * Rm[:, :3, :3], -1)
+            ro = Rm[:, :3, 3]
+            gd = dstack[fid, fl]
+            gc = cstack[fid, fl]
+            keep = gd > 0
+            keep = keep & (gd <= H.inside_threshold(gd[keep]))
+            r2 = rstack[fid, fl][keep] if rstack is not None else None
+            xs_on = self.exposure_on and stage == 'color'
+            out = self.render(rcfg, ro[keep], rd[keep], gd[keep], geo_t, col_t, W, stage, r2_ray=r2, color_sigmoid=not self.exposure_on)
+            colr = out['color']
+            if xs_on:                           # per-keyframe affine on the rendered logits (Mapper.py:697-715)
+                aff = torch.stack([H.exposure_affine(W, x) for x in xfeats])[fid[keep]]
+                colr = torch.sigmoid(torch.einsum('ri,rij->rj', colr, aff[:, :9].reshape(-1, 3, 3)) + aff[:, 9:])
+            loss, _, _, _ = H.mapper_loss(out['depth'], colr, out['valid_ray'], gd[keep], gc[keep], stage, m['w_color_loss'])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        with torch.no_grad():
+            self.geo[rows] = geo_p.detach()
+            self.col[rows] = col_p.detach()
+            for n in dec_names:
+                self.Wt[n] = W[n].detach().clone()
+        if self.exposure_on:
+            self.exposure_feat = cur_x.detach().clone()
+            self.cur_exposure_feat = cur_x.detach().clone()
+            self.exposure_feat_all.append(cur_x.detach().clone())
+        self.map_log.append(dict(idx=int(idx), iters=int(num_joint_iters), added=int(frame_pts_add), rows=int(rows.numel()), frames=F,
+                                 loss_first=losses[0] if losses else None, loss_last=losses[-1] if losses else None))
+        return num_joint_iters
+
+    # ---- one mapped frame (Mapper.py:835-1037)
+    def map_frame(self, idx, color, depth, gt_c2w, cur_c2w):
+        m = self.cfg['mapping']
+        init, last = idx == 0, idx == self.n_img - 1
+        color_refine = bool(last and m.get('color_refine', False) and not init)
+        num_joint_iters, outer = (m['iters_first'] if init else m['iters']), 1
+        saved = None
+        if not init:
+            self.window = m['mapping_window_size'] * (2 if self.n_img > 4000 else 1)
+            if color_refine:
+                saved = (self.window, self.geo_iter_ratio, self.fix_color_decoder, self.frustum_selection, self.kf_method)
+                outer = 5
+                self.window *= 2
+                self.geo_iter_ratio = 0.4
+                num_joint_iters *= 10
+                self.fix_color_decoder, self.frustum_selection, self.kf_method = True, False, 'segments'
+        num_joint_iters //= outer
+        for _ in range(outer):
+            self.optimize_map(num_joint_iters, idx, color, depth, cur_c2w, color_refine=color_refine)
+        if saved is not None:
+            self.window, self.geo_iter_ratio, self.fix_color_decoder, self.frustum_selection, self.kf_method = saved
+        if (idx % m['keyframe_every'] == 0 or idx == self.n_img - 2) and idx not in self.keyframe_list and bool(torch.isfinite(gt_c2w).all()):
+            self.keyframe_list.append(idx)
+            self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': color, 'depth': depth, 'est_c2w': cur_c2w.clone(),
+                                       'r_query': getattr(self, 'cur_r_query', None),
+                                       'exposure_feat': self.cur_exposure_feat if self.exposure_on else None})
+        self.prev_c2w = cur_c2w.clone()
+
+    def run(self, n_frames=None, callback=None):
+        n = n_frames or self.n_img
+        every = self.cfg['mapping']['every_frame']
+        for k in range(n):
+            idx, color, depth, c2w = self.frames[k]
+            est = self.track_frame(idx, color, depth, c2w)
+            if idx == 0 or idx % every == 0 or idx == n - 1:
+                self.map_frame(idx, color, depth, c2w, est)
+            self.log(f'oracle frame {idx}: |t - t_gt| = {100 * float((est[:3, 3] - c2w[:3, 3]).norm()):.3f} cm, {self.pos.shape[0]} points')
+            if callback:
+                callback(idx, est, c2w)
+        return self.est[:n], self.gt[:n]
+
+    # ---- rendered-depth L1 (Mapper.py:1146-1182) on a pixel grid of the given stride
+    def depth_l1(self, frame_ids, stride=4):
+        fx, fy, cx, cy = self.intr
+        rcfg = self.rcfg(self.cfg['rendering']['sigmoid_coef_mapper'])
+        vals = []
+        for k in frame_ids:
+            _, color, depth, _ = self.frames[k]
+            jj, ii = torch.meshgrid(torch.arange(0, self.H, stride, dtype=torch.float32), torch.arange(0, self.W, stride, dtype=torch.float32),
+                                    indexing='ij')
+            i, j = ii.reshape(-1), jj.reshape(-1)
+            ro, rd = H.rays_from_uv(i, j, self.est[k], fx, fy, cx, cy)
+            gd = depth[j.long(), i.long()]
+            r2 = None
+            if self.dynamic:
+                r2 = (self.radius_maps(color)[2].double() ** 2).float()[j.long(), i.long()]
+            with torch.no_grad():
+                out = self.render(rcfg, ro, rd, gd, self.geo, self.col, self.Wt, 'geometry', r2_ray=r2)
+            mask = gd > 0
+            vals.append(float((gd[mask] - out['depth'][mask]).abs().mean()))
+        return vals
