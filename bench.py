@@ -7,7 +7,9 @@ synthetic 640x480 RGB-D, N GPUs of one node (one process per GPU, RCCL gradient 
 
 A "step" = one frame-equivalent of the reference's budget (loopy_slam_amd/workload.py):
 40 tracking iterations x 1500 rays + 60 mapping iterations x 5000 rays (24 geometry + 36 colour),
-each iteration = ray gather, inside-mask, render forward, loss, render backward, Adam.
+each iteration = ray gather, inside-mask, render forward, loss, render backward, Adam - and on every 5th step (a mapped
+frame) the frame's point insertion + index rebuild + full-frame render (the headline since round 4; the iterations alone
+are reported beside it as ms_per_step_iterations).
 Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for how roofline / cpu_baseline are obtained.
 """
 import argparse
@@ -108,16 +110,23 @@ def main():
     kall = prof_all.stop()
     dominant = os.environ.get('BENCH_ROOFLINE_KERNEL') or profile.dominant_kernel(
         {k: v for k, v in kall.items() if k in profile.work_per_step(budget)})
-    # ... and the timed region records events on the launch stream around that kernel only
+    # ... and the timed region records events on the launch stream around that kernel only.
+    # THE TIMED STEP IS THE FULL STEP: 40 tracking + 60 mapping iterations per frame and, on every 5th step (a MAPPED frame of the
+    # reference's schedule, mapping.every_frame), what that frame does around its iterations - insertion of 6 000 pixels through the
+    # radius test + feature rows + index rebuild (Mapper.py:421-482) and the full-frame render (Mapper.py:966-969)
+    wl.frame_no = 0
+    wl.step(full=True)                  # untimed: first-use allocations of the full-frame render state
+    wl.frame_no = 0
     prof = profile.KernelTimer(eng, dominant)
     barrier()
     prof.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step()
+        wl.step(full=True)
     barrier()
     dt = time.perf_counter() - t0
     kstat = prof.stop()
+    n_mapped = (args.steps + budget.every_frame - 1) // budget.every_frame
     # the same kernel alone on the chip: one more untimed step with the library's second stream switched off
     eng.lib.check(eng.lib.dll.lk_set_serial(1), 'lk_set_serial')
     barrier()
@@ -127,18 +136,13 @@ def main():
     barrier()
     kstat_serial = prof_s.stop()
     eng.lib.check(eng.lib.dll.lk_set_serial(0), 'lk_set_serial')
-    # the same step with the once-per-mapped-frame work the reference does beside its iterations (every 5th frame: insertion of 6 000
-    # pixels through the radius test + feature rows + index rebuild, Mapper.py:421-482; the full-frame render, Mapper.py:966-969)
-    n_full = 2 * budget.every_frame
-    wl.frame_no = 0
-    wl.step(full=True)                  # untimed: first-use allocations of the full-frame render state
-    wl.frame_no = 0
+    # beside it: the iterations alone (no mapped-frame extras) - the figure rounds 1-3 reported as `value`
     barrier()
-    t0f = time.perf_counter()
-    for _ in range(n_full):
-        wl.step(full=True)
+    t0i = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
     barrier()
-    dt_full = time.perf_counter() - t0f
+    dt_iter = time.perf_counter() - t0i
     # PCIe-inclusive: the C ABI takes DEVICE pointers, so a caller that receives its RGB-D frames in host memory uploads one frame
     # (640 x 480 fp32 depth + RGB = 4.9 MB) per step; the same timed steps with that upload from pinned memory in front of each
     # (reported beside `value`, never as `value`)
@@ -150,13 +154,13 @@ def main():
         k = wl.frame_no % budget.window
         wl.depth_stack[k].copy_(host_d[k], non_blocking=True)
         wl.color_stack[k].copy_(host_c[k], non_blocking=True)
-        wl.step()
+        wl.step(full=True)
     barrier()
     dt_host = time.perf_counter() - t0h
     if world > 1:
-        t = torch.tensor([dt, dt_full, dt_host], device='cuda')
+        t = torch.tensor([dt, dt_iter, dt_host], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_full, dt_host = float(t[0].item()), float(t[1].item()), float(t[2].item())
+        dt, dt_iter, dt_host = float(t[0].item()), float(t[1].item()), float(t[2].item())
     rays_per_step = budget.rays_per_frame
     # whole-job rays of a step: every rank brings its own mapping rays; the tracking iterations are REPLICATED on the ranks (the same
     # rays everywhere, no exchange - steps.TrackOptimizer), so they count once however many ranks repeat them
@@ -170,10 +174,11 @@ def main():
         'value': total_rays / dt, 'unit': 'rays/s',
         # every rank works on the SAME frame (the ranks share one map and sum their gradients): a step is one frame whatever N is
         'frames_per_s': args.steps / dt,
-        # ... and with a mapped frame's point insertion + index rebuild + full-frame render every 5th step (Mapper.py:421-482, 966-969)
-        'frames_per_s_full': n_full / dt_full, 'ms_per_step_full': 1e3 * dt_full / n_full,
-        'full_step': f'{n_full} steps, every {budget.every_frame}th also inserts {budget.pixels_adding} pixels (lk_add_points + feature rows + lk_knn_build) and '
-                     f'renders the 640x480 frame (307 200 rays); {wl.n_added} points added, map {wl.n} points',
+        'step': f'the FULL step: every {budget.every_frame}th of the {args.steps} timed steps ({n_mapped} of them) is a mapped frame that also inserts '
+                f'{budget.pixels_adding} pixels (lk_add_points + feature rows + lk_knn_build, Mapper.py:421-482) and renders the 640x480 frame '
+                f'(307 200 rays, Mapper.py:966-969; these rays are NOT counted in `value`); {wl.n_added} points added over the run, map {wl.n} points',
+        # the iterations alone (what rounds 1-3 reported as the headline)
+        'ms_per_step_iterations': 1e3 * dt_iter / args.steps, 'frames_per_s_iterations': args.steps / dt_iter,
         'ms_per_step_host_frames': 1e3 * dt_host / args.steps,
         'host_frames': 'the same steps with one RGB-D frame (4.9 MB, pinned host memory) uploaded over PCIe in front of each - the boundary takes device pointers',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

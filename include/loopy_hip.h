@@ -320,7 +320,9 @@ int lk_add_points(lk_knn_t knn, const float* rays_o, const float* rays_d, const 
  * (r2_add / r2_query may be NULL).
  * lk_top_grad_pixels: the K pixels of largest grad_mag over the whole image (ties at the cut in ascending flat index),
  * kept only inside the window [H0,H1) x [W0,W1) and where depth > 0 (depth may be NULL; depth_limit: also <= 5):
- * out_index[0..*out_count) ascending flat indices (out_index must hold K ints). */
+ * out_index[0..*out_count) ascending flat indices (out_index must hold K ints).  Images above 16 384 pixels use a library-owned
+ * scratch, one per DEVICE (grown with a stream synchronisation when a larger image first arrives): on one device the calls must be
+ * ordered - one stream, or streams ordered by events - like the calls on one lk_knn_t handle. */
 int lk_radius_maps(const float* color, int32_t H, int32_t W, double color_grad_threshold, double radius_add_max,
                    double radius_add_min, double radius_query_ratio, float* grad_mag, float* r2_add, float* r2_query, void* stream);
 int lk_top_grad_pixels(const float* grad_mag, int32_t H, int32_t W, int32_t K, int32_t H0, int32_t H1, int32_t W0, int32_t W1,

@@ -302,7 +302,9 @@ extern "C" int lk_streams_init(void) {
     if (lk_serial_mode()) return LK_OK;
     SideStream& s = side_stream();
     LkAuxStream& a = lk_aux_stream();
-    LK_REQUIRE(s.ok && a.ok, "lk_streams_init: stream / event creation failed");
+    // a failed creation costs the overlap, not the results: every user of the side streams checks `ok` and falls back to the launch
+    // stream - so it is not an error of this call either; the process then runs as with LK_SERIAL=1
+    if (!(s.ok && a.ok)) { g_serial = 1; lk_set_error("lk_streams_init: stream / event creation failed - running on the launch stream only"); }
     return LK_OK;
 }
 extern "C" int lk_debug_occupancy(int32_t out[5]) {

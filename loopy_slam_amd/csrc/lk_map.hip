@@ -357,7 +357,14 @@ __global__ __launch_bounds__(1024) void k_top_grad(const float* __restrict__ gra
 // (ascending indices).  Same pool, bit for bit.
 #define LK_TG_WGS 256
 struct TgScratch { unsigned* hist; unsigned* above; unsigned* ties; uint8_t* mask; int32_t* blocks; size_t mask_cap; };
-static TgScratch& tg_scratch() { static TgScratch s = {nullptr, nullptr, nullptr, nullptr, nullptr, 0}; return s; }
+// one scratch set PER DEVICE (a process that drives several devices must not hand one device's pointers to another's kernels); calls on
+// ONE device share it: lk_top_grad_pixels is one-call-at-a-time per device (include/loopy_hip.h)
+static TgScratch& tg_scratch() {
+    static TgScratch s[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    return s[dev];
+}
 
 // prefix (bit pattern so far) and rank (ascending rank inside the candidates) after `passes` radix passes; called by wave 0, all 64 lanes
 __device__ __forceinline__ void tg_select(const unsigned* __restrict__ hist_all, int passes, unsigned rank0, unsigned& prefix, unsigned& rank) {

@@ -97,7 +97,10 @@ class DistContext:
         rows = mo.rows if mo.rows is not None else self.touched_rows(mo, it)
         # the segment table of a stage is the same for every iteration of an optimize_map call (same buffers, same row list): built
         # once - at 72-us 'geometry' iterations the interpreter time of rebuilding it per iteration was the longer side
-        key = (stage, rows.data_ptr(), rows.numel(), gs.g_weights.data_ptr(), gs.g_geo.data_ptr(), id(mo.exposure))
+        # keyed by the optimiser's call token (steps.MapOptimizer.call_token: a process-wide counter bumped by every constructor and
+        # new_frame) - device addresses and id()s are reused by the allocator / CPython across optimize_map calls, a key made of them
+        # could hit with another call's exposure buffers or decoder ranges; the entry keeps what its segment table points at alive
+        key = (stage, mo.call_token, rows.data_ptr(), rows.numel())
         if self._seg_cache is not None and self._seg_cache[0] == key:
             _, segs, n, offs = self._seg_cache
             bucket = self._bucket[:n]
@@ -125,7 +128,7 @@ class DistContext:
             segs[k].row_index, segs[k].row_len = ptr(rows), t.shape[1]
             offs['tables'].append(n)
             n += segs[k].n
-        self._keep = rows
+        self._keep = (rows, gs.g_weights, gs.g_geo, gs.g_col, xs.g_aff if xs is not None else None, mo)
         if xs is not None:
             k = len(ranges) + len(tables)
             segs[k].data, segs[k].n, segs[k].row_index, segs[k].row_len = ptr(xs.g_aff), xs.g_aff.numel(), None, 1

@@ -870,12 +870,13 @@ class SyntheticRoomDataset:
         # data.motion: 'loop' = the slow closed loop (3 mm, 0.2 degrees per frame: throughput runs), 'handheld' = 1-2 cm and 0.5-1.2 degrees
         # per frame with a changing velocity (synthetic.handheld_pose: the accuracy runs, where the tracker has to do something)
         self.motion = cfg['data'].get('motion', 'loop')
+        self.scene = cfg['data'].get('scene', 'plain')         # 'furnished': boxes along the walls, finer relief and texture (synthetic.FURNITURE)
 
     def __len__(self):
         return self.n_img
 
     def __getitem__(self, idx):
-        d, c, p = synthetic.render_frame(idx, intr=self.intr, device=self.device, holes=0.01, n_poses=2000, motion=self.motion)
+        d, c, p = synthetic.render_frame(idx, intr=self.intr, device=self.device, holes=0.01, n_poses=2000, motion=self.motion, scene=self.scene)
         e = self.crop_edge
         if e > 0:       # the reference's readers crop the frames (src/utils/datasets.py), Point_SLAM.update_cam the intrinsics
             d, c = d[e:-e, e:-e].contiguous(), c[e:-e, e:-e].contiguous()

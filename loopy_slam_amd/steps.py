@@ -139,6 +139,13 @@ class ExposureState:
 class MapOptimizer:
     """One optimize_map call: Adam over {decoder params, selected geo rows, selected colour rows}."""
 
+    _tokens = 0                 # process-wide: every constructor and every new_frame takes the next one (caches key on it, never on addresses)
+
+    @classmethod
+    def _next_token(cls):
+        cls._tokens += 1
+        return cls._tokens
+
     def __init__(self, eng, cfg, dec, knn, pos, geo_feats, col_feats, row_index, R, lrs, w_color=0.1,
                  dynamic_radius=False, fix_color_decoder=False, dist=None, exposure=None, fix_geo_decoder=True):
         """row_index: int32 [n_f] rows being optimised (frustum selection, Mapper.py:498-512) or None = all rows.
@@ -146,6 +153,7 @@ class MapOptimizer:
         self.eng, self.cfg, self.dec, self.knn = eng, cfg, dec, knn
         self.pos, self.geo, self.col = pos, geo_feats, col_feats
         self.rows = row_index
+        self.call_token = self._next_token()
         self.lrs, self.w_color = lrs, w_color
         self.R = R
         self.batch = RayBatch(eng, R, dynamic_radius)
@@ -289,7 +297,7 @@ class MapOptimizer:
                 d.it_offset, d.iters = s0, n
                 d.rnd, d.log = ptr(rnd_all[s0:]), ptr(log[s0:])
                 # the first segment's batches may have been assembled ahead of the row selection (prepare)
-                d.batches_ready = 1 if (s0 == 0 and prepared == (n_iters, rnd_all.data_ptr(), log.data_ptr(), (self._work.data_ptr() if self._work is not None else 0))) else 0
+                d.batches_ready = 1 if (s0 == 0 and prepared == self._prepare_key(n_iters, frames, rnd_all, frame_id, window, intr, H, W, log)) else 0
                 eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n, 3, eng.stream), 'lk_map_frame')
         else:
             self._nat_desc = d
@@ -319,8 +327,15 @@ class MapOptimizer:
         d, seg_iters = self._native_desc(n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log, rows_known=False)
         d.iters, d.it_offset = min(seg_iters, n_iters), 0
         self.eng.lib.check(self.eng.lib.dll.lk_map_prepare(_ffi.C.byref(d), self.eng.stream), 'lk_map_prepare')
-        self._prepared = (n_iters, rnd_all.data_ptr(), log.data_ptr(), (self._work.data_ptr() if self._work is not None else 0))
+        self._prepared = self._prepare_key(n_iters, frames, rnd_all, frame_id, window, intr, H, W, log)
         return True
+
+    def _prepare_key(self, n_iters, frames, rnd_all, frame_id, window, intr, H, W, log):
+        """What a prepare() assembled its batches FROM: a run() may build on them only if every input is the same buffer with the same
+        geometry (the draws, the frame stacks, the frame ids, the window, the intrinsics); prepare() keeps the tensors alive
+        (_native_desc: _keep_native), so an address cannot have been freed and handed out again in between."""
+        ptrs = tuple(t.data_ptr() if t is not None else 0 for t in (rnd_all, log, frame_id, self._work) + tuple(frames))
+        return (n_iters, ptrs, tuple(int(x) for x in window), tuple(float(x) for x in intr), int(H), int(W))
 
     def _native_desc(self, n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log, rows_known=True):
         """lk_map_desc of an optimize_map call + the segment length.  rows_known False (prepare): the optimiser-state part is left out."""
@@ -421,6 +436,7 @@ class MapOptimizer:
         (Mapper.py:570) and clean gradient tables (zero=False: prepare() has cleared them already).  row_mask (uint8 [N], 1 on the
         rows of row_index) lets the backward skip the scatter into rows nobody optimises."""
         self.rows = row_index
+        self.call_token = self._next_token()
         self.gs.row_mask = row_mask
         self.adam = optim.Adam(self.eng)
         if zero:
@@ -476,7 +492,7 @@ class TrackOptimizer:
             # the whole loop as ONE C-ABI call (lk_track_frame): no interpreter between the launches
             self._track_native(cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log, xs)
             best = torch.argmin(log[:, 0])      # Tracker.py:375-377 (first minimum)
-            return self._agree(hist.index_select(0, best.reshape(1))[0]), log   # (hist[best] would read `best` back: a host sync)
+            return self._agree(hist.index_select(0, best.reshape(1))[0], xs), log   # (hist[best] would read `best` back: a host sync)
         if self.eye is None:
             self.eye = torch.eye(4, device=eng.device).reshape(1, 4, 4).contiguous()
         dstack, cstack = depth_img.reshape(1, H, W), color_img.reshape(1, H, W, 3)
@@ -510,12 +526,17 @@ class TrackOptimizer:
             if not self.separate_lr:
                 hist[it].copy_(cam)             # one leaf tensor stepped in place: the candidate is the pose AFTER the update
         best = torch.argmin(log[:, 0])          # Tracker.py:375-377 (first minimum)
-        return self._agree(hist.index_select(0, best.reshape(1))[0]), log
+        return self._agree(hist.index_select(0, best.reshape(1))[0], xs), log
 
-    def _agree(self, cam7):
-        """Replicated tracking: every rank continues from rank 0's pose."""
+    def _agree(self, cam7, xs=None):
+        """Replicated tracking: every rank continues from rank 0's pose - and, with exposure encoding, from rank 0's exposure feature and
+        mlp_exposure tensors: the tracking loop steps them on every rank (Tracker.py:329-344) from gradients that were summed with float
+        atomics, and the mapper's no-parameter-broadcast scheme needs bit-identical replicas (2 708 floats once per frame)."""
         if self.dist is not None:
             self.dist.broadcast(cam7, src=0)
+            if xs is not None:
+                for t in (xs.feats, xs.W1, xs.b1, xs.W2, xs.b2):
+                    self.dist.broadcast(t, src=0)
         return cam7
 
     def _track_native(self, cam, depth_img, color_img, iters, window, intr, rnd_all, r2_map, hist, log, xs=None):

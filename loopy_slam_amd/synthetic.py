@@ -88,15 +88,71 @@ def room_color(points):
     return torch.stack([r, g, b], -1).clamp(0, 1).float()
 
 
-def render_frame(k, intr=TUM_INTR, holes=0.02, device='cpu', seed=1219, n_poses=200, motion='loop'):
+# 'furnished' scene (data.scene of the config; the accuracy runs): the plain room is one or two smooth walls per view - a camera can slide
+# along them and only a 3 cm relief of 2 m period and a texture of 3 m period say no, so pose tracking is ill-conditioned by construction.
+# Axis-aligned boxes along the walls (cabinets, shelves, a table: depth edges and faces in three orientations within every view), a finer
+# relief and a finer texture make it a scene a tracker can lock on to, like the furniture of a Replica room.  (centre, half size) in metres;
+# everything stays outside the camera's walk (an ellipse of 0.9 x 0.6 m around the room's centre).
+FURNITURE = (
+    ((2.60, 0.00, -0.90), (0.40, 0.90, 0.60)), ((2.70, -1.50, 0.30), (0.30, 0.35, 1.20)), ((2.55, 1.45, -0.50), (0.45, 0.40, 1.00)),
+    ((-2.60, 0.30, -0.80), (0.40, 1.10, 0.70)), ((-2.70, -1.40, 0.20), (0.30, 0.40, 1.30)), ((-2.65, 1.60, 0.60), (0.35, 0.30, 0.50)),
+    ((0.20, 1.70, -0.85), (1.00, 0.30, 0.65)), ((-1.50, 1.75, 0.40), (0.35, 0.25, 0.90)), ((1.60, 1.70, 0.55), (0.40, 0.30, 0.45)),
+    ((-0.30, -1.70, -0.90), (0.90, 0.30, 0.60)), ((1.50, -1.75, 0.30), (0.35, 0.25, 1.00)), ((-1.70, -1.70, 0.50), (0.30, 0.30, 0.60)),
+    ((1.75, 0.95, -1.20), (0.35, 0.35, 0.30)), ((-1.80, -0.90, -1.15), (0.30, 0.40, 0.35)),
+)
+
+
+def furnished_hit(rays_o, rays_d):
+    """(t [R], object [R]) of the furnished room: object -1 = the walls (room_depth with a second, finer relief), k >= 0 = box k of
+    FURNITURE (slab test per box, the nearest entry in front of the camera)."""
+    half = torch.tensor(ROOM, device=rays_o.device) / 2
+    inv = 1.0 / torch.where(rays_d.abs() < 1e-9, torch.full_like(rays_d, 1e-9), rays_d)
+    t = torch.maximum((half - rays_o) * inv, (-half - rays_o) * inv).min(dim=-1).values
+    hit = rays_o + rays_d * t[:, None]
+    relief = 0.03 * torch.sin(3.0 * hit[:, 0]) * torch.sin(2.5 * hit[:, 1] + 1.0) * torch.cos(2.0 * hit[:, 2]) + \
+        0.025 * torch.sin(11.0 * hit[:, 0] + 0.5) * torch.cos(9.0 * hit[:, 1]) * torch.sin(10.0 * hit[:, 2] + 0.3)
+    t = t * (1.0 + relief / t.clamp(min=0.5))
+    obj = torch.full_like(t, -1.0)
+    c = torch.tensor([b[0] for b in FURNITURE], device=rays_o.device)         # [K,3]
+    h = torch.tensor([b[1] for b in FURNITURE], device=rays_o.device)
+    lo = (c - h)[None] - rays_o[:, None, :]                                    # [R,K,3]
+    hi = (c + h)[None] - rays_o[:, None, :]
+    t1, t2 = lo * inv[:, None, :], hi * inv[:, None, :]
+    tn = torch.minimum(t1, t2).max(dim=-1).values                              # entry
+    tf = torch.maximum(t1, t2).min(dim=-1).values                              # exit
+    ok = (tn < tf) & (tn > 1e-3)
+    tn = torch.where(ok, tn, torch.full_like(tn, float('inf')))
+    tb, kb = tn.min(dim=1)
+    closer = tb < t
+    return torch.where(closer, tb, t).float(), torch.where(closer, kb.float(), obj)
+
+
+def furnished_color(points, obj):
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    base = room_color(points)
+    fine = torch.stack([0.5 + 0.5 * torch.sin(13.0 * x + 2.0 * y) * torch.cos(11.0 * z),
+                        0.5 + 0.5 * torch.sin(12.0 * y - 3.0 * z + 1.0),
+                        0.5 + 0.5 * torch.cos(14.0 * z + 9.0 * x) * torch.sin(10.0 * y + 0.4)], -1)
+    k = obj.clamp(min=0)
+    tint = torch.stack([0.5 + 0.5 * torch.sin(1.7 * k + 0.3), 0.5 + 0.5 * torch.sin(2.3 * k + 1.9), 0.5 + 0.5 * torch.sin(3.1 * k + 4.0)], -1)
+    wall = 0.65 * base + 0.35 * fine
+    box = 0.5 * tint + 0.2 * base + 0.3 * fine
+    return torch.where((obj >= 0)[:, None], box, wall).clamp(0, 1).float()
+
+
+def render_frame(k, intr=TUM_INTR, holes=0.02, device='cpu', seed=1219, n_poses=200, motion='loop', scene='plain'):
     """Synthetic RGB-D frame k: (depth [H,W], color [H,W,3], c2w [4,4])."""
     H, W = intr['H'], intr['W']
     c2w = sequence_pose(k, motion, n_poses, device)
     jj, ii = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
                             torch.arange(W, device=device, dtype=torch.float32), indexing='ij')
     ro, rd = pixel_rays(c2w, ii.reshape(-1), jj.reshape(-1), intr)
-    d = room_depth(ro, rd)
-    col = room_color(ro + rd * d[:, None])
+    if scene == 'furnished':
+        d, obj = furnished_hit(ro, rd)
+        col = furnished_color(ro + rd * d[:, None], obj)
+    else:
+        d = room_depth(ro, rd)
+        col = room_color(ro + rd * d[:, None])
     if holes > 0:
         g = torch.Generator(device='cpu').manual_seed(seed + k)
         m = (torch.rand(H * W, generator=g) < holes).to(device)

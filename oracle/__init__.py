@@ -4,7 +4,7 @@ This package is a from-scratch CPU restatement (torch-CPU fp32 + numpy) of the
 reference's per-frame neural-point render/optimise path.  It exists so that the
 HIP kernels in ``loopy_slam_amd/csrc`` can be checked for parity.
 
-Rules (enforced by tests/test_no_oracle_in_product.py):
+Rules (enforced by tests/test_product_hygiene.py):
   * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
     ``cpu_baseline`` leg may import anything from here;
   * the product package ``loopy_slam_amd`` never imports it and has no CPU

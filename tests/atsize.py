@@ -59,6 +59,70 @@ def contract_knn(pos, p, r2, got_idx=None):
     return d2, idx, cnt, n_re
 
 
+class ref64:
+    """Context: the oracle's graph evaluated in FLOAT64 ON THE FP32-ROUNDED INPUTS - the referee between two fp32 implementations.
+    Inside it, hotpath.sample_z / sample_points / fourier return the values an fp32 evaluation produces (sample depths, sample
+    positions p = o + d z with the rounded multiply and add, Fourier arguments (2 pi x) @ B in torch-CPU's fp32 order - the quantities
+    the kernels reproduce BIT FOR BIT) as float64 tensors whose derivative is the float64 graph's (value of the rounded quantity,
+    derivative of the exact one: x32.double() + (x64 - x64.detach())); everything downstream - interpolation weights, both MLPs, the
+    composite, the losses, autograd - runs in float64.  err(HIP, ref64) and err(fp32 oracle, ref64) are then both pure COMPUTATION
+    errors of the same function of the same numbers, and the bound "HIP is no farther from float64 than the fp32 oracle is" does not
+    depend on which SIMD kernels the host's torch picks."""
+
+    def __enter__(self):
+        self.saved = (H.sample_z, H.sample_points, H.fourier)
+        o_z, o_p, o_f = self.saved
+
+        def sample_z(gt_depth, *a):
+            z, far = o_z(gt_depth.detach().float(), *a)
+            return z.double(), far
+
+        def sample_points(ro, rd, z):
+            p32 = o_p(ro.detach().float(), rd.detach().float(), z.detach().float())
+            pg = o_p(ro.double(), rd.double(), z.double())
+            return p32.double() + (pg - pg.detach())
+
+        def fourier(x, B, concat):
+            y32 = (H.TWO_PI * x.detach().float()) @ B.detach().float()
+            yg = (H.TWO_PI * x.double()) @ B.double()
+            y = y32.double() + (yg - yg.detach())
+            return torch.cat((torch.sin(y), torch.cos(y)), dim=-1) if concat else torch.sin(y)
+        H.sample_z, H.sample_points, H.fourier = sample_z, sample_points, fourier
+        return self
+
+    def __exit__(self, *exc):
+        H.sample_z, H.sample_points, H.fourier = self.saved
+        return False
+
+
+def to64(x):
+    """float tensors / dicts of them / kNN triples -> float64 (the VALUES stay the fp32 ones)."""
+    if isinstance(x, dict):
+        return {k: to64(v) for k, v in x.items()}
+    if isinstance(x, tuple):
+        return tuple(to64(v) for v in x)
+    if torch.is_tensor(x):
+        return x.double() if x.is_floating_point() else x
+    if isinstance(x, np.ndarray):
+        return x.astype(np.float64) if x.dtype.kind == 'f' else x
+    return x
+
+
+def oracle_mapper64(rel_pos, stage, b, pos, geo, col, W, knn, w_color=0.1, exclude=None):
+    """oracle_mapper's gradients from the float64 referee (ref64)."""
+    with ref64():
+        return oracle_mapper(rel_pos, stage, to64(b), pos.double(), geo.double(), col.double(), to64(W), to64(tuple(knn)), w_color, True, exclude)
+
+
+def oracle_tracker64(rel_pos, b, cam, pos, geo, col, W, knn, w_color=0.5, exclude=None, var32=None, rays_value=None):
+    """var32: the fp32 evaluation's rendered variance.  The tracker's loss divides by sqrt(var) with var DETACHED (Tracker.py:171-175) - a
+    constant of the differentiated function, and as a difference of nearly equal numbers the one quantity whose fp32 value is far (1e-3
+    relative on flat rays) from its float64 value in EVERY fp32 implementation alike; the referee takes it as the rounded input it is."""
+    with ref64():
+        return oracle_tracker(rel_pos, to64(b), cam.double(), pos.double(), geo.double(), col.double(), to64(W), to64(tuple(knn)), w_color, exclude,
+                              var_const=None if var32 is None else var32.double(), rays_value=rays_value)
+
+
 def oracle_mapper(rel_pos, stage, b, pos, geo, col, W, knn, w_color=0.1, grads=True, exclude=None):
     """Oracle forward + mapper loss (+ autograd).  Returns dict(out=render dict, loss=(loss, geo, col, mask),
     g_geo, g_col, gW{name: grad}).  exclude: bool [R] rays left out of the loss that is differentiated (their loss
@@ -78,20 +142,27 @@ def oracle_mapper(rel_pos, stage, b, pos, geo, col, W, knn, w_color=0.1, grads=T
     return res
 
 
-def oracle_tracker(rel_pos, b, cam, pos, geo, col, W, knn, w_color=0.5, exclude=None):
+def oracle_tracker(rel_pos, b, cam, pos, geo, col, W, knn, w_color=0.5, exclude=None, var_const=None, rays_value=None):
     """Oracle tracking iteration: rays from the 7-vector pose, render in tracker mode, tracker loss, autograd to the pose
-    (and to the rays).  knn must be the list for these rays."""
+    (and to the rays).  knn must be the list for these rays.
+    rays_value = (rays_o, rays_d): the VALUES of the rays (the kernel's own fp32 rays) under the pose function's derivative - the
+    gradient with respect to a sample position goes through 2 pi B cos(2 pi p B) with |B| ~ 25-32, sums of 93 / 40 terms that cancel: a
+    one-ulp difference in a ray direction moves it by 1e-3 of its size, so two implementations are compared AT THE SAME RAYS."""
     cam_r = cam.clone().requires_grad_(True)
     ro, rd = H.rays_from_uv(b['i'], b['j'], H.quat_to_c2w(cam_r), *INTR)
+    if rays_value is not None:
+        ro = rays_value[0].to(ro.dtype) + (ro - ro.detach())
+        rd = rays_value[1].to(rd.dtype) + (rd - rd.detach())
     ro, rd = ro.contiguous(), rd.contiguous()
     ro.retain_grad(); rd.retain_grad()
     o = H.render_batch(ocfg(rel_pos), ro, rd, b['gt_depth'], pos, geo, col, W, 'color', tracker=True, knn=knn)
-    loss = H.tracker_loss(o['depth'], o['var'], o['color'], b['gt_depth'], b['gt_color'], w_color)
+    var = o['var'] if var_const is None else var_const
+    loss = H.tracker_loss(o['depth'], var, o['color'], b['gt_depth'], b['gt_color'], w_color)
     if exclude is None:
         loss[0].backward()
     else:           # the same loss with the excluded rays' terms removed (mask and mean are those of the full batch)
         m = loss[3] & ~exclude
-        tmp = torch.abs(b['gt_depth'] - o['depth']) / torch.sqrt(o['var'].detach() + 1e-10)
+        tmp = torch.abs(b['gt_depth'] - o['depth']) / torch.sqrt(var.detach() + 1e-10)
         (torch.clamp(tmp, min=0.0, max=1e3)[m].sum() + w_color * torch.abs(b['gt_color'] - o['color'])[m].sum()).backward()
     return dict(out=o, loss=loss, g_cam=cam_r.grad, g_rays_o=ro.grad, g_rays_d=rd.grad, rays_o=ro.detach(), rays_d=rd.detach())
 

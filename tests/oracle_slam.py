@@ -235,7 +235,7 @@ class OracleSLAM:
             before = cam_t.detach().clone()
             loss.backward()
             opt.step()
-            lv = float(loss)
+            lv = float(loss.detach())
             losses.append(lv)
             cand = before if sep else cam_v.detach().clone()        # separate_LR: the concatenation made BEFORE the step (Tracker.py:363-377)
             if lv < best_loss:
@@ -395,7 +395,7 @@ class OracleSLAM:
             loss, _, _, _ = H.mapper_loss(out['depth'], colr, out['valid_ray'], gd[keep], gc[keep], stage, m['w_color_loss'])
             loss.backward()
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         with torch.no_grad():
             self.geo[rows] = geo_p.detach()
             self.col[rows] = col_p.detach()

@@ -179,7 +179,7 @@ def run_forward(eng, name, g, stage, tracker=False, affine=None, color_logits=Fa
 def check_outputs(st, g, has_color=True):
     assert np.array_equal(st.valid_ray.cpu().numpy().astype(bool), g['valid_ray'])
     np.testing.assert_allclose(st.depth.cpu().numpy(), g['depth'], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(st.var.cpu().numpy(), g['var'], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(st.var.cpu().numpy(), g["var"], rtol=2e-4, atol=1e-9)       # the at-size bound (tests/test_parity_at_size.py: TOL_VAR)
     if has_color:
         np.testing.assert_allclose(st.color.cpu().numpy(), g['color'], rtol=1e-4, atol=2e-5)
 

@@ -33,7 +33,16 @@ TOL_VAR = 2e-4          # variance = sum w (z - depth)^2: a difference of nearly
 # test depend on the box it ran on; a real defect shows at 1e-3 and above.  The measured values of every run are in
 # gpurun_out/parity_at_size.json.
 TOL_GRAD = 1e-4         # every gradient tensor, max |a - b| <= TOL_GRAD * max |b|
-TOL_GRAD_EL = 3e-2      # and element-wise: |a - b| <= TOL_GRAD_EL * (|b| + 1e-3 max|b|)
+TOL_GRAD_EL = 3e-2      # and element-wise: |a - b| <= TOL_GRAD_EL * (|b| + 1e-3 max|b|)  (only where no float64 referee is evaluated)
+# Round 4: the FLOAT64 REFEREE (atsize.ref64: the oracle's graph in float64 on the fp32-rounded sample depths, positions and Fourier
+# arguments - the quantities the kernels reproduce bit for bit - and, in tracker mode, at the kernel's own rays).  Against it the fp32 CPU
+# oracle itself sits at 2-3e-6 max-norm on every gradient tensor, whatever SIMD kernels the host's torch runs (the 7e-5 / 1.7e-2 of round 3
+# was NOT oracle noise: the oracle's rays differed from the kernel's by an ulp, and d/dp through 2 pi B cos(2 pi p B) amplifies that a
+# thousandfold).  Gradient tensors are held to: HIP is no farther from float64 than 1.5 x the fp32 oracle is - or than an absolute floor
+# that a 0.5 % per-element regression does not pass.
+REF_FACTOR = 1.5
+REF_FLOOR_MAX = 2e-5    # max |a - r64| / max |r64|
+REF_FLOOR_EL = 4e-3     # max |a - r64| / (|r64| + 1e-3 max |r64|)
 _REPORT = {}
 
 
@@ -77,8 +86,22 @@ def _check_forward(st, o, case, gt_depth):
     np.testing.assert_allclose(st.var.cpu().numpy(), o['var'].detach().numpy(), rtol=TOL_VAR, atol=1e-9)
 
 
-def _check_grad(name, got, ref, case, skip_rows=None, tol=None, tol_el=None):
+def _check_grad(name, got, ref, case, skip_rows=None, tol=None, tol_el=None, ref64=None):
     got, ref = torch.as_tensor(got), torch.as_tensor(ref)
+    if ref64 is not None:
+        # the referee decides: both fp32 results against the float64 evaluation of the same graph on the same rounded inputs
+        r64 = torch.as_tensor(ref64).double().reshape(ref.shape)
+        s = float(r64.abs().max()) + 1e-300
+        d_hip, d_o32 = (got.double() - r64).abs(), (ref.double() - r64).abs()
+        den = r64.abs() + 1e-3 * s
+        e_hip, e_o32 = float(d_hip.max()) / s, float(d_o32.max()) / s
+        el_hip, el_o32 = float((d_hip / den).max()), float((d_o32 / den).max())
+        rms_hip, rms_o32 = float(d_hip.pow(2).mean().sqrt()) / s, float(d_o32.pow(2).mean().sqrt()) / s
+        _record(case, **{f'g[{name}]_hip_vs_f64_max': e_hip, f'g[{name}]_o32_vs_f64_max': e_o32, f'g[{name}]_hip_vs_f64_el': el_hip,
+                         f'g[{name}]_o32_vs_f64_el': el_o32, f'g[{name}]_hip_vs_f64_rms': rms_hip, f'g[{name}]_o32_vs_f64_rms': rms_o32})
+        assert e_hip <= max(REF_FACTOR * e_o32, REF_FLOOR_MAX), (case, name, 'max-norm vs float64', e_hip, e_o32)
+        assert el_hip <= max(REF_FACTOR * el_o32, REF_FLOOR_EL), (case, name, 'element-wise vs float64', el_hip, el_o32)
+        tol_el = float('inf')               # (the fixed element-wise bound against the fp32 oracle is what the referee replaces)
     if skip_rows is not None and skip_rows.numel():
         keep = torch.ones(ref.shape[0], dtype=torch.bool)
         keep[skip_rows] = False
@@ -139,9 +162,10 @@ def test_mapper_iteration_vs_oracle_at_bench_size(model, R, stage, unit, geo_dec
     core.render_backward(eng, st, gs, d_depth, d_color)
     torch.cuda.synchronize()
     r = A.oracle_mapper(rel, stage, b, pos, geo, col, W, kn, exclude=bp)
-    _check_grad('geo_feats', gs.g_geo.cpu(), r['g_geo'], case)
+    r64 = A.oracle_mapper64(rel, stage, b, pos, geo, col, W, kn, exclude=bp)
+    _check_grad('geo_feats', gs.g_geo.cpu(), r['g_geo'], case, ref64=r64['g_geo'])
     if stage == 'color':
-        _check_grad('col_feats', gs.g_col.cpu(), r['g_col'], case)
+        _check_grad('col_feats', gs.g_col.cpu(), r['g_col'], case, ref64=r64['g_col'])
     gW = dec.unpack(gs.g_weights)
     n = 0
     for name, ref in r['gW'].items():
@@ -149,7 +173,7 @@ def test_mapper_iteration_vs_oracle_at_bench_size(model, R, stage, unit, geo_dec
             continue                          # frozen in every reference config (mapping.fix_geo_decoder, Mapper.py:537-541)
         if name not in gW or (stage == 'geometry' and not name.startswith('geo_decoder.')):
             continue
-        _check_grad(name, gW[name].reshape(ref.shape), ref, case)
+        _check_grad(name, gW[name].reshape(ref.shape), ref, case, ref64=r64['gW'][name])
         n += 1
     assert n >= (1 if stage == 'geometry' else (27 if rel else 22)) + (22 if geo_dec else 0)
 
@@ -207,13 +231,14 @@ def test_ba_mode_backward_at_bench_size(model, R, unit):
     kn = _check_knn_and_z(st, b, pos, case)
     names = [k for k in W if k != 'color_decoder.embedder._B']
 
-    def oracle(exclude=None, grads=True):
-        Wr = {k: v.clone().requires_grad_(grads and k in names) for k, v in W.items()}
-        geo_r, col_r = geo.clone().requires_grad_(grads), col.clone().requires_grad_(grads)
-        ro_r, rd_r = b['rays_o'].clone().requires_grad_(grads), b['rays_d'].clone().requires_grad_(grads)
-        o = H.render_batch(A.ocfg(rel), ro_r, rd_r, b['gt_depth'], pos, geo_r, col_r, Wr, 'color', tracker=True, knn=kn)
+    def oracle(exclude=None, grads=True, f64=False):
+        c = A.to64 if f64 else (lambda x: x)
+        Wr = {k: c(v).clone().requires_grad_(grads and k in names) for k, v in W.items()}
+        geo_r, col_r = c(geo).clone().requires_grad_(grads), c(col).clone().requires_grad_(grads)
+        ro_r, rd_r = c(b['rays_o']).clone().requires_grad_(grads), c(b['rays_d']).clone().requires_grad_(grads)
+        o = H.render_batch(A.ocfg(rel), ro_r, rd_r, c(b['gt_depth']), c(pos), geo_r, col_r, Wr, 'color', tracker=True, knn=c(tuple(kn)))
         valid = o['valid_ray'] if exclude is None else o['valid_ray'] & ~exclude
-        loss = H.mapper_loss(o['depth'], o['color'], valid, b['gt_depth'], b['gt_color'], 'color', 0.1)
+        loss = H.mapper_loss(o['depth'], o['color'], valid, c(b['gt_depth']), c(b['gt_color']), 'color', 0.1)
         if grads:
             loss[0].backward()
         return o, loss, geo_r.grad, col_r.grad, {k: Wr[k].grad for k in names if Wr[k].grad is not None}, ro_r.grad, rd_r.grad
@@ -235,21 +260,23 @@ def test_ba_mode_backward_at_bench_size(model, R, unit):
     core.render_backward(eng, st, gs, d_depth, d_color)
     torch.cuda.synchronize()
     _, _, g_geo, g_col, gWo, g_ro, g_rd = oracle(exclude=bp)
-    _check_grad('geo_feats', gs.g_geo.cpu(), g_geo, case)
-    _check_grad('col_feats', gs.g_col.cpu(), g_col, case)
+    with A.ref64():
+        _, _, g_geo64, g_col64, gWo64, g_ro64, g_rd64 = oracle(exclude=bp, f64=True)
+    _check_grad('geo_feats', gs.g_geo.cpu(), g_geo, case, ref64=g_geo64)
+    _check_grad('col_feats', gs.g_col.cpu(), g_col, case, ref64=g_col64)
     # The ray gradients of THIS loss (d depth = +-1 on every ray) are sums over 40 neighbour terms per ray that cancel to a few per cent of
     # their size: measured 0.9-1.4e-4 max-norm / 2.2-3.2e-2 element-wise, IDENTICAL for bf16 and fp16 pieces (so not a piece effect), while the
     # fp32 oracle's own distance to its float64 evaluation on these two tensors is 0.8-1.2e-2 (tools/probe/oracle_noise_ba.py).  Twice the
     # common bars would hold on the boxes seen so far; three times, because the oracle's noise moves with the HOST's torch kernels (the note at
     # TOL_GRAD) - feature rows and weights of the same backward stay on the common bars.
-    _check_grad('rays_o', gs.g_rays_o.cpu(), g_ro, case, tol=3 * TOL_GRAD, tol_el=3 * TOL_GRAD_EL)
-    _check_grad('rays_d', gs.g_rays_d.cpu(), g_rd, case, tol=3 * TOL_GRAD, tol_el=3 * TOL_GRAD_EL)
+    _check_grad('rays_o', gs.g_rays_o.cpu(), g_ro, case, tol=3 * TOL_GRAD, ref64=g_ro64)
+    _check_grad('rays_d', gs.g_rays_d.cpu(), g_rd, case, tol=3 * TOL_GRAD, ref64=g_rd64)
     gW = dec.unpack(gs.g_weights)
     n = 0
     for name, ref in gWo.items():
         if (name.startswith('geo_decoder.') and name != 'geo_decoder.embedder._B') or name not in gW:
             continue
-        _check_grad(name, gW[name].reshape(ref.shape), ref, case)
+        _check_grad(name, gW[name].reshape(ref.shape), ref, case, ref64=gWo64[name])
         n += 1
     assert n >= (27 if rel else 22)
 
@@ -303,10 +330,12 @@ def test_tracker_iteration_vs_oracle_at_bench_size(model, R, unit):
     g_cam = eng.zeros(7)
     optim.pose_bwd(eng, dcam, pi, pj, A.INTR, gs.g_rays_o, gs.g_rays_d, g_cam)
     torch.cuda.synchronize()
-    r = A.oracle_tracker(rel, b, cam, pos, geo, col, W, kn, exclude=bp)
-    _check_grad('rays_o', gs.g_rays_o.cpu(), r['g_rays_o'], case)
-    _check_grad('rays_d', gs.g_rays_d.cpu(), r['g_rays_d'], case)
-    _check_grad('cam', g_cam.cpu(), r['g_cam'], case)
+    kr = (ro.cpu(), rd.cpu())               # every evaluation AT THE KERNEL'S RAYS (atsize.oracle_tracker: rays_value)
+    r = A.oracle_tracker(rel, b, cam, pos, geo, col, W, kn, exclude=bp, rays_value=kr)
+    r64 = A.oracle_tracker64(rel, b, cam, pos, geo, col, W, kn, exclude=bp, var32=r['out']['var'].detach(), rays_value=kr)
+    _check_grad('rays_o', gs.g_rays_o.cpu(), r['g_rays_o'], case, ref64=r64['g_rays_o'])
+    _check_grad('rays_d', gs.g_rays_d.cpu(), r['g_rays_d'], case, ref64=r64['g_rays_d'])
+    _check_grad('cam', g_cam.cpu(), r['g_cam'], case, ref64=r64['g_cam'])
 
 
 def I_H():

@@ -128,14 +128,17 @@ def test_mapper_iteration_dynamic_radius_holes_exposure(model, stage):
                             extra_flags=_ffi.FLAG_ZERO_ABSENT, mapper_loss=(dv['gc'], 0.1, d_depth, d_color, out4))
     torch.cuda.synchronize()
     kn = _knn_of_kept(st, b, pos, m, case)
-    ro, rd, gd, gc, r2k, fk = b['rays_o'][keep], b['rays_d'][keep], b['gt_depth'][keep], b['gt_color'][keep], b['r2'][keep], b['fid'][keep].long()
+    ro_, rd_, gd_, gc_, r2k, fk = b['rays_o'][keep], b['rays_d'][keep], b['gt_depth'][keep], b['gt_color'][keep], b['r2'][keep], b['fid'][keep].long()
+    gd, gc = gd_, gc_
 
-    def oracle(exclude=None, grads=True):
+    def oracle(exclude=None, grads=True, f64=False):
+        c = A.to64 if f64 else (lambda x: x)             # f64: the float64 referee (inside atsize.ref64)
         names = [k for k in W if k != 'color_decoder.embedder._B']
-        Wr = {k: v.clone().requires_grad_(grads and k in names) for k, v in W.items()}
-        geo_r, col_r = geo.clone().requires_grad_(grads), col.clone().requires_grad_(grads)
-        fo = [f.clone().requires_grad_(grads) for f in feats0] if m['exposure'] else None
-        o = H.render_batch(_ocfg(m), ro, rd, gd, pos, geo_r, col_r, Wr, stage, r2_ray=r2k, knn=kn, color_sigmoid=not m['exposure'])
+        Wr = {k: c(v).clone().requires_grad_(grads and k in names) for k, v in W.items()}
+        geo_r, col_r = c(geo).clone().requires_grad_(grads), c(col).clone().requires_grad_(grads)
+        fo = [c(f).clone().requires_grad_(grads) for f in feats0] if m['exposure'] else None
+        ro, rd, gd, gc = c(ro_), c(rd_), c(gd_), c(gc_)
+        o = H.render_batch(_ocfg(m), ro, rd, gd, c(pos), geo_r, col_r, Wr, stage, r2_ray=r2k, knn=c(tuple(kn)), color_sigmoid=not m['exposure'])
         color = o['color']
         if m['exposure']:       # Mapper.py:697-715: the keyframe's affine on the composited logits, then the sigmoid
             aff = torch.stack([H.exposure_affine(Wr, f) for f in fo])
@@ -182,9 +185,11 @@ def test_mapper_iteration_dynamic_radius_holes_exposure(model, stage):
         xs.backward(xs.g_aff)
     torch.cuda.synchronize()
     r = oracle(exclude=bp)
-    _check_grad('geo_feats', gs.g_geo.cpu(), r['g_geo'], case)
+    with A.ref64():
+        q = oracle(exclude=bp, f64=True)
+    _check_grad('geo_feats', gs.g_geo.cpu(), r['g_geo'], case, ref64=q['g_geo'])
     if stage == 'color':
-        _check_grad('col_feats', gs.g_col.cpu(), r['g_col'], case)
+        _check_grad('col_feats', gs.g_col.cpu(), r['g_col'], case, ref64=q['g_col'])
     gW = dec.unpack(gs.g_weights)
     n = 0
     for name, ref in r['gW'].items():
@@ -192,16 +197,17 @@ def test_mapper_iteration_dynamic_radius_holes_exposure(model, stage):
             continue
         if name not in gW or (stage == 'geometry' and not name.startswith('geo_decoder.')):
             continue
-        _check_grad(name, gW[name].reshape(ref.shape), ref, case)
+        _check_grad(name, gW[name].reshape(ref.shape), ref, case, ref64=q['gW'][name])
         n += 1
     assert n >= (1 if stage == 'geometry' else 22)
     if xs is not None:
         g = xs.g.cpu()
-        _check_grad('mlp_exposure.linear1.weight', g[0:1024].reshape(128, 8), r['gW']['color_decoder.mlp_exposure.linear1.weight'], case)
-        _check_grad('mlp_exposure.linear1.bias', g[1024:1152], r['gW']['color_decoder.mlp_exposure.linear1.bias'], case)
-        _check_grad('mlp_exposure.linear2.weight', g[1152:2688].reshape(12, 128), r['gW']['color_decoder.mlp_exposure.linear2.weight'], case)
-        _check_grad('mlp_exposure.linear2.bias', g[2688:2700], r['gW']['color_decoder.mlp_exposure.linear2.bias'], case)
-        _check_grad('exposure_feats', g[2700:2700 + 8 * F].reshape(F, 8), torch.stack(r['g_feats']), case)
+        X = 'color_decoder.mlp_exposure.'
+        _check_grad('mlp_exposure.linear1.weight', g[0:1024].reshape(128, 8), r['gW'][X + 'linear1.weight'], case, ref64=q['gW'][X + 'linear1.weight'])
+        _check_grad('mlp_exposure.linear1.bias', g[1024:1152], r['gW'][X + 'linear1.bias'], case, ref64=q['gW'][X + 'linear1.bias'])
+        _check_grad('mlp_exposure.linear2.weight', g[1152:2688].reshape(12, 128), r['gW'][X + 'linear2.weight'], case, ref64=q['gW'][X + 'linear2.weight'])
+        _check_grad('mlp_exposure.linear2.bias', g[2688:2700], r['gW'][X + 'linear2.bias'], case, ref64=q['gW'][X + 'linear2.bias'])
+        _check_grad('exposure_feats', g[2700:2700 + 8 * F].reshape(F, 8), torch.stack(r['g_feats']), case, ref64=torch.stack(q['g_feats']))
 
 
 @pytest.mark.parametrize('model', ('tum', 'scannet'))
@@ -238,20 +244,27 @@ def test_tracker_iteration_dynamic_radius_holes_exposure(model):
     bo = dict(b)
     bo['rays_o'], bo['rays_d'] = ro.cpu(), rd.cpu()
     kn = _knn_of_kept(st, bo, pos, m, case)
-    ik, jk, gd, gc, r2k = b['i'][keep], b['j'][keep], b['gt_depth'][keep], b['gt_color'][keep], b['r2'][keep]
+    ik, jk, gd_, gc_, r2k = b['i'][keep], b['j'][keep], b['gt_depth'][keep], b['gt_color'][keep], b['r2'][keep]
+    gd, gc = gd_, gc_
 
-    def oracle(exclude=None, grads=True):
-        cam_r = cam.clone().requires_grad_(grads)
-        Wr = {k: (v.clone().requires_grad_(grads) if 'mlp_exposure' in k else v) for k, v in W.items()}
-        fo = feat0.clone().requires_grad_(grads) if m['exposure'] else None
-        ro_o, rd_o = H.rays_from_uv(ik, jk, H.quat_to_c2w(cam_r), *A.INTR)
-        o = H.render_batch(_ocfg(m), ro_o, rd_o, gd, pos, geo, col, Wr, 'color', tracker=True, r2_ray=r2k, knn=kn,
+    kro, krd = ro.cpu()[keep], rd.cpu()[keep]            # every evaluation AT THE KERNEL'S RAYS (atsize.oracle_tracker: rays_value)
+
+    def oracle(exclude=None, grads=True, f64=False, var32=None):
+        c = A.to64 if f64 else (lambda x: x)             # f64: the float64 referee (inside atsize.ref64), var32: atsize.oracle_tracker64
+        cam_r = c(cam).clone().requires_grad_(grads)
+        Wr = {k: (c(v).clone().requires_grad_(grads) if 'mlp_exposure' in k else c(v)) for k, v in W.items()}
+        fo = c(feat0).clone().requires_grad_(grads) if m['exposure'] else None
+        gd, gc = c(gd_), c(gc_)
+        ro_o, rd_o = H.rays_from_uv(c(ik), c(jk), H.quat_to_c2w(cam_r), *A.INTR)
+        ro_o, rd_o = c(kro) + (ro_o - ro_o.detach()), c(krd) + (rd_o - rd_o.detach())
+        o = H.render_batch(_ocfg(m), ro_o, rd_o, gd, c(pos), c(geo), c(col), Wr, 'color', tracker=True, r2_ray=r2k, knn=c(tuple(kn)),
                            affine=H.exposure_affine(Wr, fo) if fo is not None else None)
-        loss = H.tracker_loss(o['depth'], o['var'], o['color'], gd, gc, 0.5)
+        var = o['var'] if var32 is None else c(var32)
+        loss = H.tracker_loss(o['depth'], var, o['color'], gd, gc, 0.5)
         res = dict(out=o, loss=loss)
         if grads:
             mk = loss[3] if exclude is None else (loss[3] & ~exclude)
-            tmp = torch.abs(gd - o['depth']) / torch.sqrt(o['var'].detach() + 1e-10)
+            tmp = torch.abs(gd - o['depth']) / torch.sqrt(var.detach() + 1e-10)
             (torch.clamp(tmp, min=0.0, max=1e3)[mk].sum() + 0.5 * torch.abs(gc - o['color'])[mk].sum()).backward()
             res.update(g_cam=cam_r.grad, gW={k: v.grad for k, v in Wr.items() if 'mlp_exposure' in k}, g_feat=fo.grad if fo is not None else None)
         return res
@@ -279,14 +292,17 @@ def test_tracker_iteration_dynamic_radius_holes_exposure(model):
         xs.backward(gs.g_affine)
     torch.cuda.synchronize()
     r = oracle(exclude=bp)
-    _check_grad('cam', g_cam.cpu(), r['g_cam'], case)
+    with A.ref64():
+        q = oracle(exclude=bp, f64=True, var32=r['out']['var'].detach())
+    _check_grad('cam', g_cam.cpu(), r['g_cam'], case, ref64=q['g_cam'])
     assert float(gs.g_rays_d.cpu()[~keep].abs().max()) == 0.0                           # absent rays carry no gradient
     if xs is not None:
         g = xs.g.cpu()
-        _check_grad('mlp_exposure.linear1.weight', g[0:1024].reshape(128, 8), r['gW']['color_decoder.mlp_exposure.linear1.weight'], case)
-        _check_grad('mlp_exposure.linear2.weight', g[1152:2688].reshape(12, 128), r['gW']['color_decoder.mlp_exposure.linear2.weight'], case)
-        _check_grad('mlp_exposure.linear2.bias', g[2688:2700], r['gW']['color_decoder.mlp_exposure.linear2.bias'], case)
-        _check_grad('exposure_feat', g[2700:2708], r['g_feat'], case)
+        X = 'color_decoder.mlp_exposure.'
+        _check_grad('mlp_exposure.linear1.weight', g[0:1024].reshape(128, 8), r['gW'][X + 'linear1.weight'], case, ref64=q['gW'][X + 'linear1.weight'])
+        _check_grad('mlp_exposure.linear2.weight', g[1152:2688].reshape(12, 128), r['gW'][X + 'linear2.weight'], case, ref64=q['gW'][X + 'linear2.weight'])
+        _check_grad('mlp_exposure.linear2.bias', g[2688:2700], r['gW'][X + 'linear2.bias'], case, ref64=q['gW'][X + 'linear2.bias'])
+        _check_grad('exposure_feat', g[2700:2708], r['g_feat'], case, ref64=q['g_feat'])
 
 
 def test_forward_with_half_tables_at_5m_points():

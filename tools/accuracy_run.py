@@ -29,11 +29,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def make_cfg(path, frames, rays, iters_scale=1.0, iters_first=None, seed=None, color_refine=None):
+def make_cfg(path, frames, rays, iters_scale=1.0, iters_first=None, seed=None, color_refine=None, scene='furnished'):
     from loopy_slam_amd import config
     cfg = copy.deepcopy(config.load_config(path, os.path.join(ROOT, 'configs/point_slam.yaml')))
     cfg['data']['n_frames'] = frames
     cfg['data']['motion'] = 'handheld'
+    cfg['data']['scene'] = scene
     if rays:
         cfg['tracking']['pixels'] = rays
         cfg['mapping']['pixels'] = rays
@@ -147,15 +148,16 @@ def main():
     ap.add_argument('--iters-first', type=int, default=None)
     ap.add_argument('--seed', type=int, default=None)
     ap.add_argument('--color-refine', type=int, default=None)
+    ap.add_argument('--scene', default='furnished', choices=('plain', 'furnished'))
     ap.add_argument('--threads', type=int, default=max(1, (os.cpu_count() or 2) // 2))
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
-    cfg = make_cfg(a.config, a.frames, a.rays, a.iters_scale, a.iters_first, a.seed, a.color_refine)
+    cfg = make_cfg(a.config, a.frames, a.rays, a.iters_scale, a.iters_first, a.seed, a.color_refine, a.scene)
     res = run_oracle(cfg, a.threads) if a.pipeline == 'oracle' else run_product(cfg, emu=a.pipeline == 'emu')
     res['config'] = {'file': a.config, 'frames': a.frames, 'rays_per_iteration': a.rays, 'iters_scale': a.iters_scale,
                      'tracking_iters': cfg['tracking']['iters'], 'mapping_iters': cfg['mapping']['iters'],
                      'iters_first': cfg['mapping']['iters_first'], 'seed': cfg.get('setup_seed', 1219),
-                     'color_refine': bool(cfg['mapping'].get('color_refine', False)), 'motion': 'handheld'}
+                     'color_refine': bool(cfg['mapping'].get('color_refine', False)), 'motion': 'handheld', 'scene': a.scene}
     brief = {k: v for k, v in res.items() if k not in ('est_c2w', 'map_log', 'track_loss_first_best')}
     print(json.dumps(brief))
     if a.out:
