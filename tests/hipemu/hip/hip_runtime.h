@@ -70,6 +70,7 @@ uint64_t wave_ballot(bool p);
 void wave_mfma32x32x2(float a, float b, const float* c, float* d);
 void wave_mfma16x16x4(float a, float b, const float* c, float* d);
 void wave_mfma32x32x16_bf16(const float* a8, const float* b8, const float* c, float* d);
+void wave_mfma16x16x32(const float* a8, const float* b8, const float* c, float* d);
 int lane_id();
 }  // namespace hipemu
 
@@ -167,6 +168,29 @@ static inline f32x16_emu __builtin_amdgcn_mfma_f32_32x32x16_f16(f16x8_emu a, f16
     hipemu::wave_mfma32x32x16_bf16(fa, fb, ci, di);
     f32x16_emu d;
     for (int r = 0; r < 16; ++r) d[r] = di[r];
+    return d;
+}
+static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x32_f16(f16x8_emu a, f16x8_emu b, f32x4_emu c, int, int, int) {
+    float fa[8], fb[8], ci[4], di[4];
+    for (int e = 0; e < 8; ++e) { fa[e] = (float)a[e]; fb[e] = (float)b[e]; }
+    for (int r = 0; r < 4; ++r) ci[r] = c[r];
+    hipemu::wave_mfma16x16x32(fa, fb, ci, di);
+    f32x4_emu d;
+    for (int r = 0; r < 4; ++r) d[r] = di[r];
+    return d;
+}
+static inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf16x8_emu a, bf16x8_emu b, f32x4_emu c, int, int, int) {
+    unsigned short ua[8], ub[8];
+    std::memcpy(ua, &a, 16); std::memcpy(ub, &b, 16);
+    float fa[8], fb[8], ci[4], di[4];
+    for (int e = 0; e < 8; ++e) {
+        unsigned x = (unsigned)ua[e] << 16, y = (unsigned)ub[e] << 16;
+        std::memcpy(&fa[e], &x, 4); std::memcpy(&fb[e], &y, 4);
+    }
+    for (int r = 0; r < 4; ++r) ci[r] = c[r];
+    hipemu::wave_mfma16x16x32(fa, fb, ci, di);
+    f32x4_emu d;
+    for (int r = 0; r < 4; ++r) d[r] = di[r];
     return d;
 }
 typedef __fp16 f16x2_emu __attribute__((ext_vector_type(2)));

