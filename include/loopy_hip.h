@@ -508,6 +508,10 @@ int lk_profile_end(char* buf, int cap);
  * registers and LDS of the loaded code objects (hipOccupancyMaxActiveBlocksPerMultiprocessor): out[0..4] = k_decode_fwd,
  * k_decode_bwd (mapper form), k_relpos_fwd, k_relpos_bwd_fused, k_wgrad.  Needs a device. */
 int lk_debug_occupancy(int32_t out[5]);
+/* Debug / A-B switch: the decoder forward in its 16 x 16 x 32 matrix-instruction form (eight waves per 32-sample colour tile, one wave per
+ * sixteen geometry samples; k_decode_fwd16) instead of the default 32 x 32 x 16 form.  Same results to fp32 rounding, measured slower on
+ * MI355X at the reference's batch sizes; environment LK_C16=1 sets the initial value. */
+int lk_debug_set_c16(int on);
 
 #ifdef __cplusplus
 }

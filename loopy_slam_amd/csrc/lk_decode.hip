@@ -569,6 +569,19 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
 //   geometry    : one wave per SIXTEEN samples, two accumulators (the two 16-unit blocks); the chain from one layer to the next goes
 //                 through a 2-KB piece buffer of the wave's own (the lane that holds a value of the accumulator layout is not the lane that feeds
 //                 it to the next product), ordered by a wave barrier, no workgroup barrier.
+#ifdef LK_PROBE_CLK
+__device__ unsigned long long lk_dbg_clk16[8 * 8 * 32];         // colour: [tile < 8][wave][stamp]
+__device__ unsigned long long lk_dbg_clkg[64 * 16];             // geometry: [16-sample tile < 64][stamp]
+#define LK_CLK16(i) do { __builtin_amdgcn_sched_barrier(0); if (tile < 8 && lane == 0) lk_dbg_clk16[(tile * 8 + w) * 32 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LK_CLKG(i) do { __builtin_amdgcn_sched_barrier(0); if (tile16 < 64 && lane == 0) lk_dbg_clkg[tile16 * 16 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int lk_debug_clk16_read(unsigned long long* col, unsigned long long* geo) {
+    int e = (int)hipMemcpyFromSymbol(col, HIP_SYMBOL(lk_dbg_clk16), sizeof(lk_dbg_clk16));
+    return e ? e : (int)hipMemcpyFromSymbol(geo, HIP_SYMBOL(lk_dbg_clkg), sizeof(lk_dbg_clkg));
+}
+#else
+#define LK_CLK16(i)
+#define LK_CLKG(i)
+#endif
 struct DecSample16 { int sample[2], sp[2]; bool live[2]; float a0[2], a1[2], a2[2]; };
 __device__ __forceinline__ void dec_sample16_fill(const LkDecodeArgs& a, int sample, int k, DecSample16& d) {
     d.sample[k] = sample;
@@ -596,6 +609,7 @@ __device__ __forceinline__ f32x4 c16_bias4(const float* __restrict__ v, int unit
 
 __device__ __forceinline__ void decode_geo_wave16(const LkDecodeArgs& a, int tile16, int lane, u32x4* __restrict__ s_g /* [2][2 * 64] of this wave */) {
     const int q4 = lane >> 4;
+    LK_CLKG(0);
     DecSample16 d;
     dec_sample16_fill(a, tile16 * 16 + (lane & 15), 0, d);
     const bool live = d.live[0];
@@ -655,11 +669,12 @@ __device__ __forceinline__ void decode_geo_wave16(const LkDecodeArgs& a, int til
 #pragma unroll
         for (int ub = 0; ub < 2; ++ub) acc[ub] = lk_mma3h16(lk_fragh_load16(frag, 1, G0, ub, lane), b, acc[ub]);
     };
-    start(G_B0); embed(FB + FM0_FWDH); finish(0, FB + FM5_FWDH, true);
-    start(G_B1); hidden(FB + FM1_FWDH, 0, 0); finish(1, FB + FM6_FWDH, true);
-    start(G_B2); hidden(FB + FM2_FWDH, 0, 1); finish(2, FB + FM7_FWDH, true);
-    start(G_B3); embed(FB + FM3_FWDH); hidden(FB + FM3_FWDH, 6, 2); finish(3, FB + FM8_FWDH, true);
-    start(G_B4); hidden(FB + FM4_FWDH, 0, 3); finish(4, FB + FM9_FWDH, false);
+    LK_CLKG(1);
+    start(G_B0); embed(FB + FM0_FWDH); LK_CLKG(2); finish(0, FB + FM5_FWDH, true); LK_CLKG(3);
+    start(G_B1); hidden(FB + FM1_FWDH, 0, 0); LK_CLKG(4); finish(1, FB + FM6_FWDH, true); LK_CLKG(5);
+    start(G_B2); hidden(FB + FM2_FWDH, 0, 1); LK_CLKG(6); finish(2, FB + FM7_FWDH, true); LK_CLKG(7);
+    start(G_B3); embed(FB + FM3_FWDH); hidden(FB + FM3_FWDH, 6, 2); LK_CLKG(8); finish(3, FB + FM8_FWDH, true); LK_CLKG(9);
+    start(G_B4); hidden(FB + FM4_FWDH, 0, 3); LK_CLKG(10); finish(4, FB + FM9_FWDH, false); LK_CLKG(11);
     float part = 0.0f;
 #pragma unroll
     for (int ub = 0; ub < 2; ++ub) {
@@ -675,6 +690,7 @@ __device__ __forceinline__ void decode_geo_wave16(const LkDecodeArgs& a, int til
 // LDS of a colour workgroup: s_x [2][16 * 64] activation pieces (double-buffered), s_e [8 * 64] embedding pieces, s_o [8][96], s_bias [10][128]
 __device__ __forceinline__ void decode_col_wg16(const LkDecodeArgs& a, int tile, int w, int lane,
                                                 u32x4 (*s_x)[16 * 64], u32x4* __restrict__ s_e, float (*s_o)[3 * 32], float (*s_bias)[128]) {
+    LK_CLK16(0);
     {
         const int t = (int)threadIdx.x;
         const int b_off[5] = {C_B0, C_B1, C_B2, C_B3, C_B4};
@@ -769,32 +785,48 @@ __device__ __forceinline__ void decode_col_wg16(const LkDecodeArgs& a, int tile,
             for (int sh = 0; sh < 2; ++sh) lk_c16_park(s_x[buf], w, sh, lk_split4h(acc[sh][0], acc[sh][1], acc[sh][2], acc[sh][3]), lane);
         }
     };
+    LK_CLK16(1);
     un = lk_fragh_load16(FB + FM15_FWDH, 4, 0, w, lane);
     start(0); embed(FB + FM10_FWDH);
     prefetch_hidden(FB + FM11_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
+    LK_CLK16(2);
     finish(0, 0);
+    LK_CLK16(3);
     __syncthreads();
+    LK_CLK16(4);
     un = lk_fragh_load16(FB + FM16_FWDH, 4, 0, w, lane);
     start(1); hidden(FB + FM11_FWDH, 0, 0);
     prefetch_hidden(FB + FM12_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
+    LK_CLK16(5);
     finish(1, 1);
+    LK_CLK16(6);
     __syncthreads();
+    LK_CLK16(7);
     un = lk_fragh_load16(FB + FM17_FWDH, 4, 0, w, lane);
     start(2); hidden(FB + FM12_FWDH, 0, 1);
     prefetch_hidden(FB + FM13_FWDH, 3);
     __builtin_amdgcn_sched_barrier(0);
+    LK_CLK16(8);
     finish(2, 0);
+    LK_CLK16(9);
     __syncthreads();
+    LK_CLK16(10);
     un = lk_fragh_load16(FB + FM18_FWDH, 4, 0, w, lane);
     start(3); embed(FB + FM13_FWDH); hidden(FB + FM13_FWDH, 3, 0);
     prefetch_hidden(FB + FM14_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
+    LK_CLK16(11);
     finish(3, 1);
+    LK_CLK16(12);
     __syncthreads();
+    LK_CLK16(13);
     un = lk_fragh_load16(FB + FM19_FWDH, 4, 0, w, lane);
-    start(4); hidden(FB + FM14_FWDH, 0, 1); finish(4, -1);
+    start(4); hidden(FB + FM14_FWDH, 0, 1);
+    LK_CLK16(14);
+    finish(4, -1);
+    LK_CLK16(15);
     // output 128 -> 3: per-lane partial over its 4 units, summed over the lane groups, then over the eight waves in fixed order
     {
         const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + 16 * w + 4 * q4);
@@ -832,6 +864,7 @@ __device__ __forceinline__ void decode_col_wg16(const LkDecodeArgs& a, int tile,
         const int sample = tile * 32 + lane;
         if (sample < a.P) { float* out = a.raw + (size_t)sample * 4; out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; }
     }
+    LK_CLK16(16);
 }
 
 // Block roles of the 16 x 16 x 32 launches: geometry workgroups first (eight waves = eight 16-sample tiles), then one colour workgroup
@@ -839,7 +872,7 @@ __device__ __forceinline__ void decode_col_wg16(const LkDecodeArgs& a, int tile,
 // neighbour rows per wave, as k_relpos_fwd) - the tracker's launches.
 #define LK_C16_LDS_U4 (2 * 16 * 64 + 8 * 64)
 template <bool RELPOS>
-__global__ __launch_bounds__(512, 4) void k_decode_fwd16(LkRelposArgs ra, LkDecodeArgs a, int n_col_blocks) {
+__global__ __launch_bounds__(512, RELPOS ? 2 : 4) void k_decode_fwd16(LkRelposArgs ra, LkDecodeArgs a, int n_col_blocks) {
     __shared__ u32x4 s_all[LK_C16_LDS_U4];
     __shared__ float s_o[8][3 * 32];
     __shared__ float s_bias[10][128];
@@ -859,15 +892,21 @@ __global__ __launch_bounds__(512, 4) void k_decode_fwd16(LkRelposArgs ra, LkDeco
     }
     const int tile = (int)blockIdx.x - n_geo_blocks;
     if (tile * 32 >= P_live) return;
+    LK_CLK16(17);
     if (RELPOS) {
         const int sample0 = tile * 32 + 4 * w;
         if (sample0 < ra.P) relpos_fwd_wave(ra, sample0, ra.P);
+        LK_CLK16(18);
         __syncthreads();
     }
     decode_col_wg16(a, tile, w, lane, reinterpret_cast<u32x4 (*)[16 * 64]>(s_all), s_all + 2 * 16 * 64, s_o, s_bias);
 }
-// LK_C16=0 switches back to the 32 x 32 x 16 kernels (same-box A/B)
-static bool lk_c16_fwd() { static const bool on = []{ const char* e = getenv("LK_C16"); return e == nullptr || e[0] != '0'; }(); return on; }
+// The 16 x 16 x 32 form is OFF by default: on one box (three alternating bench pairs + rocprofv3 per-iteration traces, round 4) it measured
+// tracker launch 35.5 -> 35.0 us, geometry launch 15.6 -> 15.8 us, mapper colour launch 46.2 -> 52.7 us, step 18.2 -> 18.6 ms.
+// LK_C16=1 (environment, read once) or lk_debug_set_c16(1) selects it (tests/test_c16_forward.py runs the goldens through both forms).
+static int g_c16 = -1;
+static bool lk_c16_fwd() { if (g_c16 < 0) { const char* e = getenv("LK_C16"); g_c16 = (e != nullptr && e[0] == '1') ? 1 : 0; } return g_c16 != 0; }
+extern "C" int lk_debug_set_c16(int on) { g_c16 = on ? 1 : 0; return LK_OK; }
 
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
