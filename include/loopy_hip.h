@@ -456,6 +456,11 @@ typedef struct {
                                    over and the step counts continue.  The work buffer then holds one segment's batches and neighbour
                                    lists instead of the whole call's (26 floats per sample and iteration).  0 for an unsegmented call */
     int32_t batches_ready;      /* non-zero: lk_map_prepare has already assembled this descriptor's batches (see there) */
+    int32_t signal_rows;        /* phase-1 calls of a data-parallel caller: non-zero = the backward records a library-owned event on the launch stream
+                                   right behind the feature-row gather - the point from which g_geo_feats / g_col_feats of the iteration are final,
+                                   while the weight-gradient launch and the reduction of the decoder gradients are still to run.  lk_map_wait_rows
+                                   makes another stream wait for it: the caller exchanges the row part of its gradient bucket there, beside the
+                                   tail of the backward (loopy_slam_amd/parallel.py) */
 } lk_map_desc;
 int64_t lk_map_work_floats(int32_t R, int32_t S, int32_t iters);
 /* The batch assembly of lk_map_frame's first call (pixels, rays, colours, radii, inside masks of all `iters` iterations: one launch) AHEAD of
@@ -479,6 +484,9 @@ int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t
  * searches ahead of its loop on a library-owned stream.  Valid after the phase-1 call of iteration it - 1 (or it) of the same
  * optimize_map call has returned. */
 int lk_map_wait_lists(const lk_map_desc* d, int32_t it, void* stream);
+/* `stream` waits until the feature-row gradients of the LAST phase-1 call issued with lk_map_desc::signal_rows are final (no-op when the
+ * library runs on the launch stream only). */
+int lk_map_wait_rows(const lk_map_desc* d, void* stream);
 
 /* ---------------------------------------------------------------- weight-gradient building block
  * dW[n][k] += sum_rows A'[row][n] * B[row][k], db[n] += sum_rows A'[row][n] (db may be NULL); row-major operands.

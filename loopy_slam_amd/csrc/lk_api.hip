@@ -275,7 +275,7 @@ extern "C" int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t f
 // beside the rel-pos backward and the feature scatter (fork / join with events; created once per process).
 namespace {
 int g_serial = -1;            // -1: not decided yet (environment LK_SERIAL), 0 / 1: set by lk_set_serial
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr, fork0 = nullptr, link = nullptr; bool ok = false; };
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr, fork0 = nullptr, link = nullptr, rows = nullptr; bool ok = false; bool rows_set = false; };
 SideStream& side_stream() {
     static SideStream s, none;
     if (g_serial < 0) g_serial = getenv("LK_SERIAL") != nullptr ? 1 : 0;
@@ -286,7 +286,8 @@ SideStream& side_stream() {
                hipEventCreateWithFlags(&s.mid, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&s.fork0, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&s.link, hipEventDisableTiming) == hipSuccess;
+               hipEventCreateWithFlags(&s.link, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&s.rows, hipEventDisableTiming) == hipSuccess;
     }
     return s;
 }
@@ -305,6 +306,11 @@ extern "C" int lk_streams_init(void) {
     // a failed creation costs the overlap, not the results: every user of the side streams checks `ok` and falls back to the launch
     // stream - so it is not an error of this call either; the process then runs as with LK_SERIAL=1
     if (!(s.ok && a.ok)) { g_serial = 1; lk_set_error("lk_streams_init: stream / event creation failed - running on the launch stream only"); }
+    return LK_OK;
+}
+int lk_wait_rows_event(hipStream_t st) {
+    SideStream& s = side_stream();
+    if (s.ok && s.rows_set) LK_HIP_TRY(hipStreamWaitEvent(st, s.rows, 0));
     return LK_OK;
 }
 extern "C" int lk_debug_occupancy(int32_t out[5]) {
@@ -504,6 +510,8 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         fs.act_flag = ex ? ex->act_flag : nullptr;
         if (bg_rides) { fs.red_part = S0 + L.part_bg; fs.red_n = lk_cdiv(lk_cdiv(P, 32), 4); fs.red_width = 288; fs.red_out = d->g_weights + G_EB; }
         lk_launch_feat_scatter(fs, st);
+        // data-parallel caller: the feature-row gradients are final from here (lk_map_desc::signal_rows)
+        if (ex && ex->signal_rows && ss.ok) { (void)hipEventRecord(ss.rows, st); ss.rows_set = true; }
     }
     if (gr) {
         LkInterpBwdArgs ib;

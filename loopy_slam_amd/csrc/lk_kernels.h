@@ -156,7 +156,7 @@ struct LkStepRider {
 };
 struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
                     int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale;
-                    uint8_t* act_flag; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead)
+                    uint8_t* act_flag; int signal_rows; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
@@ -273,6 +273,7 @@ enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, L
 // cnt: the batch holds n iterations of P_iter samples each (n <= LK_SEG_BATCH); their rows are counted per point on the way
 struct LkPresampleCount { int P_iter; int32_t* seg_rank; const int32_t* live_rays; const int32_t* key_of; };
 int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount* cnt = nullptr);
+int lk_wait_rows_event(hipStream_t st);                     // lk_map_wait_rows
 bool lk_serial_mode();                                      // LK_SERIAL / lk_set_serial: one stream only
 // library-owned third stream (lk_map_frame's search ahead of the loop; small independent launches of the backward)
 #define LK_PRE_CHUNKS 16

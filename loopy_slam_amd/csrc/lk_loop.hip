@@ -759,6 +759,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             }
             ex.live_rays = live;
             ex.act_flag = act_rows ? kn_h->act_flag : nullptr;
+            ex.signal_rows = ((phases & 3) == 1) ? d->signal_rows : 0;
             ex.dscale = (xd && (rd.flags & LK_FLAG_UNIT_LOSS_GRADS)) ? xd->bwd_scale : nullptr;
             LkStepRider sr;
             if (use_rider) {
@@ -838,6 +839,11 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     }
     LK_LAUNCH_CHECK();
     return LK_OK;
+}
+
+extern "C" int lk_map_wait_rows(const lk_map_desc* d, void* stream_) {
+    LK_REQUIRE(d != nullptr, "lk_map_wait_rows: NULL descriptor");
+    return lk_wait_rows_event((hipStream_t)stream_);
 }
 
 // The look-ahead chunk that holds iteration `it` has been enqueued (see the header): `stream` waits for its event.

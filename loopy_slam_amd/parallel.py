@@ -11,6 +11,7 @@ iteration (the union of the rows the ranks' batches touch) is agreed ONE ITERATI
 (lk_map_frame's neighbour search runs ahead of its loop, so the lists of iteration it + 1 exist while iteration it
 renders), and the host only ever waits for that side stream's event."""
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -56,6 +57,11 @@ class DistContext:
         self._agree = {}            # slot (it & 1) -> _RowAgreement
         self._side = None
         self._main_ev = None
+        # the row part of the gradient bucket is exchanged on a communication stream of its own, beside the tail of the backward
+        # (LOOPY_DIST_NO_OVERLAP=1: everything on the launch stream, as in round 3 - A/B)
+        self.overlap = os.environ.get('LOOPY_DIST_NO_OVERLAP') != '1'
+        self._comm = None
+        self._comm_ev = None
 
     # ------------------------------------------------------------------ collectives
     def _all_reduce(self, t, op):
@@ -104,12 +110,7 @@ class DistContext:
         if self._seg_cache is not None and self._seg_cache[0] == key:
             _, segs, n, offs = self._seg_cache
             bucket = self._bucket[:n]
-            eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 2 if direct else 0, eng.stream), 'lk_bucket_copy')
-            self._all_reduce(bucket, dist.ReduceOp.SUM)
-            if direct:
-                self._point_desc_at_bucket(mo, desc, stage, bucket, offs)
-            else:
-                eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
+            self._exchange(mo, desc, stage, segs, bucket, offs, direct)
             return
         ranges = _merge(list(mo.geo_dec_ranges) + (list(mo.col_dec_ranges) if stage == 'color' else []))
         tables = [gs.g_geo] + ([gs.g_col] if stage == 'color' else [])
@@ -137,13 +138,47 @@ class DistContext:
             self._bucket = torch.empty(max(n, 2 * (self._bucket.numel() if self._bucket is not None else 0)),
                                        dtype=torch.float32, device=gs.g_weights.device)
         bucket = self._bucket[:n]
+        offs['n_ranges'], offs['n_dec'] = len(ranges), (offs['tables'][0] if offs['tables'] else n)
         self._seg_cache = (key, segs, n, offs) if mo.rows is not None else None       # touched-row lists change every iteration
-        eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 2 if direct else 0, eng.stream), 'lk_bucket_copy')
-        self._all_reduce(bucket, dist.ReduceOp.SUM)
-        if direct:
-            self._point_desc_at_bucket(mo, desc, stage, bucket, offs)
-        else:
-            eng.lib.check(eng.lib.dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
+        self._exchange(mo, desc, stage, segs, bucket, offs, direct)
+
+    def overlaps_rows(self, mo):
+        """True when the iterations of `mo` exchange their feature-row gradients beside the tail of the backward (lk_map_desc::signal_rows)."""
+        return self.overlap and mo.rows is not None and mo.exposure is None and mo.eng.device.type == 'cuda' and self.world >= 1
+
+    def _exchange(self, mo, desc, stage, segs, bucket, offs, direct):
+        """Pack, all-reduce, (unpack).  The bucket is [decoder spans | rows of the geometry table | rows of the colour table].  The row part
+        is final as soon as the feature-row gather of the backward has run (k_feat_gather), while the weight-gradient launch and the
+        reduction of the decoder gradients (k_wgrad, k_bwd_reduce: 50-130 us of a 'color' iteration) are still to come: with a phase-split
+        lk_map_frame loop over a row list (`direct`) the row part is packed and all-reduced on a COMMUNICATION stream that waits for the
+        library's rows event (lk_map_wait_rows) only - beside that tail - and the launch stream packs and all-reduces the (small) decoder
+        part behind the reduction, then waits for the communication stream.  RCCL runs the two collectives in the order they were issued
+        (rows first) on every rank."""
+        eng = mo.eng
+        dll = eng.lib.dll
+        if not (direct and self.overlaps_rows(mo)):
+            eng.lib.check(dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 2 if direct else 0, eng.stream), 'lk_bucket_copy')
+            self._all_reduce(bucket, dist.ReduceOp.SUM)
+            if direct:
+                self._point_desc_at_bucket(mo, desc, stage, bucket, offs)
+            else:
+                eng.lib.check(dll.lk_bucket_copy(segs, len(segs), ptr(bucket), 1, eng.stream), 'lk_bucket_copy')
+            return
+        nr, nd = offs['n_ranges'], offs['n_dec']
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(eng.device)
+            self._comm_ev = torch.cuda.Event()
+        seg_t = type(segs[0])
+        row_segs = (seg_t * (len(segs) - nr)).from_address(C.addressof(segs) + nr * C.sizeof(seg_t))
+        with torch.cuda.stream(self._comm):
+            eng.lib.check(dll.lk_map_wait_rows(C.byref(desc), eng.stream), 'lk_map_wait_rows')
+            eng.lib.check(dll.lk_bucket_copy(row_segs, len(segs) - nr, ptr(bucket[nd:]), 2, eng.stream), 'lk_bucket_copy')
+            self._all_reduce(bucket[nd:], dist.ReduceOp.SUM)
+            self._comm_ev.record(self._comm)
+        eng.lib.check(dll.lk_bucket_copy(segs, nr, ptr(bucket[:nd]), 2, eng.stream), 'lk_bucket_copy')
+        self._all_reduce(bucket[:nd], dist.ReduceOp.SUM)
+        torch.cuda.current_stream(eng.device).wait_event(self._comm_ev)
+        self._point_desc_at_bucket(mo, desc, stage, bucket, offs)
 
     @staticmethod
     def _point_desc_at_bucket(mo, desc, stage, bucket, offs):

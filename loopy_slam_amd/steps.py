@@ -301,6 +301,7 @@ class MapOptimizer:
                 eng.lib.check(dll.lk_map_frame(C.byref(d), 0, n, 3, eng.stream), 'lk_map_frame')
         else:
             self._nat_desc = d
+            d.signal_rows = 1 if self.dist.overlaps_rows(self) else 0
             for it in range(n_iters):
                 eng.lib.check(dll.lk_map_frame(C.byref(d), it, it + 1, 1, eng.stream), 'lk_map_frame')
                 if self.rows is None and it + 1 < n_iters and self._nat_lists is not None:
