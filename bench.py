@@ -176,7 +176,7 @@ def main():
         'frames_per_s': args.steps / dt,
         'step': f'the FULL step: every {budget.every_frame}th of the {args.steps} timed steps ({n_mapped} of them) is a mapped frame that also inserts '
                 f'{budget.pixels_adding} pixels (lk_add_points + feature rows + lk_knn_build, Mapper.py:421-482) and renders the 640x480 frame '
-                f'(307 200 rays, Mapper.py:966-969; these rays are NOT counted in `value`); {wl.n_added} points added over the run, map {wl.n} points',
+                f'(307 200 rays, Mapper.py:966-969; these rays are NOT counted in `value`' + (', on a stream of its own beside the next frames\' tracking' if wl.render_stream is not None else '') + f'); {wl.n_added} points added over the run, map {wl.n} points',
         # the iterations alone (what rounds 1-3 reported as the headline)
         'ms_per_step_iterations': 1e3 * dt_iter / args.steps, 'frames_per_s_iterations': args.steps / dt_iter,
         'ms_per_step_host_frames': 1e3 * dt_host / args.steps,

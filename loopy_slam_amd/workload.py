@@ -7,6 +7,7 @@ Replica room0 budget (configs/Replica/replica.yaml:21-22,25,33,36-37; configs/po
             geo_iter_ratio 0.4 -> 24 'geometry' + 36 'color' iterations
   => 360 000 rays per frame, S = 5 samples per ray, rel-pos colour MLP on, static radius 0.08.
 """
+import os
 from dataclasses import dataclass
 
 import torch
@@ -98,6 +99,12 @@ class FrameWorkload:
         self.frame_no = 0
         self.img_state = None               # RenderState of the full-frame render (full step)
         self.n_added = 0
+        # The full-frame render of a mapped frame (Mapper.py:966-969: an image for the run's output folder, nothing of the loop consumes it) runs
+        # on a stream of its own, beside the next frames' tracking - forward-only work over a map that nobody changes until the next mapped
+        # frame's insertion, which waits for it.  LOOPY_RENDER_INLINE=1: on the launch stream, behind the mapping iterations (A/B).
+        self.render_stream = None
+        if eng.device.type == 'cuda' and os.environ.get('LOOPY_RENDER_INLINE') != '1':
+            self.render_stream = torch.cuda.Stream(eng.device)
 
     def _draws(self, iters, R, n, gen=None):
         return torch.randint(0, n, (iters, R), generator=gen or self.gen, dtype=torch.int32, device=self.eng.device)
@@ -149,6 +156,8 @@ class FrameWorkload:
         best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win, self.intr, rnd_t)
         mapped = full and self.frame_no % b.every_frame == 0
         if mapped:
+            if self.render_stream is not None:      # the insertion changes the map and its index: the last frame's render must be through
+                torch.cuda.current_stream(eng.device).wait_stream(self.render_stream)
             self.mapped_frame_extras(k)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
         fid = self._fid
@@ -162,6 +171,11 @@ class FrameWorkload:
         self.mapper.new_frame(self.rows, row_mask, zero=not prepared)
         self.mapper.run(b.map_iters, b.map_geo_iters, self.frames, rnd_m, fid, (0, H, 0, W), self.intr, H, W, self.map_log)
         if mapped:
-            self.render_frame(k)
+            if self.render_stream is not None:
+                self.render_stream.wait_stream(torch.cuda.current_stream(eng.device))
+                with torch.cuda.stream(self.render_stream):
+                    self.render_frame(k)
+            else:
+                self.render_frame(k)
         self.frame_no += 1
         return best, tlog, self.map_log
