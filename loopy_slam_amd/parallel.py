@@ -57,16 +57,39 @@ class DistContext:
         self._agree = {}            # slot (it & 1) -> _RowAgreement
         self._side = None
         self._main_ev = None
-        # the row part of the gradient bucket is exchanged on a communication stream of its own, beside the tail of the backward
-        # (LOOPY_DIST_NO_OVERLAP=1: everything on the launch stream, as in round 3 - A/B)
-        self.overlap = os.environ.get('LOOPY_DIST_NO_OVERLAP') != '1'
+        # LOOPY_DIST_OVERLAP=1: the row part of the gradient bucket is exchanged on a communication stream of its own, beside the tail of the
+        # backward (_exchange).  OFF by default: with ONE rank over RCCL (nothing on the wire to hide) the second collective and its stream
+        # hand-overs cost ~30 us per mapping iteration with torch's collectives (bench step 19.7 -> 21.6 ms, profiles/r4_ab_dist_exchange.txt) - it
+        # pays only where the row exchange itself takes longer than that on the wire
+        self.overlap = os.environ.get('LOOPY_DIST_OVERLAP') == '1'
         self._comm = None
         self._comm_ev = None
+        self._rccl = None
 
     # ------------------------------------------------------------------ collectives
+    def _direct(self, t):
+        """The library's own RCCL communicator (loopy_slam_amd/rccl.py: collectives enqueued on the launch stream itself - no second stream,
+        no event hand-overs) for device tensors when the process group runs over RCCL; LOOPY_DIST_TORCH=1 keeps torch's collectives (A/B).
+        Created at the first collective - every rank reaches it at the same point of the program."""
+        if not t.is_cuda or dist.get_backend() != 'nccl' or os.environ.get('LOOPY_DIST_TORCH') == '1':
+            return None
+        if self._rccl is None:
+            from . import rccl
+            try:
+                self._rccl = rccl.RcclComm(self.rank, self.world, t.device)
+            except Exception as e:          # noqa: BLE001 - any failure of the direct path falls back on torch's collectives, loudly
+                import warnings
+                warnings.warn(f'direct RCCL communicator unavailable ({e}): collectives go through torch.distributed')
+                self._rccl = False
+        return self._rccl or None
+
     def _all_reduce(self, t, op):
-        """dist.all_reduce; on a backend without device collectives (gloo with HIP tensors: the 2-ranks-on-one-GPU test
+        """All-reduce in place; on a backend without device collectives (gloo with HIP tensors: the 2-ranks-on-one-GPU test
         hook - RCCL refuses two ranks on one device) the tensor is staged through the host."""
+        r = self._direct(t)
+        if r is not None:
+            r.all_reduce(t, 'sum' if op == dist.ReduceOp.SUM else 'max')
+            return
         if t.is_cuda and dist.get_backend() != 'nccl':
             h = t.cpu()
             dist.all_reduce(h, op=op)
@@ -75,6 +98,9 @@ class DistContext:
             dist.all_reduce(t, op=op)
 
     def broadcast(self, t, src=0):
+        r = self._direct(t)
+        if r is not None and t.dtype in (torch.float32, torch.uint8) and t.is_contiguous():
+            return r.broadcast(t, src)
         if t.is_cuda and dist.get_backend() != 'nccl':
             h = t.cpu()
             dist.broadcast(h, src=src)

@@ -146,10 +146,16 @@ def test_two_rank_grad_allreduce_matches_single_process(all_rows, native, backen
     assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.0025
 
 
-def _rccl_worker(port, q, all_rows):
+def _rccl_worker(port, q, all_rows, mode='direct'):
     try:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
+        # mode: 'direct' = the library's own RCCL communicator on the launch stream (loopy_slam_amd/rccl.py, the default), 'torch' = torch's
+        # process-group collectives, 'overlap' = direct + the row part of the bucket on a communication stream beside the backward's tail
+        if mode == 'torch':
+            os.environ['LOOPY_DIST_TORCH'] = '1'
+        if mode == 'overlap':
+            os.environ['LOOPY_DIST_OVERLAP'] = '1'
         torch.cuda.set_device(0)
         from loopy_slam_amd import parallel
         from util import make_engine
@@ -166,8 +172,9 @@ def _rccl_worker(port, q, all_rows):
         dctx.broadcast(v, src=0)
         dctx.all_reduce_vec(v)
         torch.cuda.synchronize()
+        used = 'direct' if dctx._rccl else 'torch'
         q.put(([float(x) for x in log[:, 0].cpu()], dec.blob.cpu().numpy().copy(), geo_d.cpu().numpy().copy(), col_d.cpu().numpy().copy(),
-               v.cpu().numpy().copy(), dist.get_backend()))
+               v.cpu().numpy().copy(), dist.get_backend(), used))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
@@ -177,8 +184,8 @@ def _rccl_worker(port, q, all_rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('all_rows', (False, True))
-def test_rccl_collectives_on_the_launch_stream(all_rows):
+@pytest.mark.parametrize('all_rows,mode', ((False, 'direct'), (True, 'direct'), (False, 'torch'), (False, 'overlap')))
+def test_rccl_collectives_on_the_launch_stream(all_rows, mode):
     """The production exchange on the production backend: ONE rank, backend 'nccl' (= RCCL), the native loop split in phases around
     dist.all_reduce of the gradient bucket on DEVICE memory (no host staging), the uint8 MAX agreement on the touched rows and the
     pose broadcast.  A sum over one rank is the identity, so parameters and losses must equal the plain single-process loop - what
@@ -198,14 +205,14 @@ def test_rccl_collectives_on_the_launch_stream(all_rows):
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(port, q, all_rows))
+    p = ctx.Process(target=_rccl_worker, args=(port, q, all_rows, mode))
     p.start()
     res = q.get(timeout=600)
     p.join(timeout=120)
     if p.is_alive():
         p.kill()
     assert res[0] != 'error', res[1]
-    assert p.exitcode == 0 and res[5] == 'nccl'
+    assert p.exitcode == 0 and res[5] == 'nccl' and res[6] == ('torch' if mode == 'torch' else 'direct')
     np.testing.assert_allclose(res[0], log[:, 0].cpu().numpy(), rtol=1e-6)
     np.testing.assert_allclose(res[1], dec.blob.cpu().numpy(), rtol=0, atol=2e-6)
     # (feature rows: float atomics order inside the gather is the only source of difference between two runs of the same loop)
