@@ -31,7 +31,8 @@ def main():
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--strong', action='store_true',
                     help='strong scaling: the per-frame ray budget is SPLIT over the ranks (R / N rays per rank and iteration) instead of '
-                         'every rank bringing a full batch; frames/s then is the per-frame rate the "x6 at 8 GPUs" target speaks of')
+                         'every rank bringing a full batch.  frames/s of ONE sequence is bounded by the replicated tracking and the track -> map '
+                         'dependency (about 2-2.8x at 8 GPUs, DESIGN.md section 6); the 6x-at-8-GPUs target is the weak-scaling rays/s figure')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
