@@ -93,7 +93,7 @@ def test_accuracy_matches_the_oracle_loop(name):
     """The product on the GPU against the committed oracle runs of the same config and seeds:
       (a) rendered-depth L1 within 5 % of the oracle's, seed by seed (it is set by the map, which both build from the same draws' distribution);
       (b) ATE RMSE: every run beats the one-step constant-speed prior and is >= 3x better than dead reckoning, and the MEAN over the seeds is
-          within 5 % of the oracle's mean or within two standard errors of the difference (the ATE of one 50-frame run scatters by ~10 %
+          within 5 % of the oracle's mean or within three standard errors of the difference (a two-sigma bound fails one honest run in twenty) (the ATE of one 50-frame run scatters by ~10 %
           from seed to seed in BOTH pipelines - measured, profiles/r4_accuracy.json);
       (c) the numbers go to gpurun_out/accuracy_<name>.json."""
     import sys
@@ -125,4 +125,4 @@ def test_accuracy_matches_the_oracle_loop(name):
     assert abs(hl.mean() / ol.mean() - 1) <= 0.03
     assert ha.max() < prior['one_step_ate_cm'] and 3.0 * ha.max() <= prior['dead_reckoning_ate_cm']
     assert oa.max() < prior['one_step_ate_cm'] and 3.0 * oa.max() <= prior['dead_reckoning_ate_cm']
-    assert abs(ha.mean() - oa.mean()) <= max(0.05 * oa.mean(), 2.0 * se), (float(ha.mean()), float(oa.mean()), se)
+    assert abs(ha.mean() - oa.mean()) <= max(0.05 * oa.mean(), 3.0 * se), (float(ha.mean()), float(oa.mean()), se)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# round-4 closing job: GPU suite, bench + the three rocprofv3 passes, per-iteration timelines, SQ counters, the accuracy runs of the product
+# on the TUM / ScanNet configs (the oracle's runs are fixtures made in the build container), the three end-to-end throughput runs.
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > gpurun_out/gpu_tests.log
+tail -2 gpurun_out/gpu_tests.log
+bash tools/profile_round.sh r4 2>&1 | tail -4
+bash tools/gpu_trace_modes.sh r4 > /dev/null 2>&1; grep -E "^period|host enqueue" gpurun_out/trace_r4.md
+bash tools/profile_sq.sh r4 > /dev/null 2>&1
+for s in 1219 1220 1221; do
+  timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/ScanNet/scene0000.yaml --frames 50 --rays 500 --color-refine 0 --seed $s --out gpurun_out/acc_scannet_hip_s$s.json 2> gpurun_out/acc_scannet_hip_s$s.err | cut -c1-200
+  timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/TUM_RGBD/freiburg1_desk.yaml --frames 50 --rays 500 --iters-scale 0.5 --color-refine 0 --seed $s --out gpurun_out/acc_tum_hip_s$s.json 2> gpurun_out/acc_tum_hip_s$s.err | cut -c1-200
+done
+timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/Synthetic/room.yaml --frames 50 --rays 0 --color-refine 0 --out gpurun_out/acc_room_hip_fullrays.json 2> /dev/null | cut -c1-200
+timeout 300 python tools/slam_run.py --frames 51 --out gpurun_out/slam_run_room.json > /dev/null 2> gpurun_out/slam_run_room.err
+for c in ScanNet/scene0000 TUM_RGBD/freiburg1_desk; do
+  n=$(basename $c)
+  timeout 400 python tools/slam_run.py --frames 31 --config configs/$c.yaml --out gpurun_out/slam_run_$n.json > /dev/null 2> gpurun_out/slam_run_$n.err
+done
+for f in gpurun_out/slam_run_*.json; do python -c "
+import json; d = json.load(open('$f')); print('$f', 'tracked', d['ms_tracked_frame'], 'mapped steady', d.get('ms_mapped_frame_steady'), 'fps', d['frames_per_s'], 'ate cm', d['ate_rmse_cm'])"; done
