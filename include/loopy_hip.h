@@ -456,6 +456,10 @@ typedef struct {
                                    over and the step counts continue.  The work buffer then holds one segment's batches and neighbour
                                    lists instead of the whole call's (26 floats per sample and iteration).  0 for an unsegmented call */
     int32_t batches_ready;      /* non-zero: lk_map_prepare has already assembled this descriptor's batches (see there) */
+    int32_t train_geo_decoder;  /* mapping.fix_geo_decoder: False (Mapper.py:524-526): the geometry decoder's own matrices and biases are parameters too - they are
+                                   listed in geo_dec (all of the decoder's used tensors), every backward also forms their gradients
+                                   (LK_FLAG_GRAD_GEO_DECODER: size render.bwd_scratch with that flag), and the matrix fragments are refreshed after the
+                                   'geometry' steps as well */
     int32_t signal_rows;        /* phase-1 calls of a data-parallel caller: non-zero = the backward records a library-owned event on the launch stream
                                    right behind the feature-row gather - the point from which g_geo_feats / g_col_feats of the iteration are final,
                                    while the weight-gradient launch and the reduction of the decoder gradients are still to run.  lk_map_wait_rows

@@ -121,7 +121,7 @@ class MapDesc(C.Structure):
         ('iters', C.c_int32), ('n_geo_iters', C.c_int32), ('work', _fp), ('exposure', C.POINTER(ExposureDesc)),
         ('grad_bucket', _fp), ('bucket_geo_dec', C.c_int64 * MAX_SPANS), ('bucket_col_dec', C.c_int64 * MAX_SPANS),
         ('bucket_geo_rows', C.c_int64), ('bucket_col_rows', C.c_int64),
-        ('union_rows_flagged', C.c_int32), ('it_offset', C.c_int32), ('batches_ready', C.c_int32), ('signal_rows', C.c_int32),
+        ('union_rows_flagged', C.c_int32), ('it_offset', C.c_int32), ('batches_ready', C.c_int32), ('train_geo_decoder', C.c_int32), ('signal_rows', C.c_int32),
     ]
 
 

@@ -411,8 +411,9 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.dscale = ex ? ex->dscale : nullptr;
     lk_launch_decode_bwd(db, st);
     if (gw && (flags & LK_FLAG_GRAD_GEO_DECODER)) {      // mapping.fix_geo_decoder: False - the geometry decoder's own matrices and biases
-        LK_REQUIRE(!(flags & LK_FLAG_EMBED_GRADS_ONLY) && !(ex && ex->live_rays), "lk_render_bwd: GRAD_GEO_DECODER is a per-statement option (no EMBED_GRADS_ONLY, no partitioned batch)");
-        rc = lk_launch_geo_wgrad(P, d->S, d->rays_o, d->rays_d, d->z, d->weights, d->act, d->c_geo, S0 + L.d_raw, S0 + L.geo_part, d->g_weights, st);
+        LK_REQUIRE(!(flags & LK_FLAG_EMBED_GRADS_ONLY), "lk_render_bwd: GRAD_GEO_DECODER does not combine with EMBED_GRADS_ONLY");
+        rc = lk_launch_geo_wgrad(P, d->S, d->rays_o, d->rays_d, d->z, d->weights, d->act, d->c_geo, S0 + L.d_raw, S0 + L.geo_part, d->g_weights, st,
+                                 ex ? ex->live_rays : nullptr);
         if (rc != LK_OK) return rc;
     }
     // d affine: the colour tiles stored their 12 sums, one small launch adds them into g_affine (49 adds per address instead of 782)

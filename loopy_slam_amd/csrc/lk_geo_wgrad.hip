@@ -73,6 +73,7 @@ struct LkGeoWgradArgs {
     const float* c_geo;        // [P][32]
     const float* d_raw;        // [P][4], .w = d loss / d occ
     float* part;               // [gridDim.x][GW_SPAN]
+    const int32_t* live_rays;  // [1] or NULL: only the samples of the first *live_rays rays were rendered (partitioned batches of lk_map_frame)
 };
 
 __global__ __launch_bounds__(256) void k_geo_wgrad(LkGeoWgradArgs a) {
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(256) void k_geo_wgrad(LkGeoWgradArgs a) {
         slot[j] = ia | (ib << 16);
     }
     float* __restrict__ R = rec + s * RO_STRIDE;
-    const int n_tiles = (a.P + GW_TILE - 1) / GW_TILE;
+    const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;      // the forward saved nothing for the samples behind the live prefix
+    const int n_tiles = (P_live + GW_TILE - 1) / GW_TILE;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int sp = tile * GW_TILE + s;
-        const bool live = sp < a.P;
+        const bool live = sp < P_live;
         __syncthreads();                                                   // the accumulate phase of the tile before
         // ---- stage: d occ, constants, embedding, relu outputs, c
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
@@ -172,9 +174,10 @@ int64_t lk_geo_wgrad_part_floats(int P) { return (int64_t)lk_geo_wgrad_parts(P) 
 
 // d_raw must be complete (composite backward); g_weights accumulates
 int lk_launch_geo_wgrad(int P, int S, const float* rays_o, const float* rays_d, const float* z, const float* W, const float* act,
-                        const float* c_geo, const float* d_raw, float* part, float* g_weights, hipStream_t st) {
+                        const float* c_geo, const float* d_raw, float* part, float* g_weights, hipStream_t st, const int32_t* live_rays) {
     if (P <= 0) return LK_OK;
     LkGeoWgradArgs a;
+    a.live_rays = live_rays;
     a.P = P; a.S = S; a.rays_o = rays_o; a.rays_d = rays_d; a.z = z; a.W = W; a.act = act; a.c_geo = c_geo; a.d_raw = d_raw; a.part = part;
     const int n = lk_geo_wgrad_parts(P);
     hipLaunchKernelGGL(k_geo_wgrad, dim3(n), dim3(256), 0, st, a);

@@ -308,7 +308,7 @@ int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* 
 // geometry decoder weight gradients (LK_FLAG_GRAD_GEO_DECODER; lk_geo_wgrad.hip)
 int64_t lk_geo_wgrad_part_floats(int P);
 int lk_launch_geo_wgrad(int P, int S, const float* rays_o, const float* rays_d, const float* z, const float* W, const float* act,
-                        const float* c_geo, const float* d_raw, float* part, float* g_weights, hipStream_t st);
+                        const float* c_geo, const float* d_raw, float* part, float* g_weights, hipStream_t st, const int32_t* live_rays = nullptr);
 
 int lk_launch_depth_stats(const float* gt, int R, int chunk, float* far_out, hipStream_t st);
 int lk_launch_sample_interp(const LkSampleArgs& a, hipStream_t st, int mode = 0, const LkTrackFinalArgs* pose = nullptr);     // 1: search only, 2: interpolation of given lists; pose: k_sample_interp_pose

@@ -674,7 +674,8 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     bool repack_pending = false, stepped_pending = false;
     // Step rider (LkStepRider, lk_kernels.h): in a 'color' iteration that is followed by another one in this call, with no gradient
     // exchange in between (phases == 3), the Adam step happens inside the reduction launch of the backward
-    const bool rider_ok = pre && !xd && (phases & 3) == 3 && d->render.weights == d->weights_rw && d->render.g_weights != nullptr &&
+    const bool train_geo = d->train_geo_decoder != 0;      // (its gradients come from a launch of their own, k_geo_wgrad: no owner thread in the reduction launch -> no rider)
+    const bool rider_ok = pre && !xd && !train_geo && (phases & 3) == 3 && d->render.weights == d->weights_rw && d->render.g_weights != nullptr &&
                           (!(d->render.flags & LK_FLAG_REL_POS) || lk_relpos_fused(d->render.flags | LK_FLAG_GRAD_WEIGHTS)) &&
                           d->n_geo_dec + d->n_col_dec <= 16 && nb < (1ll << 31);
     // fix_color_decoder (the end-of-sequence refinement, Mapper.py:531-535): of the colour-stage spans only embedder_rel_pos._B is left (or
@@ -682,6 +683,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
     bool embed_only = true;
     for (int k = 0; k < d->n_col_dec; ++k)
         embed_only = embed_only && d->col_dec[k].offset >= R_EB && d->col_dec[k].offset + d->col_dec[k].n <= R_EB + 3 * 10;
+    if (train_geo) embed_only = false;          // (the geometry decoder's weight gradients need the full backward)
     bool w_next_ready = false;
     bool x_fwd_done = it_begin > n_geo_l;          // a later call of a phase-split sequence: the step launch of the iteration before did the forward
     for (int it = it_begin; it < it_end; ++it) {
@@ -690,7 +692,8 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         lk_render_desc rd = d->render;
         const bool xit = xd != nullptr && color;            // this iteration's loss is the exposure variant (its own launch after the composite)
         rd.flags = (d->render.flags & (LK_FLAG_REL_POS | LK_FLAG_UNIT_LOSS_GRADS | LK_FLAG_FEATS_F16)) | (color ? LK_FLAG_STAGE_COLOR : 0) | LK_FLAG_SAVE_ACT |
-                   LK_FLAG_GRAD_FEATS | LK_FLAG_GRAD_WEIGHTS | LK_FLAG_ZERO_ABSENT | LK_FLAG_MAPPER_LOSS | (embed_only && color ? LK_FLAG_EMBED_GRADS_ONLY : 0);
+                   LK_FLAG_GRAD_FEATS | LK_FLAG_GRAD_WEIGHTS | LK_FLAG_ZERO_ABSENT | LK_FLAG_MAPPER_LOSS | (embed_only && color ? LK_FLAG_EMBED_GRADS_ONLY : 0) |
+                   (train_geo ? LK_FLAG_GRAD_GEO_DECODER : 0);
         // d logits = w sigma' A with a LEARNED A: unit scale only relative to the power of two the exposure step keeps in xd->bwd_scale (the
         // kernels apply it on top of their 2^10); without that cell, or with the rel-pos MLP (its fused backward has no such hook): bf16 pieces
         const bool x_unit = xd && xd->bwd_scale && !(d->render.flags & LK_FLAG_REL_POS);
@@ -825,10 +828,11 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 rc = lk_adam_step(seg, ns, beta1, beta2, eps, st);
             }
             if (rc != LK_OK) return rc;
-            if (color && !embed_only) {        // the matrix fragments are copies of the colour-decoder matrices, which only move in this stage
+            if ((color && !embed_only) || train_geo) {  // the matrix fragments are copies of the colour-decoder matrices, which only move in this stage
+                // (and of the geometry decoder's, which move in both stages when they are trained)
                 // (rd.weights == weights_rw: the next iteration's forward reads what this step wrote)
                 if (pre && (phases & 3) == 3 && it + 1 < it_end && d->render.weights == d->weights_rw) repack_pending = true;
-                else if (pre && (phases & 3) == 2 && it + 1 < d->iters && d->render.weights == d->weights_rw) {
+                else if (color && !embed_only && pre && (phases & 3) == 2 && it + 1 < d->iters && d->render.weights == d->weights_rw) {
                     // phase-split caller: the phase-1 call of iteration it + 1 repacks in its interpolation launch (split_repack below)
                 } else {
                     rc = lk_weights_repack(d->weights_rw, d->weights_frag_rw, st);

@@ -314,7 +314,7 @@ class MapOptimizer:
         return log
 
     def _takes_native_loop(self):
-        return self.native_loop and self.ba is None and self.fix_geo_decoder and not (self.exposure is not None and self.R > 16384)
+        return self.native_loop and self.ba is None and not (self.exposure is not None and self.R > 16384)
 
     def prepare(self, n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log):
         """The row-independent head of run(): clears the gradient tables and assembles the batches of the call (lk_map_prepare) - for a
@@ -347,7 +347,7 @@ class MapOptimizer:
         # the scratch layout depends on the flags: size it with exactly the words lk_map_frame renders with, in both stages
         unit = _ffi.FLAG_UNIT_LOSS_GRADS if self.exposure is None else 0       # with exposure encoding the loss gradients are not unit scale
         base = (_ffi.FLAG_REL_POS if self.cfg.rel_pos else 0) | unit | _ffi.FLAG_SAVE_ACT | _ffi.FLAG_GRAD_FEATS | \
-            _ffi.FLAG_GRAD_WEIGHTS | _ffi.FLAG_ZERO_ABSENT | _ffi.FLAG_MAPPER_LOSS
+            _ffi.FLAG_GRAD_WEIGHTS | _ffi.FLAG_ZERO_ABSENT | _ffi.FLAG_MAPPER_LOSS | (0 if self.fix_geo_decoder else _ffi.FLAG_GRAD_GEO_DECODER)
         need = max(int(eng.lib.dll.lk_render_bwd_scratch_floats(self.R, self.cfg.S, base | extra)) for extra in (0, _ffi.FLAG_STAGE_COLOR))
         if gs.scratch is None or gs.scratch.numel() < need:
             gs.scratch = eng.empty(max(1, need))
@@ -392,6 +392,7 @@ class MapOptimizer:
             for k in range(3):
                 d.lr[si][k] = self.lrs[stage][k]
         d.iters, d.n_geo_iters = n_iters, n_geo_iters
+        d.train_geo_decoder = 0 if self.fix_geo_decoder else 1
         if self.exposure is not None:
             # Mapper.py:524-570: mlp_exposure steps with the colour decoder (decoders_lr of stage 'color', frozen with it), of the window's
             # exposure features only the current frame's (the last) is an Adam parameter

@@ -9,6 +9,13 @@ tail -2 gpurun_out/gpu_tests.log
 bash tools/profile_round.sh r4 2>&1 | tail -4
 bash tools/gpu_trace_modes.sh r4 > /dev/null 2>&1; grep -E "^period|host enqueue" gpurun_out/trace_r4.md
 bash tools/profile_sq.sh r4 > /dev/null 2>&1
+# mapping.fix_geo_decoder: False inside the native loop: per-iteration timelines with the geometry decoder trained (k_geo_wgrad timed on the chip)
+for mode in geo color; do
+  rm -rf /tmp/trace_gf_$mode
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_gf_$mode -o t -- python tools/mode_trace.py $mode 40 --geo-free > /tmp/trace_gf_$mode.log 2>&1
+  python tools/trace_summary.py /tmp/trace_gf_$mode "$mode, fix_geo_decoder: False (R = 5000, N = 100 000)" >> gpurun_out/trace_r4_geofree.md
+done
+grep -E "^period|k_geo_wgrad" gpurun_out/trace_r4_geofree.md
 for s in 1219 1220 1221; do
   timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/ScanNet/scene0000.yaml --frames 50 --rays 500 --color-refine 0 --seed $s --out gpurun_out/acc_scannet_hip_s$s.json 2> gpurun_out/acc_scannet_hip_s$s.err | cut -c1-200
   timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/TUM_RGBD/freiburg1_desk.yaml --frames 50 --rays 500 --iters-scale 0.5 --color-refine 0 --seed $s --out gpurun_out/acc_tum_hip_s$s.json 2> gpurun_out/acc_tum_hip_s$s.err | cut -c1-200

@@ -21,12 +21,16 @@ def main():
     ap.add_argument('--points', type=int, default=100_000)
     ap.add_argument('--repeat', type=int, default=3)
     ap.add_argument('--rays', type=int, default=0, help='override the mapping batch size')
+    ap.add_argument('--geo-free', action='store_true', help='mapping.fix_geo_decoder: False - the geometry decoder is trained too (k_geo_wgrad)')
     args = ap.parse_args()
     eng = core.Engine()
     b = workload.Budget(n_points=args.points)
     if args.rays:
         b.map_rays = args.rays
     wl = workload.FrameWorkload(eng, b)
+    if args.geo_free:
+        from loopy_slam_amd import steps
+        wl.mapper = steps.MapOptimizer(eng, wl.cfg, wl.dec, wl.knn, wl.pos, wl.geo, wl.col, wl.rows, b.map_rays, workload.MAP_LRS, w_color=0.1, fix_geo_decoder=False)
     H, W = wl.H, wl.W
     e = min(b.ignore_edge, H // 4)
     win = (e, H - e, e, W - e)
