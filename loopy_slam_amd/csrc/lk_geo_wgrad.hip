@@ -166,9 +166,11 @@ __global__ __launch_bounds__(256) void k_geo_wgrad(LkGeoWgradArgs a) {
     }
 }
 
+// up to three workgroups per compute unit (49 KB of LDS each): with 256 - one per unit, four waves - the launch measured 670 us per 25 000
+// samples on the chip (profiles/r4_iteration_timeline_geofree.md), bound by the dependent LDS reads of its accumulate phase
 int lk_geo_wgrad_parts(int P) {
     const int tiles = lk_cdiv(P, GW_TILE);
-    return tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256;
+    return tiles < 768 ? (tiles < 1 ? 1 : tiles) : 768;
 }
 int64_t lk_geo_wgrad_part_floats(int P) { return (int64_t)lk_geo_wgrad_parts(P) * GW_SPAN; }
 

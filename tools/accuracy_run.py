@@ -114,6 +114,7 @@ def run_product(cfg, emu=False):
     if emu:
         from util import make_engine
         eng = make_engine('emu')
+    torch.manual_seed(cfg.get('setup_seed', 1219))          # run.py's setup_seed: mlp_exposure's initial weights come from the global generator
     ps = slam.Point_SLAM(cfg, None, eng=eng)
     frames = [ps.frame_reader[i] for i in range(len(ps.frame_reader))]
 

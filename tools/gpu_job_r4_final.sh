@@ -16,9 +16,9 @@ for mode in geo color; do
   python tools/trace_summary.py /tmp/trace_gf_$mode "$mode, fix_geo_decoder: False (R = 5000, N = 100 000)" >> gpurun_out/trace_r4_geofree.md
 done
 grep -E "^period|k_geo_wgrad" gpurun_out/trace_r4_geofree.md
-for s in 1219 1220 1221; do
-  timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/ScanNet/scene0000.yaml --frames 50 --rays 500 --color-refine 0 --seed $s --out gpurun_out/acc_scannet_hip_s$s.json 2> gpurun_out/acc_scannet_hip_s$s.err | cut -c1-200
-  timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/TUM_RGBD/freiburg1_desk.yaml --frames 50 --rays 500 --iters-scale 0.5 --color-refine 0 --seed $s --out gpurun_out/acc_tum_hip_s$s.json 2> gpurun_out/acc_tum_hip_s$s.err | cut -c1-200
+for s in 1219 1220 1221 1222 1223; do
+  timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/ScanNet/scene0000.yaml --frames 50 --rays 2000 --color-refine 0 --seed $s --out gpurun_out/acc_scannet_hip_s$s.json 2> gpurun_out/acc_scannet_hip_s$s.err | cut -c1-200
+  timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/TUM_RGBD/freiburg1_desk.yaml --frames 50 --rays 2000 --iters-scale 0.5 --color-refine 0 --seed $s --out gpurun_out/acc_tum_hip_s$s.json 2> gpurun_out/acc_tum_hip_s$s.err | cut -c1-200
 done
 timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/Synthetic/room.yaml --frames 50 --rays 0 --color-refine 0 --out gpurun_out/acc_room_hip_fullrays.json 2> /dev/null | cut -c1-200
 timeout 300 python tools/slam_run.py --frames 51 --out gpurun_out/slam_run_room.json > /dev/null 2> gpurun_out/slam_run_room.err
