@@ -367,6 +367,17 @@ __device__ __forceinline__ LkH8 lk_c16_read(const u32x4* __restrict__ region, in
     return b;
 }
 
+// Barrier among SOME waves of a workgroup (s_barrier waits for every wave of the workgroup that has not ended: a wave that runs a long chain
+// of its own - the geometry decoder on wave 4 of the tracker's fused forward - holds the others at their first barrier until it is through).
+// cnt: an LDS word, zero when the participants start; target = participants x (ordinal of this barrier, from 1).  Every participant calls
+// it the same number of times; LDS writes before it are visible to the others' reads after it.
+__device__ __forceinline__ void lk_soft_barrier(unsigned* cnt, unsigned target) {
+    __threadfence_block();
+    if (lk_lane() == 0) atomicAdd(cnt, 1u);
+    while (*reinterpret_cast<volatile unsigned*>(cnt) < target) __builtin_amdgcn_s_sleep(1);
+    __threadfence_block();
+}
+
 // Sum over the 32 lanes of each half-wave with DPP adds (plain VALU, no LDS traffic: the ds_bpermute form of the same
 // reduction cost 0.8 ms per benchmark step in the embedding-gradient sections).  quad swaps, then the two mirrors give
 // every lane its 16-lane row total; row_bcast15 adds row 0 (2) into row 1 (3).

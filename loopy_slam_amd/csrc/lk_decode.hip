@@ -210,10 +210,17 @@ __device__ __forceinline__ f32x16 ct_bias_lds(const float* __restrict__ v, int u
 // the next layer (and the three embedding blocks of layer 3) are fetched before the stores of the current one, 40 registers more;
 // with one tile per compute unit nothing else hides the L2 round trip of the in-line blocks (decode_clock.py: 2.5-5 k cycles per
 // product phase for 1 k cycles of matrix instructions).
-template <bool DEEP>
+// SOFTBAR (s_cnt: an LDS word, zero on entry): the four waves meet at a barrier of their own (lk_soft_barrier) instead of s_barrier - for
+// workgroups in which a fifth wave runs something else meanwhile (k_relpos_decode_fwd: the geometry decoder on wave 4)
+template <bool DEEP, bool SOFTBAR = false>
 __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
                                               u32x4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */,
-                                              float (*s_bias)[128] /* [10][128] */) {
+                                              float (*s_bias)[128] /* [10][128] */, unsigned* s_cnt = nullptr) {
+    unsigned n_bar = 0;
+    auto wg_barrier = [&]() {
+        if (SOFTBAR) lk_soft_barrier(s_cnt, 4u * (++n_bar));
+        else __syncthreads();
+    };
     LK_CLK(0);
     {
         const int t = (int)threadIdx.x;
@@ -272,7 +279,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
         cb[0] = lk_split_cth(cc, 0); cb[1] = lk_split_cth(cc, 1);
     }
-    __syncthreads();                                   // the embedding pieces and s_bias are complete
+    wg_barrier();                                   // the embedding pieces and s_bias are complete
 #pragma unroll
     for (int G = 0; G < 3; ++G) {
         eb[G].p[0] = s_x[1][(G * 2 + 0) * 64 + lane];
@@ -347,7 +354,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     LK_CLK(2);
     finish(acc, act_col_a, 0, 0);
     LK_CLK(3);
-    __syncthreads();
+    wg_barrier();
     LK_CLK(4);
     // layers 1, 2: 128 -> 128
 #pragma unroll
@@ -361,7 +368,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         LK_CLK(2 + 3 * L);
         finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, L) : nullptr, L, L & 1);
         LK_CLK(3 + 3 * L);
-        __syncthreads();
+        wg_barrier();
         LK_CLK(4 + 3 * L);
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
@@ -374,7 +381,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     LK_CLK(11);
     finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, 3) : nullptr, 3, 1);
     LK_CLK(12);
-    __syncthreads();
+    wg_barrier();
     LK_CLK(13);
     // layer 4
     prefetch_u(FB + FM19_FWDH);
@@ -398,7 +405,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     }
     o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
     if (h == 0) { s_o[w][lane] = o0; s_o[w][32 + lane] = o1; s_o[w][64 + lane] = o2; }
-    __syncthreads();
+    wg_barrier();
     if (w == 0 && h == 0) {
         o0 = ((s_o[0][lane] + s_o[1][lane]) + s_o[2][lane]) + s_o[3][lane];
         o1 = ((s_o[0][32 + lane] + s_o[1][32 + lane]) + s_o[2][32 + lane]) + s_o[3][32 + lane];
@@ -545,21 +552,29 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
 // one barrier, then waves 0..3 decode the tile's colour as decode_col_wg does, wave 4 runs the geometry decoder of the SAME tile (no
 // barriers in it) and waves 5..7 leave - a barrier only counts the waves still alive.  One workgroup per tile and nothing else in the
 // grid: an eight-wave workgroup at this register count fills a compute unit, and a tracking batch (235 tiles) must not need a second round.
-template <bool DEEP>
+// SOFTBAR: the four colour waves use a barrier of their own.  With s_barrier they stood at their FIRST barrier until wave 4 - the geometry
+// decoder, no barrier in it - had ended: the hardware barrier waits for every wave of the workgroup that is still alive (shader-clock
+// stamps, profiles/r4_decode_clock32.txt: 23 k cycles in the decode's set-up phase of the tracker's launch against 7.7 k for the same
+// code in the mapper's, where the geometry tiles are workgroups of their own).
+template <bool DEEP, bool SOFTBAR>
 __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDecodeArgs a) {
     __shared__ u32x4 s_x[2][16 * 64];
     __shared__ float s_o[4][3 * 32];
     __shared__ float s_bias[10][128];
+    __shared__ unsigned s_cnt;
     const int lane = lk_lane();
     const int w = (int)threadIdx.x >> 6;
     const int tile = (int)blockIdx.x;
     const int sample0 = tile * 32 + 4 * w;
+    if (threadIdx.x == 0) s_cnt = 0u;
     if (sample0 < ra.P) relpos_fwd_wave(ra, sample0, ra.P);
     __syncthreads();                               // the tile's c_col rows are written
     if (w > 4) return;
     if (w == 4) { decode_geo_wave(a, tile, lane); return; }
-    decode_col_wg<DEEP>(a, tile, w, lane, s_x, s_o, s_bias);
+    decode_col_wg<DEEP, SOFTBAR>(a, tile, w, lane, s_x, s_o, s_bias, &s_cnt);
 }
+// LK_SOFTBAR=0 switches the colour waves back to s_barrier (A/B)
+static bool lk_softbar() { static const bool on = []{ const char* e = getenv("LK_SOFTBAR"); return e == nullptr || e[0] != '0'; }(); return on; }
 
 // =====================================================================================================================================
 // The 16 x 16 x 32 form of both decoders (lk_common.h "C16"; round 4).  Same arithmetic per product (fp16x3), same saved rows, other shape:
@@ -942,7 +957,8 @@ int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, h
         hipLaunchKernelGGL(k_decode_fwd16<true>, dim3(tiles + lk_cdiv(a.P, 128)), dim3(512), 0, st, ra, a, tiles);
         return LK_OK;
     }
-    hipLaunchKernelGGL(k_relpos_decode_fwd<true>, dim3(tiles), dim3(512), 0, st, ra, a);
+    if (lk_softbar()) hipLaunchKernelGGL((k_relpos_decode_fwd<true, true>), dim3(tiles), dim3(512), 0, st, ra, a);
+    else hipLaunchKernelGGL((k_relpos_decode_fwd<true, false>), dim3(tiles), dim3(512), 0, st, ra, a);
     return LK_OK;
 }
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {

@@ -201,12 +201,16 @@ def rows_of_samples(out, sample_mask):
     return torch.unique(idx[idx >= 0].long())
 
 
-def branch_point_rays(out, b, pos, geo, W, tracker_loss=None, tol=2e-6, r2=None):
+def branch_point_rays(out, b, pos, geo, W, tracker_loss=None, tol=1e-5, r2=None):
     """bool [R]: rays whose gradient is not comparable between two fp32 implementations because they sit on a branch point
     of the graph at rounding level - a geometry-decoder ReLU with |pre-activation| < tol in one of their samples
     (geo_gate_margin), an L1 term with |depth - gt| < tol, or (tracker) a residual within 1e-5 relative of the loss mask's
     threshold 10 * mean or of the 1e3 clamp (Tracker.py:177-183).  Their loss gradient is zeroed on both sides; the count is
-    recorded and bounded by the tests."""
+    recorded and bounded by the tests.
+    tol = 1e-5 (round 4; 2e-6 before): the kernels' pre-activations differ from the CPU oracle's by ~1e-6, and the oracle's own move at that
+    level with the host's SIMD kernels - at 2e-6 ONE ray within 2-3e-6 of a gate was classified differently on one box of the pool and its
+    flipped term (7e-5 of the largest entry) failed the float64 referee's 2e-5 floor; 1e-5 keeps an order of magnitude between the
+    rounding noise and the line."""
     R = b['gt_depth'].shape[0]
     margin = geo_gate_margin(out, pos, geo, W, r2=r2)          # r2: per-sample squared radius [P] (dynamic radius) or None = 0.08^2
     rays = (margin < tol).reshape(R, -1).any(1)

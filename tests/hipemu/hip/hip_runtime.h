@@ -71,6 +71,7 @@ void wave_mfma32x32x2(float a, float b, const float* c, float* d);
 void wave_mfma16x16x4(float a, float b, const float* c, float* d);
 void wave_mfma32x32x16_bf16(const float* a8, const float* b8, const float* c, float* d);
 void wave_mfma16x16x32(const float* a8, const float* b8, const float* c, float* d);
+void spin_yield();
 int lane_id();
 }  // namespace hipemu
 
@@ -247,6 +248,7 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only 
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 // compiler-level wave barrier on the device; here the point where every lane's LDS accesses so far have happened
+static inline void __builtin_amdgcn_s_sleep(int) { hipemu::spin_yield(); }
 static inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_ballot(true); }
 
 // ---- math (round-to-nearest, never contracted)

@@ -87,6 +87,9 @@ extern "C" void hipemu_trampoline() {
     lane_exit();
 }
 
+// a lane that polls memory (software barrier): let the other lanes run; no progress of its own (a block whose live lanes all spin is a deadlock)
+void spin_yield() { yield_to_main(); }
+
 void syncthreads() {
     unsigned g = g_bar_gen;
     g_bar_arrived++;

@@ -20,6 +20,12 @@ def test_package_never_touches_oracle_or_emulator():
         for pat in (r'^\s*(from|import)\s+oracle', r'hipemu', r'libloopyhip_emu', r'HIPEMU'):
             if re.search(pat, src, re.M):
                 bad.append((os.path.relpath(path, ROOT), pat))
+    # the entry points at the repository root and the `src.*` import aliases are product too
+    for path in [os.path.join(ROOT, 'run.py')] + glob.glob(os.path.join(ROOT, 'src', '**', '*.py'), recursive=True):
+        src = open(path).read()
+        for pat in (r'^\s*(from|import)\s+oracle', r'hipemu', r'libloopyhip_emu', r'oracle_slam', r'sys\.path.*tests'):
+            if re.search(pat, src, re.M):
+                bad.append((os.path.relpath(path, ROOT), pat))
     assert not bad, bad
     for name in ('bench.py', '__graft_entry__.py'):
         src = open(os.path.join(ROOT, name)).read()
