@@ -34,16 +34,16 @@ def setup_seed(seed):
 
 
 def main(argv=None):
-    parser = argparse.ArgumentParser(description='Arguments for running the Point-SLAM hot path on MI355X.')
-    parser.add_argument('config', type=str, help='Path to config file.')
-    parser.add_argument('--input_folder', type=str, help='input folder, this have higher priority, can overwrite the one in config file')
-    parser.add_argument('--output', type=str, help='output folder, this have higher priority, can overwrite the one in config file')
+    parser = argparse.ArgumentParser(description='Neural-point SLAM hot path on MI355X behind the reference command line.')
+    parser.add_argument('config', type=str, help='scene configuration (YAML, inherit_from chain over configs/point_slam.yaml)')
+    parser.add_argument('--input_folder', type=str, help='frames directory; overrides data.input_folder of the configuration')
+    parser.add_argument('--output', type=str, help='results directory; overrides data.output of the configuration')
     parser.add_argument('--wandb', action='store_true')
     parser.add_argument('--no_wandb', action='store_true')
 
     def optional_int(string):
         return None if string == 'None' else int(string)
-    parser.add_argument('--stop', type=optional_int, help='stop after n frames')
+    parser.add_argument('--stop', type=optional_int, help='end the run after frame N (checkpoint there)')
     parser.add_argument('--frames', type=optional_int, default=None, help='(synthetic reader only) length of the sequence')
     args = parser.parse_args(argv)
 
