@@ -88,7 +88,7 @@ def test_oracle_loop_and_product_agree_on_a_miniature_sequence():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ('room',))
+@pytest.mark.parametrize('name', ('room', 'tum', 'scannet'))
 def test_accuracy_matches_the_oracle_loop(name):
     """The product on the GPU against the committed oracle runs of the same config and seeds:
       (a) rendered-depth L1 within 5 % of the oracle's, seed by seed (it is set by the map, which both build from the same draws' distribution);
@@ -100,7 +100,30 @@ def test_accuracy_matches_the_oracle_loop(name):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import accuracy_run as AR
     fx = _fixtures(name)
-    assert len(fx) >= 3, 'oracle fixtures missing (tools/accuracy_run.py --pipeline oracle)'
+    if name != 'room' and not fx:
+        pytest.skip(f'no oracle fixture for the {name} config')
+    assert len(fx) >= (3 if name == 'room' else 1), 'oracle fixtures missing (tools/accuracy_run.py --pipeline oracle)'
+    if name != 'room':
+        # TUM / ScanNet configs (dynamic radii, gradient-pool tracking pixels, exposure encoding) at 2 000 rays per iteration - at config 1's
+        # 500 rays BOTH pipelines lose track on this sequence (oracle 22 cm, product 14-31 cm): ONE oracle run each (55-60 minutes of CPU),
+        # three product runs; a band instead of a statistical bound
+        o = fx[0]
+        c = o['config']
+        res = []
+        for seed in (c['seed'], c['seed'] + 1, c['seed'] + 2):
+            cfg = AR.make_cfg(os.path.join(ROOT, c['file']), c['frames'], c['rays_per_iteration'], c['iters_scale'], None, seed, int(c['color_refine']), c['scene'])
+            res.append(AR.run_product(cfg))
+        ha = np.array([r['ate_rmse_cm'] for r in res]); hl = np.array([r['depth_l1_cm'] for r in res])
+        out = os.path.join(ROOT, 'gpurun_out')
+        if os.path.isdir(out):
+            with open(os.path.join(out, f'accuracy_{name}.json'), 'w') as f:
+                json.dump(dict(config=c, oracle=dict(ate_rmse_cm=o['ate_rmse_cm'], depth_l1_cm=o['depth_l1_cm'], rot_err_deg=o['rot_err_deg']),
+                               hip_ate_rmse_cm=ha.tolist(), hip_depth_l1_cm=hl.tolist()), f, indent=1)
+        prior = o['prior_only']
+        assert 0.4 * o['ate_rmse_cm'] <= float(np.median(ha)) <= 2.5 * o['ate_rmse_cm'], (ha.tolist(), o['ate_rmse_cm'])
+        assert abs(float(hl.mean()) / o['depth_l1_cm'] - 1) <= 0.2, (hl.tolist(), o['depth_l1_cm'])
+        assert float(np.median(ha)) < prior['dead_reckoning_ate_cm'] / 1.5
+        return
     rows = []
     for o in fx:
         c = o['config']
