@@ -191,7 +191,8 @@ int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount
 
 extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
 
-int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays, const LkRepackRider* repack, const LkTrackFinalArgs* pose) {
+int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays, const LkRepackRider* repack, const LkTrackFinalArgs* pose,
+                       const LkTrackLossArgs* comp, int* comp_tiles) {
     int rc = check_desc(d, "lk_render_fwd");
     if (rc != LK_OK) return rc;
     if (d->R == 0) return LK_OK;
@@ -228,7 +229,8 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     da.R = d->R; da.S = d->S; da.P = P; da.flags = d->flags;
     da.rays_o = d->rays_o; da.rays_d = d->rays_d; da.z = d->z;
     da.c_geo = d->c_geo; da.c_col = d->c_col; da.W = d->weights; da.Wfrag = d->weights_frag; da.affine = d->affine;
-    da.raw = d->raw; da.act = d->act; da.live_rays = live_rays;
+    da.raw = d->raw; da.act = d->act; da.live_rays = live_rays; da.tile_stride = 0;
+    if (comp_tiles) *comp_tiles = 0;
     const bool fuse_small = (skip & LK_FUSE_SMALL) && lk_relpos_decode_fusable(da);
     if (color && (d->flags & LK_FLAG_REL_POS)) {
         LkRelposArgs ra;
@@ -237,7 +239,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         ra.pos = d->pos; ra.col_feats = d->col_feats; ra.feats_f16 = (d->flags & LK_FLAG_FEATS_F16) ? 1 : 0; ra.live_rays = live_rays;
         ra.nbr_idx = d->nbr_idx; ra.nbr_w = d->nbr_w; ra.nbr_count = d->nbr_count;
         ra.W = d->weights; ra.Wfrag = d->weights_frag; ra.noise_col = d->noise_col; ra.c_col = d->c_col;
-        if (fuse_small) lk_launch_relpos_decode_fwd(ra, da, st);
+        if (fuse_small) lk_launch_relpos_decode_fwd(ra, da, st, comp, comp_tiles);
         else lk_launch_relpos_fwd(ra, st);
     }
     if (!fuse_small) lk_launch_decode_fwd(da, st);
@@ -409,6 +411,12 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.dp_embed = S0 + L.dp_embed; db.dp_embed_col = S0 + L.dp_embed_col; db.g_weights = d->g_weights; db.g_affine = d->g_affine; db.g_affine_part = S0 + L.aff_part; db.part_bg = S0 + L.part_bg;
     db.live_rays = ex ? ex->live_rays : nullptr;
     db.dscale = ex ? ex->dscale : nullptr;
+    db.tl_n_part = 0;
+    memset(&db.tl, 0, sizeof(db.tl));
+    if (ex && ex->track_loss) {      // tracking loop: the loss and the composite backward are the launch's prologue (no d_raw array)
+        LK_REQUIRE((flags & LK_FLAG_GRAD_RAYS) != 0 && ex->track_n_part > 0, "lk_render_bwd: the inline tracker loss needs ray gradients");
+        db.tl = *ex->track_loss; db.tl_n_part = ex->track_n_part;
+    }
     lk_launch_decode_bwd(db, st);
     if (gw && (flags & LK_FLAG_GRAD_GEO_DECODER)) {      // mapping.fix_geo_decoder: False - the geometry decoder's own matrices and biases
         LK_REQUIRE(!(flags & LK_FLAG_EMBED_GRADS_ONLY), "lk_render_bwd: GRAD_GEO_DECODER does not combine with EMBED_GRADS_ONLY");

@@ -6,6 +6,7 @@
 #include "lk_common.h"
 #include "lk_kernels.h"
 #include "lk_composite_dev.h"
+#include "lk_track_dev.h"
 
 using namespace lkw;
 
@@ -95,7 +96,8 @@ template <> struct BwdPiece<true> {
 
 // DEEP: as in the forward (lk_decode.hip) - launches whose tiles are all resident at once fetch more blocks of W_i^T ahead
 // (all eight; the register count of the kernel is set by its geometry role)
-template <bool H16, bool DEEP>
+// TL: the launch may belong to the tracking loop (LkDecodeBwdArgs::tl_n_part) - d raw formed in the prologue instead of read
+template <bool H16, bool DEEP, bool TL>
 __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int tile, int w, int lane,
                                                   u32x4* __restrict__ s_x /* [2][24*64] */, float (*s_o)[3 * 32]) {
     typedef BwdPiece<H16> PC;
@@ -115,7 +117,9 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128;            // layer-major: + LK_COL_LAYER(P, layer)
     const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128;
-    float4 draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
+    float4 draw;
+    if (TL && a.tl_n_part > 0) draw = lk_track_draw(a.tl, a.tl_n_part, sp, nullptr);
+    else draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
     if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
     float g0 = draw.x, g1 = draw.y, g2 = draw.z;
     const float4 yo = *reinterpret_cast<const float4*>(a.raw + (size_t)sp * 4);
@@ -369,7 +373,18 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_geo = a.act + (size_t)sp * LK_ACT_GEO_A;
-    float4 draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
+    float4 draw;
+    if (!GH16 && a.tl_n_part > 0) {
+        // tracking loop: the loss term of the sample's ray and the composite backward of it, here instead of in a launch of its own
+        // (k_track_loss2: 6 us of an iteration of 117); the ray's first sample carries its terms to the loss row (Tracker.py:183-191)
+        LkTrackRayLoss row;
+        draw = lk_track_draw(a.tl, a.tl_n_part, sp, &row);
+        const bool first = live && h == 0 && sp % a.S == 0;
+        float G = first ? row.geo : 0.0f, C = first ? row.col : 0.0f, N = first ? row.cnt : 0.0f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { G += __shfl_xor(G, o); C += __shfl_xor(C, o); N += __shfl_xor(N, o); }
+        if (lane == 0) *reinterpret_cast<float4*>(a.tl.row_part + (size_t)tile * 4) = make_float4(G + (a.tl.use_color ? a.tl.w_color * C : 0.0f), G, C, N);
+    } else draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
     if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
     float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;                     // this lane's share of dL/dp (embedding path)
     // ================= geometry decoder =================
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(256, LK_DBWD_MINB) void k_decode_bwd(LkDecodeBwdArg
             if (a.affine && a.g_affine && threadIdx.x < 12) a.g_affine_part[(size_t)bid * 12 + threadIdx.x] = 0.0f;
             return;
         }
-        decode_bwd_col_wg<H16, DEEP>(a, bid, w, lk_lane(), s_x, s_o);
+        decode_bwd_col_wg<H16, DEEP, !GH16>(a, bid, w, lk_lane(), s_x, s_o);
         return;
     }
     float (*s_part)[3 * EGP] = reinterpret_cast<float (*)[3 * EGP]>(s_x);

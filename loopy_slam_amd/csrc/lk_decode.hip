@@ -13,6 +13,8 @@
 // lane-contiguous split pieces (decode_col_wg).
 #include "lk_common.h"
 #include "lk_kernels.h"
+#include "lk_composite_dev.h"
+#include <string.h>
 
 using namespace lkw;
 
@@ -101,8 +103,9 @@ struct DecSample {
 };
 __device__ __forceinline__ DecSample dec_sample(const LkDecodeArgs& a, int tile, int lane) {
     DecSample d;
-    d.sample = tile * 32 + (lane & 31);
-    d.live = d.sample < a.P;
+    const int ts = a.tile_stride ? a.tile_stride : 32;           // (a tile of whole rays: LkDecodeArgs::tile_stride)
+    d.sample = tile * ts + (lane & 31);
+    d.live = d.sample < a.P && (lane & 31) < ts;
     d.h = lane >> 5;
     d.sp = d.live ? d.sample : a.P - 1;                          // clamp: dead lanes compute, never store
     const int r = d.sp / a.S;
@@ -115,7 +118,7 @@ __device__ __forceinline__ DecSample dec_sample(const LkDecodeArgs& a, int tile,
 }
 
 // ================= geometry decoder (hidden 32, relu): one wave = one 32-sample tile, registers only =================
-__device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile, int lane) {
+__device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile, int lane) {      // returns the occupancy of lane & 31's sample
     const DecSample d = dec_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
     const bool live = d.live;
@@ -177,6 +180,7 @@ __device__ __forceinline__ void decode_geo_wave(const LkDecodeArgs& a, int tile,
     }
     part += __shfl_xor(part, 32);
     if (live && h == 0) a.raw[(size_t)d.sample * 4 + 3] = part + W[G_BO];
+    return part + W[G_BO];
 }
 
 #ifdef LK_PROBE_CLK      // timing probe (tools/probe/decode_clock.py): shader-clock stamps of the first workgroups' waves at the phase boundaries
@@ -212,10 +216,11 @@ __device__ __forceinline__ f32x16 ct_bias_lds(const float* __restrict__ v, int u
 // product phase for 1 k cycles of matrix instructions).
 // SOFTBAR (s_cnt: an LDS word, zero on entry): the four waves meet at a barrier of their own (lk_soft_barrier) instead of s_barrier - for
 // workgroups in which a fifth wave runs something else meanwhile (k_relpos_decode_fwd: the geometry decoder on wave 4)
+// s_raw (or NULL; wave 0 only reads it): the tile's colours are also left there as raw rows [32][4] (k_relpos_decode_fwd's composite epilogue)
 template <bool DEEP, bool SOFTBAR = false>
 __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
                                               u32x4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */,
-                                              float (*s_bias)[128] /* [10][128] */, unsigned* s_cnt = nullptr) {
+                                              float (*s_bias)[128] /* [10][128] */, unsigned* s_cnt = nullptr, float* s_raw = nullptr) {
     unsigned n_bar = 0;
     auto wg_barrier = [&]() {
         if (SOFTBAR) lk_soft_barrier(s_cnt, 4u * (++n_bar));
@@ -423,6 +428,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
             float* out = a.raw + (size_t)d.sample * 4;
             out[0] = o0; out[1] = o1; out[2] = o2;
         }
+        if (s_raw) { s_raw[4 * lane] = o0; s_raw[4 * lane + 1] = o1; s_raw[4 * lane + 2] = o2; }
     }
     LK_CLK(16);
 }
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col
     }
     const int tile = (bid - n_col_blocks) * 4 + w;
     if (tile * 32 >= P_live) return;
-    decode_geo_wave(a, tile, lane);
+    (void)decode_geo_wave(a, tile, lane);
     if (n_col_blocks == 0) {
         const int sample = tile * 32 + (lane & 31);
         if (sample < a.P && lane < 32) { float* out = a.raw + (size_t)sample * 4; out[0] = 0.0f; out[1] = 0.0f; out[2] = 0.0f; }
@@ -556,22 +562,81 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
 // decoder, no barrier in it - had ended: the hardware barrier waits for every wave of the workgroup that is still alive (shader-clock
 // stamps, profiles/r4_decode_clock32.txt: 23 k cycles in the decode's set-up phase of the tracker's launch against 7.7 k for the same
 // code in the mapper's, where the geometry tiles are workgroups of their own).
-template <bool DEEP, bool SOFTBAR>
-__global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDecodeArgs a) {
+// COMP (with SOFTBAR; the tracking loop): pass 1 of the tracker's loss is the launch's epilogue.  Tiles hold WHOLE rays (a.tile_stride = (32 / S) S
+// samples, 30 of the 32 lanes at S = 5: 250 tiles instead of 235 for 1 500 rays, still one per compute unit); wave 4 leaves its occupancies and
+// wave 0 its colours in LDS as raw rows, wave 0 waits for wave 4 (a counter in LDS, as the soft barrier) and its first lanes composite one ray
+// each (lk_composite_ray on the LDS rows: the arithmetic of k_track_composite), write the ray's outputs and residual, and the tile's
+// (sum of residuals, #present rays) pair - the mask threshold's partial sums are per tile instead of per 256 rays (5 us of an iteration of 117)
+template <bool DEEP, bool SOFTBAR, bool COMP>
+__global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDecodeArgs a, LkTrackLossArgs tl) {
     __shared__ u32x4 s_x[2][16 * 64];
     __shared__ float s_o[4][3 * 32];
     __shared__ float s_bias[10][128];
     __shared__ unsigned s_cnt;
+    __shared__ unsigned s_geo_done;
+    __shared__ __attribute__((aligned(16))) float s_raw[32 * 4];
     const int lane = lk_lane();
     const int w = (int)threadIdx.x >> 6;
     const int tile = (int)blockIdx.x;
-    const int sample0 = tile * 32 + 4 * w;
-    if (threadIdx.x == 0) s_cnt = 0u;
-    if (sample0 < ra.P) relpos_fwd_wave(ra, sample0, ra.P);
+    const int ts = COMP ? a.tile_stride : 32;
+    const int base = tile * ts;
+    const int lim = COMP ? min(ra.P, base + ts) : ra.P;      // the rel-pos rows of the tile's own samples only
+    const int sample0 = base + 4 * w;
+    if (threadIdx.x == 0) { s_cnt = 0u; s_geo_done = 0u; }
+    if (sample0 < lim) relpos_fwd_wave(ra, sample0, lim);
     __syncthreads();                               // the tile's c_col rows are written
     if (w > 4) return;
-    if (w == 4) { decode_geo_wave(a, tile, lane); return; }
-    decode_col_wg<DEEP, SOFTBAR>(a, tile, w, lane, s_x, s_o, s_bias, &s_cnt);
+    if (w == 4) {
+        const float occ = decode_geo_wave(a, tile, lane);
+        if (COMP) {
+            if (lane < 32) s_raw[4 * lane + 3] = occ;
+            __builtin_amdgcn_wave_barrier();       // (the host emulation runs lanes as fibers: every lane's row before lane 0's signal)
+            __threadfence_block();
+            if (lane == 0) atomicAdd(&s_geo_done, 1u);
+        }
+        return;
+    }
+    // the composite's global operands (the ray's reading, its samples' depths and neighbour counts) are fetched here, five layers ahead
+    // of their use: behind the decoder they were a round trip at the end of every tile's chain
+    const int S = COMP ? tl.S : 1;
+    const int n_rays = COMP ? (lim - base) / S : 0;       // P and the tile stride are multiples of S
+    float cz[LK_S_MAX], gd = 0.0f;
+    bool chas[LK_S_MAX];
+#pragma unroll
+    for (int s = 0; s < LK_S_MAX; ++s) { cz[s] = 0.0f; chas[s] = false; }
+    if (COMP && w == 0 && lane < n_rays) {
+        gd = tl.gt_depth[base / S + lane];
+#pragma unroll
+        for (int s = 0; s < LK_S_MAX; ++s) {
+            if (s < S) { cz[s] = tl.z[base + lane * S + s]; chas[s] = tl.nbr_count[base + lane * S + s] >= tl.min_nn; }
+        }
+    }
+    decode_col_wg<DEEP, SOFTBAR>(a, tile, w, lane, s_x, s_o, s_bias, &s_cnt, COMP ? s_raw : nullptr);
+    if (COMP && w == 0) {
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        while (*reinterpret_cast<volatile unsigned*>(&s_geo_done) < 1u) __builtin_amdgcn_s_sleep(1);
+        __threadfence_block();
+        float tv = 0.0f, cv = 0.0f;
+        if (lane < n_rays) {
+            const int r = base / S + lane;
+            float4 q[LK_S_MAX];
+#pragma unroll
+            for (int s = 0; s < LK_S_MAX; ++s) q[s] = (s < S) ? *reinterpret_cast<const float4*>(s_raw + (lane * S + s) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const LkRayOut o = lk_composite_vals(q, chas, cz, S, tl.coef, gd);
+            tl.depth[r] = o.depth; tl.var[r] = o.var;
+            tl.color[3 * r] = o.c0; tl.color[3 * r + 1] = o.c1; tl.color[3 * r + 2] = o.c2;
+            tl.valid_ray[r] = o.valid ? 1 : 0;
+            const bool present = gd > 0.0f;
+            tv = present ? fabsf(gd - o.depth) / sqrtf(o.var + 1e-10f) : 0.0f;
+            cv = present ? 1.0f : 0.0f;
+            tl.resid[r] = tl.median ? (present ? fabsf(gd - o.depth) : -1.0f) : tv;
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { tv += __shfl_xor(tv, o); cv += __shfl_xor(cv, o); }       // n_rays <= 8 (S >= 4)
+        if (lane == 0) { tl.part[2 * tile] = tv; tl.part[2 * tile + 1] = cv; }
+        if (tile == 0 && lane < 4) tl.out4[lane] = 0.0f;        // the loss row pass 2 accumulates into
+    }
 }
 // LK_SOFTBAR=0 switches the colour waves back to s_barrier (A/B)
 static bool lk_softbar() { static const bool on = []{ const char* e = getenv("LK_SOFTBAR"); return e == nullptr || e[0] != '0'; }(); return on; }
@@ -950,15 +1015,28 @@ bool lk_relpos_decode_fusable(const LkDecodeArgs& a) {
     const int tiles = lk_cdiv(a.P, 32);
     return (a.flags & LK_FLAG_STAGE_COLOR) && (a.flags & LK_FLAG_REL_POS) && tiles > 0 && tiles <= LK_DEEP_MAX_TILES_FWD && a.live_rays == nullptr;
 }
-int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, hipStream_t st) {
+// LK_TRACK_COMP_INLINE=0: pass 1 of the tracker's loss stays a launch of its own (k_track_composite; A/B)
+static bool lk_track_comp_inline() { static const bool on = []{ const char* e = getenv("LK_TRACK_COMP_INLINE"); return e == nullptr || e[0] != '0'; }(); return on; }
+int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, hipStream_t st, const LkTrackLossArgs* comp, int* comp_tiles) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
     const int tiles = lk_cdiv(a.P, 32);
     if (lk_c16_fwd()) {
         hipLaunchKernelGGL(k_decode_fwd16<true>, dim3(tiles + lk_cdiv(a.P, 128)), dim3(512), 0, st, ra, a, tiles);
         return LK_OK;
     }
-    if (lk_softbar()) hipLaunchKernelGGL((k_relpos_decode_fwd<true, true>), dim3(tiles), dim3(512), 0, st, ra, a);
-    else hipLaunchKernelGGL((k_relpos_decode_fwd<true, false>), dim3(tiles), dim3(512), 0, st, ra, a);
+    LkTrackLossArgs tl;
+    memset(&tl, 0, sizeof(tl));
+    const int ts = a.S > 0 ? (32 / a.S) * a.S : 0;
+    if (comp && lk_softbar() && lk_track_comp_inline() && a.S >= 4 && a.S <= 32 && a.P % a.S == 0 && comp->S == a.S && lk_cdiv(a.P, ts) <= LK_DEEP_MAX_TILES_FWD) {
+        LkDecodeArgs b = a;
+        b.tile_stride = ts;
+        const int ctiles = lk_cdiv(a.P, ts);
+        hipLaunchKernelGGL((k_relpos_decode_fwd<true, true, true>), dim3(ctiles), dim3(512), 0, st, ra, b, *comp);
+        if (comp_tiles) *comp_tiles = ctiles;
+        return LK_OK;
+    }
+    if (lk_softbar()) hipLaunchKernelGGL((k_relpos_decode_fwd<true, true, false>), dim3(tiles), dim3(512), 0, st, ra, a, tl);
+    else hipLaunchKernelGGL((k_relpos_decode_fwd<true, false, false>), dim3(tiles), dim3(512), 0, st, ra, a, tl);
     return LK_OK;
 }
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {

@@ -59,6 +59,8 @@ struct LkDecodeArgs {
     float* act;                                   // SAVE_ACT scratch or NULL
     const int32_t* live_rays;                     // as LkRelposArgs: tiles behind the live prefix of a partitioned batch are not decoded (the
                                                   // reference never renders those rays: they are filtered out before the render, Mapper.py:645-681)
+    int tile_stride;                              // 0 = 32; k_relpos_decode_fwd with the composite inside: (32 / S) S - a tile holds whole rays,
+                                                  // its lanes >= tile_stride idle
 };
 
 // relative-position neighbour MLP (colour features, Replica config)
@@ -84,6 +86,21 @@ struct LkCompositeBwdArgs {
     int keep_depth;                                // as LkCompositeArgs
 };
 
+// tracker loss in two passes (lk_loop.hip: k_track_composite, then k_track_loss2 or - LkDecodeBwdArgs::tl_n_part - the prologue of k_decode_bwd)
+struct LkTrackLossArgs {
+    int R, S, min_nn;
+    float coef, w_color;
+    int use_color;
+    const float* raw; const float* z; const int32_t* nbr_count; const float* gt_depth; const float* gt_color;
+    float* depth; float* var; float* color; uint8_t* valid_ray;
+    float* d_depth; float* d_color; float* d_raw; float* out4;
+    float* resid;                 // [R] normalised residual of every ray (median: |gt - depth|, sign bit set for an absent ray)
+    float* part;                  // [blocks][2] per-workgroup (sum of residuals, #present rays); median: part[0] = 10 x the median
+    int median;                   // tracking.handle_dynamic: False (LK_TRACK_MEDIAN_MASK): k_track_median runs between the two passes
+    float* row_part;              // [decoder-backward tiles][4] the loss row's terms per tile (pass 2 as the prologue of k_decode_bwd: summed by the
+                                  // pose step, LkTrackFinalArgs::loss_part - 235 tiles x 4 atomics on one line stalled the geometry waves for 14 us)
+};
+
 struct LkDecodeBwdArgs {
     int R, S, P;
     unsigned flags;
@@ -103,6 +120,9 @@ struct LkDecodeBwdArgs {
     const int32_t* live_rays;                      // as LkDecodeArgs
     const float* dscale;                           // [1] device-side power of two on top of the fp16-piece form's 2^10 pre-scale (exposure encoding:
                                                    // the loss gradient is scaled by a LEARNED affine, lk_exposure_desc::bwd_scale), or NULL = 1
+    int tl_n_part;                                 // > 0 (tracking loop): d_raw is NOT read - every lane forms the tracker's loss term of its sample's ray
+    LkTrackLossArgs tl;                            // and the composite backward of it from pass 1's per-ray outputs (tl.part: tl_n_part pairs); the
+                                                   // geometry role adds the loss row (tl.out4)
 };
 
 struct LkTrackFinalArgs {
@@ -115,6 +135,7 @@ struct LkTrackFinalArgs {
     int do_update;                                                 // 0: only the rays of `cam` (before the first iteration)
     const float* cam_in; const float* mv_in;                       // or NULL: the pose / moments are read from here and written to cam / adam_mv
                                                                    // (the step as the prologue of the next iteration's search: every workgroup reads, one writes)
+    const float* loss_part; int n_loss_part; float* log_row;       // or NULL: the stepped iteration's loss row = sum of [n_loss_part][4] (LkTrackLossArgs::row_part)
 };
 // interpolation backward: feature-row scatter (+ tracker: weights -> distances -> positions)
 struct LkInterpBwdArgs {
@@ -156,7 +177,7 @@ struct LkStepRider {
 };
 struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
                     int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale;
-                    uint8_t* act_flag; int signal_rows; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
+                    uint8_t* act_flag; int signal_rows; const LkTrackLossArgs* track_loss; int track_n_part; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
@@ -283,7 +304,7 @@ LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour
 // writable) and, with copy_dst, copy src[0 .. copy_n) over copy_dst (= d->weights, writable) - the blob stepped by the step rider
 struct LkRepackRider { float* frag; const float* src; float* copy_dst; int copy_n; };
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr, const LkRepackRider* repack = nullptr,
-                       const LkTrackFinalArgs* pose = nullptr);       // pose: the tracking loop's pose step as the prologue of the search launch
+                       const LkTrackFinalArgs* pose = nullptr, const LkTrackLossArgs* comp = nullptr, int* comp_tiles = nullptr);       // pose: the tracking loop's pose step as the prologue of the search launch
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total, aff_part; };
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch
@@ -316,7 +337,10 @@ int lk_launch_composite(const LkCompositeArgs& a, hipStream_t st);
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st);
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st);
 bool lk_relpos_decode_fusable(const LkDecodeArgs& a);
-int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, hipStream_t st);       // k_relpos_fwd + k_decode_fwd in one launch
+struct LkTrackLossArgs;
+// comp (tracking loop): pass 1 of the tracker's loss - composite, residuals, per-TILE sums - as the epilogue of the launch; *comp_tiles = the
+// number of (sum, count) pairs it left in comp->part, or 0 where the launch cannot carry it (the caller launches k_track_composite then)
+int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, hipStream_t st, const LkTrackLossArgs* comp = nullptr, int* comp_tiles = nullptr);       // k_relpos_fwd + k_decode_fwd in one launch
 int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs& ib, hipStream_t st);  // k_relpos_bwd + k_interp_bwd in one launch
 
 // activation scratch layout (floats per sample), SAVE_ACT

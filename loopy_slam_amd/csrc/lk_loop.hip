@@ -44,7 +44,6 @@ __device__ __forceinline__ float lp_block_sum_1024(float v, float* sh /*[16]*/) 
     for (int i = 0; i < 16; ++i) s += sh[i];
     return s;
 }
-__device__ __forceinline__ float lp_sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 // ------------------------------------------------------------------ k_pregather
 // Batch assembly of ALL iterations of a frame in one launch (workgroup b = iteration b): pixel gather (get_samples,
 // common.py:237-259), inside mask (Tracker.py:153-160 / Mapper.py:674-681: rejected rays become absent, gt_depth = 0) and - for
@@ -162,17 +161,6 @@ __global__ __launch_bounds__(1024) void k_pregather(LkPregatherArgs a) {
 }
 
 // ------------------------------------------------------------------ tracker loss in two many-workgroup launches
-struct LkTrackLossArgs {
-    int R, S, min_nn;
-    float coef, w_color;
-    int use_color;
-    const float* raw; const float* z; const int32_t* nbr_count; const float* gt_depth; const float* gt_color;
-    float* depth; float* var; float* color; uint8_t* valid_ray;
-    float* d_depth; float* d_color; float* d_raw; float* out4;
-    float* resid;                 // [R] normalised residual of every ray (median: |gt - depth|, sign bit set for an absent ray)
-    float* part;                  // [blocks][2] per-workgroup (sum of residuals, #present rays); median: part[0] = 10 x the median
-    int median;                   // tracking.handle_dynamic: False (LK_TRACK_MEDIAN_MASK): k_track_median runs between the two passes
-};
 // pass 1: raw2outputs_nerf_color (common.py:382-422) + the uncertainty-normalised residual of every ray and its block sums
 __global__ __launch_bounds__(256) void k_track_composite(LkTrackLossArgs a) {
     __shared__ float sh[2][4];
@@ -208,32 +196,15 @@ __global__ __launch_bounds__(1024) void k_track_median(LkTrackLossArgs a) {
 }
 __global__ __launch_bounds__(256) void k_track_loss2(LkTrackLossArgs a, int n_part) {
     __shared__ float sh[3][4];
-    float thr;
-    if (a.median) {
-        thr = a.part[0];
-    } else {
-        float tsum = 0.0f, csum = 0.0f;
-        for (int b = 0; b < n_part; ++b) { tsum += a.part[2 * b]; csum += a.part[2 * b + 1]; }
-        thr = 10.0f * (tsum / fmaxf(csum, 1.0f));
-    }
+    const float thr = lk_track_threshold(a, n_part);
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
     float geo = 0.0f, col = 0.0f, cnt = 0.0f;
     if (r < a.R) {
-        const float d = a.depth[r], v = a.var[r], g = a.gt_depth[r], tm = a.resid[r];
-        const float tt = a.median ? fabsf(g - d) / sqrtf(v + 1e-10f) : tm;          // the loss term stays uncertainty-normalised
-        const bool m = (tm < thr) && (g > 0.0f) && !(d != d) && !(v != v);
-        float dd = 0.0f, dc0 = 0.0f, dc1 = 0.0f, dc2 = 0.0f;
-        if (m) {
-            geo = fminf(fmaxf(tt, 0.0f), 1e3f);
-            if (tt <= 1e3f) dd = lp_sgn(d - g) / sqrtf(v + 1e-10f);
-            cnt = 1.0f;
-            const float e0 = a.color[3 * r] - a.gt_color[3 * r], e1 = a.color[3 * r + 1] - a.gt_color[3 * r + 1], e2 = a.color[3 * r + 2] - a.gt_color[3 * r + 2];
-            col = fabsf(e0) + fabsf(e1) + fabsf(e2);
-            if (a.use_color) { dc0 = a.w_color * lp_sgn(e0); dc1 = a.w_color * lp_sgn(e1); dc2 = a.w_color * lp_sgn(e2); }
-        }
-        a.d_depth[r] = dd;
-        a.d_color[3 * r] = dc0; a.d_color[3 * r + 1] = dc1; a.d_color[3 * r + 2] = dc2;
-        lk_composite_bwd_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, g, dd, 0.0f, dc0, dc1, dc2, a.d_raw);
+        const LkTrackRayLoss o = lk_track_ray_loss(a, r, thr);
+        geo = o.geo; col = o.col; cnt = o.cnt;
+        a.d_depth[r] = o.dd;
+        a.d_color[3 * r] = o.dc0; a.d_color[3 * r + 1] = o.dc1; a.d_color[3 * r + 2] = o.dc2;
+        lk_composite_bwd_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, o.gt, o.dd, 0.0f, o.dc0, o.dc1, o.dc2, a.d_raw);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { geo += __shfl_xor(geo, o); col += __shfl_xor(col, o); cnt += __shfl_xor(cnt, o); }
@@ -270,7 +241,13 @@ void adam_scalars(float lr, int step, float beta1, float beta2, float* step_size
     *bc2_sqrt = (float)sqrt(bc2);
 }
 int64_t al4(int64_t x) { return (x + 3) / 4 * 4; }
-struct TrackWork { int64_t gt_depth, gt_color, pix_i, pix_j, r2_ray, thr, resid, loss_part, pose_part, ring, total; };
+// pass 1's (sum, count) pairs: one per 256 rays (k_track_composite) or one per tile of whole rays (k_relpos_decode_fwd's epilogue)
+static int64_t track_loss_parts(int64_t R, int64_t S) {
+    const int64_t s = S < 1 ? 1 : (S > 32 ? 32 : S), ts = (32 / s) * s;
+    const int64_t a = (R + 255) / 256, b = (R * S + ts - 1) / ts;
+    return a > b ? a : b;
+}
+struct TrackWork { int64_t gt_depth, gt_color, pix_i, pix_j, r2_ray, thr, resid, loss_part, pose_part, row_part, ring, total; };
 TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     TrackWork w;
     int64_t o = 0;
@@ -281,8 +258,9 @@ TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     w.r2_ray = o; o += al4(iters * R);
     w.thr = o; o += al4(iters);
     w.resid = o; o += al4(R);
-    w.loss_part = o; o += al4(2 * ((R + 255) / 256));
+    w.loss_part = o; o += al4(2 * track_loss_parts(R, S));
     w.pose_part = o; o += al4(12 * (int64_t)lk_bwd_pose_parts(R * S));
+    w.row_part = o; o += 4 * (int64_t)lk_bwd_pose_parts(R * S);      // LkTrackLossArgs::row_part
     w.ring = o; o += 48;              // two poses [2][8] and their Adam moments [2][16]: the pose step as the prologue of the next search launch
     w.total = o;
     return w;
@@ -359,6 +337,9 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     const TrackWork wk = track_work(R, S, iters);
     float* W0 = d->work;
     const int n_pose = lk_bwd_pose_parts((int64_t)R * S), n_lp = lk_cdiv(R, 256);
+    // the loss terms and the composite backward as the prologue of the decoder backward (LK_TRACK_LOSS_INLINE=0: k_track_loss2, A/B)
+    static const bool loss_inline_on = []{ const char* e = getenv("LK_TRACK_LOSS_INLINE"); return e == nullptr || e[0] != '0'; }();
+    const bool loss_inline = fused && loss_inline_on;
     LkTrackFinalArgs fa;
     memset(&fa, 0, sizeof(fa));
     if (fused) {
@@ -426,20 +407,29 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             pa.mv_in = W0 + wk.ring + 16 + 16 * ((it - 1) & 1); pa.adam_mv = W0 + wk.ring + 16 + 16 * (it & 1);
             pa.rays_o = const_cast<float*>(rd.rays_o); pa.rays_d = const_cast<float*>(rd.rays_d);
             pa.next_pix_i = W0 + wk.pix_i + (size_t)it * R; pa.next_pix_j = W0 + wk.pix_j + (size_t)it * R;
+            if (loss_inline) { pa.loss_part = W0 + wk.row_part; pa.n_loss_part = n_pose; pa.log_row = d->log + (size_t)(it - 1) * 4; }
         }
-        int rc = lk_render_fwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE | LK_FUSE_SMALL) : 0, nullptr, nullptr, (prologue && it > 0) ? &pa : nullptr);
-        if (rc != LK_OK) return rc;
+        LkTrackLossArgs la;
+        memset(&la, 0, sizeof(la));
         if (fused) {
-            LkTrackLossArgs la;
             la.R = R; la.S = S; la.min_nn = rd.min_nn; la.coef = rd.coef; la.w_color = d->w_color;
             la.use_color = d->use_color & LK_TRACK_USE_COLOR; la.median = (d->use_color & LK_TRACK_MEDIAN_MASK) ? 1 : 0;
             la.raw = rd.raw; la.z = rd.z; la.nbr_count = rd.nbr_count; la.gt_depth = rd.gt_depth; la.gt_color = gt_color;
             la.depth = rd.depth; la.var = rd.var; la.color = rd.color; la.valid_ray = rd.valid_ray;
             la.d_depth = const_cast<float*>(rd.d_depth); la.d_color = const_cast<float*>(rd.d_color);
             la.d_raw = rd.bwd_scratch + off.d_raw; la.out4 = log_row; la.resid = W0 + wk.resid; la.part = W0 + wk.loss_part;
-            hipLaunchKernelGGL(k_track_composite, dim3(n_lp), dim3(256), 0, st, la);
+            la.row_part = W0 + wk.row_part;
+        }
+        // (pass 1 of the loss rides in the forward's launch where it can: comp_tiles = its number of partial pairs)
+        int comp_tiles = 0;
+        int rc = lk_render_fwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE | LK_FUSE_SMALL) : 0, nullptr, nullptr, (prologue && it > 0) ? &pa : nullptr,
+                                    fused ? &la : nullptr, &comp_tiles);
+        if (rc != LK_OK) return rc;
+        const int n_part = comp_tiles > 0 ? comp_tiles : n_lp;
+        if (fused) {
+            if (comp_tiles == 0) hipLaunchKernelGGL(k_track_composite, dim3(n_lp), dim3(256), 0, st, la);
             if (la.median) hipLaunchKernelGGL(k_track_median, dim3(1), dim3(1024), 0, st, la);
-            hipLaunchKernelGGL(k_track_loss2, dim3(n_lp), dim3(256), 0, st, la, n_lp);
+            if (!loss_inline) hipLaunchKernelGGL(k_track_loss2, dim3(n_lp), dim3(256), 0, st, la, n_part);
         } else {
             rc = lk_loss_tracker(R, rd.depth, rd.var, rd.color, rd.gt_depth, d->gt_color, d->w_color, d->use_color,
                                  const_cast<float*>(rd.d_depth), const_cast<float*>(rd.d_color), log_row, d->loss_scratch, st);
@@ -447,6 +437,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         }
         LkBwdExtra ex;
         memset(&ex, 0, sizeof(ex));
+        if (fused && loss_inline) { ex.track_loss = &la; ex.track_n_part = n_part; }
         ex.pose_part = fused ? W0 + wk.pose_part : nullptr;
         ex.dscale = (xd && (rd.flags & LK_FLAG_UNIT_LOSS_GRADS)) ? xd->bwd_scale : nullptr;
         ex.pix_i = W0 ? W0 + wk.pix_i + (size_t)it * R : nullptr; ex.pix_j = W0 ? W0 + wk.pix_j + (size_t)it * R : nullptr;
@@ -470,6 +461,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
                 fa.cam_in = W0 + wk.ring + 8 * (it & 1); fa.mv_in = W0 + wk.ring + 16 + 16 * (it & 1);
             }
             fa.step_T = step_T; fa.step_q = step_q; fa.bc2_sqrt = bc2s; fa.do_update = 1;
+            if (loss_inline) { fa.loss_part = W0 + wk.row_part; fa.n_loss_part = n_pose; fa.log_row = log_row; }
             fa.hist_pre = d->hist_post ? nullptr : hist_row; fa.hist_post = d->hist_post ? hist_row : nullptr;
             const bool more = it + 1 < iters;
             fa.rays_o = more ? const_cast<float*>(rd.rays_o) : nullptr; fa.rays_d = const_cast<float*>(rd.rays_d);

@@ -3,6 +3,46 @@
 #pragma once
 #include "lk_common.h"
 #include "lk_kernels.h"
+#include "lk_composite_dev.h"
+
+__device__ __forceinline__ float lp_sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+// ---- the tracker's loss (Tracker.py:169-191) per ray, shared by k_track_loss2 and the prologue of the tracking loop's k_decode_bwd
+// mask threshold 10 x the batch mean of the normalised residuals from pass 1's block sums: a whole wave calls, every wave of every workgroup
+// adds the same pairs in the same order - the same threshold everywhere
+__device__ __forceinline__ float lk_track_threshold(const LkTrackLossArgs& a, int n_part) {
+    if (a.median) return a.part[0];
+    float ts = 0.0f, cs = 0.0f;
+    for (int b = lk_lane(); b < n_part; b += 64) { ts += a.part[2 * b]; cs += a.part[2 * b + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ts += __shfl_xor(ts, o); cs += __shfl_xor(cs, o); }
+    return 10.0f * (ts / fmaxf(cs, 1.0f));
+}
+struct LkTrackRayLoss { float dd, dc0, dc1, dc2, geo, col, cnt, gt; };
+__device__ __forceinline__ LkTrackRayLoss lk_track_ray_loss(const LkTrackLossArgs& a, int r, float thr) {
+    LkTrackRayLoss o;
+    const float d = a.depth[r], v = a.var[r], g = a.gt_depth[r], tm = a.resid[r];
+    const float tt = a.median ? fabsf(g - d) / sqrtf(v + 1e-10f) : tm;          // the loss term stays uncertainty-normalised
+    const bool m = (tm < thr) && (g > 0.0f) && !(d != d) && !(v != v);
+    o.dd = 0.0f; o.dc0 = 0.0f; o.dc1 = 0.0f; o.dc2 = 0.0f; o.geo = 0.0f; o.col = 0.0f; o.cnt = 0.0f; o.gt = g;
+    if (m) {
+        o.geo = fminf(fmaxf(tt, 0.0f), 1e3f);
+        if (tt <= 1e3f) o.dd = lp_sgn(d - g) / sqrtf(v + 1e-10f);
+        o.cnt = 1.0f;
+        const float e0 = a.color[3 * r] - a.gt_color[3 * r], e1 = a.color[3 * r + 1] - a.gt_color[3 * r + 1], e2 = a.color[3 * r + 2] - a.gt_color[3 * r + 2];
+        o.col = fabsf(e0) + fabsf(e1) + fabsf(e2);
+        if (a.use_color) { o.dc0 = a.w_color * lp_sgn(e0); o.dc1 = a.w_color * lp_sgn(e1); o.dc2 = a.w_color * lp_sgn(e2); }
+    }
+    return o;
+}
+// d raw of sample sp (its lane calls; all 64 lanes of the wave must call - the threshold is a wave sum); *row: the ray's loss terms
+__device__ __forceinline__ float4 lk_track_draw(const LkTrackLossArgs& a, int n_part, int sp, LkTrackRayLoss* row) {
+    const float thr = lk_track_threshold(a, n_part);
+    const int r = sp / a.S;
+    const LkTrackRayLoss o = lk_track_ray_loss(a, r, thr);
+    if (row) *row = o;
+    return lk_composite_bwd_sample(a.raw, a.z, a.nbr_count, r, a.S, sp - r * a.S, a.min_nn, a.coef, o.gt, o.dd, 0.0f, o.dc0, o.dc1, o.dc2);
+}
 
 __device__ __forceinline__ void lp_quat_rot(const float* __restrict__ cam, float (&Rm)[9]) {       // common.py:301-324
     const float qr = cam[0], qi = cam[1], qj = cam[2], qk = cam[3];
@@ -18,8 +58,8 @@ __device__ __forceinline__ void lp_quat_rot(const float* __restrict__ cam, float
 // write: store the pose, its moments, the gradient and the log row (exactly one workgroup of a launch does).
 template <int NW>
 __device__ __forceinline__ void lk_track_pose_step(const LkTrackFinalArgs& a, float* __restrict__ s_cam, bool write) {
-    __shared__ float s_w[NW][12];
-    __shared__ float acc[12];
+    __shared__ float s_w[NW][16];
+    __shared__ float acc[16];
     const int t = threadIdx.x;
     float cam0[7], mv0[14];
     if (t == 0) {       // issued first: these do not depend on the partial sums
@@ -31,28 +71,35 @@ __device__ __forceinline__ void lk_track_pose_step(const LkTrackFinalArgs& a, fl
         for (int e = 0; e < 14; ++e) mv0[e] = a.do_update ? mi[e] : 0.0f;
     }
     if (a.do_update) {
-        float v12[12];
+        float v12[16];                       // 12 ray moments + the 4 terms of the iteration's loss row (a.loss_part)
 #pragma unroll
-        for (int q = 0; q < 12; ++q) v12[q] = 0.0f;
+        for (int q = 0; q < 16; ++q) v12[q] = 0.0f;
         for (int b = t; b < a.n_part; b += 64 * NW) {
 #pragma unroll
             for (int q = 0; q < 12; ++q) v12[q] += a.pose_part[(size_t)b * 12 + q];
         }
+        if (a.loss_part) {
+            for (int b = t; b < a.n_loss_part; b += 64 * NW) {
+                const float4 v = *reinterpret_cast<const float4*>(a.loss_part + (size_t)b * 4);
+                v12[12] += v.x; v12[13] += v.y; v12[14] += v.z; v12[15] += v.w;
+            }
+        }
 #pragma unroll
-        for (int q = 0; q < 12; ++q) {
+        for (int q = 0; q < 16; ++q) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v12[q] += __shfl_xor(v12[q], o);
         }
         if (lk_lane() == 0) {
 #pragma unroll
-            for (int q = 0; q < 12; ++q) s_w[t >> 6][q] = v12[q];
+            for (int q = 0; q < 16; ++q) s_w[t >> 6][q] = v12[q];
         }
         __syncthreads();
-        if (t < 12) {
+        if (t < 16) {
             float s = 0.0f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += s_w[w][t];
             acc[t] = s;
+            if (write && a.log_row && a.loss_part && t >= 12) a.log_row[t - 12] = s;
         }
         __syncthreads();
         if (t == 0) {
