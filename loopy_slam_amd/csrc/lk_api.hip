@@ -245,6 +245,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     if (!fuse_small) lk_launch_decode_fwd(da, st);
 
     if (skip & LK_SKIP_COMPOSITE) { LK_LAUNCH_CHECK(); return LK_OK; }     // the caller composites (fused loss kernel, lk_loop.hip)
+    if ((skip & LK_COMPOSITE_IN_BWD) && (d->flags & LK_FLAG_MAPPER_LOSS)) { LK_LAUNCH_CHECK(); return LK_OK; }     // ... or the decoder backward does
     LkCompositeArgs ca;
     ca.R = d->R; ca.S = d->S; ca.min_nn = d->min_nn; ca.coef = d->coef;
     ca.raw = d->raw; ca.z = d->z; ca.nbr_count = d->nbr_count; ca.gt_depth = d->gt_depth;
@@ -413,6 +414,20 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.dscale = ex ? ex->dscale : nullptr;
     db.tl_n_part = 0;
     memset(&db.tl, 0, sizeof(db.tl));
+    db.ml_on = 0; db.ml_row_part = nullptr;
+    memset(&db.ml, 0, sizeof(db.ml));
+    if ((skip & LK_COMPOSITE_IN_BWD) && (flags & LK_FLAG_MAPPER_LOSS)) {      // as the composite launch of lk_render_fwd_impl would have been set up
+        LK_REQUIRE(ex && ex->loss_rows && d->d_depth && d->d_color && d->loss_gt_color && (skip & LK_SKIP_COMPOSITE_BWD),
+                   "lk_render_bwd: the composite inside the decoder backward needs loss_rows, loss_gt_color, d_depth, d_color");
+        LkCompositeArgs& ca = db.ml;
+        ca.R = d->R; ca.S = d->S; ca.min_nn = d->min_nn; ca.coef = d->coef;
+        ca.raw = d->raw; ca.z = d->z; ca.nbr_count = d->nbr_count; ca.gt_depth = d->gt_depth;
+        ca.depth = d->depth; ca.var = d->var; ca.color = d->color; ca.valid_ray = d->valid_ray;
+        ca.keep_depth = (flags & LK_FLAG_Z_GIVEN) ? 1 : 0;
+        ca.gt_color = d->loss_gt_color; ca.w_color = d->loss_w_color; ca.use_color = color ? 1 : 0;
+        ca.d_depth = const_cast<float*>(d->d_depth); ca.d_color = const_cast<float*>(d->d_color);
+        db.ml_on = 1; db.ml_row_part = ex->loss_rows;
+    }
     if (ex && ex->track_loss) {      // tracking loop: the loss and the composite backward are the launch's prologue (no d_raw array)
         LK_REQUIRE((flags & LK_FLAG_GRAD_RAYS) != 0 && ex->track_n_part > 0, "lk_render_bwd: the inline tracker loss needs ray gradients");
         db.tl = *ex->track_loss; db.tl_n_part = ex->track_n_part;

@@ -118,7 +118,8 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128;            // layer-major: + LK_COL_LAYER(P, layer)
     const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128;
     float4 draw;
-    if (TL && a.tl_n_part > 0) draw = lk_track_draw(a.tl, a.tl_n_part, sp, nullptr);
+    if (a.ml_on) { float t0, t1, t2; draw = lk_map_draw(a.ml, sp, false, &t0, &t1, &t2); }
+    else if (TL && a.tl_n_part > 0) draw = lk_track_draw(a.tl, a.tl_n_part, sp, nullptr);
     else draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
     if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
     float g0 = draw.x, g1 = draw.y, g2 = draw.z;
@@ -374,7 +375,17 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     const float* act_geo = a.act + (size_t)sp * LK_ACT_GEO_A;
     float4 draw;
-    if (!GH16 && a.tl_n_part > 0) {
+    if (a.ml_on) {
+        // mapping loop: composite, loss term and composite backward here instead of in k_composite (7-9 us of every iteration); the lane of a
+        // ray's first sample stores the ray's outputs, the tile's terms of the loss row go to ml_row_part
+        const bool first = live && h == 0 && sp % a.S == 0;
+        float G, C, N;
+        draw = lk_map_draw(a.ml, sp, first, &G, &C, &N);
+        if (!first) { G = 0.0f; C = 0.0f; N = 0.0f; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { G += __shfl_xor(G, o); C += __shfl_xor(C, o); N += __shfl_xor(N, o); }
+        if (lane == 0) *reinterpret_cast<float4*>(a.ml_row_part + (size_t)tile * 4) = make_float4(G + (a.ml.use_color ? a.ml.w_color * C : 0.0f), G, C, N);
+    } else if (!GH16 && a.tl_n_part > 0) {
         // tracking loop: the loss term of the sample's ray and the composite backward of it, here instead of in a launch of its own
         // (k_track_loss2: 6 us of an iteration of 117); the ray's first sample carries its terms to the loss row (Tracker.py:183-191)
         LkTrackRayLoss row;

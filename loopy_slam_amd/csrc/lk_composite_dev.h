@@ -3,6 +3,7 @@
 // fused forms of the tracking loop (lk_loop.hip).
 #pragma once
 #include "lk_common.h"
+#include "lk_kernels.h"
 
 struct LkRayOut { float depth, var, c0, c1, c2; bool valid; };
 
@@ -57,56 +58,80 @@ __device__ __forceinline__ LkRayOut lk_composite_ray(const float* __restrict__ r
     return lk_composite_vals(q, has, z, S, coef, gt_depth);
 }
 
-// d(depth, var, colour) -> d raw[S][4] of one ray (the forward is recomputed from raw), left in out[s]
-__device__ __forceinline__ void lk_composite_bwd_ray_core(const float* __restrict__ raw_, const float* __restrict__ zbuf,
-                                                          const int32_t* __restrict__ nbr_count, int r, int S, int min_nn, float coef,
-                                                          float gt_depth, float d_depth, float gvar, float g0, float g1, float g2,
-                                                          float4 (&out)[LK_S_MAX]) {
+// The composite of one ray as its backward needs it (recomputed from raw): per-sample alpha / transmittance / weight, the normalised outputs
+struct LkRayState {
     float al[LK_S_MAX], be[LK_S_MAX], Tt[LK_S_MAX], wv[LK_S_MAX], zv[LK_S_MAX], cr[LK_S_MAX], cg[LK_S_MAX], cb[LK_S_MAX];
+    float W, depth, col0, col1, col2;
+    int nhas;
+};
+__device__ __forceinline__ void lk_ray_state(const float* __restrict__ raw_, const float* __restrict__ zbuf, const int32_t* __restrict__ nbr_count,
+                                             int r, int S, int min_nn, float coef, LkRayState& st) {
     float T = 1.0f, wsum = 0.0f, dsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    st.nhas = 0;
 #pragma unroll
     for (int s = 0; s < LK_S_MAX; ++s) {
-        al[s] = be[s] = Tt[s] = wv[s] = zv[s] = cr[s] = cg[s] = cb[s] = 0.0f;
+        st.al[s] = st.be[s] = st.Tt[s] = st.wv[s] = st.zv[s] = st.cr[s] = st.cg[s] = st.cb[s] = 0.0f;
         if (s < S) {
             const int p = r * S + s;
             const float4 raw = *reinterpret_cast<const float4*>(raw_ + (size_t)p * 4);
             const bool has = nbr_count[p] >= min_nn;
+            st.nhas += has ? 1 : 0;
             const float occ = has ? raw.w : -100.0f;
             const float alpha = lk_sigmoid(coef * occ);
-            al[s] = alpha; Tt[s] = T; be[s] = 1.0f - alpha + 1e-10f;
+            st.al[s] = alpha; st.Tt[s] = T; st.be[s] = 1.0f - alpha + 1e-10f;
             const float w = alpha * T;
-            T *= be[s];
-            wv[s] = w; zv[s] = zbuf[p];
-            cr[s] = raw.x; cg[s] = raw.y; cb[s] = raw.z;
-            wsum += w; dsum += w * zv[s];
+            T *= st.be[s];
+            st.wv[s] = w; st.zv[s] = zbuf[p];
+            st.cr[s] = raw.x; st.cg[s] = raw.y; st.cb[s] = raw.z;
+            wsum += w; dsum += w * st.zv[s];
             c0 += w * raw.x; c1 += w * raw.y; c2 += w * raw.z;
         }
     }
-    const float W = wsum + 1e-10f;
-    const float depth = dsum / W;
-    const float col0 = c0 / W, col1 = c1 / W, col2 = c2 / W;
+    st.W = wsum + 1e-10f;
+    st.depth = dsum / st.W;
+    st.col0 = c0 / st.W; st.col1 = c1 / st.W; st.col2 = c2 / st.W;
+}
+__device__ __forceinline__ float lk_ray_var(const LkRayState& st) {
+    float var = 0.0f;
+#pragma unroll
+    for (int s = 0; s < LK_S_MAX; ++s) { const float t = st.zv[s] - st.depth; var += st.wv[s] * t * t; }
+    return var;
+}
+// d(depth, var, colour) -> d raw[S][4] of the ray, left in out[s]
+__device__ __forceinline__ void lk_ray_grad(const LkRayState& st, int S, float coef, float gt_depth, float d_depth, float gvar, float g0, float g1, float g2,
+                                            float4 (&out)[LK_S_MAX]) {
+    const float W = st.W, depth = st.depth;
     float gdep = (gt_depth > 0.0f) ? d_depth : 0.0f;                    // depth of zero-depth rays is overwritten
     float dvar_ddepth = 0.0f;
 #pragma unroll
-    for (int s = 0; s < LK_S_MAX; ++s) dvar_ddepth += -2.0f * wv[s] * (zv[s] - depth);
+    for (int s = 0; s < LK_S_MAX; ++s) dvar_ddepth += -2.0f * st.wv[s] * (st.zv[s] - depth);
     gdep += gvar * dvar_ddepth;
     float gw[LK_S_MAX];
 #pragma unroll
     for (int s = 0; s < LK_S_MAX; ++s) {
-        const float dz = zv[s] - depth;
-        gw[s] = (gdep * dz + g0 * (cr[s] - col0) + g1 * (cg[s] - col1) + g2 * (cb[s] - col2)) / W + gvar * dz * dz;
+        const float dz = st.zv[s] - depth;
+        gw[s] = (gdep * dz + g0 * (st.cr[s] - st.col0) + g1 * (st.cg[s] - st.col1) + g2 * (st.cb[s] - st.col2)) / W + gvar * dz * dz;
     }
     float suffix = 0.0f;                                                // sum_{u>s} gw_u w_u
 #pragma unroll
     for (int s = LK_S_MAX - 1; s >= 0; --s) {
         if (s < S) {
-            const float galpha = gw[s] * Tt[s] - suffix / be[s];
-            const float gocc = galpha * al[s] * (1.0f - al[s]) * coef;
-            suffix += gw[s] * wv[s];
-            const float k = wv[s] / W;
+            const float galpha = gw[s] * st.Tt[s] - suffix / st.be[s];
+            const float gocc = galpha * st.al[s] * (1.0f - st.al[s]) * coef;
+            suffix += gw[s] * st.wv[s];
+            const float k = st.wv[s] / W;
             out[s] = make_float4(g0 * k, g1 * k, g2 * k, gocc);
         } else out[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+}
+// d(depth, var, colour) -> d raw[S][4] of one ray (the forward is recomputed from raw), left in out[s]
+__device__ __forceinline__ void lk_composite_bwd_ray_core(const float* __restrict__ raw_, const float* __restrict__ zbuf,
+                                                          const int32_t* __restrict__ nbr_count, int r, int S, int min_nn, float coef,
+                                                          float gt_depth, float d_depth, float gvar, float g0, float g1, float g2,
+                                                          float4 (&out)[LK_S_MAX]) {
+    LkRayState st;
+    lk_ray_state(raw_, zbuf, nbr_count, r, S, min_nn, coef, st);
+    lk_ray_grad(st, S, coef, gt_depth, d_depth, gvar, g0, g1, g2, out);
 }
 __device__ __forceinline__ void lk_composite_bwd_ray(const float* __restrict__ raw_, const float* __restrict__ zbuf,
                                                      const int32_t* __restrict__ nbr_count, int r, int S, int min_nn, float coef,
@@ -124,6 +149,48 @@ __device__ __forceinline__ float4 lk_composite_bwd_sample(const float* __restric
                                                           float gt_depth, float d_depth, float gvar, float g0, float g1, float g2) {
     float4 out[LK_S_MAX];
     lk_composite_bwd_ray_core(raw_, zbuf, nbr_count, r, S, min_nn, coef, gt_depth, d_depth, gvar, g0, g1, g2, out);
+    float4 o = out[0];
+#pragma unroll
+    for (int s = 1; s < LK_S_MAX; ++s)
+        if (s == s_own) o = out[s];
+    return o;
+}
+
+// The mapper's loss (Mapper.py:691-720) of the ray of sample sp and the composite backward of it for that sample - k_composite's arithmetic (forward,
+// mask, terms, gradients) with the ray recomputed by the sample's own lane.  write_ray: this lane also stores the ray's outputs (one lane per ray does);
+// *geo / *col / *cnt: the ray's terms of the loss row.
+__device__ __forceinline__ float4 lk_map_draw(const LkCompositeArgs& a, int sp, bool write_ray, float* geo, float* col, float* cnt) {
+    const int S = a.S;
+    const int r = sp / S, s_own = sp - r * S;
+    const float gd = a.gt_depth[r];
+    LkRayState st;
+    lk_ray_state(a.raw, a.z, a.nbr_count, r, S, a.min_nn, a.coef, st);
+    const float dout = ((a.keep_depth ? 1.0f : gd) > 0.0f) ? st.depth : 0.0f;             // Renderer.py:197-198
+    const bool valid = st.nhas >= S / 2 + 1;
+    const bool m = (gd > 0.0f) && valid && !(dout != dout);
+    float dd = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, l_geo = 0.0f, l_col = 0.0f, l_cnt = 0.0f;
+    if (m) {
+        l_geo = fabsf(gd - dout);
+        dd = (dout > gd) ? 1.0f : ((dout < gd) ? -1.0f : 0.0f);
+        l_cnt = 1.0f;
+        if (a.use_color) {
+            const float e0 = st.col0 - a.gt_color[3 * r], e1 = st.col1 - a.gt_color[3 * r + 1], e2 = st.col2 - a.gt_color[3 * r + 2];
+            l_col = fabsf(e0) + fabsf(e1) + fabsf(e2);
+            d0 = a.w_color * ((e0 > 0.0f) ? 1.0f : ((e0 < 0.0f) ? -1.0f : 0.0f));
+            d1 = a.w_color * ((e1 > 0.0f) ? 1.0f : ((e1 < 0.0f) ? -1.0f : 0.0f));
+            d2 = a.w_color * ((e2 > 0.0f) ? 1.0f : ((e2 < 0.0f) ? -1.0f : 0.0f));
+        }
+    }
+    if (write_ray) {
+        a.depth[r] = dout; a.var[r] = lk_ray_var(st);
+        a.color[3 * r] = st.col0; a.color[3 * r + 1] = st.col1; a.color[3 * r + 2] = st.col2;
+        a.valid_ray[r] = valid ? 1 : 0;
+        a.d_depth[r] = dd;
+        a.d_color[3 * r] = d0; a.d_color[3 * r + 1] = d1; a.d_color[3 * r + 2] = d2;
+    }
+    *geo = l_geo; *col = l_col; *cnt = l_cnt;
+    float4 out[LK_S_MAX];
+    lk_ray_grad(st, S, a.coef, gd, dd, 0.0f, d0, d1, d2, out);
     float4 o = out[0];
 #pragma unroll
     for (int s = 1; s < LK_S_MAX; ++s)

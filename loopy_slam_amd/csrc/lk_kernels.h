@@ -120,6 +120,10 @@ struct LkDecodeBwdArgs {
     const int32_t* live_rays;                      // as LkDecodeArgs
     const float* dscale;                           // [1] device-side power of two on top of the fp16-piece form's 2^10 pre-scale (exposure encoding:
                                                    // the loss gradient is scaled by a LEARNED affine, lk_exposure_desc::bwd_scale), or NULL = 1
+    int ml_on;                                     // 1 (mapping loop, LK_COMPOSITE_IN_BWD): d_raw is NOT read and k_composite was NOT launched - every
+    LkCompositeArgs ml;                            // lane composites its sample's ray from raw, forms the mapper's loss term (Mapper.py:691-720) and the
+    float* ml_row_part;                            // composite backward of it; the geometry role writes the ray's outputs and the loss row's terms of
+                                                   // its tile ([tiles][4], summed per iteration at the end of the lk_map_frame call)
     int tl_n_part;                                 // > 0 (tracking loop): d_raw is NOT read - every lane forms the tracker's loss term of its sample's ray
     LkTrackLossArgs tl;                            // and the composite backward of it from pass 1's per-ray outputs (tl.part: tl_n_part pairs); the
                                                    // geometry role adds the loss row (tl.out4)
@@ -177,7 +181,8 @@ struct LkStepRider {
 };
 struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
                     int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale;
-                    uint8_t* act_flag; int signal_rows; const LkTrackLossArgs* track_loss; int track_n_part; };     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
+                    uint8_t* act_flag; int signal_rows; const LkTrackLossArgs* track_loss; int track_n_part;
+                    float* loss_rows; };           // LK_COMPOSITE_IN_BWD: LkDecodeBwdArgs::ml_row_part of this iteration     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 struct LkFeatScatterArgs {
@@ -290,6 +295,7 @@ enum { LK_SKIP_COMPOSITE = 1, LK_SKIP_COMPOSITE_BWD = 2, LK_SKIP_RAYS_BWD = 4, L
        LK_SEG_SORTED = 32 /* bwd: the forward (LK_FUSE_COMPOSITE_BWD + GRAD_FEATS) already sorted the rows by point */,
        LK_PRESAMPLED = 64 /* fwd: z / nbr_idx / nbr_w / nbr_count are given (lk_presample), only interpolate */,
        LK_SKIP_AFF_REDUCE = 256 /* bwd: the caller sums the per-tile d affine partials itself (k_track_final's exposure workgroup) */,
+       LK_COMPOSITE_IN_BWD = 512 /* mapping loop (MAPPER_LOSS): fwd launches no composite; bwd forms d raw in the prologue of k_decode_bwd (LkBwdExtra::loss_rows) */,
        LK_FUSE_SMALL = 128 /* tracker-sized batches: rel-pos MLP + decoders in one launch (fwd), rel-pos backward + interpolation backward in one (bwd) */ };
 // cnt: the batch holds n iterations of P_iter samples each (n <= LK_SEG_BATCH); their rows are counted per point on the way
 struct LkPresampleCount { int P_iter; int32_t* seg_rank; const int32_t* live_rays; const int32_t* key_of; };

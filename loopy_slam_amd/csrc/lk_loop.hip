@@ -219,6 +219,30 @@ __global__ __launch_bounds__(256) void k_track_loss2(LkTrackLossArgs a, int n_pa
     }
 }
 
+// loss rows of the iterations [it0, it0 + gridDim.x) of an lk_map_frame call from the per-tile terms k_decode_bwd left (LK_COMPOSITE_IN_BWD):
+// one workgroup per iteration, fixed order, no atomics; tiles behind the live prefix of a partitioned batch were not processed
+__global__ __launch_bounds__(256) void k_loss_rows_sum(const float* __restrict__ rows, int tiles, int P, int S, const int32_t* __restrict__ n_live, int it0,
+                                                        float* __restrict__ log) {
+    __shared__ float4 sh[4];
+    const int it = it0 + (int)blockIdx.x;
+    const int P_live = n_live ? min(P, n_live[it] * S) : P;
+    const int nt = (P_live + 31) / 32;
+    const float* base = rows + (size_t)it * tiles * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = threadIdx.x; b < nt; b += 256) {
+        const float4 q = *reinterpret_cast<const float4*>(base + (size_t)b * 4);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o); }
+    if (lk_lane() == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = log + (size_t)it * 4;
+        o[0] = (sh[0].x + sh[1].x) + (sh[2].x + sh[3].x); o[1] = (sh[0].y + sh[1].y) + (sh[2].y + sh[3].y);
+        o[2] = (sh[0].z + sh[1].z) + (sh[2].z + sh[3].z); o[3] = (sh[0].w + sh[1].w) + (sh[2].w + sh[3].w);
+    }
+}
 // position of every optimised row in the row list of an lk_map_frame call (lk_knn_s::row_rank, cleared to -1 before)
 __global__ __launch_bounds__(256) void k_row_rank(const int32_t* __restrict__ rows, int n_rows, int N, int32_t* __restrict__ rank) {
     const int i = blockIdx.x * 256 + (int)threadIdx.x;
@@ -265,7 +289,7 @@ TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     w.total = o;
     return w;
 }
-struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, n_live, frame_id, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, w_next, total; };
+struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, n_live, frame_id, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, w_next, loss_rows, total; };
 MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     MapWork w;
     int64_t o = 0;
@@ -288,6 +312,7 @@ MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     w.seg_total = o; o += al4(iters);
     w.seg_rank = o; o += al4(P * LK_K * LK_SEG_BATCH);        // the rows of up to LK_SEG_BATCH iterations are sorted per launch
     w.w_next = o; o += al4(lk_weight_blob_floats());          // the decoder blob as stepped by the step rider (LkStepRider::w_next)
+    w.loss_rows = o; o += iters * 4 * ((P + 31) / 32);        // the loss row's terms per decoder-backward tile (LK_COMPOSITE_IN_BWD): [iters][tiles][4]
     w.total = o;
     return w;
 }
@@ -677,6 +702,8 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         embed_only = embed_only && d->col_dec[k].offset >= R_EB && d->col_dec[k].offset + d->col_dec[k].n <= R_EB + 3 * 10;
     if (train_geo) embed_only = false;          // (the geometry decoder's weight gradients need the full backward)
     bool w_next_ready = false;
+    static const bool map_loss_inline = []{ const char* e = getenv("LK_MAP_LOSS_INLINE"); return e == nullptr || e[0] != '0'; }();
+    int sum_lo = -1, sum_hi = -1;                  // iterations whose loss rows are summed at the end of the call (the exposure variant's are not)
     bool x_fwd_done = it_begin > n_geo_l;          // a later call of a phase-split sequence: the step launch of the iteration before did the forward
     for (int it = it_begin; it < it_end; ++it) {
         const bool color = it >= n_geo_l;
@@ -736,7 +763,11 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             // phase-split caller: the step of 'color' iteration it - 1 (its own call) moved the colour decoder and left the repack to this launch
             const bool split_repack = pre && (phases & 3) == 1 && it == it_begin && it > n_geo_l && !embed_only && d->n_col_dec > 0 &&
                                       d->render.weights == d->weights_rw;
-            rc = lk_render_fwd_impl(&rd, st, (xit ? 0 : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0), live,
+            // the composite, the loss and its backward as the prologue of the decoder backward (no k_composite launch; LK_MAP_LOSS_INLINE=0: off)
+            const bool comp_bwd = pre && !xit && !train_geo && map_loss_inline;
+            if (comp_bwd) { if (sum_lo < 0) sum_lo = it; sum_hi = it + 1; }
+            rc = lk_render_fwd_impl(&rd, st, (xit ? 0 : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0) |
+                                    (comp_bwd ? LK_COMPOSITE_IN_BWD : 0), live,
                                     (repack_pending || stepped_pending || split_repack) ? &rr : nullptr);
             repack_pending = false; stepped_pending = false;
             if (rc != LK_OK) return rc;
@@ -787,7 +818,8 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 }
                 ex.step = &sr;
             }
-            rc = lk_render_bwd_impl(&rd, st, (xit ? 0 : LK_SKIP_COMPOSITE_BWD) | LK_SEG_SORTED, pre ? &ex : nullptr);
+            if (comp_bwd) ex.loss_rows = W0 + wk.loss_rows + (size_t)it * 4 * lk_cdiv(Pn, 32);
+            rc = lk_render_bwd_impl(&rd, st, (xit ? 0 : LK_SKIP_COMPOSITE_BWD) | LK_SEG_SORTED | (comp_bwd ? LK_COMPOSITE_IN_BWD : 0), pre ? &ex : nullptr);
             if (rc != LK_OK) return rc;
         }
         if (phases & 2) {
@@ -833,6 +865,9 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             }
         }
     }
+    if (sum_lo >= 0)
+        hipLaunchKernelGGL(k_loss_rows_sum, dim3(sum_hi - sum_lo), dim3(256), 0, st, W0 + wk.loss_rows, lk_cdiv(Pn, 32), (int)Pn, d->render.S,
+                           reinterpret_cast<const int32_t*>(W0 + wk.n_live), sum_lo, d->log);
     LK_LAUNCH_CHECK();
     return LK_OK;
 }
