@@ -24,7 +24,7 @@ def main():
     rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
-            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')))
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', ''), r.get('Queue_Id', '?')))
     rows.sort()
     # first launch of every iteration: the sampler (not its search-only form <T, 1>, which lk_map_frame runs ahead of the loop)
     starts = [i for i, r in enumerate(rows) if r[2].startswith('k_interp_repack') or (r[2].startswith('k_sample_interp') and not r[2].rstrip().endswith(', 1>'))]
@@ -35,10 +35,10 @@ def main():
     for a, b in zip(starts[:-1], starts[1:]):
         seg = rows[a:b]
         period = rows[b][0] - seg[0][0]
-        busy = sum(e - s for s, e, _ in seg)
+        busy = sum(r[1] - r[0] for r in seg)
         # union of the busy intervals (two streams may overlap)
         cover, cur_s, cur_e = 0, None, None
-        for s, e, _ in sorted(seg):
+        for s, e, *_ in sorted(seg):
             if cur_e is None or s > cur_e:
                 if cur_e is not None:
                     cover += cur_e - cur_s
@@ -55,7 +55,7 @@ def main():
     for _, _, _, seg in its:
         c = collections.Counter()
         t = collections.Counter()
-        for s, e, n in seg:
+        for s, e, n, *_ in seg:
             c[n] += 1
             t[n] += e - s
         for n in t:
@@ -71,6 +71,14 @@ def main():
         once = '' if len(v) >= 0.9 * len(its) else f' (only in {len(v)} of {len(its)} iterations: medians over those)'
         print(f'| {n[:60]}{once} | {med(cnt[n]):.0f} | {med(v) / 1e3:.1f} | {100 * med(v) / period:.1f} % |')
     print()
+    if len(sys.argv) > 3 and sys.argv[3] == 'gantt':       # one iteration of median length, launch by launch (us from its first launch; queue = stream)
+        pick = min(its, key=lambda i: abs(i[0] - period))
+        t0 = pick[3][0][0]
+        print('| start | end | us | queue | kernel |')
+        print('|---|---|---|---|---|')
+        for r in pick[3]:
+            print(f'| {(r[0] - t0) / 1e3:.1f} | {(r[1] - t0) / 1e3:.1f} | {(r[1] - r[0]) / 1e3:.1f} | {r[3]} | {r[2][:60]} |')
+        print()
 
 
 if __name__ == '__main__':
