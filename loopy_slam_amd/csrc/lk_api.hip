@@ -451,6 +451,8 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     const bool bg_rides = gw && !defer && gf;
     if (gw && !defer && !bg_rides) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
+    static const bool dw2_rider_on = []{ const char* e = getenv("LK_DW2_RIDER"); return e == nullptr || e[0] != '0'; }();
+    const bool dw2_rides = dw2_rider_on && gf && gwf && relpos && lk_relpos_fused(flags);
     const bool forked = gwf && color && ss.ok;
     hipStream_t wst = st;                      // stream of the weight-gradient launches
     if (forked) {
@@ -533,6 +535,10 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         else if (ss.ok) (void)hipStreamWaitEvent(st, ss.link, 0);
         fs.act_flag = ex ? ex->act_flag : nullptr;
         if (bg_rides) { fs.red_part = S0 + L.part_bg; fs.red_n = lk_cdiv(lk_cdiv(P, 32), 4); fs.red_width = 288; fs.red_out = d->g_weights + G_EB; }
+        if (dw2_rides) {       // linear2 of the rel-pos MLP: k_dw2_hbar's blocks in front of the gather's (LK_DW2_RIDER=0: a launch of its own, below)
+            fs.dw2_dc = S0 + L.dc_col; fs.dw2_w_sum = S0 + L.w_sum; fs.dw2_hbar = S0 + L.hbar; fs.dw2_part = S0 + L.dw2_part;
+            fs.dw2_blocks = lk_dw2_parts(P); fs.dw2_live = ex ? ex->live_rays : nullptr; fs.dw2_S = d->S;
+        }
         lk_launch_feat_scatter(fs, st);
         // data-parallel caller: the feature-row gradients are final from here (lk_map_desc::signal_rows)
         if (ex && ex->signal_rows && ss.ok) { (void)hipEventRecord(ss.rows, st); ss.rows_set = true; }
@@ -568,7 +574,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             rb.live_rays = ex ? ex->live_rays : nullptr;
             // on the caller's stream: after the fused kernel and the gather it has room, the weight-gradient stream is the longer one
             // (on the third stream beside the gather: no gain, 399 -> 409 us per colour iteration)
-            lk_launch_dw2_hbar(rb, S0 + L.dw2_part, st);
+            if (!dw2_rides) lk_launch_dw2_hbar(rb, S0 + L.dw2_part, st);
         } else {
             LkWgradArgs wr;
             memset(&wr, 0, sizeof(wr));

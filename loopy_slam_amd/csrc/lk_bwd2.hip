@@ -162,18 +162,75 @@ __global__ __launch_bounds__(256) void k_seg_place(LkFeatScatterArgs a) {
     if (row == 0 && a.seg_total) a.seg_total[y] = off[a.N];
 }
 
+// linear2 of the rel-pos MLP (see k_dw2_hbar below) as a body: block bx of nb.  LDS for 32 samples at a time (20 KB: as a rider of k_feat_gather
+// it must not cost that kernel its eight workgroups per compute unit), a block's 64 samples in two passes.
+#define LK_DW2_LDS_SAMPLES 32
+__device__ __forceinline__ void dw2_body(const float* __restrict__ dc, const float* __restrict__ w_sum, const float* __restrict__ hbar,
+                                         int P_all, const int32_t* __restrict__ live_rays, int S, float* __restrict__ part, int bx, int nb) {
+    const int P = live_rays ? min(P_all, *live_rays * S) : P_all;
+    __shared__ __attribute__((aligned(16))) float s_h[LK_DW2_LDS_SAMPLES][128];
+    __shared__ float s_a[LK_DW2_LDS_SAMPLES][33];
+    const int t = (int)threadIdx.x, n = t >> 3, k0 = 16 * (t & 7);
+    float acc[16], bsum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int s0 = bx * 64; s0 < P; s0 += nb * 64) {
+        for (int half = 0; half < 64; half += LK_DW2_LDS_SAMPLES) {
+            const int ns = min(LK_DW2_LDS_SAMPLES, P - s0 - half);
+            if (ns <= 0) break;
+            __syncthreads();
+            // Hbar rows: ns x 32 float4, thread t takes every 256th; A' = wsum * d c: ns x 32 floats
+#pragma unroll
+            for (int q = 0; q < LK_DW2_LDS_SAMPLES * 32 / 256; ++q) {
+                const int e = q * 256 + t, sm = e >> 5;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                float av = 0.0f;
+                if (sm < ns) {
+                    v = reinterpret_cast<const float4*>(hbar + (size_t)(s0 + half + sm) * 128)[e & 31];
+                    av = w_sum[s0 + half + sm] * dc[(size_t)(s0 + half + sm) * LK_C + (e & 31)];
+                }
+                reinterpret_cast<float4*>(&s_h[sm][0])[e & 31] = v;
+                s_a[sm][e & 31] = av;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int sm = 0; sm < LK_DW2_LDS_SAMPLES; ++sm) {
+                const float av = s_a[sm][n];
+                const float4* __restrict__ hb = reinterpret_cast<const float4*>(&s_h[sm][k0]);
+                bsum += av;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = hb[q];
+                    acc[4 * q] = fmaf(av, v.x, acc[4 * q]); acc[4 * q + 1] = fmaf(av, v.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(av, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(av, v.w, acc[4 * q + 3]);
+                }
+            }
+        }
+    }
+    float* __restrict__ out = part + (size_t)bx * (32 * 129) + n * 129;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[k0 + i] = acc[i];
+    if (k0 == 0) out[128] = bsum;
+}
 #define LK_GATHER_CHUNK 16
 __device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, int n_parts, int width, float* __restrict__ out, int bx, float (*sh)[32],
                                                 const LkStepRider& sr);
 __global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
-    if (a.red_part && (int)blockIdx.x >= a.red_block0) {     // rider: column sums of a partial table of the kernel before (one launch less)
+    // rider, FIRST in the grid: linear2 of the rel-pos MLP (k_dw2_hbar's blocks; it reads what the rel-pos backward left, as the gather does) -
+    // as a launch of its own behind the gather it ran alone on the chip for 16 us of every 'color' iteration
+    if ((int)blockIdx.x < a.dw2_blocks) {
+        dw2_body(a.dw2_dc, a.dw2_w_sum, a.dw2_hbar, a.P, a.dw2_live, a.dw2_S, a.dw2_part, (int)blockIdx.x, a.dw2_blocks);
+        return;
+    }
+    const int bx = (int)blockIdx.x - a.dw2_blocks;
+    if (a.red_part && bx >= a.red_block0) {     // rider: column sums of a partial table of the kernel before (one launch less)
         __shared__ float sh[8][32];
         LkStepRider none; none.n_span = 0;
-        col_reduce_body(a.red_part, a.red_n, a.red_width, a.red_out, (int)blockIdx.x - a.red_block0, sh, none);
+        col_reduce_body(a.red_part, a.red_n, a.red_width, a.red_out, bx - a.red_block0, sh, none);
         return;
     }
     const int c = (int)threadIdx.x & 31;
-    const long long i0 = ((long long)blockIdx.x * 8 + ((int)threadIdx.x >> 5)) * LK_GATHER_CHUNK;
+    const long long i0 = ((long long)bx * 8 + ((int)threadIdx.x >> 5)) * LK_GATHER_CHUNK;
     const int total = a.seg_total ? *a.seg_total : a.seg_off[a.N];
     if (i0 >= total) return;
     const int n = min(LK_GATHER_CHUNK, (int)(total - i0));
@@ -798,47 +855,7 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) 
 #define LK_DW2_SAMPLES 64
 __global__ __launch_bounds__(256) void k_dw2_hbar(const float* __restrict__ dc, const float* __restrict__ w_sum, const float* __restrict__ hbar,
                                                   int P_all, const int32_t* __restrict__ live_rays, int S, float* __restrict__ part) {
-    const int P = live_rays ? min(P_all, *live_rays * S) : P_all;
-    __shared__ __attribute__((aligned(16))) float s_h[LK_DW2_SAMPLES][128];
-    __shared__ float s_a[LK_DW2_SAMPLES][33];
-    const int t = (int)threadIdx.x, n = t >> 3, k0 = 16 * (t & 7);
-    float acc[16], bsum = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    for (int s0 = (int)blockIdx.x * LK_DW2_SAMPLES; s0 < P; s0 += (int)gridDim.x * LK_DW2_SAMPLES) {
-        const int ns = min(LK_DW2_SAMPLES, P - s0);
-        __syncthreads();
-        // Hbar rows: ns x 32 float4, thread t takes every 256th; A' = wsum * d c: ns x 32 floats
-#pragma unroll
-        for (int q = 0; q < LK_DW2_SAMPLES * 32 / 256; ++q) {
-            const int e = q * 256 + t, sm = e >> 5;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            float av = 0.0f;
-            if (sm < ns) {
-                v = reinterpret_cast<const float4*>(hbar + (size_t)(s0 + sm) * 128)[e & 31];
-                av = w_sum[s0 + sm] * dc[(size_t)(s0 + sm) * LK_C + (e & 31)];
-            }
-            reinterpret_cast<float4*>(&s_h[sm][0])[e & 31] = v;
-            s_a[sm][e & 31] = av;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int sm = 0; sm < LK_DW2_SAMPLES; ++sm) {
-            const float av = s_a[sm][n];
-            const float4* __restrict__ hb = reinterpret_cast<const float4*>(&s_h[sm][k0]);
-            bsum += av;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = hb[q];
-                acc[4 * q] = fmaf(av, v.x, acc[4 * q]); acc[4 * q + 1] = fmaf(av, v.y, acc[4 * q + 1]);
-                acc[4 * q + 2] = fmaf(av, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(av, v.w, acc[4 * q + 3]);
-            }
-        }
-    }
-    float* __restrict__ out = part + (size_t)blockIdx.x * LK_DW2_TILE + n * 129;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) out[k0 + i] = acc[i];
-    if (k0 == 0) out[128] = bsum;
+    dw2_body(dc, w_sum, hbar, P_all, live_rays, S, part, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Sums of the partial tiles of the fused variant (a part of k_bwd_reduce): linear1 [n1][128][64] (column 52 = bias) from
@@ -1307,7 +1324,8 @@ int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_FEAT_SCATTER, st);
     LkFeatScatterArgs b = a;
     b.red_block0 = lk_cdiv((long long)a.P * LK_K, 8 * LK_GATHER_CHUNK);
-    hipLaunchKernelGGL(k_feat_gather, dim3(b.red_block0 + (a.red_part ? lk_cdiv(a.red_width, 32) : 0)), dim3(256), 0, st, b);
+    if (!b.dw2_part) b.dw2_blocks = 0;
+    hipLaunchKernelGGL(k_feat_gather, dim3(b.dw2_blocks + b.red_block0 + (a.red_part ? lk_cdiv(a.red_width, 32) : 0)), dim3(256), 0, st, b);
     return LK_OK;
 }
 int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st, int batch) {

@@ -203,6 +203,8 @@ struct LkFeatScatterArgs {
     int cnt_stride, sums_stride;
     // k_feat_gather rider: out[width] += column sums of part[n][width] (the geometry Fourier-matrix partials of k_decode_bwd), blocks >= red_block0
     const float* red_part; int red_n, red_width, red_block0; float* red_out;
+    // k_feat_gather rider, first in the grid: k_dw2_hbar's blocks (dw2_part = NULL: none); samples = P, live prefix = *dw2_live rays of dw2_S samples (or NULL)
+    const float* dw2_dc; const float* dw2_w_sum; const float* dw2_hbar; float* dw2_part; int dw2_blocks; const int32_t* dw2_live; int dw2_S;
     const int32_t* live_rays; int S;               // rows of rays >= *live_rays take no part (NULL: all)
     int N;
     uint8_t* act_flag;                             // or NULL: k_feat_gather flags every point it adds a gradient to (lk_knn_s::act_flag)
