@@ -88,7 +88,7 @@ def test_oracle_loop_and_product_agree_on_a_miniature_sequence():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ('room', 'tum', 'scannet'))
+@pytest.mark.parametrize('name', ('room', 'roomfull', 'tum', 'scannet'))
 def test_accuracy_matches_the_oracle_loop(name):
     """The product on the GPU against the committed oracle runs of the same config and seeds:
       (a) rendered-depth L1 within 5 % of the oracle's, seed by seed (it is set by the map, which both build from the same draws' distribution);
@@ -105,9 +105,11 @@ def test_accuracy_matches_the_oracle_loop(name):
     assert len(fx) >= (3 if name == 'room' else 1), 'oracle fixtures missing (tools/accuracy_run.py --pipeline oracle)'
     if name != 'room':
         # TUM / ScanNet configs (dynamic radii, gradient-pool tracking pixels, exposure encoding) at 2 000 rays per iteration - at config 1's
-        # 500 rays BOTH pipelines lose track on this sequence (oracle 22 cm, product 14-31 cm): ONE oracle run each (55-60 minutes of CPU),
-        # three product runs; a band instead of a statistical bound
-        o = fx[0]
+        # 500 rays BOTH pipelines lose track on this sequence (oracle 22 cm, product 14-31 cm): ONE oracle run each (25-60 minutes of CPU),
+        # three product runs; a band instead of a statistical bound.  roomfull: the room config at its OWN ray budget (1 500 / 5 000 rays per
+        # iteration - the bench workload's), one oracle run of 50 minutes; the depth L1 there is held to 5 %
+        o = dict(fx[0])                       # (more than one oracle run of the config: the band is around their means)
+        o['ate_rmse_cm'] = float(np.mean([f['ate_rmse_cm'] for f in fx])); o['depth_l1_cm'] = float(np.mean([f['depth_l1_cm'] for f in fx]))
         c = o['config']
         res = []
         for seed in (c['seed'], c['seed'] + 1, c['seed'] + 2):
@@ -121,7 +123,7 @@ def test_accuracy_matches_the_oracle_loop(name):
                                hip_ate_rmse_cm=ha.tolist(), hip_depth_l1_cm=hl.tolist()), f, indent=1)
         prior = o['prior_only']
         assert 0.4 * o['ate_rmse_cm'] <= float(np.median(ha)) <= 2.5 * o['ate_rmse_cm'], (ha.tolist(), o['ate_rmse_cm'])
-        assert abs(float(hl.mean()) / o['depth_l1_cm'] - 1) <= 0.2, (hl.tolist(), o['depth_l1_cm'])
+        assert abs(float(hl.mean()) / o['depth_l1_cm'] - 1) <= (0.05 if name == 'roomfull' else 0.2), (hl.tolist(), o['depth_l1_cm'])
         assert float(np.median(ha)) < prior['dead_reckoning_ate_cm'] / 1.5
         return
     rows = []

@@ -30,7 +30,7 @@ out = {'what': 'product (libloopyhip on one MI355X) against the CPU oracle chain
                'synthetic hand-held sequence through the furnished room; metrics of src/tools/eval_ate.py:44-79,195-234 and src/Mapper.py:1146-1182 '
                '(depth L1 on a stride-4 pixel grid); random-init decoders on both sides; the trajectories are chaotic, the metrics are compared',
        'configs': {}}
-for name in ('room', 'tum', 'scannet'):
+for name in ('room', 'roomfull', 'tum', 'scannet'):
     fx = [json.load(open(f)) for f in sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', f'accuracy_{name}_oracle_s*.json')))]
     if not fx:
         continue
@@ -43,12 +43,16 @@ for name in ('room', 'tum', 'scannet'):
     runs = [dict(seed=h['config']['seed'], **brief(h)) for h in hip]
     if os.path.exists(test):
         t = json.load(open(test))
-        runs += [dict(seed=r['seed'], ate_rmse_cm=round(r['hip_ate'], 4), depth_l1_cm=round(r['hip_l1'], 4), rot_err_deg=round(r['hip_rot'], 4),
-                      wall_s=r['hip_wall_s'], source='tests/test_accuracy.py') for r in t['runs']]
+        if 'runs' in t:
+            runs += [dict(seed=r['seed'], ate_rmse_cm=round(r['hip_ate'], 4), depth_l1_cm=round(r['hip_l1'], 4), rot_err_deg=round(r['hip_rot'], 4),
+                          wall_s=r['hip_wall_s'], source='tests/test_accuracy.py') for r in t['runs']]
+        else:       # the band form (one oracle run, three product runs)
+            runs += [dict(seed=fx[0]['config']['seed'] + k, ate_rmse_cm=round(a, 4), depth_l1_cm=round(l, 4), source='tests/test_accuracy.py')
+                     for k, (a, l) in enumerate(zip(t['hip_ate_rmse_cm'], t['hip_depth_l1_cm']))]
     if runs:
         c['hip_runs'] = runs
         c['hip'] = {'ate_rmse_cm': stats([r['ate_rmse_cm'] for r in runs]), 'depth_l1_cm': stats([r['depth_l1_cm'] for r in runs]),
-                    'rot_err_deg': stats([r['rot_err_deg'] for r in runs])}
+                    'rot_err_deg': stats([r['rot_err_deg'] for r in runs if 'rot_err_deg' in r])}
         c['ate_mean_hip_over_oracle'] = round(c['hip']['ate_rmse_cm']['mean'] / c['oracle']['ate_rmse_cm']['mean'], 3)
         c['depth_l1_mean_hip_over_oracle'] = round(c['hip']['depth_l1_cm']['mean'] / c['oracle']['depth_l1_cm']['mean'], 3)
         c['ate_vs_prior'] = {'one_step_over_hip': round(c['prior_only']['one_step_ate_cm'] / c['hip']['ate_rmse_cm']['mean'], 2),
