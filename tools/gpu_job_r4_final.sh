@@ -8,6 +8,7 @@ timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > gpurun_out/gpu
 tail -2 gpurun_out/gpu_tests.log
 bash tools/profile_round.sh r4 2>&1 | tail -4
 bash tools/gpu_trace_modes.sh r4 > /dev/null 2>&1; grep -E "^period|host enqueue" gpurun_out/trace_r4.md
+for mode in track geo color; do python tools/trace_summary.py /tmp/trace_$mode "$mode" gantt | sed -n '/^| start/,$p' > gpurun_out/gantt_$mode.md; done
 bash tools/profile_sq.sh r4 > /dev/null 2>&1
 # mapping.fix_geo_decoder: False inside the native loop: per-iteration timelines with the geometry decoder trained (k_geo_wgrad timed on the chip)
 for mode in geo color; do
@@ -20,7 +21,7 @@ for s in 1219 1220 1221 1222 1223; do
   timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/ScanNet/scene0000.yaml --frames 50 --rays 2000 --color-refine 0 --seed $s --out gpurun_out/acc_scannet_hip_s$s.json 2> gpurun_out/acc_scannet_hip_s$s.err | cut -c1-200
   timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/TUM_RGBD/freiburg1_desk.yaml --frames 50 --rays 2000 --iters-scale 0.5 --color-refine 0 --seed $s --out gpurun_out/acc_tum_hip_s$s.json 2> gpurun_out/acc_tum_hip_s$s.err | cut -c1-200
 done
-timeout 300 python tools/accuracy_run.py --pipeline hip --config configs/Synthetic/room.yaml --frames 50 --rays 0 --color-refine 0 --out gpurun_out/acc_room_hip_fullrays.json 2> /dev/null | cut -c1-200
+rm -f gpurun_out/acc_room_hip_fullrays.json
 timeout 300 python tools/slam_run.py --frames 51 --out gpurun_out/slam_run_room.json > /dev/null 2> gpurun_out/slam_run_room.err
 for c in ScanNet/scene0000 TUM_RGBD/freiburg1_desk; do
   n=$(basename $c)
