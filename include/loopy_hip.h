@@ -390,7 +390,8 @@ typedef struct {
     int32_t hist_post;          /* 0: hist[it] = pose BEFORE iteration it (separate_LR: the candidate is a detached copy);
                                    1: pose AFTER its update (one leaf tensor stepped in place, Tracker.py:375-377) */
     float* hist;                /* [iters][7] candidate poses */
-    float* log;                 /* [iters][4] loss, geo, colour, #masked rays per iteration */
+    float* log;                 /* [iters][4] loss, geo, colour, #masked rays per iteration; complete when the call's work has
+                                 * completed (a row may be written by the iteration AFTER its own: the pose step sums its terms) */
     int32_t iters;
     float* work;                /* lk_track_work_floats(R, S, iters) floats: with it (and R <= 8192) every iteration's pixels, colours,
                                    radii and inside mask are assembled by ONE launch up front and the small steps of an iteration run
@@ -421,7 +422,8 @@ typedef struct {
     float fx, fy, cx, cy;
     float* gt_color; float* thr; uint32_t* scratch_u32;
     float w_color;
-    float* log;                 /* [iters][4] */
+    float* log;                 /* [iters][4] as lk_track_desc::log; the rows of a call's iterations are complete at the END of that
+                                 * lk_map_frame call (one launch sums the per-tile terms the decoder backward left) */
     /* optimiser (a fresh Adam per optimize_map call, Mapper.py:570: the caller zeroes the state buffers) */
     float* weights_rw;          /* = render.weights, writable */
     float* weights_frag_rw;     /* = render.weights_frag, writable */
