@@ -395,7 +395,7 @@ typedef struct {
     int32_t iters;
     float* work;                /* lk_track_work_floats(R, S, iters) floats: with it (and R <= 8192) every iteration's pixels, colours,
                                    radii and inside mask are assembled by ONE launch up front and the small steps of an iteration run
-                                   fused (9 launches per iteration instead of 16); gt_color / pix_i / pix_j / thr / scratch_u32 /
+                                   fused (4 launches per iteration instead of 16); gt_color / pix_i / pix_j / thr / scratch_u32 /
                                    loss_scratch and render.g_rays_o / g_rays_d are then not used and may be NULL.  NULL: the
                                    per-iteration launch sequence */
     const lk_exposure_desc* exposure;   /* model.encode_exposure (HOST pointer) or NULL: the frame's affine is applied per sample inside the
