@@ -200,6 +200,9 @@ def main():
         if out['roofline'] is not None and ser is not None:
             out['roofline']['serial'] = {k: ser[k] for k in ('avg_launch_us', 'achieved', 'frac') if k in ser}
             out['roofline']['serial']['note'] = 'same kernel with the side stream off (lk_set_serial): nothing else shares the chip'
+        if out['roofline'] is not None:
+            out['roofline']['chosen_by'] = ('largest summed duration in the profiled step; kernels within 3 % of it are level (k_decode_bwd and k_wgrad trade '
+                                            'places from run to run) and the longer average launch decides - every kernel is in roofline_all_kernels')
         # north_star: fraction of the HBM roofline of the whole step (11.1 KB/ray forward, +20.5 KB/ray backward with the
         # feature-gradient scatter; tracking iterations have no scatter: 2 x 11.1 KB/ray)
         step_bytes = world * (budget.map_iters * budget.map_rays * 31.6e3 + budget.track_iters * budget.track_rays * 22.2e3)

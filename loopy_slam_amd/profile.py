@@ -122,7 +122,13 @@ def pmc_traffic(kernel, path=None):
 
 
 def dominant_kernel(kstat):
-    return max(kstat.items(), key=lambda kv: kv[1]['total_ms'])[0] if kstat else None
+    """The kernel with the largest summed duration over the profiled step; kernels within 3 % of it are level (run-to-run scatter: since round 4
+    k_decode_bwd - 100 launches per step in three forms - and k_wgrad - 36 launches - trade places) and the longer AVERAGE LAUNCH decides."""
+    if not kstat:
+        return None
+    top = max(v['total_ms'] for v in kstat.values())
+    level = {k: v for k, v in kstat.items() if v['total_ms'] >= 0.97 * top}
+    return max(level.items(), key=lambda kv: kv[1]['total_ms'] / max(kv[1]['calls'], 1))[0]
 
 
 def roofline(kstat, budget, kernel):
