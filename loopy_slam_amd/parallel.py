@@ -57,11 +57,12 @@ class DistContext:
         self._agree = {}            # slot (it & 1) -> _RowAgreement
         self._side = None
         self._main_ev = None
-        # LOOPY_DIST_OVERLAP=1: the row part of the gradient bucket is exchanged on a communication stream of its own, beside the tail of the
-        # backward (_exchange).  OFF by default: with ONE rank over RCCL (nothing on the wire to hide) the second collective and its stream
-        # hand-overs cost ~30 us per mapping iteration with torch's collectives (bench step 19.7 -> 21.6 ms, profiles/r4_ab_dist_exchange.txt) - it
-        # pays only where the row exchange itself takes longer than that on the wire
-        self.overlap = os.environ.get('LOOPY_DIST_OVERLAP') == '1'
+        # the row part of the gradient bucket on a communication stream beside the backward's tail (_exchange): with ONE rank it costs two event
+        # hand-overs and hides nothing (+1.2 ms per step, profiles/r4_ab_dist_exchange.txt) - with peers on the wire it hides the larger of the two collectives (3-4 MB of
+        # feature-row gradients: tens of microseconds of ring time per iteration against ~35 us of hand-overs).  Default: on when ranks exchange over
+        # RCCL, off otherwise; LOOPY_DIST_OVERLAP=0 / 1 overrides
+        ov = os.environ.get('LOOPY_DIST_OVERLAP')
+        self.overlap = (ov == '1') if ov is not None else (world > 1 and dist.is_initialized() and dist.get_backend() == 'nccl')
         self._comm = None
         self._comm_ev = None
         self._rccl = None

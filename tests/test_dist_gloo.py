@@ -48,8 +48,10 @@ def draws():
     return torch.randint(0, HH * WW, (ITERS, 2, R), generator=g, dtype=torch.int32)
 
 
-def worker(rank, port, q, all_rows=False, native=True, backend='emu'):
+def worker(rank, port, q, all_rows=False, native=True, backend='emu', overlap=False):
     try:
+        if overlap:          # the row part of the bucket on a communication stream beside the backward's tail (parallel._exchange)
+            os.environ['LOOPY_DIST_OVERLAP'] = '1'
         _worker(rank, port, q, all_rows, native, backend)
     except Exception:                                   # surface the reason in the parent instead of a bare exit code
         import traceback
@@ -94,12 +96,14 @@ from util import backends  # noqa: E402
 
 
 @pytest.mark.parametrize('backend', backends())
-@pytest.mark.parametrize('all_rows,native', ((False, False), (False, True), (True, True)))
+@pytest.mark.parametrize('all_rows,native', ((False, False), (False, True), (True, True), (False, 'overlap')))
 def test_two_rank_grad_allreduce_matches_single_process(all_rows, native, backend):
     """native: the two-rank side runs lk_map_frame split in phases 1 / 2 around the all-reduce (else the per-statement path).
     all_rows: every row of the map is a parameter (final refinement) - the ranks exchange the union of the touched rows, agreed
     one iteration ahead on a side stream.  backend hip: both ranks on cuda:0."""
     from util import make_engine
+    overlap = native == 'overlap'        # the native loop with the overlapped exchange (the default of a multi-rank RCCL run)
+    native = bool(native)
     torch.set_num_threads(1)
     eng = make_engine(backend)
     mo, frames, dec, geo_d, col_d = build(eng, 2 * R, None, all_rows)
@@ -117,7 +121,7 @@ def test_two_rank_grad_allreduce_matches_single_process(all_rows, native, backen
         s.close()
         ctx = mp.get_context('spawn')
         q = ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, port, q, all_rows, native, backend)) for r in range(2)]
+        procs = [ctx.Process(target=worker, args=(r, port, q, all_rows, native, backend, overlap)) for r in range(2)]
         for p in procs:
             p.start()
         try:
