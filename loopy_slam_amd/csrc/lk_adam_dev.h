@@ -36,8 +36,14 @@ __device__ __forceinline__ void lk_adam_seg_flagged(const AdamSegDev& S, float b
     const long long n_rows = S.n / S.row_len;
     const long long wave = (long long)bx * 4 + ((int)threadIdx.x >> 6), n_waves = (long long)gx * 4;
     const bool pair = S.row_len <= 32;
-    for (long long r0 = wave * 64; r0 < n_rows; r0 += n_waves * 64) {
-        const bool on = r0 + lane < n_rows && S.row_flags[r0 + lane] != 0;
+    // rows per wave and pass: 64 (one coalesced flag load) where the table has at least that many rows per wave of the launch; fewer on smaller
+    // tables - a wave walks its flagged rows two at a time, each step a dependent load -> step -> store round trip, and with DENSE flags (the
+    // end-of-sequence refinement of a 20 000-point map: every row touched) 64 rows per wave were 32 such round trips on 312 of the launch's
+    // 8 192 waves: 29 us for what the row-list form does in 6
+    int RW = 64;
+    while (RW > 2 && n_rows < n_waves * RW) RW >>= 1;
+    for (long long r0 = wave * RW; r0 < n_rows; r0 += n_waves * RW) {
+        const bool on = lane < RW && r0 + lane < n_rows && S.row_flags[r0 + lane] != 0;
         unsigned long long mask = __ballot(on);
         while (mask) {
             const int ra = __ffsll((long long)mask) - 1;
