@@ -397,7 +397,11 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     cb.raw = d->raw; cb.z = d->z; cb.nbr_count = d->nbr_count; cb.gt_depth = d->gt_depth;
     cb.d_depth = d->d_depth; cb.d_var = d->d_var; cb.d_color = color ? d->d_color : nullptr;
     cb.d_raw = S0 + L.d_raw; cb.keep_depth = (flags & LK_FLAG_Z_GIVEN) ? 1 : 0;
-    if (!(skip & LK_SKIP_COMPOSITE_BWD)) lk_launch_composite_bwd(cb, st);
+    // the composite backward as the prologue of the decoder backward (every lane: its own sample) instead of a launch in front of it;
+    // k_geo_wgrad reads the d raw array (LK_FLAG_GRAD_GEO_DECODER: the launch stays).  LK_CB_INLINE=0: the launch (A/B)
+    static const bool cb_inline_on = []{ const char* e = getenv("LK_CB_INLINE"); return e == nullptr || e[0] != '0'; }();
+    const bool cb_inline = cb_inline_on && !(skip & LK_SKIP_COMPOSITE_BWD) && !(gw && (flags & LK_FLAG_GRAD_GEO_DECODER));
+    if (!(skip & LK_SKIP_COMPOSITE_BWD) && !cb_inline) lk_launch_composite_bwd(cb, st);
 
     // tracker-sized batches: rel-pos backward + interpolation backward in one launch (k_relpos_interp_bwd)
     const bool fuse_small = (skip & LK_FUSE_SMALL) && relpos && gr && !gw && !gf && lk_cdiv(P, 32) <= LK_DEEP_MAX_TILES;
@@ -414,6 +418,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     db.dscale = ex ? ex->dscale : nullptr;
     db.tl_n_part = 0;
     memset(&db.tl, 0, sizeof(db.tl));
+    db.cb_on = cb_inline ? 1 : 0; db.cb = cb;
     db.ml_on = 0; db.ml_row_part = nullptr;
     memset(&db.ml, 0, sizeof(db.ml));
     if ((skip & LK_COMPOSITE_IN_BWD) && (flags & LK_FLAG_MAPPER_LOSS)) {      // as the composite launch of lk_render_fwd_impl would have been set up

@@ -119,6 +119,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128;
     float4 draw;
     if (a.ml_on) { float t0, t1, t2; draw = lk_map_draw(a.ml, sp, false, &t0, &t1, &t2); }
+    else if (a.cb_on) draw = lk_cb_draw(a.cb, sp);
     else if (TL && a.tl_n_part > 0) draw = lk_track_draw(a.tl, a.tl_n_part, sp, nullptr);
     else draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
     if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
@@ -385,6 +386,8 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { G += __shfl_xor(G, o); C += __shfl_xor(C, o); N += __shfl_xor(N, o); }
         if (lane == 0) *reinterpret_cast<float4*>(a.ml_row_part + (size_t)tile * 4) = make_float4(G + (a.ml.use_color ? a.ml.w_color * C : 0.0f), G, C, N);
+    } else if (a.cb_on) {
+        draw = lk_cb_draw(a.cb, sp);
     } else if (!GH16 && a.tl_n_part > 0) {
         // tracking loop: the loss term of the sample's ray and the composite backward of it, here instead of in a launch of its own
         // (k_track_loss2: 6 us of an iteration of 117); the ray's first sample carries its terms to the loss row (Tracker.py:183-191)

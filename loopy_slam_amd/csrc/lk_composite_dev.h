@@ -197,3 +197,12 @@ __device__ __forceinline__ float4 lk_map_draw(const LkCompositeArgs& a, int sp, 
         if (s == s_own) o = out[s];
     return o;
 }
+
+// The composite backward of sample sp from the per-ray loss gradients a caller left in d_depth / d_var / d_color (k_composite_bwd's arithmetic
+// for one sample; the sample's own lane calls)
+__device__ __forceinline__ float4 lk_cb_draw(const LkCompositeBwdArgs& a, int sp) {
+    const int r = sp / a.S;
+    return lk_composite_bwd_sample(a.raw, a.z, a.nbr_count, r, a.S, sp - r * a.S, a.min_nn, a.coef, a.keep_depth ? 1.0f : a.gt_depth[r], a.d_depth[r],
+                                   a.d_var ? a.d_var[r] : 0.0f, a.d_color ? a.d_color[3 * r] : 0.0f, a.d_color ? a.d_color[3 * r + 1] : 0.0f,
+                                   a.d_color ? a.d_color[3 * r + 2] : 0.0f);
+}

@@ -120,6 +120,8 @@ struct LkDecodeBwdArgs {
     const int32_t* live_rays;                      // as LkDecodeArgs
     const float* dscale;                           // [1] device-side power of two on top of the fp16-piece form's 2^10 pre-scale (exposure encoding:
                                                    // the loss gradient is scaled by a LEARNED affine, lk_exposure_desc::bwd_scale), or NULL = 1
+    int cb_on;                                     // 1: d_raw is NOT read and k_composite_bwd was NOT launched - every lane forms the composite backward
+    LkCompositeBwdArgs cb;                         // of its own sample from the per-ray loss gradients (cb.d_depth / d_var / d_color; cb.d_raw unused)
     int ml_on;                                     // 1 (mapping loop, LK_COMPOSITE_IN_BWD): d_raw is NOT read and k_composite was NOT launched - every
     LkCompositeArgs ml;                            // lane composites its sample's ray from raw, forms the mapper's loss term (Mapper.py:691-720) and the
     float* ml_row_part;                            // composite backward of it; the geometry role writes the ray's outputs and the loss row's terms of
