@@ -544,6 +544,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             fs.dw2_dc = S0 + L.dc_col; fs.dw2_w_sum = S0 + L.w_sum; fs.dw2_hbar = S0 + L.hbar; fs.dw2_part = S0 + L.dw2_part;
             fs.dw2_blocks = lk_dw2_parts(P); fs.dw2_live = ex ? ex->live_rays : nullptr; fs.dw2_S = d->S;
         }
+        if (ex && ex->xstep) { fs.x_on = 1; fs.x = *ex->xstep; }
         lk_launch_feat_scatter(fs, st);
         // data-parallel caller: the feature-row gradients are final from here (lk_map_desc::signal_rows)
         if (ex && ex->signal_rows && ss.ok) { (void)hipEventRecord(ss.rows, st); ss.rows_set = true; }

@@ -9,6 +9,7 @@
 #include "lk_common.h"
 #include "lk_kernels.h"
 #include "lk_adam_dev.h"
+#include "lk_exposure_dev.h"
 
 using namespace lkw;
 
@@ -218,11 +219,13 @@ __device__ __forceinline__ void col_reduce_body(const float* __restrict__ part, 
 __global__ __launch_bounds__(256) void k_feat_gather(LkFeatScatterArgs a) {
     // rider, FIRST in the grid: linear2 of the rel-pos MLP (k_dw2_hbar's blocks; it reads what the rel-pos backward left, as the gather does) -
     // as a launch of its own behind the gather it ran alone on the chip for 16 us of every 'color' iteration
-    if ((int)blockIdx.x < a.dw2_blocks) {
-        dw2_body(a.dw2_dc, a.dw2_w_sum, a.dw2_hbar, a.P, a.dw2_live, a.dw2_S, a.dw2_part, (int)blockIdx.x, a.dw2_blocks);
+    const int xb = a.x_on ? 1 : 0;                 // rider in block 0: the exposure step's backward + Adam half (LkFeatScatterArgs::x)
+    if (xb && blockIdx.x == 0) { lk_exposure_step_body(a.x, nullptr, 0); return; }
+    if ((int)blockIdx.x - xb < a.dw2_blocks) {
+        dw2_body(a.dw2_dc, a.dw2_w_sum, a.dw2_hbar, a.P, a.dw2_live, a.dw2_S, a.dw2_part, (int)blockIdx.x - xb, a.dw2_blocks);
         return;
     }
-    const int bx = (int)blockIdx.x - a.dw2_blocks;
+    const int bx = (int)blockIdx.x - xb - a.dw2_blocks;
     if (a.red_part && bx >= a.red_block0) {     // rider: column sums of a partial table of the kernel before (one launch less)
         __shared__ float sh[8][32];
         LkStepRider none; none.n_span = 0;
@@ -1325,7 +1328,7 @@ int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {
     LkFeatScatterArgs b = a;
     b.red_block0 = lk_cdiv((long long)a.P * LK_K, 8 * LK_GATHER_CHUNK);
     if (!b.dw2_part) b.dw2_blocks = 0;
-    hipLaunchKernelGGL(k_feat_gather, dim3(b.dw2_blocks + b.red_block0 + (a.red_part ? lk_cdiv(a.red_width, 32) : 0)), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_feat_gather, dim3((b.x_on ? 1 : 0) + b.dw2_blocks + b.red_block0 + (a.red_part ? lk_cdiv(a.red_width, 32) : 0)), dim3(256), 0, st, b);
     return LK_OK;
 }
 int lk_launch_seg_sort(const LkFeatScatterArgs& a, bool counted, hipStream_t st, int batch) {

@@ -2,16 +2,12 @@
 #pragma once
 #include "lk_common.h"
 #include "lk_adam_dev.h"
+#include "lk_kernels.h"
 
 // One launch per iteration of the per-frame loops (lk_exposure_desc, include/loopy_hip.h): backward of the exposure MLP from g_aff
 // (the body of k_exposure_bwd, gradients kept in g), Adam on the MLP's tensors and on the trainable features, forward with the stepped
 // values (k_exposure_fwd) for the next iteration, g_aff cleared.  mode bit 0: backward + step, bit 1: forward (+ clear).
-struct ExposureStepArgs {
-    float* feats; float* W1; float* b1; float* W2; float* b2; int F;
-    float* aff; float* hid; float* g_aff; float* g; float* m; float* v; float* bwd_scale;
-    float step_mlp, step_feat, bc2_sqrt, beta1, beta2, eps;      // lr / bias_correction1 per group (step_mlp < 0: frozen), sqrt(bias_correction2)
-    int feat_first, feat_count, mode;
-};
+// (struct ExposureStepArgs: lk_kernels.h - it also travels inside LkFeatScatterArgs)
 // Called by EVERY thread of a workgroup of >= 256 threads (barriers inside); the first 256 do the work.
 // part / n_part (or NULL): per-tile sums [n_part][12] of the tracked frame's d affine as k_decode_bwd leaves them (LkDecodeBwdArgs::g_affine_part,
 // F = 1): summed here, on top of g_aff, instead of by a launch of their own.

@@ -181,11 +181,21 @@ struct LkStepRider {
     float beta1, beta2, eps;
     AdamSegDev feat[2]; int n_feat, feat_gx;       // feature-row segments: n_feat * feat_gx extra blocks
 };
+struct ExposureStepArgs;
 struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; float fx, fy, cx, cy;
                     int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale;
                     uint8_t* act_flag; int signal_rows; const LkTrackLossArgs* track_loss; int track_n_part;
-                    float* loss_rows; };           // LK_COMPOSITE_IN_BWD: LkDecodeBwdArgs::ml_row_part of this iteration     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
+                    float* loss_rows;              // LK_COMPOSITE_IN_BWD: LkDecodeBwdArgs::ml_row_part of this iteration
+                    const ExposureStepArgs* xstep; };   // or NULL: LkFeatScatterArgs::x (rides in the gather launch)     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
+
+// One exposure step of the per-frame loops (lk_exposure_dev.h: lk_exposure_step_body)
+struct ExposureStepArgs {
+    float* feats; float* W1; float* b1; float* W2; float* b2; int F;
+    float* aff; float* hid; float* g_aff; float* g; float* m; float* v; float* bwd_scale;
+    float step_mlp, step_feat, bc2_sqrt, beta1, beta2, eps;      // lr / bias_correction1 per group (step_mlp < 0: frozen), sqrt(bias_correction2)
+    int feat_first, feat_count, mode;
+};
 
 struct LkFeatScatterArgs {
     int P, min_nn;
@@ -206,6 +216,9 @@ struct LkFeatScatterArgs {
     // k_feat_gather rider: out[width] += column sums of part[n][width] (the geometry Fourier-matrix partials of k_decode_bwd), blocks >= red_block0
     const float* red_part; int red_n, red_width, red_block0; float* red_out;
     // k_feat_gather rider, first in the grid: k_dw2_hbar's blocks (dw2_part = NULL: none); samples = P, live prefix = *dw2_live rays of dw2_S samples (or NULL)
+    // k_feat_gather rider, block 0 when x_on: the BACKWARD + Adam half of the mapping iteration's exposure step (x.mode = 1) - it needs d affine
+    // only, final since the loss kernel; its 20-us chain of one workgroup then runs beside the gather instead of in the Adam launch
+    int x_on; ExposureStepArgs x;
     const float* dw2_dc; const float* dw2_w_sum; const float* dw2_hbar; float* dw2_part; int dw2_blocks; const int32_t* dw2_live; int dw2_S;
     const int32_t* live_rays; int S;               // rows of rays >= *live_rays take no part (NULL: all)
     int N;

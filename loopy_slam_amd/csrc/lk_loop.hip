@@ -702,6 +702,8 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         embed_only = embed_only && d->col_dec[k].offset >= R_EB && d->col_dec[k].offset + d->col_dec[k].n <= R_EB + 3 * 10;
     if (train_geo) embed_only = false;          // (the geometry decoder's weight gradients need the full backward)
     bool w_next_ready = false;
+    static const bool xstep_early_on = []{ const char* e = getenv("LK_XSTEP_EARLY"); return e == nullptr || e[0] != '0'; }();
+    bool x_early = false;                          // this iteration's exposure backward + Adam already ran (in the gather launch)
     static const bool map_loss_inline = []{ const char* e = getenv("LK_MAP_LOSS_INLINE"); return e == nullptr || e[0] != '0'; }();
     int sum_lo = -1, sum_hi = -1;                  // iterations whose loss rows are summed at the end of the call (the exposure variant's are not)
     bool x_fwd_done = it_begin > n_geo_l;          // a later call of a phase-split sequence: the step launch of the iteration before did the forward
@@ -819,6 +821,16 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 ex.step = &sr;
             }
             if (comp_bwd) ex.loss_rows = W0 + wk.loss_rows + (size_t)it * 4 * lk_cdiv(Pn, 32);
+            // exposure encoding, one process: the backward + Adam half of the exposure step rides in this backward's gather launch (d affine is
+            // final since the loss kernel above; with ranks it is exchanged first and the whole step stays in the Adam launch).  LK_XSTEP_EARLY=0: off
+            ExposureStepArgs xa_early;
+            x_early = false;
+            if (xit && pre && (phases & 3) == 3 && xstep_early_on) {
+                rc = lk_exposure_step_args(*xd, 1, it - n_geo_l + 1, beta1, beta2, eps, &xa_early);
+                if (rc != LK_OK) return rc;
+                ex.xstep = &xa_early;
+                x_early = true;
+            }
             rc = lk_render_bwd_impl(&rd, st, (xit ? 0 : LK_SKIP_COMPOSITE_BWD) | LK_SEG_SORTED | (comp_bwd ? LK_COMPOSITE_IN_BWD : 0), pre ? &ex : nullptr);
             if (rc != LK_OK) return rc;
         }
@@ -845,7 +857,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             int rc;
             if (xit) {          // exposure MLP backward + its Adam groups + the affines of the next iteration: one more block of the Adam launch
                 ExposureStepArgs xa;
-                rc = lk_exposure_step_args(*xd, 3, it - n_geo_l + 1, beta1, beta2, eps, &xa);
+                rc = lk_exposure_step_args(*xd, x_early ? 2 : 3, it - n_geo_l + 1, beta1, beta2, eps, &xa);
                 if (rc != LK_OK) return rc;
                 rc = lk_adam_step_x(seg, ns, beta1, beta2, eps, &xa, st);
             } else {
