@@ -108,8 +108,9 @@ def test_accuracy_matches_the_oracle_loop(name):
         # 500 rays BOTH pipelines lose track on this sequence (oracle 22 cm, product 14-31 cm): ONE oracle run each (25-60 minutes of CPU),
         # three product runs; a band instead of a statistical bound.  roomfull: the room config at its OWN ray budget (1 500 / 5 000 rays per
         # iteration - the bench workload's), one oracle run of 50 minutes; the depth L1 there is held to 5 %
-        o = dict(fx[0])                       # (more than one oracle run of the config: the band is around their means)
-        o['ate_rmse_cm'] = float(np.mean([f['ate_rmse_cm'] for f in fx])); o['depth_l1_cm'] = float(np.mean([f['depth_l1_cm'] for f in fx]))
+        o = dict(fx[0])                       # (more than one oracle run of the config: the band is around their MEDIANS - one oracle run in
+        # three of the ScanNet config drifts to 4.4 cm ATE, and its depth L1 with it; the product's eight runs stay at 1.5-2.3 cm)
+        o['ate_rmse_cm'] = float(np.median([f['ate_rmse_cm'] for f in fx])); o['depth_l1_cm'] = float(np.median([f['depth_l1_cm'] for f in fx]))
         c = o['config']
         res = []
         for seed in (c['seed'], c['seed'] + 1, c['seed'] + 2):
