@@ -118,6 +118,13 @@ __device__ __forceinline__ void interp_bwd_block(const LkInterpBwdArgs& a, int b
     }
 }
 __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) { interp_bwd_block(a, (int)blockIdx.x); }
+// the same launch with one more workgroup: the tracking iteration's exposure step (backward of the exposure MLP from the per-tile sums of d affine
+// the decoder backward left, Adam, forward for the next iteration) - nothing between the decoder backward and the next forward reads what it
+// writes, and in a launch of its own (k_track_final's second workgroup) it kept the pose step out of the next search launch
+__global__ __launch_bounds__(256) void k_interp_bwd_x(LkInterpBwdArgs a, ExposureStepArgs xa, const float* __restrict__ part, int n_part) {
+    if (blockIdx.x + 1 == gridDim.x) { lk_exposure_step_body(xa, part, n_part); return; }
+    interp_bwd_block(a, (int)blockIdx.x);
+}
 
 // Feature-row gradients:
 //   geometry rows:            g_geo[idx] += w * d c_geo[sample]
@@ -1318,9 +1325,10 @@ int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs
     else hipLaunchKernelGGL(k_relpos_interp_bwd<false>, dim3(lk_cdiv(rb.P, 32)), dim3(512), 0, st, rb, ib);
     return LK_OK;
 }
-int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st) {
+int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st, const ExposureStepArgs* xstep, const float* xstep_part, int xstep_n_part) {
     LkProfScope prof_(LKK_INTERP_BWD, st);
-    hipLaunchKernelGGL(k_interp_bwd, dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
+    if (xstep) hipLaunchKernelGGL(k_interp_bwd_x, dim3(lk_cdiv(a.P, 32) + 1), dim3(256), 0, st, a, *xstep, xstep_part, xstep_n_part);
+    else hipLaunchKernelGGL(k_interp_bwd, dim3(lk_cdiv(a.P, 32)), dim3(256), 0, st, a);
     return LK_OK;
 }
 int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st) {

@@ -186,7 +186,9 @@ struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; fl
                     int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale;
                     uint8_t* act_flag; int signal_rows; const LkTrackLossArgs* track_loss; int track_n_part;
                     float* loss_rows;              // LK_COMPOSITE_IN_BWD: LkDecodeBwdArgs::ml_row_part of this iteration
-                    const ExposureStepArgs* xstep; };   // or NULL: LkFeatScatterArgs::x (rides in the gather launch)     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
+                    const ExposureStepArgs* xstep;      // or NULL: an exposure step that rides in this backward - in the gather launch (mapper:
+                    const float* xstep_part; int xstep_n_part; };   // LkFeatScatterArgs::x) or, without feature gradients (tracker), as the last workgroup
+                                                        // of the interpolation backward's launch, which then also sums the per-tile d affine (xstep_part)     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
 inline int lk_bwd_pose_parts(int64_t P) { return (int)((P + 31) / 32); }
 
 // One exposure step of the per-frame loops (lk_exposure_dev.h: lk_exposure_step_body)
@@ -334,7 +336,7 @@ LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of
 
 int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st);
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st);
-int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st);
+int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st, const ExposureStepArgs* xstep = nullptr, const float* xstep_part = nullptr, int xstep_n_part = 0);
 int lk_launch_rays_bwd(const LkRaysBwdArgs& a, hipStream_t st);
 int lk_launch_feat_scatter(const LkFeatScatterArgs& a, hipStream_t st);
 int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st);

@@ -350,7 +350,11 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     const bool fused = R <= LK_TRACK_FUSED_MAX_R && d->work != nullptr;
     // the pose step of an iteration as the prologue of the NEXT iteration's search launch (with exposure encoding the step keeps its own launch:
     // the exposure workgroup rides in it)
-    const bool prologue = fused && d->exposure == nullptr && getenv("LK_NO_POSE_PROLOGUE") == nullptr;
+    // (round 4: with exposure encoding too - the exposure step then rides as the last workgroup of the interpolation backward's launch,
+    // LK_TRACK_XSTEP_IN_BWD=0: the old form, the step's own launch k_track_final with the exposure workgroup in it)
+    static const bool x_in_bwd_on = []{ const char* e = getenv("LK_TRACK_XSTEP_IN_BWD"); return e == nullptr || e[0] != '0'; }();
+    const bool x_in_bwd = fused && d->exposure != nullptr && x_in_bwd_on && !(rd.flags & LK_FLAG_REL_POS) && getenv("LK_NO_POSE_PROLOGUE") == nullptr;
+    const bool prologue = fused && (d->exposure == nullptr || x_in_bwd) && getenv("LK_NO_POSE_PROLOGUE") == nullptr;
     // (with exposure encoding d out passes through the learned affine first: unit scale only relative to xd->bwd_scale, which the fused
     // sequence hands to the kernels)
     if ((xd == nullptr || (xd->bwd_scale && fused)) && fabsf(d->w_color) <= 4.0f) rd.flags |= LK_FLAG_UNIT_LOSS_GRADS;
@@ -467,6 +471,12 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         ex.dscale = (xd && (rd.flags & LK_FLAG_UNIT_LOSS_GRADS)) ? xd->bwd_scale : nullptr;
         ex.pix_i = W0 ? W0 + wk.pix_i + (size_t)it * R : nullptr; ex.pix_j = W0 ? W0 + wk.pix_j + (size_t)it * R : nullptr;
         ex.fx = d->fx; ex.fy = d->fy; ex.cx = d->cx; ex.cy = d->cy;
+        ExposureStepArgs xa_bwd;
+        if (x_in_bwd) {
+            rc = lk_exposure_step_args(*xd, 3, it + 1, beta1, beta2, eps, &xa_bwd);
+            if (rc != LK_OK) return rc;
+            ex.xstep = &xa_bwd; ex.xstep_part = rd.bwd_scratch + off.aff_part; ex.xstep_n_part = lk_cdiv(R * S, 32);
+        }
         rc = lk_render_bwd_impl(&rd, st, fused ? (LK_SKIP_COMPOSITE_BWD | LK_SKIP_RAYS_BWD | LK_FUSE_SMALL | (xd ? LK_SKIP_AFF_REDUCE : 0)) : 0, fused ? &ex : nullptr);
         if (rc != LK_OK) return rc;
         if (xd && !fused) {
@@ -493,12 +503,13 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             fa.next_pix_i = W0 + wk.pix_i + (size_t)(it + 1) * R * (more ? 1 : 0); fa.next_pix_j = W0 + wk.pix_j + (size_t)(it + 1) * R * (more ? 1 : 0);
             ExposureStepArgs xa;
             memset(&xa, 0, sizeof(xa));
-            if (xd) {
+            const bool x_here = xd != nullptr && !x_in_bwd;       // (else the exposure step of this iteration rode in the backward above)
+            if (x_here) {
                 rc = lk_exposure_step_args(*xd, 3, it + 1, beta1, beta2, eps, &xa);
                 if (rc != LK_OK) return rc;
             }
-            hipLaunchKernelGGL(k_track_final, dim3(xd ? 2 : 1), dim3(1024), 0, st, fa, xa,
-                               xd ? (const float*)(rd.bwd_scratch + off.aff_part) : (const float*)nullptr, xd ? lk_cdiv(R * S, 32) : 0);
+            hipLaunchKernelGGL(k_track_final, dim3(x_here ? 2 : 1), dim3(1024), 0, st, fa, xa,
+                               x_here ? (const float*)(rd.bwd_scratch + off.aff_part) : (const float*)nullptr, x_here ? lk_cdiv(R * S, 32) : 0);
         }
         if (!fused) {
             rc = lk_pose_bwd(d->cam7, d->pix_i, d->pix_j, R, d->fx, d->fy, d->cx, d->cy, rd.g_rays_o, rd.g_rays_d, d->g_cam7, st);
