@@ -26,6 +26,8 @@ using namespace lkw;
 int lk_launch_exposure_step(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, hipStream_t st);      // lk_optim.hip
 int lk_exposure_step_args(const lk_exposure_desc& x, int mode, int step, float beta1, float beta2, float eps, ExposureStepArgs* out);
 int lk_adam_step_x(const lk_adam_seg* segs, int32_t n_seg, float beta1, float beta2, float eps, const ExposureStepArgs* xa, void* stream_);
+int lk_launch_composite_loss_exposure(const LkCompositeArgs& ca, const float* gt_color, const int32_t* frame_id, const float* aff, int F, float w_color,
+                                      float* d_depth, float* d_logits, float* out_loss, float* g_aff, hipStream_t st);
 int lk_launch_loss_mapper_exposure(int R, const float* depth, const float* logits, const uint8_t* valid_ray, const float* gt_depth,
                                    const float* gt_color, const int32_t* frame_id, const float* aff, int F, float w_color,
                                    float* d_depth, float* d_logits, float* out_loss, float* g_aff, hipStream_t st);
@@ -713,6 +715,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         embed_only = embed_only && d->col_dec[k].offset >= R_EB && d->col_dec[k].offset + d->col_dec[k].n <= R_EB + 3 * 10;
     if (train_geo) embed_only = false;          // (the geometry decoder's weight gradients need the full backward)
     bool w_next_ready = false;
+    static const bool xloss_fused_on = []{ const char* e = getenv("LK_XLOSS_FUSED"); return e == nullptr || e[0] != '0'; }();
     static const bool xstep_early_on = []{ const char* e = getenv("LK_XSTEP_EARLY"); return e == nullptr || e[0] != '0'; }();
     bool x_early = false;                          // this iteration's exposure backward + Adam already ran (in the gather launch)
     static const bool map_loss_inline = []{ const char* e = getenv("LK_MAP_LOSS_INLINE"); return e == nullptr || e[0] != '0'; }();
@@ -779,12 +782,24 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             // the composite, the loss and its backward as the prologue of the decoder backward (no k_composite launch; LK_MAP_LOSS_INLINE=0: off)
             const bool comp_bwd = pre && !xit && !train_geo && map_loss_inline;
             if (comp_bwd) { if (sum_lo < 0) sum_lo = it; sum_hi = it + 1; }
-            rc = lk_render_fwd_impl(&rd, st, (xit ? 0 : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) | (sort_ahead ? LK_SEG_SORTED : 0) |
-                                    (comp_bwd ? LK_COMPOSITE_IN_BWD : 0), live,
+            // exposure variant: the composite runs inside the loss kernel below (one launch instead of two; LK_XLOSS_FUSED=0: two)
+            const bool x_fused = xit && xloss_fused_on;
+            rc = lk_render_fwd_impl(&rd, st, (xit ? (x_fused ? LK_SKIP_COMPOSITE : 0) : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) |
+                                    (sort_ahead ? LK_SEG_SORTED : 0) | (comp_bwd ? LK_COMPOSITE_IN_BWD : 0), live,
                                     (repack_pending || stepped_pending || split_repack) ? &rr : nullptr);
             repack_pending = false; stepped_pending = false;
             if (rc != LK_OK) return rc;
-            if (xit) {          // Mapper.py:697-715 on the rendered logits: d depth, d logits, loss row, d loss / d affine
+            if (x_fused) {      // composite + Mapper.py:697-715 on the rendered logits in one launch
+                LkCompositeArgs ca;
+                memset(&ca, 0, sizeof(ca));
+                ca.R = R; ca.S = rd.S; ca.min_nn = rd.min_nn; ca.coef = rd.coef;
+                ca.raw = rd.raw; ca.z = rd.z; ca.nbr_count = rd.nbr_count; ca.gt_depth = rd.gt_depth;
+                ca.depth = rd.depth; ca.var = rd.var; ca.color = rd.color; ca.valid_ray = rd.valid_ray;
+                ca.keep_depth = (rd.flags & LK_FLAG_Z_GIVEN) ? 1 : 0;
+                rc = lk_launch_composite_loss_exposure(ca, rd.loss_gt_color, reinterpret_cast<const int32_t*>(W0 + wk.frame_id) + (size_t)it * R, xd->aff, xd->F,
+                                                       d->w_color, const_cast<float*>(rd.d_depth), const_cast<float*>(rd.d_color), rd.loss_out4, xd->g_aff, st);
+                if (rc != LK_OK) return rc;
+            } else if (xit) {          // Mapper.py:697-715 on the rendered logits: d depth, d logits, loss row, d loss / d affine
                 rc = lk_launch_loss_mapper_exposure(R, rd.depth, rd.color, rd.valid_ray, rd.gt_depth, rd.loss_gt_color,
                                                     reinterpret_cast<const int32_t*>(W0 + wk.frame_id) + (size_t)it * R, xd->aff, xd->F, d->w_color,
                                                     const_cast<float*>(rd.d_depth), const_cast<float*>(rd.d_color), rd.loss_out4, xd->g_aff, st);

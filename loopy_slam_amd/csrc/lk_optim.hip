@@ -8,6 +8,7 @@
 #include "lk_mask_dev.h"
 #include "lk_adam_dev.h"
 #include "lk_exposure_dev.h"
+#include "lk_composite_dev.h"
 
 #include <math.h>
 #include <string.h>
@@ -489,7 +490,12 @@ __global__ __launch_bounds__(256) void k_exposure_bwd(const float* __restrict__ 
 
 // Mapper loss of the colour stage with exposure encoding (Mapper.py:691-720): the rays of keyframe f get
 // sigmoid(logits @ rot_f + trans_f); returns d depth, d logits, [loss, geo, colour, #masked] and d loss / d affine [F,12].
-__global__ __launch_bounds__(256) void k_loss_mapper_exposure(int R, const float* __restrict__ depth, const float* __restrict__ logits,
+// COMP (the mapping loop): the composite of the ray (k_composite's arithmetic and outputs) in the same thread - one launch instead of two.
+// d affine: the rays of a batch are grouped by keyframe, so the lanes of a wave share one or two keyframes - the twelve terms are summed over
+// the lanes of a keyframe by shuffles and added to the workgroup's LDS table once per wave and keyframe (one LDS float atomic per LANE and
+// term retired a lane every two cycles with all 64 on the same address: most of the kernel's 14 us).
+template <bool COMP>
+__global__ __launch_bounds__(256) void k_loss_mapper_exposure(LkCompositeArgs ca, int R, const float* __restrict__ depth, const float* __restrict__ logits,
                                                               const uint8_t* __restrict__ valid, const float* __restrict__ gt_depth,
                                                               const float* __restrict__ gt_color, const int32_t* __restrict__ frame_id,
                                                               const float* __restrict__ aff, int F, float w_color,
@@ -499,15 +505,33 @@ __global__ __launch_bounds__(256) void k_loss_mapper_exposure(int R, const float
     for (int e = threadIdx.x; e < F * 12; e += 256) { s_aff[e] = aff[e]; s_g[e] = 0.0f; }
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0.0f;
     __syncthreads();
+    const int lane = (int)threadIdx.x & 63;
     float geo = 0.0f, col = 0.0f, cnt = 0.0f;
-    for (int r = blockIdx.x * 256 + (int)threadIdx.x; r < R; r += gridDim.x * 256) {
-        const float d = depth[r], gd = gt_depth[r];
-        const bool m = (gd > 0.0f) && valid[r] && !(d != d);
-        float dd = 0.0f, dl[3] = {0.0f, 0.0f, 0.0f};
+    for (int r0 = blockIdx.x * 256; r0 < R; r0 += gridDim.x * 256) {      // (whole waves stay in the loop: wave collectives inside)
+        const int r = r0 + (int)threadIdx.x;
+        const bool in = r < R;
+        float d = 0.0f, gd = 0.0f, l0 = 0.0f, l1 = 0.0f, l2 = 0.0f;
+        bool val = false;
+        if (in) {
+            gd = gt_depth[r];
+            if (COMP) {
+                const LkRayOut ro = lk_composite_ray(ca.raw, ca.z, ca.nbr_count, r, ca.S, ca.min_nn, ca.coef, ca.keep_depth ? 1.0f : gd);
+                ca.depth[r] = ro.depth; ca.var[r] = ro.var;
+                ca.color[3 * r] = ro.c0; ca.color[3 * r + 1] = ro.c1; ca.color[3 * r + 2] = ro.c2;
+                ca.valid_ray[r] = ro.valid ? 1 : 0;
+                d = ro.depth; l0 = ro.c0; l1 = ro.c1; l2 = ro.c2; val = ro.valid;
+            } else {
+                d = depth[r]; val = valid[r] != 0;
+            }
+        }
+        const bool m = in && (gd > 0.0f) && val && !(d != d);
+        const int f = (m && frame_id) ? frame_id[r] : 0;
+        float dd = 0.0f, dl[3] = {0.0f, 0.0f, 0.0f}, ga[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) ga[k] = 0.0f;
         if (m) {
-            const int f = frame_id ? frame_id[r] : 0;
             const float* A = s_aff + f * 12;
-            const float l0 = logits[3 * r], l1 = logits[3 * r + 1], l2 = logits[3 * r + 2];
+            if (!COMP) { l0 = logits[3 * r]; l1 = logits[3 * r + 1]; l2 = logits[3 * r + 2]; }
             float dp[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -525,15 +549,34 @@ __global__ __launch_bounds__(256) void k_loss_mapper_exposure(int R, const float
             for (int i = 0; i < 3; ++i) {
                 dl[i] = A[3 * i] * dp[0] + A[3 * i + 1] * dp[1] + A[3 * i + 2] * dp[2];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) atomicAdd(&s_g[f * 12 + 3 * i + c], lv[i] * dp[c]);
+                for (int c = 0; c < 3; ++c) ga[3 * i + c] = lv[i] * dp[c];
             }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(&s_g[f * 12 + 9 + c], dp[c]);
+            for (int c = 0; c < 3; ++c) ga[9 + c] = dp[c];
         }
-        d_depth[r] = dd;
-        d_logits[3 * r] = dl[0]; d_logits[3 * r + 1] = dl[1]; d_logits[3 * r + 2] = dl[2];
+        // d affine of the wave's rays, keyframe by keyframe
+        unsigned long long todo = __ballot(m);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int fl = __shfl(f, leader);
+            const bool mine = m && f == fl;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                float v = mine ? ga[k] : 0.0f;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == leader) atomicAdd(&s_g[fl * 12 + k], v);
+            }
+            todo &= ~__ballot(mine);
+        }
+        if (in) {
+            d_depth[r] = dd;
+            d_logits[3 * r] = dl[0]; d_logits[3 * r + 1] = dl[1]; d_logits[3 * r + 2] = dl[2];
+        }
     }
-    atomicAdd(&s_sum[0], geo); atomicAdd(&s_sum[1], col); atomicAdd(&s_sum[2], cnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { geo += __shfl_xor(geo, o); col += __shfl_xor(col, o); cnt += __shfl_xor(cnt, o); }
+    if (lane == 0) { atomicAdd(&s_sum[0], geo); atomicAdd(&s_sum[1], col); atomicAdd(&s_sum[2], cnt); }
     __syncthreads();
     for (int e = threadIdx.x; e < F * 12; e += 256) atomicAdd(g_aff + e, s_g[e]);
     if (threadIdx.x == 0) {
@@ -574,8 +617,20 @@ int lk_launch_loss_mapper_exposure(int R, const float* depth, const float* logit
     if (R == 0) return LK_OK;
     int gx = lk_cdiv(R, 256);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k_loss_mapper_exposure, dim3(gx), dim3(256), 0, st, R, depth, logits, valid_ray, gt_depth, gt_color,
+    LkCompositeArgs none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(k_loss_mapper_exposure<false>, dim3(gx), dim3(256), 0, st, none, R, depth, logits, valid_ray, gt_depth, gt_color,
                        frame_id, aff, F, w_color, d_depth, d_logits, out_loss, g_aff);
+    return LK_OK;
+}
+// ... with the composite of the rays inside (the mapping loop: no k_composite launch in front); ca carries raw / z / nbr_count and the outputs
+int lk_launch_composite_loss_exposure(const LkCompositeArgs& ca, const float* gt_color, const int32_t* frame_id, const float* aff, int F, float w_color,
+                                      float* d_depth, float* d_logits, float* out_loss, float* g_aff, hipStream_t st) {
+    if (ca.R == 0) return LK_OK;
+    int gx = lk_cdiv(ca.R, 256);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(k_loss_mapper_exposure<true>, dim3(gx), dim3(256), 0, st, ca, ca.R, (const float*)nullptr, (const float*)nullptr,
+                       (const uint8_t*)nullptr, ca.gt_depth, gt_color, frame_id, aff, F, w_color, d_depth, d_logits, out_loss, g_aff);
     return LK_OK;
 }
 
@@ -662,10 +717,9 @@ extern "C" int lk_loss_mapper_exposure(int32_t R, const float* depth, const floa
     LK_HIP_TRY(hipMemsetAsync(out_loss, 0, 4 * sizeof(float), st));
     LK_HIP_TRY(hipMemsetAsync(g_aff, 0, (size_t)F * 12 * sizeof(float), st));
     if (R == 0) return LK_OK;
-    int gx = lk_cdiv(R, 256);
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k_loss_mapper_exposure, dim3(gx), dim3(256), 0, st, (int)R, depth, logits, valid_ray, gt_depth, gt_color,
-                       frame_id, aff, (int)F, w_color, d_depth, d_logits, out_loss, g_aff);
+    const int rc = lk_launch_loss_mapper_exposure((int)R, depth, logits, valid_ray, gt_depth, gt_color, frame_id, aff, (int)F, w_color, d_depth, d_logits,
+                                                  out_loss, g_aff, st);
+    if (rc != LK_OK) return rc;
     LK_LAUNCH_CHECK();
     return LK_OK;
 }

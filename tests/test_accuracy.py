@@ -106,14 +106,14 @@ def test_accuracy_matches_the_oracle_loop(name):
     if name != 'room':
         # TUM / ScanNet configs (dynamic radii, gradient-pool tracking pixels, exposure encoding) at 2 000 rays per iteration - at config 1's
         # 500 rays BOTH pipelines lose track on this sequence (oracle 22 cm, product 14-31 cm): ONE oracle run each (25-60 minutes of CPU),
-        # three product runs; a band instead of a statistical bound.  roomfull: the room config at its OWN ray budget (1 500 / 5 000 rays per
+        # five product runs (three at the room's own budget); a band instead of a statistical bound.  roomfull: the room config at its OWN ray budget (1 500 / 5 000 rays per
         # iteration - the bench workload's), one oracle run of 50 minutes; the depth L1 there is held to 5 %
         o = dict(fx[0])                       # (more than one oracle run of the config: the band is around their MEDIANS - one oracle run in
         # three of the ScanNet config drifts to 4.4 cm ATE, and its depth L1 with it; the product's eight runs stay at 1.5-2.3 cm)
         o['ate_rmse_cm'] = float(np.median([f['ate_rmse_cm'] for f in fx])); o['depth_l1_cm'] = float(np.median([f['depth_l1_cm'] for f in fx]))
         c = o['config']
         res = []
-        for seed in (c['seed'], c['seed'] + 1, c['seed'] + 2):
+        for seed in range(c['seed'], c['seed'] + (3 if name == 'roomfull' else 5)):
             cfg = AR.make_cfg(os.path.join(ROOT, c['file']), c['frames'], c['rays_per_iteration'], c['iters_scale'], None, seed, int(c['color_refine']), c['scene'])
             res.append(AR.run_product(cfg))
         ha = np.array([r['ate_rmse_cm'] for r in res]); hl = np.array([r['depth_l1_cm'] for r in res])
@@ -124,7 +124,8 @@ def test_accuracy_matches_the_oracle_loop(name):
                                hip_ate_rmse_cm=ha.tolist(), hip_depth_l1_cm=hl.tolist()), f, indent=1)
         prior = o['prior_only']
         assert 0.4 * o['ate_rmse_cm'] <= float(np.median(ha)) <= 2.5 * o['ate_rmse_cm'], (ha.tolist(), o['ate_rmse_cm'])
-        assert abs(float(hl.mean()) / o['depth_l1_cm'] - 1) <= (0.05 if name == 'roomfull' else 0.2), (hl.tolist(), o['depth_l1_cm'])
+        # (medians on both sides: a run of either pipeline that drifts - one in three to five does on the ScanNet config - takes its depth L1 with it)
+        assert abs(float(np.median(hl)) / o['depth_l1_cm'] - 1) <= (0.05 if name == 'roomfull' else 0.2), (hl.tolist(), o['depth_l1_cm'])
         assert float(np.median(ha)) < prior['dead_reckoning_ate_cm'] / 1.5
         return
     rows = []
