@@ -903,9 +903,14 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             }
         }
     }
-    if (sum_lo >= 0)
-        hipLaunchKernelGGL(k_loss_rows_sum, dim3(sum_hi - sum_lo), dim3(256), 0, st, W0 + wk.loss_rows, lk_cdiv(Pn, 32), (int)Pn, d->render.S,
-                           reinterpret_cast<const int32_t*>(W0 + wk.n_live), sum_lo, d->log);
+    if (sum_lo >= 0) {
+        // a phase-split caller (one call per iteration around its gradient exchange) gets ONE sum launch, with the call that reaches the last
+        // iteration: the rows of every iteration that left per-tile terms (all of them, or the 'geometry' ones with exposure encoding)
+        if ((phases & 3) != 3) { sum_lo = 0; sum_hi = (it_end == d->iters) ? (xd ? (n_geo_l < 0 ? 0 : (n_geo_l > d->iters ? d->iters : n_geo_l)) : d->iters) : 0; }
+        if (sum_hi > sum_lo)
+            hipLaunchKernelGGL(k_loss_rows_sum, dim3(sum_hi - sum_lo), dim3(256), 0, st, W0 + wk.loss_rows, lk_cdiv(Pn, 32), (int)Pn, d->render.S,
+                               reinterpret_cast<const int32_t*>(W0 + wk.n_live), sum_lo, d->log);
+    }
     LK_LAUNCH_CHECK();
     return LK_OK;
 }
