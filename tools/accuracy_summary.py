@@ -24,7 +24,7 @@ def stats(v):
     v = np.asarray(v, float)
     if v.size == 0:
         return None
-    return {'mean': round(float(v.mean()), 4), 'sd': round(float(v.std(ddof=1)), 4) if v.size > 1 else None, 'min': round(float(v.min()), 4),
+    return {'median': round(float(np.median(v)), 4), 'mean': round(float(v.mean()), 4), 'sd': round(float(v.std(ddof=1)), 4) if v.size > 1 else None, 'min': round(float(v.min()), 4),
             'max': round(float(v.max()), 4), 'n': int(v.size)}
 
 
