@@ -110,7 +110,10 @@ def test_accuracy_matches_the_oracle_loop(name):
         # iteration - the bench workload's), one oracle run of 50 minutes; the depth L1 there is held to 5 %
         o = dict(fx[0])                       # (more than one oracle run of the config: the band is around their MEDIANS - one oracle run in
         # three of the ScanNet config drifts to 4.4 cm ATE, and its depth L1 with it; the product's eight runs stay at 1.5-2.3 cm)
-        o['ate_rmse_cm'] = float(np.median([f['ate_rmse_cm'] for f in fx])); o['depth_l1_cm'] = float(np.median([f['depth_l1_cm'] for f in fx]))
+        o['ate_rmse_cm'] = float(np.median([f['ate_rmse_cm'] for f in fx]))
+        # depth L1 of the runs that kept track (ATE within 1.5 x the pipeline's median): a drifted run's depth L1 is up to twice the others'
+        held = lambda ate, l1: float(np.median([l for a, l in zip(ate, l1) if a <= 1.5 * np.median(ate)]))
+        o['depth_l1_cm'] = held([f['ate_rmse_cm'] for f in fx], [f['depth_l1_cm'] for f in fx])
         c = o['config']
         res = []
         for seed in range(c['seed'], c['seed'] + (3 if name == 'roomfull' else 5)):
@@ -125,7 +128,7 @@ def test_accuracy_matches_the_oracle_loop(name):
         prior = o['prior_only']
         assert 0.4 * o['ate_rmse_cm'] <= float(np.median(ha)) <= 2.5 * o['ate_rmse_cm'], (ha.tolist(), o['ate_rmse_cm'])
         # (medians on both sides: a run of either pipeline that drifts - one in three to five does on the ScanNet config - takes its depth L1 with it)
-        assert abs(float(np.median(hl)) / o['depth_l1_cm'] - 1) <= (0.05 if name == 'roomfull' else 0.2), (hl.tolist(), o['depth_l1_cm'])
+        assert abs(held(ha, hl) / o['depth_l1_cm'] - 1) <= (0.05 if name == 'roomfull' else 0.2), (hl.tolist(), o['depth_l1_cm'])
         assert float(np.median(ha)) < prior['dead_reckoning_ate_cm'] / 1.5
         return
     rows = []
