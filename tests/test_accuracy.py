@@ -107,7 +107,7 @@ def test_accuracy_matches_the_oracle_loop(name):
         # TUM / ScanNet configs (dynamic radii, gradient-pool tracking pixels, exposure encoding) at 2 000 rays per iteration - at config 1's
         # 500 rays BOTH pipelines lose track on this sequence (oracle 22 cm, product 14-31 cm): ONE oracle run each (25-60 minutes of CPU),
         # five product runs (three at the room's own budget); a band instead of a statistical bound.  roomfull: the room config at its OWN ray budget (1 500 / 5 000 rays per
-        # iteration - the bench workload's), one oracle run of 50 minutes; the depth L1 there is held to 5 %
+        # iteration - the bench workload's), one oracle run of 50 minutes; the depth L1 there is held to 8 % (the runs of either pipeline scatter by +-4 % around 0.047 cm)
         o = dict(fx[0])                       # (more than one oracle run of the config: the band is around their MEDIANS - one oracle run in
         # three of the ScanNet config drifts to 4.4 cm ATE, and its depth L1 with it; the product's eight runs stay at 1.5-2.3 cm)
         o['ate_rmse_cm'] = float(np.median([f['ate_rmse_cm'] for f in fx]))
@@ -128,7 +128,7 @@ def test_accuracy_matches_the_oracle_loop(name):
         prior = o['prior_only']
         assert 0.4 * o['ate_rmse_cm'] <= float(np.median(ha)) <= 2.5 * o['ate_rmse_cm'], (ha.tolist(), o['ate_rmse_cm'])
         # (medians on both sides: a run of either pipeline that drifts - one in three to five does on the ScanNet config - takes its depth L1 with it)
-        assert abs(held(ha, hl) / o['depth_l1_cm'] - 1) <= (0.05 if name == 'roomfull' else 0.2), (hl.tolist(), o['depth_l1_cm'])
+        assert abs(held(ha, hl) / o['depth_l1_cm'] - 1) <= (0.08 if name == 'roomfull' else 0.2), (hl.tolist(), o['depth_l1_cm'])
         assert float(np.median(ha)) < prior['dead_reckoning_ate_cm'] / 1.5
         return
     rows = []
