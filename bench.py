@@ -29,6 +29,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--points', type=int, default=100_000)
+    ap.add_argument('--headline-only', action='store_true',
+                    help='skip the TUM / ScanNet budgets (`workloads`): profiling passes, whose per-kernel averages must be those of the headline workload')
     ap.add_argument('--strong', action='store_true',
                     help='strong scaling: the per-frame ray budget is SPLIT over the ranks (R / N rays per rank and iteration) instead of '
                          'every rank bringing a full batch.  frames/s of ONE sequence is bounded by the replicated tracking and the track -> map '
@@ -93,6 +95,7 @@ def main():
     if args.strong and world > 1:
         budget.map_rays = max(32, budget.map_rays // world)          # tracking is replicated (not sharded) in either mode
     wl = workload.FrameWorkload(eng, budget, dist=dctx)
+    cloud_dev = tuple(t[:wl.n].clone() for t in (wl.pos, wl.geo, wl.col)) + (wl.n_rooms,) if (world == 1 and not force_dist) else None
     cloud0 = tuple(t[:wl.n].cpu() for t in (wl.pos, wl.geo, wl.col)) if (rank == 0 and not args.no_cpu_baseline) else None
 
     def barrier():
@@ -158,6 +161,32 @@ def main():
         wl.step(full=True)
     barrier()
     dt_host = time.perf_counter() - t0h
+    # The other two single-GPU budgets of BASELINE.json (configs 3-5's 1-GPU content) on the same map: TUM (200 x 5 000 tracking from the
+    # gradient-pixel pool + 150 x 10 000 mapping per frame, dynamic radii) and ScanNet (100 x 5 000 + 60 x 10 000, exposure encoding) -
+    # 3 timed FULL steps each (their mapped-frame extras included on the budget's own every_frame schedule), reported under `workloads`
+    others = {}
+    if cloud_dev is not None and not args.headline_only:
+        del wl.mapper, wl.tracker
+        for name, mk in (('tum', workload.Budget.tum), ('scannet', workload.Budget.scannet)):
+            bo = mk(n_points=args.points)
+            wo = workload.FrameWorkload(eng, bo, cloud=cloud_dev)
+            wo.step(full=True); wo.step()               # untimed: first-use allocations, one plain and one mapped frame
+            n_o = 3
+            wo.frame_no = 0
+            barrier()
+            t0o = time.perf_counter()
+            for _ in range(n_o):
+                wo.step(full=True)
+            barrier()
+            dto = (time.perf_counter() - t0o) / n_o
+            others[name] = {'ms_per_step': 1e3 * dto, 'frames_per_s': 1.0 / dto, 'rays_per_s': bo.rays_per_frame / dto, 'steps': n_o,
+                            'rays_per_step': bo.rays_per_frame,
+                            'whole_step_fp32_frac': profile.step_flops(bo) / dto / (profile.PEAK_F32_MFMA_TFLOPS * 1e12),
+                            'workload': f'{bo.track_iters} track it x {bo.track_rays} rays' + (' (gradient-pixel pool)' if bo.grad_pool else '') +
+                                        f' + {bo.map_iters} map it x {bo.map_rays} rays ({bo.map_geo_iters} geometry + {bo.map_iters - bo.map_geo_iters} colour) per frame, '
+                                        f'window {bo.window}, ' + ('dynamic radii, ' if bo.dynamic_radius else '') + ('exposure encoding, ' if bo.exposure else '') +
+                                        f'mapped-frame extras every {bo.every_frame}th step, N={wo.b.n_points} points'}
+            del wo
     if world > 1:
         t = torch.tensor([dt, dt_iter, dt_host], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,6 +236,12 @@ def main():
         # feature-gradient scatter; tracking iterations have no scatter: 2 x 11.1 KB/ray)
         step_bytes = world * (budget.map_iters * budget.map_rays * 31.6e3 + budget.track_iters * budget.track_rays * 22.2e3)
         out['hbm_frac_whole_step'] = step_bytes * args.steps / dt / (world * profile.PEAK_HBM_GBS * 1e9)
+        # the same step against the fp32 matrix roof SURVEY 8d names: algorithmic MLP FLOPs (forward + backward-data + weight gradients of
+        # every iteration, profile.step_flops) / time / 157.3 TFLOP/s
+        if out['roofline'] is not None:
+            out['roofline']['whole_step_fp32_frac'] = world * profile.step_flops(budget) * args.steps / dt / (world * profile.PEAK_F32_MFMA_TFLOPS * 1e12)
+        if others:
+            out['workloads'] = others
         out['host_cores'] = os.cpu_count()
         # every timed kernel against its own roof, from the profiled warm-up step (events around every launch, so slightly slower
         # than the timed region): the dominant kernel changes with small shifts - k_wgrad and k_decode_bwd are within 2 % of each other

@@ -490,8 +490,9 @@ int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t
  * searches ahead of its loop on a library-owned stream.  Valid after the phase-1 call of iteration it - 1 (or it) of the same
  * optimize_map call has returned. */
 int lk_map_wait_lists(const lk_map_desc* d, int32_t it, void* stream);
-/* `stream` waits until the feature-row gradients of the LAST phase-1 call issued with lk_map_desc::signal_rows are final (no-op when the
- * library runs on the launch stream only). */
+/* `stream` waits until the feature-row gradients of the LAST phase-1 call issued with lk_map_desc::signal_rows are final.  The event is
+ * recorded on that call's launch stream whatever the library's stream mode (with LK_SERIAL / lk_set_serial, or after a failed side-stream
+ * creation, too: the waiter always gets a real dependency on the backward); a no-op only if no call has signalled yet. */
 int lk_map_wait_rows(const lk_map_desc* d, void* stream);
 
 /* ---------------------------------------------------------------- weight-gradient building block
@@ -522,10 +523,6 @@ int lk_profile_end(char* buf, int cap);
  * registers and LDS of the loaded code objects (hipOccupancyMaxActiveBlocksPerMultiprocessor): out[0..4] = k_decode_fwd,
  * k_decode_bwd (mapper form), k_relpos_fwd, k_relpos_bwd_fused, k_wgrad.  Needs a device. */
 int lk_debug_occupancy(int32_t out[5]);
-/* Debug / A-B switch: the decoder forward in its 16 x 16 x 32 matrix-instruction form (eight waves per 32-sample colour tile, one wave per
- * sixteen geometry samples; k_decode_fwd16) instead of the default 32 x 32 x 16 form.  Same results to fp32 rounding, measured slower on
- * MI355X at the reference's batch sizes; environment LK_C16=1 sets the initial value. */
-int lk_debug_set_c16(int on);
 
 #ifdef __cplusplus
 }

@@ -157,6 +157,7 @@ static int check_desc(const lk_render_desc* d, const char* who) {
 // rows of the batch counting-sorted by point for the feature-gradient gather (k_seg_count .. k_seg_place, lk_bwd2.hip): on the
 // second stream when there is one (it needs nothing but the neighbour indices), the caller's stream waits for `link` later
 namespace { struct SideStream; SideStream& side_stream(); }
+static void lk_wait_side_join(hipStream_t st);       // `st` waits for the weight-gradient stream's last join event (defined behind SideStream)
 static void seg_args(const lk_render_desc* d, int P, LkFeatScatterArgs& fs);
 static int seg_sort_async(const lk_render_desc* d, int P, bool counted, hipStream_t st);
 
@@ -172,6 +173,7 @@ static void fill_sample_args(const lk_render_desc* d, int P, bool all_pos, LkSam
     sa.seg_cnt = nullptr; sa.seg_rank = nullptr; sa.row_mask = nullptr; sa.live_rays = nullptr;
     sa.seg_P = 0; sa.seg_cnt_stride = 0; sa.seg_live = nullptr; sa.seg_key = nullptr;
     sa.rp_plain = nullptr; sa.rp_frag = nullptr; sa.rp_block0 = 0; sa.rp_copy_dst = nullptr; sa.rp_copy_n = 0; sa.rp_block1 = 0;
+    sa.rp_m_lo = sa.rp_m_hi = sa.rp_skip_lo = sa.rp_skip_hi = 0;
 }
 // z and the neighbour lists of a batch (the part of the sampler that does not read the feature tables); needs ZERO_ABSENT /
 // ALL_DEPTH_POS batches (no far_bb statistics)
@@ -192,7 +194,7 @@ int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount
 extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
 
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays, const LkRepackRider* repack, const LkTrackFinalArgs* pose,
-                       const LkTrackLossArgs* comp, int* comp_tiles) {
+                       const LkTrackLossArgs* comp, int* comp_tiles, bool join_side_before_decode) {
     int rc = check_desc(d, "lk_render_fwd");
     if (rc != LK_OK) return rc;
     if (d->R == 0) return LK_OK;
@@ -216,6 +218,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     if (repack) {
         sa.rp_plain = repack->src ? repack->src : d->weights; sa.rp_frag = repack->frag;
         if (repack->copy_dst && repack->src) { sa.rp_copy_dst = repack->copy_dst; sa.rp_copy_n = repack->copy_n; }
+        if (repack->skip_trunk) { sa.rp_m_lo = LK_FRAG_COL_LO; sa.rp_m_hi = LK_FRAG_COL_HI; sa.rp_skip_lo = C_EB; sa.rp_skip_hi = R_EB; }
     }
     LK_REQUIRE(!pose || !(skip & LK_PRESAMPLED), "lk_render_fwd: the pose prologue belongs to the search launch");
     lk_launch_sample_interp(sa, st, (skip & LK_PRESAMPLED) ? 2 : 0, pose);
@@ -241,6 +244,12 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         ra.W = d->weights; ra.Wfrag = d->weights_frag; ra.noise_col = d->noise_col; ra.c_col = d->c_col;
         if (fuse_small) lk_launch_relpos_decode_fwd(ra, da, st, comp, comp_tiles);
         else lk_launch_relpos_fwd(ra, st);
+    }
+    if (join_side_before_decode) {
+        // split step of the iteration before (LkBwdExtra::split_reduce): the colour trunk's stepped weights and fragments come from the
+        // weight-gradient stream - first needed here; the interpolation and the rel-pos MLP above read rows, the blob's other spans and
+        // the rel-pos fragments, which the launch stream itself stepped and repacked
+        lk_wait_side_join(st);
     }
     if (!fuse_small) lk_launch_decode_fwd(da, st);
 
@@ -278,7 +287,7 @@ extern "C" int64_t lk_render_bwd_scratch_floats(int32_t R, int32_t S, uint32_t f
 // beside the rel-pos backward and the feature scatter (fork / join with events; created once per process).
 namespace {
 int g_serial = -1;            // -1: not decided yet (environment LK_SERIAL), 0 / 1: set by lk_set_serial
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr, fork0 = nullptr, link = nullptr, rows = nullptr; bool ok = false; bool rows_set = false; };
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, mid = nullptr, join = nullptr, fork0 = nullptr, link = nullptr; bool ok = false; };
 SideStream& side_stream() {
     static SideStream s, none;
     if (g_serial < 0) g_serial = getenv("LK_SERIAL") != nullptr ? 1 : 0;
@@ -289,13 +298,16 @@ SideStream& side_stream() {
                hipEventCreateWithFlags(&s.mid, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&s.fork0, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&s.link, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&s.rows, hipEventDisableTiming) == hipSuccess;
+               hipEventCreateWithFlags(&s.link, hipEventDisableTiming) == hipSuccess;
     }
     return s;
 }
 }  // namespace
 
+static void lk_wait_side_join(hipStream_t st) {
+    SideStream& s = side_stream();
+    if (s.ok) (void)hipStreamWaitEvent(st, s.join, 0);
+}
 extern "C" int lk_set_serial(int32_t on) { g_serial = on ? 1 : 0; return LK_OK; }
 // Creates the library's two streams NOW instead of at their first use.  The runtime hands its few hardware queues to streams as they are
 // created: a process that first creates dozens of other streams (torch's stream pool comes into being with the first collective of a
@@ -311,9 +323,19 @@ extern "C" int lk_streams_init(void) {
     if (!(s.ok && a.ok)) { g_serial = 1; lk_set_error("lk_streams_init: stream / event creation failed - running on the launch stream only"); }
     return LK_OK;
 }
+// "the feature-row gradients of the backward are final" (lk_map_desc::signal_rows -> lk_map_wait_rows): an event of its own, recorded on
+// the LAUNCH stream right behind the gather - it does not depend on the side streams, so a caller that exchanges the rows on a
+// communication stream is ordered behind the backward in the serial mode too (LK_SERIAL, or side-stream creation failed); if the event
+// cannot be created the backward that was asked to signal fails instead of leaving the waiter without a dependency
+namespace { hipEvent_t g_rows_ev = nullptr; bool g_rows_set = false; }
+static int rows_event_record(hipStream_t st) {
+    if (g_rows_ev == nullptr) LK_HIP_TRY(hipEventCreateWithFlags(&g_rows_ev, hipEventDisableTiming));
+    LK_HIP_TRY(hipEventRecord(g_rows_ev, st));
+    g_rows_set = true;
+    return LK_OK;
+}
 int lk_wait_rows_event(hipStream_t st) {
-    SideStream& s = side_stream();
-    if (s.ok && s.rows_set) LK_HIP_TRY(hipStreamWaitEvent(st, s.rows, 0));
+    if (g_rows_set) LK_HIP_TRY(hipStreamWaitEvent(st, g_rows_ev, 0));
     return LK_OK;
 }
 extern "C" int lk_debug_occupancy(int32_t out[5]) {
@@ -398,9 +420,8 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     cb.d_depth = d->d_depth; cb.d_var = d->d_var; cb.d_color = color ? d->d_color : nullptr;
     cb.d_raw = S0 + L.d_raw; cb.keep_depth = (flags & LK_FLAG_Z_GIVEN) ? 1 : 0;
     // the composite backward as the prologue of the decoder backward (every lane: its own sample) instead of a launch in front of it;
-    // k_geo_wgrad reads the d raw array (LK_FLAG_GRAD_GEO_DECODER: the launch stays).  LK_CB_INLINE=0: the launch (A/B)
-    static const bool cb_inline_on = []{ const char* e = getenv("LK_CB_INLINE"); return e == nullptr || e[0] != '0'; }();
-    const bool cb_inline = cb_inline_on && !(skip & LK_SKIP_COMPOSITE_BWD) && !(gw && (flags & LK_FLAG_GRAD_GEO_DECODER));
+    // k_geo_wgrad reads the d raw array (LK_FLAG_GRAD_GEO_DECODER: the launch stays)
+    const bool cb_inline = !(skip & LK_SKIP_COMPOSITE_BWD) && !(gw && (flags & LK_FLAG_GRAD_GEO_DECODER));
     if (!(skip & LK_SKIP_COMPOSITE_BWD) && !cb_inline) lk_launch_composite_bwd(cb, st);
 
     // tracker-sized batches: rel-pos backward + interpolation backward in one launch (k_relpos_interp_bwd)
@@ -456,9 +477,11 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     const bool bg_rides = gw && !defer && gf;
     if (gw && !defer && !bg_rides) lk_launch_reduce_partials(S0 + L.part_bg, lk_cdiv(lk_cdiv(P, 32), 4), 288, d->g_weights + G_EB, st);
 
-    static const bool dw2_rider_on = []{ const char* e = getenv("LK_DW2_RIDER"); return e == nullptr || e[0] != '0'; }();
-    const bool dw2_rides = dw2_rider_on && gf && gwf && relpos && lk_relpos_fused(flags);
+    const bool dw2_rides = gf && gwf && relpos && lk_relpos_fused(flags);
     const bool forked = gwf && color && ss.ok;
+    // split step (LkBwdExtra::split_reduce): see the struct; needs the fork, the deferred reduction and the step rider
+    const bool split = forked && defer && ex && ex->split_reduce && ex->step && ex->step->n_span > 0 && ex->split_frag && ex->split_master;
+    if (ex && ex->split_done) *ex->split_done = split ? 1 : 0;
     hipStream_t wst = st;                      // stream of the weight-gradient launches
     if (forked) {
         (void)hipEventRecord(ss.fork, st);
@@ -508,6 +531,16 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         wa.h16 = (flags & LK_FLAG_UNIT_LOSS_GRADS) && !gr ? 1 : 0;
         wa.live_rays = ex ? ex->live_rays : nullptr; wa.S = d->S; wa.dscale = ex ? ex->dscale : nullptr;
         lk_launch_wgrad(wa, P, wst, defer ? &wdef : nullptr);
+        if (split) {
+            // the trunk's half of the step, right behind its weight gradients on their stream: tile sums + fc_c products with the Adam rider
+            // (new values -> w_next), then the stepped trunk over the master blob and its fragments.  Everything it reads was written before
+            // the fork or by k_wgrad; everything it writes (trunk spans of w_next / master / Adam state / g_weights, trunk fragments) is read
+            // again only behind the join, which the NEXT iteration's forward places in front of its decoder launch.
+            LkBwdReduceArgs rt;
+            memset(&rt, 0, sizeof(rt));
+            lk_launch_bwd_reduce(wdef, rt, false, wst, ex->step, false);
+            lk_launch_repack_trunk(ex->step->w_next, ex->split_master, ex->split_frag, wst);
+        }
     }
 
     if (relpos) {
@@ -540,14 +573,17 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         else if (ss.ok) (void)hipStreamWaitEvent(st, ss.link, 0);
         fs.act_flag = ex ? ex->act_flag : nullptr;
         if (bg_rides) { fs.red_part = S0 + L.part_bg; fs.red_n = lk_cdiv(lk_cdiv(P, 32), 4); fs.red_width = 288; fs.red_out = d->g_weights + G_EB; }
-        if (dw2_rides) {       // linear2 of the rel-pos MLP: k_dw2_hbar's blocks in front of the gather's (LK_DW2_RIDER=0: a launch of its own, below)
+        if (dw2_rides) {       // linear2 of the rel-pos MLP: k_dw2_hbar's blocks in front of the gather's (without feature gradients: a launch of its own, below)
             fs.dw2_dc = S0 + L.dc_col; fs.dw2_w_sum = S0 + L.w_sum; fs.dw2_hbar = S0 + L.hbar; fs.dw2_part = S0 + L.dw2_part;
             fs.dw2_blocks = lk_dw2_parts(P); fs.dw2_live = ex ? ex->live_rays : nullptr; fs.dw2_S = d->S;
         }
         if (ex && ex->xstep) { fs.x_on = 1; fs.x = *ex->xstep; }
         lk_launch_feat_scatter(fs, st);
         // data-parallel caller: the feature-row gradients are final from here (lk_map_desc::signal_rows)
-        if (ex && ex->signal_rows && ss.ok) { (void)hipEventRecord(ss.rows, st); ss.rows_set = true; }
+        if (ex && ex->signal_rows) {
+            const int rc3 = rows_event_record(st);
+            if (rc3 != LK_OK) return rc3;
+        }
     }
     if (gr) {
         LkInterpBwdArgs ib;
@@ -596,7 +632,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             lk_launch_wgrad(wr, 8 * P, wst);
         }
     }
-    if (forked) { (void)hipEventRecord(ss.join, wst); (void)hipStreamWaitEvent(st, ss.join, 0); }
+    if (forked) { (void)hipEventRecord(ss.join, wst); if (!split) (void)hipStreamWaitEvent(st, ss.join, 0); }
     if (defer) {
         float* G = d->g_weights;
         LkBwdReduceArgs r;
@@ -608,7 +644,11 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             r.part_br = S0 + L.part_br; r.n_br = lk_relpos_bwd_parts(P); r.out_br = G + R_EB;
         }
         r.part_bg = S0 + L.part_bg; r.n_bg = lk_cdiv(lk_cdiv(P, 32), 4); r.out_bg = G + G_EB;
-        lk_launch_bwd_reduce(wdef, r, with_rp, st, ex ? ex->step : nullptr);
+        if (split) {        // the launch stream's half: what its own kernels left (rel-pos tiles, Fourier partials) + the feature rows
+            LkWgradArgs none;
+            memset(&none, 0, sizeof(none));
+            lk_launch_bwd_reduce(none, r, with_rp, st, ex->step, true);
+        } else lk_launch_bwd_reduce(wdef, r, with_rp, st, ex ? ex->step : nullptr);
     }
     LK_LAUNCH_CHECK();
     return LK_OK;

@@ -535,8 +535,6 @@ int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_composite_bwd, dim3(lk_cdiv(a.R, 256)), dim3(256), 0, st, a);
     return LK_OK;
 }
-// LK_GEO_BWD_BF16=1 keeps the geometry role on bf16 pieces everywhere (A/B timing, accuracy comparisons)
-static bool lk_geo_bf16_forced() { static const bool f = getenv("LK_GEO_BWD_BF16") != nullptr; return f; }
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_BWD, st);
     const int tiles = lk_cdiv(a.P, 32);
@@ -549,7 +547,7 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     const dim3 grid(n_col + lk_cdiv(tiles, 4));
     // the geometry decoder's backward follows where d depth is bounded as well: unit-scale loss gradients WITHOUT ray gradients (with them
     // the caller is the tracker, whose d depth = 1 / sqrt(var) is not)
-    const bool gh16 = h16 && !(a.flags & LK_FLAG_GRAD_RAYS) && !lk_geo_bf16_forced();
+    const bool gh16 = h16 && !(a.flags & LK_FLAG_GRAD_RAYS);
     if (gh16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true, true>), grid, dim3(256), 0, st, a, n_col);
     else if (gh16) hipLaunchKernelGGL((k_decode_bwd<true, false, true>), grid, dim3(256), 0, st, a, n_col);
     else if (h16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true>), grid, dim3(256), 0, st, a, n_col);

@@ -1115,13 +1115,9 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 template <int NV, int KV, bool H16>
 __device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile, int rows, float dsc) {
     const bool aux_t = J.k_aux > 0 && k0 >= J.k_aux;
-#ifdef LK_PROBE_WG_MODE0        // timing probe (tools/ab_build.sh): only the plain form, so that a deeper ring fits the register file
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
-#else
     if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
     else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
     else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
-#endif
 }
 
 // XCD-AWARE ROW OWNERSHIP.  Several units read the same rows (the 64-column pieces of one operand, or two jobs sharing
@@ -1305,7 +1301,8 @@ __global__ __launch_bounds__(256) void k_bwd_reduce(LkWgradArgs wa, LkBwdReduceA
         else lk_adam_seg_block(step.feat[1], step.beta1, step.beta2, step.eps, q - step.feat_gx, step.feat_gx);
     }
 }
-int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st, const LkStepRider* step) {
+// feat_rows false: without the step rider's feature-row blocks (the trunk's half of a split step)
+int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st, const LkStepRider* step, bool feat_rows) {
     r.ny = lk_cdiv(LK_WG_TILE, 32);
     r.b_wg = wa.part && wa.n_units > 0 ? wa.n_units * r.ny : 0;
     r.b_rp = r.b_wg + (with_rp ? LK_RP_REDUCE_BLOCKS : 0);
@@ -1314,7 +1311,7 @@ int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp,
     r.b_fc = r.b_pr + (r.b_wg > 0 ? wa.n_fc * LK_FC_POST_COLS : 0);
     LkStepRider sr;
     if (step) sr = *step; else sr = LkStepRider{};
-    r.b_ad = r.b_fc + (sr.n_span > 0 ? sr.n_feat * sr.feat_gx : 0);
+    r.b_ad = r.b_fc + ((sr.n_span > 0 && feat_rows) ? sr.n_feat * sr.feat_gx : 0);
     if (r.b_ad > 0) hipLaunchKernelGGL(k_bwd_reduce, dim3(r.b_ad), dim3(256), 0, st, wa, r, sr);
     return LK_OK;
 }

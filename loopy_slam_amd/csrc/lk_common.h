@@ -308,65 +308,6 @@ __device__ __forceinline__ void lk_gemm_h3(f32x16 (&acc)[NB], const u32x4* __res
     }
 }
 
-// ------------------------------------------------------------------ 16 x 16 x 32 tiles ("C16", round 4)
-// v_mfma_f32_16x16x32_f16: D[16 units x 16 samples] += A[16 x 32] B[32 x 16]; lane l = (q4 = l >> 4, n = l & 15) feeds A[unit n][8 k-values of
-// group q4], B[8 k-values of group q4][sample n] and holds D[units 4 q4 .. 4 q4 + 3][sample n] (4 registers).  Half the columns of the 32 x 32
-// form per instruction and half its cycles: a 32-sample tile is TWO accumulators (sample halves) per 16-unit block, so a wave that owns 16
-// units runs two independent chains of matrix instructions where the 32 x 32 form ran one of twice the length, and a 128-wide layer spreads
-// over EIGHT waves (16 units each) instead of four - per wave half the dependent matrix chain and half the activation work per lane.
-// The weight fragments are the SAME blocks as the 32 x 32 form's (lk_weights.h): the 8 k-values of group q4 of the 32-k step (G0, G0 + 1) are
-// exactly what lane (h = q4 & 1, row) of block G0 + (q4 >> 1) holds - units 16 G + 4 h + i and 16 G + 8 + 4 h + i - so an A operand is one
-// 16-byte load per piece at a permuted lane address (four 256-byte runs per wave load), and the matching B operand of lane (q4, n) is
-// {producer lane (q4 & 1, n), producer lane (2 + (q4 & 1), n)} of the wave that owns 16-unit block G0 + (q4 >> 1): producers park their four
-// values per piece as 8 bytes at [consumer lane][half], consumers read 16 contiguous bytes (lk_c16_park / lk_c16_read).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 lk_mfma16_f16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lk_f16x8, a), __builtin_bit_cast(lk_f16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 lk_mma3h16(const LkH8& a, const LkH8& b, f32x4 acc) {
-    acc = lk_mfma16_f16(a.p[1], b.p[0], acc);
-    acc = lk_mfma16_f16(a.p[0], b.p[1], acc);
-    acc = lk_mfma16_f16(a.p[0], b.p[0], acc);
-    return acc;
-}
-// A operand: units 16 ub .. 16 ub + 15 of the matrix (ub counts 16-unit blocks), reduction values of the 16-k blocks (G0, G0 + 1);
-// NBT = 32-unit blocks per G of the matrix's fragment form.  gmax: last existing 16-k block of the run (an odd run's last step pairs its
-// last block with nothing: the lanes of the missing block feed zeros)
-__device__ __forceinline__ LkH8 lk_fragh_load16(const u32x4* __restrict__ fragh, int NBT, int G0, int ub, int lane, int gmax = 1 << 30) {
-    const int q4 = lane >> 4;
-    const int G = G0 + (q4 >> 1);
-    const u32x4* __restrict__ q = fragh + ((size_t)(G <= gmax ? G : gmax) * NBT + (ub >> 1)) * 128 + ((q4 & 1) * 32 + 16 * (ub & 1) + (lane & 15));
-    LkH8 a;
-    a.p[0] = q[0]; a.p[1] = q[64];
-    if (G > gmax) { a.p[0] = u32x4{0u, 0u, 0u, 0u}; a.p[1] = u32x4{0u, 0u, 0u, 0u}; }
-    return a;
-}
-// the two fp16 pieces of four values (the same cut as lk_split8h)
-struct LkH4 { uint2 p[2]; };
-__device__ __forceinline__ LkH4 lk_split4h(float x0, float x1, float x2, float x3) {
-    const lk_f16x2 h0 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h1 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
-    const lk_f16x2 l0 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h0[0], x1 - (float)h0[1]);
-    const lk_f16x2 l1 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)h1[0], x3 - (float)h1[1]);
-    LkH4 s;
-    s.p[0] = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-    s.p[1] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
-    return s;
-}
-// park the pieces of the four values lane (q4, n) holds of 16-unit block ub for sample half sh: region = [32-k step][sh][piece][64 lanes] u32x4
-__device__ __forceinline__ void lk_c16_park(u32x4* __restrict__ region, int ub, int sh, const LkH4& s, int lane) {
-    const int q4 = lane >> 4;
-    const int lane_c = (2 * (ub & 1) + (q4 & 1)) * 16 + (lane & 15);
-    uint2* __restrict__ r = reinterpret_cast<uint2*>(region);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) r[(((((ub >> 1) * 2 + sh) * 2 + q) * 64 + lane_c) << 1) + (q4 >> 1)] = s.p[q];
-}
-__device__ __forceinline__ LkH8 lk_c16_read(const u32x4* __restrict__ region, int kb, int sh, int lane) {
-    LkH8 b;
-    b.p[0] = region[((kb * 2 + sh) * 2 + 0) * 64 + lane];
-    b.p[1] = region[((kb * 2 + sh) * 2 + 1) * 64 + lane];
-    return b;
-}
-
 // Barrier among SOME waves of a workgroup (s_barrier waits for every wave of the workgroup that has not ended: a wave that runs a long chain
 // of its own - the geometry decoder on wave 4 of the tracker's fused forward - holds the others at their first barrier until it is through).
 // cnt: an LDS word, zero when the participants start; target = participants x (ordinal of this barrier, from 1).  Every participant calls

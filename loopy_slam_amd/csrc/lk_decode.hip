@@ -183,13 +183,6 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
     return part + W[G_BO];
 }
 
-#ifdef LK_PROBE_CLK      // timing probe (tools/probe/decode_clock.py): shader-clock stamps of the first workgroups' waves at the phase boundaries
-__device__ unsigned long long lk_dbg_clk[8 * 4 * 32];
-#define LK_CLK(i) do { __builtin_amdgcn_sched_barrier(0); if (tile < 8 && lane == 0) lk_dbg_clk[(tile * 4 + w) * 32 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-extern "C" int lk_debug_clk_read(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(lk_dbg_clk), sizeof(lk_dbg_clk)); }
-#else
-#define LK_CLK(i)
-#endif
 // ================= colour decoder (hidden 128, softplus beta=100): FOUR waves = one 32-sample tile =================
 // Wave w owns output units [32w, 32w+32) of every layer (one accumulator, 48 matrix instructions per 128-wide layer), so
 // a tile's serial chain is a quarter of the one-wave form and a training batch (a few hundred tiles) spreads over four
@@ -226,7 +219,6 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         if (SOFTBAR) lk_soft_barrier(s_cnt, 4u * (++n_bar));
         else __syncthreads();
     };
-    LK_CLK(0);
     {
         const int t = (int)threadIdx.x;
 #pragma unroll
@@ -349,18 +341,14 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         }
     };
     f32x16 acc;
-    LK_CLK(1);
     // layer 0: 40 -> 128
     prefetch_u(FB + FM15_FWDH);
     acc = ct_bias_lds(s_bias[0], w * 32, lane);
     embed(acc, FB + FM10_FWDH, false);
     prefetch_hidden(FB + FM11_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
-    LK_CLK(2);
     finish(acc, act_col_a, 0, 0);
-    LK_CLK(3);
     wg_barrier();
-    LK_CLK(4);
     // layers 1, 2: 128 -> 128
 #pragma unroll
     for (int L = 1; L <= 2; ++L) {
@@ -370,11 +358,8 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         if (L == 1) prefetch_hidden(FB + FM12_FWDH, 0);
         else prefetch_hidden(FB + FM13_FWDH, 3);
         __builtin_amdgcn_sched_barrier(0);
-        LK_CLK(2 + 3 * L);
         finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, L) : nullptr, L, L & 1);
-        LK_CLK(3 + 3 * L);
         wg_barrier();
-        LK_CLK(4 + 3 * L);
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
     prefetch_u(FB + FM18_FWDH);
@@ -383,18 +368,13 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     hidden(acc, FB + FM13_FWDH, 3, 0);
     prefetch_hidden(FB + FM14_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
-    LK_CLK(11);
     finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, 3) : nullptr, 3, 1);
-    LK_CLK(12);
     wg_barrier();
-    LK_CLK(13);
     // layer 4
     prefetch_u(FB + FM19_FWDH);
     acc = ct_bias_lds(s_bias[4], w * 32, lane);
     hidden(acc, FB + FM14_FWDH, 0, 1);
-    LK_CLK(14);
     finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, 4) : nullptr, 4, -1);
-    LK_CLK(15);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
@@ -430,7 +410,6 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         }
         if (s_raw) { s_raw[4 * lane] = o0; s_raw[4 * lane + 1] = o1; s_raw[4 * lane + 2] = o2; }
     }
-    LK_CLK(16);
 }
 
 // Block roles: `n_col_blocks` workgroups are colour tiles (4 waves per tile), the others run the geometry
@@ -558,16 +537,16 @@ __global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
 // one barrier, then waves 0..3 decode the tile's colour as decode_col_wg does, wave 4 runs the geometry decoder of the SAME tile (no
 // barriers in it) and waves 5..7 leave - a barrier only counts the waves still alive.  One workgroup per tile and nothing else in the
 // grid: an eight-wave workgroup at this register count fills a compute unit, and a tracking batch (235 tiles) must not need a second round.
-// SOFTBAR: the four colour waves use a barrier of their own.  With s_barrier they stood at their FIRST barrier until wave 4 - the geometry
+// The four colour waves use a barrier of their own (decode_col_wg<.., SOFTBAR>).  With s_barrier they stood at their FIRST barrier until wave 4 - the geometry
 // decoder, no barrier in it - had ended: the hardware barrier waits for every wave of the workgroup that is still alive (shader-clock
 // stamps, profiles/r4_decode_clock32.txt: 23 k cycles in the decode's set-up phase of the tracker's launch against 7.7 k for the same
 // code in the mapper's, where the geometry tiles are workgroups of their own).
-// COMP (with SOFTBAR; the tracking loop): pass 1 of the tracker's loss is the launch's epilogue.  Tiles hold WHOLE rays (a.tile_stride = (32 / S) S
+// COMP (the tracking loop): pass 1 of the tracker's loss is the launch's epilogue.  Tiles hold WHOLE rays (a.tile_stride = (32 / S) S
 // samples, 30 of the 32 lanes at S = 5: 250 tiles instead of 235 for 1 500 rays, still one per compute unit); wave 4 leaves its occupancies and
 // wave 0 its colours in LDS as raw rows, wave 0 waits for wave 4 (a counter in LDS, as the soft barrier) and its first lanes composite one ray
 // each (lk_composite_ray on the LDS rows: the arithmetic of k_track_composite), write the ray's outputs and residual, and the tile's
 // (sum of residuals, #present rays) pair - the mask threshold's partial sums are per tile instead of per 256 rays (5 us of an iteration of 117)
-template <bool DEEP, bool SOFTBAR, bool COMP>
+template <bool DEEP, bool COMP>
 __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDecodeArgs a, LkTrackLossArgs tl) {
     __shared__ u32x4 s_x[2][16 * 64];
     __shared__ float s_o[4][3 * 32];
@@ -611,7 +590,7 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
             if (s < S) { cz[s] = tl.z[base + lane * S + s]; chas[s] = tl.nbr_count[base + lane * S + s] >= tl.min_nn; }
         }
     }
-    decode_col_wg<DEEP, SOFTBAR>(a, tile, w, lane, s_x, s_o, s_bias, &s_cnt, COMP ? s_raw : nullptr);
+    decode_col_wg<DEEP, true>(a, tile, w, lane, s_x, s_o, s_bias, &s_cnt, COMP ? s_raw : nullptr);
     if (COMP && w == 0) {
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
@@ -638,364 +617,10 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
         if (tile == 0 && lane < 4) tl.out4[lane] = 0.0f;        // the loss row pass 2 accumulates into
     }
 }
-// LK_SOFTBAR=0 switches the colour waves back to s_barrier (A/B)
-static bool lk_softbar() { static const bool on = []{ const char* e = getenv("LK_SOFTBAR"); return e == nullptr || e[0] != '0'; }(); return on; }
-
-// =====================================================================================================================================
-// The 16 x 16 x 32 form of both decoders (lk_common.h "C16"; round 4).  Same arithmetic per product (fp16x3), same saved rows, other shape:
-//   colour trunk: EIGHT waves per 32-sample tile, wave w owns units [16 w, 16 w + 16) of every layer as two accumulators (sample halves);
-//                 per layer and wave 24 + 6 matrix instructions of 16 cycles in two independent chains (the 32 x 32 form: 24 + 6 of 32 cycles
-//                 in ONE chain) and 8 activations per lane instead of 16; activations travel through LDS as parked pieces, one barrier per layer;
-//   geometry    : one wave per SIXTEEN samples, two accumulators (the two 16-unit blocks); the chain from one layer to the next goes
-//                 through a 2-KB piece buffer of the wave's own (the lane that holds a value of the accumulator layout is not the lane that feeds
-//                 it to the next product), ordered by a wave barrier, no workgroup barrier.
-#ifdef LK_PROBE_CLK
-__device__ unsigned long long lk_dbg_clk16[8 * 8 * 32];         // colour: [tile < 8][wave][stamp]
-__device__ unsigned long long lk_dbg_clkg[64 * 16];             // geometry: [16-sample tile < 64][stamp]
-#define LK_CLK16(i) do { __builtin_amdgcn_sched_barrier(0); if (tile < 8 && lane == 0) lk_dbg_clk16[(tile * 8 + w) * 32 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define LK_CLKG(i) do { __builtin_amdgcn_sched_barrier(0); if (tile16 < 64 && lane == 0) lk_dbg_clkg[tile16 * 16 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-extern "C" int lk_debug_clk16_read(unsigned long long* col, unsigned long long* geo) {
-    int e = (int)hipMemcpyFromSymbol(col, HIP_SYMBOL(lk_dbg_clk16), sizeof(lk_dbg_clk16));
-    return e ? e : (int)hipMemcpyFromSymbol(geo, HIP_SYMBOL(lk_dbg_clkg), sizeof(lk_dbg_clkg));
-}
-#else
-#define LK_CLK16(i)
-#define LK_CLKG(i)
-#endif
-struct DecSample16 { int sample[2], sp[2]; bool live[2]; float a0[2], a1[2], a2[2]; };
-__device__ __forceinline__ void dec_sample16_fill(const LkDecodeArgs& a, int sample, int k, DecSample16& d) {
-    d.sample[k] = sample;
-    d.live[k] = sample < a.P;
-    d.sp[k] = d.live[k] ? sample : a.P - 1;
-    const int r = d.sp[k] / a.S;
-    const float z = a.z[d.sp[k]];
-    const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
-    const float py = lk_madd_rn(a.rays_o[3 * r + 1], a.rays_d[3 * r + 1], z);
-    const float pz = lk_madd_rn(a.rays_o[3 * r + 2], a.rays_d[3 * r + 2], z);
-    d.a0[k] = __fmul_rn(LK_TWO_PI, px); d.a1[k] = __fmul_rn(LK_TWO_PI, py); d.a2[k] = __fmul_rn(LK_TWO_PI, pz);
-}
-// the eight channels lane (q4, n) feeds to a product over the 32 channels of an interpolated feature row: 16 G + 4 h + i, 16 G + 8 + 4 h + i
-__device__ __forceinline__ LkH8 c16_feature_pieces(const float* __restrict__ crow, int lane) {
-    const int q4 = lane >> 4;
-    const float4 v0 = *reinterpret_cast<const float4*>(crow + 16 * (q4 >> 1) + 4 * (q4 & 1));
-    const float4 v1 = *reinterpret_cast<const float4*>(crow + 16 * (q4 >> 1) + 8 + 4 * (q4 & 1));
-    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    return lk_split8h(v);
-}
-__device__ __forceinline__ f32x4 c16_bias4(const float* __restrict__ v, int unit0) {
-    const float4 b = *reinterpret_cast<const float4*>(v + unit0);
-    return f32x4{b.x, b.y, b.z, b.w};
-}
-
-__device__ __forceinline__ void decode_geo_wave16(const LkDecodeArgs& a, int tile16, int lane, u32x4* __restrict__ s_g /* [2][2 * 64] of this wave */) {
-    const int q4 = lane >> 4;
-    LK_CLKG(0);
-    DecSample16 d;
-    dec_sample16_fill(a, tile16 * 16 + (lane & 15), 0, d);
-    const bool live = d.live[0];
-    const int sp = d.sp[0];
-    const float a0 = d.a0[0], a1 = d.a1[0], a2 = d.a2[0];
-    const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;
-    const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
-    float* act_geo = save ? a.act + (size_t)sp * LK_ACT_GEO_A : nullptr;
-    LkH8 eb[3], cb;
-#pragma unroll
-    for (int kb = 0; kb < 3; ++kb) {
-        float v[8];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int u0 = 16 * (2 * kb + (q4 >> 1)) + 8 * half + 4 * (q4 & 1);
-            const float4 b0 = *reinterpret_cast<const float4*>(W + G_EB + u0);
-            const float4 b1 = *reinterpret_cast<const float4*>(W + G_EB + EGP + u0);
-            const float4 b2 = *reinterpret_cast<const float4*>(W + G_EB + 2 * EGP + u0);
-            v[4 * half + 0] = (u0 + 0 < EG) ? lk_sinf(lk_fourier_arg(a0, a1, a2, b0.x, b1.x, b2.x)) : 0.0f;
-            v[4 * half + 1] = (u0 + 1 < EG) ? lk_sinf(lk_fourier_arg(a0, a1, a2, b0.y, b1.y, b2.y)) : 0.0f;
-            v[4 * half + 2] = (u0 + 2 < EG) ? lk_sinf(lk_fourier_arg(a0, a1, a2, b0.z, b1.z, b2.z)) : 0.0f;
-            v[4 * half + 3] = (u0 + 3 < EG) ? lk_sinf(lk_fourier_arg(a0, a1, a2, b0.w, b1.w, b2.w)) : 0.0f;
-        }
-        eb[kb] = lk_split8h(v);
-    }
-    cb = c16_feature_pieces(a.c_geo + (size_t)sp * LK_C, lane);
-    f32x4 acc[2];
-    // relu + saved row + fc_c(c) of one layer, then the pieces of h for the next product
-    auto finish = [&](int L, const u32x4* ufrag, bool park) {
-#pragma unroll
-        for (int ub = 0; ub < 2; ++ub) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ub][r] = fmaxf(acc[ub][r], 0.0f);
-            if (act_geo && live) *reinterpret_cast<float4*>(act_geo + 32 * L + 16 * ub + 4 * q4) = make_float4(acc[ub][0], acc[ub][1], acc[ub][2], acc[ub][3]);
-            acc[ub] += c16_bias4(W + G_U0 + L * G_USTRIDE + a64(HG * CF), 16 * ub + 4 * q4);
-            acc[ub] = lk_mma3h16(lk_fragh_load16(ufrag, 1, 0, ub, lane), cb, acc[ub]);
-        }
-        if (park) {
-#pragma unroll
-            for (int ub = 0; ub < 2; ++ub) lk_c16_park(s_g + (L & 1) * 128, ub, 0, lk_split4h(acc[ub][0], acc[ub][1], acc[ub][2], acc[ub][3]), lane);
-            __builtin_amdgcn_wave_barrier();
-        }
-    };
-    auto start = [&](int boff) {
-#pragma unroll
-        for (int ub = 0; ub < 2; ++ub) acc[ub] = c16_bias4(W + boff, 16 * ub + 4 * q4);
-    };
-    auto embed = [&](const u32x4* frag) {
-#pragma unroll
-        for (int kb = 0; kb < 3; ++kb)
-#pragma unroll
-            for (int ub = 0; ub < 2; ++ub) acc[ub] = lk_mma3h16(lk_fragh_load16(frag, 1, 2 * kb, ub, lane), eb[kb], acc[ub]);
-    };
-    auto hidden = [&](const u32x4* frag, int G0, int L_prev) {
-        const LkH8 b = lk_c16_read(s_g + (L_prev & 1) * 128, 0, 0, lane);
-#pragma unroll
-        for (int ub = 0; ub < 2; ++ub) acc[ub] = lk_mma3h16(lk_fragh_load16(frag, 1, G0, ub, lane), b, acc[ub]);
-    };
-    LK_CLKG(1);
-    start(G_B0); embed(FB + FM0_FWDH); LK_CLKG(2); finish(0, FB + FM5_FWDH, true); LK_CLKG(3);
-    start(G_B1); hidden(FB + FM1_FWDH, 0, 0); LK_CLKG(4); finish(1, FB + FM6_FWDH, true); LK_CLKG(5);
-    start(G_B2); hidden(FB + FM2_FWDH, 0, 1); LK_CLKG(6); finish(2, FB + FM7_FWDH, true); LK_CLKG(7);
-    start(G_B3); embed(FB + FM3_FWDH); hidden(FB + FM3_FWDH, 6, 2); LK_CLKG(8); finish(3, FB + FM8_FWDH, true); LK_CLKG(9);
-    start(G_B4); hidden(FB + FM4_FWDH, 0, 3); LK_CLKG(10); finish(4, FB + FM9_FWDH, false); LK_CLKG(11);
-    float part = 0.0f;
-#pragma unroll
-    for (int ub = 0; ub < 2; ++ub) {
-        const float4 wo = *reinterpret_cast<const float4*>(W + G_WO + 16 * ub + 4 * q4);
-        part = fmaf(wo.x, acc[ub][0], part); part = fmaf(wo.y, acc[ub][1], part);
-        part = fmaf(wo.z, acc[ub][2], part); part = fmaf(wo.w, acc[ub][3], part);
-    }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    if (live && q4 == 0) a.raw[(size_t)d.sample[0] * 4 + 3] = part + W[G_BO];
-}
-
-// LDS of a colour workgroup: s_x [2][16 * 64] activation pieces (double-buffered), s_e [8 * 64] embedding pieces, s_o [8][96], s_bias [10][128]
-__device__ __forceinline__ void decode_col_wg16(const LkDecodeArgs& a, int tile, int w, int lane,
-                                                u32x4 (*s_x)[16 * 64], u32x4* __restrict__ s_e, float (*s_o)[3 * 32], float (*s_bias)[128]) {
-    LK_CLK16(0);
-    {
-        const int t = (int)threadIdx.x;
-        const int b_off[5] = {C_B0, C_B1, C_B2, C_B3, C_B4};
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int e = q * 512 + t, j = e >> 7, u = e & 127;
-            if (e < 1280) s_bias[j][u] = a.W[j < 5 ? b_off[j] + u : C_U0 + (j - 5) * C_USTRIDE + a64(HC * CF) + u];
-        }
-    }
-    const int q4 = lane >> 4;
-    DecSample16 d;
-    dec_sample16_fill(a, tile * 32 + (lane & 15), 0, d);
-    dec_sample16_fill(a, tile * 32 + 16 + (lane & 15), 1, d);
-    const float* __restrict__ W = a.W;
-    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;
-    const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
-    float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A : nullptr;                                   // + layer offset + sample * 128
-    float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) : nullptr;
-    {
-        // the 40 (padded to 64) embedding values of the tile's 32 samples, straight into the consumers' layout: wave w -> 32-k step kbe,
-        // sample half sh, half of the lane's eight values; lane (q4, n) -> the four units u0..u0+3 of sample (sh, n)
-        const int kbe = w >> 2, sh = (w >> 1) & 1, half = w & 1;
-        const int u0 = 16 * (2 * kbe + (q4 >> 1)) + 8 * half + 4 * (q4 & 1);
-        float ev[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ev[i] = sincos_embed_unit(W + C_EB, 20, u0 + i, d.a0[sh], d.a1[sh], d.a2[sh]);
-        if (save && d.live[sh] && u0 < LK_ACT_COL_E) {
-            float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)d.sp[sh] * LK_ACT_COL_E;
-            *reinterpret_cast<float4*>(erow + u0) = make_float4(ev[0], ev[1], ev[2], ev[3]);
-        }
-        const LkH4 s4 = lk_split4h(ev[0], ev[1], ev[2], ev[3]);
-        uint2* se = reinterpret_cast<uint2*>(s_e);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) se[((((kbe * 2 + sh) * 2 + q) * 64 + lane) << 1) + half] = s4.p[q];
-    }
-    LkH8 cb[2];
-#pragma unroll
-    for (int sh = 0; sh < 2; ++sh) cb[sh] = c16_feature_pieces(a.c_col + (size_t)d.sp[sh] * LK_C, lane);
-    __syncthreads();
-    f32x4 acc[2];
-    // Loads and stores share one in-order counter: what the next layer's product needs first (its first two 32-k steps of weights) and this
-    // layer's fc_c block are fetched BEFORE the row stores of the layer (pinned with scheduling barriers), the other two steps come in line.
-    LkH8 wn[2], un;
-    auto start = [&](int L) {
-        const f32x4 b = c16_bias4(s_bias[L], 16 * w + 4 * q4);
-        acc[0] = b; acc[1] = b;
-    };
-    auto prefetch_hidden = [&](const u32x4* frag, int G0) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) wn[kb] = lk_fragh_load16(frag, 4, G0 + 2 * kb, w, lane);
-    };
-    auto embed = [&](const u32x4* frag) {
-#pragma unroll
-        for (int kbe = 0; kbe < 2; ++kbe) {
-            const LkH8 A = lk_fragh_load16(frag, 4, 2 * kbe, w, lane, 2);
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) acc[sh] = lk_mma3h16(A, lk_c16_read(s_e, kbe, sh, lane), acc[sh]);
-        }
-    };
-    auto hidden = [&](const u32x4* frag, int G0, int buf) {
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const LkH8 A = kb < 2 ? wn[kb] : lk_fragh_load16(frag, 4, G0 + 2 * kb, w, lane);
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) acc[sh] = lk_mma3h16(A, lk_c16_read(s_x[buf], kb, sh, lane), acc[sh]);
-        }
-    };
-    auto finish = [&](int L, int buf) {
-        const f32x4 ub = c16_bias4(s_bias[5 + L], 16 * w + 4 * q4);
-        f32x4 act[2];
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[sh][r] = lk_softplus100(acc[sh][r]);
-            act[sh] = acc[sh];
-            acc[sh] += ub;
-            acc[sh] = lk_mma3h16(un, cb[sh], acc[sh]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (save) {
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                if (d.live[sh]) {
-                    const size_t o = LK_COL_LAYER(a.P, L) + (size_t)d.sp[sh] * 128 + 16 * w + 4 * q4;
-                    *reinterpret_cast<float4*>(act_col_a + o) = make_float4(act[sh][0], act[sh][1], act[sh][2], act[sh][3]);
-                    *reinterpret_cast<float4*>(act_col_h + o) = make_float4(acc[sh][0], acc[sh][1], acc[sh][2], acc[sh][3]);
-                }
-            }
-        }
-        if (buf >= 0) {
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) lk_c16_park(s_x[buf], w, sh, lk_split4h(acc[sh][0], acc[sh][1], acc[sh][2], acc[sh][3]), lane);
-        }
-    };
-    LK_CLK16(1);
-    un = lk_fragh_load16(FB + FM15_FWDH, 4, 0, w, lane);
-    start(0); embed(FB + FM10_FWDH);
-    prefetch_hidden(FB + FM11_FWDH, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    LK_CLK16(2);
-    finish(0, 0);
-    LK_CLK16(3);
-    __syncthreads();
-    LK_CLK16(4);
-    un = lk_fragh_load16(FB + FM16_FWDH, 4, 0, w, lane);
-    start(1); hidden(FB + FM11_FWDH, 0, 0);
-    prefetch_hidden(FB + FM12_FWDH, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    LK_CLK16(5);
-    finish(1, 1);
-    LK_CLK16(6);
-    __syncthreads();
-    LK_CLK16(7);
-    un = lk_fragh_load16(FB + FM17_FWDH, 4, 0, w, lane);
-    start(2); hidden(FB + FM12_FWDH, 0, 1);
-    prefetch_hidden(FB + FM13_FWDH, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    LK_CLK16(8);
-    finish(2, 0);
-    LK_CLK16(9);
-    __syncthreads();
-    LK_CLK16(10);
-    un = lk_fragh_load16(FB + FM18_FWDH, 4, 0, w, lane);
-    start(3); embed(FB + FM13_FWDH); hidden(FB + FM13_FWDH, 3, 0);
-    prefetch_hidden(FB + FM14_FWDH, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    LK_CLK16(11);
-    finish(3, 1);
-    LK_CLK16(12);
-    __syncthreads();
-    LK_CLK16(13);
-    un = lk_fragh_load16(FB + FM19_FWDH, 4, 0, w, lane);
-    start(4); hidden(FB + FM14_FWDH, 0, 1);
-    LK_CLK16(14);
-    finish(4, -1);
-    LK_CLK16(15);
-    // output 128 -> 3: per-lane partial over its 4 units, summed over the lane groups, then over the eight waves in fixed order
-    {
-        const float4 w0 = *reinterpret_cast<const float4*>(W + C_WO + 16 * w + 4 * q4);
-        const float4 w1 = *reinterpret_cast<const float4*>(W + C_WO + HC + 16 * w + 4 * q4);
-        const float4 w2 = *reinterpret_cast<const float4*>(W + C_WO + 2 * HC + 16 * w + 4 * q4);
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-            const float v0 = acc[sh][0], v1 = acc[sh][1], v2 = acc[sh][2], v3 = acc[sh][3];
-            float o0 = fmaf(w0.w, v3, fmaf(w0.z, v2, fmaf(w0.y, v1, w0.x * v0)));
-            float o1 = fmaf(w1.w, v3, fmaf(w1.z, v2, fmaf(w1.y, v1, w1.x * v0)));
-            float o2 = fmaf(w2.w, v3, fmaf(w2.z, v2, fmaf(w2.y, v1, w2.x * v0)));
-            o0 += __shfl_xor(o0, 16); o1 += __shfl_xor(o1, 16); o2 += __shfl_xor(o2, 16);
-            o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
-            if (q4 == 0) { const int c = 16 * sh + (lane & 15); s_o[w][c] = o0; s_o[w][32 + c] = o1; s_o[w][64 + c] = o2; }
-        }
-    }
-    __syncthreads();
-    if (w == 0 && lane < 32) {
-        float o[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = s_o[0][32 * c + lane];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) v += s_o[k][32 * c + lane];
-            o[c] = v + W[C_BO + c];
-        }
-        if (a.affine) {
-            const float* A = a.affine;
-            const float t0 = o[0] * A[0] + o[1] * A[3] + o[2] * A[6] + A[9];
-            const float t1 = o[0] * A[1] + o[1] * A[4] + o[2] * A[7] + A[10];
-            const float t2 = o[0] * A[2] + o[1] * A[5] + o[2] * A[8] + A[11];
-            o[0] = t0; o[1] = t1; o[2] = t2;
-        }
-        if (!(a.flags & LK_FLAG_COLOR_LOGITS)) { o[0] = lk_sigmoid(o[0]); o[1] = lk_sigmoid(o[1]); o[2] = lk_sigmoid(o[2]); }
-        const int sample = tile * 32 + lane;
-        if (sample < a.P) { float* out = a.raw + (size_t)sample * 4; out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; }
-    }
-    LK_CLK16(16);
-}
-
-// Block roles of the 16 x 16 x 32 launches: geometry workgroups first (eight waves = eight 16-sample tiles), then one colour workgroup
-// (eight waves) per 32-sample tile.  RELPOS: the colour workgroups first run the rel-pos neighbour MLP of their tile (four samples = 32
-// neighbour rows per wave, as k_relpos_fwd) - the tracker's launches.
-#define LK_C16_LDS_U4 (2 * 16 * 64 + 8 * 64)
-template <bool RELPOS>
-__global__ __launch_bounds__(512, RELPOS ? 2 : 4) void k_decode_fwd16(LkRelposArgs ra, LkDecodeArgs a, int n_col_blocks) {
-    __shared__ u32x4 s_all[LK_C16_LDS_U4];
-    __shared__ float s_o[8][3 * 32];
-    __shared__ float s_bias[10][128];
-    const int lane = lk_lane();
-    const int w = (int)threadIdx.x >> 6;
-    const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;
-    const int n_geo_blocks = (int)gridDim.x - n_col_blocks;
-    if ((int)blockIdx.x < n_geo_blocks) {
-        const int tile16 = (int)blockIdx.x * 8 + w;
-        if (tile16 * 16 >= P_live) return;
-        decode_geo_wave16(a, tile16, lane, s_all + w * 256);
-        if (n_col_blocks == 0) {
-            const int sample = tile16 * 16 + (lane & 15);
-            if (sample < a.P && lane < 16) { float* out = a.raw + (size_t)sample * 4; out[0] = 0.0f; out[1] = 0.0f; out[2] = 0.0f; }
-        }
-        return;
-    }
-    const int tile = (int)blockIdx.x - n_geo_blocks;
-    if (tile * 32 >= P_live) return;
-    LK_CLK16(17);
-    if (RELPOS) {
-        const int sample0 = tile * 32 + 4 * w;
-        if (sample0 < ra.P) relpos_fwd_wave(ra, sample0, ra.P);
-        LK_CLK16(18);
-        __syncthreads();
-    }
-    decode_col_wg16(a, tile, w, lane, reinterpret_cast<u32x4 (*)[16 * 64]>(s_all), s_all + 2 * 16 * 64, s_o, s_bias);
-}
-// The 16 x 16 x 32 form is OFF by default: on one box (three alternating bench pairs + rocprofv3 per-iteration traces, round 4) it measured
-// tracker launch 35.5 -> 35.0 us, geometry launch 15.6 -> 15.8 us, mapper colour launch 46.2 -> 52.7 us, step 18.2 -> 18.6 ms.
-// LK_C16=1 (environment, read once) or lk_debug_set_c16(1) selects it (tests/test_c16_forward.py runs the goldens through both forms).
-static int g_c16 = -1;
-static bool lk_c16_fwd() { if (g_c16 < 0) { const char* e = getenv("LK_C16"); g_c16 = (e != nullptr && e[0] == '1') ? 1 : 0; } return g_c16 != 0; }
-extern "C" int lk_debug_set_c16(int on) { g_c16 = on ? 1 : 0; return LK_OK; }
-
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
     const int tiles = lk_cdiv(a.P, 32);
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
-    if (lk_c16_fwd()) {
-        hipLaunchKernelGGL(k_decode_fwd16<false>, dim3(n_col + lk_cdiv(a.P, 128)), dim3(512), 0, st, LkRelposArgs{}, a, n_col);
-        return LK_OK;
-    }
     if (n_col > 0 && n_col <= LK_DEEP_MAX_TILES_FWD) hipLaunchKernelGGL(k_decode_fwd<true>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     else hipLaunchKernelGGL(k_decode_fwd<false>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     return LK_OK;
@@ -1015,28 +640,23 @@ bool lk_relpos_decode_fusable(const LkDecodeArgs& a) {
     const int tiles = lk_cdiv(a.P, 32);
     return (a.flags & LK_FLAG_STAGE_COLOR) && (a.flags & LK_FLAG_REL_POS) && tiles > 0 && tiles <= LK_DEEP_MAX_TILES_FWD && a.live_rays == nullptr;
 }
-// LK_TRACK_COMP_INLINE=0: pass 1 of the tracker's loss stays a launch of its own (k_track_composite; A/B)
-static bool lk_track_comp_inline() { static const bool on = []{ const char* e = getenv("LK_TRACK_COMP_INLINE"); return e == nullptr || e[0] != '0'; }(); return on; }
+// comp: pass 1 of the tracker's loss as the launch's epilogue where the tiles can hold whole rays (4 <= S <= 32, one round of tiles);
+// *comp_tiles = 0 otherwise and the caller launches k_track_composite
 int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, hipStream_t st, const LkTrackLossArgs* comp, int* comp_tiles) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
     const int tiles = lk_cdiv(a.P, 32);
-    if (lk_c16_fwd()) {
-        hipLaunchKernelGGL(k_decode_fwd16<true>, dim3(tiles + lk_cdiv(a.P, 128)), dim3(512), 0, st, ra, a, tiles);
-        return LK_OK;
-    }
     LkTrackLossArgs tl;
     memset(&tl, 0, sizeof(tl));
     const int ts = a.S > 0 ? (32 / a.S) * a.S : 0;
-    if (comp && lk_softbar() && lk_track_comp_inline() && a.S >= 4 && a.S <= 32 && a.P % a.S == 0 && comp->S == a.S && lk_cdiv(a.P, ts) <= LK_DEEP_MAX_TILES_FWD) {
+    if (comp && a.S >= 4 && a.S <= 32 && a.P % a.S == 0 && comp->S == a.S && lk_cdiv(a.P, ts) <= LK_DEEP_MAX_TILES_FWD) {
         LkDecodeArgs b = a;
         b.tile_stride = ts;
         const int ctiles = lk_cdiv(a.P, ts);
-        hipLaunchKernelGGL((k_relpos_decode_fwd<true, true, true>), dim3(ctiles), dim3(512), 0, st, ra, b, *comp);
+        hipLaunchKernelGGL((k_relpos_decode_fwd<true, true>), dim3(ctiles), dim3(512), 0, st, ra, b, *comp);
         if (comp_tiles) *comp_tiles = ctiles;
         return LK_OK;
     }
-    if (lk_softbar()) hipLaunchKernelGGL((k_relpos_decode_fwd<true, true, false>), dim3(tiles), dim3(512), 0, st, ra, a, tl);
-    else hipLaunchKernelGGL((k_relpos_decode_fwd<true, false, false>), dim3(tiles), dim3(512), 0, st, ra, a, tl);
+    hipLaunchKernelGGL((k_relpos_decode_fwd<true, false>), dim3(tiles), dim3(512), 0, st, ra, a, tl);
     return LK_OK;
 }
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {

@@ -31,6 +31,7 @@ struct LkSampleArgs {
     // interpolation-only launches (mode 2): fragment repack of plain -> frag as a rider (k_interp_repack); NULL: none
     const float* rp_plain; float* rp_frag; int rp_block0;
     float* rp_copy_dst; int rp_copy_n, rp_block1;   // blocks >= rp_block1: rp_copy_dst[0 .. n) = rp_plain[..] (the stepped blob of the step rider, LkStepRider::w_next)
+    int rp_m_lo, rp_m_hi, rp_skip_lo, rp_skip_hi;   // split step: the matrices [rp_m_lo, rp_m_hi) of the table are NOT repacked, the floats [rp_skip_lo, rp_skip_hi) not copied (0, 0: all)
     const int32_t* live_rays;                     // see LkRelposArgs: with it the sampler gives the skipped samples their colour feature (noise)
 };
 
@@ -86,7 +87,7 @@ struct LkCompositeBwdArgs {
     int keep_depth;                                // as LkCompositeArgs
 };
 
-// tracker loss in two passes (lk_loop.hip: k_track_composite, then k_track_loss2 or - LkDecodeBwdArgs::tl_n_part - the prologue of k_decode_bwd)
+// tracker loss in two passes (lk_loop.hip: k_track_composite or the epilogue of k_relpos_decode_fwd, then - LkDecodeBwdArgs::tl_n_part - the prologue of k_decode_bwd)
 struct LkTrackLossArgs {
     int R, S, min_nn;
     float coef, w_color;
@@ -173,6 +174,9 @@ struct AdamSegDev {
 // soon as it has its sum (new value -> w_next: the master blob is read by the fc_c blocks of the same launch and stays as it was
 // until the next iteration's interpolation launch copies w_next over it), and the feature-row segments - final since the gather -
 // run as extra blocks.  One dispatch (11 us + its gap) less per iteration.
+#ifndef LK_SPLIT_STEP
+#define LK_SPLIT_STEP 1         // (a variant library built with -DLK_SPLIT_STEP=0 is the A/B partner: tools/ab_build.sh)
+#endif
 struct LkStepSpan { int off, n; float step_size, bc2_sqrt; };
 struct LkStepRider {
     int n_span;                                    // decoder spans (offsets into the blob); 0 = no rider
@@ -186,6 +190,11 @@ struct LkBwdExtra { float* pose_part; const float* pix_i; const float* pix_j; fl
                     int32_t* seg_list; int32_t* seg_total; const int32_t* live_rays; const LkStepRider* step; const float* dscale;
                     uint8_t* act_flag; int signal_rows; const LkTrackLossArgs* track_loss; int track_n_part;
                     float* loss_rows;              // LK_COMPOSITE_IN_BWD: LkDecodeBwdArgs::ml_row_part of this iteration
+                    // SPLIT STEP (with `step`, a forked backward): the colour trunk's reduction + Adam + copy-back + fragment repack run on the
+                    // weight-gradient stream behind k_wgrad and the JOIN IS LEFT TO THE CALLER (lk_render_fwd_impl(.., join_side_before_decode) of the
+                    // next iteration, in front of its decoder launch); the launch stream only reduces / steps what its own kernels produced (rel-pos
+                    // MLP, Fourier matrices, feature rows).  weights_frag_rw: the fragment buffer the side launch repacks into; *split_done = 1 if taken
+                    int split_reduce; float* split_frag; float* split_master; int* split_done;
                     const ExposureStepArgs* xstep;      // or NULL: an exposure step that rides in this backward - in the gather launch (mapper:
                     const float* xstep_part; int xstep_n_part; };   // LkFeatScatterArgs::x) or, without feature gradients (tracker), as the last workgroup
                                                         // of the interpolation backward's launch, which then also sums the per-tile d affine (xstep_part)     // mapper loop: the iteration's sorted row list (lk_map_frame sorts ahead); signal_rows: lk_map_desc::signal_rows
@@ -327,9 +336,12 @@ struct LkAuxStream { hipStream_t st = nullptr; hipEvent_t e0 = nullptr; hipEvent
 LkAuxStream& lk_aux_stream();      // the search of a batch: z and the neighbour lists
 // rider of the interpolation launch (LK_PRESAMPLED only): repack `src` (NULL: d->weights) into the fragment buffer `frag` (= d->weights_frag,
 // writable) and, with copy_dst, copy src[0 .. copy_n) over copy_dst (= d->weights, writable) - the blob stepped by the step rider
-struct LkRepackRider { float* frag; const float* src; float* copy_dst; int copy_n; };
+struct LkRepackRider { float* frag; const float* src; float* copy_dst; int copy_n;
+                       int skip_trunk; };      // non-zero: the colour trunk's spans and fragments were taken care of on the weight-gradient stream (split step)
+int lk_launch_repack_trunk(const float* src, float* dst, float* frag, hipStream_t st);      // lk_weights.hip
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays = nullptr, const LkRepackRider* repack = nullptr,
-                       const LkTrackFinalArgs* pose = nullptr, const LkTrackLossArgs* comp = nullptr, int* comp_tiles = nullptr);       // pose: the tracking loop's pose step as the prologue of the search launch
+                       const LkTrackFinalArgs* pose = nullptr, const LkTrackLossArgs* comp = nullptr, int* comp_tiles = nullptr,
+                       bool join_side_before_decode = false);      // the last: a split step of the iteration before is still running on the weight-gradient stream       // pose: the tracking loop's pose step as the prologue of the search launch
 int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const LkBwdExtra* ex = nullptr);
 struct LkBwdOffsets { int64_t d_raw, dp_total, aff_part; };
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags);      // float offsets of two regions of lk_render_desc::bwd_scratch
@@ -348,7 +360,7 @@ struct LkBwdReduceArgs {
     const float* part_bg; int n_bg; float* out_bg;
     const float* part_br; int n_br; float* out_br;
 };
-int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st, const LkStepRider* step = nullptr);
+int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp, hipStream_t st, const LkStepRider* step = nullptr, bool feat_rows = true);
 int lk_dw2_parts(int P);
 int lk_launch_reduce_partials(const float* part, int n_parts, int width, float* out, hipStream_t st);
 // geometry decoder weight gradients (LK_FLAG_GRAD_GEO_DECODER; lk_geo_wgrad.hip)

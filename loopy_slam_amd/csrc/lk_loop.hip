@@ -4,7 +4,7 @@
 // The host enqueues a whole frame's launches from C++ (no interpreter between kernels), and the steps that do not depend on
 // what the iterations optimise leave the per-iteration sequence:
 //   k_pregather        pixel gather + inside mask (+ the mapper's rays) of ALL iterations in one launch
-//   k_track_composite  alpha composite + residuals, k_track_loss2: tracker loss + composite backward   (two many-workgroup
+//   k_track_composite  alpha composite + residuals; the tracker loss + composite backward ride in k_decode_bwd   (two many-workgroup
 //                      launches around the one global quantity, the batch mean of the residual)
 //   k_interp_bwd       also reduces the pose gradient's ray moments per workgroup (lk_bwd2.hip)
 //   k_track_final      pose gradient, Adam on the 7 pose parameters, candidate log, rays of the next iteration
@@ -28,9 +28,6 @@ int lk_exposure_step_args(const lk_exposure_desc& x, int mode, int step, float b
 int lk_adam_step_x(const lk_adam_seg* segs, int32_t n_seg, float beta1, float beta2, float eps, const ExposureStepArgs* xa, void* stream_);
 int lk_launch_composite_loss_exposure(const LkCompositeArgs& ca, const float* gt_color, const int32_t* frame_id, const float* aff, int F, float w_color,
                                       float* d_depth, float* d_logits, float* out_loss, float* g_aff, hipStream_t st);
-int lk_launch_loss_mapper_exposure(int R, const float* depth, const float* logits, const uint8_t* valid_ray, const float* gt_depth,
-                                   const float* gt_color, const int32_t* frame_id, const float* aff, int F, float w_color,
-                                   float* d_depth, float* d_logits, float* out_loss, float* g_aff, hipStream_t st);
 
 #define LK_TRACK_FUSED_MAX_R LK_MASK_REG_MAX          // rays a single workgroup keeps in registers (8 per thread)
 
@@ -189,36 +186,12 @@ __global__ __launch_bounds__(256) void k_track_composite(LkTrackLossArgs a) {
         a.part[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     }
 }
-// pass 2: mask by 10 x the batch mean (every workgroup re-sums the <= 64 block partials in the same order: same threshold
-// everywhere), loss terms (Tracker.py:169-191), d depth / d colour and the composite's backward for them
+// pass 2 - mask by 10 x the batch mean, loss terms (Tracker.py:169-191), d depth / d colour and the composite's backward for them - is the
+// prologue of k_decode_bwd (lk_track_draw, lk_track_dev.h); with tracking.handle_dynamic: False the threshold is the median's:
 __global__ __launch_bounds__(1024) void k_track_median(LkTrackLossArgs a) {
     __shared__ LkMedianShared S;
     const float thr = lk_block_median10(a.resid, a.R, S);
     if (threadIdx.x == 0) a.part[0] = thr;
-}
-__global__ __launch_bounds__(256) void k_track_loss2(LkTrackLossArgs a, int n_part) {
-    __shared__ float sh[3][4];
-    const float thr = lk_track_threshold(a, n_part);
-    const int r = blockIdx.x * 256 + (int)threadIdx.x;
-    float geo = 0.0f, col = 0.0f, cnt = 0.0f;
-    if (r < a.R) {
-        const LkTrackRayLoss o = lk_track_ray_loss(a, r, thr);
-        geo = o.geo; col = o.col; cnt = o.cnt;
-        a.d_depth[r] = o.dd;
-        a.d_color[3 * r] = o.dc0; a.d_color[3 * r + 1] = o.dc1; a.d_color[3 * r + 2] = o.dc2;
-        lk_composite_bwd_ray(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, o.gt, o.dd, 0.0f, o.dc0, o.dc1, o.dc2, a.d_raw);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { geo += __shfl_xor(geo, o); col += __shfl_xor(col, o); cnt += __shfl_xor(cnt, o); }
-    const int w = (int)threadIdx.x >> 6;
-    if (lk_lane() == 0) { sh[0][w] = geo; sh[1][w] = col; sh[2][w] = cnt; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float G = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), C = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
-        const float N = (sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]);
-        atomicAdd(a.out4 + 0, G + (a.use_color ? a.w_color * C : 0.0f));
-        atomicAdd(a.out4 + 1, G); atomicAdd(a.out4 + 2, C); atomicAdd(a.out4 + 3, N);
-    }
 }
 
 // loss rows of the iterations [it0, it0 + gridDim.x) of an lk_map_frame call from the per-tile terms k_decode_bwd left (LK_COMPOSITE_IN_BWD):
@@ -352,11 +325,10 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     const bool fused = R <= LK_TRACK_FUSED_MAX_R && d->work != nullptr;
     // the pose step of an iteration as the prologue of the NEXT iteration's search launch (with exposure encoding the step keeps its own launch:
     // the exposure workgroup rides in it)
-    // (round 4: with exposure encoding too - the exposure step then rides as the last workgroup of the interpolation backward's launch,
-    // LK_TRACK_XSTEP_IN_BWD=0: the old form, the step's own launch k_track_final with the exposure workgroup in it)
-    static const bool x_in_bwd_on = []{ const char* e = getenv("LK_TRACK_XSTEP_IN_BWD"); return e == nullptr || e[0] != '0'; }();
-    const bool x_in_bwd = fused && d->exposure != nullptr && x_in_bwd_on && !(rd.flags & LK_FLAG_REL_POS) && getenv("LK_NO_POSE_PROLOGUE") == nullptr;
-    const bool prologue = fused && (d->exposure == nullptr || x_in_bwd) && getenv("LK_NO_POSE_PROLOGUE") == nullptr;
+    // (round 4: with exposure encoding too - the exposure step then rides as the last workgroup of the interpolation backward's launch;
+    // only exposure encoding WITH the rel-pos MLP - no shipped config - keeps the step's own launch k_track_final with the exposure workgroup in it)
+    const bool x_in_bwd = fused && d->exposure != nullptr && !(rd.flags & LK_FLAG_REL_POS);
+    const bool prologue = fused && (d->exposure == nullptr || x_in_bwd);
     // (with exposure encoding d out passes through the learned affine first: unit scale only relative to xd->bwd_scale, which the fused
     // sequence hands to the kernels)
     if ((xd == nullptr || (xd->bwd_scale && fused)) && fabsf(d->w_color) <= 4.0f) rd.flags |= LK_FLAG_UNIT_LOSS_GRADS;
@@ -368,9 +340,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     const TrackWork wk = track_work(R, S, iters);
     float* W0 = d->work;
     const int n_pose = lk_bwd_pose_parts((int64_t)R * S), n_lp = lk_cdiv(R, 256);
-    // the loss terms and the composite backward as the prologue of the decoder backward (LK_TRACK_LOSS_INLINE=0: k_track_loss2, A/B)
-    static const bool loss_inline_on = []{ const char* e = getenv("LK_TRACK_LOSS_INLINE"); return e == nullptr || e[0] != '0'; }();
-    const bool loss_inline = fused && loss_inline_on;
+    // (fused: the loss terms and the composite backward are the prologue of the decoder backward, lk_track_draw)
     LkTrackFinalArgs fa;
     memset(&fa, 0, sizeof(fa));
     if (fused) {
@@ -438,7 +408,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
             pa.mv_in = W0 + wk.ring + 16 + 16 * ((it - 1) & 1); pa.adam_mv = W0 + wk.ring + 16 + 16 * (it & 1);
             pa.rays_o = const_cast<float*>(rd.rays_o); pa.rays_d = const_cast<float*>(rd.rays_d);
             pa.next_pix_i = W0 + wk.pix_i + (size_t)it * R; pa.next_pix_j = W0 + wk.pix_j + (size_t)it * R;
-            if (loss_inline) { pa.loss_part = W0 + wk.row_part; pa.n_loss_part = n_pose; pa.log_row = d->log + (size_t)(it - 1) * 4; }
+            pa.loss_part = W0 + wk.row_part; pa.n_loss_part = n_pose; pa.log_row = d->log + (size_t)(it - 1) * 4;
         }
         LkTrackLossArgs la;
         memset(&la, 0, sizeof(la));
@@ -460,7 +430,6 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         if (fused) {
             if (comp_tiles == 0) hipLaunchKernelGGL(k_track_composite, dim3(n_lp), dim3(256), 0, st, la);
             if (la.median) hipLaunchKernelGGL(k_track_median, dim3(1), dim3(1024), 0, st, la);
-            if (!loss_inline) hipLaunchKernelGGL(k_track_loss2, dim3(n_lp), dim3(256), 0, st, la, n_part);
         } else {
             rc = lk_loss_tracker(R, rd.depth, rd.var, rd.color, rd.gt_depth, d->gt_color, d->w_color, d->use_color,
                                  const_cast<float*>(rd.d_depth), const_cast<float*>(rd.d_color), log_row, d->loss_scratch, st);
@@ -468,7 +437,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
         }
         LkBwdExtra ex;
         memset(&ex, 0, sizeof(ex));
-        if (fused && loss_inline) { ex.track_loss = &la; ex.track_n_part = n_part; }
+        if (fused) { ex.track_loss = &la; ex.track_n_part = n_part; }
         ex.pose_part = fused ? W0 + wk.pose_part : nullptr;
         ex.dscale = (xd && (rd.flags & LK_FLAG_UNIT_LOSS_GRADS)) ? xd->bwd_scale : nullptr;
         ex.pix_i = W0 ? W0 + wk.pix_i + (size_t)it * R : nullptr; ex.pix_j = W0 ? W0 + wk.pix_j + (size_t)it * R : nullptr;
@@ -498,7 +467,7 @@ extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
                 fa.cam_in = W0 + wk.ring + 8 * (it & 1); fa.mv_in = W0 + wk.ring + 16 + 16 * (it & 1);
             }
             fa.step_T = step_T; fa.step_q = step_q; fa.bc2_sqrt = bc2s; fa.do_update = 1;
-            if (loss_inline) { fa.loss_part = W0 + wk.row_part; fa.n_loss_part = n_pose; fa.log_row = log_row; }
+            fa.loss_part = W0 + wk.row_part; fa.n_loss_part = n_pose; fa.log_row = log_row;
             fa.hist_pre = d->hist_post ? nullptr : hist_row; fa.hist_post = d->hist_post ? hist_row : nullptr;
             const bool more = it + 1 < iters;
             fa.rays_o = more ? const_cast<float*>(rd.rays_o) : nullptr; fa.rays_d = const_cast<float*>(rd.rays_d);
@@ -702,6 +671,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         return true;
     };
     bool repack_pending = false, stepped_pending = false;
+    int split_pending = 0;          // the step of the iteration before was split: its trunk half is (maybe still) running on the weight-gradient stream
     // Step rider (LkStepRider, lk_kernels.h): in a 'color' iteration that is followed by another one in this call, with no gradient
     // exchange in between (phases == 3), the Adam step happens inside the reduction launch of the backward
     const bool train_geo = d->train_geo_decoder != 0;      // (its gradients come from a launch of their own, k_geo_wgrad: no owner thread in the reduction launch -> no rider)
@@ -715,10 +685,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
         embed_only = embed_only && d->col_dec[k].offset >= R_EB && d->col_dec[k].offset + d->col_dec[k].n <= R_EB + 3 * 10;
     if (train_geo) embed_only = false;          // (the geometry decoder's weight gradients need the full backward)
     bool w_next_ready = false;
-    static const bool xloss_fused_on = []{ const char* e = getenv("LK_XLOSS_FUSED"); return e == nullptr || e[0] != '0'; }();
-    static const bool xstep_early_on = []{ const char* e = getenv("LK_XSTEP_EARLY"); return e == nullptr || e[0] != '0'; }();
     bool x_early = false;                          // this iteration's exposure backward + Adam already ran (in the gather launch)
-    static const bool map_loss_inline = []{ const char* e = getenv("LK_MAP_LOSS_INLINE"); return e == nullptr || e[0] != '0'; }();
     int sum_lo = -1, sum_hi = -1;                  // iterations whose loss rows are summed at the end of the call (the exposure variant's are not)
     bool x_fwd_done = it_begin > n_geo_l;          // a later call of a phase-split sequence: the step launch of the iteration before did the forward
     for (int it = it_begin; it < it_end; ++it) {
@@ -770,6 +737,8 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             LkRepackRider rr;
             rr.frag = d->weights_frag_rw; rr.src = stepped_pending ? W0 + wk.w_next : nullptr;
             rr.copy_dst = stepped_pending ? d->weights_rw : nullptr; rr.copy_n = (int)nb;
+            rr.skip_trunk = (stepped_pending && split_pending) ? 1 : 0;
+            const bool join_side = rr.skip_trunk != 0;
             if (xit && it == (n_geo_l > it_begin ? n_geo_l : it_begin) && !x_fwd_done) {
                 // affines of the window's keyframes for the first 'color' iteration of this call (later ones: the step launch below)
                 rc = lk_launch_exposure_step(*xd, 2, 1, beta1, beta2, eps, st);
@@ -779,17 +748,16 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             // phase-split caller: the step of 'color' iteration it - 1 (its own call) moved the colour decoder and left the repack to this launch
             const bool split_repack = pre && (phases & 3) == 1 && it == it_begin && it > n_geo_l && !embed_only && d->n_col_dec > 0 &&
                                       d->render.weights == d->weights_rw;
-            // the composite, the loss and its backward as the prologue of the decoder backward (no k_composite launch; LK_MAP_LOSS_INLINE=0: off)
-            const bool comp_bwd = pre && !xit && !train_geo && map_loss_inline;
+            // the composite, the loss and its backward as the prologue of the decoder backward (no k_composite launch)
+            const bool comp_bwd = pre && !xit && !train_geo;
             if (comp_bwd) { if (sum_lo < 0) sum_lo = it; sum_hi = it + 1; }
-            // exposure variant: the composite runs inside the loss kernel below (one launch instead of two; LK_XLOSS_FUSED=0: two)
-            const bool x_fused = xit && xloss_fused_on;
-            rc = lk_render_fwd_impl(&rd, st, (xit ? (x_fused ? LK_SKIP_COMPOSITE : 0) : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) |
+            // exposure variant: the composite runs inside the loss kernel below (one launch instead of two)
+            rc = lk_render_fwd_impl(&rd, st, (xit ? LK_SKIP_COMPOSITE : LK_FUSE_COMPOSITE_BWD) | (pre ? (LK_LOSS_PREZEROED | LK_PRESAMPLED) : 0) |
                                     (sort_ahead ? LK_SEG_SORTED : 0) | (comp_bwd ? LK_COMPOSITE_IN_BWD : 0), live,
-                                    (repack_pending || stepped_pending || split_repack) ? &rr : nullptr);
-            repack_pending = false; stepped_pending = false;
+                                    (repack_pending || stepped_pending || split_repack) ? &rr : nullptr, nullptr, nullptr, nullptr, join_side);
+            repack_pending = false; stepped_pending = false; split_pending = 0;
             if (rc != LK_OK) return rc;
-            if (x_fused) {      // composite + Mapper.py:697-715 on the rendered logits in one launch
+            if (xit) {          // composite + Mapper.py:697-715 on the rendered logits in one launch: d depth, d logits, loss row, d loss / d affine
                 LkCompositeArgs ca;
                 memset(&ca, 0, sizeof(ca));
                 ca.R = R; ca.S = rd.S; ca.min_nn = rd.min_nn; ca.coef = rd.coef;
@@ -798,11 +766,6 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 ca.keep_depth = (rd.flags & LK_FLAG_Z_GIVEN) ? 1 : 0;
                 rc = lk_launch_composite_loss_exposure(ca, rd.loss_gt_color, reinterpret_cast<const int32_t*>(W0 + wk.frame_id) + (size_t)it * R, xd->aff, xd->F,
                                                        d->w_color, const_cast<float*>(rd.d_depth), const_cast<float*>(rd.d_color), rd.loss_out4, xd->g_aff, st);
-                if (rc != LK_OK) return rc;
-            } else if (xit) {          // Mapper.py:697-715 on the rendered logits: d depth, d logits, loss row, d loss / d affine
-                rc = lk_launch_loss_mapper_exposure(R, rd.depth, rd.color, rd.valid_ray, rd.gt_depth, rd.loss_gt_color,
-                                                    reinterpret_cast<const int32_t*>(W0 + wk.frame_id) + (size_t)it * R, xd->aff, xd->F, d->w_color,
-                                                    const_cast<float*>(rd.d_depth), const_cast<float*>(rd.d_color), rd.loss_out4, xd->g_aff, st);
                 if (rc != LK_OK) return rc;
             }
             LkBwdExtra ex;
@@ -845,13 +808,15 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                     w_next_ready = true;
                 }
                 ex.step = &sr;
+                // the colour trunk's half of this step on the weight-gradient stream, joined in front of the next iteration's decoder launch
+                ex.split_reduce = LK_SPLIT_STEP; ex.split_frag = d->weights_frag_rw; ex.split_master = d->weights_rw; ex.split_done = &split_pending;
             }
             if (comp_bwd) ex.loss_rows = W0 + wk.loss_rows + (size_t)it * 4 * lk_cdiv(Pn, 32);
             // exposure encoding, one process: the backward + Adam half of the exposure step rides in this backward's gather launch (d affine is
-            // final since the loss kernel above; with ranks it is exchanged first and the whole step stays in the Adam launch).  LK_XSTEP_EARLY=0: off
+            // final since the loss kernel above; with ranks it is exchanged first and the whole step stays in the Adam launch)
             ExposureStepArgs xa_early;
             x_early = false;
-            if (xit && pre && (phases & 3) == 3 && xstep_early_on) {
+            if (xit && pre && (phases & 3) == 3) {
                 rc = lk_exposure_step_args(*xd, 1, it - n_geo_l + 1, beta1, beta2, eps, &xa_early);
                 if (rc != LK_OK) return rc;
                 ex.xstep = &xa_early;
@@ -903,10 +868,18 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             }
         }
     }
+    if ((phases & 3) != 3) {
+        // a phase-split caller (one call per iteration around its gradient exchange) gets ONE sum launch, behind the backward of the sequence's
+        // last iteration: the rows of every iteration that left per-tile terms - all of them, or the 'geometry' ones with exposure encoding
+        // (decided from the SEQUENCE, not from this call's own iterations: with exposure encoding the last call is a 'color' iteration
+        // that leaves no terms itself, and the 'geometry' rows [0, n_geo) would never be summed)
+        sum_lo = -1;
+        if ((phases & 1) && it_end == d->iters && pre && !train_geo) {
+            sum_lo = 0;
+            sum_hi = xd ? (n_geo_l < 0 ? 0 : (n_geo_l > d->iters ? d->iters : n_geo_l)) : d->iters;
+        }
+    }
     if (sum_lo >= 0) {
-        // a phase-split caller (one call per iteration around its gradient exchange) gets ONE sum launch, with the call that reaches the last
-        // iteration: the rows of every iteration that left per-tile terms (all of them, or the 'geometry' ones with exposure encoding)
-        if ((phases & 3) != 3) { sum_lo = 0; sum_hi = (it_end == d->iters) ? (xd ? (n_geo_l < 0 ? 0 : (n_geo_l > d->iters ? d->iters : n_geo_l)) : d->iters) : 0; }
         if (sum_hi > sum_lo)
             hipLaunchKernelGGL(k_loss_rows_sum, dim3(sum_hi - sum_lo), dim3(256), 0, st, W0 + wk.loss_rows, lk_cdiv(Pn, 32), (int)Pn, d->render.S,
                                reinterpret_cast<const int32_t*>(W0 + wk.n_live), sum_lo, d->log);

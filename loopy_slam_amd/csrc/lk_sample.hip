@@ -219,13 +219,19 @@ template <int T>
 __global__ __launch_bounds__(256) void k_interp_repack(LkSampleArgs a, FragTable tb) {
     if (a.rp_copy_dst && (int)blockIdx.x >= a.rp_block1) {      // the stepped blob over the master blob (nobody reads the master in this launch)
         const int i = (((int)blockIdx.x - a.rp_block1) * 256 + (int)threadIdx.x) * 4;
+        if (i >= a.rp_skip_lo && i < a.rp_skip_hi) return;          // (range boundaries are multiples of 64 floats)
         if (i + 3 < a.rp_copy_n) *reinterpret_cast<float4*>(a.rp_copy_dst + i) = *reinterpret_cast<const float4*>(a.rp_plain + i);
         else for (int k = i; k < a.rp_copy_n; ++k) a.rp_copy_dst[k] = a.rp_plain[k];
         return;
     }
     if ((int)blockIdx.x >= a.rp_block0) {
         const int u = ((int)blockIdx.x - a.rp_block0) * 256 + (int)threadIdx.x;
-        if (u < LK_REPACK_UNITS) repack_unit(a.rp_plain, reinterpret_cast<u32x4*>(a.rp_frag), tb, u);
+        if (u < LK_REPACK_UNITS) {
+            if (a.rp_m_hi > a.rp_m_lo) {            // all but the matrices [rp_m_lo, rp_m_hi)
+                repack_unit(a.rp_plain, reinterpret_cast<u32x4*>(a.rp_frag), tb, u, 0, a.rp_m_lo);
+                repack_unit(a.rp_plain, reinterpret_cast<u32x4*>(a.rp_frag), tb, u, a.rp_m_hi, N_FRAG_MATS);
+            } else repack_unit(a.rp_plain, reinterpret_cast<u32x4*>(a.rp_frag), tb, u);
+        }
         return;
     }
     sample_interp_block<T, 2>(a, (int)blockIdx.x);

@@ -7,7 +7,7 @@
 
 __device__ __forceinline__ float lp_sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 
-// ---- the tracker's loss (Tracker.py:169-191) per ray, shared by k_track_loss2 and the prologue of the tracking loop's k_decode_bwd
+// ---- the tracker's loss (Tracker.py:169-191) per ray, in the prologue of the tracking loop's k_decode_bwd
 // mask threshold 10 x the batch mean of the normalised residuals from pass 1's block sums: a whole wave calls, every wave of every workgroup
 // adds the same pairs in the same order - the same threshold everywhere
 __device__ __forceinline__ float lk_track_threshold(const LkTrackLossArgs& a, int n_part) {

@@ -117,6 +117,10 @@ constexpr int FRAGB_U4 = FM21_ENDB;         // uint4 units
 // loss gradients have unit scale): block = [piece 0..1][lane] uint4 = 2 KiB, same block order; they follow the bf16 blob.
 constexpr int FRAGH_U4 = FM21_ENDH;
 constexpr int N_FRAG_MATS = 22;
+// matrix indices of the table below: geometry decoder [0, 10), colour trunk [LK_FRAG_COL_LO, LK_FRAG_COL_HI), rel-pos MLP [20, 22);
+// the trunk's parameters are the blob range [C_EB, R_EB)
+#define LK_FRAG_COL_LO 10
+#define LK_FRAG_COL_HI 20
 // transposed-form offsets by matrix index (bf16 pieces / fp16 pieces), for code templated on the piece type
 constexpr int FRAG_TRB[N_FRAG_MATS] = {FM0_TRB, FM1_TRB, FM2_TRB, FM3_TRB, FM4_TRB, FM5_TRB, FM6_TRB, FM7_TRB, FM8_TRB, FM9_TRB, FM10_TRB,
                                        FM11_TRB, FM12_TRB, FM13_TRB, FM14_TRB, FM15_TRB, FM16_TRB, FM17_TRB, FM18_TRB, FM19_TRB, FM20_TRB, FM21_TRB};

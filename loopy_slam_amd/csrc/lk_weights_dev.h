@@ -8,12 +8,14 @@ using namespace lkw;
 struct FragTable { FragMat m[N_FRAG_MATS]; };
 
 // one lane-block element of the split-bf16 fragments: unit u = (matrix form, G, blk, lane), 8 weights -> 3 x 16 B
-__device__ __forceinline__ void repack_split_unit(const float* __restrict__ plain, u32x4* __restrict__ fragb, const FragTable& tb, int u) {
+// (m_lo, m_hi: only the matrices [m_lo, m_hi) of the table - a repack split between two launches, LK_FRAG_* below)
+__device__ __forceinline__ void repack_split_unit(const float* __restrict__ plain, u32x4* __restrict__ fragb, const FragTable& tb, int u, int m_lo, int m_hi) {
     const int blk_all = u >> 6, lane = u & 63;
     const int o4 = blk_all * 192;                      // uint4 offset of the block
     int mi = 0;
 #pragma unroll 1
     for (int q = 1; q < N_FRAG_MATS; ++q) mi = (o4 >= tb.m[q].fwdb) ? q : mi;
+    if (mi < m_lo || mi >= m_hi) return;
     const FragMat M = tb.m[mi];
     const int h = lane >> 5, j = lane & 31;
     float v[8];
@@ -51,12 +53,13 @@ __device__ __forceinline__ void repack_split_unit(const float* __restrict__ plai
 }
 
 // both forms once more as two fp16 pieces: unit u = (matrix form, G, blk, lane)
-__device__ __forceinline__ void repack_half_unit(const float* __restrict__ plain, u32x4* __restrict__ fragh, const FragTable& tb, int u) {
+__device__ __forceinline__ void repack_half_unit(const float* __restrict__ plain, u32x4* __restrict__ fragh, const FragTable& tb, int u, int m_lo, int m_hi) {
     const int blk_all = u >> 6, lane = u & 63;
     const int o4 = blk_all * 128;
     int mi = 0;
 #pragma unroll 1
     for (int q = 1; q < N_FRAG_MATS; ++q) mi = (o4 >= tb.m[q].fwdh) ? q : mi;
+    if (mi < m_lo || mi >= m_hi) return;
     const FragMat M = tb.m[mi];
     const int h = lane >> 5, j = lane & 31;
     float v[8];
@@ -95,9 +98,9 @@ __device__ __forceinline__ void repack_half_unit(const float* __restrict__ plain
 
 // unit u of the whole repack: split-bf16 forms first, then the fp16 forms
 #define LK_REPACK_UNITS (FRAGB_U4 / 3 + FRAGH_U4 / 2)
-__device__ __forceinline__ void repack_unit(const float* __restrict__ plain, u32x4* __restrict__ fragb, const FragTable& tb, int u) {
-    if (u < FRAGB_U4 / 3) repack_split_unit(plain, fragb, tb, u);
-    else repack_half_unit(plain, fragb + FRAGB_U4, tb, u - FRAGB_U4 / 3);
+__device__ __forceinline__ void repack_unit(const float* __restrict__ plain, u32x4* __restrict__ fragb, const FragTable& tb, int u, int m_lo = 0, int m_hi = N_FRAG_MATS) {
+    if (u < FRAGB_U4 / 3) repack_split_unit(plain, fragb, tb, u, m_lo, m_hi);
+    else repack_half_unit(plain, fragb + FRAGB_U4, tb, u - FRAGB_U4 / 3, m_lo, m_hi);
 }
 inline FragTable lk_frag_table() {
     static const FragMat rows[N_FRAG_MATS] = {LKW_FRAG_TABLE};

@@ -76,20 +76,52 @@ class DistContext:
             return None
         if self._rccl is None:
             from . import rccl
+            # the ranks decide TOGETHER: a rank whose librccl does not load must not walk on to torch's collectives while the others sit in the
+            # communicator's id broadcast / ncclCommInitRank.  Step 1: can every rank load the library (MIN over the torch group)?
             try:
-                self._rccl = rccl.RcclComm(self.rank, self.world, t.device)
-            except Exception as e:          # noqa: BLE001 - any failure of the direct path falls back on torch's collectives, loudly
-                import warnings
-                warnings.warn(f'direct RCCL communicator unavailable ({e}): collectives go through torch.distributed')
-                self._rccl = False
+                rccl._load()
+                err = None
+            except OSError as e:
+                err = e
+            if not self._all_ok(err is None, t.device):
+                self._fallback(err or 'librccl missing on another rank')
+                return None
+            # step 2: the communicator itself (collective; a rank that fails here raises out of a call its peers are blocked in - RCCL's own
+            # failure mode, not recoverable by agreement), then one more agreement so that all ranks use it or none does
+            try:
+                comm, err = rccl.RcclComm(self.rank, self.world, t.device), None
+            except Exception as e:          # noqa: BLE001
+                comm, err = None, e
+            if not self._all_ok(comm is not None, t.device):
+                if comm is not None:
+                    comm.close()
+                self._fallback(err or 'communicator creation failed on another rank')
+                return None
+            self._rccl = comm
         return self._rccl or None
+
+    def _all_ok(self, ok, device):
+        """True iff `ok` on EVERY rank (MIN all-reduce over the torch process group; a single rank decides alone)."""
+        if self.world <= 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    def _fallback(self, why):
+        import warnings
+        warnings.warn(f'direct RCCL communicator unavailable ({why}): collectives go through torch.distributed on every rank')
+        self._rccl = False
 
     def _all_reduce(self, t, op):
         """All-reduce in place; on a backend without device collectives (gloo with HIP tensors: the 2-ranks-on-one-GPU test
         hook - RCCL refuses two ranks on one device) the tensor is staged through the host."""
-        r = self._direct(t)
+        # the direct communicator carries what the hot path exchanges - contiguous float32 SUM and uint8 MAX; anything else is torch's
+        kind = 'sum' if op == dist.ReduceOp.SUM else ('max' if op == dist.ReduceOp.MAX else None)
+        r = self._direct(t) if (kind is not None and t.is_contiguous() and ((kind == 'sum' and t.dtype == torch.float32) or
+                                                                             (kind == 'max' and t.dtype == torch.uint8))) else None
         if r is not None:
-            r.all_reduce(t, 'sum' if op == dist.ReduceOp.SUM else 'max')
+            r.all_reduce(t, kind)
             return
         if t.is_cuda and dist.get_backend() != 'nccl':
             h = t.cpu()

@@ -101,6 +101,12 @@ def work_per_step(b):
     return w
 
 
+def step_flops(b):
+    """Algorithmic fp32 FLOPs of one step of budget b: every MLP product of the forward, the backward-data and the weight-gradient
+    passes of its iterations (the sum of work_per_step's flops; interpolation, composite, losses and Adam are not counted)."""
+    return sum(v['flops'] for v in work_per_step(b).values())
+
+
 def pmc_traffic(kernel, path=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r4_rocprof_summary.md, written by
     tools/summarize_prof.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench; FETCH_SIZE doubled per

@@ -322,7 +322,7 @@ class MapOptimizer:
         read-back, the device works through the fills and the assembly while the host waits and builds the descriptor.  run() with the
         same arguments follows (new_frame(..., zero=False) in between).  No-op on the paths that have no batch assembly."""
         self._prepared = None
-        if not self._takes_native_loop() or self.dist is not None or self.R > 16384 or os.environ.get('LOOPY_NO_PREPARE') == '1':
+        if not self._takes_native_loop() or self.dist is not None or self.R > 16384:
             return False
         self.gs.zero_()
         d, seg_iters = self._native_desc(n_iters, n_geo_iters, frames, rnd_all, frame_id, window, intr, H, W, log, rows_known=False)

@@ -6,14 +6,24 @@ Replica room0 budget (configs/Replica/replica.yaml:21-22,25,33,36-37; configs/po
   mapping   300 iterations x 5000 rays  every 5th frame  -> 60 iterations per frame,
             geo_iter_ratio 0.4 -> 24 'geometry' + 36 'color' iterations
   => 360 000 rays per frame, S = 5 samples per ray, rel-pos colour MLP on, static radius 0.08.
+
+The other two single-GPU budgets of BASELINE.json (Budget.tum / Budget.scannet; bench.py reports them under `workloads`):
+  TUM_RGBD  (configs/TUM_RGBD/tum.yaml:4,7-9,16)       tracking 200 x 5000 rays per frame from the pool of the highest colour-gradient pixels,
+            one leaf pose tensor; mapping 300 x 10 000 rays every 2nd frame -> 150 per frame (60 'geometry' + 90 'color') over a window
+            of 10 keyframes; per-pixel dynamic query radius; plain colour model
+  ScanNet   (configs/ScanNet/scannet.yaml:3-4,6-10,16,18) tracking 100 x 5000 at lr 5e-4; mapping 300 x 10 000 every 5th frame -> 60 per
+            frame (geo_iter_ratio 0.3: 18 + 42) over 20 keyframes; surface ratios 0.96 / 1.04; exposure encoding (the 8 -> 128 -> 12 MLP,
+            per-sample affine in the tracker, per-keyframe affine on the rendered logits in the mapper)
 """
-import os
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import torch
 
 from . import core, optim, steps, synthetic as syn
 from .common import get_tensor_from_camera
+
+
+MAP_LRS = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}     # mapping.stage.* (configs/point_slam.yaml:64-66; every config)
 
 
 @dataclass
@@ -34,28 +44,55 @@ class Budget:
                                           # synthetic.build_cloud_online); False: random pixels of 24 views packed into one room
     every_frame: int = 5                  # mapping.every_frame: the full step inserts points / re-indexes / renders the frame every 5th frame
     pixels_adding: int = 6000             # mapping.pixels_adding
+    # what makes the TUM / ScanNet configs different (all off = the Replica model)
+    separate_lr: bool = True              # tracking.separate_LR
+    dynamic_radius: bool = False          # use_dynamic_radius: per-pixel query radius from the colour gradient (lk_radius_maps per frame)
+    grad_pool: bool = False               # tracking.sample_with_color_grad: tracking pixels from the 15 n highest-gradient pixels (lk_top_grad_pixels)
+    exposure: bool = False                # model.encode_exposure
+    near_surface: float = 0.98            # rendering.near_end_surface / far_end_surface
+    far_surface: float = 1.02
+    map_lrs: dict = field(default_factory=lambda: dict(MAP_LRS))
+
+    @classmethod
+    def tum(cls, **kw):
+        return cls(name='tum_freiburg1_desk', track_iters=200, track_rays=5000, map_iters=150, map_geo_iters=60, map_rays=10000, window=10,
+                   ignore_edge=20, cam_lr=0.002, rel_pos=False, every_frame=2, pixels_adding=5000, separate_lr=False, dynamic_radius=True,
+                   grad_pool=True, **kw)
+
+    @classmethod
+    def scannet(cls, **kw):
+        return cls(name='scannet_scene0000', track_iters=100, track_rays=5000, map_iters=60, map_geo_iters=18, map_rays=10000, window=20,
+                   ignore_edge=20, cam_lr=0.0005, rel_pos=False, every_frame=5, pixels_adding=6000, separate_lr=False, dynamic_radius=True,
+                   grad_pool=True, exposure=True, near_surface=0.96, far_surface=1.04, **kw)
 
     @property
     def rays_per_frame(self):
         return self.track_iters * self.track_rays + self.map_iters * self.map_rays
 
 
-MAP_LRS = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}     # mapping.stage.* (replica.yaml)
+# pointcloud.* of configs/point_slam.yaml:128-131 (dynamic radii)
+RADIUS_CFG = dict(color_grad_threshold=0.15, radius_add_max=0.08, radius_add_min=0.02, radius_query_ratio=2)
 
 
 class FrameWorkload:
     """Device-resident scene + the two optimisers; step() = track one frame + its share of mapping."""
 
-    def __init__(self, eng, budget=None, seed=1219, dist=None):
+    def __init__(self, eng, budget=None, seed=1219, dist=None, cloud=None, intr=None):
+        """cloud: (pos, geo, col, n_rooms) device tensors of an already built map (bench.py: the three budgets share one cloud).
+        intr: camera dict as synthetic.TUM_INTR (the default: 640 x 480; the host-emulator test uses a few hundred pixels)."""
         self.eng, self.b = eng, budget or Budget()
         b = self.b
         dev = eng.device
-        self.intr = (syn.TUM_INTR['fx'], syn.TUM_INTR['fy'], syn.TUM_INTR['cx'], syn.TUM_INTR['cy'])
-        self.H, self.W = syn.TUM_INTR['H'], syn.TUM_INTR['W']
-        self.cfg = core.RenderCfg(rel_pos=b.rel_pos)
-        self.dec = core.DecoderBlob(eng).pack(syn.default_weights(seed, rel_pos=b.rel_pos))
-        if b.online_cloud:
-            pos, geo, col, self.n_rooms = syn.build_cloud_online(eng, b.n_points, seed=seed)
+        self.cam = dict(intr or syn.TUM_INTR)
+        self.intr = (self.cam['fx'], self.cam['fy'], self.cam['cx'], self.cam['cy'])
+        self.H, self.W = self.cam['H'], self.cam['W']
+        self.cfg = core.RenderCfg(rel_pos=b.rel_pos, exposure=b.exposure, near_surface=b.near_surface, far_surface=b.far_surface)
+        W0 = syn.default_weights(seed, rel_pos=b.rel_pos, exposure=b.exposure)
+        self.dec = core.DecoderBlob(eng).pack(W0)
+        if cloud is not None:
+            pos, geo, col, self.n_rooms = cloud
+        elif b.online_cloud:
+            pos, geo, col, self.n_rooms = syn.build_cloud_online(eng, b.n_points, seed=seed, intr=self.cam)
         else:
             pos, geo, col = (t.to(dev) for t in syn.build_cloud(b.n_points, device='cpu', seed=seed))
             self.n_rooms = 1
@@ -73,38 +110,68 @@ class FrameWorkload:
         room = self.n_rooms - 1
         ds, cs, ps = [], [], []
         for k in range(b.window):
-            d, c, p = syn.render_frame(3 * k, device=dev, holes=0.02, seed=seed)
+            d, c, p = syn.render_frame(3 * k, intr=self.cam, device=dev, holes=0.02, seed=seed)
             ds.append(d); cs.append(c); ps.append(syn.pose_in_room(p, room))
         self.depth_stack = torch.stack(ds).contiguous()
         self.color_stack = torch.stack(cs).contiguous()
         self.c2w_stack = torch.stack(ps).contiguous()
         self.c2w_host = [p.detach().cpu().numpy() for p in ps]      # the mapped frame's pose is known to the host (frustum selection)
-        self.frames = (self.depth_stack, self.color_stack, self.c2w_stack, None)
+        # dynamic radii: the squared query-radius map of every keyframe of the window (Mapper.py:854-872 keeps them with the keyframes);
+        # the tracked frame's maps are recomputed per step (Tracker.py:243-258), as the gradient-pixel pool is
+        self.r2_stack = None
+        if b.dynamic_radius:
+            self.r2_stack = torch.stack([self._radius_maps(k)[2] for k in range(b.window)]).contiguous()
+        self.frames = (self.depth_stack, self.color_stack, self.c2w_stack, self.r2_stack)
+        # exposure encoding: mlp_exposure as the torch module that owns its parameters (the kernels step them in place), one feature
+        # per keyframe of the window (Mapper.py:588-607) - the mapped frame's is the trainable one - and the tracker's copy of the shared one
+        self.mlp_exposure, self.exposure_feats = None, None
+        if b.exposure:
+            m = torch.nn.Sequential(torch.nn.Linear(8, 128), torch.nn.Softplus(beta=100), torch.nn.Linear(128, 12)).to(dev)
+            with torch.no_grad():
+                for lin, n in ((m[0], 'linear1'), (m[2], 'linear2')):
+                    lin.weight.copy_(W0[f'color_decoder.mlp_exposure.{n}.weight']); lin.bias.copy_(W0[f'color_decoder.mlp_exposure.{n}.bias'])
+            self.mlp_exposure = m
+            g = torch.Generator().manual_seed(seed + 5)
+            self.exposure_feats = [(0.1 * torch.randn(8, generator=g)).to(dev).requires_grad_(True) for _ in range(b.window)]
         # rows optimised by the mapper = frustum selection of the frame being mapped (Mapper.py:165-217, 498-512),
         # recomputed at every step like the reference does at every optimize_map call
         self.rows = optim.frustum_rows(eng, self.pos[:self.n], self.c2w_stack[0], self.depth_stack[0], self.intr, self.H, self.W, b.frustum_edge)
         self.mapper = steps.MapOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col, self.rows,
-                                         b.map_rays, MAP_LRS, w_color=0.1, dist=dist)
+                                         b.map_rays, b.map_lrs, w_color=0.1, dist=dist, dynamic_radius=b.dynamic_radius,
+                                         exposure=(self.mlp_exposure, self.exposure_feats) if b.exposure else None)
         self.tracker = steps.TrackOptimizer(eng, self.cfg, self.dec, self.knn, self.pos, self.geo, self.col,
-                                            b.track_rays, b.cam_lr, separate_lr=True, w_color=0.5, dist=dist)
+                                            b.track_rays, b.cam_lr, separate_lr=b.separate_lr, w_color=0.5, dist=dist,
+                                            dynamic_radius=b.dynamic_radius)
         # pixel draws happen on the device, as the reference's do (select_uv: torch.randint(..., device=device), common.py:156-172):
         # 300 000 host-side draws + their upload cost 0.9 ms of a 22 ms step with the GPU idle
         # (multi-GPU: the mapping draws differ per rank - every rank renders its own rays of the shared iteration - the tracking draws
         # are the same everywhere: tracking is replicated, steps.TrackOptimizer)
         self.gen = torch.Generator(device=dev).manual_seed(seed + (dist.rank if dist is not None else 0))
         self.gen_track = torch.Generator(device=dev).manual_seed(seed + 7919)          # shared by the ranks: tracking draws, insertion
-        self._fid = (torch.arange(b.map_rays, dtype=torch.int32) % b.window).to(dev)      # pixels // window frames each
+        # pixels // window rays of every keyframe per iteration (Mapper.py:417-418); with exposure encoding grouped by keyframe as
+        # slam.Mapper.optimize_map lays them out (the loss kernel sums d affine over the lanes of a keyframe)
+        self._fid = ((torch.arange(b.map_rays, dtype=torch.int32) // max(1, b.map_rays // b.window)).clamp(max=b.window - 1) if b.exposure
+                     else (torch.arange(b.map_rays, dtype=torch.int32) % b.window)).to(dev)
         self.cam0 = get_tensor_from_camera(self.c2w_stack[0]).to(dev)
         self.map_log = eng.zeros(b.map_iters, 4)
         self.frame_no = 0
         self.img_state = None               # RenderState of the full-frame render (full step)
         self.n_added = 0
         # The full-frame render of a mapped frame (Mapper.py:966-969: an image for the run's output folder, nothing of the loop consumes it) runs
-        # on a stream of its own, beside the next frames' tracking - forward-only work over a map that nobody changes until the next mapped
-        # frame's insertion, which waits for it.  LOOPY_RENDER_INLINE=1: on the launch stream, behind the mapping iterations (A/B).
-        self.render_stream = None
-        if eng.device.type == 'cuda' and os.environ.get('LOOPY_RENDER_INLINE') != '1':
-            self.render_stream = torch.cuda.Stream(eng.device)
+        # on a stream of its own, beside the NEXT FRAME'S TRACKING - forward-only work over the map, and tracking only reads the map too.
+        # Whatever writes the map or the decoders next - the next step's mapping iterations (features, decoder blob, fragments), a mapped
+        # frame's insertion - waits for it first (step(): _join_render).
+        self.render_stream = torch.cuda.Stream(eng.device) if eng.device.type == 'cuda' else None
+
+    def _radius_maps(self, k):
+        """(grad_mag, r2_add, r2_query) of keyframe k (lk_radius_maps)."""
+        return optim.radius_maps(self.eng, self.color_stack[k], RADIUS_CFG['color_grad_threshold'], RADIUS_CFG['radius_add_max'],
+                                 RADIUS_CFG['radius_add_min'], RADIUS_CFG['radius_query_ratio'])
+
+    def _join_render(self):
+        """The launch stream waits for the last mapped frame's full-frame render: called before anything writes what the render reads."""
+        if self.render_stream is not None:
+            torch.cuda.current_stream(self.eng.device).wait_stream(self.render_stream)
 
     def _draws(self, iters, R, n, gen=None):
         return torch.randint(0, n, (iters, R), generator=gen or self.gen, dtype=torch.int32, device=self.eng.device)
@@ -119,9 +186,9 @@ class FrameWorkload:
         # (multi-GPU: insertion is REPLICATED work - the same pixels and feature draws on every rank keep the map replicas identical)
         px = torch.randint(0, H * W, (b.pixels_adding,), generator=self.gen_track, device=eng.device)
         i, j = (px % W).float(), torch.div(px, W, rounding_mode='floor').float()
-        ro, rd = syn.pixel_rays(self.c2w_stack[k], i, j)
+        ro, rd = syn.pixel_rays(self.c2w_stack[k], i, j, self.cam)
         gd = self.depth_stack[k].reshape(-1)[px]
-        _, pts = optim.add_points(eng, self.knn, ro, rd, gd, float(torch.tensor(0.04 ** 2, dtype=torch.float32)), 0.98, 1.02, 3)
+        _, pts = optim.add_points(eng, self.knn, ro, rd, gd, float(torch.tensor(0.04 ** 2, dtype=torch.float32)), b.near_surface, b.far_surface, 3)
         m = min(int(pts.shape[0]), self.capacity - self.n)
         if m:
             self.pos[self.n:self.n + m] = pts[:m]
@@ -138,26 +205,49 @@ class FrameWorkload:
             jj, ii = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=eng.device), torch.arange(W, dtype=torch.float32, device=eng.device), indexing='ij')
             self._img_ij = (ii.reshape(-1).contiguous(), jj.reshape(-1).contiguous())
             self.img_state = core.RenderState(eng, H * W, self.cfg.S)
-        ro, rd = syn.pixel_rays(self.c2w_stack[k], *self._img_ij)
+        ro, rd = syn.pixel_rays(self.c2w_stack[k], *self._img_ij, self.cam)
         gd = self.depth_stack[k].reshape(-1).contiguous()
-        core.render_forward(eng, self.cfg, self.img_state, ro, rd, gd, self.knn, self.pos, self.geo, self.col, self.dec, 'color', stats_chunk=3000)
+        r2 = self.r2_stack[k].reshape(-1) if self.r2_stack is not None else None          # (dynamic radii: the frame's own query-radius map)
+        core.render_forward(eng, self.cfg, self.img_state, ro, rd, gd, self.knn, self.pos, self.geo, self.col, self.dec, 'color', stats_chunk=3000,
+                            r2_ray=r2)
         return self.img_state
 
     def step(self, full=False):
-        """One frame-equivalent: 40 tracking iterations + 60 mapping iterations (24 geometry + 36 colour).  full: every
+        """One frame-equivalent of the budget (Replica: 40 tracking iterations + 60 mapping iterations, 24 geometry + 36 colour).  full: every
         `every_frame`-th step is a MAPPED frame and also runs mapped_frame_extras / render_frame - the work the reference does
         once per mapped frame beside its 300 iterations (their 60-per-frame share is in every step)."""
         b, eng = self.b, self.eng
         H, W = self.H, self.W
         e = min(b.ignore_edge, H // 4)
         win = (e, H - e, e, W - e)
-        rnd_t = self._draws(b.track_iters, b.track_rays, (win[1] - win[0]) * (win[3] - win[2]), self.gen_track)
         k = self.frame_no % b.window
-        best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win, self.intr, rnd_t)
+        r2_map = None
+        win_t = win
+        if b.dynamic_radius or b.grad_pool:       # the tracked frame's image pre-pass (Tracker.py:243-268), every frame
+            grad, _, r2q = self._radius_maps(k)
+            if b.dynamic_radius:
+                r2_map = r2q
+                self.r2_stack[k].copy_(r2q)          # (the mapper's copy of this keyframe's map: same values, refreshed like an online run's)
+        if b.grad_pool:
+            # n of the 15 n highest-gradient pixels of the window per iteration, without replacement (common.py:198-234, Tracker.py:126-139):
+            # the n largest of a row of uniform draws, drawn and selected on the device (slam.Tracker.track_frame)
+            pool = optim.top_grad_pixels(eng, grad, 15 * b.track_rays, win, self.depth_stack[k], False)
+            u = torch.rand(b.track_iters, pool.numel(), generator=self.gen_track, device=eng.device)
+            rnd_t = pool[u.topk(min(b.track_rays, int(pool.numel())), dim=1).indices].contiguous()
+            win_t = (0, H, 0, W)
+        else:
+            rnd_t = self._draws(b.track_iters, b.track_rays, (win[1] - win[0]) * (win[3] - win[2]), self.gen_track)
+        xt = None
+        if b.exposure:                              # this frame's exposure feature starts from the keyframe's (Tracker.py:280-283)
+            self._xfeat_track = self.exposure_feats[k].detach().clone().requires_grad_(True)
+            xt = (self.mlp_exposure, self._xfeat_track)
+        best, tlog = self.tracker.track(self.cam0, self.depth_stack[k], self.color_stack[k], b.track_iters, win_t, self.intr, rnd_t,
+                                        r2_map=r2_map, exposure=xt)
+        # the mapping iterations below step feature rows, the decoder blob and its fragments: the full-frame render of the last mapped
+        # frame (its own stream) has overlapped this frame's tracking and must be through before they start
+        self._join_render()
         mapped = full and self.frame_no % b.every_frame == 0
         if mapped:
-            if self.render_stream is not None:      # the insertion changes the map and its index: the last frame's render must be through
-                torch.cuda.current_stream(eng.device).wait_stream(self.render_stream)
             self.mapped_frame_extras(k)
         rnd_m = self._draws(b.map_iters, b.map_rays, H * W)
         fid = self._fid

@@ -380,7 +380,10 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
 def knn_tree(points, queries, k, r2, tree=None):
     """Same contract as knn_exact for large clouds (CPU baseline timing): a KD-tree proposes the k nearest
     within the radius, distances are then recomputed in fp32 with the contract's formula and re-ordered by
-    (d2, index).  (Only differs from knn_exact if fp64 and fp32 orderings disagree at the k-th neighbour.)
+    (d2, index).  The tree proposes 2k candidates, of which the k smallest by the fp32 key are kept: fp64 and fp32 orderings disagree
+    around the k-th neighbour wherever distances tie to rounding (points inserted at fixed ratios along the rays that are sampled at
+    the same ratios tie exactly) - with k proposals 3 % of the lists of a small synthetic scene differed from knn_exact, with 2k none
+    (only differs from knn_exact if more than k candidates tie with the k-th).
     tree: a cKDTree already built over `points` as float64 (a caller that searches one cloud many times)."""
     from scipy.spatial import cKDTree
     pts = np.ascontiguousarray(np.asarray(points, dtype=np.float32).reshape(-1, 3))
@@ -390,7 +393,7 @@ def knn_tree(points, queries, k, r2, tree=None):
     if tree is None:
         tree = cKDTree(pts.astype(np.float64))
     rmax = float(np.sqrt(r2a.max())) * 1.001
-    _, ii = tree.query(q.astype(np.float64), k=k, distance_upper_bound=rmax, workers=-1)
+    _, ii = tree.query(q.astype(np.float64), k=2 * k, distance_upper_bound=rmax, workers=-1)
     ok = ii < pts.shape[0]
     I = np.where(ok, ii, 0)
     d = pts[I] - q[:, None, :]
@@ -398,8 +401,8 @@ def knn_tree(points, queries, k, r2, tree=None):
     ok &= d2 <= r2a[:, None]
     d2 = np.where(ok, d2, np.float32(np.inf)).astype(np.float32)
     key = np.lexsort((np.where(ok, ii, np.iinfo(np.int64).max), d2), axis=1)
-    d2 = np.take_along_axis(d2, key, 1)
-    idx = np.take_along_axis(np.where(ok, ii, -1), key, 1).astype(np.int32)
+    d2 = np.take_along_axis(d2, key, 1)[:, :k]
+    idx = np.take_along_axis(np.where(ok, ii, -1), key, 1)[:, :k].astype(np.int32)
     okk = np.isfinite(d2)
     cnt = (okk & (d2 < r2a[:, None])).sum(1).astype(np.int32)
     return np.where(okk, d2, np.float32(FLT_MAX)).astype(np.float32), idx, cnt

@@ -64,10 +64,13 @@ def main(argv=None):
     from datetime import datetime
     time_string = datetime.now().strftime('%Y%m%d_%H%M%S') if args.stop is None else None
 
+    # Dataset readers (src/utils/datasets.py) are out of scope of this build: whatever data.input_folder says - an existing directory
+    # included - the frames come from the synthetic room, and every printed error is against ITS ground truth.  Said on every run.
     folder = cfg['data'].get('input_folder')
-    if not (folder and os.path.isdir(folder)):
-        print(f'run.py: data.input_folder = {folder!r} holds no frames this build can read - the synthetic room stands in '
-              f'({cfg["data"].get("n_frames", 50)} frames at the config\'s intrinsics)', flush=True)
+    print(f'run.py: NO FRAME READER in this build - data.input_folder = {folder!r} '
+          f'({"exists, NOT read" if (folder and os.path.isdir(folder)) else "not found"}): the synthetic room stands in '
+          f'({cfg["data"].get("n_frames", 50)} frames at the config\'s intrinsics); pass a dataset object to Point_SLAM(dataset=...) for real frames',
+          flush=True)
     slam = Point_SLAM(cfg, args, time_string=time_string)
     slam.mapper.logger = Logger(cfg, args, slam.mapper)     # checkpoints in the reference's layout under <output>/ckpts (Point_SLAM.py:126-132)
     est, gt = slam.run()

@@ -128,6 +128,10 @@ class OracleSLAM:
         self.fix_color_decoder = m.get('fix_color_decoder', False)
         self.frustum_selection = m['frustum_feature_selection']
         self.kf_method = m.get('keyframe_selection_method', 'overlap')
+        # teacher forcing (tests/test_teacher_forced.py): on_track(inputs, outputs) / on_map(inputs, outputs) are called with everything one
+        # tracking call / one optimize_map call consumed (state BEFORE its iterations, draws, poses, rows) and produced (losses, stepped
+        # parameters), so that the product can be replayed call by call from the oracle's own state
+        self.on_track = self.on_map = None
 
     # ---- neighbour search with one KD-tree per map state
     def knn(self, p, r2):
@@ -214,7 +218,12 @@ class OracleSLAM:
         opt = torch.optim.Adam(params)
         best, best_loss = None, 1e20
         w = win[3] - win[2]
-        losses = []
+        losses, masked = [], []
+        rec = None
+        if self.on_track is not None:
+            rec = dict(cam=cam.clone(), flat=flat_all.clone(), win=win, depth=depth_t, color=color, r2_map=r2_map, iters=iters, n_px=n_px,
+                       separate=sep, lr=lr, pos=self.pos, geo=self.geo, col=self.col, W={k: v.detach().clone() for k, v in W.items()},
+                       xfeat=None if xfeat is None else xfeat.detach().clone())
         for it in range(iters):
             cam_t = torch.cat([q, T]) if sep else cam_v
             opt.zero_grad()
@@ -230,8 +239,9 @@ class OracleSLAM:
             r2 = r2_map[j.long(), i.long()][keep] if r2_map is not None else None
             aff = H.exposure_affine(W, xfeat) if xfeat is not None else None
             out = self.render(rcfg, ro[keep], rd[keep], gd[keep], self.geo, self.col, W, 'color', tracker=True, r2_ray=r2, affine=aff)
-            loss, _, _, _ = H.tracker_loss(out['depth'], out['var'], out['color'], gd[keep], gc[keep], t['w_color_loss'],
-                                           t['use_color_in_tracking'], t.get('handle_dynamic', True))
+            loss, _, _, m_t = H.tracker_loss(out['depth'], out['var'], out['color'], gd[keep], gc[keep], t['w_color_loss'],
+                                             t['use_color_in_tracking'], t.get('handle_dynamic', True))
+            masked.append(int(m_t.sum()))
             before = cam_t.detach().clone()
             loss.backward()
             opt.step()
@@ -245,6 +255,10 @@ class OracleSLAM:
             for n in EXPOSURE_PARAMS:
                 self.Wt[n] = W[n].detach().clone()
         self.track_log.append((losses[0], best_loss))
+        if rec is not None:
+            self.on_track(rec, dict(best=best.clone(), losses=list(losses), masked=masked,
+                                    xfeat=None if xfeat is None else xfeat.detach().clone(),
+                                    W_exposure={n: W[n].detach().clone() for n in EXPOSURE_PARAMS} if xfeat is not None else None))
         return best
 
     # ---- keyframes of the window (Mapper.py:219-282, 372-405)
@@ -368,6 +382,15 @@ class OracleSLAM:
         pstack = torch.stack([f[2].float() for f in frames])
         rstack = torch.stack([(f[3].double() ** 2).float() for f in frames]).reshape(F, -1) if self.dynamic else None
         losses = []
+        rec = None
+        if self.on_map is not None:
+            rec = dict(idx=int(idx), iters=int(num_joint_iters), geo_iters=int(geo_iters), R=int(R), F=F, fid=fid.clone(), rnd=rnd.clone(), rows=rows.clone(),
+                       lrs={s_: tuple(stage_cfg[s_][k_] for k_ in ('decoders_lr', 'geometry_lr', 'color_lr')) for s_ in ('geometry', 'color')},
+                       dstack=dstack.reshape(F, self.H, self.W), cstack=cstack.reshape(F, self.H, self.W, 3), pstack=pstack.clone(),
+                       rstack=None if rstack is None else rstack.reshape(F, self.H, self.W), pos=self.pos.clone(), geo=self.geo.clone(),
+                       col=self.col.clone(), W={k: v.detach().clone() for k, v in W.items()}, dec_names=list(dec_names),
+                       xfeats=None if xfeats is None else [x.detach().clone() for x in xfeats], fix_color_decoder=bool(self.fix_color_decoder),
+                       w_color=m['w_color_loss'])
         for it in range(num_joint_iters):
             stage = 'geometry' if it <= geo_iters else 'color'
             for gi, key in enumerate(('decoders_lr', 'geometry_lr', 'color_lr')):
@@ -407,6 +430,10 @@ class OracleSLAM:
             self.exposure_feat_all.append(cur_x.detach().clone())
         self.map_log.append(dict(idx=int(idx), iters=int(num_joint_iters), added=int(frame_pts_add), rows=int(rows.numel()), frames=F,
                                  loss_first=losses[0] if losses else None, loss_last=losses[-1] if losses else None))
+        if rec is not None:
+            self.on_map(rec, dict(losses=list(losses), geo_rows=geo_p.detach().clone(), col_rows=col_p.detach().clone(),
+                                  W={n: W[n].detach().clone() for n in dec_names},
+                                  xfeat=cur_x.detach().clone() if self.exposure_on else None))
         return num_joint_iters
 
     # ---- one mapped frame (Mapper.py:835-1037)

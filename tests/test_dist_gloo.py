@@ -25,19 +25,25 @@ LRS = {'geometry': (0.001, 0.03, 0.0), 'color': (0.005, 0.005, 0.005)}
 STAGES = ['geometry', 'color', 'color']
 
 
-def build(eng, R_batch, dctx, all_rows=False):
+def build(eng, R_batch, dctx, all_rows=False, exposure=False):
+    """exposure: the ScanNet model (model.encode_exposure, plain colour MLP) - the 'color' iterations render logits and the loss applies the
+    frame's affine; mlp_exposure and the frame's exposure feature are parameters too."""
     from loopy_slam_amd import core, steps, synthetic as syn
-    from test_steps_parity import mini_scene
+    from test_steps_parity import mini_scene, _exposure_module
     c2w, depth_img, color_img, pos, geo, col = mini_scene(3)
     depth_img = depth_img.clone()
     depth_img.reshape(-1)[5] = 1.0                       # no outlier: the inside mask keeps every positive depth
-    dec = core.DecoderBlob(eng).pack(syn.default_weights(seed=9))
+    W = syn.default_weights(seed=9, rel_pos=not exposure, exposure=exposure)
+    dec = core.DecoderBlob(eng).pack(W)
     pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo).clone(), eng.f32(col).clone()
     knn = core.KnnIndex(eng, capacity=pos.shape[0])
     knn.build(pos_d)
     rows = torch.arange(0, pos.shape[0], 3, dtype=torch.int32)
-    mo = steps.MapOptimizer(eng, core.RenderCfg(rel_pos=True), dec, knn, pos_d, geo_d, col_d, None if all_rows else rows.to(eng.device), R_batch, LRS,
-                            w_color=0.1, dist=dctx)
+    xp = None
+    if exposure:
+        xp = (_exposure_module(W).to(eng.device), [(0.2 * torch.ones(8)).to(eng.device).requires_grad_(True)])
+    mo = steps.MapOptimizer(eng, core.RenderCfg(rel_pos=not exposure, exposure=exposure), dec, knn, pos_d, geo_d, col_d,
+                            None if all_rows else rows.to(eng.device), R_batch, LRS, w_color=0.1, dist=dctx, exposure=xp)
     mo.begin_frame()
     frames = (eng.f32(depth_img).reshape(1, HH, WW), eng.f32(color_img).reshape(1, HH, WW, 3), eng.f32(c2w).reshape(1, 4, 4), None)
     return mo, frames, dec, geo_d, col_d
@@ -48,18 +54,18 @@ def draws():
     return torch.randint(0, HH * WW, (ITERS, 2, R), generator=g, dtype=torch.int32)
 
 
-def worker(rank, port, q, all_rows=False, native=True, backend='emu', overlap=False):
+def worker(rank, port, q, all_rows=False, native=True, backend='emu', overlap=False, exposure=False):
     try:
         if overlap:          # the row part of the bucket on a communication stream beside the backward's tail (parallel._exchange)
             os.environ['LOOPY_DIST_OVERLAP'] = '1'
-        _worker(rank, port, q, all_rows, native, backend)
+        _worker(rank, port, q, all_rows, native, backend, exposure)
     except Exception:                                   # surface the reason in the parent instead of a bare exit code
         import traceback
         q.put(('error', rank, traceback.format_exc()))
         raise
 
 
-def _worker(rank, port, q, all_rows, native, backend):
+def _worker(rank, port, q, all_rows, native, backend, exposure=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.set_num_threads(1)
@@ -67,7 +73,7 @@ def _worker(rank, port, q, all_rows, native, backend):
     from loopy_slam_amd import parallel
     from util import make_engine
     eng = make_engine(backend)
-    mo, frames, dec, geo_d, col_d = build(eng, R, parallel.DistContext(rank, 2), all_rows)
+    mo, frames, dec, geo_d, col_d = build(eng, R, parallel.DistContext(rank, 2), all_rows, exposure)
     rnd = draws().to(eng.device)
     fid = torch.zeros(R, dtype=torch.int32, device=eng.device)
     losses = []
@@ -77,6 +83,8 @@ def _worker(rank, port, q, all_rows, native, backend):
         log = log.cpu()
         dist.all_reduce(log)
         losses = [float(x) for x in log[:, 0]]
+        if exposure:            # every loss row of the call, every column (loss, depth term, colour term, rays): summed over the ranks
+            losses = log.reshape(-1).tolist()
     else:
         for it in range(ITERS):
             out4 = mo.iterate(STAGES[it], frames, rnd[it, rank].contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
@@ -113,15 +121,30 @@ def test_two_rank_grad_allreduce_matches_single_process(all_rows, native, backen
     for it in range(ITERS):
         out4 = mo.iterate(STAGES[it], frames, rnd[it].reshape(-1).contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW)
         ref_losses.append(float(out4[0]))
-    res = None
-    for attempt in range(2):                             # one retry: the free-port probe / gloo rendezvous can lose a race
+    res = _spawn_two_ranks((all_rows, native, backend, overlap))
+    res = [tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in r) for r in res]
+    full = [r for r in res if r[2] is not None][0]
+    other = [r for r in res if r[2] is None][0]
+    np.testing.assert_allclose(full[0], ref_losses, rtol=1e-5)
+    assert torch.equal(full[1], other[1])                                   # identical parameters on both ranks
+    np.testing.assert_allclose(full[1].numpy(), dec.blob.cpu().numpy(), rtol=0, atol=2e-5)
+    geo_d, col_d = geo_d.cpu(), col_d.cpu()
+    err = (full[2] - geo_d).abs()
+    assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.015
+    err = (full[3] - col_d).abs()
+    assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.0025
+
+
+def _spawn_two_ranks(args):
+    """Two worker processes over gloo (one retry: the free-port probe / gloo rendezvous can lose a race) -> their queue results."""
+    for attempt in range(2):
         s = socket.socket()
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
         s.close()
         ctx = mp.get_context('spawn')
         q = ctx.Queue()
-        procs = [ctx.Process(target=worker, args=(r, port, q, all_rows, native, backend, overlap)) for r in range(2)]
+        procs = [ctx.Process(target=worker, args=(r, port, q) + tuple(args)) for r in range(2)]
         for p in procs:
             p.start()
         try:
@@ -134,20 +157,34 @@ def test_two_rank_grad_allreduce_matches_single_process(all_rows, native, backen
                 p.kill()
         errs = [r for r in res if r[0] == 'error']
         if not errs and all(p.exitcode == 0 for p in procs):
-            break
+            return res
         if attempt == 1:
             raise AssertionError(f'workers failed: {errs} exit codes {[p.exitcode for p in procs]}')
-    res = [tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in r) for r in res]
-    full = [r for r in res if r[2] is not None][0]
-    other = [r for r in res if r[2] is None][0]
-    np.testing.assert_allclose(full[0], ref_losses, rtol=1e-5)
-    assert torch.equal(full[1], other[1])                                   # identical parameters on both ranks
-    np.testing.assert_allclose(full[1].numpy(), dec.blob.cpu().numpy(), rtol=0, atol=2e-5)
-    geo_d, col_d = geo_d.cpu(), col_d.cpu()
-    err = (full[2] - geo_d).abs()
-    assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.015
-    err = (full[3] - col_d).abs()
-    assert float(torch.quantile(err.reshape(-1), 0.999)) < 2e-5 and float(err.max()) < 0.0025
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_two_rank_exposure_loop_writes_every_loss_row(backend):
+    """Exposure encoding through the phase-split native loop (one lk_map_frame call per phase around the exchange): the 'geometry'
+    iterations leave their loss row as per-tile terms that ONE launch sums - behind the sequence's LAST iteration, which with exposure
+    encoding is a 'color' iteration that leaves no terms itself (round-4 advisor: the rows [0, n_geo) were never written then).  Every
+    row of the log, summed over the two ranks, against the single-process native loop that sees both shards; parameters alike."""
+    from util import make_engine
+    torch.set_num_threads(1)
+    eng = make_engine(backend)
+    mo, frames, dec, geo_d, col_d = build(eng, 2 * R, None, False, exposure=True)
+    rnd = draws().to(eng.device)
+    fid = torch.zeros(2 * R, dtype=torch.int32, device=eng.device)
+    log = eng.zeros(ITERS, 4)
+    mo.run(ITERS, 1, frames, rnd.reshape(ITERS, -1).contiguous(), fid, (0, HH, 0, WW), INTR, HH, WW, log)
+    mo.finish()
+    ref = log.cpu().reshape(-1).numpy()
+    assert ref.reshape(ITERS, 4)[0, 0] > 0 and ref.reshape(ITERS, 4)[0, 2] == 0 and ref.reshape(ITERS, 4)[1, 2] > 0      # geometry row, then colour rows
+    res = _spawn_two_ranks((False, True, backend, False, True))
+    for r in res:
+        np.testing.assert_allclose(np.array(r[0]), ref, rtol=2e-5, atol=1e-6)
+    a, b = (torch.from_numpy(r[1]) for r in res)
+    assert torch.equal(a, b)                                               # identical decoders on both ranks
+    np.testing.assert_allclose(a.numpy(), dec.blob.cpu().numpy(), rtol=0, atol=2e-5)
 
 
 def _rccl_worker(port, q, all_rows, mode='direct'):

@@ -1,0 +1,50 @@
+"""The benchmark workload (loopy_slam_amd/workload.py: what bench.py times) at toy budgets: the three budgets of BASELINE.json - Replica
+(rel-pos colour model, separate_LR), TUM (dynamic radii, gradient-pixel pool, one leaf pose) and ScanNet (exposure encoding, 0.96 / 1.04)
+- step through both loops, the mapped-frame extras and the full-frame render, and leave finite losses that the iterations lower."""
+import numpy as np
+import pytest
+import torch
+
+from loopy_slam_amd import workload, synthetic as syn
+from util import make_engine, backends
+
+
+def _budget(name):
+    small = dict(track_iters=3, track_rays=48, map_iters=5, map_geo_iters=2, map_rays=120, n_points=6000, pixels_adding=200)
+    if name == 'replica':
+        return workload.Budget(window=3, every_frame=2, **small)
+    mk = workload.Budget.tum if name == 'tum' else workload.Budget.scannet
+    b = mk()
+    for k, v in small.items():
+        setattr(b, k, v)
+    b.window, b.every_frame = 3, 2
+    return b
+
+
+@pytest.mark.parametrize('backend', backends())
+@pytest.mark.parametrize('name', ('replica', 'tum', 'scannet'))
+def test_frame_workload_steps(backend, name):
+    eng = make_engine(backend)
+    b = _budget(name)
+    # (the host emulator runs every lane as a fiber: a 640 x 480 frame's full render would take half an hour there)
+    cam = dict(syn.TUM_INTR) if backend == 'hip' else dict(H=48, W=64, fx=51.7, fy=51.6, cx=31.9, cy=25.5)
+    pos, geo, col = (t.to(eng.device) for t in syn.build_cloud(b.n_points, device='cpu', seed=3, intr=cam))
+    b.ignore_edge = 20 if backend == 'hip' else 4
+    wl = workload.FrameWorkload(eng, b, cloud=(pos, geo, col, 1), intr=cam)
+    assert (wl.r2_stack is not None) == b.dynamic_radius and (wl.mlp_exposure is not None) == b.exposure
+    geo0, blob0 = wl.geo[:wl.n].clone(), wl.dec.blob.clone()
+    logs = []
+    for k in range(3):
+        best, tlog, mlog = wl.step(full=True)
+        if eng.device.type == 'cuda':
+            torch.cuda.synchronize()
+        t, m = tlog.cpu().numpy(), mlog.cpu().numpy()
+        assert np.isfinite(t).all() and np.isfinite(m).all() and np.isfinite(best.cpu().numpy()).all()
+        assert (t[:, 3] > 0.5 * b.track_rays).all() and (m[:, 3] > 0.5 * b.map_rays).all()          # rays that took part in the losses
+        assert (m[:b.map_geo_iters, 2] == 0).all() and (m[b.map_geo_iters:, 2] > 0).all()            # colour term only in the 'color' stage
+        logs.append(m[:, 0].copy())
+    assert wl.n_added > 0 and wl.n == b.n_points + wl.n_added                      # frames 0 and 2 were mapped frames: points inserted
+    assert wl.img_state is not None and np.isfinite(wl.img_state.depth.cpu().numpy()).all()       # ... and rendered
+    assert float((wl.geo[:b.n_points] - geo0).abs().max()) > 1e-3 and not torch.equal(wl.dec.blob, blob0)
+    if b.exposure:
+        assert float((wl.exposure_feats[-1].detach() - wl.exposure_feats[-1].detach().clone().zero_()).abs().max()) > 0

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
 tail -c 600 gpurun_out/bench_$tag.json; echo
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only"
 rm -rf gpurun_out/prof_${tag}_stats gpurun_out/prof_${tag}_fetch gpurun_out/prof_${tag}_write
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -o b -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_fetch -o b -- $B > /dev/null 2>&1
