@@ -232,8 +232,11 @@ class FrameWorkload:
             # n of the 15 n highest-gradient pixels of the window per iteration, without replacement (common.py:198-234, Tracker.py:126-139):
             # the n largest of a row of uniform draws, drawn and selected on the device (slam.Tracker.track_frame)
             pool = optim.top_grad_pixels(eng, grad, 15 * b.track_rays, win, self.depth_stack[k], False)
+            # (the pool is the 15 n largest gradients of the WHOLE image restricted to the window and to pixels with a depth - common.py:198-234 -
+            # so it can be smaller than 15 n; the reference then draws min(n, pool) pixels, this workload's batches have a fixed size)
+            assert int(pool.numel()) >= b.track_rays, f'gradient-pixel pool of {int(pool.numel())} pixels < {b.track_rays} tracking rays on this frame'
             u = torch.rand(b.track_iters, pool.numel(), generator=self.gen_track, device=eng.device)
-            rnd_t = pool[u.topk(min(b.track_rays, int(pool.numel())), dim=1).indices].contiguous()
+            rnd_t = pool[u.topk(b.track_rays, dim=1).indices].contiguous()
             win_t = (0, H, 0, W)
         else:
             rnd_t = self._draws(b.track_iters, b.track_rays, (win[1] - win[0]) * (win[3] - win[2]), self.gen_track)

@@ -4,8 +4,14 @@ native loops - from the oracle's own state at that call (cloud after the frame's
 state, keyframe window, frustum rows) and the oracle's own draws.
 
 tests/test_accuracy.py compares two chaotic trajectories through their statistics (ATE means over seeds); here the chaos is cut at every
-call, so each call is a deterministic comparison: the per-iteration losses, the chosen pose, the stepped rows and decoders.  A 1 % error
-in a loop that the ATE band cannot see shows here as a 1 % loss difference in the first iterations of the first frame.
+call.  Inside a call it is still there - measured: the oracle's own 300-iteration mapping call of frame 0, re-run with its feature table
+perturbed by 1e-7 relative, ends 4.7 % apart in the loss (11 % at the worst iteration) and 0.2 apart in 1 % of the stepped entries; a
+40-iteration tracking call at the configured rate separates by a factor of ~10 per iteration from the sixth iteration on - so every call is
+compared (a) TIGHTLY where rounding has not been amplified yet: the first iterations (loss 5e-5 / 1e-4, masked-ray counts, candidate
+poses) and, for tracking calls, the whole call once more with the rate divided by 200 ("stiff": every iteration of the launch sequence on
+all but identical inputs); (b) over the whole call against a YARDSTICK: the oracle loop re-run with the feature tables perturbed by 1e-7 -
+the product may be 3 x as far from the oracle as that.  A 1 % error in a loop, which the ATE band cannot see, fails (a) in the first
+iteration of the first frame.
 
   config 1   configs/Synthetic/room.yaml at 500 rays per iteration (BASELINE config 1), 10 frames of the hand-held walk through the
              furnished room: frames 2..9 tracked (40 iterations), frames 0 and 5 mapped (iters_first shortened, see CFG1)
@@ -26,6 +32,7 @@ import torch
 import oracle_slam as OS
 from oracle import hotpath as H
 from loopy_slam_amd import config, core, slam, steps
+import test_loops_at_size as L
 from test_loops_at_size import param_error_stats
 from util import make_engine
 
@@ -57,8 +64,8 @@ def _exposure_module(W, dev):
 class Replayer:
     """Replays the oracle's calls through steps.TrackOptimizer / steps.MapOptimizer (the classes slam.Tracker / slam.Mapper drive)."""
 
-    def __init__(self, eng, cfg, case, tol):
-        self.eng, self.cfg, self.case, self.tol = eng, cfg, case, tol
+    def __init__(self, eng, cfg, case):
+        self.eng, self.cfg, self.case = eng, cfg, case
         c = cfg['cam']
         e = c.get('crop_edge', 0) or 0
         self.H, self.W = c['H'] - 2 * e, c['W'] - 2 * e
@@ -82,36 +89,67 @@ class Replayer:
         knn, dpos = self._index(rec['pos'])
         dgeo, dcol = eng.f32(rec['geo']), eng.f32(rec['col'])
         flat = rec['flat']
-        to = steps.TrackOptimizer(eng, rcfg, dec, knn, dpos, dgeo, dcol, flat.shape[1], rec['lr'], separate_lr=rec['separate'],
-                                  w_color=t['w_color_loss'], use_color=t['use_color_in_tracking'], dynamic_radius=rec['r2_map'] is not None,
-                                  handle_dynamic=t.get('handle_dynamic', True))
-        assert to.native_loop
-        xp = feat = None
+        dflat = flat.to(torch.int32).to(eng.device)
+        dr2 = eng.f32(rec['r2_map']) if rec['r2_map'] is not None else None
+        ddepth, dcolor = eng.f32(rec['depth']), eng.f32(rec['color'])
+        c2w = lambda c: H.quat_to_c2w(c.double())           # poses as [R | t]: |q| is a free direction (tests/test_loops_at_size.py)
+
+        def product(lr, exposure):
+            to = steps.TrackOptimizer(eng, rcfg, dec, knn, dpos, dgeo, dcol, flat.shape[1], lr, separate_lr=rec['separate'], w_color=t['w_color_loss'],
+                                      use_color=t['use_color_in_tracking'], dynamic_radius=dr2 is not None, handle_dynamic=t.get('handle_dynamic', True))
+            assert to.native_loop
+            best, log = to.track(eng.f32(rec['cam']), ddepth, dcolor, rec['iters'], rec['win'], self.intr, dflat, r2_map=dr2, exposure=exposure)
+            _sync(eng)
+            return best.cpu(), log[:, 0].cpu().numpy().astype(np.float64), log[:, 3].cpu().numpy().astype(int), to._keep_native[5].cpu()
+
+        xp = feat = mlp = None
         if rec['xfeat'] is not None:
             mlp = _exposure_module(rec['W'], eng.device)
             feat = eng.f32(rec['xfeat']).clone().requires_grad_(True)
             xp = (mlp, feat)
-        best, log = to.track(eng.f32(rec['cam']), eng.f32(rec['depth']), eng.f32(rec['color']), rec['iters'], rec['win'], self.intr,
-                             flat.to(torch.int32).to(eng.device), r2_map=eng.f32(rec['r2_map']) if rec['r2_map'] is not None else None, exposure=xp)
-        _sync(eng)
-        kl, ol = log[:, 0].cpu().numpy().astype(np.float64), np.array(out['losses'])
-        km, om = log[:, 3].cpu().numpy().astype(int), np.array(out['masked'])
+        best, kl, km, hist = product(rec['lr'], xp)
+        ol, om = np.array(out['losses']), np.array(out['masked'])
         rel = np.abs(kl - ol) / np.abs(ol)
-        s = dict(frame=len(self.track_stats), loss_rel_first=float(rel[0]), loss_rel_first10=float(rel[:10].max()), loss_rel_all=float(rel.max()),
-                 loss_rel_last=float(rel[-1]), masked_diff=int(np.abs(km - om).max()), pose_err=float((best.cpu() - out['best']).abs().max()),
-                 chosen=(int(np.argmin(kl)), int(np.argmin(ol))), moved=float((out['best'] - rec['cam']).abs().max()), points=int(rec['pos'].shape[0]))
+        s = dict(frame=len(self.track_stats), iters=rec['iters'], rays=int(flat.shape[1]), loss_rel=rel.tolist(), masked_diff=np.abs(km - om).tolist(),
+                 pose_err=float((c2w(best) - c2w(out['best'])).abs().max()), chosen=(int(np.argmin(kl)), int(np.argmin(ol))),
+                 best_loss_ratio=float(kl.min() / ol.min()), moved=float((c2w(out['best']) - c2w(rec['cam'])).abs().max()), points=int(rec['pos'].shape[0]))
         if feat is not None:
             s['xfeat_err'] = float((feat.detach().cpu() - out['xfeat']).abs().max())
             s['xfeat_moved'] = float((out['xfeat'] - rec['xfeat']).abs().max())
             s['xb2_err'] = float((mlp[2].bias.detach().cpu() - out['W_exposure']['color_decoder.mlp_exposure.linear2.bias']).abs().max())
+        else:
+            # the stiff call: the same draws with the rate divided by 200, product against the oracle loop (test_loops_at_size.oracle_track_loop)
+            lr_s = rec['lr'] / 200.0
+            render = L.TreeRender(rec['pos'], rcfg.rel_pos, near=rcfg.near_surface, far=rcfg.far_surface)
+            render.cfg.radius_query, render.cfg.coef, render.cfg.min_nn = rcfg.radius_query, rcfg.coef, rcfg.min_nn
+            sl, sm, sc, sb = L.oracle_track_loop(render, rec['geo'], rec['col'], rec['W'], rec['cam'], rec['depth'], rec['color'], flat, rec['win'], self.intr,
+                                                 lr_s, rec['separate'], w_color=t['w_color_loss'], r2_map=rec['r2_map'])
+            bs, ks, kms, hs = product(lr_s, None)
+            s['stiff_loss_rel'] = (np.abs(ks - np.array(sl)) / np.abs(np.array(sl))).tolist()
+            s['stiff_masked_diff'] = np.abs(kms - np.array(sm)).tolist()
+            s['stiff_pose_err'] = [float((c2w(hs[it]) - c2w(sc[it])).abs().max()) for it in range(rec['iters'])]
+            s['stiff_lr'] = lr_s
         self.track_stats.append(s)
         _record(self.case, track=self.track_stats)
-        tl = self.tol
-        assert np.isfinite(kl).all()
-        assert s['loss_rel_first'] <= tl['loss_first'] and s['loss_rel_first10'] <= tl['loss_first10'] and s['loss_rel_all'] <= tl['loss_all'], s
-        assert s['masked_diff'] <= tl['masked'], s
-        assert s['pose_err'] <= tl['pose'], s
-        if feat is not None:
+
+    def check_track(self, s, exact_iters=5):
+        """Assertions on one tracking call's statistics (after the run: a failing call leaves every call's numbers in the report).
+        Measured on the chip (gpurun_out/teacher_forced.json, round 5): first five iterations <= 4e-5 at 500 rays (<= 3e-6 in seven of eight
+        calls), stiff calls <= 3.4e-4 at 500 rays / <= 7e-7 at 5 000 (ONE sample whose eighth neighbour sits on the radius edge is 1 / (5 R) of the
+        batch), stiff poses <= 2.1e-6 = 0.2 steps after 40 iterations; at the configured rate the calls end up to 11 % apart in the loss and up
+        to 0.016 in the pose - as far as the oracle is from itself after a 1e-7 perturbation (see the module header)."""
+        n = min(exact_iters, s['iters'])
+        rel, dm = np.array(s['loss_rel']), np.array(s['masked_diff'])
+        assert np.isfinite(rel).all() and rel[0] <= 2e-5 and rel[:n].max() <= 1e-4, ('first iterations', s)
+        assert dm[:n].max() == 0 and dm.max() <= max(3, s['rays'] // 200), ('masked rays', s)
+        lr = self.cfg['tracking']['lr']
+        # the whole call at the configured rate: a sanity band only (chaotic from ~ the sixth iteration on)
+        assert rel.max() <= 0.3 and abs(s['best_loss_ratio'] - 1) <= 0.1 and s['pose_err'] <= lr * s['iters'], ('whole call', s)
+        if 'stiff_loss_rel' in s:
+            sr, sp = np.array(s['stiff_loss_rel']), np.array(s['stiff_pose_err'])
+            assert sr.max() <= max(5e-5, 0.25 / s['rays']) and max(s['stiff_masked_diff']) == 0, ('stiff call', s)
+            assert (sp <= 0.1 * s['stiff_lr'] * (1 + np.arange(sp.size)) + 2e-7).all(), ('stiff call, poses', s)
+        if 'xfeat_err' in s:
             assert s['xfeat_err'] <= 2e-4 and s['xb2_err'] <= 3e-4, s
 
     # ---- one optimize_map call (Mapper.py:562-735)
@@ -170,18 +208,51 @@ class Replayer:
             s['xfeat_err'] = float((feats[-1].detach().cpu() - out['xfeat']).abs().max())
             s['xfeat_moved'] = float((out['xfeat'] - rec['xfeats'][-1]).abs().max())
             s['keyframe_feats_constant'] = all(torch.equal(f.detach().cpu(), x) for f, x in zip(feats[:-1], rec['xfeats'][:-1]))
+        if iters > 40:
+            # YARDSTICK of a long call: the oracle loop once more with both feature tables perturbed by 1e-7 relative, against the oracle's own run
+            g = torch.Generator().manual_seed(1000 + rec['idx'])
+            pert = lambda x: x * (1 + 1e-7 * torch.randn(x.shape, generator=g))
+            render = L.TreeRender(rec['pos'], rcfg.rel_pos, near=rcfg.near_surface, far=rcfg.far_surface)
+            render.cfg.radius_query, render.cfg.coef, render.cfg.min_nn = rcfg.radius_query, rcfg.coef, rcfg.min_nn
+            if rec['xfeats'] is None:
+                yl, yg, yc, _ = L.oracle_map_loop(render, pert(rec['geo']), pert(rec['col']), W, rows, (rec['dstack'], rec['cstack'], rec['pstack']), rec['fid'], rec['rnd'],
+                                                  n_geo, self.intr, rec['lrs'], rec['dec_names'], w_color=rec['w_color'], rstack=rec['rstack'])
+                s['yard_loss_rel'] = (np.abs(np.array(yl) - ol) / np.abs(ol)).tolist()
+                s.update({f'yard_geo_{k}': v for k, v in param_error_stats(yg, out['geo_rows'], rec['geo'][rows]).items()})
+                s.update({f'yard_col_{k}': v for k, v in param_error_stats(yc, out['col_rows'], rec['col'][rows]).items()})
+        s['loss_rel'] = rel.tolist()
         self.map_stats.append(s)
         _record(self.case, map=self.map_stats)
-        tl = self.tol
-        assert np.isfinite(kl).all()
-        assert s['loss_rel_first'] <= tl['map_loss_first'] and s['loss_rel_first10'] <= tl['map_loss_first10'] and s['loss_rel_all'] <= tl['map_loss_all'], s
+
+    def check_map(self, s):
+        """Measured on the chip (round 5): first ten iterations <= 7e-6 (Replica model) / 1.3e-4 (TUM model at 10 000 rays); 10-iteration calls end
+        <= 1.3e-4 apart; the 285-372-iteration calls of config 1 end 1-10 % apart with 1 % of the stepped entries 0.2-0.3 apart - the
+        perturbed-oracle yardstick of the same calls: 0.5-18 %, 0.19-0.27."""
+        rel = np.array(s['loss_rel'])
+        iters, n_geo = s['iters'], s['n_geo']
+        lr_g, lr_c = self.cfg['mapping']['stage']['geometry']['geometry_lr'], self.cfg['mapping']['stage']['color']['color_lr']
+        assert np.isfinite(rel).all() and rel[0] <= 2e-5 and rel[:5].max() <= 5e-5 and rel[:10].max() <= 5e-4, ('first iterations', s)
         assert s['untouched_rows_equal'], s
         n_col = max(1, iters - n_geo)
-        assert s['geo_err_q99'] <= 0.02 * lr_g * iters ** 0.5 and s['geo_err_max'] <= 2.0 * lr_g * iters, s
-        assert s['col_err_q99'] <= 0.02 * lr_c * n_col ** 0.5 and s['col_err_max'] <= 2.0 * lr_c * n_col, s
-        assert s['decoder_excess_q999'] <= 2e-4, s
-        if feats is not None:
+        if 'yard_loss_rel' in s:
+            yard, h = np.array(s['yard_loss_rel']), iters // 2
+            assert rel.max() <= 5.0 * yard.max() + 1e-3 and np.median(rel[h:]) <= 5.0 * np.median(yard[h:]) + 1e-3, ('loss against the perturbed-oracle yardstick', s)
+            for t in ('geo', 'col'):
+                assert s[f'{t}_err_q99'] <= max(3.0 * s[f'yard_{t}_err_q99'], 1e-3) and s[f'{t}_err_q999'] <= max(3.0 * s[f'yard_{t}_err_q999'], 5e-3), (t, s)
+        else:
+            assert rel.max() <= 2e-3, ('loss, whole call', s)
+            assert s['geo_err_q99'] <= 0.02 * lr_g * iters ** 0.5 and s['geo_err_q999'] <= 0.1 * lr_g * iters ** 0.5, s
+            assert s['col_err_q99'] <= 0.05 * lr_c * n_col ** 0.5 + 2e-3 and s['col_err_q999'] <= 0.2 * lr_c * n_col ** 0.5 + 4e-3, s
+            assert s['decoder_excess_q999'] <= 2e-2, s
+        assert s['geo_err_max'] <= 2.0 * lr_g * iters and s['col_err_max'] <= 2.0 * max(lr_c, lr_g) * iters, s
+        if 'xfeat_err' in s:
             assert s['xfeat_err'] <= 3e-4 and s['xb2_err'] <= 3e-4 and s['keyframe_feats_constant'], s
+
+    def check_all(self):
+        for s in self.track_stats:
+            self.check_track(s, exact_iters=3 if not self.cfg['tracking']['separate_LR'] else 5)
+        for s in self.map_stats:
+            self.check_map(s)
 
 
 def _load(path, **over):
@@ -195,21 +266,20 @@ def _load(path, **over):
 # oracle iteration at 500 rays is 0.03-0.08 s: 1 500 of them would be two minutes of every run for the same code path)
 CFG1 = dict(tracking=dict(pixels=500), mapping=dict(pixels=500, iters_first=300, geo_iter_first=120, color_refine=False),
             data=dict(n_frames=10, motion='handheld', scene='furnished'))
-TOL1 = dict(loss_first=2e-4, loss_first10=5e-4, loss_all=5e-3, masked=1, pose=1e-4, map_loss_first=2e-4, map_loss_first10=1e-3, map_loss_all=2e-2)
 # TUM / ScanNet at their own ray budgets, 10 iterations per call, three frames (two tracked, frames 0 and 2 mapped)
 CFG_TUM = dict(tracking=dict(iters=10), mapping=dict(iters_first=10, geo_iter_first=3, iters=10, every_frame=2, keyframe_every=1, color_refine=False,
                                                        min_iter_ratio=1.0),
                data=dict(n_frames=4, motion='handheld', scene='furnished'))
-TOL_X = dict(loss_first=2e-4, loss_first10=5e-4, loss_all=5e-4, masked=1, pose=1e-4, map_loss_first=2e-4, map_loss_first10=1e-3, map_loss_all=1e-3)
 
 
-def run_teacher_forced(eng, case, cfg, n_frames, tol):
+def run_teacher_forced(eng, case, cfg, n_frames):
     reader = slam.SyntheticRoomDataset(cfg, 'cpu', n_frames)            # (the product's frame reader: the synthetic sequence, cropped as the config says)
     frames = [reader[i] for i in range(n_frames)]
     o = OS.OracleSLAM(cfg, frames)
-    rp = Replayer(eng, cfg, case, tol)
+    rp = Replayer(eng, cfg, case)
     o.on_track, o.on_map = rp.on_track, rp.on_map
     o.run(n_frames)
+    rp.check_all()
     return o, rp
 
 
@@ -217,9 +287,9 @@ def run_teacher_forced(eng, case, cfg, n_frames, tol):
 def test_config1_ten_frames_teacher_forced():
     cfg = _load('configs/Synthetic/room.yaml', **CFG1)
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-    o, rp = run_teacher_forced(make_engine('hip'), 'config1-500rays-10frames', cfg, 10, TOL1)
+    o, rp = run_teacher_forced(make_engine('hip'), 'config1-500rays-10frames', cfg, 10)
     assert len(rp.track_stats) == 8 and len(rp.map_stats) == 3          # frames 2..9 tracked; frames 0, 5 and the last one (9) mapped
-    assert max(s['pose_err'] for s in rp.track_stats) <= 1e-4
+    assert all('stiff_loss_rel' in s for s in rp.track_stats) and any('yard_loss_rel' in s for s in rp.map_stats)
     # the oracle itself tracked: better than the constant-speed prior it starts every frame from
     gt = torch.stack([f[3] for f in o.frames[:10]])
     assert OS.ate_rmse(o.est[:10], gt) < OS.prior_only_metrics(gt)['one_step_ate_cm'] / 100
@@ -230,7 +300,7 @@ def test_config1_ten_frames_teacher_forced():
 def test_tum_scannet_budgets_teacher_forced(name, path):
     cfg = _load(path, **CFG_TUM)
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-    o, rp = run_teacher_forced(make_engine('hip'), f'{name}-fullrays-10it', cfg, 4, TOL_X)
+    o, rp = run_teacher_forced(make_engine('hip'), f'{name}-fullrays-10it', cfg, 4)
     assert len(rp.track_stats) == 2 and len(rp.map_stats) >= 2
     assert rp.track_stats[0]['points'] > 10_000 and rp.map_stats[-1]['rays'] >= 9_000
     if name == 'scannet':
@@ -245,7 +315,6 @@ def test_teacher_forced_miniature_on_the_emulator():
                 pointcloud=dict(radius_add=0.12, radius_query=0.24, radius_min=0.06), data=dict(n_frames=5, motion='handheld', scene='furnished'))
     cfg['cam'].update(H=24, W=32, fx=26.0, fy=26.0, cx=15.5, cy=11.5)
     torch.set_num_threads(4)
-    tol = dict(TOL1, loss_all=2e-3, map_loss_all=5e-3)
-    o, rp = run_teacher_forced(make_engine('emu'), 'emu-miniature', cfg, 5, tol)
+    o, rp = run_teacher_forced(make_engine('emu'), 'emu-miniature', cfg, 5)
     assert len(rp.track_stats) == 3 and len(rp.map_stats) == 3
     _REPORT.clear()
