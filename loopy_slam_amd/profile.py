@@ -108,11 +108,17 @@ def step_flops(b):
 
 
 def pmc_traffic(kernel, path=None):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r4_rocprof_summary.md, written by
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (the newest profiles/r<N>_rocprof_summary.md, written by
     tools/summarize_prof.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this bench; FETCH_SIZE doubled per
     the gfx950 note of MI355X_MICROARCH.md): (bytes, source) or (None, None).  bench.py cannot collect PMC counters live."""
+    import glob
     import os
-    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r4_rocprof_summary.md')
+    import re
+    if path is None:
+        cands = glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r*_rocprof_summary.md'))
+        if not cands:
+            return None, None
+        path = max(cands, key=lambda f: int(re.match(r'r(\d+)_', os.path.basename(f)).group(1)))
     try:
         tot_n, tot_b = 0, 0.0
         for line in open(path):
@@ -121,7 +127,7 @@ def pmc_traffic(kernel, path=None):
                 tot_n += int(c[1])
                 tot_b += int(c[1]) * (float(c[3]) * 1e6 + float(c[4]) * 1024.0)
         if tot_n:
-            return tot_b / tot_n, 'profiles/r4_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
+            return tot_b / tot_n, f'profiles/{os.path.basename(path)} (separate --pmc FETCH_SIZE / WRITE_SIZE passes)'
     except (OSError, ValueError):
         pass
     return None, None

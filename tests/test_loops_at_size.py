@@ -101,7 +101,7 @@ def envelope_ok(e_a, e_yard, factor, floor):
     return bool((np.asarray(e_a) <= bound).all()), bound
 
 
-def run_track_case(eng, case, N, R, iters, rel_pos, separate, lr, grad_pool=False, dynamic=False, exact_iters=5):
+def run_track_case(eng, case, N, R, iters, rel_pos, separate, lr, grad_pool=False, dynamic=False, exact_iters=3):
     """One lk_track_frame call against oracle_track_loop.  grad_pool: the pixels come from the pool of the highest colour-gradient pixels
     (tracking.sample_with_color_grad, common.py:198-234), dynamic: per-pixel query radius (use_dynamic_radius) - both from the ORACLE's image
     pre-pass, handed to the product as inputs (the call under test is the loop, not the pre-pass).
@@ -288,7 +288,11 @@ def run_map_case(eng, case, N, R, iters, n_geo, rel_pos, window=12, exact_iters=
     # measured on the chip (5 000 x 60): <= 2e-6 through the 24 'geometry' iterations, then growing by ~15 % per iteration of the 'color' stage
     # to 1-4e-4 (Adam's sign-like steps on noise-level entries feed back through the colour decoder's weights)
     checks.append((rel[:exact_iters].max() <= 2e-5 and rel[:n_geo].max() <= 5e-5 and rel[min(n_geo, iters - 1)] <= 5e-5, ('loss, first iterations / geometry stage', rel.tolist())))
-    checks.append((rel.max() <= max(3.0 * yrel.max(), 5e-4), ('loss, whole call, against the perturbed-oracle yardstick', rel.tolist(), yrel.tolist())))
+    # (the call has BRANCHES: 24 runs of it on one box - tools/probe/split_step_race.py, profiles/r5_map_call_branches.txt - follow one of four
+    # loss sequences from the second 'color' iteration on, e.g. 9.3e-6, 5.9e-6, 9.7e-6 ... or 2.7e-4, 2.3e-4, 2.2e-4 ..., the same digits every
+    # time: which one is decided by the sign of a few noise-level gradient entries in the colour decoder's first, sign-like Adam step, i.e. by
+    # the order of the gather's float atomics in the 24 'geometry' iterations before it; the largest difference of a call was 3.8e-4 ... 1.2e-3)
+    checks.append((rel.max() <= max(3.0 * yrel.max(), 3e-3), ('loss, whole call, against the perturbed-oracle yardstick', rel.tolist(), yrel.tolist())))
     checks.append((o_losses[-1] < o_losses[min(n_geo, iters - 1)], 'the colour stage lowered its loss'))
     # rows outside the list: bit for bit where they were
     other = torch.ones(N, dtype=torch.bool)
@@ -312,7 +316,9 @@ def run_map_case(eng, case, N, R, iters, n_geo, rel_pos, window=12, exact_iters=
         st, sy = param_error_stats(Wk[n], W_o[n], W[n]), param_error_stats(W_y[n], W_o[n], W[n])
         scale = max(1.0, float(W[n].abs().max()))
         worst[n] = (st['err_q999'] / scale, st['err_max'] / scale, sy['err_q999'] / scale, sy['err_max'] / scale)
-        checks.append((st['err_q999'] <= max(3.0 * sy['err_q999'], 2e-4 * scale) and st['err_max'] <= max(3.0 * sy['err_max'], 2e-4 * scale + 0.5 * st['moved_max']), (n, st, sy)))
+        # (floors relative to what the tensor MOVED: a bias vector is 128 entries - its 99.9 % level is its single worst entry)
+        checks.append((st['err_q999'] <= max(3.0 * sy['err_q999'], 2e-4 * scale + 0.1 * st['moved_max']) and
+                       st['err_max'] <= max(3.0 * sy['err_max'], 2e-4 * scale + 0.5 * st['moved_max']), (n, st, sy)))
     _record(case, decoder_err_q999_rel_max=max(v[0] for v in worst.values()), decoder_err_max_rel_max=max(v[1] for v in worst.values()),
             decoder_yard_q999_rel_max=max(v[2] for v in worst.values()), decoder_yard_max_rel_max=max(v[3] for v in worst.values()), decoder_tensors=len(worst))
     checks.append((len(worst) >= (28 if rel_pos else 23), 'every decoder tensor compared'))
@@ -342,7 +348,7 @@ def run_map_case(eng, case, N, R, iters, n_geo, rel_pos, window=12, exact_iters=
     # (worst ray and the 99 % level of the per-ray colour difference), floors 2e-4 / 1e-3
     checks.append((e_d <= max(3.0 * y_d, 2e-4) and e_c <= max(3.0 * y_c, 1e-3) and q(dc, .99) <= max(3.0 * q(yc, .99), 5e-4), ('functional', e_d, e_c, y_d, y_c)))
     failed = [c[1] for c in checks if not c[0]]
-    _record(case, failed_checks=len(failed))
+    _record(case, failed_checks=[str(f)[:200] for f in failed])
     assert not failed, (case, failed)
     return rel
 

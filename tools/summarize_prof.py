@@ -17,7 +17,7 @@ dst = os.path.join(root, 'profiles')
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, f'prof_{src_tag}_stats', 'b_kernel_stats.csv'), os.path.join(dst, f'{tag}_kernel_stats.csv'))
 lines = [f'# rocprofv3 summary, round tag {tag}', '',
-         'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline`',
+         'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only`',
          '(kernel table = profiles/%s_kernel_stats.csv; durations in ns).' % tag, '',
          '| kernel | calls | avg us | % |', '|---|---|---|---|']
 for r in list(csv.DictReader(open(os.path.join(dst, f'{tag}_kernel_stats.csv'))))[:24]:
