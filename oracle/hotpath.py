@@ -157,8 +157,28 @@ def fourier(x, B, concat):
     multiply-adds in k order (pinned by tests/test_oracle_golden.py::test_embed_fma_order);
     the HIP kernels use exactly that sequence so sin/cos see bit-identical arguments.
     """
-    y = (TWO_PI * x) @ B
+    y = fourier_arg(x, B)
     return torch.cat((torch.sin(y), torch.cos(y)), dim=-1) if concat else torch.sin(y)
+
+
+def fourier_arg(x, B):
+    """(2 pi x) @ B for K = 3 in fp32 with the VALUES of the sequence a0*b0, fma(a1, b1, .), fma(a2, b2, .) on every host, and matmul's
+    derivative.  On the host the goldens were captured on (and the build container) torch.matmul produces exactly that sequence - 0 of
+    18.6 M arguments differ - but which kernel MKL picks depends on the CPU: on an AMD EPYC 9575F host (round 5, one kind of box of the
+    GPU pool) its arguments differ from that sequence in the last bit, d/dp through 2 pi B cos(2 pi p B) with |B| ~ 25-32 amplifies an ulp
+    a thousandfold, and the at-size tracker gradients of the kernels (which use the sequence) sat 7e-5 ... 1.2e-4 from this oracle instead of
+    3e-6.  The fused multiply-add is evaluated in float64 (the product of two fp32 numbers is exact there) and rounded once; other dtypes
+    (the float64 referee) go through matmul."""
+    a = TWO_PI * x
+    y = a @ B
+    if y.dtype != torch.float32 or B.shape[0] != 3:
+        return y
+    with torch.no_grad():
+        ad, Bd = a.detach().double(), B.detach().double()
+        t = (a.detach()[..., 0:1] * B.detach()[0:1, :])                                  # a0 * b0, rounded to fp32
+        t = (ad[..., 1:2] * Bd[1:2, :] + t.double()).float()                             # fma(a1, b1, t)
+        t = (ad[..., 2:3] * Bd[2:3, :] + t.double()).float()                             # fma(a2, b2, t)
+    return y + (t - y).detach()
 
 
 def interp_weights(p, pos, idx, d2, r2, tracker):

@@ -83,7 +83,7 @@ class ref64:
             return p32.double() + (pg - pg.detach())
 
         def fourier(x, B, concat):
-            y32 = (H.TWO_PI * x.detach().float()) @ B.detach().float()
+            y32 = H.fourier_arg(x.detach().float(), B.detach().float())          # (the kernels' fma sequence, whatever matmul kernel this host's MKL picks)
             yg = (H.TWO_PI * x.double()) @ B.double()
             y = y32.double() + (yg - yg.detach())
             return torch.cat((torch.sin(y), torch.cos(y)), dim=-1) if concat else torch.sin(y)
