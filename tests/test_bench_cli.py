@@ -61,8 +61,9 @@ def test_one_rank_over_rccl_exchange_overhead(plain):
     gpurun_out/bench_dist_one_rank.json): plain loop 18.55 ms, direct communicator on the launch stream 19.56 (+1.0: per mapping iteration the
     pack launch, the one-rank RCCL kernel and the Adam launch that otherwise rides in the reduction launch - and the phase-split loop cannot
     take the split step of the plain one), overlapped row exchange 20.88 (+2.3: a second collective and two stream hand-overs per iteration
-    with nothing on the wire to hide - it is the default only where ranks exchange over xGMI).  Bounds: +1.5 / +3.0 ms - a regression of a
-    launch per iteration (0.3-0.4 ms per step) fails; the round-4 review's +1.0 ms target for the direct path is NOT met (1.0 measured)."""
+    with nothing on the wire to hide - it is the default only where ranks exchange over xGMI).  Bounds: +8 % / +16 % of the plain step (measured
+    +5.4 % / +12.5 %; relative, because one box of the pool runs every kernel 1.4x slower) - a regression of a launch per iteration (0.3-0.4 ms
+    per step = 2 %) fails; the round-4 review's +1.0 ms target for the direct path is on the line (1.0 measured)."""
     direct = _bench(['--steps', '5', '--warmup', '1', '--no-cpu-baseline'], env={'LOOPY_DIST_FORCE': '1', 'LOOPY_DIST_OVERLAP': '0'})
     over = _bench(['--steps', '5', '--warmup', '1', '--no-cpu-baseline'], env={'LOOPY_DIST_FORCE': '1', 'LOOPY_DIST_OVERLAP': '1'})
     out = os.path.join(ROOT, 'gpurun_out')
@@ -71,5 +72,5 @@ def test_one_rank_over_rccl_exchange_overhead(plain):
             json.dump({'plain_ms': plain['ms_per_step'], 'direct_ms': direct['ms_per_step'], 'overlap_ms': over['ms_per_step'],
                        'plain_iterations_ms': plain['ms_per_step_iterations'], 'direct_iterations_ms': direct['ms_per_step_iterations'],
                        'overlap_iterations_ms': over['ms_per_step_iterations']}, f, indent=1)
-    assert direct['n_gpus'] == 1 and direct['ms_per_step'] - plain['ms_per_step'] <= 1.5, (plain['ms_per_step'], direct['ms_per_step'])
-    assert over['ms_per_step'] - plain['ms_per_step'] <= 3.0, (plain['ms_per_step'], over['ms_per_step'])
+    assert direct['n_gpus'] == 1 and direct['ms_per_step'] <= 1.08 * plain['ms_per_step'], (plain['ms_per_step'], direct['ms_per_step'])
+    assert over['ms_per_step'] <= 1.16 * plain['ms_per_step'], (plain['ms_per_step'], over['ms_per_step'])
