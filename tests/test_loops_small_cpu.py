@@ -19,13 +19,13 @@ def small(monkeypatch):
 
 
 def test_track_call_small(small):
-    L.run_track_case(make_engine('emu'), 'cpu-track-replica', 24_000, 160, 12, True, True, 0.002)
+    L.run_track_case(make_engine('emu'), 'cpu-track-replica', 24_000, 128, 8, True, True, 0.002)
     assert max(L._REPORT['cpu-track-replica-stiff']['loss_rel']) <= 5e-5
 
 
 def test_track_call_small_gradient_pool(small):
-    L.run_track_case(make_engine('emu'), 'cpu-track-tum', 24_000, 200, 6, False, False, 0.002, grad_pool=True, dynamic=True)
+    L.run_track_case(make_engine('emu'), 'cpu-track-tum', 24_000, 160, 4, False, False, 0.002, grad_pool=True, dynamic=True)
 
 
 def test_map_call_small(small):
-    L.run_map_case(make_engine('emu'), 'cpu-map-replica', 24_000, 240, 10, 4, True, window=4)
+    L.run_map_case(make_engine('emu'), 'cpu-map-replica', 24_000, 160, 7, 3, True, window=4)

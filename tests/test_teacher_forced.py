@@ -142,15 +142,16 @@ class Replayer:
         rel, dm = np.array(s['loss_rel']), np.array(s['masked_diff'])
         # (ONE sample whose eighth neighbour sits on the radius edge, or one ray on the loss mask's threshold, is 1 / (5 R) ... 1 / R of the batch:
         # 1e-4 at 5 000 rays, 5e-4 at 500)
-        assert np.isfinite(rel).all() and rel[0] <= 2e-5 and rel[:n].max() <= max(1e-4, 0.25 / s['rays']), ('first iterations', s)
-        assert dm[:n].max() == 0 and dm.max() <= max(5, s['rays'] // 100), ('masked rays', s)
+        assert np.isfinite(rel).all() and L.stiff_call_ok(rel[:n], dm[:n], s['rays'], max(1e-4, 0.25 / s['rays'])), ('first iterations', s)
+        assert dm.max() <= max(5, s['rays'] // 100), ('masked rays', s)
         lr = self.cfg['tracking']['lr']
         # the whole call at the configured rate: a sanity band only (chaotic from ~ the sixth iteration on)
         assert rel.max() <= 0.3 and abs(s['best_loss_ratio'] - 1) <= 0.1 and s['pose_err'] <= lr * s['iters'], ('whole call', s)
         if 'stiff_loss_rel' in s:
             sr, sp = np.array(s['stiff_loss_rel']), np.array(s['stiff_pose_err'])
-            # (one ray's worth of loss: measured <= 6.3e-4 at 500 rays - 24 stiff calls on three boxes - and <= 7e-7 at 5 000)
-            assert sr.max() <= max(5e-5, 1.0 / s['rays']) and max(s['stiff_masked_diff']) == 0, ('stiff call', s)
+            # (one ray's worth of loss: measured <= 6.3e-4 at 500 rays - 32 stiff calls on four boxes - and <= 7e-7 at 5 000; a ray on the loss
+            # mask's threshold: test_loops_at_size.stiff_call_ok)
+            assert L.stiff_call_ok(sr, s['stiff_masked_diff'], s['rays'], max(5e-5, 1.0 / s['rays'])), ('stiff call', s)
             assert (sp <= 0.1 * s['stiff_lr'] * (1 + np.arange(sp.size)) + 2e-7).all(), ('stiff call, poses', s)
         if 'xfeat_err' in s:
             assert s['xfeat_err'] <= 2e-4 and s['xb2_err'] <= 3e-4, s

@@ -12,8 +12,9 @@ from util import make_engine, backends
 def _budget(name, backend):
     # (tracking rays of the gradient-pool budgets: the pool is the 15 n largest gradients of the whole frame INSIDE the window - on the
     # 640 x 480 synthetic room 22 396 of the 30 000 largest, none of the 720 largest: n = 2 000 there, 48 on the emulator's 64 x 48 frames)
-    small = dict(track_iters=3, track_rays=48 if (backend == 'emu' or name == 'replica') else 2000, map_iters=5, map_geo_iters=2, map_rays=120,
-                 n_points=6000, pixels_adding=200)
+    small = dict(track_iters=3 if backend == 'hip' else 2, track_rays=48 if (backend == 'emu' or name == 'replica') else 2000,
+                 map_iters=5 if backend == 'hip' else 4, map_geo_iters=2, map_rays=120 if backend == 'hip' else 72,
+                 n_points=6000 if backend == 'hip' else 4000, pixels_adding=200)
     if name == 'replica':
         return workload.Budget(window=3, every_frame=2, **small)
     mk = workload.Budget.tum if name == 'tum' else workload.Budget.scannet
