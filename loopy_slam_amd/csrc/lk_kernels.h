@@ -174,9 +174,6 @@ struct AdamSegDev {
 // soon as it has its sum (new value -> w_next: the master blob is read by the fc_c blocks of the same launch and stays as it was
 // until the next iteration's interpolation launch copies w_next over it), and the feature-row segments - final since the gather -
 // run as extra blocks.  One dispatch (11 us + its gap) less per iteration.
-#ifndef LK_SPLIT_STEP
-#define LK_SPLIT_STEP 1         // (a variant library built with -DLK_SPLIT_STEP=0 is the A/B partner: tools/ab_build.sh)
-#endif
 struct LkStepSpan { int off, n; float step_size, bc2_sqrt; };
 struct LkStepRider {
     int n_span;                                    // decoder spans (offsets into the blob); 0 = no rider

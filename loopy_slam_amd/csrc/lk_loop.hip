@@ -809,7 +809,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
                 }
                 ex.step = &sr;
                 // the colour trunk's half of this step on the weight-gradient stream, joined in front of the next iteration's decoder launch
-                ex.split_reduce = LK_SPLIT_STEP; ex.split_frag = d->weights_frag_rw; ex.split_master = d->weights_rw; ex.split_done = &split_pending;
+                ex.split_reduce = 1; ex.split_frag = d->weights_frag_rw; ex.split_master = d->weights_rw; ex.split_done = &split_pending;
             }
             if (comp_bwd) ex.loss_rows = W0 + wk.loss_rows + (size_t)it * 4 * lk_cdiv(Pn, 32);
             // exposure encoding, one process: the backward + Adam half of the exposure step rides in this backward's gather launch (d affine is

@@ -195,12 +195,16 @@ def _rccl_worker(port, q, all_rows, mode='direct'):
         # process-group collectives, 'overlap' = direct + the row part of the bucket on a communication stream beside the backward's tail
         if mode == 'torch':
             os.environ['LOOPY_DIST_TORCH'] = '1'
-        if mode == 'overlap':
+        if mode in ('overlap', 'overlap-serial'):
             os.environ['LOOPY_DIST_OVERLAP'] = '1'
         torch.cuda.set_device(0)
         from loopy_slam_amd import parallel
         from util import make_engine
         eng = make_engine('hip')                 # before the process group: the library's streams take their hardware queues first
+        if mode == 'overlap-serial':
+            # the library on the launch stream only (LK_SERIAL / a failed side-stream creation): the communication stream of the overlapped
+            # exchange still gets a real dependency on the backward - the rows event is recorded whatever the stream mode (round-4 advisor)
+            eng.lib.check(eng.lib.dll.lk_set_serial(1), 'lk_set_serial')
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
         dctx = parallel.DistContext(0, 1)
         mo, frames, dec, geo_d, col_d = build(eng, 2 * R, dctx, all_rows)
@@ -225,7 +229,7 @@ def _rccl_worker(port, q, all_rows, mode='direct'):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('all_rows,mode', ((False, 'direct'), (True, 'direct'), (False, 'torch'), (False, 'overlap')))
+@pytest.mark.parametrize('all_rows,mode', ((False, 'direct'), (True, 'direct'), (False, 'torch'), (False, 'overlap'), (False, 'overlap-serial')))
 def test_rccl_collectives_on_the_launch_stream(all_rows, mode):
     """The production exchange on the production backend: ONE rank, backend 'nccl' (= RCCL), the native loop split in phases around
     dist.all_reduce of the gradient bucket on DEVICE memory (no host staging), the uint8 MAX agreement on the touched rows and the

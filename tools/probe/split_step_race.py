@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Is the split step (LkBwdExtra::split_reduce) race-free?  The at-size mapping call of tests/test_loops_at_size.py, repeated K times per
-library variant in ONE process each (ab/lib_split.so, ab/lib_nosplit.so), the per-iteration losses against the oracle loop's (computed
-once).  A stale read behind the moved join would show as an occasional jump of the loss difference right after the first 'color'
+library variant in ONE process each (ab/lib_split.so = the shipped library, ab/lib_nosplit.so = the same sources with `ex.split_reduce = 0` in
+lk_loop.hip - round 5 built it with a -DLK_SPLIT_STEP=0 macro that has since been removed), the per-iteration losses against the oracle loop's
+(computed once).  A stale read behind the moved join would show as an occasional jump of the loss difference right after the first 'color'
 iterations; chaos alone grows smoothly from ~1e-5 there.
 
     python tools/probe/split_step_race.py K          (on the GPU box; prints one line per run)"""
