@@ -12,9 +12,9 @@ from util import make_engine, backends
 def _budget(name, backend):
     # (tracking rays of the gradient-pool budgets: the pool is the 15 n largest gradients of the whole frame INSIDE the window - on the
     # 640 x 480 synthetic room 22 396 of the 30 000 largest, none of the 720 largest: n = 2 000 there, 48 on the emulator's 64 x 48 frames)
-    small = dict(track_iters=3 if backend == 'hip' else 2, track_rays=48 if (backend == 'emu' or name == 'replica') else 2000,
-                 map_iters=5 if backend == 'hip' else 4, map_geo_iters=2, map_rays=120 if backend == 'hip' else 72,
-                 n_points=6000 if backend == 'hip' else 4000, pixels_adding=200)
+    small = dict(track_iters=3 if backend == 'hip' else 2, track_rays=(48 if backend == 'hip' else 32) if (backend == 'emu' or name == 'replica') else 2000,
+                 map_iters=5 if backend == 'hip' else 4, map_geo_iters=2, map_rays=120 if backend == 'hip' else 48,
+                 n_points=6000 if backend == 'hip' else 4000, pixels_adding=200 if backend == 'hip' else 120)
     if name == 'replica':
         return workload.Budget(window=3, every_frame=2, **small)
     mk = workload.Budget.tum if name == 'tum' else workload.Budget.scannet
@@ -38,13 +38,13 @@ def test_frame_workload_steps(backend, name):
     assert (wl.r2_stack is not None) == b.dynamic_radius and (wl.mlp_exposure is not None) == b.exposure
     geo0, blob0 = wl.geo[:wl.n].clone(), wl.dec.blob.clone()
     logs = []
-    for k in range(3):
+    for k in range(3 if backend == 'hip' else 2):          # (every_frame 2: steps 0 and 2 are mapped frames; the emulator runs two)
         best, tlog, mlog = wl.step(full=True)
         if eng.device.type == 'cuda':
             torch.cuda.synchronize()
         t, m = tlog.cpu().numpy(), mlog.cpu().numpy()
         assert np.isfinite(t).all() and np.isfinite(m).all() and np.isfinite(best.cpu().numpy()).all()
-        assert (t[:, 3] > 0.5 * b.track_rays).all() and (m[:, 3] > 0.5 * b.map_rays).all()          # rays that took part in the losses
+        assert (t[:, 3] > 0.4 * b.track_rays).all() and (m[:, 3] > 0.4 * b.map_rays).all()          # rays that took part in the losses
         assert (m[:b.map_geo_iters, 2] == 0).all() and (m[b.map_geo_iters:, 2] > 0).all()            # colour term only in the 'color' stage
         logs.append(m[:, 0].copy())
     assert wl.n_added > 0 and wl.n == b.n_points + wl.n_added                      # frames 0 and 2 were mapped frames: points inserted
