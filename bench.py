@@ -230,8 +230,8 @@ def main():
             out['roofline']['serial'] = {k: ser[k] for k in ('avg_launch_us', 'achieved', 'frac') if k in ser}
             out['roofline']['serial']['note'] = 'same kernel with the side stream off (lk_set_serial): nothing else shares the chip'
         if out['roofline'] is not None:
-            out['roofline']['chosen_by'] = ('largest summed duration in the profiled step; kernels within 3 % of it are level (k_decode_bwd and k_wgrad trade '
-                                            'places from run to run) and the longer average launch decides - every kernel is in roofline_all_kernels')
+            out['roofline']['chosen_by'] = ('largest summed duration in the profiled step (kernels within 3 % of it are level and the longer average launch decides); '
+                                            'every kernel is in roofline_all_kernels')
         # north_star: fraction of the HBM roofline of the whole step (11.1 KB/ray forward, +20.5 KB/ray backward with the
         # feature-gradient scatter; tracking iterations have no scatter: 2 x 11.1 KB/ray)
         step_bytes = world * (budget.map_iters * budget.map_rays * 31.6e3 + budget.track_iters * budget.track_rays * 22.2e3)
@@ -244,7 +244,7 @@ def main():
             out['workloads'] = others
         out['host_cores'] = os.cpu_count()
         # every timed kernel against its own roof, from the profiled warm-up step (events around every launch, so slightly slower
-        # than the timed region): the dominant kernel changes with small shifts - k_wgrad and k_decode_bwd are within 2 % of each other
+        # than the timed region)
         out['roofline_all_kernels'] = []
         for kn in sorted(kall, key=lambda k: -kall[k]['total_ms']):
             rk = profile.roofline(kall, budget, kn)

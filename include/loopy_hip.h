@@ -507,7 +507,9 @@ int lk_wgrad_single(const float* A, int32_t lda, int32_t a_mode, const float* A2
 /* ---------------------------------------------------------------- measurement
  * Per-kernel GPU time with HIP events recorded on the launch stream around the selected kernels
  * (names: comma-separated, e.g. "k_decode_bwd", or "*").  lk_profile_end synchronises those events and writes
- * "name calls total_ms" lines into buf.  Used by bench.py for the roofline figure. */
+ * "name calls total_ms" lines into buf.  Used by bench.py for the roofline figure.  A name stands for the instantiations rocprofv3 lists
+ * under it, with one split: the decoder backward of launches WITH ray gradients (the tracker's: other instantiations, bf16 pieces in the
+ * geometry role) is timed as "k_decode_bwd_track", the mapper's as "k_decode_bwd". */
 int lk_profile_begin(const char* names);
 /* lk_render_bwd runs the decoder weight-gradient reductions on a second, library-owned HIP stream beside the rel-pos backward and
  * the feature scatter (fork / join with events on the caller's stream: the caller sees one ordered stream).  on != 0 keeps

@@ -677,7 +677,7 @@ extern "C" int lk_wgrad_single(const float* A, int32_t lda, int32_t a_mode, cons
 #include <string>
 namespace {
 const char* kKernelNames[LKK_COUNT] = {"k_depth_stats", "k_sample_interp", "k_relpos_fwd", "k_decode_fwd", "k_composite",
-                                       "k_composite_bwd", "k_decode_bwd", "k_relpos_bwd", "k_interp_bwd", "k_rays_bwd", "k_wgrad", "k_feat_gather"};
+                                       "k_composite_bwd", "k_decode_bwd", "k_relpos_bwd", "k_interp_bwd", "k_rays_bwd", "k_wgrad", "k_feat_gather", "k_decode_bwd_track"};
 struct ProfState {
     bool on = false;
     bool enabled[LKK_COUNT] = {};

@@ -51,7 +51,7 @@ __device__ __forceinline__ void interp_bwd_block(const LkInterpBwdArgs& a, int b
                 part += dcc.x * c.x + dcc.y * c.y + dcc.z * c.z + dcc.w * c.w;
             }
         }
-        part = lk_sum8(part);
+        part = lk_sum8<true>(part);
         if (color && relpos && a.dw_rel && has) part += a.dw_rel[(size_t)pidx * LK_K + j];
         dwn[j] = part;
     }
@@ -391,7 +391,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     //            hidden vector Hbar [P][128] and the per-sample weight sum are needed (8x fewer rows, no hid rows)
     if (want_w) {
         float wsum = wgt;
-        wsum = lk_sum8(wsum);
+        wsum = lk_sum8<true>(wsum);
         if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
     }
     // ---- d hid = (W2^T d out) * softplus'(hid), block by block IN PLACE of hid (64 fewer live registers)
@@ -419,7 +419,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     float sred = wgt * hid[nb][4 * g + tt];
-                    sred = lk_sum8(sred);
+                    sred = lk_sum8<true>(sred);
                     v[tt] = sred;
                 }
                 if (live && nb_i == 0)
@@ -510,9 +510,9 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     if (want_p) {
         // both halves of a row, then the 8 neighbour rows of the sample; d p = - d (x_I - p)
         dax += __shfl_xor(dax, 32); day += __shfl_xor(day, 32); daz += __shfl_xor(daz, 32);
-        dax = lk_sum8(dax);
-        day = lk_sum8(day);
-        daz = lk_sum8(daz);
+        dax = lk_sum8<true>(dax);
+        day = lk_sum8<true>(day);
+        daz = lk_sum8<true>(daz);
         if (live && h == 0 && nb_i == 0) *reinterpret_cast<float4*>(a.dp_rel + (size_t)sp * 4) = make_float4(-dax, -day, -daz, 0.0f);
     }
 }
@@ -616,7 +616,7 @@ __device__ __forceinline__ u32x4 rpf_operand(const uint16_t* __restrict__ img, i
 
 // WG = false (LK_FLAG_EMBED_GRADS_ONLY: the MLP's matrices are frozen, only the Fourier matrix and the feature rows get gradients): no
 // LDS images, no linear1 blocks, no per-sample Hbar / weight-sum rows, no barriers - the same d x / d feature / d B arithmetic.
-template <bool WG>
+template <bool WG, bool F16>     // F16: half feature tables, a template as in relpos_bwd_wave (the run-time branch cost ~100 instructions of moves per tile)
 __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, int sample0, int P_live, float* __restrict__ part,
                                                       uint16_t* __restrict__ stage_wg, int w, f32x16 (&acc)[2]) {
     const int lane = lk_opaque(lk_lane());            // per tile: see lk_opaque
@@ -641,7 +641,6 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
     const float* __restrict__ W = a.W;
     const u32x4* __restrict__ FH = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;
     const size_t frow = (size_t)idx * LK_C;
-    const bool f16 = (a.flags & LK_FLAG_FEATS_F16) != 0;
     uint16_t* __restrict__ stage = stage_wg + w * RPF_STAGE_HALVES;
     uint16_t* __restrict__ xt_hi = stage;
     uint16_t* __restrict__ xt_lo = stage + RPF_XU * 32;
@@ -657,7 +656,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
 #pragma unroll
             for (int t = 0; t < 4; ++t) x0[4 * g + t] = rp_embed_unit(W + R_EB, u0 + t, a0, a1, a2);
         } else {
-            const float4 v = lk_feat4(a.col_feats, f16, frow + (u0 - ER));
+            const float4 v = lk_feat4(a.col_feats, F16, frow + (u0 - ER));
             x0[4 * g] = v.x; x0[4 * g + 1] = v.y; x0[4 * g + 2] = v.z; x0[4 * g + 3] = v.w;
         }
     }
@@ -666,7 +665,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
     for (int g = 0; g < 3; ++g) {
         const int u0 = 32 + 8 * g + 4 * h;
         if (u0 < KR) {
-            const float4 v = lk_feat4(a.col_feats, f16, frow + (u0 - ER));
+            const float4 v = lk_feat4(a.col_feats, F16, frow + (u0 - ER));
             x1[4 * g] = v.x; x1[4 * g + 1] = v.y; x1[4 * g + 2] = v.z; x1[4 * g + 3] = v.w;
         }
     }
@@ -717,7 +716,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
         dout[4 * g] = v.x * wsc; dout[4 * g + 1] = v.y * wsc; dout[4 * g + 2] = v.z * wsc; dout[4 * g + 3] = v.w * wsc;
     }
     if (WG) {   // linear2 is reduced per SAMPLE (see relpos_bwd_wave): weight sum and weighted hidden vector
-        const float wsum = lk_sum8(wgt);
+        const float wsum = lk_sum8<true>(wgt);
         if (live && h == 0 && nb_i == 0) a.w_sum[sp] = wsum;
     }
     // ---- d hid = (W2^T d out) * softplus'(hid), block by block in place of hid
@@ -739,7 +738,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
             for (int g = 0; g < 4; ++g) {
                 float v[4];
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) v[tt] = lk_sum8(wgt * hid[nb][4 * g + tt]);
+                for (int tt = 0; tt < 4; ++tt) v[tt] = lk_sum8<true>(wgt * hid[nb][4 * g + tt]);
                 if (live && nb_i == 0)
                     *reinterpret_cast<float4*>(a.hbar + (size_t)sp * 128 + nb * 32 + 8 * g + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -821,7 +820,7 @@ __device__ __forceinline__ void relpos_bwd_wave_fused(const LkRelposBwdArgs& a, 
         }
 }
 
-template <bool WG>
+template <bool WG, bool F16>
 __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) {
     __shared__ float s_part[4][32];
     __shared__ __attribute__((aligned(16))) uint16_t s_stage[WG ? 4 * RPF_STAGE_HALVES : 8];
@@ -840,7 +839,7 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd_fused(LkRelposBwdArgs a) 
     // every wave runs every tile of the workgroup (barriers inside); rows past the end are dead lanes with weight 0
     const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;       // the rays without a reading sit behind the prefix
     for (int t = (int)blockIdx.x; t * 16 < P_live; t += (int)gridDim.x)
-        relpos_bwd_wave_fused<WG>(a, (t * 4 + w) * 4, P_live, s_part[w], s_stage, w, acc);
+        relpos_bwd_wave_fused<WG, F16>(a, (t * 4 + w) * 4, P_live, s_part[w], s_stage, w, acc);
     __syncthreads();
     if (threadIdx.x < 32)
         a.part_br[(size_t)blockIdx.x * 32 + threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] +
@@ -1353,8 +1352,14 @@ int lk_relpos_bwd_parts(int P) { const int n = lk_cdiv(lk_cdiv(P, 4), 4); return
 int lk_launch_relpos_bwd(const LkRelposBwdArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_RELPOS_BWD, st);
     const int waves = lk_cdiv(a.P, 4);
-    if (lk_relpos_fused(a.flags) && (a.flags & LK_FLAG_EMBED_GRADS_ONLY)) hipLaunchKernelGGL(k_relpos_bwd_fused<false>, dim3(lk_relpos_bwd_parts(a.P)), dim3(256), 0, st, a);
-    else if (lk_relpos_fused(a.flags)) hipLaunchKernelGGL(k_relpos_bwd_fused<true>, dim3(lk_relpos_bwd_parts(a.P)), dim3(256), 0, st, a);
+    if (lk_relpos_fused(a.flags)) {
+        const bool wg = !(a.flags & LK_FLAG_EMBED_GRADS_ONLY), f16 = (a.flags & LK_FLAG_FEATS_F16) != 0;
+        const dim3 grid(lk_relpos_bwd_parts(a.P));
+        if (wg && f16) hipLaunchKernelGGL((k_relpos_bwd_fused<true, true>), grid, dim3(256), 0, st, a);
+        else if (wg) hipLaunchKernelGGL((k_relpos_bwd_fused<true, false>), grid, dim3(256), 0, st, a);
+        else if (f16) hipLaunchKernelGGL((k_relpos_bwd_fused<false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_relpos_bwd_fused<false, false>), grid, dim3(256), 0, st, a);
+    }
     else if (a.flags & LK_FLAG_FEATS_F16) hipLaunchKernelGGL(k_relpos_bwd<true>, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_relpos_bwd<false>, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;
@@ -1367,7 +1372,7 @@ int lk_launch_dw2_hbar(const LkRelposBwdArgs& a, float* dw2_part, hipStream_t st
 }
 int lk_occupancy_relpos_bwd_fused() {
     int n = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_relpos_bwd_fused<true>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_relpos_bwd_fused<true, false>, 256, 0);
     return n;
 }
 int lk_occupancy_wgrad() {

@@ -328,20 +328,27 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float lk_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
+// PIN: an empty asm behind the last add keeps it beside its DPP move.  Where the consumer sits in a one-lane branch the compiler otherwise sinks
+// the add into the branch, and the step is mov 0 + mov_dpp + add instead of ONE add_dpp (rel-pos backward kernels: 128 instructions per tile);
+// where the sums feed straight-line code (k_decode_bwd) the pin only costs hazard nops - chosen per call site.
+template <bool PIN = false>
 __device__ __forceinline__ float lk_half_wave_sum(float v) {
     v += lk_dpp<0xB1, 0xF>(v);          // quad_perm [1,0,3,2]
     v += lk_dpp<0x4E, 0xF>(v);          // quad_perm [2,3,0,1]
     v += lk_dpp<0x141, 0xF>(v);         // row_half_mirror: the other quad of the 8-group
     v += lk_dpp<0x140, 0xF>(v);         // row_mirror: the other 8-group of the row
     v += lk_dpp<0x142, 0xA>(v);         // row_bcast15 into rows 1 and 3
+    if (PIN) asm("" : "+v"(v));
     return v;
 }
 
 // sum over the 8 lanes of an aligned 8-group (the 8 neighbour rows of a sample): every lane gets the total
+template <bool PIN = false>
 __device__ __forceinline__ float lk_sum8(float v) {
     v += lk_dpp<0xB1, 0xF>(v);
     v += lk_dpp<0x4E, 0xF>(v);
     v += lk_dpp<0x141, 0xF>(v);
+    if (PIN) asm("" : "+v"(v));
     return v;
 }
 // 64-bit value of the partner lane in DPP pairing `CTRL` (quad swaps and the row mirrors are perfect matchings between

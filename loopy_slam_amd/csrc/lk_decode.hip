@@ -512,7 +512,7 @@ __device__ __forceinline__ void relpos_fwd_wave(const LkRelposArgs& a, int sampl
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float s = wgt * out[0][4 * g + t];
-            s = lk_sum8(s);
+            s = lk_sum8<true>(s);
             v[t] = s;
         }
         if (live && nb_i == 0) {

@@ -4,7 +4,7 @@
 
 // ---- optional per-kernel timing with HIP events on the launch stream (lk_profile_begin / lk_profile_end)
 enum LkKernelId { LKK_DEPTH_STATS = 0, LKK_SAMPLE_INTERP, LKK_RELPOS_FWD, LKK_DECODE_FWD, LKK_COMPOSITE, LKK_COMPOSITE_BWD,
-                  LKK_DECODE_BWD, LKK_RELPOS_BWD, LKK_INTERP_BWD, LKK_RAYS_BWD, LKK_WGRAD, LKK_FEAT_SCATTER, LKK_COUNT };
+                  LKK_DECODE_BWD, LKK_RELPOS_BWD, LKK_INTERP_BWD, LKK_RAYS_BWD, LKK_WGRAD, LKK_FEAT_SCATTER, LKK_DECODE_BWD_TRACK, LKK_COUNT };
 void lk_prof_before(int kid, hipStream_t st);
 void lk_prof_after(int kid, hipStream_t st);
 struct LkProfScope {

@@ -144,7 +144,7 @@ def test_mlp_kernels_keep_their_register_budget():
     budget = {'_Z12k_decode_bwdILb1ELb0ELb1EEv15LkDecodeBwdArgsi': 168,     # mapper form: three workgroups per unit
               '_Z12k_decode_fwdILb0EEv12LkDecodeArgsi': 168,
               '_Z12k_relpos_fwd12LkRelposArgs': 168,
-              '_Z18k_relpos_bwd_fusedILb1EEv15LkRelposBwdArgs': 256,     # two per unit (LDS-bound anyway)
+              '_Z18k_relpos_bwd_fusedILb1ELb0EEv15LkRelposBwdArgs': 256,     # two per unit (LDS-bound anyway)
               '_Z7k_wgradILb1EEv11LkWgradArgs': 256}
     for name, cap in budget.items():
         assert name in by, name
