@@ -43,9 +43,10 @@ def _sync(eng):
 class TreeRender:
     """The oracle's render over a fixed cloud with its KD-tree neighbour search (hotpath.knn_tree: tree proposal re-ranked in fp32)."""
 
-    def __init__(self, pos, rel_pos, near=0.98, far=1.02, exposure=False):
+    def __init__(self, pos, rel_pos, near=0.98, far=1.02, exposure=False, exact=False):
         from scipy.spatial import cKDTree
         self.pos = pos
+        self.exact = exact                  # hotpath.knn_exact (the contract itself, O(P N)) instead of the tree: diagnosis of a disagreement
         self.tree = cKDTree(pos.numpy().astype(np.float64))
         self.cfg = H.RenderCfg(S=5, near_surface=near, far_surface=far, near_end=0.3, coef=0.1, k=8, min_nn=2, radius_query=0.08,
                                rel_pos=rel_pos, exposure=exposure)
@@ -55,7 +56,7 @@ class TreeRender:
         z, _ = H.sample_z(gd, c.near_surface, c.far_surface, c.near_end, c.S)
         p = H.sample_points(ro.detach(), rd.detach(), z).numpy()
         r2 = np.float32(c.radius_query ** 2) if r2_ray is None else r2_ray.float().reshape(-1, 1).repeat(1, c.S).reshape(-1).numpy()
-        kn = H.knn_tree(self.pos.numpy(), p, 8, r2, tree=self.tree)
+        kn = H.knn_exact(self.pos.numpy(), p, 8, r2) if self.exact else H.knn_tree(self.pos.numpy(), p, 8, r2, tree=self.tree)
         return H.render_batch(c, ro, rd, gd, self.pos, geo, col, W, stage, tracker=tracker, r2_ray=r2_ray, affine=affine,
                               color_sigmoid=color_sigmoid, knn=kn)
 
