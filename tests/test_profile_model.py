@@ -1,0 +1,51 @@
+"""The roofline bookkeeping of bench.py (loopy_slam_amd/profile.py) on the CPU: the work model per timer name adds up to the step's algorithmic
+FLOPs, the decoder backward's two names (mapper / tracker launches - two kernels in rocprofv3's table) carry the launches and the work of their
+own iterations only, and the dominant-kernel rule is stable against the run-to-run scatter that once flipped it."""
+import pytest
+
+from loopy_slam_amd import profile, workload
+
+
+@pytest.mark.parametrize('mk', [workload.Budget, workload.Budget.tum, workload.Budget.scannet])
+def test_work_model_adds_up(mk):
+    b = mk()
+    w = profile.work_per_step(b)
+    assert profile.step_flops(b) == pytest.approx(sum(v['flops'] for v in w.values()))
+    Pm, Pt = b.map_rays * profile.S, b.track_rays * profile.S
+    n_col = b.map_iters - b.map_geo_iters
+    M = profile.MAC
+    # decoder backward: mapper launches and tracker launches under their own names, nothing counted twice
+    assert w['k_decode_bwd']['launches'] == b.map_iters and w['k_decode_bwd_track']['launches'] == b.track_iters
+    assert w['k_decode_bwd']['flops'] == pytest.approx(2.0 * (b.map_geo_iters * Pm * M['dec_bwd_geo'] + n_col * Pm * (M['dec_bwd_geo'] + M['dec_bwd_col'])))
+    trk = w['k_decode_bwd_track']
+    assert trk['flops'] == pytest.approx(2.0 * b.track_iters * Pt * (M['dec_bwd_geo'] + M['dec_bwd_col'] + M['dec_bwd_track_extra']))
+    assert sum(trk['flops_by_path'].values()) == pytest.approx(trk['flops'])
+    for name, v in w.items():
+        assert v['launches'] > 0 and (v['flops'] > 0 or v['bytes'] > 0), name
+        if v.get('flops_by_path'):
+            assert sum(v['flops_by_path'].values()) == pytest.approx(v['flops']), name
+        assert name in profile.MFMA_PATH or v['flops'] == 0, name
+
+
+def test_dominant_kernel_rule():
+    # the bench step as the timer reports it (profiles/r5_bench.json, kernel_ms_per_step): k_wgrad leads the mapper's decoder backward by a wide
+    # margin once the tracker's launches have their own name ...
+    k = {'k_wgrad': dict(calls=36, total_ms=3.99), 'k_relpos_bwd': dict(calls=76, total_ms=3.70), 'k_decode_fwd': dict(calls=100, total_ms=3.59),
+         'k_decode_bwd': dict(calls=60, total_ms=2.72), 'k_decode_bwd_track': dict(calls=40, total_ms=1.23)}
+    assert profile.dominant_kernel(k) == 'k_wgrad'
+    # ... and within 3 % the longer average launch decides, whichever way the scatter went
+    for a, b in ((3.99, 4.05), (4.05, 3.99)):
+        k2 = dict(k, k_wgrad=dict(calls=36, total_ms=a), k_relpos_bwd=dict(calls=76, total_ms=b))
+        assert profile.dominant_kernel(k2) == 'k_wgrad'
+    assert profile.dominant_kernel({}) is None
+
+
+def test_roofline_prices_each_form_on_its_own_pieces():
+    b = workload.Budget()
+    w = profile.work_per_step(b)
+    # one second of each: the mapper's form on fp16 pieces (three products per fp32 product), the tracker's geometry role on bf16 pieces (six)
+    for name in ('k_decode_bwd', 'k_decode_bwd_track'):
+        r = profile.roofline({name: dict(calls=w[name]['launches'], total_ms=1000.0)}, b, name)
+        assert r is not None and r['kernel'] == name and 0 < r['frac'] < 1
+    rm = profile.roofline({'k_decode_bwd': dict(calls=w['k_decode_bwd']['launches'], total_ms=1.0)}, b, 'k_decode_bwd')
+    assert rm['peak'] == pytest.approx(profile.PEAK_F32_VIA_F16X3_TFLOPS, rel=1e-6) or rm['bound'] == 'hbm'
