@@ -525,6 +525,10 @@ int lk_profile_end(char* buf, int cap);
  * registers and LDS of the loaded code objects (hipOccupancyMaxActiveBlocksPerMultiprocessor): out[0..4] = k_decode_fwd,
  * k_decode_bwd (mapper form), k_relpos_fwd, k_relpos_bwd_fused, k_wgrad.  Needs a device. */
 int lk_debug_occupancy(int32_t out[5]);
+/* Test hook: every weight-gradient launch forked onto the library's side stream is preceded there by a kernel that spins for `us`
+ * microseconds (0 = off, the default) - a missing ordering between the side stream and the launch stream then fails deterministically
+ * instead of by timing (tests/test_split_step_order.py).  Results must not depend on it. */
+int lk_debug_side_delay(int32_t us);
 
 #ifdef __cplusplus
 }

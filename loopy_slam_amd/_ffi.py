@@ -188,6 +188,7 @@ class LoopyLib:
             ('lk_set_serial', [C.c_int32], C.c_int),
             ('lk_streams_init', [], C.c_int),
             ('lk_debug_occupancy', [C.POINTER(C.c_int32)], C.c_int),
+            ('lk_debug_side_delay', [C.c_int32], C.c_int),
             ('lk_track_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
             ('lk_map_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
             ('lk_map_work_nbr_idx', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),

@@ -157,7 +157,7 @@ static int check_desc(const lk_render_desc* d, const char* who) {
 // rows of the batch counting-sorted by point for the feature-gradient gather (k_seg_count .. k_seg_place, lk_bwd2.hip): on the
 // second stream when there is one (it needs nothing but the neighbour indices), the caller's stream waits for `link` later
 namespace { struct SideStream; SideStream& side_stream(); }
-static void lk_wait_side_join(hipStream_t st);       // `st` waits for the weight-gradient stream's last join event (defined behind SideStream)
+static int lk_wait_side_join(hipStream_t st);        // `st` waits for the weight-gradient stream's last join event (defined behind SideStream)
 static void seg_args(const lk_render_desc* d, int P, LkFeatScatterArgs& fs);
 static int seg_sort_async(const lk_render_desc* d, int P, bool counted, hipStream_t st);
 
@@ -249,7 +249,9 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         // split step of the iteration before (LkBwdExtra::split_reduce): the colour trunk's stepped weights and fragments come from the
         // weight-gradient stream - first needed here; the interpolation and the rel-pos MLP above read rows, the blob's other spans and
         // the rel-pos fragments, which the launch stream itself stepped and repacked
-        lk_wait_side_join(st);
+        // (a correctness dependency ACROSS calls since the split step: a failed wait must not let the decoder read half-written fragments)
+        const int rcj = lk_wait_side_join(st);
+        if (rcj != LK_OK) return rcj;
     }
     if (!fuse_small) lk_launch_decode_fwd(da, st);
 
@@ -304,10 +306,22 @@ SideStream& side_stream() {
 }
 }  // namespace
 
-static void lk_wait_side_join(hipStream_t st) {
+static int lk_wait_side_join(hipStream_t st) {
     SideStream& s = side_stream();
-    if (s.ok) (void)hipStreamWaitEvent(st, s.join, 0);
+    // the caller skipped the trunk's repack and copy-back because a split step recorded `join`: without the side stream that state cannot exist
+    LK_REQUIRE(s.ok, "lk_render_fwd: a split step is pending but the weight-gradient stream is gone");
+    LK_HIP_TRY(hipStreamWaitEvent(st, s.join, 0));
+    return LK_OK;
 }
+// Test hook (tests/test_split_step_order.py): every weight-gradient launch that is forked onto the side stream is preceded there by a kernel
+// that spins for `us` microseconds - the side stream then trails the launch stream by that much, which turns any missing ordering between
+// the two (round 5: iteration it's k_wgrad against iteration it + 1's c_col writes) from a timing accident into a deterministic failure.
+namespace { int g_side_delay_us = 0; }
+__global__ void k_spin_us(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int lk_debug_side_delay(int32_t us) { g_side_delay_us = us > 0 ? us : 0; return LK_OK; }
 extern "C" int lk_set_serial(int32_t on) { g_serial = on ? 1 : 0; return LK_OK; }
 // Creates the library's two streams NOW instead of at their first use.  The runtime hands its few hardware queues to streams as they are
 // created: a process that first creates dozens of other streams (torch's stream pool comes into being with the first collective of a
@@ -530,6 +544,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         wa.n_jobs = nj; wa.chunk = 0; wa.part = S0 + L.wg_part;
         wa.h16 = (flags & LK_FLAG_UNIT_LOSS_GRADS) && !gr ? 1 : 0;
         wa.live_rays = ex ? ex->live_rays : nullptr; wa.S = d->S; wa.dscale = ex ? ex->dscale : nullptr;
+        if (forked && g_side_delay_us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, wst, (long long)g_side_delay_us * 100);   // wall_clock64: 100 MHz
         lk_launch_wgrad(wa, P, wst, defer ? &wdef : nullptr);
         if (split) {
             // the trunk's half of the step, right behind its weight gradients on their stream: tile sums + fc_c products with the Adam rider
@@ -632,7 +647,11 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
             lk_launch_wgrad(wr, 8 * P, wst);
         }
     }
-    if (forked) { (void)hipEventRecord(ss.join, wst); if (!split) (void)hipStreamWaitEvent(st, ss.join, 0); }
+    if (forked) {
+        // (since the split step the join orders the NEXT call's decoder behind this call's trunk step: its failure is an error, not a lost overlap)
+        LK_HIP_TRY(hipEventRecord(ss.join, wst));
+        if (!split) LK_HIP_TRY(hipStreamWaitEvent(st, ss.join, 0));
+    }
     if (defer) {
         float* G = d->g_weights;
         LkBwdReduceArgs r;

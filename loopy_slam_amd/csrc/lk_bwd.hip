@@ -536,10 +536,11 @@ int lk_launch_composite_bwd(const LkCompositeBwdArgs& a, hipStream_t st) {
     return LK_OK;
 }
 int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
-    // two timer names, as rocprofv3 lists two kernels: the <., ., true> instantiations (mapper iterations: both decoder roles on fp16 pieces)
-    // and the <., ., false> ones (launches with ray gradients or unbounded loss gradients: the tracker's) - "k_decode_bwd_track"
-    const bool gh16_form = (a.flags & LK_FLAG_UNIT_LOSS_GRADS) && !(a.flags & LK_FLAG_GRAD_RAYS);
-    LkProfScope prof_(gh16_form ? LKK_DECODE_BWD : LKK_DECODE_BWD_TRACK, st);
+    // two timer names: launches WITH ray gradients (the tracker's, and a BA-mode mapper's) are "k_decode_bwd_track", launches without
+    // them (the mapper's) "k_decode_bwd" - whatever pieces they run on: profile.work_per_step books every mapping iteration under the
+    // mapper's name, and a mapper launch without unit-scale loss gradients (exposure encoding with the rel-pos MLP, a standalone
+    // lk_render_bwd) used to land under the tracker's (round-5 advisor)
+    LkProfScope prof_((a.flags & LK_FLAG_GRAD_RAYS) ? LKK_DECODE_BWD_TRACK : LKK_DECODE_BWD, st);
     const int tiles = lk_cdiv(a.P, 32);
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
     // fp16 pieces only where the COLOUR loss gradients have unit scale (see decode_bwd_col_wg): the mapper's L1 sums, and the tracker's

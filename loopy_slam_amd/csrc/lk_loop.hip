@@ -264,7 +264,7 @@ TrackWork track_work(int64_t R, int64_t S, int64_t iters) {
     w.total = o;
     return w;
 }
-struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, n_live, frame_id, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, w_next, loss_rows, total; };
+struct MapWork { int64_t rays_o, rays_d, gt_depth, gt_color, r2_ray, thr, n_live, frame_id, z, nbr_idx, nbr_w, nbr_count, seg_list, seg_total, seg_rank, w_next, loss_rows, c_col_alt, total; };
 MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     MapWork w;
     int64_t o = 0;
@@ -287,7 +287,14 @@ MapWork map_work(int64_t R, int64_t S, int64_t iters) {
     w.seg_total = o; o += al4(iters);
     w.seg_rank = o; o += al4(P * LK_K * LK_SEG_BATCH);        // the rows of up to LK_SEG_BATCH iterations are sorted per launch
     w.w_next = o; o += al4(lk_weight_blob_floats());          // the decoder blob as stepped by the step rider (LkStepRider::w_next)
-    w.loss_rows = o; o += iters * 4 * ((P + 31) / 32);        // the loss row's terms per decoder-backward tile (LK_COMPOSITE_IN_BWD): [iters][tiles][4]
+    w.loss_rows = o; o += al4(iters * 4 * ((P + 31) / 32));   // the loss row's terms per decoder-backward tile (LK_COMPOSITE_IN_BWD): [iters][tiles][4]
+    // second interpolated-colour-feature buffer [P][32]: odd iterations of the call write this one, even ones lk_render_desc::c_col.  The
+    // weight-gradient launch of a SPLIT step (LkBwdExtra::split_reduce) streams c_col as the auxiliary columns of its fc_c jobs on the side
+    // stream while the launch stream is already in the next iteration, whose interpolation / rel-pos MLP writes c_col BEFORE the join in
+    // front of its decoder launch - with one buffer that overwrite raced with k_wgrad (round-5 advisor: the TUM budget, no rel-pos MLP,
+    // rewrites it a few microseconds into the next iteration).  With two, iteration it + 2 is the next writer of iteration it's buffer, and
+    // it starts behind the join of iteration it + 1, which is behind iteration it's k_wgrad on the side stream.
+    w.c_col_alt = o; o += al4(P * LK_C);
     w.total = o;
     return w;
 }
@@ -710,6 +717,7 @@ extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_e
             if (rd.r2_ray) rd.r2_ray = W0 + wk.r2_ray + (size_t)it * R;
             rd.z = W0 + wk.z + (size_t)it * Pn; rd.nbr_count = reinterpret_cast<int32_t*>(W0 + wk.nbr_count) + (size_t)it * Pn;
             rd.nbr_idx = reinterpret_cast<int32_t*>(W0 + wk.nbr_idx) + (size_t)it * Pn * LK_K; rd.nbr_w = W0 + wk.nbr_w + (size_t)it * Pn * LK_K;
+            if ((goff + it) & 1) rd.c_col = W0 + wk.c_col_alt;          // see MapWork::c_col_alt: the split step's k_wgrad may still be reading the other one
             const int ck = chunk_of(it);
             if ((phases & 1) && it == chunk_start(ck)) {     // entering chunk ck: enqueue chunk ck + 1, then wait for chunk ck
                 const int rc = enqueue_chunk(ck + 1);

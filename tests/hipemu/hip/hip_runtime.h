@@ -250,6 +250,9 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}
 // compiler-level wave barrier on the device; here the point where every lane's LDS accesses so far have happened
 static inline void __builtin_amdgcn_s_sleep(int) { hipemu::spin_yield(); }
 static inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_ballot(true); }
+// 100 MHz wall clock of the device (k_spin_us, the side-stream delay test hook): the emulator's streams run in order on one host thread,
+// so a delay has nothing to reorder - it returns at once
+static inline long long wall_clock64() { static long long t = 0; return t += (1ll << 40); }
 
 // ---- math (round-to-nearest, never contracted)
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }

@@ -379,6 +379,14 @@ def test_map_call_at_bench_size():
     run_map_case(make_engine('hip'), 'map-replica-5000x60', 100_000, 5000, 60, 24, True)
 
 
+def test_map_call_tum_budget_without_relpos():
+    """(b') the TUM mapping budget's ray count with the plain colour model (no rel-pos MLP): 6 'geometry' + 14 'color' iterations x 10 000
+    rays.  Without the rel-pos launch the next iteration's interpolation rewrites the interpolated colour features right at its start -
+    the buffer the split step's k_wgrad (still running on the side stream) streams as its fc_c columns (round-5 advisor; the fix and the
+    deterministic form of the check: tests/test_split_step_order.py)."""
+    run_map_case(make_engine('hip'), 'map-tum-10000x20', 100_000, 10000, 20, 6, False, window=10)
+
+
 def test_track_call_tum_model_gradient_pool():
     """(c) the TUM / ScanNet tracker: 5 000 rays per iteration from the gradient-pixel pool, one leaf pose tensor (candidate AFTER the step),
     per-pixel dynamic query radius, plain colour model - 10 iterations."""
