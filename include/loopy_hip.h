@@ -38,6 +38,7 @@ extern "C" {
 #define LK_ERR_ARG (-1)
 #define LK_ERR_HIP (-2)
 #define LK_ERR_STATE (-3)
+#define LK_ERR_RANGE (-4)   /* an operand left the range of the split fp16 products (see lk_status_peek) */
 
 typedef struct lk_knn_s* lk_knn_t;
 
@@ -90,6 +91,27 @@ int64_t lk_weight_blob_floats(void);
  * refresh it after every change of the master blob (optimiser step, load). */
 int64_t lk_weight_frag_floats(void);
 int lk_weights_repack(const float* blob, float* frag, void* stream);
+/* The same, then `stream` is synchronised and the range check of the repack (LK_STATUS_WEIGHT_RANGE below) is reported: LK_ERR_RANGE with
+ * the message in lk_last_error() when a matrix entry is non-finite or |w| >= 32768.  For the places where weights enter from outside
+ * (checkpoint load, DecoderBlob.pack); the per-step repacks stay asynchronous and report through the sticky status word. */
+int lk_weights_repack_checked(const float* blob, float* frag, void* stream);
+
+/* ---------------------------------------------------------------- operand-range status (sticky)
+ * The decoders' fp32 products run as split fp16 products on the 16-bit matrix pipe: exact to fp32 class for operands
+ * below fp16's ceiling, SATURATING above it - the reference (src/conv_onet/models/decoder.py:513-546, plain fp32) has no such ceiling.
+ * The library therefore keeps one status word (host-mapped memory, written by the kernels, read by the host without synchronisation):
+ *   LK_STATUS_WEIGHT_RANGE  a repack (lk_weights_repack, the repack riders of lk_map_frame) met a matrix entry that is non-finite or
+ *                           has |w| >= 32768;
+ *   LK_STATUS_ACT_RANGE     a forward launched with LK_FLAG_CHECK_RANGE met an operand (interpolated feature, activation) that is
+ *                           non-finite or has |x| >= 65504.
+ * The word is STICKY: once a bit is set every lk_render_fwd / lk_render_bwd / lk_track_frame / lk_map_frame / lk_weights_repack call
+ * fails with LK_ERR_RANGE (nothing is launched) until lk_status_clear().  A bit set by a launch that is still running shows at a later
+ * call; lk_status_sync waits for `stream` first. */
+#define LK_STATUS_WEIGHT_RANGE 1u
+#define LK_STATUS_ACT_RANGE    2u
+int lk_status_peek(uint32_t* bits);
+int lk_status_sync(void* stream, uint32_t* bits);
+int lk_status_clear(void);
 
 /* ---------------------------------------------------------------- render forward / backward */
 #define LK_FLAG_STAGE_COLOR   (1u << 0)  /* NICER stage 'color' (else 'geometry': rgb = 0)          */
@@ -122,6 +144,8 @@ int lk_weights_repack(const float* blob, float* frag, void* stream);
                                            fix_color_decoder, the end-of-sequence refinement): no weight-gradient rows are written and no
                                            weight-gradient reduction is launched; the rest of g_weights is left untouched */
 
+#define LK_FLAG_CHECK_RANGE   (1u << 16) /* lk_render_fwd (debug): the decoder kernels test every operand they cut into fp16 pieces (interpolated
+                                           features, activations) and set LK_STATUS_ACT_RANGE when one is non-finite or >= 65504 in magnitude */
 #define LK_FLAG_GRAD_GEO_DECODER (1u << 15) /* lk_render_bwd, with LK_FLAG_GRAD_WEIGHTS: the geometry decoder's matrices and biases receive
                                            gradients too (mapping.fix_geo_decoder: False, Mapper.py:524-526; every reference config keeps
                                            them frozen and trains geo_decoder.embedder._B alone) - one more launch that redoes the 32-wide

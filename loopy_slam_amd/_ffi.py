@@ -31,6 +31,9 @@ FLAG_FEATS_F16 = 1 << 13
 FLAG_UNIT_LOSS_GRADS = 1 << 11
 FLAG_EMBED_GRADS_ONLY = 1 << 14
 FLAG_GRAD_GEO_DECODER = 1 << 15
+FLAG_CHECK_RANGE = 1 << 16
+STATUS_WEIGHT_RANGE, STATUS_ACT_RANGE = 1, 2
+ERR_RANGE = -4
 
 EXPOSURE_MAX_F = 32
 ADAM_MAX_SEG = 16
@@ -189,6 +192,10 @@ class LoopyLib:
             ('lk_streams_init', [], C.c_int),
             ('lk_debug_occupancy', [C.POINTER(C.c_int32)], C.c_int),
             ('lk_debug_side_delay', [C.c_int32], C.c_int),
+            ('lk_weights_repack_checked', [_fp, _fp, C.c_void_p], C.c_int),
+            ('lk_status_peek', [C.POINTER(C.c_uint32)], C.c_int),
+            ('lk_status_sync', [C.c_void_p, C.POINTER(C.c_uint32)], C.c_int),
+            ('lk_status_clear', [], C.c_int),
             ('lk_track_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
             ('lk_map_work_floats', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),
             ('lk_map_work_nbr_idx', [C.c_int32, C.c_int32, C.c_int32], C.c_int64),

@@ -19,6 +19,11 @@ from . import _ffi
 from ._ffi import RenderDesc, ptr
 
 
+import os as _os
+# LOOPY_CHECK_RANGE=1: every forward tests its fp16-piece operands (LK_FLAG_CHECK_RANGE; a few per cent of the decoder kernels' time)
+_CHECK_RANGE = _ffi.FLAG_CHECK_RANGE if _os.environ.get('LOOPY_CHECK_RANGE') == '1' else 0
+
+
 class Engine:
     """Library + device.  `lib=None` -> the in-tree gfx950 build on cuda:<current> (product path)."""
 
@@ -46,6 +51,20 @@ class Engine:
 
     def f32(self, x):
         return torch.as_tensor(x, dtype=torch.float32).to(self.device).contiguous()
+
+    # ---- operand-range status of the split fp16 products (include/loopy_hip.h: lk_status_peek).  The reference's decoder is plain fp32
+    # (src/conv_onet/models/decoder.py:513-546) and has no ceiling; here a weight >= 2^15 or (debug flag) an activation >= 65504 is
+    # REPORTED: every later library call fails with LK_ERR_RANGE until clear_status()
+    def status(self, sync=False):
+        bits = C.c_uint32(0)
+        if sync:
+            self.lib.check(self.lib.dll.lk_status_sync(self.stream, C.byref(bits)), 'lk_status_sync')
+        else:
+            self.lib.check(self.lib.dll.lk_status_peek(C.byref(bits)), 'lk_status_peek')
+        return int(bits.value)
+
+    def clear_status(self):
+        self.lib.check(self.lib.dll.lk_status_clear(), 'lk_status_clear')
 
 
 @dataclass
@@ -154,12 +173,15 @@ class DecoderBlob:
                 else:
                     v[:, :e['cols']] = t
         self.blob.copy_(host.to(self.eng.device))
-        return self.repack()
+        return self.repack(checked=True)
 
-    def repack(self):
-        """Refresh the fragment copy the kernels read (call after every change of `blob`)."""
-        self.eng.lib.check(self.eng.lib.dll.lk_weights_repack(ptr(self.blob), ptr(self.frag), self.eng.stream),
-                           'lk_weights_repack')
+    def repack(self, checked=False):
+        """Refresh the fragment copy the kernels read (call after every change of `blob`).
+        checked: weights entering from outside (pack = checkpoint load / construction) - waits for the repack and raises LoopyError if a
+        matrix entry is non-finite or |w| >= 32768, the ceiling of the forward's split fp16 products; the per-step repacks stay
+        asynchronous and report through the sticky status word (Engine.status)."""
+        fn = self.eng.lib.dll.lk_weights_repack_checked if checked else self.eng.lib.dll.lk_weights_repack
+        self.eng.lib.check(fn(ptr(self.blob), ptr(self.frag), self.eng.stream), 'lk_weights_repack')
         return self
 
     def unpack(self, flat=None):
@@ -231,7 +253,7 @@ def fill_desc(eng, cfg, st, rays_o, rays_d, gt_depth, knn, pos, geo_feats, col_f
               color_logits=False, save_act=False, stats_chunk=None, extra_flags=0, mapper_loss=None, z_given=None):
     d = RenderDesc()
     R = rays_o.shape[0]
-    flags = extra_flags
+    flags = extra_flags | _CHECK_RANGE
     if stage == 'color':
         flags |= _ffi.FLAG_STAGE_COLOR
     if tracker:

@@ -19,6 +19,50 @@ void lk_set_error(const char* fmt, ...) {
 }
 
 extern "C" int lk_version(void) { return LK_ABI_VERSION; }
+
+// ------------------------------------------------------------------ operand-range status word (loopy_hip.h)
+namespace {
+struct StatusWord { volatile unsigned* host = nullptr; unsigned* dev = nullptr; bool tried = false; };
+StatusWord& status_word() {
+    static StatusWord w;
+    if (!w.tried) {
+        w.tried = true;
+        void* h = nullptr; void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            memset(h, 0, 64);
+            w.host = static_cast<volatile unsigned*>(h); w.dev = static_cast<unsigned*>(d);
+        } else (void)hipGetLastError();          // no word: the checks are off (lk_status_peek says so), nothing else changes
+    }
+    return w;
+}
+}  // namespace
+unsigned* lk_status_dev() { return status_word().dev; }
+int lk_status_gate(const char* who) {
+    StatusWord& w = status_word();
+    const unsigned bits = w.host ? *w.host : 0u;
+    if (!bits) return LK_OK;
+    lk_set_error("%s: refused - an earlier launch left the range of the split fp16 products (status %u:%s%s); the results since then are not "
+                 "the reference's fp32 results.  lk_status_clear() after fixing the inputs", who, bits,
+                 (bits & LK_STATUS_WEIGHT_RANGE) ? " a decoder matrix entry is non-finite or |w| >= 32768" : "",
+                 (bits & LK_STATUS_ACT_RANGE) ? " a forward operand (feature / activation) is non-finite or |x| >= 65504" : "");
+    return LK_ERR_RANGE;
+}
+extern "C" int lk_status_peek(uint32_t* bits) {
+    LK_REQUIRE(bits != nullptr, "lk_status_peek: NULL bits");
+    StatusWord& w = status_word();
+    if (!w.host) { *bits = 0; lk_set_error("lk_status_peek: the status word could not be allocated - range checks are off"); return LK_ERR_STATE; }
+    *bits = *w.host;
+    return LK_OK;
+}
+extern "C" int lk_status_sync(void* stream_, uint32_t* bits) {
+    LK_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    return lk_status_peek(bits);
+}
+extern "C" int lk_status_clear(void) {
+    StatusWord& w = status_word();
+    if (w.host) *w.host = 0u;
+    return LK_OK;
+}
 extern "C" const char* lk_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ weight layout table
@@ -191,7 +235,10 @@ int lk_presample(const lk_render_desc* d, hipStream_t st, const LkPresampleCount
     return lk_launch_sample_interp(sa, st, 1);
 }
 
-extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) { return lk_render_fwd_impl(d, (hipStream_t)stream_, 0); }
+extern "C" int lk_render_fwd(const lk_render_desc* d, void* stream_) {
+    const int rcg = lk_status_gate("lk_render_fwd");
+    return rcg != LK_OK ? rcg : lk_render_fwd_impl(d, (hipStream_t)stream_, 0);
+}
 
 int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, const int32_t* live_rays, const LkRepackRider* repack, const LkTrackFinalArgs* pose,
                        const LkTrackLossArgs* comp, int* comp_tiles, bool join_side_before_decode) {
@@ -233,6 +280,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
     da.rays_o = d->rays_o; da.rays_d = d->rays_d; da.z = d->z;
     da.c_geo = d->c_geo; da.c_col = d->c_col; da.W = d->weights; da.Wfrag = d->weights_frag; da.affine = d->affine;
     da.raw = d->raw; da.act = d->act; da.live_rays = live_rays; da.tile_stride = 0;
+    da.status = (d->flags & LK_FLAG_CHECK_RANGE) ? lk_status_dev() : nullptr;
     if (comp_tiles) *comp_tiles = 0;
     const bool fuse_small = (skip & LK_FUSE_SMALL) && lk_relpos_decode_fusable(da);
     if (color && (d->flags & LK_FLAG_REL_POS)) {
@@ -242,6 +290,7 @@ int lk_render_fwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         ra.pos = d->pos; ra.col_feats = d->col_feats; ra.feats_f16 = (d->flags & LK_FLAG_FEATS_F16) ? 1 : 0; ra.live_rays = live_rays;
         ra.nbr_idx = d->nbr_idx; ra.nbr_w = d->nbr_w; ra.nbr_count = d->nbr_count;
         ra.W = d->weights; ra.Wfrag = d->weights_frag; ra.noise_col = d->noise_col; ra.c_col = d->c_col;
+        ra.status = da.status;
         if (fuse_small) lk_launch_relpos_decode_fwd(ra, da, st, comp, comp_tiles);
         else lk_launch_relpos_fwd(ra, st);
     }
@@ -393,7 +442,10 @@ static int seg_sort_async(const lk_render_desc* d, int P, bool counted, hipStrea
     return rc;
 }
 
-extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) { return lk_render_bwd_impl(d, (hipStream_t)stream_, 0, nullptr); }
+extern "C" int lk_render_bwd(const lk_render_desc* d, void* stream_) {
+    const int rcg = lk_status_gate("lk_render_bwd");
+    return rcg != LK_OK ? rcg : lk_render_bwd_impl(d, (hipStream_t)stream_, 0, nullptr);
+}
 
 LkBwdOffsets lk_bwd_offsets(int64_t P, uint32_t flags) {
     const BwdLayout L = bwd_layout(P, flags);

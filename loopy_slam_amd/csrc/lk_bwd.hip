@@ -115,7 +115,8 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     // (the colour trunk has no trainable Fourier matrix: with LK_FLAG_EMBED_GRADS_ONLY nothing here is a weight-gradient operand)
     const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0 && !(a.flags & LK_FLAG_EMBED_GRADS_ONLY);
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
-    const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128;            // layer-major: + LK_COL_LAYER(P, layer)
+    // the derivative mask softplus'(z_i) as the forward stored it (unorm16 pairs, this lane's 16 values contiguous): + LK_COL_SLAYER(P, layer)
+    const unsigned* act_col_s = reinterpret_cast<const unsigned*>(a.act + (size_t)a.P * LK_ACT_GEO_A) + (size_t)sp * 64 + 16 * w + 8 * h;
     const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128;
     float4 draw;
     if (a.ml_on) { float t0, t1, t2; draw = lk_map_draw(a.ml, sp, false, &t0, &t1, &t2); }
@@ -193,16 +194,16 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     f32x16 dc = lk_zero16(), de = lk_zero16();
     int buf = 0;
     // Split-bf16 products (lk_common.h::lk_mma6).  Loads and stores share one in-order counter, so what a layer needs
-    // right after its d y store - un = U_i^T blocks of the own units, av = saved a_i, wn = first four blocks of W_i^T for
+    // right after its d y store - un = U_i^T blocks of the own units, sv = the saved derivative mask, wn = first four blocks of W_i^T for
     // the own output block - is fetched BEFORE that store, at the end of the previous layer; blocks 4..7 come in line.
     constexpr int NPF = DEEP ? 8 : 4;
     Piece un[2], wn[NPF];
-    f32x16 av;
+    u32x4 sv0, sv1;
     auto prefetch = [&](int i) {
         const u32x4* ut = FB + PC::tr(15 + i);
 #pragma unroll
         for (int G = 0; G < 2; ++G) un[G] = PC::load(ut, 1, 2 * w + G, 0, lane);
-        av = ct_load32(act_col_a + LK_COL_LAYER(a.P, i) + w * 32, lane);
+        sv0 = *reinterpret_cast<const u32x4*>(act_col_s + LK_COL_SLAYER(a.P, i)); sv1 = *reinterpret_cast<const u32x4*>(act_col_s + LK_COL_SLAYER(a.P, i) + 4);
         if (i >= 1) {
             const u32x4* wt = FB + PC::tr(10 + i);
 #pragma unroll
@@ -220,7 +221,10 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) dy[q] = dh[q] * lk_softplus100_grad_from_out(av[q]);
+        for (int q = 0; q < 4; ++q) {
+            dy[2 * q] = dh[2 * q] * lk_unorm16_lo(sv0[q]); dy[2 * q + 1] = dh[2 * q + 1] * lk_unorm16_hi(sv0[q]);
+            dy[8 + 2 * q] = dh[8 + 2 * q] * lk_unorm16_lo(sv1[q]); dy[8 + 2 * q + 1] = dh[8 + 2 * q + 1] * lk_unorm16_hi(sv1[q]);
+        }
         // d y_i rows for the weight-gradient jobs (W_i and, through the auxiliary columns of job i, U_{i-1}: lk_kernels.h LkFcPost).
         // (Round 1 stored a register COPY of its rows, believing that the stores must not read registers the next product
         // overwrites.  The cause was elsewhere: the copy happened to stop the SLP vectoriser from turning d h = Wo^T d out into

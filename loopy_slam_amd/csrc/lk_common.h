@@ -41,6 +41,15 @@ void lk_set_error(const char* fmt, ...);
 
 static inline int lk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ------------------------------------------------------------------ operand-range status word (loopy_hip.h: lk_status_peek)
+unsigned* lk_status_dev();                  // device address of the word (host-mapped memory), or NULL if it could not be allocated
+int lk_status_gate(const char* who);        // LK_ERR_RANGE (+ message) while a bit is set, else LK_OK
+__device__ __forceinline__ void lk_status_raise(unsigned* status, unsigned bits) {
+    if (status) __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// fp16x3 operand ceiling: |x| < lim and finite (NaN fails the comparison)
+__device__ __forceinline__ bool lk_out_of_range(float x, float lim) { return !(fabsf(x) < lim); }
+
 // ------------------------------------------------------------------ neighbour grid (device resident)
 struct LkGrid {
     float ox, oy, oz;      // origin = min corner of the point AABB
@@ -116,6 +125,16 @@ __device__ __forceinline__ float lk_softplus100(float x) {
 // d softplus100 / dx expressed through the OUTPUT a = softplus100(x): sigmoid(100x) = 1 - exp(-100a)
 __device__ __forceinline__ float lk_softplus100_grad_from_out(float a) { return 1.0f - lk_exp2_raw(a * -144.26950408889634f); }
 __device__ __forceinline__ float lk_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// The colour trunk's SAVED derivative mask: softplus'(z_i) in [0, 1] as unorm16 (v_cvt_pknorm_u16_f32 packs two values per instruction),
+// |error| <= 2^-17 = 7.6e-6 absolute.  The backward needs a_i = softplus(z_i) for nothing but this factor (d y_i = d h_i softplus'(z_i));
+// the other way to drop the a_i rows - recovering a_i = h_i - (U_i c + u_i) from the h_i rows the weight gradients stream anyway - has
+// the same error (half an ulp of h_i times the factor 100 of d softplus' / d a) at the price of a 128 x 32 product per layer in the
+// backward.  Stored: 256 instead of 512 bytes per sample and layer (DESIGN.md §2 "activation scratch").
+__device__ __forceinline__ unsigned lk_pack_unorm16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(lo, hi));
+}
+__device__ __forceinline__ float lk_unorm16_lo(unsigned w) { return (float)(w & 0xffffu) * (1.0f / 65535.0f); }
+__device__ __forceinline__ float lk_unorm16_hi(unsigned w) { return (float)(w >> 16) * (1.0f / 65535.0f); }
 
 // sin / cos for |x| < ~1e5: n = rint(x * 2/pi); r = x - n*pi/2 by a 3-term Cody-Waite reduction with
 // fma (pi/2 = P1 + P2 + P3, P1 has 8 significant bits so n*P1 is exact), then the fdlibm minimax

@@ -40,6 +40,19 @@ __device__ __forceinline__ void ct_store_rows32(float* __restrict__ row, const f
         *reinterpret_cast<float4*>(row + 8 * g + 4 * h) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
 }
 
+// LK_FLAG_CHECK_RANGE (status != NULL, wave-uniform): a tile that is about to be cut into fp16 pieces (lk_split_cth) is tested against fp16's
+// ceiling - the pack-convert saturates silently there (loopy_hip.h: LK_STATUS_ACT_RANGE)
+// CHECK is a template parameter of the kernels: the test costs the default forward 8 registers otherwise (173 > the 168 of three workgroups
+// per compute unit); launches with the flag take the <.., true> instantiations (and never the fused tracker launch)
+template <bool CHECK>
+__device__ __forceinline__ void ct_check_range(const f32x16& t, unsigned* status) {
+    if (!CHECK || !status) return;
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bad = bad || lk_out_of_range(t[r], 65504.0f);
+    if (bad) lk_status_raise(status, LK_STATUS_ACT_RANGE);
+}
+
 // geometry embedding tile b (units 32b..32b+31 of sin((2*pi*p) @ B_g), B_g padded [3][96])
 __device__ __forceinline__ f32x16 geo_embed_tile(const float* __restrict__ B, int b, float a0, float a1, float a2, int lane) {
     const int h = lane >> 5;
@@ -118,6 +131,7 @@ __device__ __forceinline__ DecSample dec_sample(const LkDecodeArgs& a, int tile,
 }
 
 // ================= geometry decoder (hidden 32, relu): one wave = one 32-sample tile, registers only =================
+template <bool CHECK = false>
 __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile, int lane) {      // returns the occupancy of lane & 31's sample
     const DecSample d = dec_sample(a, tile, lane);
     const int h = d.h, sp = d.sp;
@@ -137,6 +151,7 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
         const f32x16 e2 = geo_embed_tile(W + G_EB, 2, a0, a1, a2, lane);
         eb[4] = lk_split_cth(e2, 0); eb[5] = lk_split_cth(e2, 1);
         const f32x16 cg = ct_load_rows32(a.c_geo + (size_t)sp * LK_C, true, lane);
+        ct_check_range<CHECK>(cg, a.status);
         cb[0] = lk_split_cth(cg, 0); cb[1] = lk_split_cth(cg, 1);
     }
     f32x16 acc[1], hh;
@@ -145,18 +160,18 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
 #pragma unroll
     for (int G = 0; G < 6; ++G) acc[0] = lk_mma3h(lk_fragh_load(FB + FM0_FWDH, 1, G, 0, lane), eb[G], acc[0]);
     layer_finish<1, false>(acc, FB + FM5_FWDH, W + G_U0 + a64(HG * CF), cb, act_geo, live, lane);
-    hh = acc[0];
+    hh = acc[0]; ct_check_range<CHECK>(hh, a.status);
     // layers 1, 2: 32 -> 32
     acc[0] = lk_rowvec_tile(W + G_B1, 0, lane);
     lk_gemm_h3<1, 2>(acc, FB + FM1_FWDH, 1, 0, 0, hh, 0, lane);
     layer_finish<1, false>(acc, FB + FM6_FWDH, W + G_U0 + G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 32 : nullptr, live, lane);
-    hh = acc[0];
+    hh = acc[0]; ct_check_range<CHECK>(hh, a.status);
     acc[0] = lk_rowvec_tile(W + G_B2, 0, lane);
     lk_gemm_h3<1, 2>(acc, FB + FM2_FWDH, 1, 0, 0, hh, 0, lane);
     layer_finish<1, false>(acc, FB + FM7_FWDH, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 64 : nullptr, live, lane);
-    hh = acc[0];
+    hh = acc[0]; ct_check_range<CHECK>(hh, a.status);
     // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
     acc[0] = lk_rowvec_tile(W + G_B3, 0, lane);
 #pragma unroll
@@ -164,7 +179,7 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
     lk_gemm_h3<1, 2>(acc, FB + FM3_FWDH, 1, 6, 0, hh, 0, lane);
     layer_finish<1, false>(acc, FB + FM8_FWDH, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 96 : nullptr, live, lane);
-    hh = acc[0];
+    hh = acc[0]; ct_check_range<CHECK>(hh, a.status);
     // layer 4
     acc[0] = lk_rowvec_tile(W + G_B4, 0, lane);
     lk_gemm_h3<1, 2>(acc, FB + FM4_FWDH, 1, 0, 0, hh, 0, lane);
@@ -210,7 +225,7 @@ __device__ __forceinline__ f32x16 ct_bias_lds(const float* __restrict__ v, int u
 // SOFTBAR (s_cnt: an LDS word, zero on entry): the four waves meet at a barrier of their own (lk_soft_barrier) instead of s_barrier - for
 // workgroups in which a fifth wave runs something else meanwhile (k_relpos_decode_fwd: the geometry decoder on wave 4)
 // s_raw (or NULL; wave 0 only reads it): the tile's colours are also left there as raw rows [32][4] (k_relpos_decode_fwd's composite epilogue)
-template <bool DEEP, bool SOFTBAR = false>
+template <bool DEEP, bool SOFTBAR = false, bool CHECK = false>
 __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
                                               u32x4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */,
                                               float (*s_bias)[128] /* [10][128] */, unsigned* s_cnt = nullptr, float* s_raw = nullptr) {
@@ -236,7 +251,8 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;      // fp16 forward fragments
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     // this sample's row of layer 0; layer L is LK_COL_LAYER(P, L) floats further (layer-major, lk_kernels.h)
-    float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128 : nullptr;
+    // (the derivative mask: 64 words per sample and layer; wave w, lane half h own words [16 w + 8 h, + 8) - a lane's 16 values are contiguous)
+    unsigned* act_col_s = save ? reinterpret_cast<unsigned*>(a.act + (size_t)a.P * LK_ACT_GEO_A) + (size_t)sp * 64 + 16 * w + 8 * h : nullptr;
     float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128 : nullptr;
     // embedding (40 units = blocks 0, 1 and a quarter of 2) and interpolated feature: B operands of two / five products, split once.
     // The forty sin / cos values are the same for the four waves: wave w evaluates register group g = w of block 0 (units 8 w + 4 h + t),
@@ -274,6 +290,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
             s_x[1][(2 * 2 + 1) * 64 + lane] = u32x4{lo0, lo1, 0u, 0u};
         }
         const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
+        ct_check_range<CHECK>(cc, a.status);
         cb[0] = lk_split_cth(cc, 0); cb[1] = lk_split_cth(cc, 1);
     }
     wg_barrier();                                   // the embedding pieces and s_bias are complete
@@ -317,10 +334,17 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         for (int G = 0; G < 3; ++G) acc = lk_mma3h((DEEP && fetched) ? we[G] : lk_fragh_load(fragb, 4, G, w, lane), eb[G], acc);
     };
     // bias + softplus + fc_c(c) for the wave's own 32-unit block, then ALL stores of the layer: saved a / h rows, LDS park
-    auto finish = [&](f32x16& acc, float* save_a, int L, int buf) {
+    auto finish = [&](f32x16& acc, unsigned* save_s, int L, int buf) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);          // acc started from the layer's bias
-        const f32x16 act = acc;
+        u32x4 sg0 = {0u, 0u, 0u, 0u}, sg1 = {0u, 0u, 0u, 0u};
+        if (save_s) {        // softplus'(z) = sigmoid(100 z) = 1 - exp(-100 a): all the backward wants of a (lk_common.h: lk_pack_unorm16)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sg0[q] = lk_pack_unorm16(lk_softplus100_grad_from_out(acc[2 * q]), lk_softplus100_grad_from_out(acc[2 * q + 1]));
+                sg1[q] = lk_pack_unorm16(lk_softplus100_grad_from_out(acc[8 + 2 * q]), lk_softplus100_grad_from_out(acc[8 + 2 * q + 1]));
+            }
+        }
         {
             const f32x16 ub = ct_bias_lds(s_bias[5 + L], w * 32, lane);
 #pragma unroll
@@ -329,9 +353,10 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
 #pragma unroll
         for (int G = 0; G < 2; ++G) acc = lk_mma3h(un[G], cb[G], acc);
         __builtin_amdgcn_sched_barrier(0);
-        if (save_a) ct_store_rows32(save_a + w * 32, act, live, lane);
+        if (save_s && live) { *reinterpret_cast<u32x4*>(save_s) = sg0; *reinterpret_cast<u32x4*>(save_s + 4) = sg1; }
         if (save) ct_store_rows32(act_col_h + LK_COL_LAYER(a.P, L) + w * 32, acc, live, lane);
         if (buf >= 0) {
+            ct_check_range<CHECK>(acc, a.status);
 #pragma unroll
             for (int G = 0; G < 2; ++G) {
                 const LkH8 b = lk_split_cth(acc, G);
@@ -347,7 +372,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     embed(acc, FB + FM10_FWDH, false);
     prefetch_hidden(FB + FM11_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(acc, act_col_a, 0, 0);
+    finish(acc, act_col_s, 0, 0);
     wg_barrier();
     // layers 1, 2: 128 -> 128
 #pragma unroll
@@ -358,7 +383,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         if (L == 1) prefetch_hidden(FB + FM12_FWDH, 0);
         else prefetch_hidden(FB + FM13_FWDH, 3);
         __builtin_amdgcn_sched_barrier(0);
-        finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, L) : nullptr, L, L & 1);
+        finish(acc, act_col_s ? act_col_s + LK_COL_SLAYER(a.P, L) : nullptr, L, L & 1);
         wg_barrier();
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
@@ -368,13 +393,13 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     hidden(acc, FB + FM13_FWDH, 3, 0);
     prefetch_hidden(FB + FM14_FWDH, 0);
     __builtin_amdgcn_sched_barrier(0);
-    finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, 3) : nullptr, 3, 1);
+    finish(acc, act_col_s ? act_col_s + LK_COL_SLAYER(a.P, 3) : nullptr, 3, 1);
     wg_barrier();
     // layer 4
     prefetch_u(FB + FM19_FWDH);
     acc = ct_bias_lds(s_bias[4], w * 32, lane);
     hidden(acc, FB + FM14_FWDH, 0, 1);
-    finish(acc, act_col_a ? act_col_a + LK_COL_LAYER(a.P, 4) : nullptr, 4, -1);
+    finish(acc, act_col_s ? act_col_s + LK_COL_SLAYER(a.P, 4) : nullptr, 4, -1);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
@@ -415,7 +440,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
 // Block roles: `n_col_blocks` workgroups are colour tiles (4 waves per tile), the others run the geometry
 // decoder (4 independent tiles per workgroup) and come FIRST in the grid.  raw[:, 0:3] and raw[:, 3] are written by the two roles separately;
 // in the geometry stage there are no colour blocks and raw[:, 0:3] is zero-filled by the geometry wave.
-template <bool DEEP>
+template <bool DEEP, bool CHECK = false>
 __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col_blocks) {
     __shared__ u32x4 s_x[2][16 * 64];
     __shared__ float s_o[4][3 * 32];
@@ -428,12 +453,12 @@ __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col
     const int bid = (int)blockIdx.x < n_geo_blocks ? n_col_blocks + (int)blockIdx.x : (int)blockIdx.x - n_geo_blocks;
     if (bid < n_col_blocks) {
         if (bid * 32 >= P_live) return;
-        decode_col_wg<DEEP>(a, bid, w, lane, s_x, s_o, s_bias);
+        decode_col_wg<DEEP, false, CHECK>(a, bid, w, lane, s_x, s_o, s_bias);
         return;
     }
     const int tile = (bid - n_col_blocks) * 4 + w;
     if (tile * 32 >= P_live) return;
-    (void)decode_geo_wave(a, tile, lane);
+    (void)decode_geo_wave<CHECK>(a, tile, lane);
     if (n_col_blocks == 0) {
         const int sample = tile * 32 + (lane & 31);
         if (sample < a.P && lane < 32) { float* out = a.raw + (size_t)sample * 4; out[0] = 0.0f; out[1] = 0.0f; out[2] = 0.0f; }
@@ -443,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_decode_fwd(LkDecodeArgs a, int n_col
 // ---------------------------------------------------------------------------------------------
 // Relative-position neighbour MLP: one wave = 32 neighbour rows = 4 samples x 8 neighbours.
 //   x_j = [sin(2 pi D_j B_r), cos(2 pi D_j B_r), F[I_j]] (52) -> 128 softplus100 -> 32;  c = sum_j w_j f_j
+template <bool CHECK = false>
 __device__ __forceinline__ void relpos_fwd_wave(const LkRelposArgs& a, int sample0, int P) {
     const int lane = lk_lane();
     const int h = lane >> 5;
@@ -489,6 +515,7 @@ __device__ __forceinline__ void relpos_fwd_wave(const LkRelposArgs& a, int sampl
             x1[4 * g] = v.x; x1[4 * g + 1] = v.y; x1[4 * g + 2] = v.z; x1[4 * g + 3] = v.w;
         }
     }
+    ct_check_range<CHECK>(x0, a.status); ct_check_range<CHECK>(x1, a.status);
     f32x16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_rowvec_tile(W + R_B1, nb * 32, lane);      // accumulators start from the bias
@@ -498,6 +525,7 @@ __device__ __forceinline__ void relpos_fwd_wave(const LkRelposArgs& a, int sampl
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) hid[nb][q] = lk_softplus100(hid[nb][q]);
+        ct_check_range<CHECK>(hid[nb], a.status);
     }
     f32x16 out[1];
     out[0] = lk_rowvec_tile(W + R_B2, 0, lane);
@@ -523,13 +551,16 @@ __device__ __forceinline__ void relpos_fwd_wave(const LkRelposArgs& a, int sampl
         }
     }
 }
-__global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) {
+template <bool CHECK>
+__device__ __forceinline__ void relpos_fwd_kernel(const LkRelposArgs& a) {
     const int wave = blockIdx.x * 4 + ((int)threadIdx.x >> 6);
     const int sample0 = wave * 4;
     const int P = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;      // rays without a reading sit behind the live prefix: skipped
     if (sample0 >= P) return;
-    relpos_fwd_wave(a, sample0, P);
+    relpos_fwd_wave<CHECK>(a, sample0, P);
 }
+__global__ __launch_bounds__(256) void k_relpos_fwd(LkRelposArgs a) { relpos_fwd_kernel<false>(a); }
+__global__ __launch_bounds__(256) void k_relpos_fwd_checked(LkRelposArgs a) { relpos_fwd_kernel<true>(a); }       // LK_FLAG_CHECK_RANGE
 
 // Rel-pos neighbour MLP + both decoders in ONE launch (the tracker's batches: every kernel of an iteration is a single partial round
 // of the chip, so a launch boundary costs its fixed ~6 us - dispatch, an L2-cold start, the drain - for nothing).  A colour workgroup is
@@ -621,7 +652,8 @@ int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_DECODE_FWD, st);
     const int tiles = lk_cdiv(a.P, 32);
     const int n_col = (a.flags & LK_FLAG_STAGE_COLOR) ? tiles : 0;
-    if (n_col > 0 && n_col <= LK_DEEP_MAX_TILES_FWD) hipLaunchKernelGGL(k_decode_fwd<true>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
+    if (a.status) hipLaunchKernelGGL((k_decode_fwd<false, true>), dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);      // LK_FLAG_CHECK_RANGE
+    else if (n_col > 0 && n_col <= LK_DEEP_MAX_TILES_FWD) hipLaunchKernelGGL(k_decode_fwd<true>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     else hipLaunchKernelGGL(k_decode_fwd<false>, dim3(n_col + lk_cdiv(tiles, 4)), dim3(256), 0, st, a, n_col);
     return LK_OK;
 }
@@ -638,7 +670,8 @@ int lk_occupancy_relpos_fwd() {
 // tracker-sized colour batches with the rel-pos MLP (lk_track_frame): see k_relpos_decode_fwd
 bool lk_relpos_decode_fusable(const LkDecodeArgs& a) {
     const int tiles = lk_cdiv(a.P, 32);
-    return (a.flags & LK_FLAG_STAGE_COLOR) && (a.flags & LK_FLAG_REL_POS) && tiles > 0 && tiles <= LK_DEEP_MAX_TILES_FWD && a.live_rays == nullptr;
+    // (not with LK_FLAG_CHECK_RANGE: the operand tests live in the two separate kernels' checked instantiations)
+    return (a.flags & LK_FLAG_STAGE_COLOR) && (a.flags & LK_FLAG_REL_POS) && tiles > 0 && tiles <= LK_DEEP_MAX_TILES_FWD && a.live_rays == nullptr && a.status == nullptr;
 }
 // comp: pass 1 of the tracker's loss as the launch's epilogue where the tiles can hold whole rays (4 <= S <= 32, one round of tiles);
 // *comp_tiles = 0 otherwise and the caller launches k_track_composite
@@ -662,6 +695,7 @@ int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, h
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {
     LkProfScope prof_(LKK_RELPOS_FWD, st);
     const int waves = lk_cdiv(a.P, 4);
-    hipLaunchKernelGGL(k_relpos_fwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    if (a.status) hipLaunchKernelGGL(k_relpos_fwd_checked, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_relpos_fwd, dim3(lk_cdiv(waves, 4)), dim3(256), 0, st, a);
     return LK_OK;
 }

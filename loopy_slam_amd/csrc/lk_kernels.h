@@ -62,6 +62,7 @@ struct LkDecodeArgs {
                                                   // reference never renders those rays: they are filtered out before the render, Mapper.py:645-681)
     int tile_stride;                              // 0 = 32; k_relpos_decode_fwd with the composite inside: (32 / S) S - a tile holds whole rays,
                                                   // its lanes >= tile_stride idle
+    unsigned* status;                             // LK_FLAG_CHECK_RANGE: lk_status_dev(), else NULL (no operand checks)
 };
 
 // relative-position neighbour MLP (colour features, Replica config)
@@ -76,6 +77,7 @@ struct LkRelposArgs {
     int feats_f16;                                // LK_FLAG_FEATS_F16
     const int32_t* live_rays;                     // [1] or NULL: only the first *live_rays rays of the batch have a depth reading (k_pregather
                                                   // partitions the mapper's batches); the samples of the others are not processed
+    unsigned* status;                             // as LkDecodeArgs::status
 };
 
 struct LkCompositeBwdArgs {
@@ -378,10 +380,11 @@ int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, h
 int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs& ib, hipStream_t st);  // k_relpos_bwd + k_interp_bwd in one launch
 
 // activation scratch layout (floats per sample), SAVE_ACT
-//   [P][160] geometry a_i | [P][640] colour a_i | [P][640] colour h_i | [P][40] colour embedding  (i = 0..4)
-//   a_i = act(W_i x_i + b_i), h_i = a_i + fc_c_i(c)
+//   [P][160] geometry a_i | [P][320] colour softplus'(z_i) as unorm16 pairs | [P][640] colour h_i | [P][40] colour embedding  (i = 0..4)
+//   a_i = act(z_i), z_i = W_i x_i + b_i, h_i = a_i + fc_c_i(c).  The colour trunk's backward needs a_i only for d y_i = d h_i softplus'(z_i):
+//   the forward stores that factor in 16 bits (lk_pack_unorm16; round 5 stored the a_i rows, 64 MB per 5 000-ray batch written and read back)
 #define LK_ACT_GEO_A (5 * 32)
-#define LK_ACT_COL_A (5 * 128)
+#define LK_ACT_COL_A (5 * 64)        // words: 128 unorm16 per sample and layer, lane-contiguous (LK_COL_SLAYER, decode_col_wg::finish)
 #define LK_ACT_COL_H (5 * 128)
 #define LK_ACT_COL_E 40       // colour Fourier embedding (input of layers 0 and 3)
 #define LK_ACT_FLOATS_PER_SAMPLE (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H + LK_ACT_COL_E)
@@ -396,6 +399,7 @@ int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs
 #define LK_DEEP_MAX_TILES_FWD 512
 #endif
 #define LK_COL_LAYER(P, layer) ((size_t)(layer) * (size_t)(P) * 128)
+#define LK_COL_SLAYER(P, layer) ((size_t)(layer) * (size_t)(P) * 64)       // the derivative mask: 64 words per sample and layer
 
 // resident 256-thread workgroups per compute unit as the runtime computes them (registers, LDS): lk_debug_occupancy
 int lk_occupancy_decode_fwd();

@@ -311,6 +311,7 @@ extern "C" int64_t lk_map_work_nbr_idx(int32_t R, int32_t S, int32_t iters) { re
 
 extern "C" int lk_track_frame(const lk_track_desc* d, void* stream_) {
     LK_REQUIRE(d != nullptr, "lk_track_frame: NULL descriptor");
+    { const int rcg = lk_status_gate("lk_track_frame"); if (rcg != LK_OK) return rcg; }
     LK_REQUIRE(d->iters >= 0 && d->render.R >= 0 && d->w > 0, "lk_track_frame: bad sizes");
     if (d->iters == 0 || d->render.R == 0) return LK_OK;
     LK_REQUIRE(d->depth_img && d->color_img && d->rnd && d->cam7 && d->g_cam7 && d->adam_mv && d->hist && d->log, "lk_track_frame: NULL buffer");
@@ -552,6 +553,7 @@ extern "C" int lk_map_prepare(const lk_map_desc* d, void* stream_) {
 
 extern "C" int lk_map_frame(const lk_map_desc* d, int32_t it_begin, int32_t it_end, int32_t phases, void* stream_) {
     LK_REQUIRE(d != nullptr, "lk_map_frame: NULL descriptor");
+    { const int rcg = lk_status_gate("lk_map_frame"); if (rcg != LK_OK) return rcg; }
     LK_REQUIRE(it_begin >= 0 && it_end <= d->iters && it_begin <= it_end && (phases & 3), "lk_map_frame: bad iteration range / phases");
     LK_REQUIRE(d->n_geo_dec >= 0 && d->n_geo_dec <= LK_MAX_SPANS && d->n_col_dec >= 0 && d->n_col_dec <= LK_MAX_SPANS, "lk_map_frame: too many spans");
     if (it_begin == it_end || d->render.R == 0) return LK_OK;

@@ -32,9 +32,20 @@ extern "C" int64_t lk_weight_frag_floats(void) { return 4 * ((int64_t)FRAGB_U4 +
 
 extern "C" int lk_weights_repack(const float* plain, float* frag, void* stream_) {
     LK_REQUIRE(plain && frag, "lk_weights_repack: NULL buffer");
+    { const int rcg = lk_status_gate("lk_weights_repack"); if (rcg != LK_OK) return rcg; }
     const FragTable tb = lk_frag_table();
     hipLaunchKernelGGL(k_weights_repack, dim3(lk_cdiv(LK_REPACK_UNITS, 256)), dim3(256), 0, (hipStream_t)stream_, plain,
                        reinterpret_cast<u32x4*>(frag), tb);
     LK_LAUNCH_CHECK();
     return LK_OK;
+}
+
+extern "C" int lk_weights_repack_checked(const float* plain, float* frag, void* stream_) {
+    const int rc = lk_weights_repack(plain, frag, stream_);
+    if (rc != LK_OK) return rc;
+    if (!lk_status_dev()) return LK_OK;          // no status word (allocation failed): nothing to report
+    uint32_t bits = 0;
+    const int rc2 = lk_status_sync(stream_, &bits);
+    if (rc2 != LK_OK) return rc2;
+    return lk_status_gate("lk_weights_repack_checked");
 }

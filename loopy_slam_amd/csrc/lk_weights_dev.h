@@ -5,7 +5,7 @@
 
 using namespace lkw;
 
-struct FragTable { FragMat m[N_FRAG_MATS]; };
+struct FragTable { FragMat m[N_FRAG_MATS]; unsigned* status; };      // status: lk_status_dev() - the range check of the fp16 forms
 
 // one lane-block element of the split-bf16 fragments: unit u = (matrix form, G, blk, lane), 8 weights -> 3 x 16 B
 // (m_lo, m_hi: only the matrices [m_lo, m_hi) of the table - a repack split between two launches, LK_FRAG_* below)
@@ -91,6 +91,12 @@ __device__ __forceinline__ void repack_half_unit(const float* __restrict__ plain
             v[i] = (col >= 0 && col < M.ld) ? plain[M.plain + n * M.ld + col] : 0.0f;
         }
     }
+    // fp16 pieces saturate where bf16 pieces do not: a weight at or above 2^15 (or a non-finite one) is reported, not silently clipped
+    // (LK_STATUS_WEIGHT_RANGE; the reference's fp32 decoder has no ceiling, decoder.py:513-546)
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bad = bad || lk_out_of_range(v[i], 32768.0f);
+    if (bad) lk_status_raise(tb.status, LK_STATUS_WEIGHT_RANGE);
     const LkH8 s = lk_split8h(v);
     u32x4* __restrict__ q = fragh + o4 + lane;
     q[0] = s.p[0]; q[64] = s.p[1];
@@ -106,5 +112,6 @@ inline FragTable lk_frag_table() {
     static const FragMat rows[N_FRAG_MATS] = {LKW_FRAG_TABLE};
     FragTable tb;
     for (int i = 0; i < N_FRAG_MATS; ++i) tb.m[i] = rows[i];
+    tb.status = lk_status_dev();
     return tb;
 }

@@ -212,6 +212,11 @@ static inline f16x2_emu __builtin_amdgcn_cvt_pkrtz(float a, float b) {
     return r;
 }
 // v_perm_b32: byte pool {S0 = bytes 7..4, S1 = bytes 3..0}, selector byte n of `sel` picks pool byte (0..7)
+typedef unsigned short u16x2_emu __attribute__((ext_vector_type(2)));
+static inline u16x2_emu __builtin_amdgcn_cvt_pknorm_u16(float a, float b) {        // v_cvt_pknorm_u16_f32: round-to-nearest-even of clamp(x, 0, 1) * 65535
+    auto q = [](float x) { x = x != x ? 0.0f : (x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x)); return (unsigned short)::nearbyintf(x * 65535.0f); };
+    u16x2_emu r; r[0] = q(a); r[1] = q(b); return r;
+}
 static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
     const unsigned long long pool = ((unsigned long long)s0 << 32) | s1;
     unsigned r = 0;
@@ -280,12 +285,19 @@ template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+// (__hip_atomic_fetch_or / __HIP_MEMORY_SCOPE_SYSTEM are clang builtins on the host too: lk_status_raise compiles as it stands)
+#ifndef __HIP_MEMORY_SCOPE_SYSTEM
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#endif
 
 // ---- host API
 namespace hipemu { void* guarded_alloc(size_t n); void guarded_free(void* p); }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = hipemu::guarded_alloc(n); return *p ? hipSuccess : 2; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { hipemu::guarded_free(p); return hipSuccess; }
+#define hipHostMallocMapped 2
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = hipemu::guarded_alloc(n); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }

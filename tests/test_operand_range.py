@@ -1,0 +1,73 @@
+"""The split fp16 products of the decoder forward (csrc/lk_common.h: lk_mma3h) have a ceiling the reference's plain-fp32 decoder
+(/root/reference/src/conv_onet/models/decoder.py:513-546) does not: the pack-convert to fp16 pieces saturates at 65 504.  The library
+reports instead of clipping: the repack flags a matrix entry that is non-finite or >= 2^15 in magnitude (LK_STATUS_WEIGHT_RANGE), a
+forward launched with LK_FLAG_CHECK_RANGE flags an operand >= 65 504 (LK_STATUS_ACT_RANGE), and from then on every render / loop /
+repack entry point refuses with LK_ERR_RANGE until lk_status_clear() (include/loopy_hip.h)."""
+import numpy as np
+import pytest
+import torch
+
+from loopy_slam_amd import _ffi, core
+from util import backends, load, make_engine, tens, weights
+
+
+def _render(eng, W, geo_scale=1.0, extra=0):
+    g = load('g6_render_replica_map_color')
+    cfg = core.RenderCfg()
+    dec = core.DecoderBlob(eng).pack(W)
+    ro, rd, gd, pos, geo, col = [eng.f32(x) for x in tens(g, 'rays_o', 'rays_d', 'gt_depth', 'pos', 'geo', 'col')]
+    knn = core.KnnIndex(eng, capacity=pos.shape[0])
+    knn.build(pos)
+    st = core.RenderState(eng, ro.shape[0], cfg.S)
+    core.render_forward(eng, cfg, st, ro, rd, gd, knn, pos, geo * geo_scale, col, dec, 'color', noise_geo=eng.f32(g['noise_geo']),
+                        noise_col=eng.f32(g['noise_col']), extra_flags=extra)
+    return st
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_weight_out_of_range_is_a_clean_error(backend):
+    eng = make_engine(backend)
+    eng.clear_status()
+    W = dict(weights('replica'))
+    assert eng.status(sync=True) == 0
+    _render(eng, W)                                             # in range: nothing is raised, nothing is flagged
+    assert eng.status(sync=True) == 0
+    for bad in (1e5, float('nan'), float('-inf')):
+        Wb = dict(W)
+        t = Wb['color_decoder.pts_linears.1.weight'].clone()
+        t[3, 7] = bad
+        Wb['color_decoder.pts_linears.1.weight'] = t
+        with pytest.raises(_ffi.LoopyError, match='32768'):
+            core.DecoderBlob(eng).pack(Wb)
+        assert eng.status() & _ffi.STATUS_WEIGHT_RANGE
+        with pytest.raises(_ffi.LoopyError, match='refused'):      # sticky: no render on weights that are not the reference's
+            _render(eng, W)
+        eng.clear_status()
+    # biases, Fourier matrices and output layers are fp32 operands: no ceiling applies to them
+    Wb = dict(W)
+    Wb['color_decoder.pts_linears.1.bias'] = Wb['color_decoder.pts_linears.1.bias'].clone()
+    Wb['color_decoder.pts_linears.1.bias'][0] = 4e4
+    core.DecoderBlob(eng).pack(Wb)
+    assert eng.status(sync=True) == 0
+    _render(eng, W)
+    assert eng.status(sync=True) == 0
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_saturated_operand_is_flagged_under_the_debug_flag(backend):
+    eng = make_engine(backend)
+    eng.clear_status()
+    W = weights('replica')
+    st = _render(eng, W, geo_scale=1.0, extra=_ffi.FLAG_CHECK_RANGE)
+    assert eng.status(sync=True) == 0
+    ref = st.depth.clone()
+    # geometry features scaled to ~1e6: the interpolated feature c is an fp16-piece operand of every fc_c product
+    _render(eng, W, geo_scale=3e7)                              # without the flag: not tested (the documented default)
+    assert eng.status(sync=True) == 0
+    _render(eng, W, geo_scale=3e7, extra=_ffi.FLAG_CHECK_RANGE)
+    assert eng.status(sync=True) & _ffi.STATUS_ACT_RANGE
+    with pytest.raises(_ffi.LoopyError, match='65504'):
+        _render(eng, W)
+    eng.clear_status()
+    st2 = _render(eng, W, extra=_ffi.FLAG_CHECK_RANGE)
+    assert eng.status(sync=True) == 0 and torch.equal(st2.depth, ref)

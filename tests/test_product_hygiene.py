@@ -142,7 +142,7 @@ def test_mlp_kernels_keep_their_register_budget():
     spilled = sorted(n for n, d in by.items() if d.get('vgpr_spill_count', 0) > 0 and 'k_pregather' not in n)
     assert not spilled, spilled
     budget = {'_Z12k_decode_bwdILb1ELb0ELb1EEv15LkDecodeBwdArgsi': 168,     # mapper form: three workgroups per unit
-              '_Z12k_decode_fwdILb0EEv12LkDecodeArgsi': 168,
+              '_Z12k_decode_fwdILb0ELb0EEv12LkDecodeArgsi': 168,
               '_Z12k_relpos_fwd12LkRelposArgs': 168,
               '_Z18k_relpos_bwd_fusedILb1ELb0EEv15LkRelposBwdArgs': 256,     # two per unit (LDS-bound anyway)
               '_Z7k_wgradILb1EEv11LkWgradArgs': 256}
@@ -151,4 +151,4 @@ def test_mlp_kernels_keep_their_register_budget():
         assert by[name]['vgpr_count'] <= cap, (name, by[name])
     # LDS: three decoder workgroups must fit the 160 KB of a compute unit
     assert 3 * by['_Z12k_decode_bwdILb1ELb0ELb1EEv15LkDecodeBwdArgsi']['group_segment_fixed_size'] <= 160 * 1024
-    assert 3 * by['_Z12k_decode_fwdILb0EEv12LkDecodeArgsi']['group_segment_fixed_size'] <= 160 * 1024
+    assert 3 * by['_Z12k_decode_fwdILb0ELb0EEv12LkDecodeArgsi']['group_segment_fixed_size'] <= 160 * 1024
