@@ -263,6 +263,9 @@ class FrameWorkload:
         self.rows, row_mask = sel.finish()
         self.mapper.new_frame(self.rows, row_mask, zero=not prepared)
         self.mapper.run(b.map_iters, b.map_geo_iters, self.frames, rnd_m, fid, (0, H, 0, W), self.intr, H, W, self.map_log)
+        # end of the optimize_map call: the stepped exposure feature goes back to its keyframe's tensor (Mapper.py:772-777 for the rows, the
+        # feature with them) - the next frame's tracker starts from it; round 5 left it in the optimiser's stacked copy (advisor)
+        self.mapper.finish()
         if mapped:
             if self.render_stream is not None:
                 self.render_stream.wait_stream(torch.cuda.current_stream(eng.device))

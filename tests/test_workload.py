@@ -37,6 +37,9 @@ def test_frame_workload_steps(backend, name):
     wl = workload.FrameWorkload(eng, b, cloud=(pos, geo, col, 1), intr=cam)
     assert (wl.r2_stack is not None) == b.dynamic_radius and (wl.mlp_exposure is not None) == b.exposure
     geo0, blob0 = wl.geo[:wl.n].clone(), wl.dec.blob.clone()
+    if b.exposure:          # before the steps: the window's exposure features and the module the kernels step in place
+        xf0 = [f.detach().clone() for f in wl.exposure_feats]
+        xw0 = [p.detach().clone() for p in wl.mlp_exposure.parameters()]
     logs = []
     for k in range(3 if backend == 'hip' else 2):          # (every_frame 2: steps 0 and 2 are mapped frames; the emulator runs two)
         best, tlog, mlog = wl.step(full=True)
@@ -51,4 +54,8 @@ def test_frame_workload_steps(backend, name):
     assert wl.img_state is not None and np.isfinite(wl.img_state.depth.cpu().numpy()).all()       # ... and rendered
     assert float((wl.geo[:b.n_points] - geo0).abs().max()) > 1e-3 and not torch.equal(wl.dec.blob, blob0)
     if b.exposure:
-        assert float((wl.exposure_feats[-1].detach() - wl.exposure_feats[-1].detach().clone().zero_()).abs().max()) > 0
+        # Mapper.py:524-570, 588-607: the mapped frame's own feature (the last of the window) and mlp_exposure are Adam parameters of the
+        # mapping call, the other keyframes' features are constants - trained means MOVED, frozen means bit for bit where it was
+        assert float((wl.exposure_feats[-1].detach() - xf0[-1]).abs().max()) > 1e-4
+        assert all(torch.equal(f.detach(), f0) for f, f0 in zip(wl.exposure_feats[:-1], xf0[:-1]))
+        assert all(float((p.detach() - p0).abs().max()) > 1e-5 for p, p0 in zip(wl.mlp_exposure.parameters(), xw0))

@@ -20,8 +20,18 @@ modes = sys.argv[4:] or ['color']
 ALGO = {'color': (5000, 31.6e3), 'geo': (5000, 0.5 * 31.6e3), 'track': (1500, 11.1e3)}
 
 
+# kernels of the workload's SET-UP (synthetic scene, map insertion, index build - once per process, torch's own element-wise kernels): not
+# part of an iteration; listed in one line under the table
+SETUP = {'k_aabb', 'k_count', 'k_scatter', 'k_zero_counts', 'k_grid_finalize', 'k_add_test', 'k_add_emit', 'k_compact', 'k_frustum_sample', 'k_frustum_mask',
+         'k_compact_count', 'k_compact_scan', 'k_compact_write'}
+
+
 def short(n):
     return n.split('(')[0].replace('void ', '').strip()
+
+
+def is_setup(k):
+    return k.startswith('at::') or k in SETUP
 
 
 def counter(mode, pass_, name):
@@ -55,7 +65,7 @@ for mode in modes:
     n_it = iters * calls
     fe, wr, du = counter(mode, 'fetch', 'FETCH_SIZE'), counter(mode, 'write', 'WRITE_SIZE'), durations(mode)
     rays, per_ray = ALGO[mode]
-    rows, tot_r, tot_w, tot_us = [], 0.0, 0.0, 0.0
+    rows, tot_r, tot_w, tot_us, setup_mb = [], 0.0, 0.0, 0.0, 0.0
     for k in sorted(set(fe) | set(wr) | set(du), key=lambda k: -(2 * fe[k][1] + wr[k][1])):
         n = max(fe[k][0], wr[k][0], du[k][0])
         if n == 0:
@@ -63,6 +73,9 @@ for mode in modes:
         r_mb = 2 * fe[k][1] * 1024 / 1e6
         w_mb = wr[k][1] * 1024 / 1e6
         us = du[k][1]
+        if is_setup(k):
+            setup_mb += r_mb + w_mb
+            continue
         tot_r += r_mb; tot_w += w_mb; tot_us += us
         if (r_mb + w_mb) / n_it < 0.05 and us / n_it < 0.5:
             continue
@@ -76,6 +89,8 @@ for mode in modes:
         print(f'| {k} | {lpi:.2f} | {us:.1f} | {r1:.1f} | {w1:.1f} | {ri:.1f} | {wi:.1f} |')
     algo = rays * per_ray / 1e6
     tot = (tot_r + tot_w) / n_it
+    print()
+    print(f'(left out: the set-up of the process - synthetic scene, insertion, index build, torch element-wise kernels - {setup_mb:.0f} MB in all.)')
     print()
     print(f'**Per iteration: read {tot_r / n_it:.0f} MB + written {tot_w / n_it:.0f} MB = {tot:.0f} MB; sum of kernel durations {tot_us / n_it:.0f} us; '
           f'SURVEY §8(d) algorithmic bytes {algo:.0f} MB ({rays} rays x {per_ray / 1e3:.1f} KB) -> traffic ratio {tot / algo:.2f}.**')
