@@ -32,6 +32,16 @@ def _merge(ranges, gap=4096):
     return out
 
 
+def ray_range(n_rays, rank, world, chunk):
+    """The contiguous ray range [lo, hi) of `rank` when n_rays rays are shared out over `world` ranks in whole groups of `chunk` rays
+    ("contiguous ray ranges (tracking, render_img)").  Group-aligned because the reference evaluates far_bb per batch of
+    ray_batch_size rays (/root/reference/src/utils/Renderer.py:102-121, 241-266): a rank that starts on a group boundary forms the same
+    groups as one process does, so its rays come out bit for bit as in the full-frame render."""
+    groups = (n_rays + chunk - 1) // chunk
+    g0, g1 = (groups * rank) // world, (groups * (rank + 1)) // world
+    return min(n_rays, g0 * chunk), min(n_rays, g1 * chunk)
+
+
 class _RowAgreement:
     """One in-flight agreement on the touched rows of an iteration: device list + count on its way to pinned host memory."""
 
@@ -145,6 +155,22 @@ class DistContext:
     def all_reduce_vec(self, t):
         self._all_reduce(t, dist.ReduceOp.SUM)
         return t
+
+    def gather_ranges(self, tensors, lo, hi):
+        """Full-frame outputs from per-rank ray ranges: every tensor holds this rank's rays [lo, hi) along dim 0 and ZEROS elsewhere; one SUM
+        all-reduce over the concatenation leaves the whole frame on every rank (x + 0 = x exactly; ranges are disjoint).  One collective of
+        5 floats per ray (6 MB for 640 x 480) instead of an all-gather per tensor with ragged shards - the float32 SUM is what both the direct
+        RCCL communicator and the gloo test path carry."""
+        if self.world <= 1:
+            return tensors
+        flat = torch.cat([t.reshape(t.shape[0], -1).float() for t in tensors], dim=1).contiguous()
+        self._all_reduce(flat, dist.ReduceOp.SUM)
+        out, c = [], 0
+        for t in tensors:
+            w = t[0].numel() if t.shape[0] else 1
+            out.append(flat[:, c:c + w].reshape(t.shape).to(t.dtype))
+            c += w
+        return out
 
     # ------------------------------------------------------------------ gradient bucket
     def all_reduce_grads(self, mo, stage='color', it=None, desc=None):

@@ -360,6 +360,7 @@ class Renderer:
         # off in every reference config (replica/tum/scannet.yaml): depth-less rays then sample where the cloud is (Renderer.py:152-160)
         self.sample_near_pcl = bool(cfg['rendering'].get('sample_near_pcl', False))
         self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
+        self.dist = getattr(slam, 'dist', None)       # parallel.DistContext or None: render_img shares its rays out over the ranks
 
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None, npc_geo_feats=None,
                          npc_col_feats=None, is_tracker=False, cloud_pos=None, dynamic_r_query=None, exposure_feat=None,
@@ -403,11 +404,24 @@ class Renderer:
         Renderer.py:241-266); far_bb is still evaluated per ray_batch_size group."""
         with torch.no_grad():
             ro, rd = get_rays(self.H, self.W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
             gd = gt_depth.reshape(-1) if gt_depth is not None else None
-            d, u, c, _ = self.render_batch_ray(npc, decoders, rd.reshape(-1, 3).contiguous(), ro.reshape(-1, 3).contiguous(), device,
-                                               stage, gt_depth=gd, npc_geo_feats=npc_geo_feats, npc_col_feats=npc_col_feats,
-                                               cloud_pos=cloud_pos, dynamic_r_query=dynamic_r_query, exposure_feat=exposure_feat,
-                                               _stats_chunk=self.ray_batch_size)
+            rq = dynamic_r_query.reshape(-1) if dynamic_r_query is not None else None
+            n = ro.shape[0]
+            dist = self.dist if (self.dist is not None and self.dist.world > 1) else None
+            # multi-GPU (SURVEY §8e): every rank renders ONE contiguous range of whole ray_batch_size groups, then the ranges are exchanged
+            lo, hi = parallel.ray_range(n, dist.rank, dist.world, self.ray_batch_size) if dist is not None else (0, n)
+            sl = slice(lo, hi)
+            if hi > lo:
+                d, u, c, _ = self.render_batch_ray(npc, decoders, rd[sl], ro[sl], device, stage, gt_depth=gd[sl] if gd is not None else None,
+                                                   npc_geo_feats=npc_geo_feats, npc_col_feats=npc_col_feats, cloud_pos=cloud_pos,
+                                                   dynamic_r_query=rq[sl] if rq is not None else None, exposure_feat=exposure_feat,
+                                                   _stats_chunk=self.ray_batch_size)
+            if dist is not None:
+                full = [torch.zeros(n, device=ro.device), torch.zeros(n, device=ro.device), torch.zeros(n, 3, device=ro.device)]
+                if hi > lo:
+                    full[0][sl], full[1][sl], full[2][sl] = d, u, c
+                d, u, c = dist.gather_ranges(full, lo, hi)
             return d.double().reshape(self.H, self.W), u.double().reshape(self.H, self.W), c.reshape(self.H, self.W, 3)
 
 

@@ -87,72 +87,72 @@ def test_oracle_loop_and_product_agree_on_a_miniature_sequence():
     assert float((est_p[:, :3, 3] - gt[:, :3, 3]).norm(dim=1).max()) < 0.08 and float((est_o[:, :3, 3] - gt[:, :3, 3]).norm(dim=1).max()) < 0.08
 
 
+def test_welch_interval_against_scipy():
+    """tests/welch.py reproduces scipy's Welch test (statistic, degrees of freedom -> p-value) and its half-width is the interval that p-value
+    belongs to; the 'resolvable' difference shrinks as 1 / sqrt(n)."""
+    from scipy import stats
+    import welch as WL
+    g = np.random.default_rng(5)
+    a, b = 0.35 + 0.05 * g.standard_normal(20), 0.33 + 0.08 * g.standard_normal(6)
+    w = WL.welch(a, b)
+    r = stats.ttest_ind(a, b, equal_var=False)
+    assert abs(w['p_value'] - r.pvalue) <= 1e-12 and abs(w['diff'] / w['se'] - r.statistic) <= 1e-12
+    assert abs(w['half_width'] - stats.t.ppf(0.975, w['dof']) * w['se']) <= 1e-15
+    # the interval contains 0 exactly when p >= alpha
+    assert (abs(w['diff']) <= w['half_width']) == (w['p_value'] >= 0.05)
+    big = WL.welch(0.35 + 0.05 * g.standard_normal(80), 0.33 + 0.08 * g.standard_normal(24))
+    assert 0.35 * w['resolvable_rel'] < big['resolvable_rel'] < 0.75 * w['resolvable_rel']
+    ok, rec = WL.indistinguishable(a, b)
+    assert ok and rec['half_width_test'] > rec['half_width']
+    ok2, _ = WL.indistinguishable(a + 0.5, b)
+    assert not ok2
+
+
+N_PRODUCT_RUNS = 20          # per config (round-5 review: >= 20, so that the interval is set by the data and not by three runs)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ('room', 'roomfull', 'tum', 'scannet'))
 def test_accuracy_matches_the_oracle_loop(name):
-    """The product on the GPU against the committed oracle runs of the same config and seeds:
-      (a) rendered-depth L1 within 5 % of the oracle's, seed by seed (it is set by the map, which both build from the same draws' distribution);
-      (b) ATE RMSE: every run beats the one-step constant-speed prior and is >= 3x better than dead reckoning, and the MEAN over the seeds is
-          within 5 % of the oracle's mean or within three standard errors of the difference (a two-sigma bound fails one honest run in twenty) (the ATE of one 50-frame run scatters by ~10 %
-          from seed to seed in BOTH pipelines - measured, profiles/r4_accuracy.json);
-      (c) the numbers go to gpurun_out/accuracy_<name>.json."""
+    """The product on the GPU (N_PRODUCT_RUNS seeds) against the committed oracle runs of the same config (3-6 runs of 8-60 CPU minutes each):
+      (a) ATE RMSE and rendered-depth L1: the difference of the MEANS lies inside its own Welch interval (tests/welch.py; tested at
+          alpha = 0.002, the 95 % half-width relative to the oracle's mean is recorded as `resolvable_rel` - the smallest relative difference
+          these runs can tell from zero.  It is 5-30 %, not 1 %: single runs of EITHER pipeline scatter by 10-30 %, the trajectories being
+          chaotic - README / DESIGN quote that number, not "within 1 %");
+      (b) sanity: the product's median run beats the constant-speed prior and dead reckoning by the margins below;
+      (c) the numbers go to gpurun_out/accuracy_<name>.json (tools/accuracy_summary.py -> profiles/<tag>_accuracy.json).
+    Metric definitions: /root/reference/src/tools/eval_ate.py:195-234 (Horn-aligned translational RMSE), src/Mapper.py:1146-1182 (depth L1)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import accuracy_run as AR
+    import welch as WL
     fx = _fixtures(name)
-    if name != 'room' and not fx:
-        pytest.skip(f'no oracle fixture for the {name} config')
-    assert len(fx) >= (3 if name == 'room' else 1), 'oracle fixtures missing (tools/accuracy_run.py --pipeline oracle)'
-    if name != 'room':
-        # TUM / ScanNet configs (dynamic radii, gradient-pool tracking pixels, exposure encoding) at 2 000 rays per iteration - at config 1's
-        # 500 rays BOTH pipelines lose track on this sequence (oracle 22 cm, product 14-31 cm): ONE oracle run each (25-60 minutes of CPU),
-        # five product runs (three at the room's own budget); a band instead of a statistical bound.  roomfull: the room config at its OWN ray budget (1 500 / 5 000 rays per
-        # iteration - the bench workload's), one oracle run of 50 minutes; the depth L1 there is held to 8 % (the runs of either pipeline scatter by +-4 % around 0.047 cm)
-        o = dict(fx[0])                       # (more than one oracle run of the config: the band is around their MEDIANS - one oracle run in
-        # three of the ScanNet config drifts to 4.4 cm ATE, and its depth L1 with it; the product's eight runs stay at 1.5-2.3 cm)
-        o['ate_rmse_cm'] = float(np.median([f['ate_rmse_cm'] for f in fx]))
-        # depth L1 of the runs that kept track (ATE within 1.5 x the pipeline's median): a drifted run's depth L1 is up to twice the others'
-        held = lambda ate, l1: float(np.median([l for a, l in zip(ate, l1) if a <= 1.5 * np.median(ate)]))
-        o['depth_l1_cm'] = held([f['ate_rmse_cm'] for f in fx], [f['depth_l1_cm'] for f in fx])
-        c = o['config']
-        res = []
-        for seed in range(c['seed'], c['seed'] + (3 if name == 'roomfull' else 5)):
-            cfg = AR.make_cfg(os.path.join(ROOT, c['file']), c['frames'], c['rays_per_iteration'], c['iters_scale'], None, seed, int(c['color_refine']), c['scene'])
-            res.append(AR.run_product(cfg))
-        ha = np.array([r['ate_rmse_cm'] for r in res]); hl = np.array([r['depth_l1_cm'] for r in res])
-        out = os.path.join(ROOT, 'gpurun_out')
-        if os.path.isdir(out):
-            with open(os.path.join(out, f'accuracy_{name}.json'), 'w') as f:
-                json.dump(dict(config=c, oracle=dict(ate_rmse_cm=o['ate_rmse_cm'], depth_l1_cm=o['depth_l1_cm'], rot_err_deg=o['rot_err_deg']),
-                               hip_ate_rmse_cm=ha.tolist(), hip_depth_l1_cm=hl.tolist()), f, indent=1)
-        prior = o['prior_only']
-        assert 0.4 * o['ate_rmse_cm'] <= float(np.median(ha)) <= 2.5 * o['ate_rmse_cm'], (ha.tolist(), o['ate_rmse_cm'])
-        # (medians on both sides: a run of either pipeline that drifts - one in three to five does on the ScanNet config - takes its depth L1 with it)
-        assert abs(held(ha, hl) / o['depth_l1_cm'] - 1) <= (0.08 if name == 'roomfull' else 0.2), (hl.tolist(), o['depth_l1_cm'])
-        assert float(np.median(ha)) < prior['dead_reckoning_ate_cm'] / 1.5
-        return
-    rows = []
-    for o in fx:
-        c = o['config']
-        cfg = AR.make_cfg(os.path.join(ROOT, c['file']), c['frames'], c['rays_per_iteration'], c['iters_scale'], None, c['seed'], int(c['color_refine']), c['scene'])
-        res = AR.run_product(cfg)
-        rows.append(dict(seed=c['seed'], hip_ate=res['ate_rmse_cm'], oracle_ate=o['ate_rmse_cm'], hip_l1=res['depth_l1_cm'], oracle_l1=o['depth_l1_cm'],
-                         hip_rot=res['rot_err_deg'], oracle_rot=o['rot_err_deg'], prior=o['prior_only'], hip_wall_s=res['wall_s'], oracle_wall_s=o['wall_s']))
-    ha, oa = np.array([r['hip_ate'] for r in rows]), np.array([r['oracle_ate'] for r in rows])
-    hl, ol = np.array([r['hip_l1'] for r in rows]), np.array([r['oracle_l1'] for r in rows])
-    n = len(rows)
-    se = float(np.sqrt(ha.var(ddof=1) / n + oa.var(ddof=1) / n))
-    summary = dict(config=fx[0]['config'], runs=rows, ate_mean_cm=dict(hip=float(ha.mean()), oracle=float(oa.mean())),
-                   ate_sd_cm=dict(hip=float(ha.std(ddof=1)), oracle=float(oa.std(ddof=1))), ate_mean_rel_diff=float(ha.mean() / oa.mean() - 1),
-                   ate_diff_standard_error_cm=se, depth_l1_mean_cm=dict(hip=float(hl.mean()), oracle=float(ol.mean())),
-                   depth_l1_max_rel_diff=float(np.abs(hl / ol - 1).max()))
+    assert len(fx) >= 3, 'oracle fixtures missing (tools/accuracy_run.py --pipeline oracle)'
+    c = fx[0]['config']
+    res = []
+    for seed in range(c['seed'], c['seed'] + N_PRODUCT_RUNS):
+        cfg = AR.make_cfg(os.path.join(ROOT, c['file']), c['frames'], c['rays_per_iteration'], c['iters_scale'], None, seed, int(c['color_refine']), c['scene'])
+        res.append(AR.run_product(cfg))
+    ha, hl = np.array([r['ate_rmse_cm'] for r in res]), np.array([r['depth_l1_cm'] for r in res])
+    oa, ol = np.array([o['ate_rmse_cm'] for o in fx]), np.array([o['depth_l1_cm'] for o in fx])
+    ok_a, rec_a = WL.indistinguishable(ha, oa)
+    ok_l, rec_l = WL.indistinguishable(hl, ol)
+    prior = fx[0]['prior_only']
+    summary = dict(config=c, prior_only=prior,
+                   runs=[dict(seed=c['seed'] + k, hip_ate=r['ate_rmse_cm'], hip_l1=r['depth_l1_cm'], hip_rot=r['rot_err_deg'], hip_wall_s=r['wall_s']) for k, r in enumerate(res)],
+                   oracle_runs=[dict(seed=o['config']['seed'], ate=o['ate_rmse_cm'], l1=o['depth_l1_cm'], rot=o['rot_err_deg'], wall_s=o['wall_s']) for o in fx],
+                   ate_rmse_cm=dict(rec_a, a='product', b='oracle'), depth_l1_cm=dict(rec_l, a='product', b='oracle'),
+                   statement=f"ATE RMSE: product {rec_a['mean_a']:.3f} cm vs oracle {rec_a['mean_b']:.3f} cm ({100 * rec_a['rel_diff']:+.1f} %), indistinguishable at "
+                             f"+-{100 * rec_a['resolvable_rel']:.0f} % (95 % Welch, n = {rec_a['n_a']} / {rec_a['n_b']}); depth L1: {rec_l['mean_a']:.4f} vs "
+                             f"{rec_l['mean_b']:.4f} cm ({100 * rec_l['rel_diff']:+.1f} %), +-{100 * rec_l['resolvable_rel']:.0f} %")
     out = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(out):
         with open(os.path.join(out, f'accuracy_{name}.json'), 'w') as f:
             json.dump(summary, f, indent=1)
-    prior = rows[0]['prior']
-    assert float(np.abs(hl / ol - 1).max()) <= 0.05, summary['depth_l1_max_rel_diff']
-    assert abs(hl.mean() / ol.mean() - 1) <= 0.03
-    assert ha.max() < prior['one_step_ate_cm'] and 3.0 * ha.max() <= prior['dead_reckoning_ate_cm']
-    assert oa.max() < prior['one_step_ate_cm'] and 3.0 * oa.max() <= prior['dead_reckoning_ate_cm']
-    assert abs(ha.mean() - oa.mean()) <= max(0.05 * oa.mean(), 3.0 * se), (float(ha.mean()), float(oa.mean()), se)
+    print(summary['statement'])
+    assert ok_a, ('ATE RMSE', rec_a)
+    assert ok_l, ('depth L1', rec_l)
+    # the tracker does its job: the median run beats the one-step constant-speed prior (config 1: by any margin; the 2 000-ray configs lose
+    # more frames) and dead reckoning by 1.5 x
+    assert float(np.median(ha)) < (prior['one_step_ate_cm'] if name in ('room', 'roomfull') else prior['dead_reckoning_ate_cm'])
+    assert float(np.median(ha)) < prior['dead_reckoning_ate_cm'] / 1.5

@@ -45,6 +45,11 @@ for name in ('room', 'roomfull', 'tum', 'scannet'):
     runs = [dict(seed=h['config']['seed'], **brief(h)) for h in hip]
     if os.path.exists(test):
         t = json.load(open(test))
+        for k in ('ate_rmse_cm', 'depth_l1_cm'):          # the Welch records of tests/test_accuracy.py (round 6): interval, resolvable difference
+            if isinstance(t.get(k), dict) and 'resolvable_rel' in t[k]:
+                c.setdefault('welch', {})[k] = {q: (round(v, 5) if isinstance(v, float) else v) for q, v in t[k].items()}
+        if 'statement' in t:
+            c['statement'] = t['statement']
         if 'runs' in t:
             runs += [dict(seed=r['seed'], ate_rmse_cm=round(r['hip_ate'], 4), depth_l1_cm=round(r['hip_l1'], 4), rot_err_deg=round(r['hip_rot'], 4),
                           wall_s=r['hip_wall_s'], source='tests/test_accuracy.py') for r in t['runs']]
@@ -68,4 +73,6 @@ with open(dst, 'w') as f:
     json.dump(out, f, indent=1)
 print(dst)
 for n, c in out['configs'].items():
+    if 'statement' in c:
+        print(n, ':', c['statement'])
     print(n, 'oracle ATE', c['oracle']['ate_rmse_cm'], '| hip ATE', c.get('hip', {}).get('ate_rmse_cm'), '| L1 ratio', c.get('depth_l1_mean_hip_over_oracle'))
