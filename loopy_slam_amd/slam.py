@@ -19,7 +19,7 @@ import types
 import numpy as np
 import torch
 
-from . import _ffi, core, optim, steps, synthetic
+from . import _ffi, core, optim, parallel, steps, synthetic
 from .common import get_camera_from_tensor, get_tensor_from_camera, get_rays, get_samples, get_rays_from_uv
 
 

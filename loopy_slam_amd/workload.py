@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 
 import torch
 
-from . import core, optim, steps, synthetic as syn
+from . import core, optim, parallel, steps, synthetic as syn
 from .common import get_tensor_from_camera
 
 
@@ -80,6 +80,7 @@ class FrameWorkload:
     def __init__(self, eng, budget=None, seed=1219, dist=None, cloud=None, intr=None):
         """cloud: (pos, geo, col, n_rooms) device tensors of an already built map (bench.py: the three budgets share one cloud).
         intr: camera dict as synthetic.TUM_INTR (the default: 640 x 480; the host-emulator test uses a few hundred pixels)."""
+        self.dist = dist            # parallel.DistContext or None
         self.eng, self.b = eng, budget or Budget()
         b = self.b
         dev = eng.device
@@ -201,15 +202,26 @@ class FrameWorkload:
     def render_frame(self, k):
         """Renderer.render_img of keyframe k: all H*W rays in one fused pass."""
         eng, H, W = self.eng, self.H, self.W
+        # several ranks: each renders ONE contiguous range of whole 3000-ray groups (SURVEY §8e; parallel.ray_range) and the ranges are
+        # exchanged with one sum all-reduce of the zero-padded outputs - the frame of slam.Renderer.render_img on every rank
+        dist = self.dist if (self.dist is not None and self.dist.world > 1) else None
+        lo, hi = parallel.ray_range(H * W, dist.rank, dist.world, 3000) if dist is not None else (0, H * W)
         if self.img_state is None:
             jj, ii = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=eng.device), torch.arange(W, dtype=torch.float32, device=eng.device), indexing='ij')
-            self._img_ij = (ii.reshape(-1).contiguous(), jj.reshape(-1).contiguous())
-            self.img_state = core.RenderState(eng, H * W, self.cfg.S)
+            self._img_ij = (ii.reshape(-1)[lo:hi].contiguous(), jj.reshape(-1)[lo:hi].contiguous())
+            self.img_state = core.RenderState(eng, hi - lo, self.cfg.S)
+            self.img_full = [eng.zeros(H * W), eng.zeros(H * W), eng.zeros(H * W, 3)] if dist is not None else None
         ro, rd = syn.pixel_rays(self.c2w_stack[k], *self._img_ij, self.cam)
-        gd = self.depth_stack[k].reshape(-1).contiguous()
-        r2 = self.r2_stack[k].reshape(-1) if self.r2_stack is not None else None          # (dynamic radii: the frame's own query-radius map)
+        gd = self.depth_stack[k].reshape(-1)[lo:hi].contiguous()
+        r2 = self.r2_stack[k].reshape(-1)[lo:hi].contiguous() if self.r2_stack is not None else None          # (dynamic radii: the frame's own query-radius map)
         core.render_forward(eng, self.cfg, self.img_state, ro, rd, gd, self.knn, self.pos, self.geo, self.col, self.dec, 'color', stats_chunk=3000,
                             r2_ray=r2)
+        if dist is not None:
+            st = self.img_state
+            for t in self.img_full:
+                t.zero_()
+            self.img_full[0][lo:hi], self.img_full[1][lo:hi], self.img_full[2][lo:hi] = st.depth, st.var, st.color
+            self.img_frame = dist.gather_ranges(self.img_full, lo, hi)
         return self.img_state
 
     def step(self, full=False):
