@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--points', type=int, default=100_000)
@@ -187,6 +187,52 @@ def main():
                                         f'window {bo.window}, ' + ('dynamic radii, ' if bo.dynamic_radius else '') + ('exposure encoding, ' if bo.exposure else '') +
                                         f'mapped-frame extras every {bo.every_frame}th step, N={wo.b.n_points} points'}
             del wo
+        # BASELINE configs 4 / 5's single-GPU content at THEIR map sizes: the map grows by rooms at the online density (synthetic.build_cloud_online:
+        # one 6 x 4 x 3 m room per 100 000 points, the camera in the last one - the rest is dead weight for the index and the tables, as
+        # in a long sequence): (i) the Replica budget's full step on a 2 000 000-point map (config 4's merged cloud), (ii) ONE end-of-sequence
+        # refinement call over ALL rows of a 5 000 000-point map with half-precision feature tables (config 5: every row trainable, colour
+        # decoder frozen, 10 000 rays per iteration, Mapper.py:884-897; LK_FLAG_FEATS_F16)
+        from loopy_slam_amd import steps as _steps, synthetic as _syn
+
+        def grown(n_rooms, seed):
+            base = cloud_dev[0][:budget.n_points // 3 * 3]
+            pos = torch.cat([base + _syn.room_offset(r, eng.device) for r in range(n_rooms)], 0).contiguous()
+            g = torch.Generator(device=eng.device).manual_seed(seed)
+            return (pos, 0.1 * torch.randn(pos.shape[0], 32, generator=g, device=eng.device), 0.1 * torch.randn(pos.shape[0], 32, generator=g, device=eng.device), n_rooms)
+
+        big = workload.FrameWorkload(eng, workload.Budget(n_points=budget.n_points * 20), cloud=grown(20, 7))
+        big.step(full=True); big.step()
+        big.frame_no = 0
+        barrier()
+        t0o = time.perf_counter()
+        for _ in range(5):
+            big.step(full=True)
+        barrier()
+        dto = (time.perf_counter() - t0o) / 5
+        others['replica_2m'] = {'ms_per_step': 1e3 * dto, 'frames_per_s': 1.0 / dto, 'rays_per_s': budget.rays_per_frame / dto, 'steps': 5,
+                                'rays_per_step': budget.rays_per_frame, 'n_points': big.n,
+                                'workload': f'the headline budget (40 x 1500 + 60 x 5000 rays, mapped-frame extras on step 1 of 5) on a {big.n}-point map (20 rooms)'}
+        del big
+        bo = workload.Budget.tum(n_points=budget.n_points * 50)      # plain colour model, 10 000 mapping rays, per-pixel dynamic radii
+        ref = workload.FrameWorkload(eng, bo, cloud=grown(50, 11))
+        geo16, col16 = ref.geo.half(), ref.col.half()
+        mo = _steps.MapOptimizer(eng, ref.cfg, ref.dec, ref.knn, ref.pos, geo16, col16, None, bo.map_rays, workload.MAP_LRS, w_color=0.1, fix_color_decoder=True)
+        n_it, n_geo = 300, 90                 # one optimize_map call of the refinement's size class (mapping.iters 300, geo_iter_ratio 0.3)
+        rnd = ref._draws(n_it, bo.map_rays, ref.H * ref.W)
+        fid = (torch.arange(bo.map_rays, dtype=torch.int32) % bo.window).to(eng.device)
+        log = eng.zeros(n_it, 4)
+        for rep in range(2):                  # the second call is timed (the first allocates)
+            mo.new_frame(None, None)
+            barrier()
+            t0o = time.perf_counter()
+            mo.run(n_it, n_geo, ref.frames, rnd, fid, (0, ref.H, 0, ref.W), ref.intr, ref.H, ref.W, log)
+            barrier()
+            dto = time.perf_counter() - t0o
+        others['refine_5m_f16'] = {'ms_per_call': 1e3 * dto, 'ms_per_iteration': 1e3 * dto / n_it, 'rays_per_s': n_it * bo.map_rays / dto, 'iterations': n_it,
+                                   'n_points': ref.n, 'feature_tables': 'float16 (LK_FLAG_FEATS_F16), gradients / Adam moments fp32',
+                                   'workload': f'one whole-map refinement call: {n_geo} geometry + {n_it - n_geo} colour iterations x {bo.map_rays} rays, every row of the '
+                                               f'{ref.n}-point map trainable (rows = NULL: only rows that received a gradient are stepped), colour decoder frozen'}
+        del mo, ref, geo16, col16
     if world > 1:
         t = torch.tensor([dt, dt_iter, dt_host], device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,7 +296,17 @@ def main():
             rk = profile.roofline(kall, budget, kn)
             if rk is not None:
                 out['roofline_all_kernels'].append({k: (round(rk[k], 4) if isinstance(rk[k], float) else rk[k])
-                                                    for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us') if k in rk})
+                                                    for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'bound_from',
+                                                              'measured_bytes_per_launch_avg', 'algorithmic_flops_per_launch_avg', 't_mfma_over_t_hbm_measured') if k in rk})
+        # the whole 'color' iteration (57 % of the step) against SURVEY 8(d)'s algorithmic bytes, from the committed per-stage counter table
+        modes, src_st = profile.stage_traffic()
+        if modes and 'color' in modes and out['roofline'] is not None:
+            c = modes['color']
+            out['roofline']['color_iteration'] = {
+                'traffic_mb': round(c['read_mb_per_iteration'] + c['written_mb_per_iteration'], 1), 'algorithmic_mb': c['algorithmic_mb_per_iteration'],
+                'traffic_ratio': c['traffic_ratio'], 'source': src_st,
+                'note': 'L2-fabric bytes of every launch of one 5 000-ray colour iteration (separate --pmc FETCH_SIZE / WRITE_SIZE passes, tools/stage_traffic.sh) '
+                        '/ 5 000 rays x 31.6 KB'}
         out['kernel_ms_per_step'] = {k: round(v['total_ms'], 3) for k, v in sorted(kall.items(), key=lambda kv: -kv[1]['total_ms'])}
         if not args.no_cpu_baseline:
             import bench_cpu_baseline

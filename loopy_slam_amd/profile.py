@@ -140,6 +140,51 @@ def pmc_traffic(kernel, path=None):
     return None, None
 
 
+# rocprofv3 kernel name (template arguments stripped) -> the timer name it is booked under (lk_api.hip: kKernelNames)
+TIMER_OF = {'k_decode_fwd': 'k_decode_fwd', 'k_relpos_decode_fwd': 'k_decode_fwd', 'k_relpos_fwd': 'k_relpos_fwd', 'k_wgrad': 'k_wgrad',
+            'k_feat_gather': 'k_feat_gather', 'k_relpos_bwd_fused': 'k_relpos_bwd', 'k_relpos_bwd': 'k_relpos_bwd', 'k_relpos_interp_bwd': 'k_relpos_bwd',
+            'k_sample_interp': 'k_sample_interp', 'k_sample_interp_pose': 'k_sample_interp', 'k_interp_repack': 'k_sample_interp'}
+
+
+def stage_traffic(path=None):
+    """The committed per-STAGE counter table (profiles/r<N>_stage_traffic.json, tools/stage_traffic.sh: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes over ONE iteration type at a time): {mode: {kernels: {name: {launches_per_iteration, read_mb_per_launch, ...}}}} or None."""
+    import glob
+    import json
+    import os
+    import re
+    if path is None:
+        cands = glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r*_stage_traffic.json'))
+        if not cands:
+            return None, None
+        path = max(cands, key=lambda f: int(re.match(r'r(\d+)_', os.path.basename(f)).group(1)))
+    try:
+        with open(path) as f:
+            return json.load(f)['modes'], f'profiles/{os.path.basename(path)}'
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
+def measured_bytes_per_step(b, kernel, modes):
+    """L2-fabric bytes (read + written) of the launches booked under timer name `kernel` in one step of budget b, from the per-stage
+    table: sum over the iteration types of iterations x launches per iteration x MB per launch.  The decoder backward's two names are the
+    tracker's (`k_decode_bwd<.., .., false>` with ray gradients) and the mapper's launches of the same rocprofv3 kernel family."""
+    n_it = {'color': b.map_iters - b.map_geo_iters, 'geo': b.map_geo_iters, 'track': b.track_iters}
+    tot, seen = 0.0, False
+    for mode, n in n_it.items():
+        for name, k in (modes.get(mode, {}).get('kernels') or {}).items():
+            base = name.split('<')[0]
+            if base == 'k_decode_bwd':
+                t = 'k_decode_bwd_track' if mode == 'track' else 'k_decode_bwd'
+            else:
+                t = TIMER_OF.get(base)
+            if t != kernel:
+                continue
+            seen = True
+            tot += n * k['launches_per_iteration'] * (k['read_mb_per_launch'] + k['written_mb_per_launch']) * 1e6
+    return tot if seen else None
+
+
 def dominant_kernel(kstat):
     """The kernel with the largest summed duration over the profiled step; kernels within 3 % of it are level (run-to-run scatter) and the
     longer AVERAGE LAUNCH decides.  (Rounds 4-5: the decoder backward's tracker and mapper launches were timed under ONE name and their
@@ -171,6 +216,20 @@ def roofline(kstat, budget, kernel):
         path = '+'.join(sorted(p for p, f in model['flops_by_path'].items() if f > 0))
     t_hbm = nbytes / (PEAK_HBM_GBS * 1e9)
     out = {'kernel': kernel, 'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'], 'traffic': None}
+    # Which roof binds the kernel is decided from MEASURED bytes where the per-stage counter table has them (round-5 review: the training
+    # forward was labelled `mfma` at 0.11 of the matrix roof while it WRITES 146 MB of saved activations per launch - it sits at 0.4 of
+    # the HBM roof): t_hbm = counter bytes / 8 TB/s against t_mfma = algorithmic flops / the pipe's roof; `achieved` on the HBM side is
+    # then counter bytes / time (the bytes the kernel really moves), `algorithmic_bytes_per_launch_avg` stays the model's figure beside it
+    modes, src_st = stage_traffic()
+    meas = measured_bytes_per_step(budget, kernel, modes) if modes else None
+    if meas is not None:
+        out['measured_bytes_per_launch_avg'] = meas / model['launches']
+        out['measured_bytes_source'] = src_st
+        t_meas = meas * n_steps / (PEAK_HBM_GBS * 1e9)
+        out['t_mfma_over_t_hbm_measured'] = (t_mfma / t_meas) if t_meas > 0 else None
+        if t_meas > t_mfma and t_meas > t_hbm:
+            nbytes, t_hbm = meas * n_steps, t_meas
+            out['bound_from'] = 'measured counter bytes'
     if t_mfma >= t_hbm:
         out.update(bound='mfma', achieved=flops / secs / 1e12, peak=peak_mfma, unit='TFLOP/s', mfma_path=path,
                    frac_of_f32_mfma_peak=flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS)

@@ -452,6 +452,17 @@ class Mapper:
         self.last_add_counts, self.last_frame_pts_add, self.last_num_joint_iters = [], 0, 0
         self.use_dynamic_radius = cfg['use_dynamic_radius']
         self.keyframe_list, self.keyframe_dict = [], []
+        # SEGMENTS (the reference's map fragments, neural_point.py:1300-1326): the loop-closure machinery that owns them is out of scope,
+        # but the end-of-sequence refinement optimises over ONE KEYFRAME PER SEGMENT (Mapper.py:386-396, neural_point.py:1424-1433) - so
+        # the segmentation of the trajectory is kept: a segment starts at frame 0 and at every mapped frame whose tracked pose has left the
+        # last segment's keyframe pose by more than segment_rel_trans metres or whose optical axis makes a cosine below segment_rot_cos
+        # with it (segment_strategy 'rot_trans'; 'fixed': every fixed_segment_size frames).  `segments` is a plain list of
+        # {idx, color, depth, est_c2w, r2_query, exposure_feat} records: a caller that runs its own segmentation (a loop-closure module)
+        # may replace or extend it before the last frame is mapped
+        self.segments = []
+        self.segment_strategy = m.get('segment_strategy', 'rot_trans')
+        self.segment_rot_cos, self.segment_rel_trans = m.get('segment_rot_cos', 0.94), m.get('segment_rel_trans', 0.30)
+        self.fixed_segment_size = m.get('fixed_segment_size', 50)
         # draws on the device, like the reference's select_uv (common.py:156-172): no host RNG + upload between GPU launches
         self.gen = torch.Generator(device=self.eng.device).manual_seed(cfg.get('setup_seed', 1219) + 7)
         # Multi-GPU (slam.dist, loopy_slam_amd/parallel.py): everything that changes the MAP or the window - insertion pixels, keyframe
@@ -583,10 +594,10 @@ class Mapper:
         sel = []
         if len(keyframe_dict) > 0:
             if segments:
-                # final refinement (Mapper.py:398-406): the reference optimises over one keyframe per map FRAGMENT (loop-closure
-                # bookkeeping, out of scope here); this single-segment build spreads the same budget over its keyframes
-                n_kf = min(len(keyframe_dict), max(1, 2 * self.mapping_window_size - 1))
-                sel = sorted(set(int(round(x)) for x in np.linspace(0, len(keyframe_dict) - 1, n_kf)))
+                # end-of-sequence refinement (Mapper.py:386-396): the window is one keyframe per SEGMENT - the frame that opened it, with
+                # the pose it was mapped at - all of them (`optimize_frame = list(range(len(keyframe_dict)))`), plus the current frame
+                keyframe_dict = self.segments if self.segments else keyframe_dict[:1]
+                sel = list(range(len(keyframe_dict)))
             elif self.keyframe_selection_method == 'global':
                 num = self.mapping_window_size - 2
                 sel = list(range(max(0, len(keyframe_dict) - 1 - num), len(keyframe_dict) - 1))
@@ -597,6 +608,7 @@ class Mapper:
         frames_d = [keyframe_dict[k]['depth'] for k in sel] + [cur_gt_depth]
         frames_c = [keyframe_dict[k]['color'] for k in sel] + [cur_gt_color]
         frames_p = [keyframe_dict[k]['est_c2w'] for k in sel] + [cur_c2w]
+        self.last_window_idx = [int(keyframe_dict[k]['idx']) for k in sel] + [int(idx)]       # frame indices of this call's window (logging, tests)
         grad_mag = r2_add_map = r2_query_map = None
         if self.use_dynamic_radius:                 # per-pixel radii of the current frame (Mapper.py:854-872)
             grad_mag, r2_add_map, r2_query_map = frame_radius_maps(eng, cfg, cur_gt_color)
@@ -672,6 +684,21 @@ class Mapper:
             return new[-1].to(cur_c2w).clone()
         return None
 
+    def new_segment(self, idx, cur_c2w):
+        """Mapper.check_new_fragment (Mapper.py:338-345) / NeuralPointCloud.check_rot_trans (neural_point.py:1317-1326) with
+        compute_rel_trans / compute_cos_rel_rot (common.py:759-777): does the mapped frame idx open a new segment?"""
+        if not self.segments:
+            return True
+        if self.segment_strategy == 'fixed':
+            return idx % self.fixed_segment_size == 0
+        if self.segment_strategy != 'rot_trans':
+            raise NotImplementedError(self.segment_strategy)
+        last = self.segments[-1]['est_c2w'].detach().cpu().float()
+        cur = cur_c2w.detach().cpu().float()
+        rel_trans = float((cur[:3, 3] - last[:3, 3]).norm(2))
+        cos = float(torch.dot(last[:3, 2], cur[:3, 2]))          # the optical axes R e_z of the two cameras
+        return rel_trans > self.segment_rel_trans or cos < self.segment_rot_cos
+
     def map_frame(self, idx, gt_color, gt_depth, gt_c2w, cur_c2w=None):
         """One mapped frame: the body of Mapper.run's loop (Mapper.py:835-1037) minus I/O and visualisation."""
         slam, cfg = self.slam, self.cfg
@@ -710,6 +737,10 @@ class Mapper:
             self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': gt_color, 'depth': gt_depth, 'est_c2w': cur_c2w.clone(),
                                        'r2_query': getattr(self, 'cur_r2_query', None),
                                        'exposure_feat': self.cur_exposure_feat.detach() if self.slam.encode_exposure else None})
+        if self.new_segment(idx, cur_c2w):
+            self.segments.append({'idx': idx, 'color': gt_color, 'depth': gt_depth, 'est_c2w': cur_c2w.clone(), 'gt_c2w': gt_c2w,
+                                  'r2_query': getattr(self, 'cur_r2_query', None),
+                                  'exposure_feat': self.cur_exposure_feat.detach() if self.slam.encode_exposure else None})
         self.prev_c2w = cur_c2w.clone()         # Mapper.py:1001
         slam.mapping_idx[0] = idx
         return self.last_log

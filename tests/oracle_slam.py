@@ -21,7 +21,7 @@ therefore see identical pixels and feature rows and can be compared pose for pos
 (tests/test_accuracy.py); on the GPU the device generator draws differently, the trajectories are two samples of the same
 process and only the METRICS are comparable.
 
-Out of scope, as in the product: loop closure / fragments ('segments' keyframes are this build's own single-segment spread), BA, the
+Out of scope, as in the product: loop closure / fragment MAPS (the segmentation of the trajectory is kept: 'segments' keyframes), BA, the
 image pre-passes that need absent libraries are the oracle's own restatements (H.radius_maps, H.top_grad_pixels)."""
 import math
 
@@ -117,6 +117,7 @@ class OracleSLAM:
         self.est = torch.zeros(self.n_img, 4, 4)
         self.gt = torch.zeros(self.n_img, 4, 4)
         self.keyframe_list, self.keyframe_dict = [], []
+        self.segments = []              # one record per segment of the trajectory (map_frame: _new_segment)
         self.prev_c2w = None
         self.exposure_feat = torch.zeros(cfg['model']['exposure_dim']) if self.exposure_on else None
         self.exposure_feat_all = []
@@ -266,9 +267,8 @@ class OracleSLAM:
         kd = self.keyframe_dict
         if len(kd) == 0:
             return []
-        if self.kf_method == 'segments':            # this build's single-segment spread (slam.Mapper.optimize_map)
-            n_kf = min(len(kd), max(1, 2 * self.window - 1))
-            return sorted(set(int(round(x)) for x in np.linspace(0, len(kd) - 1, n_kf)))
+        if self.kf_method == 'segments':            # one keyframe per segment, all of them (Mapper.py:386-396): optimize_map swaps the dict
+            return list(range(len(self.segments) if self.segments else 1))
         if self.kf_method == 'global':
             num = self.window - 2
             sel = list(range(max(0, len(kd) - 1 - num), len(kd) - 1))
@@ -333,6 +333,8 @@ class OracleSLAM:
         segments = self.kf_method == 'segments'
         sel = self._select_keyframes(color, depth, cur_c2w)
         kd = self.keyframe_dict
+        if segments:
+            kd = self.segments if self.segments else self.keyframe_dict[:1]
         grad_mag = r_add_map = r_query_map = None
         if self.dynamic:
             grad_mag, r_add_map, r_query_map = self.radius_maps(color)
@@ -462,7 +464,23 @@ class OracleSLAM:
             self.keyframe_dict.append({'gt_c2w': gt_c2w, 'idx': idx, 'color': color, 'depth': depth, 'est_c2w': cur_c2w.clone(),
                                        'r_query': getattr(self, 'cur_r_query', None),
                                        'exposure_feat': self.cur_exposure_feat if self.exposure_on else None})
+        # segment bookkeeping (Mapper.py:338-345, neural_point.py:1317-1326, common.py:759-777)
+        if self._new_segment(idx, cur_c2w):
+            self.segments.append({'idx': idx, 'color': color, 'depth': depth, 'est_c2w': cur_c2w.clone(), 'gt_c2w': gt_c2w,
+                                  'r_query': getattr(self, 'cur_r_query', None),
+                                  'exposure_feat': self.cur_exposure_feat if self.exposure_on else None})
         self.prev_c2w = cur_c2w.clone()
+
+    def _new_segment(self, idx, cur_c2w):
+        m = self.cfg['mapping']
+        if not self.segments:
+            return True
+        if m.get('segment_strategy', 'rot_trans') == 'fixed':
+            return idx % m.get('fixed_segment_size', 50) == 0
+        last = self.segments[-1]['est_c2w']
+        optical = torch.zeros(3); optical[2] = 1
+        cos = torch.dot(last[:3, :3] @ optical, cur_c2w[:3, :3] @ optical)
+        return bool((cur_c2w[:3, -1] - last[:3, -1]).norm(2) > m.get('segment_rel_trans', 0.30)) or bool(cos < m.get('segment_rot_cos', 0.94))
 
     def run(self, n_frames=None, callback=None):
         n = n_frames or self.n_img

@@ -376,6 +376,9 @@ def test_final_refinement_optimises_the_whole_map(backend):
     eng = make_engine(backend)
     cfg = mini_cfg()
     cfg['mapping'].update(iters=2, color_refine=True, pixels=96, iters_first=8, geo_iter_first=3)
+    # segments (Mapper.py:338-345, neural_point.py:1317-1326): the synthetic camera moves 2-7 mm per frame - with a 5 mm threshold the mapped
+    # frame 2 opens a segment behind frame 0's, and the refinement's window is the segments that exist when the last frame is mapped + that frame
+    cfg['mapping'].update(segment_strategy='rot_trans', segment_rel_trans=0.005, segment_rot_cos=0.0)
     ps = slam.Point_SLAM(cfg, None, eng=eng)
     calls = []
     orig = ps.mapper.optimize_map
@@ -386,13 +389,23 @@ def test_final_refinement_optimises_the_whole_map(backend):
         w0 = ps.shared_decoders.dec.blob.clone()
         r = orig(num_joint_iters, idx, *a, **k)
         moved = (ps.npc.get_geo_feats()[:n0] != geo0).any(1)
-        calls.append(dict(idx=idx, iters=num_joint_iters, refine=k.get('color_refine', False), added=ps.npc.pts_num() - n0,
+        calls.append(dict(idx=idx, iters=num_joint_iters, refine=k.get('color_refine', False), added=ps.npc.pts_num() - n0, window=list(ps.mapper.last_window_idx),
                           frac_moved=float(moved.float().mean()), w_moved=int((ps.shared_decoders.dec.blob != w0).sum())))
         return r
     ps.mapper.optimize_map = spy
     ps.run()
     last = [c for c in calls if c['idx'] == 3]
     assert len(last) == 5 and all(c['refine'] and c['iters'] == 2 * 10 // 5 and c['added'] == 0 for c in last)
+    step = [float((ps.estimate_c2w_list[k + 1][:3, 3] - ps.estimate_c2w_list[k][:3, 3]).norm()) for k in range(3)]
+    seg = [s['idx'] for s in ps.mapper.segments]
+    assert seg[0] == 0 and 2 <= len(seg) <= 3 and all(0.001 < x < 0.02 for x in step), (seg, step)
+    # the refinement's window: one keyframe per segment that existed when the last frame was mapped, plus that frame
+    assert all(c['window'] == [i for i in seg if i < 3] + [3] for c in last), (last[0]['window'], seg)
+    ps.mapper.segments = ps.mapper.segments[:1]            # a caller's own segmentation: one segment -> {0} + the current frame
+    ps.mapper.keyframe_selection_method = 'segments'
+    ps.mapper.optimize_map(2, 3, *ps.frame_reader[3][1:3], ps.frame_reader[3][3], ps.mapper.keyframe_dict, ps.mapper.keyframe_list,
+                           ps.estimate_c2w_list[3].to(eng.device), color_refine=True)
+    assert ps.mapper.last_window_idx == [0, 3]
     # rows far outside the last frustum moved too; only the two embedding matrices of the decoders may change (fix_color_decoder)
     assert min(c['frac_moved'] for c in last) > 0.5
     normal = [c for c in calls if c['idx'] == 0][0]         # first frame: iters_first with colour iterations, all decoder weights move

@@ -55,6 +55,9 @@ def durations(mode):
     return a
 
 
+import json
+JS = {'what': 'per iteration TYPE and kernel: launches per iteration, average duration (us), L2-fabric read / written MB per launch (read = 2 x FETCH_SIZE, '
+              'MI355X_MICROARCH.md §HBM); tools/stage_traffic.py', 'modes': {}}
 print(f'# HBM-side traffic per iteration TYPE ({tag}): rocprofv3 passes over `python tools/mode_trace.py <mode> {iters} --repeat {calls - 1}`')
 print()
 print('Three passes per mode (`--kernel-trace --stats`, `--kernel-trace --pmc FETCH_SIZE`, `--kernel-trace --pmc WRITE_SIZE`); counters = the L2\'s')
@@ -80,6 +83,9 @@ for mode in modes:
         if (r_mb + w_mb) / n_it < 0.05 and us / n_it < 0.5:
             continue
         rows.append((k, n / n_it, us / max(du[k][0], 1), r_mb / max(fe[k][0], 1), w_mb / max(wr[k][0], 1), r_mb / n_it, w_mb / n_it))
+        JS['modes'].setdefault(mode, {'rays': rays, 'kernels': {}})['kernels'][k] = dict(
+            launches_per_iteration=round(n / n_it, 4), avg_us=round(us / max(du[k][0], 1), 2), read_mb_per_launch=round(r_mb / max(fe[k][0], 1), 3),
+            written_mb_per_launch=round(w_mb / max(wr[k][0], 1), 3))
     print()
     print(f'## {mode} (R = {rays})')
     print()
@@ -94,3 +100,9 @@ for mode in modes:
     print()
     print(f'**Per iteration: read {tot_r / n_it:.0f} MB + written {tot_w / n_it:.0f} MB = {tot:.0f} MB; sum of kernel durations {tot_us / n_it:.0f} us; '
           f'SURVEY §8(d) algorithmic bytes {algo:.0f} MB ({rays} rays x {per_ray / 1e3:.1f} KB) -> traffic ratio {tot / algo:.2f}.**')
+    JS['modes'][mode].update(read_mb_per_iteration=round(tot_r / n_it, 1), written_mb_per_iteration=round(tot_w / n_it, 1), algorithmic_mb_per_iteration=round(algo, 1),
+                             traffic_ratio=round(tot / algo, 3), kernel_us_per_iteration=round(tot_us / n_it, 1))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.isdir(os.path.join(root, 'gpurun_out')):
+    with open(os.path.join(root, 'gpurun_out', f'stage_traffic_{tag}.json'), 'w') as f:
+        json.dump(JS, f, indent=1)
