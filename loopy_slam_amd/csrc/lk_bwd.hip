@@ -117,6 +117,10 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     // the derivative mask softplus'(z_i) as the forward stored it (unorm16 pairs, this lane's 16 values contiguous): + LK_COL_SLAYER(P, layer)
     const unsigned* act_col_s = reinterpret_cast<const unsigned*>(a.act + (size_t)a.P * LK_ACT_GEO_A) + (size_t)sp * 64 + 16 * w + 8 * h;
+    // ... or, behind a TRACKER-mode forward (lk_kernels.h: LK_ACT_COL_A), the fp32 a_i rows.  Only the TL instantiations can meet one (the
+    // launcher keeps tracker-mode descriptors out of the mapper-loop form), so the mapper form carries no second load path
+    const bool a32 = TL && (a.flags & LK_FLAG_TRACKER) != 0;
+    const float* act_col_a = a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128 + w * 32;
     const float* act_col_h = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128;
     float4 draw;
     if (a.ml_on) { float t0, t1, t2; draw = lk_map_draw(a.ml, sp, false, &t0, &t1, &t2); }
@@ -199,11 +203,13 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     constexpr int NPF = DEEP ? 8 : 4;
     Piece un[2], wn[NPF];
     u32x4 sv0, sv1;
+    f32x16 av;
     auto prefetch = [&](int i) {
         const u32x4* ut = FB + PC::tr(15 + i);
 #pragma unroll
         for (int G = 0; G < 2; ++G) un[G] = PC::load(ut, 1, 2 * w + G, 0, lane);
-        sv0 = *reinterpret_cast<const u32x4*>(act_col_s + LK_COL_SLAYER(a.P, i)); sv1 = *reinterpret_cast<const u32x4*>(act_col_s + LK_COL_SLAYER(a.P, i) + 4);
+        if (TL && a32) av = ct_load32(act_col_a + LK_COL_LAYER(a.P, i), lane);
+        else { sv0 = *reinterpret_cast<const u32x4*>(act_col_s + LK_COL_SLAYER(a.P, i)); sv1 = *reinterpret_cast<const u32x4*>(act_col_s + LK_COL_SLAYER(a.P, i) + 4); }
         if (i >= 1) {
             const u32x4* wt = FB + PC::tr(10 + i);
 #pragma unroll
@@ -220,10 +226,15 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     prefetch(4);
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
+        if (TL && a32) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            dy[2 * q] = dh[2 * q] * lk_unorm16_lo(sv0[q]); dy[2 * q + 1] = dh[2 * q + 1] * lk_unorm16_hi(sv0[q]);
-            dy[8 + 2 * q] = dh[8 + 2 * q] * lk_unorm16_lo(sv1[q]); dy[8 + 2 * q + 1] = dh[8 + 2 * q + 1] * lk_unorm16_hi(sv1[q]);
+            for (int q = 0; q < 16; ++q) dy[q] = dh[q] * lk_softplus100_grad_from_out(av[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dy[2 * q] = dh[2 * q] * lk_unorm16_lo(sv0[q]); dy[2 * q + 1] = dh[2 * q + 1] * lk_unorm16_hi(sv0[q]);
+                dy[8 + 2 * q] = dh[8 + 2 * q] * lk_unorm16_lo(sv1[q]); dy[8 + 2 * q + 1] = dh[8 + 2 * q + 1] * lk_unorm16_hi(sv1[q]);
+            }
         }
         // d y_i rows for the weight-gradient jobs (W_i and, through the auxiliary columns of job i, U_{i-1}: lk_kernels.h LkFcPost).
         // (Round 1 stored a register COPY of its rows, believing that the stores must not read registers the next product
@@ -555,7 +566,8 @@ int lk_launch_decode_bwd(const LkDecodeBwdArgs& a, hipStream_t st) {
     const dim3 grid(n_col + lk_cdiv(tiles, 4));
     // the geometry decoder's backward follows where d depth is bounded as well: unit-scale loss gradients WITHOUT ray gradients (with them
     // the caller is the tracker, whose d depth = 1 / sqrt(var) is not)
-    const bool gh16 = h16 && !(a.flags & LK_FLAG_GRAD_RAYS);
+    // (and not behind a tracker-mode forward, whose saved activations have the fp32 layout only the other instantiations read)
+    const bool gh16 = h16 && !(a.flags & (LK_FLAG_GRAD_RAYS | LK_FLAG_TRACKER));
     if (gh16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true, true>), grid, dim3(256), 0, st, a, n_col);
     else if (gh16) hipLaunchKernelGGL((k_decode_bwd<true, false, true>), grid, dim3(256), 0, st, a, n_col);
     else if (h16 && deep) hipLaunchKernelGGL((k_decode_bwd<true, true>), grid, dim3(256), 0, st, a, n_col);

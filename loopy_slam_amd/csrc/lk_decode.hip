@@ -253,6 +253,9 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     // this sample's row of layer 0; layer L is LK_COL_LAYER(P, L) floats further (layer-major, lk_kernels.h)
     // (the derivative mask: 64 words per sample and layer; wave w, lane half h own words [16 w + 8 h, + 8) - a lane's 16 values are contiguous)
     unsigned* act_col_s = save ? reinterpret_cast<unsigned*>(a.act + (size_t)a.P * LK_ACT_GEO_A) + (size_t)sp * 64 + 16 * w + 8 * h : nullptr;
+    // tracker mode (lk_kernels.h: LK_ACT_COL_A): the fp32 a_i rows instead, [layer][P][128] in the same region
+    const bool a32 = (a.flags & LK_FLAG_TRACKER) != 0;
+    float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128 + w * 32 : nullptr;
     float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128 : nullptr;
     // embedding (40 units = blocks 0, 1 and a quarter of 2) and interpolated feature: B operands of two / five products, split once.
     // The forty sin / cos values are the same for the four waves: wave w evaluates register group g = w of block 0 (units 8 w + 4 h + t),
@@ -338,7 +341,9 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = lk_softplus100(acc[r]);          // acc started from the layer's bias
         u32x4 sg0 = {0u, 0u, 0u, 0u}, sg1 = {0u, 0u, 0u, 0u};
-        if (save_s) {        // softplus'(z) = sigmoid(100 z) = 1 - exp(-100 a): all the backward wants of a (lk_common.h: lk_pack_unorm16)
+        f32x16 act;
+        if (save_s && a32) act = acc;
+        else if (save_s) {        // softplus'(z) = sigmoid(100 z) = 1 - exp(-100 a): all the backward wants of a (lk_common.h: lk_pack_unorm16)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 sg0[q] = lk_pack_unorm16(lk_softplus100_grad_from_out(acc[2 * q]), lk_softplus100_grad_from_out(acc[2 * q + 1]));
@@ -353,7 +358,8 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
 #pragma unroll
         for (int G = 0; G < 2; ++G) acc = lk_mma3h(un[G], cb[G], acc);
         __builtin_amdgcn_sched_barrier(0);
-        if (save_s && live) { *reinterpret_cast<u32x4*>(save_s) = sg0; *reinterpret_cast<u32x4*>(save_s + 4) = sg1; }
+        if (save_s && a32) ct_store_rows32(act_col_a + LK_COL_LAYER(a.P, L), act, live, lane);
+        else if (save_s && live) { *reinterpret_cast<u32x4*>(save_s) = sg0; *reinterpret_cast<u32x4*>(save_s + 4) = sg1; }
         if (save) ct_store_rows32(act_col_h + LK_COL_LAYER(a.P, L) + w * 32, acc, live, lane);
         if (buf >= 0) {
             ct_check_range<CHECK>(acc, a.status);

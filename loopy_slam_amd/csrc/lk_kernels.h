@@ -384,7 +384,12 @@ int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs
 //   a_i = act(z_i), z_i = W_i x_i + b_i, h_i = a_i + fc_c_i(c).  The colour trunk's backward needs a_i only for d y_i = d h_i softplus'(z_i):
 //   the forward stores that factor in 16 bits (lk_pack_unorm16; round 5 stored the a_i rows, 64 MB per 5 000-ray batch written and read back)
 #define LK_ACT_GEO_A (5 * 32)
-#define LK_ACT_COL_A (5 * 64)        // words: 128 unorm16 per sample and layer, lane-contiguous (LK_COL_SLAYER, decode_col_wg::finish)
+#define LK_ACT_COL_A (5 * 128)       // mapper mode uses the first 5 * 64 words: 128 unorm16 per sample and layer, lane-contiguous (LK_COL_SLAYER,
+                                     // decode_col_wg::finish); TRACKER MODE (LK_FLAG_TRACKER: the tracking loop, bundle adjustment) keeps the fp32 a_i rows
+                                     // [layer][P][128] - the pose gradient goes through 2 pi B cos(2 pi p B), |B| ~ 25-32, and amplifies a
+                                     // 7.6e-6 quantisation of the mask into visibly different pose trajectories (tests/test_steps_parity.py, BA case:
+                                     // 0.75 % instead of 0.006 % of the geometry rows more than 1e-4 from the oracle's after four iterations),
+                                     // and its 235-tile launches are latency-bound, not store-bound
 #define LK_ACT_COL_H (5 * 128)
 #define LK_ACT_COL_E 40       // colour Fourier embedding (input of layers 0 and 3)
 #define LK_ACT_FLOATS_PER_SAMPLE (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H + LK_ACT_COL_E)
