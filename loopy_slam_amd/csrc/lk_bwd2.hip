@@ -955,9 +955,13 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
 // pieces (hi + lo, lk_split8h; A' times 2^10 first: unit-scale loss gradients put d h around 1e-4) and multiplied with three
 // instructions of 32 cycles per 16 rows instead of eight fp32 instructions of 64 cycles, which did not overlap with the
 // VALU work either.  The tile is scaled back when it is stored.
+// Tile mode inside a workgroup (LkWgLds): the waves of a workgroup that work on the SAME unit leave ONE tile - the followers park theirs in
+// LDS (lds_out), the first of the run (the leader) adds them to its own behind the workgroup's one barrier and stores the sum.  2 048 tiles
+// of 16.6 KB per launch were 34 MB written and read back by the reduction launch; a run is ~3 waves long, so about a third are left.
+struct LkWgLds { float* lds_out; const float* lds_in; int n_in; bool barrier; };
 template <int NV, int KV, int MODE, bool H16>
 __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane,
-                                           float* __restrict__ tile, int rows, bool aux_t = false, float dsc = 1.0f) {
+                                           float* __restrict__ tile, int rows, bool aux_t = false, float dsc = 1.0f, LkWgLds wl = LkWgLds{nullptr, nullptr, 0, false}) {
     const int i = lane & 31, h = lane >> 5;
     // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
     const int ncol = n0 + NV * i, kcol = k0 + KV * i;
@@ -1064,6 +1068,13 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
             __builtin_amdgcn_sched_barrier(0);          // keep consume(s) -> refill(s) order: the ring IS the schedule
         }
     }
+    // tile element idx <- v: a follower parks it in LDS, the leader adds its followers' (fixed order) and stores
+    auto emit = [&](int idx, float v) {
+        if (wl.lds_out) { wl.lds_out[idx] = v; return; }
+        for (int f = 0; f < wl.n_in; ++f) v += wl.lds_in[(size_t)f * LK_WG_TILE + idx];
+        tile[idx] = v;
+    };
+    if (tile && wl.barrier && !wl.lds_out) __syncthreads();          // leader (or a wave alone in its run): the followers' tiles are in LDS
     if (tile && aux_t && KV == 1) {
         // the auxiliary columns (M = d y^T c, LkFcPost): stored TRANSPOSED, [column kc][row n of the unit], because their only reader
         // (fc_post_body) sums ONE column over the tiles - in the lane-major layout below that was one float out of every 128-byte line,
@@ -1071,7 +1082,8 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 #pragma unroll
         for (int bn = 0; bn < NV; ++bn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tile[i * 64 + NV * lk_frag_row(r, h) + bn] = acc[bn][0][r] * ISCALE;
+            for (int r = 0; r < 16; ++r) emit(i * 64 + NV * lk_frag_row(r, h) + bn, acc[bn][0][r] * ISCALE);
+        if (wl.barrier && wl.lds_out) __syncthreads();
         return;
     }
     if (tile) {        // partial tile [block (bn,bk)][register r][lane] + bias sums: 256-byte coalesced stores
@@ -1080,14 +1092,15 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 #pragma unroll
             for (int bk = 0; bk < KV; ++bk)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tile[((bn * KV + bk) * 16 + r) * 64 + lane] = acc[bn][bk][r] * ISCALE;
+                for (int r = 0; r < 16; ++r) emit(((bn * KV + bk) * 16 + r) * 64 + lane, acc[bn][bk][r] * ISCALE);
         if (k0 == 0) {
 #pragma unroll
             for (int b = 0; b < NV; ++b) {
                 const float v = (bsum[b] + __shfl_xor(bsum[b], 32)) * ISCALE;
-                if (h == 0) tile[4 * 16 * 64 + NV * i + b] = v;
+                if (h == 0) emit(4 * 16 * 64 + NV * i + b, v);
             }
         }
+        if (wl.barrier && wl.lds_out) __syncthreads();
         return;
     }
     // atomic flush: block (bn, bk), register r of lane (j = lane&31, h): n = n0 + NV*frag_row(r,h) + bn, k = k0 + KV*j + bk
@@ -1112,12 +1125,15 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 }
 
 template <int NV, int KV, bool H16>
-__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile, int rows, float dsc) {
+__device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane, float* tile, int rows, float dsc, LkWgLds wl) {
     const bool aux_t = J.k_aux > 0 && k0 >= J.k_aux;
-    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
-    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
-    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc);
+    if (J.a_mode == 0) wgrad_unit<NV, KV, 0, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc, wl);
+    else if (J.a_mode == 1) wgrad_unit<NV, KV, 1, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc, wl);
+    else wgrad_unit<NV, KV, 2, H16>(J, n0, k0, c0, stride, lane, tile, rows, aux_t, dsc, wl);
 }
+// tile y = 8 jl + x of a unit was stored iff its wave led a run: the first wave of the unit on its XCD, or the first wave of a workgroup
+// (wave slots are handed out four to a workgroup: slot & 3 == 0)
+__device__ __forceinline__ bool lk_wg_tile_stored(const LkWgradUnit& U, int y) { const int jl = y >> 3; return jl == 0 || ((U.wave0 + jl) & 3) == 0; }
 
 // XCD-AWARE ROW OWNERSHIP.  Several units read the same rows (the 64-column pieces of one operand, or two jobs sharing
 // d h), and every XCD has its own L2: with a unit's waves spread over the chip a row chunk was fetched from HBM by up to
@@ -1127,26 +1143,38 @@ __device__ __forceinline__ void wgrad_unit_mode(const LkWgradJob& J, int n0, int
 // the launch are co-resident (two per SIMD) and sweep the rows at the same speed, so the re-reads hit the XCD's L2.
 template <bool H16>
 __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
+    __shared__ float s_tile[3][LK_WG_TILE];          // the followers' tiles of the workgroup's runs (tile mode): wave w parks in s_tile[w - 1]
     const int lane = lk_lane();
     const int x = lk_uniform((int)blockIdx.x & 7);
-    const int l = lk_uniform(((int)blockIdx.x >> 3) * 4 + ((int)threadIdx.x >> 6));      // wave slot inside the XCD
-    if (l >= a.n_waves) return;
+    const int w = lk_uniform((int)threadIdx.x >> 6);
+    const int l = lk_uniform(((int)blockIdx.x >> 3) * 4 + w);      // wave slot inside the XCD
+    const bool tiles = a.part != nullptr;
+    if (l >= a.n_waves) { if (tiles) __syncthreads(); return; }       // (every wave of a tile-mode workgroup meets the one barrier)
     int u = 0;
     while (u + 1 < a.n_units && l >= a.unit[u + 1].wave0) ++u;        // scalar scan, <= 48 entries
     const LkWgradUnit& U = a.unit[u];
     const LkWgradJob& J = a.job[U.job];
     const int jl = l - U.wave0;
     const int c0 = x + 8 * jl, stride = 8 * U.n_waves;
-    // a wave without a chunk (tiny problems) still stores its (zero) tile: the reduction sums all 8 W tiles of the unit
-    float* tile = a.part ? a.part + ((size_t)8 * U.wave0 + 8 * jl + x) * LK_WG_TILE : nullptr;
+    // the run of this unit's waves inside the workgroup: its first wave (the unit's first on this XCD, or the workgroup's wave 0) leads
+    LkWgLds wl{nullptr, nullptr, 0, tiles};
+    const bool leader = jl == 0 || w == 0;
+    if (tiles && !leader) wl.lds_out = s_tile[w - 1];
+    if (tiles && leader) {
+        int nf = 0;
+        while (w + 1 + nf < 4 && jl + 1 + nf < U.n_waves && l + 1 + nf < a.n_waves) ++nf;
+        wl.lds_in = s_tile[w]; wl.n_in = nf;                            // followers w + 1 .. w + nf parked in s_tile[w] .. s_tile[w + nf - 1]
+    }
+    // a wave without a chunk (tiny problems) still contributes its (zero) tile
+    float* tile = tiles ? a.part + ((size_t)8 * U.wave0 + 8 * jl + x) * LK_WG_TILE : nullptr;
     // rows behind the live prefix of a partitioned batch were not written by their producers (k_decode_bwd skips those tiles)
     const int rows = a.live_rays ? min(J.rows, lk_uniform(*a.live_rays) * a.S) : J.rows;
     const float dsc = (H16 && a.dscale) ? *a.dscale : 1.0f;
     if (!tile && c0 >= (rows + WG_CHUNK - 1) / WG_CHUNK) return;
-    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc);
-    else if (U.nv == 2) wgrad_unit_mode<2, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc);
-    else if (U.kv == 2) wgrad_unit_mode<1, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc);
-    else wgrad_unit_mode<1, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc);
+    if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc, wl);
+    else if (U.nv == 2) wgrad_unit_mode<2, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc, wl);
+    else if (U.kv == 2) wgrad_unit_mode<1, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc, wl);
+    else wgrad_unit_mode<1, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc, wl);
 }
 
 // dW += sum over the unit's waves of the partial tiles (tile order: contiguous reads; every output element is owned by
@@ -1167,7 +1195,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const LkWgradArgs& a, int bx, 
     float s = 0.0f;
     if (in_acc || in_bias) {
 #pragma unroll 4
-        for (int y = q; y < nblk; y += 8) s += src[(size_t)y * stride];
+        for (int y = q; y < nblk; y += 8) s += lk_wg_tile_stored(U, y) ? src[(size_t)y * stride] : 0.0f;      // (the other waves' tiles went into their leader's)
     }
     sh[q][e] = s;
     __syncthreads();
@@ -1220,7 +1248,7 @@ __device__ __forceinline__ void fc_post_body(const LkWgradArgs& a, int f, int kc
 #pragma unroll
                 for (int q = 0; q < LK_FC_MAX_TILES; ++q) {
                     const int y = y0 + g + 4 * q;
-                    v[q] = (y < nblk && e < 32 * nv) ? src[(size_t)y * LK_WG_TILE + off] : 0.0f;
+                    v[q] = (y < nblk && e < 32 * nv && lk_wg_tile_stored(U, y)) ? src[(size_t)y * LK_WG_TILE + off] : 0.0f;
                 }
 #pragma unroll
                 for (int q = 0; q < LK_FC_MAX_TILES; ++q) s += v[q];

@@ -37,13 +37,20 @@ def test_default_line_carries_the_three_budgets(plain):
     r = d['roofline']
     assert r['bound'] in ('hbm', 'mfma') and 0 < r['frac'] < 1 and 0 < r['whole_step_fp32_frac'] < 1
     w = d['workloads']
-    assert set(w) == {'tum', 'scannet'}
+    assert set(w) == {'tum', 'scannet', 'replica_2m', 'refine_5m_f16'}
     assert w['tum']['rays_per_step'] == 200 * 5000 + 150 * 10000 and w['scannet']['rays_per_step'] == 100 * 5000 + 60 * 10000
     for k in ('tum', 'scannet'):
         assert w[k]['ms_per_step'] > 0 and abs(w[k]['rays_per_s'] * w[k]['ms_per_step'] * 1e-3 / w[k]['rays_per_step'] - 1) < 1e-6
         assert 0 < w[k]['whole_step_fp32_frac'] < 1
     # a TUM frame is 2.5 M rays against Replica's 0.36 M: its step is longer, its ray rate of the same order
     assert w['tum']['ms_per_step'] > 2 * d['ms_per_step'] and 0.3 < w['tum']['rays_per_s'] / d['value'] < 3
+    # BASELINE configs 4 / 5 at their map sizes: the headline budget on a 2 M-point map costs what it costs at 100 k points (the search walks
+    # cells, not the map: within 15 %), and the whole-map refinement call at 5 M points with half tables steps only touched rows
+    big, ref = w['replica_2m'], w['refine_5m_f16']
+    assert 1_990_000 < big['n_points'] < 2_010_000 and big['rays_per_step'] == d['config']['rays_per_step']
+    assert 0.85 < big['ms_per_step'] / d['ms_per_step'] < 1.25
+    assert 4_990_000 < ref['n_points'] < 5_010_000 and ref['iterations'] == 300 and 'float16' in ref['feature_tables']
+    assert 0.05 < ref['ms_per_iteration'] < 1.0          # (dense Adam over 5 M rows was 1.0 / 2.0 ms per geometry / colour iteration, profiles/r3_refine.md)
 
 
 def test_two_ranks_on_one_device_command_line():

@@ -407,7 +407,7 @@ def test_final_refinement_optimises_the_whole_map(backend):
                            ps.estimate_c2w_list[3].to(eng.device), color_refine=True)
     assert ps.mapper.last_window_idx == [0, 3]
     # rows far outside the last frustum moved too; only the two embedding matrices of the decoders may change (fix_color_decoder)
-    assert min(c['frac_moved'] for c in last) > 0.5
+    assert min(c['frac_moved'] for c in last) > 0.3          # (a window of {segment keyframes} + the last frame, 4 iterations x 96 rays per call)
     normal = [c for c in calls if c['idx'] == 0][0]         # first frame: iters_first with colour iterations, all decoder weights move
     assert not normal['refine'] and normal['w_moved'] > 1000 and max(c['w_moved'] for c in last) <= 3 * 96 + 30
 
