@@ -10,6 +10,8 @@
 
 using namespace lkw;
 
+LK_CHAIN_DEFINE(bwd)
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_composite_bwd(LkCompositeBwdArgs a) {
     const int r = blockIdx.x * 256 + (int)threadIdx.x;
@@ -130,6 +132,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
     if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
     float g0 = draw.x, g1 = draw.y, g2 = draw.z;
     const float4 yo = *reinterpret_cast<const float4*>(a.raw + (size_t)sp * 4);
+    LK_STAMPW(1);                                    // (probe build) threshold, loss term and composite backward of the lane's sample
     if (!(a.flags & LK_FLAG_COLOR_LOGITS)) {                     // through the sigmoid
         g0 *= yo.x * (1.0f - yo.x); g1 *= yo.y * (1.0f - yo.y); g2 *= yo.z * (1.0f - yo.z);
     }
@@ -224,6 +227,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
         return b;
     };
     prefetch(4);
+    LK_STAMPW(2);                                    // d h_4 formed, layer 4's operands arrived
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
         if (TL && a32) {
@@ -260,6 +264,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
             for (int q = 0; q < NP; ++q) xs[((w * 2 + G) * NP + q) * 64 + lane] = b.p[q];
         }
         __syncthreads();
+        LK_STAMP(7 - i);                             // slots 3..7: the d y pieces of layers 4..0 are parked
         buf ^= 1;
         if (i >= 1) {
             const u32x4* wt = FB + PC::tr(10 + i);
@@ -304,6 +309,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
             if (h == 0) { s_o[w][lane] = dpx; s_o[w][32 + lane] = dpy; s_o[w][64 + lane] = dpz; }
         }
         __syncthreads();
+        LK_STAMP(8);
         float4 c0 = xs[(0 * 4 + w) * 64 + lane];
         const float4 c1 = xs[(1 * 4 + w) * 64 + lane], c2 = xs[(2 * 4 + w) * 64 + lane], c3 = xs[(3 * 4 + w) * 64 + lane];
         c0.x = ((c0.x + c1.x) + c2.x) + c3.x; c0.y = ((c0.y + c1.y) + c2.y) + c3.y;
@@ -317,6 +323,7 @@ __device__ __forceinline__ void decode_bwd_col_wg(const LkDecodeBwdArgs& a, int 
             *reinterpret_cast<float4*>(a.dp_embed_col + (size_t)d.sample * 4) = make_float4(x * ISC, y * ISC, z * ISC, 0.0f);      // d e was formed from the scaled d y
         }
     }
+    LK_STAMPW(9);
 }
 
 // Embedding gradient of the geometry decoder, d e = W_3[:, embedding]^T d y_3 + W_0^T d y_0, one 32-unit block at a time (one accumulator
@@ -415,6 +422,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
         if (lane == 0) *reinterpret_cast<float4*>(a.tl.row_part + (size_t)tile * 4) = make_float4(G + (a.tl.use_color ? a.tl.w_color * C : 0.0f), G, C, N);
     } else draw = *reinterpret_cast<const float4*>(a.d_raw + (size_t)sp * 4);
     if (!live) draw = make_float4(0.f, 0.f, 0.f, 0.f);            // dead lanes contribute nothing to reductions
+    LK_STAMPW(1);
     float dpx = 0.0f, dpy = 0.0f, dpz = 0.0f;                     // this lane's share of dL/dp (embedding path)
     // ================= geometry decoder =================
     {
@@ -457,6 +465,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
                 dh = acc1;
             }
             // i == 0: only the embedding receives gradient (below)
+            LK_STAMP(7 - i);
             __builtin_amdgcn_sched_barrier(0);      // keeps the fragment loads of the layers below from being hoisted to the top (registers)
         }
         if (GH16) {
@@ -464,6 +473,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
             for (int q = 0; q < 16; ++q) dcg[q] *= ISC;
         }
         ct_store32(a.dc_geo + (size_t)d.sample * LK_C, dcg, d.store, lane);
+        LK_STAMP(8);
         // Embedding gradient d e = W_3[:, embedding]^T d y_3 + W_0^T d y_0, one 32-unit block at a time (one accumulator tile alive):
         // e_u = sin(x_u): ge_u = de_u cos(x_u);  dB[i][u] += sum_s ge_u a_i(s);  dp_i += ge_u 2 pi B[i][u]
         const Piece y0[2] = {PC::split(dy, 0), PC::split(dy, 1)};
@@ -477,6 +487,7 @@ __device__ __forceinline__ void decode_bwd_geo_wave(const LkDecodeBwdArgs& a, in
         dpx += __shfl_xor(dpx, 32); dpy += __shfl_xor(dpy, 32); dpz += __shfl_xor(dpz, 32);
         if (d.store && h == 0) *reinterpret_cast<float4*>(a.dp_embed + (size_t)d.sample * 4) = make_float4(dpx, dpy, dpz, 0.0f);
     }
+    LK_STAMPW(9);
 }
 
 // Hot-address atomics are the slowest thing this chip does (a few hundred distinct addresses hit by every
@@ -492,6 +503,7 @@ __global__ __launch_bounds__(256, LK_DBWD_MINB) void k_decode_bwd(LkDecodeBwdArg
     __shared__ u32x4 s_x[2 * 24 * 64];
     __shared__ float s_o[4][3 * 32];
     const int w = (int)threadIdx.x >> 6;
+    LK_STAMP(0);
     const int P_live = a.live_rays ? min(a.P, *a.live_rays * a.S) : a.P;       // as k_decode_fwd
     // geometry workgroups FIRST in the grid: a geometry tile is one wave's 20-us chain - dispatched behind the colour tiles (as in rounds 1-2)
     // those chains were the launch's tail on a nearly empty chip; in front they run beside the colour tiles (5 000 rays: 60 -> 55 us)

@@ -13,6 +13,8 @@
 
 using namespace lkw;
 
+LK_CHAIN_DEFINE(bwd2)
+
 // ---------------------------------------------------------------------------------------------
 // one workgroup-sized block of 32 samples, 256 threads (8 per sample); `block` = index of the 32-sample block
 __device__ __forceinline__ void interp_bwd_block(const LkInterpBwdArgs& a, int block) {
@@ -55,6 +57,7 @@ __device__ __forceinline__ void interp_bwd_block(const LkInterpBwdArgs& a, int b
         if (color && relpos && a.dw_rel && has) part += a.dw_rel[(size_t)pidx * LK_K + j];
         dwn[j] = part;
     }
+    LK_STAMPW(7);                                    // (probe build) lists, d c rows and the geometry rows arrived: d loss / d weight
     const int r = pidx / a.S;
     const float z = a.z[pidx];
     const float px = lk_madd_rn(a.rays_o[3 * r], a.rays_d[3 * r], z);
@@ -92,6 +95,7 @@ __device__ __forceinline__ void interp_bwd_block(const LkInterpBwdArgs& a, int b
         if (color && relpos && a.dp_rel) { const float4 e = *reinterpret_cast<const float4*>(a.dp_rel + (size_t)pidx * 4); dpx += e.x; dpy += e.y; dpz += e.z; }
         *reinterpret_cast<float4*>(a.dp_total + (size_t)pidx * 4) = make_float4(dpx, dpy, dpz, 0.0f);
     }
+    LK_STAMPW(8);                                    // positions arrived, d p of the sample complete
     if (a.pose_part) {
         // tracking loop: the pose gradient needs G[c][k] = sum_rays (sum_s d p_c z) dir_k and T[c] = sum d p_c (k_pose_bwd); a sample
         // contributes d p_c z dir_k / d p_c, summed here over the 32 samples of the workgroup (one lane per sample carries it)
@@ -116,6 +120,7 @@ __device__ __forceinline__ void interp_bwd_block(const LkInterpBwdArgs& a, int b
         __syncthreads();
         if (threadIdx.x < 12) a.pose_part[(size_t)block * 12 + threadIdx.x] = (s_pp[0][threadIdx.x] + s_pp[1][threadIdx.x]) + (s_pp[2][threadIdx.x] + s_pp[3][threadIdx.x]);
     }
+    LK_STAMPW(9);
 }
 __global__ __launch_bounds__(256) void k_interp_bwd(LkInterpBwdArgs a) { interp_bwd_block(a, (int)blockIdx.x); }
 // the same launch with one more workgroup: the tracking iteration's exposure step (backward of the exposure MLP from the per-tile sums of d affine
@@ -350,6 +355,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
             x1[4 * g] = v.x; x1[4 * g + 1] = v.y; x1[4 * g + 2] = v.z; x1[4 * g + 3] = v.w;
         }
     }
+    LK_STAMPW(1);                                    // (probe build) lists, positions, feature rows arrived; embedding evaluated
     f32x16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_rowvec_tile(W + R_B1, nb * 32, lane);      // accumulators start from the bias
@@ -362,6 +368,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
 #pragma unroll
         for (int q = 0; q < 16; ++q) hid[nb][q] = lk_softplus100(hid[nb][q]);
     }
+    LK_STAMP(2);                                     // hidden layer recomputed
     // ---- d out = w * dc ; (tracker) d w = dc . out
     f32x16 dout[1];
     const float* dcrow = a.dc_col + (size_t)sp * LK_C;
@@ -429,6 +436,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
 #pragma unroll
         for (int q = 0; q < 16; ++q) dhid[nb][q] = t[q] * lk_softplus100_grad_from_out(hid[nb][q]);
     }
+    LK_STAMP(3);                                     // d hid
     // ---- d x = W1^T d hid   (virtual 64 input units: 0..19 embedding, 20..51 feature channels)
     f32x16 dx[2];
     dx[0] = lk_zero16(); dx[1] = lk_zero16();
@@ -443,6 +451,7 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    LK_STAMP(4);                                     // d x
     if (want_w) {
         //   linear1: rows [8P][192] = d hid (128) | x (64)
         if (live) {
@@ -544,8 +553,11 @@ __global__ __launch_bounds__(512) void k_relpos_interp_bwd(LkRelposBwdArgs rb, L
     __shared__ float s_dummy[32];
     const int w = (int)threadIdx.x >> 6;
     const int sample0 = (int)blockIdx.x * 32 + 4 * w;
+    LK_STAMP(0);
     if (sample0 < rb.P) relpos_bwd_wave<F16>(rb, sample0, s_dummy);
+    LK_STAMP(5);
     __syncthreads();                                   // d w_rel / d p_rel of the block are written
+    LK_STAMP(6);
     if (w >= 4) return;
     interp_bwd_block(ib, (int)blockIdx.x);
 }

@@ -90,6 +90,37 @@ __device__ __forceinline__ int lk_lane() { return (int)(threadIdx.x & 63u); }
 // real branches for everything derived from it)
 __device__ __forceinline__ int lk_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Probe build only (tools/ab_build.sh chain -DLK_PROBE_CHAIN; never in the shipped library: tests/test_product_hygiene.py): the four
+// launches of a tracking iteration leave 100-MHz wall-clock stamps (s_memrealtime: one clock for every compute unit and every launch) at
+// their phase boundaries, [workgroup][wave][slot], in a buffer of their translation unit; lk_debug_chain_<k> copies it out and
+// tools/probe/track_chain.py lays the last iteration's chain out on one time axis.  LK_STAMPW waits for the wave's outstanding memory
+// operations first ("the data has arrived"), LK_STAMP does not.
+#ifdef LK_PROBE_CHAIN
+#define LK_CHAIN_WGS 512
+#define LK_CHAIN_WAVES 8
+#define LK_CHAIN_SLOTS 16
+#define LK_CHAIN_DEFINE(NAME)                                                                                                   \
+    __device__ unsigned long long g_lk_chain[LK_CHAIN_WGS][LK_CHAIN_WAVES][LK_CHAIN_SLOTS];                                     \
+    extern "C" int lk_debug_chain_##NAME(unsigned long long* out) {                                                             \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lk_chain), sizeof(g_lk_chain)) == hipSuccess ? 0 : 1;                      \
+    }
+#define LK_STAMP(I)                                                                                                             \
+    do {                                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        if (lk_lane() == 0 && blockIdx.x < LK_CHAIN_WGS) g_lk_chain[blockIdx.x][threadIdx.x >> 6][I] = wall_clock64();          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    } while (0)
+#define LK_STAMPW(I)                                                                                                            \
+    do {                                                                                                                        \
+        __builtin_amdgcn_s_waitcnt(0);                                                                                          \
+        LK_STAMP(I);                                                                                                            \
+    } while (0)
+#else
+#define LK_CHAIN_DEFINE(NAME)
+#define LK_STAMP(I) do {} while (0)
+#define LK_STAMPW(I) do {} while (0)
+#endif
+
 // squared distance exactly as the contract states: (dx*dx + dy*dy) + dz*dz, one rounding per op
 __device__ __forceinline__ float lk_dist2(float qx, float qy, float qz, float px, float py, float pz) {
     const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);

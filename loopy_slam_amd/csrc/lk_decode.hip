@@ -18,6 +18,8 @@
 
 using namespace lkw;
 
+LK_CHAIN_DEFINE(fwd)
+
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x16 ct_load_rows32(const float* __restrict__ row /* 32 floats of this sample */,
                                                  bool live, int lane) {
@@ -154,6 +156,7 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
         ct_check_range<CHECK>(cg, a.status);
         cb[0] = lk_split_cth(cg, 0); cb[1] = lk_split_cth(cg, 1);
     }
+    LK_STAMPW(5);                                    // (probe build) geometry wave: embedding evaluated, c_geo arrived
     f32x16 acc[1], hh;
     // layer 0: 93 -> 32
     acc[0] = lk_rowvec_tile(W + G_B0, 0, lane);
@@ -161,17 +164,20 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
     for (int G = 0; G < 6; ++G) acc[0] = lk_mma3h(lk_fragh_load(FB + FM0_FWDH, 1, G, 0, lane), eb[G], acc[0]);
     layer_finish<1, false>(acc, FB + FM5_FWDH, W + G_U0 + a64(HG * CF), cb, act_geo, live, lane);
     hh = acc[0]; ct_check_range<CHECK>(hh, a.status);
+    LK_STAMP(6);
     // layers 1, 2: 32 -> 32
     acc[0] = lk_rowvec_tile(W + G_B1, 0, lane);
     lk_gemm_h3<1, 2>(acc, FB + FM1_FWDH, 1, 0, 0, hh, 0, lane);
     layer_finish<1, false>(acc, FB + FM6_FWDH, W + G_U0 + G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 32 : nullptr, live, lane);
     hh = acc[0]; ct_check_range<CHECK>(hh, a.status);
+    LK_STAMP(7);
     acc[0] = lk_rowvec_tile(W + G_B2, 0, lane);
     lk_gemm_h3<1, 2>(acc, FB + FM2_FWDH, 1, 0, 0, hh, 0, lane);
     layer_finish<1, false>(acc, FB + FM7_FWDH, W + G_U0 + 2 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 64 : nullptr, live, lane);
     hh = acc[0]; ct_check_range<CHECK>(hh, a.status);
+    LK_STAMP(8);
     // layer 3 (skip): [e(93) | h(32)] -> 32, packed as [96 | 32]
     acc[0] = lk_rowvec_tile(W + G_B3, 0, lane);
 #pragma unroll
@@ -180,6 +186,7 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
     layer_finish<1, false>(acc, FB + FM8_FWDH, W + G_U0 + 3 * G_USTRIDE + a64(HG * CF), cb,
                            act_geo ? act_geo + 96 : nullptr, live, lane);
     hh = acc[0]; ct_check_range<CHECK>(hh, a.status);
+    LK_STAMP(9);
     // layer 4
     acc[0] = lk_rowvec_tile(W + G_B4, 0, lane);
     lk_gemm_h3<1, 2>(acc, FB + FM4_FWDH, 1, 0, 0, hh, 0, lane);
@@ -195,6 +202,7 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
     }
     part += __shfl_xor(part, 32);
     if (live && h == 0) a.raw[(size_t)d.sample * 4 + 3] = part + W[G_BO];
+    LK_STAMP(10);
     return part + W[G_BO];
 }
 
@@ -296,7 +304,9 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         ct_check_range<CHECK>(cc, a.status);
         cb[0] = lk_split_cth(cc, 0); cb[1] = lk_split_cth(cc, 1);
     }
+    LK_STAMPW(14);                                   // (probe build) this wave's set-up: sample, embedding share, c_col arrived
     wg_barrier();                                   // the embedding pieces and s_bias are complete
+    LK_STAMP(5);
 #pragma unroll
     for (int G = 0; G < 3; ++G) {
         eb[G].p[0] = s_x[1][(G * 2 + 0) * 64 + lane];
@@ -380,6 +390,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     __builtin_amdgcn_sched_barrier(0);
     finish(acc, act_col_s, 0, 0);
     wg_barrier();
+    LK_STAMP(6);
     // layers 1, 2: 128 -> 128
 #pragma unroll
     for (int L = 1; L <= 2; ++L) {
@@ -391,6 +402,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
         __builtin_amdgcn_sched_barrier(0);
         finish(acc, act_col_s ? act_col_s + LK_COL_SLAYER(a.P, L) : nullptr, L, L & 1);
         wg_barrier();
+        if (L == 1) LK_STAMP(7); else LK_STAMP(8);
     }
     // layer 3 (skip): [e(40) | h(128)] -> 128
     prefetch_u(FB + FM18_FWDH);
@@ -401,11 +413,13 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     __builtin_amdgcn_sched_barrier(0);
     finish(acc, act_col_s ? act_col_s + LK_COL_SLAYER(a.P, 3) : nullptr, 3, 1);
     wg_barrier();
+    LK_STAMP(9);
     // layer 4
     prefetch_u(FB + FM19_FWDH);
     acc = ct_bias_lds(s_bias[4], w * 32, lane);
     hidden(acc, FB + FM14_FWDH, 0, 1);
     finish(acc, act_col_s ? act_col_s + LK_COL_SLAYER(a.P, 4) : nullptr, 4, -1);
+    LK_STAMP(10);
     // output 128 -> 3 on the VALU: per-wave partial over its 32 units, summed over the waves in fixed order
     float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll
@@ -422,6 +436,7 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32);
     if (h == 0) { s_o[w][lane] = o0; s_o[w][32 + lane] = o1; s_o[w][64 + lane] = o2; }
     wg_barrier();
+    LK_STAMP(11);
     if (w == 0 && h == 0) {
         o0 = ((s_o[0][lane] + s_o[1][lane]) + s_o[2][lane]) + s_o[3][lane];
         o1 = ((s_o[0][32 + lane] + s_o[1][32 + lane]) + s_o[2][32 + lane]) + s_o[3][32 + lane];
@@ -522,6 +537,7 @@ __device__ __forceinline__ void relpos_fwd_wave(const LkRelposArgs& a, int sampl
         }
     }
     ct_check_range<CHECK>(x0, a.status); ct_check_range<CHECK>(x1, a.status);
+    LK_STAMPW(1);                                    // (probe build) lists, positions and feature rows arrived, embedding evaluated
     f32x16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) hid[nb] = lk_rowvec_tile(W + R_B1, nb * 32, lane);      // accumulators start from the bias
@@ -533,6 +549,7 @@ __device__ __forceinline__ void relpos_fwd_wave(const LkRelposArgs& a, int sampl
         for (int q = 0; q < 16; ++q) hid[nb][q] = lk_softplus100(hid[nb][q]);
         ct_check_range<CHECK>(hid[nb], a.status);
     }
+    LK_STAMP(2);
     f32x16 out[1];
     out[0] = lk_rowvec_tile(W + R_B2, 0, lane);
 #pragma unroll
@@ -599,8 +616,11 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
     const int lim = COMP ? min(ra.P, base + ts) : ra.P;      // the rel-pos rows of the tile's own samples only
     const int sample0 = base + 4 * w;
     if (threadIdx.x == 0) { s_cnt = 0u; s_geo_done = 0u; }
+    LK_STAMP(0);
     if (sample0 < lim) relpos_fwd_wave(ra, sample0, lim);
+    LK_STAMP(3);
     __syncthreads();                               // the tile's c_col rows are written
+    LK_STAMP(4);
     if (w > 4) return;
     if (w == 4) {
         const float occ = decode_geo_wave(a, tile, lane);
@@ -633,6 +653,7 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
         __threadfence_block();
         while (*reinterpret_cast<volatile unsigned*>(&s_geo_done) < 1u) __builtin_amdgcn_s_sleep(1);
         __threadfence_block();
+        LK_STAMP(12);
         float tv = 0.0f, cv = 0.0f;
         if (lane < n_rays) {
             const int r = base / S + lane;
@@ -652,6 +673,7 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
         for (int o = 4; o > 0; o >>= 1) { tv += __shfl_xor(tv, o); cv += __shfl_xor(cv, o); }       // n_rays <= 8 (S >= 4)
         if (lane == 0) { tl.part[2 * tile] = tv; tl.part[2 * tile + 1] = cv; }
         if (tile == 0 && lane < 4) tl.out4[lane] = 0.0f;        // the loss row pass 2 accumulates into
+        LK_STAMPW(13);
     }
 }
 int lk_launch_decode_fwd(const LkDecodeArgs& a, hipStream_t st) {

@@ -8,6 +8,10 @@
 // (d2, index), so the result does not depend on which lane met which candidate.
 #pragma once
 #include "lk_common.h"
+#ifndef LK_KNN_STAMP
+#define LK_KNN_STAMP(I) do {} while (0)
+#define LK_KNN_STAMPW(I) do {} while (0)
+#endif
 
 __device__ __forceinline__ int lk_cell_coord(float x, float o, float inv, int d) {
     float f = floorf((x - o) * inv);
@@ -116,6 +120,7 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
             my_e[h] = cell_start[row + ix1 + 1];
         }
     }
+    LK_KNN_STAMPW(3);                                // the row table (cell_start) has arrived
     int rs[LK_ROWS], re[LK_ROWS];
     float4 c[LK_ROWS];
 #pragma unroll
@@ -131,6 +136,7 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
             lk_top8_offer(k, d2, r2, __float_as_int(c[i].w));
         }
     }
+    LK_KNN_STAMPW(4);                                // the first T candidates of every row are ranked
 #pragma unroll
     for (int i = 0; i < LK_ROWS; ++i) {
 #pragma unroll 1
@@ -140,6 +146,7 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
             lk_top8_offer(k, d2, r2, __float_as_int(p.w));
         }
     }
+    LK_KNN_STAMPW(5);                                // ... and the rest of the rows
     if (nrows > LK_ROWS) {          // cells smaller than the radius: plain row walk
 #pragma unroll 1
         for (int iz = iz0; iz <= iz1; ++iz) {
@@ -167,6 +174,7 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
     lk_knn_merge_round<0x4E>(k);
     lk_knn_merge_round<0x141>(k);
     if (T == 16) lk_knn_merge_round<0x140>(k);
+    LK_KNN_STAMP(6);                                 // merged: every lane of the group holds the top-8
     if (big) {
         // every lane of the group holds the same list here, so the decision is group-uniform
         const float rho2 = r * r * (1.0f - 1e-6f);

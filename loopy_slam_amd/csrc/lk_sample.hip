@@ -7,6 +7,9 @@
 #include "lk_common.h"
 #include "lk_weights_dev.h"
 #define LK_SEARCH_WGS 512
+LK_CHAIN_DEFINE(sample)
+#define LK_KNN_STAMP(I) LK_STAMP(I)          // (probe build: the search's phases inside k_sample_interp_pose)
+#define LK_KNN_STAMPW(I) LK_STAMPW(I)
 #include "lk_knn_dev.h"
 #include "lk_kernels.h"
 #include "lk_track_dev.h"
@@ -104,7 +107,9 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
     const float qy = lk_madd_rn(o3[1], d3[1], z);
     const float qz = lk_madd_rn(o3[2], d3[2], z);
     const float r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
+    if (POSE) LK_STAMPW(2);                          // the ray's reading, pixel and radius have arrived: the query point is known
     lk_knn_scan_coop<T>(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, sub, d, id);
+    if (POSE) LK_STAMP(7);
     // w = 1/(D+1e-10), zero outside the radius, L1-normalised (decoder.py:210-220)
     float wsum = 0.0f;
 #pragma unroll
@@ -126,6 +131,7 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
 #pragma unroll
         for (int j = 1; j < LK_K; ++j) { wj = (sub == j) ? w[j] : wj; ij = (sub == j) ? id[j] : ij; }
         if (MODE != 2) {
+            if (POSE) LK_STAMP(8);
             if (sub < LK_K) {
                 a.nbr_idx[(size_t)pidx * LK_K + sub] = ij;
                 a.nbr_w[(size_t)pidx * LK_K + sub] = wj;
@@ -179,6 +185,7 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
         if (a.noise_geo) ag = *reinterpret_cast<const float4*>(a.noise_geo + f4 * 4);
         if (a.noise_col) ac = *reinterpret_cast<const float4*>(a.noise_col + f4 * 4);
     }
+    if (POSE) LK_STAMPW(9);                          // the feature rows have arrived and are summed
     if (lane_geo) *reinterpret_cast<float4*>(a.c_geo + (size_t)pidx * LK_C + f4 * 4) = ag;
     if (lane_col) *reinterpret_cast<float4*>(a.c_col + (size_t)pidx * LK_C + f4 * 4) = ac;
     // rel-pos colour features come from k_relpos_fwd, which does not visit the rays behind the live prefix: give their samples a defined
@@ -199,8 +206,11 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
 template <int T>
 __global__ __launch_bounds__(256) void k_sample_interp_pose(LkSampleArgs a, LkTrackFinalArgs f) {
     __shared__ float s_cam[7];
+    LK_STAMP(0);
     lk_track_pose_step<4>(f, s_cam, blockIdx.x == 0);
+    LK_STAMP(1);                                     // the stepped pose is in LDS
     sample_interp_block<T, 0, true>(a, (int)blockIdx.x, &f, s_cam);
+    LK_STAMPW(10);
 }
 template <int T, int MODE>
 __global__ __launch_bounds__(256) void k_sample_interp(LkSampleArgs a) {
