@@ -665,7 +665,7 @@ int lk_render_bwd_impl(const lk_render_desc* d, hipStream_t st, unsigned skip, c
         ib.pose_part = ex ? ex->pose_part : nullptr;
         if (ex) { ib.pix_i = ex->pix_i; ib.pix_j = ex->pix_j; ib.fx = ex->fx; ib.fy = ex->fy; ib.cx = ex->cx; ib.cy = ex->cy; }
         else { ib.pix_i = ib.pix_j = nullptr; ib.fx = ib.fy = 1.0f; ib.cx = ib.cy = 0.0f; }
-        if (fuse_rb) lk_launch_relpos_interp_bwd(rb_fused, ib, st);
+        if (fuse_rb) lk_launch_relpos_interp_bwd(rb_fused, ib, st, (flags & LK_FLAG_UNIT_LOSS_GRADS) && d->affine == nullptr);
         else lk_launch_interp_bwd(ib, st, (ex && !gf) ? ex->xstep : nullptr, ex ? ex->xstep_part : nullptr, ex ? ex->xstep_n_part : 0);
     }
     if (gr && !(skip & LK_SKIP_RAYS_BWD)) {

@@ -78,24 +78,6 @@ __device__ __forceinline__ BwdSample bwd_sample(const LkDecodeBwdArgs& a, int ti
 // (LK_FLAG_UNIT_LOSS_GRADS, mapper mode): the whole chain d h_4 .. d h_0 is linear in d out, so d out is multiplied by 2^10
 // once (median |d h| 1.5e-4 -> 0.15: both fp16 pieces normal numbers), everything in between is scaled with it, and the
 // stored d h rows / d c are scaled back where they are written (in the copy resp. the final sum: no extra instruction).
-template <bool H16> struct BwdPiece;
-template <> struct BwdPiece<false> {
-    typedef LkB8 T;
-    static constexpr int NP = 3;
-    static __device__ __forceinline__ T split(const f32x16& x, int G) { return lk_split_ct(x, G); }
-    static __device__ __forceinline__ f32x16 mma(const T& a, const T& b, f32x16 c) { return lk_mma6(a, b, c); }
-    static __device__ __forceinline__ T load(const u32x4* f, int NBT, int G, int nb, int lane) { return lk_fragb_load(f, NBT, G, nb, lane); }
-    static __device__ __forceinline__ int tr(int idx) { return FRAG_TRB[idx]; }
-};
-template <> struct BwdPiece<true> {
-    typedef LkH8 T;
-    static constexpr int NP = 2;
-    static __device__ __forceinline__ T split(const f32x16& x, int G) { return lk_split_cth(x, G); }
-    static __device__ __forceinline__ f32x16 mma(const T& a, const T& b, f32x16 c) { return lk_mma3h(a, b, c); }
-    static __device__ __forceinline__ T load(const u32x4* f, int NBT, int G, int nb, int lane) { return lk_fragh_load(f, NBT, G, nb, lane); }
-    static __device__ __forceinline__ int tr(int idx) { return FRAG_TRH[idx]; }
-};
-
 // DEEP: as in the forward (lk_decode.hip) - launches whose tiles are all resident at once fetch more blocks of W_i^T ahead
 // (all eight; the register count of the kernel is set by its geometry role)
 // TL: the launch may belong to the tracking loop (LkDecodeBwdArgs::tl_n_part) - d raw formed in the prologue instead of read

@@ -306,8 +306,15 @@ __device__ __forceinline__ float rp_embed_unit(const float* __restrict__ B, int 
     return (u < 10) ? lk_sinf(x) : lk_cosf(x);
 }
 
-template <bool F16>          // F16: half feature tables (LK_FLAG_FEATS_F16) - a template, the kernel has no register to spare for a branch
+// H16 (the tracking loop's launch, k_relpos_interp_bwd: unit-scale colour loss gradients, no weight gradients): the two backward products on
+// fp16 pieces of the 2^10-scaled chain instead of bf16 pieces, as decode_bwd_col_wg<true> and the mapper's fused variant below - d c_col is
+// what the colour trunk's scaled chain delivered, so the same pre-scale puts d out, d hid in fp16's normal range; half the matrix
+// instructions (72 instead of 144 per 32 rows) and 3 instead of 5.5 vector instructions per split value; d x is scaled back where it leaves.
+template <bool F16, bool H16 = false>          // F16: half feature tables (LK_FLAG_FEATS_F16) - a template, the kernel has no register to spare for a branch
 __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sample0, float* __restrict__ part) {
+    typedef BwdPiece<H16> PC;
+    typedef typename PC::T Piece;
+    constexpr float SC = H16 ? 1024.0f : 1.0f, ISC = H16 ? 1.0f / 1024.0f : 1.0f;
     const int lane = lk_lane();
     const int h = lane >> 5;
     const int j = lane & 31;
@@ -329,9 +336,10 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     const float a2 = __fmul_rn(LK_TWO_PI, __fsub_rn(a.pos[3 * (size_t)idx + 2], pz));
     const float* __restrict__ W = a.W;
     const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag);
+    const u32x4* __restrict__ FP = FB + (H16 ? FRAGB_U4 : 0);      // the backward products' pieces
     const size_t frow = (size_t)idx * LK_C;
     constexpr bool f16 = F16;
-    const bool want_w = (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
+    const bool want_w = !H16 && (a.flags & LK_FLAG_GRAD_WEIGHTS) != 0;
     const bool want_p = (a.flags & LK_FLAG_GRAD_RAYS) != 0;
     // ---- recompute the forward of this tile
     f32x16 x0, x1;
@@ -388,8 +396,11 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
         part += __shfl_xor(part, 32);
         if (live && h == 0) a.dw_rel[(size_t)sp * LK_K + nb_i] = (has && a.nbr_idx[(size_t)sp * LK_K + nb_i] >= 0) ? part : 0.0f;
     }
+    {
+        const float ws = H16 ? wgt * SC : wgt;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) dout[0][q] *= wgt;
+        for (int q = 0; q < 16; ++q) dout[0][q] *= ws;
+    }
     // Loads and stores share one in-order counter: a fragment fetched after a store cannot be waited for before that store
     // has landed.  Every product's fragments are therefore fetched BEFORE the stores that precede it in the data flow
     // (one block ahead, pinned with scheduling barriers), and the big row stores go last.
@@ -403,20 +414,20 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     }
     // ---- d hid = (W2^T d out) * softplus'(hid), block by block IN PLACE of hid (64 fewer live registers)
     f32x16 (&dhid)[4] = hid;
-    const LkB8 db0 = lk_split_ct(dout[0], 0), db1 = lk_split_ct(dout[0], 1);
-    LkB8 fa0 = lk_fragb_load(FB + FM21_TRB, 4, 0, 0, lane), fa1 = lk_fragb_load(FB + FM21_TRB, 4, 1, 0, lane);
-    LkB8 fx[4];                                  // head of the d x product (block 0 of d hid), fetched before the last stores
+    const Piece db0 = PC::split(dout[0], 0), db1 = PC::split(dout[0], 1);
+    Piece fa0 = PC::load(FP + PC::tr(21), 4, 0, 0, lane), fa1 = PC::load(FP + PC::tr(21), 4, 1, 0, lane);
+    Piece fx[4];                                  // head of the d x product (block 0 of d hid), fetched before the last stores
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         f32x16 t = lk_zero16();
-        t = lk_mma6(fa0, db0, t);
-        t = lk_mma6(fa1, db1, t);
+        t = PC::mma(fa0, db0, t);
+        t = PC::mma(fa1, db1, t);
         if (nb < 3) {
-            fa0 = lk_fragb_load(FB + FM21_TRB, 4, 0, nb + 1, lane);
-            fa1 = lk_fragb_load(FB + FM21_TRB, 4, 1, nb + 1, lane);
+            fa0 = PC::load(FP + PC::tr(21), 4, 0, nb + 1, lane);
+            fa1 = PC::load(FP + PC::tr(21), 4, 1, nb + 1, lane);
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fx[q] = lk_fragb_load(FB + FM20_TRB, 2, q >> 1, q & 1, lane);
+            for (int q = 0; q < 4; ++q) fx[q] = PC::load(FP + PC::tr(20), 2, q >> 1, q & 1, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (want_w) {
@@ -444,11 +455,17 @@ __device__ __forceinline__ void relpos_bwd_wave(const LkRelposBwdArgs& a, int sa
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
         for (int G = 0; G < 2; ++G) {
-            const LkB8 b = lk_split_ct(dhid[nb], G);
+            const Piece b = PC::split(dhid[nb], G);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
-                dx[kb] = lk_mma6(nb == 0 ? fx[2 * G + kb] : lk_fragb_load(FB + FM20_TRB, 2, 2 * nb + G, kb, lane), b, dx[kb]);
+                dx[kb] = PC::mma(nb == 0 ? fx[2 * G + kb] : PC::load(FP + PC::tr(20), 2, 2 * nb + G, kb, lane), b, dx[kb]);
         }
+    }
+    if (H16) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dx[kb][q] *= ISC;
     }
     __builtin_amdgcn_sched_barrier(0);
     LK_STAMP(4);                                     // d x
@@ -548,13 +565,13 @@ __global__ __launch_bounds__(256, 2) void k_relpos_bwd(LkRelposBwdArgs a) {
 // Tracker-sized batches (lk_track_frame): the rel-pos backward and the interpolation backward of a 32-sample block in ONE launch - eight
 // waves run the rel-pos backward (4 samples each, as k_relpos_bwd), one barrier, waves 4..7 leave, waves 0..3 are k_interp_bwd's block.
 // No weight gradients here (the tracker optimises the pose only).
-template <bool F16>
+template <bool F16, bool H16>
 __global__ __launch_bounds__(512) void k_relpos_interp_bwd(LkRelposBwdArgs rb, LkInterpBwdArgs ib) {
     __shared__ float s_dummy[32];
     const int w = (int)threadIdx.x >> 6;
     const int sample0 = (int)blockIdx.x * 32 + 4 * w;
     LK_STAMP(0);
-    if (sample0 < rb.P) relpos_bwd_wave<F16>(rb, sample0, s_dummy);
+    if (sample0 < rb.P) relpos_bwd_wave<F16, H16>(rb, sample0, s_dummy);
     LK_STAMP(5);
     __syncthreads();                                   // d w_rel / d p_rel of the block are written
     LK_STAMP(6);
@@ -1355,10 +1372,18 @@ int lk_launch_bwd_reduce(const LkWgradArgs& wa, LkBwdReduceArgs r, bool with_rp,
     return LK_OK;
 }
 
-int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs& ib, hipStream_t st) {
+// h16: d c_col comes from the colour trunk's pre-scaled fp16 chain with unit-scale loss gradients and no exposure affine in between
+// (relpos_bwd_wave<.., true>)
+int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs& ib, hipStream_t st, bool h16) {
     LkProfScope prof_(LKK_RELPOS_BWD, st);
-    if (rb.flags & LK_FLAG_FEATS_F16) hipLaunchKernelGGL(k_relpos_interp_bwd<true>, dim3(lk_cdiv(rb.P, 32)), dim3(512), 0, st, rb, ib);
-    else hipLaunchKernelGGL(k_relpos_interp_bwd<false>, dim3(lk_cdiv(rb.P, 32)), dim3(512), 0, st, rb, ib);
+    const dim3 grid(lk_cdiv(rb.P, 32));
+    if (rb.flags & LK_FLAG_FEATS_F16) {
+        if (h16) hipLaunchKernelGGL((k_relpos_interp_bwd<true, true>), grid, dim3(512), 0, st, rb, ib);
+        else hipLaunchKernelGGL((k_relpos_interp_bwd<true, false>), grid, dim3(512), 0, st, rb, ib);
+    } else {
+        if (h16) hipLaunchKernelGGL((k_relpos_interp_bwd<false, true>), grid, dim3(512), 0, st, rb, ib);
+        else hipLaunchKernelGGL((k_relpos_interp_bwd<false, false>), grid, dim3(512), 0, st, rb, ib);
+    }
     return LK_OK;
 }
 int lk_launch_interp_bwd(const LkInterpBwdArgs& a, hipStream_t st, const ExposureStepArgs* xstep, const float* xstep_part, int xstep_n_part) {

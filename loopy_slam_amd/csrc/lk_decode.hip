@@ -206,6 +206,120 @@ __device__ __forceinline__ float decode_geo_wave(const LkDecodeArgs& a, int tile
     return part + W[G_BO];
 }
 
+// The same decoder with its operands in LDS (the tracker's fused launch, k_relpos_decode_fwd: one tile per compute unit, and the geometry wave's
+// chain is what the tile's composite waits for).  In decode_geo_wave a layer is two dependent global round trips - its W fragments and bias,
+// then (behind the activation store: loads issued after a store are not moved above it) its fc_c fragments and bias - 2.3-2.6 us per 32-wide
+// layer whose matrix work is 0.3 us, 7 us for layer 0 (profiles/r6_track_chain_before.md).  The launch's eight waves copy the decoder's 30
+// forward fragment blocks (60 KB, fp16 pieces) and ten bias vectors into LDS while they wait for the rel-pos MLP's inputs (lk_geo_stage:
+// global_load_lds, no register in between), and this wave reads them from there.  Same products in the same order: bit-identical.
+// s_gw: blocks in the order of use - W0 (6), U0 (2), W1, U1, W2, U2 (2 each), W3 (8), U3, W4, U4; s_gb: b_0..b_4, u_0..u_4
+#define LK_GEO_STAGE_BLOCKS 30
+#define LK_GLDS_MAX_TILES 256           // compute units of the chip: one tile each
+__device__ __forceinline__ void lk_geo_stage(const LkDecodeArgs& a, int w, int lane, u32x4* __restrict__ s_gw, float (*s_gb)[32]) {
+    const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;
+    constexpr int SRC[10] = {FM0_FWDH, FM5_FWDH, FM1_FWDH, FM6_FWDH, FM2_FWDH, FM7_FWDH, FM3_FWDH, FM8_FWDH, FM4_FWDH, FM9_FWDH};
+    constexpr int NBLK[10] = {6, 2, 2, 2, 2, 2, 8, 2, 2, 2};
+    int chunk = 0;                      // 1-KB chunks (one piece of one block = one wave-wide 16-byte access), dealt round-robin to the 8 waves
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+#pragma unroll
+        for (int c = 0; c < 2 * NBLK[m]; ++c, ++chunk) {
+            if ((chunk & 7) == w) {
+#ifndef HIPEMU
+                __builtin_amdgcn_global_load_lds(FB + SRC[m] + c * 64 + lane, (__attribute__((address_space(3))) u32x4*)(s_gw + chunk * 64), 16, 0, 0);
+#else
+                s_gw[chunk * 64 + lane] = FB[SRC[m] + c * 64 + lane];
+#endif
+            }
+        }
+    }
+    const int t = w * 64 + lane;
+    if (t < 320) {
+        const int j = t >> 5, u = t & 31;
+        const int b_off[5] = {G_B0, G_B1, G_B2, G_B3, G_B4};
+        s_gb[j][u] = a.W[j < 5 ? b_off[j] + u : G_U0 + (j - 5) * G_USTRIDE + a64(HG * CF) + u];
+    }
+}
+template <bool CHECK = false>
+__device__ __forceinline__ float decode_geo_wave_lds(const LkDecodeArgs& a, int tile, int lane, const u32x4* __restrict__ s_gw, const float (*s_gb)[32]) {
+    const DecSample d = dec_sample(a, tile, lane);
+    const int h = d.h, sp = d.sp;
+    const bool live = d.live;
+    const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
+    const float* __restrict__ W = a.W;
+    const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
+    float* act_geo = save ? a.act + (size_t)sp * LK_ACT_GEO_A : nullptr;
+    constexpr int WB[5] = {0, 8, 12, 16, 26}, UB[5] = {6, 10, 14, 24, 28};      // first block of W_i / U_i in s_gw
+    auto frag = [&](int block) {
+        LkH8 f;
+        f.p[0] = s_gw[(block * 2 + 0) * 64 + lane]; f.p[1] = s_gw[(block * 2 + 1) * 64 + lane];
+        return f;
+    };
+    auto bias = [&](int j) {
+        f32x16 t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(&s_gb[j][8 * g + 4 * h]);
+            t[4 * g + 0] = b.x; t[4 * g + 1] = b.y; t[4 * g + 2] = b.z; t[4 * g + 3] = b.w;
+        }
+        return t;
+    };
+    LkH8 eb[6], cb[2];
+    {
+        const f32x16 e0 = geo_embed_tile(W + G_EB, 0, a0, a1, a2, lane);
+        eb[0] = lk_split_cth(e0, 0); eb[1] = lk_split_cth(e0, 1);
+        const f32x16 e1 = geo_embed_tile(W + G_EB, 1, a0, a1, a2, lane);
+        eb[2] = lk_split_cth(e1, 0); eb[3] = lk_split_cth(e1, 1);
+        const f32x16 e2 = geo_embed_tile(W + G_EB, 2, a0, a1, a2, lane);
+        eb[4] = lk_split_cth(e2, 0); eb[5] = lk_split_cth(e2, 1);
+        const f32x16 cg = ct_load_rows32(a.c_geo + (size_t)sp * LK_C, true, lane);
+        ct_check_range<CHECK>(cg, a.status);
+        cb[0] = lk_split_cth(cg, 0); cb[1] = lk_split_cth(cg, 1);
+    }
+    LK_STAMPW(5);
+    f32x16 acc, hh = lk_zero16();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        acc = bias(i);
+        if (i == 0 || i == 3) {         // [embedding (6 blocks) | hidden (layer 3: 2 blocks)]
+#pragma unroll
+            for (int G = 0; G < 6; ++G) acc = lk_mma3h(frag(WB[i] + G), eb[G], acc);
+            if (i == 3) {
+#pragma unroll
+                for (int G = 0; G < 2; ++G) acc = lk_mma3h(frag(WB[i] + 6 + G), lk_split_cth(hh, G), acc);
+            }
+        } else {
+#pragma unroll
+            for (int G = 0; G < 2; ++G) acc = lk_mma3h(frag(WB[i] + G), lk_split_cth(hh, G), acc);
+        }
+        // epilogue: relu, saved row, + u_i, + U_i c
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+        if (act_geo) ct_store_rows32(act_geo + 32 * i, acc, live, lane);
+        {
+            const f32x16 ub = bias(5 + i);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += ub[r];
+        }
+#pragma unroll
+        for (int G = 0; G < 2; ++G) acc = lk_mma3h(frag(UB[i] + G), cb[G], acc);
+        LK_STAMP(6 + i);
+        hh = acc;
+        if (i < 4) ct_check_range<CHECK>(hh, a.status);
+    }
+    // output 32 -> 1 on the VALU: each half-wave holds 16 of the 32 units of its sample
+    float part = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 wo = *reinterpret_cast<const float4*>(W + G_WO + 8 * g + 4 * h);
+        part = fmaf(wo.x, acc[4 * g], part); part = fmaf(wo.y, acc[4 * g + 1], part);
+        part = fmaf(wo.z, acc[4 * g + 2], part); part = fmaf(wo.w, acc[4 * g + 3], part);
+    }
+    part += __shfl_xor(part, 32);
+    if (live && h == 0) a.raw[(size_t)d.sample * 4 + 3] = part + W[G_BO];
+    return part + W[G_BO];
+}
+
 // ================= colour decoder (hidden 128, softplus beta=100): FOUR waves = one 32-sample tile =================
 // Wave w owns output units [32w, 32w+32) of every layer (one accumulator, 48 matrix instructions per 128-wide layer), so
 // a tile's serial chain is a quarter of the one-wave form and a training batch (a few hundred tiles) spreads over four
@@ -233,15 +347,12 @@ __device__ __forceinline__ f32x16 ct_bias_lds(const float* __restrict__ v, int u
 // SOFTBAR (s_cnt: an LDS word, zero on entry): the four waves meet at a barrier of their own (lk_soft_barrier) instead of s_barrier - for
 // workgroups in which a fifth wave runs something else meanwhile (k_relpos_decode_fwd: the geometry decoder on wave 4)
 // s_raw (or NULL; wave 0 only reads it): the tile's colours are also left there as raw rows [32][4] (k_relpos_decode_fwd's composite epilogue)
-template <bool DEEP, bool SOFTBAR = false, bool CHECK = false>
-__device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
-                                              u32x4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */,
-                                              float (*s_bias)[128] /* [10][128] */, unsigned* s_cnt = nullptr, float* s_raw = nullptr) {
-    unsigned n_bar = 0;
-    auto wg_barrier = [&]() {
-        if (SOFTBAR) lk_soft_barrier(s_cnt, 4u * (++n_bar));
-        else __syncthreads();
-    };
+// The part of a colour tile's set-up that does NOT depend on the interpolated colour feature: the ten bias vectors into s_bias, the wave's
+// share of the forty sin / cos values as fp16 pieces into s_x[1] (and as rows for the weight gradients).  decode_col_wg runs it first thing;
+// the tracker's fused launch (k_relpos_decode_fwd) runs it IN FRONT of the rel-pos MLP, whose output is the colour feature - behind it, as
+// until round 6, its cold fetches (biases, Fourier matrix, the sample's depth and ray) were 2.9 us of every tile's chain
+// (profiles/r6_track_chain_before.md, "decoder set-up").  Its LDS writes are ordered before their readers by decode_col_wg's first barrier.
+__device__ __forceinline__ void decode_col_setup(const LkDecodeArgs& a, int tile, int w, int lane, u32x4 (*s_x)[16 * 64], float (*s_bias)[128]) {
     {
         const int t = (int)threadIdx.x;
 #pragma unroll
@@ -256,6 +367,58 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     const bool live = d.live;
     const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
     const float* __restrict__ W = a.W;
+    const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
+    // embedding (40 units = blocks 0, 1 and a quarter of 2): B operand of two products, split once.
+    // The forty sin / cos values are the same for the four waves: wave w evaluates register group g = w of block 0 (units 8 w + 4 h + t),
+    // wave 3 also block 1's four, and the fp16 pieces travel through s_x[1] (an activation buffer from layer 1's epilogue on, two
+    // barriers later) - 4 to 8 evaluations per lane instead of 20, a fifth of the kernel's VALU instructions.
+    float ev[4], e1v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ev[t] = sincos_embed_unit(W + C_EB, 20, 8 * w + 4 * h + t, a0, a1, a2);
+    if (w == 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e1v[t] = sincos_embed_unit(W + C_EB, 20, 32 + 4 * h + t, a0, a1, a2);
+    }
+    if (save && live) {              // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
+        float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
+        *reinterpret_cast<float4*>(erow + 8 * w + 4 * h) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+        if (w == 3) *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1v[0], e1v[1], e1v[2], e1v[3]);
+    }
+    // the same cut as lk_split8h: hi = rtz_f16 of the pair, lo = rtz_f16 of the remainders
+    auto cut2 = [&](float x, float y, unsigned& hi, unsigned& lo) {
+        const lk_f16x2 hh = __builtin_amdgcn_cvt_pkrtz(x, y);
+        const lk_f16x2 ll = __builtin_amdgcn_cvt_pkrtz(x - (float)hh[0], y - (float)hh[1]);
+        hi = __builtin_bit_cast(unsigned, hh); lo = __builtin_bit_cast(unsigned, ll);
+    };
+    unsigned* se = reinterpret_cast<unsigned*>(s_x[1]);
+    unsigned hi0, lo0, hi1, lo1;
+    cut2(ev[0], ev[1], hi0, lo0); cut2(ev[2], ev[3], hi1, lo1);
+    const int G = w >> 1, c0 = 2 * (w & 1);
+    *reinterpret_cast<uint2*>(se + ((G * 2 + 0) * 64 + lane) * 4 + c0) = make_uint2(hi0, hi1);
+    *reinterpret_cast<uint2*>(se + ((G * 2 + 1) * 64 + lane) * 4 + c0) = make_uint2(lo0, lo1);
+    if (w == 3) {
+        cut2(e1v[0], e1v[1], hi0, lo0); cut2(e1v[2], e1v[3], hi1, lo1);
+        s_x[1][(2 * 2 + 0) * 64 + lane] = u32x4{hi0, hi1, 0u, 0u};
+        s_x[1][(2 * 2 + 1) * 64 + lane] = u32x4{lo0, lo1, 0u, 0u};
+    }
+}
+
+// PRESET: the caller has run decode_col_setup for this tile already (k_relpos_decode_fwd)
+template <bool DEEP, bool SOFTBAR = false, bool CHECK = false, bool PRESET = false>
+__device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, int w, int lane,
+                                              u32x4 (*s_x)[16 * 64] /* [2][16*64] */, float (*s_o)[3 * 32] /* [4][96] */,
+                                              float (*s_bias)[128] /* [10][128] */, unsigned* s_cnt = nullptr, float* s_raw = nullptr) {
+    unsigned n_bar = 0;
+    auto wg_barrier = [&]() {
+        if (SOFTBAR) lk_soft_barrier(s_cnt, 4u * (++n_bar));
+        else __syncthreads();
+    };
+    if (!PRESET) decode_col_setup(a, tile, w, lane, s_x, s_bias);
+    const DecSample d = dec_sample(a, tile, lane);
+    const int h = d.h, sp = d.sp;
+    const bool live = d.live;
+    const float a0 = d.a0, a1 = d.a1, a2 = d.a2;
+    const float* __restrict__ W = a.W;
     const u32x4* __restrict__ FB = reinterpret_cast<const u32x4*>(a.Wfrag) + FRAGB_U4;      // fp16 forward fragments
     const bool save = (a.flags & LK_FLAG_SAVE_ACT) && a.act != nullptr;
     // this sample's row of layer 0; layer L is LK_COL_LAYER(P, L) floats further (layer-major, lk_kernels.h)
@@ -265,41 +428,9 @@ __device__ __forceinline__ void decode_col_wg(const LkDecodeArgs& a, int tile, i
     const bool a32 = (a.flags & LK_FLAG_TRACKER) != 0;
     float* act_col_a = save ? a.act + (size_t)a.P * LK_ACT_GEO_A + (size_t)sp * 128 + w * 32 : nullptr;
     float* act_col_h = save ? a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A) + (size_t)sp * 128 : nullptr;
-    // embedding (40 units = blocks 0, 1 and a quarter of 2) and interpolated feature: B operands of two / five products, split once.
-    // The forty sin / cos values are the same for the four waves: wave w evaluates register group g = w of block 0 (units 8 w + 4 h + t),
-    // wave 3 also block 1's four, and the fp16 pieces travel through s_x[1] (an activation buffer from layer 1's epilogue on, two
-    // barriers later) - 4 to 8 evaluations per lane instead of 20, a fifth of the kernel's VALU instructions.
+    // the embedding pieces are in s_x[1] (decode_col_setup); the interpolated feature is the B operand of five products: split once
     LkH8 eb[3], cb[2];
     {
-        float ev[4], e1v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) ev[t] = sincos_embed_unit(W + C_EB, 20, 8 * w + 4 * h + t, a0, a1, a2);
-        if (w == 3) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) e1v[t] = sincos_embed_unit(W + C_EB, 20, 32 + 4 * h + t, a0, a1, a2);
-        }
-        if (save && live) {              // embedding rows 0..39 (input of layers 0 and 3) for the weight gradients
-            float* erow = a.act + (size_t)a.P * (LK_ACT_GEO_A + LK_ACT_COL_A + LK_ACT_COL_H) + (size_t)sp * LK_ACT_COL_E;
-            *reinterpret_cast<float4*>(erow + 8 * w + 4 * h) = make_float4(ev[0], ev[1], ev[2], ev[3]);
-            if (w == 3) *reinterpret_cast<float4*>(erow + 32 + 4 * h) = make_float4(e1v[0], e1v[1], e1v[2], e1v[3]);
-        }
-        // the same cut as lk_split8h: hi = rtz_f16 of the pair, lo = rtz_f16 of the remainders
-        auto cut2 = [&](float x, float y, unsigned& hi, unsigned& lo) {
-            const lk_f16x2 hh = __builtin_amdgcn_cvt_pkrtz(x, y);
-            const lk_f16x2 ll = __builtin_amdgcn_cvt_pkrtz(x - (float)hh[0], y - (float)hh[1]);
-            hi = __builtin_bit_cast(unsigned, hh); lo = __builtin_bit_cast(unsigned, ll);
-        };
-        unsigned* se = reinterpret_cast<unsigned*>(s_x[1]);
-        unsigned hi0, lo0, hi1, lo1;
-        cut2(ev[0], ev[1], hi0, lo0); cut2(ev[2], ev[3], hi1, lo1);
-        const int G = w >> 1, c0 = 2 * (w & 1);
-        *reinterpret_cast<uint2*>(se + ((G * 2 + 0) * 64 + lane) * 4 + c0) = make_uint2(hi0, hi1);
-        *reinterpret_cast<uint2*>(se + ((G * 2 + 1) * 64 + lane) * 4 + c0) = make_uint2(lo0, lo1);
-        if (w == 3) {
-            cut2(e1v[0], e1v[1], hi0, lo0); cut2(e1v[2], e1v[3], hi1, lo1);
-            s_x[1][(2 * 2 + 0) * 64 + lane] = u32x4{hi0, hi1, 0u, 0u};
-            s_x[1][(2 * 2 + 1) * 64 + lane] = u32x4{lo0, lo1, 0u, 0u};
-        }
         const f32x16 cc = ct_load_rows32(a.c_col + (size_t)sp * LK_C, true, lane);
         ct_check_range<CHECK>(cc, a.status);
         cb[0] = lk_split_cth(cc, 0); cb[1] = lk_split_cth(cc, 1);
@@ -600,7 +731,9 @@ __global__ __launch_bounds__(256) void k_relpos_fwd_checked(LkRelposArgs a) { re
 // wave 0 its colours in LDS as raw rows, wave 0 waits for wave 4 (a counter in LDS, as the soft barrier) and its first lanes composite one ray
 // each (lk_composite_ray on the LDS rows: the arithmetic of k_track_composite), write the ray's outputs and residual, and the tile's
 // (sum of residuals, #present rays) pair - the mask threshold's partial sums are per tile instead of per 256 rays (5 us of an iteration of 117)
-template <bool DEEP, bool COMP>
+// GLDS (launches of at most one tile per compute unit - the 104 KB of LDS keep a second workgroup off the unit): the geometry decoder's operands
+// staged in LDS, decode_geo_wave_lds
+template <bool DEEP, bool COMP, bool GLDS>
 __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDecodeArgs a, LkTrackLossArgs tl) {
     __shared__ u32x4 s_x[2][16 * 64];
     __shared__ float s_o[4][3 * 32];
@@ -608,6 +741,8 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
     __shared__ unsigned s_cnt;
     __shared__ unsigned s_geo_done;
     __shared__ __attribute__((aligned(16))) float s_raw[32 * 4];
+    __shared__ u32x4 s_gw[GLDS ? LK_GEO_STAGE_BLOCKS * 128 : 1];
+    __shared__ __attribute__((aligned(16))) float s_gb[GLDS ? 10 : 1][32];
     const int lane = lk_lane();
     const int w = (int)threadIdx.x >> 6;
     const int tile = (int)blockIdx.x;
@@ -617,13 +752,15 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
     const int sample0 = base + 4 * w;
     if (threadIdx.x == 0) { s_cnt = 0u; s_geo_done = 0u; }
     LK_STAMP(0);
+    if (w < 4) decode_col_setup(a, tile, w, lane, s_x, s_bias);      // (in front of the rel-pos MLP: its fetches are cold, and independent of it)
+    if (GLDS) lk_geo_stage(a, w, lane, s_gw, s_gb);                  // the geometry decoder's operands into LDS (decode_geo_wave_lds)
     if (sample0 < lim) relpos_fwd_wave(ra, sample0, lim);
     LK_STAMP(3);
     __syncthreads();                               // the tile's c_col rows are written
     LK_STAMP(4);
     if (w > 4) return;
     if (w == 4) {
-        const float occ = decode_geo_wave(a, tile, lane);
+        const float occ = GLDS ? decode_geo_wave_lds(a, tile, lane, s_gw, s_gb) : decode_geo_wave(a, tile, lane);
         if (COMP) {
             if (lane < 32) s_raw[4 * lane + 3] = occ;
             __builtin_amdgcn_wave_barrier();       // (the host emulation runs lanes as fibers: every lane's row before lane 0's signal)
@@ -647,7 +784,7 @@ __global__ __launch_bounds__(512) void k_relpos_decode_fwd(LkRelposArgs ra, LkDe
             if (s < S) { cz[s] = tl.z[base + lane * S + s]; chas[s] = tl.nbr_count[base + lane * S + s] >= tl.min_nn; }
         }
     }
-    decode_col_wg<DEEP, true>(a, tile, w, lane, s_x, s_o, s_bias, &s_cnt, COMP ? s_raw : nullptr);
+    decode_col_wg<DEEP, true, false, true>(a, tile, w, lane, s_x, s_o, s_bias, &s_cnt, COMP ? s_raw : nullptr);
     if (COMP && w == 0) {
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
@@ -713,11 +850,13 @@ int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, h
         LkDecodeArgs b = a;
         b.tile_stride = ts;
         const int ctiles = lk_cdiv(a.P, ts);
-        hipLaunchKernelGGL((k_relpos_decode_fwd<true, true>), dim3(ctiles), dim3(512), 0, st, ra, b, *comp);
+        if (ctiles <= LK_GLDS_MAX_TILES) hipLaunchKernelGGL((k_relpos_decode_fwd<true, true, true>), dim3(ctiles), dim3(512), 0, st, ra, b, *comp);
+        else hipLaunchKernelGGL((k_relpos_decode_fwd<true, true, false>), dim3(ctiles), dim3(512), 0, st, ra, b, *comp);
         if (comp_tiles) *comp_tiles = ctiles;
         return LK_OK;
     }
-    hipLaunchKernelGGL((k_relpos_decode_fwd<true, false>), dim3(tiles), dim3(512), 0, st, ra, a, tl);
+    if (tiles <= LK_GLDS_MAX_TILES) hipLaunchKernelGGL((k_relpos_decode_fwd<true, false, true>), dim3(tiles), dim3(512), 0, st, ra, a, tl);
+    else hipLaunchKernelGGL((k_relpos_decode_fwd<true, false, false>), dim3(tiles), dim3(512), 0, st, ra, a, tl);
     return LK_OK;
 }
 int lk_launch_relpos_fwd(const LkRelposArgs& a, hipStream_t st) {

@@ -2,6 +2,27 @@
 #pragma once
 #include "lk_common.h"
 
+// the piece type of a backward product chain: three bf16 pieces (lk_mma6: any scale) or two fp16 pieces of a PRE-SCALED chain (lk_mma3h: unit-scale
+// loss gradients times 2^10) - decode_bwd_col_wg, decode_bwd_geo_wave (lk_bwd.hip), relpos_bwd_wave (lk_bwd2.hip)
+template <bool H16> struct BwdPiece;
+template <> struct BwdPiece<false> {
+    typedef LkB8 T;
+    static constexpr int NP = 3;
+    static __device__ __forceinline__ T split(const f32x16& x, int G) { return lk_split_ct(x, G); }
+    static __device__ __forceinline__ f32x16 mma(const T& a, const T& b, f32x16 c) { return lk_mma6(a, b, c); }
+    static __device__ __forceinline__ T load(const u32x4* f, int NBT, int G, int nb, int lane) { return lk_fragb_load(f, NBT, G, nb, lane); }
+    static __device__ __forceinline__ int tr(int idx) { return lkw::FRAG_TRB[idx]; }
+};
+template <> struct BwdPiece<true> {
+    typedef LkH8 T;
+    static constexpr int NP = 2;
+    static __device__ __forceinline__ T split(const f32x16& x, int G) { return lk_split_cth(x, G); }
+    static __device__ __forceinline__ f32x16 mma(const T& a, const T& b, f32x16 c) { return lk_mma3h(a, b, c); }
+    static __device__ __forceinline__ T load(const u32x4* f, int NBT, int G, int nb, int lane) { return lk_fragh_load(f, NBT, G, nb, lane); }
+    static __device__ __forceinline__ int tr(int idx) { return lkw::FRAG_TRH[idx]; }
+};
+
+
 // ---- optional per-kernel timing with HIP events on the launch stream (lk_profile_begin / lk_profile_end)
 enum LkKernelId { LKK_DEPTH_STATS = 0, LKK_SAMPLE_INTERP, LKK_RELPOS_FWD, LKK_DECODE_FWD, LKK_COMPOSITE, LKK_COMPOSITE_BWD,
                   LKK_DECODE_BWD, LKK_RELPOS_BWD, LKK_INTERP_BWD, LKK_RAYS_BWD, LKK_WGRAD, LKK_FEAT_SCATTER, LKK_DECODE_BWD_TRACK, LKK_COUNT };
@@ -377,7 +398,7 @@ struct LkTrackLossArgs;
 // comp (tracking loop): pass 1 of the tracker's loss - composite, residuals, per-TILE sums - as the epilogue of the launch; *comp_tiles = the
 // number of (sum, count) pairs it left in comp->part, or 0 where the launch cannot carry it (the caller launches k_track_composite then)
 int lk_launch_relpos_decode_fwd(const LkRelposArgs& ra, const LkDecodeArgs& a, hipStream_t st, const LkTrackLossArgs* comp = nullptr, int* comp_tiles = nullptr);       // k_relpos_fwd + k_decode_fwd in one launch
-int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs& ib, hipStream_t st);  // k_relpos_bwd + k_interp_bwd in one launch
+int lk_launch_relpos_interp_bwd(const LkRelposBwdArgs& rb, const LkInterpBwdArgs& ib, hipStream_t st, bool h16);  // k_relpos_bwd + k_interp_bwd in one launch
 
 // activation scratch layout (floats per sample), SAVE_ACT
 //   [P][160] geometry a_i | [P][320] colour softplus'(z_i) as unorm16 pairs | [P][640] colour h_i | [P][40] colour embedding  (i = 0..4)

@@ -19,6 +19,7 @@ __device__ __forceinline__ int lk_cell_coord(float x, float o, float inv, int d)
     return (int)f;
 }
 
+template <int V> struct LkInt { static constexpr int value = V; };
 // A candidate is ONE 64-bit key: (bits of d2) << 32 | index.  d2 >= +0, so the unsigned order of the float bits is the
 // float order and the key order is the strict total order (d2, index) in a single v_cmp_lt_u64.
 // The empty slot is (FLT_MAX, -1) = the largest key any list ever holds.
@@ -28,9 +29,12 @@ __device__ __forceinline__ uint64_t lk_key(float d2, int idx) {
 }
 
 // insert into the ascending 8-list, dropping the largest: k[s] <- max(k[s-1], min(key, k[s])); branch-free
+// FILL: the list holds at most FILL real entries when the call is made (the rest are LK_KEY_EMPTY) - the stages above slot FILL would move
+// EMPTY over EMPTY and are left out: the j-th candidate a lane meets costs j stages, not 7
+template <int FILL = LK_K>
 __device__ __forceinline__ void lk_top8_insert(uint64_t (&k)[LK_K], uint64_t key) {
 #pragma unroll
-    for (int s = LK_K - 1; s > 0; --s) {
+    for (int s = (FILL < LK_K - 1 ? FILL : LK_K - 1); s > 0; --s) {
         const uint64_t lo = key < k[s] ? key : k[s];
         k[s] = key < k[s - 1] ? k[s - 1] : lo;
     }
@@ -40,9 +44,10 @@ __device__ __forceinline__ void lk_top8_insert(uint64_t (&k)[LK_K], uint64_t key
 // a candidate enters the insertion network only if it is inside the radius AND ahead of the list's current last entry (the order is
 // total, so this is exactly "belongs to the 8 smallest so far"): in a dense cloud most in-radius candidates arrive when the list is
 // already full of nearer ones, and the 8-stage network is the search's largest VALU item
+template <int FILL = LK_K>
 __device__ __forceinline__ void lk_top8_offer(uint64_t (&k)[LK_K], float d2, float r2, int idx) {
     const uint64_t key = lk_key(d2, idx);
-    if (d2 <= r2 && key < k[LK_K - 1]) lk_top8_insert(k, key);
+    if (d2 <= r2 && key < k[LK_K - 1]) lk_top8_insert<FILL>(k, key);
 }
 
 // one butterfly round: my ascending 8-list against the partner's, keep the 8 smallest, re-sort (see the merge note below)
@@ -129,12 +134,17 @@ __device__ __forceinline__ void lk_knn_scan_coop(const LkGrid* __restrict__ G, c
         re[i] = __shfl(my_e[i / T], i & (T - 1), T);
         if (rs[i] < re[i]) c[i] = sorted[rs[i]];
     }
-#pragma unroll
-    for (int i = 0; i < LK_ROWS; ++i) {
-        if (rs[i] < re[i]) {
-            const float d2 = lk_dist2(qx, qy, qz, c[i].x, c[i].y, c[i].z);
-            lk_top8_offer(k, d2, r2, __float_as_int(c[i].w));
-        }
+    // (row i's candidate is at most the (i + 1)-th this lane has met)
+    {
+        auto first = [&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (rs[i] < re[i]) {
+                const float d2 = lk_dist2(qx, qy, qz, c[i].x, c[i].y, c[i].z);
+                lk_top8_offer<i>(k, d2, r2, __float_as_int(c[i].w));
+            }
+        };
+        first(LkInt<0>()); first(LkInt<1>()); first(LkInt<2>()); first(LkInt<3>()); first(LkInt<4>());
+        first(LkInt<5>()); first(LkInt<6>()); first(LkInt<7>()); first(LkInt<8>());
     }
     LK_KNN_STAMPW(4);                                // the first T candidates of every row are ranked
 #pragma unroll

@@ -54,8 +54,12 @@ __global__ __launch_bounds__(256) void k_depth_stats(const float* __restrict__ g
 // POSE (tracking loop, MODE 0): the rays are not read but derived from the pose s_cam[7] (LDS: the pose step of the iteration before ran as
 // this launch's prologue, k_sample_interp_pose) and the batch's pixels, with k_track_final's arithmetic; the group of a ray's first
 // sample also stores them for the kernels behind this one.
+// (POSE) what a sample group reads that does NOT depend on the pose: fetched by k_sample_interp_pose in front of the pose step, whose three
+// barriers the compiler moves no load across - behind it the ray's reading and pixel were one more cold round trip of every group's chain
+struct LkPoseEarly { float gt, pix_i, pix_j, r2; LkGrid grid; };
 template <int T, int MODE, bool POSE = false>
-__device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int block, const LkTrackFinalArgs* f = nullptr, const float* s_cam = nullptr) {
+__device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int block, const LkTrackFinalArgs* f = nullptr, const float* s_cam = nullptr,
+                                                    const LkPoseEarly* early = nullptr) {
     const int sub = (int)threadIdx.x & (T - 1);
     const int p_raw = block * (256 / T) + (int)threadIdx.x / T;
     const bool live = p_raw < a.P;
@@ -74,7 +78,7 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
         w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
         count = a.nbr_count[pidx];
     } else {
-    const float gt = a.gt_depth[r];
+    const float gt = POSE ? early->gt : a.gt_depth[r];
     if (gt > 0.0f) {
         const float t = lk_linspace(0.0f, 1.0f, a.S, s);
         z = __fadd_rn(__fmul_rn(__fmul_rn(a.near_surface, gt), __fsub_rn(1.0f, t)),
@@ -89,7 +93,7 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
     if (POSE) {
         float Rm[9];
         lp_quat_rot(s_cam, Rm);
-        const float d0 = (f->next_pix_i[r] - f->cx) / f->fx, d1 = -(f->next_pix_j[r] - f->cy) / f->fy, d2 = -1.0f;
+        const float d0 = (early->pix_i - f->cx) / f->fx, d1 = -(early->pix_j - f->cy) / f->fy, d2 = -1.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             d3[c] = (d0 * Rm[3 * c] + d1 * Rm[3 * c + 1]) + d2 * Rm[3 * c + 2];
@@ -106,9 +110,9 @@ __device__ __forceinline__ void sample_interp_block(const LkSampleArgs& a, int b
     const float qx = lk_madd_rn(o3[0], d3[0], z);
     const float qy = lk_madd_rn(o3[1], d3[1], z);
     const float qz = lk_madd_rn(o3[2], d3[2], z);
-    const float r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
+    const float r2 = POSE ? early->r2 : (a.r2_ray ? a.r2_ray[r] : a.r2_static);
     if (POSE) LK_STAMPW(2);                          // the ray's reading, pixel and radius have arrived: the query point is known
-    lk_knn_scan_coop<T>(a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, sub, d, id);
+    lk_knn_scan_coop<T>(POSE ? &early->grid : a.grid, a.sorted, a.cell_start, qx, qy, qz, r2, sub, d, id);
     if (POSE) LK_STAMP(7);
     // w = 1/(D+1e-10), zero outside the radius, L1-normalised (decoder.py:210-220)
     float wsum = 0.0f;
@@ -207,9 +211,17 @@ template <int T>
 __global__ __launch_bounds__(256) void k_sample_interp_pose(LkSampleArgs a, LkTrackFinalArgs f) {
     __shared__ float s_cam[7];
     LK_STAMP(0);
+    LkPoseEarly e;
+    {       // (the group's ray, as sample_interp_block derives it)
+        const int p_raw = (int)blockIdx.x * (256 / T) + (int)threadIdx.x / T;
+        const int r = (p_raw < a.P ? p_raw : a.P - 1) / a.S;
+        e.gt = a.gt_depth[r]; e.pix_i = f.next_pix_i[r]; e.pix_j = f.next_pix_j[r];
+        e.r2 = a.r2_ray ? a.r2_ray[r] : a.r2_static;
+        e.grid = *a.grid;
+    }
     lk_track_pose_step<4>(f, s_cam, blockIdx.x == 0);
     LK_STAMP(1);                                     // the stepped pose is in LDS
-    sample_interp_block<T, 0, true>(a, (int)blockIdx.x, &f, s_cam);
+    sample_interp_block<T, 0, true>(a, (int)blockIdx.x, &f, s_cam, &e);
     LK_STAMPW(10);
 }
 template <int T, int MODE>

@@ -10,18 +10,45 @@ __device__ __forceinline__ float lp_sgn(float x) { return (x > 0.0f) ? 1.0f : ((
 // ---- the tracker's loss (Tracker.py:169-191) per ray, in the prologue of the tracking loop's k_decode_bwd
 // mask threshold 10 x the batch mean of the normalised residuals from pass 1's block sums: a whole wave calls, every wave of every workgroup
 // adds the same pairs in the same order - the same threshold everywhere
-__device__ __forceinline__ float lk_track_threshold(const LkTrackLossArgs& a, int n_part) {
+// (split in two: the first four pairs of every lane - all of them up to 256 partial pairs, the fused loop's 250 tiles - are FETCHED by lk_track_parts_load
+// and summed later by lk_track_threshold, so that the caller can issue its own loads in between: with the sum taken first, the ray's operands
+// were a second cold round trip behind the partials' - 5-6 us of prologue in every tile of the tracking loop's k_decode_bwd,
+// profiles/r6_track_chain_before.md.  The order of the additions is the one it always was.)
+struct LkTrackParts { float t[4], c[4]; };
+__device__ __forceinline__ LkTrackParts lk_track_parts_load(const LkTrackLossArgs& a, int n_part) {
+    LkTrackParts p;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = lk_lane() + 64 * q;
+        p.t[q] = 0.0f; p.c[q] = 0.0f;
+        if (!a.median && b < n_part) { const float2 v = *reinterpret_cast<const float2*>(a.part + 2 * b); p.t[q] = v.x; p.c[q] = v.y; }
+    }
+    return p;
+}
+__device__ __forceinline__ float lk_track_threshold(const LkTrackLossArgs& a, int n_part, const LkTrackParts& p) {
     if (a.median) return a.part[0];
     float ts = 0.0f, cs = 0.0f;
-    for (int b = lk_lane(); b < n_part; b += 64) { ts += a.part[2 * b]; cs += a.part[2 * b + 1]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (lk_lane() + 64 * q < n_part) { ts += p.t[q]; cs += p.c[q]; }
+    }
+    for (int b = lk_lane() + 256; b < n_part; b += 64) { ts += a.part[2 * b]; cs += a.part[2 * b + 1]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { ts += __shfl_xor(ts, o); cs += __shfl_xor(cs, o); }
     return 10.0f * (ts / fmaxf(cs, 1.0f));
 }
 struct LkTrackRayLoss { float dd, dc0, dc1, dc2, geo, col, cnt, gt; };
-__device__ __forceinline__ LkTrackRayLoss lk_track_ray_loss(const LkTrackLossArgs& a, int r, float thr) {
+struct LkTrackRayIn { float d, v, g, tm, c0, c1, c2, g0, g1, g2; };
+__device__ __forceinline__ LkTrackRayIn lk_track_ray_in(const LkTrackLossArgs& a, int r) {
+    LkTrackRayIn i;
+    i.d = a.depth[r]; i.v = a.var[r]; i.g = a.gt_depth[r]; i.tm = a.resid[r];
+    i.c0 = a.color[3 * r]; i.c1 = a.color[3 * r + 1]; i.c2 = a.color[3 * r + 2];
+    i.g0 = a.gt_color[3 * r]; i.g1 = a.gt_color[3 * r + 1]; i.g2 = a.gt_color[3 * r + 2];
+    return i;
+}
+__device__ __forceinline__ LkTrackRayLoss lk_track_ray_loss(const LkTrackLossArgs& a, const LkTrackRayIn& in, float thr) {
     LkTrackRayLoss o;
-    const float d = a.depth[r], v = a.var[r], g = a.gt_depth[r], tm = a.resid[r];
+    const float d = in.d, v = in.v, g = in.g, tm = in.tm;
     const float tt = a.median ? fabsf(g - d) / sqrtf(v + 1e-10f) : tm;          // the loss term stays uncertainty-normalised
     const bool m = (tm < thr) && (g > 0.0f) && !(d != d) && !(v != v);
     o.dd = 0.0f; o.dc0 = 0.0f; o.dc1 = 0.0f; o.dc2 = 0.0f; o.geo = 0.0f; o.col = 0.0f; o.cnt = 0.0f; o.gt = g;
@@ -29,7 +56,7 @@ __device__ __forceinline__ LkTrackRayLoss lk_track_ray_loss(const LkTrackLossArg
         o.geo = fminf(fmaxf(tt, 0.0f), 1e3f);
         if (tt <= 1e3f) o.dd = lp_sgn(d - g) / sqrtf(v + 1e-10f);
         o.cnt = 1.0f;
-        const float e0 = a.color[3 * r] - a.gt_color[3 * r], e1 = a.color[3 * r + 1] - a.gt_color[3 * r + 1], e2 = a.color[3 * r + 2] - a.gt_color[3 * r + 2];
+        const float e0 = in.c0 - in.g0, e1 = in.c1 - in.g1, e2 = in.c2 - in.g2;
         o.col = fabsf(e0) + fabsf(e1) + fabsf(e2);
         if (a.use_color) { o.dc0 = a.w_color * lp_sgn(e0); o.dc1 = a.w_color * lp_sgn(e1); o.dc2 = a.w_color * lp_sgn(e2); }
     }
@@ -37,11 +64,23 @@ __device__ __forceinline__ LkTrackRayLoss lk_track_ray_loss(const LkTrackLossArg
 }
 // d raw of sample sp (its lane calls; all 64 lanes of the wave must call - the threshold is a wave sum); *row: the ray's loss terms
 __device__ __forceinline__ float4 lk_track_draw(const LkTrackLossArgs& a, int n_part, int sp, LkTrackRayLoss* row) {
-    const float thr = lk_track_threshold(a, n_part);
     const int r = sp / a.S;
-    const LkTrackRayLoss o = lk_track_ray_loss(a, r, thr);
+    // three independent sets of operands - the partial pairs, the ray's outputs and readings, its samples' raw values - in flight together
+    const LkTrackParts parts = lk_track_parts_load(a, n_part);
+    const LkTrackRayIn in = lk_track_ray_in(a, r);
+    LkRayState st;
+    lk_ray_state(a.raw, a.z, a.nbr_count, r, a.S, a.min_nn, a.coef, st);
+    const float thr = lk_track_threshold(a, n_part, parts);
+    const LkTrackRayLoss o = lk_track_ray_loss(a, in, thr);
     if (row) *row = o;
-    return lk_composite_bwd_sample(a.raw, a.z, a.nbr_count, r, a.S, sp - r * a.S, a.min_nn, a.coef, o.gt, o.dd, 0.0f, o.dc0, o.dc1, o.dc2);
+    float4 out[LK_S_MAX];
+    lk_ray_grad(st, a.S, a.coef, o.gt, o.dd, 0.0f, o.dc0, o.dc1, o.dc2, out);
+    const int s_own = sp - r * a.S;
+    float4 res = out[0];
+#pragma unroll
+    for (int s = 1; s < LK_S_MAX; ++s)
+        if (s == s_own) res = out[s];
+    return res;
 }
 
 __device__ __forceinline__ void lp_quat_rot(const float* __restrict__ cam, float (&Rm)[9]) {       // common.py:301-324
