@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-6 job I: the tracking loop's forward as one launch (k_track_fwd): parity tests, chain stamps, timeline, alternating bench runs
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+( timeout 1500 python -m pytest tests/test_steps_parity.py tests/test_forward_parity.py tests/test_parity_at_size.py tests/test_loops_at_size.py tests/test_teacher_forced.py tests/test_slam_api.py -m gpu -q -rf --tb=short 2>&1 | grep -v Warning | tail -40 ) > gpurun_out/r6i_tests.log 2>&1
+tail -4 gpurun_out/r6i_tests.log
+cp loopy_slam_amd/libloopyhip.so /tmp/lib_ship.so
+cp ab/lib_chain.so loopy_slam_amd/libloopyhip.so
+timeout 300 python tools/probe/track_chain.py 40 > gpurun_out/track_chain_r6i.md 2> gpurun_out/track_chain_r6i.err
+cp /tmp/lib_ship.so loopy_slam_amd/libloopyhip.so
+tail -3 gpurun_out/track_chain_r6i.err
+grep -A7 "four launches" gpurun_out/track_chain_r6i.md
+rm -rf /tmp/trace_track
+rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_track -o t -- python tools/mode_trace.py track 40 > /tmp/trace_track.log 2>&1
+python tools/trace_summary.py /tmp/trace_track "track (R = 1500)" gantt 2>/dev/null | grep -v "only in" | head -24
+bash tools/ab_quick.sh 3 base new
+cp /tmp/lib_ship.so loopy_slam_amd/libloopyhip.so

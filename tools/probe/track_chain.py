@@ -36,6 +36,17 @@ K2C = ('k_relpos_decode_fwd (colour waves 0-3)', 'fwd', [
 K2G = ('k_relpos_decode_fwd (geometry wave 4)', 'fwd', [
     (0, 'entry'), (1, 'W rel-pos inputs arrived'), (2, 'rel-pos hidden layer'), (3, 'rel-pos output stored'), (4, 'workgroup barrier'),
     (5, 'W embedding (96 sin) + c_geo'), (6, 'layer 0'), (7, 'layer 1'), (8, 'layer 2'), (9, 'layer 3'), (10, 'layer 4 + output')])
+# the forward as ONE launch (k_track_fwd, round 6): pose step, search, rel-pos MLP, decoders
+KFC = ('k_track_fwd (colour waves 0-3)', 'fwd', [
+    (0, 'entry'), (3, 'pose stepped (partials reduced, Adam, LDS)'), (4, 'search + interpolation of the wave\'s four samples (lists in registers, stores issued)'),
+    (1, 'W rel-pos operands arrived (positions, rows)'), (2, 'rel-pos hidden layer'), (15, 'rel-pos output + workgroup barrier'),
+    (14, 'W embedding share, c_col from LDS'), (5, 'barrier 0'), (6, 'layer 0 + barrier'), (7, 'layer 1 + barrier'),
+    (8, 'layer 2 + barrier'), (9, 'layer 3 + barrier'), (10, 'layer 4'), (11, 'output partials + barrier'), (12, 'wave 0: geometry wave done'),
+    (13, 'W wave 0: composite, outputs stored')])
+KFG = ('k_track_fwd (geometry wave 4)', 'fwd', [
+    (0, 'entry'), (3, 'pose stepped'), (4, 'search + interpolation'), (1, 'W rel-pos operands arrived'), (2, 'rel-pos hidden layer'),
+    (15, 'rel-pos output + workgroup barrier'), (5, 'W embedding (96 sin), c_geo from LDS'), (6, 'layer 0'), (7, 'layer 1'), (8, 'layer 2'), (9, 'layer 3'),
+    (10, 'layer 4 + output')])
 K3C = ('k_decode_bwd<true, true, false> (colour tiles)', 'bwd', [
     (0, 'entry'), (1, 'W threshold, loss term, composite backward'), (2, 'W d h_4, layer 4 operands'), (3, 'layer 4 parked + barrier'),
     (4, 'layer 3'), (5, 'layer 2'), (6, 'layer 1'), (7, 'layer 0'), (8, 'embedding gradient, d c partials + barrier'), (9, 'W stores retired')])
@@ -101,7 +112,8 @@ def main():
     n_k2 = (P + ts - 1) // ts
     tiles = (P + 31) // 32
     n_geo = (tiles + 3) // 4
-    t0 = t['sample'][:n_k1, :4, 0]
+    merged = not (t['sample'][:n_k1, :4, 0] > 0).any()          # k_track_fwd: the search is part of the forward launch
+    t0 = t['fwd'][:n_k2, :4, 0] if merged else t['sample'][:n_k1, :4, 0]
     t0 = int(t0[t0 > 0].min())
     out = [f'# One tracking iteration as a dependent chain (round 6): wall-clock stamps of the LAST of {iters} iterations, {R} rays x {S} samples, '
            f'N = {b.n_points} points', '',
@@ -110,10 +122,15 @@ def main():
            'launches 1-2 us each (the waits serialise loads the shipped build overlaps); read the table for the SHAPE of the chain, the shipped',
            'durations are in `r6_iteration_timeline.md`.  Times in us from the first stamp of the iteration\'s first launch.', '']
     spans = []
-    spans.append(('k_sample_interp_pose', table(K1[0], t['sample'], t0, slice(0, n_k1), [0, 1, 2, 3], K1[2], out)))
-    a = table(K2C[0], t['fwd'], t0, slice(0, n_k2), [0, 1, 2, 3], K2C[2], out)
-    g = table(K2G[0], t['fwd'], t0, slice(0, n_k2), [4], K2G[2], out)
-    spans.append(('k_relpos_decode_fwd', (min(a[0], g[0]), max(a[1], g[1]))))
+    if merged:
+        a = table(KFC[0], t['fwd'], t0, slice(0, n_k2), [0, 1, 2, 3], KFC[2], out)
+        g = table(KFG[0], t['fwd'], t0, slice(0, n_k2), [4], KFG[2], out)
+        spans.append(('k_track_fwd', (min(a[0], g[0]), max(a[1], g[1]))))
+    else:
+        spans.append(('k_sample_interp_pose', table(K1[0], t['sample'], t0, slice(0, n_k1), [0, 1, 2, 3], K1[2], out)))
+        a = table(K2C[0], t['fwd'], t0, slice(0, n_k2), [0, 1, 2, 3], K2C[2], out)
+        g = table(K2G[0], t['fwd'], t0, slice(0, n_k2), [4], K2G[2], out)
+        spans.append(('k_relpos_decode_fwd', (min(a[0], g[0]), max(a[1], g[1]))))
     a = table(K3C[0], t['bwd'], t0, slice(n_geo, n_geo + tiles), [0, 1, 2, 3], K3C[2], out)
     # a geometry workgroup is four independent one-wave tiles: a "workgroup" row here is the slowest of its waves
     g = table(K3G[0], t['bwd'], t0, slice(0, n_geo), [0, 1, 2, 3], K3G[2], out)

@@ -3,7 +3,7 @@
 
     python tools/trace_summary.py <dir with *_kernel_trace.csv> [label]
 
-An iteration = from one k_sample_interp (or k_interp_repack) dispatch - the first launch of every iteration type - to the next.  Reports, as medians over the last iterations of the trace:
+An iteration = from one k_sample_interp (or k_interp_repack, or the tracking loop's k_track_fwd) dispatch - the first launch of every iteration type - to the next.  Reports, as medians over the last iterations of the trace:
 the period (start to start), the sum of kernel durations, the idle time between kernels on the critical stream, and every
 kernel's duration / share.  Writes markdown to stdout."""
 import collections
@@ -27,7 +27,7 @@ def main():
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', ''), r.get('Queue_Id', '?')))
     rows.sort()
     # first launch of every iteration: the sampler (not its search-only form <T, 1>, which lk_map_frame runs ahead of the loop)
-    starts = [i for i, r in enumerate(rows) if r[2].startswith('k_interp_repack') or (r[2].startswith('k_sample_interp') and not r[2].rstrip().endswith(', 1>'))]
+    starts = [i for i, r in enumerate(rows) if r[2].startswith(('k_interp_repack', 'k_track_fwd')) or (r[2].startswith('k_sample_interp') and not r[2].rstrip().endswith(', 1>'))]
     if len(starts) < 8:
         print('too few iterations in the trace')
         return
