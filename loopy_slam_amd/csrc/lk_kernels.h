@@ -286,7 +286,9 @@ struct LkRelposBwdArgs {
 };
 // k_relpos_bwd_fused (lk_bwd2.hip): linear1's weight gradient inside the rel-pos backward - mapper mode only (scaled fp16 pieces
 // need unit-scale loss gradients; the ray-gradient products stay on the plain kernel)
+#ifndef LK_RPF_MAX_PARTS
 #define LK_RPF_MAX_PARTS 512                       // persistent workgroups: two per compute unit
+#endif
 static inline bool lk_relpos_fused(unsigned flags) {
     return (flags & LK_FLAG_GRAD_WEIGHTS) && (flags & LK_FLAG_UNIT_LOSS_GRADS) && !(flags & LK_FLAG_GRAD_RAYS);
 }
@@ -333,7 +335,9 @@ struct LkWgradArgs {
     const float* dscale;                           // as LkDecodeBwdArgs (h16 only)
 };
 static_assert(sizeof(LkWgradArgs) <= 3600, "LkWgradArgs travels as a kernel argument next to LkBwdReduceArgs (4 KB limit)");
+#ifndef LK_WG_MAX_WAVES
 #define LK_WG_MAX_WAVES 2048                       // waves of one weight-gradient launch: two per SIMD, all co-resident
+#endif
 #define LK_WG_TILE (4 * 16 * 64 + 64)              // floats per tile: accumulators [block][reg][lane] + bias sums
 // floats of LkWgradArgs::part (one tile per wave, whatever the problem size)
 inline int64_t lk_wgrad_part_floats(int64_t, bool) { return (int64_t)LK_WG_MAX_WAVES * LK_WG_TILE; }
