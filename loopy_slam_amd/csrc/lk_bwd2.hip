@@ -984,16 +984,17 @@ __device__ __forceinline__ WgVec<V> wg_load(const float* __restrict__ p) {
 // pieces (hi + lo, lk_split8h; A' times 2^10 first: unit-scale loss gradients put d h around 1e-4) and multiplied with three
 // instructions of 32 cycles per 16 rows instead of eight fp32 instructions of 64 cycles, which did not overlap with the
 // VALU work either.  The tile is scaled back when it is stored.
-// Tile mode inside a workgroup (LkWgLds): the waves of a workgroup that work on the SAME unit (a "run", ~3 waves) leave ONE tile.  EVERY wave of the
-// workgroup parks its tile in LDS (park), and behind the workgroup's one barrier the k-th wave of a run of r sums the k-th of r slices of the
-// run's tiles (run0: the run's first parked tile; leader first, then the followers in order - the order the leader alone used to add them in,
-// bit-identical) and stores it into the LEADER's global tile.  2 048 tiles of 16.6 KB per launch were 34 MB written and read back by the reduction
-// launch; about a third are left.  (Round 6 first had the leader add its followers' tiles element by element - a chain of 65 dependent LDS
-// round trips per follower at the very end of every wave's life, 6.4 us of a 48-us launch; shared out it is one batch of reads per wave.)
-struct LkWgLds { float* park; const float* run0; int r, k; };
+// Tile mode inside a workgroup (LkWgLds): the waves of a workgroup that work on the SAME unit (a "run", ~3 waves) leave ONE tile - the followers park
+// theirs in LDS (park), the first of the run (the leader) adds them to its own behind the workgroup's one barrier, in order, and stores the sum.
+// 2 048 tiles of 16.6 KB per launch were 34 MB written and read back by the reduction launch; about a third are left.  The leader reads ALL THREE
+// follower slots of every element unconditionally (in[f]: a follower's tile, or any valid tile where the run is shorter - the value is then
+// dropped by a select): with a loop over the run's length per element the sum was a chain of dependent LDS round trips at the very end of
+// every wave's life, 6.4 us of a 48-us launch (knock-out build), now one batch of reads per block.  (Sharing the sum out over the run's waves was
+// 1 us faster alone but needs all four tiles in LDS - 66 KB per workgroup, and k_feat_gather's workgroups no longer fit beside two of them.)
+struct LkWgLds { float* park; const float* in[3]; int n_in; bool on; };
 template <int NV, int KV, int MODE, bool H16>
 __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, int c0, int stride, int lane,
-                                           float* __restrict__ tile, int rows, bool aux_t = false, float dsc = 1.0f, LkWgLds wl = LkWgLds{nullptr, nullptr, 1, 0}) {
+                                           float* __restrict__ tile, int rows, bool aux_t = false, float dsc = 1.0f, LkWgLds wl = LkWgLds{nullptr, {nullptr, nullptr, nullptr}, 0, false}) {
     const int i = lane & 31, h = lane >> 5;
     // this lane's columns; out-of-range columns read a legal address and are zeroed (A) / never flushed (B)
     const int ncol = n0 + NV * i, kcol = k0 + KV * i;
@@ -1112,9 +1113,20 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
             __builtin_amdgcn_sched_barrier(0);          // keep consume(s) -> refill(s) order: the ring IS the schedule
         }
     }
-    // tile mode.  Without LDS (wl.park == nullptr: lk_wgrad_single) the wave stores its own tile.
+    // tile mode: a follower parks element idx in LDS, the leader (or a wave alone) adds the run's and stores
     if (tile) {
-        float* __restrict__ out = wl.park ? wl.park : tile;
+        const bool follower = wl.park != nullptr;
+        if (wl.on && !follower) __syncthreads();              // the followers' tiles are in LDS
+        auto put = [&](int idx, float v) {
+            if (follower) { wl.park[idx] = v; return; }
+            if (wl.on) {
+                const float v0 = wl.in[0][idx], v1 = wl.in[1][idx], v2 = wl.in[2][idx];
+                v += (wl.n_in > 0) ? v0 : 0.0f;
+                v += (wl.n_in > 1) ? v1 : 0.0f;
+                v += (wl.n_in > 2) ? v2 : 0.0f;
+            }
+            tile[idx] = v;
+        };
         if (aux_t && KV == 1) {
             // the auxiliary columns (M = d y^T c, LkFcPost): stored TRANSPOSED, [column kc][row n of the unit], because their only reader
             // (fc_post_body) sums ONE column over the tiles - in the lane-major layout below that was one float out of every 128-byte line,
@@ -1122,45 +1134,23 @@ __device__ __forceinline__ void wgrad_unit(const LkWgradJob& J, int n0, int k0, 
 #pragma unroll
             for (int bn = 0; bn < NV; ++bn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[i * 64 + NV * lk_frag_row(r, h) + bn] = acc[bn][0][r] * ISCALE;
+                for (int r = 0; r < 16; ++r) put(i * 64 + NV * lk_frag_row(r, h) + bn, acc[bn][0][r] * ISCALE);
         } else {       // partial tile [block (bn,bk)][register r][lane] + bias sums: 256-byte coalesced stores
 #pragma unroll
             for (int bn = 0; bn < NV; ++bn)
 #pragma unroll
                 for (int bk = 0; bk < KV; ++bk)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) out[((bn * KV + bk) * 16 + r) * 64 + lane] = acc[bn][bk][r] * ISCALE;
+                    for (int r = 0; r < 16; ++r) put(((bn * KV + bk) * 16 + r) * 64 + lane, acc[bn][bk][r] * ISCALE);
             if (k0 == 0) {
 #pragma unroll
                 for (int b = 0; b < NV; ++b) {
                     const float v = (bsum[b] + __shfl_xor(bsum[b], 32)) * ISCALE;
-                    if (h == 0) out[4 * 16 * 64 + NV * i + b] = v;
+                    if (h == 0) put(4 * 16 * 64 + NV * i + b, v);
                 }
             }
         }
-        if (!wl.park) return;
-        __syncthreads();
-        // slice k of r of the tile's rows of 64 floats, the run's tiles summed in order
-        const int n_rows = (aux_t && KV == 1) ? 32 : NV * KV * 16;          // (transposed: one row per column of the piece, 32 * NV entries each)
-        const int lo = wl.k * n_rows / wl.r, hi = (wl.k + 1) * n_rows / wl.r;
-        const float* __restrict__ t0 = wl.run0 + lane;
-        auto sum_row = [&](int row) {
-            float v = t0[row * 64];
-            if (wl.r > 1) v += t0[LK_WG_TILE + row * 64];
-            if (wl.r > 2) v += t0[2 * LK_WG_TILE + row * 64];
-            if (wl.r > 3) v += t0[3 * LK_WG_TILE + row * 64];
-            return v;
-        };
-        int row = lo;
-        for (; row + 4 <= hi; row += 4) {
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = sum_row(row + q);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tile[(row + q) * 64 + lane] = v[q];
-        }
-        for (; row < hi; ++row) tile[row * 64 + lane] = sum_row(row);
-        if (wl.k == 0 && k0 == 0 && !(aux_t && KV == 1) && lane < 32 * NV) tile[4 * 16 * 64 + lane] = sum_row(64);
+        if (wl.on && follower) __syncthreads();
         return;
     }
     // atomic flush: block (bn, bk), register r of lane (j = lane&31, h): n = n0 + NV*frag_row(r,h) + bn, k = k0 + KV*j + bk
@@ -1203,7 +1193,7 @@ __device__ __forceinline__ bool lk_wg_tile_stored(const LkWgradUnit& U, int y) {
 // the launch are co-resident (two per SIMD) and sweep the rows at the same speed, so the re-reads hit the XCD's L2.
 template <bool H16>
 __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
-    __shared__ float s_tile[4][LK_WG_TILE];          // every wave's tile (tile mode): the waves of a run share out the sum, see LkWgLds
+    __shared__ float s_tile[3][LK_WG_TILE];          // the followers' tiles of the workgroup's runs (tile mode): wave w parks in s_tile[w - 1]
     const int lane = lk_lane();
     const int x = lk_uniform((int)blockIdx.x & 7);
     const int w = lk_uniform((int)threadIdx.x >> 6);
@@ -1216,18 +1206,18 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     const LkWgradJob& J = a.job[U.job];
     const int jl = l - U.wave0;
     const int c0 = x + 8 * jl, stride = 8 * U.n_waves;
-    // the run of this unit's waves inside the workgroup: waves w0 .. w0 + r - 1, this one is its k-th; the first (the unit's first on this XCD, or the
-    // workgroup's wave 0) is the leader, whose global tile the run's sum goes to
-    LkWgLds wl{nullptr, nullptr, 1, 0};
-    int k_run = 0;
-    if (tiles) {
-        k_run = min(w, jl);
-        int after = 0;
-        while (w + 1 + after < 4 && jl + 1 + after < U.n_waves && l + 1 + after < a.n_waves) ++after;
-        wl.park = s_tile[w]; wl.run0 = s_tile[w - k_run]; wl.r = k_run + 1 + after; wl.k = k_run;
+    // the run of this unit's waves inside the workgroup: its first wave (the unit's first on this XCD, or the workgroup's wave 0) leads
+    LkWgLds wl{nullptr, {s_tile[0], s_tile[0], s_tile[0]}, 0, tiles};
+    const bool leader = jl == 0 || w == 0;
+    if (tiles && !leader) wl.park = s_tile[w - 1];
+    if (tiles && leader) {
+        int nf = 0;
+        while (w + 1 + nf < 4 && jl + 1 + nf < U.n_waves && l + 1 + nf < a.n_waves) ++nf;
+        wl.n_in = nf;                                                   // followers w + 1 .. w + nf parked in s_tile[w] .. s_tile[w + nf - 1]
+        for (int f = 0; f < 3; ++f) wl.in[f] = s_tile[f < nf ? w + f : 0];
     }
     // a wave without a chunk (tiny problems) still contributes its (zero) tile
-    float* tile = tiles ? a.part + ((size_t)8 * U.wave0 + 8 * (jl - k_run) + x) * LK_WG_TILE : nullptr;      // the run leader's tile
+    float* tile = tiles ? a.part + ((size_t)8 * U.wave0 + 8 * jl + x) * LK_WG_TILE : nullptr;
     // rows behind the live prefix of a partitioned batch were not written by their producers (k_decode_bwd skips those tiles)
     const int rows = a.live_rays ? min(J.rows, lk_uniform(*a.live_rays) * a.S) : J.rows;
     const float dsc = (H16 && a.dscale) ? *a.dscale : 1.0f;
