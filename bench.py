@@ -296,8 +296,9 @@ def main():
             rk = profile.roofline(kall, budget, kn)
             if rk is not None:
                 out['roofline_all_kernels'].append({k: (round(rk[k], 4) if isinstance(rk[k], float) else rk[k])
-                                                    for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'bound_from',
-                                                              'measured_bytes_per_launch_avg', 'algorithmic_flops_per_launch_avg', 't_mfma_over_t_hbm_measured') if k in rk})
+                                                    for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'achieved_from',
+                                                              'algorithmic_bytes_per_launch_avg', 'measured_bytes_per_launch_avg', 'frac_of_hbm_peak_measured_bytes',
+                                                              'algorithmic_flops_per_launch_avg', 't_mfma_over_t_hbm_measured') if k in rk})
         # the whole 'color' iteration (57 % of the step) against SURVEY 8(d)'s algorithmic bytes, from the committed per-stage counter table
         modes, src_st = profile.stage_traffic()
         if modes and 'color' in modes and out['roofline'] is not None:

@@ -216,10 +216,14 @@ def roofline(kstat, budget, kernel):
         path = '+'.join(sorted(p for p, f in model['flops_by_path'].items() if f > 0))
     t_hbm = nbytes / (PEAK_HBM_GBS * 1e9)
     out = {'kernel': kernel, 'launches': k['calls'], 'avg_launch_us': 1e3 * k['total_ms'] / k['calls'], 'traffic': None}
-    # Which roof binds the kernel is decided from MEASURED bytes where the per-stage counter table has them (round-5 review: the training
-    # forward was labelled `mfma` at 0.11 of the matrix roof while it WRITES 146 MB of saved activations per launch - it sits at 0.4 of
-    # the HBM roof): t_hbm = counter bytes / 8 TB/s against t_mfma = algorithmic flops / the pipe's roof; `achieved` on the HBM side is
-    # then counter bytes / time (the bytes the kernel really moves), `algorithmic_bytes_per_launch_avg` stays the model's figure beside it
+    # `achieved` is ALGORITHMIC work / time (the work model above: DESIGN.md section 3's bytes and MACs per sample x the samples of the launch).
+    # Which roof binds the kernel is decided from MEASURED bytes too where the per-stage counter table has them (round-5 review: the training
+    # forward was labelled `mfma` at 0.11 of the matrix roof while it WRITES 115-146 MB of saved activations per launch - it sits at 0.3-0.4
+    # of the HBM roof): a kernel whose model says `mfma` but whose counter bytes / 8 TB/s exceed its matrix time is bound by the bytes it
+    # really moves, and only then `achieved` is counter bytes / time (`achieved_from` says so; the model's bytes stay beside it).  For a
+    # kernel the model itself puts on the HBM roof (k_wgrad) the counter bytes are reported (`measured_bytes_per_launch_avg`,
+    # `frac_of_hbm_peak_measured_bytes`) and never replace the algorithmic figure.
+    model_bytes = nbytes
     modes, src_st = stage_traffic()
     meas = measured_bytes_per_step(budget, kernel, modes) if modes else None
     if meas is not None:
@@ -227,9 +231,10 @@ def roofline(kstat, budget, kernel):
         out['measured_bytes_source'] = src_st
         t_meas = meas * n_steps / (PEAK_HBM_GBS * 1e9)
         out['t_mfma_over_t_hbm_measured'] = (t_mfma / t_meas) if t_meas > 0 else None
-        if t_meas > t_mfma and t_meas > t_hbm:
+        out['frac_of_hbm_peak_measured_bytes'] = meas * n_steps / secs / 1e9 / PEAK_HBM_GBS
+        if t_mfma >= t_hbm and t_meas > t_mfma:
             nbytes, t_hbm = meas * n_steps, t_meas
-            out['bound_from'] = 'measured counter bytes'
+            out['bound_from'] = out['achieved_from'] = 'measured counter bytes (the work model has the kernel on the matrix roof)'
     if t_mfma >= t_hbm:
         out.update(bound='mfma', achieved=flops / secs / 1e12, peak=peak_mfma, unit='TFLOP/s', mfma_path=path,
                    frac_of_f32_mfma_peak=flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS)
@@ -243,5 +248,5 @@ def roofline(kstat, budget, kernel):
     if src:
         out['traffic_unit'], out['traffic_source'] = 'bytes per launch (HBM read + write)', src
     out['algorithmic_flops_per_launch_avg'] = flops / k['calls']
-    out['algorithmic_bytes_per_launch_avg'] = nbytes / k['calls']
+    out['algorithmic_bytes_per_launch_avg'] = model_bytes / k['calls']
     return out

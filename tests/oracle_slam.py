@@ -421,6 +421,8 @@ class OracleSLAM:
             loss.backward()
             opt.step()
             losses.append(float(loss.detach()))
+            if it == 0 and rec is not None:         # the small decoder tensors every sample shares, after the FIRST step (sign-like: lr g / (|g| + 1e-8))
+                w_first = {n: W[n].detach().clone() for n in dec_names if W[n].numel() <= 1024}
         with torch.no_grad():
             self.geo[rows] = geo_p.detach()
             self.col[rows] = col_p.detach()
@@ -434,7 +436,7 @@ class OracleSLAM:
                                  loss_first=losses[0] if losses else None, loss_last=losses[-1] if losses else None))
         if rec is not None:
             self.on_map(rec, dict(losses=list(losses), geo_rows=geo_p.detach().clone(), col_rows=col_p.detach().clone(),
-                                  W={n: W[n].detach().clone() for n in dec_names},
+                                  W={n: W[n].detach().clone() for n in dec_names}, W_first=w_first if num_joint_iters > 0 else {},
                                   xfeat=cur_x.detach().clone() if self.exposure_on else None))
         return num_joint_iters
 

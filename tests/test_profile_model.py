@@ -49,3 +49,23 @@ def test_roofline_prices_each_form_on_its_own_pieces():
         assert r is not None and r['kernel'] == name and 0 < r['frac'] < 1
     rm = profile.roofline({'k_decode_bwd': dict(calls=w['k_decode_bwd']['launches'], total_ms=1.0)}, b, 'k_decode_bwd')
     assert rm['peak'] == pytest.approx(profile.PEAK_F32_VIA_F16X3_TFLOPS, rel=1e-6) or rm['bound'] == 'hbm'
+
+
+def test_headline_roofline_is_priced_on_the_work_models_bytes():
+    """`achieved` of a kernel the work model itself puts on the HBM roof (k_wgrad) is ALGORITHMIC bytes / time - 5 424 B per sample x 25 000
+    samples per launch - whatever the committed counter table says; the counter bytes are reported beside it and only
+    decide the LABEL of a kernel the model has on the matrix roof (the training forward, bound by the activations it stores)."""
+    b = workload.Budget()
+    w = profile.work_per_step(b)['k_wgrad']
+    secs = 36 * 95e-6
+    r = profile.roofline({'k_wgrad': dict(calls=w['launches'], total_ms=secs * 1e3)}, b, 'k_wgrad')
+    per_launch = w['bytes'] / w['launches']
+    assert per_launch == pytest.approx(5424 * 25000, rel=0.02)
+    assert r['bound'] == 'hbm' and 'achieved_from' not in r
+    assert r['algorithmic_bytes_per_launch_avg'] == pytest.approx(per_launch)
+    assert r['achieved'] == pytest.approx(w['bytes'] / secs / 1e9) and r['frac'] == pytest.approx(r['achieved'] / profile.PEAK_HBM_GBS)
+    if 'measured_bytes_per_launch_avg' in r:          # (the committed per-stage table: what the kernel really moves, beside the model)
+        assert r['frac_of_hbm_peak_measured_bytes'] == pytest.approx(r['measured_bytes_per_launch_avg'] * w['launches'] / secs / 1e9 / profile.PEAK_HBM_GBS)
+    f = profile.roofline({'k_decode_fwd': dict(calls=profile.work_per_step(b)['k_decode_fwd']['launches'], total_ms=3.5)}, b, 'k_decode_fwd')
+    if f.get('achieved_from'):
+        assert f['bound'] == 'hbm' and f['algorithmic_bytes_per_launch_avg'] < f['measured_bytes_per_launch_avg']

@@ -161,33 +161,38 @@ class Replayer:
         eng, cfg = self.eng, self.cfg
         rcfg = slam.render_cfg_from(cfg, cfg['rendering']['sigmoid_coef_mapper'])
         W = rec['W']
-        dec = core.DecoderBlob(eng).pack(W)
         knn, dpos = self._index(rec['pos'])
-        dgeo, dcol = eng.f32(rec['geo']).clone(), eng.f32(rec['col']).clone()
         N, R, iters = rec['pos'].shape[0], rec['R'], rec['iters']
-        xp = feats = None
-        if rec['xfeats'] is not None:
-            mlp = _exposure_module(W, eng.device)
-            feats = [eng.f32(x).clone().requires_grad_(True) for x in rec['xfeats']]
-            xp = (mlp, feats)
-        mo = steps.MapOptimizer(eng, rcfg, dec, knn, dpos, dgeo, dcol, None, R, rec['lrs'], w_color=rec['w_color'], dynamic_radius=rec['rstack'] is not None,
-                                fix_color_decoder=rec['fix_color_decoder'], exposure=xp)
-        assert mo._takes_native_loop()
         rows = rec['rows']
-        all_rows = rows.numel() == N and bool((rows == torch.arange(N)).all())
-        if all_rows:
-            mo.begin_frame()
-        else:
-            mask = torch.zeros(N, dtype=torch.uint8)
-            mask[rows] = 1
-            mo.new_frame(rows.to(torch.int32).to(eng.device), mask.to(eng.device))
-        log = eng.zeros(iters, 4)
-        frames = (eng.f32(rec['dstack']), eng.f32(rec['cstack']), eng.f32(rec['pstack']), eng.f32(rec['rstack']) if rec['rstack'] is not None else None)
         n_geo = min(iters, rec['geo_iters'] + 1)                    # stage 'geometry' while it <= geo_iters (Mapper.py:594-597)
-        mo.run(iters, n_geo, frames, rec['rnd'].to(torch.int32).to(eng.device), rec['fid'].to(torch.int32).to(eng.device), (0, self.H, 0, self.W),
-               self.intr, self.H, self.W, log)
-        mo.finish()
-        _sync(eng)
+
+        def product(n_it=iters):
+            dec = core.DecoderBlob(eng).pack(W)
+            dgeo, dcol = eng.f32(rec['geo']).clone(), eng.f32(rec['col']).clone()
+            xp = feats = mlp = None
+            if rec['xfeats'] is not None:
+                mlp = _exposure_module(W, eng.device)
+                feats = [eng.f32(x).clone().requires_grad_(True) for x in rec['xfeats']]
+                xp = (mlp, feats)
+            mo = steps.MapOptimizer(eng, rcfg, dec, knn, dpos, dgeo, dcol, None, R, rec['lrs'], w_color=rec['w_color'], dynamic_radius=rec['rstack'] is not None,
+                                    fix_color_decoder=rec['fix_color_decoder'], exposure=xp)
+            assert mo._takes_native_loop()
+            all_rows = rows.numel() == N and bool((rows == torch.arange(N)).all())
+            if all_rows:
+                mo.begin_frame()
+            else:
+                mask = torch.zeros(N, dtype=torch.uint8)
+                mask[rows] = 1
+                mo.new_frame(rows.to(torch.int32).to(eng.device), mask.to(eng.device))
+            log = eng.zeros(n_it, 4)
+            frames = (eng.f32(rec['dstack']), eng.f32(rec['cstack']), eng.f32(rec['pstack']), eng.f32(rec['rstack']) if rec['rstack'] is not None else None)
+            mo.run(n_it, min(n_geo, n_it), frames, rec['rnd'][:n_it].to(torch.int32).to(eng.device), rec['fid'].to(torch.int32).to(eng.device), (0, self.H, 0, self.W),
+                   self.intr, self.H, self.W, log)
+            mo.finish()
+            _sync(eng)
+            return log, dgeo, dcol, dec, feats, mlp
+
+        log, dgeo, dcol, dec, feats, mlp = product()
         kl, ol = log[:, 0].cpu().numpy().astype(np.float64), np.array(out['losses'])
         rel = np.abs(kl - ol) / np.abs(ol)
         s = dict(idx=rec['idx'], iters=iters, n_geo=n_geo, rays=R, rows=int(rows.numel()), points=N, frames=rec['F'], loss_rel_first=float(rel[0]),
@@ -212,6 +217,32 @@ class Replayer:
             s['xfeat_err'] = float((feats[-1].detach().cpu() - out['xfeat']).abs().max())
             s['xfeat_moved'] = float((out['xfeat'] - rec['xfeats'][-1]).abs().max())
             s['keyframe_feats_constant'] = all(torch.equal(f.detach().cpu(), x) for f, x in zip(feats[:-1], rec['xfeats'][:-1]))
+        # WHICH BRANCH: Adam's first step is sign-like (lr g / (|g| + 1e-8)) and the decoder's small tensors - the Fourier matrices - are shared by every
+        # sample; their gradients are cancelling sums over the batch that fp32 resolves to ~1e-3 of the tensor's largest entry (the fp32 oracle
+        # itself is that far from a float64 evaluation).  An entry below that takes its first step either way, and from the second iteration on
+        # EVERY sample sees another embedding: on the chip about one 10-iteration TUM / ScanNet call in thirty ended with 1 % of its stepped
+        # geometry entries 4e-3 ... 7e-3 from the oracle's (bulk of the other calls: 3e-4 ... 7e-4) - reproducibly on the same record (three
+        # replays agree to 1e-4), on the host emulator as on the chip, per-statement path as native loop, exhaustive search as KD-tree, with ONE
+        # entry of geo_decoder.embedder._B stepped the other way (oracle gradient +3.3e-4, product -1.2e-4, largest entry 0.65; float64: +1.3e-3;
+        # tools/probe/tf_outlier.py).  So: the product's first step alone (one iteration of the same call) against the oracle's tensors after ITS
+        # first step - the number of entries that went the other way is recorded and check_map holds a call to the tight bounds only on the
+        # oracle's own branch.
+        if iters <= 40 and iters > 1 and out.get('W_first'):
+            W1 = product(1)[3].unpack()
+            lr0 = rec['lrs']['geometry'][0]
+            s['first_step_flips'] = int(sum(int(((W1[n].reshape(v.shape).cpu() - v).abs() > lr0).sum()) for n, v in out['W_first'].items() if n in W1)) if lr0 > 0 else 0
+        short_outlier = iters <= 40 and (s['geo_err_q99'] > 0.02 * lr_g * iters ** 0.5 or s['geo_err_q999'] > 0.1 * lr_g * iters ** 0.5)
+        if short_outlier:           # is it the call or the run?  the product twice more on the same record
+            rp = []
+            for _ in range(2):
+                lg2, g2 = product()[:2]
+                rp.append(dict(geo_err_q99=param_error_stats(g2.cpu()[rows], out['geo_rows'], rec['geo'][rows])['err_q99'],
+                               geo_vs_first_run_q99=param_error_stats(g2.cpu()[rows], gk[rows], rec['geo'][rows])['err_q99']))
+            s['replay'] = rp
+            dump = os.environ.get('LK_TF_DUMP')                    # diagnosis: the call's record, for a replay elsewhere (tools/probe/tf_outlier.py)
+            if dump:
+                torch.save({'rec': {k: v for k, v in rec.items()}, 'out': out, 'case': self.case, 'product_geo_rows': gk[rows], 'product_losses': kl},
+                           os.path.join(dump, f'tf_outlier_{self.case}_{rec["idx"]}.pt'))
         if iters > 40:
             # YARDSTICK of a long call: the oracle loop once more with both feature tables perturbed by 1e-7 relative, against the oracle's own run
             g = torch.Generator().manual_seed(1000 + rec['idx'])
@@ -266,9 +297,15 @@ class Replayer:
                 assert s[f'{t}_err_q99'] <= max(3.0 * s[f'yard_{t}_err_q99'], 1e-3) and s[f'{t}_err_q999'] <= max(3.0 * s[f'yard_{t}_err_q999'], 5e-3), (t, s)
         else:
             assert rel.max() <= 2e-3, ('loss, whole call', s)
-            assert s['geo_err_q99'] <= 0.02 * lr_g * iters ** 0.5 and s['geo_err_q999'] <= 0.1 * lr_g * iters ** 0.5, s
-            assert s['col_err_q99'] <= 0.05 * lr_c * n_col ** 0.5 + 2e-3 and s['col_err_q999'] <= 0.2 * lr_c * n_col ** 0.5 + 4e-3, s
+            # on the oracle's own branch (no shared decoder entry took its first step the other way, on_map "WHICH BRANCH") the stepped rows are
+            # held tightly; on another branch to a sanity band (measured there: q99 <= 7.1e-3, q99.9 <= 2.3e-2 after ten iterations), and such a
+            # call must reproduce on its own record (no run-to-run effect hiding behind the branch)
+            k = 1.0 if s.get('first_step_flips', 0) == 0 else 6.0
+            assert s['geo_err_q99'] <= k * 0.02 * lr_g * iters ** 0.5 and s['geo_err_q999'] <= k * 0.1 * lr_g * iters ** 0.5, s
+            assert s['col_err_q99'] <= k * (0.05 * lr_c * n_col ** 0.5 + 2e-3) and s['col_err_q999'] <= k * (0.2 * lr_c * n_col ** 0.5 + 4e-3), s
             assert s['decoder_excess_q999'] <= 2e-2, s
+            for r in s.get('replay', []):
+                assert r['geo_vs_first_run_q99'] <= 1e-3, ('a call off the oracle\'s branch must reproduce on its own record', s)
         assert s['geo_err_max'] <= 2.0 * lr_g * iters and s['col_err_max'] <= 2.0 * max(lr_c, lr_g) * iters, s
         if 'xfeat_err' in s:
             assert s['xfeat_err'] <= 3e-4 and s['xb2_err'] <= 3e-4 and s['keyframe_feats_constant'], s
