@@ -16,3 +16,11 @@ for f in loops_at_size teacher_forced bench_dist_one_rank; do      # (compact: t
   [ -f gpurun_out/$f.json ] && python -c "import json; json.dump(json.load(open('gpurun_out/$f.json')), open('profiles/${tag}_$f.json', 'w'), separators=(',', ':'))"
 done
 ls -la profiles/${tag}_* | awk '{print $5, $9}'
+# round 6: per-stage counter traffic (the roofline's measured bytes), single-stream colour iteration, tracking chain, measurement grid, accuracy
+[ -f gpurun_out/stage_traffic_$tag.json ] && cp gpurun_out/stage_traffic_$tag.json profiles/${tag}_stage_traffic.json && cp gpurun_out/stage_traffic_$tag.md profiles/${tag}_color_iteration_traffic.md
+[ -f gpurun_out/gantt_${tag}_color_serial.md ] && cp gpurun_out/gantt_${tag}_color_serial.md profiles/${tag}_color_iteration_one_stream.md
+[ -f gpurun_out/track_chain_$tag.md ] && cp gpurun_out/track_chain_$tag.md profiles/${tag}_track_chain.md
+[ -f gpurun_out/sweep_$tag.md ] && cp gpurun_out/sweep_$tag.md profiles/${tag}_sweep.md
+[ -f gpurun_out/gpu_tests_$tag.log ] && tail -n 12 gpurun_out/gpu_tests_$tag.log > profiles/${tag}_gpu_tests.txt
+ls gpurun_out/accuracy_*.json > /dev/null 2>&1 && python tools/accuracy_summary.py $tag > /dev/null
+ls -la profiles/${tag}_* | awk '{print $5, $9}'

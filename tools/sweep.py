@@ -16,16 +16,19 @@ from loopy_slam_amd import core, workload, synthetic as syn
 
 
 def timed(fn, iters, warm=2):
+    """Median over `iters` calls, each between its own pair of events (one call that lands behind a free / a first-use allocation of the process -
+    the r6 grid first had ONE cell at 15 x its neighbours - does not set the figure)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in ev:
+        e0.record()
         fn()
-    e1.record()
+        e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    t = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return t[len(t) // 2]
 
 
 def main():
