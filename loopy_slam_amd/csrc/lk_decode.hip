@@ -225,11 +225,7 @@ __device__ __forceinline__ void lk_geo_stage(const LkDecodeArgs& a, int w, int l
 #pragma unroll
         for (int c = 0; c < 2 * NBLK[m]; ++c, ++chunk) {
             if ((chunk & 7) == w) {
-#ifndef HIPEMU
                 __builtin_amdgcn_global_load_lds(FB + SRC[m] + c * 64 + lane, (__attribute__((address_space(3))) u32x4*)(s_gw + chunk * 64), 16, 0, 0);
-#else
-                s_gw[chunk * 64 + lane] = FB[SRC[m] + c * 64 + lane];
-#endif
             }
         }
     }

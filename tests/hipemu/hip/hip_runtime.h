@@ -251,6 +251,12 @@ static inline float __builtin_amdgcn_exp2f(float v) { return ::exp2f(v); }
 static inline float __builtin_amdgcn_logf(float v) { return ::log2f(v); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only ever applied to wave-uniform values
 static inline void __builtin_amdgcn_s_setprio(int) {}
+// global_load_lds_dwordx4 (gfx950): every lane's 16 bytes go straight to LDS at (uniform base) + 16 * lane, no register in between
+template <class G, class L>
+static inline void __builtin_amdgcn_global_load_lds(const G* g, L lds_base, int size, int, int) {
+    char* dst = (char*)(__UINTPTR_TYPE__)lds_base + (size_t)size * hipemu::lane_id();
+    __builtin_memcpy(dst, (const void*)g, size);
+}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 // compiler-level wave barrier on the device; here the point where every lane's LDS accesses so far have happened
 static inline void __builtin_amdgcn_s_sleep(int) { hipemu::spin_yield(); }
