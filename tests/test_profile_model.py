@@ -69,3 +69,34 @@ def test_headline_roofline_is_priced_on_the_work_models_bytes():
     f = profile.roofline({'k_decode_fwd': dict(calls=profile.work_per_step(b)['k_decode_fwd']['launches'], total_ms=3.5)}, b, 'k_decode_fwd')
     if f.get('achieved_from'):
         assert f['bound'] == 'hbm' and f['algorithmic_bytes_per_launch_avg'] < f['measured_bytes_per_launch_avg']
+
+
+def test_work_model_against_the_decoders_own_shapes_and_the_counter_table():
+    """The MACs per sample the roofline is priced on, derived independently from the shapes of the weight tensors the kernels consume
+    (synthetic.default_weights: the reference's NICER decoders, decoder.py:12-43,180-288,431-626), and the model's bytes for the dominant
+    kernel held against what the PMC counters of the committed per-stage table say it really moves (round-5 review: the model was checked
+    only against itself)."""
+    from loopy_slam_amd import synthetic as syn
+    W = syn.default_weights(rel_pos=True)
+    mm = lambda prefix: sum(v.shape[0] * v.shape[1] for k, v in W.items() if k.startswith(prefix) and k.endswith('.weight'))
+    M = profile.MAC
+    col = mm('color_decoder.pts_linears') + mm('color_decoder.fc_c') + mm('color_decoder.output_linear')
+    geo = mm('geo_decoder.pts_linears') + mm('geo_decoder.fc_c') + mm('geo_decoder.output_linear')
+    assert M['dec_fwd_col'] == col == 96640
+    assert M['dec_fwd_geo'] == geo == 15200                                     # (+ 3 x 93 for the Fourier argument, on the vector unit)
+    assert M['rel_fwd'] == 8 * mm('color_decoder.mlp_col_neighbor') == 86016    # eight neighbours per sample
+    # weight gradients: one outer product per trunk / output matrix entry + the 32 auxiliary columns M_i = d y_i^T c of the four trunk jobs and
+    # the output job that the fc_c gradients are formed from (DESIGN section 3, k_wgrad (b))
+    assert M['wgrad_col'] == mm('color_decoder.pts_linears') + mm('color_decoder.output_linear') + 4 * 128 * 32 + 3 * 32
+    # backward-data: every trunk matrix transposed, minus the first layer's embedding columns (no gradient wanted there in mapper mode)
+    assert M['dec_bwd_col'] == 3 * 128 * 128 + 128 * 128 + mm('color_decoder.fc_c') + mm('color_decoder.output_linear')
+    # bytes of the dominant kernel: the model's rows (d y 640 + layer inputs 512 + e 40 + c 32 + h_4 128 + d logit 4 floats per sample) against the counters
+    b = workload.Budget()
+    w = profile.work_per_step(b)['k_wgrad']
+    per_launch = w['bytes'] / w['launches']
+    assert per_launch == pytest.approx(4.0 * (640 + 512 + 40 + 32 + 128 + 4) * b.map_rays * profile.S)
+    modes, src = profile.stage_traffic()
+    if modes:
+        k = [v for n, v in modes['color']['kernels'].items() if n.startswith('k_wgrad')][0]
+        read_mb = k['read_mb_per_launch']
+        assert 0.85 <= per_launch / 1e6 / read_mb <= 1.02, (per_launch, read_mb, src)      # the rows are fetched 1.0-1.15 x (units that share rows, XCD by XCD)
