@@ -58,6 +58,25 @@ __global__ __launch_bounds__(256) void k_read_half_dup(const float2* __restrict_
     }
     if (acc == 123.456f) out[0] = acc;
 }
+// ... and as k_wgrad has it since the XCD-aware ownership: the two waves that request a row half sit in DIFFERENT workgroups of the same XCD (b and b + gridDim / 2)
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_read_half_dup_far(const float2* __restrict__ src, size_t rows, float* __restrict__ out) {
+    const int w = threadIdx.x / 64, lane = threadIdx.x & 63;
+    const size_t half_grid = gridDim.x / 2;
+    const size_t b = blockIdx.x % half_grid;              // both copies walk the same row pairs
+    const int h = (w & 1);
+    float acc = 0.f;
+    const size_t pairs = rows / 2;
+    // a workgroup takes two consecutive groups of DEPTH row pairs, waves (0, 1) the two halves of the first, (2, 3) of the second; the far copy (b + gridDim / 2) reads the same
+    for (size_t p = (b * 2 + (w >> 1)) * DEPTH; p + DEPTH <= pairs; p += half_grid * 2 * DEPTH) {
+        float2 v[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) v[d] = src[(2 * (p + d) + (lane >> 5)) * 64 + (lane & 31) + 32 * h];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) acc += v[d].x + v[d].y;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
 // the same rows staged ONCE per workgroup: every wave loads a quarter of the chunk (contiguous 16-B loads), LDS hands the halves out
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_read_lds(const float4* __restrict__ src, size_t rows, float* __restrict__ out) {
@@ -137,6 +156,8 @@ int main() {
             run("read half rows depth 30, 512 workgroups", bytes, nbuf, [&](float4* p) { hipLaunchKernelGGL(k_read_half<30>, dim3(512), dim3(256), 0, 0, (const float2*)p, bytes / 512, out); });
             run("read half rows TWICE per workgroup depth 16, 512", bytes, nbuf, [&](float4* p) { hipLaunchKernelGGL(k_read_half_dup<16>, dim3(512), dim3(256), 0, 0, (const float2*)p, bytes / 512, out); });
             run("read half rows TWICE per workgroup depth 8, 512", bytes, nbuf, [&](float4* p) { hipLaunchKernelGGL(k_read_half_dup<8>, dim3(512), dim3(256), 0, 0, (const float2*)p, bytes / 512, out); });
+            run("read half rows ONCE, 1024 workgroups (each half by one wave)", bytes, nbuf, [&](float4* p) { hipLaunchKernelGGL(k_read_half<16>, dim3(1024), dim3(256), 0, 0, (const float2*)p, bytes / 512, out); });
+            run("read every half row TWICE from far workgroups depth 16, 512", bytes, nbuf, [&](float4* p) { hipLaunchKernelGGL(k_read_half_dup_far<16>, dim3(512), dim3(256), 0, 0, (const float2*)p, bytes / 512, out); });
             run("read once into LDS (32-row chunks), 512", bytes, nbuf, [&](float4* p) { hipLaunchKernelGGL(k_read_lds<32>, dim3(512), dim3(256), 0, 0, p, bytes / 512, out); });
             run("read once into LDS (32-row chunks), 768", bytes, nbuf, [&](float4* p) { hipLaunchKernelGGL(k_read_lds<32>, dim3(768), dim3(256), 0, 0, p, bytes / 512, out); });
             run("read once into LDS (64-row chunks), 512", bytes, nbuf, [&](float4* p) { hipLaunchKernelGGL(k_read_lds<64>, dim3(512), dim3(256), 0, 0, p, bytes / 512, out); });
