@@ -1200,8 +1200,12 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     const int l = lk_uniform(((int)blockIdx.x >> 3) * 4 + w);      // wave slot inside the XCD
     const bool tiles = a.part != nullptr;
     if (l >= a.n_waves) { if (tiles) __syncthreads(); return; }       // (every wave of a tile-mode workgroup meets the one barrier)
-    int u = 0;
-    while (u + 1 < a.n_units && l >= a.unit[u + 1].wave0) ++u;        // scalar scan, <= 48 entries
+    // the two device-side scalars of the launch first: their round trips run beside the unit look-up (they were two dependent loads behind it)
+    const int live_rays = a.live_rays ? lk_uniform(*a.live_rays) : 0;
+    const float dsc = (H16 && a.dscale) ? *a.dscale : 1.0f;
+    int u = 0;                                                          // the unit whose slots [wave0, wave0 + n_waves) hold l: bisection over <= 48 entries
+    for (int step = 32; step > 0; step >>= 1)
+        if (u + step < a.n_units && l >= a.unit[u + step].wave0) u += step;
     const LkWgradUnit& U = a.unit[u];
     const LkWgradJob& J = a.job[U.job];
     const int jl = l - U.wave0;
@@ -1219,8 +1223,7 @@ __global__ __launch_bounds__(256) void k_wgrad(LkWgradArgs a) {
     // a wave without a chunk (tiny problems) still contributes its (zero) tile
     float* tile = tiles ? a.part + ((size_t)8 * U.wave0 + 8 * jl + x) * LK_WG_TILE : nullptr;
     // rows behind the live prefix of a partitioned batch were not written by their producers (k_decode_bwd skips those tiles)
-    const int rows = a.live_rays ? min(J.rows, lk_uniform(*a.live_rays) * a.S) : J.rows;
-    const float dsc = (H16 && a.dscale) ? *a.dscale : 1.0f;
+    const int rows = a.live_rays ? min(J.rows, live_rays * a.S) : J.rows;
     if (!tile && c0 >= (rows + WG_CHUNK - 1) / WG_CHUNK) return;
     if (U.nv == 2 && U.kv == 2) wgrad_unit_mode<2, 2, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc, wl);
     else if (U.nv == 2) wgrad_unit_mode<2, 1, H16>(J, U.n0, U.k0, c0, stride, lane, tile, rows, dsc, wl);
