@@ -71,3 +71,24 @@ def test_saturated_operand_is_flagged_under_the_debug_flag(backend):
     eng.clear_status()
     st2 = _render(eng, W, extra=_ffi.FLAG_CHECK_RANGE)
     assert eng.status(sync=True) == 0 and torch.equal(st2.depth, ref)
+
+
+@pytest.mark.gpu
+def test_a_decoder_trained_in_the_loop_stays_in_range():
+    """Round-5 review: only default-init weights (x 3, x 30) had been through the range test.  No pretrained checkpoint is available offline, so the
+    decoders are trained where the system trains them: the drop-in pipeline over 21 frames of the synthetic room (five mapped frames, ~1 500 joint
+    iterations on the colour decoder at lr 5e-3, every forward launched with LK_FLAG_CHECK_RANGE through LOOPY_CHECK_RANGE=1) must end without a
+    range status - any flagged operand makes the next entry point fail with LK_ERR_RANGE and the run exit non-zero."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'run.json')
+        env = dict(os.environ, LOOPY_CHECK_RANGE='1')
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'slam_run.py'), '--frames', '21', '--out', out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.load(open(out))
+        assert d['ate_rmse_cm'] < 2.0            # (and it still tracks: the checked kernels are the same kernels)
