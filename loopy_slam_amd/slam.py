@@ -878,7 +878,7 @@ class Tracker:
                                       self.npc.get_col_feats(), n_px, self.cam_lr, separate_lr=self.separate_LR,
                                       w_color=self.w_color_loss, use_color=self.use_color_in_tracking,
                                       dynamic_radius=r2_query is not None, dist=getattr(slam, 'dist', None),
-                                      handle_dynamic=self.handle_dynamic)
+                                      handle_dynamic=self.handle_dynamic, shard_rays=bool(self.cfg['tracking'].get('shard_rays', False)))
             exposure = None
             if slam.encode_exposure:                # this frame's exposure feature starts from the shared one (Tracker.py:280-283)
                 self.exposure_feat = slam.exposure_feat.detach().clone().requires_grad_(True)

@@ -455,15 +455,25 @@ class TrackOptimizer:
     """Pose optimisation of one frame: Adam over the 7-vector (quaternion wxyz, translation)."""
 
     def __init__(self, eng, cfg, dec, knn, pos, geo_feats, col_feats, R, cam_lr, separate_lr=True, w_color=0.5,
-                 use_color=True, dynamic_radius=False, dist=None, handle_dynamic=True):
+                 use_color=True, dynamic_radius=False, dist=None, handle_dynamic=True, shard_rays=False):
         self.eng, self.cfg, self.dec, self.knn = eng, cfg, dec, knn
         self.pos, self.geo, self.col = pos, geo_feats, col_feats
         self.R, self.cam_lr, self.separate_lr = R, cam_lr, separate_lr
         self.w_color, self.use_color = w_color, use_color
         self.handle_dynamic = handle_dynamic    # False: median-of-residual outlier mask (Tracker.py:177-179)
-        self.batch = RayBatch(eng, R, dynamic_radius)
-        self.st = core.RenderState(eng, R, cfg.S, need_act=True)
-        self.gs = core.GradState(eng, geo_feats.shape[0], R, dec.n, feats=False, weights=False, rays=True)
+        # shard_rays (opt-in, `tracking.shard_rays`; SURVEY 8(e) "contiguous ray ranges (tracking, ...)"): rank r renders and back-propagates the
+        # contiguous range parallel.ray_range(R, r, world) of every iteration's draws, ONE all-reduce per iteration sums {pose gradient (7), loss
+        # row (4), exposure-affine gradient (12)} and the identical Adam step runs on every rank.  Per-statement path (the exchange sits between
+        # the backward and the step).  The inside mask and the residual median are per shard, as the mapper's (DESIGN section 4 "deviations").
+        self.shard_rays = bool(shard_rays and dist is not None and dist.world > 1)
+        self.R_own = R
+        if self.shard_rays:
+            from . import parallel
+            self.own = parallel.ray_range(R, dist.rank, dist.world, 1)
+            self.R_own = max(1, max(parallel.ray_range(R, r, dist.world, 1)[1] - parallel.ray_range(R, r, dist.world, 1)[0] for r in range(dist.world)))
+        self.batch = RayBatch(eng, self.R_own, dynamic_radius)
+        self.st = core.RenderState(eng, self.R_own, cfg.S, need_act=True)
+        self.gs = core.GradState(eng, geo_feats.shape[0], self.R_own, dec.n, feats=False, weights=False, rays=True)
         self.g_cam = eng.zeros(7)
         self.eye = None
         # Multi-GPU: tracking is REPLICATED, not sharded.  An iteration at the reference's batch (1 500-5 000 rays) sits at the
@@ -472,7 +482,7 @@ class TrackOptimizer:
         # native loop on the same draws against its replica of the map; rank 0's result is broadcast once per frame so that the
         # ranks cannot drift apart through the loss log's float atomics (the candidate choice, Tracker.py:375-377).
         self.dist = dist
-        self.native_loop = True                 # lk_track_frame (one call per frame); False = one launch sequence per statement
+        self.native_loop = not self.shard_rays  # lk_track_frame (one call per frame); False = one launch sequence per statement
 
     def track(self, cam7_init, depth_img, color_img, iters, window, intr, rnd_all, r2_map=None, exposure=None):
         """Tracker.run loop body for one frame (Tracker.py:313-401).  cam7_init: [7] device tensor.
@@ -499,11 +509,21 @@ class TrackOptimizer:
             self.eye = torch.eye(4, device=eng.device).reshape(1, 4, 4).contiguous()
         dstack, cstack = depth_img.reshape(1, H, W), color_img.reshape(1, H, W, 3)
         r2s = r2_map.reshape(1, H, W) if r2_map is not None else None
+        xch = eng.zeros(7 + 4 + 12) if self.shard_rays else None
         for it in range(iters):
             if self.separate_lr:
                 hist[it].copy_(cam)             # candidate = detached copy of the pose BEFORE the step (Tracker.py:363-377)
             # pixels, depth, colour (identity pose: only the image gathers are used), then rays of the CURRENT pose
-            optim.gather_rays(eng, dstack, cstack, self.eye, None, rnd_all[it], H, W, window, intr, b.as_out(), r2s)
+            draws = rnd_all[it]
+            if self.shard_rays:                 # this rank's contiguous range of the batch, padded to the largest range with its last draw
+                lo, hi = self.own
+                draws = draws[lo:hi] if hi > lo else draws[:1]
+                if draws.shape[0] < self.R_own:
+                    draws = torch.cat([draws, draws[-1:].expand(self.R_own - draws.shape[0])])
+                draws = draws.contiguous()
+            optim.gather_rays(eng, dstack, cstack, self.eye, None, draws, H, W, window, intr, b.as_out(), r2s)
+            if self.shard_rays and hi - lo < self.R_own:
+                b.gt_depth[max(hi - lo, 0):].zero_()             # the padding: rays without a reading are absent from the losses and carry no gradient
             optim.rays_from_pose(eng, cam, b.pix_i, b.pix_j, intr, b.rays_o, b.rays_d)
             optim.inside_mask(eng, b.gt_depth, None, b.thr, b.scratch_u32, depth_filtered=b.gt_depth)
             aff = None
@@ -517,6 +537,14 @@ class TrackOptimizer:
                                log[it], b.loss_scratch, handle_dynamic=self.handle_dynamic)
             core.render_backward(eng, st, gs, b.d_depth, b.d_color)
             optim.pose_bwd(eng, cam, b.pix_i, b.pix_j, intr, gs.g_rays_o, gs.g_rays_d, self.g_cam)
+            if self.shard_rays:                 # the iteration's one exchange: sums over the ranks' ranges
+                xch[:7].copy_(self.g_cam); xch[7:11].copy_(log[it])
+                if xs is not None:
+                    xch[11:].copy_(gs.g_affine)
+                self.dist.all_reduce_vec(xch)
+                self.g_cam.copy_(xch[:7]); log[it].copy_(xch[7:11])
+                if xs is not None:
+                    gs.g_affine.copy_(xch[11:])
             if self.separate_lr:                # T: lr, quaternion: 0.2*lr (Tracker.py:317-333)
                 segs = [('T', cam[4:7], self.g_cam[4:7], self.cam_lr), ('q', cam[0:4], self.g_cam[0:4], 0.2 * self.cam_lr)]
             else:

@@ -350,6 +350,109 @@ def test_two_rank_render_img_equals_the_full_frame_render(backend):
     assert res[0][5] == res[1][5] > 300
 
 
+# ------------------------------------------------------------------ tracking shared out by ray ranges (opt-in: tracking.shard_rays)
+T_R, T_ITERS = 91, 4            # odd: the ranks' ranges are 45 and 46 rays, the shorter one is padded with an absent ray
+
+
+def _track_setup(eng, dctx, shard):
+    from loopy_slam_amd import core, steps, synthetic as syn
+    from test_steps_parity import mini_scene
+    c2w, depth_img, color_img, pos, geo, col = mini_scene(3)
+    depth_img = depth_img.clone()
+    depth_img.reshape(-1)[5] = 1.0                       # no outlier: the inside mask keeps every positive depth, on every shard
+    W = syn.default_weights(seed=9, rel_pos=True)
+    dec = core.DecoderBlob(eng).pack(W)
+    pos_d, geo_d, col_d = eng.f32(pos), eng.f32(geo), eng.f32(col)
+    knn = core.KnnIndex(eng, capacity=pos.shape[0])
+    knn.build(pos_d)
+    to = steps.TrackOptimizer(eng, core.RenderCfg(rel_pos=True), dec, knn, pos_d, geo_d, col_d, T_R, 2e-4, separate_lr=True, w_color=0.5,
+                              dist=dctx, shard_rays=shard)
+    from loopy_slam_amd import common
+    cam0 = common.get_tensor_from_camera(c2w)
+    cam0 = cam0 + torch.tensor([0, 0, 0, 0, 0.004, -0.003, 0.002])         # a pose a few millimetres off
+    g = torch.Generator().manual_seed(33)
+    rnd = torch.randint(0, HH * WW, (T_ITERS, T_R), generator=g, dtype=torch.int32)
+    return to, eng.f32(cam0), eng.f32(depth_img), eng.f32(color_img), rnd.to(eng.device)
+
+
+def _track_worker(rank, port, q, backend):
+    try:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        torch.set_num_threads(1)
+        from loopy_slam_amd import parallel
+        from util import make_engine
+        dist.init_process_group('gloo', rank=rank, world_size=2)
+        eng = make_engine(backend)
+        to, cam0, depth, color, rnd = _track_setup(eng, parallel.DistContext(rank, 2), True)
+        assert to.shard_rays and not to.native_loop and to.R_own == (T_R + 1) // 2
+        best, log = to.track(cam0, depth, color, T_ITERS, (0, HH, 0, WW), INTR, rnd)
+        q.put((rank, best.cpu().numpy().copy(), log.cpu().numpy().copy()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(('error', rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize('backend', backends())
+def test_two_rank_sharded_tracking_matches_single_process(backend):
+    """tracking.shard_rays (tracking by contiguous ray ranges): two ranks track one frame, each on its half of every iteration's
+    draws, one all-reduce of {pose gradient, loss row} per iteration - against ONE process on the whole batch (per-statement path, the same
+    draws): the per-iteration losses agree to summation order and both ranks end on the same pose, which is the single process's to the few
+    ulps that four sign-like Adam steps leave (Tracker.py:102-197, 313-401)."""
+    from util import make_engine
+    res = _spawn(_track_worker, (backend,))
+    res.sort(key=lambda r: r[0])
+    eng = make_engine(backend)
+    to, cam0, depth, color, rnd = _track_setup(eng, None, False)
+    to.native_loop = False
+    best, log = to.track(cam0, depth, color, T_ITERS, (0, HH, 0, WW), INTR, rnd)
+    best, log = best.cpu().numpy(), log.cpu().numpy()
+    np.testing.assert_array_equal(res[0][1], res[1][1])                      # the ranks agree bit for bit (the same sums, the same step)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_allclose(res[0][2][:, 0], log[:, 0], rtol=2e-5)
+    np.testing.assert_allclose(res[0][2][:, 3], log[:, 3], rtol=0, atol=0)   # the same rays counted
+    np.testing.assert_allclose(res[0][1], best, rtol=0, atol=2e-6)
+    assert len(set(float(x) for x in log[:, 0])) == T_ITERS                  # (and the pose moved: every iteration's loss is that of another pose -
+    #                                                                          the losses of iterations 1.. agree only if the summed steps did)
+
+
+def _slam_shard_worker(rank, port, q, backend):
+    try:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        torch.set_num_threads(1)
+        dist.init_process_group('gloo', rank=rank, world_size=2)
+        from loopy_slam_amd import parallel, slam
+        from test_slam_api import mini_cfg
+        from util import make_engine
+        eng = make_engine(backend)
+        cfg = mini_cfg()
+        cfg['tracking']['shard_rays'] = True
+        ps = slam.Point_SLAM(cfg, None, eng=eng, dist=parallel.DistContext(rank, 2))
+        ps.run(n_frames=4)
+        est = ps.estimate_c2w_list[:4].cpu().numpy().copy()
+        gt = torch.stack([ps.frame_reader[k][3] for k in range(4)]).numpy()
+        q.put((rank, est, float(np.abs(est[:, :3, 3] - gt[:, :3, 3]).max()), int(ps.npc.pts_num())))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(('error', rank, traceback.format_exc()))
+        raise
+
+
+def test_point_slam_with_sharded_tracking_keeps_the_replicas_identical():
+    """`tracking.shard_rays: True` through the drop-in classes: four frames tracked on two ranks' ray ranges and mapped with the gradient exchange -
+    the ranks' trajectories and maps are identical (every step is computed from all-reduced sums) and the frames are tracked."""
+    res = _spawn(_slam_shard_worker, ('emu',))
+    res.sort(key=lambda r: r[0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][3] == res[1][3] > 300 and res[0][2] < 0.05
+
+
 # ------------------------------------------------------------------ two ranks over RCCL: runs wherever two GPUs are visible
 two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the 1-GPU lease skips; a multi-GPU box runs it)')
 
